@@ -1,0 +1,178 @@
+"""CPU oracle for the NU_Scaler hot path -- TEST INFRASTRUCTURE ONLY.
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline``
+leg may import this package, and only as the checker / CPU baseline.  The
+product (``nu_scaler_amd``) never imports it.
+
+``oracle.c`` is a ctypes view of ``liboracle.so`` (built from ``nus_oracle.c`` by
+``oracle/Makefile``); ``oracle.oracle_np`` is an independent numpy restatement
+used to cross-check the C code and to generate fixtures.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "liboracle.so")
+
+FILTER_LANCZOS3 = 0
+FILTER_CATMULLROM = 1
+FILTER_TRIANGLE = 2
+
+
+def build(force: bool = False) -> str:
+    """Compile liboracle.so with gcc (no GPU, no reference sources involved)."""
+    src = os.path.join(_HERE, "nus_oracle.c")
+    hdr = os.path.join(_HERE, "nus_oracle.h")
+    stale = (not os.path.exists(_LIB_PATH)
+             or os.path.getmtime(_LIB_PATH) < max(os.path.getmtime(src), os.path.getmtime(hdr)))
+    if force or stale:
+        subprocess.run(["make", "-C", _HERE, "-B" if force else "-s", "liboracle.so"],
+                       check=True, capture_output=True)
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib() -> ctypes.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            build()
+        L = ctypes.CDLL(_LIB_PATH)
+        u8p = ctypes.c_void_p
+        u32 = ctypes.c_uint32
+        up = [u8p, u32, u32, u8p, u32, u32]
+        for name in ("orc_nearest", "orc_bilinear", "orc_bilinear_wgsl"):
+            getattr(L, name).argtypes = up
+            getattr(L, name).restype = None
+        L.orc_resize.argtypes = up + [ctypes.c_int]
+        L.orc_resize.restype = ctypes.c_int
+        L.orc_lanczos3.argtypes = up
+        L.orc_lanczos3.restype = ctypes.c_int
+        L.orc_resize_axis.argtypes = [u32, u32, ctypes.c_int, u32, u8p, u8p, u8p]
+        L.orc_resize_axis.restype = ctypes.c_int
+        L.orc_warp_blend.argtypes = [u8p, u8p, u8p, u32, u32, ctypes.c_float, u8p]
+        L.orc_warp_blend.restype = None
+        L.orc_nearest_mt.argtypes = up + [ctypes.c_int]
+        L.orc_nearest_mt.restype = None
+        L.orc_bilinear_mt.argtypes = up + [ctypes.c_int]
+        L.orc_bilinear_mt.restype = None
+        L.orc_lanczos3_mt.argtypes = up + [ctypes.c_int]
+        L.orc_lanczos3_mt.restype = ctypes.c_int
+        L.orc_warp_blend_mt.argtypes = [u8p, u8p, u8p, u32, u32, ctypes.c_float, u8p, ctypes.c_int]
+        L.orc_warp_blend_mt.restype = None
+        L.orc_max_threads.argtypes = []
+        L.orc_max_threads.restype = ctypes.c_int
+        L.orc_gen_gradient.argtypes = [u8p, u32, u32, u32]
+        L.orc_gen_gradient.restype = None
+        L.orc_gen_noise.argtypes = [u8p, u32, u32, ctypes.c_uint64]
+        L.orc_gen_noise.restype = None
+        L.orc_gen_box.argtypes = [u8p, u32, u32] + [ctypes.c_uint8] * 4
+        L.orc_gen_box.restype = None
+        _lib = L
+    return _lib
+
+
+def _img(a: np.ndarray) -> np.ndarray:
+    a = np.ascontiguousarray(a, dtype=np.uint8)
+    if a.ndim != 3 or a.shape[2] != 4:
+        raise ValueError("expected an (h, w, 4) uint8 image")
+    return a
+
+
+def _ptr(a: np.ndarray) -> int:
+    return a.ctypes.data
+
+
+def _upscale(fn, img, ow, oh, *extra):
+    img = _img(img)
+    ih, iw = img.shape[:2]
+    out = np.empty((oh, ow, 4), dtype=np.uint8)
+    rc = fn(_ptr(img), iw, ih, _ptr(out), ow, oh, *extra)
+    if rc not in (None, 0):
+        raise RuntimeError("oracle call failed")
+    return out
+
+
+def nearest(img, ow, oh, threads: int = 1):
+    if threads == 1:
+        return _upscale(lib().orc_nearest, img, ow, oh)
+    return _upscale(lib().orc_nearest_mt, img, ow, oh, threads)
+
+
+def bilinear(img, ow, oh, threads: int = 1):
+    if threads == 1:
+        return _upscale(lib().orc_bilinear, img, ow, oh)
+    return _upscale(lib().orc_bilinear_mt, img, ow, oh, threads)
+
+
+def bilinear_wgsl(img, ow, oh):
+    return _upscale(lib().orc_bilinear_wgsl, img, ow, oh)
+
+
+def resize(img, ow, oh, filt: int = FILTER_LANCZOS3):
+    return _upscale(lib().orc_resize, img, ow, oh, filt)
+
+
+def lanczos3(img, ow, oh, threads: int = 1):
+    if threads == 1:
+        return _upscale(lib().orc_lanczos3, img, ow, oh)
+    return _upscale(lib().orc_lanczos3_mt, img, ow, oh, threads)
+
+
+def resize_axis(in_n: int, out_n: int, filt: int = FILTER_LANCZOS3, max_taps: int = 32):
+    left = np.zeros(out_n, dtype=np.int32)
+    ntaps = np.zeros(out_n, dtype=np.uint32)
+    w = np.zeros((out_n, max_taps), dtype=np.float32)
+    rc = lib().orc_resize_axis(in_n, out_n, filt, max_taps, _ptr(left), _ptr(ntaps), _ptr(w))
+    if rc < 0:
+        raise RuntimeError("orc_resize_axis failed (too many taps?)")
+    return left, ntaps, w
+
+
+def warp_blend(a, b, flow, t: float, threads: int = 1):
+    a = _img(a)
+    b = _img(b)
+    if a.shape != b.shape:
+        raise ValueError("frame shapes differ")
+    h, w = a.shape[:2]
+    fp = None
+    if flow is not None:
+        flow = np.ascontiguousarray(flow, dtype=np.float32)
+        if flow.shape != (h, w, 2):
+            raise ValueError("flow must be (h, w, 2) float32")
+        fp = _ptr(flow)
+    out = np.empty_like(a)
+    if threads == 1:
+        lib().orc_warp_blend(_ptr(a), _ptr(b), fp, w, h, t, _ptr(out))
+    else:
+        lib().orc_warp_blend_mt(_ptr(a), _ptr(b), fp, w, h, t, _ptr(out), threads)
+    return out
+
+
+def max_threads() -> int:
+    return int(lib().orc_max_threads())
+
+
+def gen_gradient(w: int, h: int, shift: int = 0):
+    out = np.empty((h, w, 4), dtype=np.uint8)
+    lib().orc_gen_gradient(_ptr(out), w, h, shift)
+    return out
+
+
+def gen_noise(w: int, h: int, seed: int = 0x5EED):
+    out = np.empty((h, w, 4), dtype=np.uint8)
+    lib().orc_gen_noise(_ptr(out), w, h, seed)
+    return out
+
+
+def gen_box(w: int, h: int, rgba=(255, 0, 0, 255)):
+    out = np.empty((h, w, 4), dtype=np.uint8)
+    lib().orc_gen_box(_ptr(out), w, h, *[int(v) for v in rgba])
+    return out

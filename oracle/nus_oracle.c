@@ -1,0 +1,503 @@
+/*
+ * nus_oracle.c -- CPU oracle for the NU_Scaler upscale + interpolation hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY (see nus_oracle.h).  Build with
+ *     gcc -O2 -ffp-contract=off -fno-fast-math -fopenmp -shared -fPIC
+ * so every f32 multiply and add rounds separately, as the Rust reference does.
+ *
+ * Pinning status (DESIGN.md "Oracle"):
+ *   orc_nearest       pure integer index arithmetic; pinned by construction and by
+ *                     tests/golden (x2 of ref_test_input.png == pixel replication).
+ *   orc_bilinear      pinned: tests/golden/ref_test_input.png -> top-left 320x240 of
+ *                     ref_test_output.png, 0 mismatches (tests/test_oracle_golden.py).
+ *   orc_bilinear_wgsl pinned by the same pair (both forms coincide on that gradient).
+ *   orc_warp_blend    zero-flow mode pinned by tests/golden/ref_interp_half.png
+ *                     (255*0.5 -> 127).  Flow mode: geometry from the WGSL shader,
+ *                     rounding from the reference's CPU blend; no reference fixture
+ *                     exercises non-zero flow (the live path always passes zero flow).
+ *   orc_resize /      PARITY UNPINNED.  The arithmetic lives in the third-party crate
+ *   orc_lanczos3      `image` 0.24.9 (Nu_scale/Cargo.toml:10, Nu_scale/Cargo.lock:2696-2699),
+ *                     called at Nu_scale/src/upscale/common.rs:243-251.  The crate is not
+ *                     vendored under /root/reference and no reference test pins a byte of
+ *                     its output.  This file restates the crate's published algorithm
+ *                     (imageops::resize = vertical_sample into f32, then horizontal_sample
+ *                     with clamp + round-to-nearest) from its documentation/source as
+ *                     remembered; it could not be verified against the crate here.
+ *
+ * The reference is Rust; it cannot be compiled in this image (no cargo/rustc), so
+ * there is no oracle/_ref build.
+ */
+#include "nus_oracle.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+/* ---- Rust cast semantics ------------------------------------------------------ */
+
+/* Rust `f32 as u8`: truncate toward zero, saturate, NaN -> 0. */
+static inline uint8_t f32_as_u8(float v)
+{
+    if (!(v > 0.0f)) return 0;          /* also NaN, -0.0 */
+    if (v >= 255.0f) return 255;
+    return (uint8_t)v;                  /* C conversion truncates toward zero */
+}
+
+/* Rust f32::clamp(lo, hi) for non-NaN input. */
+static inline float f32_clamp(float v, float lo, float hi)
+{
+    if (v < lo) return lo;
+    if (v > hi) return hi;
+    return v;
+}
+
+static inline uint32_t u32_min(uint32_t a, uint32_t b) { return a < b ? a : b; }
+
+/* ---- nearest ------------------------------------------------------------------ */
+
+/* Nu_scale/src/upscale/common.rs:188-198 (dup :309-319); identical to the WGSL
+ * kernel nu_scaler_core/src/upscale/mod.rs:200-204 whenever ow >= iw.
+ * Rust u32 arithmetic: x * iw must not overflow u32 (the reference would panic in
+ * debug / wrap in release); the oracle uses 64-bit to stay defined and callers
+ * keep (ow-1)*iw < 2^32. */
+static void nearest_rows(const uint8_t *in, uint32_t iw, uint32_t ih,
+                         uint8_t *out, uint32_t ow, uint32_t oh,
+                         uint32_t y_begin, uint32_t y_end)
+{
+    const uint32_t *src = (const uint32_t *)in;
+    uint32_t *dst = (uint32_t *)out;
+    for (uint32_t y = y_begin; y < y_end; ++y) {
+        for (uint32_t x = 0; x < ow; ++x) {
+            uint32_t sx = u32_min((uint32_t)(((uint64_t)x * iw) / ow), iw - 1);
+            uint32_t sy = u32_min((uint32_t)(((uint64_t)y * ih) / oh), ih - 1);
+            dst[(size_t)y * ow + x] = src[(size_t)sy * iw + sx];
+        }
+    }
+}
+
+void orc_nearest(const uint8_t *in, uint32_t iw, uint32_t ih,
+                 uint8_t *out, uint32_t ow, uint32_t oh)
+{
+    nearest_rows(in, iw, ih, out, ow, oh, 0, oh);
+}
+
+/* ---- bilinear, CPU form ------------------------------------------------------- */
+
+/* Nu_scale/src/upscale/common.rs:199-231.  0..255 domain, f32, expression order as
+ * written there, `clamp(0,255) as u8` (truncation), alpha interpolated like colour. */
+static void bilinear_rows(const uint8_t *in, uint32_t iw, uint32_t ih,
+                          uint8_t *out, uint32_t ow, uint32_t oh,
+                          uint32_t y_begin, uint32_t y_end)
+{
+    for (uint32_t y = y_begin; y < y_end; ++y) {
+        for (uint32_t x = 0; x < ow; ++x) {
+            float src_x = fminf((float)x * (float)iw / (float)ow, (float)iw - 1.0f);
+            float src_y = fminf((float)y * (float)ih / (float)oh, (float)ih - 1.0f);
+            uint32_t x0 = (uint32_t)floorf(src_x);
+            uint32_t y0 = (uint32_t)floorf(src_y);
+            uint32_t x1 = u32_min(x0 + 1, iw - 1);
+            uint32_t y1 = u32_min(y0 + 1, ih - 1);
+            float dx = src_x - (float)x0;
+            float dy = src_y - (float)y0;
+            const uint8_t *p00 = in + ((size_t)y0 * iw + x0) * 4;
+            const uint8_t *p10 = in + ((size_t)y0 * iw + x1) * 4;
+            const uint8_t *p01 = in + ((size_t)y1 * iw + x0) * 4;
+            const uint8_t *p11 = in + ((size_t)y1 * iw + x1) * 4;
+            uint8_t *o = out + ((size_t)y * ow + x) * 4;
+            for (int c = 0; c < 4; ++c) {
+                float top = (float)p00[c] * (1.0f - dx) + (float)p10[c] * dx;
+                float bottom = (float)p01[c] * (1.0f - dx) + (float)p11[c] * dx;
+                float value = top * (1.0f - dy) + bottom * dy;
+                o[c] = f32_as_u8(f32_clamp(value, 0.0f, 255.0f));
+            }
+        }
+    }
+}
+
+void orc_bilinear(const uint8_t *in, uint32_t iw, uint32_t ih,
+                  uint8_t *out, uint32_t ow, uint32_t oh)
+{
+    bilinear_rows(in, iw, ih, out, ow, oh, 0, oh);
+}
+
+/* ---- bilinear, WGSL form (diff-only) ------------------------------------------ */
+
+/* nu_scaler_core/src/upscale/mod.rs:220-234 (unpack /255, pack clamp*255 truncating)
+ * and :241-261 (coordinates, mix).  WGSL mix(a,b,t) = a*(1-t) + b*t. */
+void orc_bilinear_wgsl(const uint8_t *in, uint32_t iw, uint32_t ih,
+                       uint8_t *out, uint32_t ow, uint32_t oh)
+{
+    for (uint32_t y = 0; y < oh; ++y) {
+        for (uint32_t x = 0; x < ow; ++x) {
+            float fx = (float)x * (float)iw / (float)ow;
+            float fy = (float)y * (float)ih / (float)oh;
+            uint32_t x0 = (uint32_t)fx;
+            uint32_t y0 = (uint32_t)fy;
+            uint32_t x1 = u32_min(x0 + 1, iw - 1);
+            uint32_t y1 = u32_min(y0 + 1, ih - 1);
+            float dx = fx - (float)x0;
+            float dy = fy - (float)y0;
+            const uint8_t *p00 = in + ((size_t)y0 * iw + x0) * 4;
+            const uint8_t *p10 = in + ((size_t)y0 * iw + x1) * 4;
+            const uint8_t *p01 = in + ((size_t)y1 * iw + x0) * 4;
+            const uint8_t *p11 = in + ((size_t)y1 * iw + x1) * 4;
+            uint8_t *o = out + ((size_t)y * ow + x) * 4;
+            for (int c = 0; c < 4; ++c) {
+                float c00 = (float)p00[c] / 255.0f, c10 = (float)p10[c] / 255.0f;
+                float c01 = (float)p01[c] / 255.0f, c11 = (float)p11[c] / 255.0f;
+                float c0 = c00 * (1.0f - dx) + c10 * dx;
+                float c1 = c01 * (1.0f - dx) + c11 * dx;
+                float v = c0 * (1.0f - dy) + c1 * dy;
+                o[c] = (uint8_t)(uint32_t)(f32_clamp(v, 0.0f, 1.0f) * 255.0f);
+            }
+        }
+    }
+}
+
+/* ---- separable resize (image-0.24.9 imageops::resize) -- PARITY UNPINNED ------ */
+
+#define ORC_PI_F 3.14159265358979323846f /* rounds to f32::consts::PI */
+
+static float k_sinc(float t)
+{
+    float a = t * ORC_PI_F;
+    if (t == 0.0f) return 1.0f;
+    return sinf(a) / a;
+}
+
+static float k_lanczos3(float x)
+{
+    if (fabsf(x) < 3.0f) return k_sinc(x) * k_sinc(x / 3.0f);
+    return 0.0f;
+}
+
+/* image-0.24 bicubic_kernel(x, b=0, c=0.5) (CatmullRom). */
+static float k_catmullrom(float x)
+{
+    const float b = 0.0f, c = 0.5f;
+    float a = fabsf(x);
+    float k;
+    if (a < 1.0f)
+        k = (12.0f - 9.0f * b - 6.0f * c) * (a * a * a) + (-18.0f + 12.0f * b + 6.0f * c) * (a * a) + (6.0f - 2.0f * b);
+    else if (a < 2.0f)
+        k = (-b - 6.0f * c) * (a * a * a) + (6.0f * b + 30.0f * c) * (a * a) + (-12.0f * b - 48.0f * c) * a + (8.0f * b + 24.0f * c);
+    else
+        k = 0.0f;
+    return k / 6.0f;
+}
+
+static float k_triangle(float x)
+{
+    float a = fabsf(x);
+    return a < 1.0f ? 1.0f - a : 0.0f;
+}
+
+static int filter_params(int filter, float (**kernel)(float), float *support)
+{
+    switch (filter) {
+    case 0: *kernel = k_lanczos3; *support = 3.0f; return 0;
+    case 1: *kernel = k_catmullrom; *support = 2.0f; return 0;
+    case 2: *kernel = k_triangle; *support = 1.0f; return 0;
+    default: return -1;
+    }
+}
+
+static int64_t i64_clamp(int64_t v, int64_t lo, int64_t hi)
+{
+    return v < lo ? lo : (v > hi ? hi : v);
+}
+
+/* One output index of vertical_sample / horizontal_sample: the tap window
+ * [left, right) and its normalised weights.  Returns right - left. */
+static uint32_t axis_taps(uint32_t in_n, uint32_t out_n, uint32_t o,
+                          float (*kernel)(float), float support,
+                          int32_t *left_out, float *ws, uint32_t max_taps)
+{
+    float ratio = (float)in_n / (float)out_n;
+    float sratio = ratio < 1.0f ? 1.0f : ratio;
+    float src_support = support * sratio;
+    float input = ((float)o + 0.5f) * ratio;
+    int64_t left = (int64_t)floorf(input - src_support);
+    left = i64_clamp(left, 0, (int64_t)in_n - 1);
+    int64_t right = (int64_t)ceilf(input + src_support);
+    right = i64_clamp(right, left + 1, (int64_t)in_n);
+    input = input - 0.5f;
+    uint32_t n = (uint32_t)(right - left);
+    *left_out = (int32_t)left;
+    if (n > max_taps) return n;
+    float sum = 0.0f;
+    for (uint32_t i = 0; i < n; ++i) {
+        float w = kernel(((float)(left + i) - input) / sratio);
+        ws[i] = w;
+        sum += w;
+    }
+    for (uint32_t i = 0; i < n; ++i) ws[i] /= sum;
+    return n;
+}
+
+int orc_resize_axis(uint32_t in_n, uint32_t out_n, int filter, uint32_t max_taps,
+                    int32_t *left, uint32_t *ntaps, float *weights)
+{
+    float (*kernel)(float);
+    float support;
+    if (filter_params(filter, &kernel, &support) || in_n == 0 || out_n == 0) return -1;
+    uint32_t worst = 0;
+    for (uint32_t o = 0; o < out_n; ++o) {
+        float *ws = weights + (size_t)o * max_taps;
+        memset(ws, 0, sizeof(float) * max_taps);
+        uint32_t n = axis_taps(in_n, out_n, o, kernel, support, &left[o], ws, max_taps);
+        if (n > max_taps) return -1;
+        ntaps[o] = n;
+        if (n > worst) worst = n;
+    }
+    return (int)worst;
+}
+
+#define ORC_MAX_TAPS 256
+
+static int resize_impl(const uint8_t *in, uint32_t iw, uint32_t ih,
+                       uint8_t *out, uint32_t ow, uint32_t oh, int filter, int threads)
+{
+    float (*kernel)(float);
+    float support;
+    if (filter_params(filter, &kernel, &support)) return -1;
+    if (iw == 0 || ih == 0 || ow == 0 || oh == 0) return -1;
+    /* imageops::resize returns a plain copy when the dimensions are unchanged. */
+    if (iw == ow && ih == oh) {
+        memcpy(out, in, (size_t)iw * ih * 4);
+        return 0;
+    }
+    /* vertical_sample: u8 image (iw x ih) -> f32 image (iw x oh). */
+    float *tmp = (float *)malloc((size_t)iw * oh * 4 * sizeof(float));
+    if (!tmp) return -1;
+    int rc = 0;
+    (void)threads;
+#pragma omp parallel for schedule(static) num_threads(threads) if (threads > 1)
+    for (uint32_t oy = 0; oy < oh; ++oy) {
+        float ws[ORC_MAX_TAPS];
+        int32_t left;
+        uint32_t n = axis_taps(ih, oh, oy, kernel, support, &left, ws, ORC_MAX_TAPS);
+        if (n > ORC_MAX_TAPS) { rc = -1; continue; }
+        for (uint32_t x = 0; x < iw; ++x) {
+            float t0 = 0.0f, t1 = 0.0f, t2 = 0.0f, t3 = 0.0f;
+            for (uint32_t i = 0; i < n; ++i) {
+                const uint8_t *p = in + ((size_t)(left + (int32_t)i) * iw + x) * 4;
+                float w = ws[i];
+                t0 += (float)p[0] * w;
+                t1 += (float)p[1] * w;
+                t2 += (float)p[2] * w;
+                t3 += (float)p[3] * w;
+            }
+            float *q = tmp + ((size_t)oy * iw + x) * 4;
+            q[0] = t0; q[1] = t1; q[2] = t2; q[3] = t3;
+        }
+    }
+    if (rc) { free(tmp); return rc; }
+    /* horizontal_sample: f32 image (iw x oh) -> u8 image (ow x oh), clamp then
+     * round-to-nearest (f32::round: half away from zero).  Loop order as in the
+     * crate: outx outermost (weights computed once per output column), y inside. */
+#pragma omp parallel for schedule(static) num_threads(threads) if (threads > 1)
+    for (uint32_t ox = 0; ox < ow; ++ox) {
+        float ws[ORC_MAX_TAPS];
+        int32_t left;
+        uint32_t n = axis_taps(iw, ow, ox, kernel, support, &left, ws, ORC_MAX_TAPS);
+        if (n > ORC_MAX_TAPS) { rc = -1; continue; }
+        for (uint32_t y = 0; y < oh; ++y) {
+            float t0 = 0.0f, t1 = 0.0f, t2 = 0.0f, t3 = 0.0f;
+            for (uint32_t i = 0; i < n; ++i) {
+                const float *p = tmp + ((size_t)y * iw + (size_t)(left + (int32_t)i)) * 4;
+                float w = ws[i];
+                t0 += p[0] * w;
+                t1 += p[1] * w;
+                t2 += p[2] * w;
+                t3 += p[3] * w;
+            }
+            uint8_t *o = out + ((size_t)y * ow + ox) * 4;
+            o[0] = (uint8_t)roundf(f32_clamp(t0, 0.0f, 255.0f));
+            o[1] = (uint8_t)roundf(f32_clamp(t1, 0.0f, 255.0f));
+            o[2] = (uint8_t)roundf(f32_clamp(t2, 0.0f, 255.0f));
+            o[3] = (uint8_t)roundf(f32_clamp(t3, 0.0f, 255.0f));
+        }
+    }
+    free(tmp);
+    return rc;
+}
+
+int orc_resize(const uint8_t *in, uint32_t iw, uint32_t ih,
+               uint8_t *out, uint32_t ow, uint32_t oh, int filter)
+{
+    return resize_impl(in, iw, ih, out, ow, oh, filter, 1);
+}
+
+int orc_lanczos3(const uint8_t *in, uint32_t iw, uint32_t ih,
+                 uint8_t *out, uint32_t ow, uint32_t oh)
+{
+    return resize_impl(in, iw, ih, out, ow, oh, 0, 1);
+}
+
+/* ---- warp + blend ------------------------------------------------------------- */
+
+/* Bilinear sample with coordinates clamped to the image, result truncated to u8.
+ * nu_scaler_core/src/interpolation/mod.rs:467-510 (sample_frame); equals the
+ * clamp-to-edge bilinear sampler of wgpu_interpolator.rs:700-709 in texel space. */
+static void sample_frame(const uint8_t *frame, uint32_t w, uint32_t h,
+                         float x, float y, uint8_t res[4])
+{
+    x = f32_clamp(x, 0.0f, (float)(w - 1));
+    y = f32_clamp(y, 0.0f, (float)(h - 1));
+    uint32_t x0 = (uint32_t)floorf(x);
+    uint32_t y0 = (uint32_t)floorf(y);
+    uint32_t x1 = u32_min(x0 + 1, w - 1);
+    uint32_t y1 = u32_min(y0 + 1, h - 1);
+    float xf = x - (float)x0;
+    float yf = y - (float)y0;
+    const uint8_t *p00 = frame + ((size_t)y0 * w + x0) * 4;
+    const uint8_t *p01 = frame + ((size_t)y0 * w + x1) * 4;
+    const uint8_t *p10 = frame + ((size_t)y1 * w + x0) * 4;
+    const uint8_t *p11 = frame + ((size_t)y1 * w + x1) * 4;
+    for (int c = 0; c < 4; ++c) {
+        float top = (float)p00[c] * (1.0f - xf) + (float)p01[c] * xf;
+        float bottom = (float)p10[c] * (1.0f - xf) + (float)p11[c] * xf;
+        float value = top * (1.0f - yf) + bottom * yf;
+        res[c] = f32_as_u8(value);
+    }
+}
+
+/* Geometry and flow sign: shaders/warp_blend.wgsl:25-43 -- with uv = (p + 0.5 -/+ ...)/size
+ * and a linear clamp-to-edge sampler, the texel-space sample position is
+ * p - t*flow in A and p + (1-t)*flow in B.  Blend + truncation:
+ * interpolation/mod.rs:407-411. */
+static void warp_rows(const uint8_t *a, const uint8_t *b, const float *flow,
+                      uint32_t w, uint32_t h, float t, uint8_t *out,
+                      uint32_t y_begin, uint32_t y_end)
+{
+    for (uint32_t y = y_begin; y < y_end; ++y) {
+        for (uint32_t x = 0; x < w; ++x) {
+            size_t idx = (size_t)y * w + x;
+            float fx = flow ? flow[idx * 2] : 0.0f;
+            float fy = flow ? flow[idx * 2 + 1] : 0.0f;
+            float ax = (float)x - t * fx;
+            float ay = (float)y - t * fy;
+            float bx = (float)x + (1.0f - t) * fx;
+            float by = (float)y + (1.0f - t) * fy;
+            uint8_t pa[4], pb[4];
+            sample_frame(a, w, h, ax, ay, pa);
+            sample_frame(b, w, h, bx, by, pb);
+            for (int c = 0; c < 4; ++c)
+                out[idx * 4 + c] = f32_as_u8((1.0f - t) * (float)pa[c] + t * (float)pb[c]);
+        }
+    }
+}
+
+void orc_warp_blend(const uint8_t *a, const uint8_t *b, const float *flow,
+                    uint32_t w, uint32_t h, float t, uint8_t *out)
+{
+    warp_rows(a, b, flow, w, h, t, out, 0, h);
+}
+
+/* ---- OpenMP row-parallel variants (CPU baseline only) -------------------------- */
+
+int orc_max_threads(void)
+{
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+
+static int pick_threads(int threads)
+{
+    int m = orc_max_threads();
+    if (threads <= 0 || threads > m) return m;
+    return threads;
+}
+
+#define ROW_PARALLEL(total_rows, threads, CALL)                                    \
+    do {                                                                            \
+        int nt_ = pick_threads(threads);                                            \
+        _Pragma("omp parallel for schedule(static) num_threads(nt_)")               \
+        for (int blk_ = 0; blk_ < nt_; ++blk_) {                                    \
+            uint32_t y_begin = (uint32_t)(((uint64_t)(total_rows) * blk_) / nt_);    \
+            uint32_t y_end = (uint32_t)(((uint64_t)(total_rows) * (blk_ + 1)) / nt_);\
+            CALL;                                                                   \
+        }                                                                           \
+    } while (0)
+
+void orc_nearest_mt(const uint8_t *in, uint32_t iw, uint32_t ih,
+                    uint8_t *out, uint32_t ow, uint32_t oh, int threads)
+{
+    ROW_PARALLEL(oh, threads, nearest_rows(in, iw, ih, out, ow, oh, y_begin, y_end));
+}
+
+void orc_bilinear_mt(const uint8_t *in, uint32_t iw, uint32_t ih,
+                     uint8_t *out, uint32_t ow, uint32_t oh, int threads)
+{
+    ROW_PARALLEL(oh, threads, bilinear_rows(in, iw, ih, out, ow, oh, y_begin, y_end));
+}
+
+int orc_lanczos3_mt(const uint8_t *in, uint32_t iw, uint32_t ih,
+                    uint8_t *out, uint32_t ow, uint32_t oh, int threads)
+{
+    return resize_impl(in, iw, ih, out, ow, oh, 0, pick_threads(threads));
+}
+
+void orc_warp_blend_mt(const uint8_t *a, const uint8_t *b, const float *flow,
+                       uint32_t w, uint32_t h, float t, uint8_t *out, int threads)
+{
+    ROW_PARALLEL(h, threads, warp_rows(a, b, flow, w, h, t, out, y_begin, y_end));
+}
+
+/* ---- synthetic inputs ---------------------------------------------------------- */
+
+/* S1: nu_scaler_core/src/benchmark.rs:188-207, with the column index rotated by
+ * `shift` (frame k of the synthetic stream: 1 px/frame horizontal motion). */
+void orc_gen_gradient(uint8_t *out, uint32_t w, uint32_t h, uint32_t shift)
+{
+    for (uint32_t y = 0; y < h; ++y) {
+        for (uint32_t x = 0; x < w; ++x) {
+            uint32_t xs = (uint32_t)(((uint64_t)x + shift) % w);
+            uint8_t *p = out + ((size_t)y * w + x) * 4;
+            p[0] = (uint8_t)(xs * 255 / w);
+            p[1] = (uint8_t)(y * 255 / h);
+            p[2] = (uint8_t)((xs + y) * 255 / (w + h));
+            p[3] = 255;
+        }
+    }
+}
+
+static uint64_t splitmix64(uint64_t *s)
+{
+    uint64_t z = (*s += 0x9E3779B97F4A7C15ull);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+/* S3: 8 bytes per splitmix64 draw, little-endian. */
+void orc_gen_noise(uint8_t *out, uint32_t w, uint32_t h, uint64_t seed)
+{
+    size_t n = (size_t)w * h * 4;
+    uint64_t s = seed;
+    size_t i = 0;
+    while (i < n) {
+        uint64_t z = splitmix64(&s);
+        for (int k = 0; k < 8 && i < n; ++k, ++i) out[i] = (uint8_t)(z >> (8 * k));
+    }
+}
+
+/* S4: nu_scaler_py/test_interpolator.py:23-34. */
+void orc_gen_box(uint8_t *out, uint32_t w, uint32_t h,
+                 uint8_t r, uint8_t g, uint8_t b, uint8_t a)
+{
+    memset(out, 0, (size_t)w * h * 4);
+    uint32_t ch = h / 2, cw = w / 2, hh = h / 4, hw = w / 4;
+    for (uint32_t y = ch - hh; y < ch + hh; ++y)
+        for (uint32_t x = cw - hw; x < cw + hw; ++x) {
+            uint8_t *p = out + ((size_t)y * w + x) * 4;
+            p[0] = r; p[1] = g; p[2] = b; p[3] = a;
+        }
+}
