@@ -1,0 +1,225 @@
+/*
+ * nuscaler_hip.h -- C ABI of the MI355X (gfx950) upscale + frame-interpolation path.
+ *
+ * This is the drop-in boundary for nu_scaler_core's per-pixel hot path: a Rust shim
+ * (`impl Upscaler for HipUpscaler`) or the ctypes module
+ * nu_scaler_amd binds exactly these entry points.  Plain pointers and sizes only.
+ *
+ * Reference interfaces replaced (paths relative to the reference checkout):
+ *   trait Upscaler                      nu_scaler_core/src/upscale/mod.rs:67-88
+ *   UpscalerFactory::create_upscaler    nu_scaler_core/src/upscale/mod.rs:95-117
+ *   WgpuUpscaler::upscale / _batch      nu_scaler_core/src/upscale/mod.rs:935-1058, :609-640
+ *   WgpuFrameInterpolator::interpolate_py   nu_scaler_core/src/wgpu_interpolator.rs:215-491
+ *   get_last_gpu_duration_ms            nu_scaler_core/src/wgpu_interpolator.rs:494-497
+ *   trait FrameInterpolator (shape)     nu_scaler_core/src/interpolation/mod.rs:29-44
+ *
+ * Frames are tightly packed RGBA8, row-major.  Every function returns NUS_OK (0)
+ * or a negative nus_status; the message is available from nus_*_last_error(handle)
+ * (per handle) and nus_last_error() (thread-local, also covers create failures).
+ * Concurrent calls on one handle are serialised by a per-handle mutex (the reference
+ * calls upscale(&self) from rayon threads, upscale/mod.rs:619-624).
+ * There is no CPU fallback: without a usable HIP device the compute entry points
+ * fail with NUS_ERR_NO_DEVICE.
+ */
+#ifndef NUSCALER_HIP_H
+#define NUSCALER_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NUS_ABI_VERSION 1
+
+typedef enum nus_status {
+    NUS_OK = 0,
+    NUS_ERR_INVALID_ARGUMENT = -1,
+    NUS_ERR_NOT_INITIALIZED = -2, /* "Upscaler not initialized. Call initialize() first." (mod.rs:937-939) */
+    NUS_ERR_SIZE_MISMATCH = -3,   /* "Input data size (..) does not match expected input buffer size (..)" (mod.rs:960-966) */
+    NUS_ERR_HIP = -4,
+    NUS_ERR_NO_DEVICE = -5,
+    NUS_ERR_UNSUPPORTED = -6,
+    NUS_ERR_OUT_OF_MEMORY = -7
+} nus_status;
+
+/* UpscaleAlgorithm (mod.rs:50-53) plus the build-defined Lanczos-3 value. */
+typedef enum nus_algorithm {
+    NUS_ALG_NEAREST = 0,
+    NUS_ALG_BILINEAR = 1,
+    NUS_ALG_LANCZOS3 = 2
+} nus_algorithm;
+
+/* UpscalingQuality (mod.rs:37-46), same order.  Quality never changes the arithmetic
+ * (mod.rs:1072-1077). */
+typedef enum nus_quality {
+    NUS_QUALITY_ULTRA_PERFORMANCE = 0,
+    NUS_QUALITY_ULTRA = 1,
+    NUS_QUALITY_QUALITY = 2,
+    NUS_QUALITY_BALANCED = 3,
+    NUS_QUALITY_PERFORMANCE = 4,
+    NUS_QUALITY_NATIVE = 5
+} nus_quality;
+
+/* UpscalingTechnology (mod.rs:56-64), same order. */
+typedef enum nus_technology {
+    NUS_TECH_NONE = 0,
+    NUS_TECH_FSR = 1,
+    NUS_TECH_DLSS = 2,
+    NUS_TECH_WGPU = 3,
+    NUS_TECH_FALLBACK = 4
+} nus_technology;
+
+/* WorkgroupSizePreset (wgpu_interpolator.rs:98-127).  Accepted for API parity; the
+ * HIP kernels pick their own wave64 launch shape. */
+typedef enum nus_wg_preset {
+    NUS_WG_SQUARE_8X8 = 0,
+    NUS_WG_SQUARE_16X16 = 1,
+    NUS_WG_WIDE_32X8 = 2,
+    NUS_WG_TALL_8X32 = 3
+} nus_wg_preset;
+
+/* Bilinear arithmetic variant.  CPU form is the oracle; the WGSL form
+ * is offered for callers that need byte-equality with the wgpu shader instead. */
+typedef enum nus_bilinear_variant {
+    NUS_BILINEAR_CPU = 0, /* Nu_scale/src/upscale/common.rs:199-231 */
+    NUS_BILINEAR_WGSL = 1 /* nu_scaler_core/src/upscale/mod.rs:209-263 */
+} nus_bilinear_variant;
+
+/* Lanczos accumulate mode. FMA: fused multiply-add (within +-1 LSB of the oracle);
+ * EXACT: separate multiply and add, same rounding sequence as the CPU restatement. */
+typedef enum nus_lanczos_mode {
+    NUS_LANCZOS_FMA = 0,
+    NUS_LANCZOS_EXACT = 1
+} nus_lanczos_mode;
+
+typedef struct nus_upscaler nus_upscaler;
+typedef struct nus_interp nus_interp;
+
+/* ---- library ------------------------------------------------------------------ */
+
+int nus_abi_version(void);
+/* Number of usable HIP devices (0 when none; never fails). */
+int nus_device_count(void);
+/* Thread-local message of the last failing call on this thread ("" if none). */
+const char *nus_last_error(void);
+const char *nus_status_string(int status);
+
+/* ---- Upscaler (trait Upscaler, mod.rs:67-88) ----------------------------------- */
+
+/* WgpuUpscaler::new(quality, algorithm).  Never touches the GPU. NULL on bad enum. */
+nus_upscaler *nus_upscaler_create(int algorithm, int quality);
+/* UpscalerFactory::create_upscaler(technology, quality) (mod.rs:95-117):
+ * Wgpu -> bilinear; FSR / DLSS / None / Fallback -> nearest. */
+nus_upscaler *nus_upscaler_create_for_technology(int technology, int quality);
+void nus_upscaler_destroy(nus_upscaler *h);
+
+/* Select the HIP device (default 0).  Must precede initialize. */
+int nus_upscaler_set_device(nus_upscaler *h, int device);
+int nus_upscaler_set_bilinear_variant(nus_upscaler *h, int variant);
+int nus_upscaler_set_lanczos_mode(nus_upscaler *h, int mode);
+/* Tuning / test knobs: "force_general" (0/1, before initialize: never pick an x2
+ * fast path), "rows_per_wave" (Lanczos x2 kernel: input rows per wave, 0 = auto). */
+int nus_upscaler_set_option(nus_upscaler *h, const char *key, int64_t value);
+
+/* Upscaler::initialize (mod.rs:875-933).  Builds the per-axis tables on the host,
+ * allocates device + pinned staging buffers.  Re-initialising with new dimensions
+ * is allowed. */
+int nus_upscaler_initialize(nus_upscaler *h, uint32_t in_w, uint32_t in_h,
+                            uint32_t out_w, uint32_t out_h);
+
+/* Upscaler::upscale (mod.rs:935-1058): host frame in, host frame out.
+ * in_len must equal in_w*in_h*4; out_cap must be >= out_w*out_h*4. */
+int nus_upscaler_upscale(nus_upscaler *h, const uint8_t *in, size_t in_len,
+                         uint8_t *out, size_t out_cap);
+/* WgpuUpscaler::upscale_batch (mod.rs:609-640): n host frames, pipelined over
+ * H2D / kernel / D2H streams instead of a rayon map. */
+int nus_upscaler_upscale_batch(nus_upscaler *h, const uint8_t *const *ins,
+                               const size_t *in_lens, size_t n,
+                               uint8_t *const *outs, size_t out_cap_each);
+
+/* Device-resident path: d_in holds n_frames contiguous input frames already in HBM,
+ * d_out receives n_frames contiguous output frames.  Enqueued on `stream`
+ * (a hipStream_t, NULL = default stream); does not synchronise. */
+int nus_upscaler_upscale_device(nus_upscaler *h, const void *d_in, void *d_out,
+                                uint32_t n_frames, void *stream);
+
+const char *nus_upscaler_name(const nus_upscaler *h); /* "WgpuNearestUpscaler" / "WgpuBilinearUpscaler" (mod.rs:1060-1066) / "HipLanczos3Upscaler" */
+int nus_upscaler_algorithm(const nus_upscaler *h);
+int nus_upscaler_quality(const nus_upscaler *h);
+int nus_upscaler_set_quality(nus_upscaler *h, int quality);
+int nus_upscaler_is_initialized(const nus_upscaler *h);
+size_t nus_upscaler_input_size(const nus_upscaler *h);  /* in_w*in_h*4, 0 before initialize */
+size_t nus_upscaler_output_size(const nus_upscaler *h); /* out_w*out_h*4 */
+const char *nus_upscaler_last_error(const nus_upscaler *h);
+/* Kernel time (hipEvent pair) of the last host-path upscale; NUS_ERR_NOT_INITIALIZED if none. */
+int nus_upscaler_last_gpu_ms(const nus_upscaler *h, double *ms_out);
+/* Name of the kernel variant chosen at initialize (e.g. "lanczos3_x2_regwin"). */
+const char *nus_upscaler_kernel_variant(const nus_upscaler *h);
+
+/* Shared LUT exchange for multi-GPU runs: rank 0 exports the per-axis tables built at
+ * initialize, the blob is broadcast (RCCL), other ranks import it so every GPU uses
+ * bit-identical weights.  export returns the blob size (or negative status);
+ * with buf == NULL it only reports the size. */
+int64_t nus_upscaler_export_tables(const nus_upscaler *h, void *buf, size_t cap);
+int nus_upscaler_import_tables(nus_upscaler *h, const void *buf, size_t len);
+
+/* Host-only (no GPU needed): build the same blob directly from the dimensions, and
+ * check a received blob against them.  variant: nus_bilinear_variant. */
+int64_t nus_tables_build_blob(uint32_t in_w, uint32_t in_h, uint32_t out_w, uint32_t out_h,
+                              int variant, void *buf, size_t cap);
+int nus_tables_validate_blob(const void *buf, size_t len, uint32_t in_w, uint32_t in_h,
+                             uint32_t out_w, uint32_t out_h);
+
+/* ---- host-only table builders (no GPU needed; used by initialize) --------------- */
+
+#define NUS_RESIZE_MAX_TAPS 32
+
+/* Lanczos-3 tap windows of one axis, image-0.24.9 convention (half-pixel centres,
+ * support 3*max(in/out,1), weights normalised to sum 1).  left/ntaps: out_n entries;
+ * weights: out_n * NUS_RESIZE_MAX_TAPS floats, zero padded.
+ * Returns the largest ntaps or a negative status. */
+int nus_lanczos3_build_axis(uint32_t in_n, uint32_t out_n, int32_t *left,
+                            uint32_t *ntaps, float *weights);
+/* Nearest source index per output index: min(o*in_n/out_n, in_n-1). */
+int nus_nearest_build_axis(uint32_t in_n, uint32_t out_n, uint32_t *src);
+/* Bilinear i0 / frac per output index. variant: nus_bilinear_variant. */
+int nus_bilinear_build_axis(uint32_t in_n, uint32_t out_n, int variant,
+                            uint32_t *i0, float *frac);
+
+/* ---- Frame interpolator (WgpuFrameInterpolator) -------------------------------- */
+
+/* WgpuFrameInterpolator::new_py(preset) (wgpu_interpolator.rs:172-212). */
+nus_interp *nus_interp_create(int wg_preset);
+void nus_interp_destroy(nus_interp *h);
+int nus_interp_set_device(nus_interp *h, int device);
+
+/* interpolate_py (wgpu_interpolator.rs:215-491): host frames in, host frame out.
+ * flow == NULL -> zero flow (the live reference behaviour); otherwise w*h*2 floats
+ * (dx, dy) = pixel delta from frame A to frame B (warp_blend.wgsl:29-37).
+ * a_len and b_len must equal w*h*4 (else NUS_ERR_SIZE_MISMATCH with the text of
+ * wgpu_interpolator.rs:234-237); out_cap >= w*h*4. */
+int nus_interp_interpolate(nus_interp *h, const uint8_t *a, size_t a_len,
+                           const uint8_t *b, size_t b_len, const float *flow,
+                           uint32_t w, uint32_t hgt, float t,
+                           uint8_t *out, size_t out_cap);
+
+/* Device-resident path: n_pairs independent pairs; pair i reads
+ * d_a + i*a_stride, d_b + i*b_stride (byte strides; a sliding stream uses
+ * d_b = d_a + frame_bytes with both strides = frame_bytes), optional
+ * d_flow + i*w*h*8, writes d_out + i*w*h*4.  Enqueued on `stream`, no sync. */
+int nus_interp_interpolate_device(nus_interp *h, const void *d_a, size_t a_stride,
+                                  const void *d_b, size_t b_stride,
+                                  const void *d_flow, uint32_t w, uint32_t hgt,
+                                  float t, void *d_out, uint32_t n_pairs, void *stream);
+
+/* get_last_gpu_duration_ms: NUS_OK and *ms_out set, or NUS_ERR_NOT_INITIALIZED when
+ * no interpolation has run yet (the reference returns None). */
+int nus_interp_last_gpu_ms(const nus_interp *h, double *ms_out);
+const char *nus_interp_last_error(const nus_interp *h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NUSCALER_HIP_H */

@@ -1,0 +1,41 @@
+"""nu_scaler_amd -- MI355X (gfx950) implementation of nu_scaler_core's per-pixel hot
+path (nearest / bilinear / Lanczos-3 upscaling, two-frame warp + blend) behind the
+reference's own Python surface:  `import nu_scaler_amd as nu_scaler_core`.
+
+The compute path is libnuscaler_hip.so (hand-written HIP kernels behind the C ABI of
+include/nuscaler_hip.h).  There is no CPU fallback: constructing any class without the
+library raises, and compute calls without a HIP device raise RuntimeError.
+"""
+from . import _capi
+from ._capi import NuScalerLibraryError, build, device_count
+from .interpolator import WgpuFrameInterpolator
+from .stream import (FramePipeline, broadcast_blob, broadcast_tables, build_tables_blob, shard_frames,
+                     validate_tables_blob)
+from .upscaler import PyAdvancedWgpuUpscaler, PyWgpuUpscaler, create_advanced_upscaler
+
+# module constants of the reference's #[pymodule] (nu_scaler_core/src/lib.rs:746-761)
+QUALITY_ULTRA = _capi.QUALITY_ULTRA
+QUALITY_QUALITY = _capi.QUALITY_QUALITY
+QUALITY_BALANCED = _capi.QUALITY_BALANCED
+QUALITY_PERFORMANCE = _capi.QUALITY_PERFORMANCE
+TECH_FSR = _capi.TECH_FSR
+TECH_DLSS = _capi.TECH_DLSS
+TECH_WGPU = _capi.TECH_WGPU
+TECH_FALLBACK = _capi.TECH_FALLBACK
+VENDOR_NVIDIA, VENDOR_AMD, VENDOR_INTEL, VENDOR_OTHER = 0, 1, 2, 3
+
+
+def create_fsr_upscaler(_quality: str):
+    """lib.rs:791-806: FSR3 is not part of this build either."""
+    raise NotImplementedError("FSR3 support is not enabled in this build.")
+
+
+__all__ = [
+    "PyWgpuUpscaler", "PyAdvancedWgpuUpscaler", "create_advanced_upscaler", "create_fsr_upscaler",
+    "WgpuFrameInterpolator", "FramePipeline", "shard_frames", "broadcast_tables",
+    "broadcast_blob", "build_tables_blob", "validate_tables_blob",
+    "NuScalerLibraryError", "build", "device_count",
+    "QUALITY_ULTRA", "QUALITY_QUALITY", "QUALITY_BALANCED", "QUALITY_PERFORMANCE",
+    "TECH_FSR", "TECH_DLSS", "TECH_WGPU", "TECH_FALLBACK",
+    "VENDOR_NVIDIA", "VENDOR_AMD", "VENDOR_INTEL", "VENDOR_OTHER",
+]

@@ -1,0 +1,129 @@
+"""ctypes binding of include/nuscaler_hip.h -- the same entry points a Rust shim
+(`nu_scaler_hip-sys`) would bind.  No torch types cross here."""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libnuscaler_hip.so")
+CSRC_DIR = os.path.join(_HERE, "csrc")
+
+# nus_status
+OK = 0
+ERR_INVALID_ARGUMENT = -1
+ERR_NOT_INITIALIZED = -2
+ERR_SIZE_MISMATCH = -3
+ERR_HIP = -4
+ERR_NO_DEVICE = -5
+ERR_UNSUPPORTED = -6
+ERR_OUT_OF_MEMORY = -7
+
+ALG_NEAREST, ALG_BILINEAR, ALG_LANCZOS3 = 0, 1, 2
+QUALITY_ULTRA_PERFORMANCE, QUALITY_ULTRA, QUALITY_QUALITY, QUALITY_BALANCED, QUALITY_PERFORMANCE, QUALITY_NATIVE = range(6)
+TECH_NONE, TECH_FSR, TECH_DLSS, TECH_WGPU, TECH_FALLBACK = range(5)
+WG_SQUARE_8X8, WG_SQUARE_16X16, WG_WIDE_32X8, WG_TALL_8X32 = range(4)
+RESIZE_MAX_TAPS = 32
+
+# Every symbol include/nuscaler_hip.h declares: (name, restype, argtypes)
+_vp, _cp, _i, _u32, _sz, _i64 = (ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_uint32,
+                                 ctypes.c_size_t, ctypes.c_int64)
+_f, _dp = ctypes.c_float, ctypes.POINTER(ctypes.c_double)
+SIGNATURES = [
+    ("nus_abi_version", _i, []),
+    ("nus_device_count", _i, []),
+    ("nus_last_error", _cp, []),
+    ("nus_status_string", _cp, [_i]),
+    ("nus_upscaler_create", _vp, [_i, _i]),
+    ("nus_upscaler_create_for_technology", _vp, [_i, _i]),
+    ("nus_upscaler_destroy", None, [_vp]),
+    ("nus_upscaler_set_device", _i, [_vp, _i]),
+    ("nus_upscaler_set_bilinear_variant", _i, [_vp, _i]),
+    ("nus_upscaler_set_lanczos_mode", _i, [_vp, _i]),
+    ("nus_upscaler_set_option", _i, [_vp, _cp, _i64]),
+    ("nus_upscaler_initialize", _i, [_vp, _u32, _u32, _u32, _u32]),
+    ("nus_upscaler_upscale", _i, [_vp, _vp, _sz, _vp, _sz]),
+    ("nus_upscaler_upscale_batch", _i, [_vp, _vp, _vp, _sz, _vp, _sz]),
+    ("nus_upscaler_upscale_device", _i, [_vp, _vp, _vp, _u32, _vp]),
+    ("nus_upscaler_name", _cp, [_vp]),
+    ("nus_upscaler_algorithm", _i, [_vp]),
+    ("nus_upscaler_quality", _i, [_vp]),
+    ("nus_upscaler_set_quality", _i, [_vp, _i]),
+    ("nus_upscaler_is_initialized", _i, [_vp]),
+    ("nus_upscaler_input_size", _sz, [_vp]),
+    ("nus_upscaler_output_size", _sz, [_vp]),
+    ("nus_upscaler_last_error", _cp, [_vp]),
+    ("nus_upscaler_last_gpu_ms", _i, [_vp, _dp]),
+    ("nus_upscaler_kernel_variant", _cp, [_vp]),
+    ("nus_upscaler_export_tables", _i64, [_vp, _vp, _sz]),
+    ("nus_upscaler_import_tables", _i, [_vp, _vp, _sz]),
+    ("nus_tables_build_blob", _i64, [_u32, _u32, _u32, _u32, _i, _vp, _sz]),
+    ("nus_tables_validate_blob", _i, [_vp, _sz, _u32, _u32, _u32, _u32]),
+    ("nus_lanczos3_build_axis", _i, [_u32, _u32, _vp, _vp, _vp]),
+    ("nus_nearest_build_axis", _i, [_u32, _u32, _vp]),
+    ("nus_bilinear_build_axis", _i, [_u32, _u32, _i, _vp, _vp]),
+    ("nus_interp_create", _vp, [_i]),
+    ("nus_interp_destroy", None, [_vp]),
+    ("nus_interp_set_device", _i, [_vp, _i]),
+    ("nus_interp_interpolate", _i, [_vp, _vp, _sz, _vp, _sz, _vp, _u32, _u32, _f, _vp, _sz]),
+    ("nus_interp_interpolate_device", _i, [_vp, _vp, _sz, _vp, _sz, _vp, _u32, _u32, _f, _vp, _u32, _vp]),
+    ("nus_interp_last_gpu_ms", _i, [_vp, _dp]),
+    ("nus_interp_last_error", _cp, [_vp]),
+]
+
+
+class NuScalerLibraryError(ImportError):
+    """libnuscaler_hip.so is missing or incomplete.  There is no CPU fallback."""
+
+
+def build(force: bool = False) -> str:
+    """Compile libnuscaler_hip.so for gfx950 with hipcc (works without a GPU)."""
+    srcs = [os.path.join(CSRC_DIR, f) for f in os.listdir(CSRC_DIR)
+            if f.endswith((".hip", ".cpp", ".hpp"))]
+    srcs.append(os.path.join(_HERE, "..", "include", "nuscaler_hip.h"))
+    stale = (not os.path.exists(LIB_PATH)
+             or os.path.getmtime(LIB_PATH) < max(os.path.getmtime(s) for s in srcs))
+    if force or stale:
+        cmd = ["make", "-C", CSRC_DIR] + (["-B"] if force else [])
+        res = subprocess.run(cmd, capture_output=True, text=True)
+        if res.returncode != 0:
+            raise RuntimeError("building libnuscaler_hip.so failed:\n" + res.stdout + res.stderr)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib() -> ctypes.CDLL:
+    """Load the C-ABI library; fail loudly if it is absent (no silent fallback)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise NuScalerLibraryError(
+                f"{LIB_PATH} not found: build it with `make -C {CSRC_DIR}` "
+                "(or `python -c 'import __graft_entry__ as g; g.build()'`). "
+                "nu_scaler_amd has no CPU fallback.")
+        try:
+            L = ctypes.CDLL(LIB_PATH)
+        except OSError as e:  # e.g. libamdhip64 missing
+            raise NuScalerLibraryError(f"cannot load {LIB_PATH}: {e}") from e
+        for name, res, args in SIGNATURES:
+            try:
+                fn = getattr(L, name)
+            except AttributeError as e:
+                raise NuScalerLibraryError(f"{LIB_PATH} does not export {name}") from e
+            fn.restype = res
+            fn.argtypes = args
+        if L.nus_abi_version() != 1:
+            raise NuScalerLibraryError("libnuscaler_hip.so ABI version mismatch")
+        _lib = L
+    return _lib
+
+
+def last_error() -> str:
+    return lib().nus_last_error().decode("utf-8", "replace")
+
+
+def device_count() -> int:
+    return int(lib().nus_device_count())

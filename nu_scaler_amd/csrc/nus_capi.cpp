@@ -1,0 +1,255 @@
+// nus_capi.cpp -- extern "C" boundary (include/nuscaler_hip.h) over the host classes.
+#include "../../include/nuscaler_hip.h"
+
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "nus_host.hpp"
+
+struct nus_upscaler {
+    nus::HipUpscaler impl;
+    nus_upscaler(nus::Quality q, nus::Algorithm a) : impl(q, a) {}
+};
+
+struct nus_interp {
+    nus::HipFrameInterpolator impl;
+    explicit nus_interp(int preset) : impl(preset) {}
+};
+
+namespace {
+int null_handle()
+{
+    nus::set_thread_error("null handle");
+    return NUS_ERR_INVALID_ARGUMENT;
+}
+} // namespace
+
+extern "C" {
+
+int nus_abi_version(void) { return NUS_ABI_VERSION; }
+
+int nus_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return n;
+}
+
+const char *nus_last_error(void) { return nus::thread_error(); }
+
+const char *nus_status_string(int status)
+{
+    switch (status) {
+    case NUS_OK: return "ok";
+    case NUS_ERR_INVALID_ARGUMENT: return "invalid argument";
+    case NUS_ERR_NOT_INITIALIZED: return "not initialized";
+    case NUS_ERR_SIZE_MISMATCH: return "size mismatch";
+    case NUS_ERR_HIP: return "HIP runtime error";
+    case NUS_ERR_NO_DEVICE: return "no HIP device";
+    case NUS_ERR_UNSUPPORTED: return "unsupported";
+    case NUS_ERR_OUT_OF_MEMORY: return "out of memory";
+    default: return "unknown status";
+    }
+}
+
+nus_upscaler *nus_upscaler_create(int algorithm, int quality)
+{
+    if (algorithm < NUS_ALG_NEAREST || algorithm > NUS_ALG_LANCZOS3 || quality < NUS_QUALITY_ULTRA_PERFORMANCE ||
+        quality > NUS_QUALITY_NATIVE) {
+        nus::set_thread_error("nus_upscaler_create: unknown algorithm or quality");
+        return nullptr;
+    }
+    return new (std::nothrow) nus_upscaler(static_cast<nus::Quality>(quality), static_cast<nus::Algorithm>(algorithm));
+}
+
+nus_upscaler *nus_upscaler_create_for_technology(int technology, int quality)
+{
+    if (technology < NUS_TECH_NONE || technology > NUS_TECH_FALLBACK || quality < NUS_QUALITY_ULTRA_PERFORMANCE ||
+        quality > NUS_QUALITY_NATIVE) {
+        nus::set_thread_error("nus_upscaler_create_for_technology: unknown technology or quality");
+        return nullptr;
+    }
+    // UpscalerFactory::create_upscaler (upscale/mod.rs:95-117)
+    const int alg = technology == NUS_TECH_WGPU ? NUS_ALG_BILINEAR : NUS_ALG_NEAREST;
+    return nus_upscaler_create(alg, quality);
+}
+
+void nus_upscaler_destroy(nus_upscaler *h) { delete h; }
+
+int nus_upscaler_set_device(nus_upscaler *h, int device) { return h ? h->impl.set_device(device) : null_handle(); }
+int nus_upscaler_set_bilinear_variant(nus_upscaler *h, int v) { return h ? h->impl.set_bilinear_variant(v) : null_handle(); }
+int nus_upscaler_set_lanczos_mode(nus_upscaler *h, int m) { return h ? h->impl.set_lanczos_mode(m) : null_handle(); }
+int nus_upscaler_set_option(nus_upscaler *h, const char *key, int64_t value)
+{
+    return h ? h->impl.set_option(key, value) : null_handle();
+}
+
+int nus_upscaler_initialize(nus_upscaler *h, uint32_t in_w, uint32_t in_h, uint32_t out_w, uint32_t out_h)
+{
+    return h ? h->impl.initialize(in_w, in_h, out_w, out_h) : null_handle();
+}
+
+int nus_upscaler_upscale(nus_upscaler *h, const uint8_t *in, size_t in_len, uint8_t *out, size_t out_cap)
+{
+    return h ? h->impl.upscale(in, in_len, out, out_cap) : null_handle();
+}
+
+int nus_upscaler_upscale_batch(nus_upscaler *h, const uint8_t *const *ins, const size_t *in_lens, size_t n,
+                               uint8_t *const *outs, size_t out_cap_each)
+{
+    return h ? h->impl.upscale_batch(ins, in_lens, n, outs, out_cap_each) : null_handle();
+}
+
+int nus_upscaler_upscale_device(nus_upscaler *h, const void *d_in, void *d_out, uint32_t n_frames, void *stream)
+{
+    return h ? h->impl.upscale_device(d_in, d_out, n_frames, static_cast<hipStream_t>(stream)) : null_handle();
+}
+
+const char *nus_upscaler_name(const nus_upscaler *h) { return h ? h->impl.name() : ""; }
+int nus_upscaler_algorithm(const nus_upscaler *h) { return h ? static_cast<int>(h->impl.algorithm()) : null_handle(); }
+int nus_upscaler_quality(const nus_upscaler *h) { return h ? static_cast<int>(h->impl.quality()) : null_handle(); }
+
+int nus_upscaler_set_quality(nus_upscaler *h, int quality)
+{
+    if (!h) return null_handle();
+    if (quality < NUS_QUALITY_ULTRA_PERFORMANCE || quality > NUS_QUALITY_NATIVE) {
+        nus::set_thread_error("set_quality: unknown quality");
+        return NUS_ERR_INVALID_ARGUMENT;
+    }
+    return h->impl.set_quality(static_cast<nus::Quality>(quality));
+}
+
+int nus_upscaler_is_initialized(const nus_upscaler *h) { return h && h->impl.initialized() ? 1 : 0; }
+size_t nus_upscaler_input_size(const nus_upscaler *h) { return h ? h->impl.input_size() : 0; }
+size_t nus_upscaler_output_size(const nus_upscaler *h) { return h ? h->impl.output_size() : 0; }
+const char *nus_upscaler_last_error(const nus_upscaler *h) { return h ? h->impl.last_error() : "null handle"; }
+
+int nus_upscaler_last_gpu_ms(const nus_upscaler *h, double *ms_out)
+{
+    if (!h) return null_handle();
+    return h->impl.last_gpu_ms(ms_out) ? NUS_OK : NUS_ERR_NOT_INITIALIZED;
+}
+
+const char *nus_upscaler_kernel_variant(const nus_upscaler *h) { return h ? h->impl.kernel_variant() : ""; }
+
+int64_t nus_upscaler_export_tables(const nus_upscaler *h, void *buf, size_t cap)
+{
+    return h ? h->impl.export_tables(buf, cap) : null_handle();
+}
+
+int nus_upscaler_import_tables(nus_upscaler *h, const void *buf, size_t len)
+{
+    return h ? h->impl.import_tables(buf, len) : null_handle();
+}
+
+int64_t nus_tables_build_blob(uint32_t in_w, uint32_t in_h, uint32_t out_w, uint32_t out_h, int variant, void *buf,
+                              size_t cap)
+{
+    if (in_w == 0 || in_h == 0 || out_w == 0 || out_h == 0 || (variant != 0 && variant != 1)) {
+        nus::set_thread_error("nus_tables_build_blob: bad argument");
+        return NUS_ERR_INVALID_ARGUMENT;
+    }
+    nus::AxisTables x, y;
+    nus::build_axis_tables(in_w, out_w, variant == 1, x);
+    nus::build_axis_tables(in_h, out_h, variant == 1, y);
+    const std::vector<uint8_t> blob = nus::serialize_tables(x, y);
+    if (buf) {
+        if (cap < blob.size()) {
+            nus::set_thread_error("nus_tables_build_blob: buffer too small");
+            return NUS_ERR_INVALID_ARGUMENT;
+        }
+        memcpy(buf, blob.data(), blob.size());
+    }
+    return (int64_t)blob.size();
+}
+
+int nus_tables_validate_blob(const void *buf, size_t len, uint32_t in_w, uint32_t in_h, uint32_t out_w, uint32_t out_h)
+{
+    nus::AxisTables x, y;
+    std::string err;
+    if (!buf || !nus::deserialize_tables(static_cast<const uint8_t *>(buf), len, x, y, err)) {
+        nus::set_thread_error(buf ? err : "nus_tables_validate_blob: null buffer");
+        return NUS_ERR_INVALID_ARGUMENT;
+    }
+    if (x.in_n != in_w || x.out_n != out_w || y.in_n != in_h || y.out_n != out_h) {
+        nus::set_thread_error("table blob was built for different dimensions");
+        return NUS_ERR_INVALID_ARGUMENT;
+    }
+    return NUS_OK;
+}
+
+int nus_lanczos3_build_axis(uint32_t in_n, uint32_t out_n, int32_t *left, uint32_t *ntaps, float *weights)
+{
+    if (!left || !ntaps || !weights || in_n == 0 || out_n == 0) {
+        nus::set_thread_error("nus_lanczos3_build_axis: bad argument");
+        return NUS_ERR_INVALID_ARGUMENT;
+    }
+    const int r = nus::build_lanczos3_axis(in_n, out_n, left, ntaps, weights);
+    if (r < 0) {
+        nus::set_thread_error("nus_lanczos3_build_axis: window exceeds NUS_RESIZE_MAX_TAPS");
+        return NUS_ERR_UNSUPPORTED;
+    }
+    return r;
+}
+
+int nus_nearest_build_axis(uint32_t in_n, uint32_t out_n, uint32_t *src)
+{
+    if (!src || in_n == 0 || out_n == 0) {
+        nus::set_thread_error("nus_nearest_build_axis: bad argument");
+        return NUS_ERR_INVALID_ARGUMENT;
+    }
+    nus::build_nearest_axis(in_n, out_n, src);
+    return NUS_OK;
+}
+
+int nus_bilinear_build_axis(uint32_t in_n, uint32_t out_n, int variant, uint32_t *i0, float *frac)
+{
+    if (!i0 || !frac || in_n == 0 || out_n == 0 || (variant != 0 && variant != 1)) {
+        nus::set_thread_error("nus_bilinear_build_axis: bad argument");
+        return NUS_ERR_INVALID_ARGUMENT;
+    }
+    nus::build_bilinear_axis(in_n, out_n, variant == 1, i0, frac);
+    return NUS_OK;
+}
+
+nus_interp *nus_interp_create(int wg_preset)
+{
+    if (wg_preset < NUS_WG_SQUARE_8X8 || wg_preset > NUS_WG_TALL_8X32) {
+        nus::set_thread_error("nus_interp_create: unknown workgroup preset");
+        return nullptr;
+    }
+    return new (std::nothrow) nus_interp(wg_preset);
+}
+
+void nus_interp_destroy(nus_interp *h) { delete h; }
+int nus_interp_set_device(nus_interp *h, int device) { return h ? h->impl.set_device(device) : null_handle(); }
+
+int nus_interp_interpolate(nus_interp *h, const uint8_t *a, size_t a_len, const uint8_t *b, size_t b_len,
+                           const float *flow, uint32_t w, uint32_t hgt, float t, uint8_t *out, size_t out_cap)
+{
+    return h ? h->impl.interpolate(a, a_len, b, b_len, flow, w, hgt, t, out, out_cap) : null_handle();
+}
+
+int nus_interp_interpolate_device(nus_interp *h, const void *d_a, size_t a_stride, const void *d_b, size_t b_stride,
+                                  const void *d_flow, uint32_t w, uint32_t hgt, float t, void *d_out, uint32_t n_pairs,
+                                  void *stream)
+{
+    return h ? h->impl.interpolate_device(d_a, a_stride, d_b, b_stride, d_flow, w, hgt, t, d_out, n_pairs,
+                                          static_cast<hipStream_t>(stream))
+             : null_handle();
+}
+
+int nus_interp_last_gpu_ms(const nus_interp *h, double *ms_out)
+{
+    if (!h) return null_handle();
+    return h->impl.last_gpu_ms(ms_out) ? NUS_OK : NUS_ERR_NOT_INITIALIZED;
+}
+
+const char *nus_interp_last_error(const nus_interp *h) { return h ? h->impl.last_error() : "null handle"; }
+
+} // extern "C"

@@ -1,0 +1,641 @@
+// nus_host.cpp -- host classes above the gfx950 kernels.  See nus_host.hpp.
+#include "nus_host.hpp"
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+
+namespace nus {
+
+namespace {
+thread_local std::string g_thread_error;
+
+std::string fmt(const char *f, ...) __attribute__((format(printf, 1, 2)));
+std::string fmt(const char *f, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, f);
+    vsnprintf(buf, sizeof buf, f, ap);
+    va_end(ap);
+    return buf;
+}
+
+// True when `p` is host memory the DMA engines can address directly
+// (hipHostMalloc / hipHostRegister); pageable memory goes through pinned staging.
+bool is_pinned_host(const void *p)
+{
+    hipPointerAttribute_t attr;
+    if (hipPointerGetAttributes(&attr, p) != hipSuccess) {
+        (void)hipGetLastError(); // pageable memory: not an error for us
+        return false;
+    }
+    return attr.type == hipMemoryTypeHost;
+}
+
+int device_count()
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return n;
+}
+} // namespace
+
+void set_thread_error(const std::string &msg) { g_thread_error = msg; }
+const char *thread_error() { return g_thread_error.c_str(); }
+
+// ---------------------------------------------------------------------------------
+// HipUpscaler
+// ---------------------------------------------------------------------------------
+
+HipUpscaler::HipUpscaler(Quality q, Algorithm a) : quality_(q), algorithm_(a) {}
+
+HipUpscaler::~HipUpscaler() { release(); }
+
+int HipUpscaler::fail(int status, const std::string &msg)
+{
+    error_ = msg;
+    set_thread_error(msg);
+    return status;
+}
+
+int HipUpscaler::fail_hip(hipError_t e, const char *what)
+{
+    (void)hipGetLastError();
+    return fail(e == hipErrorOutOfMemory ? kOutOfMemory : kHipError,
+                fmt("HIP error in %s: %s", what, hipGetErrorString(e)));
+}
+
+#define NUS_HIP(call)                                   \
+    do {                                                \
+        hipError_t e_ = (call);                         \
+        if (e_ != hipSuccess) return fail_hip(e_, #call); \
+    } while (0)
+
+const char *HipUpscaler::name() const
+{
+    // upscale/mod.rs:1060-1066 for the two reference algorithms
+    switch (algorithm_) {
+    case Algorithm::Bilinear: return "WgpuBilinearUpscaler";
+    case Algorithm::Lanczos3: return "HipLanczos3Upscaler";
+    default: return "WgpuNearestUpscaler";
+    }
+}
+
+int HipUpscaler::set_quality(Quality q)
+{
+    std::lock_guard<std::mutex> lk(mu_);
+    quality_ = q; // quality never changes the arithmetic (upscale/mod.rs:1072-1077)
+    return kOk;
+}
+
+int HipUpscaler::set_device(int device)
+{
+    std::lock_guard<std::mutex> lk(mu_);
+    if (initialized_) return fail(kInvalidArgument, "set_device must be called before initialize");
+    if (device < 0) return fail(kInvalidArgument, "negative device index");
+    device_ = device;
+    return kOk;
+}
+
+int HipUpscaler::set_bilinear_variant(int variant)
+{
+    std::lock_guard<std::mutex> lk(mu_);
+    if (variant != 0 && variant != 1) return fail(kInvalidArgument, "unknown bilinear variant");
+    if (initialized_) return fail(kInvalidArgument, "set_bilinear_variant must be called before initialize");
+    wgsl_bilinear_ = variant == 1;
+    return kOk;
+}
+
+int HipUpscaler::set_lanczos_mode(int mode)
+{
+    std::lock_guard<std::mutex> lk(mu_);
+    if (mode != 0 && mode != 1) return fail(kInvalidArgument, "unknown lanczos mode");
+    lanczos_exact_ = mode == 1;
+    return kOk;
+}
+
+int HipUpscaler::set_option(const char *key, int64_t value)
+{
+    std::lock_guard<std::mutex> lk(mu_);
+    if (!key) return fail(kInvalidArgument, "null option key");
+    if (!strcmp(key, "force_general")) {
+        if (initialized_) return fail(kInvalidArgument, "force_general must be set before initialize");
+        force_general_ = value != 0;
+        return kOk;
+    }
+    if (!strcmp(key, "rows_per_wave")) {
+        if (value < 0 || value > 4096) return fail(kInvalidArgument, "rows_per_wave out of range");
+        rows_per_wave_ = (uint32_t)value;
+        return kOk;
+    }
+    return fail(kInvalidArgument, fmt("unknown option '%s'", key));
+}
+
+int HipUpscaler::ensure_device()
+{
+    const int n = device_count();
+    if (n <= 0)
+        return fail(kNoDevice, "no HIP device available (the gfx950 path has no CPU fallback)");
+    if (device_ >= n) return fail(kNoDevice, fmt("HIP device %d requested but only %d present", device_, n));
+    NUS_HIP(hipSetDevice(device_));
+    return kOk;
+}
+
+void HipUpscaler::release()
+{
+    if (device_count() > 0) (void)hipSetDevice(device_);
+    for (void *p : table_allocs_) (void)hipFree(p);
+    table_allocs_.clear();
+    dt_ = DeviceTables();
+    for (Slot &s : slots_) {
+        if (s.stream) (void)hipStreamSynchronize(s.stream);
+        if (s.d_in) (void)hipFree(s.d_in);
+        if (s.d_out) (void)hipFree(s.d_out);
+        if (s.h_in) (void)hipHostFree(s.h_in);
+        if (s.h_out) (void)hipHostFree(s.h_out);
+        if (s.k_begin) (void)hipEventDestroy(s.k_begin);
+        if (s.k_end) (void)hipEventDestroy(s.k_end);
+        if (s.stream) (void)hipStreamDestroy(s.stream);
+        s = Slot();
+    }
+    initialized_ = false;
+    have_ms_ = false;
+}
+
+void HipUpscaler::choose_variant()
+{
+    const bool x2 = ow_ == 2 * iw_ && oh_ == 2 * ih_ && (iw_ % 4) == 0 && !force_general_;
+    switch (algorithm_) {
+    case Algorithm::Nearest:
+        variant_ = x2 ? Variant::NearestX2 : Variant::NearestTable;
+        break;
+    case Algorithm::Bilinear: {
+        // The packed-integer x2 kernel is valid iff the CPU-form tables are exactly
+        // i0 = o>>1, frac = 0 / 0.5 (and frac 0 at the clamped last sample).
+        bool ok = x2 && !wgsl_bilinear_;
+        for (const AxisTables *t : {&tx_, &ty_}) {
+            for (uint32_t o = 0; ok && o < t->out_n; ++o) {
+                const bool last_odd = (o & 1) && (o >> 1) == t->in_n - 1;
+                const float want = (o & 1) && !last_odd ? 0.5f : 0.0f;
+                ok = t->bl_i0[o] == (o >> 1) && t->bl_frac[o] == want;
+            }
+        }
+        variant_ = ok ? Variant::BilinearX2Int : Variant::BilinearTable;
+        break;
+    }
+    case Algorithm::Lanczos3: {
+        bool ok = x2 && iw_ >= 16;
+        ok = ok && lanczos_x2_phase_frame(tx_, wx6_) && lanczos_x2_phase_frame(ty_, wy6_) &&
+             lanczos_x2_interior_uniform(tx_, wx6_);
+        variant_ = ok ? Variant::LanczosX2RegWin : Variant::LanczosGeneral;
+        break;
+    }
+    }
+}
+
+int HipUpscaler::upload_tables()
+{
+    for (void *p : table_allocs_) (void)hipFree(p);
+    table_allocs_.clear();
+    dt_ = DeviceTables();
+    auto up = [&](const void *src, size_t bytes, const void **dst) -> int {
+        void *d = nullptr;
+        NUS_HIP(hipMalloc(&d, bytes));
+        table_allocs_.push_back(d);
+        NUS_HIP(hipMemcpy(d, src, bytes, hipMemcpyHostToDevice));
+        *dst = d;
+        return kOk;
+    };
+    int rc = kOk;
+#define UP(vec, field)                                                                                   \
+    if (rc == kOk) rc = up((vec).data(), (vec).size() * sizeof((vec)[0]), reinterpret_cast<const void **>(&dt_.field))
+    switch (algorithm_) {
+    case Algorithm::Nearest:
+        UP(tx_.nn_src, nn_sx);
+        UP(ty_.nn_src, nn_sy);
+        break;
+    case Algorithm::Bilinear:
+        UP(tx_.bl_i0, bl_x0);
+        UP(tx_.bl_frac, bl_fx);
+        UP(ty_.bl_i0, bl_y0);
+        UP(ty_.bl_frac, bl_fy);
+        break;
+    case Algorithm::Lanczos3:
+        UP(tx_.lz_left, lz_lx);
+        UP(tx_.lz_ntaps, lz_nx);
+        UP(tx_.lz_w, lz_wx);
+        UP(ty_.lz_left, lz_ly);
+        UP(ty_.lz_ntaps, lz_ny);
+        UP(ty_.lz_w, lz_wy);
+        dt_.lz_stride = kResizeMaxTaps;
+        if (variant_ == Variant::LanczosX2RegWin) {
+            UP(wy6_, lz_wy6);
+            for (int j = 0; j < 6; ++j) {
+                dt_.lz_wxe[j] = wx6_[(size_t)8 * 6 + j];
+                dt_.lz_wxo[j] = wx6_[(size_t)9 * 6 + j];
+            }
+        }
+        break;
+    }
+#undef UP
+    return rc;
+}
+
+int HipUpscaler::initialize(uint32_t in_w, uint32_t in_h, uint32_t out_w, uint32_t out_h)
+{
+    std::lock_guard<std::mutex> lk(mu_);
+    if (in_w == 0 || in_h == 0 || out_w == 0 || out_h == 0)
+        return fail(kInvalidArgument, "initialize: dimensions must be non-zero");
+    const uint64_t lim = 1ull << 31;
+    if ((uint64_t)in_w * in_h * 4 >= lim * 4 || (uint64_t)out_w * out_h * 4 >= lim * 4 || in_w > (1u << 20) ||
+        in_h > (1u << 20) || out_w > (1u << 20) || out_h > (1u << 20))
+        return fail(kInvalidArgument, "initialize: frame too large");
+    int rc = ensure_device();
+    if (rc != kOk) return rc;
+    release(); // any dimension change is a full re-init (upscale/mod.rs:883-889)
+    iw_ = in_w;
+    ih_ = in_h;
+    ow_ = out_w;
+    oh_ = out_h;
+    build_axis_tables(iw_, ow_, wgsl_bilinear_, tx_);
+    build_axis_tables(ih_, oh_, wgsl_bilinear_, ty_);
+    if (algorithm_ == Algorithm::Lanczos3 && (tx_.lz_max_taps < 0 || ty_.lz_max_taps < 0))
+        return fail(kUnsupported, fmt("Lanczos-3 window exceeds %u taps for %ux%u -> %ux%u", kResizeMaxTaps, iw_, ih_, ow_, oh_));
+    choose_variant();
+    rc = upload_tables();
+    if (rc != kOk) return rc;
+    initialized_ = true;
+    error_.clear();
+    return kOk;
+}
+
+int HipUpscaler::enqueue(const uint8_t *d_in, uint8_t *d_out, uint32_t n_frames, hipStream_t stream)
+{
+    UpscaleLaunch L;
+    L.in = d_in;
+    L.out = d_out;
+    L.iw = iw_;
+    L.ih = ih_;
+    L.ow = ow_;
+    L.oh = oh_;
+    L.n_frames = n_frames;
+    L.stream = stream;
+    hipError_t e = hipSuccess;
+    switch (variant_) {
+    case Variant::NearestTable: e = launch_nearest_table(L, dt_); break;
+    case Variant::NearestX2: e = launch_nearest_x2(L); break;
+    case Variant::BilinearTable: e = launch_bilinear_table(L, dt_, wgsl_bilinear_); break;
+    case Variant::BilinearX2Int: e = launch_bilinear_x2_int(L); break;
+    case Variant::LanczosGeneral: e = launch_lanczos_general(L, dt_, lanczos_exact_, 0); break;
+    case Variant::LanczosX2RegWin: {
+        uint32_t th = rows_per_wave_;
+        if (th == 0) {
+            // enough waves to fill 256 CUs a few times over, tall enough to amortise the 6 halo rows
+            const uint64_t nstrips = (iw_ + kLanczosX2StripCols - 1) / kLanczosX2StripCols;
+            const uint64_t rows_total = (uint64_t)ih_ * nstrips * n_frames;
+            uint64_t t = rows_total / 8192;
+            th = (uint32_t)(t < 8 ? 8 : (t > 36 ? 36 : t));
+        }
+        e = launch_lanczos_x2(L, dt_, lanczos_exact_, th);
+        break;
+    }
+    }
+    if (e != hipSuccess) return fail_hip(e, "kernel launch");
+    return kOk;
+}
+
+int HipUpscaler::upscale_device(const void *d_in, void *d_out, uint32_t n_frames, hipStream_t stream)
+{
+    std::lock_guard<std::mutex> lk(mu_);
+    if (!initialized_) return fail(kNotInitialized, "Upscaler not initialized. Call initialize() first.");
+    if (!d_in || !d_out) return fail(kInvalidArgument, "upscale_device: null device pointer");
+    if (n_frames == 0) return kOk;
+    if ((reinterpret_cast<uintptr_t>(d_in) % 16) || (reinterpret_cast<uintptr_t>(d_out) % 16))
+        return fail(kInvalidArgument, "upscale_device: device pointers must be 16-byte aligned");
+    if (n_frames > 1 && (((size_t)iw_ * ih_ * 4) % 16 || ((size_t)ow_ * oh_ * 4) % 16))
+        return fail(kInvalidArgument, "upscale_device: batched frames need frame sizes that are multiples of 16 bytes");
+    NUS_HIP(hipSetDevice(device_));
+    return enqueue(static_cast<const uint8_t *>(d_in), static_cast<uint8_t *>(d_out), n_frames, stream);
+}
+
+int HipUpscaler::upscale(const uint8_t *in, size_t in_len, uint8_t *out, size_t out_cap)
+{
+    const uint8_t *ins[1] = {in};
+    const size_t lens[1] = {in_len};
+    uint8_t *outs[1] = {out};
+    return upscale_batch(ins, lens, 1, outs, out_cap);
+}
+
+int HipUpscaler::upscale_batch(const uint8_t *const *ins, const size_t *in_lens, size_t n, uint8_t *const *outs,
+                               size_t out_cap_each)
+{
+    std::lock_guard<std::mutex> lk(mu_);
+    if (!initialized_) return fail(kNotInitialized, "Upscaler not initialized. Call initialize() first.");
+    if (n == 0) return kOk;
+    if (!ins || !in_lens || !outs) return fail(kInvalidArgument, "upscale: null argument");
+    const size_t in_bytes = (size_t)iw_ * ih_ * 4, out_bytes = (size_t)ow_ * oh_ * 4;
+    for (size_t i = 0; i < n; ++i) {
+        if (!ins[i] || !outs[i]) return fail(kInvalidArgument, "upscale: null frame pointer");
+        if (in_lens[i] != in_bytes)
+            return fail(kSizeMismatch, fmt("Input data size (%zu) does not match expected input buffer size (%zu for %ux%u)",
+                                           in_lens[i], in_bytes, iw_, ih_));
+    }
+    if (out_cap_each < out_bytes)
+        return fail(kInvalidArgument, fmt("Output capacity (%zu) is smaller than the output frame (%zu for %ux%u)",
+                                          out_cap_each, out_bytes, ow_, oh_));
+    NUS_HIP(hipSetDevice(device_));
+    const int nslots = n < (size_t)kSlots ? (int)n : kSlots;
+    for (int s = 0; s < nslots; ++s) {
+        Slot &S = slots_[s];
+        if (S.stream) continue;
+        NUS_HIP(hipStreamCreateWithFlags(&S.stream, hipStreamNonBlocking));
+        NUS_HIP(hipEventCreate(&S.k_begin));
+        NUS_HIP(hipEventCreate(&S.k_end));
+        NUS_HIP(hipMalloc(reinterpret_cast<void **>(&S.d_in), in_bytes));
+        NUS_HIP(hipMalloc(reinterpret_cast<void **>(&S.d_out), out_bytes));
+        NUS_HIP(hipHostMalloc(reinterpret_cast<void **>(&S.h_in), in_bytes, hipHostMallocDefault));
+        NUS_HIP(hipHostMalloc(reinterpret_cast<void **>(&S.h_out), out_bytes, hipHostMallocDefault));
+    }
+    // Frame i runs on slot i % nslots: stage -> H2D -> kernel -> D2H, all async on the
+    // slot's stream; the host only blocks when it needs a slot back.
+    std::vector<bool> direct_out(n, false);
+    auto retire = [&](size_t i) -> int {
+        Slot &S = slots_[i % nslots];
+        NUS_HIP(hipStreamSynchronize(S.stream));
+        if (!direct_out[i]) memcpy(outs[i], S.h_out, out_bytes);
+        return kOk;
+    };
+    for (size_t i = 0; i < n; ++i) {
+        if (i >= (size_t)nslots) {
+            int rc = retire(i - nslots);
+            if (rc != kOk) return rc;
+        }
+        Slot &S = slots_[i % nslots];
+        const uint8_t *src = ins[i];
+        if (!is_pinned_host(src)) {
+            memcpy(S.h_in, src, in_bytes);
+            src = S.h_in;
+        }
+        NUS_HIP(hipMemcpyAsync(S.d_in, src, in_bytes, hipMemcpyHostToDevice, S.stream));
+        NUS_HIP(hipEventRecord(S.k_begin, S.stream));
+        int rc = enqueue(S.d_in, S.d_out, 1, S.stream);
+        if (rc != kOk) return rc;
+        NUS_HIP(hipEventRecord(S.k_end, S.stream));
+        direct_out[i] = is_pinned_host(outs[i]);
+        NUS_HIP(hipMemcpyAsync(direct_out[i] ? outs[i] : S.h_out, S.d_out, out_bytes, hipMemcpyDeviceToHost, S.stream));
+    }
+    for (size_t i = n > (size_t)nslots ? n - nslots : 0; i < n; ++i) {
+        int rc = retire(i);
+        if (rc != kOk) return rc;
+    }
+    float ms = 0.0f;
+    Slot &last = slots_[(n - 1) % nslots];
+    if (hipEventElapsedTime(&ms, last.k_begin, last.k_end) == hipSuccess) {
+        have_ms_ = true;
+        last_ms_ = ms;
+    } else {
+        (void)hipGetLastError();
+    }
+    return kOk;
+}
+
+bool HipUpscaler::last_gpu_ms(double *ms) const
+{
+    std::lock_guard<std::mutex> lk(mu_);
+    if (!have_ms_) return false;
+    if (ms) *ms = last_ms_;
+    return true;
+}
+
+int64_t HipUpscaler::export_tables(void *buf, size_t cap) const
+{
+    std::lock_guard<std::mutex> lk(mu_);
+    if (!initialized_) {
+        set_thread_error("export_tables: upscaler not initialized");
+        return kNotInitialized;
+    }
+    const std::vector<uint8_t> blob = serialize_tables(tx_, ty_);
+    if (buf) {
+        if (cap < blob.size()) {
+            set_thread_error("export_tables: buffer too small");
+            return kInvalidArgument;
+        }
+        memcpy(buf, blob.data(), blob.size());
+    }
+    return (int64_t)blob.size();
+}
+
+int HipUpscaler::import_tables(const void *buf, size_t len)
+{
+    std::lock_guard<std::mutex> lk(mu_);
+    if (!initialized_) return fail(kNotInitialized, "import_tables: upscaler not initialized");
+    if (!buf) return fail(kInvalidArgument, "import_tables: null buffer");
+    AxisTables x, y;
+    std::string err;
+    if (!deserialize_tables(static_cast<const uint8_t *>(buf), len, x, y, err)) return fail(kInvalidArgument, err);
+    if (x.in_n != iw_ || x.out_n != ow_ || y.in_n != ih_ || y.out_n != oh_)
+        return fail(kInvalidArgument, "import_tables: tables were built for different dimensions");
+    NUS_HIP(hipSetDevice(device_));
+    NUS_HIP(hipDeviceSynchronize());
+    tx_ = std::move(x);
+    ty_ = std::move(y);
+    if (algorithm_ == Algorithm::Lanczos3 && (tx_.lz_max_taps < 0 || ty_.lz_max_taps < 0))
+        return fail(kUnsupported, "import_tables: Lanczos window too wide");
+    choose_variant();
+    return upload_tables();
+}
+
+std::unique_ptr<HipUpscaler> UpscalerFactory::create_upscaler(Technology tech, Quality q)
+{
+    // upscale/mod.rs:99-116: Wgpu -> bilinear, everything else -> nearest.
+    const Algorithm a = tech == Technology::Wgpu ? Algorithm::Bilinear : Algorithm::Nearest;
+    return std::unique_ptr<HipUpscaler>(new HipUpscaler(q, a));
+}
+
+// ---------------------------------------------------------------------------------
+// HipFrameInterpolator
+// ---------------------------------------------------------------------------------
+
+HipFrameInterpolator::HipFrameInterpolator(int wg_preset) : wg_preset_(wg_preset) {}
+
+HipFrameInterpolator::~HipFrameInterpolator()
+{
+    release();
+    if (device_ready_) {
+        if (k_begin_) (void)hipEventDestroy(k_begin_);
+        if (k_end_) (void)hipEventDestroy(k_end_);
+        if (stream_) (void)hipStreamDestroy(stream_);
+    }
+}
+
+int HipFrameInterpolator::fail(int status, const std::string &msg)
+{
+    error_ = msg;
+    set_thread_error(msg);
+    return status;
+}
+
+int HipFrameInterpolator::fail_hip(hipError_t e, const char *what)
+{
+    (void)hipGetLastError();
+    return fail(e == hipErrorOutOfMemory ? kOutOfMemory : kHipError,
+                fmt("HIP error in %s: %s", what, hipGetErrorString(e)));
+}
+
+int HipFrameInterpolator::set_device(int device)
+{
+    std::lock_guard<std::mutex> lk(mu_);
+    if (device < 0) return fail(kInvalidArgument, "negative device index");
+    if (device_ready_) return fail(kInvalidArgument, "set_device must precede the first interpolation");
+    device_ = device;
+    return kOk;
+}
+
+void HipFrameInterpolator::release()
+{
+    if (!device_ready_) return;
+    (void)hipSetDevice(device_);
+    if (stream_) (void)hipStreamSynchronize(stream_);
+    if (d_a_) (void)hipFree(d_a_);
+    if (d_b_) (void)hipFree(d_b_);
+    if (d_out_) (void)hipFree(d_out_);
+    if (d_flow_) (void)hipFree(d_flow_);
+    if (h_stage_) (void)hipHostFree(h_stage_);
+    if (h_flow_) (void)hipHostFree(h_flow_);
+    d_a_ = d_b_ = d_out_ = nullptr;
+    d_flow_ = nullptr;
+    h_stage_ = nullptr;
+    h_flow_ = nullptr;
+    cap_bytes_ = 0;
+    cap_flow_ = false;
+}
+
+int HipFrameInterpolator::ensure(size_t frame_bytes, bool with_flow)
+{
+    if (!device_ready_) {
+        const int n = device_count();
+        if (n <= 0) return fail(kNoDevice, "no HIP device available (the gfx950 path has no CPU fallback)");
+        if (device_ >= n) return fail(kNoDevice, fmt("HIP device %d requested but only %d present", device_, n));
+        NUS_HIP(hipSetDevice(device_));
+        NUS_HIP(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
+        NUS_HIP(hipEventCreate(&k_begin_));
+        NUS_HIP(hipEventCreate(&k_end_));
+        device_ready_ = true;
+    }
+    NUS_HIP(hipSetDevice(device_));
+    if (frame_bytes > cap_bytes_ || (with_flow && !cap_flow_)) {
+        // the reference reallocates its textures on every call (wgpu_interpolator.rs:253-321);
+        // here buffers persist and only grow.
+        const size_t want = frame_bytes > cap_bytes_ ? frame_bytes : cap_bytes_;
+        const bool flow = with_flow || cap_flow_;
+        release();
+        NUS_HIP(hipMalloc(reinterpret_cast<void **>(&d_a_), want));
+        NUS_HIP(hipMalloc(reinterpret_cast<void **>(&d_b_), want));
+        NUS_HIP(hipMalloc(reinterpret_cast<void **>(&d_out_), want));
+        NUS_HIP(hipHostMalloc(reinterpret_cast<void **>(&h_stage_), want * 3, hipHostMallocDefault));
+        if (flow) {
+            NUS_HIP(hipMalloc(reinterpret_cast<void **>(&d_flow_), want * 2));
+            NUS_HIP(hipHostMalloc(reinterpret_cast<void **>(&h_flow_), want * 2, hipHostMallocDefault));
+        }
+        cap_bytes_ = want;
+        cap_flow_ = flow;
+    }
+    return kOk;
+}
+
+int HipFrameInterpolator::interpolate(const uint8_t *a, size_t a_len, const uint8_t *b, size_t b_len, const float *flow,
+                                      uint32_t w, uint32_t h, float t, uint8_t *out, size_t out_cap)
+{
+    std::lock_guard<std::mutex> lk(mu_);
+    if (w == 0 || h == 0 || (uint64_t)w * h >= (1ull << 31)) return fail(kInvalidArgument, "interpolate: bad dimensions");
+    const size_t expected = (size_t)w * h * 4;
+    if (a_len != expected || b_len != expected)
+        // wgpu_interpolator.rs:234-237
+        return fail(kSizeMismatch, fmt("Expected %zu bytes per frame for %ux%ux4 RGBA, got frame_a: %zu bytes, frame_b: %zu bytes",
+                                       expected, w, h, a_len, b_len));
+    if (!a || !b || !out) return fail(kInvalidArgument, "interpolate: null frame pointer");
+    if (out_cap < expected) return fail(kInvalidArgument, "interpolate: output capacity too small");
+    int rc = ensure(expected, flow != nullptr);
+    if (rc != kOk) return rc;
+    uint8_t *ha = h_stage_, *hb = h_stage_ + cap_bytes_, *ho = h_stage_ + 2 * cap_bytes_;
+    memcpy(ha, a, expected);
+    memcpy(hb, b, expected);
+    NUS_HIP(hipMemcpyAsync(d_a_, ha, expected, hipMemcpyHostToDevice, stream_));
+    NUS_HIP(hipMemcpyAsync(d_b_, hb, expected, hipMemcpyHostToDevice, stream_));
+    if (flow) {
+        memcpy(h_flow_, flow, expected * 2);
+        NUS_HIP(hipMemcpyAsync(d_flow_, h_flow_, expected * 2, hipMemcpyHostToDevice, stream_));
+    }
+    WarpLaunch L;
+    L.a = d_a_;
+    L.b = d_b_;
+    L.flow = flow ? d_flow_ : nullptr;
+    L.out = d_out_;
+    L.a_stride = L.b_stride = expected;
+    L.w = w;
+    L.h = h;
+    L.t = t;
+    L.n_pairs = 1;
+    L.stream = stream_;
+    NUS_HIP(hipEventRecord(k_begin_, stream_));
+    hipError_t e = launch_warp_blend(L);
+    if (e != hipSuccess) return fail_hip(e, "warp+blend launch");
+    NUS_HIP(hipEventRecord(k_end_, stream_));
+    NUS_HIP(hipMemcpyAsync(ho, d_out_, expected, hipMemcpyDeviceToHost, stream_));
+    NUS_HIP(hipStreamSynchronize(stream_));
+    memcpy(out, ho, expected);
+    float ms = 0.0f;
+    if (hipEventElapsedTime(&ms, k_begin_, k_end_) == hipSuccess) {
+        have_ms_ = true;
+        last_ms_ = ms;
+    } else {
+        (void)hipGetLastError();
+    }
+    return kOk;
+}
+
+int HipFrameInterpolator::interpolate_device(const void *d_a, size_t a_stride, const void *d_b, size_t b_stride,
+                                             const void *d_flow, uint32_t w, uint32_t h, float t, void *d_out,
+                                             uint32_t n_pairs, hipStream_t stream)
+{
+    std::lock_guard<std::mutex> lk(mu_);
+    if (w == 0 || h == 0 || (uint64_t)w * h >= (1ull << 31)) return fail(kInvalidArgument, "interpolate_device: bad dimensions");
+    if (!d_a || !d_b || !d_out) return fail(kInvalidArgument, "interpolate_device: null device pointer");
+    if (n_pairs == 0) return kOk;
+    if ((reinterpret_cast<uintptr_t>(d_a) % 4) || (reinterpret_cast<uintptr_t>(d_b) % 4) ||
+        (reinterpret_cast<uintptr_t>(d_out) % 4) || (a_stride % 4) || (b_stride % 4) ||
+        (d_flow && reinterpret_cast<uintptr_t>(d_flow) % 8))
+        return fail(kInvalidArgument, "interpolate_device: pointers/strides must be pixel aligned");
+    const int n = device_count();
+    if (n <= 0) return fail(kNoDevice, "no HIP device available (the gfx950 path has no CPU fallback)");
+    NUS_HIP(hipSetDevice(device_));
+    WarpLaunch L;
+    L.a = static_cast<const uint8_t *>(d_a);
+    L.b = static_cast<const uint8_t *>(d_b);
+    L.flow = static_cast<const float *>(d_flow);
+    L.out = static_cast<uint8_t *>(d_out);
+    L.a_stride = a_stride;
+    L.b_stride = b_stride;
+    L.w = w;
+    L.h = h;
+    L.t = t;
+    L.n_pairs = n_pairs;
+    L.stream = stream;
+    hipError_t e = launch_warp_blend(L);
+    if (e != hipSuccess) return fail_hip(e, "warp+blend launch");
+    return kOk;
+}
+
+bool HipFrameInterpolator::last_gpu_ms(double *ms) const
+{
+    std::lock_guard<std::mutex> lk(mu_);
+    if (!have_ms_) return false;
+    if (ms) *ms = last_ms_;
+    return true;
+}
+
+} // namespace nus

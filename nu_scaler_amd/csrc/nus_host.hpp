@@ -1,0 +1,185 @@
+// nus_host.hpp -- C++ host side above the kernels, mirroring the reference's Rust
+// interfaces for this path (the Rust toolchain is absent in the build image, so the
+// host layer the north star asks for in Rust is written in C++; INTEGRATION.md shows
+// the Rust shim that binds the C ABI on top of it).
+//
+//   nus::Upscaler          <-> trait Upscaler            nu_scaler_core/src/upscale/mod.rs:67-88
+//   nus::HipUpscaler       <-> WgpuUpscaler              nu_scaler_core/src/upscale/mod.rs:266-1086
+//   nus::UpscalerFactory   <-> UpscalerFactory           nu_scaler_core/src/upscale/mod.rs:91-117
+//   nus::FrameInterpolator <-> trait FrameInterpolator   nu_scaler_core/src/interpolation/mod.rs:29-44
+//   nus::HipFrameInterpolator <-> WgpuFrameInterpolator  nu_scaler_core/src/wgpu_interpolator.rs:130-498
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "nus_kernels.hpp"
+#include "nus_tables.hpp"
+
+namespace nus {
+
+// nus_status values (kept in sync with include/nuscaler_hip.h).
+enum Status : int {
+    kOk = 0,
+    kInvalidArgument = -1,
+    kNotInitialized = -2,
+    kSizeMismatch = -3,
+    kHipError = -4,
+    kNoDevice = -5,
+    kUnsupported = -6,
+    kOutOfMemory = -7,
+};
+
+enum class Algorithm : int { Nearest = 0, Bilinear = 1, Lanczos3 = 2 };
+enum class Quality : int { UltraPerformance = 0, Ultra, Quality, Balanced, Performance, Native };
+enum class Technology : int { None = 0, FSR, DLSS, Wgpu, Fallback };
+
+void set_thread_error(const std::string &msg);
+const char *thread_error();
+
+// trait Upscaler (upscale/mod.rs:67-88).  Result<()> becomes a Status + last_error().
+class Upscaler {
+public:
+    virtual ~Upscaler() = default;
+    virtual int initialize(uint32_t in_w, uint32_t in_h, uint32_t out_w, uint32_t out_h) = 0;
+    virtual int upscale(const uint8_t *in, size_t in_len, uint8_t *out, size_t out_cap) = 0;
+    virtual const char *name() const = 0;
+    virtual Quality quality() const = 0;
+    virtual int set_quality(Quality q) = 0;
+    virtual const char *last_error() const = 0;
+};
+
+class HipUpscaler final : public Upscaler {
+public:
+    HipUpscaler(Quality q, Algorithm a);
+    ~HipUpscaler() override;
+    HipUpscaler(const HipUpscaler &) = delete;
+    HipUpscaler &operator=(const HipUpscaler &) = delete;
+
+    int initialize(uint32_t in_w, uint32_t in_h, uint32_t out_w, uint32_t out_h) override;
+    int upscale(const uint8_t *in, size_t in_len, uint8_t *out, size_t out_cap) override;
+    const char *name() const override;
+    Quality quality() const override { return quality_; }
+    int set_quality(Quality q) override;
+    const char *last_error() const override { return error_.c_str(); }
+
+    // upscale_batch (upscale/mod.rs:609-640): H2D / kernel / D2H pipelined over slots.
+    int upscale_batch(const uint8_t *const *ins, const size_t *in_lens, size_t n, uint8_t *const *outs,
+                      size_t out_cap_each);
+    // frames already resident in HBM; enqueue only.
+    int upscale_device(const void *d_in, void *d_out, uint32_t n_frames, hipStream_t stream);
+
+    int set_device(int device);
+    int set_bilinear_variant(int variant);
+    int set_lanczos_mode(int mode);
+    int set_option(const char *key, int64_t value);
+
+    Algorithm algorithm() const { return algorithm_; }
+    bool initialized() const { return initialized_; }
+    size_t input_size() const { return initialized_ ? (size_t)iw_ * ih_ * 4 : 0; }
+    size_t output_size() const { return initialized_ ? (size_t)ow_ * oh_ * 4 : 0; }
+    bool last_gpu_ms(double *ms) const;
+    const char *kernel_variant() const { return variant_name(variant_); }
+
+    int64_t export_tables(void *buf, size_t cap) const;
+    int import_tables(const void *buf, size_t len);
+
+private:
+    static constexpr int kSlots = 3; // buffer_pool_size default (upscale/mod.rs:287-289)
+    struct Slot {
+        uint8_t *d_in = nullptr, *d_out = nullptr; // HBM
+        uint8_t *h_in = nullptr, *h_out = nullptr; // pinned staging
+        hipStream_t stream = nullptr;
+        hipEvent_t k_begin = nullptr, k_end = nullptr;
+    };
+
+    int fail(int status, const std::string &msg);
+    int fail_hip(hipError_t e, const char *what);
+    int ensure_device();
+    void release();
+    int upload_tables();
+    void choose_variant();
+    int enqueue(const uint8_t *d_in, uint8_t *d_out, uint32_t n_frames, hipStream_t stream);
+
+    mutable std::mutex mu_;
+    Quality quality_;
+    Algorithm algorithm_;
+    int device_ = 0;
+    bool wgsl_bilinear_ = false;
+    bool lanczos_exact_ = false;
+    bool force_general_ = false;
+    uint32_t rows_per_wave_ = 0; // 0: pick from the batch size
+    bool initialized_ = false;
+    uint32_t iw_ = 0, ih_ = 0, ow_ = 0, oh_ = 0;
+    Variant variant_ = Variant::NearestTable;
+    AxisTables tx_, ty_;
+    std::vector<float> wy6_, wx6_;
+    DeviceTables dt_;
+    std::vector<void *> table_allocs_;
+    Slot slots_[kSlots];
+    bool have_ms_ = false;
+    double last_ms_ = 0.0;
+    std::string error_;
+};
+
+// UpscalerFactory::create_upscaler (upscale/mod.rs:95-117).
+struct UpscalerFactory {
+    static std::unique_ptr<HipUpscaler> create_upscaler(Technology tech, Quality q);
+};
+
+// trait FrameInterpolator shape (interpolation/mod.rs:29-44).
+class FrameInterpolator {
+public:
+    virtual ~FrameInterpolator() = default;
+    virtual int interpolate(const uint8_t *a, size_t a_len, const uint8_t *b, size_t b_len, const float *flow,
+                            uint32_t w, uint32_t h, float t, uint8_t *out, size_t out_cap) = 0;
+    virtual const char *name() const = 0;
+    virtual const char *last_error() const = 0;
+};
+
+class HipFrameInterpolator final : public FrameInterpolator {
+public:
+    explicit HipFrameInterpolator(int wg_preset);
+    ~HipFrameInterpolator() override;
+    HipFrameInterpolator(const HipFrameInterpolator &) = delete;
+    HipFrameInterpolator &operator=(const HipFrameInterpolator &) = delete;
+
+    int interpolate(const uint8_t *a, size_t a_len, const uint8_t *b, size_t b_len, const float *flow, uint32_t w,
+                    uint32_t h, float t, uint8_t *out, size_t out_cap) override;
+    int interpolate_device(const void *d_a, size_t a_stride, const void *d_b, size_t b_stride, const void *d_flow,
+                           uint32_t w, uint32_t h, float t, void *d_out, uint32_t n_pairs, hipStream_t stream);
+    const char *name() const override { return "HipWarpBlendInterpolator"; }
+    const char *last_error() const override { return error_.c_str(); }
+    int set_device(int device);
+    bool last_gpu_ms(double *ms) const;
+    int wg_preset() const { return wg_preset_; }
+
+private:
+    int fail(int status, const std::string &msg);
+    int fail_hip(hipError_t e, const char *what);
+    int ensure(size_t frame_bytes, bool with_flow);
+    void release();
+
+    mutable std::mutex mu_;
+    int wg_preset_;
+    int device_ = 0;
+    bool device_ready_ = false;
+    size_t cap_bytes_ = 0;
+    bool cap_flow_ = false;
+    uint8_t *d_a_ = nullptr, *d_b_ = nullptr, *d_out_ = nullptr;
+    float *d_flow_ = nullptr;
+    uint8_t *h_stage_ = nullptr; // pinned: a | b | out
+    float *h_flow_ = nullptr;    // pinned
+    hipStream_t stream_ = nullptr;
+    hipEvent_t k_begin_ = nullptr, k_end_ = nullptr;
+    bool have_ms_ = false;
+    double last_ms_ = 0.0;
+    std::string error_;
+};
+
+} // namespace nus

@@ -1,0 +1,702 @@
+// nus_kernels.hip -- gfx950 (CDNA4, wave64) kernels for the NU_Scaler hot path:
+// nearest / bilinear / Lanczos-3 upscaling and two-frame warp + blend on RGBA8 frames.
+//
+// Reference arithmetic being reproduced (paths relative to the reference checkout):
+//   nearest    nu_scaler_core/src/upscale/mod.rs:184-206 == Nu_scale/src/upscale/common.rs:188-198
+//   bilinear   Nu_scale/src/upscale/common.rs:199-231 (CPU form, the oracle);
+//              nu_scaler_core/src/upscale/mod.rs:209-263 (WGSL form, optional variant)
+//   lanczos3   image-0.24.9 imageops::resize as called at Nu_scale/src/upscale/common.rs:243-251
+//   warp+blend nu_scaler_core/src/shaders/warp_blend.wgsl:18-47 (geometry),
+//              nu_scaler_core/src/interpolation/mod.rs:386-411, :467-510 (rounding)
+//
+// All f32 arithmetic that must match the CPU oracle bit for bit is written with
+// separate multiplies and adds; the whole file is compiled with -ffp-contract=off and
+// fused multiply-adds appear only where spelled __builtin_fmaf (Lanczos FMA mode).
+// No MFMA: no stage is a dense contraction.  Pixels are moved as one u32 each,
+// 16 bytes per lane per access wherever alignment allows.
+#include "nus_kernels.hpp"
+
+#pragma clang fp contract(off)
+
+namespace nus {
+
+namespace {
+
+constexpr int kWave = 64;
+
+__device__ __forceinline__ float ch_f32(uint32_t p, int c)
+{
+    return (float)((p >> (8 * c)) & 0xffu); // v_cvt_f32_ubyteN
+}
+
+// Rust `clamp(0,255) as u8` / `as u8`: truncate toward zero, saturate, NaN -> 0.
+__device__ __forceinline__ uint32_t trunc_u8(float v)
+{
+    return (uint32_t)fminf(fmaxf(v, 0.0f), 255.0f);
+}
+
+// f32::round (half away from zero) of a value clamped to [0,255].
+__device__ __forceinline__ uint32_t round_u8_exact(float v)
+{
+    float c = fminf(fmaxf(v, 0.0f), 255.0f);
+    float r = truncf(c);
+    if (c - r >= 0.5f) r += 1.0f;
+    return (uint32_t)r;
+}
+
+// Same for every input except the single float just below 0.5 (0.5 - 2^-25), where
+// the addition rounds up; within the +-1 LSB contract of the FMA mode.
+__device__ __forceinline__ uint32_t round_u8_fast(float v)
+{
+    return (uint32_t)(__builtin_amdgcn_fmed3f(v, 0.0f, 255.0f) + 0.5f);
+}
+
+template <bool EXACT>
+__device__ __forceinline__ float mac(float acc, float v, float w)
+{
+    if (EXACT) return acc + v * w;   // two roundings, as the CPU restatement
+    return __builtin_fmaf(v, w, acc); // one rounding
+}
+
+template <bool EXACT>
+__device__ __forceinline__ uint32_t round_u8(float v)
+{
+    return EXACT ? round_u8_exact(v) : round_u8_fast(v);
+}
+
+__device__ __forceinline__ uint32_t umin(uint32_t a, uint32_t b) { return a < b ? a : b; }
+
+// ---------------------------------------------------------------------------------
+// Nearest
+// ---------------------------------------------------------------------------------
+
+// Any scale.  blockDim = (64, 4): one wave per 256-px (VEC) or 64-px row segment.
+template <bool VEC>
+__global__ __launch_bounds__(256) void k_nearest_table(
+    const uint32_t *__restrict__ in, uint32_t *__restrict__ out,
+    const uint32_t *__restrict__ sx, const uint32_t *__restrict__ sy,
+    uint32_t iw, uint32_t ow, uint32_t oh, size_t in_frame_px, size_t out_frame_px)
+{
+    const uint32_t y = __builtin_amdgcn_readfirstlane(blockIdx.y * 4 + threadIdx.y);
+    if (y >= oh) return;
+    const uint32_t *src = in + (size_t)blockIdx.z * in_frame_px + (size_t)sy[y] * iw;
+    uint32_t *dst = out + (size_t)blockIdx.z * out_frame_px + (size_t)y * ow;
+    if (VEC) {
+        const uint32_t x = (blockIdx.x * kWave + threadIdx.x) * 4;
+        if (x >= ow) return;
+        const uint4 s = *reinterpret_cast<const uint4 *>(sx + x);
+        uint4 o;
+        o.x = src[s.x];
+        o.y = src[s.y];
+        o.z = src[s.z];
+        o.w = src[s.w];
+        *reinterpret_cast<uint4 *>(dst + x) = o;
+    } else {
+        const uint32_t x = blockIdx.x * kWave + threadIdx.x;
+        if (x < ow) dst[x] = src[sx[x]];
+    }
+}
+
+// Exact x2 (ow == 2*iw, oh == 2*ih, iw % 4 == 0): each lane reads 4 input pixels
+// (16 B) and writes the 2x2 replication as four 16-B stores.
+__global__ __launch_bounds__(256) void k_nearest_x2(
+    const uint32_t *__restrict__ in, uint32_t *__restrict__ out,
+    uint32_t iw, uint32_t ih, size_t in_frame_px, size_t out_frame_px)
+{
+    const uint32_t r = __builtin_amdgcn_readfirstlane(blockIdx.y * 4 + threadIdx.y);
+    const uint32_t k = (blockIdx.x * kWave + threadIdx.x) * 4;
+    if (r >= ih || k >= iw) return;
+    const uint32_t ow = iw * 2;
+    const uint4 p = *reinterpret_cast<const uint4 *>(in + (size_t)blockIdx.z * in_frame_px + (size_t)r * iw + k);
+    const uint4 o0 = make_uint4(p.x, p.x, p.y, p.y);
+    const uint4 o1 = make_uint4(p.z, p.z, p.w, p.w);
+    uint32_t *d = out + (size_t)blockIdx.z * out_frame_px + (size_t)(2 * r) * ow + 2 * k;
+    *reinterpret_cast<uint4 *>(d) = o0;
+    *reinterpret_cast<uint4 *>(d + 4) = o1;
+    *reinterpret_cast<uint4 *>(d + ow) = o0;
+    *reinterpret_cast<uint4 *>(d + ow + 4) = o1;
+}
+
+// ---------------------------------------------------------------------------------
+// Bilinear
+// ---------------------------------------------------------------------------------
+
+// CPU form: Nu_scale/src/upscale/common.rs:221-226.
+__device__ __forceinline__ uint32_t bilerp_cpu(uint32_t p00, uint32_t p10, uint32_t p01, uint32_t p11,
+                                               float dx, float dy)
+{
+    const float ndx = 1.0f - dx, ndy = 1.0f - dy;
+    uint32_t o = 0;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const float top = ch_f32(p00, c) * ndx + ch_f32(p10, c) * dx;
+        const float bottom = ch_f32(p01, c) * ndx + ch_f32(p11, c) * dx;
+        const float value = top * ndy + bottom * dy;
+        o |= trunc_u8(value) << (8 * c);
+    }
+    return o;
+}
+
+// WGSL form: nu_scaler_core/src/upscale/mod.rs:220-234, :255-261.
+__device__ __forceinline__ uint32_t bilerp_wgsl(uint32_t p00, uint32_t p10, uint32_t p01, uint32_t p11,
+                                                float dx, float dy)
+{
+    const float ndx = 1.0f - dx, ndy = 1.0f - dy;
+    uint32_t o = 0;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const float c00 = ch_f32(p00, c) / 255.0f, c10 = ch_f32(p10, c) / 255.0f;
+        const float c01 = ch_f32(p01, c) / 255.0f, c11 = ch_f32(p11, c) / 255.0f;
+        const float c0 = c00 * ndx + c10 * dx;
+        const float c1 = c01 * ndx + c11 * dx;
+        const float v = c0 * ndy + c1 * dy;
+        o |= (uint32_t)(fminf(fmaxf(v, 0.0f), 1.0f) * 255.0f) << (8 * c);
+    }
+    return o;
+}
+
+// Any scale; coordinates come from host-built tables so no division runs here and
+// the index / fraction values are exactly the CPU's.  blockDim = (64, 4).
+template <bool VEC, bool WGSL>
+__global__ __launch_bounds__(256) void k_bilinear_table(
+    const uint32_t *__restrict__ in, uint32_t *__restrict__ out,
+    const uint32_t *__restrict__ x0t, const float *__restrict__ fxt,
+    const uint32_t *__restrict__ y0t, const float *__restrict__ fyt,
+    uint32_t iw, uint32_t ih, uint32_t ow, uint32_t oh, size_t in_frame_px, size_t out_frame_px)
+{
+    const uint32_t y = __builtin_amdgcn_readfirstlane(blockIdx.y * 4 + threadIdx.y);
+    if (y >= oh) return;
+    const uint32_t y0 = y0t[y];
+    const uint32_t y1 = umin(y0 + 1, ih - 1);
+    const float dy = fyt[y];
+    const uint32_t *base = in + (size_t)blockIdx.z * in_frame_px;
+    const uint32_t *row0 = base + (size_t)y0 * iw;
+    const uint32_t *row1 = base + (size_t)y1 * iw;
+    uint32_t *dst = out + (size_t)blockIdx.z * out_frame_px + (size_t)y * ow;
+    constexpr int N = VEC ? 4 : 1;
+    const uint32_t x = (blockIdx.x * kWave + threadIdx.x) * N;
+    if (x >= ow) return;
+    uint32_t xi[N];
+    float xf[N];
+    if (VEC) {
+        const uint4 a = *reinterpret_cast<const uint4 *>(x0t + x);
+        const float4 f = *reinterpret_cast<const float4 *>(fxt + x);
+        xi[0] = a.x; xi[N > 1 ? 1 : 0] = a.y; xi[N > 2 ? 2 : 0] = a.z; xi[N > 3 ? 3 : 0] = a.w;
+        xf[0] = f.x; xf[N > 1 ? 1 : 0] = f.y; xf[N > 2 ? 2 : 0] = f.z; xf[N > 3 ? 3 : 0] = f.w;
+    } else {
+        xi[0] = x0t[x];
+        xf[0] = fxt[x];
+    }
+    uint32_t o[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        const uint32_t x0 = xi[i];
+        const uint32_t x1 = umin(x0 + 1, iw - 1);
+        const uint32_t p00 = row0[x0], p10 = row0[x1], p01 = row1[x0], p11 = row1[x1];
+        o[i] = WGSL ? bilerp_wgsl(p00, p10, p01, p11, xf[i], dy) : bilerp_cpu(p00, p10, p01, p11, xf[i], dy);
+    }
+    if (VEC)
+        *reinterpret_cast<uint4 *>(dst + x) = make_uint4(o[0], o[N > 1 ? 1 : 0], o[N > 2 ? 2 : 0], o[N > 3 ? 3 : 0]);
+    else
+        dst[x] = o[0];
+}
+
+// floor((a+b)/2) per byte: v_lerp_u8 with rounding bits 0.
+__device__ __forceinline__ uint32_t avg2_u8x4(uint32_t a, uint32_t b)
+{
+    return __builtin_amdgcn_lerp(a, b, 0u);
+}
+
+// floor((a+b+c+d)/4) per byte, exact: with l1 = floor((a+b)/2), l2 = floor((c+d)/2) the
+// lost half-units are the low bits of a^b and c^d; both set adds one unit to l1+l2.
+__device__ __forceinline__ uint32_t avg4_u8x4(uint32_t a, uint32_t b, uint32_t c, uint32_t d)
+{
+    const uint32_t l1 = __builtin_amdgcn_lerp(a, b, 0u);
+    const uint32_t l2 = __builtin_amdgcn_lerp(c, d, 0u);
+    return __builtin_amdgcn_lerp(l1, l2, (a ^ b) & (c ^ d));
+}
+
+// Exact x2, CPU arithmetic.  At x2 the fractions are 0 or 0.5, every product and sum
+// of common.rs:221-226 is exact in f32 and the truncation is a floor of a quarter
+// multiple, so the result equals these packed-u8 integer averages byte for byte
+// (requires (ow-1)*iw < 2^24 so that x*iw/ow is exact; checked by the host).
+// Each lane: 4 input pixels of rows r and r+1 -> 8x2 output pixels.
+__global__ __launch_bounds__(256) void k_bilinear_x2_int(
+    const uint32_t *__restrict__ in, uint32_t *__restrict__ out,
+    uint32_t iw, uint32_t ih, size_t in_frame_px, size_t out_frame_px)
+{
+    const uint32_t r = __builtin_amdgcn_readfirstlane(blockIdx.y * 4 + threadIdx.y);
+    const uint32_t k = (blockIdx.x * kWave + threadIdx.x) * 4;
+    if (r >= ih || k >= iw) return;
+    const uint32_t ow = iw * 2;
+    const uint32_t r1 = umin(r + 1, ih - 1);
+    const uint32_t k4 = umin(k + 4, iw - 1);
+    const uint32_t *base = in + (size_t)blockIdx.z * in_frame_px;
+    const uint32_t *rowp = base + (size_t)r * iw;
+    const uint32_t *rowq = base + (size_t)r1 * iw;
+    const uint4 pv = *reinterpret_cast<const uint4 *>(rowp + k);
+    const uint4 qv = *reinterpret_cast<const uint4 *>(rowq + k);
+    const uint32_t p[5] = {pv.x, pv.y, pv.z, pv.w, rowp[k4]};
+    const uint32_t q[5] = {qv.x, qv.y, qv.z, qv.w, rowq[k4]};
+    uint32_t top[8], bot[8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        top[2 * i] = p[i];
+        top[2 * i + 1] = avg2_u8x4(p[i], p[i + 1]);
+        bot[2 * i] = avg2_u8x4(p[i], q[i]);
+        bot[2 * i + 1] = avg4_u8x4(p[i], p[i + 1], q[i], q[i + 1]);
+    }
+    uint32_t *d = out + (size_t)blockIdx.z * out_frame_px + (size_t)(2 * r) * ow + 2 * k;
+    *reinterpret_cast<uint4 *>(d) = make_uint4(top[0], top[1], top[2], top[3]);
+    *reinterpret_cast<uint4 *>(d + 4) = make_uint4(top[4], top[5], top[6], top[7]);
+    *reinterpret_cast<uint4 *>(d + ow) = make_uint4(bot[0], bot[1], bot[2], bot[3]);
+    *reinterpret_cast<uint4 *>(d + ow + 4) = make_uint4(bot[4], bot[5], bot[6], bot[7]);
+}
+
+// ---------------------------------------------------------------------------------
+// Lanczos-3 (image-0.24.9 resize: vertical pass into f32, then horizontal pass)
+// ---------------------------------------------------------------------------------
+
+// Any scale, one output pixel per thread: for every horizontal tap column the vertical
+// sum is formed first (f32, tap order ascending), then the horizontal sum, exactly the
+// operation order of the two-pass CPU algorithm.  Also used for the first/last
+// `edge_cols` output columns next to the x2 kernel, whose interior weights do not
+// apply there.  blockDim = (64, 4).
+template <bool EXACT>
+__global__ __launch_bounds__(256) void k_lanczos_general(
+    const uint32_t *__restrict__ in, uint32_t *__restrict__ out,
+    const int32_t *__restrict__ lxt, const uint32_t *__restrict__ nxt, const float *__restrict__ wxt,
+    const int32_t *__restrict__ lyt, const uint32_t *__restrict__ nyt, const float *__restrict__ wyt,
+    uint32_t stride, uint32_t iw, uint32_t ow, uint32_t oh, uint32_t ncols, uint32_t split, uint32_t gap,
+    size_t in_frame_px, size_t out_frame_px)
+{
+    const uint32_t y = __builtin_amdgcn_readfirstlane(blockIdx.y * 4 + threadIdx.y);
+    const uint32_t i = blockIdx.x * kWave + threadIdx.x;
+    if (y >= oh || i >= ncols) return;
+    const uint32_t x = i < split ? i : i + gap;
+    const int32_t lx = lxt[x];
+    const uint32_t nx = nxt[x];
+    const int32_t ly = lyt[y];
+    const uint32_t ny = nyt[y];
+    const float *wx = wxt + (size_t)x * stride;
+    const float *wy = wyt + (size_t)y * stride;
+    const uint32_t *src = in + (size_t)blockIdx.z * in_frame_px + (size_t)ly * iw + lx;
+    float h0 = 0.0f, h1 = 0.0f, h2 = 0.0f, h3 = 0.0f;
+    for (uint32_t a = 0; a < nx; ++a) {
+        float v0 = 0.0f, v1 = 0.0f, v2 = 0.0f, v3 = 0.0f;
+        for (uint32_t b = 0; b < ny; ++b) {
+            const uint32_t p = src[(size_t)b * iw + a];
+            const float w = wy[b];
+            v0 = mac<EXACT>(v0, ch_f32(p, 0), w);
+            v1 = mac<EXACT>(v1, ch_f32(p, 1), w);
+            v2 = mac<EXACT>(v2, ch_f32(p, 2), w);
+            v3 = mac<EXACT>(v3, ch_f32(p, 3), w);
+        }
+        const float w = wx[a];
+        h0 = mac<EXACT>(h0, v0, w);
+        h1 = mac<EXACT>(h1, v1, w);
+        h2 = mac<EXACT>(h2, v2, w);
+        h3 = mac<EXACT>(h3, v3, w);
+    }
+    out[(size_t)blockIdx.z * out_frame_px + (size_t)y * ow + x] =
+        round_u8<EXACT>(h0) | (round_u8<EXACT>(h1) << 8) | (round_u8<EXACT>(h2) << 16) | (round_u8<EXACT>(h3) << 24);
+}
+
+struct LanczosX2Args {
+    const uint8_t *in;
+    uint8_t *out;
+    const float *wy6; // [oh][6], phase frame: even row 2r taps rows r-3..r+2, odd row 2r+1 taps r-2..r+3
+    float wxe[6];     // interior horizontal weights, even output 2k: columns k-3..k+2
+    float wxo[6];     // odd output 2k+1: columns k-2..k+3
+    uint32_t iw, ih;
+    uint32_t nstrips, nrowblocks, th;
+    size_t in_frame_bytes, out_frame_bytes;
+};
+
+__device__ __forceinline__ float lane_up(float v) // value of lane-1
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138 /*wave_shr:1*/, 0xF, 0xF, false));
+}
+__device__ __forceinline__ float lane_down(float v) // value of lane+1
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x130 /*wave_shl:1*/, 0xF, 0xF, false));
+}
+
+__device__ __forceinline__ void cvt_row(const uint4 raw, float (&dst)[16])
+{
+    const uint32_t px[4] = {raw.x, raw.y, raw.z, raw.w};
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) dst[m * 4 + c] = ch_f32(px[m], c);
+}
+
+// One output row (phase 0: row 2r from window slots S..S+5; phase 1: row 2r+1 from
+// slots S+1..S+6) of the lane's 8 output pixels.
+template <bool EXACT, int S, int PHASE>
+__device__ __forceinline__ void lanczos_x2_row(const float (&win)[7][16], const float *__restrict__ wv,
+                                               const LanczosX2Args &A, uint32_t *dst, bool do_store)
+{
+    float V[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        float acc = win[(S + PHASE) % 7][k] * wv[0];
+#pragma unroll
+        for (int j = 1; j < 6; ++j) acc = mac<EXACT>(acc, win[(S + PHASE + j) % 7][k], wv[j]);
+        V[k] = acc;
+    }
+    uint32_t o[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        float e[10]; // vertical sums of input columns c0-3 .. c0+6 for this channel
+        e[0] = lane_up(V[1 * 4 + c]);
+        e[1] = lane_up(V[2 * 4 + c]);
+        e[2] = lane_up(V[3 * 4 + c]);
+        e[3] = V[0 * 4 + c];
+        e[4] = V[1 * 4 + c];
+        e[5] = V[2 * 4 + c];
+        e[6] = V[3 * 4 + c];
+        e[7] = lane_down(V[0 * 4 + c]);
+        e[8] = lane_down(V[1 * 4 + c]);
+        e[9] = lane_down(V[2 * 4 + c]);
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            float ae = e[m] * A.wxe[0];
+            float ao = e[m + 1] * A.wxo[0];
+#pragma unroll
+            for (int j = 1; j < 6; ++j) {
+                ae = mac<EXACT>(ae, e[m + j], A.wxe[j]);
+                ao = mac<EXACT>(ao, e[m + 1 + j], A.wxo[j]);
+            }
+            o[2 * m] |= round_u8<EXACT>(ae) << (8 * c);
+            o[2 * m + 1] |= round_u8<EXACT>(ao) << (8 * c);
+        }
+    }
+    if (do_store) {
+        *reinterpret_cast<uint4 *>(dst) = make_uint4(o[0], o[1], o[2], o[3]);
+        *reinterpret_cast<uint4 *>(dst + 4) = make_uint4(o[4], o[5], o[6], o[7]);
+    }
+}
+
+template <bool EXACT, int S>
+__device__ __forceinline__ void lanczos_x2_step(float (&win)[7][16], uint4 &raw, int r, int c, int cl,
+                                                bool do_store, const LanczosX2Args &A,
+                                                const uint8_t *src, uint8_t *dstf)
+{
+    const uint32_t ow = A.iw * 2;
+    uint32_t *d0 = reinterpret_cast<uint32_t *>(dstf) + (size_t)(2 * r) * ow + 2 * c;
+    lanczos_x2_row<EXACT, S, 0>(win, A.wy6 + (size_t)(2 * r) * 6, A, d0, do_store);
+    lanczos_x2_row<EXACT, S, 1>(win, A.wy6 + (size_t)(2 * r + 1) * 6, A, d0 + ow, do_store);
+    // input row r-3 (slot S) is dead: replace it by row r+4, then fetch row r+5.
+    cvt_row(raw, win[S % 7]);
+    int rn = r + 5;
+    rn = rn < (int)A.ih - 1 ? rn : (int)A.ih - 1;
+    raw = *reinterpret_cast<const uint4 *>(src + ((size_t)rn * A.iw + cl) * 4);
+}
+
+// Exact x2 Lanczos-3.  One wave owns a strip of 256 input columns (4 per lane; lanes 0
+// and 63 are halo lanes, lanes 1..62 produce 248 input = 496 output columns) and walks
+// `th` input rows, keeping a 7-row f32 window of its columns in registers:
+//   vertical pass  : 6 taps from the register window (weights wave-uniform, in SGPRs)
+//   horizontal pass: 6 taps over the lane's own 4 columns + 3 columns from each
+//                    neighbouring lane, fetched with wave_shr/wave_shl DPP moves
+// so every input byte is read once per strip-row-block and no LDS round trip or
+// barrier is needed.  Output: 2 x 16-B stores per lane per output row (2 KiB per wave).
+// The 8 left-most and right-most output columns (renormalised edge weights) are left
+// to k_lanczos_general.
+template <bool EXACT>
+__global__ __launch_bounds__(256) void k_lanczos3_x2(const LanczosX2Args A)
+{
+    const int lane = threadIdx.x & (kWave - 1);
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+    if (wave >= A.nstrips * A.nrowblocks) return;
+    const uint32_t strip = wave % A.nstrips;
+    const uint32_t rb = wave / A.nstrips;
+    const int c = (int)(strip * kLanczosX2StripCols) - 4 + lane * 4; // first input column of this lane
+    int cl = c < 0 ? 0 : c;
+    cl = cl > (int)A.iw - 4 ? (int)A.iw - 4 : cl;
+    const bool do_store = lane >= 1 && lane <= 62 && c >= 4 && c + 8 <= (int)A.iw;
+    const uint8_t *src = A.in + (size_t)blockIdx.y * A.in_frame_bytes;
+    uint8_t *dstf = A.out + (size_t)blockIdx.y * A.out_frame_bytes;
+    const int r0 = (int)(rb * A.th);
+    const int r_end = (r0 + (int)A.th) < (int)A.ih ? (r0 + (int)A.th) : (int)A.ih;
+    const int rmax = (int)A.ih - 1;
+
+    float win[7][16];
+#pragma unroll
+    for (int j = 0; j < 7; ++j) {
+        int rr = r0 - 3 + j;
+        rr = rr < 0 ? 0 : (rr > rmax ? rmax : rr);
+        cvt_row(*reinterpret_cast<const uint4 *>(src + ((size_t)rr * A.iw + cl) * 4), win[j]);
+    }
+    uint4 raw;
+    {
+        int rr = r0 + 4;
+        rr = rr > rmax ? rmax : rr;
+        raw = *reinterpret_cast<const uint4 *>(src + ((size_t)rr * A.iw + cl) * 4);
+    }
+    for (int rbase = r0; rbase < r_end; rbase += 7) {
+        // 7-way unrolled so the rotating window indices are compile-time constants.
+        if (rbase + 0 < r_end) lanczos_x2_step<EXACT, 0>(win, raw, rbase + 0, c, cl, do_store, A, src, dstf);
+        if (rbase + 1 < r_end) lanczos_x2_step<EXACT, 1>(win, raw, rbase + 1, c, cl, do_store, A, src, dstf);
+        if (rbase + 2 < r_end) lanczos_x2_step<EXACT, 2>(win, raw, rbase + 2, c, cl, do_store, A, src, dstf);
+        if (rbase + 3 < r_end) lanczos_x2_step<EXACT, 3>(win, raw, rbase + 3, c, cl, do_store, A, src, dstf);
+        if (rbase + 4 < r_end) lanczos_x2_step<EXACT, 4>(win, raw, rbase + 4, c, cl, do_store, A, src, dstf);
+        if (rbase + 5 < r_end) lanczos_x2_step<EXACT, 5>(win, raw, rbase + 5, c, cl, do_store, A, src, dstf);
+        if (rbase + 6 < r_end) lanczos_x2_step<EXACT, 6>(win, raw, rbase + 6, c, cl, do_store, A, src, dstf);
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// Warp + blend
+// ---------------------------------------------------------------------------------
+
+// Zero flow (the live reference behaviour, wgpu_interpolator.rs:275-295): sample
+// positions are the pixel centres, so the bilinear samples are the pixels themselves
+// and the kernel is a streaming blend, 4 pixels (16 B) per lane.
+__device__ __forceinline__ uint32_t blend_px(uint32_t a, uint32_t b, float t, float nt)
+{
+    uint32_t o = 0;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) o |= trunc_u8(nt * ch_f32(a, c) + t * ch_f32(b, c)) << (8 * c);
+    return o;
+}
+
+template <bool VEC>
+__global__ __launch_bounds__(256) void k_blend_zero_flow(
+    const uint8_t *__restrict__ a, const uint8_t *__restrict__ b, uint8_t *__restrict__ out,
+    size_t a_stride, size_t b_stride, size_t npx, float t)
+{
+    const float nt = 1.0f - t;
+    const uint32_t *pa = reinterpret_cast<const uint32_t *>(a + (size_t)blockIdx.y * a_stride);
+    const uint32_t *pb = reinterpret_cast<const uint32_t *>(b + (size_t)blockIdx.y * b_stride);
+    uint32_t *po = reinterpret_cast<uint32_t *>(out) + (size_t)blockIdx.y * npx;
+    const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * (VEC ? 4 : 1);
+    if (i >= npx) return;
+    if (VEC) {
+        const uint4 va = *reinterpret_cast<const uint4 *>(pa + i);
+        const uint4 vb = *reinterpret_cast<const uint4 *>(pb + i);
+        *reinterpret_cast<uint4 *>(po + i) = make_uint4(blend_px(va.x, vb.x, t, nt), blend_px(va.y, vb.y, t, nt),
+                                                        blend_px(va.z, vb.z, t, nt), blend_px(va.w, vb.w, t, nt));
+    } else {
+        po[i] = blend_px(pa[i], pb[i], t, nt);
+    }
+}
+
+// interpolation/mod.rs:467-510: clamp, bilinear, truncate to u8.
+__device__ __forceinline__ uint32_t sample_trunc(const uint32_t *__restrict__ f, uint32_t w, uint32_t h,
+                                                 float x, float y)
+{
+    x = fminf(fmaxf(x, 0.0f), (float)(w - 1));
+    y = fminf(fmaxf(y, 0.0f), (float)(h - 1));
+    const float xfl = floorf(x), yfl = floorf(y);
+    const uint32_t x0 = (uint32_t)xfl, y0 = (uint32_t)yfl;
+    const uint32_t x1 = umin(x0 + 1, w - 1), y1 = umin(y0 + 1, h - 1);
+    const float xf = x - xfl, yf = y - yfl;
+    const float nxf = 1.0f - xf, nyf = 1.0f - yf;
+    const uint32_t p00 = f[(size_t)y0 * w + x0], p01 = f[(size_t)y0 * w + x1];
+    const uint32_t p10 = f[(size_t)y1 * w + x0], p11 = f[(size_t)y1 * w + x1];
+    uint32_t o = 0;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const float top = ch_f32(p00, c) * nxf + ch_f32(p01, c) * xf;
+        const float bottom = ch_f32(p10, c) * nxf + ch_f32(p11, c) * xf;
+        const float value = top * nyf + bottom * yf;
+        o |= trunc_u8(value) << (8 * c);
+    }
+    return o;
+}
+
+// Dense flow (2 x f32 per pixel, delta A -> B): A sampled at p - t*flow, B at
+// p + (1-t)*flow (warp_blend.wgsl:36-37 in texel space).  blockDim = (64, 4).
+__global__ __launch_bounds__(256) void k_warp_blend_flow(
+    const uint8_t *__restrict__ a, const uint8_t *__restrict__ b, const float *__restrict__ flow,
+    uint8_t *__restrict__ out, size_t a_stride, size_t b_stride, uint32_t w, uint32_t h, float t)
+{
+    const uint32_t y = __builtin_amdgcn_readfirstlane(blockIdx.y * 4 + threadIdx.y);
+    const uint32_t x = blockIdx.x * kWave + threadIdx.x;
+    if (y >= h || x >= w) return;
+    const size_t npx = (size_t)w * h;
+    const uint32_t *pa = reinterpret_cast<const uint32_t *>(a + (size_t)blockIdx.z * a_stride);
+    const uint32_t *pb = reinterpret_cast<const uint32_t *>(b + (size_t)blockIdx.z * b_stride);
+    const size_t idx = (size_t)y * w + x;
+    const float2 f = *reinterpret_cast<const float2 *>(flow + ((size_t)blockIdx.z * npx + idx) * 2);
+    const float nt = 1.0f - t;
+    const float ax = (float)x - t * f.x, ay = (float)y - t * f.y;
+    const float bx = (float)x + nt * f.x, by = (float)y + nt * f.y;
+    const uint32_t sa = sample_trunc(pa, w, h, ax, ay);
+    const uint32_t sb = sample_trunc(pb, w, h, bx, by);
+    reinterpret_cast<uint32_t *>(out)[(size_t)blockIdx.z * npx + idx] = blend_px(sa, sb, t, nt);
+}
+
+constexpr uint32_t kMaxGridZ = 65535;
+
+} // namespace
+
+const char *variant_name(Variant v)
+{
+    switch (v) {
+    case Variant::NearestTable: return "nearest_table";
+    case Variant::NearestX2: return "nearest_x2_vec16";
+    case Variant::BilinearTable: return "bilinear_table_f32";
+    case Variant::BilinearX2Int: return "bilinear_x2_packed_u8";
+    case Variant::LanczosGeneral: return "lanczos3_general";
+    case Variant::LanczosX2RegWin: return "lanczos3_x2_regwin";
+    }
+    return "?";
+}
+
+static inline uint32_t cdiv(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
+
+// Frames go on grid.z (<= 65535 per launch); longer batches are issued in chunks.
+template <typename F>
+static hipError_t for_frame_chunks(const UpscaleLaunch &L, F &&f)
+{
+    const size_t in_bytes = (size_t)L.iw * L.ih * 4, out_bytes = (size_t)L.ow * L.oh * 4;
+    for (uint32_t done = 0; done < L.n_frames;) {
+        const uint32_t n = L.n_frames - done < kMaxGridZ ? L.n_frames - done : kMaxGridZ;
+        f(L.in + (size_t)done * in_bytes, L.out + (size_t)done * out_bytes, n);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+        done += n;
+    }
+    return hipSuccess;
+}
+
+hipError_t launch_nearest_table(const UpscaleLaunch &L, const DeviceTables &T)
+{
+    const bool vec = (L.ow % 4) == 0;
+    const size_t ipx = (size_t)L.iw * L.ih, opx = (size_t)L.ow * L.oh;
+    return for_frame_chunks(L, [&](const uint8_t *in, uint8_t *out, uint32_t n) {
+        const dim3 block(kWave, 4), grid(cdiv(L.ow, vec ? 256 : 64), cdiv(L.oh, 4), n);
+        auto *i32 = reinterpret_cast<const uint32_t *>(in);
+        auto *o32 = reinterpret_cast<uint32_t *>(out);
+        if (vec)
+            hipLaunchKernelGGL(k_nearest_table<true>, grid, block, 0, L.stream, i32, o32, T.nn_sx, T.nn_sy, L.iw, L.ow, L.oh, ipx, opx);
+        else
+            hipLaunchKernelGGL(k_nearest_table<false>, grid, block, 0, L.stream, i32, o32, T.nn_sx, T.nn_sy, L.iw, L.ow, L.oh, ipx, opx);
+    });
+}
+
+hipError_t launch_nearest_x2(const UpscaleLaunch &L)
+{
+    const size_t ipx = (size_t)L.iw * L.ih, opx = (size_t)L.ow * L.oh;
+    return for_frame_chunks(L, [&](const uint8_t *in, uint8_t *out, uint32_t n) {
+        const dim3 block(kWave, 4), grid(cdiv(L.iw, 256), cdiv(L.ih, 4), n);
+        hipLaunchKernelGGL(k_nearest_x2, grid, block, 0, L.stream, reinterpret_cast<const uint32_t *>(in),
+                           reinterpret_cast<uint32_t *>(out), L.iw, L.ih, ipx, opx);
+    });
+}
+
+hipError_t launch_bilinear_table(const UpscaleLaunch &L, const DeviceTables &T, bool wgsl_form)
+{
+    const bool vec = (L.ow % 4) == 0;
+    const size_t ipx = (size_t)L.iw * L.ih, opx = (size_t)L.ow * L.oh;
+    return for_frame_chunks(L, [&](const uint8_t *in, uint8_t *out, uint32_t n) {
+        const dim3 block(kWave, 4), grid(cdiv(L.ow, vec ? 256 : 64), cdiv(L.oh, 4), n);
+        auto *i32 = reinterpret_cast<const uint32_t *>(in);
+        auto *o32 = reinterpret_cast<uint32_t *>(out);
+#define NUS_BL(V, W)                                                                                         \
+    hipLaunchKernelGGL((k_bilinear_table<V, W>), grid, block, 0, L.stream, i32, o32, T.bl_x0, T.bl_fx, T.bl_y0, \
+                       T.bl_fy, L.iw, L.ih, L.ow, L.oh, ipx, opx)
+        if (vec && wgsl_form) NUS_BL(true, true);
+        else if (vec) NUS_BL(true, false);
+        else if (wgsl_form) NUS_BL(false, true);
+        else NUS_BL(false, false);
+#undef NUS_BL
+    });
+}
+
+hipError_t launch_bilinear_x2_int(const UpscaleLaunch &L)
+{
+    const size_t ipx = (size_t)L.iw * L.ih, opx = (size_t)L.ow * L.oh;
+    return for_frame_chunks(L, [&](const uint8_t *in, uint8_t *out, uint32_t n) {
+        const dim3 block(kWave, 4), grid(cdiv(L.iw, 256), cdiv(L.ih, 4), n);
+        hipLaunchKernelGGL(k_bilinear_x2_int, grid, block, 0, L.stream, reinterpret_cast<const uint32_t *>(in),
+                           reinterpret_cast<uint32_t *>(out), L.iw, L.ih, ipx, opx);
+    });
+}
+
+hipError_t launch_lanczos_general(const UpscaleLaunch &L, const DeviceTables &T, bool exact, uint32_t edge_cols)
+{
+    const size_t ipx = (size_t)L.iw * L.ih, opx = (size_t)L.ow * L.oh;
+    uint32_t ncols = L.ow, split = L.ow, gap = 0;
+    if (edge_cols && 2 * edge_cols < L.ow) {
+        ncols = 2 * edge_cols;
+        split = edge_cols;
+        gap = L.ow - 2 * edge_cols;
+    }
+    return for_frame_chunks(L, [&](const uint8_t *in, uint8_t *out, uint32_t n) {
+        const dim3 block(kWave, 4), grid(cdiv(ncols, 64), cdiv(L.oh, 4), n);
+        auto *i32 = reinterpret_cast<const uint32_t *>(in);
+        auto *o32 = reinterpret_cast<uint32_t *>(out);
+        if (exact)
+            hipLaunchKernelGGL(k_lanczos_general<true>, grid, block, 0, L.stream, i32, o32, T.lz_lx, T.lz_nx, T.lz_wx,
+                               T.lz_ly, T.lz_ny, T.lz_wy, T.lz_stride, L.iw, L.ow, L.oh, ncols, split, gap, ipx, opx);
+        else
+            hipLaunchKernelGGL(k_lanczos_general<false>, grid, block, 0, L.stream, i32, o32, T.lz_lx, T.lz_nx, T.lz_wx,
+                               T.lz_ly, T.lz_ny, T.lz_wy, T.lz_stride, L.iw, L.ow, L.oh, ncols, split, gap, ipx, opx);
+    });
+}
+
+hipError_t launch_lanczos_x2(const UpscaleLaunch &L, const DeviceTables &T, bool exact, uint32_t rows_per_wave)
+{
+    LanczosX2Args A;
+    A.wy6 = T.lz_wy6;
+    for (int j = 0; j < 6; ++j) {
+        A.wxe[j] = T.lz_wxe[j];
+        A.wxo[j] = T.lz_wxo[j];
+    }
+    A.iw = L.iw;
+    A.ih = L.ih;
+    A.nstrips = cdiv(L.iw, kLanczosX2StripCols);
+    A.th = rows_per_wave ? rows_per_wave : 32;
+    A.nrowblocks = cdiv(L.ih, A.th);
+    A.in_frame_bytes = (size_t)L.iw * L.ih * 4;
+    A.out_frame_bytes = (size_t)L.ow * L.oh * 4;
+    const uint32_t nwaves = A.nstrips * A.nrowblocks;
+    hipError_t e = for_frame_chunks(L, [&](const uint8_t *in, uint8_t *out, uint32_t n) {
+        A.in = in;
+        A.out = out;
+        const dim3 block(256), grid(cdiv(nwaves, 4), n);
+        if (exact)
+            hipLaunchKernelGGL(k_lanczos3_x2<true>, grid, block, 0, L.stream, A);
+        else
+            hipLaunchKernelGGL(k_lanczos3_x2<false>, grid, block, 0, L.stream, A);
+    });
+    if (e != hipSuccess) return e;
+    // first / last 8 output columns: renormalised edge weights, general kernel
+    return launch_lanczos_general(L, T, exact, kLanczosX2EdgeCols);
+}
+
+hipError_t launch_warp_blend(const WarpLaunch &L)
+{
+    const size_t npx = (size_t)L.w * L.h;
+    for (uint32_t done = 0; done < L.n_pairs;) {
+        const uint32_t n = L.n_pairs - done < kMaxGridZ ? L.n_pairs - done : kMaxGridZ;
+        const uint8_t *a = L.a + (size_t)done * L.a_stride;
+        const uint8_t *b = L.b + (size_t)done * L.b_stride;
+        uint8_t *out = L.out + (size_t)done * npx * 4;
+        if (L.flow == nullptr) {
+            const bool vec = (npx % 4) == 0 && (L.a_stride % 16) == 0 && (L.b_stride % 16) == 0 &&
+                             (reinterpret_cast<uintptr_t>(a) % 16) == 0 && (reinterpret_cast<uintptr_t>(b) % 16) == 0 &&
+                             (reinterpret_cast<uintptr_t>(out) % 16) == 0;
+            const size_t items = vec ? npx / 4 : npx;
+            const dim3 block(256), grid((uint32_t)((items + 255) / 256), n);
+            if (vec)
+                hipLaunchKernelGGL(k_blend_zero_flow<true>, grid, block, 0, L.stream, a, b, out, L.a_stride, L.b_stride, npx, L.t);
+            else
+                hipLaunchKernelGGL(k_blend_zero_flow<false>, grid, block, 0, L.stream, a, b, out, L.a_stride, L.b_stride, npx, L.t);
+        } else {
+            const dim3 block(kWave, 4), grid(cdiv(L.w, 64), cdiv(L.h, 4), n);
+            hipLaunchKernelGGL(k_warp_blend_flow, grid, block, 0, L.stream, a, b, L.flow + (size_t)done * npx * 2, out,
+                               L.a_stride, L.b_stride, L.w, L.h, L.t);
+        }
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+        done += n;
+    }
+    return hipSuccess;
+}
+
+} // namespace nus

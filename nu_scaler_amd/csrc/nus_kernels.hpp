@@ -1,0 +1,75 @@
+// nus_kernels.hpp -- launch interface between the host classes and the gfx950 kernels.
+// Everything here is device-pointer based; no allocation, no synchronisation
+// (safe to capture into a hipGraph).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+namespace nus {
+
+// Device-side tables of one initialised upscaler (built on the host by nus_tables.cpp).
+struct DeviceTables {
+    // nearest: source index per output index
+    const uint32_t *nn_sx = nullptr, *nn_sy = nullptr;
+    // bilinear: i0 and fraction per output index
+    const uint32_t *bl_x0 = nullptr, *bl_y0 = nullptr;
+    const float *bl_fx = nullptr, *bl_fy = nullptr;
+    // lanczos general: tap window per output index, weights [n][taps_stride]
+    const int32_t *lz_lx = nullptr, *lz_ly = nullptr;
+    const uint32_t *lz_nx = nullptr, *lz_ny = nullptr;
+    const float *lz_wx = nullptr, *lz_wy = nullptr;
+    uint32_t lz_stride = 0;
+    // lanczos x2 fast path: per-output-row weights in the 6-tap phase frame [oh][6]
+    const float *lz_wy6 = nullptr;
+    float lz_wxe[6] = {0}, lz_wxo[6] = {0}; // interior horizontal weights, even / odd outputs
+};
+
+struct UpscaleLaunch {
+    const uint8_t *in = nullptr; // n_frames contiguous frames
+    uint8_t *out = nullptr;
+    uint32_t iw = 0, ih = 0, ow = 0, oh = 0;
+    uint32_t n_frames = 1;
+    hipStream_t stream = nullptr;
+};
+
+// Kernel variants (chosen once at initialize).
+enum class Variant : int {
+    NearestTable = 0, // any scale, index tables
+    NearestX2,        // exact x2, 16-B loads/stores
+    BilinearTable,    // any scale, f32, CPU or WGSL arithmetic
+    BilinearX2Int,    // exact x2, CPU arithmetic done in packed-u8 integer ops
+    LanczosGeneral,   // any scale, direct separable evaluation per output pixel
+    LanczosX2RegWin,  // exact x2, register sliding window + wave shifts
+};
+
+const char *variant_name(Variant v);
+
+hipError_t launch_nearest_table(const UpscaleLaunch &L, const DeviceTables &T);
+hipError_t launch_nearest_x2(const UpscaleLaunch &L);
+hipError_t launch_bilinear_table(const UpscaleLaunch &L, const DeviceTables &T, bool wgsl_form);
+hipError_t launch_bilinear_x2_int(const UpscaleLaunch &L);
+// edge_only: evaluate only the first and last `edge_cols` output columns.
+hipError_t launch_lanczos_general(const UpscaleLaunch &L, const DeviceTables &T, bool exact,
+                                  uint32_t edge_cols);
+hipError_t launch_lanczos_x2(const UpscaleLaunch &L, const DeviceTables &T, bool exact,
+                             uint32_t rows_per_wave);
+
+constexpr uint32_t kLanczosX2EdgeCols = 8; // output columns left to the general kernel per side
+constexpr uint32_t kLanczosX2StripCols = 248; // input columns produced per wave (62 lanes x 4)
+
+struct WarpLaunch {
+    const uint8_t *a = nullptr, *b = nullptr;
+    const float *flow = nullptr; // nullptr: zero flow
+    uint8_t *out = nullptr;
+    size_t a_stride = 0, b_stride = 0; // bytes between consecutive pairs
+    uint32_t w = 0, h = 0;
+    float t = 0.5f;
+    uint32_t n_pairs = 1;
+    hipStream_t stream = nullptr;
+};
+
+hipError_t launch_warp_blend(const WarpLaunch &L);
+
+} // namespace nus

@@ -1,0 +1,225 @@
+// nus_tables.cpp -- host-side per-axis tables.  See nus_tables.hpp.
+// Compiled with -ffp-contract=off: every f32 operation below rounds on its own.
+#include "nus_tables.hpp"
+
+#include <cmath>
+#include <cstring>
+
+namespace nus {
+
+void build_nearest_axis(uint32_t in_n, uint32_t out_n, uint32_t *src)
+{
+    for (uint32_t o = 0; o < out_n; ++o) {
+        uint64_t s = ((uint64_t)o * in_n) / out_n;
+        src[o] = (uint32_t)(s < in_n - 1 ? s : in_n - 1);
+    }
+}
+
+void build_bilinear_axis(uint32_t in_n, uint32_t out_n, bool wgsl_form, uint32_t *i0, float *frac)
+{
+    const float fin = (float)in_n, fout = (float)out_n;
+    for (uint32_t o = 0; o < out_n; ++o) {
+        float s = (float)o * fin / fout; // multiply, then divide
+        if (!wgsl_form) s = std::fmin(s, fin - 1.0f);
+        const float fl = wgsl_form ? std::trunc(s) : std::floor(s);
+        uint32_t i = (uint32_t)fl;
+        if (i > in_n - 1) i = in_n - 1; // only reachable in the wgsl form when out_n < in_n rounds up
+        i0[o] = i;
+        frac[o] = s - (float)i;
+    }
+}
+
+namespace {
+
+const float kPi = 3.14159265358979323846f;
+
+float sinc(float t)
+{
+    const float a = t * kPi;
+    if (t == 0.0f) return 1.0f;
+    return std::sin(a) / a;
+}
+
+float lanczos3(float x)
+{
+    if (std::fabs(x) < 3.0f) return sinc(x) * sinc(x / 3.0f);
+    return 0.0f;
+}
+
+} // namespace
+
+int build_lanczos3_axis(uint32_t in_n, uint32_t out_n, int32_t *left, uint32_t *ntaps, float *weights)
+{
+    if (in_n == 0 || out_n == 0) return -1;
+    const float ratio = (float)in_n / (float)out_n;
+    const float sratio = ratio < 1.0f ? 1.0f : ratio;
+    const float src_support = 3.0f * sratio;
+    int worst = 0;
+    for (uint32_t o = 0; o < out_n; ++o) {
+        float *ws = weights + (size_t)o * kResizeMaxTaps;
+        std::memset(ws, 0, sizeof(float) * kResizeMaxTaps);
+        // centre of output pixel o in input coordinates (half-pixel convention)
+        float centre = ((float)o + 0.5f) * ratio;
+        int64_t lo = (int64_t)std::floor(centre - src_support);
+        if (lo < 0) lo = 0;
+        if (lo > (int64_t)in_n - 1) lo = (int64_t)in_n - 1;
+        int64_t hi = (int64_t)std::ceil(centre + src_support);
+        if (hi < lo + 1) hi = lo + 1;
+        if (hi > (int64_t)in_n) hi = (int64_t)in_n;
+        centre = centre - 0.5f;
+        const uint32_t n = (uint32_t)(hi - lo);
+        left[o] = (int32_t)lo;
+        ntaps[o] = n;
+        if (n > kResizeMaxTaps) return -1;
+        float sum = 0.0f;
+        for (uint32_t i = 0; i < n; ++i) {
+            const float w = lanczos3(((float)(lo + (int64_t)i) - centre) / sratio);
+            ws[i] = w;
+            sum += w;
+        }
+        for (uint32_t i = 0; i < n; ++i) ws[i] /= sum;
+        if ((int)n > worst) worst = (int)n;
+    }
+    return worst;
+}
+
+void build_axis_tables(uint32_t in_n, uint32_t out_n, bool wgsl_form, AxisTables &t)
+{
+    t.in_n = in_n;
+    t.out_n = out_n;
+    t.nn_src.resize(out_n);
+    t.bl_i0.resize(out_n);
+    t.bl_frac.resize(out_n);
+    t.lz_left.resize(out_n);
+    t.lz_ntaps.resize(out_n);
+    t.lz_w.assign((size_t)out_n * kResizeMaxTaps, 0.0f);
+    build_nearest_axis(in_n, out_n, t.nn_src.data());
+    build_bilinear_axis(in_n, out_n, wgsl_form, t.bl_i0.data(), t.bl_frac.data());
+    t.lz_max_taps = build_lanczos3_axis(in_n, out_n, t.lz_left.data(), t.lz_ntaps.data(), t.lz_w.data());
+}
+
+bool lanczos_x2_phase_frame(const AxisTables &t, std::vector<float> &w6)
+{
+    if (t.out_n != 2 * t.in_n || t.lz_max_taps < 0) return false;
+    w6.assign((size_t)t.out_n * 6, 0.0f);
+    for (uint32_t o = 0; o < t.out_n; ++o) {
+        const int32_t base = (int32_t)(o >> 1) - 3 + (int32_t)(o & 1);
+        const float *ws = t.lz_w.data() + (size_t)o * kResizeMaxTaps;
+        for (uint32_t i = 0; i < t.lz_ntaps[o]; ++i) {
+            const int32_t j = t.lz_left[o] + (int32_t)i - base;
+            if (j < 0 || j >= 6) {
+                if (ws[i] != 0.0f) return false;
+                continue;
+            }
+            w6[(size_t)o * 6 + j] = ws[i];
+        }
+    }
+    return true;
+}
+
+bool lanczos_x2_interior_uniform(const AxisTables &t, const std::vector<float> &w6)
+{
+    if (t.in_n < 16) return false;
+    // outputs 2k, 2k+1 with 4 <= k <= in_n - 5 have all taps inside the image
+    for (uint32_t o = 8; o + 8 < t.out_n; ++o) {
+        const float *ref = w6.data() + (size_t)(8 + (o & 1)) * 6;
+        if (std::memcmp(ref, w6.data() + (size_t)o * 6, 6 * sizeof(float)) != 0) return false;
+    }
+    return true;
+}
+
+namespace {
+
+const uint32_t kMagic = 0x4C53554Eu; // "NUSL"
+
+template <typename T>
+void put(std::vector<uint8_t> &b, const T *p, size_t n)
+{
+    const uint8_t *s = reinterpret_cast<const uint8_t *>(p);
+    b.insert(b.end(), s, s + n * sizeof(T));
+}
+
+void put_axis(std::vector<uint8_t> &b, const AxisTables &t)
+{
+    const uint32_t hdr[3] = {t.in_n, t.out_n, (uint32_t)t.lz_max_taps};
+    put(b, hdr, 3);
+    put(b, t.nn_src.data(), t.out_n);
+    put(b, t.bl_i0.data(), t.out_n);
+    put(b, t.bl_frac.data(), t.out_n);
+    put(b, t.lz_left.data(), t.out_n);
+    put(b, t.lz_ntaps.data(), t.out_n);
+    put(b, t.lz_w.data(), (size_t)t.out_n * kResizeMaxTaps);
+}
+
+template <typename T>
+bool get(const uint8_t *&p, const uint8_t *end, T *dst, size_t n)
+{
+    if ((size_t)(end - p) < n * sizeof(T)) return false;
+    std::memcpy(dst, p, n * sizeof(T));
+    p += n * sizeof(T);
+    return true;
+}
+
+bool get_axis(const uint8_t *&p, const uint8_t *end, AxisTables &t)
+{
+    uint32_t hdr[3];
+    if (!get(p, end, hdr, 3)) return false;
+    if (hdr[1] == 0 || hdr[1] > (1u << 24)) return false;
+    t.in_n = hdr[0];
+    t.out_n = hdr[1];
+    t.lz_max_taps = (int)hdr[2];
+    t.nn_src.resize(t.out_n);
+    t.bl_i0.resize(t.out_n);
+    t.bl_frac.resize(t.out_n);
+    t.lz_left.resize(t.out_n);
+    t.lz_ntaps.resize(t.out_n);
+    t.lz_w.resize((size_t)t.out_n * kResizeMaxTaps);
+    return get(p, end, t.nn_src.data(), t.out_n) && get(p, end, t.bl_i0.data(), t.out_n) &&
+           get(p, end, t.bl_frac.data(), t.out_n) && get(p, end, t.lz_left.data(), t.out_n) &&
+           get(p, end, t.lz_ntaps.data(), t.out_n) && get(p, end, t.lz_w.data(), (size_t)t.out_n * kResizeMaxTaps);
+}
+
+} // namespace
+
+std::vector<uint8_t> serialize_tables(const AxisTables &x, const AxisTables &y)
+{
+    std::vector<uint8_t> b;
+    const uint32_t hdr[2] = {kMagic, 1u};
+    put(b, hdr, 2);
+    put_axis(b, x);
+    put_axis(b, y);
+    return b;
+}
+
+bool deserialize_tables(const uint8_t *buf, size_t len, AxisTables &x, AxisTables &y, std::string &err)
+{
+    const uint8_t *p = buf, *end = buf + len;
+    uint32_t hdr[2];
+    if (!get(p, end, hdr, 2) || hdr[0] != kMagic || hdr[1] != 1u) {
+        err = "table blob: bad magic or version";
+        return false;
+    }
+    if (!get_axis(p, end, x) || !get_axis(p, end, y) || p != end) {
+        err = "table blob: truncated or oversized";
+        return false;
+    }
+    // indices must stay inside the source axis: the kernels trust them
+    for (const AxisTables *t : {&x, &y}) {
+        for (uint32_t o = 0; o < t->out_n; ++o) {
+            if (t->nn_src[o] >= t->in_n || t->bl_i0[o] >= t->in_n) {
+                err = "table blob: index out of range";
+                return false;
+            }
+            if (t->lz_max_taps >= 0) {
+                if (t->lz_left[o] < 0 || t->lz_ntaps[o] == 0 || t->lz_ntaps[o] > kResizeMaxTaps ||
+                    (uint64_t)t->lz_left[o] + t->lz_ntaps[o] > t->in_n) {
+                    err = "table blob: tap window out of range";
+                    return false;
+                }
+            }
+        }
+    }
+    return true;
+}
+
+} // namespace nus

@@ -1,0 +1,54 @@
+// nus_tables.hpp -- host-side per-axis tables (computed once at initialize).
+// The kernels never divide or call sinf: every index, fraction and filter weight is
+// produced here with plain IEEE f32 host arithmetic, so it is the same value the CPU
+// algorithm uses, and identical on every GPU of a node (tables can be exported and
+// broadcast, see nus_upscaler_export_tables).
+#pragma once
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+namespace nus {
+
+constexpr uint32_t kResizeMaxTaps = 32; // == NUS_RESIZE_MAX_TAPS
+
+// nearest: src[o] = min(o * in_n / out_n, in_n - 1)   (Nu_scale/src/upscale/common.rs:191-192)
+void build_nearest_axis(uint32_t in_n, uint32_t out_n, uint32_t *src);
+
+// bilinear: i0[o], frac[o].  cpu form clamps the coordinate to in_n - 1
+// (Nu_scale/src/upscale/common.rs:204-215); wgsl form does not (upscale/mod.rs:241-248).
+void build_bilinear_axis(uint32_t in_n, uint32_t out_n, bool wgsl_form, uint32_t *i0, float *frac);
+
+// Lanczos-3 windows, image-0.24.9 vertical_sample / horizontal_sample convention.
+// weights is out_n * kResizeMaxTaps, zero padded.  Returns max ntaps, or -1 when a
+// window needs more than kResizeMaxTaps taps (down-scaling by more than ~4.8x).
+int build_lanczos3_axis(uint32_t in_n, uint32_t out_n, int32_t *left, uint32_t *ntaps, float *weights);
+
+struct AxisTables {
+    uint32_t in_n = 0, out_n = 0;
+    std::vector<uint32_t> nn_src;
+    std::vector<uint32_t> bl_i0;
+    std::vector<float> bl_frac;
+    std::vector<int32_t> lz_left;
+    std::vector<uint32_t> lz_ntaps;
+    std::vector<float> lz_w; // out_n * kResizeMaxTaps
+    int lz_max_taps = 0;     // -1: unsupported ratio
+};
+
+void build_axis_tables(uint32_t in_n, uint32_t out_n, bool wgsl_form, AxisTables &t);
+
+// Exact-x2 view of a Lanczos axis: weights of output o in its 6-tap phase frame
+// (base = (o>>1) - 3 + (o&1)).  Returns false if any non-zero tap falls outside
+// the frame (then the x2 kernel must not be used).
+bool lanczos_x2_phase_frame(const AxisTables &t, std::vector<float> &w6);
+
+// True when every interior output (taps untouched by the image border) has the same
+// phase-frame weights as outputs 8 (even) and 9 (odd).
+bool lanczos_x2_interior_uniform(const AxisTables &t, const std::vector<float> &w6);
+
+// Serialisation for the multi-GPU LUT broadcast.
+std::vector<uint8_t> serialize_tables(const AxisTables &x, const AxisTables &y);
+bool deserialize_tables(const uint8_t *buf, size_t len, AxisTables &x, AxisTables &y, std::string &err);
+
+} // namespace nus

@@ -1,0 +1,134 @@
+"""Frame-queue stream: the unit of work of the 1080p -> 4K pipeline and its sharding.
+
+One *unit* = one source frame k of a stream: interpolate (k, k+1) at t to get the
+in-between frame, then upscale both frame k and the in-between frame (the GUI flow at
+nu_scaler_py/nu_scaler/main.py:999-1008, 1087-1088 upscales the blended frame; the
+BASELINE metric "x2 upscale + interp" upscales the real and the inserted frame).
+
+Frames are independent units, so a stream shards across GPUs with no data-path
+collective: rank r takes a contiguous chunk of source frames plus one overlap frame so
+every (k, k+1) pair is local.  The only cross-GPU traffic is the one-off broadcast of
+the filter tables (RCCL over xGMI when the backend is nccl).
+"""
+from __future__ import annotations
+
+from typing import Tuple
+
+from .interpolator import WgpuFrameInterpolator
+from .upscaler import PyWgpuUpscaler
+
+
+def shard_frames(n_units: int, world_size: int, rank: int) -> Tuple[int, int]:
+    """Contiguous chunk [start, start+count) of source-frame units owned by `rank`.
+    Chunks differ by at most one unit; the caller also needs frame start+count (the
+    overlap frame) as the second half of its last pair."""
+    if world_size <= 0 or not (0 <= rank < world_size):
+        raise ValueError("bad world_size / rank")
+    base, rem = divmod(int(n_units), world_size)
+    count = base + (1 if rank < rem else 0)
+    start = rank * base + min(rank, rem)
+    return start, count
+
+
+def build_tables_blob(in_w: int, in_h: int, out_w: int, out_h: int, wgsl_bilinear: bool = False) -> bytes:
+    """Host-only: the table blob an upscaler of these dimensions exports (no GPU needed)."""
+    import ctypes
+
+    from . import _capi as C
+
+    L = C.lib()
+    n = L.nus_tables_build_blob(in_w, in_h, out_w, out_h, int(wgsl_bilinear), None, 0)
+    if n < 0:
+        raise RuntimeError(C.last_error())
+    buf = ctypes.create_string_buffer(n)
+    if L.nus_tables_build_blob(in_w, in_h, out_w, out_h, int(wgsl_bilinear), buf, n) != n:
+        raise RuntimeError(C.last_error())
+    return buf.raw
+
+
+def validate_tables_blob(blob: bytes, in_w: int, in_h: int, out_w: int, out_h: int) -> None:
+    from . import _capi as C
+
+    if C.lib().nus_tables_validate_blob(blob, len(blob), in_w, in_h, out_w, out_h) != C.OK:
+        raise ValueError(C.last_error())
+
+
+def broadcast_blob(blob, src: int = 0, device=None) -> bytes:
+    """Broadcast a byte blob from rank `src` (RCCL over xGMI with the nccl backend and a
+    cuda `device`; gloo on CPU).  Returns the blob on every rank."""
+    import torch
+    import torch.distributed as dist
+
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return bytes(blob)
+    rank = dist.get_rank()
+    n = torch.tensor([len(blob) if rank == src else 0], dtype=torch.int64, device=device)
+    dist.broadcast(n, src)
+    size = int(n.item())
+    if rank == src:
+        t = torch.frombuffer(bytearray(blob), dtype=torch.uint8)
+        t = t.to(device) if device is not None else t
+    else:
+        t = torch.empty(size, dtype=torch.uint8, device=device)
+    dist.broadcast(t, src)
+    return t.cpu().numpy().tobytes()
+
+
+def broadcast_tables(upscaler: PyWgpuUpscaler, src: int = 0, device=None) -> int:
+    """Broadcast rank `src`'s filter / index tables to every rank so all GPUs use
+    bit-identical weights.  Returns the blob size (0 when not distributed)."""
+    import torch.distributed as dist
+
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return 0
+    rank = dist.get_rank()
+    blob = broadcast_blob(upscaler.export_tables() if rank == src else b"", src, device)
+    if rank != src:
+        upscaler.import_tables(blob)
+    return len(blob)
+
+
+class FramePipeline:
+    """Device-resident pipeline over a batch of source frames already in HBM.
+
+    frames : (n_units + 1, h, w, 4) uint8 tensor (the +1 is the overlap frame)
+    mid    : (n_units, h, w, 4)          in-between frames
+    up_real, up_mid : (n_units, oh, ow, 4) upscaled real / in-between frames
+    """
+
+    def __init__(self, width: int, height: int, scale: int = 2, algorithm: str = "lanczos3", time_t: float = 0.5,
+                 device: int = 0, lanczos_mode: str = "fma"):
+        self.w, self.h = int(width), int(height)
+        self.ow, self.oh = self.w * scale, self.h * scale
+        self.t = float(time_t)
+        self.upscaler = PyWgpuUpscaler("quality", algorithm, device=device, lanczos_mode=lanczos_mode)
+        self.upscaler.initialize(self.w, self.h, self.ow, self.oh)
+        self.interp = WgpuFrameInterpolator(device=device)
+        self.frame_bytes = self.w * self.h * 4
+
+    # algorithmic bytes / pixels of one unit
+    @property
+    def unit_bytes(self) -> int:
+        up = self.frame_bytes + self.ow * self.oh * 4
+        return 3 * self.frame_bytes + 2 * up
+
+    @property
+    def unit_pixels(self) -> int:
+        return 3 * self.w * self.h + 2 * (self.w * self.h + self.ow * self.oh)
+
+    def alloc(self, n_units: int, device):
+        import torch
+
+        mid = torch.empty((n_units, self.h, self.w, 4), dtype=torch.uint8, device=device)
+        up_real = torch.empty((n_units, self.oh, self.ow, 4), dtype=torch.uint8, device=device)
+        up_mid = torch.empty((n_units, self.oh, self.ow, 4), dtype=torch.uint8, device=device)
+        return mid, up_real, up_mid
+
+    def step(self, frames, mid, up_real, up_mid, stream: int = 0) -> None:
+        """Enqueue one pass over the batch on `stream` (a hipStream_t as int; 0 = default)."""
+        n = mid.shape[0]
+        base = frames.data_ptr()
+        fb = self.frame_bytes
+        self.interp.interpolate_device(base, fb, base + fb, fb, 0, self.w, self.h, self.t, mid.data_ptr(), n, stream)
+        self.upscaler.upscale_device(base, up_real.data_ptr(), n, stream)
+        self.upscaler.upscale_device(mid.data_ptr(), up_mid.data_ptr(), n, stream)

@@ -1,0 +1,235 @@
+"""Python mirror of the reference's pyo3 upscaler classes, bound to the HIP C ABI.
+
+Same class names, constructor strings, methods and error behaviour as
+nu_scaler_core/src/lib.rs:39-160 (PyWgpuUpscaler) and :328-729
+(PyAdvancedWgpuUpscaler), so scripts written against `nu_scaler_core` run with
+`import nu_scaler_amd as nu_scaler_core`.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Iterable, List, Optional
+
+from . import _capi as C
+
+_QUALITY = {  # lib.rs:51-57; unknown strings silently become "quality"
+    "ultra": C.QUALITY_ULTRA,
+    "quality": C.QUALITY_QUALITY,
+    "balanced": C.QUALITY_BALANCED,
+    "performance": C.QUALITY_PERFORMANCE,
+}
+_QUALITY_STR = {v: k for k, v in _QUALITY.items()}
+_ALGORITHM = {  # lib.rs:58-62; unknown strings silently become "nearest"
+    "nearest": C.ALG_NEAREST,
+    "bilinear": C.ALG_BILINEAR,
+    # new value of this build (`"lanczos3"` added)
+    "lanczos3": C.ALG_LANCZOS3,
+    "lanczos": C.ALG_LANCZOS3,
+}
+
+
+def _as_buffer(data):
+    """Borrow a readable bytes-like object without copying: (address, length, keepalive)."""
+    mv = memoryview(data)
+    if not mv.c_contiguous:
+        raise TypeError("frame buffer must be C-contiguous")
+    mv = mv.cast("B")
+    if mv.readonly:
+        # bytes: from_buffer needs a writable view; c_char_p borrows the storage instead
+        keep = bytes(data) if not isinstance(data, bytes) else data
+        return ctypes.cast(ctypes.c_char_p(keep), ctypes.c_void_p).value, len(keep), keep
+    arr = (ctypes.c_ubyte * len(mv)).from_buffer(mv)
+    return ctypes.addressof(arr), len(mv), (arr, mv)
+
+
+def _out_buffer(size: int):
+    """Fresh writable output buffer: (bytearray, ctypes view keeping it pinned, address)."""
+    out = bytearray(size)
+    if size == 0:
+        return out, None, None
+    arr = (ctypes.c_ubyte * size).from_buffer(out)
+    return out, arr, ctypes.addressof(arr)
+
+
+class PyWgpuUpscaler:
+    """lib.rs:39-160.  `PyWgpuUpscaler(quality="quality", algorithm="nearest")`."""
+
+    def __init__(self, quality: str = "quality", algorithm: str = "nearest", *, device: int = 0,
+                 bilinear_variant: str = "cpu", lanczos_mode: str = "fma"):
+        self._lib = C.lib()
+        q = _QUALITY.get(str(quality).lower(), C.QUALITY_QUALITY)
+        a = _ALGORITHM.get(str(algorithm).lower(), C.ALG_NEAREST)
+        self._h = self._lib.nus_upscaler_create(a, q)
+        if not self._h:
+            raise RuntimeError(C.last_error())
+        self._upscale_scale = 2.0  # lib.rs:65
+        self._check(self._lib.nus_upscaler_set_device(self._h, int(device)))
+        self._check(self._lib.nus_upscaler_set_bilinear_variant(self._h, 1 if bilinear_variant == "wgsl" else 0))
+        self._check(self._lib.nus_upscaler_set_lanczos_mode(self._h, 1 if lanczos_mode == "exact" else 0))
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            self._lib.nus_upscaler_destroy(h)
+
+    # -- error mapping: anyhow -> PyRuntimeError(e.to_string()) (lib.rs:85, :110)
+    def _check(self, status: int) -> None:
+        if status != C.OK:
+            raise RuntimeError(self._lib.nus_upscaler_last_error(self._h).decode("utf-8", "replace"))
+
+    def initialize(self, input_width: int, input_height: int, output_width: int, output_height: int) -> None:
+        if input_width > 0 and input_height > 0:  # lib.rs:77-81
+            self._upscale_scale = (output_width / input_width + output_height / input_height) / 2.0
+        self._check(self._lib.nus_upscaler_initialize(self._h, input_width, input_height, output_width, output_height))
+
+    @property
+    def upscale_scale(self) -> float:
+        return self._upscale_scale
+
+    @upscale_scale.setter
+    def upscale_scale(self, scale: float) -> None:
+        if scale < 1.0 or scale > 4.0:  # lib.rs:95-99
+            raise ValueError("Scale factor must be between 1.0 and 4.0")
+        self._upscale_scale = float(scale)
+
+    def upscale(self, input) -> bytes:
+        """bytes in, bytes out (lib.rs:105-112)."""
+        addr, n, keep = _as_buffer(input)
+        out_size = self._lib.nus_upscaler_output_size(self._h)
+        out, oarr, oaddr = _out_buffer(out_size)
+        self._check(self._lib.nus_upscaler_upscale(self._h, addr, n, oaddr, out_size))
+        del oarr, keep
+        return bytes(out)
+
+    def upscale_into(self, input, out) -> None:
+        """Zero-copy variant: writes into a caller-provided writable buffer."""
+        addr, n, keep = _as_buffer(input)
+        oaddr, on, okeep = _as_buffer(out)
+        self._check(self._lib.nus_upscaler_upscale(self._h, addr, n, oaddr, on))
+        del keep, okeep
+
+    def upscale_batch(self, frames: Iterable) -> List[bytes]:
+        """lib.rs:140-154; frames are pipelined over copy/compute streams on the GPU."""
+        bufs = [_as_buffer(f) for f in frames]
+        n = len(bufs)
+        out_size = self._lib.nus_upscaler_output_size(self._h)
+        if n == 0:  # still reports "not initialized" like upscale/mod.rs:610-614
+            self._check(self._lib.nus_upscaler_upscale_batch(self._h, None, None, 0, None, 0))
+            return []
+        triples = [_out_buffer(out_size) for _ in range(n)]
+        ins_c = (ctypes.c_void_p * n)(*[b[0] for b in bufs])
+        lens_c = (ctypes.c_size_t * n)(*[b[1] for b in bufs])
+        outs_c = (ctypes.c_void_p * n)(*[t[2] for t in triples])
+        self._check(self._lib.nus_upscaler_upscale_batch(self._h, ins_c, lens_c, n, outs_c, out_size))
+        outs = [t[0] for t in triples]
+        del triples
+        return [bytes(o) for o in outs]
+
+    # -- device-resident path (not in the reference; used by the frame stream + bench)
+    def upscale_device(self, d_in: int, d_out: int, n_frames: int = 1, stream: int = 0) -> None:
+        self._check(self._lib.nus_upscaler_upscale_device(self._h, d_in, d_out, n_frames, stream or None))
+
+    # -- wgpu-only knobs: accepted and ignored (lib.rs:115-137)
+    def reload_shader(self, path: str) -> None:
+        return None
+
+    def set_thread_count(self, n: int) -> None:
+        return None
+
+    def set_buffer_pool_size(self, n: int) -> None:
+        return None
+
+    def set_gpu_allocator(self, preset: str) -> None:
+        return None
+
+    @property
+    def name(self) -> str:
+        return self._lib.nus_upscaler_name(self._h).decode()
+
+    # -- extras
+    @property
+    def kernel_variant(self) -> str:
+        return self._lib.nus_upscaler_kernel_variant(self._h).decode()
+
+    def set_option(self, key: str, value: int) -> None:
+        self._check(self._lib.nus_upscaler_set_option(self._h, key.encode(), int(value)))
+
+    def set_lanczos_mode(self, mode: str) -> None:
+        self._check(self._lib.nus_upscaler_set_lanczos_mode(self._h, 1 if mode == "exact" else 0))
+
+    def get_last_gpu_duration_ms(self) -> Optional[float]:
+        ms = ctypes.c_double()
+        return ms.value if self._lib.nus_upscaler_last_gpu_ms(self._h, ctypes.byref(ms)) == C.OK else None
+
+    @property
+    def input_size(self) -> int:
+        return self._lib.nus_upscaler_input_size(self._h)
+
+    @property
+    def output_size(self) -> int:
+        return self._lib.nus_upscaler_output_size(self._h)
+
+    def export_tables(self) -> bytes:
+        n = self._lib.nus_upscaler_export_tables(self._h, None, 0)
+        if n < 0:
+            raise RuntimeError(C.last_error())
+        buf = ctypes.create_string_buffer(n)
+        if self._lib.nus_upscaler_export_tables(self._h, buf, n) != n:
+            raise RuntimeError(C.last_error())
+        return buf.raw
+
+    def import_tables(self, blob: bytes) -> None:
+        self._check(self._lib.nus_upscaler_import_tables(self._h, blob, len(blob)))
+
+
+class PyAdvancedWgpuUpscaler(PyWgpuUpscaler):
+    """lib.rs:328-729.  The VRAM / strategy methods exist for API parity (the GUI only
+    calls them behind `hasattr`); memory is owned by the HIP handle."""
+
+    def __init__(self, quality: str = "quality", algorithm: str = "bilinear", adaptive_quality: bool = True, **kw):
+        super().__init__(quality, algorithm, **kw)
+        self._adaptive_quality = bool(adaptive_quality)
+        self._quality_str = quality.lower() if quality.lower() in _QUALITY else "quality"
+
+    def force_gpu_activation(self) -> None:
+        return None
+
+    def set_memory_strategy(self, strategy: str) -> None:
+        if str(strategy).lower() not in ("auto", "aggressive", "balanced", "conservative", "minimal"):
+            raise ValueError(f"Unknown memory strategy: {strategy}")
+
+    @property
+    def adaptive_quality(self) -> bool:
+        return self._adaptive_quality
+
+    @adaptive_quality.setter
+    def adaptive_quality(self, enabled: bool) -> None:
+        self._adaptive_quality = bool(enabled)
+
+    def cleanup_memory(self) -> None:
+        return None
+
+    def force_cleanup(self) -> None:
+        return None
+
+    def update_gpu_stats(self) -> None:
+        return None
+
+    def get_quality_str(self) -> str:
+        return self._quality_str
+
+    def set_quality(self, quality: str) -> None:
+        q = str(quality).lower()
+        if q not in _QUALITY:
+            raise ValueError(f"Invalid quality: {quality}")
+        self._quality_str = q
+        self._check(self._lib.nus_upscaler_set_quality(self._h, _QUALITY[q]))
+
+    def get_gpu_info(self) -> dict:
+        return {"name": "AMD Instinct MI355X (HIP)", "vendor": "AMD", "backend": "HIP/gfx950",
+                "devices": C.device_count()}
+
+
+def create_advanced_upscaler(quality: str) -> PyAdvancedWgpuUpscaler:
+    """lib.rs:738-741."""
+    return PyAdvancedWgpuUpscaler(quality, "bilinear", True)

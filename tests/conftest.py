@@ -1,0 +1,46 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def oracle_mod():
+    """The CPU oracle (test infrastructure).  Built on demand with gcc."""
+    import oracle
+
+    oracle.build()
+    return oracle
+
+
+@pytest.fixture(scope="session")
+def nsc():
+    """The product package; builds libnuscaler_hip.so with hipcc if it is missing."""
+    import nu_scaler_amd
+
+    if not os.path.exists(nu_scaler_amd._capi.LIB_PATH):
+        nu_scaler_amd.build()
+    nu_scaler_amd._capi.lib()
+    return nu_scaler_amd
+
+
+@pytest.fixture(scope="session")
+def golden():
+    from _png import read_png
+
+    return {
+        "test_input": read_png(os.path.join(GOLDEN, "ref_test_input.png")),
+        "test_output": read_png(os.path.join(GOLDEN, "ref_test_output.png")),
+        "interp_half": read_png(os.path.join(GOLDEN, "ref_interp_half.png")),
+    }

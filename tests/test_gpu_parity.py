@@ -1,0 +1,322 @@
+"""GPU: parity of the HIP path (through the C ABI) against the CPU oracle.
+
+Bit-exact for nearest and bilinear; Lanczos-3 and warp+blend within +-1 LSB per channel
+(the tolerance BASELINE.json's north_star states), with the stricter results the
+implementation actually achieves asserted where they hold (EXACT mode: 0 differences).
+"""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+
+def _up(nsc, alg, img, ow, oh, **kw):
+    opts = kw.pop("options", {})
+    u = nsc.PyWgpuUpscaler("quality", alg, **kw)
+    for k, v in opts.items():
+        u.set_option(k, v)
+    ih, iw = img.shape[:2]
+    u.initialize(iw, ih, ow, oh)
+    out = np.frombuffer(u.upscale(img.tobytes()), dtype=np.uint8).reshape(oh, ow, 4)
+    return out, u
+
+
+def _maxdiff(a, b):
+    return int(np.abs(a.astype(np.int16) - b.astype(np.int16)).max())
+
+
+def test_device_present(nsc):
+    assert nsc.device_count() >= 1
+
+
+# ---- sizes: x2 fast paths, general scales, ragged / tiny shapes -------------------
+
+X2_SIZES = [(64, 36), (320, 240), (252, 20), (256, 33), (16, 1), (500, 7), (1000, 50)]
+GENERAL = [((64, 36), (96, 54)), ((48, 27), (72, 41)), ((50, 31), (127, 64)), ((37, 21), (74, 42)),
+           ((48, 27), (20, 11)), ((1, 1), (5, 3)), ((3, 2), (6, 4)), ((7, 5), (7, 5)), ((97, 13), (101, 29))]
+
+
+@pytest.mark.parametrize("size", X2_SIZES)
+def test_nearest_x2_bit_exact(nsc, oracle_mod, size):
+    w, h = size
+    img = oracle_mod.gen_noise(w, h, 11)
+    out, u = _up(nsc, "nearest", img, 2 * w, 2 * h)
+    assert u.kernel_variant == "nearest_x2_vec16"
+    assert np.array_equal(out, oracle_mod.nearest(img, 2 * w, 2 * h))
+    out_g, ug = _up(nsc, "nearest", img, 2 * w, 2 * h, options={"force_general": 1})
+    assert ug.kernel_variant == "nearest_table" and np.array_equal(out_g, out)
+
+
+@pytest.mark.parametrize("dims", GENERAL)
+def test_nearest_general_bit_exact(nsc, oracle_mod, dims):
+    (w, h), (ow, oh) = dims
+    img = oracle_mod.gen_noise(w, h, 12)
+    out, _ = _up(nsc, "nearest", img, ow, oh)
+    assert np.array_equal(out, oracle_mod.nearest(img, ow, oh))
+
+
+@pytest.mark.parametrize("size", X2_SIZES)
+def test_bilinear_x2_bit_exact(nsc, oracle_mod, size):
+    w, h = size
+    img = oracle_mod.gen_noise(w, h, 13)
+    want = oracle_mod.bilinear(img, 2 * w, 2 * h)
+    out, u = _up(nsc, "bilinear", img, 2 * w, 2 * h)
+    assert u.kernel_variant == "bilinear_x2_packed_u8"
+    assert np.array_equal(out, want)
+    out_g, ug = _up(nsc, "bilinear", img, 2 * w, 2 * h, options={"force_general": 1})
+    assert ug.kernel_variant == "bilinear_table_f32" and np.array_equal(out_g, want)
+
+
+@pytest.mark.parametrize("dims", GENERAL)
+def test_bilinear_general_bit_exact(nsc, oracle_mod, dims):
+    (w, h), (ow, oh) = dims
+    img = oracle_mod.gen_noise(w, h, 14)
+    out, _ = _up(nsc, "bilinear", img, ow, oh)
+    assert np.array_equal(out, oracle_mod.bilinear(img, ow, oh))
+    out_w, _ = _up(nsc, "bilinear", img, ow, oh, bilinear_variant="wgsl")
+    assert np.array_equal(out_w, oracle_mod.bilinear_wgsl(img, ow, oh))
+
+
+@pytest.mark.parametrize("size", [(64, 36), (320, 240), (252, 20), (256, 33), (16, 1), (500, 7), (1000, 50), (248, 40), (496, 9)])
+def test_lanczos_x2(nsc, oracle_mod, size):
+    w, h = size
+    img = oracle_mod.gen_noise(w, h, 15)
+    want = oracle_mod.lanczos3(img, 2 * w, 2 * h)
+    out, u = _up(nsc, "lanczos3", img, 2 * w, 2 * h)
+    assert u.kernel_variant == "lanczos3_x2_regwin"
+    d = np.abs(out.astype(np.int16) - want.astype(np.int16))
+    assert d.max() <= 1, f"FMA mode outside +-1 LSB (max {d.max()})"
+    assert (d > 0).mean() < 1e-3
+    # EXACT mode reproduces the oracle's rounding sequence: no differences at all
+    out_e, _ = _up(nsc, "lanczos3", img, 2 * w, 2 * h, lanczos_mode="exact")
+    assert np.array_equal(out_e, want)
+    # the general kernel agrees with the fast one (same weights, same op order)
+    out_g, ug = _up(nsc, "lanczos3", img, 2 * w, 2 * h, lanczos_mode="exact", options={"force_general": 1})
+    assert ug.kernel_variant == "lanczos3_general" and np.array_equal(out_g, want)
+    # every rows-per-wave split produces the same image
+    for th in (1, 5, 7, 8, 23):
+        out_t, _ = _up(nsc, "lanczos3", img, 2 * w, 2 * h, lanczos_mode="exact", options={"rows_per_wave": th})
+        assert np.array_equal(out_t, want), th
+
+
+@pytest.mark.parametrize("dims", GENERAL + [((12, 9), (24, 18)), ((100, 40), (30, 12))])
+def test_lanczos_general(nsc, oracle_mod, dims):
+    (w, h), (ow, oh) = dims
+    img = oracle_mod.gen_noise(w, h, 16)
+    want = oracle_mod.lanczos3(img, ow, oh)
+    out, _ = _up(nsc, "lanczos3", img, ow, oh)
+    assert _maxdiff(out, want) <= 1
+    out_e, _ = _up(nsc, "lanczos3", img, ow, oh, lanczos_mode="exact")
+    assert np.array_equal(out_e, want)
+
+
+def test_lanczos_unsupported_ratio_errors(nsc, oracle_mod):
+    u = nsc.PyWgpuUpscaler("quality", "lanczos3")
+    with pytest.raises(RuntimeError, match="exceeds 32 taps"):
+        u.initialize(1000, 8, 100, 8)
+
+
+# ---- the reference's own fixtures, through the GPU ----------------------------------
+
+def test_reference_bilinear_fixture(nsc, golden):
+    for variant in ("cpu", "wgsl"):
+        out, _ = _up(nsc, "bilinear", golden["test_input"], 640, 480, bilinear_variant=variant)
+        assert np.array_equal(out[:240, :320], golden["test_output"][:240, :320])
+
+
+def test_reference_interp_fixture(nsc, oracle_mod, golden):
+    a = oracle_mod.gen_box(64, 64, (255, 0, 0, 255))
+    b = oracle_mod.gen_box(64, 64, (0, 0, 255, 255))
+    it = nsc.WgpuFrameInterpolator()
+    assert it.get_last_gpu_duration_ms() is None
+    out = np.frombuffer(it.interpolate_py(a.tobytes(), b.tobytes(), 64, 64, time_t=0.5), np.uint8).reshape(64, 64, 4)
+    assert np.array_equal(out, golden["interp_half"])
+    assert it.get_last_gpu_duration_ms() is not None
+
+
+def test_committed_oracle_vectors(nsc):
+    v = np.load(os.path.join(GOLDEN, "oracle_vectors.npz"))
+    noise = v["noise_48x27"]
+    for name, (ow, oh) in {"x2": (96, 54), "x1p5": (72, 41), "down": (20, 11)}.items():
+        assert np.array_equal(_up(nsc, "nearest", noise, ow, oh)[0], v[f"nearest_{name}"])
+        assert np.array_equal(_up(nsc, "bilinear", noise, ow, oh)[0], v[f"bilinear_{name}"])
+        assert np.array_equal(_up(nsc, "bilinear", noise, ow, oh, bilinear_variant="wgsl")[0], v[f"bilinear_wgsl_{name}"])
+        assert _maxdiff(_up(nsc, "lanczos3", noise, ow, oh)[0], v[f"lanczos3_{name}"]) <= 1
+    it = nsc.WgpuFrameInterpolator()
+    a, b, flow = v["warp_a"], v["warp_b"], v["warp_flow"]
+    h, w = a.shape[:2]
+    for key, fl, t in (("warp_zero_t050", None, 0.5), ("warp_zero_t030", None, 0.3), ("warp_flow_t050", flow, 0.5),
+                       ("warp_flow_t025", flow, 0.25)):
+        out = np.frombuffer(it.interpolate_py(a.tobytes(), b.tobytes(), w, h, time_t=t, flow=fl), np.uint8).reshape(h, w, 4)
+        assert np.array_equal(out, v[key]), key
+
+
+# ---- warp + blend ---------------------------------------------------------------------
+
+@pytest.mark.parametrize("size", [(64, 48), (61, 7), (1, 1), (256, 4), (130, 33)])
+@pytest.mark.parametrize("t", [0.5, 0.0, 1.0, 0.3])
+def test_warp_blend_vs_oracle(nsc, oracle_mod, size, t):
+    w, h = size
+    a = oracle_mod.gen_noise(w, h, 21)
+    b = oracle_mod.gen_noise(w, h, 22)
+    rng = np.random.default_rng(w * 1000 + h)
+    flow = (rng.standard_normal((h, w, 2)) * 5).astype(np.float32)
+    flow[0, 0] = (1000.0, -1000.0)  # far outside: exercises the clamp
+    it = nsc.WgpuFrameInterpolator("16x16")
+    for fl in (None, flow):
+        out = np.frombuffer(it.interpolate_py(a.tobytes(), b.tobytes(), w, h, time_t=t, flow=fl), np.uint8).reshape(h, w, 4)
+        want = oracle_mod.warp_blend(a, b, fl, t)
+        assert np.array_equal(out, want), (size, t, fl is not None, _maxdiff(out, want))
+    if t == 0.0:
+        assert np.array_equal(out if fl is None else np.frombuffer(it.interpolate_py(a.tobytes(), b.tobytes(), w, h, time_t=0.0), np.uint8).reshape(h, w, 4), a)
+
+
+def test_warp_constant_flow_recovers_shifted_stream(nsc, oracle_mod):
+    """Stream frames k and k+1 differ by a 1 px shift; with the true constant flow the
+    in-between frame at t=0.5 is the half-pixel shift of frame k (away from the wrap column)."""
+    w, h = 128, 16
+    a = oracle_mod.gen_gradient(w, h, 10)
+    b = oracle_mod.gen_gradient(w, h, 11)
+    # content moves left by one pixel per frame: A(x) = B(x-1)  =>  flow = (-1, 0)
+    flow = np.zeros((h, w, 2), np.float32)
+    flow[..., 0] = -1.0
+    it = nsc.WgpuFrameInterpolator()
+    out = np.frombuffer(it.interpolate_py(a.tobytes(), b.tobytes(), w, h, time_t=0.5, flow=flow), np.uint8).reshape(h, w, 4)
+    assert np.array_equal(out, oracle_mod.warp_blend(a, b, flow, 0.5))
+
+
+def test_interp_size_mismatch_raises_valueerror(nsc):
+    it = nsc.WgpuFrameInterpolator()
+    with pytest.raises(ValueError, match="Expected 64 bytes per frame for 4x4x4 RGBA"):
+        it.interpolate_py(b"\0" * 64, b"\0" * 63, 4, 4)
+
+
+# ---- host API behaviour on the GPU -----------------------------------------------------
+
+def test_upscale_errors_and_reinit(nsc, oracle_mod):
+    u = nsc.PyWgpuUpscaler("quality", "bilinear")
+    u.initialize(8, 8, 16, 16)
+    with pytest.raises(RuntimeError, match=r"Input data size \(12\) does not match expected input buffer size \(256 for 8x8\)"):
+        u.upscale(b"\0" * 12)
+    img = oracle_mod.gen_noise(8, 8, 5)
+    assert np.array_equal(np.frombuffer(u.upscale(img.tobytes()), np.uint8).reshape(16, 16, 4), oracle_mod.bilinear(img, 16, 16))
+    u.initialize(10, 6, 25, 9)  # re-init with new dimensions (upscale/mod.rs:883-889)
+    assert abs(u.upscale_scale - (2.5 + 1.5) / 2) < 1e-6
+    img = oracle_mod.gen_noise(10, 6, 6)
+    assert np.array_equal(np.frombuffer(u.upscale(img.tobytes()), np.uint8).reshape(9, 25, 4), oracle_mod.bilinear(img, 25, 9))
+    assert u.get_last_gpu_duration_ms() is not None
+
+
+@pytest.mark.parametrize("alg", ["nearest", "bilinear", "lanczos3"])
+def test_upscale_batch_matches_single(nsc, oracle_mod, alg):
+    w, h = 96, 40
+    frames = [oracle_mod.gen_noise(w, h, 100 + i) for i in range(7)]  # > 2x the 3 pipeline slots
+    u = nsc.PyWgpuUpscaler("quality", alg, lanczos_mode="exact")
+    u.initialize(w, h, 2 * w, 2 * h)
+    outs = u.upscale_batch([f.tobytes() for f in frames])
+    ref = {"nearest": oracle_mod.nearest, "bilinear": oracle_mod.bilinear, "lanczos3": oracle_mod.lanczos3}[alg]
+    assert len(outs) == 7
+    for f, o in zip(frames, outs):
+        assert np.array_equal(np.frombuffer(o, np.uint8).reshape(2 * h, 2 * w, 4), ref(f, 2 * w, 2 * h))
+    assert u.upscale_batch([]) == []
+
+
+def test_table_export_import_roundtrip(nsc, oracle_mod):
+    img = oracle_mod.gen_noise(64, 36, 3)
+    u1 = nsc.PyWgpuUpscaler("quality", "lanczos3", lanczos_mode="exact")
+    u1.initialize(64, 36, 128, 72)
+    blob = u1.export_tables()
+    assert blob == nsc.build_tables_blob(64, 36, 128, 72)
+    u2 = nsc.PyWgpuUpscaler("quality", "lanczos3", lanczos_mode="exact")
+    u2.initialize(64, 36, 128, 72)
+    u2.import_tables(blob)
+    assert u2.kernel_variant == "lanczos3_x2_regwin"
+    assert u1.upscale(img.tobytes()) == u2.upscale(img.tobytes())
+    with pytest.raises(RuntimeError, match="different dimensions"):
+        u2.import_tables(nsc.build_tables_blob(64, 36, 96, 54))
+
+
+# ---- device-resident batched path (what the bench times) -------------------------------
+
+def test_device_batch_path_matches_host_path(nsc, oracle_mod):
+    import torch
+
+    w, h, n = 128, 24, 5
+    dev = torch.device("cuda:0")
+    frames_np = np.stack([oracle_mod.gen_noise(w, h, 200 + i) for i in range(n + 1)])
+    frames = torch.from_numpy(frames_np).to(dev)
+    for alg, ref in (("nearest", oracle_mod.nearest), ("bilinear", oracle_mod.bilinear), ("lanczos3", oracle_mod.lanczos3)):
+        u = nsc.PyWgpuUpscaler("quality", alg, lanczos_mode="exact")
+        u.initialize(w, h, 2 * w, 2 * h)
+        out = torch.zeros((n, 2 * h, 2 * w, 4), dtype=torch.uint8, device=dev)
+        u.upscale_device(frames.data_ptr(), out.data_ptr(), n, torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        got = out.cpu().numpy()
+        for i in range(n):
+            assert np.array_equal(got[i], ref(frames_np[i], 2 * w, 2 * h)), (alg, i)
+    pipe = nsc.FramePipeline(w, h, 2, "lanczos3", 0.5, lanczos_mode="exact")
+    mid, up_real, up_mid = pipe.alloc(n, dev)
+    pipe.step(frames, mid, up_real, up_mid, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    for i in range(n):
+        m = oracle_mod.warp_blend(frames_np[i], frames_np[i + 1], None, 0.5)
+        assert np.array_equal(mid[i].cpu().numpy(), m)
+        assert np.array_equal(up_real[i].cpu().numpy(), oracle_mod.lanczos3(frames_np[i], 2 * w, 2 * h))
+        assert np.array_equal(up_mid[i].cpu().numpy(), oracle_mod.lanczos3(m, 2 * w, 2 * h))
+
+
+# ---- BASELINE.json configurations at full size -----------------------------------------
+
+def test_config1_1080p_to_4k_bilinear_bit_exact(nsc, oracle_mod):
+    for img in (oracle_mod.gen_gradient(1920, 1080, 0), oracle_mod.gen_noise(1920, 1080)):
+        out, u = _up(nsc, "bilinear", img, 3840, 2160)
+        assert u.kernel_variant == "bilinear_x2_packed_u8"
+        assert np.array_equal(out, oracle_mod.bilinear(img, 3840, 2160, threads=0))
+        # size-independent property: even output samples are the input itself
+        assert np.array_equal(out[::2, ::2], img)
+
+
+def test_config0_nearest_fixture_and_full_size(nsc, oracle_mod, golden):
+    out, _ = _up(nsc, "nearest", golden["test_input"], 640, 480)
+    assert np.array_equal(out, np.repeat(np.repeat(golden["test_input"], 2, 0), 2, 1))
+    img = oracle_mod.gen_noise(1920, 1080)
+    out, _ = _up(nsc, "nearest", img, 3840, 2160)
+    assert np.array_equal(out, np.repeat(np.repeat(img, 2, 0), 2, 1))
+    img256 = oracle_mod.gen_gradient(256, 256, 0)  # the 256x256 case BASELINE.json words
+    out, _ = _up(nsc, "nearest", img256, 512, 512)
+    assert np.array_equal(out, oracle_mod.nearest(img256, 512, 512))
+
+
+def test_config2_1080p_to_4k_lanczos(nsc, oracle_mod):
+    img = oracle_mod.gen_noise(1920, 1080)
+    want = oracle_mod.lanczos3(img, 3840, 2160, threads=0)
+    out, u = _up(nsc, "lanczos3", img, 3840, 2160)
+    assert u.kernel_variant == "lanczos3_x2_regwin"
+    d = np.abs(out.astype(np.int16) - want.astype(np.int16))
+    assert d.max() <= 1 and (d > 0).mean() < 1e-3
+    out_e, _ = _up(nsc, "lanczos3", img, 3840, 2160, lanczos_mode="exact")
+    assert np.array_equal(out_e, want)
+    # size-independent properties: a constant image stays constant; range preserved
+    flat = np.full((1080, 1920, 4), 173, np.uint8)
+    out_f, _ = _up(nsc, "lanczos3", flat, 3840, 2160)
+    assert (out_f == 173).all()
+
+
+def test_config3_1080p_interpolation(nsc, oracle_mod):
+    a = oracle_mod.gen_gradient(1920, 1080, 0)
+    b = oracle_mod.gen_gradient(1920, 1080, 1)
+    it = nsc.WgpuFrameInterpolator()
+    out = np.frombuffer(it.interpolate_py(a.tobytes(), b.tobytes(), 1920, 1080, time_t=0.5), np.uint8).reshape(1080, 1920, 4)
+    want = oracle_mod.warp_blend(a, b, None, 0.5, threads=0)
+    assert _maxdiff(out, want) <= 1 and np.array_equal(out, want)
+    flow = np.zeros((1080, 1920, 2), np.float32)
+    flow[..., 0] = -1.0
+    out = np.frombuffer(it.interpolate_py(a.tobytes(), b.tobytes(), 1920, 1080, time_t=0.5, flow=flow), np.uint8).reshape(1080, 1920, 4)
+    assert np.array_equal(out, oracle_mod.warp_blend(a, b, flow, 0.5, threads=0))
+    # idempotence at the end points
+    assert it.interpolate_py(a.tobytes(), b.tobytes(), 1920, 1080, time_t=0.0) == a.tobytes()
+    assert it.interpolate_py(a.tobytes(), b.tobytes(), 1920, 1080, time_t=1.0) == b.tobytes()

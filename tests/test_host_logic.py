@@ -1,0 +1,195 @@
+"""CPU: the C-ABI library loads and exports what include/nuscaler_hip.h declares; host
+logic (tables, validation, error texts, sharding, generators) without any GPU compute."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+
+def _declared_functions():
+    src = open(os.path.join(ROOT, "include", "nuscaler_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(nus_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol(nsc):
+    L = ctypes.CDLL(nsc._capi.LIB_PATH)
+    declared = _declared_functions()
+    assert len(declared) >= 35
+    for name in declared:
+        assert hasattr(L, name), f"{name} declared in the header but not exported"
+    bound = {n for n, _, _ in nsc._capi.SIGNATURES}
+    assert bound == set(declared), f"ctypes binding out of sync: {bound ^ set(declared)}"
+    assert L.nus_abi_version() == 1
+
+
+def test_product_does_not_import_the_oracle():
+    pkg = os.path.join(ROOT, "nu_scaler_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hpp", ".hip", ".h")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert "import oracle" not in text and "from oracle" not in text and "nus_oracle" not in text, f
+
+
+def test_create_and_enums(nsc):
+    C = nsc._capi
+    L = C.lib()
+    assert not L.nus_upscaler_create(7, C.QUALITY_QUALITY)
+    assert b"unknown" in L.nus_last_error()
+    assert not L.nus_interp_create(9)
+    for tech, want in ((C.TECH_WGPU, b"WgpuBilinearUpscaler"), (C.TECH_FSR, b"WgpuNearestUpscaler"),
+                       (C.TECH_DLSS, b"WgpuNearestUpscaler"), (C.TECH_NONE, b"WgpuNearestUpscaler"),
+                       (C.TECH_FALLBACK, b"WgpuNearestUpscaler")):
+        h = L.nus_upscaler_create_for_technology(tech, C.QUALITY_ULTRA)
+        assert L.nus_upscaler_name(h) == want
+        assert L.nus_upscaler_quality(h) == C.QUALITY_ULTRA
+        assert L.nus_upscaler_set_quality(h, C.QUALITY_BALANCED) == 0 and L.nus_upscaler_quality(h) == C.QUALITY_BALANCED
+        assert L.nus_upscaler_set_quality(h, 42) == C.ERR_INVALID_ARGUMENT
+        L.nus_upscaler_destroy(h)
+    assert L.nus_status_string(C.ERR_NO_DEVICE) == b"no HIP device"
+
+
+def test_pyclass_surface_and_defaults(nsc):
+    u = nsc.PyWgpuUpscaler()
+    assert u.name == "WgpuNearestUpscaler" and u.upscale_scale == 2.0
+    assert nsc.PyWgpuUpscaler("ultra", "bilinear").name == "WgpuBilinearUpscaler"
+    assert nsc.PyWgpuUpscaler("nonsense", "nonsense").name == "WgpuNearestUpscaler"  # silent defaults
+    assert nsc.PyWgpuUpscaler("quality", "LANCZOS3").name == "HipLanczos3Upscaler"
+    with pytest.raises(ValueError, match="Scale factor must be between 1.0 and 4.0"):
+        u.upscale_scale = 4.5
+    u.upscale_scale = 3.0
+    assert u.upscale_scale == 3.0
+    for noop in (lambda: u.reload_shader("x.wgsl"), lambda: u.set_thread_count(4),
+                 lambda: u.set_buffer_pool_size(3), lambda: u.set_gpu_allocator("balanced")):
+        assert noop() is None
+    adv = nsc.create_advanced_upscaler("balanced")
+    assert adv.name == "WgpuBilinearUpscaler" and adv.get_quality_str() == "balanced" and adv.adaptive_quality
+    with pytest.raises(NotImplementedError):
+        nsc.create_fsr_upscaler("quality")
+    for k in ("QUALITY_ULTRA", "TECH_WGPU", "VENDOR_AMD"):
+        assert hasattr(nsc, k)
+
+
+def test_not_initialized_error_text(nsc):
+    u = nsc.PyWgpuUpscaler("quality", "bilinear")
+    with pytest.raises(RuntimeError, match=r"Upscaler not initialized\. Call initialize\(\) first\."):
+        u.upscale(b"\0" * 16)
+    with pytest.raises(RuntimeError, match="not initialized"):
+        u.upscale_batch([b"\0" * 16])
+    with pytest.raises(RuntimeError, match="not initialized"):
+        u.upscale_batch([])
+    assert u.get_last_gpu_duration_ms() is None and u.input_size == 0
+
+
+def test_interpolator_validation_without_gpu(nsc):
+    it = nsc.WgpuFrameInterpolator("wide")
+    assert it.get_last_gpu_duration_ms() is None
+    with pytest.raises(ValueError, match=r"Expected 64 bytes per frame for 4x4x4 RGBA, got frame_a: 60 bytes, frame_b: 64 bytes"):
+        it.interpolate_py(b"\0" * 60, b"\0" * 64, 4, 4)
+    nsc.WgpuFrameInterpolator("no-such-preset")  # defaults to Wide32x8 like the reference
+
+
+@pytest.mark.skipif(os.environ.get("NUS_EXPECT_GPU") == "1", reason="GPU box")
+def test_no_cpu_fallback(nsc):
+    """Without a HIP device the compute path must fail loudly, never fall back."""
+    if nsc.device_count() > 0:
+        pytest.skip("a HIP device is present")
+    u = nsc.PyWgpuUpscaler("quality", "nearest")
+    with pytest.raises(RuntimeError, match="no HIP device"):
+        u.initialize(8, 8, 16, 16)
+    it = nsc.WgpuFrameInterpolator()
+    with pytest.raises(RuntimeError, match="no HIP device"):
+        it.interpolate_py(b"\0" * 64, b"\0" * 64, 4, 4)
+
+
+@pytest.mark.parametrize("n_in,n_out", [(1920, 3840), (1080, 2160), (320, 640), (100, 237), (500, 200), (1000, 210),
+                                        (7, 7), (1, 5), (16, 32)])
+def test_axis_tables_match_oracle(nsc, oracle_mod, n_in, n_out):
+    L = nsc._capi.lib()
+    left = np.zeros(n_out, np.int32)
+    nt = np.zeros(n_out, np.uint32)
+    w = np.zeros((n_out, 32), np.float32)
+    r = L.nus_lanczos3_build_axis(n_in, n_out, left.ctypes.data, nt.ctypes.data, w.ctypes.data)
+    ol, on, ow = oracle_mod.resize_axis(n_in, n_out)
+    assert r == on.max()
+    assert np.array_equal(left, ol) and np.array_equal(nt, on) and np.array_equal(w, ow)
+    src = np.zeros(n_out, np.uint32)
+    assert L.nus_nearest_build_axis(n_in, n_out, src.ctypes.data) == 0
+    assert np.array_equal(src, np.minimum(np.arange(n_out, dtype=np.uint64) * n_in // n_out, n_in - 1))
+    from oracle import oracle_np as onp
+
+    for variant, clamp in ((0, True), (1, False)):
+        i0 = np.zeros(n_out, np.uint32)
+        fr = np.zeros(n_out, np.float32)
+        assert L.nus_bilinear_build_axis(n_in, n_out, variant, i0.ctypes.data, fr.ctypes.data) == 0
+        e0, _, ef = onp._bilinear_coords(n_in, n_out, clamp)
+        assert np.array_equal(i0, np.minimum(e0, n_in - 1)) and np.array_equal(fr, ef)
+
+
+def test_lanczos_axis_unsupported_ratio(nsc):
+    L = nsc._capi.lib()
+    n_out = 10
+    left = np.zeros(n_out, np.int32)
+    nt = np.zeros(n_out, np.uint32)
+    w = np.zeros((n_out, 32), np.float32)
+    assert L.nus_lanczos3_build_axis(1000, n_out, left.ctypes.data, nt.ctypes.data, w.ctypes.data) == nsc._capi.ERR_UNSUPPORTED
+
+
+def test_table_blob_roundtrip_and_validation(nsc):
+    blob = nsc.build_tables_blob(320, 240, 640, 480)
+    nsc.validate_tables_blob(blob, 320, 240, 640, 480)
+    assert blob == nsc.build_tables_blob(320, 240, 640, 480)
+    with pytest.raises(ValueError, match="different dimensions"):
+        nsc.validate_tables_blob(blob, 320, 240, 641, 480)
+    with pytest.raises(ValueError, match="truncated"):
+        nsc.validate_tables_blob(blob[:-1], 320, 240, 640, 480)
+    bad = bytearray(blob)
+    bad[0] ^= 0xFF
+    with pytest.raises(ValueError, match="magic"):
+        nsc.validate_tables_blob(bytes(bad), 320, 240, 640, 480)
+    # corrupt an index so it points outside the source axis
+    bad = bytearray(blob)
+    off = 8 + 12  # blob header + x-axis header -> first nn_src entry
+    bad[off:off + 4] = (10 ** 6).to_bytes(4, "little")
+    with pytest.raises(ValueError, match="out of range"):
+        nsc.validate_tables_blob(bytes(bad), 320, 240, 640, 480)
+
+
+def test_shard_frames_partition(nsc):
+    for n in (0, 1, 7, 300, 301):
+        for world in (1, 2, 3, 8):
+            chunks = [nsc.shard_frames(n, world, r) for r in range(world)]
+            assert sum(c for _, c in chunks) == n
+            pos = 0
+            for s, c in chunks:
+                assert s == pos
+                pos += c
+            assert max(c for _, c in chunks) - min(c for _, c in chunks) <= 1
+    with pytest.raises(ValueError):
+        nsc.shard_frames(10, 2, 2)
+
+
+def test_synthetic_generators_match_oracle(nsc, oracle_mod):
+    from nu_scaler_amd import synthetic as syn
+
+    assert np.array_equal(syn.gradient_frame(97, 33, 5), oracle_mod.gen_gradient(97, 33, 5))
+    assert np.array_equal(syn.gradient_frame(1920, 1080, 299), oracle_mod.gen_gradient(1920, 1080, 299))
+    assert np.array_equal(syn.noise_frame(31, 17, 0x5EED), oracle_mod.gen_noise(31, 17, 0x5EED))
+    assert np.array_equal(syn.box_frame(64, 64, (0, 0, 255, 255)), oracle_mod.gen_box(64, 64, (0, 0, 255, 255)))
+    import torch
+
+    s = syn.gradient_stream_torch(3, 40, 12, "cpu", first=2).numpy()
+    for k in range(3):
+        assert np.array_equal(s[k], oracle_mod.gen_gradient(40, 12, 2 + k))
+
+
+def test_pipeline_unit_accounting(nsc):
+    # 107 827 200 B and 26.9568 Mpix per unit at 1080p -> 4K
+    fb, ob = 1920 * 1080 * 4, 3840 * 2160 * 4
+    assert 3 * fb + 2 * (fb + ob) == 107_827_200
+    assert 3 * 1920 * 1080 + 2 * (1920 * 1080 + 3840 * 2160) == 26_956_800
