@@ -315,11 +315,11 @@ struct LanczosX2Args {
 
 __device__ __forceinline__ float lane_up(float v) // value of lane-1
 {
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138 /*wave_shr:1*/, 0xF, 0xF, false));
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138 /*wave_shr:1*/, 0xF, 0xF, true));
 }
 __device__ __forceinline__ float lane_down(float v) // value of lane+1
 {
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x130 /*wave_shl:1*/, 0xF, 0xF, false));
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x130 /*wave_shl:1*/, 0xF, 0xF, true));
 }
 
 __device__ __forceinline__ void cvt_row(const uint4 raw, float (&dst)[16])
