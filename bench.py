@@ -1,0 +1,207 @@
+#!/usr/bin/env python
+"""bench.py -- headline benchmark of the MI355X upscale + interpolation hot path.
+
+Workload (BASELINE.json `metric`, configs[4] sized for one GPU): a synthetic 1080p
+RGBA8 stream resident in HBM; one *unit* = one source frame k: warp+blend (k, k+1) at
+t = 0.5 into an in-between frame, then Lanczos-3 x2 of frame k and of the in-between
+frame to 3840x2160.  One *step* = one pass over the per-GPU batch of units.
+Metric: Mpixels/s, input + output pixels of every kernel counted once each
+(26.9568 Mpix per unit).
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: launched by torch.distributed.run, one rank per GPU, RCCL; frames are sharded
+   contiguously across ranks -- weak scaling, no data-path collective; the only
+   collective is the one-off broadcast of the filter tables.)
+
+Rank 0 prints ONE JSON line.  `roofline` is measured live for the dominant kernel
+(k_lanczos3_x2) with hipEvent pairs on the launch stream inside the timed region;
+`cpu_baseline` times the CPU oracle (a port of the reference's CPU algorithm -- the
+Rust reference cannot be built here) on a bounded sample of the same workload.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--units", type=int, default=300, help="source frames per GPU per step (the 300-frame stream)")
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--pattern", choices=["gradient", "noise"], default="gradient")
+    ap.add_argument("--lanczos-mode", choices=["fma", "exact"], default="fma")
+    ap.add_argument("--cpu-baseline-units", type=int, default=4, help="0 disables the CPU baseline leg")
+    ap.add_argument("--no-profile", action="store_true", help="skip the in-loop hipEvent pairs")
+    return ap.parse_args()
+
+
+def cpu_baseline(args, unit_pixels):
+    """Time the CPU oracle on a bounded sample of the same workload (single thread, as the
+    reference's BasicUpscaler runs; plus an all-cores OpenMP figure for context)."""
+    import oracle
+
+    oracle.build()
+    w, h = args.width, args.height
+    n = args.cpu_baseline_units
+    frames = [oracle.gen_gradient(w, h, k) for k in range(n + 1)]
+
+    def run(threads):
+        t0 = time.perf_counter()
+        for k in range(n):
+            mid = oracle.warp_blend(frames[k], frames[k + 1], None, 0.5, threads=threads)
+            oracle.lanczos3(frames[k], 2 * w, 2 * h, threads=threads)
+            oracle.lanczos3(mid, 2 * w, 2 * h, threads=threads)
+        return time.perf_counter() - t0
+
+    t1 = run(1)
+    cores = oracle.max_threads()
+    tn = run(0) if cores > 1 else t1
+    return {
+        "value": round(n * unit_pixels / t1 / 1e6, 3),
+        "unit": "Mpix/s",
+        "cores": 1,
+        "kind": "port",
+        "sample": f"{n} units of the same stream ({w}x{h}: zero-flow blend + 2x Lanczos-3 x2), oracle/nus_oracle.c "
+                  f"gcc -O2 -ffp-contract=off, {t1:.1f} s",
+        "all_cores": {"value": round(n * unit_pixels / tn / 1e6, 3), "cores": cores, "seconds": round(tn, 2)},
+    }
+
+
+def main():
+    args = parse_args()
+    import torch
+    import torch.distributed as dist
+
+    import nu_scaler_amd as nsc
+    from nu_scaler_amd import synthetic as syn
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    w, h = args.width, args.height
+    pipe = nsc.FramePipeline(w, h, 2, "lanczos3", 0.5, device=local_rank, lanczos_mode=args.lanczos_mode)
+    # shared LUTs: rank 0's tables to everyone (RCCL over xGMI), so all GPUs use identical weights
+    lut_bytes = nsc.broadcast_tables(pipe.upscaler, 0, dev)
+
+    # this rank's contiguous shard of the global stream, plus the overlap frame
+    n_units = args.units
+    start, count = nsc.shard_frames(n_units * world, world, rank)
+    assert count == n_units
+    gen = syn.gradient_stream_torch if args.pattern == "gradient" else None
+    frames = torch.empty((count + 1, h, w, 4), dtype=torch.uint8, device=dev)
+    for c0 in range(0, count + 1, 16):  # generate in chunks: int64 temporaries are 8x a frame
+        c1 = min(c0 + 16, count + 1)
+        if gen is not None:
+            frames[c0:c1] = gen(c1 - c0, w, h, dev, first=start + c0)
+        else:
+            frames[c0:c1] = syn.noise_stream_torch(c1 - c0, w, h, dev, seed=0x5EED + start + c0)
+    mid, up_real, up_mid = pipe.alloc(count, dev)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def barrier():
+        if world > 1:
+            dist.barrier(device_ids=[local_rank])
+
+    for _ in range(args.warmup):
+        pipe.step(frames, mid, up_real, up_mid, stream)
+    torch.cuda.synchronize()
+    profile = not args.no_profile
+    pipe.upscaler.set_profiling(profile)
+    pipe.upscaler.profile_collect()
+
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        pipe.step(frames, mid, up_real, up_mid, stream)
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+
+    launches, kernel_ms = pipe.upscaler.profile_collect() if profile else (0, 0.0)
+    pipe.upscaler.set_profiling(False)
+
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+
+    # cheap sanity check outside the timed region: the stream is a 1 px/frame shift, so
+    # the outputs must differ between units and be fully written (alpha stays 255)
+    assert int(up_real[0, ..., 3].min()) == 255 and int(up_mid[count - 1, ..., 3].min()) == 255
+
+    if rank == 0:
+        total_units = n_units * world * args.steps
+        value = total_units * pipe.unit_pixels / elapsed / 1e6
+        up_bytes = (w * h + 4 * w * h) * 4  # algorithmic bytes of one upscaled frame
+        roofline = None
+        if launches:
+            per_launch_s = kernel_ms / 1e3 / launches
+            achieved = up_bytes * count / per_launch_s / 1e9
+            roofline = {
+                "bound": "hbm", "kernel": "k_lanczos3_x2", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
+                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
+                "bytes_per_launch": up_bytes * count, "frames_per_launch": count, "launches": launches,
+                "avg_launch_ms": round(kernel_ms / launches, 4),
+                "note": "algorithmic bytes (8 294 400 R + 33 177 600 W per frame) / hipEvent time of the main "
+                        "kernel on its launch stream; traffic: see profiles/ (PMC passes are separate runs)",
+            }
+        out = {
+            "metric": "Mpixels/sec (in+out) at 1080p->4K x2 Lanczos-3 upscale + 1 interpolated frame",
+            "value": round(value, 1),
+            "unit": "Mpix/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u8 frames, f32 taps",
+            "data": "synthetic",
+            "config": {
+                "workload": f"{n_units}-frame {w}x{h} RGBA8 stream per GPU, HBM-resident: zero-flow warp+blend t=0.5 "
+                            f"(1 in-between frame per source frame) + Lanczos-3 x2 of real and in-between frame to "
+                            f"{2 * w}x{2 * h}",
+                "units_per_step_per_gpu": n_units, "pixels_per_unit": pipe.unit_pixels,
+                "algorithmic_bytes_per_unit": pipe.unit_bytes, "pattern": args.pattern,
+                "lanczos_mode": args.lanczos_mode, "kernel_variant": pipe.upscaler.kernel_variant,
+                "sharding": f"frame-parallel, contiguous shards, {world} rank(s), LUT broadcast {lut_bytes} B",
+                "frames_per_sec_per_gpu_4k_out": round(2 * n_units * args.steps / elapsed, 1),
+                "algorithmic_GBps": round(total_units * pipe.unit_bytes / elapsed / 1e9, 1),
+            },
+            "roofline": roofline,
+        }
+        if world == 1 and args.cpu_baseline_units > 0:
+            out["cpu_baseline"] = cpu_baseline(args, pipe.unit_pixels)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier(device_ids=[local_rank])
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

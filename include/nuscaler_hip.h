@@ -155,6 +155,12 @@ size_t nus_upscaler_output_size(const nus_upscaler *h); /* out_w*out_h*4 */
 const char *nus_upscaler_last_error(const nus_upscaler *h);
 /* Kernel time (hipEvent pair) of the last host-path upscale; NUS_ERR_NOT_INITIALIZED if none. */
 int nus_upscaler_last_gpu_ms(const nus_upscaler *h, double *ms_out);
+/* Device-path kernel timing.  With profiling enabled every nus_upscaler_upscale_device call
+ * brackets its main kernel launch with a hipEvent pair on the caller's stream (the Lanczos
+ * edge-column pass is outside the bracket); profile_collect waits for the recorded pairs,
+ * returns the number of launches and their summed duration, and resets the counters. */
+int nus_upscaler_set_profiling(nus_upscaler *h, int enabled);
+int nus_upscaler_profile_collect(nus_upscaler *h, uint64_t *launches, double *total_ms);
 /* Name of the kernel variant chosen at initialize (e.g. "lanczos3_x2_regwin"). */
 const char *nus_upscaler_kernel_variant(const nus_upscaler *h);
 

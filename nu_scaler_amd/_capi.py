@@ -55,6 +55,8 @@ SIGNATURES = [
     ("nus_upscaler_output_size", _sz, [_vp]),
     ("nus_upscaler_last_error", _cp, [_vp]),
     ("nus_upscaler_last_gpu_ms", _i, [_vp, _dp]),
+    ("nus_upscaler_set_profiling", _i, [_vp, _i]),
+    ("nus_upscaler_profile_collect", _i, [_vp, ctypes.POINTER(ctypes.c_uint64), _dp]),
     ("nus_upscaler_kernel_variant", _cp, [_vp]),
     ("nus_upscaler_export_tables", _i64, [_vp, _vp, _sz]),
     ("nus_upscaler_import_tables", _i, [_vp, _vp, _sz]),

@@ -135,6 +135,13 @@ int nus_upscaler_last_gpu_ms(const nus_upscaler *h, double *ms_out)
     return h->impl.last_gpu_ms(ms_out) ? NUS_OK : NUS_ERR_NOT_INITIALIZED;
 }
 
+int nus_upscaler_set_profiling(nus_upscaler *h, int enabled) { return h ? h->impl.set_profiling(enabled != 0) : null_handle(); }
+
+int nus_upscaler_profile_collect(nus_upscaler *h, uint64_t *launches, double *total_ms)
+{
+    return h ? h->impl.profile_collect(launches, total_ms) : null_handle();
+}
+
 const char *nus_upscaler_kernel_variant(const nus_upscaler *h) { return h ? h->impl.kernel_variant() : ""; }
 
 int64_t nus_upscaler_export_tables(const nus_upscaler *h, void *buf, size_t cap)

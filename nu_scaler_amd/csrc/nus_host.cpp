@@ -151,6 +151,9 @@ void HipUpscaler::release()
     for (void *p : table_allocs_) (void)hipFree(p);
     table_allocs_.clear();
     dt_ = DeviceTables();
+    for (hipEvent_t ev : prof_events_) (void)hipEventDestroy(ev);
+    prof_events_.clear();
+    prof_used_ = 0;
     for (Slot &s : slots_) {
         if (s.stream) (void)hipStreamSynchronize(s.stream);
         if (s.d_in) (void)hipFree(s.d_in);
@@ -284,7 +287,23 @@ int HipUpscaler::enqueue(const uint8_t *d_in, uint8_t *d_out, uint32_t n_frames,
     L.oh = oh_;
     L.n_frames = n_frames;
     L.stream = stream;
+    // with profiling on, bracket the main kernel (not the Lanczos edge-column pass)
+    hipEvent_t ev_begin = nullptr, ev_end = nullptr;
+    if (profiling_) {
+        if (prof_used_ + 2 > prof_events_.size()) {
+            for (int i = 0; i < 64; ++i) {
+                hipEvent_t ev;
+                NUS_HIP(hipEventCreate(&ev));
+                prof_events_.push_back(ev);
+            }
+        }
+        ev_begin = prof_events_[prof_used_];
+        ev_end = prof_events_[prof_used_ + 1];
+        prof_used_ += 2;
+        NUS_HIP(hipEventRecord(ev_begin, stream));
+    }
     hipError_t e = hipSuccess;
+    bool lanczos_edges = false;
     switch (variant_) {
     case Variant::NearestTable: e = launch_nearest_table(L, dt_); break;
     case Variant::NearestX2: e = launch_nearest_x2(L); break;
@@ -301,10 +320,41 @@ int HipUpscaler::enqueue(const uint8_t *d_in, uint8_t *d_out, uint32_t n_frames,
             th = (uint32_t)(t < 8 ? 8 : (t > 36 ? 36 : t));
         }
         e = launch_lanczos_x2(L, dt_, lanczos_exact_, th);
+        lanczos_edges = true;
         break;
     }
     }
     if (e != hipSuccess) return fail_hip(e, "kernel launch");
+    if (ev_end) NUS_HIP(hipEventRecord(ev_end, stream));
+    if (lanczos_edges) {
+        // first / last 8 output columns: renormalised edge weights, general kernel
+        e = launch_lanczos_general(L, dt_, lanczos_exact_, kLanczosX2EdgeCols);
+        if (e != hipSuccess) return fail_hip(e, "kernel launch");
+    }
+    return kOk;
+}
+
+int HipUpscaler::set_profiling(bool on)
+{
+    std::lock_guard<std::mutex> lk(mu_);
+    profiling_ = on;
+    return kOk;
+}
+
+int HipUpscaler::profile_collect(uint64_t *launches, double *total_ms)
+{
+    std::lock_guard<std::mutex> lk(mu_);
+    double sum = 0.0;
+    if (prof_used_) NUS_HIP(hipSetDevice(device_));
+    for (size_t i = 0; i + 1 < prof_used_; i += 2) {
+        NUS_HIP(hipEventSynchronize(prof_events_[i + 1]));
+        float ms = 0.0f;
+        NUS_HIP(hipEventElapsedTime(&ms, prof_events_[i], prof_events_[i + 1]));
+        sum += ms;
+    }
+    if (launches) *launches = prof_used_ / 2;
+    if (total_ms) *total_ms = sum;
+    prof_used_ = 0;
     return kOk;
 }
 

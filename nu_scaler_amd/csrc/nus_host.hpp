@@ -86,6 +86,12 @@ public:
     bool last_gpu_ms(double *ms) const;
     const char *kernel_variant() const { return variant_name(variant_); }
 
+    // Device-path kernel timing: with profiling on, every upscale_device() call brackets
+    // its main kernel launch with a hipEvent pair on the caller's stream;
+    // profile_collect() waits for them, returns launch count + summed duration, resets.
+    int set_profiling(bool on);
+    int profile_collect(uint64_t *launches, double *total_ms);
+
     int64_t export_tables(void *buf, size_t cap) const;
     int import_tables(const void *buf, size_t len);
 
@@ -124,6 +130,9 @@ private:
     Slot slots_[kSlots];
     bool have_ms_ = false;
     double last_ms_ = 0.0;
+    bool profiling_ = false;
+    std::vector<hipEvent_t> prof_events_; // begin/end pairs
+    size_t prof_used_ = 0;                // events handed out since the last collect
     std::string error_;
 };
 

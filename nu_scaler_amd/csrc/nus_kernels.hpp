@@ -53,6 +53,8 @@ hipError_t launch_bilinear_x2_int(const UpscaleLaunch &L);
 // edge_only: evaluate only the first and last `edge_cols` output columns.
 hipError_t launch_lanczos_general(const UpscaleLaunch &L, const DeviceTables &T, bool exact,
                                   uint32_t edge_cols);
+// main x2 kernel only: the first / last kLanczosX2EdgeCols output columns are NOT written;
+// follow it with launch_lanczos_general(L, T, exact, kLanczosX2EdgeCols).
 hipError_t launch_lanczos_x2(const UpscaleLaunch &L, const DeviceTables &T, bool exact,
                              uint32_t rows_per_wave);
 

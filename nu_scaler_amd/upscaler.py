@@ -157,6 +157,15 @@ class PyWgpuUpscaler:
     def set_lanczos_mode(self, mode: str) -> None:
         self._check(self._lib.nus_upscaler_set_lanczos_mode(self._h, 1 if mode == "exact" else 0))
 
+    def set_profiling(self, enabled: bool) -> None:
+        self._check(self._lib.nus_upscaler_set_profiling(self._h, int(bool(enabled))))
+
+    def profile_collect(self):
+        """(launches, total_ms) of the main-kernel hipEvent pairs recorded since the last call."""
+        n, ms = ctypes.c_uint64(), ctypes.c_double()
+        self._check(self._lib.nus_upscaler_profile_collect(self._h, ctypes.byref(n), ctypes.byref(ms)))
+        return int(n.value), float(ms.value)
+
     def get_last_gpu_duration_ms(self) -> Optional[float]:
         ms = ctypes.c_double()
         return ms.value if self._lib.nus_upscaler_last_gpu_ms(self._h, ctypes.byref(ms)) == C.OK else None
