@@ -127,6 +127,10 @@ int HipUpscaler::set_option(const char *key, int64_t value)
         force_general_ = value != 0;
         return kOk;
     }
+    if (!strcmp(key, "window_f16")) {
+        window_f16_ = value != 0;
+        return kOk;
+    }
     if (!strcmp(key, "rows_per_wave")) {
         if (value < 0 || value > 4096) return fail(kInvalidArgument, "rows_per_wave out of range");
         rows_per_wave_ = (uint32_t)value;
@@ -241,6 +245,10 @@ int HipUpscaler::upload_tables()
                 dt_.lz_wxe[j] = wx6_[(size_t)8 * 6 + j];
                 dt_.lz_wxo[j] = wx6_[(size_t)9 * 6 + j];
             }
+            for (int i = 0; i < 48; ++i) {
+                dt_.lz_wx_left[i] = wx6_[i];
+                dt_.lz_wx_right[i] = wx6_[(size_t)(ow_ - 8) * 6 + i];
+            }
         }
         break;
     }
@@ -319,7 +327,7 @@ int HipUpscaler::enqueue(const uint8_t *d_in, uint8_t *d_out, uint32_t n_frames,
             uint64_t t = rows_total / 8192;
             th = (uint32_t)(t < 8 ? 8 : (t > 36 ? 36 : t));
         }
-        e = launch_lanczos_x2(L, dt_, lanczos_exact_, th);
+        e = launch_lanczos_x2(L, dt_, lanczos_exact_, th, window_f16_);
         lanczos_edges = true;
         break;
     }
@@ -327,8 +335,8 @@ int HipUpscaler::enqueue(const uint8_t *d_in, uint8_t *d_out, uint32_t n_frames,
     if (e != hipSuccess) return fail_hip(e, "kernel launch");
     if (ev_end) NUS_HIP(hipEventRecord(ev_end, stream));
     if (lanczos_edges) {
-        // first / last 8 output columns: renormalised edge weights, general kernel
-        e = launch_lanczos_general(L, dt_, lanczos_exact_, kLanczosX2EdgeCols);
+        // first / last 8 output columns: renormalised edge weights, row-per-lane kernel
+        e = launch_lanczos_x2_edges(L, dt_, lanczos_exact_);
         if (e != hipSuccess) return fail_hip(e, "kernel launch");
     }
     return kOk;

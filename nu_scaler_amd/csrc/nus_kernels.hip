@@ -326,27 +326,57 @@ __device__ __forceinline__ float lane_down(float v) // value of lane+1
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x130 /*wave_shl:1*/, 0xF, 0xF, true));
 }
 
-__device__ __forceinline__ void cvt_row(const uint4 raw, float (&dst)[16])
-{
-    const uint32_t px[4] = {raw.x, raw.y, raw.z, raw.w};
+typedef __fp16 half2_t __attribute__((ext_vector_type(2)));
+
+// The 7-row register window of one lane: 4 input columns x 4 channels per row.
+// WIN16 = false: 16 f32 VGPRs per row.  WIN16 = true: 8 VGPRs per row holding the values
+// as packed f16 (u8 values are exact in f16); the vertical taps then issue as
+// v_fma_mix_f32 (f16 source, f32 weight and accumulator) -- bit-identical results,
+// 56 fewer VGPRs, one more wave per SIMD.
+template <bool WIN16>
+struct Window;
+
+template <>
+struct Window<false> {
+    float v[7][16];
+    __device__ __forceinline__ float get(int slot, int k) const { return v[slot][k]; }
+    __device__ __forceinline__ void set_row(int slot, const uint4 raw)
+    {
+        const uint32_t px[4] = {raw.x, raw.y, raw.z, raw.w};
 #pragma unroll
-    for (int m = 0; m < 4; ++m)
+        for (int m = 0; m < 4; ++m)
 #pragma unroll
-        for (int c = 0; c < 4; ++c) dst[m * 4 + c] = ch_f32(px[m], c);
-}
+            for (int c = 0; c < 4; ++c) v[slot][m * 4 + c] = ch_f32(px[m], c);
+    }
+};
+
+template <>
+struct Window<true> {
+    half2_t v[7][8];
+    __device__ __forceinline__ float get(int slot, int k) const { return (float)v[slot][k >> 1][k & 1]; }
+    __device__ __forceinline__ void set_row(int slot, const uint4 raw)
+    {
+        const uint32_t px[4] = {raw.x, raw.y, raw.z, raw.w};
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            v[slot][m * 2 + 0] = __builtin_amdgcn_cvt_pkrtz(ch_f32(px[m], 0), ch_f32(px[m], 1));
+            v[slot][m * 2 + 1] = __builtin_amdgcn_cvt_pkrtz(ch_f32(px[m], 2), ch_f32(px[m], 3));
+        }
+    }
+};
 
 // One output row (phase 0: row 2r from window slots S..S+5; phase 1: row 2r+1 from
 // slots S+1..S+6) of the lane's 8 output pixels.
-template <bool EXACT, int S, int PHASE>
-__device__ __forceinline__ void lanczos_x2_row(const float (&win)[7][16], const float *__restrict__ wv,
+template <bool EXACT, bool WIN16, int S, int PHASE>
+__device__ __forceinline__ void lanczos_x2_row(const Window<WIN16> &win, const float *__restrict__ wv,
                                                const LanczosX2Args &A, uint32_t *dst, bool do_store)
 {
     float V[16];
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
-        float acc = win[(S + PHASE) % 7][k] * wv[0];
+        float acc = EXACT ? win.get((S + PHASE) % 7, k) * wv[0] : __builtin_fmaf(win.get((S + PHASE) % 7, k), wv[0], 0.0f);
 #pragma unroll
-        for (int j = 1; j < 6; ++j) acc = mac<EXACT>(acc, win[(S + PHASE + j) % 7][k], wv[j]);
+        for (int j = 1; j < 6; ++j) acc = mac<EXACT>(acc, win.get((S + PHASE + j) % 7, k), wv[j]);
         V[k] = acc;
     }
     uint32_t o[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -382,17 +412,17 @@ __device__ __forceinline__ void lanczos_x2_row(const float (&win)[7][16], const 
     }
 }
 
-template <bool EXACT, int S>
-__device__ __forceinline__ void lanczos_x2_step(float (&win)[7][16], uint4 &raw, int r, int c, int cl,
+template <bool EXACT, bool WIN16, int S>
+__device__ __forceinline__ void lanczos_x2_step(Window<WIN16> &win, uint4 &raw, int r, int c, int cl,
                                                 bool do_store, const LanczosX2Args &A,
                                                 const uint8_t *src, uint8_t *dstf)
 {
     const uint32_t ow = A.iw * 2;
     uint32_t *d0 = reinterpret_cast<uint32_t *>(dstf) + (size_t)(2 * r) * ow + 2 * c;
-    lanczos_x2_row<EXACT, S, 0>(win, A.wy6 + (size_t)(2 * r) * 6, A, d0, do_store);
-    lanczos_x2_row<EXACT, S, 1>(win, A.wy6 + (size_t)(2 * r + 1) * 6, A, d0 + ow, do_store);
+    lanczos_x2_row<EXACT, WIN16, S, 0>(win, A.wy6 + (size_t)(2 * r) * 6, A, d0, do_store);
+    lanczos_x2_row<EXACT, WIN16, S, 1>(win, A.wy6 + (size_t)(2 * r + 1) * 6, A, d0 + ow, do_store);
     // input row r-3 (slot S) is dead: replace it by row r+4, then fetch row r+5.
-    cvt_row(raw, win[S % 7]);
+    win.set_row(S % 7, raw);
     int rn = r + 5;
     rn = rn < (int)A.ih - 1 ? rn : (int)A.ih - 1;
     raw = *reinterpret_cast<const uint4 *>(src + ((size_t)rn * A.iw + cl) * 4);
@@ -400,15 +430,15 @@ __device__ __forceinline__ void lanczos_x2_step(float (&win)[7][16], uint4 &raw,
 
 // Exact x2 Lanczos-3.  One wave owns a strip of 256 input columns (4 per lane; lanes 0
 // and 63 are halo lanes, lanes 1..62 produce 248 input = 496 output columns) and walks
-// `th` input rows, keeping a 7-row f32 window of its columns in registers:
+// `th` input rows, keeping a 7-row window of its columns in registers:
 //   vertical pass  : 6 taps from the register window (weights wave-uniform, in SGPRs)
 //   horizontal pass: 6 taps over the lane's own 4 columns + 3 columns from each
 //                    neighbouring lane, fetched with wave_shr/wave_shl DPP moves
 // so every input byte is read once per strip-row-block and no LDS round trip or
 // barrier is needed.  Output: 2 x 16-B stores per lane per output row (2 KiB per wave).
 // The 8 left-most and right-most output columns (renormalised edge weights) are left
-// to k_lanczos_general.
-template <bool EXACT>
+// to k_lanczos3_x2_edges.
+template <bool EXACT, bool WIN16>
 __global__ __launch_bounds__(256) void k_lanczos3_x2(const LanczosX2Args A)
 {
     const int lane = threadIdx.x & (kWave - 1);
@@ -426,12 +456,12 @@ __global__ __launch_bounds__(256) void k_lanczos3_x2(const LanczosX2Args A)
     const int r_end = (r0 + (int)A.th) < (int)A.ih ? (r0 + (int)A.th) : (int)A.ih;
     const int rmax = (int)A.ih - 1;
 
-    float win[7][16];
+    Window<WIN16> win;
 #pragma unroll
     for (int j = 0; j < 7; ++j) {
         int rr = r0 - 3 + j;
         rr = rr < 0 ? 0 : (rr > rmax ? rmax : rr);
-        cvt_row(*reinterpret_cast<const uint4 *>(src + ((size_t)rr * A.iw + cl) * 4), win[j]);
+        win.set_row(j, *reinterpret_cast<const uint4 *>(src + ((size_t)rr * A.iw + cl) * 4));
     }
     uint4 raw;
     {
@@ -441,14 +471,113 @@ __global__ __launch_bounds__(256) void k_lanczos3_x2(const LanczosX2Args A)
     }
     for (int rbase = r0; rbase < r_end; rbase += 7) {
         // 7-way unrolled so the rotating window indices are compile-time constants.
-        if (rbase + 0 < r_end) lanczos_x2_step<EXACT, 0>(win, raw, rbase + 0, c, cl, do_store, A, src, dstf);
-        if (rbase + 1 < r_end) lanczos_x2_step<EXACT, 1>(win, raw, rbase + 1, c, cl, do_store, A, src, dstf);
-        if (rbase + 2 < r_end) lanczos_x2_step<EXACT, 2>(win, raw, rbase + 2, c, cl, do_store, A, src, dstf);
-        if (rbase + 3 < r_end) lanczos_x2_step<EXACT, 3>(win, raw, rbase + 3, c, cl, do_store, A, src, dstf);
-        if (rbase + 4 < r_end) lanczos_x2_step<EXACT, 4>(win, raw, rbase + 4, c, cl, do_store, A, src, dstf);
-        if (rbase + 5 < r_end) lanczos_x2_step<EXACT, 5>(win, raw, rbase + 5, c, cl, do_store, A, src, dstf);
-        if (rbase + 6 < r_end) lanczos_x2_step<EXACT, 6>(win, raw, rbase + 6, c, cl, do_store, A, src, dstf);
+        if (rbase + 0 < r_end) lanczos_x2_step<EXACT, WIN16, 0>(win, raw, rbase + 0, c, cl, do_store, A, src, dstf);
+        if (rbase + 1 < r_end) lanczos_x2_step<EXACT, WIN16, 1>(win, raw, rbase + 1, c, cl, do_store, A, src, dstf);
+        if (rbase + 2 < r_end) lanczos_x2_step<EXACT, WIN16, 2>(win, raw, rbase + 2, c, cl, do_store, A, src, dstf);
+        if (rbase + 3 < r_end) lanczos_x2_step<EXACT, WIN16, 3>(win, raw, rbase + 3, c, cl, do_store, A, src, dstf);
+        if (rbase + 4 < r_end) lanczos_x2_step<EXACT, WIN16, 4>(win, raw, rbase + 4, c, cl, do_store, A, src, dstf);
+        if (rbase + 5 < r_end) lanczos_x2_step<EXACT, WIN16, 5>(win, raw, rbase + 5, c, cl, do_store, A, src, dstf);
+        if (rbase + 6 < r_end) lanczos_x2_step<EXACT, WIN16, 6>(win, raw, rbase + 6, c, cl, do_store, A, src, dstf);
     }
+}
+
+// Edge columns of the exact-x2 Lanczos-3: the 8 left-most and 8 right-most output columns,
+// whose tap windows are cut by the image border (weights renormalised over the taps
+// that remain).  Here lanes map to input ROWS: each lane produces the 8x2 output pixels
+// of its row pair from a 7-row x 8-column input patch, so the horizontal weights are
+// wave-uniform (kernel arguments -> SGPRs) and the vertical weights per lane.
+struct LanczosX2EdgeArgs {
+    const uint8_t *in;
+    uint8_t *out;
+    const float *wy6;
+    float wx[2][48]; // [side][output column 0..7 of that side][tap 0..5], phase frame, 0 outside the image
+    uint32_t iw, ih;
+    size_t in_frame_bytes, out_frame_bytes;
+};
+
+__device__ __forceinline__ uint32_t px_of(const uint4 (&row)[2], int col)
+{
+    const uint4 &v = row[col >> 2];
+    switch (col & 3) {
+    case 0: return v.x;
+    case 1: return v.y;
+    case 2: return v.z;
+    default: return v.w;
+    }
+}
+
+template <bool EXACT, int SIDE>
+__device__ __forceinline__ void lanczos_x2_edge_rows(const LanczosX2EdgeArgs &A, const uint4 (&raw)[7][2], int r,
+                                                     uint32_t *dst_frame)
+{
+    const uint32_t ow = A.iw * 2;
+#pragma unroll
+    for (int phase = 0; phase < 2; ++phase) {
+        const uint32_t oy = 2 * (uint32_t)r + phase;
+        const float *wvp = A.wy6 + (size_t)oy * 6;
+        float wv[6];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) wv[j] = wvp[j];
+        float V[8][4];
+#pragma unroll
+        for (int col = 0; col < 8; ++col)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                float acc = ch_f32(px_of(raw[phase], col), c) * wv[0];
+#pragma unroll
+                for (int j = 1; j < 6; ++j) acc = mac<EXACT>(acc, ch_f32(px_of(raw[phase + j], col), c), wv[j]);
+                V[col][c] = acc;
+            }
+        uint32_t o[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            // patch-local column of tap 0: left side base = (q>>1) - 3 + (q&1);
+            // right side (patch starts at iw-8, outputs start at k = iw-4): 1 + (q>>1) + (q&1)
+            const int l0 = SIDE == 0 ? (q >> 1) - 3 + (q & 1) : 1 + (q >> 1) + (q & 1);
+            uint32_t px = 0;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                float acc = 0.0f;
+#pragma unroll
+                for (int j = 0; j < 6; ++j) {
+                    int li = l0 + j;
+                    li = li < 0 ? 0 : (li > 7 ? 7 : li); // taps outside the image carry weight 0
+                    const float w = A.wx[SIDE][q * 6 + j];
+                    acc = j == 0 ? V[li][c] * w : mac<EXACT>(acc, V[li][c], w);
+                }
+                px = pack_u8<EXACT>(acc, c, px);
+            }
+            o[q] = px;
+        }
+        uint32_t *d = dst_frame + (size_t)oy * ow + (SIDE == 0 ? 0 : ow - 8);
+        *reinterpret_cast<uint4 *>(d) = make_uint4(o[0], o[1], o[2], o[3]);
+        *reinterpret_cast<uint4 *>(d + 4) = make_uint4(o[4], o[5], o[6], o[7]);
+    }
+}
+
+template <bool EXACT>
+__global__ __launch_bounds__(64) void k_lanczos3_x2_edges(const LanczosX2EdgeArgs A)
+{
+    const int r = (int)(blockIdx.x * kWave + threadIdx.x);
+    if (r >= (int)A.ih) return;
+    const int side = blockIdx.y; // 0: left, 1: right (wave-uniform)
+    const int col0 = side ? (int)A.iw - 8 : 0;
+    const int rmax = (int)A.ih - 1;
+    const uint8_t *src = A.in + (size_t)blockIdx.z * A.in_frame_bytes;
+    uint32_t *dst = reinterpret_cast<uint32_t *>(A.out + (size_t)blockIdx.z * A.out_frame_bytes);
+    uint4 raw[7][2];
+#pragma unroll
+    for (int j = 0; j < 7; ++j) {
+        int rr = r - 3 + j;
+        rr = rr < 0 ? 0 : (rr > rmax ? rmax : rr);
+        const uint4 *p = reinterpret_cast<const uint4 *>(src + ((size_t)rr * A.iw + col0) * 4);
+        raw[j][0] = p[0];
+        raw[j][1] = p[1];
+    }
+    if (side == 0)
+        lanczos_x2_edge_rows<EXACT, 0>(A, raw, r, dst);
+    else
+        lanczos_x2_edge_rows<EXACT, 1>(A, raw, r, dst);
 }
 
 // ---------------------------------------------------------------------------------
@@ -643,7 +772,7 @@ hipError_t launch_lanczos_general(const UpscaleLaunch &L, const DeviceTables &T,
     });
 }
 
-hipError_t launch_lanczos_x2(const UpscaleLaunch &L, const DeviceTables &T, bool exact, uint32_t rows_per_wave)
+hipError_t launch_lanczos_x2(const UpscaleLaunch &L, const DeviceTables &T, bool exact, uint32_t rows_per_wave, bool win16)
 {
     LanczosX2Args A;
     A.wy6 = T.lz_wy6;
@@ -663,12 +792,39 @@ hipError_t launch_lanczos_x2(const UpscaleLaunch &L, const DeviceTables &T, bool
         A.in = in;
         A.out = out;
         const dim3 block(256), grid(cdiv(nwaves, 4), n);
-        if (exact)
-            hipLaunchKernelGGL(k_lanczos3_x2<true>, grid, block, 0, L.stream, A);
+        if (exact && win16)
+            hipLaunchKernelGGL((k_lanczos3_x2<true, true>), grid, block, 0, L.stream, A);
+        else if (exact)
+            hipLaunchKernelGGL((k_lanczos3_x2<true, false>), grid, block, 0, L.stream, A);
+        else if (win16)
+            hipLaunchKernelGGL((k_lanczos3_x2<false, true>), grid, block, 0, L.stream, A);
         else
-            hipLaunchKernelGGL(k_lanczos3_x2<false>, grid, block, 0, L.stream, A);
+            hipLaunchKernelGGL((k_lanczos3_x2<false, false>), grid, block, 0, L.stream, A);
     });
     return e;
+}
+
+hipError_t launch_lanczos_x2_edges(const UpscaleLaunch &L, const DeviceTables &T, bool exact)
+{
+    LanczosX2EdgeArgs A;
+    A.wy6 = T.lz_wy6;
+    for (int i = 0; i < 48; ++i) {
+        A.wx[0][i] = T.lz_wx_left[i];
+        A.wx[1][i] = T.lz_wx_right[i];
+    }
+    A.iw = L.iw;
+    A.ih = L.ih;
+    A.in_frame_bytes = (size_t)L.iw * L.ih * 4;
+    A.out_frame_bytes = (size_t)L.ow * L.oh * 4;
+    return for_frame_chunks(L, [&](const uint8_t *in, uint8_t *out, uint32_t n) {
+        A.in = in;
+        A.out = out;
+        const dim3 block(kWave), grid(cdiv(L.ih, kWave), 2, n);
+        if (exact)
+            hipLaunchKernelGGL(k_lanczos3_x2_edges<true>, grid, block, 0, L.stream, A);
+        else
+            hipLaunchKernelGGL(k_lanczos3_x2_edges<false>, grid, block, 0, L.stream, A);
+    });
 }
 
 hipError_t launch_warp_blend(const WarpLaunch &L)

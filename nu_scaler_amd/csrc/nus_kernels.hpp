@@ -24,6 +24,7 @@ struct DeviceTables {
     // lanczos x2 fast path: per-output-row weights in the 6-tap phase frame [oh][6]
     const float *lz_wy6 = nullptr;
     float lz_wxe[6] = {0}, lz_wxo[6] = {0}; // interior horizontal weights, even / odd outputs
+    float lz_wx_left[48] = {0}, lz_wx_right[48] = {0}; // phase-frame weights of the 8 edge outputs per side
 };
 
 struct UpscaleLaunch {
@@ -54,9 +55,11 @@ hipError_t launch_bilinear_x2_int(const UpscaleLaunch &L);
 hipError_t launch_lanczos_general(const UpscaleLaunch &L, const DeviceTables &T, bool exact,
                                   uint32_t edge_cols);
 // main x2 kernel only: the first / last kLanczosX2EdgeCols output columns are NOT written;
-// follow it with launch_lanczos_general(L, T, exact, kLanczosX2EdgeCols).
+// follow it with launch_lanczos_x2_edges(L, T, exact).
 hipError_t launch_lanczos_x2(const UpscaleLaunch &L, const DeviceTables &T, bool exact,
-                             uint32_t rows_per_wave);
+                             uint32_t rows_per_wave, bool win16);
+
+hipError_t launch_lanczos_x2_edges(const UpscaleLaunch &L, const DeviceTables &T, bool exact);
 
 constexpr uint32_t kLanczosX2EdgeCols = 8; // output columns left to the general kernel per side
 constexpr uint32_t kLanczosX2StripCols = 248; // input columns produced per wave (62 lanes x 4)

@@ -24,8 +24,9 @@ __global__ void k_dpp(int *up, int *down)
 }
 
 template <int MODE>
-__global__ __launch_bounds__(256) void k_valu(float *out, float a, float b, int iters)
+__global__ __launch_bounds__(256) void k_valu(float *out, float a, float b, int iters, unsigned long long *clk)
 {
+    const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
     float x0 = threadIdx.x, x1 = x0 + 1, x2 = x0 + 2, x3 = x0 + 3, x4 = x0 + 4, x5 = x0 + 5, x6 = x0 + 6, x7 = x0 + 7;
     typedef float float2v __attribute__((ext_vector_type(2)));
     float2v p0 = {x0, x1}, p1 = {x2, x3}, p2 = {x4, x5}, p3 = {x6, x7};
@@ -74,6 +75,34 @@ __global__ __launch_bounds__(256) void k_valu(float *out, float a, float b, int 
                          "v_cvt_pk_u8_f32 %0, %1, 0, %0\n v_cvt_pk_u8_f32 %0, %2, 1, %0\n v_cvt_pk_u8_f32 %0, %3, 2, %0\n v_cvt_pk_u8_f32 %0, %4, 3, %0"
                          : "+v"(u) : "v"(x1), "v"(x2), "v"(x3), "v"(x4));
             x0 = __uint_as_float(u);
+        } else if (MODE == 7) { // 8 v_fma_mix_f32, f16 low-half source
+            asm volatile("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "+v"(x0) : "v"(x7), "v"(a));
+            asm volatile("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "+v"(x1) : "v"(x7), "v"(a));
+            asm volatile("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "+v"(x2) : "v"(x7), "v"(a));
+            asm volatile("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "+v"(x3) : "v"(x7), "v"(a));
+            asm volatile("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(x4) : "v"(x7), "v"(a));
+            asm volatile("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(x5) : "v"(x7), "v"(a));
+            asm volatile("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(x6) : "v"(x7), "v"(a));
+            asm volatile("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(x3) : "v"(x7), "v"(a));
+        } else if (MODE == 8) { // 8 v_fmac_f32 with an SGPR weight (the kernel's real form)
+            asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(x0) : "s"(a), "v"(x7));
+            asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(x1) : "s"(a), "v"(x7));
+            asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(x2) : "s"(a), "v"(x7));
+            asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(x3) : "s"(a), "v"(x7));
+            asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(x4) : "s"(a), "v"(x7));
+            asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(x5) : "s"(a), "v"(x7));
+            asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(x6) : "s"(a), "v"(x7));
+            asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(x2) : "s"(b), "v"(x7));
+        } else if (MODE == 9) { // 8 v_cvt_f32_ubyte
+            unsigned u = __float_as_uint(x7);
+            asm volatile("v_cvt_f32_ubyte0 %0, %1" : "=v"(x0) : "v"(u));
+            asm volatile("v_cvt_f32_ubyte1 %0, %1" : "=v"(x1) : "v"(u));
+            asm volatile("v_cvt_f32_ubyte2 %0, %1" : "=v"(x2) : "v"(u));
+            asm volatile("v_cvt_f32_ubyte3 %0, %1" : "=v"(x3) : "v"(u));
+            asm volatile("v_cvt_f32_ubyte0 %0, %1" : "=v"(x4) : "v"(u));
+            asm volatile("v_cvt_f32_ubyte1 %0, %1" : "=v"(x5) : "v"(u));
+            asm volatile("v_cvt_f32_ubyte2 %0, %1" : "=v"(x6) : "v"(u));
+            asm volatile("v_cvt_f32_ubyte3 %0, %1" : "=v"(x7) : "v"(u));
         } else if (MODE == 6) { // 8 ds_bpermute
             int idx = ((threadIdx.x + 1) & 63) * 4;
             x0 = __int_as_float(__builtin_amdgcn_ds_bpermute(idx, __float_as_int(x0)));
@@ -85,6 +114,10 @@ __global__ __launch_bounds__(256) void k_valu(float *out, float a, float b, int 
             x6 = __int_as_float(__builtin_amdgcn_ds_bpermute(idx, __float_as_int(x6)));
             x7 = __int_as_float(__builtin_amdgcn_ds_bpermute(idx, __float_as_int(x7)));
         }
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        clk[0] = __builtin_amdgcn_s_memtime() - c0;
+        clk[1] = __builtin_amdgcn_s_memrealtime() - r0;
     }
     out[blockIdx.x * blockDim.x + threadIdx.x] = x0 + x1 + x2 + x3 + x4 + x5 + x6 + x7 + p0.x + p0.y + p1.x + p1.y + p2.x + p2.y + p3.x + p3.y;
 }
@@ -145,17 +178,25 @@ int main()
     // 2. VALU rates: 256 CUs x 8 blocks x 256 threads -> 8 waves/SIMD
     {
         float *o; CK(hipMalloc(&o, 256 * 16 * 256 * 4));
+        unsigned long long *clk; CK(hipMalloc(&clk, 16));
         const int iters = 20000;
         const double lane_ops = 8.0 * iters * 256.0 * 2048;
-        const char *names[] = {"v_fma_f32 x8", "v_pk_fma_f32 x4 (=8 fma)", "v_mul+v_add x8", "v_pk_mul+v_pk_add x4", "v_mov_dpp wave_sh x8", "v_cvt_pk_u8_f32 x8", "ds_bpermute x8"};
-        for (int occ = 0; occ < 2; ++occ) {
-            const int blocks = occ == 0 ? 2048 : 512; // 8 or 2 waves/SIMD
-            for (int m = 0; m < 7; ++m) {
+        const char *names[] = {"v_fma_f32 x8", "v_pk_fma_f32 x4 (=8 fma)", "v_mul+v_add x8", "v_pk_mul+v_pk_add x4", "v_mov_dpp wave_sh x8",
+                               "v_cvt_pk_u8_f32 x8", "ds_bpermute x8", "v_fma_mix_f32 (f16 src) x8", "v_fmac_f32 sgpr-weight x8", "v_cvt_f32_ubyteN x8"};
+        for (int occ = 0; occ < 3; ++occ) {
+            const int blocks = occ == 0 ? 2048 : (occ == 1 ? 1024 : 512); // 8 / 4 / 2 waves per SIMD
+            for (int m = 0; m < 10; ++m) {
                 float ms = 0;
-                auto run = [&](auto kern) { ms = time_ms([&] { hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), 0, 0, o, 1.0001f, 0.5f, iters); }, 3); };
-                switch (m) { case 0: run(k_valu<0>); break; case 1: run(k_valu<1>); break; case 2: run(k_valu<2>); break; case 3: run(k_valu<3>); break; case 4: run(k_valu<4>); break; case 5: run(k_valu<5>); break; case 6: run(k_valu<6>); break; }
+                auto run = [&](auto kern) { ms = time_ms([&] { hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), 0, 0, o, 1.0001f, 0.5f, iters, clk); }, 3); };
+                switch (m) { case 0: run(k_valu<0>); break; case 1: run(k_valu<1>); break; case 2: run(k_valu<2>); break; case 3: run(k_valu<3>); break;
+                             case 4: run(k_valu<4>); break; case 5: run(k_valu<5>); break; case 6: run(k_valu<6>); break; case 7: run(k_valu<7>); break;
+                             case 8: run(k_valu<8>); break; case 9: run(k_valu<9>); break; }
+                unsigned long long hc[2]; CK(hipMemcpy(hc, clk, 16, hipMemcpyDeviceToHost));
                 const double ops = lane_ops * blocks / 2048.0;
-                printf("[valu %d waves/SIMD] %-28s %8.3f ms  %7.2f T 'slots'/s (8 per iter per lane)\n", occ == 0 ? 8 : 2, names[m], ms, ops / ms / 1e9);
+                const double ghz = hc[1] ? (double)hc[0] / (double)hc[1] * 0.1 : 0.0;
+                const double cyc_per_instr = (double)hc[0] / (8.0 * iters) / (blocks / 256.0); // per SIMD: waves/SIMD = blocks/256
+                printf("[valu %d waves/SIMD] %-28s %8.3f ms  %7.2f T lane-instr/s  clock %.2f GHz  %.2f cyc per wave-instr per SIMD\n",
+                       blocks / 256, names[m], ms, ops / ms / 1e9, ghz, cyc_per_instr);
             }
         }
     }

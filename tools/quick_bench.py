@@ -40,7 +40,8 @@ def main():
     out = torch.empty((n, 2 * h, 2 * w, 4), dtype=torch.uint8, device=dev)
     print(f"frames={n} pattern={args.pattern}  (upscale: {up_bytes/1e6:.2f} MB/frame algorithmic)")
     cases = [("nearest", {}, {}), ("nearest", {}, {"force_general": 1}), ("bilinear", {}, {}), ("bilinear", {}, {"force_general": 1}),
-             ("lanczos3", {"lanczos_mode": "fma"}, {}), ("lanczos3", {"lanczos_mode": "exact"}, {})]
+             ("lanczos3", {"lanczos_mode": "fma"}, {}), ("lanczos3", {"lanczos_mode": "exact"}, {}),
+             ("lanczos3", {"lanczos_mode": "fma"}, {"window_f16": 1})]
     if args.sweep:
         for th in (4, 8, 12, 16, 24, 32, 36, 48, 64):
             cases.append(("lanczos3", {"lanczos_mode": "fma"}, {"rows_per_wave": th}))
@@ -49,9 +50,12 @@ def main():
         for k, v in opts.items():
             u.set_option(k, v)
         u.initialize(w, h, 2 * w, 2 * h)
+        u.set_profiling(True)
         ms = timed(lambda: u.upscale_device(frames.data_ptr(), out.data_ptr(), n, s), args.reps)
+        nl, kms = u.profile_collect()
         us = ms * 1e3 / n
-        print(f"{alg:9s} {u.kernel_variant:24s} {str(kw)+str(opts):48s} {us:8.2f} us/frame  {up_bytes/us/1e6:6.2f} TB/s  {100*up_bytes/us/1e6/8.0:5.1f}% of 8 TB/s", flush=True)
+        kus = kms * 1e3 / max(nl, 1) / n
+        print(f"{alg:9s} {u.kernel_variant:24s} {str(kw)+str(opts):48s} {us:8.2f} us/frame (main kernel {kus:6.2f})  {up_bytes/kus/1e6:6.2f} TB/s  {100*up_bytes/kus/1e6/8.0:5.1f}% of 8 TB/s", flush=True)
     it = nsc.WgpuFrameInterpolator()
     mid = torch.empty((n, h, w, 4), dtype=torch.uint8, device=dev)
     fb = w * h * 4
