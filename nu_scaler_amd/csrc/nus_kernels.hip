@@ -367,9 +367,44 @@ struct Window<true> {
 
 // One output row (phase 0: row 2r from window slots S..S+5; phase 1: row 2r+1 from
 // slots S+1..S+6) of the lane's 8 output pixels.
+// gfx950 issues v_fma/v_mul/v_add_f32 with VGPR-only operands at ~2.4 cycles per wave64
+// instruction, but ~4.4-5 cycles as soon as one operand is an SGPR (tools/probe_valu.hip).
+// The wave-uniform filter weights are therefore copied into VGPRs once (the asm barrier
+// keeps the compiler from folding them back into scalar operands).
+__device__ __forceinline__ float vgpr(float s)
+{
+    asm volatile("" : "+v"(s));
+    return s;
+}
+
+__device__ __forceinline__ float sgpr(float s)
+{
+    asm volatile("" : "+s"(s));
+    return s;
+}
+
+struct HWeights {
+    float e[6], o[6];
+};
+
+// Vertical weights of one step (output rows 2r and 2r+1), fetched one step ahead with
+// scalar loads and parked in SGPRs so their latency hides behind the previous step.
+struct VWeights {
+    float w[12];
+    __device__ __forceinline__ void fetch(const float *__restrict__ wy6, int r)
+    {
+        // constant address space + uniform address -> s_load_dwordx4/x8 (the table is
+        // never written by a kernel)
+        typedef const __attribute__((address_space(4))) float *cfloat_p;
+        cfloat_p p = (cfloat_p)(uintptr_t)(wy6 + (size_t)__builtin_amdgcn_readfirstlane(r) * 12);
+#pragma unroll
+        for (int j = 0; j < 12; ++j) w[j] = sgpr(p[j]);
+    }
+};
+
 template <bool EXACT, bool WIN16, int S, int PHASE>
-__device__ __forceinline__ void lanczos_x2_row(const Window<WIN16> &win, const float *__restrict__ wv,
-                                               const LanczosX2Args &A, uint32_t *dst, bool do_store)
+__device__ __forceinline__ void lanczos_x2_row(const Window<WIN16> &win, const float (&wv)[6],
+                                               const HWeights &W, uint32_t *dst, bool do_store)
 {
     float V[16];
 #pragma unroll
@@ -395,12 +430,12 @@ __device__ __forceinline__ void lanczos_x2_row(const Window<WIN16> &win, const f
         e[9] = lane_down(V[2 * 4 + c]);
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
-            float ae = e[m] * A.wxe[0];
-            float ao = e[m + 1] * A.wxo[0];
+            float ae = e[m] * W.e[0];
+            float ao = e[m + 1] * W.o[0];
 #pragma unroll
             for (int j = 1; j < 6; ++j) {
-                ae = mac<EXACT>(ae, e[m + j], A.wxe[j]);
-                ao = mac<EXACT>(ao, e[m + 1 + j], A.wxo[j]);
+                ae = mac<EXACT>(ae, e[m + j], W.e[j]);
+                ao = mac<EXACT>(ao, e[m + 1 + j], W.o[j]);
             }
             o[2 * m] = pack_u8<EXACT>(ae, c, o[2 * m]);
             o[2 * m + 1] = pack_u8<EXACT>(ao, c, o[2 * m + 1]);
@@ -414,13 +449,24 @@ __device__ __forceinline__ void lanczos_x2_row(const Window<WIN16> &win, const f
 
 template <bool EXACT, bool WIN16, int S>
 __device__ __forceinline__ void lanczos_x2_step(Window<WIN16> &win, uint4 &raw, int r, int c, int cl,
-                                                bool do_store, const LanczosX2Args &A,
-                                                const uint8_t *src, uint8_t *dstf)
+                                                bool do_store, const LanczosX2Args &A, const HWeights &W,
+                                                VWeights &VW, const uint8_t *src, uint8_t *dstf)
 {
     const uint32_t ow = A.iw * 2;
     uint32_t *d0 = reinterpret_cast<uint32_t *>(dstf) + (size_t)(2 * r) * ow + 2 * c;
-    lanczos_x2_row<EXACT, WIN16, S, 0>(win, A.wy6 + (size_t)(2 * r) * 6, A, d0, do_store);
-    lanczos_x2_row<EXACT, WIN16, S, 1>(win, A.wy6 + (size_t)(2 * r + 1) * 6, A, d0 + ow, do_store);
+    float wv0[6], wv1[6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        wv0[j] = vgpr(VW.w[j]);
+        wv1[j] = vgpr(VW.w[6 + j]);
+    }
+    {
+        int rw = r + 1; // next step's weights; the clamp only keeps the read in bounds
+        rw = rw < (int)A.ih - 1 ? rw : (int)A.ih - 1;
+        VW.fetch(A.wy6, rw);
+    }
+    lanczos_x2_row<EXACT, WIN16, S, 0>(win, wv0, W, d0, do_store);
+    lanczos_x2_row<EXACT, WIN16, S, 1>(win, wv1, W, d0 + ow, do_store);
     // input row r-3 (slot S) is dead: replace it by row r+4, then fetch row r+5.
     win.set_row(S % 7, raw);
     int rn = r + 5;
@@ -456,6 +502,12 @@ __global__ __launch_bounds__(256) void k_lanczos3_x2(const LanczosX2Args A)
     const int r_end = (r0 + (int)A.th) < (int)A.ih ? (r0 + (int)A.th) : (int)A.ih;
     const int rmax = (int)A.ih - 1;
 
+    HWeights W;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        W.e[j] = vgpr(A.wxe[j]);
+        W.o[j] = vgpr(A.wxo[j]);
+    }
     Window<WIN16> win;
 #pragma unroll
     for (int j = 0; j < 7; ++j) {
@@ -469,15 +521,17 @@ __global__ __launch_bounds__(256) void k_lanczos3_x2(const LanczosX2Args A)
         rr = rr > rmax ? rmax : rr;
         raw = *reinterpret_cast<const uint4 *>(src + ((size_t)rr * A.iw + cl) * 4);
     }
+    VWeights VW;
+    VW.fetch(A.wy6, r0);
     for (int rbase = r0; rbase < r_end; rbase += 7) {
         // 7-way unrolled so the rotating window indices are compile-time constants.
-        if (rbase + 0 < r_end) lanczos_x2_step<EXACT, WIN16, 0>(win, raw, rbase + 0, c, cl, do_store, A, src, dstf);
-        if (rbase + 1 < r_end) lanczos_x2_step<EXACT, WIN16, 1>(win, raw, rbase + 1, c, cl, do_store, A, src, dstf);
-        if (rbase + 2 < r_end) lanczos_x2_step<EXACT, WIN16, 2>(win, raw, rbase + 2, c, cl, do_store, A, src, dstf);
-        if (rbase + 3 < r_end) lanczos_x2_step<EXACT, WIN16, 3>(win, raw, rbase + 3, c, cl, do_store, A, src, dstf);
-        if (rbase + 4 < r_end) lanczos_x2_step<EXACT, WIN16, 4>(win, raw, rbase + 4, c, cl, do_store, A, src, dstf);
-        if (rbase + 5 < r_end) lanczos_x2_step<EXACT, WIN16, 5>(win, raw, rbase + 5, c, cl, do_store, A, src, dstf);
-        if (rbase + 6 < r_end) lanczos_x2_step<EXACT, WIN16, 6>(win, raw, rbase + 6, c, cl, do_store, A, src, dstf);
+        if (rbase + 0 < r_end) lanczos_x2_step<EXACT, WIN16, 0>(win, raw, rbase + 0, c, cl, do_store, A, W, VW, src, dstf);
+        if (rbase + 1 < r_end) lanczos_x2_step<EXACT, WIN16, 1>(win, raw, rbase + 1, c, cl, do_store, A, W, VW, src, dstf);
+        if (rbase + 2 < r_end) lanczos_x2_step<EXACT, WIN16, 2>(win, raw, rbase + 2, c, cl, do_store, A, W, VW, src, dstf);
+        if (rbase + 3 < r_end) lanczos_x2_step<EXACT, WIN16, 3>(win, raw, rbase + 3, c, cl, do_store, A, W, VW, src, dstf);
+        if (rbase + 4 < r_end) lanczos_x2_step<EXACT, WIN16, 4>(win, raw, rbase + 4, c, cl, do_store, A, W, VW, src, dstf);
+        if (rbase + 5 < r_end) lanczos_x2_step<EXACT, WIN16, 5>(win, raw, rbase + 5, c, cl, do_store, A, W, VW, src, dstf);
+        if (rbase + 6 < r_end) lanczos_x2_step<EXACT, WIN16, 6>(win, raw, rbase + 6, c, cl, do_store, A, W, VW, src, dstf);
     }
 }
 

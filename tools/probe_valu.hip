@@ -1,0 +1,123 @@
+// probe_valu.hip -- classify gfx950 VALU instruction forms by issue rate (wave64).
+// Every kernel runs ITERS iterations of 8 independent copies of one instruction form at
+// 8 waves/SIMD on all CUs; rate is reported as cycles per wave-instruction per SIMD at the
+// clock measured in-kernel (s_memtime / s_memrealtime).
+// Build: hipcc --offload-arch=gfx950 -O3 tools/probe_valu.hip -o tools/probe_valu
+#include <hip/hip_runtime.h>
+#include <cstdio>
+
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
+
+#define REP8(S) S(x0) S(x1) S(x2) S(x3) S(x4) S(x5) S(x6) S(x7)
+
+#define DEFK(NAME, STMT)                                                                                  \
+    __global__ __launch_bounds__(256) void NAME(float *out, float a, float b, int iters, unsigned long long *clk) \
+    {                                                                                                      \
+        const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime(); \
+        float x0 = threadIdx.x, x1 = x0 + 1, x2 = x0 + 2, x3 = x0 + 3, x4 = x0 + 4, x5 = x0 + 5, x6 = x0 + 6, x7 = x0 + 7; \
+        float va = a + threadIdx.x * 0.0f, vb = b + threadIdx.x * 0.0f;                                   \
+        unsigned u = threadIdx.x * 2654435761u;                                                            \
+        asm volatile("" : "+v"(va), "+v"(vb), "+v"(u));                                                    \
+        for (int i = 0; i < iters; ++i) { REP8(STMT) }                                                     \
+        if (blockIdx.x == 0 && threadIdx.x == 0) {                                                         \
+            clk[0] = __builtin_amdgcn_s_memtime() - c0;                                                    \
+            clk[1] = __builtin_amdgcn_s_memrealtime() - r0;                                                \
+        }                                                                                                  \
+        out[blockIdx.x * blockDim.x + threadIdx.x] = x0 + x1 + x2 + x3 + x4 + x5 + x6 + x7 + __uint_as_float(u); \
+    }
+
+#define S_FMA_VVV(X) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(X) : "v"(va), "v"(vb));
+#define S_FMAC_VV(X) asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(X) : "v"(va), "v"(vb));
+#define S_FMAC_SV(X) asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(X) : "s"(a), "v"(vb));
+#define S_FMA_SVV(X) asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(X) : "s"(a), "v"(vb));
+#define S_FMA_VVV_ACC(X) asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(X) : "v"(va), "v"(vb));
+#define S_MUL_VV(X) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(X) : "v"(va));
+#define S_MUL_SV(X) asm volatile("v_mul_f32 %0, %1, %0" : "+v"(X) : "s"(a));
+#define S_ADD_VV(X) asm volatile("v_add_f32 %0, %0, %1" : "+v"(X) : "v"(va));
+#define S_MOV(X) asm volatile("v_mov_b32 %0, %1" : "=v"(X) : "v"(va));
+#define S_AND(X) asm volatile("v_and_b32 %0, %0, %1" : "+v"(X) : "v"(u));
+#define S_LSHL(X) asm volatile("v_lshlrev_b32 %0, 1, %0" : "+v"(X));
+#define S_ADDU(X) asm volatile("v_add_u32 %0, %0, %1" : "+v"(X) : "v"(u));
+#define S_CVT_U32(X) asm volatile("v_cvt_f32_u32 %0, %1" : "=v"(X) : "v"(u));
+#define S_CVT_UB0(X) asm volatile("v_cvt_f32_ubyte0 %0, %1" : "=v"(X) : "v"(u));
+#define S_CVT_UB3(X) asm volatile("v_cvt_f32_ubyte3 %0, %1" : "=v"(X) : "v"(u));
+#define S_MED3(X) asm volatile("v_med3_f32 %0, %0, %1, %2" : "+v"(X) : "v"(va), "v"(vb));
+#define S_MAX(X) asm volatile("v_max_f32 %0, %0, %1" : "+v"(X) : "v"(va));
+#define S_PERM(X) asm volatile("v_perm_b32 %0, %0, %1, %2" : "+v"(X) : "v"(va), "v"(u));
+#define S_BFE(X) asm volatile("v_bfe_u32 %0, %1, 8, 8" : "=v"(X) : "v"(u));
+#define S_CVTPK(X) asm volatile("v_cvt_pk_u8_f32 %0, %1, 1, %0" : "+v"(X) : "v"(va));
+#define S_DPP(X) asm volatile("v_mov_b32_dpp %0, %1 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=v"(X) : "v"(va));
+#define S_DPP_ROW(X) asm volatile("v_mov_b32_dpp %0, %1 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=v"(X) : "v"(va));
+#define S_FMAC_DPP(X) asm volatile("v_fmac_f32_dpp %0, %1, %2 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(X) : "v"(va), "v"(vb));
+#define S_MIX_LO(X) asm volatile("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "+v"(X) : "v"(u), "v"(va));
+#define S_CVT_F16(X) asm volatile("v_cvt_f32_f16 %0, %1" : "=v"(X) : "v"(u));
+#define S_LERP(X) asm volatile("v_lerp_u8 %0, %0, %1, %2" : "+v"(X) : "v"(u), "v"(va));
+#define S_DOT2(X) asm volatile("v_dot2_f32_f16 %0, %1, %2, %0" : "+v"(X) : "v"(u), "v"(va));
+#define S_DOT2C(X) asm volatile("v_dot2c_f32_f16 %0, %1, %2" : "+v"(X) : "v"(u), "v"(va));
+#define S_SDWA_MUL(X) asm volatile("v_mul_f32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:DWORD" : "=v"(X) : "v"(va), "v"(vb));
+
+DEFK(k_fma_vvv, S_FMA_VVV)
+DEFK(k_fma_vvv_acc, S_FMA_VVV_ACC)
+DEFK(k_fmac_vv, S_FMAC_VV)
+DEFK(k_fmac_sv, S_FMAC_SV)
+DEFK(k_fma_svv, S_FMA_SVV)
+DEFK(k_mul_vv, S_MUL_VV)
+DEFK(k_mul_sv, S_MUL_SV)
+DEFK(k_add_vv, S_ADD_VV)
+DEFK(k_mov, S_MOV)
+DEFK(k_and, S_AND)
+DEFK(k_lshl, S_LSHL)
+DEFK(k_addu, S_ADDU)
+DEFK(k_cvt_u32, S_CVT_U32)
+DEFK(k_cvt_ub0, S_CVT_UB0)
+DEFK(k_cvt_ub3, S_CVT_UB3)
+DEFK(k_med3, S_MED3)
+DEFK(k_max, S_MAX)
+DEFK(k_perm, S_PERM)
+DEFK(k_bfe, S_BFE)
+DEFK(k_cvtpk, S_CVTPK)
+DEFK(k_dpp, S_DPP)
+DEFK(k_dpp_row, S_DPP_ROW)
+DEFK(k_fmac_dpp, S_FMAC_DPP)
+DEFK(k_mix_lo, S_MIX_LO)
+DEFK(k_cvt_f16, S_CVT_F16)
+DEFK(k_lerp, S_LERP)
+DEFK(k_dot2, S_DOT2)
+DEFK(k_dot2c, S_DOT2C)
+DEFK(k_sdwa_mul, S_SDWA_MUL)
+
+typedef void (*kern_t)(float *, float, float, int, unsigned long long *);
+
+int main()
+{
+    float *o; CK(hipMalloc(&o, 2048 * 256 * 4));
+    unsigned long long *clk; CK(hipMalloc(&clk, 16));
+    struct { const char *name; kern_t k; } ks[] = {
+        {"v_fma_f32 x,x,v,v", k_fma_vvv}, {"v_fma_f32 x,v,v,x (acc)", k_fma_vvv_acc}, {"v_fmac_f32 x,v,v", k_fmac_vv},
+        {"v_fmac_f32 x,s,v", k_fmac_sv}, {"v_fma_f32 x,s,v,x", k_fma_svv}, {"v_mul_f32 v,v", k_mul_vv}, {"v_mul_f32 s,v", k_mul_sv},
+        {"v_add_f32 v,v", k_add_vv}, {"v_mov_b32", k_mov}, {"v_and_b32", k_and}, {"v_lshlrev_b32", k_lshl}, {"v_add_u32", k_addu},
+        {"v_cvt_f32_u32", k_cvt_u32}, {"v_cvt_f32_ubyte0", k_cvt_ub0}, {"v_cvt_f32_ubyte3", k_cvt_ub3}, {"v_med3_f32", k_med3},
+        {"v_max_f32", k_max}, {"v_perm_b32", k_perm}, {"v_bfe_u32", k_bfe}, {"v_cvt_pk_u8_f32", k_cvtpk},
+        {"v_mov_b32_dpp wave_shr", k_dpp}, {"v_mov_b32_dpp row_shr", k_dpp_row}, {"v_fmac_f32_dpp row_shr", k_fmac_dpp},
+        {"v_fma_mix_f32 f16lo", k_mix_lo}, {"v_cvt_f32_f16", k_cvt_f16}, {"v_lerp_u8", k_lerp}, {"v_dot2_f32_f16", k_dot2},
+        {"v_dot2c_f32_f16", k_dot2c}, {"v_mul_f32_sdwa", k_sdwa_mul}};
+    const int iters = 20000;
+    for (int occ : {2048, 768}) { // 8 and 3 waves per SIMD
+        for (auto &e : ks) {
+            hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+            hipLaunchKernelGGL(e.k, dim3(occ), dim3(256), 0, 0, o, 1.0001f, 0.5f, 1000, clk);
+            hipDeviceSynchronize();
+            hipEventRecord(a);
+            hipLaunchKernelGGL(e.k, dim3(occ), dim3(256), 0, 0, o, 1.0001f, 0.5f, iters, clk);
+            hipEventRecord(b); hipEventSynchronize(b);
+            float ms; hipEventElapsedTime(&ms, a, b);
+            unsigned long long hc[2]; CK(hipMemcpy(hc, clk, 16, hipMemcpyDeviceToHost));
+            const double ghz = hc[1] ? (double)hc[0] / (double)hc[1] * 0.1 : 0.0;
+            const double winstr_per_simd = 8.0 * iters * (occ / 256.0);
+            const double cyc = ms * 1e-3 * ghz * 1e9 / winstr_per_simd;
+            printf("[%d waves/SIMD] %-26s %7.3f ms  clock %.2f GHz  %.2f cycles per wave-instr per SIMD  (%.1f T lane-instr/s)\n",
+                   occ / 256, e.name, ms, ghz, cyc, winstr_per_simd * 1024 * 64 / ms / 1e9);
+        }
+    }
+    return 0;
+}
