@@ -195,7 +195,7 @@ void HipUpscaler::choose_variant()
         break;
     }
     case Algorithm::Lanczos3: {
-        bool ok = x2 && iw_ >= 16;
+        bool ok = x2 && iw_ >= 16 && (uint64_t)ow_ * oh_ * 4 < (1ull << 31); // buffer-resource addressing
         ok = ok && lanczos_x2_phase_frame(tx_, wx6_) && lanczos_x2_phase_frame(ty_, wy6_) &&
              lanczos_x2_interior_uniform(tx_, wx6_);
         variant_ = ok ? Variant::LanczosX2RegWin : Variant::LanczosGeneral;

@@ -377,12 +377,6 @@ __device__ __forceinline__ float vgpr(float s)
     return s;
 }
 
-__device__ __forceinline__ float sgpr(float s)
-{
-    asm volatile("" : "+s"(s));
-    return s;
-}
-
 struct HWeights {
     float e[6], o[6];
 };
@@ -398,13 +392,13 @@ struct VWeights {
         typedef const __attribute__((address_space(4))) float *cfloat_p;
         cfloat_p p = (cfloat_p)(uintptr_t)(wy6 + (size_t)__builtin_amdgcn_readfirstlane(r) * 12);
 #pragma unroll
-        for (int j = 0; j < 12; ++j) w[j] = sgpr(p[j]);
+        for (int j = 0; j < 12; ++j) w[j] = p[j]; // consumed one step later: the s_load latency is hidden
     }
 };
 
 template <bool EXACT, bool WIN16, int S, int PHASE>
 __device__ __forceinline__ void lanczos_x2_row(const Window<WIN16> &win, const float (&wv)[6],
-                                               const HWeights &W, uint32_t *dst, bool do_store)
+                                               const HWeights &W, __amdgpu_buffer_rsrc_t rs, uint32_t off)
 {
     float V[16];
 #pragma unroll
@@ -441,19 +435,23 @@ __device__ __forceinline__ void lanczos_x2_row(const Window<WIN16> &win, const f
             o[2 * m + 1] = pack_u8<EXACT>(ao, c, o[2 * m + 1]);
         }
     }
-    if (do_store) {
-        *reinterpret_cast<uint4 *>(dst) = make_uint4(o[0], o[1], o[2], o[3]);
-        *reinterpret_cast<uint4 *>(dst + 4) = make_uint4(o[4], o[5], o[6], o[7]);
-    }
+    // Buffer stores: lanes that must not write carry an offset beyond num_records and the
+    // hardware range check drops them.  Unlike an exec-masked store behind a branch the
+    // store instructions always issue, so the compiler can count them and wait for the
+    // prefetched input row with vmcnt(4) instead of draining every store with vmcnt(0).
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    const u32x4 lo = {o[0], o[1], o[2], o[3]}, hi = {o[4], o[5], o[6], o[7]};
+    __builtin_amdgcn_raw_buffer_store_b128(lo, rs, off, 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b128(hi, rs, off + 16, 0, 0);
 }
 
 template <bool EXACT, bool WIN16, int S>
-__device__ __forceinline__ void lanczos_x2_step(Window<WIN16> &win, uint4 &raw, int r, int c, int cl,
-                                                bool do_store, const LanczosX2Args &A, const HWeights &W,
-                                                VWeights &VW, const uint8_t *src, uint8_t *dstf)
+__device__ __forceinline__ void lanczos_x2_step(Window<WIN16> &win, uint4 &raw, int r, int cl, uint32_t lane_off,
+                                                const LanczosX2Args &A, const HWeights &W, VWeights &VW,
+                                                const uint8_t *src, __amdgpu_buffer_rsrc_t rs)
 {
-    const uint32_t ow = A.iw * 2;
-    uint32_t *d0 = reinterpret_cast<uint32_t *>(dstf) + (size_t)(2 * r) * ow + 2 * c;
+    const uint32_t row_bytes = A.iw * 8; // output row: 2*iw pixels
+    const uint32_t off0 = lane_off + (uint32_t)(2 * r) * row_bytes;
     float wv0[6], wv1[6];
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
@@ -465,8 +463,8 @@ __device__ __forceinline__ void lanczos_x2_step(Window<WIN16> &win, uint4 &raw, 
         rw = rw < (int)A.ih - 1 ? rw : (int)A.ih - 1;
         VW.fetch(A.wy6, rw);
     }
-    lanczos_x2_row<EXACT, WIN16, S, 0>(win, wv0, W, d0, do_store);
-    lanczos_x2_row<EXACT, WIN16, S, 1>(win, wv1, W, d0 + ow, do_store);
+    lanczos_x2_row<EXACT, WIN16, S, 0>(win, wv0, W, rs, off0);
+    lanczos_x2_row<EXACT, WIN16, S, 1>(win, wv1, W, rs, off0 + row_bytes);
     // input row r-3 (slot S) is dead: replace it by row r+4, then fetch row r+5.
     win.set_row(S % 7, raw);
     int rn = r + 5;
@@ -497,7 +495,11 @@ __global__ __launch_bounds__(256) void k_lanczos3_x2(const LanczosX2Args A)
     cl = cl > (int)A.iw - 4 ? (int)A.iw - 4 : cl;
     const bool do_store = lane >= 1 && lane <= 62 && c >= 4 && c + 8 <= (int)A.iw;
     const uint8_t *src = A.in + (size_t)blockIdx.y * A.in_frame_bytes;
-    uint8_t *dstf = A.out + (size_t)blockIdx.y * A.out_frame_bytes;
+    // one buffer resource per output frame (< 2 GiB, checked by the host); non-storing lanes
+    // sit at offset 2^31, outside num_records for every row
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+        A.out + (size_t)blockIdx.y * A.out_frame_bytes, 0, (uint32_t)A.out_frame_bytes, 0x00020000);
+    const uint32_t lane_off = do_store ? (uint32_t)c * 8u : 0x80000000u;
     const int r0 = (int)(rb * A.th);
     const int r_end = (r0 + (int)A.th) < (int)A.ih ? (r0 + (int)A.th) : (int)A.ih;
     const int rmax = (int)A.ih - 1;
@@ -525,13 +527,13 @@ __global__ __launch_bounds__(256) void k_lanczos3_x2(const LanczosX2Args A)
     VW.fetch(A.wy6, r0);
     for (int rbase = r0; rbase < r_end; rbase += 7) {
         // 7-way unrolled so the rotating window indices are compile-time constants.
-        if (rbase + 0 < r_end) lanczos_x2_step<EXACT, WIN16, 0>(win, raw, rbase + 0, c, cl, do_store, A, W, VW, src, dstf);
-        if (rbase + 1 < r_end) lanczos_x2_step<EXACT, WIN16, 1>(win, raw, rbase + 1, c, cl, do_store, A, W, VW, src, dstf);
-        if (rbase + 2 < r_end) lanczos_x2_step<EXACT, WIN16, 2>(win, raw, rbase + 2, c, cl, do_store, A, W, VW, src, dstf);
-        if (rbase + 3 < r_end) lanczos_x2_step<EXACT, WIN16, 3>(win, raw, rbase + 3, c, cl, do_store, A, W, VW, src, dstf);
-        if (rbase + 4 < r_end) lanczos_x2_step<EXACT, WIN16, 4>(win, raw, rbase + 4, c, cl, do_store, A, W, VW, src, dstf);
-        if (rbase + 5 < r_end) lanczos_x2_step<EXACT, WIN16, 5>(win, raw, rbase + 5, c, cl, do_store, A, W, VW, src, dstf);
-        if (rbase + 6 < r_end) lanczos_x2_step<EXACT, WIN16, 6>(win, raw, rbase + 6, c, cl, do_store, A, W, VW, src, dstf);
+        if (rbase + 0 < r_end) lanczos_x2_step<EXACT, WIN16, 0>(win, raw, rbase + 0, cl, lane_off, A, W, VW, src, rs);
+        if (rbase + 1 < r_end) lanczos_x2_step<EXACT, WIN16, 1>(win, raw, rbase + 1, cl, lane_off, A, W, VW, src, rs);
+        if (rbase + 2 < r_end) lanczos_x2_step<EXACT, WIN16, 2>(win, raw, rbase + 2, cl, lane_off, A, W, VW, src, rs);
+        if (rbase + 3 < r_end) lanczos_x2_step<EXACT, WIN16, 3>(win, raw, rbase + 3, cl, lane_off, A, W, VW, src, rs);
+        if (rbase + 4 < r_end) lanczos_x2_step<EXACT, WIN16, 4>(win, raw, rbase + 4, cl, lane_off, A, W, VW, src, rs);
+        if (rbase + 5 < r_end) lanczos_x2_step<EXACT, WIN16, 5>(win, raw, rbase + 5, cl, lane_off, A, W, VW, src, rs);
+        if (rbase + 6 < r_end) lanczos_x2_step<EXACT, WIN16, 6>(win, raw, rbase + 6, cl, lane_off, A, W, VW, src, rs);
     }
 }
 
