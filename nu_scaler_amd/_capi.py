@@ -7,7 +7,8 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libnuscaler_hip.so")
+# NUS_LIB_PATH: dev override (timing-only ablation builds, tools/ablate.sh)
+LIB_PATH = os.environ.get("NUS_LIB_PATH") or os.path.join(_HERE, "lib", "libnuscaler_hip.so")
 CSRC_DIR = os.path.join(_HERE, "csrc")
 
 # nus_status

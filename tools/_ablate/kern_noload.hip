@@ -14,14 +14,9 @@
 // fused multiply-adds appear only where spelled __builtin_fmaf (Lanczos FMA mode).
 // No MFMA: no stage is a dense contraction.  Pixels are moved as one u32 each,
 // 16 bytes per lane per access wherever alignment allows.
-#include "nus_kernels.hpp"
+#include "../../nu_scaler_amd/csrc/nus_kernels.hpp"
 
 #pragma clang fp contract(off)
-
-// cache-policy bits of the output stores (0 = default, 2 = nt); tuning knob
-#ifndef NUS_STORE_AUX
-#define NUS_STORE_AUX 0
-#endif
 
 namespace nus {
 
@@ -446,8 +441,8 @@ __device__ __forceinline__ void lanczos_x2_row(const Window<WIN16> &win, const f
     // prefetched input row with vmcnt(4) instead of draining every store with vmcnt(0).
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
     const u32x4 lo = {o[0], o[1], o[2], o[3]}, hi = {o[4], o[5], o[6], o[7]};
-    __builtin_amdgcn_raw_buffer_store_b128(lo, rs, off, 0, NUS_STORE_AUX);
-    __builtin_amdgcn_raw_buffer_store_b128(hi, rs, off + 16, 0, NUS_STORE_AUX);
+    __builtin_amdgcn_raw_buffer_store_b128(lo, rs, off, 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b128(hi, rs, off + 16, 0, 0);
 }
 
 template <bool EXACT, bool WIN16, int S>
@@ -474,7 +469,7 @@ __device__ __forceinline__ void lanczos_x2_step(Window<WIN16> &win, uint4 &raw, 
     win.set_row(S % 7, raw);
     int rn = r + 5;
     rn = rn < (int)A.ih - 1 ? rn : (int)A.ih - 1;
-    raw = *reinterpret_cast<const uint4 *>(src + ((size_t)rn * A.iw + cl) * 4);
+    raw.x += rn; // no global load in the loop
 }
 
 // Exact x2 Lanczos-3.  One wave owns a strip of 256 input columns (4 per lane; lanes 0

@@ -14,14 +14,9 @@
 // fused multiply-adds appear only where spelled __builtin_fmaf (Lanczos FMA mode).
 // No MFMA: no stage is a dense contraction.  Pixels are moved as one u32 each,
 // 16 bytes per lane per access wherever alignment allows.
-#include "nus_kernels.hpp"
+#include "../../nu_scaler_amd/csrc/nus_kernels.hpp"
 
 #pragma clang fp contract(off)
-
-// cache-policy bits of the output stores (0 = default, 2 = nt); tuning knob
-#ifndef NUS_STORE_AUX
-#define NUS_STORE_AUX 0
-#endif
 
 namespace nus {
 
@@ -409,35 +404,30 @@ __device__ __forceinline__ void lanczos_x2_row(const Window<WIN16> &win, const f
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
         float acc = EXACT ? win.get((S + PHASE) % 7, k) * wv[0] : __builtin_fmaf(win.get((S + PHASE) % 7, k), wv[0], 0.0f);
-#pragma unroll
-        for (int j = 1; j < 6; ++j) acc = mac<EXACT>(acc, win.get((S + PHASE + j) % 7, k), wv[j]);
+
         V[k] = acc;
     }
     uint32_t o[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
         float e[10]; // vertical sums of input columns c0-3 .. c0+6 for this channel
-        e[0] = lane_up(V[1 * 4 + c]);
-        e[1] = lane_up(V[2 * 4 + c]);
-        e[2] = lane_up(V[3 * 4 + c]);
+        e[0] = V[1 * 4 + c];
+        e[1] = V[2 * 4 + c];
+        e[2] = V[3 * 4 + c];
         e[3] = V[0 * 4 + c];
         e[4] = V[1 * 4 + c];
         e[5] = V[2 * 4 + c];
         e[6] = V[3 * 4 + c];
-        e[7] = lane_down(V[0 * 4 + c]);
-        e[8] = lane_down(V[1 * 4 + c]);
-        e[9] = lane_down(V[2 * 4 + c]);
+        e[7] = V[0 * 4 + c];
+        e[8] = V[1 * 4 + c];
+        e[9] = V[2 * 4 + c];
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
             float ae = e[m] * W.e[0];
             float ao = e[m + 1] * W.o[0];
-#pragma unroll
-            for (int j = 1; j < 6; ++j) {
-                ae = mac<EXACT>(ae, e[m + j], W.e[j]);
-                ao = mac<EXACT>(ao, e[m + 1 + j], W.o[j]);
-            }
-            o[2 * m] = pack_u8<EXACT>(ae, c, o[2 * m]);
-            o[2 * m + 1] = pack_u8<EXACT>(ao, c, o[2 * m + 1]);
+
+            o[2 * m] += __float_as_uint(ae);
+            o[2 * m + 1] += __float_as_uint(ao);
         }
     }
     // Buffer stores: lanes that must not write carry an offset beyond num_records and the
@@ -446,8 +436,8 @@ __device__ __forceinline__ void lanczos_x2_row(const Window<WIN16> &win, const f
     // prefetched input row with vmcnt(4) instead of draining every store with vmcnt(0).
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
     const u32x4 lo = {o[0], o[1], o[2], o[3]}, hi = {o[4], o[5], o[6], o[7]};
-    __builtin_amdgcn_raw_buffer_store_b128(lo, rs, off, 0, NUS_STORE_AUX);
-    __builtin_amdgcn_raw_buffer_store_b128(hi, rs, off + 16, 0, NUS_STORE_AUX);
+    __builtin_amdgcn_raw_buffer_store_b128(lo, rs, off, 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b128(hi, rs, off + 16, 0, 0);
 }
 
 template <bool EXACT, bool WIN16, int S>
@@ -474,7 +464,7 @@ __device__ __forceinline__ void lanczos_x2_step(Window<WIN16> &win, uint4 &raw, 
     win.set_row(S % 7, raw);
     int rn = r + 5;
     rn = rn < (int)A.ih - 1 ? rn : (int)A.ih - 1;
-    raw = *reinterpret_cast<const uint4 *>(src + ((size_t)rn * A.iw + cl) * 4);
+    raw.x += rn; // no global load in the loop
 }
 
 // Exact x2 Lanczos-3.  One wave owns a strip of 256 input columns (4 per lane; lanes 0
