@@ -43,7 +43,9 @@ def parse_args():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--pattern", choices=["gradient", "noise"], default="gradient")
     ap.add_argument("--lanczos-mode", choices=["fma", "exact"], default="fma")
-    ap.add_argument("--cpu-baseline-units", type=int, default=4, help="0 disables the CPU baseline leg")
+    ap.add_argument("--cpu-baseline-units", type=int, default=-1,
+                    help="units timed on the CPU oracle; -1 = sized for ~15 s of single-thread work, 0 disables")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 --pmc traffic passes (N=1 only)")
     ap.add_argument("--no-profile", action="store_true", help="skip the in-loop hipEvent pairs")
     return ap.parse_args()
 
@@ -55,10 +57,9 @@ def cpu_baseline(args, unit_pixels):
 
     oracle.build()
     w, h = args.width, args.height
-    n = args.cpu_baseline_units
-    frames = [oracle.gen_gradient(w, h, k) for k in range(n + 1)]
 
-    def run(threads):
+    def run(n, threads):
+        frames = [oracle.gen_gradient(w, h, k) for k in range(n + 1)]
         t0 = time.perf_counter()
         for k in range(n):
             mid = oracle.warp_blend(frames[k], frames[k + 1], None, 0.5, threads=threads)
@@ -66,18 +67,67 @@ def cpu_baseline(args, unit_pixels):
             oracle.lanczos3(mid, 2 * w, 2 * h, threads=threads)
         return time.perf_counter() - t0
 
-    t1 = run(1)
+    n = args.cpu_baseline_units
+    if n < 0:  # size the sample for ~15 s of single-thread work
+        t_unit = run(1, 1)
+        n = max(4, min(64, int(round(15.0 / max(t_unit, 1e-3)))))
+    t1 = run(n, 1)
     cores = oracle.max_threads()
-    tn = run(0) if cores > 1 else t1
+    tn = run(n, 0) if cores > 1 else t1
     return {
         "value": round(n * unit_pixels / t1 / 1e6, 3),
         "unit": "Mpix/s",
         "cores": 1,
         "kind": "port",
         "sample": f"{n} units of the same stream ({w}x{h}: zero-flow blend + 2x Lanczos-3 x2), oracle/nus_oracle.c "
-                  f"gcc -O2 -ffp-contract=off, {t1:.1f} s",
+                  f"gcc -O2 -ffp-contract=off, {t1:.1f} s single thread",
         "all_cores": {"value": round(n * unit_pixels / tn / 1e6, 3), "cores": cores, "seconds": round(tn, 2)},
     }
+
+
+def measure_traffic(frames_per_launch):
+    """HBM bytes per launch of the dominant kernel from the L2's memory-side counters, in two
+    separate rocprofv3 --pmc passes over a kernel-only child process (never combined with
+    tracing).  gfx950 corrections per /opt/skills/guides/MI355X_MICROARCH.md: FETCH_SIZE
+    reports half the bytes of a wide coalesced read (x2); WRITE_SIZE is exact; both in KiB.
+    Returns (bytes_per_launch_scaled_to_frames_per_launch, detail) or (None, reason)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+
+    exe = shutil.which("rocprofv3")
+    if not exe:
+        return None, "rocprofv3 not found"
+    n_child = 64
+    vals = {}
+    tmp = tempfile.mkdtemp(prefix="nus_pmc_", dir=os.environ.get("TMPDIR", "/tmp"))
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(tmp, counter)
+            cmd = [exe, "--pmc", counter, "-d", out, "--output-format", "csv", "--",
+                   sys.executable, os.path.join(ROOT, "tools", "lanczos_only.py"), str(n_child), "2"]
+            res = subprocess.run(cmd, capture_output=True, text=True, timeout=240, cwd=tmp)
+            if res.returncode != 0:
+                return None, f"rocprofv3 --pmc {counter} failed (rc {res.returncode})"
+            rows = []
+            for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
+                for r in csv.DictReader(open(f)):
+                    if "k_lanczos3_x2<" in r["Kernel_Name"] and r["Counter_Name"] == counter:
+                        rows.append(float(r["Counter_Value"]))
+            if not rows:
+                return None, f"no {counter} rows for k_lanczos3_x2"
+            vals[counter] = sum(rows) / len(rows)
+    except Exception as e:  # timeouts, missing files: traffic stays null
+        return None, f"{type(e).__name__}: {e}"
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    per_frame = (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0 / n_child
+    detail = {"FETCH_SIZE_KiB_per_frame": round(vals["FETCH_SIZE"] / n_child, 1),
+              "WRITE_SIZE_KiB_per_frame": round(vals["WRITE_SIZE"] / n_child, 1),
+              "fetch_correction": 2.0, "child_frames_per_launch": n_child}
+    return int(per_frame * frames_per_launch), detail
 
 
 def main():
@@ -166,8 +216,9 @@ def main():
                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
                 "bytes_per_launch": up_bytes * count, "frames_per_launch": count, "launches": launches,
                 "avg_launch_ms": round(kernel_ms / launches, 4),
-                "note": "algorithmic bytes (8 294 400 R + 33 177 600 W per frame) / hipEvent time of the main "
-                        "kernel on its launch stream; traffic: see profiles/ (PMC passes are separate runs)",
+                "note": "achieved = algorithmic bytes (8 294 400 R + 33 177 600 W per frame) / hipEvent time of the "
+                        "main kernel on its launch stream inside the timed region; traffic = (2*FETCH_SIZE + "
+                        "WRITE_SIZE)*1024 from separate rocprofv3 --pmc passes, scaled to frames_per_launch",
             }
         out = {
             "metric": "Mpixels/sec (in+out) at 1080p->4K x2 Lanczos-3 upscale + 1 interpolated frame",
@@ -195,7 +246,11 @@ def main():
             },
             "roofline": roofline,
         }
-        if world == 1 and args.cpu_baseline_units > 0:
+        if world == 1 and roofline is not None and not args.no_pmc:
+            traffic, detail = measure_traffic(count)
+            roofline["traffic"] = traffic
+            roofline["traffic_detail"] = detail
+        if world == 1 and args.cpu_baseline_units != 0:
             out["cpu_baseline"] = cpu_baseline(args, pipe.unit_pixels)
         print(json.dumps(out), flush=True)
     if world > 1:
