@@ -47,6 +47,9 @@ def parse_args():
                     help="units timed on the CPU oracle; -1 = sized for ~15 s of single-thread work, 0 disables")
     ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 --pmc traffic passes (N=1 only)")
     ap.add_argument("--no-profile", action="store_true", help="skip the in-loop hipEvent pairs")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo for rehearsal)")
+    ap.add_argument("--force-device", type=int, default=-1,
+                    help="rehearsal only: put every rank on this GPU (with --backend gloo on a 1-GPU box)")
     return ap.parse_args()
 
 
@@ -146,15 +149,22 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
+    if args.force_device >= 0:
+        local_rank = args.force_device
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    nccl = args.backend == "nccl"
+    comm_dev = dev if nccl else torch.device("cpu")  # gloo rehearsal: collectives on host tensors
     if world > 1:
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if nccl:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
 
     w, h = args.width, args.height
     pipe = nsc.FramePipeline(w, h, 2, "lanczos3", 0.5, device=local_rank, lanczos_mode=args.lanczos_mode)
     # shared LUTs: rank 0's tables to everyone (RCCL over xGMI), so all GPUs use identical weights
-    lut_bytes = nsc.broadcast_tables(pipe.upscaler, 0, dev)
+    lut_bytes = nsc.broadcast_tables(pipe.upscaler, 0, comm_dev)
 
     # this rank's contiguous shard of the global stream, plus the overlap frame
     n_units = args.units
@@ -173,7 +183,10 @@ def main():
 
     def barrier():
         if world > 1:
-            dist.barrier(device_ids=[local_rank])
+            if nccl:
+                dist.barrier(device_ids=[local_rank])
+            else:
+                dist.barrier()
 
     for _ in range(args.warmup):
         pipe.step(frames, mid, up_real, up_mid, stream)
@@ -194,7 +207,7 @@ def main():
     launches, kernel_ms = pipe.upscaler.profile_collect() if profile else (0, 0.0)
     pipe.upscaler.set_profiling(False)
 
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    t = torch.tensor([elapsed], dtype=torch.float64, device=comm_dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
@@ -240,7 +253,8 @@ def main():
                 "units_per_step_per_gpu": n_units, "pixels_per_unit": pipe.unit_pixels,
                 "algorithmic_bytes_per_unit": pipe.unit_bytes, "pattern": args.pattern,
                 "lanczos_mode": args.lanczos_mode, "kernel_variant": pipe.upscaler.kernel_variant,
-                "sharding": f"frame-parallel, contiguous shards, {world} rank(s), LUT broadcast {lut_bytes} B",
+                "sharding": f"frame-parallel, contiguous shards, {world} rank(s), LUT broadcast {lut_bytes} B over "
+                            f"{'RCCL' if nccl else args.backend}",
                 "frames_per_sec_per_gpu_4k_out": round(2 * n_units * args.steps / elapsed, 1),
                 "algorithmic_GBps": round(total_units * pipe.unit_bytes / elapsed / 1e9, 1),
             },
@@ -254,7 +268,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(args, pipe.unit_pixels)
         print(json.dumps(out), flush=True)
     if world > 1:
-        dist.barrier(device_ids=[local_rank])
+        barrier()
         dist.destroy_process_group()
 
 
