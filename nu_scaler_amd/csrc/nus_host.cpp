@@ -127,10 +127,6 @@ int HipUpscaler::set_option(const char *key, int64_t value)
         force_general_ = value != 0;
         return kOk;
     }
-    if (!strcmp(key, "window_f16")) {
-        window_f16_ = value != 0;
-        return kOk;
-    }
     if (!strcmp(key, "rows_per_wave")) {
         if (value < 0 || value > 4096) return fail(kInvalidArgument, "rows_per_wave out of range");
         rows_per_wave_ = (uint32_t)value;
@@ -196,8 +192,10 @@ void HipUpscaler::choose_variant()
     }
     case Algorithm::Lanczos3: {
         bool ok = x2 && iw_ >= 16 && (uint64_t)ow_ * oh_ * 4 < (1ull << 31); // buffer-resource addressing
-        ok = ok && lanczos_x2_phase_frame(tx_, wx6_) && lanczos_x2_phase_frame(ty_, wy6_) &&
-             lanczos_x2_interior_uniform(tx_, wx6_);
+        ok = ok && ih_ >= 16 && lanczos_x2_phase_frame(tx_, wx6_) && lanczos_x2_phase_frame(ty_, wy6_) &&
+             lanczos_x2_interior_uniform(tx_, wx6_) && lanczos_x2_interior_uniform(ty_, wy6_) &&
+             // same ratio on both axes: the interior weights of the two passes are the same 12 numbers
+             memcmp(&wx6_[(size_t)8 * 6], &wy6_[(size_t)8 * 6], 12 * sizeof(float)) == 0;
         variant_ = ok ? Variant::LanczosX2RegWin : Variant::LanczosGeneral;
         break;
     }
@@ -327,7 +325,7 @@ int HipUpscaler::enqueue(const uint8_t *d_in, uint8_t *d_out, uint32_t n_frames,
             uint64_t t = rows_total / 8192;
             th = (uint32_t)(t < 8 ? 8 : (t > 36 ? 36 : t));
         }
-        e = launch_lanczos_x2(L, dt_, lanczos_exact_, th, window_f16_);
+        e = launch_lanczos_x2(L, dt_, lanczos_exact_, th);
         lanczos_edges = true;
         break;
     }

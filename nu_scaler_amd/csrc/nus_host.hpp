@@ -120,7 +120,6 @@ private:
     bool lanczos_exact_ = false;
     bool force_general_ = false;
     uint32_t rows_per_wave_ = 0; // 0: pick from the batch size
-    bool window_f16_ = false;    // Lanczos x2: keep the register window as packed f16
     bool initialized_ = false;
     uint32_t iw_ = 0, ih_ = 0, ow_ = 0, oh_ = 0;
     Variant variant_ = Variant::NearestTable;

@@ -16,6 +16,8 @@
 // 16 bytes per lane per access wherever alignment allows.
 #include "nus_kernels.hpp"
 
+#include <cstdlib>
+
 #pragma clang fp contract(off)
 
 // cache-policy bits of the output stores (0 = default, 2 = nt); tuning knob
@@ -331,88 +333,67 @@ __device__ __forceinline__ float lane_down(float v) // value of lane+1
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x130 /*wave_shl:1*/, 0xF, 0xF, true));
 }
 
-typedef __fp16 half2_t __attribute__((ext_vector_type(2)));
-
-// The 7-row register window of one lane: 4 input columns x 4 channels per row.
-// WIN16 = false: 16 f32 VGPRs per row.  WIN16 = true: 8 VGPRs per row holding the values
-// as packed f16 (u8 values are exact in f16); the vertical taps then issue as
-// v_fma_mix_f32 (f16 source, f32 weight and accumulator) -- bit-identical results,
-// 56 fewer VGPRs, one more wave per SIMD.
-template <bool WIN16>
-struct Window;
-
-template <>
-struct Window<false> {
-    float v[7][16];
-    __device__ __forceinline__ float get(int slot, int k) const { return v[slot][k]; }
-    __device__ __forceinline__ void set_row(int slot, const uint4 raw)
-    {
-        const uint32_t px[4] = {raw.x, raw.y, raw.z, raw.w};
-#pragma unroll
-        for (int m = 0; m < 4; ++m)
-#pragma unroll
-            for (int c = 0; c < 4; ++c) v[slot][m * 4 + c] = ch_f32(px[m], c);
-    }
-};
-
-template <>
-struct Window<true> {
-    half2_t v[7][8];
-    __device__ __forceinline__ float get(int slot, int k) const { return (float)v[slot][k >> 1][k & 1]; }
-    __device__ __forceinline__ void set_row(int slot, const uint4 raw)
-    {
-        const uint32_t px[4] = {raw.x, raw.y, raw.z, raw.w};
-#pragma unroll
-        for (int m = 0; m < 4; ++m) {
-            v[slot][m * 2 + 0] = __builtin_amdgcn_cvt_pkrtz(ch_f32(px[m], 0), ch_f32(px[m], 1));
-            v[slot][m * 2 + 1] = __builtin_amdgcn_cvt_pkrtz(ch_f32(px[m], 2), ch_f32(px[m], 3));
-        }
-    }
-};
-
-// One output row (phase 0: row 2r from window slots S..S+5; phase 1: row 2r+1 from
-// slots S+1..S+6) of the lane's 8 output pixels.
 // gfx950 issues v_fma/v_mul/v_add_f32 with VGPR-only operands at ~2.4 cycles per wave64
 // instruction, but ~4.4-5 cycles as soon as one operand is an SGPR (tools/probe_valu.hip).
-// The wave-uniform filter weights are therefore copied into VGPRs once (the asm barrier
-// keeps the compiler from folding them back into scalar operands).
+// The wave-uniform interior filter weights are therefore copied into VGPRs once (the asm
+// barrier keeps the compiler from folding them back into scalar operands).
 __device__ __forceinline__ float vgpr(float s)
 {
     asm volatile("" : "+v"(s));
     return s;
 }
 
-struct HWeights {
+// Interior phase weights (even output: taps k-3..k+2, odd output: taps k-2..k+3).  At x2 on
+// both axes the vertical and horizontal interior weights are the same 12 numbers (checked by
+// the host), so one VGPR copy serves both passes.
+struct PhaseWeights {
     float e[6], o[6];
 };
 
-// Vertical weights of one step (output rows 2r and 2r+1), fetched one step ahead with
-// scalar loads and parked in SGPRs so their latency hides behind the previous step.
-struct VWeights {
-    float w[12];
-    __device__ __forceinline__ void fetch(const float *__restrict__ wy6, int r)
-    {
-        // constant address space + uniform address -> s_load_dwordx4/x8 (the table is
-        // never written by a kernel)
-        typedef const __attribute__((address_space(4))) float *cfloat_p;
-        cfloat_p p = (cfloat_p)(uintptr_t)(wy6 + (size_t)__builtin_amdgcn_readfirstlane(r) * 12);
-#pragma unroll
-        for (int j = 0; j < 12; ++j) w[j] = p[j]; // consumed one step later: the s_load latency is hidden
-    }
-};
-
-template <bool EXACT, bool WIN16, int S, int PHASE>
-__device__ __forceinline__ void lanczos_x2_row(const Window<WIN16> &win, const float (&wv)[6],
-                                               const HWeights &W, __amdgpu_buffer_rsrc_t rs, uint32_t off)
+__device__ __forceinline__ void cvt_row(const uint4 raw, float (&dst)[16])
 {
-    float V[16];
+    const uint32_t px[4] = {raw.x, raw.y, raw.z, raw.w};
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) dst[m * 4 + c] = ch_f32(px[m], c);
+}
+
+// Vertical pass of one output row: 6 taps from window slots BASE .. BASE+5 (mod 6).
+template <bool EXACT, int BASE>
+__device__ __forceinline__ void lanczos_x2_vpass(const float (&win)[6][16], const float (&w)[6], float (&V)[16])
+{
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
-        float acc = EXACT ? win.get((S + PHASE) % 7, k) * wv[0] : __builtin_fmaf(win.get((S + PHASE) % 7, k), wv[0], 0.0f);
+        float acc = EXACT ? win[BASE % 6][k] * w[0] : __builtin_fmaf(win[BASE % 6][k], w[0], 0.0f);
 #pragma unroll
-        for (int j = 1; j < 6; ++j) acc = mac<EXACT>(acc, win.get((S + PHASE + j) % 7, k), wv[j]);
+        for (int j = 1; j < 6; ++j) acc = mac<EXACT>(acc, win[(BASE + j) % 6][k], w[j]);
         V[k] = acc;
     }
+}
+
+// Same for the few rows next to the top / bottom border, whose tap windows are cut and
+// renormalised: per-row weights straight from the table (scalar operands; slow path).
+template <bool EXACT, int BASE>
+__device__ __forceinline__ void lanczos_x2_vpass_edge(const float (&win)[6][16], const float *__restrict__ wy6,
+                                                      uint32_t oy, float (&V)[16])
+{
+    typedef const __attribute__((address_space(4))) float *cfloat_p;
+    cfloat_p w = (cfloat_p)(uintptr_t)(wy6 + (size_t)__builtin_amdgcn_readfirstlane(oy) * 6);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        float acc = EXACT ? win[BASE % 6][k] * w[0] : __builtin_fmaf(win[BASE % 6][k], w[0], 0.0f);
+#pragma unroll
+        for (int j = 1; j < 6; ++j) acc = mac<EXACT>(acc, win[(BASE + j) % 6][k], w[j]);
+        V[k] = acc;
+    }
+}
+
+// Horizontal pass of the lane's 8 output pixels, convert + pack, and the two 16-B stores.
+template <bool EXACT>
+__device__ __forceinline__ void lanczos_x2_hpass_store(const float (&V)[16], const PhaseWeights &W,
+                                                       __amdgpu_buffer_rsrc_t rs, uint32_t off)
+{
     uint32_t o[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
@@ -442,52 +423,58 @@ __device__ __forceinline__ void lanczos_x2_row(const Window<WIN16> &win, const f
     }
     // Buffer stores: lanes that must not write carry an offset beyond num_records and the
     // hardware range check drops them.  Unlike an exec-masked store behind a branch the
-    // store instructions always issue, so the compiler can count them and wait for the
-    // prefetched input row with vmcnt(4) instead of draining every store with vmcnt(0).
+    // store instructions always issue, so the compiler can count them and wait for a
+    // prefetched input row with vmcnt(N) instead of draining every store with vmcnt(0).
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
     const u32x4 lo = {o[0], o[1], o[2], o[3]}, hi = {o[4], o[5], o[6], o[7]};
     __builtin_amdgcn_raw_buffer_store_b128(lo, rs, off, 0, NUS_STORE_AUX);
     __builtin_amdgcn_raw_buffer_store_b128(hi, rs, off + 16, 0, NUS_STORE_AUX);
 }
 
-template <bool EXACT, bool WIN16, int S>
-__device__ __forceinline__ void lanczos_x2_step(Window<WIN16> &win, uint4 &raw, int r, int cl, uint32_t lane_off,
-                                                const LanczosX2Args &A, const HWeights &W, VWeights &VW,
-                                                const uint8_t *src, __amdgpu_buffer_rsrc_t rs)
+// One input row r -> output rows 2r (taps r-3..r+2) and 2r+1 (taps r-2..r+3).
+// At entry window slot (S+j)%6 holds input row r-3+j, j = 0..5, and raw[S&1] holds row r+3.
+// Row r-3 dies after the even phase, so row r+3 is converted into its slot BETWEEN the two
+// phases: only 6 rows (96 VGPRs) are ever live, not 7.
+template <bool EXACT, int S>
+__device__ __forceinline__ void lanczos_x2_step(float (&win)[6][16], uint4 (&raw)[2], int r, int cl, uint32_t lane_off,
+                                                const LanczosX2Args &A, const PhaseWeights &W, const uint8_t *src,
+                                                __amdgpu_buffer_rsrc_t rs)
 {
     const uint32_t row_bytes = A.iw * 8; // output row: 2*iw pixels
     const uint32_t off0 = lane_off + (uint32_t)(2 * r) * row_bytes;
-    float wv0[6], wv1[6];
-#pragma unroll
-    for (int j = 0; j < 6; ++j) {
-        wv0[j] = vgpr(VW.w[j]);
-        wv1[j] = vgpr(VW.w[6 + j]);
-    }
+    const bool interior = r >= 4 && r + 5 <= (int)A.ih; // wave-uniform
+    float V[16];
+    if (interior)
+        lanczos_x2_vpass<EXACT, S>(win, W.e, V);
+    else
+        lanczos_x2_vpass_edge<EXACT, S>(win, A.wy6, 2 * (uint32_t)r, V);
+    lanczos_x2_hpass_store<EXACT>(V, W, rs, off0);
+    // row r+3 in, then request row r+5 into the same buffer (consumed two steps from now;
+    // vmcnt retires in order, so that wait only sits behind stores at least a step old)
+    cvt_row(raw[S & 1], win[S % 6]);
     {
-        int rw = r + 1; // next step's weights; the clamp only keeps the read in bounds
-        rw = rw < (int)A.ih - 1 ? rw : (int)A.ih - 1;
-        VW.fetch(A.wy6, rw);
+        int rn = r + 5;
+        rn = rn < (int)A.ih - 1 ? rn : (int)A.ih - 1;
+        raw[S & 1] = *reinterpret_cast<const uint4 *>(src + ((size_t)rn * A.iw + cl) * 4);
     }
-    lanczos_x2_row<EXACT, WIN16, S, 0>(win, wv0, W, rs, off0);
-    lanczos_x2_row<EXACT, WIN16, S, 1>(win, wv1, W, rs, off0 + row_bytes);
-    // input row r-3 (slot S) is dead: replace it by row r+4, then fetch row r+5.
-    win.set_row(S % 7, raw);
-    int rn = r + 5;
-    rn = rn < (int)A.ih - 1 ? rn : (int)A.ih - 1;
-    raw = *reinterpret_cast<const uint4 *>(src + ((size_t)rn * A.iw + cl) * 4);
+    if (interior)
+        lanczos_x2_vpass<EXACT, S + 1>(win, W.o, V);
+    else
+        lanczos_x2_vpass_edge<EXACT, S + 1>(win, A.wy6, 2 * (uint32_t)r + 1, V);
+    lanczos_x2_hpass_store<EXACT>(V, W, rs, off0 + row_bytes);
 }
 
 // Exact x2 Lanczos-3.  One wave owns a strip of 256 input columns (4 per lane; lanes 0
 // and 63 are halo lanes, lanes 1..62 produce 248 input = 496 output columns) and walks
-// `th` input rows, keeping a 7-row window of its columns in registers:
-//   vertical pass  : 6 taps from the register window (weights wave-uniform, in SGPRs)
+// `th` input rows, keeping a 6-row f32 window of its columns in registers:
+//   vertical pass  : 6 taps from the register window
 //   horizontal pass: 6 taps over the lane's own 4 columns + 3 columns from each
 //                    neighbouring lane, fetched with wave_shr/wave_shl DPP moves
 // so every input byte is read once per strip-row-block and no LDS round trip or
 // barrier is needed.  Output: 2 x 16-B stores per lane per output row (2 KiB per wave).
 // The 8 left-most and right-most output columns (renormalised edge weights) are left
 // to k_lanczos3_x2_edges.
-template <bool EXACT, bool WIN16>
+template <bool EXACT>
 __global__ __launch_bounds__(256) void k_lanczos3_x2(const LanczosX2Args A)
 {
     const int lane = threadIdx.x & (kWave - 1);
@@ -508,37 +495,29 @@ __global__ __launch_bounds__(256) void k_lanczos3_x2(const LanczosX2Args A)
     const int r0 = (int)(rb * A.th);
     const int r_end = (r0 + (int)A.th) < (int)A.ih ? (r0 + (int)A.th) : (int)A.ih;
     const int rmax = (int)A.ih - 1;
+    auto load_row = [&](int rr) {
+        rr = rr < 0 ? 0 : (rr > rmax ? rmax : rr);
+        return *reinterpret_cast<const uint4 *>(src + ((size_t)rr * A.iw + cl) * 4);
+    };
 
-    HWeights W;
+    PhaseWeights W;
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
         W.e[j] = vgpr(A.wxe[j]);
         W.o[j] = vgpr(A.wxo[j]);
     }
-    Window<WIN16> win;
+    float win[6][16];
 #pragma unroll
-    for (int j = 0; j < 7; ++j) {
-        int rr = r0 - 3 + j;
-        rr = rr < 0 ? 0 : (rr > rmax ? rmax : rr);
-        win.set_row(j, *reinterpret_cast<const uint4 *>(src + ((size_t)rr * A.iw + cl) * 4));
-    }
-    uint4 raw;
-    {
-        int rr = r0 + 4;
-        rr = rr > rmax ? rmax : rr;
-        raw = *reinterpret_cast<const uint4 *>(src + ((size_t)rr * A.iw + cl) * 4);
-    }
-    VWeights VW;
-    VW.fetch(A.wy6, r0);
-    for (int rbase = r0; rbase < r_end; rbase += 7) {
-        // 7-way unrolled so the rotating window indices are compile-time constants.
-        if (rbase + 0 < r_end) lanczos_x2_step<EXACT, WIN16, 0>(win, raw, rbase + 0, cl, lane_off, A, W, VW, src, rs);
-        if (rbase + 1 < r_end) lanczos_x2_step<EXACT, WIN16, 1>(win, raw, rbase + 1, cl, lane_off, A, W, VW, src, rs);
-        if (rbase + 2 < r_end) lanczos_x2_step<EXACT, WIN16, 2>(win, raw, rbase + 2, cl, lane_off, A, W, VW, src, rs);
-        if (rbase + 3 < r_end) lanczos_x2_step<EXACT, WIN16, 3>(win, raw, rbase + 3, cl, lane_off, A, W, VW, src, rs);
-        if (rbase + 4 < r_end) lanczos_x2_step<EXACT, WIN16, 4>(win, raw, rbase + 4, cl, lane_off, A, W, VW, src, rs);
-        if (rbase + 5 < r_end) lanczos_x2_step<EXACT, WIN16, 5>(win, raw, rbase + 5, cl, lane_off, A, W, VW, src, rs);
-        if (rbase + 6 < r_end) lanczos_x2_step<EXACT, WIN16, 6>(win, raw, rbase + 6, cl, lane_off, A, W, VW, src, rs);
+    for (int j = 0; j < 6; ++j) cvt_row(load_row(r0 - 3 + j), win[j]);
+    uint4 raw[2] = {load_row(r0 + 3), load_row(r0 + 4)};
+    for (int rbase = r0; rbase < r_end; rbase += 6) {
+        // 6-way unrolled so the rotating window indices are compile-time constants.
+        if (rbase + 0 < r_end) lanczos_x2_step<EXACT, 0>(win, raw, rbase + 0, cl, lane_off, A, W, src, rs);
+        if (rbase + 1 < r_end) lanczos_x2_step<EXACT, 1>(win, raw, rbase + 1, cl, lane_off, A, W, src, rs);
+        if (rbase + 2 < r_end) lanczos_x2_step<EXACT, 2>(win, raw, rbase + 2, cl, lane_off, A, W, src, rs);
+        if (rbase + 3 < r_end) lanczos_x2_step<EXACT, 3>(win, raw, rbase + 3, cl, lane_off, A, W, src, rs);
+        if (rbase + 4 < r_end) lanczos_x2_step<EXACT, 4>(win, raw, rbase + 4, cl, lane_off, A, W, src, rs);
+        if (rbase + 5 < r_end) lanczos_x2_step<EXACT, 5>(win, raw, rbase + 5, cl, lane_off, A, W, src, rs);
     }
 }
 
@@ -833,7 +812,7 @@ hipError_t launch_lanczos_general(const UpscaleLaunch &L, const DeviceTables &T,
     });
 }
 
-hipError_t launch_lanczos_x2(const UpscaleLaunch &L, const DeviceTables &T, bool exact, uint32_t rows_per_wave, bool win16)
+hipError_t launch_lanczos_x2(const UpscaleLaunch &L, const DeviceTables &T, bool exact, uint32_t rows_per_wave)
 {
     LanczosX2Args A;
     A.wy6 = T.lz_wy6;
@@ -849,18 +828,16 @@ hipError_t launch_lanczos_x2(const UpscaleLaunch &L, const DeviceTables &T, bool
     A.in_frame_bytes = (size_t)L.iw * L.ih * 4;
     A.out_frame_bytes = (size_t)L.ow * L.oh * 4;
     const uint32_t nwaves = A.nstrips * A.nrowblocks;
+    // dev knob: unused dynamic LDS per block, to study occupancy sensitivity (0 in production)
+    static const uint32_t lds_pad = getenv("NUS_LDS_PAD_KB") ? (uint32_t)atoi(getenv("NUS_LDS_PAD_KB")) * 1024u : 0u;
     hipError_t e = for_frame_chunks(L, [&](const uint8_t *in, uint8_t *out, uint32_t n) {
         A.in = in;
         A.out = out;
         const dim3 block(256), grid(cdiv(nwaves, 4), n);
-        if (exact && win16)
-            hipLaunchKernelGGL((k_lanczos3_x2<true, true>), grid, block, 0, L.stream, A);
-        else if (exact)
-            hipLaunchKernelGGL((k_lanczos3_x2<true, false>), grid, block, 0, L.stream, A);
-        else if (win16)
-            hipLaunchKernelGGL((k_lanczos3_x2<false, true>), grid, block, 0, L.stream, A);
+        if (exact)
+            hipLaunchKernelGGL(k_lanczos3_x2<true>, grid, block, lds_pad, L.stream, A);
         else
-            hipLaunchKernelGGL((k_lanczos3_x2<false, false>), grid, block, 0, L.stream, A);
+            hipLaunchKernelGGL(k_lanczos3_x2<false>, grid, block, lds_pad, L.stream, A);
     });
     return e;
 }

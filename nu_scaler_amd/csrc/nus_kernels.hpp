@@ -57,7 +57,7 @@ hipError_t launch_lanczos_general(const UpscaleLaunch &L, const DeviceTables &T,
 // main x2 kernel only: the first / last kLanczosX2EdgeCols output columns are NOT written;
 // follow it with launch_lanczos_x2_edges(L, T, exact).
 hipError_t launch_lanczos_x2(const UpscaleLaunch &L, const DeviceTables &T, bool exact,
-                             uint32_t rows_per_wave, bool win16);
+                             uint32_t rows_per_wave);
 
 hipError_t launch_lanczos_x2_edges(const UpscaleLaunch &L, const DeviceTables &T, bool exact);
 
