@@ -47,6 +47,9 @@ def parse_args():
                     help="units timed on the CPU oracle; -1 = sized for ~15 s of single-thread work, 0 disables")
     ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 --pmc traffic passes (N=1 only)")
     ap.add_argument("--no-profile", action="store_true", help="skip the in-loop hipEvent pairs")
+    ap.add_argument("--overlap", action="store_true",
+                    help="blend on a second stream, concurrent with the upscale of the real frames (measured: no gain, "
+                         "the Lanczos kernel is SIMD-time bound and slows by what the blend takes)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo for rehearsal)")
     ap.add_argument("--force-device", type=int, default=-1,
                     help="rehearsal only: put every rank on this GPU (with --backend gloo on a 1-GPU box)")
@@ -188,8 +191,14 @@ def main():
             else:
                 dist.barrier()
 
+    def do_step():
+        if args.overlap:
+            pipe.step_overlapped(frames, mid, up_real, up_mid)
+        else:
+            pipe.step(frames, mid, up_real, up_mid, stream)
+
     for _ in range(args.warmup):
-        pipe.step(frames, mid, up_real, up_mid, stream)
+        do_step()
     torch.cuda.synchronize()
     profile = not args.no_profile
     pipe.upscaler.set_profiling(profile)
@@ -199,7 +208,7 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        pipe.step(frames, mid, up_real, up_mid, stream)
+        do_step()
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
@@ -253,6 +262,8 @@ def main():
                 "units_per_step_per_gpu": n_units, "pixels_per_unit": pipe.unit_pixels,
                 "algorithmic_bytes_per_unit": pipe.unit_bytes, "pattern": args.pattern,
                 "lanczos_mode": args.lanczos_mode, "kernel_variant": pipe.upscaler.kernel_variant,
+                "schedule": "blend on a second HIP stream, concurrent with the upscale of the real frames"
+                            if args.overlap else "3 stages back to back on one stream",
                 "sharding": f"frame-parallel, contiguous shards, {world} rank(s), LUT broadcast {lut_bytes} B over "
                             f"{'RCCL' if nccl else args.backend}",
                 "frames_per_sec_per_gpu_4k_out": round(2 * n_units * args.steps / elapsed, 1),

@@ -105,6 +105,7 @@ class FramePipeline:
         self.upscaler.initialize(self.w, self.h, self.ow, self.oh)
         self.interp = WgpuFrameInterpolator(device=device)
         self.frame_bytes = self.w * self.h * 4
+        self._aux = None
 
     # algorithmic bytes / pixels of one unit
     @property
@@ -132,3 +133,28 @@ class FramePipeline:
         self.interp.interpolate_device(base, fb, base + fb, fb, 0, self.w, self.h, self.t, mid.data_ptr(), n, stream)
         self.upscaler.upscale_device(base, up_real.data_ptr(), n, stream)
         self.upscaler.upscale_device(mid.data_ptr(), up_mid.data_ptr(), n, stream)
+
+    def step_overlapped(self, frames, mid, up_real, up_mid) -> None:
+        """Same work with the blend on a second stream: the Lanczos kernel is bound by SIMD
+        time (VALU issue + store feed) and leaves HBM bandwidth idle, the zero-flow blend is
+        purely bandwidth bound, and the upscale of the real frames does not depend on the
+        blend -- so the two run concurrently and the blend is (mostly) hidden.
+        Uses torch's current stream as the main stream."""
+        import torch
+
+        if self._aux is None:
+            self._aux = torch.cuda.Stream()
+            self._ev_start = torch.cuda.Event()
+            self._ev_mid = torch.cuda.Event()
+        main = torch.cuda.current_stream()
+        n = mid.shape[0]
+        base = frames.data_ptr()
+        fb = self.frame_bytes
+        self._ev_start.record(main)
+        self._aux.wait_event(self._ev_start)  # the previous step's readers of `mid` are done
+        self.interp.interpolate_device(base, fb, base + fb, fb, 0, self.w, self.h, self.t, mid.data_ptr(), n,
+                                       self._aux.cuda_stream)
+        self._ev_mid.record(self._aux)
+        self.upscaler.upscale_device(base, up_real.data_ptr(), n, main.cuda_stream)
+        main.wait_event(self._ev_mid)
+        self.upscaler.upscale_device(mid.data_ptr(), up_mid.data_ptr(), n, main.cuda_stream)
