@@ -225,6 +225,40 @@ int nus_interp_interpolate_device(nus_interp *h, const void *d_a, size_t a_strid
 int nus_interp_last_gpu_ms(const nus_interp *h, double *ms_out);
 const char *nus_interp_last_error(const nus_interp *h);
 
+/* ---- Optical-flow front end ("next" row: SURVEY.md section 8f rank 1) --------------
+ * Mirrors WgpuFrameInterpolator::build_pyramid / compute_coarse_flow
+ * (nu_scaler_core/src/wgpu_interpolator.rs:969-1203) and the shaders
+ * gaussian_blur_{h,v}.wgsl, downsample.wgsl, horn_schunck.wgsl, flow_upsample.wgsl.
+ * Images: f32 RGBA (4 floats / pixel, u8/255); flows: 2 floats / pixel (dx, dy), the
+ * pixel delta from frame A to frame B that nus_interp_interpolate consumes. */
+typedef struct nus_flow nus_flow;
+
+nus_flow *nus_flow_create(void);
+void nus_flow_destroy(nus_flow *h);
+int nus_flow_set_device(nus_flow *h, int device);
+const char *nus_flow_last_error(const nus_flow *h);
+
+/* primitives on host buffers */
+int nus_flow_rgba8_to_f32(nus_flow *h, const uint8_t *in, uint32_t w, uint32_t hgt, float *out);
+int nus_flow_blur(nus_flow *h, const float *in, uint32_t w, uint32_t hgt, float *out); /* H pass, then V pass */
+int nus_flow_downsample(nus_flow *h, const float *in, uint32_t w, uint32_t hgt, float *out); /* -> (w+1)/2 x (h+1)/2 */
+/* `iterations` Jacobi steps; flow_in == NULL starts from zero (compute_coarse_flow). */
+int nus_flow_horn_schunck(nus_flow *h, const float *i1, const float *i2, const float *flow_in,
+                          uint32_t w, uint32_t hgt, float lambda, uint32_t iterations, float *flow_out);
+int nus_flow_upsample(nus_flow *h, const float *src, uint32_t sw, uint32_t sh,
+                      float *dst, uint32_t dw, uint32_t dh, float scale);
+
+/* Full estimator: pyramids of both RGBA8 frames (`levels`), `coarse_iters` steps from zero
+ * flow at the coarsest level, then per finer level a x2 upsample (vectors x2) and
+ * `refine_iters` steps.  flow_out: w*h*2 floats. */
+int nus_flow_estimate(nus_flow *h, const uint8_t *a, const uint8_t *b, uint32_t w, uint32_t hgt,
+                      uint32_t levels, uint32_t coarse_iters, uint32_t refine_iters, float lambda,
+                      float *flow_out);
+/* Device-resident variant; enqueues on `stream`, no synchronisation. */
+int nus_flow_estimate_device(nus_flow *h, const void *d_a, const void *d_b, uint32_t w, uint32_t hgt,
+                             uint32_t levels, uint32_t coarse_iters, uint32_t refine_iters, float lambda,
+                             void *d_flow_out, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

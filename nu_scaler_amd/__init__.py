@@ -8,6 +8,7 @@ library raises, and compute calls without a HIP device raise RuntimeError.
 """
 from . import _capi
 from ._capi import NuScalerLibraryError, build, device_count
+from .flow import FlowEstimator
 from .interpolator import WgpuFrameInterpolator
 from .stream import (FramePipeline, broadcast_blob, broadcast_tables, build_tables_blob, shard_frames,
                      validate_tables_blob)
@@ -32,7 +33,7 @@ def create_fsr_upscaler(_quality: str):
 
 __all__ = [
     "PyWgpuUpscaler", "PyAdvancedWgpuUpscaler", "create_advanced_upscaler", "create_fsr_upscaler",
-    "WgpuFrameInterpolator", "FramePipeline", "shard_frames", "broadcast_tables",
+    "WgpuFrameInterpolator", "FlowEstimator", "FramePipeline", "shard_frames", "broadcast_tables",
     "broadcast_blob", "build_tables_blob", "validate_tables_blob",
     "NuScalerLibraryError", "build", "device_count",
     "QUALITY_ULTRA", "QUALITY_QUALITY", "QUALITY_BALANCED", "QUALITY_PERFORMANCE",

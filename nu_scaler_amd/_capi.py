@@ -73,6 +73,17 @@ SIGNATURES = [
     ("nus_interp_interpolate_device", _i, [_vp, _vp, _sz, _vp, _sz, _vp, _u32, _u32, _f, _vp, _u32, _vp]),
     ("nus_interp_last_gpu_ms", _i, [_vp, _dp]),
     ("nus_interp_last_error", _cp, [_vp]),
+    ("nus_flow_create", _vp, []),
+    ("nus_flow_destroy", None, [_vp]),
+    ("nus_flow_set_device", _i, [_vp, _i]),
+    ("nus_flow_last_error", _cp, [_vp]),
+    ("nus_flow_rgba8_to_f32", _i, [_vp, _vp, _u32, _u32, _vp]),
+    ("nus_flow_blur", _i, [_vp, _vp, _u32, _u32, _vp]),
+    ("nus_flow_downsample", _i, [_vp, _vp, _u32, _u32, _vp]),
+    ("nus_flow_horn_schunck", _i, [_vp, _vp, _vp, _vp, _u32, _u32, _f, _u32, _vp]),
+    ("nus_flow_upsample", _i, [_vp, _vp, _u32, _u32, _vp, _u32, _u32, _f]),
+    ("nus_flow_estimate", _i, [_vp, _vp, _vp, _u32, _u32, _u32, _u32, _u32, _f, _vp]),
+    ("nus_flow_estimate_device", _i, [_vp, _vp, _vp, _u32, _u32, _u32, _u32, _u32, _f, _vp, _vp]),
 ]
 
 

@@ -6,11 +6,16 @@
 #include <string>
 #include <vector>
 
+#include "nus_flow.hpp"
 #include "nus_host.hpp"
 
 struct nus_upscaler {
     nus::HipUpscaler impl;
     nus_upscaler(nus::Quality q, nus::Algorithm a) : impl(q, a) {}
+};
+
+struct nus_flow {
+    nus::HipFlowEstimator impl;
 };
 
 struct nus_interp {
@@ -258,5 +263,51 @@ int nus_interp_last_gpu_ms(const nus_interp *h, double *ms_out)
 }
 
 const char *nus_interp_last_error(const nus_interp *h) { return h ? h->impl.last_error() : "null handle"; }
+
+nus_flow *nus_flow_create(void) { return new (std::nothrow) nus_flow(); }
+void nus_flow_destroy(nus_flow *h) { delete h; }
+int nus_flow_set_device(nus_flow *h, int device) { return h ? h->impl.set_device(device) : null_handle(); }
+const char *nus_flow_last_error(const nus_flow *h) { return h ? h->impl.last_error() : "null handle"; }
+
+int nus_flow_rgba8_to_f32(nus_flow *h, const uint8_t *in, uint32_t w, uint32_t hgt, float *out)
+{
+    return h ? h->impl.rgba8_to_f32(in, w, hgt, out) : null_handle();
+}
+
+int nus_flow_blur(nus_flow *h, const float *in, uint32_t w, uint32_t hgt, float *out)
+{
+    return h ? h->impl.blur(in, w, hgt, out) : null_handle();
+}
+
+int nus_flow_downsample(nus_flow *h, const float *in, uint32_t w, uint32_t hgt, float *out)
+{
+    return h ? h->impl.downsample(in, w, hgt, out) : null_handle();
+}
+
+int nus_flow_horn_schunck(nus_flow *h, const float *i1, const float *i2, const float *flow_in, uint32_t w, uint32_t hgt,
+                          float lambda, uint32_t iterations, float *flow_out)
+{
+    return h ? h->impl.horn_schunck(i1, i2, flow_in, w, hgt, lambda, iterations, flow_out) : null_handle();
+}
+
+int nus_flow_upsample(nus_flow *h, const float *src, uint32_t sw, uint32_t sh, float *dst, uint32_t dw, uint32_t dh,
+                      float scale)
+{
+    return h ? h->impl.upsample(src, sw, sh, dst, dw, dh, scale) : null_handle();
+}
+
+int nus_flow_estimate(nus_flow *h, const uint8_t *a, const uint8_t *b, uint32_t w, uint32_t hgt, uint32_t levels,
+                      uint32_t coarse_iters, uint32_t refine_iters, float lambda, float *flow_out)
+{
+    return h ? h->impl.estimate(a, b, w, hgt, levels, coarse_iters, refine_iters, lambda, flow_out) : null_handle();
+}
+
+int nus_flow_estimate_device(nus_flow *h, const void *d_a, const void *d_b, uint32_t w, uint32_t hgt, uint32_t levels,
+                             uint32_t coarse_iters, uint32_t refine_iters, float lambda, void *d_flow_out, void *stream)
+{
+    return h ? h->impl.estimate_device(d_a, d_b, w, hgt, levels, coarse_iters, refine_iters, lambda, d_flow_out,
+                                       static_cast<hipStream_t>(stream))
+             : null_handle();
+}
 
 } // extern "C"

@@ -1,0 +1,290 @@
+// nus_flow.cpp -- see nus_flow.hpp.
+#include "nus_flow.hpp"
+
+#include <cstring>
+
+#include "nus_host.hpp"
+#include "nus_kernels.hpp"
+
+namespace nus {
+
+namespace {
+int device_count_()
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return n;
+}
+} // namespace
+
+#define NUS_HIP(call)                                     \
+    do {                                                  \
+        hipError_t e_ = (call);                           \
+        if (e_ != hipSuccess) return fail_hip(e_, #call); \
+    } while (0)
+
+HipFlowEstimator::~HipFlowEstimator() { release(); }
+
+int HipFlowEstimator::fail(int status, const std::string &msg)
+{
+    error_ = msg;
+    set_thread_error(msg);
+    return status;
+}
+
+int HipFlowEstimator::fail_hip(hipError_t e, const char *what)
+{
+    (void)hipGetLastError();
+    return fail(e == hipErrorOutOfMemory ? kOutOfMemory : kHipError,
+                std::string("HIP error in ") + what + ": " + hipGetErrorString(e));
+}
+
+int HipFlowEstimator::set_device(int device)
+{
+    std::lock_guard<std::mutex> lk(mu_);
+    if (device < 0) return fail(kInvalidArgument, "negative device index");
+    if (ready_) return fail(kInvalidArgument, "set_device must precede the first call");
+    device_ = device;
+    return kOk;
+}
+
+int HipFlowEstimator::ensure_device()
+{
+    const int n = device_count_();
+    if (n <= 0) return fail(kNoDevice, "no HIP device available (the gfx950 path has no CPU fallback)");
+    if (device_ >= n) return fail(kNoDevice, "requested HIP device not present");
+    NUS_HIP(hipSetDevice(device_));
+    if (!ready_) {
+        NUS_HIP(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
+        ready_ = true;
+    }
+    return kOk;
+}
+
+int HipFlowEstimator::reserve(size_t bytes, int slot)
+{
+    if (bytes <= slot_cap_[slot]) return kOk;
+    if (slot_[slot]) {
+        NUS_HIP(hipStreamSynchronize(stream_));
+        NUS_HIP(hipFree(slot_[slot]));
+        slot_[slot] = nullptr;
+        slot_cap_[slot] = 0;
+    }
+    NUS_HIP(hipMalloc(&slot_[slot], bytes));
+    slot_cap_[slot] = bytes;
+    return kOk;
+}
+
+void HipFlowEstimator::release()
+{
+    if (!ready_) return;
+    (void)hipSetDevice(device_);
+    (void)hipStreamSynchronize(stream_);
+    for (int i = 0; i < kSlotCount; ++i) {
+        if (slot_[i]) (void)hipFree(slot_[i]);
+        slot_[i] = nullptr;
+        slot_cap_[i] = 0;
+    }
+    (void)hipStreamDestroy(stream_);
+    ready_ = false;
+}
+
+#define CHECK_DIMS(w, h)                                                             \
+    if ((w) == 0 || (h) == 0 || (uint64_t)(w) * (h) >= (1ull << 28))                 \
+        return fail(kInvalidArgument, "flow: bad image dimensions");
+
+int HipFlowEstimator::rgba8_to_f32(const uint8_t *in, uint32_t w, uint32_t h, float *out)
+{
+    std::lock_guard<std::mutex> lk(mu_);
+    CHECK_DIMS(w, h);
+    if (!in || !out) return fail(kInvalidArgument, "flow: null pointer");
+    int rc = ensure_device();
+    if (rc != kOk) return rc;
+    const size_t npx = (size_t)w * h;
+    if ((rc = reserve(npx * 4, 0)) != kOk || (rc = reserve(npx * 16, 1)) != kOk) return rc;
+    NUS_HIP(hipMemcpyAsync(slot_[0], in, npx * 4, hipMemcpyHostToDevice, stream_));
+    NUS_HIP(launch_rgba8_to_f32(static_cast<const uint8_t *>(slot_[0]), static_cast<float *>(slot_[1]), w, h, stream_));
+    NUS_HIP(hipMemcpyAsync(out, slot_[1], npx * 16, hipMemcpyDeviceToHost, stream_));
+    NUS_HIP(hipStreamSynchronize(stream_));
+    return kOk;
+}
+
+int HipFlowEstimator::blur(const float *in, uint32_t w, uint32_t h, float *out)
+{
+    std::lock_guard<std::mutex> lk(mu_);
+    CHECK_DIMS(w, h);
+    if (!in || !out) return fail(kInvalidArgument, "flow: null pointer");
+    int rc = ensure_device();
+    if (rc != kOk) return rc;
+    const size_t bytes = (size_t)w * h * 16;
+    if ((rc = reserve(bytes, 0)) != kOk || (rc = reserve(bytes, 1)) != kOk) return rc;
+    float *d0 = static_cast<float *>(slot_[0]), *d1 = static_cast<float *>(slot_[1]);
+    NUS_HIP(hipMemcpyAsync(d0, in, bytes, hipMemcpyHostToDevice, stream_));
+    NUS_HIP(launch_blur(d0, d1, w, h, true, stream_));
+    NUS_HIP(launch_blur(d1, d0, w, h, false, stream_));
+    NUS_HIP(hipMemcpyAsync(out, d0, bytes, hipMemcpyDeviceToHost, stream_));
+    NUS_HIP(hipStreamSynchronize(stream_));
+    return kOk;
+}
+
+int HipFlowEstimator::downsample(const float *in, uint32_t w, uint32_t h, float *out)
+{
+    std::lock_guard<std::mutex> lk(mu_);
+    CHECK_DIMS(w, h);
+    if (!in || !out) return fail(kInvalidArgument, "flow: null pointer");
+    int rc = ensure_device();
+    if (rc != kOk) return rc;
+    const size_t bytes = (size_t)w * h * 16, obytes = (size_t)((w + 1) / 2) * ((h + 1) / 2) * 16;
+    if ((rc = reserve(bytes, 0)) != kOk || (rc = reserve(obytes, 1)) != kOk) return rc;
+    NUS_HIP(hipMemcpyAsync(slot_[0], in, bytes, hipMemcpyHostToDevice, stream_));
+    NUS_HIP(launch_downsample(static_cast<const float *>(slot_[0]), static_cast<float *>(slot_[1]), w, h, stream_));
+    NUS_HIP(hipMemcpyAsync(out, slot_[1], obytes, hipMemcpyDeviceToHost, stream_));
+    NUS_HIP(hipStreamSynchronize(stream_));
+    return kOk;
+}
+
+int HipFlowEstimator::horn_schunck(const float *i1, const float *i2, const float *flow_in, uint32_t w, uint32_t h,
+                                   float lambda, uint32_t iterations, float *flow_out)
+{
+    std::lock_guard<std::mutex> lk(mu_);
+    CHECK_DIMS(w, h);
+    if (!i1 || !i2 || !flow_out) return fail(kInvalidArgument, "flow: null pointer");
+    int rc = ensure_device();
+    if (rc != kOk) return rc;
+    const size_t ib = (size_t)w * h * 16, fb = (size_t)w * h * 8;
+    if ((rc = reserve(ib, 0)) != kOk || (rc = reserve(ib, 1)) != kOk || (rc = reserve(fb, 2)) != kOk ||
+        (rc = reserve(fb, 3)) != kOk)
+        return rc;
+    NUS_HIP(hipMemcpyAsync(slot_[0], i1, ib, hipMemcpyHostToDevice, stream_));
+    NUS_HIP(hipMemcpyAsync(slot_[1], i2, ib, hipMemcpyHostToDevice, stream_));
+    if (flow_in)
+        NUS_HIP(hipMemcpyAsync(slot_[2], flow_in, fb, hipMemcpyHostToDevice, stream_));
+    else
+        NUS_HIP(hipMemsetAsync(slot_[2], 0, fb, stream_)); // compute_coarse_flow clears the flow (:1136-1154)
+    float *f0 = static_cast<float *>(slot_[2]), *f1 = static_cast<float *>(slot_[3]);
+    for (uint32_t i = 0; i < iterations; ++i) { // ping-pong as :1156-1193
+        NUS_HIP(launch_horn_schunck(static_cast<const float *>(slot_[0]), static_cast<const float *>(slot_[1]), f0, f1, w, h, lambda, stream_));
+        float *t = f0;
+        f0 = f1;
+        f1 = t;
+    }
+    NUS_HIP(hipMemcpyAsync(flow_out, f0, fb, hipMemcpyDeviceToHost, stream_));
+    NUS_HIP(hipStreamSynchronize(stream_));
+    return kOk;
+}
+
+int HipFlowEstimator::upsample(const float *src, uint32_t sw, uint32_t sh, float *dst, uint32_t dw, uint32_t dh, float scale)
+{
+    std::lock_guard<std::mutex> lk(mu_);
+    CHECK_DIMS(sw, sh);
+    CHECK_DIMS(dw, dh);
+    if (!src || !dst) return fail(kInvalidArgument, "flow: null pointer");
+    int rc = ensure_device();
+    if (rc != kOk) return rc;
+    const size_t sb = (size_t)sw * sh * 8, db = (size_t)dw * dh * 8;
+    if ((rc = reserve(sb, 2)) != kOk || (rc = reserve(db, 3)) != kOk) return rc;
+    NUS_HIP(hipMemcpyAsync(slot_[2], src, sb, hipMemcpyHostToDevice, stream_));
+    NUS_HIP(launch_flow_upsample(static_cast<const float *>(slot_[2]), sw, sh, static_cast<float *>(slot_[3]), dw, dh, scale, stream_));
+    NUS_HIP(hipMemcpyAsync(dst, slot_[3], db, hipMemcpyDeviceToHost, stream_));
+    NUS_HIP(hipStreamSynchronize(stream_));
+    return kOk;
+}
+
+// Device workspace layout of one estimate (slots): 0 tmp / current input (w*h*16),
+// 1 blur temp (w*h*16), 2..3 flow ping-pong (w*h*8), 4 pyramid A, 5 pyramid B (all levels,
+// packed), 6..7 RGBA8 staging for the host entry point.
+int HipFlowEstimator::estimate_device(const void *d_a, const void *d_b, uint32_t w, uint32_t h, uint32_t levels,
+                                      uint32_t coarse_iters, uint32_t refine_iters, float lambda, void *d_flow_out,
+                                      hipStream_t stream)
+{
+    std::lock_guard<std::mutex> lk(mu_);
+    CHECK_DIMS(w, h);
+    if (!d_a || !d_b || !d_flow_out) return fail(kInvalidArgument, "flow: null device pointer");
+    if (levels == 0 || levels > 12) return fail(kInvalidArgument, "flow: levels must be 1..12");
+    int rc = ensure_device();
+    if (rc != kOk) return rc;
+    // level geometry (build_pyramid: next = (cur + 1) / 2, wgpu_interpolator.rs:1008-1009)
+    uint32_t lw[12], lh[12];
+    size_t loff[12], total = 0;
+    uint32_t nl = 0;
+    for (uint32_t l = 0, cw = w, ch = h; l < levels; ++l) {
+        lw[l] = cw;
+        lh[l] = ch;
+        loff[l] = total;
+        total += (size_t)cw * ch * 16;
+        nl = l + 1;
+        if (cw == 1 && ch == 1) break;
+        cw = (cw + 1) / 2;
+        ch = (ch + 1) / 2;
+    }
+    const size_t ib = (size_t)w * h * 16, fb = (size_t)w * h * 8;
+    if ((rc = reserve(ib, 0)) != kOk || (rc = reserve(ib, 1)) != kOk || (rc = reserve(fb, 2)) != kOk ||
+        (rc = reserve(fb, 3)) != kOk || (rc = reserve(total, 4)) != kOk || (rc = reserve(total, 5)) != kOk)
+        return rc;
+    float *cur = static_cast<float *>(slot_[0]), *tmp = static_cast<float *>(slot_[1]);
+    for (int f = 0; f < 2; ++f) {
+        uint8_t *pyr = static_cast<uint8_t *>(slot_[4 + f]);
+        NUS_HIP(launch_rgba8_to_f32(static_cast<const uint8_t *>(f ? d_b : d_a), cur, w, h, stream));
+        for (uint32_t l = 0; l < nl; ++l) {
+            float *level = reinterpret_cast<float *>(pyr + loff[l]);
+            NUS_HIP(launch_blur(cur, tmp, lw[l], lh[l], true, stream));
+            NUS_HIP(launch_blur(tmp, level, lw[l], lh[l], false, stream));
+            if (l + 1 < nl) NUS_HIP(launch_downsample(level, cur, lw[l], lh[l], stream));
+        }
+    }
+    const uint8_t *pa = static_cast<const uint8_t *>(slot_[4]), *pb = static_cast<const uint8_t *>(slot_[5]);
+    float *f0 = static_cast<float *>(slot_[2]), *f1 = static_cast<float *>(slot_[3]);
+    const uint32_t L = nl - 1;
+    NUS_HIP(hipMemsetAsync(f0, 0, (size_t)lw[L] * lh[L] * 8, stream));
+    for (uint32_t i = 0; i < coarse_iters; ++i) {
+        NUS_HIP(launch_horn_schunck(reinterpret_cast<const float *>(pa + loff[L]), reinterpret_cast<const float *>(pb + loff[L]),
+                                    f0, f1, lw[L], lh[L], lambda, stream));
+        float *t = f0;
+        f0 = f1;
+        f1 = t;
+    }
+    for (int l = (int)L - 1; l >= 0; --l) {
+        NUS_HIP(launch_flow_upsample(f0, lw[l + 1], lh[l + 1], f1, lw[l], lh[l], 2.0f, stream));
+        float *t = f0;
+        f0 = f1;
+        f1 = t;
+        for (uint32_t i = 0; i < refine_iters; ++i) {
+            NUS_HIP(launch_horn_schunck(reinterpret_cast<const float *>(pa + loff[l]), reinterpret_cast<const float *>(pb + loff[l]),
+                                        f0, f1, lw[l], lh[l], lambda, stream));
+            t = f0;
+            f0 = f1;
+            f1 = t;
+        }
+    }
+    NUS_HIP(hipMemcpyAsync(d_flow_out, f0, fb, hipMemcpyDeviceToDevice, stream));
+    return kOk;
+}
+
+int HipFlowEstimator::estimate(const uint8_t *a, const uint8_t *b, uint32_t w, uint32_t h, uint32_t levels,
+                               uint32_t coarse_iters, uint32_t refine_iters, float lambda, float *flow_out)
+{
+    {
+        std::lock_guard<std::mutex> lk(mu_);
+        CHECK_DIMS(w, h);
+        if (!a || !b || !flow_out) return fail(kInvalidArgument, "flow: null pointer");
+        int rc = ensure_device();
+        if (rc != kOk) return rc;
+        const size_t fbytes = (size_t)w * h * 4;
+        if ((rc = reserve(fbytes, 6)) != kOk || (rc = reserve(fbytes > (size_t)w * h * 8 ? fbytes : (size_t)w * h * 8, 7)) != kOk) return rc;
+        NUS_HIP(hipMemcpyAsync(slot_[6], a, fbytes, hipMemcpyHostToDevice, stream_));
+        NUS_HIP(hipMemcpyAsync(slot_[7], b, fbytes, hipMemcpyHostToDevice, stream_));
+    }
+    // slot 7 doubles as the flow output once frame B has been converted (estimate_device copies
+    // into it last, after every reader of frame B has been enqueued on the same stream)
+    int rc = estimate_device(slot_[6], slot_[7], w, h, levels, coarse_iters, refine_iters, lambda, slot_[7], stream_);
+    if (rc != kOk) return rc;
+    std::lock_guard<std::mutex> lk(mu_);
+    NUS_HIP(hipMemcpyAsync(flow_out, slot_[7], (size_t)w * h * 8, hipMemcpyDeviceToHost, stream_));
+    NUS_HIP(hipStreamSynchronize(stream_));
+    return kOk;
+}
+
+} // namespace nus

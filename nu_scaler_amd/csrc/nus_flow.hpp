@@ -1,0 +1,58 @@
+// nus_flow.hpp -- optical-flow front end of the frame interpolator ("next" row, SURVEY.md
+// section 8f rank 1): mirrors WgpuFrameInterpolator::build_pyramid / compute_coarse_flow
+// (nu_scaler_core/src/wgpu_interpolator.rs:969-1203) on HIP, plus the coarse-to-fine
+// warm start the reference sketches but never wires (its refine path is dead code).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <mutex>
+#include <string>
+#include <vector>
+
+namespace nus {
+
+class HipFlowEstimator {
+public:
+    HipFlowEstimator() = default;
+    ~HipFlowEstimator();
+    HipFlowEstimator(const HipFlowEstimator &) = delete;
+    HipFlowEstimator &operator=(const HipFlowEstimator &) = delete;
+
+    int set_device(int device);
+    const char *last_error() const { return error_.c_str(); }
+
+    // Primitives on host buffers (parity tests, integration).  f32 RGBA images, float2 flows.
+    int rgba8_to_f32(const uint8_t *in, uint32_t w, uint32_t h, float *out);
+    int blur(const float *in, uint32_t w, uint32_t h, float *out);        // H pass then V pass
+    int downsample(const float *in, uint32_t w, uint32_t h, float *out);  // -> ((w+1)/2, (h+1)/2)
+    int horn_schunck(const float *i1, const float *i2, const float *flow_in_or_null, uint32_t w, uint32_t h,
+                     float lambda, uint32_t iterations, float *flow_out);
+    int upsample(const float *src, uint32_t sw, uint32_t sh, float *dst, uint32_t dw, uint32_t dh, float scale);
+
+    // Full estimator: RGBA8 frames -> dense flow (w*h*2 floats, pixel delta A -> B).
+    int estimate(const uint8_t *a, const uint8_t *b, uint32_t w, uint32_t h, uint32_t levels, uint32_t coarse_iters,
+                 uint32_t refine_iters, float lambda, float *flow_out);
+    int estimate_device(const void *d_a, const void *d_b, uint32_t w, uint32_t h, uint32_t levels,
+                        uint32_t coarse_iters, uint32_t refine_iters, float lambda, void *d_flow_out,
+                        hipStream_t stream);
+
+private:
+    int fail(int status, const std::string &msg);
+    int fail_hip(hipError_t e, const char *what);
+    int ensure_device();
+    int reserve(size_t bytes, int slot); // grow-only device scratch slots
+    void release();
+
+    std::mutex mu_;
+    int device_ = 0;
+    bool ready_ = false;
+    hipStream_t stream_ = nullptr;
+    static constexpr int kSlotCount = 8;
+    void *slot_[kSlotCount] = {nullptr};
+    size_t slot_cap_[kSlotCount] = {0};
+    std::string error_;
+};
+
+} // namespace nus

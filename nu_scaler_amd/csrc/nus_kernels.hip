@@ -702,6 +702,115 @@ __global__ __launch_bounds__(256) void k_warp_blend_flow(
     reinterpret_cast<uint32_t *>(out)[(size_t)blockIdx.z * npx + idx] = blend_px(sa, sb, t, nt);
 }
 
+// ---------------------------------------------------------------------------------
+// Optical-flow front end: Gaussian pyramid + Horn-Schunck
+// ---------------------------------------------------------------------------------
+// Images: f32 RGBA, one float4 (16 B) per pixel per lane; flows: float2 per pixel.
+// Straight per-pixel kernels with the shaders' exact expression order (no contraction).
+
+__global__ __launch_bounds__(256) void k_rgba8_to_f32(const uint32_t *__restrict__ in, float4 *__restrict__ out, size_t npx)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= npx) return;
+    const uint32_t p = in[i];
+    out[i] = make_float4(ch_f32(p, 0) / 255.0f, ch_f32(p, 1) / 255.0f, ch_f32(p, 2) / 255.0f, ch_f32(p, 3) / 255.0f);
+}
+
+__device__ __forceinline__ float4 blur5(const float4 m2, const float4 m1, const float4 c0, const float4 p1, const float4 p2)
+{
+    // gaussian_blur_h.wgsl:42-46: m2*W0 + m1*W1 + c*W2 + p1*W1 + p2*W0, left to right
+    const float W0 = 1.0f / 16.0f, W1 = 4.0f / 16.0f, W2 = 6.0f / 16.0f;
+    float4 r;
+    r.x = m2.x * W0 + m1.x * W1 + c0.x * W2 + p1.x * W1 + p2.x * W0;
+    r.y = m2.y * W0 + m1.y * W1 + c0.y * W2 + p1.y * W1 + p2.y * W0;
+    r.z = m2.z * W0 + m1.z * W1 + c0.z * W2 + p1.z * W1 + p2.z * W0;
+    r.w = m2.w * W0 + m1.w * W1 + c0.w * W2 + p1.w * W1 + p2.w * W0;
+    return r;
+}
+
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+// blockDim = (64, 4)
+template <bool HORIZONTAL>
+__global__ __launch_bounds__(256) void k_blur(const float4 *__restrict__ in, float4 *__restrict__ out, int w, int h)
+{
+    const int x = blockIdx.x * kWave + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
+    if (x >= w || y >= h) return;
+    float4 t[5];
+#pragma unroll
+    for (int k = -2; k <= 2; ++k) {
+        const int xx = HORIZONTAL ? clampi(x + k, 0, w - 1) : x;
+        const int yy = HORIZONTAL ? y : clampi(y + k, 0, h - 1);
+        t[k + 2] = in[(size_t)yy * w + xx];
+    }
+    out[(size_t)y * w + x] = blur5(t[0], t[1], t[2], t[3], t[4]);
+}
+
+// downsample.wgsl:22-37, out = ((w+1)/2, (h+1)/2), source clamped at the far edge
+__global__ __launch_bounds__(256) void k_downsample(const float4 *__restrict__ in, float4 *__restrict__ out, int w, int h)
+{
+    const int ow = (w + 1) / 2, oh = (h + 1) / 2;
+    const int x = blockIdx.x * kWave + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
+    if (x >= ow || y >= oh) return;
+    const int x0 = 2 * x, y0 = 2 * y, x1 = min(x0 + 1, w - 1), y1 = min(y0 + 1, h - 1);
+    const float4 c00 = in[(size_t)y0 * w + x0], c10 = in[(size_t)y0 * w + x1];
+    const float4 c01 = in[(size_t)y1 * w + x0], c11 = in[(size_t)y1 * w + x1];
+    float4 r;
+    r.x = (c00.x + c10.x + c01.x + c11.x) * 0.25f;
+    r.y = (c00.y + c10.y + c01.y + c11.y) * 0.25f;
+    r.z = (c00.z + c10.z + c01.z + c11.z) * 0.25f;
+    r.w = (c00.w + c10.w + c01.w + c11.w) * 0.25f;
+    out[(size_t)y * ow + x] = r;
+}
+
+__device__ __forceinline__ float lum(const float4 c) { return (c.x + c.y + c.z) * 0.33333f; } // horn_schunck.wgsl:17-20
+
+// One Jacobi step, horn_schunck.wgsl:48-92.
+__global__ __launch_bounds__(256) void k_horn_schunck(const float4 *__restrict__ i1, const float4 *__restrict__ i2,
+                                                      const float2 *__restrict__ fin, float2 *__restrict__ fout,
+                                                      int w, int h, float lambda)
+{
+    const int x = blockIdx.x * kWave + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
+    if (x >= w || y >= h) return;
+    const int xp = min(x + 1, w - 1), xm = max(x, 1) - 1, yp = min(y + 1, h - 1), ym = max(y, 1) - 1;
+    const float ix = (lum(i1[(size_t)y * w + xp]) - lum(i1[(size_t)y * w + xm])) * 0.5f;
+    const float iy = (lum(i1[(size_t)yp * w + x]) - lum(i1[(size_t)ym * w + x])) * 0.5f;
+    const float it = lum(i2[(size_t)y * w + x]) - lum(i1[(size_t)y * w + x]);
+    float su = 0.0f, sv = 0.0f, count = 0.0f;
+#pragma unroll
+    for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+        for (int dx = -1; dx <= 1; ++dx) {
+            const float2 f = fin[(size_t)clampi(y + dy, 0, h - 1) * w + clampi(x + dx, 0, w - 1)];
+            su += f.x;
+            sv += f.y;
+            count += 1.0f;
+        }
+    const float ua = su / count, va = sv / count;
+    const float common = (ix * ua + iy * va + it) / (lambda + ix * ix + iy * iy);
+    fout[(size_t)y * w + x] = make_float2(ua - common * ix, va - common * iy);
+}
+
+// flow_upsample.wgsl:27-36 (linear clamp-to-edge sampler in texel space), vectors * scale
+__global__ __launch_bounds__(256) void k_flow_upsample(const float2 *__restrict__ src, int sw, int sh,
+                                                       float2 *__restrict__ dst, int dw, int dh, float scale)
+{
+    const int x = blockIdx.x * kWave + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
+    if (x >= dw || y >= dh) return;
+    const float u = ((float)x + 0.5f) / (float)dw, v = ((float)y + 0.5f) / (float)dh;
+    const float sx = u * (float)sw - 0.5f, sy = v * (float)sh - 0.5f;
+    const float fx0 = floorf(sx), fy0 = floorf(sy);
+    const float fx = sx - fx0, fy = sy - fy0;
+    const int x0 = clampi((int)fx0, 0, sw - 1), x1 = clampi((int)fx0 + 1, 0, sw - 1);
+    const int y0 = clampi((int)fy0, 0, sh - 1), y1 = clampi((int)fy0 + 1, 0, sh - 1);
+    const float2 a = src[(size_t)y0 * sw + x0], b = src[(size_t)y0 * sw + x1];
+    const float2 c = src[(size_t)y1 * sw + x0], d = src[(size_t)y1 * sw + x1];
+    float2 r;
+    r.x = ((a.x * (1.0f - fx) + b.x * fx) * (1.0f - fy) + (c.x * (1.0f - fx) + d.x * fx) * fy) * scale;
+    r.y = ((a.y * (1.0f - fx) + b.y * fx) * (1.0f - fy) + (c.y * (1.0f - fx) + d.y * fx) * fy) * scale;
+    dst[(size_t)y * dw + x] = r;
+}
+
 constexpr uint32_t kMaxGridZ = 65535;
 
 } // namespace
@@ -863,6 +972,50 @@ hipError_t launch_lanczos_x2_edges(const UpscaleLaunch &L, const DeviceTables &T
         else
             hipLaunchKernelGGL(k_lanczos3_x2_edges<false>, grid, block, 0, L.stream, A);
     });
+}
+
+hipError_t launch_rgba8_to_f32(const uint8_t *in, float *out, uint32_t w, uint32_t h, hipStream_t stream)
+{
+    const size_t npx = (size_t)w * h;
+    hipLaunchKernelGGL(k_rgba8_to_f32, dim3((uint32_t)((npx + 255) / 256)), dim3(256), 0, stream,
+                       reinterpret_cast<const uint32_t *>(in), reinterpret_cast<float4 *>(out), npx);
+    return hipGetLastError();
+}
+
+hipError_t launch_blur(const float *in, float *out, uint32_t w, uint32_t h, bool horizontal, hipStream_t stream)
+{
+    const dim3 block(kWave, 4), grid(cdiv(w, kWave), cdiv(h, 4));
+    if (horizontal)
+        hipLaunchKernelGGL(k_blur<true>, grid, block, 0, stream, reinterpret_cast<const float4 *>(in), reinterpret_cast<float4 *>(out), (int)w, (int)h);
+    else
+        hipLaunchKernelGGL(k_blur<false>, grid, block, 0, stream, reinterpret_cast<const float4 *>(in), reinterpret_cast<float4 *>(out), (int)w, (int)h);
+    return hipGetLastError();
+}
+
+hipError_t launch_downsample(const float *in, float *out, uint32_t w, uint32_t h, hipStream_t stream)
+{
+    const dim3 block(kWave, 4), grid(cdiv((w + 1) / 2, kWave), cdiv((h + 1) / 2, 4));
+    hipLaunchKernelGGL(k_downsample, grid, block, 0, stream, reinterpret_cast<const float4 *>(in), reinterpret_cast<float4 *>(out), (int)w, (int)h);
+    return hipGetLastError();
+}
+
+hipError_t launch_horn_schunck(const float *i1, const float *i2, const float *flow_in, float *flow_out, uint32_t w,
+                               uint32_t h, float lambda, hipStream_t stream)
+{
+    const dim3 block(kWave, 4), grid(cdiv(w, kWave), cdiv(h, 4));
+    hipLaunchKernelGGL(k_horn_schunck, grid, block, 0, stream, reinterpret_cast<const float4 *>(i1),
+                       reinterpret_cast<const float4 *>(i2), reinterpret_cast<const float2 *>(flow_in),
+                       reinterpret_cast<float2 *>(flow_out), (int)w, (int)h, lambda);
+    return hipGetLastError();
+}
+
+hipError_t launch_flow_upsample(const float *src, uint32_t sw, uint32_t sh, float *dst, uint32_t dw, uint32_t dh,
+                                float scale, hipStream_t stream)
+{
+    const dim3 block(kWave, 4), grid(cdiv(dw, kWave), cdiv(dh, 4));
+    hipLaunchKernelGGL(k_flow_upsample, grid, block, 0, stream, reinterpret_cast<const float2 *>(src), (int)sw, (int)sh,
+                       reinterpret_cast<float2 *>(dst), (int)dw, (int)dh, scale);
+    return hipGetLastError();
 }
 
 hipError_t launch_warp_blend(const WarpLaunch &L)

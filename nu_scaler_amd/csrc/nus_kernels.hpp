@@ -77,4 +77,13 @@ struct WarpLaunch {
 
 hipError_t launch_warp_blend(const WarpLaunch &L);
 
+// Optical-flow front end (f32 RGBA images, float2 flows; device pointers).
+hipError_t launch_rgba8_to_f32(const uint8_t *in, float *out, uint32_t w, uint32_t h, hipStream_t stream);
+hipError_t launch_blur(const float *in, float *out, uint32_t w, uint32_t h, bool horizontal, hipStream_t stream);
+hipError_t launch_downsample(const float *in, float *out, uint32_t w, uint32_t h, hipStream_t stream);
+hipError_t launch_horn_schunck(const float *i1, const float *i2, const float *flow_in, float *flow_out, uint32_t w,
+                               uint32_t h, float lambda, hipStream_t stream);
+hipError_t launch_flow_upsample(const float *src, uint32_t sw, uint32_t sh, float *dst, uint32_t dw, uint32_t dh,
+                                float scale, hipStream_t stream);
+
 } // namespace nus

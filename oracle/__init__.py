@@ -67,6 +67,18 @@ def lib() -> ctypes.CDLL:
         L.orc_lanczos3_mt.restype = ctypes.c_int
         L.orc_warp_blend_mt.argtypes = [u8p, u8p, u8p, u32, u32, ctypes.c_float, u8p, ctypes.c_int]
         L.orc_warp_blend_mt.restype = None
+        f32p = ctypes.c_void_p
+        L.orc_rgba8_to_f32.argtypes = [u8p, u32, u32, f32p]
+        L.orc_rgba8_to_f32.restype = None
+        for name in ("orc_blur_h", "orc_blur_v", "orc_downsample"):
+            getattr(L, name).argtypes = [f32p, u32, u32, f32p]
+            getattr(L, name).restype = None
+        L.orc_horn_schunck_step.argtypes = [f32p, f32p, f32p, u32, u32, ctypes.c_float, f32p]
+        L.orc_horn_schunck_step.restype = None
+        L.orc_flow_upsample.argtypes = [f32p, u32, u32, f32p, u32, u32, ctypes.c_float]
+        L.orc_flow_upsample.restype = None
+        L.orc_flow_estimate.argtypes = [u8p, u8p, u32, u32, u32, u32, u32, ctypes.c_float, f32p]
+        L.orc_flow_estimate.restype = ctypes.c_int
         L.orc_max_threads.argtypes = []
         L.orc_max_threads.restype = ctypes.c_int
         L.orc_gen_gradient.argtypes = [u8p, u32, u32, u32]
@@ -175,4 +187,67 @@ def gen_noise(w: int, h: int, seed: int = 0x5EED):
 def gen_box(w: int, h: int, rgba=(255, 0, 0, 255)):
     out = np.empty((h, w, 4), dtype=np.uint8)
     lib().orc_gen_box(_ptr(out), w, h, *[int(v) for v in rgba])
+    return out
+
+
+# ---- optical-flow front end ("next" row) ---------------------------------------------
+
+def _f32img(a, ch=4):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    if a.ndim != 3 or a.shape[2] != ch:
+        raise ValueError(f"expected an (h, w, {ch}) float32 array")
+    return a
+
+
+def rgba8_to_f32(img):
+    img = _img(img)
+    h, w = img.shape[:2]
+    out = np.empty((h, w, 4), np.float32)
+    lib().orc_rgba8_to_f32(_ptr(img), w, h, _ptr(out))
+    return out
+
+
+def blur(img):
+    """H pass then V pass (gaussian_blur_h.wgsl, gaussian_blur_v.wgsl)."""
+    img = _f32img(img)
+    h, w = img.shape[:2]
+    tmp, out = np.empty_like(img), np.empty_like(img)
+    lib().orc_blur_h(_ptr(img), w, h, _ptr(tmp))
+    lib().orc_blur_v(_ptr(tmp), w, h, _ptr(out))
+    return out
+
+
+def downsample(img):
+    img = _f32img(img)
+    h, w = img.shape[:2]
+    out = np.empty(((h + 1) // 2, (w + 1) // 2, 4), np.float32)
+    lib().orc_downsample(_ptr(img), w, h, _ptr(out))
+    return out
+
+
+def horn_schunck(i1, i2, flow_in=None, iterations=1, lam=0.0004):
+    i1, i2 = _f32img(i1), _f32img(i2)
+    h, w = i1.shape[:2]
+    f0 = np.zeros((h, w, 2), np.float32) if flow_in is None else _f32img(flow_in, 2).copy()
+    f1 = np.empty_like(f0)
+    for _ in range(iterations):
+        lib().orc_horn_schunck_step(_ptr(i1), _ptr(i2), _ptr(f0), w, h, lam, _ptr(f1))
+        f0, f1 = f1, f0
+    return f0
+
+
+def flow_upsample(flow, dw, dh, scale=1.0):
+    flow = _f32img(flow, 2)
+    sh, sw = flow.shape[:2]
+    out = np.empty((dh, dw, 2), np.float32)
+    lib().orc_flow_upsample(_ptr(flow), sw, sh, _ptr(out), dw, dh, scale)
+    return out
+
+
+def flow_estimate(a, b, levels=3, coarse_iters=50, refine_iters=10, lam=0.0004):
+    a, b = _img(a), _img(b)
+    h, w = a.shape[:2]
+    out = np.empty((h, w, 2), np.float32)
+    if lib().orc_flow_estimate(_ptr(a), _ptr(b), w, h, levels, coarse_iters, refine_iters, lam, _ptr(out)) != 0:
+        raise RuntimeError("orc_flow_estimate failed")
     return out

@@ -398,6 +398,166 @@ void orc_warp_blend(const uint8_t *a, const uint8_t *b, const float *flow,
     warp_rows(a, b, flow, w, h, t, out, 0, h);
 }
 
+/* ---- optical-flow front end ("next" row; no reference fixture pins it) ------------ */
+
+void orc_rgba8_to_f32(const uint8_t *in, uint32_t w, uint32_t h, float *out)
+{
+    size_t n = (size_t)w * h * 4;
+    for (size_t i = 0; i < n; ++i) out[i] = (float)in[i] / 255.0f;
+}
+
+static inline uint32_t clampi(int v, int lo, int hi) { return (uint32_t)(v < lo ? lo : (v > hi ? hi : v)); }
+
+/* gaussian_blur_h.wgsl:29-48: clamp(x+-k, 0, w-1); sum = m2*W0 + m1*W1 + c*W2 + p1*W1 + p2*W0 */
+static void blur_axis(const float *in, uint32_t w, uint32_t h, float *out, int horizontal)
+{
+    const float W0 = 1.0f / 16.0f, W1 = 4.0f / 16.0f, W2 = 6.0f / 16.0f;
+    for (uint32_t y = 0; y < h; ++y) {
+        for (uint32_t x = 0; x < w; ++x) {
+            const float *p[5];
+            for (int k = -2; k <= 2; ++k) {
+                uint32_t xx = horizontal ? clampi((int)x + k, 0, (int)w - 1) : x;
+                uint32_t yy = horizontal ? y : clampi((int)y + k, 0, (int)h - 1);
+                p[k + 2] = in + ((size_t)yy * w + xx) * 4;
+            }
+            float *o = out + ((size_t)y * w + x) * 4;
+            for (int c = 0; c < 4; ++c)
+                o[c] = p[0][c] * W0 + p[1][c] * W1 + p[2][c] * W2 + p[3][c] * W1 + p[4][c] * W0;
+        }
+    }
+}
+
+void orc_blur_h(const float *in, uint32_t w, uint32_t h, float *out) { blur_axis(in, w, h, out, 1); }
+void orc_blur_v(const float *in, uint32_t w, uint32_t h, float *out) { blur_axis(in, w, h, out, 0); }
+
+/* downsample.wgsl:22-37 */
+void orc_downsample(const float *in, uint32_t w, uint32_t h, float *out)
+{
+    uint32_t ow = (w + 1) / 2, oh = (h + 1) / 2;
+    for (uint32_t y = 0; y < oh; ++y) {
+        for (uint32_t x = 0; x < ow; ++x) {
+            uint32_t x0 = x * 2, y0 = y * 2;
+            uint32_t x1 = u32_min(x0 + 1, w - 1), y1 = u32_min(y0 + 1, h - 1);
+            const float *c00 = in + ((size_t)y0 * w + x0) * 4, *c10 = in + ((size_t)y0 * w + x1) * 4;
+            const float *c01 = in + ((size_t)y1 * w + x0) * 4, *c11 = in + ((size_t)y1 * w + x1) * 4;
+            float *o = out + ((size_t)y * ow + x) * 4;
+            for (int c = 0; c < 4; ++c) o[c] = (c00[c] + c10[c] + c01[c] + c11[c]) * 0.25f;
+        }
+    }
+}
+
+/* horn_schunck.wgsl:17-20 */
+static inline float luminance(const float *px) { return (px[0] + px[1] + px[2]) * 0.33333f; }
+
+void orc_horn_schunck_step(const float *i1, const float *i2, const float *flow_in,
+                           uint32_t w, uint32_t h, float lambda, float *flow_out)
+{
+    for (uint32_t y = 0; y < h; ++y) {
+        for (uint32_t x = 0; x < w; ++x) {
+            /* :58-71 central differences on I1, clamped */
+            uint32_t xp = u32_min(x + 1, w - 1), xm = (x > 1 ? x : 1) - 1;
+            uint32_t yp = u32_min(y + 1, h - 1), ym = (y > 1 ? y : 1) - 1;
+            float ix = (luminance(i1 + ((size_t)y * w + xp) * 4) - luminance(i1 + ((size_t)y * w + xm) * 4)) * 0.5f;
+            float iy = (luminance(i1 + ((size_t)yp * w + x) * 4) - luminance(i1 + ((size_t)ym * w + x) * 4)) * 0.5f;
+            /* :74-76 */
+            float it = luminance(i2 + ((size_t)y * w + x) * 4) - luminance(i1 + ((size_t)y * w + x) * 4);
+            /* :24-46 3x3 average INCLUDING the centre, clamped neighbours, dy outer, dx inner */
+            float su = 0.0f, sv = 0.0f, count = 0.0f;
+            for (int dy = -1; dy <= 1; ++dy)
+                for (int dx = -1; dx <= 1; ++dx) {
+                    uint32_t nx = clampi((int)x + dx, 0, (int)w - 1), ny = clampi((int)y + dy, 0, (int)h - 1);
+                    su += flow_in[((size_t)ny * w + nx) * 2];
+                    sv += flow_in[((size_t)ny * w + nx) * 2 + 1];
+                    count += 1.0f;
+                }
+            float ua = su / count, va = sv / count;
+            /* :82, :89 */
+            float common = (ix * ua + iy * va + it) / (lambda + ix * ix + iy * iy);
+            flow_out[((size_t)y * w + x) * 2] = ua - common * ix;
+            flow_out[((size_t)y * w + x) * 2 + 1] = va - common * iy;
+        }
+    }
+}
+
+/* flow_upsample.wgsl:27-36 with a linear clamp-to-edge sampler: texel-space position
+ * (id + 0.5) * src/dst - 0.5, weights (1-f, f) per axis, x first. */
+void orc_flow_upsample(const float *src, uint32_t sw, uint32_t sh,
+                       float *dst, uint32_t dw, uint32_t dh, float scale)
+{
+    for (uint32_t y = 0; y < dh; ++y) {
+        for (uint32_t x = 0; x < dw; ++x) {
+            float u = ((float)x + 0.5f) / (float)dw, v = ((float)y + 0.5f) / (float)dh;
+            float sx = u * (float)sw - 0.5f, sy = v * (float)sh - 0.5f;
+            float fx0 = floorf(sx), fy0 = floorf(sy);
+            float fx = sx - fx0, fy = sy - fy0;
+            uint32_t x0 = clampi((int)fx0, 0, (int)sw - 1), x1 = clampi((int)fx0 + 1, 0, (int)sw - 1);
+            uint32_t y0 = clampi((int)fy0, 0, (int)sh - 1), y1 = clampi((int)fy0 + 1, 0, (int)sh - 1);
+            for (int c = 0; c < 2; ++c) {
+                float top = src[((size_t)y0 * sw + x0) * 2 + c] * (1.0f - fx) + src[((size_t)y0 * sw + x1) * 2 + c] * fx;
+                float bot = src[((size_t)y1 * sw + x0) * 2 + c] * (1.0f - fx) + src[((size_t)y1 * sw + x1) * 2 + c] * fx;
+                dst[((size_t)y * dw + x) * 2 + c] = (top * (1.0f - fy) + bot * fy) * scale;
+            }
+        }
+    }
+}
+
+int orc_flow_estimate(const uint8_t *a, const uint8_t *b, uint32_t w, uint32_t h,
+                      uint32_t levels, uint32_t coarse_iters, uint32_t refine_iters,
+                      float lambda, float *flow_out)
+{
+    if (levels == 0 || levels > 12 || w == 0 || h == 0) return -1;
+    float *pyr[2][12] = {{0}};
+    uint32_t lw[12], lh[12];
+    size_t npx = (size_t)w * h;
+    float *tmp = (float *)malloc(npx * 4 * sizeof(float));
+    float *cur = (float *)malloc(npx * 4 * sizeof(float));
+    int rc = tmp && cur ? 0 : -1;
+    uint32_t nl = 0;
+    for (int f = 0; f < 2 && rc == 0; ++f) {
+        /* build_pyramid (wgpu_interpolator.rs:1006-1094): level l = blur_v(blur_h(input_l)); input_{l+1} = downsample(level l) */
+        orc_rgba8_to_f32(f ? b : a, w, h, cur);
+        uint32_t cw = w, ch = h;
+        nl = 0;
+        for (uint32_t l = 0; l < levels; ++l) {
+            uint32_t nw = (cw + 1) / 2, nh = (ch + 1) / 2;
+            pyr[f][l] = (float *)malloc((size_t)cw * ch * 4 * sizeof(float));
+            if (!pyr[f][l]) { rc = -1; break; }
+            orc_blur_h(cur, cw, ch, tmp);
+            orc_blur_v(tmp, cw, ch, pyr[f][l]);
+            lw[l] = cw; lh[l] = ch;
+            nl = l + 1;
+            if (l + 1 < levels) {
+                if (cw == 1 && ch == 1) break; /* cannot shrink further */
+                orc_downsample(pyr[f][l], cw, ch, cur);
+                cw = nw; ch = nh;
+            }
+        }
+    }
+    if (rc == 0) {
+        /* compute_coarse_flow (:1102-1203): zero flow, ping-pong Jacobi steps */
+        uint32_t L = nl - 1;
+        float *f0 = (float *)calloc(npx * 2, sizeof(float)), *f1 = (float *)calloc(npx * 2, sizeof(float));
+        if (!f0 || !f1) rc = -1;
+        for (uint32_t i = 0; rc == 0 && i < coarse_iters; ++i) {
+            orc_horn_schunck_step(pyr[0][L], pyr[1][L], f0, lw[L], lh[L], lambda, f1);
+            float *t = f0; f0 = f1; f1 = t;
+        }
+        for (int l = (int)L - 1; rc == 0 && l >= 0; --l) {
+            orc_flow_upsample(f0, lw[l + 1], lh[l + 1], f1, lw[l], lh[l], 2.0f);
+            float *t = f0; f0 = f1; f1 = t;
+            for (uint32_t i = 0; i < refine_iters; ++i) {
+                orc_horn_schunck_step(pyr[0][l], pyr[1][l], f0, lw[l], lh[l], lambda, f1);
+                t = f0; f0 = f1; f1 = t;
+            }
+        }
+        if (rc == 0) memcpy(flow_out, f0, npx * 2 * sizeof(float));
+        free(f0); free(f1);
+    }
+    for (int f = 0; f < 2; ++f) for (int l = 0; l < 12; ++l) free(pyr[f][l]);
+    free(tmp); free(cur);
+    return rc;
+}
+
 /* ---- OpenMP row-parallel variants (CPU baseline only) -------------------------- */
 
 int orc_max_threads(void)

@@ -53,6 +53,32 @@ int orc_resize_axis(uint32_t in_n, uint32_t out_n, int filter, uint32_t max_taps
 void orc_warp_blend(const uint8_t *a, const uint8_t *b, const float *flow,
                     uint32_t w, uint32_t h, float t, uint8_t *out);
 
+/* ---- optical-flow front end ("next" row) --------------
+ * Images are f32 RGBA (4 floats per pixel), flows 2 floats per pixel (dx, dy).
+ * u8 -> f32: value / 255.0f (the Rgba8Unorm view the interpolator has of its frames). */
+void orc_rgba8_to_f32(const uint8_t *in, uint32_t w, uint32_t h, float *out);
+/* shaders/gaussian_blur_h.wgsl:22-52 / gaussian_blur_v.wgsl:22-52: 5 taps [1,4,6,4,1]/16, clamped. */
+void orc_blur_h(const float *in, uint32_t w, uint32_t h, float *out);
+void orc_blur_v(const float *in, uint32_t w, uint32_t h, float *out);
+/* shaders/downsample.wgsl:14-38: 2x2 box average into ((w+1)/2, (h+1)/2)
+ * (wgpu_interpolator.rs:1008-1009); source reads beyond the edge clamp (build-defined:
+ * WGSL leaves out-of-bounds textureLoad open). */
+void orc_downsample(const float *in, uint32_t w, uint32_t h, float *out);
+/* shaders/horn_schunck.wgsl:48-92: one Jacobi step. */
+void orc_horn_schunck_step(const float *i1, const float *i2, const float *flow_in,
+                           uint32_t w, uint32_t h, float lambda, float *flow_out);
+/* shaders/flow_upsample.wgsl:21-37: bilinear, normalised-UV sampling (half-pixel centres,
+ * clamp to edge); vectors multiplied by `scale` (1.0 = the shader as written). */
+void orc_flow_upsample(const float *src, uint32_t sw, uint32_t sh,
+                       float *dst, uint32_t dw, uint32_t dh, float scale);
+/* Composite (host logic of wgpu_interpolator.rs:969-1203 + build-defined coarse-to-fine
+ * warm start): pyramids of both frames, `coarse_iters` steps from zero flow at the coarsest
+ * level, then per finer level: upsample x2 (vectors x2) and `refine_iters` more steps.
+ * flow_out: w*h*2 floats at full resolution.  Returns 0 or -1. */
+int orc_flow_estimate(const uint8_t *a, const uint8_t *b, uint32_t w, uint32_t h,
+                      uint32_t levels, uint32_t coarse_iters, uint32_t refine_iters,
+                      float lambda, float *flow_out);
+
 /* OpenMP row-parallel variants for the "all host cores" baseline
  * (same arithmetic, rows distributed over threads).  threads<=0: all cores. */
 void orc_nearest_mt(const uint8_t *in, uint32_t iw, uint32_t ih,

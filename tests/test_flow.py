@@ -1,0 +1,119 @@
+"""Optical-flow front end ("next" row): oracle sanity on CPU,
+HIP kernels against the oracle on GPU.  No reference fixture pins this row."""
+import numpy as np
+import pytest
+
+
+def _smooth(w, h, shift=0.0):
+    """Smooth textured RGBA8 frame whose content is displaced by `shift` pixels in x."""
+    x = np.arange(w, dtype=np.float64)[None, :] - shift
+    y = np.arange(h, dtype=np.float64)[:, None]
+    v = 127.5 + 60 * np.sin(x / 9.0) * np.cos(y / 7.0) + 50 * np.sin((x + 2 * y) / 23.0)
+    img = np.empty((h, w, 4), np.uint8)
+    img[..., 0] = np.clip(v, 0, 255)
+    img[..., 1] = np.clip(255 - v, 0, 255)
+    img[..., 2] = np.clip(v * 0.5 + 40, 0, 255)
+    img[..., 3] = 255
+    return img
+
+
+# ---- CPU: oracle properties -----------------------------------------------------------
+
+def test_oracle_blur_and_downsample_properties(oracle_mod):
+    flat = np.full((9, 13, 4), 0.625, np.float32)
+    assert np.array_equal(oracle_mod.blur(flat), flat)           # weights sum to exactly 1
+    assert np.array_equal(oracle_mod.downsample(flat), np.full((5, 7, 4), 0.625, np.float32))
+    img = oracle_mod.rgba8_to_f32(oracle_mod.gen_noise(13, 9, 4))
+    assert img.dtype == np.float32 and img.max() <= 1.0 and img.min() >= 0.0
+    b = oracle_mod.blur(img)
+    # interior pixel equals the separable 5x5 binomial applied in H-then-V order
+    k = np.array([1, 4, 6, 4, 1], np.float32) / np.float32(16)
+    hpass = sum(img[4, 6 + d - 2] * k[d] for d in range(5))
+    assert np.allclose(oracle_mod.blur(img)[4, 6], sum(
+        (sum(img[4 + e - 2, 6 + d - 2] * k[d] for d in range(5))) * k[e] for e in range(5)), atol=1e-6)
+    d = oracle_mod.downsample(img)
+    assert d.shape == (5, 7, 4)
+    assert np.allclose(d[1, 2], (img[2, 4] + img[2, 5] + img[3, 4] + img[3, 5]) * 0.25, atol=1e-7)
+    assert np.allclose(d[4, 6], (img[8, 12] * 4) * 0.25, atol=1e-7)  # odd edge: clamped reads
+
+
+def test_oracle_horn_schunck_recovers_a_shift(oracle_mod):
+    w, h = 96, 64
+    a, b = _smooth(w, h, 0.0), _smooth(w, h, 1.0)  # content moves +1 px in x from A to B
+    flow = oracle_mod.flow_estimate(a, b, levels=3, coarse_iters=100, refine_iters=30)
+    core = flow[12:-12, 12:-12]
+    assert abs(np.median(core[..., 0]) - 1.0) < 0.35 and abs(np.median(core[..., 1])) < 0.2
+    # zero motion -> zero flow
+    z = oracle_mod.flow_estimate(a, a, levels=3, coarse_iters=20, refine_iters=5)
+    assert np.abs(z).max() == 0.0
+
+
+def test_oracle_upsample_identity_and_scale(oracle_mod):
+    f = np.random.default_rng(1).standard_normal((7, 9, 2)).astype(np.float32)
+    assert np.allclose(oracle_mod.flow_upsample(f, 9, 7, 1.0), f, atol=1e-6)
+    u = oracle_mod.flow_upsample(np.ones((4, 5, 2), np.float32), 10, 8, 2.0)
+    assert np.allclose(u, 2.0)
+
+
+# ---- GPU: kernels vs oracle -------------------------------------------------------------
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("size", [(64, 40), (65, 33), (1, 1), (5, 3), (130, 71)])
+def test_flow_primitives_match_oracle(nsc, oracle_mod, size):
+    w, h = size
+    fe = nsc.FlowEstimator()
+    u8 = oracle_mod.gen_noise(w, h, 31)
+    img = fe.rgba8_to_f32(u8)
+    assert np.array_equal(img, oracle_mod.rgba8_to_f32(u8))
+    assert np.array_equal(fe.blur(img), oracle_mod.blur(img))
+    assert np.array_equal(fe.downsample(img), oracle_mod.downsample(img))
+    img2 = oracle_mod.rgba8_to_f32(oracle_mod.gen_noise(w, h, 32))
+    rng = np.random.default_rng(w + h)
+    f0 = rng.standard_normal((h, w, 2)).astype(np.float32)
+    for fin, it in ((None, 1), (None, 4), (f0, 3)):
+        got = fe.horn_schunck(img, img2, fin, iterations=it, lambda_=4e-4)
+        want = oracle_mod.horn_schunck(img, img2, fin, iterations=it, lam=4e-4)
+        assert np.array_equal(got, want), (size, it)
+    for (dw, dh, sc) in ((2 * w, 2 * h, 2.0), (2 * w - 1, 2 * h - 1, 2.0), (w, h, 1.0), (3 * w + 1, h + 2, 0.5)):
+        assert np.array_equal(fe.upsample(f0, dw, dh, sc), oracle_mod.flow_upsample(f0, dw, dh, sc)), (dw, dh)
+
+
+@pytest.mark.gpu
+def test_flow_estimate_matches_oracle_and_improves_interpolation(nsc, oracle_mod):
+    w, h = 192, 108
+    a, b = _smooth(w, h, 0.0), _smooth(w, h, 2.0)
+    fe = nsc.FlowEstimator(levels=3, coarse_iterations=60, refine_iterations=15)
+    flow = fe.estimate(a.tobytes(), b.tobytes(), w, h)
+    want = oracle_mod.flow_estimate(a, b, 3, 60, 15, fe.lambda_)
+    assert np.array_equal(flow, want)
+    # the estimated flow makes the in-between frame closer to the true half-way frame than zero flow does
+    truth = _smooth(w, h, 1.0).astype(np.int16)
+    it = nsc.WgpuFrameInterpolator()
+    mid_flow = np.frombuffer(it.interpolate_py(a.tobytes(), b.tobytes(), w, h, time_t=0.5, flow=flow), np.uint8).reshape(h, w, 4)
+    mid_zero = np.frombuffer(it.interpolate_py(a.tobytes(), b.tobytes(), w, h, time_t=0.5), np.uint8).reshape(h, w, 4)
+    core = (slice(16, -16), slice(16, -16))
+    err_flow = np.abs(mid_flow.astype(np.int16) - truth)[core].mean()
+    err_zero = np.abs(mid_zero.astype(np.int16) - truth)[core].mean()
+    assert err_flow < 0.6 * err_zero, (err_flow, err_zero)
+
+
+@pytest.mark.gpu
+def test_flow_estimate_device_path(nsc, oracle_mod):
+    import torch
+
+    w, h = 160, 90
+    a, b = _smooth(w, h, 0.0), _smooth(w, h, 1.5)
+    dev = torch.device("cuda:0")
+    da, db = torch.from_numpy(a).to(dev), torch.from_numpy(b).to(dev)
+    dflow = torch.empty((h, w, 2), dtype=torch.float32, device=dev)
+    fe = nsc.FlowEstimator(levels=4, coarse_iterations=30, refine_iterations=8)
+    fe.estimate_device(da.data_ptr(), db.data_ptr(), w, h, dflow.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert np.array_equal(dflow.cpu().numpy(), oracle_mod.flow_estimate(a, b, 4, 30, 8, fe.lambda_))
+    # and straight into the warp on the device
+    it = nsc.WgpuFrameInterpolator()
+    out = torch.empty((h, w, 4), dtype=torch.uint8, device=dev)
+    it.interpolate_device(da.data_ptr(), w * h * 4, db.data_ptr(), w * h * 4, dflow.data_ptr(), w, h, 0.5, out.data_ptr(), 1,
+                          torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert np.array_equal(out.cpu().numpy(), oracle_mod.warp_blend(a, b, dflow.cpu().numpy(), 0.5))
