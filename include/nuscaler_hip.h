@@ -236,6 +236,9 @@ typedef struct nus_flow nus_flow;
 nus_flow *nus_flow_create(void);
 void nus_flow_destroy(nus_flow *h);
 int nus_flow_set_device(nus_flow *h, int device);
+/* 1 (default): derivatives once per level and several Jacobi steps per launch on LDS tiles;
+ * 0: one plain kernel per step, the shader's structure.  Results are bit-identical. */
+int nus_flow_set_tiled(nus_flow *h, int enabled);
 const char *nus_flow_last_error(const nus_flow *h);
 
 /* primitives on host buffers */

@@ -267,6 +267,7 @@ const char *nus_interp_last_error(const nus_interp *h) { return h ? h->impl.last
 nus_flow *nus_flow_create(void) { return new (std::nothrow) nus_flow(); }
 void nus_flow_destroy(nus_flow *h) { delete h; }
 int nus_flow_set_device(nus_flow *h, int device) { return h ? h->impl.set_device(device) : null_handle(); }
+int nus_flow_set_tiled(nus_flow *h, int enabled) { return h ? h->impl.set_tiled(enabled != 0) : null_handle(); }
 const char *nus_flow_last_error(const nus_flow *h) { return h ? h->impl.last_error() : "null handle"; }
 
 int nus_flow_rgba8_to_f32(nus_flow *h, const uint8_t *in, uint32_t w, uint32_t hgt, float *out)

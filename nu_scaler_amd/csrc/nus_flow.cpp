@@ -42,6 +42,13 @@ int HipFlowEstimator::fail_hip(hipError_t e, const char *what)
                 std::string("HIP error in ") + what + ": " + hipGetErrorString(e));
 }
 
+int HipFlowEstimator::set_tiled(bool on)
+{
+    std::lock_guard<std::mutex> lk(mu_);
+    tiled_ = on;
+    return kOk;
+}
+
 int HipFlowEstimator::set_device(int device)
 {
     std::lock_guard<std::mutex> lk(mu_);
@@ -165,11 +172,18 @@ int HipFlowEstimator::horn_schunck(const float *i1, const float *i2, const float
     else
         NUS_HIP(hipMemsetAsync(slot_[2], 0, fb, stream_)); // compute_coarse_flow clears the flow (:1136-1154)
     float *f0 = static_cast<float *>(slot_[2]), *f1 = static_cast<float *>(slot_[3]);
-    for (uint32_t i = 0; i < iterations; ++i) { // ping-pong as :1156-1193
-        NUS_HIP(launch_horn_schunck(static_cast<const float *>(slot_[0]), static_cast<const float *>(slot_[1]), f0, f1, w, h, lambda, stream_));
-        float *t = f0;
-        f0 = f1;
-        f1 = t;
+    if (tiled_) {
+        if ((rc = reserve(ib, 4)) != kOk) return rc;
+        float *coef = static_cast<float *>(slot_[4]);
+        NUS_HIP(launch_hs_prepare(static_cast<const float *>(slot_[0]), static_cast<const float *>(slot_[1]), coef, w, h, lambda, stream_));
+        NUS_HIP(launch_hs_iterate(coef, &f0, &f1, w, h, iterations, stream_));
+    } else {
+        for (uint32_t i = 0; i < iterations; ++i) { // ping-pong as :1156-1193
+            NUS_HIP(launch_horn_schunck(static_cast<const float *>(slot_[0]), static_cast<const float *>(slot_[1]), f0, f1, w, h, lambda, stream_));
+            float *t = f0;
+            f0 = f1;
+            f1 = t;
+        }
     }
     NUS_HIP(hipMemcpyAsync(flow_out, f0, fb, hipMemcpyDeviceToHost, stream_));
     NUS_HIP(hipStreamSynchronize(stream_));
@@ -225,6 +239,7 @@ int HipFlowEstimator::estimate_device(const void *d_a, const void *d_b, uint32_t
         (rc = reserve(fb, 3)) != kOk || (rc = reserve(total, 4)) != kOk || (rc = reserve(total, 5)) != kOk)
         return rc;
     float *cur = static_cast<float *>(slot_[0]), *tmp = static_cast<float *>(slot_[1]);
+    float *coef = tmp; // the blur temp is free once the pyramids exist
     for (int f = 0; f < 2; ++f) {
         uint8_t *pyr = static_cast<uint8_t *>(slot_[4 + f]);
         NUS_HIP(launch_rgba8_to_f32(static_cast<const uint8_t *>(f ? d_b : d_a), cur, w, h, stream));
@@ -239,25 +254,29 @@ int HipFlowEstimator::estimate_device(const void *d_a, const void *d_b, uint32_t
     float *f0 = static_cast<float *>(slot_[2]), *f1 = static_cast<float *>(slot_[3]);
     const uint32_t L = nl - 1;
     NUS_HIP(hipMemsetAsync(f0, 0, (size_t)lw[L] * lh[L] * 8, stream));
-    for (uint32_t i = 0; i < coarse_iters; ++i) {
-        NUS_HIP(launch_horn_schunck(reinterpret_cast<const float *>(pa + loff[L]), reinterpret_cast<const float *>(pb + loff[L]),
-                                    f0, f1, lw[L], lh[L], lambda, stream));
-        float *t = f0;
-        f0 = f1;
-        f1 = t;
-    }
+    auto iterate = [&](uint32_t l, uint32_t iters) -> int {
+        const float *i1 = reinterpret_cast<const float *>(pa + loff[l]), *i2 = reinterpret_cast<const float *>(pb + loff[l]);
+        if (iters == 0) return kOk;
+        if (tiled_) {
+            NUS_HIP(launch_hs_prepare(i1, i2, coef, lw[l], lh[l], lambda, stream));
+            NUS_HIP(launch_hs_iterate(coef, &f0, &f1, lw[l], lh[l], iters, stream));
+            return kOk;
+        }
+        for (uint32_t i = 0; i < iters; ++i) {
+            NUS_HIP(launch_horn_schunck(i1, i2, f0, f1, lw[l], lh[l], lambda, stream));
+            float *t = f0;
+            f0 = f1;
+            f1 = t;
+        }
+        return kOk;
+    };
+    if ((rc = iterate(L, coarse_iters)) != kOk) return rc;
     for (int l = (int)L - 1; l >= 0; --l) {
         NUS_HIP(launch_flow_upsample(f0, lw[l + 1], lh[l + 1], f1, lw[l], lh[l], 2.0f, stream));
         float *t = f0;
         f0 = f1;
         f1 = t;
-        for (uint32_t i = 0; i < refine_iters; ++i) {
-            NUS_HIP(launch_horn_schunck(reinterpret_cast<const float *>(pa + loff[l]), reinterpret_cast<const float *>(pb + loff[l]),
-                                        f0, f1, lw[l], lh[l], lambda, stream));
-            t = f0;
-            f0 = f1;
-            f1 = t;
-        }
+        if ((rc = iterate((uint32_t)l, refine_iters)) != kOk) return rc;
     }
     NUS_HIP(hipMemcpyAsync(d_flow_out, f0, fb, hipMemcpyDeviceToDevice, stream));
     return kOk;

@@ -21,6 +21,9 @@ public:
     HipFlowEstimator &operator=(const HipFlowEstimator &) = delete;
 
     int set_device(int device);
+    // true (default): derivatives once per level + K Jacobi steps per launch in LDS; false: one
+    // plain kernel per step (the shader's structure).  Bit-identical results.
+    int set_tiled(bool on);
     const char *last_error() const { return error_.c_str(); }
 
     // Primitives on host buffers (parity tests, integration).  f32 RGBA images, float2 flows.
@@ -48,6 +51,7 @@ private:
     std::mutex mu_;
     int device_ = 0;
     bool ready_ = false;
+    bool tiled_ = true;
     hipStream_t stream_ = nullptr;
     static constexpr int kSlotCount = 8;
     void *slot_[kSlotCount] = {nullptr};

@@ -791,6 +791,78 @@ __global__ __launch_bounds__(256) void k_horn_schunck(const float4 *__restrict__
     fout[(size_t)y * w + x] = make_float2(ua - common * ix, va - common * iy);
 }
 
+// Derivatives of one pyramid level, computed once per level instead of once per Jacobi step:
+// (ix, iy, it, lambda + ix*ix + iy*iy) with exactly the expressions of horn_schunck.wgsl:58-82.
+__global__ __launch_bounds__(256) void k_hs_prepare(const float4 *__restrict__ i1, const float4 *__restrict__ i2,
+                                                    float4 *__restrict__ coef, int w, int h, float lambda)
+{
+    const int x = blockIdx.x * kWave + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
+    if (x >= w || y >= h) return;
+    const int xp = min(x + 1, w - 1), xm = max(x, 1) - 1, yp = min(y + 1, h - 1), ym = max(y, 1) - 1;
+    const float ix = (lum(i1[(size_t)y * w + xp]) - lum(i1[(size_t)y * w + xm])) * 0.5f;
+    const float iy = (lum(i1[(size_t)yp * w + x]) - lum(i1[(size_t)ym * w + x])) * 0.5f;
+    const float it = lum(i2[(size_t)y * w + x]) - lum(i1[(size_t)y * w + x]);
+    coef[(size_t)y * w + x] = make_float4(ix, iy, it, lambda + ix * ix + iy * iy);
+}
+
+// K Jacobi steps per launch on an LDS tile (temporal blocking): a 32x32 output tile is loaded
+// with a K-cell halo of the current flow and the per-cell coefficients; step j updates the
+// cells whose 3x3 neighbourhood was valid after step j-1 (the region shrinks by one ring per
+// step, except at the image border where neighbours clamp inwards), ping-ponging between two
+// LDS flow buffers.  Same arithmetic and order as k_horn_schunck, so K launches of that
+// kernel and one launch of this one produce identical bits.
+constexpr int kHsTile = 32;
+
+template <int K>
+__global__ __launch_bounds__(256) void k_hs_tiled(const float4 *__restrict__ coef, const float2 *__restrict__ fin,
+                                                  float2 *__restrict__ fout, int w, int h)
+{
+    constexpr int R = kHsTile + 2 * K;
+    __shared__ float4 s_coef[R * R];
+    __shared__ float2 s_flow[2][R * R];
+    const int x0 = blockIdx.x * kHsTile - K, y0 = blockIdx.y * kHsTile - K; // image coords of LDS cell (0,0)
+    for (int i = threadIdx.x; i < R * R; i += 256) {
+        const int lx = i % R, ly = i / R;
+        const int gx = clampi(x0 + lx, 0, w - 1), gy = clampi(y0 + ly, 0, h - 1);
+        s_coef[i] = coef[(size_t)gy * w + gx];
+        s_flow[0][i] = fin[(size_t)gy * w + gx];
+    }
+    __syncthreads();
+    int cur = 0;
+#pragma unroll 1
+    for (int j = 1; j <= K; ++j) {
+        const int m = j; // cells [m, R-m) are updated in step j (plus everything the image border clamps)
+        const int side = R - 2 * m;
+        for (int i = threadIdx.x; i < side * side; i += 256) {
+            const int lx = m + i % side, ly = m + i / side;
+            const int gx = x0 + lx, gy = y0 + ly;
+            if (gx < 0 || gy < 0 || gx >= w || gy >= h) continue;
+            float su = 0.0f, sv = 0.0f, count = 0.0f;
+#pragma unroll
+            for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+                for (int dx = -1; dx <= 1; ++dx) {
+                    const int nx = clampi(gx + dx, 0, w - 1) - x0, ny = clampi(gy + dy, 0, h - 1) - y0;
+                    const float2 f = s_flow[cur][ny * R + nx];
+                    su += f.x;
+                    sv += f.y;
+                    count += 1.0f;
+                }
+            const float ua = su / count, va = sv / count;
+            const float4 c = s_coef[ly * R + lx];
+            const float common = (c.x * ua + c.y * va + c.z) / c.w;
+            s_flow[cur ^ 1][ly * R + lx] = make_float2(ua - common * c.x, va - common * c.y);
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+    for (int i = threadIdx.x; i < kHsTile * kHsTile; i += 256) {
+        const int lx = K + i % kHsTile, ly = K + i / kHsTile;
+        const int gx = x0 + lx, gy = y0 + ly;
+        if (gx < w && gy < h) fout[(size_t)gy * w + gx] = s_flow[cur][ly * R + lx];
+    }
+}
+
 // flow_upsample.wgsl:27-36 (linear clamp-to-edge sampler in texel space), vectors * scale
 __global__ __launch_bounds__(256) void k_flow_upsample(const float2 *__restrict__ src, int sw, int sh,
                                                        float2 *__restrict__ dst, int dw, int dh, float scale)
@@ -1007,6 +1079,49 @@ hipError_t launch_horn_schunck(const float *i1, const float *i2, const float *fl
                        reinterpret_cast<const float4 *>(i2), reinterpret_cast<const float2 *>(flow_in),
                        reinterpret_cast<float2 *>(flow_out), (int)w, (int)h, lambda);
     return hipGetLastError();
+}
+
+hipError_t launch_hs_prepare(const float *i1, const float *i2, float *coef, uint32_t w, uint32_t h, float lambda,
+                             hipStream_t stream)
+{
+    const dim3 block(kWave, 4), grid(cdiv(w, kWave), cdiv(h, 4));
+    hipLaunchKernelGGL(k_hs_prepare, grid, block, 0, stream, reinterpret_cast<const float4 *>(i1),
+                       reinterpret_cast<const float4 *>(i2), reinterpret_cast<float4 *>(coef), (int)w, (int)h, lambda);
+    return hipGetLastError();
+}
+
+// `iterations` Jacobi steps from *flow_a, ping-ponging with *flow_b; on return *flow_a holds the
+// result (the pointers are swapped as needed).  Steps are grouped 8 / 4 / 2 / 1 per launch.
+hipError_t launch_hs_iterate(const float *coef, float **flow_a, float **flow_b, uint32_t w, uint32_t h,
+                             uint32_t iterations, hipStream_t stream)
+{
+    const dim3 block(256), grid(cdiv(w, kHsTile), cdiv(h, kHsTile));
+    auto c4 = reinterpret_cast<const float4 *>(coef);
+    while (iterations > 0) {
+        auto fi = reinterpret_cast<const float2 *>(*flow_a);
+        auto fo = reinterpret_cast<float2 *>(*flow_b);
+        uint32_t k;
+        if (iterations >= 8) {
+            k = 8;
+            hipLaunchKernelGGL(k_hs_tiled<8>, grid, block, 0, stream, c4, fi, fo, (int)w, (int)h);
+        } else if (iterations >= 4) {
+            k = 4;
+            hipLaunchKernelGGL(k_hs_tiled<4>, grid, block, 0, stream, c4, fi, fo, (int)w, (int)h);
+        } else if (iterations >= 2) {
+            k = 2;
+            hipLaunchKernelGGL(k_hs_tiled<2>, grid, block, 0, stream, c4, fi, fo, (int)w, (int)h);
+        } else {
+            k = 1;
+            hipLaunchKernelGGL(k_hs_tiled<1>, grid, block, 0, stream, c4, fi, fo, (int)w, (int)h);
+        }
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+        iterations -= k;
+        float *t = *flow_a;
+        *flow_a = *flow_b;
+        *flow_b = t;
+    }
+    return hipSuccess;
 }
 
 hipError_t launch_flow_upsample(const float *src, uint32_t sw, uint32_t sh, float *dst, uint32_t dw, uint32_t dh,

@@ -31,6 +31,10 @@ class FlowEstimator:
         if h:
             self._lib.nus_flow_destroy(h)
 
+    def set_tiled(self, enabled: bool) -> None:
+        """True (default): LDS-tiled multi-step Horn-Schunck; False: one plain kernel per step."""
+        self._check(self._lib.nus_flow_set_tiled(self._h, int(bool(enabled))))
+
     def _check(self, status: int) -> None:
         if status != C.OK:
             raise RuntimeError(self._lib.nus_flow_last_error(self._h).decode("utf-8", "replace"))

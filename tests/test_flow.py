@@ -70,10 +70,12 @@ def test_flow_primitives_match_oracle(nsc, oracle_mod, size):
     img2 = oracle_mod.rgba8_to_f32(oracle_mod.gen_noise(w, h, 32))
     rng = np.random.default_rng(w + h)
     f0 = rng.standard_normal((h, w, 2)).astype(np.float32)
-    for fin, it in ((None, 1), (None, 4), (f0, 3)):
-        got = fe.horn_schunck(img, img2, fin, iterations=it, lambda_=4e-4)
+    for fin, it in ((None, 1), (None, 4), (f0, 3), (f0, 15), (None, 8)):
         want = oracle_mod.horn_schunck(img, img2, fin, iterations=it, lam=4e-4)
-        assert np.array_equal(got, want), (size, it)
+        for tiled in (True, False):  # LDS-tiled multi-step kernel and the plain per-step kernel
+            fe.set_tiled(tiled)
+            got = fe.horn_schunck(img, img2, fin, iterations=it, lambda_=4e-4)
+            assert np.array_equal(got, want), (size, it, tiled)
     for (dw, dh, sc) in ((2 * w, 2 * h, 2.0), (2 * w - 1, 2 * h - 1, 2.0), (w, h, 1.0), (3 * w + 1, h + 2, 0.5)):
         assert np.array_equal(fe.upsample(f0, dw, dh, sc), oracle_mod.flow_upsample(f0, dw, dh, sc)), (dw, dh)
 
