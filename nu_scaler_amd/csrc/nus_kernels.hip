@@ -811,56 +811,74 @@ __global__ __launch_bounds__(256) void k_hs_prepare(const float4 *__restrict__ i
 // step, except at the image border where neighbours clamp inwards), ping-ponging between two
 // LDS flow buffers.  Same arithmetic and order as k_horn_schunck, so K launches of that
 // kernel and one launch of this one produce identical bits.
-constexpr int kHsTile = 32;
-
-template <int K>
-__global__ __launch_bounds__(256) void k_hs_tiled(const float4 *__restrict__ coef, const float2 *__restrict__ fin,
-                                                  float2 *__restrict__ fout, int w, int h)
+template <int T, int K, bool BORDER>
+__device__ __forceinline__ void hs_tile_steps(float4 *s_coef, float2 (*s_flow)[(T + 2 * K) * (T + 2 * K)], int x0, int y0,
+                                              int w, int h, int &cur)
 {
-    constexpr int R = kHsTile + 2 * K;
-    __shared__ float4 s_coef[R * R];
-    __shared__ float2 s_flow[2][R * R];
-    const int x0 = blockIdx.x * kHsTile - K, y0 = blockIdx.y * kHsTile - K; // image coords of LDS cell (0,0)
-    for (int i = threadIdx.x; i < R * R; i += 256) {
-        const int lx = i % R, ly = i / R;
-        const int gx = clampi(x0 + lx, 0, w - 1), gy = clampi(y0 + ly, 0, h - 1);
-        s_coef[i] = coef[(size_t)gy * w + gx];
-        s_flow[0][i] = fin[(size_t)gy * w + gx];
-    }
-    __syncthreads();
-    int cur = 0;
+    constexpr int R = T + 2 * K;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
 #pragma unroll 1
     for (int j = 1; j <= K; ++j) {
-        const int m = j; // cells [m, R-m) are updated in step j (plus everything the image border clamps)
-        const int side = R - 2 * m;
-        for (int i = threadIdx.x; i < side * side; i += 256) {
-            const int lx = m + i % side, ly = m + i / side;
-            const int gx = x0 + lx, gy = y0 + ly;
-            if (gx < 0 || gy < 0 || gx >= w || gy >= h) continue;
-            float su = 0.0f, sv = 0.0f, count = 0.0f;
+        // step j updates cells [j, R-j) of the tile (plus whatever the image border clamps inwards)
+        for (int ly = ty + j; ly < R - j; ly += 8) {
+            for (int lx = tx + j; lx < R - j; lx += 32) {
+                const int gx = x0 + lx, gy = y0 + ly;
+                if (BORDER && (gx < 0 || gy < 0 || gx >= w || gy >= h)) continue;
+                float su = 0.0f, sv = 0.0f, count = 0.0f;
 #pragma unroll
-            for (int dy = -1; dy <= 1; ++dy)
+                for (int dy = -1; dy <= 1; ++dy)
 #pragma unroll
-                for (int dx = -1; dx <= 1; ++dx) {
-                    const int nx = clampi(gx + dx, 0, w - 1) - x0, ny = clampi(gy + dy, 0, h - 1) - y0;
-                    const float2 f = s_flow[cur][ny * R + nx];
-                    su += f.x;
-                    sv += f.y;
-                    count += 1.0f;
-                }
-            const float ua = su / count, va = sv / count;
-            const float4 c = s_coef[ly * R + lx];
-            const float common = (c.x * ua + c.y * va + c.z) / c.w;
-            s_flow[cur ^ 1][ly * R + lx] = make_float2(ua - common * c.x, va - common * c.y);
+                    for (int dx = -1; dx <= 1; ++dx) {
+                        int nx = lx + dx, ny = ly + dy;
+                        if (BORDER) {
+                            nx = clampi(gx + dx, 0, w - 1) - x0;
+                            ny = clampi(gy + dy, 0, h - 1) - y0;
+                        }
+                        const float2 f = s_flow[cur][ny * R + nx];
+                        su += f.x;
+                        sv += f.y;
+                        count += 1.0f;
+                    }
+                const float ua = su / count, va = sv / count;
+                const float4 c = s_coef[ly * R + lx];
+                const float common = (c.x * ua + c.y * va + c.z) / c.w;
+                s_flow[cur ^ 1][ly * R + lx] = make_float2(ua - common * c.x, va - common * c.y);
+            }
         }
         __syncthreads();
         cur ^= 1;
     }
-    for (int i = threadIdx.x; i < kHsTile * kHsTile; i += 256) {
-        const int lx = K + i % kHsTile, ly = K + i / kHsTile;
-        const int gx = x0 + lx, gy = y0 + ly;
-        if (gx < w && gy < h) fout[(size_t)gy * w + gx] = s_flow[cur][ly * R + lx];
-    }
+}
+
+// T x T output tile, K steps; blockDim = 256 (32 x 8 cells per sweep).
+template <int T, int K>
+__global__ __launch_bounds__(256) void k_hs_tiled(const float4 *__restrict__ coef, const float2 *__restrict__ fin,
+                                                  float2 *__restrict__ fout, int w, int h)
+{
+    constexpr int R = T + 2 * K;
+    __shared__ float4 s_coef[R * R];
+    __shared__ float2 s_flow[2][R * R];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int x0 = blockIdx.x * T - K, y0 = blockIdx.y * T - K; // image coords of LDS cell (0,0)
+    for (int ly = ty; ly < R; ly += 8)
+        for (int lx = tx; lx < R; lx += 32) {
+            const int gx = clampi(x0 + lx, 0, w - 1), gy = clampi(y0 + ly, 0, h - 1);
+            s_coef[ly * R + lx] = coef[(size_t)gy * w + gx];
+            s_flow[0][ly * R + lx] = fin[(size_t)gy * w + gx];
+        }
+    __syncthreads();
+    int cur = 0;
+    // tiles whose loaded region lies strictly inside the image need no clamping at all
+    const bool border = x0 < 0 || y0 < 0 || x0 + R > w || y0 + R > h; // block-uniform
+    if (border)
+        hs_tile_steps<T, K, true>(s_coef, s_flow, x0, y0, w, h, cur);
+    else
+        hs_tile_steps<T, K, false>(s_coef, s_flow, x0, y0, w, h, cur);
+    for (int ly = ty + K; ly < T + K; ly += 8)
+        for (int lx = tx + K; lx < T + K; lx += 32) {
+            const int gx = x0 + lx, gy = y0 + ly;
+            if (gx < w && gy < h) fout[(size_t)gy * w + gx] = s_flow[cur][ly * R + lx];
+        }
 }
 
 // flow_upsample.wgsl:27-36 (linear clamp-to-edge sampler in texel space), vectors * scale
@@ -1091,29 +1109,34 @@ hipError_t launch_hs_prepare(const float *i1, const float *i2, float *coef, uint
 }
 
 // `iterations` Jacobi steps from *flow_a, ping-ponging with *flow_b; on return *flow_a holds the
-// result (the pointers are swapped as needed).  Steps are grouped 8 / 4 / 2 / 1 per launch.
+// result (the pointers are swapped as needed).  Steps are grouped 8 / 4 / 2 / 1 per launch; small
+// levels use 16x16 tiles so that the grid still covers the 256 CUs.
 hipError_t launch_hs_iterate(const float *coef, float **flow_a, float **flow_b, uint32_t w, uint32_t h,
                              uint32_t iterations, hipStream_t stream)
 {
-    const dim3 block(256), grid(cdiv(w, kHsTile), cdiv(h, kHsTile));
+    const bool small = (uint64_t)cdiv(w, 32) * cdiv(h, 32) < 1024;
+    const uint32_t T = small ? 16 : 32;
+    const dim3 block(256), grid(cdiv(w, T), cdiv(h, T));
     auto c4 = reinterpret_cast<const float4 *>(coef);
     while (iterations > 0) {
         auto fi = reinterpret_cast<const float2 *>(*flow_a);
         auto fo = reinterpret_cast<float2 *>(*flow_b);
         uint32_t k;
+#define NUS_HS(TT, KK) hipLaunchKernelGGL((k_hs_tiled<TT, KK>), grid, block, 0, stream, c4, fi, fo, (int)w, (int)h)
         if (iterations >= 8) {
             k = 8;
-            hipLaunchKernelGGL(k_hs_tiled<8>, grid, block, 0, stream, c4, fi, fo, (int)w, (int)h);
+            if (small) NUS_HS(16, 8); else NUS_HS(32, 8);
         } else if (iterations >= 4) {
             k = 4;
-            hipLaunchKernelGGL(k_hs_tiled<4>, grid, block, 0, stream, c4, fi, fo, (int)w, (int)h);
+            if (small) NUS_HS(16, 4); else NUS_HS(32, 4);
         } else if (iterations >= 2) {
             k = 2;
-            hipLaunchKernelGGL(k_hs_tiled<2>, grid, block, 0, stream, c4, fi, fo, (int)w, (int)h);
+            if (small) NUS_HS(16, 2); else NUS_HS(32, 2);
         } else {
             k = 1;
-            hipLaunchKernelGGL(k_hs_tiled<1>, grid, block, 0, stream, c4, fi, fo, (int)w, (int)h);
+            if (small) NUS_HS(16, 1); else NUS_HS(32, 1);
         }
+#undef NUS_HS
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
         iterations -= k;
