@@ -5,6 +5,10 @@ reference's own Python surface:  `import nu_scaler_amd as nu_scaler_core`.
 The compute path is libnuscaler_hip.so (hand-written HIP kernels behind the C ABI of
 include/nuscaler_hip.h).  There is no CPU fallback: constructing any class without the
 library raises, and compute calls without a HIP device raise RuntimeError.
+
+When the same process also uses PyTorch-ROCm (bench.py, the device-resident tests), import torch
+BEFORE this package: torch ships its own HIP runtime and fails to see the GPU if /opt/rocm's
+libamdhip64 (pulled in by libnuscaler_hip.so) is loaded first.
 """
 from . import _capi
 from ._capi import NuScalerLibraryError, build, device_count

@@ -3,6 +3,11 @@ import sys
 
 import pytest
 
+try:  # torch bundles its own HIP runtime: load it before libnuscaler_hip.so pulls in /opt/rocm's,
+    import torch  # noqa: F401  (otherwise torch.cuda later reports "No HIP GPUs are available")
+except Exception:  # pragma: no cover
+    torch = None
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "tests")):
     if p not in sys.path:
