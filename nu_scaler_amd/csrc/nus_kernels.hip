@@ -794,7 +794,8 @@ __global__ __launch_bounds__(256) void k_horn_schunck(const float4 *__restrict__
 // Derivatives of one pyramid level, computed once per level instead of once per Jacobi step:
 // (ix, iy, it, lambda + ix*ix + iy*iy) with exactly the expressions of horn_schunck.wgsl:58-82.
 __global__ __launch_bounds__(256) void k_hs_prepare(const float4 *__restrict__ i1, const float4 *__restrict__ i2,
-                                                    float4 *__restrict__ coef, int w, int h, float lambda)
+                                                    float4 *__restrict__ coef, float *__restrict__ zinv, int w, int h,
+                                                    float lambda)
 {
     const int x = blockIdx.x * kWave + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
     if (x >= w || y >= h) return;
@@ -802,7 +803,9 @@ __global__ __launch_bounds__(256) void k_hs_prepare(const float4 *__restrict__ i
     const float ix = (lum(i1[(size_t)y * w + xp]) - lum(i1[(size_t)y * w + xm])) * 0.5f;
     const float iy = (lum(i1[(size_t)yp * w + x]) - lum(i1[(size_t)ym * w + x])) * 0.5f;
     const float it = lum(i2[(size_t)y * w + x]) - lum(i1[(size_t)y * w + x]);
-    coef[(size_t)y * w + x] = make_float4(ix, iy, it, lambda + ix * ix + iy * iy);
+    const float den = lambda + ix * ix + iy * iy;
+    coef[(size_t)y * w + x] = make_float4(ix, iy, it, den);
+    zinv[(size_t)y * w + x] = 1.0f / den; // correctly rounded reciprocal, for div_by_recip
 }
 
 // K Jacobi steps per launch on an LDS tile (temporal blocking): a 32x32 output tile is loaded
@@ -811,69 +814,92 @@ __global__ __launch_bounds__(256) void k_hs_prepare(const float4 *__restrict__ i
 // step, except at the image border where neighbours clamp inwards), ping-ponging between two
 // LDS flow buffers.  Same arithmetic and order as k_horn_schunck, so K launches of that
 // kernel and one launch of this one produce identical bits.
-template <int T, int K, bool BORDER>
-__device__ __forceinline__ void hs_tile_steps(float4 *s_coef, float2 (*s_flow)[(T + 2 * K) * (T + 2 * K)], int x0, int y0,
-                                              int w, int h, int &cur)
+// Correctly rounded x / y from z = RN(1/y) with one multiply and two FMAs (Markstein): q = RN(x z),
+// r = x - q y (exact in the FMA), result = RN(q + r z).  Equal to the IEEE quotient for every finite
+// x when y = 9 (checked exhaustively on the CPU) and for every y whose mantissa is not all ones;
+// those y take the real division.  Replaces ~11 slow-class instructions per division by 3 fast ones.
+__device__ __forceinline__ float div_by_recip(float x, float y, float z)
+{
+    const float q = x * z;
+    const float r = __builtin_fmaf(-y, q, x);
+    return __builtin_fmaf(r, z, q);
+}
+
+struct HsCell {
+    float ix, iy, it, den, zinv;
+    bool plain_div; // mantissa of den all ones: Markstein's exception
+};
+
+// T x T output tile, K Jacobi steps per launch (temporal blocking); blockDim = 256 = 32 x 8 cells
+// per sweep.  Each thread owns the same (T+2K)^2 / 256 cells in every step, so their coefficients
+// live in registers and only the two ping-pong flow tiles are in LDS.
+template <int T, int K>
+__global__ __launch_bounds__(256) void k_hs_tiled(const float4 *__restrict__ coef, const float *__restrict__ zinv,
+                                                  const float2 *__restrict__ fin, float2 *__restrict__ fout, int w, int h)
 {
     constexpr int R = T + 2 * K;
+    constexpr int NA = (R + 7) / 8, NB = (R + 31) / 32;
+    __shared__ float2 s_flow[2][R * R];
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int x0 = blockIdx.x * T - K, y0 = blockIdx.y * T - K; // image coords of LDS cell (0,0)
+    HsCell cell[NA][NB];
+#pragma unroll
+    for (int a = 0; a < NA; ++a)
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            const int ly = ty + 8 * a, lx = tx + 32 * b;
+            if (ly < R && lx < R) {
+                const int gx = clampi(x0 + lx, 0, w - 1), gy = clampi(y0 + ly, 0, h - 1);
+                const size_t g = (size_t)gy * w + gx;
+                const float4 c = coef[g];
+                cell[a][b].ix = c.x;
+                cell[a][b].iy = c.y;
+                cell[a][b].it = c.z;
+                cell[a][b].den = c.w;
+                cell[a][b].zinv = zinv[g];
+                cell[a][b].plain_div = (__float_as_uint(c.w) & 0x7fffffu) == 0x7fffffu;
+                s_flow[0][ly * R + lx] = fin[g];
+            }
+        }
+    __syncthreads();
+    // tiles whose loaded region lies strictly inside the image need no clamping at all
+    const bool border = x0 < 0 || y0 < 0 || x0 + R > w || y0 + R > h; // block-uniform
+    int cur = 0;
 #pragma unroll 1
     for (int j = 1; j <= K; ++j) {
         // step j updates cells [j, R-j) of the tile (plus whatever the image border clamps inwards)
-        for (int ly = ty + j; ly < R - j; ly += 8) {
-            for (int lx = tx + j; lx < R - j; lx += 32) {
+#pragma unroll
+        for (int a = 0; a < NA; ++a)
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                const int ly = ty + 8 * a, lx = tx + 32 * b;
+                if (ly < j || ly >= R - j || lx < j || lx >= R - j) continue;
                 const int gx = x0 + lx, gy = y0 + ly;
-                if (BORDER && (gx < 0 || gy < 0 || gx >= w || gy >= h)) continue;
-                float su = 0.0f, sv = 0.0f, count = 0.0f;
+                if (border && (gx < 0 || gy < 0 || gx >= w || gy >= h)) continue;
+                float su = 0.0f, sv = 0.0f;
 #pragma unroll
                 for (int dy = -1; dy <= 1; ++dy)
 #pragma unroll
                     for (int dx = -1; dx <= 1; ++dx) {
                         int nx = lx + dx, ny = ly + dy;
-                        if (BORDER) {
+                        if (border) {
                             nx = clampi(gx + dx, 0, w - 1) - x0;
                             ny = clampi(gy + dy, 0, h - 1) - y0;
                         }
                         const float2 f = s_flow[cur][ny * R + nx];
                         su += f.x;
                         sv += f.y;
-                        count += 1.0f;
                     }
-                const float ua = su / count, va = sv / count;
-                const float4 c = s_coef[ly * R + lx];
-                const float common = (c.x * ua + c.y * va + c.z) / c.w;
-                s_flow[cur ^ 1][ly * R + lx] = make_float2(ua - common * c.x, va - common * c.y);
+                // sum / count with count == 9 (horn_schunck.wgsl:38-41)
+                const float ua = div_by_recip(su, 9.0f, 1.0f / 9.0f), va = div_by_recip(sv, 9.0f, 1.0f / 9.0f);
+                const HsCell &c = cell[a][b];
+                const float num = c.ix * ua + c.iy * va + c.it;
+                const float common = c.plain_div ? num / c.den : div_by_recip(num, c.den, c.zinv);
+                s_flow[cur ^ 1][ly * R + lx] = make_float2(ua - common * c.ix, va - common * c.iy);
             }
-        }
         __syncthreads();
         cur ^= 1;
     }
-}
-
-// T x T output tile, K steps; blockDim = 256 (32 x 8 cells per sweep).
-template <int T, int K>
-__global__ __launch_bounds__(256) void k_hs_tiled(const float4 *__restrict__ coef, const float2 *__restrict__ fin,
-                                                  float2 *__restrict__ fout, int w, int h)
-{
-    constexpr int R = T + 2 * K;
-    __shared__ float4 s_coef[R * R];
-    __shared__ float2 s_flow[2][R * R];
-    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-    const int x0 = blockIdx.x * T - K, y0 = blockIdx.y * T - K; // image coords of LDS cell (0,0)
-    for (int ly = ty; ly < R; ly += 8)
-        for (int lx = tx; lx < R; lx += 32) {
-            const int gx = clampi(x0 + lx, 0, w - 1), gy = clampi(y0 + ly, 0, h - 1);
-            s_coef[ly * R + lx] = coef[(size_t)gy * w + gx];
-            s_flow[0][ly * R + lx] = fin[(size_t)gy * w + gx];
-        }
-    __syncthreads();
-    int cur = 0;
-    // tiles whose loaded region lies strictly inside the image need no clamping at all
-    const bool border = x0 < 0 || y0 < 0 || x0 + R > w || y0 + R > h; // block-uniform
-    if (border)
-        hs_tile_steps<T, K, true>(s_coef, s_flow, x0, y0, w, h, cur);
-    else
-        hs_tile_steps<T, K, false>(s_coef, s_flow, x0, y0, w, h, cur);
     for (int ly = ty + K; ly < T + K; ly += 8)
         for (int lx = tx + K; lx < T + K; lx += 32) {
             const int gx = x0 + lx, gy = y0 + ly;
@@ -1099,12 +1125,14 @@ hipError_t launch_horn_schunck(const float *i1, const float *i2, const float *fl
     return hipGetLastError();
 }
 
+// coef: w*h float4 followed by w*h floats (reciprocals) -> w*h*20 bytes
 hipError_t launch_hs_prepare(const float *i1, const float *i2, float *coef, uint32_t w, uint32_t h, float lambda,
                              hipStream_t stream)
 {
     const dim3 block(kWave, 4), grid(cdiv(w, kWave), cdiv(h, 4));
     hipLaunchKernelGGL(k_hs_prepare, grid, block, 0, stream, reinterpret_cast<const float4 *>(i1),
-                       reinterpret_cast<const float4 *>(i2), reinterpret_cast<float4 *>(coef), (int)w, (int)h, lambda);
+                       reinterpret_cast<const float4 *>(i2), reinterpret_cast<float4 *>(coef),
+                       coef + (size_t)w * h * 4, (int)w, (int)h, lambda);
     return hipGetLastError();
 }
 
@@ -1118,11 +1146,12 @@ hipError_t launch_hs_iterate(const float *coef, float **flow_a, float **flow_b, 
     const uint32_t T = small ? 16 : 32;
     const dim3 block(256), grid(cdiv(w, T), cdiv(h, T));
     auto c4 = reinterpret_cast<const float4 *>(coef);
+    const float *zi = coef + (size_t)w * h * 4;
     while (iterations > 0) {
         auto fi = reinterpret_cast<const float2 *>(*flow_a);
         auto fo = reinterpret_cast<float2 *>(*flow_b);
         uint32_t k;
-#define NUS_HS(TT, KK) hipLaunchKernelGGL((k_hs_tiled<TT, KK>), grid, block, 0, stream, c4, fi, fo, (int)w, (int)h)
+#define NUS_HS(TT, KK) hipLaunchKernelGGL((k_hs_tiled<TT, KK>), grid, block, 0, stream, c4, zi, fi, fo, (int)w, (int)h)
         if (iterations >= 8) {
             k = 8;
             if (small) NUS_HS(16, 8); else NUS_HS(32, 8);
