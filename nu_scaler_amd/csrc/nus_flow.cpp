@@ -243,12 +243,25 @@ int HipFlowEstimator::estimate_device(const void *d_a, const void *d_b, uint32_t
     float *coef = tmp; // the blur temp is free once the pyramids exist
     for (int f = 0; f < 2; ++f) {
         uint8_t *pyr = static_cast<uint8_t *>(slot_[4 + f]);
-        NUS_HIP(launch_rgba8_to_f32(static_cast<const uint8_t *>(f ? d_b : d_a), cur, w, h, stream));
-        for (uint32_t l = 0; l < nl; ++l) {
-            float *level = reinterpret_cast<float *>(pyr + loff[l]);
-            NUS_HIP(launch_blur(cur, tmp, lw[l], lh[l], true, stream));
-            NUS_HIP(launch_blur(tmp, level, lw[l], lh[l], false, stream));
-            if (l + 1 < nl) NUS_HIP(launch_downsample(level, cur, lw[l], lh[l], stream));
+        const void *frame = f ? d_b : d_a;
+        if (tiled_) {
+            // fused level kernel; the downsampled input of level l+1 ping-pongs between cur and tmp
+            float *nxt[2] = {cur, tmp};
+            const void *src = frame;
+            for (uint32_t l = 0; l < nl; ++l) {
+                float *level = reinterpret_cast<float *>(pyr + loff[l]);
+                float *next = l + 1 < nl ? nxt[l & 1] : nullptr;
+                NUS_HIP(launch_pyramid_level(src, l == 0, level, next, lw[l], lh[l], stream));
+                src = next;
+            }
+        } else {
+            NUS_HIP(launch_rgba8_to_f32(static_cast<const uint8_t *>(frame), cur, w, h, stream));
+            for (uint32_t l = 0; l < nl; ++l) {
+                float *level = reinterpret_cast<float *>(pyr + loff[l]);
+                NUS_HIP(launch_blur(cur, tmp, lw[l], lh[l], true, stream));
+                NUS_HIP(launch_blur(tmp, level, lw[l], lh[l], false, stream));
+                if (l + 1 < nl) NUS_HIP(launch_downsample(level, cur, lw[l], lh[l], stream));
+            }
         }
     }
     const uint8_t *pa = static_cast<const uint8_t *>(slot_[4]), *pb = static_cast<const uint8_t *>(slot_[5]);

@@ -708,12 +708,23 @@ __global__ __launch_bounds__(256) void k_warp_blend_flow(
 // Images: f32 RGBA, one float4 (16 B) per pixel per lane; flows: float2 per pixel.
 // Straight per-pixel kernels with the shaders' exact expression order (no contraction).
 
+__device__ __forceinline__ float div_by_recip(float x, float y, float z);
+
+// u8 -> f32 / 255 (the Rgba8Unorm view of a frame); exact IEEE quotient via the reciprocal + 2 FMAs
+// (equal to x / 255.0f for all 256 inputs, checked on the CPU).
+__device__ __forceinline__ float4 unorm8(uint32_t p)
+{
+    const float z = 1.0f / 255.0f;
+    return make_float4(div_by_recip(ch_f32(p, 0), 255.0f, z), div_by_recip(ch_f32(p, 1), 255.0f, z),
+                       div_by_recip(ch_f32(p, 2), 255.0f, z), div_by_recip(ch_f32(p, 3), 255.0f, z));
+}
+
 __global__ __launch_bounds__(256) void k_rgba8_to_f32(const uint32_t *__restrict__ in, float4 *__restrict__ out, size_t npx)
 {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= npx) return;
     const uint32_t p = in[i];
-    out[i] = make_float4(ch_f32(p, 0) / 255.0f, ch_f32(p, 1) / 255.0f, ch_f32(p, 2) / 255.0f, ch_f32(p, 3) / 255.0f);
+    out[i] = unorm8(p);
 }
 
 __device__ __forceinline__ float4 blur5(const float4 m2, const float4 m1, const float4 c0, const float4 p1, const float4 p2)
@@ -789,6 +800,69 @@ __global__ __launch_bounds__(256) void k_horn_schunck(const float4 *__restrict__
     const float ua = su / count, va = sv / count;
     const float common = (ix * ua + iy * va + it) / (lambda + ix * ix + iy * iy);
     fout[(size_t)y * w + x] = make_float2(ua - common * ix, va - common * iy);
+}
+
+// One pyramid level in one launch (build_pyramid's three dispatches, wgpu_interpolator.rs:1068-1085,
+// fused): a 64x16 output tile stages its (64+4)x(16+4) input region in LDS (converted from RGBA8
+// at level 0), runs the horizontal blur into a second LDS tile, the vertical blur from there, writes
+// the blurred level and, from the same tile, the 2x2-averaged input of the next level.  Each value
+// goes through exactly the arithmetic of k_blur<true>, k_blur<false> and k_downsample, so the
+// result is bit-identical to the three separate kernels while HBM sees the input once.
+constexpr int kPyrTW = 64, kPyrTH = 16;
+
+template <bool U8IN>
+__global__ __launch_bounds__(256) void k_pyramid_level(const void *__restrict__ in, float4 *__restrict__ level,
+                                                       float4 *__restrict__ next, int w, int h)
+{
+    __shared__ float4 s_a[(kPyrTH + 4) * (kPyrTW + 4)]; // input region; later the V-blurred tile
+    __shared__ float4 s_h[(kPyrTH + 4) * kPyrTW];        // H-blurred rows
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6; // 64 x 4
+    const int bx = blockIdx.x * kPyrTW, by = blockIdx.y * kPyrTH;
+    // stage input rows by-2 .. by+17, columns bx-2 .. bx+65, coordinates clamped into the image
+    for (int r = ty; r < kPyrTH + 4; r += 4) {
+        const int gy = clampi(by - 2 + r, 0, h - 1);
+        for (int c = tx; c < kPyrTW + 4; c += 64) {
+            const int gx = clampi(bx - 2 + c, 0, w - 1);
+            const size_t g = (size_t)gy * w + gx;
+            s_a[r * (kPyrTW + 4) + c] = U8IN ? unorm8(static_cast<const uint32_t *>(in)[g]) : static_cast<const float4 *>(in)[g];
+        }
+    }
+    __syncthreads();
+    // horizontal pass for the 20 staged rows.  The shader clamps x+-k into the image; the staged
+    // columns already hold clamp(bx-2+c), so column (tx+2)+k is the clamped neighbour as long as
+    // the output column itself is inside the image.
+    for (int r = ty; r < kPyrTH + 4; r += 4) {
+        const float4 *row = s_a + r * (kPyrTW + 4) + tx;
+        s_h[r * kPyrTW + tx] = blur5(row[0], row[1], row[2], row[3], row[4]);
+    }
+    __syncthreads();
+    // vertical pass -> blurred level; keep the tile in LDS (s_a is free now) for the downsample
+    const int gx = bx + tx;
+    for (int r = ty; r < kPyrTH; r += 4) {
+        const float4 v = blur5(s_h[r * kPyrTW + tx], s_h[(r + 1) * kPyrTW + tx], s_h[(r + 2) * kPyrTW + tx],
+                               s_h[(r + 3) * kPyrTW + tx], s_h[(r + 4) * kPyrTW + tx]);
+        s_a[r * kPyrTW + tx] = v;
+        const int gy = by + r;
+        if (gx < w && gy < h) level[(size_t)gy * w + gx] = v;
+    }
+    if (next == nullptr) return; // block-uniform
+    __syncthreads();
+    // 2x2 box average of the blurred tile (tile origin is even, so every 2x2 block is inside it)
+    const int ow = (w + 1) / 2, oh = (h + 1) / 2;
+    const int dxl = threadIdx.x & 31, dyl = threadIdx.x >> 5; // 32 x 8 outputs per tile
+    const int ox = bx / 2 + dxl, oy = by / 2 + dyl;
+    if (ox < ow && oy < oh) {
+        const int x0 = 2 * dxl, y0 = 2 * dyl;
+        const int x1 = min(bx + x0 + 1, w - 1) - bx, y1 = min(by + y0 + 1, h - 1) - by;
+        const float4 c00 = s_a[y0 * kPyrTW + x0], c10 = s_a[y0 * kPyrTW + x1];
+        const float4 c01 = s_a[y1 * kPyrTW + x0], c11 = s_a[y1 * kPyrTW + x1];
+        float4 r;
+        r.x = (c00.x + c10.x + c01.x + c11.x) * 0.25f;
+        r.y = (c00.y + c10.y + c01.y + c11.y) * 0.25f;
+        r.z = (c00.z + c10.z + c01.z + c11.z) * 0.25f;
+        r.w = (c00.w + c10.w + c01.w + c11.w) * 0.25f;
+        next[(size_t)oy * ow + ox] = r;
+    }
 }
 
 // Derivatives of one pyramid level, computed once per level instead of once per Jacobi step:
@@ -1125,6 +1199,20 @@ hipError_t launch_horn_schunck(const float *i1, const float *i2, const float *fl
     return hipGetLastError();
 }
 
+// One fused pyramid level: `in` is RGBA8 (u8_input) or f32 RGBA; `next` may be null (last level).
+hipError_t launch_pyramid_level(const void *in, bool u8_input, float *level, float *next, uint32_t w, uint32_t h,
+                                hipStream_t stream)
+{
+    const dim3 block(256), grid(cdiv(w, kPyrTW), cdiv(h, kPyrTH));
+    if (u8_input)
+        hipLaunchKernelGGL(k_pyramid_level<true>, grid, block, 0, stream, in, reinterpret_cast<float4 *>(level),
+                           reinterpret_cast<float4 *>(next), (int)w, (int)h);
+    else
+        hipLaunchKernelGGL(k_pyramid_level<false>, grid, block, 0, stream, in, reinterpret_cast<float4 *>(level),
+                           reinterpret_cast<float4 *>(next), (int)w, (int)h);
+    return hipGetLastError();
+}
+
 // coef: w*h float4 followed by w*h floats (reciprocals) -> w*h*20 bytes
 hipError_t launch_hs_prepare(const float *i1, const float *i2, float *coef, uint32_t w, uint32_t h, float lambda,
                              hipStream_t stream)
@@ -1147,28 +1235,26 @@ hipError_t launch_hs_iterate(const float *coef, float **flow_a, float **flow_b, 
     const dim3 block(256), grid(cdiv(w, T), cdiv(h, T));
     auto c4 = reinterpret_cast<const float4 *>(coef);
     const float *zi = coef + (size_t)w * h * 4;
+    uint32_t launches = (iterations + 7) / 8;
     while (iterations > 0) {
         auto fi = reinterpret_cast<const float2 *>(*flow_a);
         auto fo = reinterpret_cast<float2 *>(*flow_b);
-        uint32_t k;
-#define NUS_HS(TT, KK) hipLaunchKernelGGL((k_hs_tiled<TT, KK>), grid, block, 0, stream, c4, zi, fi, fo, (int)w, (int)h)
-        if (iterations >= 8) {
-            k = 8;
-            if (small) NUS_HS(16, 8); else NUS_HS(32, 8);
-        } else if (iterations >= 4) {
-            k = 4;
-            if (small) NUS_HS(16, 4); else NUS_HS(32, 4);
-        } else if (iterations >= 2) {
-            k = 2;
-            if (small) NUS_HS(16, 2); else NUS_HS(32, 2);
-        } else {
-            k = 1;
-            if (small) NUS_HS(16, 1); else NUS_HS(32, 1);
+        const uint32_t k = (iterations + launches - 1) / launches; // even split, 1..8 steps per launch
+#define NUS_HS(KK)                                                                                              \
+    case KK:                                                                                                    \
+        if (small)                                                                                              \
+            hipLaunchKernelGGL((k_hs_tiled<16, KK>), grid, block, 0, stream, c4, zi, fi, fo, (int)w, (int)h);   \
+        else                                                                                                    \
+            hipLaunchKernelGGL((k_hs_tiled<32, KK>), grid, block, 0, stream, c4, zi, fi, fo, (int)w, (int)h);   \
+        break;
+        switch (k) {
+            NUS_HS(1) NUS_HS(2) NUS_HS(3) NUS_HS(4) NUS_HS(5) NUS_HS(6) NUS_HS(7) NUS_HS(8)
         }
 #undef NUS_HS
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
         iterations -= k;
+        --launches;
         float *t = *flow_a;
         *flow_a = *flow_b;
         *flow_b = t;

@@ -83,6 +83,9 @@ hipError_t launch_blur(const float *in, float *out, uint32_t w, uint32_t h, bool
 hipError_t launch_downsample(const float *in, float *out, uint32_t w, uint32_t h, hipStream_t stream);
 hipError_t launch_horn_schunck(const float *i1, const float *i2, const float *flow_in, float *flow_out, uint32_t w,
                                uint32_t h, float lambda, hipStream_t stream);
+// blur H + blur V + downsample of one level in one launch (LDS tile with a 2-pixel halo).
+hipError_t launch_pyramid_level(const void *in, bool u8_input, float *level, float *next, uint32_t w, uint32_t h,
+                                hipStream_t stream);
 // Fast path of the same iteration: derivatives once per level, then K steps per launch in LDS.
 hipError_t launch_hs_prepare(const float *i1, const float *i2, float *coef, uint32_t w, uint32_t h, float lambda,
                              hipStream_t stream);

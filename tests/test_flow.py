@@ -87,7 +87,10 @@ def test_flow_estimate_matches_oracle_and_improves_interpolation(nsc, oracle_mod
     fe = nsc.FlowEstimator(levels=3, coarse_iterations=60, refine_iterations=15)
     flow = fe.estimate(a.tobytes(), b.tobytes(), w, h)
     want = oracle_mod.flow_estimate(a, b, 3, 60, 15, fe.lambda_)
-    assert np.array_equal(flow, want)
+    assert np.array_equal(flow, want)  # fused pyramid kernel + LDS-tiled multi-step Horn-Schunck
+    fe.set_tiled(False)               # one plain kernel per shader dispatch
+    assert np.array_equal(fe.estimate(a.tobytes(), b.tobytes(), w, h), want)
+    fe.set_tiled(True)
     # the estimated flow makes the in-between frame closer to the true half-way frame than zero flow does
     truth = _smooth(w, h, 2.0).astype(np.int16)
     it = nsc.WgpuFrameInterpolator()
@@ -97,6 +100,18 @@ def test_flow_estimate_matches_oracle_and_improves_interpolation(nsc, oracle_mod
     err_flow = np.abs(mid_flow.astype(np.int16) - truth)[core].mean()
     err_zero = np.abs(mid_zero.astype(np.int16) - truth)[core].mean()
     assert err_flow < 0.5 * err_zero, (err_flow, err_zero)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("size,levels", [((67, 35), 3), ((130, 17), 4), ((64, 16), 2), ((33, 33), 6), ((5, 3), 3)])
+def test_flow_estimate_ragged_sizes(nsc, oracle_mod, size, levels):
+    w, h = size
+    a, b = oracle_mod.gen_noise(w, h, 41), oracle_mod.gen_noise(w, h, 42)
+    fe = nsc.FlowEstimator(levels=levels, coarse_iterations=11, refine_iterations=3)
+    want = oracle_mod.flow_estimate(a, b, levels, 11, 3, fe.lambda_)
+    for tiled in (True, False):
+        fe.set_tiled(tiled)
+        assert np.array_equal(fe.estimate(a, b, w, h), want), (size, levels, tiled)
 
 
 @pytest.mark.gpu
