@@ -48,7 +48,11 @@ typedef enum nus_status {
 typedef enum nus_algorithm {
     NUS_ALG_NEAREST = 0,
     NUS_ALG_BILINEAR = 1,
-    NUS_ALG_LANCZOS3 = 2
+    NUS_ALG_LANCZOS3 = 2,
+    /* "next" row: the other image-0.24.9 filters the legacy
+     * BasicUpscaler delegates to (Nu_scale/src/upscale/common.rs:233-260) */
+    NUS_ALG_BICUBIC = 3,  /* FilterType::CatmullRom (UpscalingAlgorithm::Bicubic) */
+    NUS_ALG_TRIANGLE = 4  /* FilterType::Triangle (what Lanczos2 / Mitchell map to there) */
 } nus_algorithm;
 
 /* UpscalingQuality (mod.rs:37-46), same order.  Quality never changes the arithmetic
@@ -145,7 +149,7 @@ int nus_upscaler_upscale_batch(nus_upscaler *h, const uint8_t *const *ins,
 int nus_upscaler_upscale_device(nus_upscaler *h, const void *d_in, void *d_out,
                                 uint32_t n_frames, void *stream);
 
-const char *nus_upscaler_name(const nus_upscaler *h); /* "WgpuNearestUpscaler" / "WgpuBilinearUpscaler" (mod.rs:1060-1066) / "HipLanczos3Upscaler" */
+const char *nus_upscaler_name(const nus_upscaler *h); /* "WgpuNearestUpscaler" / "WgpuBilinearUpscaler" (mod.rs:1060-1066) / "Hip{Lanczos3,Bicubic,Triangle}Upscaler" */
 int nus_upscaler_algorithm(const nus_upscaler *h);
 int nus_upscaler_quality(const nus_upscaler *h);
 int nus_upscaler_set_quality(nus_upscaler *h, int quality);
@@ -175,6 +179,8 @@ int nus_upscaler_import_tables(nus_upscaler *h, const void *buf, size_t len);
  * check a received blob against them.  variant: nus_bilinear_variant. */
 int64_t nus_tables_build_blob(uint32_t in_w, uint32_t in_h, uint32_t out_w, uint32_t out_h,
                               int variant, void *buf, size_t cap);
+int64_t nus_tables_build_blob_for(int algorithm, uint32_t in_w, uint32_t in_h, uint32_t out_w,
+                                  uint32_t out_h, int variant, void *buf, size_t cap);
 int nus_tables_validate_blob(const void *buf, size_t len, uint32_t in_w, uint32_t in_h,
                              uint32_t out_w, uint32_t out_h);
 
@@ -188,6 +194,9 @@ int nus_tables_validate_blob(const void *buf, size_t len, uint32_t in_w, uint32_
  * Returns the largest ntaps or a negative status. */
 int nus_lanczos3_build_axis(uint32_t in_n, uint32_t out_n, int32_t *left,
                             uint32_t *ntaps, float *weights);
+/* Same for filter 0 = Lanczos3, 1 = CatmullRom, 2 = Triangle. */
+int nus_resize_build_axis(int filter, uint32_t in_n, uint32_t out_n, int32_t *left,
+                          uint32_t *ntaps, float *weights);
 /* Nearest source index per output index: min(o*in_n/out_n, in_n-1). */
 int nus_nearest_build_axis(uint32_t in_n, uint32_t out_n, uint32_t *src);
 /* Bilinear i0 / frac per output index. variant: nus_bilinear_variant. */

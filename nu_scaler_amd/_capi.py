@@ -21,7 +21,7 @@ ERR_NO_DEVICE = -5
 ERR_UNSUPPORTED = -6
 ERR_OUT_OF_MEMORY = -7
 
-ALG_NEAREST, ALG_BILINEAR, ALG_LANCZOS3 = 0, 1, 2
+ALG_NEAREST, ALG_BILINEAR, ALG_LANCZOS3, ALG_BICUBIC, ALG_TRIANGLE = 0, 1, 2, 3, 4
 QUALITY_ULTRA_PERFORMANCE, QUALITY_ULTRA, QUALITY_QUALITY, QUALITY_BALANCED, QUALITY_PERFORMANCE, QUALITY_NATIVE = range(6)
 TECH_NONE, TECH_FSR, TECH_DLSS, TECH_WGPU, TECH_FALLBACK = range(5)
 WG_SQUARE_8X8, WG_SQUARE_16X16, WG_WIDE_32X8, WG_TALL_8X32 = range(4)
@@ -62,8 +62,10 @@ SIGNATURES = [
     ("nus_upscaler_export_tables", _i64, [_vp, _vp, _sz]),
     ("nus_upscaler_import_tables", _i, [_vp, _vp, _sz]),
     ("nus_tables_build_blob", _i64, [_u32, _u32, _u32, _u32, _i, _vp, _sz]),
+    ("nus_tables_build_blob_for", _i64, [_i, _u32, _u32, _u32, _u32, _i, _vp, _sz]),
     ("nus_tables_validate_blob", _i, [_vp, _sz, _u32, _u32, _u32, _u32]),
     ("nus_lanczos3_build_axis", _i, [_u32, _u32, _vp, _vp, _vp]),
+    ("nus_resize_build_axis", _i, [_i, _u32, _u32, _vp, _vp, _vp]),
     ("nus_nearest_build_axis", _i, [_u32, _u32, _vp]),
     ("nus_bilinear_build_axis", _i, [_u32, _u32, _i, _vp, _vp]),
     ("nus_interp_create", _vp, [_i]),

@@ -64,7 +64,7 @@ const char *nus_status_string(int status)
 
 nus_upscaler *nus_upscaler_create(int algorithm, int quality)
 {
-    if (algorithm < NUS_ALG_NEAREST || algorithm > NUS_ALG_LANCZOS3 || quality < NUS_QUALITY_ULTRA_PERFORMANCE ||
+    if (algorithm < NUS_ALG_NEAREST || algorithm > NUS_ALG_TRIANGLE || quality < NUS_QUALITY_ULTRA_PERFORMANCE ||
         quality > NUS_QUALITY_NATIVE) {
         nus::set_thread_error("nus_upscaler_create: unknown algorithm or quality");
         return nullptr;
@@ -162,13 +162,23 @@ int nus_upscaler_import_tables(nus_upscaler *h, const void *buf, size_t len)
 int64_t nus_tables_build_blob(uint32_t in_w, uint32_t in_h, uint32_t out_w, uint32_t out_h, int variant, void *buf,
                               size_t cap)
 {
-    if (in_w == 0 || in_h == 0 || out_w == 0 || out_h == 0 || (variant != 0 && variant != 1)) {
+    return nus_tables_build_blob_for(NUS_ALG_LANCZOS3, in_w, in_h, out_w, out_h, variant, buf, cap);
+}
+
+int64_t nus_tables_build_blob_for(int algorithm, uint32_t in_w, uint32_t in_h, uint32_t out_w, uint32_t out_h,
+                                  int variant, void *buf, size_t cap)
+{
+    if (in_w == 0 || in_h == 0 || out_w == 0 || out_h == 0 || (variant != 0 && variant != 1) ||
+        algorithm < NUS_ALG_NEAREST || algorithm > NUS_ALG_TRIANGLE) {
         nus::set_thread_error("nus_tables_build_blob: bad argument");
         return NUS_ERR_INVALID_ARGUMENT;
     }
+    const nus::ResizeFilter filter = algorithm == NUS_ALG_BICUBIC    ? nus::ResizeFilter::CatmullRom
+                                     : algorithm == NUS_ALG_TRIANGLE ? nus::ResizeFilter::Triangle
+                                                                     : nus::ResizeFilter::Lanczos3;
     nus::AxisTables x, y;
-    nus::build_axis_tables(in_w, out_w, variant == 1, x);
-    nus::build_axis_tables(in_h, out_h, variant == 1, y);
+    nus::build_axis_tables(in_w, out_w, variant == 1, x, filter);
+    nus::build_axis_tables(in_h, out_h, variant == 1, y, filter);
     const std::vector<uint8_t> blob = nus::serialize_tables(x, y);
     if (buf) {
         if (cap < blob.size()) {
@@ -204,6 +214,20 @@ int nus_lanczos3_build_axis(uint32_t in_n, uint32_t out_n, int32_t *left, uint32
     const int r = nus::build_lanczos3_axis(in_n, out_n, left, ntaps, weights);
     if (r < 0) {
         nus::set_thread_error("nus_lanczos3_build_axis: window exceeds NUS_RESIZE_MAX_TAPS");
+        return NUS_ERR_UNSUPPORTED;
+    }
+    return r;
+}
+
+int nus_resize_build_axis(int filter, uint32_t in_n, uint32_t out_n, int32_t *left, uint32_t *ntaps, float *weights)
+{
+    if (!left || !ntaps || !weights || in_n == 0 || out_n == 0 || filter < 0 || filter > 2) {
+        nus::set_thread_error("nus_resize_build_axis: bad argument");
+        return NUS_ERR_INVALID_ARGUMENT;
+    }
+    const int r = nus::build_resize_axis(static_cast<nus::ResizeFilter>(filter), in_n, out_n, left, ntaps, weights);
+    if (r < 0) {
+        nus::set_thread_error("nus_resize_build_axis: window exceeds NUS_RESIZE_MAX_TAPS");
         return NUS_ERR_UNSUPPORTED;
     }
     return r;

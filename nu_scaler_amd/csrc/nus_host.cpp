@@ -81,7 +81,18 @@ const char *HipUpscaler::name() const
     switch (algorithm_) {
     case Algorithm::Bilinear: return "WgpuBilinearUpscaler";
     case Algorithm::Lanczos3: return "HipLanczos3Upscaler";
+    case Algorithm::Bicubic: return "HipBicubicUpscaler";
+    case Algorithm::Triangle: return "HipTriangleUpscaler";
     default: return "WgpuNearestUpscaler";
+    }
+}
+
+ResizeFilter HipUpscaler::resize_filter() const
+{
+    switch (algorithm_) {
+    case Algorithm::Bicubic: return ResizeFilter::CatmullRom;
+    case Algorithm::Triangle: return ResizeFilter::Triangle;
+    default: return ResizeFilter::Lanczos3;
     }
 }
 
@@ -190,7 +201,9 @@ void HipUpscaler::choose_variant()
         variant_ = ok ? Variant::BilinearX2Int : Variant::BilinearTable;
         break;
     }
-    case Algorithm::Lanczos3: {
+    case Algorithm::Lanczos3:
+    case Algorithm::Bicubic:
+    case Algorithm::Triangle: {
         bool ok = x2 && iw_ >= 16 && (uint64_t)ow_ * oh_ * 4 < (1ull << 31); // buffer-resource addressing
         ok = ok && ih_ >= 16 && lanczos_x2_phase_frame(tx_, wx6_) && lanczos_x2_phase_frame(ty_, wy6_) &&
              lanczos_x2_interior_uniform(tx_, wx6_) && lanczos_x2_interior_uniform(ty_, wy6_) &&
@@ -230,6 +243,8 @@ int HipUpscaler::upload_tables()
         UP(ty_.bl_frac, bl_fy);
         break;
     case Algorithm::Lanczos3:
+    case Algorithm::Bicubic:
+    case Algorithm::Triangle:
         UP(tx_.lz_left, lz_lx);
         UP(tx_.lz_ntaps, lz_nx);
         UP(tx_.lz_w, lz_wx);
@@ -270,9 +285,9 @@ int HipUpscaler::initialize(uint32_t in_w, uint32_t in_h, uint32_t out_w, uint32
     ih_ = in_h;
     ow_ = out_w;
     oh_ = out_h;
-    build_axis_tables(iw_, ow_, wgsl_bilinear_, tx_);
-    build_axis_tables(ih_, oh_, wgsl_bilinear_, ty_);
-    if (algorithm_ == Algorithm::Lanczos3 && (tx_.lz_max_taps < 0 || ty_.lz_max_taps < 0))
+    build_axis_tables(iw_, ow_, wgsl_bilinear_, tx_, resize_filter());
+    build_axis_tables(ih_, oh_, wgsl_bilinear_, ty_, resize_filter());
+    if (is_resize() && (tx_.lz_max_taps < 0 || ty_.lz_max_taps < 0))
         return fail(kUnsupported, fmt("Lanczos-3 window exceeds %u taps for %ux%u -> %ux%u", kResizeMaxTaps, iw_, ih_, ow_, oh_));
     choose_variant();
     rc = upload_tables();
@@ -497,9 +512,11 @@ int HipUpscaler::import_tables(const void *buf, size_t len)
         return fail(kInvalidArgument, "import_tables: tables were built for different dimensions");
     NUS_HIP(hipSetDevice(device_));
     NUS_HIP(hipDeviceSynchronize());
+    if (is_resize() && (x.filter != resize_filter() || y.filter != resize_filter()))
+        return fail(kInvalidArgument, "import_tables: tables were built for a different resize filter");
     tx_ = std::move(x);
     ty_ = std::move(y);
-    if (algorithm_ == Algorithm::Lanczos3 && (tx_.lz_max_taps < 0 || ty_.lz_max_taps < 0))
+    if (is_resize() && (tx_.lz_max_taps < 0 || ty_.lz_max_taps < 0))
         return fail(kUnsupported, "import_tables: Lanczos window too wide");
     choose_variant();
     return upload_tables();

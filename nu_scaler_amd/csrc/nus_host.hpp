@@ -35,7 +35,7 @@ enum Status : int {
     kOutOfMemory = -7,
 };
 
-enum class Algorithm : int { Nearest = 0, Bilinear = 1, Lanczos3 = 2 };
+enum class Algorithm : int { Nearest = 0, Bilinear = 1, Lanczos3 = 2, Bicubic = 3, Triangle = 4 };
 enum class Quality : int { UltraPerformance = 0, Ultra, Quality, Balanced, Performance, Native };
 enum class Technology : int { None = 0, FSR, DLSS, Wgpu, Fallback };
 
@@ -109,6 +109,8 @@ private:
     int ensure_device();
     void release();
     int upload_tables();
+    bool is_resize() const { return algorithm_ == Algorithm::Lanczos3 || algorithm_ == Algorithm::Bicubic || algorithm_ == Algorithm::Triangle; }
+    ResizeFilter resize_filter() const;
     void choose_variant();
     int enqueue(const uint8_t *d_in, uint8_t *d_out, uint32_t n_frames, hipStream_t stream);
 

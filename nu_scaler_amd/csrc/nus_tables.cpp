@@ -46,14 +46,44 @@ float lanczos3(float x)
     return 0.0f;
 }
 
+// Catmull-Rom: the crate's bicubic_kernel(x, b = 0, c = 0.5)
+float catmull_rom(float x)
+{
+    const float b = 0.0f, c = 0.5f;
+    const float a = std::fabs(x);
+    float k;
+    if (a < 1.0f)
+        k = (12.0f - 9.0f * b - 6.0f * c) * (a * a * a) + (-18.0f + 12.0f * b + 6.0f * c) * (a * a) + (6.0f - 2.0f * b);
+    else if (a < 2.0f)
+        k = (-b - 6.0f * c) * (a * a * a) + (6.0f * b + 30.0f * c) * (a * a) + (-12.0f * b - 48.0f * c) * a + (8.0f * b + 24.0f * c);
+    else
+        k = 0.0f;
+    return k / 6.0f;
+}
+
+float triangle(float x)
+{
+    const float a = std::fabs(x);
+    return a < 1.0f ? 1.0f - a : 0.0f;
+}
+
 } // namespace
 
-int build_lanczos3_axis(uint32_t in_n, uint32_t out_n, int32_t *left, uint32_t *ntaps, float *weights)
+int build_resize_axis(ResizeFilter filter, uint32_t in_n, uint32_t out_n, int32_t *left, uint32_t *ntaps, float *weights)
 {
     if (in_n == 0 || out_n == 0) return -1;
+    float (*kernel)(float) = lanczos3;
+    float support = 3.0f;
+    if (filter == ResizeFilter::CatmullRom) {
+        kernel = catmull_rom;
+        support = 2.0f;
+    } else if (filter == ResizeFilter::Triangle) {
+        kernel = triangle;
+        support = 1.0f;
+    }
     const float ratio = (float)in_n / (float)out_n;
     const float sratio = ratio < 1.0f ? 1.0f : ratio;
-    const float src_support = 3.0f * sratio;
+    const float src_support = support * sratio;
     int worst = 0;
     for (uint32_t o = 0; o < out_n; ++o) {
         float *ws = weights + (size_t)o * kResizeMaxTaps;
@@ -73,7 +103,7 @@ int build_lanczos3_axis(uint32_t in_n, uint32_t out_n, int32_t *left, uint32_t *
         if (n > kResizeMaxTaps) return -1;
         float sum = 0.0f;
         for (uint32_t i = 0; i < n; ++i) {
-            const float w = lanczos3(((float)(lo + (int64_t)i) - centre) / sratio);
+            const float w = kernel(((float)(lo + (int64_t)i) - centre) / sratio);
             ws[i] = w;
             sum += w;
         }
@@ -83,8 +113,9 @@ int build_lanczos3_axis(uint32_t in_n, uint32_t out_n, int32_t *left, uint32_t *
     return worst;
 }
 
-void build_axis_tables(uint32_t in_n, uint32_t out_n, bool wgsl_form, AxisTables &t)
+void build_axis_tables(uint32_t in_n, uint32_t out_n, bool wgsl_form, AxisTables &t, ResizeFilter filter)
 {
+    t.filter = filter;
     t.in_n = in_n;
     t.out_n = out_n;
     t.nn_src.resize(out_n);
@@ -95,7 +126,7 @@ void build_axis_tables(uint32_t in_n, uint32_t out_n, bool wgsl_form, AxisTables
     t.lz_w.assign((size_t)out_n * kResizeMaxTaps, 0.0f);
     build_nearest_axis(in_n, out_n, t.nn_src.data());
     build_bilinear_axis(in_n, out_n, wgsl_form, t.bl_i0.data(), t.bl_frac.data());
-    t.lz_max_taps = build_lanczos3_axis(in_n, out_n, t.lz_left.data(), t.lz_ntaps.data(), t.lz_w.data());
+    t.lz_max_taps = build_resize_axis(filter, in_n, out_n, t.lz_left.data(), t.lz_ntaps.data(), t.lz_w.data());
 }
 
 bool lanczos_x2_phase_frame(const AxisTables &t, std::vector<float> &w6)
@@ -141,8 +172,8 @@ void put(std::vector<uint8_t> &b, const T *p, size_t n)
 
 void put_axis(std::vector<uint8_t> &b, const AxisTables &t)
 {
-    const uint32_t hdr[3] = {t.in_n, t.out_n, (uint32_t)t.lz_max_taps};
-    put(b, hdr, 3);
+    const uint32_t hdr[4] = {t.in_n, t.out_n, (uint32_t)t.lz_max_taps, (uint32_t)t.filter};
+    put(b, hdr, 4);
     put(b, t.nn_src.data(), t.out_n);
     put(b, t.bl_i0.data(), t.out_n);
     put(b, t.bl_frac.data(), t.out_n);
@@ -162,12 +193,13 @@ bool get(const uint8_t *&p, const uint8_t *end, T *dst, size_t n)
 
 bool get_axis(const uint8_t *&p, const uint8_t *end, AxisTables &t)
 {
-    uint32_t hdr[3];
-    if (!get(p, end, hdr, 3)) return false;
-    if (hdr[1] == 0 || hdr[1] > (1u << 24)) return false;
+    uint32_t hdr[4];
+    if (!get(p, end, hdr, 4)) return false;
+    if (hdr[1] == 0 || hdr[1] > (1u << 24) || hdr[3] > 2u) return false;
     t.in_n = hdr[0];
     t.out_n = hdr[1];
     t.lz_max_taps = (int)hdr[2];
+    t.filter = static_cast<ResizeFilter>(hdr[3]);
     t.nn_src.resize(t.out_n);
     t.bl_i0.resize(t.out_n);
     t.bl_frac.resize(t.out_n);
@@ -184,7 +216,7 @@ bool get_axis(const uint8_t *&p, const uint8_t *end, AxisTables &t)
 std::vector<uint8_t> serialize_tables(const AxisTables &x, const AxisTables &y)
 {
     std::vector<uint8_t> b;
-    const uint32_t hdr[2] = {kMagic, 1u};
+    const uint32_t hdr[2] = {kMagic, 2u};
     put(b, hdr, 2);
     put_axis(b, x);
     put_axis(b, y);
@@ -195,7 +227,7 @@ bool deserialize_tables(const uint8_t *buf, size_t len, AxisTables &x, AxisTable
 {
     const uint8_t *p = buf, *end = buf + len;
     uint32_t hdr[2];
-    if (!get(p, end, hdr, 2) || hdr[0] != kMagic || hdr[1] != 1u) {
+    if (!get(p, end, hdr, 2) || hdr[0] != kMagic || hdr[1] != 2u) {
         err = "table blob: bad magic or version";
         return false;
     }

@@ -20,23 +20,32 @@ void build_nearest_axis(uint32_t in_n, uint32_t out_n, uint32_t *src);
 // (Nu_scale/src/upscale/common.rs:204-215); wgsl form does not (upscale/mod.rs:241-248).
 void build_bilinear_axis(uint32_t in_n, uint32_t out_n, bool wgsl_form, uint32_t *i0, float *frac);
 
-// Lanczos-3 windows, image-0.24.9 vertical_sample / horizontal_sample convention.
+// Separable resampling filters of image-0.24.9 `imageops::resize` (FilterType::*).
+enum class ResizeFilter : int { Lanczos3 = 0, CatmullRom = 1, Triangle = 2 };
+
+// Tap windows, image-0.24.9 vertical_sample / horizontal_sample convention.
 // weights is out_n * kResizeMaxTaps, zero padded.  Returns max ntaps, or -1 when a
-// window needs more than kResizeMaxTaps taps (down-scaling by more than ~4.8x).
-int build_lanczos3_axis(uint32_t in_n, uint32_t out_n, int32_t *left, uint32_t *ntaps, float *weights);
+// window needs more than kResizeMaxTaps taps (Lanczos-3: down-scaling by more than ~4.8x).
+int build_resize_axis(ResizeFilter filter, uint32_t in_n, uint32_t out_n, int32_t *left, uint32_t *ntaps, float *weights);
+inline int build_lanczos3_axis(uint32_t in_n, uint32_t out_n, int32_t *left, uint32_t *ntaps, float *weights)
+{
+    return build_resize_axis(ResizeFilter::Lanczos3, in_n, out_n, left, ntaps, weights);
+}
 
 struct AxisTables {
     uint32_t in_n = 0, out_n = 0;
     std::vector<uint32_t> nn_src;
     std::vector<uint32_t> bl_i0;
     std::vector<float> bl_frac;
+    ResizeFilter filter = ResizeFilter::Lanczos3; // which filter the lz_* tables were built for
     std::vector<int32_t> lz_left;
     std::vector<uint32_t> lz_ntaps;
     std::vector<float> lz_w; // out_n * kResizeMaxTaps
     int lz_max_taps = 0;     // -1: unsupported ratio
 };
 
-void build_axis_tables(uint32_t in_n, uint32_t out_n, bool wgsl_form, AxisTables &t);
+void build_axis_tables(uint32_t in_n, uint32_t out_n, bool wgsl_form, AxisTables &t,
+                       ResizeFilter filter = ResizeFilter::Lanczos3);
 
 // Exact-x2 view of a Lanczos axis: weights of output o in its 6-tap phase frame
 // (base = (o>>1) - 3 + (o&1)).  Returns false if any non-zero tap falls outside

@@ -30,18 +30,21 @@ def shard_frames(n_units: int, world_size: int, rank: int) -> Tuple[int, int]:
     return start, count
 
 
-def build_tables_blob(in_w: int, in_h: int, out_w: int, out_h: int, wgsl_bilinear: bool = False) -> bytes:
-    """Host-only: the table blob an upscaler of these dimensions exports (no GPU needed)."""
+def build_tables_blob(in_w: int, in_h: int, out_w: int, out_h: int, wgsl_bilinear: bool = False,
+                      algorithm: str = "lanczos3") -> bytes:
+    """Host-only: the table blob an upscaler of these dimensions and algorithm exports (no GPU needed)."""
     import ctypes
 
     from . import _capi as C
+    from .upscaler import _ALGORITHM
 
     L = C.lib()
-    n = L.nus_tables_build_blob(in_w, in_h, out_w, out_h, int(wgsl_bilinear), None, 0)
+    alg = _ALGORITHM[algorithm]
+    n = L.nus_tables_build_blob_for(alg, in_w, in_h, out_w, out_h, int(wgsl_bilinear), None, 0)
     if n < 0:
         raise RuntimeError(C.last_error())
     buf = ctypes.create_string_buffer(n)
-    if L.nus_tables_build_blob(in_w, in_h, out_w, out_h, int(wgsl_bilinear), buf, n) != n:
+    if L.nus_tables_build_blob_for(alg, in_w, in_h, out_w, out_h, int(wgsl_bilinear), buf, n) != n:
         raise RuntimeError(C.last_error())
     return buf.raw
 

@@ -25,6 +25,10 @@ _ALGORITHM = {  # lib.rs:58-62; unknown strings silently become "nearest"
     # new value of this build (`"lanczos3"` added)
     "lanczos3": C.ALG_LANCZOS3,
     "lanczos": C.ALG_LANCZOS3,
+    # image-0.24.9 filters of the legacy BasicUpscaler (Nu_scale/src/upscale/common.rs:233-260)
+    "bicubic": C.ALG_BICUBIC,
+    "catmullrom": C.ALG_BICUBIC,
+    "triangle": C.ALG_TRIANGLE,
 }
 
 

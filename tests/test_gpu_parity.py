@@ -116,6 +116,32 @@ def test_lanczos_general(nsc, oracle_mod, dims):
     assert np.array_equal(out_e, want)
 
 
+@pytest.mark.parametrize("alg,filt", [("bicubic", 1), ("triangle", 2)])
+@pytest.mark.parametrize("dims", [((64, 36), (128, 72)), ((320, 240), (640, 480)), ((252, 20), (504, 40)), ((48, 27), (72, 41)),
+                                  ((50, 31), (127, 64)), ((48, 27), (20, 11)), ((7, 5), (7, 5)), ((12, 9), (24, 18))])
+def test_bicubic_and_triangle_resize(nsc, oracle_mod, alg, filt, dims):
+    """Next row 8f-4: the other image-0.24.9 filters of the legacy BasicUpscaler (CatmullRom, Triangle),
+    through the same table-driven kernels (x2 register-window kernel where it applies)."""
+    (w, h), (ow, oh) = dims
+    img = oracle_mod.gen_noise(w, h, 17)
+    want = oracle_mod.resize(img, ow, oh, filt)
+    out, u = _up(nsc, alg, img, ow, oh)
+    x2 = (ow, oh) == (2 * w, 2 * h) and w % 4 == 0 and w >= 16 and h >= 16
+    assert u.kernel_variant == ("lanczos3_x2_regwin" if x2 else "lanczos3_general")
+    assert _maxdiff(out, want) <= 1
+    out_e, _ = _up(nsc, alg, img, ow, oh, lanczos_mode="exact")
+    assert np.array_equal(out_e, want)
+    assert u.name == {"bicubic": "HipBicubicUpscaler", "triangle": "HipTriangleUpscaler"}[alg]
+
+
+def test_table_blob_filter_mismatch_rejected(nsc):
+    u = nsc.PyWgpuUpscaler("quality", "bicubic")
+    u.initialize(64, 36, 128, 72)
+    assert u.export_tables() == nsc.build_tables_blob(64, 36, 128, 72, algorithm="bicubic")
+    with pytest.raises(RuntimeError, match="different resize filter"):
+        u.import_tables(nsc.build_tables_blob(64, 36, 128, 72, algorithm="lanczos3"))
+
+
 def test_lanczos_unsupported_ratio_errors(nsc, oracle_mod):
     u = nsc.PyWgpuUpscaler("quality", "lanczos3")
     with pytest.raises(RuntimeError, match="exceeds 32 taps"):

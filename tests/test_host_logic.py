@@ -131,6 +131,18 @@ def test_axis_tables_match_oracle(nsc, oracle_mod, n_in, n_out):
         assert np.array_equal(i0, np.minimum(e0, n_in - 1)) and np.array_equal(fr, ef)
 
 
+@pytest.mark.parametrize("filt", [0, 1, 2])
+@pytest.mark.parametrize("n_in,n_out", [(1920, 3840), (100, 237), (500, 200), (16, 32), (9, 9)])
+def test_resize_filter_tables_match_oracle(nsc, oracle_mod, filt, n_in, n_out):
+    L = nsc._capi.lib()
+    left = np.zeros(n_out, np.int32)
+    nt = np.zeros(n_out, np.uint32)
+    w = np.zeros((n_out, 32), np.float32)
+    r = L.nus_resize_build_axis(filt, n_in, n_out, left.ctypes.data, nt.ctypes.data, w.ctypes.data)
+    ol, on, ow = oracle_mod.resize_axis(n_in, n_out, filt)
+    assert r == on.max() and np.array_equal(left, ol) and np.array_equal(nt, on) and np.array_equal(w, ow)
+
+
 def test_lanczos_axis_unsupported_ratio(nsc):
     L = nsc._capi.lib()
     n_out = 10
@@ -154,7 +166,7 @@ def test_table_blob_roundtrip_and_validation(nsc):
         nsc.validate_tables_blob(bytes(bad), 320, 240, 640, 480)
     # corrupt an index so it points outside the source axis
     bad = bytearray(blob)
-    off = 8 + 12  # blob header + x-axis header -> first nn_src entry
+    off = 8 + 16  # blob header + x-axis header -> first nn_src entry
     bad[off:off + 4] = (10 ** 6).to_bytes(4, "little")
     with pytest.raises(ValueError, match="out of range"):
         nsc.validate_tables_blob(bytes(bad), 320, 240, 640, 480)
