@@ -234,6 +234,29 @@ int nus_interp_interpolate_device(nus_interp *h, const void *d_a, size_t a_strid
 int nus_interp_last_gpu_ms(const nus_interp *h, double *ms_out);
 const char *nus_interp_last_error(const nus_interp *h);
 
+/* ---- Frame queue + capture swizzle ("next" row: SURVEY.md section 8f rank 3) -----------
+ * nus_frame_queue mirrors the legacy FrameBuffer (Nu_scale/src/capture/frame_buffer.rs:11-100):
+ * bounded, drop-oldest on overflow, consumers read the latest frame.  Host memory only. */
+typedef struct nus_frame_queue nus_frame_queue;
+
+nus_frame_queue *nus_frame_queue_create(size_t capacity); /* reference default: 5 */
+void nus_frame_queue_destroy(nus_frame_queue *q);
+/* Copies the frame in; returns the total number of frames dropped so far (>= 0) or a status. */
+int64_t nus_frame_queue_add(nus_frame_queue *q, const uint8_t *rgba, uint32_t w, uint32_t hgt);
+/* Latest frame (stays queued) / oldest frame (removed).  Waits up to timeout_ms when empty.
+ * Returns 1 and fills out (cap >= w*h*4), 0 when no frame arrived, negative status on error. */
+int nus_frame_queue_latest(nus_frame_queue *q, int64_t timeout_ms, uint8_t *out, size_t out_cap,
+                           uint32_t *w, uint32_t *hgt, uint64_t *sequence);
+int nus_frame_queue_pop(nus_frame_queue *q, int64_t timeout_ms, uint8_t *out, size_t out_cap,
+                        uint32_t *w, uint32_t *hgt, uint64_t *sequence);
+size_t nus_frame_queue_size(const nus_frame_queue *q);
+size_t nus_frame_queue_capacity(const nus_frame_queue *q);
+uint64_t nus_frame_queue_dropped(const nus_frame_queue *q);
+
+/* BGRA -> RGBA of a captured frame on the GPU (the CPU loop of nu_scaler_core/src/lib.rs:251-270).
+ * Device pointers, n_pixels pixels, in place allowed; enqueues on `stream`. */
+int nus_swizzle_bgra_to_rgba_device(const void *d_in, void *d_out, size_t n_pixels, void *stream);
+
 /* ---- Optical-flow front end ("next" row: SURVEY.md section 8f rank 1) --------------
  * Mirrors WgpuFrameInterpolator::build_pyramid / compute_coarse_flow
  * (nu_scaler_core/src/wgpu_interpolator.rs:969-1203) and the shaders

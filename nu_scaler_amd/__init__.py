@@ -14,6 +14,7 @@ from . import _capi
 from ._capi import NuScalerLibraryError, build, device_count
 from .flow import FlowEstimator
 from .interpolator import WgpuFrameInterpolator
+from .queue import FrameBuffer, swizzle_bgra_to_rgba_device
 from .stream import (FramePipeline, broadcast_blob, broadcast_tables, build_tables_blob, shard_frames,
                      validate_tables_blob)
 from .upscaler import PyAdvancedWgpuUpscaler, PyWgpuUpscaler, create_advanced_upscaler
@@ -37,7 +38,7 @@ def create_fsr_upscaler(_quality: str):
 
 __all__ = [
     "PyWgpuUpscaler", "PyAdvancedWgpuUpscaler", "create_advanced_upscaler", "create_fsr_upscaler",
-    "WgpuFrameInterpolator", "FlowEstimator", "FramePipeline", "shard_frames", "broadcast_tables",
+    "WgpuFrameInterpolator", "FlowEstimator", "FrameBuffer", "swizzle_bgra_to_rgba_device", "FramePipeline", "shard_frames", "broadcast_tables",
     "broadcast_blob", "build_tables_blob", "validate_tables_blob",
     "NuScalerLibraryError", "build", "device_count",
     "QUALITY_ULTRA", "QUALITY_QUALITY", "QUALITY_BALANCED", "QUALITY_PERFORMANCE",

@@ -75,6 +75,15 @@ SIGNATURES = [
     ("nus_interp_interpolate_device", _i, [_vp, _vp, _sz, _vp, _sz, _vp, _u32, _u32, _f, _vp, _u32, _vp]),
     ("nus_interp_last_gpu_ms", _i, [_vp, _dp]),
     ("nus_interp_last_error", _cp, [_vp]),
+    ("nus_frame_queue_create", _vp, [_sz]),
+    ("nus_frame_queue_destroy", None, [_vp]),
+    ("nus_frame_queue_add", _i64, [_vp, _vp, _u32, _u32]),
+    ("nus_frame_queue_latest", _i, [_vp, _i64, _vp, _sz, ctypes.POINTER(_u32), ctypes.POINTER(_u32), ctypes.POINTER(ctypes.c_uint64)]),
+    ("nus_frame_queue_pop", _i, [_vp, _i64, _vp, _sz, ctypes.POINTER(_u32), ctypes.POINTER(_u32), ctypes.POINTER(ctypes.c_uint64)]),
+    ("nus_frame_queue_size", _sz, [_vp]),
+    ("nus_frame_queue_capacity", _sz, [_vp]),
+    ("nus_frame_queue_dropped", ctypes.c_uint64, [_vp]),
+    ("nus_swizzle_bgra_to_rgba_device", _i, [_vp, _vp, _sz, _vp]),
     ("nus_flow_create", _vp, []),
     ("nus_flow_destroy", None, [_vp]),
     ("nus_flow_set_device", _i, [_vp, _i]),

@@ -8,10 +8,16 @@
 
 #include "nus_flow.hpp"
 #include "nus_host.hpp"
+#include "nus_queue.hpp"
 
 struct nus_upscaler {
     nus::HipUpscaler impl;
     nus_upscaler(nus::Quality q, nus::Algorithm a) : impl(q, a) {}
+};
+
+struct nus_frame_queue {
+    nus::FrameQueue impl;
+    explicit nus_frame_queue(size_t cap) : impl(cap) {}
 };
 
 struct nus_flow {
@@ -287,6 +293,74 @@ int nus_interp_last_gpu_ms(const nus_interp *h, double *ms_out)
 }
 
 const char *nus_interp_last_error(const nus_interp *h) { return h ? h->impl.last_error() : "null handle"; }
+
+nus_frame_queue *nus_frame_queue_create(size_t capacity) { return new (std::nothrow) nus_frame_queue(capacity); }
+void nus_frame_queue_destroy(nus_frame_queue *q) { delete q; }
+
+int64_t nus_frame_queue_add(nus_frame_queue *q, const uint8_t *rgba, uint32_t w, uint32_t hgt)
+{
+    if (!q) return null_handle();
+    if (!rgba || w == 0 || hgt == 0) {
+        nus::set_thread_error("nus_frame_queue_add: bad frame");
+        return NUS_ERR_INVALID_ARGUMENT;
+    }
+    return (int64_t)q->impl.add(rgba, w, hgt);
+}
+
+static int frame_out(const std::shared_ptr<nus::QueuedFrame> &f, uint8_t *out, size_t out_cap, uint32_t *w,
+                     uint32_t *hgt, uint64_t *sequence)
+{
+    if (!f) return 0;
+    if (!out || out_cap < f->data.size()) {
+        nus::set_thread_error("frame queue: output buffer too small");
+        return NUS_ERR_INVALID_ARGUMENT;
+    }
+    memcpy(out, f->data.data(), f->data.size());
+    if (w) *w = f->width;
+    if (hgt) *hgt = f->height;
+    if (sequence) *sequence = f->sequence;
+    return 1;
+}
+
+int nus_frame_queue_latest(nus_frame_queue *q, int64_t timeout_ms, uint8_t *out, size_t out_cap, uint32_t *w,
+                           uint32_t *hgt, uint64_t *sequence)
+{
+    return q ? frame_out(q->impl.latest(timeout_ms), out, out_cap, w, hgt, sequence) : null_handle();
+}
+
+int nus_frame_queue_pop(nus_frame_queue *q, int64_t timeout_ms, uint8_t *out, size_t out_cap, uint32_t *w,
+                        uint32_t *hgt, uint64_t *sequence)
+{
+    if (!q) return null_handle();
+    // peek first so that a too-small buffer does not lose the frame
+    auto f = q->impl.latest(0);
+    if (f && (!out || out_cap < f->data.size())) {
+        nus::set_thread_error("frame queue: output buffer too small");
+        return NUS_ERR_INVALID_ARGUMENT;
+    }
+    return frame_out(q->impl.pop(timeout_ms), out, out_cap, w, hgt, sequence);
+}
+
+size_t nus_frame_queue_size(const nus_frame_queue *q) { return q ? q->impl.size() : 0; }
+size_t nus_frame_queue_capacity(const nus_frame_queue *q) { return q ? q->impl.capacity() : 0; }
+uint64_t nus_frame_queue_dropped(const nus_frame_queue *q) { return q ? q->impl.dropped() : 0; }
+
+int nus_swizzle_bgra_to_rgba_device(const void *d_in, void *d_out, size_t n_pixels, void *stream)
+{
+    if (!d_in || !d_out || (reinterpret_cast<uintptr_t>(d_in) % 4) || (reinterpret_cast<uintptr_t>(d_out) % 4)) {
+        nus::set_thread_error("nus_swizzle_bgra_to_rgba_device: bad pointer");
+        return NUS_ERR_INVALID_ARGUMENT;
+    }
+    if (n_pixels == 0) return NUS_OK;
+    const hipError_t e = nus::launch_swizzle_bgra(static_cast<const uint8_t *>(d_in), static_cast<uint8_t *>(d_out),
+                                                  n_pixels, static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        nus::set_thread_error(std::string("HIP error in swizzle launch: ") + hipGetErrorString(e));
+        return NUS_ERR_HIP;
+    }
+    return NUS_OK;
+}
 
 nus_flow *nus_flow_create(void) { return new (std::nothrow) nus_flow(); }
 void nus_flow_destroy(nus_flow *h) { delete h; }

@@ -703,6 +703,27 @@ __global__ __launch_bounds__(256) void k_warp_blend_flow(
 }
 
 // ---------------------------------------------------------------------------------
+// BGRA -> RGBA swizzle of captured frames (nu_scaler_core/src/lib.rs:251-270), 4 px per lane
+// ---------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t swap_rb(uint32_t p)
+{
+    return __builtin_amdgcn_perm(p, p, 0x03000102u); // bytes (2, 1, 0, 3): one v_perm_b32
+}
+
+template <bool VEC>
+__global__ __launch_bounds__(256) void k_swizzle_bgra(const uint32_t *__restrict__ in, uint32_t *__restrict__ out, size_t npx)
+{
+    const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * (VEC ? 4 : 1);
+    if (i >= npx) return;
+    if (VEC) {
+        const uint4 v = *reinterpret_cast<const uint4 *>(in + i);
+        *reinterpret_cast<uint4 *>(out + i) = make_uint4(swap_rb(v.x), swap_rb(v.y), swap_rb(v.z), swap_rb(v.w));
+    } else {
+        out[i] = swap_rb(in[i]);
+    }
+}
+
+// ---------------------------------------------------------------------------------
 // Optical-flow front end: Gaussian pyramid + Horn-Schunck
 // ---------------------------------------------------------------------------------
 // Images: f32 RGBA, one float4 (16 B) per pixel per lane; flows: float2 per pixel.
@@ -1162,6 +1183,18 @@ hipError_t launch_lanczos_x2_edges(const UpscaleLaunch &L, const DeviceTables &T
         else
             hipLaunchKernelGGL(k_lanczos3_x2_edges<false>, grid, block, 0, L.stream, A);
     });
+}
+
+hipError_t launch_swizzle_bgra(const uint8_t *in, uint8_t *out, size_t npx, hipStream_t stream)
+{
+    const bool vec = (npx % 4) == 0 && (reinterpret_cast<uintptr_t>(in) % 16) == 0 && (reinterpret_cast<uintptr_t>(out) % 16) == 0;
+    const size_t items = vec ? npx / 4 : npx;
+    const dim3 block(256), grid((uint32_t)((items + 255) / 256));
+    if (vec)
+        hipLaunchKernelGGL(k_swizzle_bgra<true>, grid, block, 0, stream, reinterpret_cast<const uint32_t *>(in), reinterpret_cast<uint32_t *>(out), npx);
+    else
+        hipLaunchKernelGGL(k_swizzle_bgra<false>, grid, block, 0, stream, reinterpret_cast<const uint32_t *>(in), reinterpret_cast<uint32_t *>(out), npx);
+    return hipGetLastError();
 }
 
 hipError_t launch_rgba8_to_f32(const uint8_t *in, float *out, uint32_t w, uint32_t h, hipStream_t stream)

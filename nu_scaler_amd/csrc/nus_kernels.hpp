@@ -77,6 +77,9 @@ struct WarpLaunch {
 
 hipError_t launch_warp_blend(const WarpLaunch &L);
 
+// BGRA -> RGBA (in place allowed: in == out).
+hipError_t launch_swizzle_bgra(const uint8_t *in, uint8_t *out, size_t npx, hipStream_t stream);
+
 // Optical-flow front end (f32 RGBA images, float2 flows; device pointers).
 hipError_t launch_rgba8_to_f32(const uint8_t *in, float *out, uint32_t w, uint32_t h, hipStream_t stream);
 hipError_t launch_blur(const float *in, float *out, uint32_t w, uint32_t h, bool horizontal, hipStream_t stream);

@@ -348,3 +348,17 @@ def test_config3_1080p_interpolation(nsc, oracle_mod):
     # idempotence at the end points
     assert it.interpolate_py(a.tobytes(), b.tobytes(), 1920, 1080, time_t=0.0) == a.tobytes()
     assert it.interpolate_py(a.tobytes(), b.tobytes(), 1920, 1080, time_t=1.0) == b.tobytes()
+
+
+def test_swizzle_bgra_to_rgba_device(nsc, oracle_mod):
+    import torch
+
+    for n in (64 * 36, 61 * 7):  # vector and scalar paths
+        bgra = torch.from_numpy(oracle_mod.gen_noise(n, 1, 77).reshape(n, 4).copy()).to("cuda:0")
+        out = torch.empty_like(bgra)
+        nsc.swizzle_bgra_to_rgba_device(bgra.data_ptr(), out.data_ptr(), n, torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        assert torch.equal(out.cpu(), bgra.cpu()[:, [2, 1, 0, 3]])
+        nsc.swizzle_bgra_to_rgba_device(out.data_ptr(), out.data_ptr(), n, torch.cuda.current_stream().cuda_stream)  # in place
+        torch.cuda.synchronize()
+        assert torch.equal(out.cpu(), bgra.cpu())

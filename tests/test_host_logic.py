@@ -205,3 +205,30 @@ def test_pipeline_unit_accounting(nsc):
     fb, ob = 1920 * 1080 * 4, 3840 * 2160 * 4
     assert 3 * fb + 2 * (fb + ob) == 107_827_200
     assert 3 * 1920 * 1080 + 2 * (1920 * 1080 + 3840 * 2160) == 26_956_800
+
+
+def test_frame_buffer_drop_oldest_and_latest(nsc):
+    """Legacy FrameBuffer semantics (Nu_scale/src/capture/frame_buffer.rs:37-55)."""
+    fb = nsc.FrameBuffer(capacity=3, max_frame_bytes=4 * 2 * 4)
+    assert len(fb) == 0 and fb.capacity == 3 and fb.get_latest_frame() is None and fb.pop_frame() is None
+    frames = [bytes([k] * 32) for k in range(5)]
+    drops = [fb.add_frame(f, 4, 2) for f in frames]
+    assert drops == [0, 0, 0, 1, 2] and len(fb) == 3 and fb.dropped == 2
+    data, w, h, seq = fb.get_latest_frame()
+    assert (data, w, h, seq) == (frames[4], 4, 2, 4) and len(fb) == 3  # latest stays queued
+    assert [fb.pop_frame()[3] for _ in range(3)] == [2, 3, 4] and fb.pop_frame() is None
+    with pytest.raises(ValueError):
+        fb.add_frame(b"123", 4, 2)
+
+
+def test_frame_buffer_timeout_and_threads(nsc):
+    import threading
+    import time
+
+    fb = nsc.FrameBuffer(capacity=5, max_frame_bytes=64)
+    t0 = time.perf_counter()
+    assert fb.get_latest_frame(timeout_ms=50) is None
+    assert time.perf_counter() - t0 >= 0.04
+    threading.Timer(0.05, lambda: fb.add_frame(bytes(16), 2, 2)).start()
+    got = fb.pop_frame(timeout_ms=2000)
+    assert got is not None and got[1:] == (2, 2, 0)
