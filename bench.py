@@ -47,6 +47,9 @@ def parse_args():
                     help="units timed on the CPU oracle; -1 = sized for ~15 s of single-thread work, 0 disables")
     ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 --pmc traffic passes (N=1 only)")
     ap.add_argument("--no-profile", action="store_true", help="skip the in-loop hipEvent pairs")
+    ap.add_argument("--fused", action="store_true",
+                    help="blend inside the second upscale's row loads (in-between frame never written to HBM); "
+                         "same output frames, reported separately from the default 3-stage step")
     ap.add_argument("--overlap", action="store_true",
                     help="blend on a second stream, concurrent with the upscale of the real frames (measured: no gain, "
                          "the Lanczos kernel is SIMD-time bound and slows by what the blend takes)")
@@ -192,7 +195,9 @@ def main():
                 dist.barrier()
 
     def do_step():
-        if args.overlap:
+        if args.fused:
+            pipe.step_fused(frames, up_real, up_mid, stream)
+        elif args.overlap:
             pipe.step_overlapped(frames, mid, up_real, up_mid)
         else:
             pipe.step(frames, mid, up_real, up_mid, stream)
@@ -262,7 +267,9 @@ def main():
                 "units_per_step_per_gpu": n_units, "pixels_per_unit": pipe.unit_pixels,
                 "algorithmic_bytes_per_unit": pipe.unit_bytes, "pattern": args.pattern,
                 "lanczos_mode": args.lanczos_mode, "kernel_variant": pipe.upscaler.kernel_variant,
-                "schedule": "blend on a second HIP stream, concurrent with the upscale of the real frames"
+                "schedule": "fused: upscale(real) + upscale(blend(A,B)) with the blend in the row loads, 2 launches"
+                            if args.fused else
+                            "blend on a second HIP stream, concurrent with the upscale of the real frames"
                             if args.overlap else "3 stages back to back on one stream",
                 "sharding": f"frame-parallel, contiguous shards, {world} rank(s), LUT broadcast {lut_bytes} B over "
                             f"{'RCCL' if nccl else args.backend}",

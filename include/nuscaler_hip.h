@@ -149,6 +149,16 @@ int nus_upscaler_upscale_batch(nus_upscaler *h, const uint8_t *const *ins,
 int nus_upscaler_upscale_device(nus_upscaler *h, const void *d_in, void *d_out,
                                 uint32_t n_frames, void *stream);
 
+/* Fused "interpolate with zero flow, then upscale the in-between frame" -- the GUI's own sequence
+ * (nu_scaler_py/nu_scaler/main.py:999-1008) -- without materialising the 1080p in-between frame:
+ * unit i blends frames d_a + i*a_stride and d_b + i*b_stride at t (per channel
+ * trunc((1-t) a + t b), the pixel nus_interp_interpolate would have produced) inside the resize
+ * kernel's row loads.  Available for the exact-x2 resize kernels (Lanczos-3 / bicubic / triangle);
+ * otherwise NUS_ERR_UNSUPPORTED and the caller runs the two stages separately.  Results equal
+ * nus_interp_interpolate_device followed by nus_upscaler_upscale_device bit for bit. */
+int nus_upscaler_upscale_blend_device(nus_upscaler *h, const void *d_a, size_t a_stride, const void *d_b,
+                                      size_t b_stride, float t, void *d_out, uint32_t n_frames, void *stream);
+
 const char *nus_upscaler_name(const nus_upscaler *h); /* "WgpuNearestUpscaler" / "WgpuBilinearUpscaler" (mod.rs:1060-1066) / "Hip{Lanczos3,Bicubic,Triangle}Upscaler" */
 int nus_upscaler_algorithm(const nus_upscaler *h);
 int nus_upscaler_quality(const nus_upscaler *h);

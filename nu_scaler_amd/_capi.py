@@ -47,6 +47,7 @@ SIGNATURES = [
     ("nus_upscaler_upscale", _i, [_vp, _vp, _sz, _vp, _sz]),
     ("nus_upscaler_upscale_batch", _i, [_vp, _vp, _vp, _sz, _vp, _sz]),
     ("nus_upscaler_upscale_device", _i, [_vp, _vp, _vp, _u32, _vp]),
+    ("nus_upscaler_upscale_blend_device", _i, [_vp, _vp, _sz, _vp, _sz, _f, _vp, _u32, _vp]),
     ("nus_upscaler_name", _cp, [_vp]),
     ("nus_upscaler_algorithm", _i, [_vp]),
     ("nus_upscaler_quality", _i, [_vp]),

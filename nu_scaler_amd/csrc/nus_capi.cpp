@@ -121,6 +121,13 @@ int nus_upscaler_upscale_device(nus_upscaler *h, const void *d_in, void *d_out, 
     return h ? h->impl.upscale_device(d_in, d_out, n_frames, static_cast<hipStream_t>(stream)) : null_handle();
 }
 
+int nus_upscaler_upscale_blend_device(nus_upscaler *h, const void *d_a, size_t a_stride, const void *d_b, size_t b_stride,
+                                      float t, void *d_out, uint32_t n_frames, void *stream)
+{
+    return h ? h->impl.upscale_blend_device(d_a, a_stride, d_b, b_stride, t, d_out, n_frames, static_cast<hipStream_t>(stream))
+             : null_handle();
+}
+
 const char *nus_upscaler_name(const nus_upscaler *h) { return h ? h->impl.name() : ""; }
 int nus_upscaler_algorithm(const nus_upscaler *h) { return h ? static_cast<int>(h->impl.algorithm()) : null_handle(); }
 int nus_upscaler_quality(const nus_upscaler *h) { return h ? static_cast<int>(h->impl.quality()) : null_handle(); }

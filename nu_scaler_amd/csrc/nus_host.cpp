@@ -297,7 +297,7 @@ int HipUpscaler::initialize(uint32_t in_w, uint32_t in_h, uint32_t out_w, uint32
     return kOk;
 }
 
-int HipUpscaler::enqueue(const uint8_t *d_in, uint8_t *d_out, uint32_t n_frames, hipStream_t stream)
+int HipUpscaler::enqueue(const uint8_t *d_in, uint8_t *d_out, uint32_t n_frames, hipStream_t stream, const BlendSrc *blend)
 {
     UpscaleLaunch L;
     L.in = d_in;
@@ -308,6 +308,12 @@ int HipUpscaler::enqueue(const uint8_t *d_in, uint8_t *d_out, uint32_t n_frames,
     L.oh = oh_;
     L.n_frames = n_frames;
     L.stream = stream;
+    if (blend) {
+        L.in_stride = blend->a_stride;
+        L.in_b = blend->b;
+        L.in_b_stride = blend->b_stride;
+        L.blend_t = blend->t;
+    }
     // with profiling on, bracket the main kernel (not the Lanczos edge-column pass)
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
     if (profiling_) {
@@ -391,6 +397,29 @@ int HipUpscaler::upscale_device(const void *d_in, void *d_out, uint32_t n_frames
         return fail(kInvalidArgument, "upscale_device: batched frames need frame sizes that are multiples of 16 bytes");
     NUS_HIP(hipSetDevice(device_));
     return enqueue(static_cast<const uint8_t *>(d_in), static_cast<uint8_t *>(d_out), n_frames, stream);
+}
+
+int HipUpscaler::upscale_blend_device(const void *d_a, size_t a_stride, const void *d_b, size_t b_stride, float t,
+                                      void *d_out, uint32_t n_frames, hipStream_t stream)
+{
+    std::lock_guard<std::mutex> lk(mu_);
+    if (!initialized_) return fail(kNotInitialized, "Upscaler not initialized. Call initialize() first.");
+    if (variant_ != Variant::LanczosX2RegWin)
+        return fail(kUnsupported, "upscale_blend_device: only the exact-x2 resize kernels fuse the blend; "
+                                  "run interpolate + upscale separately for this configuration");
+    if (!d_a || !d_b || !d_out) return fail(kInvalidArgument, "upscale_blend_device: null device pointer");
+    if (n_frames == 0) return kOk;
+    if ((reinterpret_cast<uintptr_t>(d_a) % 16) || (reinterpret_cast<uintptr_t>(d_b) % 16) ||
+        (reinterpret_cast<uintptr_t>(d_out) % 16) || (a_stride % 16) || (b_stride % 16) ||
+        (n_frames > 1 && ((size_t)ow_ * oh_ * 4) % 16))
+        return fail(kInvalidArgument, "upscale_blend_device: pointers and strides must be 16-byte aligned");
+    NUS_HIP(hipSetDevice(device_));
+    BlendSrc bs;
+    bs.b = static_cast<const uint8_t *>(d_b);
+    bs.a_stride = a_stride;
+    bs.b_stride = b_stride;
+    bs.t = t;
+    return enqueue(static_cast<const uint8_t *>(d_a), static_cast<uint8_t *>(d_out), n_frames, stream, &bs);
 }
 
 int HipUpscaler::upscale(const uint8_t *in, size_t in_len, uint8_t *out, size_t out_cap)

@@ -73,6 +73,10 @@ public:
                       size_t out_cap_each);
     // frames already resident in HBM; enqueue only.
     int upscale_device(const void *d_in, void *d_out, uint32_t n_frames, hipStream_t stream);
+    // Fused "interpolate (zero flow) then upscale the in-between frame": unit i reads frame
+    // d_a + i*a_stride and d_b + i*b_stride.  x2 resize kernels only (else kUnsupported).
+    int upscale_blend_device(const void *d_a, size_t a_stride, const void *d_b, size_t b_stride, float t, void *d_out,
+                             uint32_t n_frames, hipStream_t stream);
 
     int set_device(int device);
     int set_bilinear_variant(int variant);
@@ -112,7 +116,12 @@ private:
     bool is_resize() const { return algorithm_ == Algorithm::Lanczos3 || algorithm_ == Algorithm::Bicubic || algorithm_ == Algorithm::Triangle; }
     ResizeFilter resize_filter() const;
     void choose_variant();
-    int enqueue(const uint8_t *d_in, uint8_t *d_out, uint32_t n_frames, hipStream_t stream);
+    struct BlendSrc {
+        const uint8_t *b = nullptr;
+        size_t a_stride = 0, b_stride = 0;
+        float t = 0.5f;
+    };
+    int enqueue(const uint8_t *d_in, uint8_t *d_out, uint32_t n_frames, hipStream_t stream, const BlendSrc *blend = nullptr);
 
     mutable std::mutex mu_;
     Quality quality_;

@@ -315,14 +315,57 @@ __global__ __launch_bounds__(256) void k_lanczos_general(
 
 struct LanczosX2Args {
     const uint8_t *in;
+    const uint8_t *in_b; // BLEND != 0: second frame of each pair
+    float t;             // BLEND == 2: blend factor
     uint8_t *out;
     const float *wy6; // [oh][6], phase frame: even row 2r taps rows r-3..r+2, odd row 2r+1 taps r-2..r+3
     float wxe[6];     // interior horizontal weights, even output 2k: columns k-3..k+2
     float wxo[6];     // odd output 2k+1: columns k-2..k+3
     uint32_t iw, ih;
     uint32_t nstrips, nrowblocks, th;
-    size_t in_frame_bytes, out_frame_bytes;
+    size_t in_frame_bytes, in_b_frame_bytes, out_frame_bytes; // byte strides between consecutive frames
 };
+
+// Input rows of the x2 kernels.  BLEND 0: the frame itself.  BLEND 1 / 2: the zero-flow in-between
+// frame of a pair (A, B) is formed on the fly -- trunc((1-t) a + t b) per channel, exactly the u8
+// pixel k_blend_zero_flow would have stored (interpolation/mod.rs:407-411) -- so "interpolate, then
+// upscale the interpolated frame" (nu_scaler_py/nu_scaler/main.py:999-1008) needs no round trip
+// through HBM.  At t = 0.5 both products and the sum are exact and the truncation is a floor of a
+// half-integer: one v_lerp_u8 per pixel.
+__device__ __forceinline__ uint32_t blend_px(uint32_t a, uint32_t b, float t, float nt);
+
+template <int BLEND>
+struct RowRaw {
+    uint4 a, b;
+};
+template <>
+struct RowRaw<0> {
+    uint4 a;
+};
+
+template <int BLEND>
+__device__ __forceinline__ RowRaw<BLEND> fetch_row(const uint8_t *pa, const uint8_t *pb, size_t off)
+{
+    RowRaw<BLEND> r;
+    r.a = *reinterpret_cast<const uint4 *>(pa + off);
+    if constexpr (BLEND != 0) r.b = *reinterpret_cast<const uint4 *>(pb + off);
+    return r;
+}
+
+template <int BLEND>
+__device__ __forceinline__ uint4 resolve_row(const RowRaw<BLEND> &r, float t)
+{
+    if constexpr (BLEND == 0) {
+        return r.a;
+    } else if constexpr (BLEND == 1) {
+        return make_uint4(__builtin_amdgcn_lerp(r.a.x, r.b.x, 0u), __builtin_amdgcn_lerp(r.a.y, r.b.y, 0u),
+                          __builtin_amdgcn_lerp(r.a.z, r.b.z, 0u), __builtin_amdgcn_lerp(r.a.w, r.b.w, 0u));
+    } else {
+        const float nt = 1.0f - t;
+        return make_uint4(blend_px(r.a.x, r.b.x, t, nt), blend_px(r.a.y, r.b.y, t, nt), blend_px(r.a.z, r.b.z, t, nt),
+                          blend_px(r.a.w, r.b.w, t, nt));
+    }
+}
 
 __device__ __forceinline__ float lane_up(float v) // value of lane-1
 {
@@ -435,10 +478,10 @@ __device__ __forceinline__ void lanczos_x2_hpass_store(const float (&V)[16], con
 // At entry window slot (S+j)%6 holds input row r-3+j, j = 0..5, and raw[S&1] holds row r+3.
 // Row r-3 dies after the even phase, so row r+3 is converted into its slot BETWEEN the two
 // phases: only 6 rows (96 VGPRs) are ever live, not 7.
-template <bool EXACT, int S>
-__device__ __forceinline__ void lanczos_x2_step(float (&win)[6][16], uint4 (&raw)[2], int r, int cl, uint32_t lane_off,
-                                                const LanczosX2Args &A, const PhaseWeights &W, const uint8_t *src,
-                                                __amdgpu_buffer_rsrc_t rs)
+template <bool EXACT, int BLEND, int S>
+__device__ __forceinline__ void lanczos_x2_step(float (&win)[6][16], RowRaw<BLEND> (&raw)[2], int r, int cl,
+                                                uint32_t lane_off, const LanczosX2Args &A, const PhaseWeights &W,
+                                                const uint8_t *src, const uint8_t *src_b, __amdgpu_buffer_rsrc_t rs)
 {
     const uint32_t row_bytes = A.iw * 8; // output row: 2*iw pixels
     const uint32_t off0 = lane_off + (uint32_t)(2 * r) * row_bytes;
@@ -451,11 +494,11 @@ __device__ __forceinline__ void lanczos_x2_step(float (&win)[6][16], uint4 (&raw
     lanczos_x2_hpass_store<EXACT>(V, W, rs, off0);
     // row r+3 in, then request row r+5 into the same buffer (consumed two steps from now;
     // vmcnt retires in order, so that wait only sits behind stores at least a step old)
-    cvt_row(raw[S & 1], win[S % 6]);
+    cvt_row(resolve_row<BLEND>(raw[S & 1], A.t), win[S % 6]);
     {
         int rn = r + 5;
         rn = rn < (int)A.ih - 1 ? rn : (int)A.ih - 1;
-        raw[S & 1] = *reinterpret_cast<const uint4 *>(src + ((size_t)rn * A.iw + cl) * 4);
+        raw[S & 1] = fetch_row<BLEND>(src, src_b, ((size_t)rn * A.iw + cl) * 4);
     }
     if (interior)
         lanczos_x2_vpass<EXACT, S + 1>(win, W.o, V);
@@ -474,7 +517,7 @@ __device__ __forceinline__ void lanczos_x2_step(float (&win)[6][16], uint4 (&raw
 // barrier is needed.  Output: 2 x 16-B stores per lane per output row (2 KiB per wave).
 // The 8 left-most and right-most output columns (renormalised edge weights) are left
 // to k_lanczos3_x2_edges.
-template <bool EXACT>
+template <bool EXACT, int BLEND>
 __global__ __launch_bounds__(256) void k_lanczos3_x2(const LanczosX2Args A)
 {
     const int lane = threadIdx.x & (kWave - 1);
@@ -487,6 +530,7 @@ __global__ __launch_bounds__(256) void k_lanczos3_x2(const LanczosX2Args A)
     cl = cl > (int)A.iw - 4 ? (int)A.iw - 4 : cl;
     const bool do_store = lane >= 1 && lane <= 62 && c >= 4 && c + 8 <= (int)A.iw;
     const uint8_t *src = A.in + (size_t)blockIdx.y * A.in_frame_bytes;
+    const uint8_t *src_b = BLEND ? A.in_b + (size_t)blockIdx.y * A.in_b_frame_bytes : src;
     // one buffer resource per output frame (< 2 GiB, checked by the host); non-storing lanes
     // sit at offset 2^31, outside num_records for every row
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
@@ -497,7 +541,7 @@ __global__ __launch_bounds__(256) void k_lanczos3_x2(const LanczosX2Args A)
     const int rmax = (int)A.ih - 1;
     auto load_row = [&](int rr) {
         rr = rr < 0 ? 0 : (rr > rmax ? rmax : rr);
-        return *reinterpret_cast<const uint4 *>(src + ((size_t)rr * A.iw + cl) * 4);
+        return fetch_row<BLEND>(src, src_b, ((size_t)rr * A.iw + cl) * 4);
     };
 
     PhaseWeights W;
@@ -508,16 +552,16 @@ __global__ __launch_bounds__(256) void k_lanczos3_x2(const LanczosX2Args A)
     }
     float win[6][16];
 #pragma unroll
-    for (int j = 0; j < 6; ++j) cvt_row(load_row(r0 - 3 + j), win[j]);
-    uint4 raw[2] = {load_row(r0 + 3), load_row(r0 + 4)};
+    for (int j = 0; j < 6; ++j) cvt_row(resolve_row<BLEND>(load_row(r0 - 3 + j), A.t), win[j]);
+    RowRaw<BLEND> raw[2] = {load_row(r0 + 3), load_row(r0 + 4)};
     for (int rbase = r0; rbase < r_end; rbase += 6) {
         // 6-way unrolled so the rotating window indices are compile-time constants.
-        if (rbase + 0 < r_end) lanczos_x2_step<EXACT, 0>(win, raw, rbase + 0, cl, lane_off, A, W, src, rs);
-        if (rbase + 1 < r_end) lanczos_x2_step<EXACT, 1>(win, raw, rbase + 1, cl, lane_off, A, W, src, rs);
-        if (rbase + 2 < r_end) lanczos_x2_step<EXACT, 2>(win, raw, rbase + 2, cl, lane_off, A, W, src, rs);
-        if (rbase + 3 < r_end) lanczos_x2_step<EXACT, 3>(win, raw, rbase + 3, cl, lane_off, A, W, src, rs);
-        if (rbase + 4 < r_end) lanczos_x2_step<EXACT, 4>(win, raw, rbase + 4, cl, lane_off, A, W, src, rs);
-        if (rbase + 5 < r_end) lanczos_x2_step<EXACT, 5>(win, raw, rbase + 5, cl, lane_off, A, W, src, rs);
+        if (rbase + 0 < r_end) lanczos_x2_step<EXACT, BLEND, 0>(win, raw, rbase + 0, cl, lane_off, A, W, src, src_b, rs);
+        if (rbase + 1 < r_end) lanczos_x2_step<EXACT, BLEND, 1>(win, raw, rbase + 1, cl, lane_off, A, W, src, src_b, rs);
+        if (rbase + 2 < r_end) lanczos_x2_step<EXACT, BLEND, 2>(win, raw, rbase + 2, cl, lane_off, A, W, src, src_b, rs);
+        if (rbase + 3 < r_end) lanczos_x2_step<EXACT, BLEND, 3>(win, raw, rbase + 3, cl, lane_off, A, W, src, src_b, rs);
+        if (rbase + 4 < r_end) lanczos_x2_step<EXACT, BLEND, 4>(win, raw, rbase + 4, cl, lane_off, A, W, src, src_b, rs);
+        if (rbase + 5 < r_end) lanczos_x2_step<EXACT, BLEND, 5>(win, raw, rbase + 5, cl, lane_off, A, W, src, src_b, rs);
     }
 }
 
@@ -528,11 +572,13 @@ __global__ __launch_bounds__(256) void k_lanczos3_x2(const LanczosX2Args A)
 // wave-uniform (kernel arguments -> SGPRs) and the vertical weights per lane.
 struct LanczosX2EdgeArgs {
     const uint8_t *in;
+    const uint8_t *in_b;
+    float t;
     uint8_t *out;
     const float *wy6;
     float wx[2][48]; // [side][output column 0..7 of that side][tap 0..5], phase frame, 0 outside the image
     uint32_t iw, ih;
-    size_t in_frame_bytes, out_frame_bytes;
+    size_t in_frame_bytes, in_b_frame_bytes, out_frame_bytes;
 };
 
 __device__ __forceinline__ uint32_t px_of(const uint4 (&row)[2], int col)
@@ -595,7 +641,7 @@ __device__ __forceinline__ void lanczos_x2_edge_rows(const LanczosX2EdgeArgs &A,
     }
 }
 
-template <bool EXACT>
+template <bool EXACT, int BLEND>
 __global__ __launch_bounds__(64) void k_lanczos3_x2_edges(const LanczosX2EdgeArgs A)
 {
     const int r = (int)(blockIdx.x * kWave + threadIdx.x);
@@ -604,15 +650,16 @@ __global__ __launch_bounds__(64) void k_lanczos3_x2_edges(const LanczosX2EdgeArg
     const int col0 = side ? (int)A.iw - 8 : 0;
     const int rmax = (int)A.ih - 1;
     const uint8_t *src = A.in + (size_t)blockIdx.z * A.in_frame_bytes;
+    const uint8_t *src_b = BLEND ? A.in_b + (size_t)blockIdx.z * A.in_b_frame_bytes : src;
     uint32_t *dst = reinterpret_cast<uint32_t *>(A.out + (size_t)blockIdx.z * A.out_frame_bytes);
     uint4 raw[7][2];
 #pragma unroll
     for (int j = 0; j < 7; ++j) {
         int rr = r - 3 + j;
         rr = rr < 0 ? 0 : (rr > rmax ? rmax : rr);
-        const uint4 *p = reinterpret_cast<const uint4 *>(src + ((size_t)rr * A.iw + col0) * 4);
-        raw[j][0] = p[0];
-        raw[j][1] = p[1];
+        const size_t off = ((size_t)rr * A.iw + col0) * 4;
+        raw[j][0] = resolve_row<BLEND>(fetch_row<BLEND>(src, src_b, off), A.t);
+        raw[j][1] = resolve_row<BLEND>(fetch_row<BLEND>(src, src_b, off + 16), A.t);
     }
     if (side == 0)
         lanczos_x2_edge_rows<EXACT, 0>(A, raw, r, dst);
@@ -1042,12 +1089,14 @@ const char *variant_name(Variant v)
 static inline uint32_t cdiv(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
 
 // Frames go on grid.z (<= 65535 per launch); longer batches are issued in chunks.
+static thread_local uint32_t g_chunk_first_frame = 0; // index of the chunk's first frame, for second inputs
 template <typename F>
 static hipError_t for_frame_chunks(const UpscaleLaunch &L, F &&f)
 {
-    const size_t in_bytes = (size_t)L.iw * L.ih * 4, out_bytes = (size_t)L.ow * L.oh * 4;
+    const size_t in_bytes = L.in_stride ? L.in_stride : (size_t)L.iw * L.ih * 4, out_bytes = (size_t)L.ow * L.oh * 4;
     for (uint32_t done = 0; done < L.n_frames;) {
         const uint32_t n = L.n_frames - done < kMaxGridZ ? L.n_frames - done : kMaxGridZ;
+        g_chunk_first_frame = done;
         f(L.in + (size_t)done * in_bytes, L.out + (size_t)done * out_bytes, n);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
@@ -1145,19 +1194,26 @@ hipError_t launch_lanczos_x2(const UpscaleLaunch &L, const DeviceTables &T, bool
     A.nstrips = cdiv(L.iw, kLanczosX2StripCols);
     A.th = rows_per_wave ? rows_per_wave : 32;
     A.nrowblocks = cdiv(L.ih, A.th);
-    A.in_frame_bytes = (size_t)L.iw * L.ih * 4;
+    A.in_frame_bytes = L.in_stride ? L.in_stride : (size_t)L.iw * L.ih * 4;
+    A.in_b_frame_bytes = L.in_b_stride;
     A.out_frame_bytes = (size_t)L.ow * L.oh * 4;
+    A.t = L.blend_t;
+    const int blend = L.in_b == nullptr ? 0 : (L.blend_t == 0.5f ? 1 : 2);
     const uint32_t nwaves = A.nstrips * A.nrowblocks;
     // dev knob: unused dynamic LDS per block, to study occupancy sensitivity (0 in production)
     static const uint32_t lds_pad = getenv("NUS_LDS_PAD_KB") ? (uint32_t)atoi(getenv("NUS_LDS_PAD_KB")) * 1024u : 0u;
     hipError_t e = for_frame_chunks(L, [&](const uint8_t *in, uint8_t *out, uint32_t n) {
         A.in = in;
+        A.in_b = L.in_b ? L.in_b + (size_t)g_chunk_first_frame * L.in_b_stride : nullptr;
         A.out = out;
         const dim3 block(256), grid(cdiv(nwaves, 4), n);
-        if (exact)
-            hipLaunchKernelGGL(k_lanczos3_x2<true>, grid, block, lds_pad, L.stream, A);
-        else
-            hipLaunchKernelGGL(k_lanczos3_x2<false>, grid, block, lds_pad, L.stream, A);
+#define NUS_LZ(E, B) hipLaunchKernelGGL((k_lanczos3_x2<E, B>), grid, block, lds_pad, L.stream, A)
+        if (exact) {
+            if (blend == 0) NUS_LZ(true, 0); else if (blend == 1) NUS_LZ(true, 1); else NUS_LZ(true, 2);
+        } else {
+            if (blend == 0) NUS_LZ(false, 0); else if (blend == 1) NUS_LZ(false, 1); else NUS_LZ(false, 2);
+        }
+#undef NUS_LZ
     });
     return e;
 }
@@ -1172,16 +1228,23 @@ hipError_t launch_lanczos_x2_edges(const UpscaleLaunch &L, const DeviceTables &T
     }
     A.iw = L.iw;
     A.ih = L.ih;
-    A.in_frame_bytes = (size_t)L.iw * L.ih * 4;
+    A.in_frame_bytes = L.in_stride ? L.in_stride : (size_t)L.iw * L.ih * 4;
+    A.in_b_frame_bytes = L.in_b_stride;
     A.out_frame_bytes = (size_t)L.ow * L.oh * 4;
+    A.t = L.blend_t;
+    const int blend = L.in_b == nullptr ? 0 : (L.blend_t == 0.5f ? 1 : 2);
     return for_frame_chunks(L, [&](const uint8_t *in, uint8_t *out, uint32_t n) {
         A.in = in;
+        A.in_b = L.in_b ? L.in_b + (size_t)g_chunk_first_frame * L.in_b_stride : nullptr;
         A.out = out;
         const dim3 block(kWave), grid(cdiv(L.ih, kWave), 2, n);
-        if (exact)
-            hipLaunchKernelGGL(k_lanczos3_x2_edges<true>, grid, block, 0, L.stream, A);
-        else
-            hipLaunchKernelGGL(k_lanczos3_x2_edges<false>, grid, block, 0, L.stream, A);
+#define NUS_LZE(E, B) hipLaunchKernelGGL((k_lanczos3_x2_edges<E, B>), grid, block, 0, L.stream, A)
+        if (exact) {
+            if (blend == 0) NUS_LZE(true, 0); else if (blend == 1) NUS_LZE(true, 1); else NUS_LZE(true, 2);
+        } else {
+            if (blend == 0) NUS_LZE(false, 0); else if (blend == 1) NUS_LZE(false, 1); else NUS_LZE(false, 2);
+        }
+#undef NUS_LZE
     });
 }
 

@@ -33,6 +33,12 @@ struct UpscaleLaunch {
     uint32_t iw = 0, ih = 0, ow = 0, oh = 0;
     uint32_t n_frames = 1;
     hipStream_t stream = nullptr;
+    // x2 resize kernels only: input frame stride in bytes (0 = tightly packed), and an optional
+    // second frame per unit to blend with on the fly (zero-flow in-between frame at blend_t)
+    size_t in_stride = 0;
+    const uint8_t *in_b = nullptr;
+    size_t in_b_stride = 0;
+    float blend_t = 0.5f;
 };
 
 // Kernel variants (chosen once at initialize).

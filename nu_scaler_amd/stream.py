@@ -137,6 +137,15 @@ class FramePipeline:
         self.upscaler.upscale_device(base, up_real.data_ptr(), n, stream)
         self.upscaler.upscale_device(mid.data_ptr(), up_mid.data_ptr(), n, stream)
 
+    def step_fused(self, frames, up_real, up_mid, stream: int = 0) -> None:
+        """Same outputs without materialising the in-between frames: the blend happens inside the
+        second upscale's row loads (two launches instead of three, 16.6 MB less HBM traffic per unit)."""
+        n = up_real.shape[0]
+        base = frames.data_ptr()
+        fb = self.frame_bytes
+        self.upscaler.upscale_device(base, up_real.data_ptr(), n, stream)
+        self.upscaler.upscale_blend_device(base, fb, base + fb, fb, self.t, up_mid.data_ptr(), n, stream)
+
     def step_overlapped(self, frames, mid, up_real, up_mid) -> None:
         """Same work with the blend on a second stream: the Lanczos kernel is bound by SIMD
         time (VALU issue + store feed) and leaves HBM bandwidth idle, the zero-flow blend is

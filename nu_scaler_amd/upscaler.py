@@ -133,6 +133,12 @@ class PyWgpuUpscaler:
     def upscale_device(self, d_in: int, d_out: int, n_frames: int = 1, stream: int = 0) -> None:
         self._check(self._lib.nus_upscaler_upscale_device(self._h, d_in, d_out, n_frames, stream or None))
 
+    def upscale_blend_device(self, d_a: int, a_stride: int, d_b: int, b_stride: int, time_t: float, d_out: int,
+                             n_frames: int = 1, stream: int = 0) -> None:
+        """Fused zero-flow interpolate + upscale of the in-between frame (exact-x2 resize kernels)."""
+        self._check(self._lib.nus_upscaler_upscale_blend_device(self._h, d_a, a_stride, d_b, b_stride, float(time_t),
+                                                                d_out, n_frames, stream or None))
+
     # -- wgpu-only knobs: accepted and ignored (lib.rs:115-137)
     def reload_shader(self, path: str) -> None:
         return None

@@ -362,3 +362,40 @@ def test_swizzle_bgra_to_rgba_device(nsc, oracle_mod):
         nsc.swizzle_bgra_to_rgba_device(out.data_ptr(), out.data_ptr(), n, torch.cuda.current_stream().cuda_stream)  # in place
         torch.cuda.synchronize()
         assert torch.equal(out.cpu(), bgra.cpu())
+
+
+@pytest.mark.parametrize("alg", ["lanczos3", "bicubic"])
+@pytest.mark.parametrize("t", [0.5, 0.3, 0.0, 1.0])
+def test_fused_blend_upscale_equals_two_stage(nsc, oracle_mod, alg, t):
+    """upscale_blend_device == interpolate (zero flow) then upscale, bit for bit (sliding stream layout)."""
+    import torch
+
+    w, h, n = 128, 40, 4
+    dev = torch.device("cuda:0")
+    frames_np = np.stack([oracle_mod.gen_noise(w, h, 300 + i) for i in range(n + 1)])
+    frames = torch.from_numpy(frames_np).to(dev)
+    filt = {"lanczos3": 0, "bicubic": 1}[alg]
+    for mode in ("exact", "fma"):
+        u = nsc.PyWgpuUpscaler("quality", alg, lanczos_mode=mode)
+        u.initialize(w, h, 2 * w, 2 * h)
+        fused = torch.zeros((n, 2 * h, 2 * w, 4), dtype=torch.uint8, device=dev)
+        fb = w * h * 4
+        u.upscale_blend_device(frames.data_ptr(), fb, frames.data_ptr() + fb, fb, t, fused.data_ptr(), n,
+                               torch.cuda.current_stream().cuda_stream)
+        # two-stage reference on the GPU
+        it = nsc.WgpuFrameInterpolator()
+        mid = torch.empty((n, h, w, 4), dtype=torch.uint8, device=dev)
+        two = torch.zeros_like(fused)
+        s = torch.cuda.current_stream().cuda_stream
+        it.interpolate_device(frames.data_ptr(), fb, frames.data_ptr() + fb, fb, 0, w, h, t, mid.data_ptr(), n, s)
+        u.upscale_device(mid.data_ptr(), two.data_ptr(), n, s)
+        torch.cuda.synchronize()
+        assert torch.equal(fused, two), (alg, t, mode)
+        if mode == "exact":
+            for i in range(n):
+                m = oracle_mod.warp_blend(frames_np[i], frames_np[i + 1], None, t)
+                assert np.array_equal(fused[i].cpu().numpy(), oracle_mod.resize(m, 2 * w, 2 * h, filt)), (alg, t, i)
+    ub = nsc.PyWgpuUpscaler("quality", "bilinear")
+    ub.initialize(w, h, 2 * w, 2 * h)
+    with pytest.raises(RuntimeError, match="only the exact-x2 resize kernels"):
+        ub.upscale_blend_device(frames.data_ptr(), fb, frames.data_ptr() + fb, fb, 0.5, fused.data_ptr(), 1, 0)

@@ -72,6 +72,9 @@ def main():
     mid, up_real, up_mid = pipe.alloc(n, dev)
     ms = timed(lambda: pipe.step(frames, mid, up_real, up_mid, s), args.reps)
     us = ms * 1e3 / n
+    msf = timed(lambda: pipe.step_fused(frames, up_real, up_mid, s), args.reps)
+    usf = msf * 1e3 / n
+    print(f"fused unit (lanczos + blend-in-load lanczos): {usf:8.2f} us/unit  {pipe.unit_pixels/usf:8.1f} Mpix/s (BASELINE unit pixels)")
     print(f"pipeline unit (interp + 2x lanczos): {us:8.2f} us/unit  {pipe.unit_pixels/us:8.1f} Mpix/s  {pipe.unit_bytes/us/1e6:6.2f} TB/s  {1e6/us:8.0f} units/s")
 
 
