@@ -41,7 +41,7 @@ def main():
     print(f"frames={n} pattern={args.pattern}  (upscale: {up_bytes/1e6:.2f} MB/frame algorithmic)")
     cases = [("nearest", {}, {}), ("nearest", {}, {"force_general": 1}), ("bilinear", {}, {}), ("bilinear", {}, {"force_general": 1}),
              ("lanczos3", {"lanczos_mode": "fma"}, {}), ("lanczos3", {"lanczos_mode": "exact"}, {}),
-             ("lanczos3", {"lanczos_mode": "fma"}, {"window_f16": 1})]
+             ("bicubic", {"lanczos_mode": "fma"}, {})]
     if args.sweep:
         for th in (4, 8, 12, 16, 24, 32, 36, 48, 64):
             cases.append(("lanczos3", {"lanczos_mode": "fma"}, {"rows_per_wave": th}))
