@@ -399,3 +399,61 @@ def test_fused_blend_upscale_equals_two_stage(nsc, oracle_mod, alg, t):
     ub.initialize(w, h, 2 * w, 2 * h)
     with pytest.raises(RuntimeError, match="only the exact-x2 resize kernels"):
         ub.upscale_blend_device(frames.data_ptr(), fb, frames.data_ptr() + fb, fb, 0.5, fused.data_ptr(), 1, 0)
+
+
+def test_concurrent_calls_on_one_handle_are_serialised(nsc, oracle_mod):
+    """The reference calls upscale(&self) from rayon threads (upscale/mod.rs:619-624): one handle,
+    many threads.  ctypes releases the GIL, so these really run concurrently into the C ABI."""
+    import threading
+
+    w, h = 96, 40
+    u = nsc.PyWgpuUpscaler("quality", "lanczos3", lanczos_mode="exact")
+    u.initialize(w, h, 2 * w, 2 * h)
+    frames = [oracle_mod.gen_noise(w, h, 500 + i) for i in range(8)]
+    want = [oracle_mod.lanczos3(f, 2 * w, 2 * h) for f in frames]
+    got, errs = [None] * len(frames), []
+
+    def work(i):
+        try:
+            for _ in range(5):
+                got[i] = np.frombuffer(u.upscale(frames[i].tobytes()), np.uint8).reshape(2 * h, 2 * w, 4)
+        except Exception as e:  # pragma: no cover
+            errs.append(e)
+
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(len(frames))]
+    [t.start() for t in threads]
+    [t.join() for t in threads]
+    assert not errs
+    for g, wnt in zip(got, want):
+        assert np.array_equal(g, wnt)
+
+
+def test_device_path_is_graph_capturable(nsc, oracle_mod):
+    """The device entry points allocate nothing and never synchronise: one pipeline step can be
+    captured into a hipGraph and replayed."""
+    import torch
+
+    w, h, n = 128, 24, 3
+    dev = torch.device("cuda:0")
+    frames_np = np.stack([oracle_mod.gen_noise(w, h, 600 + i) for i in range(n + 1)])
+    frames = torch.from_numpy(frames_np).to(dev)
+    pipe = nsc.FramePipeline(w, h, 2, "lanczos3", 0.5, lanczos_mode="exact")
+    mid, up_real, up_mid = pipe.alloc(n, dev)
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        pipe.step(frames, mid, up_real, up_mid, side.cuda_stream)  # warm-up outside capture
+    side.synchronize()
+    for t in (mid, up_real, up_mid):
+        t.zero_()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=side):
+        pipe.step(frames, mid, up_real, up_mid, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert int(up_real.max()) == 0  # capture does not execute
+    g.replay()
+    torch.cuda.synchronize()
+    for i in range(n):
+        m = oracle_mod.warp_blend(frames_np[i], frames_np[i + 1], None, 0.5)
+        assert np.array_equal(mid[i].cpu().numpy(), m)
+        assert np.array_equal(up_real[i].cpu().numpy(), oracle_mod.lanczos3(frames_np[i], 2 * w, 2 * h))
+        assert np.array_equal(up_mid[i].cpu().numpy(), oracle_mod.lanczos3(m, 2 * w, 2 * h))
