@@ -42,6 +42,14 @@ __device__ __forceinline__ uint32_t trunc_u8(float v)
     return (uint32_t)fminf(fmaxf(v, 0.0f), 255.0f);
 }
 
+// Same value (truncate toward zero, saturate to [0,255]) inserted as byte c of acc in two
+// instructions: v_floor_f32 makes the argument an integer (for negative inputs floor and trunc differ
+// but both saturate to 0), so v_cvt_pk_u8_f32's rounding mode no longer matters.
+__device__ __forceinline__ uint32_t pack_trunc_u8(float v, int c, uint32_t acc)
+{
+    return __builtin_amdgcn_cvt_pk_u8_f32(floorf(v), c, acc);
+}
+
 // f32::round (half away from zero) of a value clamped to [0,255].
 __device__ __forceinline__ uint32_t round_u8_exact(float v)
 {
@@ -143,7 +151,7 @@ __device__ __forceinline__ uint32_t bilerp_cpu(uint32_t p00, uint32_t p10, uint3
         const float top = ch_f32(p00, c) * ndx + ch_f32(p10, c) * dx;
         const float bottom = ch_f32(p01, c) * ndx + ch_f32(p11, c) * dx;
         const float value = top * ndy + bottom * dy;
-        o |= trunc_u8(value) << (8 * c);
+        o = pack_trunc_u8(value, c, o);
     }
     return o;
 }
@@ -161,7 +169,8 @@ __device__ __forceinline__ uint32_t bilerp_wgsl(uint32_t p00, uint32_t p10, uint
         const float c0 = c00 * ndx + c10 * dx;
         const float c1 = c01 * ndx + c11 * dx;
         const float v = c0 * ndy + c1 * dy;
-        o |= (uint32_t)(fminf(fmaxf(v, 0.0f), 1.0f) * 255.0f) << (8 * c);
+        // u32(clamp(v, 0, 1) * 255): the saturating pack performs the lower clamp
+        o = pack_trunc_u8(fminf(v, 1.0f) * 255.0f, c, o);
     }
     return o;
 }
@@ -678,7 +687,7 @@ __device__ __forceinline__ uint32_t blend_px(uint32_t a, uint32_t b, float t, fl
 {
     uint32_t o = 0;
 #pragma unroll
-    for (int c = 0; c < 4; ++c) o |= trunc_u8(nt * ch_f32(a, c) + t * ch_f32(b, c)) << (8 * c);
+    for (int c = 0; c < 4; ++c) o = pack_trunc_u8(nt * ch_f32(a, c) + t * ch_f32(b, c), c, o);
     return o;
 }
 
@@ -703,9 +712,9 @@ __global__ __launch_bounds__(256) void k_blend_zero_flow(
     }
 }
 
-// interpolation/mod.rs:467-510: clamp, bilinear, truncate to u8.
-__device__ __forceinline__ uint32_t sample_trunc(const uint32_t *__restrict__ f, uint32_t w, uint32_t h,
-                                                 float x, float y)
+// interpolation/mod.rs:467-510: clamp, bilinear, truncate to u8 -- returned as the four truncated
+// channel values still in f32 (floor of a value in [0, 255]) so the blend needs no unpack.
+__device__ __forceinline__ float4 sample_trunc(const uint32_t *__restrict__ f, uint32_t w, uint32_t h, float x, float y)
 {
     x = fminf(fmaxf(x, 0.0f), (float)(w - 1));
     y = fminf(fmaxf(y, 0.0f), (float)(h - 1));
@@ -716,15 +725,15 @@ __device__ __forceinline__ uint32_t sample_trunc(const uint32_t *__restrict__ f,
     const float nxf = 1.0f - xf, nyf = 1.0f - yf;
     const uint32_t p00 = f[(size_t)y0 * w + x0], p01 = f[(size_t)y0 * w + x1];
     const uint32_t p10 = f[(size_t)y1 * w + x0], p11 = f[(size_t)y1 * w + x1];
-    uint32_t o = 0;
+    float r[4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
         const float top = ch_f32(p00, c) * nxf + ch_f32(p01, c) * xf;
         const float bottom = ch_f32(p10, c) * nxf + ch_f32(p11, c) * xf;
         const float value = top * nyf + bottom * yf;
-        o |= trunc_u8(value) << (8 * c);
+        r[c] = fminf(floorf(value), 255.0f); // `value as u8`; value >= 0 here
     }
-    return o;
+    return make_float4(r[0], r[1], r[2], r[3]);
 }
 
 // Dense flow (2 x f32 per pixel, delta A -> B): A sampled at p - t*flow, B at
@@ -741,12 +750,19 @@ __global__ __launch_bounds__(256) void k_warp_blend_flow(
     const uint32_t *pb = reinterpret_cast<const uint32_t *>(b + (size_t)blockIdx.z * b_stride);
     const size_t idx = (size_t)y * w + x;
     const float2 f = *reinterpret_cast<const float2 *>(flow + ((size_t)blockIdx.z * npx + idx) * 2);
-    const float nt = 1.0f - t;
-    const float ax = (float)x - t * f.x, ay = (float)y - t * f.y;
+    float tv = t; // per-lane copy: scalar operands halve the VALU issue rate on gfx950
+    asm volatile("" : "+v"(tv));
+    const float nt = 1.0f - tv;
+    const float ax = (float)x - tv * f.x, ay = (float)y - tv * f.y;
     const float bx = (float)x + nt * f.x, by = (float)y + nt * f.y;
-    const uint32_t sa = sample_trunc(pa, w, h, ax, ay);
-    const uint32_t sb = sample_trunc(pb, w, h, bx, by);
-    reinterpret_cast<uint32_t *>(out)[(size_t)blockIdx.z * npx + idx] = blend_px(sa, sb, t, nt);
+    const float4 sa = sample_trunc(pa, w, h, ax, ay);
+    const float4 sb = sample_trunc(pb, w, h, bx, by);
+    uint32_t o = 0;
+    o = pack_trunc_u8(nt * sa.x + tv * sb.x, 0, o);
+    o = pack_trunc_u8(nt * sa.y + tv * sb.y, 1, o);
+    o = pack_trunc_u8(nt * sa.z + tv * sb.z, 2, o);
+    o = pack_trunc_u8(nt * sa.w + tv * sb.w, 3, o);
+    reinterpret_cast<uint32_t *>(out)[(size_t)blockIdx.z * npx + idx] = o;
 }
 
 // ---------------------------------------------------------------------------------
