@@ -36,13 +36,8 @@ __device__ __forceinline__ float ch_f32(uint32_t p, int c)
     return (float)((p >> (8 * c)) & 0xffu); // v_cvt_f32_ubyteN
 }
 
-// Rust `clamp(0,255) as u8` / `as u8`: truncate toward zero, saturate, NaN -> 0.
-__device__ __forceinline__ uint32_t trunc_u8(float v)
-{
-    return (uint32_t)fminf(fmaxf(v, 0.0f), 255.0f);
-}
-
-// Same value (truncate toward zero, saturate to [0,255]) inserted as byte c of acc in two
+// Rust `clamp(0,255) as u8` / `as u8` (truncate toward zero, saturate, NaN -> 0), inserted as byte c
+// of acc in two
 // instructions: v_floor_f32 makes the argument an integer (for negative inputs floor and trunc differ
 // but both saturate to 0), so v_cvt_pk_u8_f32's rounding mode no longer matters.
 __device__ __forceinline__ uint32_t pack_trunc_u8(float v, int c, uint32_t acc)
@@ -85,34 +80,49 @@ __device__ __forceinline__ uint32_t pack_u8(float v, int c, uint32_t acc)
 
 __device__ __forceinline__ uint32_t umin(uint32_t a, uint32_t b) { return a < b ? a : b; }
 
+__device__ __forceinline__ float div_by_recip(float x, float y, float z); // defined with the flow kernels
+
 // ---------------------------------------------------------------------------------
 // Nearest
 // ---------------------------------------------------------------------------------
 
-// Any scale.  blockDim = (64, 4): one wave per 256-px (VEC) or 64-px row segment.
+// Any scale.  blockDim = (64, 4): each wave owns a 256-px (VEC) or 64-px column segment and walks
+// `rows_per_wave` output rows; the gathered source pixels are kept in registers and re-fetched only
+// when the source row changes (an upscale stores each gathered row several times).
 template <bool VEC>
 __global__ __launch_bounds__(256) void k_nearest_table(
     const uint32_t *__restrict__ in, uint32_t *__restrict__ out,
     const uint32_t *__restrict__ sx, const uint32_t *__restrict__ sy,
-    uint32_t iw, uint32_t ow, uint32_t oh, size_t in_frame_px, size_t out_frame_px)
+    uint32_t iw, uint32_t ow, uint32_t oh, uint32_t rows_per_wave, size_t in_frame_px, size_t out_frame_px)
 {
-    const uint32_t y = __builtin_amdgcn_readfirstlane(blockIdx.y * 4 + threadIdx.y);
-    if (y >= oh) return;
-    const uint32_t *src = in + (size_t)blockIdx.z * in_frame_px + (size_t)sy[y] * iw;
-    uint32_t *dst = out + (size_t)blockIdx.z * out_frame_px + (size_t)y * ow;
+    constexpr int N = VEC ? 4 : 1;
+    const uint32_t rb = __builtin_amdgcn_readfirstlane(blockIdx.y * 4 + threadIdx.y);
+    const uint32_t y_begin = rb * rows_per_wave;
+    const uint32_t x = (blockIdx.x * kWave + threadIdx.x) * N;
+    if (y_begin >= oh || x >= ow) return;
+    const uint32_t y_end = umin(y_begin + rows_per_wave, oh);
+    const uint32_t *base = in + (size_t)blockIdx.z * in_frame_px;
+    uint32_t *dst = out + (size_t)blockIdx.z * out_frame_px + x;
+    uint32_t s[N], o[N];
     if (VEC) {
-        const uint32_t x = (blockIdx.x * kWave + threadIdx.x) * 4;
-        if (x >= ow) return;
-        const uint4 s = *reinterpret_cast<const uint4 *>(sx + x);
-        uint4 o;
-        o.x = src[s.x];
-        o.y = src[s.y];
-        o.z = src[s.z];
-        o.w = src[s.w];
-        *reinterpret_cast<uint4 *>(dst + x) = o;
+        const uint4 v = *reinterpret_cast<const uint4 *>(sx + x);
+        s[0] = v.x; s[N > 1 ? 1 : 0] = v.y; s[N > 2 ? 2 : 0] = v.z; s[N > 3 ? 3 : 0] = v.w;
     } else {
-        const uint32_t x = blockIdx.x * kWave + threadIdx.x;
-        if (x < ow) dst[x] = src[sx[x]];
+        s[0] = sx[x];
+    }
+    uint32_t have = 0xffffffffu;
+    for (uint32_t y = y_begin; y < y_end; ++y) {
+        const uint32_t r = __builtin_amdgcn_readfirstlane(sy[y]);
+        if (r != have) { // wave-uniform
+            const uint32_t *src = base + (size_t)r * iw;
+#pragma unroll
+            for (int i = 0; i < N; ++i) o[i] = src[s[i]];
+            have = r;
+        }
+        if (VEC)
+            *reinterpret_cast<uint4 *>(dst + (size_t)y * ow) = make_uint4(o[0], o[N > 1 ? 1 : 0], o[N > 2 ? 2 : 0], o[N > 3 ? 3 : 0]);
+        else
+            dst[(size_t)y * ow] = o[0];
     }
 }
 
@@ -140,62 +150,49 @@ __global__ __launch_bounds__(256) void k_nearest_x2(
 // Bilinear
 // ---------------------------------------------------------------------------------
 
-// CPU form: Nu_scale/src/upscale/common.rs:221-226.
-__device__ __forceinline__ uint32_t bilerp_cpu(uint32_t p00, uint32_t p10, uint32_t p01, uint32_t p11,
-                                               float dx, float dy)
+// Horizontal lerp of one source row for the lane's N outputs (common.rs:221-222; upscale/mod.rs:255-256
+// for the WGSL form, whose texels are first divided by 255).
+template <int N, bool WGSL>
+__device__ __forceinline__ void bilinear_hrow(const uint32_t *__restrict__ row, const uint32_t (&xi)[N], const float (&xf)[N],
+                                              uint32_t iw, float (&h)[N * 4])
 {
-    const float ndx = 1.0f - dx, ndy = 1.0f - dy;
-    uint32_t o = 0;
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        const float top = ch_f32(p00, c) * ndx + ch_f32(p10, c) * dx;
-        const float bottom = ch_f32(p01, c) * ndx + ch_f32(p11, c) * dx;
-        const float value = top * ndy + bottom * dy;
-        o = pack_trunc_u8(value, c, o);
+    for (int i = 0; i < N; ++i) {
+        const uint32_t p0 = row[xi[i]], p1 = row[umin(xi[i] + 1, iw - 1)];
+        const float dx = xf[i], ndx = 1.0f - dx;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            float a = ch_f32(p0, c), b = ch_f32(p1, c);
+            if (WGSL) {
+                a = div_by_recip(a, 255.0f, 1.0f / 255.0f); // == a / 255.0f for every u8 (checked on the CPU)
+                b = div_by_recip(b, 255.0f, 1.0f / 255.0f);
+            }
+            h[i * 4 + c] = a * ndx + b * dx;
+        }
     }
-    return o;
 }
 
-// WGSL form: nu_scaler_core/src/upscale/mod.rs:220-234, :255-261.
-__device__ __forceinline__ uint32_t bilerp_wgsl(uint32_t p00, uint32_t p10, uint32_t p01, uint32_t p11,
-                                                float dx, float dy)
-{
-    const float ndx = 1.0f - dx, ndy = 1.0f - dy;
-    uint32_t o = 0;
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        const float c00 = ch_f32(p00, c) / 255.0f, c10 = ch_f32(p10, c) / 255.0f;
-        const float c01 = ch_f32(p01, c) / 255.0f, c11 = ch_f32(p11, c) / 255.0f;
-        const float c0 = c00 * ndx + c10 * dx;
-        const float c1 = c01 * ndx + c11 * dx;
-        const float v = c0 * ndy + c1 * dy;
-        // u32(clamp(v, 0, 1) * 255): the saturating pack performs the lower clamp
-        o = pack_trunc_u8(fminf(v, 1.0f) * 255.0f, c, o);
-    }
-    return o;
-}
-
-// Any scale; coordinates come from host-built tables so no division runs here and
-// the index / fraction values are exactly the CPU's.  blockDim = (64, 4).
+// Any scale; coordinates come from host-built tables so no division runs here and the index /
+// fraction values are exactly the CPU's.  blockDim = (64, 4): each wave owns a column segment
+// (4 outputs per lane when VEC) and walks `rows_per_wave` output rows.  The horizontally lerped
+// source rows ("top" / "bottom" of common.rs:221-222) depend only on the source row, so they stay
+// in registers while consecutive output rows map to the same source rows -- on an upscale each is
+// reused for ~scale output rows -- and only the vertical lerp + pack runs per output pixel.
 template <bool VEC, bool WGSL>
 __global__ __launch_bounds__(256) void k_bilinear_table(
     const uint32_t *__restrict__ in, uint32_t *__restrict__ out,
     const uint32_t *__restrict__ x0t, const float *__restrict__ fxt,
     const uint32_t *__restrict__ y0t, const float *__restrict__ fyt,
-    uint32_t iw, uint32_t ih, uint32_t ow, uint32_t oh, size_t in_frame_px, size_t out_frame_px)
+    uint32_t iw, uint32_t ih, uint32_t ow, uint32_t oh, uint32_t rows_per_wave, size_t in_frame_px, size_t out_frame_px)
 {
-    const uint32_t y = __builtin_amdgcn_readfirstlane(blockIdx.y * 4 + threadIdx.y);
-    if (y >= oh) return;
-    const uint32_t y0 = y0t[y];
-    const uint32_t y1 = umin(y0 + 1, ih - 1);
-    const float dy = fyt[y];
-    const uint32_t *base = in + (size_t)blockIdx.z * in_frame_px;
-    const uint32_t *row0 = base + (size_t)y0 * iw;
-    const uint32_t *row1 = base + (size_t)y1 * iw;
-    uint32_t *dst = out + (size_t)blockIdx.z * out_frame_px + (size_t)y * ow;
     constexpr int N = VEC ? 4 : 1;
+    const uint32_t rb = __builtin_amdgcn_readfirstlane(blockIdx.y * 4 + threadIdx.y);
+    const uint32_t y_begin = rb * rows_per_wave;
     const uint32_t x = (blockIdx.x * kWave + threadIdx.x) * N;
-    if (x >= ow) return;
+    if (y_begin >= oh || x >= ow) return;
+    const uint32_t y_end = umin(y_begin + rows_per_wave, oh);
+    const uint32_t *base = in + (size_t)blockIdx.z * in_frame_px;
+    uint32_t *dst = out + (size_t)blockIdx.z * out_frame_px + x;
     uint32_t xi[N];
     float xf[N];
     if (VEC) {
@@ -207,18 +204,49 @@ __global__ __launch_bounds__(256) void k_bilinear_table(
         xi[0] = x0t[x];
         xf[0] = fxt[x];
     }
-    uint32_t o[N];
+    float ht[N * 4], hb[N * 4]; // lerped source rows top_row / bot_row
+    uint32_t top_row = 0xffffffffu, bot_row = 0xffffffffu;
+    for (uint32_t y = y_begin; y < y_end; ++y) {
+        const uint32_t y0 = __builtin_amdgcn_readfirstlane(y0t[y]);
+        const uint32_t y1 = umin(y0 + 1, ih - 1);
+        float dy = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(fyt[y])));
+        asm volatile("" : "+v"(dy)); // VGPR copy: scalar operands halve the VALU issue rate
+        const float ndy = 1.0f - dy;
+        if (y0 != top_row) { // wave-uniform
+            if (y0 == bot_row) {
 #pragma unroll
-    for (int i = 0; i < N; ++i) {
-        const uint32_t x0 = xi[i];
-        const uint32_t x1 = umin(x0 + 1, iw - 1);
-        const uint32_t p00 = row0[x0], p10 = row0[x1], p01 = row1[x0], p11 = row1[x1];
-        o[i] = WGSL ? bilerp_wgsl(p00, p10, p01, p11, xf[i], dy) : bilerp_cpu(p00, p10, p01, p11, xf[i], dy);
+                for (int k = 0; k < N * 4; ++k) ht[k] = hb[k];
+            } else {
+                bilinear_hrow<N, WGSL>(base + (size_t)y0 * iw, xi, xf, iw, ht);
+            }
+            top_row = y0;
+        }
+        if (y1 != bot_row) {
+            if (y1 == y0) {
+#pragma unroll
+                for (int k = 0; k < N * 4; ++k) hb[k] = ht[k];
+            } else {
+                bilinear_hrow<N, WGSL>(base + (size_t)y1 * iw, xi, xf, iw, hb);
+            }
+            bot_row = y1;
+        }
+        uint32_t o[N];
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            uint32_t px = 0;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const float v = ht[i * 4 + c] * ndy + hb[i * 4 + c] * dy;
+                // CPU form: clamp(0,255) as u8; WGSL form: u32(clamp(v,0,1)*255) -- the saturating pack clamps below
+                px = pack_trunc_u8(WGSL ? fminf(v, 1.0f) * 255.0f : v, c, px);
+            }
+            o[i] = px;
+        }
+        if (VEC)
+            *reinterpret_cast<uint4 *>(dst + (size_t)y * ow) = make_uint4(o[0], o[N > 1 ? 1 : 0], o[N > 2 ? 2 : 0], o[N > 3 ? 3 : 0]);
+        else
+            dst[(size_t)y * ow] = o[0];
     }
-    if (VEC)
-        *reinterpret_cast<uint4 *>(dst + x) = make_uint4(o[0], o[N > 1 ? 1 : 0], o[N > 2 ? 2 : 0], o[N > 3 ? 3 : 0]);
-    else
-        dst[x] = o[0];
 }
 
 // floor((a+b)/2) per byte: v_lerp_u8 with rounding bits 0.
@@ -1121,18 +1149,28 @@ static hipError_t for_frame_chunks(const UpscaleLaunch &L, F &&f)
     return hipSuccess;
 }
 
+// Output rows per wave of the row-walking table kernels: tall enough that the lerped / gathered source
+// rows get reused, small enough that the launch still has a few thousand waves.
+static uint32_t rows_per_wave_for(const UpscaleLaunch &L, uint32_t cols_per_wave, uint32_t n_frames)
+{
+    const uint64_t strips = cdiv(L.ow, cols_per_wave);
+    const uint64_t t = (uint64_t)L.oh * strips * n_frames / 8192;
+    return (uint32_t)(t < 8 ? 8 : (t > 64 ? 64 : t));
+}
+
 hipError_t launch_nearest_table(const UpscaleLaunch &L, const DeviceTables &T)
 {
     const bool vec = (L.ow % 4) == 0;
     const size_t ipx = (size_t)L.iw * L.ih, opx = (size_t)L.ow * L.oh;
     return for_frame_chunks(L, [&](const uint8_t *in, uint8_t *out, uint32_t n) {
-        const dim3 block(kWave, 4), grid(cdiv(L.ow, vec ? 256 : 64), cdiv(L.oh, 4), n);
+        const uint32_t rpw = rows_per_wave_for(L, vec ? 256 : 64, n);
+        const dim3 block(kWave, 4), grid(cdiv(L.ow, vec ? 256 : 64), cdiv(cdiv(L.oh, rpw), 4), n);
         auto *i32 = reinterpret_cast<const uint32_t *>(in);
         auto *o32 = reinterpret_cast<uint32_t *>(out);
         if (vec)
-            hipLaunchKernelGGL(k_nearest_table<true>, grid, block, 0, L.stream, i32, o32, T.nn_sx, T.nn_sy, L.iw, L.ow, L.oh, ipx, opx);
+            hipLaunchKernelGGL(k_nearest_table<true>, grid, block, 0, L.stream, i32, o32, T.nn_sx, T.nn_sy, L.iw, L.ow, L.oh, rpw, ipx, opx);
         else
-            hipLaunchKernelGGL(k_nearest_table<false>, grid, block, 0, L.stream, i32, o32, T.nn_sx, T.nn_sy, L.iw, L.ow, L.oh, ipx, opx);
+            hipLaunchKernelGGL(k_nearest_table<false>, grid, block, 0, L.stream, i32, o32, T.nn_sx, T.nn_sy, L.iw, L.ow, L.oh, rpw, ipx, opx);
     });
 }
 
@@ -1151,12 +1189,13 @@ hipError_t launch_bilinear_table(const UpscaleLaunch &L, const DeviceTables &T, 
     const bool vec = (L.ow % 4) == 0;
     const size_t ipx = (size_t)L.iw * L.ih, opx = (size_t)L.ow * L.oh;
     return for_frame_chunks(L, [&](const uint8_t *in, uint8_t *out, uint32_t n) {
-        const dim3 block(kWave, 4), grid(cdiv(L.ow, vec ? 256 : 64), cdiv(L.oh, 4), n);
+        const uint32_t rpw = rows_per_wave_for(L, vec ? 256 : 64, n);
+        const dim3 block(kWave, 4), grid(cdiv(L.ow, vec ? 256 : 64), cdiv(cdiv(L.oh, rpw), 4), n);
         auto *i32 = reinterpret_cast<const uint32_t *>(in);
         auto *o32 = reinterpret_cast<uint32_t *>(out);
 #define NUS_BL(V, W)                                                                                         \
     hipLaunchKernelGGL((k_bilinear_table<V, W>), grid, block, 0, L.stream, i32, o32, T.bl_x0, T.bl_fx, T.bl_y0, \
-                       T.bl_fy, L.iw, L.ih, L.ow, L.oh, ipx, opx)
+                       T.bl_fy, L.iw, L.ih, L.ow, L.oh, rpw, ipx, opx)
         if (vec && wgsl_form) NUS_BL(true, true);
         else if (vec) NUS_BL(true, false);
         else if (wgsl_form) NUS_BL(false, true);
