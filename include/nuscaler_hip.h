@@ -124,7 +124,8 @@ int nus_upscaler_set_device(nus_upscaler *h, int device);
 int nus_upscaler_set_bilinear_variant(nus_upscaler *h, int variant);
 int nus_upscaler_set_lanczos_mode(nus_upscaler *h, int mode);
 /* Tuning / test knobs: "force_general" (0/1, before initialize: never pick an x2
- * fast path), "rows_per_wave" (Lanczos x2 kernel: input rows per wave, 0 = auto). */
+ * fast path), "force_per_pixel" (0/1, before initialize: resize without the LDS row kernel),
+ * "rows_per_wave" (Lanczos x2 kernel: input rows per wave, 0 = auto). */
 int nus_upscaler_set_option(nus_upscaler *h, const char *key, int64_t value);
 
 /* Upscaler::initialize (mod.rs:875-933).  Builds the per-axis tables on the host,

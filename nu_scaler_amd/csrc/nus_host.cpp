@@ -138,6 +138,11 @@ int HipUpscaler::set_option(const char *key, int64_t value)
         force_general_ = value != 0;
         return kOk;
     }
+    if (!strcmp(key, "force_per_pixel")) {
+        if (initialized_) return fail(kInvalidArgument, "force_per_pixel must be set before initialize");
+        force_per_pixel_ = value != 0;
+        return kOk;
+    }
     if (!strcmp(key, "rows_per_wave")) {
         if (value < 0 || value > 4096) return fail(kInvalidArgument, "rows_per_wave out of range");
         rows_per_wave_ = (uint32_t)value;
@@ -210,6 +215,21 @@ void HipUpscaler::choose_variant()
              // same ratio on both axes: the interior weights of the two passes are the same 12 numbers
              memcmp(&wx6_[(size_t)8 * 6], &wy6_[(size_t)8 * 6], 12 * sizeof(float)) == 0;
         variant_ = ok ? Variant::LanczosX2RegWin : Variant::LanczosGeneral;
+        if (!ok && !force_per_pixel_) {
+            // LDS row kernel: needs the widest segment footprint to fit the per-wave LDS row
+            const uint32_t segw = (ow_ % 4) == 0 ? 256 : 64;
+            uint32_t widest = 0;
+            for (uint32_t x0 = 0; x0 < ow_; x0 += segw) {
+                const uint32_t xl = (x0 + segw < ow_ ? x0 + segw : ow_) - 1;
+                const uint32_t span = (uint32_t)(tx_.lz_left[xl] + (int32_t)tx_.lz_ntaps[xl] - tx_.lz_left[x0]);
+                if (span > widest) widest = span;
+            }
+            if (widest <= 640) { // 4 waves x 640 x 16 B = 40 KiB of LDS per block
+                variant_ = Variant::ResizeRows;
+                resize_ncols_max_ = widest;
+                resize_small_taps_ = tx_.lz_max_taps <= 8 && ty_.lz_max_taps <= 8;
+            }
+        }
         break;
     }
     }
@@ -337,6 +357,7 @@ int HipUpscaler::enqueue(const uint8_t *d_in, uint8_t *d_out, uint32_t n_frames,
     case Variant::BilinearTable: e = launch_bilinear_table(L, dt_, wgsl_bilinear_); break;
     case Variant::BilinearX2Int: e = launch_bilinear_x2_int(L); break;
     case Variant::LanczosGeneral: e = launch_lanczos_general(L, dt_, lanczos_exact_, 0); break;
+    case Variant::ResizeRows: e = launch_resize_rows(L, dt_, lanczos_exact_, resize_ncols_max_, resize_small_taps_); break;
     case Variant::LanczosX2RegWin: {
         uint32_t th = rows_per_wave_;
         if (th == 0) {

@@ -130,6 +130,9 @@ private:
     bool wgsl_bilinear_ = false;
     bool lanczos_exact_ = false;
     bool force_general_ = false;
+    bool force_per_pixel_ = false; // resize: never use the LDS row kernel
+    uint32_t resize_ncols_max_ = 0; // LDS row length of the ResizeRows variant
+    bool resize_small_taps_ = false;
     uint32_t rows_per_wave_ = 0; // 0: pick from the batch size
     bool initialized_ = false;
     uint32_t iw_ = 0, ih_ = 0, ow_ = 0, oh_ = 0;

@@ -350,6 +350,134 @@ __global__ __launch_bounds__(256) void k_lanczos_general(
         pack_u8<EXACT>(h3, 3, pack_u8<EXACT>(h2, 2, pack_u8<EXACT>(h1, 1, pack_u8<EXACT>(h0, 0, 0u))));
 }
 
+// Any scale, separable, two passes per output row through an LDS row (the data flow of
+// vertical_sample -> horizontal_sample with only ONE f32 row of the intermediate image alive):
+//   blockDim = (64, 4): the 4 waves own 4 adjacent output column segments (64*N columns each) of the
+//   same block of output rows, so they run the same trip counts and share barriers.
+//   per output row y:  V pass -- the lanes sweep the input columns their segment's taps touch and
+//                      store  V[col] = sum_j wy[y][j] * in[ly[y]+j][col]  (f32 x 4 channels) in LDS;
+//                      H pass -- each lane sums its outputs' taps from LDS (16-B reads), packs, stores.
+// Same f32 operation order as k_lanczos_general (and the CPU algorithm); replaces its nx*ny taps per
+// pixel by nx + ny/scale.  SMALL: every window has <= 8 taps (any upscale), weights stay in VGPRs.
+template <bool EXACT, bool VEC, bool SMALL>
+__global__ __launch_bounds__(256) void k_resize_rows(
+    const uint32_t *__restrict__ in, uint32_t *__restrict__ out,
+    const int32_t *__restrict__ lxt, const uint32_t *__restrict__ nxt, const float *__restrict__ wxt,
+    const int32_t *__restrict__ lyt, const uint32_t *__restrict__ nyt, const float *__restrict__ wyt,
+    uint32_t stride, uint32_t iw, uint32_t ow, uint32_t oh, uint32_t rows_per_block, uint32_t ncols_max,
+    size_t in_frame_px, size_t out_frame_px)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int N = VEC ? 4 : 1;
+    constexpr uint32_t SEGW = kWave * N;
+    float4 *s_v = reinterpret_cast<float4 *>(smem) + (size_t)threadIdx.y * ncols_max;
+    const uint32_t seg = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + threadIdx.y);
+    const uint32_t X0 = seg * SEGW;
+    const bool seg_active = X0 < ow; // wave-uniform; inactive waves only keep the barriers company
+    const uint32_t Xlast = seg_active ? umin(X0 + SEGW, ow) - 1 : 0;
+    const int32_t cmin = seg_active ? lxt[X0] : 0;
+    const int32_t cmax = seg_active ? lxt[Xlast] + (int32_t)nxt[Xlast] : 0;
+    const uint32_t x = X0 + threadIdx.x * N;
+    const bool lane_active = seg_active && x < ow;
+    const uint32_t y_begin = blockIdx.y * rows_per_block;
+    const uint32_t y_end = umin(y_begin + rows_per_block, oh);
+    const uint32_t *base = in + (size_t)blockIdx.z * in_frame_px;
+    uint32_t *dst = out + (size_t)blockIdx.z * out_frame_px + x;
+
+    // horizontal windows of this lane's outputs
+    int32_t hl[N];
+    uint32_t hn[N];
+    float hw[N][8];
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        const uint32_t xo = lane_active ? x + i : 0;
+        hl[i] = lxt[xo] - cmin;
+        hn[i] = nxt[xo];
+        if (SMALL) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) hw[i][k] = wxt[(size_t)xo * stride + k]; // zero padded beyond hn
+        }
+    }
+
+    for (uint32_t y = y_begin; y < y_end; ++y) {
+        const int32_t ly = lyt[y];
+        const uint32_t ny = nyt[y];
+        const float *wy = wyt + (size_t)y * stride;
+        if (seg_active) {
+            float wv[8];
+            if (SMALL) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    wv[j] = wy[j];
+                    asm volatile("" : "+v"(wv[j])); // VGPR copy: scalar operands halve the VALU issue rate
+                }
+            }
+            const uint32_t *src = base + (size_t)ly * iw;
+            for (int32_t col = cmin + (int32_t)threadIdx.x; col < cmax; col += kWave) {
+                float v0 = 0.0f, v1 = 0.0f, v2 = 0.0f, v3 = 0.0f;
+                if (SMALL) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        if ((uint32_t)j < ny) { // wave-uniform
+                            const uint32_t p = src[(size_t)j * iw + col];
+                            v0 = mac<EXACT>(v0, ch_f32(p, 0), wv[j]);
+                            v1 = mac<EXACT>(v1, ch_f32(p, 1), wv[j]);
+                            v2 = mac<EXACT>(v2, ch_f32(p, 2), wv[j]);
+                            v3 = mac<EXACT>(v3, ch_f32(p, 3), wv[j]);
+                        }
+                    }
+                } else {
+                    for (uint32_t j = 0; j < ny; ++j) {
+                        const uint32_t p = src[(size_t)j * iw + col];
+                        const float w = wy[j];
+                        v0 = mac<EXACT>(v0, ch_f32(p, 0), w);
+                        v1 = mac<EXACT>(v1, ch_f32(p, 1), w);
+                        v2 = mac<EXACT>(v2, ch_f32(p, 2), w);
+                        v3 = mac<EXACT>(v3, ch_f32(p, 3), w);
+                    }
+                }
+                s_v[col - cmin] = make_float4(v0, v1, v2, v3);
+            }
+        }
+        __syncthreads();
+        if (lane_active) {
+            uint32_t o[N];
+#pragma unroll
+            for (int i = 0; i < N; ++i) {
+                float h0 = 0.0f, h1 = 0.0f, h2 = 0.0f, h3 = 0.0f;
+                if (SMALL) {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        if ((uint32_t)k < hn[i]) {
+                            const float4 v = s_v[hl[i] + k];
+                            h0 = mac<EXACT>(h0, v.x, hw[i][k]);
+                            h1 = mac<EXACT>(h1, v.y, hw[i][k]);
+                            h2 = mac<EXACT>(h2, v.z, hw[i][k]);
+                            h3 = mac<EXACT>(h3, v.w, hw[i][k]);
+                        }
+                    }
+                } else {
+                    const float *wx = wxt + (size_t)(x + i) * stride;
+                    for (uint32_t k = 0; k < hn[i]; ++k) {
+                        const float4 v = s_v[hl[i] + (int32_t)k];
+                        const float w = wx[k];
+                        h0 = mac<EXACT>(h0, v.x, w);
+                        h1 = mac<EXACT>(h1, v.y, w);
+                        h2 = mac<EXACT>(h2, v.z, w);
+                        h3 = mac<EXACT>(h3, v.w, w);
+                    }
+                }
+                o[i] = pack_u8<EXACT>(h3, 3, pack_u8<EXACT>(h2, 2, pack_u8<EXACT>(h1, 1, pack_u8<EXACT>(h0, 0, 0u))));
+            }
+            if (VEC)
+                *reinterpret_cast<uint4 *>(dst + (size_t)y * ow) = make_uint4(o[0], o[N > 1 ? 1 : 0], o[N > 2 ? 2 : 0], o[N > 3 ? 3 : 0]);
+            else
+                dst[(size_t)y * ow] = o[0];
+        }
+        __syncthreads(); // the next row's V pass overwrites s_v
+    }
+}
+
 struct LanczosX2Args {
     const uint8_t *in;
     const uint8_t *in_b; // BLEND != 0: second frame of each pair
@@ -1125,6 +1253,7 @@ const char *variant_name(Variant v)
     case Variant::BilinearTable: return "bilinear_table_f32";
     case Variant::BilinearX2Int: return "bilinear_x2_packed_u8";
     case Variant::LanczosGeneral: return "lanczos3_general";
+    case Variant::ResizeRows: return "resize_rows_lds";
     case Variant::LanczosX2RegWin: return "lanczos3_x2_regwin";
     }
     return "?";
@@ -1233,6 +1362,33 @@ hipError_t launch_lanczos_general(const UpscaleLaunch &L, const DeviceTables &T,
         else
             hipLaunchKernelGGL(k_lanczos_general<false>, grid, block, 0, L.stream, i32, o32, T.lz_lx, T.lz_nx, T.lz_wx,
                                T.lz_ly, T.lz_ny, T.lz_wy, T.lz_stride, L.iw, L.ow, L.oh, ncols, split, gap, ipx, opx);
+    });
+}
+
+hipError_t launch_resize_rows(const UpscaleLaunch &L, const DeviceTables &T, bool exact, uint32_t ncols_max, bool small_taps)
+{
+    const bool vec = (L.ow % 4) == 0;
+    const size_t ipx = (size_t)L.iw * L.ih, opx = (size_t)L.ow * L.oh;
+    const uint32_t segw = vec ? 256 : 64;
+    const size_t lds = (size_t)4 * ncols_max * sizeof(float4);
+    return for_frame_chunks(L, [&](const uint8_t *in, uint8_t *out, uint32_t n) {
+        const uint64_t blocks_x = cdiv(cdiv(L.ow, segw), 4);
+        uint64_t rpb = (uint64_t)L.oh * blocks_x * n / 4096; // a few thousand blocks per launch
+        rpb = rpb < 4 ? 4 : (rpb > 32 ? 32 : rpb);
+        const dim3 block(kWave, 4), grid((uint32_t)blocks_x, cdiv(L.oh, (uint32_t)rpb), n);
+        auto *i32 = reinterpret_cast<const uint32_t *>(in);
+        auto *o32 = reinterpret_cast<uint32_t *>(out);
+#define NUS_RR(E, V, S)                                                                                             \
+    hipLaunchKernelGGL((k_resize_rows<E, V, S>), grid, block, lds, L.stream, i32, o32, T.lz_lx, T.lz_nx, T.lz_wx, T.lz_ly, \
+                       T.lz_ny, T.lz_wy, T.lz_stride, L.iw, L.ow, L.oh, (uint32_t)rpb, ncols_max, ipx, opx)
+        if (exact) {
+            if (vec) { if (small_taps) NUS_RR(true, true, true); else NUS_RR(true, true, false); }
+            else { if (small_taps) NUS_RR(true, false, true); else NUS_RR(true, false, false); }
+        } else {
+            if (vec) { if (small_taps) NUS_RR(false, true, true); else NUS_RR(false, true, false); }
+            else { if (small_taps) NUS_RR(false, false, true); else NUS_RR(false, false, false); }
+        }
+#undef NUS_RR
     });
 }
 

@@ -47,7 +47,8 @@ enum class Variant : int {
     NearestX2,        // exact x2, 16-B loads/stores
     BilinearTable,    // any scale, f32, CPU or WGSL arithmetic
     BilinearX2Int,    // exact x2, CPU arithmetic done in packed-u8 integer ops
-    LanczosGeneral,   // any scale, direct separable evaluation per output pixel
+    LanczosGeneral,   // any scale, direct separable evaluation per output pixel (fallback)
+    ResizeRows,       // any scale, separable: V pass into an LDS row, H pass out of it
     LanczosX2RegWin,  // exact x2, register sliding window + wave shifts
 };
 
@@ -60,6 +61,10 @@ hipError_t launch_bilinear_x2_int(const UpscaleLaunch &L);
 // edge_only: evaluate only the first and last `edge_cols` output columns.
 hipError_t launch_lanczos_general(const UpscaleLaunch &L, const DeviceTables &T, bool exact,
                                   uint32_t edge_cols);
+// ncols_max: widest input-column footprint of a 64*N-column output segment (LDS row length);
+// small_taps: every tap window has <= 8 taps.
+hipError_t launch_resize_rows(const UpscaleLaunch &L, const DeviceTables &T, bool exact, uint32_t ncols_max,
+                              bool small_taps);
 // main x2 kernel only: the first / last kLanczosX2EdgeCols output columns are NOT written;
 // follow it with launch_lanczos_x2_edges(L, T, exact).
 hipError_t launch_lanczos_x2(const UpscaleLaunch &L, const DeviceTables &T, bool exact,

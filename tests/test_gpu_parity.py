@@ -89,7 +89,7 @@ def test_lanczos_x2(nsc, oracle_mod, size):
     want = oracle_mod.lanczos3(img, 2 * w, 2 * h)
     out, u = _up(nsc, "lanczos3", img, 2 * w, 2 * h)
     # the register-window kernel needs >= 16 rows and columns; smaller frames take the general one
-    assert u.kernel_variant == ("lanczos3_x2_regwin" if w >= 16 and h >= 16 else "lanczos3_general")
+    assert u.kernel_variant == ("lanczos3_x2_regwin" if w >= 16 and h >= 16 else "resize_rows_lds")
     d = np.abs(out.astype(np.int16) - want.astype(np.int16))
     assert d.max() <= 1, f"FMA mode outside +-1 LSB (max {d.max()})"
     assert (d > 0).mean() < 1e-3
@@ -98,7 +98,9 @@ def test_lanczos_x2(nsc, oracle_mod, size):
     assert np.array_equal(out_e, want)
     # the general kernel agrees with the fast one (same weights, same op order)
     out_g, ug = _up(nsc, "lanczos3", img, 2 * w, 2 * h, lanczos_mode="exact", options={"force_general": 1})
-    assert ug.kernel_variant == "lanczos3_general" and np.array_equal(out_g, want)
+    assert ug.kernel_variant == "resize_rows_lds" and np.array_equal(out_g, want)
+    out_p, up_ = _up(nsc, "lanczos3", img, 2 * w, 2 * h, lanczos_mode="exact", options={"force_general": 1, "force_per_pixel": 1})
+    assert up_.kernel_variant == "lanczos3_general" and np.array_equal(out_p, want)
     # every rows-per-wave split produces the same image
     for th in (1, 5, 7, 8, 23):
         out_t, _ = _up(nsc, "lanczos3", img, 2 * w, 2 * h, lanczos_mode="exact", options={"rows_per_wave": th})
@@ -127,7 +129,7 @@ def test_bicubic_and_triangle_resize(nsc, oracle_mod, alg, filt, dims):
     want = oracle_mod.resize(img, ow, oh, filt)
     out, u = _up(nsc, alg, img, ow, oh)
     x2 = (ow, oh) == (2 * w, 2 * h) and w % 4 == 0 and w >= 16 and h >= 16
-    assert u.kernel_variant == ("lanczos3_x2_regwin" if x2 else "lanczos3_general")
+    assert u.kernel_variant == ("lanczos3_x2_regwin" if x2 else "resize_rows_lds")
     assert _maxdiff(out, want) <= 1
     out_e, _ = _up(nsc, alg, img, ow, oh, lanczos_mode="exact")
     assert np.array_equal(out_e, want)
