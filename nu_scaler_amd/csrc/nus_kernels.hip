@@ -353,7 +353,7 @@ __global__ __launch_bounds__(256) void k_lanczos_general(
 // Any scale, separable, two passes per output row through an LDS row (the data flow of
 // vertical_sample -> horizontal_sample with only ONE f32 row of the intermediate image alive):
 //   blockDim = (64, 4): the 4 waves own 4 adjacent output column segments (64*N columns each) of the
-//   same block of output rows, so they run the same trip counts and share barriers.
+//   same block of output rows; each wave has its own LDS row and never reads another wave's.
 //   per output row y:  V pass -- the lanes sweep the input columns their segment's taps touch and
 //                      store  V[col] = sum_j wy[y][j] * in[ly[y]+j][col]  (f32 x 4 channels) in LDS;
 //                      H pass -- each lane sums its outputs' taps from LDS (16-B reads), packs, stores.
@@ -373,12 +373,12 @@ __global__ __launch_bounds__(256) void k_resize_rows(
     float4 *s_v = reinterpret_cast<float4 *>(smem) + (size_t)threadIdx.y * ncols_max;
     const uint32_t seg = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + threadIdx.y);
     const uint32_t X0 = seg * SEGW;
-    const bool seg_active = X0 < ow; // wave-uniform; inactive waves only keep the barriers company
-    const uint32_t Xlast = seg_active ? umin(X0 + SEGW, ow) - 1 : 0;
-    const int32_t cmin = seg_active ? lxt[X0] : 0;
-    const int32_t cmax = seg_active ? lxt[Xlast] + (int32_t)nxt[Xlast] : 0;
+    if (X0 >= ow) return; // whole wave; no workgroup barriers below
+    const uint32_t Xlast = umin(X0 + SEGW, ow) - 1;
+    const int32_t cmin = lxt[X0];
+    const int32_t cmax = lxt[Xlast] + (int32_t)nxt[Xlast];
     const uint32_t x = X0 + threadIdx.x * N;
-    const bool lane_active = seg_active && x < ow;
+    const bool lane_active = x < ow;
     const uint32_t y_begin = blockIdx.y * rows_per_block;
     const uint32_t y_end = umin(y_begin + rows_per_block, oh);
     const uint32_t *base = in + (size_t)blockIdx.z * in_frame_px;
@@ -403,7 +403,7 @@ __global__ __launch_bounds__(256) void k_resize_rows(
         const int32_t ly = lyt[y];
         const uint32_t ny = nyt[y];
         const float *wy = wyt + (size_t)y * stride;
-        if (seg_active) {
+        {
             float wv[8];
             if (SMALL) {
 #pragma unroll
@@ -413,33 +413,58 @@ __global__ __launch_bounds__(256) void k_resize_rows(
                 }
             }
             const uint32_t *src = base + (size_t)ly * iw;
-            for (int32_t col = cmin + (int32_t)threadIdx.x; col < cmax; col += kWave) {
-                float v0 = 0.0f, v1 = 0.0f, v2 = 0.0f, v3 = 0.0f;
+            // V pass: 4 input columns per lane per sweep; all tap rows of a group are requested before
+            // the first is consumed (16-B loads where the group lies inside the row)
+            for (int32_t col = cmin + 4 * (int32_t)threadIdx.x; col < cmax; col += 4 * kWave) {
+                float v[4][4] = {{0.0f}};
+                const bool whole = col + 4 <= (int32_t)iw; // else: last group of the row, per-pixel loads
                 if (SMALL) {
+                    uint32_t p[8][4];
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
                         if ((uint32_t)j < ny) { // wave-uniform
-                            const uint32_t p = src[(size_t)j * iw + col];
-                            v0 = mac<EXACT>(v0, ch_f32(p, 0), wv[j]);
-                            v1 = mac<EXACT>(v1, ch_f32(p, 1), wv[j]);
-                            v2 = mac<EXACT>(v2, ch_f32(p, 2), wv[j]);
-                            v3 = mac<EXACT>(v3, ch_f32(p, 3), wv[j]);
+                            const uint32_t *q = src + (size_t)j * iw + col;
+                            if (whole) {
+                                // dword-aligned 16-B load (global loads need no 16-B alignment)
+                                const uint4 t = *reinterpret_cast<const __attribute__((aligned(4))) uint4 *>(q);
+                                p[j][0] = t.x; p[j][1] = t.y; p[j][2] = t.z; p[j][3] = t.w;
+                            } else {
+#pragma unroll
+                                for (int m = 0; m < 4; ++m) p[j][m] = col + m < (int32_t)iw ? q[m] : 0u;
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        if ((uint32_t)j < ny) {
+#pragma unroll
+                            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                                for (int c = 0; c < 4; ++c) v[m][c] = mac<EXACT>(v[m][c], ch_f32(p[j][m], c), wv[j]);
                         }
                     }
                 } else {
                     for (uint32_t j = 0; j < ny; ++j) {
-                        const uint32_t p = src[(size_t)j * iw + col];
+                        const uint32_t *q = src + (size_t)j * iw + col;
                         const float w = wy[j];
-                        v0 = mac<EXACT>(v0, ch_f32(p, 0), w);
-                        v1 = mac<EXACT>(v1, ch_f32(p, 1), w);
-                        v2 = mac<EXACT>(v2, ch_f32(p, 2), w);
-                        v3 = mac<EXACT>(v3, ch_f32(p, 3), w);
+#pragma unroll
+                        for (int m = 0; m < 4; ++m) {
+                            const uint32_t px = col + m < (int32_t)iw ? q[m] : 0u;
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) v[m][c] = mac<EXACT>(v[m][c], ch_f32(px, c), w);
+                        }
                     }
                 }
-                s_v[col - cmin] = make_float4(v0, v1, v2, v3);
+#pragma unroll
+                for (int m = 0; m < 4; ++m)
+                    if (col + m < cmax) s_v[col - cmin + m] = make_float4(v[m][0], v[m][1], v[m][2], v[m][3]);
             }
         }
-        __syncthreads();
+        // A wave only ever reads the LDS row it wrote itself, and the LDS executes one wave's
+        // instructions in order: no workgroup barrier, just keep the compiler from reordering.
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         if (lane_active) {
             uint32_t o[N];
 #pragma unroll
@@ -474,7 +499,8 @@ __global__ __launch_bounds__(256) void k_resize_rows(
             else
                 dst[(size_t)y * ow] = o[0];
         }
-        __syncthreads(); // the next row's V pass overwrites s_v
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); // the next row's V pass overwrites s_v
+        __builtin_amdgcn_wave_barrier();
     }
 }
 
