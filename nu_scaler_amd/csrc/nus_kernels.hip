@@ -370,7 +370,7 @@ __global__ __launch_bounds__(256) void k_resize_rows(
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int N = VEC ? 4 : 1;
     constexpr uint32_t SEGW = kWave * N;
-    float4 *s_v = reinterpret_cast<float4 *>(smem) + (size_t)threadIdx.y * ncols_max;
+    float4 *s_v = reinterpret_cast<float4 *>(smem) + (size_t)threadIdx.y * (ncols_max + 8);
     const uint32_t seg = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + threadIdx.y);
     const uint32_t X0 = seg * SEGW;
     if (X0 >= ow) return; // whole wave; no workgroup barriers below
@@ -384,6 +384,7 @@ __global__ __launch_bounds__(256) void k_resize_rows(
     const uint32_t *base = in + (size_t)blockIdx.z * in_frame_px;
     uint32_t *dst = out + (size_t)blockIdx.z * out_frame_px + x;
 
+    if (threadIdx.x < 8) s_v[(cmax - cmin) + threadIdx.x] = make_float4(0.0f, 0.0f, 0.0f, 0.0f); // slack, see the H pass
     // horizontal windows of this lane's outputs
     int32_t hl[N];
     uint32_t hn[N];
@@ -471,15 +472,15 @@ __global__ __launch_bounds__(256) void k_resize_rows(
             for (int i = 0; i < N; ++i) {
                 float h0 = 0.0f, h1 = 0.0f, h2 = 0.0f, h3 = 0.0f;
                 if (SMALL) {
+                    // all 8 slots, no per-lane branch: slots beyond the window carry weight 0 and read
+                    // finite values (the row has 8 zeroed slack entries), so they add +-0
 #pragma unroll
                     for (int k = 0; k < 8; ++k) {
-                        if ((uint32_t)k < hn[i]) {
-                            const float4 v = s_v[hl[i] + k];
-                            h0 = mac<EXACT>(h0, v.x, hw[i][k]);
-                            h1 = mac<EXACT>(h1, v.y, hw[i][k]);
-                            h2 = mac<EXACT>(h2, v.z, hw[i][k]);
-                            h3 = mac<EXACT>(h3, v.w, hw[i][k]);
-                        }
+                        const float4 v = s_v[hl[i] + k];
+                        h0 = mac<EXACT>(h0, v.x, hw[i][k]);
+                        h1 = mac<EXACT>(h1, v.y, hw[i][k]);
+                        h2 = mac<EXACT>(h2, v.z, hw[i][k]);
+                        h3 = mac<EXACT>(h3, v.w, hw[i][k]);
                     }
                 } else {
                     const float *wx = wxt + (size_t)(x + i) * stride;
@@ -1396,7 +1397,7 @@ hipError_t launch_resize_rows(const UpscaleLaunch &L, const DeviceTables &T, boo
     const bool vec = (L.ow % 4) == 0;
     const size_t ipx = (size_t)L.iw * L.ih, opx = (size_t)L.ow * L.oh;
     const uint32_t segw = vec ? 256 : 64;
-    const size_t lds = (size_t)4 * ncols_max * sizeof(float4);
+    const size_t lds = (size_t)4 * (ncols_max + 8) * sizeof(float4);
     return for_frame_chunks(L, [&](const uint8_t *in, uint8_t *out, uint32_t n) {
         const uint64_t blocks_x = cdiv(cdiv(L.ow, segw), 4);
         uint64_t rpb = (uint64_t)L.oh * blocks_x * n / 4096; // a few thousand blocks per launch
