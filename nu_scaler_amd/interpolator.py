@@ -65,7 +65,7 @@ class WgpuFrameInterpolator:
                                               float(time_t), oaddr, expected)
         del oarr, ka, kb, kf
         self._raise(st)
-        return bytes(out)
+        return out
 
     def interpolate_device(self, d_a: int, a_stride: int, d_b: int, b_stride: int, d_flow: int, width: int,
                            height: int, time_t: float, d_out: int, n_pairs: int = 1, stream: int = 0) -> None:

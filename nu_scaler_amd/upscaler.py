@@ -47,12 +47,13 @@ def _as_buffer(data):
 
 
 def _out_buffer(size: int):
-    """Fresh writable output buffer: (bytearray, ctypes view keeping it pinned, address)."""
-    out = bytearray(size)
+    """Fresh output buffer the C side writes into: (bytes, keepalive, address).  The bytes object is
+    allocated zero-filled (calloc) and filled in place before anyone else can see it -- what pyo3's
+    PyBytes::new does with one copy less -- so returning it costs no second 33 MB copy."""
+    out = bytes(size)
     if size == 0:
         return out, None, None
-    arr = (ctypes.c_ubyte * size).from_buffer(out)
-    return out, arr, ctypes.addressof(arr)
+    return out, out, ctypes.cast(ctypes.c_char_p(out), ctypes.c_void_p).value
 
 
 class PyWgpuUpscaler:
@@ -103,7 +104,7 @@ class PyWgpuUpscaler:
         out, oarr, oaddr = _out_buffer(out_size)
         self._check(self._lib.nus_upscaler_upscale(self._h, addr, n, oaddr, out_size))
         del oarr, keep
-        return bytes(out)
+        return out
 
     def upscale_into(self, input, out) -> None:
         """Zero-copy variant: writes into a caller-provided writable buffer."""
@@ -127,7 +128,7 @@ class PyWgpuUpscaler:
         self._check(self._lib.nus_upscaler_upscale_batch(self._h, ins_c, lens_c, n, outs_c, out_size))
         outs = [t[0] for t in triples]
         del triples
-        return [bytes(o) for o in outs]
+        return outs
 
     # -- device-resident path (not in the reference; used by the frame stream + bench)
     def upscale_device(self, d_in: int, d_out: int, n_frames: int = 1, stream: int = 0) -> None:

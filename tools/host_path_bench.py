@@ -28,10 +28,16 @@ def main():
             u.upscale_into(frames[i % len(frames)], out)
         dt = (time.perf_counter() - t0) / n
         t0 = time.perf_counter()
+        for i in range(6):
+            o = u.upscale(frames[i])  # returns a fresh bytes object, like the reference's PyBytes
+        dtp = (time.perf_counter() - t0) / 6
+        del o
+        t0 = time.perf_counter()
         outs = u.upscale_batch(frames)
         dtb = (time.perf_counter() - t0) / len(frames)
+        del outs
         print(f"{alg:9s} upscale(): {dt*1e3:7.3f} ms/frame = {1/dt:7.1f} frames/s, {(u.input_size+u.output_size)/dt/1e9:6.2f} GB/s host<->device;"
-              f" upscale_batch(12): {dtb*1e3:7.3f} ms/frame = {1/dtb:7.1f} frames/s; kernel {u.get_last_gpu_duration_ms()*1e3:7.1f} us")
+              f" upscale()->bytes {dtp*1e3:6.2f} ms; upscale_batch(12): {dtb*1e3:7.3f} ms/frame = {1/dtb:7.1f} frames/s; kernel {u.get_last_gpu_duration_ms()*1e3:7.1f} us")
     it = nsc.WgpuFrameInterpolator()
     it.interpolate_py(frames[0], frames[1], w, h)
     t0 = time.perf_counter()
