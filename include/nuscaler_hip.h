@@ -52,7 +52,12 @@ typedef enum nus_algorithm {
     /* "next" row: the other image-0.24.9 filters the legacy
      * BasicUpscaler delegates to (Nu_scale/src/upscale/common.rs:233-260) */
     NUS_ALG_BICUBIC = 3,  /* FilterType::CatmullRom (UpscalingAlgorithm::Bicubic) */
-    NUS_ALG_TRIANGLE = 4  /* FilterType::Triangle (what Lanczos2 / Mitchell map to there) */
+    NUS_ALG_TRIANGLE = 4, /* FilterType::Triangle (what Lanczos2 / Mitchell map to there) */
+    /* same row: the FSR1-style shader pair the reference keeps but never dispatches
+     * (nu_scaler_core/src/upscale/fsr.rs:24-169 EASU, :173-260 RCAS).  PARITY UNPINNED. */
+    NUS_ALG_FSR1 = 5,     /* EASU then RCAS, fused (the EASU image stays in LDS) */
+    NUS_ALG_FSR_EASU = 6, /* EASU alone */
+    NUS_ALG_FSR_RCAS = 7  /* RCAS alone: output size must equal input size */
 } nus_algorithm;
 
 /* UpscalingQuality (mod.rs:37-46), same order.  Quality never changes the arithmetic
@@ -127,6 +132,12 @@ int nus_upscaler_set_lanczos_mode(nus_upscaler *h, int mode);
  * fast path), "force_per_pixel" (0/1, before initialize: resize without the LDS row kernel),
  * "rows_per_wave" (Lanczos x2 kernel: input rows per wave, 0 = auto). */
 int nus_upscaler_set_option(nus_upscaler *h, const char *key, int64_t value);
+/* FSR1-style passes: the `sharpness` uniform of each shader (fsr.rs:35, :178), <= 1.  A negative
+ * value keeps the default: EASU 0 (build-defined; the reference never assigns it), RCAS by quality
+ * as the reference's CPU FSR path does -- Ultra 0.8, Quality 0.7, Balanced 0.6, else 0.5
+ * (Nu_scale/src/upscale/fsr3.rs:231-236).  May be called at any time. */
+int nus_upscaler_set_sharpness(nus_upscaler *h, float easu, float rcas);
+int nus_upscaler_get_sharpness(const nus_upscaler *h, float *easu, float *rcas);
 
 /* Upscaler::initialize (mod.rs:875-933).  Builds the per-axis tables on the host,
  * allocates device + pinned staging buffers.  Re-initialising with new dimensions

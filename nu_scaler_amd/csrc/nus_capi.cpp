@@ -70,7 +70,7 @@ const char *nus_status_string(int status)
 
 nus_upscaler *nus_upscaler_create(int algorithm, int quality)
 {
-    if (algorithm < NUS_ALG_NEAREST || algorithm > NUS_ALG_TRIANGLE || quality < NUS_QUALITY_ULTRA_PERFORMANCE ||
+    if (algorithm < NUS_ALG_NEAREST || algorithm > NUS_ALG_FSR_RCAS || quality < NUS_QUALITY_ULTRA_PERFORMANCE ||
         quality > NUS_QUALITY_NATIVE) {
         nus::set_thread_error("nus_upscaler_create: unknown algorithm or quality");
         return nullptr;
@@ -98,6 +98,17 @@ int nus_upscaler_set_lanczos_mode(nus_upscaler *h, int m) { return h ? h->impl.s
 int nus_upscaler_set_option(nus_upscaler *h, const char *key, int64_t value)
 {
     return h ? h->impl.set_option(key, value) : null_handle();
+}
+int nus_upscaler_set_sharpness(nus_upscaler *h, float easu, float rcas)
+{
+    return h ? h->impl.set_sharpness(easu, rcas) : null_handle();
+}
+int nus_upscaler_get_sharpness(const nus_upscaler *h, float *easu, float *rcas)
+{
+    if (!h) return null_handle();
+    if (easu) *easu = h->impl.easu_sharpness();
+    if (rcas) *rcas = h->impl.rcas_sharpness();
+    return NUS_OK;
 }
 
 int nus_upscaler_initialize(nus_upscaler *h, uint32_t in_w, uint32_t in_h, uint32_t out_w, uint32_t out_h)

@@ -83,6 +83,9 @@ const char *HipUpscaler::name() const
     case Algorithm::Lanczos3: return "HipLanczos3Upscaler";
     case Algorithm::Bicubic: return "HipBicubicUpscaler";
     case Algorithm::Triangle: return "HipTriangleUpscaler";
+    case Algorithm::Fsr1: return "HipFsr1Upscaler";
+    case Algorithm::FsrEasu: return "HipFsrEasuUpscaler";
+    case Algorithm::FsrRcas: return "HipFsrRcasUpscaler";
     default: return "WgpuNearestUpscaler";
     }
 }
@@ -99,7 +102,9 @@ ResizeFilter HipUpscaler::resize_filter() const
 int HipUpscaler::set_quality(Quality q)
 {
     std::lock_guard<std::mutex> lk(mu_);
-    quality_ = q; // quality never changes the arithmetic (upscale/mod.rs:1072-1077)
+    // quality never changes the arithmetic of the reference's own algorithms
+    // (upscale/mod.rs:1072-1077); the FSR1-style passes take their default sharpness from it
+    quality_ = q;
     return kOk;
 }
 
@@ -149,6 +154,32 @@ int HipUpscaler::set_option(const char *key, int64_t value)
         return kOk;
     }
     return fail(kInvalidArgument, fmt("unknown option '%s'", key));
+}
+
+int HipUpscaler::set_sharpness(float easu, float rcas)
+{
+    std::lock_guard<std::mutex> lk(mu_);
+    if (easu > 1.0f || rcas > 1.0f || easu != easu || rcas != rcas)
+        return fail(kInvalidArgument, "sharpness must be <= 1 (negative: quality default)");
+    easu_sharp_ = easu;
+    rcas_sharp_ = rcas;
+    return kOk;
+}
+
+// EASU's "quality-dependent sharpness factor" (fsr.rs:35) is never given a value by the
+// reference; build-defined default 0 (no pull toward the centre texel).
+float HipUpscaler::easu_sharpness() const { return easu_sharp_ >= 0.0f ? easu_sharp_ : 0.0f; }
+
+// Default per quality as the reference's CPU FSR path sets it (Nu_scale/src/upscale/fsr3.rs:231-236).
+float HipUpscaler::rcas_sharpness() const
+{
+    if (rcas_sharp_ >= 0.0f) return rcas_sharp_;
+    switch (quality_) {
+    case Quality::Ultra: return 0.8f;
+    case Quality::Quality: return 0.7f;
+    case Quality::Balanced: return 0.6f;
+    default: return 0.5f;
+    }
 }
 
 int HipUpscaler::ensure_device()
@@ -232,6 +263,9 @@ void HipUpscaler::choose_variant()
         }
         break;
     }
+    case Algorithm::Fsr1: variant_ = Variant::Fsr1Fused; break;
+    case Algorithm::FsrEasu: variant_ = Variant::FsrEasu; break;
+    case Algorithm::FsrRcas: variant_ = Variant::FsrRcas; break;
     }
 }
 
@@ -284,6 +318,7 @@ int HipUpscaler::upload_tables()
             }
         }
         break;
+    default: break; // FSR1-style passes compute their coordinates in the kernel, as the shaders do
     }
 #undef UP
     return rc;
@@ -309,6 +344,8 @@ int HipUpscaler::initialize(uint32_t in_w, uint32_t in_h, uint32_t out_w, uint32
     build_axis_tables(ih_, oh_, wgsl_bilinear_, ty_, resize_filter());
     if (is_resize() && (tx_.lz_max_taps < 0 || ty_.lz_max_taps < 0))
         return fail(kUnsupported, fmt("Lanczos-3 window exceeds %u taps for %ux%u -> %ux%u", kResizeMaxTaps, iw_, ih_, ow_, oh_));
+    if (algorithm_ == Algorithm::FsrRcas && (iw_ != ow_ || ih_ != oh_))
+        return fail(kInvalidArgument, "initialize: RCAS alone is a same-size pass (output size must equal input size)");
     choose_variant();
     rc = upload_tables();
     if (rc != kOk) return rc;
@@ -358,6 +395,9 @@ int HipUpscaler::enqueue(const uint8_t *d_in, uint8_t *d_out, uint32_t n_frames,
     case Variant::BilinearX2Int: e = launch_bilinear_x2_int(L); break;
     case Variant::LanczosGeneral: e = launch_lanczos_general(L, dt_, lanczos_exact_, 0); break;
     case Variant::ResizeRows: e = launch_resize_rows(L, dt_, lanczos_exact_, resize_ncols_max_, resize_small_taps_); break;
+    case Variant::FsrEasu: e = launch_fsr1(L, 0, easu_sharpness(), rcas_sharpness()); break;
+    case Variant::FsrRcas: e = launch_fsr1(L, 1, easu_sharpness(), rcas_sharpness()); break;
+    case Variant::Fsr1Fused: e = launch_fsr1(L, 2, easu_sharpness(), rcas_sharpness()); break;
     case Variant::LanczosX2RegWin: {
         uint32_t th = rows_per_wave_;
         if (th == 0) {

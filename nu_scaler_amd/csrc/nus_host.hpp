@@ -35,7 +35,7 @@ enum Status : int {
     kOutOfMemory = -7,
 };
 
-enum class Algorithm : int { Nearest = 0, Bilinear = 1, Lanczos3 = 2, Bicubic = 3, Triangle = 4 };
+enum class Algorithm : int { Nearest = 0, Bilinear = 1, Lanczos3 = 2, Bicubic = 3, Triangle = 4, Fsr1 = 5, FsrEasu = 6, FsrRcas = 7 };
 enum class Quality : int { UltraPerformance = 0, Ultra, Quality, Balanced, Performance, Native };
 enum class Technology : int { None = 0, FSR, DLSS, Wgpu, Fallback };
 
@@ -82,6 +82,10 @@ public:
     int set_bilinear_variant(int variant);
     int set_lanczos_mode(int mode);
     int set_option(const char *key, int64_t value);
+    // FSR1-style passes: negative value = keep the quality-derived default.
+    int set_sharpness(float easu, float rcas);
+    float easu_sharpness() const;
+    float rcas_sharpness() const;
 
     Algorithm algorithm() const { return algorithm_; }
     bool initialized() const { return initialized_; }
@@ -113,6 +117,7 @@ private:
     int ensure_device();
     void release();
     int upload_tables();
+    bool is_fsr() const { return algorithm_ == Algorithm::Fsr1 || algorithm_ == Algorithm::FsrEasu || algorithm_ == Algorithm::FsrRcas; }
     bool is_resize() const { return algorithm_ == Algorithm::Lanczos3 || algorithm_ == Algorithm::Bicubic || algorithm_ == Algorithm::Triangle; }
     ResizeFilter resize_filter() const;
     void choose_variant();
@@ -134,6 +139,7 @@ private:
     uint32_t resize_ncols_max_ = 0; // LDS row length of the ResizeRows variant
     bool resize_small_taps_ = false;
     uint32_t rows_per_wave_ = 0; // 0: pick from the batch size
+    float easu_sharp_ = -1.0f, rcas_sharp_ = -1.0f; // < 0: derive from quality_
     bool initialized_ = false;
     uint32_t iw_ = 0, ih_ = 0, ow_ = 0, oh_ = 0;
     Variant variant_ = Variant::NearestTable;

@@ -1272,6 +1272,168 @@ constexpr uint32_t kMaxGridZ = 65535;
 
 } // namespace
 
+// ---------------------------------------------------------------------------------
+// FSR1-style EASU + RCAS: nu_scaler_core/src/upscale/fsr.rs:24-260
+// ---------------------------------------------------------------------------------
+// One kernel, three modes.  Stage 1 fills an LDS tile of packed RGBA8 pixels -- EASU evaluations
+// (modes Easu, Fused) or plain loads (mode Rcas) -- with a 1-pixel halo when RCAS follows; stage 2
+// writes the tile out, through the 5-tap RCAS when asked.  The fused mode therefore never writes the
+// EASU image to HBM (the shader pair round-trips it as RGBA8, which the LDS tile reproduces exactly:
+// same truncating pack between the passes).  Expression order follows the shaders; no contraction.
+enum class FsrMode : int { Easu = 0, Rcas = 1, Fused = 2 };
+
+constexpr int kFsrTW = 64, kFsrTH = 32; // output tile per 256-thread block
+
+struct FsrArgs {
+    const uint32_t *in;
+    uint32_t *out;
+    int iw, ih, ow, oh;
+    size_t ipx, opx;   // pixels per input / output frame
+    float sx, sy;      // f32(iw) / f32(ow), f32(ih) / f32(oh)   (host, IEEE)
+    float easu_sharp, rcas_sharp;
+};
+
+__device__ __forceinline__ float3 fsr_rgb(uint32_t p)
+{
+    const float z = 1.0f / 255.0f;
+    return make_float3(div_by_recip(ch_f32(p, 0), 255.0f, z), div_by_recip(ch_f32(p, 1), 255.0f, z),
+                       div_by_recip(ch_f32(p, 2), 255.0f, z));
+}
+
+__device__ __forceinline__ float fsr_cubic(float d) // fsr.rs:74-84
+{
+    const float d2 = d * d;
+    const float d3 = d * d2;
+    const float near = 2.0f - 1.5f * d - 0.5f * d3 + d2;
+    const float far = 0.0f - 0.5f * d + 2.5f * d2 - d3;
+    return d <= 1.0f ? near : (d <= 2.0f ? far : 0.0f);
+}
+
+__device__ __forceinline__ float clamp01(float v) { return fminf(fmaxf(v, 0.0f), 1.0f); }
+
+// pack_rgba8(vec4(rgb, 1.0)): u32(clamp(v, 0, 1) * 255.0) per channel
+__device__ __forceinline__ uint32_t fsr_pack(float r, float g, float b)
+{
+    uint32_t o = 0xff000000u;
+    o = pack_trunc_u8(clamp01(r) * 255.0f, 0, o);
+    o = pack_trunc_u8(clamp01(g) * 255.0f, 1, o);
+    o = pack_trunc_u8(clamp01(b) * 255.0f, 2, o);
+    return o;
+}
+
+// EASU at output pixel (gx, gy): fsr.rs:104-169
+__device__ __forceinline__ uint32_t fsr_easu_px(const uint32_t *__restrict__ in, const FsrArgs &A, int gx, int gy)
+{
+    const float cx = ((float)gx + 0.5f) * A.sx, cy = ((float)gy + 0.5f) * A.sy;
+    const int ix = (int)cx, iy = (int)cy;
+    const float fx = cx - floorf(cx), fy = cy - floorf(cy);
+    int xs[4], ys[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        xs[k] = clampi(ix - 1 + k, 0, A.iw - 1);
+        ys[k] = clampi(iy - 1 + k, 0, A.ih - 1);
+    }
+    uint32_t raw[4][4];
+#pragma unroll
+    for (int y = 0; y < 4; ++y)
+#pragma unroll
+        for (int x = 0; x < 4; ++x) raw[y][x] = in[(size_t)ys[y] * A.iw + xs[x]];
+    // FsrDirA at (ix, iy): its four neighbours are taps (1,0) (1,2) (0,1) (2,1) of the 4x4 block
+    // whenever ix, iy lie inside the image (always: cx < iw, cy < ih)
+    const float3 up = fsr_rgb(raw[0][1]), dn = fsr_rgb(raw[2][1]), lf = fsr_rgb(raw[1][0]), rt = fsr_rgb(raw[1][2]);
+    const float vgx = (fabsf(up.x - dn.x) + fabsf(up.y - dn.y) + fabsf(up.z - dn.z)) / 3.0f;
+    const float vgy = (fabsf(lf.x - rt.x) + fabsf(lf.y - rt.y) + fabsf(lf.z - rt.z)) / 3.0f;
+    const float dxr = vgx + 0.0001f, dyr = vgy + 0.0001f;
+    const float len = sqrtf(dxr * dxr + dyr * dyr);
+    const float dirx = dxr / len, diry = dyr / len;
+    const float wx = fabsf(dirx) / (fabsf(dirx) + fabsf(diry));
+    const float wy = 1.0f - wx;
+    float sr = 0.0f, sg = 0.0f, sb = 0.0f, sw = 0.0f;
+#pragma unroll
+    for (int y = 0; y < 4; ++y) {
+        const float pyw = ((float)y - fy) * wy;
+#pragma unroll
+        for (int x = 0; x < 4; ++x) {
+            const float3 c = fsr_rgb(raw[y][x]);
+            const float dist = fabsf(((float)x - fx) * wx + pyw);
+            const float wgt = fsr_cubic(dist);
+            sr = sr + c.x * wgt;
+            sg = sg + c.y * wgt;
+            sb = sb + c.z * wgt;
+            sw = sw + wgt;
+        }
+    }
+    const float den = fmaxf(sw, 0.0001f);
+    float r = sr / den, g = sg / den, b = sb / den;
+    if (A.easu_sharp > 0.001f) {
+        const float3 ctr = fsr_rgb(raw[1][1]);
+        const float s = A.easu_sharp, ns = 1.0f - A.easu_sharp;
+        r = r * ns + ctr.x * s;
+        g = g * ns + ctr.y * s;
+        b = b * ns + ctr.z * s;
+    }
+    return fsr_pack(r, g, b);
+}
+
+__device__ __forceinline__ float fsr_luma(const float3 c) { return c.x * 0.299f + c.y * 0.587f + c.z * 0.114f; }
+
+// RCAS from its five packed taps: fsr.rs:218-260
+__device__ __forceinline__ uint32_t fsr_rcas_px(uint32_t pc, uint32_t pt, uint32_t pb, uint32_t pl, uint32_t pr, float sharp)
+{
+    const float3 c = fsr_rgb(pc), t = fsr_rgb(pt), b = fsr_rgb(pb), l = fsr_rgb(pl), r = fsr_rgb(pr);
+    const float lc = fsr_luma(c), lt = fsr_luma(t), lb = fsr_luma(b), ll = fsr_luma(l), lr = fsr_luma(r);
+    const float mn = fminf(lc, fminf(fminf(lt, lb), fminf(ll, lr)));
+    const float mx = fmaxf(lc, fmaxf(fmaxf(lt, lb), fmaxf(ll, lr)));
+    const float st = clamp01((mx - mn - 0.0f) / (0.2f - 0.0f));
+    const float strength = sharp * (1.0f - st * st * (3.0f - 2.0f * st));
+    return fsr_pack(c.x + (4.0f * c.x - t.x - b.x - l.x - r.x) * strength,
+                    c.y + (4.0f * c.y - t.y - b.y - l.y - r.y) * strength,
+                    c.z + (4.0f * c.z - t.z - b.z - l.z - r.z) * strength);
+}
+
+template <FsrMode MODE, bool VEC>
+__global__ __launch_bounds__(256) void k_fsr1(const FsrArgs A)
+{
+    constexpr int HALO = MODE == FsrMode::Easu ? 0 : 1;
+    constexpr int LW = kFsrTW + 2 * HALO, LH = kFsrTH + 2 * HALO;
+    __shared__ uint32_t tile[LW * LH];
+    const uint32_t *__restrict__ in = A.in + (size_t)blockIdx.z * A.ipx;
+    uint32_t *__restrict__ out = A.out + (size_t)blockIdx.z * A.opx;
+    const int x0 = blockIdx.x * kFsrTW, y0 = blockIdx.y * kFsrTH;
+    const int tid = threadIdx.x;
+    // stage 1: the tile (+ halo), coordinates clamped into the image as both shaders' fetches do
+    for (int i = tid; i < LW * LH; i += 256) {
+        const int ly = i / LW, lx = i - ly * LW;
+        const int gx = clampi(x0 + lx - HALO, 0, A.ow - 1), gy = clampi(y0 + ly - HALO, 0, A.oh - 1);
+        tile[i] = MODE == FsrMode::Rcas ? in[(size_t)gy * A.ow + gx] : fsr_easu_px(in, A, gx, gy);
+    }
+    __syncthreads();
+    // stage 2: 4 pixels per thread, 16 threads per row, 16 rows per sweep
+    const int qx = (tid & 15) * 4, qy = tid >> 4;
+#pragma unroll
+    for (int sweep = 0; sweep < kFsrTH / 16; ++sweep) {
+        const int ly = qy + sweep * 16, gy = y0 + ly;
+        if (gy >= A.oh || x0 + qx >= A.ow) continue;
+        uint32_t px[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int c = (ly + HALO) * LW + qx + k + HALO;
+            if (MODE == FsrMode::Easu)
+                px[k] = tile[c];
+            else
+                px[k] = fsr_rcas_px(tile[c], tile[c - LW], tile[c + LW], tile[c - 1], tile[c + 1], A.rcas_sharp);
+        }
+        uint32_t *dst = out + (size_t)gy * A.ow + x0 + qx;
+        if (VEC) {
+            *reinterpret_cast<uint4 *>(dst) = make_uint4(px[0], px[1], px[2], px[3]);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (x0 + qx + k < A.ow) dst[k] = px[k];
+        }
+    }
+}
+
 const char *variant_name(Variant v)
 {
     switch (v) {
@@ -1282,6 +1444,9 @@ const char *variant_name(Variant v)
     case Variant::LanczosGeneral: return "lanczos3_general";
     case Variant::ResizeRows: return "resize_rows_lds";
     case Variant::LanczosX2RegWin: return "lanczos3_x2_regwin";
+    case Variant::FsrEasu: return "fsr1_easu_tile";
+    case Variant::FsrRcas: return "fsr1_rcas_tile";
+    case Variant::Fsr1Fused: return "fsr1_easu_rcas_fused_lds";
     }
     return "?";
 }
@@ -1483,6 +1648,40 @@ hipError_t launch_lanczos_x2_edges(const UpscaleLaunch &L, const DeviceTables &T
             if (blend == 0) NUS_LZE(false, 0); else if (blend == 1) NUS_LZE(false, 1); else NUS_LZE(false, 2);
         }
 #undef NUS_LZE
+    });
+}
+
+hipError_t launch_fsr1(const UpscaleLaunch &L, int mode, float easu_sharpness, float rcas_sharpness)
+{
+    FsrArgs A;
+    A.iw = (int)L.iw;
+    A.ih = (int)L.ih;
+    A.ow = (int)L.ow;
+    A.oh = (int)L.oh;
+    A.ipx = (size_t)L.iw * L.ih;
+    A.opx = (size_t)L.ow * L.oh;
+    A.sx = (float)L.iw / (float)L.ow;
+    A.sy = (float)L.ih / (float)L.oh;
+    A.easu_sharp = easu_sharpness;
+    A.rcas_sharp = rcas_sharpness;
+    const bool vec = (L.ow % 4) == 0;
+    return for_frame_chunks(L, [&](const uint8_t *in, uint8_t *out, uint32_t n) {
+        A.in = reinterpret_cast<const uint32_t *>(in);
+        A.out = reinterpret_cast<uint32_t *>(out);
+        const dim3 block(256), grid(cdiv(L.ow, kFsrTW), cdiv(L.oh, kFsrTH), n);
+#define NUS_FSR(M)                                                                  \
+    if (vec)                                                                        \
+        hipLaunchKernelGGL((k_fsr1<M, true>), grid, block, 0, L.stream, A);         \
+    else                                                                            \
+        hipLaunchKernelGGL((k_fsr1<M, false>), grid, block, 0, L.stream, A)
+        if (mode == 0) {
+            NUS_FSR(FsrMode::Easu);
+        } else if (mode == 1) {
+            NUS_FSR(FsrMode::Rcas);
+        } else {
+            NUS_FSR(FsrMode::Fused);
+        }
+#undef NUS_FSR
     });
 }
 

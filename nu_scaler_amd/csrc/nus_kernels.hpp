@@ -50,6 +50,9 @@ enum class Variant : int {
     LanczosGeneral,   // any scale, direct separable evaluation per output pixel (fallback)
     ResizeRows,       // any scale, separable: V pass into an LDS row, H pass out of it
     LanczosX2RegWin,  // exact x2, register sliding window + wave shifts
+    FsrEasu,          // FSR1-style EASU alone (any scale)
+    FsrRcas,          // FSR1-style RCAS alone (same size in and out)
+    Fsr1Fused,        // EASU tile (+1 px halo) in LDS, RCAS out of it
 };
 
 const char *variant_name(Variant v);
@@ -71,6 +74,8 @@ hipError_t launch_lanczos_x2(const UpscaleLaunch &L, const DeviceTables &T, bool
                              uint32_t rows_per_wave);
 
 hipError_t launch_lanczos_x2_edges(const UpscaleLaunch &L, const DeviceTables &T, bool exact);
+// FSR1-style passes (fsr.rs:24-260).  mode 0: EASU, 1: RCAS (iw == ow, ih == oh), 2: EASU then RCAS fused.
+hipError_t launch_fsr1(const UpscaleLaunch &L, int mode, float easu_sharpness, float rcas_sharpness);
 
 constexpr uint32_t kLanczosX2EdgeCols = 8; // output columns left to the general kernel per side
 constexpr uint32_t kLanczosX2StripCols = 248; // input columns produced per wave (62 lanes x 4)

@@ -29,6 +29,11 @@ _ALGORITHM = {  # lib.rs:58-62; unknown strings silently become "nearest"
     "bicubic": C.ALG_BICUBIC,
     "catmullrom": C.ALG_BICUBIC,
     "triangle": C.ALG_TRIANGLE,
+    # FSR1-style shader pair of nu_scaler_core/src/upscale/fsr.rs:24-260
+    "fsr1": C.ALG_FSR1,
+    "fsr": C.ALG_FSR1,
+    "easu": C.ALG_FSR_EASU,
+    "rcas": C.ALG_FSR_RCAS,
 }
 
 
@@ -164,6 +169,15 @@ class PyWgpuUpscaler:
 
     def set_option(self, key: str, value: int) -> None:
         self._check(self._lib.nus_upscaler_set_option(self._h, key.encode(), int(value)))
+
+    def set_sharpness(self, easu: float = -1.0, rcas: float = -1.0) -> None:
+        """FSR1-style passes: shader `sharpness` uniforms; negative keeps the quality default."""
+        self._check(self._lib.nus_upscaler_set_sharpness(self._h, float(easu), float(rcas)))
+
+    def get_sharpness(self):
+        e, r = ctypes.c_float(), ctypes.c_float()
+        self._check(self._lib.nus_upscaler_get_sharpness(self._h, ctypes.byref(e), ctypes.byref(r)))
+        return e.value, r.value
 
     def set_lanczos_mode(self, mode: str) -> None:
         self._check(self._lib.nus_upscaler_set_lanczos_mode(self._h, 1 if mode == "exact" else 0))

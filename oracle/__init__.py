@@ -79,6 +79,12 @@ def lib() -> ctypes.CDLL:
         L.orc_flow_upsample.restype = None
         L.orc_flow_estimate.argtypes = [u8p, u8p, u32, u32, u32, u32, u32, ctypes.c_float, f32p]
         L.orc_flow_estimate.restype = ctypes.c_int
+        L.orc_fsr_easu.argtypes = up + [ctypes.c_float]
+        L.orc_fsr_easu.restype = None
+        L.orc_fsr_rcas.argtypes = [u8p, u32, u32, u8p, ctypes.c_float]
+        L.orc_fsr_rcas.restype = None
+        L.orc_fsr1.argtypes = up + [ctypes.c_float, ctypes.c_float]
+        L.orc_fsr1.restype = ctypes.c_int
         L.orc_max_threads.argtypes = []
         L.orc_max_threads.restype = ctypes.c_int
         L.orc_gen_gradient.argtypes = [u8p, u32, u32, u32]
@@ -166,6 +172,22 @@ def warp_blend(a, b, flow, t: float, threads: int = 1):
     else:
         lib().orc_warp_blend_mt(_ptr(a), _ptr(b), fp, w, h, t, _ptr(out), threads)
     return out
+
+
+def fsr_easu(img, ow, oh, sharpness: float = 0.0):
+    return _upscale(lib().orc_fsr_easu, img, ow, oh, sharpness)
+
+
+def fsr_rcas(img, sharpness: float):
+    img = _img(img)
+    h, w = img.shape[:2]
+    out = np.empty_like(img)
+    lib().orc_fsr_rcas(_ptr(img), w, h, _ptr(out), sharpness)
+    return out
+
+
+def fsr1(img, ow, oh, easu_sharpness: float = 0.0, rcas_sharpness: float = 0.7):
+    return _upscale(lib().orc_fsr1, img, ow, oh, easu_sharpness, rcas_sharpness)
 
 
 def max_threads() -> int:

@@ -24,6 +24,10 @@
  *                     with clamp + round-to-nearest) from its documentation/source as
  *                     remembered; it could not be verified against the crate here.
  *
+ *   orc_fsr_easu /    PARITY UNPINNED.  Restates the WGSL EASU / RCAS shaders in
+ *   orc_fsr_rcas      nu_scaler_core/src/upscale/fsr.rs:24-260, which the reference never runs
+ *                     (no fixture, no test); "next" row, SURVEY.md section 8f rank 4.
+ *
  * The reference is Rust; it cannot be compiled in this image (no cargo/rustc), so
  * there is no oracle/_ref build.
  */
@@ -559,6 +563,143 @@ int orc_flow_estimate(const uint8_t *a, const uint8_t *b, uint32_t w, uint32_t h
 }
 
 /* ---- OpenMP row-parallel variants (CPU baseline only) -------------------------- */
+
+/* ---- FSR1-style EASU + RCAS ("next" row) ------------------
+ * Restatement of the two WGSL compute shaders the reference keeps in
+ * nu_scaler_core/src/upscale/fsr.rs:24-169 (EASU) and :173-260 (RCAS).  PARITY UNPINNED:
+ * the reference never dispatches them (the file is behind the `fsr3` feature and its
+ * FsrUpscaler returns "not implemented"), and no fixture holds their output.
+ * WGSL semantics restated: vec ops are per component, expressions evaluate left to right,
+ * no contraction; i32(f) truncates; fract(x) = x - floor(x); normalize(v) = v / sqrt(dot(v,v));
+ * mix(a,b,t) = a*(1-t) + b*t; smoothstep(lo,hi,x): t = clamp((x-lo)/(hi-lo),0,1), t*t*(3-2*t);
+ * unpack = u8 / 255.0; pack = u32(clamp(v,0,1) * 255.0) (truncation); alpha is written as 1.0. */
+
+static inline float f32_clamp01(float v) { return fminf(fmaxf(v, 0.0f), 1.0f); }
+
+static inline uint8_t pack_unorm_trunc(float v) { return (uint8_t)(uint32_t)(f32_clamp01(v) * 255.0f); }
+
+/* FsrEasuF / FsrRcasSample (fsr.rs:63-71, :208-216): clamped fetch, rgb / 255 */
+static inline void fsr_fetch(const uint8_t *img, uint32_t w, uint32_t h, int x, int y, float rgb[3])
+{
+    const uint8_t *p = img + ((size_t)clampi(y, 0, (int)h - 1) * w + clampi(x, 0, (int)w - 1)) * 4;
+    for (int c = 0; c < 3; ++c) rgb[c] = (float)p[c] / 255.0f;
+}
+
+/* FsrCubic (fsr.rs:74-84) */
+static inline float fsr_cubic(float d)
+{
+    const float d2 = d * d;
+    const float d3 = d * d2;
+    if (d <= 1.0f) return 2.0f - 1.5f * d - 0.5f * d3 + d2;
+    if (d <= 2.0f) return 0.0f - 0.5f * d + 2.5f * d2 - d3;
+    return 0.0f;
+}
+
+static void easu_rows(const uint8_t *in, uint32_t iw, uint32_t ih, uint8_t *out, uint32_t ow, uint32_t oh,
+                      float sharpness, uint32_t y_begin, uint32_t y_end)
+{
+    const float sx = (float)iw / (float)ow, sy = (float)ih / (float)oh;
+    for (uint32_t gy = y_begin; gy < y_end; ++gy) {
+        for (uint32_t gx = 0; gx < ow; ++gx) {
+            /* fsr.rs:110-120 */
+            const float cx = ((float)gx + 0.5f) * sx, cy = ((float)gy + 0.5f) * sy;
+            const int ix = (int)cx, iy = (int)cy;
+            const float fx = cx - floorf(cx), fy = cy - floorf(cy);
+            /* FsrDirA (fsr.rs:87-102) */
+            float up[3], dn[3], lf[3], rt[3];
+            fsr_fetch(in, iw, ih, ix, iy - 1, up);
+            fsr_fetch(in, iw, ih, ix, iy + 1, dn);
+            fsr_fetch(in, iw, ih, ix - 1, iy, lf);
+            fsr_fetch(in, iw, ih, ix + 1, iy, rt);
+            const float vgx = (fabsf(up[0] - dn[0]) + fabsf(up[1] - dn[1]) + fabsf(up[2] - dn[2])) / 3.0f;
+            const float vgy = (fabsf(lf[0] - rt[0]) + fabsf(lf[1] - rt[1]) + fabsf(lf[2] - rt[2])) / 3.0f;
+            const float dxr = vgx + 0.0001f, dyr = vgy + 0.0001f;
+            const float len = sqrtf(dxr * dxr + dyr * dyr);
+            const float dirx = dxr / len, diry = dyr / len;
+            /* fsr.rs:131-152 */
+            const float wx = fabsf(dirx) / (fabsf(dirx) + fabsf(diry));
+            const float wy = 1.0f - wx;
+            float sum[3] = {0.0f, 0.0f, 0.0f}, sumw = 0.0f;
+            for (int y = 0; y < 4; ++y) {
+                for (int x = 0; x < 4; ++x) {
+                    float c[3];
+                    fsr_fetch(in, iw, ih, ix - 1 + x, iy - 1 + y, c);
+                    const float px = (float)x - fx, py = (float)y - fy;
+                    const float dist = fabsf(px * wx + py * wy);
+                    const float wgt = fsr_cubic(dist);
+                    for (int k = 0; k < 3; ++k) sum[k] = sum[k] + c[k] * wgt;
+                    sumw = sumw + wgt;
+                }
+            }
+            /* fsr.rs:155-161 */
+            const float den = fmaxf(sumw, 0.0001f);
+            float col[3];
+            for (int k = 0; k < 3; ++k) col[k] = sum[k] / den;
+            if (sharpness > 0.001f) {
+                float ctr[3];
+                fsr_fetch(in, iw, ih, ix, iy, ctr);
+                for (int k = 0; k < 3; ++k) col[k] = col[k] * (1.0f - sharpness) + ctr[k] * sharpness;
+            }
+            uint8_t *o = out + ((size_t)gy * ow + gx) * 4;
+            for (int k = 0; k < 3; ++k) o[k] = pack_unorm_trunc(col[k]);
+            o[3] = 255;
+        }
+    }
+}
+
+static void rcas_rows(const uint8_t *in, uint32_t w, uint32_t h, uint8_t *out, float sharpness,
+                      uint32_t y_begin, uint32_t y_end)
+{
+    for (uint32_t gy = y_begin; gy < y_end; ++gy) {
+        for (uint32_t gx = 0; gx < w; ++gx) {
+            /* fsr.rs:226-231 */
+            float c[3], t[3], b[3], l[3], r[3];
+            fsr_fetch(in, w, h, (int)gx, (int)gy, c);
+            fsr_fetch(in, w, h, (int)gx, (int)gy - 1, t);
+            fsr_fetch(in, w, h, (int)gx, (int)gy + 1, b);
+            fsr_fetch(in, w, h, (int)gx - 1, (int)gy, l);
+            fsr_fetch(in, w, h, (int)gx + 1, (int)gy, r);
+            /* fsr.rs:234-247 */
+#define NUS_LUMA(p) ((p)[0] * 0.299f + (p)[1] * 0.587f + (p)[2] * 0.114f)
+            const float lc = NUS_LUMA(c), lt = NUS_LUMA(t), lb = NUS_LUMA(b), ll = NUS_LUMA(l), lr = NUS_LUMA(r);
+#undef NUS_LUMA
+            const float mn = fminf(lc, fminf(fminf(lt, lb), fminf(ll, lr)));
+            const float mx = fmaxf(lc, fmaxf(fmaxf(lt, lb), fmaxf(ll, lr)));
+            const float contrast = mx - mn;
+            const float st = f32_clamp01((contrast - 0.0f) / (0.2f - 0.0f));
+            const float smooth = st * st * (3.0f - 2.0f * st);
+            const float strength = sharpness * (1.0f - smooth);
+            /* fsr.rs:250-258 */
+            uint8_t *o = out + ((size_t)gy * w + gx) * 4;
+            for (int k = 0; k < 3; ++k) {
+                const float lap = 4.0f * c[k] - t[k] - b[k] - l[k] - r[k];
+                o[k] = pack_unorm_trunc(c[k] + lap * strength);
+            }
+            o[3] = 255;
+        }
+    }
+}
+
+void orc_fsr_easu(const uint8_t *in, uint32_t iw, uint32_t ih, uint8_t *out, uint32_t ow, uint32_t oh, float sharpness)
+{
+    easu_rows(in, iw, ih, out, ow, oh, sharpness, 0, oh);
+}
+
+void orc_fsr_rcas(const uint8_t *in, uint32_t w, uint32_t h, uint8_t *out, float sharpness)
+{
+    rcas_rows(in, w, h, out, sharpness, 0, h);
+}
+
+int orc_fsr1(const uint8_t *in, uint32_t iw, uint32_t ih, uint8_t *out, uint32_t ow, uint32_t oh,
+             float easu_sharpness, float rcas_sharpness)
+{
+    uint8_t *tmp = (uint8_t *)malloc((size_t)ow * oh * 4);
+    if (!tmp) return -1;
+    easu_rows(in, iw, ih, tmp, ow, oh, easu_sharpness, 0, oh);
+    rcas_rows(tmp, ow, oh, out, rcas_sharpness, 0, oh);
+    free(tmp);
+    return 0;
+}
 
 int orc_max_threads(void)
 {

@@ -79,6 +79,18 @@ int orc_flow_estimate(const uint8_t *a, const uint8_t *b, uint32_t w, uint32_t h
                       uint32_t levels, uint32_t coarse_iters, uint32_t refine_iters,
                       float lambda, float *flow_out);
 
+/* ---- FSR1-style EASU + RCAS ("next" row; PARITY UNPINNED) ----
+ * nu_scaler_core/src/upscale/fsr.rs:24-169 (EASU: 4x4 taps, cubic weight of the distance
+ * projected on the local gradient direction, optional mix toward the centre texel) and
+ * :173-260 (RCAS: 5-tap laplacian sharpen, strength faded by local luma contrast).
+ * Both write alpha = 255 and pack by truncation. */
+void orc_fsr_easu(const uint8_t *in, uint32_t iw, uint32_t ih,
+                  uint8_t *out, uint32_t ow, uint32_t oh, float sharpness);
+void orc_fsr_rcas(const uint8_t *in, uint32_t w, uint32_t h, uint8_t *out, float sharpness);
+/* EASU into a temporary, then RCAS.  Returns 0 or -1 (allocation). */
+int orc_fsr1(const uint8_t *in, uint32_t iw, uint32_t ih, uint8_t *out, uint32_t ow, uint32_t oh,
+             float easu_sharpness, float rcas_sharpness);
+
 /* OpenMP row-parallel variants for the "all host cores" baseline
  * (same arithmetic, rows distributed over threads).  threads<=0: all cores. */
 void orc_nearest_mt(const uint8_t *in, uint32_t iw, uint32_t ih,

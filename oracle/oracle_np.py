@@ -181,3 +181,83 @@ def gen_py_gradient(w: int, h: int) -> np.ndarray:
     img[:, :, 2] = ((X + Y) / 2) * 255
     img[:, :, 3] = 255
     return img
+
+
+# ---- FSR1-style EASU + RCAS (nu_scaler_core/src/upscale/fsr.rs:24-260), f32 throughout ----
+
+_F = np.float32
+
+
+def _fsr_fetch(img: np.ndarray, x: np.ndarray, y: np.ndarray) -> np.ndarray:
+    h, w = img.shape[:2]
+    return img[np.clip(y, 0, h - 1), np.clip(x, 0, w - 1), :3].astype(_F) / _F(255.0)
+
+
+def _fsr_cubic(d: np.ndarray) -> np.ndarray:
+    d2 = d * d
+    d3 = d * d2
+    near = _F(2.0) - _F(1.5) * d - _F(0.5) * d3 + d2
+    far = _F(0.0) - _F(0.5) * d + _F(2.5) * d2 - d3
+    return np.where(d <= 1, near, np.where(d <= 2, far, _F(0.0))).astype(_F)
+
+
+def _pack_trunc(v: np.ndarray) -> np.ndarray:
+    return (np.minimum(np.maximum(v, _F(0.0)), _F(1.0)) * _F(255.0)).astype(np.uint32).astype(np.uint8)
+
+
+def fsr_easu(img: np.ndarray, ow: int, oh: int, sharpness: float = 0.0) -> np.ndarray:
+    ih, iw = img.shape[:2]
+    s = _F(sharpness)
+    gx, gy = np.meshgrid(np.arange(ow), np.arange(oh))
+    cx = (gx.astype(_F) + _F(0.5)) * (_F(iw) / _F(ow))
+    cy = (gy.astype(_F) + _F(0.5)) * (_F(ih) / _F(oh))
+    ix, iy = cx.astype(np.int32), cy.astype(np.int32)
+    fx, fy = cx - np.floor(cx), cy - np.floor(cy)
+    up, dn = _fsr_fetch(img, ix, iy - 1), _fsr_fetch(img, ix, iy + 1)
+    lf, rt = _fsr_fetch(img, ix - 1, iy), _fsr_fetch(img, ix + 1, iy)
+    a, b = np.abs(up - dn), np.abs(lf - rt)
+    vgx = (a[..., 0] + a[..., 1] + a[..., 2]) / _F(3.0)
+    vgy = (b[..., 0] + b[..., 1] + b[..., 2]) / _F(3.0)
+    dx, dy = vgx + _F(0.0001), vgy + _F(0.0001)
+    ln = np.sqrt(dx * dx + dy * dy)
+    dx, dy = dx / ln, dy / ln
+    wx = np.abs(dx) / (np.abs(dx) + np.abs(dy))
+    wy = _F(1.0) - wx
+    acc = np.zeros((oh, ow, 3), _F)
+    accw = np.zeros((oh, ow), _F)
+    for y in range(4):
+        for x in range(4):
+            c = _fsr_fetch(img, ix - 1 + x, iy - 1 + y)
+            dist = np.abs((_F(x) - fx) * wx + (_F(y) - fy) * wy)
+            wgt = _fsr_cubic(dist)
+            acc = acc + c * wgt[..., None]
+            accw = accw + wgt
+    col = acc / np.maximum(accw, _F(0.0001))[..., None]
+    if s > _F(0.001):
+        col = col * (_F(1.0) - s) + _fsr_fetch(img, ix, iy) * s
+    out = np.empty((oh, ow, 4), np.uint8)
+    out[..., :3] = _pack_trunc(col)
+    out[..., 3] = 255
+    return out
+
+
+def fsr_rcas(img: np.ndarray, sharpness: float) -> np.ndarray:
+    h, w = img.shape[:2]
+    gx, gy = np.meshgrid(np.arange(w), np.arange(h))
+    c = _fsr_fetch(img, gx, gy)
+    t, b = _fsr_fetch(img, gx, gy - 1), _fsr_fetch(img, gx, gy + 1)
+    l, r = _fsr_fetch(img, gx - 1, gy), _fsr_fetch(img, gx + 1, gy)
+
+    def luma(p):
+        return p[..., 0] * _F(0.299) + p[..., 1] * _F(0.587) + p[..., 2] * _F(0.114)
+
+    lc, lt, lb, ll, lr = luma(c), luma(t), luma(b), luma(l), luma(r)
+    mn = np.minimum(lc, np.minimum(np.minimum(lt, lb), np.minimum(ll, lr)))
+    mx = np.maximum(lc, np.maximum(np.maximum(lt, lb), np.maximum(ll, lr)))
+    st = np.minimum(np.maximum((mx - mn - _F(0.0)) / (_F(0.2) - _F(0.0)), _F(0.0)), _F(1.0))
+    strength = _F(sharpness) * (_F(1.0) - st * st * (_F(3.0) - _F(2.0) * st))
+    lap = _F(4.0) * c - t - b - l - r
+    out = np.empty((h, w, 4), np.uint8)
+    out[..., :3] = _pack_trunc(c + lap * strength[..., None])
+    out[..., 3] = 255
+    return out

@@ -1,0 +1,96 @@
+"""FSR1-style EASU + RCAS ("next" row).
+
+CPU: the C oracle against its independent numpy twin (PARITY UNPINNED: the reference keeps the two
+WGSL shaders in nu_scaler_core/src/upscale/fsr.rs:24-260 but never dispatches them, so there is no
+fixture to pin either restatement to).  GPU: the HIP kernels, through the C ABI, bit-exact against
+the C oracle -- each pass alone and the fused pair.
+"""
+import numpy as np
+import pytest
+
+SIZES = [((32, 24), (64, 48)), ((17, 13), (40, 29)), ((20, 20), (20, 20)), ((33, 21), (25, 17)), ((1, 1), (3, 2)),
+         ((5, 3), (130, 67))]
+
+
+@pytest.mark.parametrize("dims", SIZES)
+def test_oracle_c_equals_numpy_twin(oracle_mod, dims):
+    from oracle import oracle_np as onp
+    (w, h), (ow, oh) = dims
+    for img in (oracle_mod.gen_noise(w, h, 31), oracle_mod.gen_gradient(w, h)):
+        for s in (0.0, 0.3):
+            e = oracle_mod.fsr_easu(img, ow, oh, s)
+            assert np.array_equal(e, onp.fsr_easu(img, ow, oh, s))
+            assert np.array_equal(oracle_mod.fsr_rcas(e, 0.7), onp.fsr_rcas(e, 0.7))
+            assert np.array_equal(oracle_mod.fsr1(img, ow, oh, s, 0.7), oracle_mod.fsr_rcas(e, 0.7))
+
+
+def test_oracle_fsr_properties(oracle_mod):
+    # flat image: EASU's weights normalise, so it returns the value up to the truncating pack; alpha -> 255
+    flat = np.full((9, 11, 4), 77, np.uint8)
+    flat[..., 3] = 3
+    e = oracle_mod.fsr_easu(flat, 22, 18, 0.0)
+    assert set(np.unique(e[..., :3])) <= {76, 77} and (e[..., 3] == 255).all()
+    # ... and RCAS's laplacian vanishes there up to f32 rounding (4c - c - c - c - c is not exact)
+    assert set(np.unique(oracle_mod.fsr_rcas(flat, 0.9)[..., :3])) <= {76, 77}
+    # zero sharpness: RCAS is unpack -> pack, which loses at most one count to the truncation
+    img = oracle_mod.gen_noise(16, 8, 5)
+    r = oracle_mod.fsr_rcas(img, 0.0)
+    d = img[..., :3].astype(int) - r[..., :3].astype(int)
+    assert d.min() >= 0 and d.max() <= 1 and (r[..., 3] == 255).all()
+
+
+def _run(nsc, alg, img, ow, oh, easu=-1.0, rcas=-1.0, quality="quality"):
+    u = nsc.PyWgpuUpscaler(quality, alg)
+    u.set_sharpness(easu, rcas)
+    ih, iw = img.shape[:2]
+    u.initialize(iw, ih, ow, oh)
+    return np.frombuffer(u.upscale(img.tobytes()), np.uint8).reshape(oh, ow, 4), u
+
+
+GPU_SIZES = SIZES + [((64, 36), (128, 72)), ((320, 180), (640, 360)), ((100, 70), (257, 131)), ((70, 40), (64, 33))]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dims", GPU_SIZES)
+def test_gpu_easu_rcas_and_fused_bit_exact(nsc, oracle_mod, dims):
+    (w, h), (ow, oh) = dims
+    for img in (oracle_mod.gen_noise(w, h, 32), oracle_mod.gen_gradient(w, h)):
+        for es in (0.0, 0.3):
+            want_e = oracle_mod.fsr_easu(img, ow, oh, es)
+            got_e, u = _run(nsc, "easu", img, ow, oh, easu=es)
+            assert u.kernel_variant == "fsr1_easu_tile"
+            assert np.array_equal(got_e, want_e)
+            got_f, u = _run(nsc, "fsr1", img, ow, oh, easu=es, rcas=0.7)
+            assert u.kernel_variant == "fsr1_easu_rcas_fused_lds"
+            assert np.array_equal(got_f, oracle_mod.fsr1(img, ow, oh, es, 0.7))
+        got_r, u = _run(nsc, "rcas", img, w, h, rcas=0.6)
+        assert u.kernel_variant == "fsr1_rcas_tile"
+        assert np.array_equal(got_r, oracle_mod.fsr_rcas(img, 0.6))
+
+
+@pytest.mark.gpu
+def test_gpu_fsr1_quality_default_and_errors(nsc, oracle_mod):
+    img = oracle_mod.gen_noise(48, 27, 33)
+    for q, s in (("ultra", 0.8), ("balanced", 0.6)):
+        got, _ = _run(nsc, "fsr1", img, 96, 54, quality=q)
+        assert np.array_equal(got, oracle_mod.fsr1(img, 96, 54, 0.0, s))
+    u = nsc.PyWgpuUpscaler("quality", "rcas")
+    with pytest.raises(RuntimeError, match="same-size"):
+        u.initialize(8, 8, 16, 16)
+
+
+@pytest.mark.gpu
+def test_gpu_fsr1_1080p_to_4k_device_batch(nsc, oracle_mod):
+    """BASELINE-size frame through the device path (3 frames per launch) against the oracle."""
+    import torch
+    w, h = 1920, 1080
+    frames = np.stack([oracle_mod.gen_gradient(w, h, k) for k in range(2)] + [oracle_mod.gen_noise(w, h, 34)])
+    u = nsc.PyWgpuUpscaler("quality", "fsr1")
+    u.initialize(w, h, 2 * w, 2 * h)
+    d_in = torch.from_numpy(frames).cuda()
+    d_out = torch.empty((3, 2 * h, 2 * w, 4), dtype=torch.uint8, device="cuda")
+    u.upscale_device(d_in.data_ptr(), d_out.data_ptr(), 3, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    got = d_out.cpu().numpy()
+    for k in (0, 2):
+        assert np.array_equal(got[k], oracle_mod.fsr1(frames[k], 2 * w, 2 * h, 0.0, 0.7))

@@ -39,7 +39,7 @@ def test_product_does_not_import_the_oracle():
 def test_create_and_enums(nsc):
     C = nsc._capi
     L = C.lib()
-    assert not L.nus_upscaler_create(7, C.QUALITY_QUALITY)
+    assert not L.nus_upscaler_create(8, C.QUALITY_QUALITY)
     assert b"unknown" in L.nus_last_error()
     assert not L.nus_interp_create(9)
     for tech, want in ((C.TECH_WGPU, b"WgpuBilinearUpscaler"), (C.TECH_FSR, b"WgpuNearestUpscaler"),
@@ -52,6 +52,25 @@ def test_create_and_enums(nsc):
         assert L.nus_upscaler_set_quality(h, 42) == C.ERR_INVALID_ARGUMENT
         L.nus_upscaler_destroy(h)
     assert L.nus_status_string(C.ERR_NO_DEVICE) == b"no HIP device"
+
+
+def test_fsr1_names_and_sharpness_defaults(nsc):
+    # RCAS default per quality: Nu_scale/src/upscale/fsr3.rs:231-236; EASU default 0 (build-defined)
+    for q, want in (("ultra", 0.8), ("quality", 0.7), ("balanced", 0.6), ("performance", 0.5)):
+        u = nsc.PyWgpuUpscaler(q, "fsr1")
+        assert u.name == "HipFsr1Upscaler"
+        e, r = u.get_sharpness()
+        assert e == 0.0 and abs(r - want) < 1e-7
+    u = nsc.PyWgpuUpscaler("quality", "easu")
+    assert u.name == "HipFsrEasuUpscaler"
+    u.set_sharpness(0.25, 0.5)
+    e, r = u.get_sharpness()
+    assert (e, r) == (0.25, 0.5)
+    u.set_sharpness(-1.0, -1.0)
+    assert u.get_sharpness()[0] == 0.0
+    with pytest.raises(RuntimeError, match="sharpness"):
+        u.set_sharpness(2.0, 0.5)
+    assert nsc.PyWgpuUpscaler("quality", "rcas").name == "HipFsrRcasUpscaler"
 
 
 def test_pyclass_surface_and_defaults(nsc):

@@ -86,6 +86,36 @@ DEFK(k_dot2, S_DOT2)
 DEFK(k_dot2c, S_DOT2C)
 DEFK(k_sdwa_mul, S_SDWA_MUL)
 
+// packed-f32 forms: operands are VGPR pairs
+typedef float f2 __attribute__((ext_vector_type(2)));
+#define DEFK2(NAME, STMT)                                                                                  \
+    __global__ __launch_bounds__(256) void NAME(float *out, float a, float b, int iters, unsigned long long *clk) \
+    {                                                                                                      \
+        const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime(); \
+        const float t = threadIdx.x;                                                                       \
+        f2 x0 = {t, t + 1}, x1 = {t + 2, t + 3}, x2 = {t + 4, t + 5}, x3 = {t + 6, t + 7}, x4 = {t + 8, t + 9}, \
+           x5 = {t + 10, t + 11}, x6 = {t + 12, t + 13}, x7 = {t + 14, t + 15};                            \
+        f2 va = {a + t * 0.0f, a}, vb = {b + t * 0.0f, b};                                                 \
+        asm volatile("" : "+v"(va), "+v"(vb));                                                             \
+        for (int i = 0; i < iters; ++i) { REP8(STMT) }                                                     \
+        if (blockIdx.x == 0 && threadIdx.x == 0) {                                                         \
+            clk[0] = __builtin_amdgcn_s_memtime() - c0;                                                    \
+            clk[1] = __builtin_amdgcn_s_memrealtime() - r0;                                                \
+        }                                                                                                  \
+        const f2 s = x0 + x1 + x2 + x3 + x4 + x5 + x6 + x7;                                                \
+        out[blockIdx.x * blockDim.x + threadIdx.x] = s.x + s.y;                                            \
+    }
+#define S_PK_FMA(X) asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(X) : "v"(va), "v"(vb));
+#define S_PK_FMA_BCAST(X) asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(X) : "v"(va), "v"(vb));
+#define S_PK_MUL(X) asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(X) : "v"(va));
+#define S_PK_ADD(X) asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(X) : "v"(va));
+#define S_PK_MOV(X) asm volatile("v_pk_mov_b32 %0, %1, %2" : "=v"(X) : "v"(va), "v"(vb));
+DEFK2(k_pk_fma, S_PK_FMA)
+DEFK2(k_pk_fma_bcast, S_PK_FMA_BCAST)
+DEFK2(k_pk_mul, S_PK_MUL)
+DEFK2(k_pk_add, S_PK_ADD)
+DEFK2(k_pk_mov, S_PK_MOV)
+
 typedef void (*kern_t)(float *, float, float, int, unsigned long long *);
 
 int main()
@@ -100,7 +130,9 @@ int main()
         {"v_max_f32", k_max}, {"v_perm_b32", k_perm}, {"v_bfe_u32", k_bfe}, {"v_cvt_pk_u8_f32", k_cvtpk},
         {"v_mov_b32_dpp wave_shr", k_dpp}, {"v_mov_b32_dpp row_shr", k_dpp_row}, {"v_fmac_f32_dpp row_shr", k_fmac_dpp},
         {"v_fma_mix_f32 f16lo", k_mix_lo}, {"v_cvt_f32_f16", k_cvt_f16}, {"v_lerp_u8", k_lerp}, {"v_dot2_f32_f16", k_dot2},
-        {"v_dot2c_f32_f16", k_dot2c}, {"v_mul_f32_sdwa", k_sdwa_mul}};
+        {"v_dot2c_f32_f16", k_dot2c}, {"v_mul_f32_sdwa", k_sdwa_mul},
+        {"v_pk_fma_f32 (2 fma)", k_pk_fma}, {"v_pk_fma_f32 bcast lo", k_pk_fma_bcast}, {"v_pk_mul_f32", k_pk_mul},
+        {"v_pk_add_f32", k_pk_add}, {"v_pk_mov_b32", k_pk_mov}};
     const int iters = 20000;
     for (int occ : {2048, 768}) { // 8 and 3 waves per SIMD
         for (auto &e : ks) {

@@ -31,6 +31,7 @@ def main():
     ap.add_argument("--reps", type=int, default=10)
     ap.add_argument("--pattern", default="noise")
     ap.add_argument("--sweep", action="store_true")
+    ap.add_argument("--only", default="", help="comma-separated algorithm names; skips the interpolation legs")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     w, h, n = 1920, 1080, args.frames
@@ -41,7 +42,9 @@ def main():
     print(f"frames={n} pattern={args.pattern}  (upscale: {up_bytes/1e6:.2f} MB/frame algorithmic)")
     cases = [("nearest", {}, {}), ("nearest", {}, {"force_general": 1}), ("bilinear", {}, {}), ("bilinear", {}, {"force_general": 1}),
              ("lanczos3", {"lanczos_mode": "fma"}, {}), ("lanczos3", {"lanczos_mode": "exact"}, {}),
-             ("bicubic", {"lanczos_mode": "fma"}, {})]
+             ("bicubic", {"lanczos_mode": "fma"}, {}), ("easu", {}, {}), ("fsr1", {}, {})]
+    if args.only:
+        cases = [c for c in cases if c[0] in args.only.split(",")]
     if args.sweep:
         for th in (4, 8, 12, 16, 24, 32, 36, 48, 64):
             cases.append(("lanczos3", {"lanczos_mode": "fma"}, {"rows_per_wave": th}))
@@ -56,6 +59,8 @@ def main():
         us = ms * 1e3 / n
         kus = kms * 1e3 / max(nl, 1) / n
         print(f"{alg:9s} {u.kernel_variant:24s} {str(kw)+str(opts):48s} {us:8.2f} us/frame (main kernel {kus:6.2f})  {up_bytes/kus/1e6:6.2f} TB/s  {100*up_bytes/kus/1e6/8.0:5.1f}% of 8 TB/s", flush=True)
+    if args.only:
+        return
     it = nsc.WgpuFrameInterpolator()
     mid = torch.empty((n, h, w, 4), dtype=torch.uint8, device=dev)
     fb = w * h * 4
