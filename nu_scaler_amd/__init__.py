@@ -13,6 +13,7 @@ libamdhip64 (pulled in by libnuscaler_hip.so) is loaded first.
 from . import _capi
 from ._capi import NuScalerLibraryError, build, device_count
 from .flow import FlowEstimator
+from .imagefile import interpolate_image_files, upscale_image_file
 from .interpolator import WgpuFrameInterpolator
 from .queue import FrameBuffer, swizzle_bgra_to_rgba_device
 from .stream import (FramePipeline, broadcast_blob, broadcast_tables, build_tables_blob, shard_frames,
@@ -38,6 +39,7 @@ def create_fsr_upscaler(_quality: str):
 
 __all__ = [
     "PyWgpuUpscaler", "PyAdvancedWgpuUpscaler", "create_advanced_upscaler", "create_fsr_upscaler",
+    "upscale_image_file", "interpolate_image_files",
     "WgpuFrameInterpolator", "FlowEstimator", "FrameBuffer", "swizzle_bgra_to_rgba_device", "FramePipeline", "shard_frames", "broadcast_tables",
     "broadcast_blob", "build_tables_blob", "validate_tables_blob",
     "NuScalerLibraryError", "build", "device_count",
