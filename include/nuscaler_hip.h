@@ -132,6 +132,12 @@ int nus_upscaler_set_lanczos_mode(nus_upscaler *h, int mode);
  * fast path), "force_per_pixel" (0/1, before initialize: resize without the LDS row kernel),
  * "rows_per_wave" (Lanczos x2 kernel: input rows per wave, 0 = auto). */
 int nus_upscaler_set_option(nus_upscaler *h, const char *key, int64_t value);
+/* Channel order of the input frames.  Captured frames arrive as BGRA and the reference swizzles them
+ * on the CPU before upscaling (nu_scaler_core/src/lib.rs:251-270); with NUS_FORMAT_BGRA8 the kernels
+ * do it inside their loads (one v_perm_b32 per loaded pixel, no extra pass).  Output is always RGBA8.
+ * May be called at any time. */
+typedef enum nus_pixel_format { NUS_FORMAT_RGBA8 = 0, NUS_FORMAT_BGRA8 = 1 } nus_pixel_format;
+int nus_upscaler_set_input_format(nus_upscaler *h, int format);
 /* FSR1-style passes: the `sharpness` uniform of each shader (fsr.rs:35, :178), <= 1.  A negative
  * value keeps the default: EASU 0 (build-defined; the reference never assigns it), RCAS by quality
  * as the reference's CPU FSR path does -- Ultra 0.8, Quality 0.7, Balanced 0.6, else 0.5
@@ -231,6 +237,8 @@ int nus_bilinear_build_axis(uint32_t in_n, uint32_t out_n, int variant,
 nus_interp *nus_interp_create(int wg_preset);
 void nus_interp_destroy(nus_interp *h);
 int nus_interp_set_device(nus_interp *h, int device);
+/* Channel order of BOTH input frames (see nus_upscaler_set_input_format); the new frame is RGBA8. */
+int nus_interp_set_input_format(nus_interp *h, int format);
 
 /* interpolate_py (wgpu_interpolator.rs:215-491): host frames in, host frame out.
  * flow == NULL -> zero flow (the live reference behaviour); otherwise w*h*2 floats

@@ -23,6 +23,7 @@ ERR_OUT_OF_MEMORY = -7
 
 ALG_NEAREST, ALG_BILINEAR, ALG_LANCZOS3, ALG_BICUBIC, ALG_TRIANGLE = 0, 1, 2, 3, 4
 ALG_FSR1, ALG_FSR_EASU, ALG_FSR_RCAS = 5, 6, 7
+FORMAT_RGBA8, FORMAT_BGRA8 = 0, 1
 QUALITY_ULTRA_PERFORMANCE, QUALITY_ULTRA, QUALITY_QUALITY, QUALITY_BALANCED, QUALITY_PERFORMANCE, QUALITY_NATIVE = range(6)
 TECH_NONE, TECH_FSR, TECH_DLSS, TECH_WGPU, TECH_FALLBACK = range(5)
 WG_SQUARE_8X8, WG_SQUARE_16X16, WG_WIDE_32X8, WG_TALL_8X32 = range(4)
@@ -44,6 +45,7 @@ SIGNATURES = [
     ("nus_upscaler_set_bilinear_variant", _i, [_vp, _i]),
     ("nus_upscaler_set_lanczos_mode", _i, [_vp, _i]),
     ("nus_upscaler_set_option", _i, [_vp, _cp, _i64]),
+    ("nus_upscaler_set_input_format", _i, [_vp, _i]),
     ("nus_upscaler_set_sharpness", _i, [_vp, _f, _f]),
     ("nus_upscaler_get_sharpness", _i, [_vp, ctypes.POINTER(_f), ctypes.POINTER(_f)]),
     ("nus_upscaler_initialize", _i, [_vp, _u32, _u32, _u32, _u32]),
@@ -75,6 +77,7 @@ SIGNATURES = [
     ("nus_interp_create", _vp, [_i]),
     ("nus_interp_destroy", None, [_vp]),
     ("nus_interp_set_device", _i, [_vp, _i]),
+    ("nus_interp_set_input_format", _i, [_vp, _i]),
     ("nus_interp_interpolate", _i, [_vp, _vp, _sz, _vp, _sz, _vp, _u32, _u32, _f, _vp, _sz]),
     ("nus_interp_interpolate_device", _i, [_vp, _vp, _sz, _vp, _sz, _vp, _u32, _u32, _f, _vp, _u32, _vp]),
     ("nus_interp_last_gpu_ms", _i, [_vp, _dp]),

@@ -99,6 +99,10 @@ int nus_upscaler_set_option(nus_upscaler *h, const char *key, int64_t value)
 {
     return h ? h->impl.set_option(key, value) : null_handle();
 }
+int nus_upscaler_set_input_format(nus_upscaler *h, int format)
+{
+    return h ? h->impl.set_input_format(format) : null_handle();
+}
 int nus_upscaler_set_sharpness(nus_upscaler *h, float easu, float rcas)
 {
     return h ? h->impl.set_sharpness(easu, rcas) : null_handle();
@@ -288,6 +292,7 @@ nus_interp *nus_interp_create(int wg_preset)
 
 void nus_interp_destroy(nus_interp *h) { delete h; }
 int nus_interp_set_device(nus_interp *h, int device) { return h ? h->impl.set_device(device) : null_handle(); }
+int nus_interp_set_input_format(nus_interp *h, int format) { return h ? h->impl.set_input_format(format) : null_handle(); }
 
 int nus_interp_interpolate(nus_interp *h, const uint8_t *a, size_t a_len, const uint8_t *b, size_t b_len,
                            const float *flow, uint32_t w, uint32_t hgt, float t, uint8_t *out, size_t out_cap)

@@ -82,6 +82,9 @@ public:
     int set_bilinear_variant(int variant);
     int set_lanczos_mode(int mode);
     int set_option(const char *key, int64_t value);
+    // 0: RGBA8 (default), 1: BGRA8 -- captured frames, swizzled inside the kernels' loads
+    // (the reference's CPU loop: nu_scaler_core/src/lib.rs:251-270).  Output is always RGBA8.
+    int set_input_format(int format);
     // FSR1-style passes: negative value = keep the quality-derived default.
     int set_sharpness(float easu, float rcas);
     float easu_sharpness() const;
@@ -140,6 +143,7 @@ private:
     bool resize_small_taps_ = false;
     uint32_t rows_per_wave_ = 0; // 0: pick from the batch size
     float easu_sharp_ = -1.0f, rcas_sharp_ = -1.0f; // < 0: derive from quality_
+    bool bgra_ = false;
     bool initialized_ = false;
     uint32_t iw_ = 0, ih_ = 0, ow_ = 0, oh_ = 0;
     Variant variant_ = Variant::NearestTable;
@@ -185,6 +189,7 @@ public:
     const char *name() const override { return "HipWarpBlendInterpolator"; }
     const char *last_error() const override { return error_.c_str(); }
     int set_device(int device);
+    int set_input_format(int format); // 0 RGBA8, 1 BGRA8 (both frames); output RGBA8
     bool last_gpu_ms(double *ms) const;
     int wg_preset() const { return wg_preset_; }
 
@@ -198,6 +203,7 @@ private:
     int wg_preset_;
     int device_ = 0;
     bool device_ready_ = false;
+    bool bgra_ = false;
     size_t cap_bytes_ = 0;
     bool cap_flow_ = false;
     uint8_t *d_a_ = nullptr, *d_b_ = nullptr, *d_out_ = nullptr;

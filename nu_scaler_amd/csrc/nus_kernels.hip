@@ -80,6 +80,26 @@ __device__ __forceinline__ uint32_t pack_u8(float v, int c, uint32_t acc)
 
 __device__ __forceinline__ uint32_t umin(uint32_t a, uint32_t b) { return a < b ? a : b; }
 
+// Input channel order.  Captured frames arrive as BGRA and the reference swizzles them on the CPU before
+// upscaling (nu_scaler_core/src/lib.rs:251-270); here every kernel passes the pixels it loads through one
+// v_perm_b32 whose selector `sel` is kSelRGBA (identity) or kSelBGRA (bytes 2,1,0,3), so a BGRA source
+// costs no extra pass over the frame (UpscaleLaunch::in_sel).
+#ifndef NUS_SWZ_ON_LOAD
+#define NUS_SWZ_ON_LOAD 1 // dev macro: 0 builds the loads without the v_perm_b32 (A/B timing of its cost only)
+#endif
+__device__ __forceinline__ uint32_t swz(uint32_t p, uint32_t sel)
+{
+#if NUS_SWZ_ON_LOAD
+    return __builtin_amdgcn_perm(p, p, sel);
+#else
+    return p;
+#endif
+}
+__device__ __forceinline__ uint4 swz4(const uint4 v, uint32_t sel)
+{
+    return make_uint4(swz(v.x, sel), swz(v.y, sel), swz(v.z, sel), swz(v.w, sel));
+}
+
 __device__ __forceinline__ float div_by_recip(float x, float y, float z); // defined with the flow kernels
 
 // ---------------------------------------------------------------------------------
@@ -93,7 +113,7 @@ template <bool VEC>
 __global__ __launch_bounds__(256) void k_nearest_table(
     const uint32_t *__restrict__ in, uint32_t *__restrict__ out,
     const uint32_t *__restrict__ sx, const uint32_t *__restrict__ sy,
-    uint32_t iw, uint32_t ow, uint32_t oh, uint32_t rows_per_wave, size_t in_frame_px, size_t out_frame_px)
+    uint32_t iw, uint32_t ow, uint32_t oh, uint32_t rows_per_wave, size_t in_frame_px, size_t out_frame_px, uint32_t sel)
 {
     constexpr int N = VEC ? 4 : 1;
     const uint32_t rb = __builtin_amdgcn_readfirstlane(blockIdx.y * 4 + threadIdx.y);
@@ -116,7 +136,7 @@ __global__ __launch_bounds__(256) void k_nearest_table(
         if (r != have) { // wave-uniform
             const uint32_t *src = base + (size_t)r * iw;
 #pragma unroll
-            for (int i = 0; i < N; ++i) o[i] = src[s[i]];
+            for (int i = 0; i < N; ++i) o[i] = swz(src[s[i]], sel);
             have = r;
         }
         if (VEC)
@@ -130,13 +150,13 @@ __global__ __launch_bounds__(256) void k_nearest_table(
 // (16 B) and writes the 2x2 replication as four 16-B stores.
 __global__ __launch_bounds__(256) void k_nearest_x2(
     const uint32_t *__restrict__ in, uint32_t *__restrict__ out,
-    uint32_t iw, uint32_t ih, size_t in_frame_px, size_t out_frame_px)
+    uint32_t iw, uint32_t ih, size_t in_frame_px, size_t out_frame_px, uint32_t sel)
 {
     const uint32_t r = __builtin_amdgcn_readfirstlane(blockIdx.y * 4 + threadIdx.y);
     const uint32_t k = (blockIdx.x * kWave + threadIdx.x) * 4;
     if (r >= ih || k >= iw) return;
     const uint32_t ow = iw * 2;
-    const uint4 p = *reinterpret_cast<const uint4 *>(in + (size_t)blockIdx.z * in_frame_px + (size_t)r * iw + k);
+    const uint4 p = swz4(*reinterpret_cast<const uint4 *>(in + (size_t)blockIdx.z * in_frame_px + (size_t)r * iw + k), sel);
     const uint4 o0 = make_uint4(p.x, p.x, p.y, p.y);
     const uint4 o1 = make_uint4(p.z, p.z, p.w, p.w);
     uint32_t *d = out + (size_t)blockIdx.z * out_frame_px + (size_t)(2 * r) * ow + 2 * k;
@@ -154,11 +174,11 @@ __global__ __launch_bounds__(256) void k_nearest_x2(
 // for the WGSL form, whose texels are first divided by 255).
 template <int N, bool WGSL>
 __device__ __forceinline__ void bilinear_hrow(const uint32_t *__restrict__ row, const uint32_t (&xi)[N], const float (&xf)[N],
-                                              uint32_t iw, float (&h)[N * 4])
+                                              uint32_t iw, uint32_t sel, float (&h)[N * 4])
 {
 #pragma unroll
     for (int i = 0; i < N; ++i) {
-        const uint32_t p0 = row[xi[i]], p1 = row[umin(xi[i] + 1, iw - 1)];
+        const uint32_t p0 = swz(row[xi[i]], sel), p1 = swz(row[umin(xi[i] + 1, iw - 1)], sel);
         const float dx = xf[i], ndx = 1.0f - dx;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
@@ -183,7 +203,8 @@ __global__ __launch_bounds__(256) void k_bilinear_table(
     const uint32_t *__restrict__ in, uint32_t *__restrict__ out,
     const uint32_t *__restrict__ x0t, const float *__restrict__ fxt,
     const uint32_t *__restrict__ y0t, const float *__restrict__ fyt,
-    uint32_t iw, uint32_t ih, uint32_t ow, uint32_t oh, uint32_t rows_per_wave, size_t in_frame_px, size_t out_frame_px)
+    uint32_t iw, uint32_t ih, uint32_t ow, uint32_t oh, uint32_t rows_per_wave, size_t in_frame_px, size_t out_frame_px,
+    uint32_t sel)
 {
     constexpr int N = VEC ? 4 : 1;
     const uint32_t rb = __builtin_amdgcn_readfirstlane(blockIdx.y * 4 + threadIdx.y);
@@ -217,7 +238,7 @@ __global__ __launch_bounds__(256) void k_bilinear_table(
 #pragma unroll
                 for (int k = 0; k < N * 4; ++k) ht[k] = hb[k];
             } else {
-                bilinear_hrow<N, WGSL>(base + (size_t)y0 * iw, xi, xf, iw, ht);
+                bilinear_hrow<N, WGSL>(base + (size_t)y0 * iw, xi, xf, iw, sel, ht);
             }
             top_row = y0;
         }
@@ -226,7 +247,7 @@ __global__ __launch_bounds__(256) void k_bilinear_table(
 #pragma unroll
                 for (int k = 0; k < N * 4; ++k) hb[k] = ht[k];
             } else {
-                bilinear_hrow<N, WGSL>(base + (size_t)y1 * iw, xi, xf, iw, hb);
+                bilinear_hrow<N, WGSL>(base + (size_t)y1 * iw, xi, xf, iw, sel, hb);
             }
             bot_row = y1;
         }
@@ -271,7 +292,7 @@ __device__ __forceinline__ uint32_t avg4_u8x4(uint32_t a, uint32_t b, uint32_t c
 // Each lane: 4 input pixels of rows r and r+1 -> 8x2 output pixels.
 __global__ __launch_bounds__(256) void k_bilinear_x2_int(
     const uint32_t *__restrict__ in, uint32_t *__restrict__ out,
-    uint32_t iw, uint32_t ih, size_t in_frame_px, size_t out_frame_px)
+    uint32_t iw, uint32_t ih, size_t in_frame_px, size_t out_frame_px, uint32_t sel)
 {
     const uint32_t r = __builtin_amdgcn_readfirstlane(blockIdx.y * 4 + threadIdx.y);
     const uint32_t k = (blockIdx.x * kWave + threadIdx.x) * 4;
@@ -282,10 +303,10 @@ __global__ __launch_bounds__(256) void k_bilinear_x2_int(
     const uint32_t *base = in + (size_t)blockIdx.z * in_frame_px;
     const uint32_t *rowp = base + (size_t)r * iw;
     const uint32_t *rowq = base + (size_t)r1 * iw;
-    const uint4 pv = *reinterpret_cast<const uint4 *>(rowp + k);
-    const uint4 qv = *reinterpret_cast<const uint4 *>(rowq + k);
-    const uint32_t p[5] = {pv.x, pv.y, pv.z, pv.w, rowp[k4]};
-    const uint32_t q[5] = {qv.x, qv.y, qv.z, qv.w, rowq[k4]};
+    const uint4 pv = swz4(*reinterpret_cast<const uint4 *>(rowp + k), sel);
+    const uint4 qv = swz4(*reinterpret_cast<const uint4 *>(rowq + k), sel);
+    const uint32_t p[5] = {pv.x, pv.y, pv.z, pv.w, swz(rowp[k4], sel)};
+    const uint32_t q[5] = {qv.x, qv.y, qv.z, qv.w, swz(rowq[k4], sel)};
     uint32_t top[8], bot[8];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -316,7 +337,7 @@ __global__ __launch_bounds__(256) void k_lanczos_general(
     const int32_t *__restrict__ lxt, const uint32_t *__restrict__ nxt, const float *__restrict__ wxt,
     const int32_t *__restrict__ lyt, const uint32_t *__restrict__ nyt, const float *__restrict__ wyt,
     uint32_t stride, uint32_t iw, uint32_t ow, uint32_t oh, uint32_t ncols, uint32_t split, uint32_t gap,
-    size_t in_frame_px, size_t out_frame_px)
+    size_t in_frame_px, size_t out_frame_px, uint32_t sel)
 {
     const uint32_t y = __builtin_amdgcn_readfirstlane(blockIdx.y * 4 + threadIdx.y);
     const uint32_t i = blockIdx.x * kWave + threadIdx.x;
@@ -333,7 +354,7 @@ __global__ __launch_bounds__(256) void k_lanczos_general(
     for (uint32_t a = 0; a < nx; ++a) {
         float v0 = 0.0f, v1 = 0.0f, v2 = 0.0f, v3 = 0.0f;
         for (uint32_t b = 0; b < ny; ++b) {
-            const uint32_t p = src[(size_t)b * iw + a];
+            const uint32_t p = swz(src[(size_t)b * iw + a], sel);
             const float w = wy[b];
             v0 = mac<EXACT>(v0, ch_f32(p, 0), w);
             v1 = mac<EXACT>(v1, ch_f32(p, 1), w);
@@ -365,7 +386,7 @@ __global__ __launch_bounds__(256) void k_resize_rows(
     const int32_t *__restrict__ lxt, const uint32_t *__restrict__ nxt, const float *__restrict__ wxt,
     const int32_t *__restrict__ lyt, const uint32_t *__restrict__ nyt, const float *__restrict__ wyt,
     uint32_t stride, uint32_t iw, uint32_t ow, uint32_t oh, uint32_t rows_per_block, uint32_t ncols_max,
-    size_t in_frame_px, size_t out_frame_px)
+    size_t in_frame_px, size_t out_frame_px, uint32_t sel)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int N = VEC ? 4 : 1;
@@ -441,7 +462,7 @@ __global__ __launch_bounds__(256) void k_resize_rows(
 #pragma unroll
                             for (int m = 0; m < 4; ++m)
 #pragma unroll
-                                for (int c = 0; c < 4; ++c) v[m][c] = mac<EXACT>(v[m][c], ch_f32(p[j][m], c), wv[j]);
+                                for (int c = 0; c < 4; ++c) v[m][c] = mac<EXACT>(v[m][c], ch_f32(swz(p[j][m], sel), c), wv[j]);
                         }
                     }
                 } else {
@@ -450,7 +471,7 @@ __global__ __launch_bounds__(256) void k_resize_rows(
                         const float w = wy[j];
 #pragma unroll
                         for (int m = 0; m < 4; ++m) {
-                            const uint32_t px = col + m < (int32_t)iw ? q[m] : 0u;
+                            const uint32_t px = swz(col + m < (int32_t)iw ? q[m] : 0u, sel);
 #pragma unroll
                             for (int c = 0; c < 4; ++c) v[m][c] = mac<EXACT>(v[m][c], ch_f32(px, c), w);
                         }
@@ -509,6 +530,7 @@ struct LanczosX2Args {
     const uint8_t *in;
     const uint8_t *in_b; // BLEND != 0: second frame of each pair
     float t;             // BLEND == 2: blend factor
+    uint32_t sel;        // input channel order (kSelRGBA / kSelBGRA)
     uint8_t *out;
     const float *wy6; // [oh][6], phase frame: even row 2r taps rows r-3..r+2, odd row 2r+1 taps r-2..r+3
     float wxe[6];     // interior horizontal weights, even output 2k: columns k-3..k+2
@@ -544,18 +566,19 @@ __device__ __forceinline__ RowRaw<BLEND> fetch_row(const uint8_t *pa, const uint
     return r;
 }
 
+// (the blend is per channel, so the channel swizzle is applied once, to the blended pixel)
 template <int BLEND>
-__device__ __forceinline__ uint4 resolve_row(const RowRaw<BLEND> &r, float t)
+__device__ __forceinline__ uint4 resolve_row(const RowRaw<BLEND> &r, float t, uint32_t sel)
 {
     if constexpr (BLEND == 0) {
-        return r.a;
+        return swz4(r.a, sel);
     } else if constexpr (BLEND == 1) {
-        return make_uint4(__builtin_amdgcn_lerp(r.a.x, r.b.x, 0u), __builtin_amdgcn_lerp(r.a.y, r.b.y, 0u),
-                          __builtin_amdgcn_lerp(r.a.z, r.b.z, 0u), __builtin_amdgcn_lerp(r.a.w, r.b.w, 0u));
+        return swz4(make_uint4(__builtin_amdgcn_lerp(r.a.x, r.b.x, 0u), __builtin_amdgcn_lerp(r.a.y, r.b.y, 0u),
+                               __builtin_amdgcn_lerp(r.a.z, r.b.z, 0u), __builtin_amdgcn_lerp(r.a.w, r.b.w, 0u)), sel);
     } else {
         const float nt = 1.0f - t;
-        return make_uint4(blend_px(r.a.x, r.b.x, t, nt), blend_px(r.a.y, r.b.y, t, nt), blend_px(r.a.z, r.b.z, t, nt),
-                          blend_px(r.a.w, r.b.w, t, nt));
+        return swz4(make_uint4(blend_px(r.a.x, r.b.x, t, nt), blend_px(r.a.y, r.b.y, t, nt), blend_px(r.a.z, r.b.z, t, nt),
+                               blend_px(r.a.w, r.b.w, t, nt)), sel);
     }
 }
 
@@ -686,7 +709,7 @@ __device__ __forceinline__ void lanczos_x2_step(float (&win)[6][16], RowRaw<BLEN
     lanczos_x2_hpass_store<EXACT>(V, W, rs, off0);
     // row r+3 in, then request row r+5 into the same buffer (consumed two steps from now;
     // vmcnt retires in order, so that wait only sits behind stores at least a step old)
-    cvt_row(resolve_row<BLEND>(raw[S & 1], A.t), win[S % 6]);
+    cvt_row(resolve_row<BLEND>(raw[S & 1], A.t, A.sel), win[S % 6]);
     {
         int rn = r + 5;
         rn = rn < (int)A.ih - 1 ? rn : (int)A.ih - 1;
@@ -744,7 +767,7 @@ __global__ __launch_bounds__(256) void k_lanczos3_x2(const LanczosX2Args A)
     }
     float win[6][16];
 #pragma unroll
-    for (int j = 0; j < 6; ++j) cvt_row(resolve_row<BLEND>(load_row(r0 - 3 + j), A.t), win[j]);
+    for (int j = 0; j < 6; ++j) cvt_row(resolve_row<BLEND>(load_row(r0 - 3 + j), A.t, A.sel), win[j]);
     RowRaw<BLEND> raw[2] = {load_row(r0 + 3), load_row(r0 + 4)};
     for (int rbase = r0; rbase < r_end; rbase += 6) {
         // 6-way unrolled so the rotating window indices are compile-time constants.
@@ -766,6 +789,7 @@ struct LanczosX2EdgeArgs {
     const uint8_t *in;
     const uint8_t *in_b;
     float t;
+    uint32_t sel;
     uint8_t *out;
     const float *wy6;
     float wx[2][48]; // [side][output column 0..7 of that side][tap 0..5], phase frame, 0 outside the image
@@ -850,8 +874,8 @@ __global__ __launch_bounds__(64) void k_lanczos3_x2_edges(const LanczosX2EdgeArg
         int rr = r - 3 + j;
         rr = rr < 0 ? 0 : (rr > rmax ? rmax : rr);
         const size_t off = ((size_t)rr * A.iw + col0) * 4;
-        raw[j][0] = resolve_row<BLEND>(fetch_row<BLEND>(src, src_b, off), A.t);
-        raw[j][1] = resolve_row<BLEND>(fetch_row<BLEND>(src, src_b, off + 16), A.t);
+        raw[j][0] = resolve_row<BLEND>(fetch_row<BLEND>(src, src_b, off), A.t, A.sel);
+        raw[j][1] = resolve_row<BLEND>(fetch_row<BLEND>(src, src_b, off + 16), A.t, A.sel);
     }
     if (side == 0)
         lanczos_x2_edge_rows<EXACT, 0>(A, raw, r, dst);
@@ -877,7 +901,7 @@ __device__ __forceinline__ uint32_t blend_px(uint32_t a, uint32_t b, float t, fl
 template <bool VEC>
 __global__ __launch_bounds__(256) void k_blend_zero_flow(
     const uint8_t *__restrict__ a, const uint8_t *__restrict__ b, uint8_t *__restrict__ out,
-    size_t a_stride, size_t b_stride, size_t npx, float t)
+    size_t a_stride, size_t b_stride, size_t npx, float t, uint32_t sel)
 {
     const float nt = 1.0f - t;
     const uint32_t *pa = reinterpret_cast<const uint32_t *>(a + (size_t)blockIdx.y * a_stride);
@@ -888,10 +912,11 @@ __global__ __launch_bounds__(256) void k_blend_zero_flow(
     if (VEC) {
         const uint4 va = *reinterpret_cast<const uint4 *>(pa + i);
         const uint4 vb = *reinterpret_cast<const uint4 *>(pb + i);
-        *reinterpret_cast<uint4 *>(po + i) = make_uint4(blend_px(va.x, vb.x, t, nt), blend_px(va.y, vb.y, t, nt),
-                                                        blend_px(va.z, vb.z, t, nt), blend_px(va.w, vb.w, t, nt));
+        // per-channel arithmetic: swizzling the blended pixel equals blending swizzled inputs
+        *reinterpret_cast<uint4 *>(po + i) = swz4(make_uint4(blend_px(va.x, vb.x, t, nt), blend_px(va.y, vb.y, t, nt),
+                                                             blend_px(va.z, vb.z, t, nt), blend_px(va.w, vb.w, t, nt)), sel);
     } else {
-        po[i] = blend_px(pa[i], pb[i], t, nt);
+        po[i] = swz(blend_px(pa[i], pb[i], t, nt), sel);
     }
 }
 
@@ -923,7 +948,7 @@ __device__ __forceinline__ float4 sample_trunc(const uint32_t *__restrict__ f, u
 // p + (1-t)*flow (warp_blend.wgsl:36-37 in texel space).  blockDim = (64, 4).
 __global__ __launch_bounds__(256) void k_warp_blend_flow(
     const uint8_t *__restrict__ a, const uint8_t *__restrict__ b, const float *__restrict__ flow,
-    uint8_t *__restrict__ out, size_t a_stride, size_t b_stride, uint32_t w, uint32_t h, float t)
+    uint8_t *__restrict__ out, size_t a_stride, size_t b_stride, uint32_t w, uint32_t h, float t, uint32_t sel)
 {
     const uint32_t y = __builtin_amdgcn_readfirstlane(blockIdx.y * 4 + threadIdx.y);
     const uint32_t x = blockIdx.x * kWave + threadIdx.x;
@@ -945,7 +970,7 @@ __global__ __launch_bounds__(256) void k_warp_blend_flow(
     o = pack_trunc_u8(nt * sa.y + tv * sb.y, 1, o);
     o = pack_trunc_u8(nt * sa.z + tv * sb.z, 2, o);
     o = pack_trunc_u8(nt * sa.w + tv * sb.w, 3, o);
-    reinterpret_cast<uint32_t *>(out)[(size_t)blockIdx.z * npx + idx] = o;
+    reinterpret_cast<uint32_t *>(out)[(size_t)blockIdx.z * npx + idx] = swz(o, sel);
 }
 
 // ---------------------------------------------------------------------------------
@@ -1293,6 +1318,7 @@ struct FsrArgs {
     size_t ipx, opx;   // pixels per input / output frame
     float sx, sy;      // f32(iw) / f32(ow), f32(ih) / f32(oh)   (host, IEEE)
     float easu_sharp, rcas_sharp;
+    uint32_t sel;      // input channel order (kSelRGBA / kSelBGRA)
 };
 
 __device__ __forceinline__ float3 fsr_rgb(uint32_t p)
@@ -1400,7 +1426,7 @@ __device__ __forceinline__ uint32_t fsr_easu_px(const uint32_t *__restrict__ in,
     for (int y = 0; y < 4; ++y)
 #pragma unroll
         for (int x = 0; x < 4; ++x) {
-            const float3 c = fsr_rgb(in[(size_t)ys[y] * A.iw + xs[x]]);
+            const float3 c = fsr_rgb(swz(in[(size_t)ys[y] * A.iw + xs[x]], A.sel));
             t[y][x] = make_float4(c.x, c.y, c.z, 0.0f);
         }
     // FsrDirA at (ix, iy): its four neighbours are taps (1,0) (1,2) (0,1) (2,1) of the 4x4 block
@@ -1460,7 +1486,7 @@ __global__ __launch_bounds__(256) void k_fsr1(const FsrArgs A, const int src_cap
         const int n = fw * fh; // <= src_cap (host-checked)
         for (int i = tid; i < n; i += 256) {
             const int ly = i / fw, lx = i - ly * fw;
-            const float3 c = fsr_rgb(in[(size_t)clampi(fy0 + ly, 0, A.ih - 1) * A.iw + clampi(fx0 + lx, 0, A.iw - 1)]);
+            const float3 c = fsr_rgb(swz(in[(size_t)clampi(fy0 + ly, 0, A.ih - 1) * A.iw + clampi(fx0 + lx, 0, A.iw - 1)], A.sel));
             src[i] = make_float4(c.x, c.y, c.z, 0.0f);
         }
         __syncthreads();
@@ -1480,7 +1506,7 @@ __global__ __launch_bounds__(256) void k_fsr1(const FsrArgs A, const int src_cap
         const int gx = clampi(x0 + lx - HALO, 0, A.ow - 1), gy = clampi(y0 + ly - HALO, 0, A.oh - 1);
         uint32_t p;
         if (MODE == FsrMode::Rcas) {
-            p = in[(size_t)gy * A.ow + gx];
+            p = swz(in[(size_t)gy * A.ow + gx], A.sel);
         } else if (SRC_LDS) {
             const float cx = ((float)gx + 0.5f) * A.sx, cy = ((float)gy + 0.5f) * A.sy;
             const int ix = (int)cx, iy = (int)cy;
@@ -1579,9 +1605,9 @@ hipError_t launch_nearest_table(const UpscaleLaunch &L, const DeviceTables &T)
         auto *i32 = reinterpret_cast<const uint32_t *>(in);
         auto *o32 = reinterpret_cast<uint32_t *>(out);
         if (vec)
-            hipLaunchKernelGGL(k_nearest_table<true>, grid, block, 0, L.stream, i32, o32, T.nn_sx, T.nn_sy, L.iw, L.ow, L.oh, rpw, ipx, opx);
+            hipLaunchKernelGGL(k_nearest_table<true>, grid, block, 0, L.stream, i32, o32, T.nn_sx, T.nn_sy, L.iw, L.ow, L.oh, rpw, ipx, opx, L.in_sel);
         else
-            hipLaunchKernelGGL(k_nearest_table<false>, grid, block, 0, L.stream, i32, o32, T.nn_sx, T.nn_sy, L.iw, L.ow, L.oh, rpw, ipx, opx);
+            hipLaunchKernelGGL(k_nearest_table<false>, grid, block, 0, L.stream, i32, o32, T.nn_sx, T.nn_sy, L.iw, L.ow, L.oh, rpw, ipx, opx, L.in_sel);
     });
 }
 
@@ -1591,7 +1617,7 @@ hipError_t launch_nearest_x2(const UpscaleLaunch &L)
     return for_frame_chunks(L, [&](const uint8_t *in, uint8_t *out, uint32_t n) {
         const dim3 block(kWave, 4), grid(cdiv(L.iw, 256), cdiv(L.ih, 4), n);
         hipLaunchKernelGGL(k_nearest_x2, grid, block, 0, L.stream, reinterpret_cast<const uint32_t *>(in),
-                           reinterpret_cast<uint32_t *>(out), L.iw, L.ih, ipx, opx);
+                           reinterpret_cast<uint32_t *>(out), L.iw, L.ih, ipx, opx, L.in_sel);
     });
 }
 
@@ -1606,7 +1632,7 @@ hipError_t launch_bilinear_table(const UpscaleLaunch &L, const DeviceTables &T, 
         auto *o32 = reinterpret_cast<uint32_t *>(out);
 #define NUS_BL(V, W)                                                                                         \
     hipLaunchKernelGGL((k_bilinear_table<V, W>), grid, block, 0, L.stream, i32, o32, T.bl_x0, T.bl_fx, T.bl_y0, \
-                       T.bl_fy, L.iw, L.ih, L.ow, L.oh, rpw, ipx, opx)
+                       T.bl_fy, L.iw, L.ih, L.ow, L.oh, rpw, ipx, opx, L.in_sel)
         if (vec && wgsl_form) NUS_BL(true, true);
         else if (vec) NUS_BL(true, false);
         else if (wgsl_form) NUS_BL(false, true);
@@ -1621,7 +1647,7 @@ hipError_t launch_bilinear_x2_int(const UpscaleLaunch &L)
     return for_frame_chunks(L, [&](const uint8_t *in, uint8_t *out, uint32_t n) {
         const dim3 block(kWave, 4), grid(cdiv(L.iw, 256), cdiv(L.ih, 4), n);
         hipLaunchKernelGGL(k_bilinear_x2_int, grid, block, 0, L.stream, reinterpret_cast<const uint32_t *>(in),
-                           reinterpret_cast<uint32_t *>(out), L.iw, L.ih, ipx, opx);
+                           reinterpret_cast<uint32_t *>(out), L.iw, L.ih, ipx, opx, L.in_sel);
     });
 }
 
@@ -1640,10 +1666,10 @@ hipError_t launch_lanczos_general(const UpscaleLaunch &L, const DeviceTables &T,
         auto *o32 = reinterpret_cast<uint32_t *>(out);
         if (exact)
             hipLaunchKernelGGL(k_lanczos_general<true>, grid, block, 0, L.stream, i32, o32, T.lz_lx, T.lz_nx, T.lz_wx,
-                               T.lz_ly, T.lz_ny, T.lz_wy, T.lz_stride, L.iw, L.ow, L.oh, ncols, split, gap, ipx, opx);
+                               T.lz_ly, T.lz_ny, T.lz_wy, T.lz_stride, L.iw, L.ow, L.oh, ncols, split, gap, ipx, opx, L.in_sel);
         else
             hipLaunchKernelGGL(k_lanczos_general<false>, grid, block, 0, L.stream, i32, o32, T.lz_lx, T.lz_nx, T.lz_wx,
-                               T.lz_ly, T.lz_ny, T.lz_wy, T.lz_stride, L.iw, L.ow, L.oh, ncols, split, gap, ipx, opx);
+                               T.lz_ly, T.lz_ny, T.lz_wy, T.lz_stride, L.iw, L.ow, L.oh, ncols, split, gap, ipx, opx, L.in_sel);
     });
 }
 
@@ -1662,7 +1688,7 @@ hipError_t launch_resize_rows(const UpscaleLaunch &L, const DeviceTables &T, boo
         auto *o32 = reinterpret_cast<uint32_t *>(out);
 #define NUS_RR(E, V, S)                                                                                             \
     hipLaunchKernelGGL((k_resize_rows<E, V, S>), grid, block, lds, L.stream, i32, o32, T.lz_lx, T.lz_nx, T.lz_wx, T.lz_ly, \
-                       T.lz_ny, T.lz_wy, T.lz_stride, L.iw, L.ow, L.oh, (uint32_t)rpb, ncols_max, ipx, opx)
+                       T.lz_ny, T.lz_wy, T.lz_stride, L.iw, L.ow, L.oh, (uint32_t)rpb, ncols_max, ipx, opx, L.in_sel)
         if (exact) {
             if (vec) { if (small_taps) NUS_RR(true, true, true); else NUS_RR(true, true, false); }
             else { if (small_taps) NUS_RR(true, false, true); else NUS_RR(true, false, false); }
@@ -1691,6 +1717,7 @@ hipError_t launch_lanczos_x2(const UpscaleLaunch &L, const DeviceTables &T, bool
     A.in_b_frame_bytes = L.in_b_stride;
     A.out_frame_bytes = (size_t)L.ow * L.oh * 4;
     A.t = L.blend_t;
+    A.sel = L.in_sel;
     const int blend = L.in_b == nullptr ? 0 : (L.blend_t == 0.5f ? 1 : 2);
     const uint32_t nwaves = A.nstrips * A.nrowblocks;
     // dev knob: unused dynamic LDS per block, to study occupancy sensitivity (0 in production)
@@ -1725,6 +1752,7 @@ hipError_t launch_lanczos_x2_edges(const UpscaleLaunch &L, const DeviceTables &T
     A.in_b_frame_bytes = L.in_b_stride;
     A.out_frame_bytes = (size_t)L.ow * L.oh * 4;
     A.t = L.blend_t;
+    A.sel = L.in_sel;
     const int blend = L.in_b == nullptr ? 0 : (L.blend_t == 0.5f ? 1 : 2);
     return for_frame_chunks(L, [&](const uint8_t *in, uint8_t *out, uint32_t n) {
         A.in = in;
@@ -1770,6 +1798,7 @@ hipError_t launch_fsr1(const UpscaleLaunch &L, int mode, float easu_sharpness, f
     A.sy = (float)L.ih / (float)L.oh;
     A.easu_sharp = easu_sharpness;
     A.rcas_sharp = rcas_sharpness;
+    A.sel = L.in_sel;
     const bool vec = (L.ow % 4) == 0;
     // LDS source tile when every tile's footprint fits beside the pixel tile in 64 KiB: 3072 texels for
     // EASU alone (any up-scaling ratio), 1700 next to the fused mode's float4 tile (ratios >= ~1.3)
@@ -1939,13 +1968,13 @@ hipError_t launch_warp_blend(const WarpLaunch &L)
             const size_t items = vec ? npx / 4 : npx;
             const dim3 block(256), grid((uint32_t)((items + 255) / 256), n);
             if (vec)
-                hipLaunchKernelGGL(k_blend_zero_flow<true>, grid, block, 0, L.stream, a, b, out, L.a_stride, L.b_stride, npx, L.t);
+                hipLaunchKernelGGL(k_blend_zero_flow<true>, grid, block, 0, L.stream, a, b, out, L.a_stride, L.b_stride, npx, L.t, L.in_sel);
             else
-                hipLaunchKernelGGL(k_blend_zero_flow<false>, grid, block, 0, L.stream, a, b, out, L.a_stride, L.b_stride, npx, L.t);
+                hipLaunchKernelGGL(k_blend_zero_flow<false>, grid, block, 0, L.stream, a, b, out, L.a_stride, L.b_stride, npx, L.t, L.in_sel);
         } else {
             const dim3 block(kWave, 4), grid(cdiv(L.w, 64), cdiv(L.h, 4), n);
             hipLaunchKernelGGL(k_warp_blend_flow, grid, block, 0, L.stream, a, b, L.flow + (size_t)done * npx * 2, out,
-                               L.a_stride, L.b_stride, L.w, L.h, L.t);
+                               L.a_stride, L.b_stride, L.w, L.h, L.t, L.in_sel);
         }
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;

@@ -27,6 +27,10 @@ struct DeviceTables {
     float lz_wx_left[48] = {0}, lz_wx_right[48] = {0}; // phase-frame weights of the 8 edge outputs per side
 };
 
+// v_perm_b32 selectors applied to every loaded input pixel: RGBA8 as is, or BGRA8 (capture order,
+// nu_scaler_core/src/lib.rs:251-270) swizzled to RGBA on the way in.
+constexpr uint32_t kSelRGBA = 0x03020100u, kSelBGRA = 0x03000102u;
+
 struct UpscaleLaunch {
     const uint8_t *in = nullptr; // n_frames contiguous frames
     uint8_t *out = nullptr;
@@ -39,6 +43,7 @@ struct UpscaleLaunch {
     const uint8_t *in_b = nullptr;
     size_t in_b_stride = 0;
     float blend_t = 0.5f;
+    uint32_t in_sel = kSelRGBA; // input channel order
 };
 
 // Kernel variants (chosen once at initialize).
@@ -89,6 +94,7 @@ struct WarpLaunch {
     float t = 0.5f;
     uint32_t n_pairs = 1;
     hipStream_t stream = nullptr;
+    uint32_t in_sel = kSelRGBA; // channel order of both input frames (the output is RGBA)
 };
 
 hipError_t launch_warp_blend(const WarpLaunch &L);

@@ -72,6 +72,13 @@ class WgpuFrameInterpolator:
         self._raise(self._lib.nus_interp_interpolate_device(self._h, d_a, a_stride, d_b, b_stride, d_flow or None,
                                                             width, height, float(time_t), d_out, n_pairs, stream or None))
 
+    def set_input_format(self, fmt: str) -> None:
+        """"rgba" (default) or "bgra" for both input frames; the new frame is RGBA."""
+        f = {"rgba": C.FORMAT_RGBA8, "bgra": C.FORMAT_BGRA8}.get(str(fmt).lower())
+        if f is None:
+            raise ValueError("input format must be 'rgba' or 'bgra'")
+        self._raise(self._lib.nus_interp_set_input_format(self._h, f))
+
     def get_last_gpu_duration_ms(self) -> Optional[float]:
         """wgpu_interpolator.rs:494-497: None until an interpolation has run."""
         ms = ctypes.c_double()

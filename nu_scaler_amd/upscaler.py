@@ -170,6 +170,14 @@ class PyWgpuUpscaler:
     def set_option(self, key: str, value: int) -> None:
         self._check(self._lib.nus_upscaler_set_option(self._h, key.encode(), int(value)))
 
+    def set_input_format(self, fmt: str) -> None:
+        """"rgba" (default) or "bgra": captured frames are swizzled inside the kernels' loads
+        (the reference's CPU loop, lib.rs:251-270).  The output is always RGBA."""
+        f = {"rgba": C.FORMAT_RGBA8, "bgra": C.FORMAT_BGRA8}.get(str(fmt).lower())
+        if f is None:
+            raise ValueError("input format must be 'rgba' or 'bgra'")
+        self._check(self._lib.nus_upscaler_set_input_format(self._h, f))
+
     def set_sharpness(self, easu: float = -1.0, rcas: float = -1.0) -> None:
         """FSR1-style passes: shader `sharpness` uniforms; negative keeps the quality default."""
         self._check(self._lib.nus_upscaler_set_sharpness(self._h, float(easu), float(rcas)))

@@ -459,3 +459,61 @@ def test_device_path_is_graph_capturable(nsc, oracle_mod):
         assert np.array_equal(mid[i].cpu().numpy(), m)
         assert np.array_equal(up_real[i].cpu().numpy(), oracle_mod.lanczos3(frames_np[i], 2 * w, 2 * h))
         assert np.array_equal(up_mid[i].cpu().numpy(), oracle_mod.lanczos3(m, 2 * w, 2 * h))
+
+
+# ---- BGRA input: the capture feed's channel order, swizzled inside the kernels' loads ----------
+
+def _bgra(img):
+    return np.ascontiguousarray(img[..., [2, 1, 0, 3]])
+
+
+@pytest.mark.parametrize("alg,kw", [("nearest", {}), ("bilinear", {}), ("bilinear", {"bilinear_variant": "wgsl"}),
+                                    ("lanczos3", {}), ("lanczos3", {"lanczos_mode": "exact"}), ("bicubic", {}),
+                                    ("triangle", {}), ("fsr1", {}), ("easu", {})])
+@pytest.mark.parametrize("dims,opts", [(((252, 40), (504, 80)), {}), (((252, 40), (504, 80)), {"force_general": 1}),
+                                       (((48, 27), (72, 41)), {}), (((64, 36), (128, 72)), {"force_per_pixel": 1, "force_general": 1}),
+                                       (((100, 40), (30, 12)), {})])
+def test_bgra_input_equals_swizzle_then_upscale(nsc, oracle_mod, alg, kw, dims, opts):
+    """Upscaling a BGRA frame with input format "bgra" == upscaling its RGBA swizzle, for every kernel variant."""
+    (w, h), (ow, oh) = dims
+    img = oracle_mod.gen_noise(w, h, 41)
+    want, u0 = _up(nsc, alg, img, ow, oh, options=dict(opts), **kw)
+    u = nsc.PyWgpuUpscaler("quality", alg, **kw)
+    for k, v in opts.items():
+        u.set_option(k, v)
+    u.set_input_format("bgra")
+    u.initialize(w, h, ow, oh)
+    got = np.frombuffer(u.upscale(_bgra(img).tobytes()), np.uint8).reshape(oh, ow, 4)
+    assert u.kernel_variant == u0.kernel_variant
+    assert np.array_equal(got, want), (alg, u.kernel_variant)
+    u.set_input_format("rgba")  # switchable at any time
+    assert np.array_equal(np.frombuffer(u.upscale(img.tobytes()), np.uint8).reshape(oh, ow, 4), want)
+    with pytest.raises(ValueError):
+        u.set_input_format("argb")
+
+
+def test_bgra_input_interpolator_and_fused_blend(nsc, oracle_mod):
+    import torch
+    w, h = 252, 40
+    a, b = oracle_mod.gen_noise(w, h, 42), oracle_mod.gen_noise(w, h, 43)
+    flow = np.zeros((h, w, 2), np.float32)
+    flow[..., 0], flow[..., 1] = 1.25, -0.5
+    it = nsc.WgpuFrameInterpolator()
+    it.set_input_format("bgra")
+    for f in (None, flow):
+        for t in (0.5, 0.3):
+            got = np.frombuffer(it.interpolate_py(_bgra(a).tobytes(), _bgra(b).tobytes(), w, h, time_t=t, flow=f), np.uint8)
+            assert np.array_equal(got.reshape(h, w, 4), oracle_mod.warp_blend(a, b, f, t))
+    # fused blend + x2 upscale on BGRA pairs
+    for alg in ("lanczos3", "bicubic"):
+        for t in (0.5, 0.3):
+            u = nsc.PyWgpuUpscaler("quality", alg)
+            u.initialize(w, h, 2 * w, 2 * h)
+            mid = oracle_mod.warp_blend(a, b, None, t)
+            want = np.frombuffer(u.upscale(mid.tobytes()), np.uint8).reshape(2 * h, 2 * w, 4)
+            u.set_input_format("bgra")
+            da, db = torch.from_numpy(_bgra(a)).cuda(), torch.from_numpy(_bgra(b)).cuda()
+            out = torch.empty((2 * h, 2 * w, 4), dtype=torch.uint8, device="cuda")
+            u.upscale_blend_device(da.data_ptr(), 0, db.data_ptr(), 0, t, out.data_ptr(), 1, torch.cuda.current_stream().cuda_stream)
+            torch.cuda.synchronize()
+            assert np.array_equal(out.cpu().numpy(), want), (alg, t)
