@@ -517,3 +517,50 @@ def test_bgra_input_interpolator_and_fused_blend(nsc, oracle_mod):
             u.upscale_blend_device(da.data_ptr(), 0, db.data_ptr(), 0, t, out.data_ptr(), 1, torch.cuda.current_stream().cuda_stream)
             torch.cuda.synchronize()
             assert np.array_equal(out.cpu().numpy(), want), (alg, t)
+
+
+# ---- seeded random shape sweep: ragged widths around the kernels' segment sizes --------------------
+
+def _random_dims(seed, n):
+    rng = np.random.default_rng(seed)
+    dims = []
+    for _ in range(n):
+        w = int(rng.choice([rng.integers(1, 40), rng.integers(60, 70), rng.integers(120, 135), rng.integers(250, 262),
+                            rng.integers(505, 520)]))
+        h = int(rng.integers(1, 48))
+        kind = rng.integers(0, 4)
+        if kind == 0:  # exact x2
+            ow, oh = 2 * w, 2 * h
+        elif kind == 1:  # any up-scale, independent per axis
+            ow, oh = int(w * rng.uniform(1.0, 3.2)) + 1, int(h * rng.uniform(1.0, 3.2)) + 1
+        elif kind == 2:  # down-scale (kept within the 32-tap window of the resize filters)
+            ow, oh = max(1, int(w / rng.uniform(1.0, 3.0))), max(1, int(h / rng.uniform(1.0, 3.0)))
+        else:  # mixed
+            ow, oh = int(w * rng.uniform(1.0, 2.5)) + 1, max(1, int(h / rng.uniform(1.0, 2.5)))
+        dims.append(((w, h), (ow, oh)))
+    return dims
+
+
+@pytest.mark.parametrize("alg", ["nearest", "bilinear", "lanczos3", "bicubic", "triangle", "fsr1"])
+def test_random_shape_sweep(nsc, oracle_mod, alg):
+    ref = {"nearest": oracle_mod.nearest, "bilinear": oracle_mod.bilinear,
+           "lanczos3": lambda i, ow, oh: oracle_mod.resize(i, ow, oh, oracle_mod.FILTER_LANCZOS3),
+           "bicubic": lambda i, ow, oh: oracle_mod.resize(i, ow, oh, oracle_mod.FILTER_CATMULLROM),
+           "triangle": lambda i, ow, oh: oracle_mod.resize(i, ow, oh, oracle_mod.FILTER_TRIANGLE),
+           "fsr1": lambda i, ow, oh: oracle_mod.fsr1(i, ow, oh, 0.0, 0.7)}[alg]
+    resize = alg in ("lanczos3", "bicubic", "triangle")
+    seen = set()
+    seed = {"nearest": 1, "bilinear": 2, "lanczos3": 3, "bicubic": 4, "triangle": 5, "fsr1": 6}[alg]
+    for k, ((w, h), (ow, oh)) in enumerate(_random_dims(seed, 40)):
+        img = oracle_mod.gen_noise(w, h, 100 + k)
+        want = ref(img, ow, oh)
+        if resize:
+            got, u = _up(nsc, alg, img, ow, oh, lanczos_mode="exact")
+            assert np.array_equal(got, want), (alg, (w, h), (ow, oh), u.kernel_variant)
+            got_f, _ = _up(nsc, alg, img, ow, oh)
+            assert _maxdiff(got_f, want) <= 1, (alg, (w, h), (ow, oh))
+        else:
+            got, u = _up(nsc, alg, img, ow, oh)
+            assert np.array_equal(got, want), (alg, (w, h), (ow, oh), u.kernel_variant)
+        seen.add(u.kernel_variant)
+    assert len(seen) >= (2 if alg != "fsr1" else 1), seen
