@@ -617,12 +617,24 @@ __device__ __forceinline__ void cvt_row(const uint4 raw, float (&dst)[16])
         for (int c = 0; c < 4; ++c) dst[m * 4 + c] = ch_f32(px[m], c);
 }
 
+// 1 when every pixel of this input row held by the wave (all 64 lanes x 4 columns) is opaque.
+// Rows whose whole 6-row tap window is opaque take the 3-channel path below: alpha of the output is
+// then 255 on both the CPU and here -- the taps are normalised, sum(w) * 255 is within 1e-3 of 255 in
+// f32 -- so it is stored as a constant and a quarter of the per-pixel arithmetic is skipped.
+// Captured and rendered frames are opaque; frames with real alpha just take the 4-channel path.
+__device__ __forceinline__ uint32_t row_is_opaque(const uint4 raw)
+{
+    const bool lane_opaque = (raw.x & raw.y & raw.z & raw.w) >= 0xFF000000u;
+    return __builtin_amdgcn_ballot_w64(!lane_opaque) == 0ull ? 1u : 0u;
+}
+
 // Vertical pass of one output row: 6 taps from window slots BASE .. BASE+5 (mod 6).
-template <bool EXACT, int BASE>
+template <bool EXACT, int BASE, bool ALPHA>
 __device__ __forceinline__ void lanczos_x2_vpass(const float (&win)[6][16], const float (&w)[6], float (&V)[16])
 {
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
+        if (!ALPHA && (k & 3) == 3) continue; // V[alpha] is not read by the 3-channel horizontal pass
         float acc = EXACT ? win[BASE % 6][k] * w[0] : __builtin_fmaf(win[BASE % 6][k], w[0], 0.0f);
 #pragma unroll
         for (int j = 1; j < 6; ++j) acc = mac<EXACT>(acc, win[(BASE + j) % 6][k], w[j]);
@@ -648,13 +660,14 @@ __device__ __forceinline__ void lanczos_x2_vpass_edge(const float (&win)[6][16],
 }
 
 // Horizontal pass of the lane's 8 output pixels, convert + pack, and the two 16-B stores.
-template <bool EXACT>
+template <bool EXACT, bool ALPHA>
 __device__ __forceinline__ void lanczos_x2_hpass_store(const float (&V)[16], const PhaseWeights &W,
                                                        __amdgpu_buffer_rsrc_t rs, uint32_t off)
 {
-    uint32_t o[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    constexpr uint32_t a0 = ALPHA ? 0u : 0xFF000000u; // 3-channel path: opaque output
+    uint32_t o[8] = {a0, a0, a0, a0, a0, a0, a0, a0};
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
+    for (int c = 0; c < (ALPHA ? 4 : 3); ++c) {
         float e[10]; // vertical sums of input columns c0-3 .. c0+6 for this channel
         e[0] = lane_up(V[1 * 4 + c]);
         e[1] = lane_up(V[2 * 4 + c]);
@@ -694,7 +707,7 @@ __device__ __forceinline__ void lanczos_x2_hpass_store(const float (&V)[16], con
 // Row r-3 dies after the even phase, so row r+3 is converted into its slot BETWEEN the two
 // phases: only 6 rows (96 VGPRs) are ever live, not 7.
 template <bool EXACT, int BLEND, int S>
-__device__ __forceinline__ void lanczos_x2_step(float (&win)[6][16], RowRaw<BLEND> (&raw)[2], int r, int cl,
+__device__ __forceinline__ void lanczos_x2_step(float (&win)[6][16], RowRaw<BLEND> (&raw)[2], uint32_t &opaque, int r, int cl,
                                                 uint32_t lane_off, const LanczosX2Args &A, const PhaseWeights &W,
                                                 const uint8_t *src, const uint8_t *src_b, __amdgpu_buffer_rsrc_t rs)
 {
@@ -702,24 +715,39 @@ __device__ __forceinline__ void lanczos_x2_step(float (&win)[6][16], RowRaw<BLEN
     const uint32_t off0 = lane_off + (uint32_t)(2 * r) * row_bytes;
     const bool interior = r >= 4 && r + 5 <= (int)A.ih; // wave-uniform
     float V[16];
-    if (interior)
-        lanczos_x2_vpass<EXACT, S>(win, W.e, V);
-    else
+    // `opaque`: bit j = input row (newest - j) is opaque; the six newest rows are this phase's taps
+    if (!interior) {
         lanczos_x2_vpass_edge<EXACT, S>(win, A.wy6, 2 * (uint32_t)r, V);
-    lanczos_x2_hpass_store<EXACT>(V, W, rs, off0);
+        lanczos_x2_hpass_store<EXACT, true>(V, W, rs, off0);
+    } else if (!EXACT && (opaque & 0x3Fu) == 0x3Fu) { // wave-uniform; FMA mode only (EXACT is the register-hungry debug mode)
+        lanczos_x2_vpass<EXACT, S, false>(win, W.e, V);
+        lanczos_x2_hpass_store<EXACT, false>(V, W, rs, off0);
+    } else {
+        lanczos_x2_vpass<EXACT, S, true>(win, W.e, V);
+        lanczos_x2_hpass_store<EXACT, true>(V, W, rs, off0);
+    }
     // row r+3 in, then request row r+5 into the same buffer (consumed two steps from now;
     // vmcnt retires in order, so that wait only sits behind stores at least a step old)
-    cvt_row(resolve_row<BLEND>(raw[S & 1], A.t, A.sel), win[S % 6]);
+    {
+        const uint4 px = resolve_row<BLEND>(raw[S & 1], A.t, A.sel);
+        if (!EXACT) opaque = (opaque << 1) | row_is_opaque(px);
+        cvt_row(px, win[S % 6]);
+    }
     {
         int rn = r + 5;
         rn = rn < (int)A.ih - 1 ? rn : (int)A.ih - 1;
         raw[S & 1] = fetch_row<BLEND>(src, src_b, ((size_t)rn * A.iw + cl) * 4);
     }
-    if (interior)
-        lanczos_x2_vpass<EXACT, S + 1>(win, W.o, V);
-    else
+    if (!interior) {
         lanczos_x2_vpass_edge<EXACT, S + 1>(win, A.wy6, 2 * (uint32_t)r + 1, V);
-    lanczos_x2_hpass_store<EXACT>(V, W, rs, off0 + row_bytes);
+        lanczos_x2_hpass_store<EXACT, true>(V, W, rs, off0 + row_bytes);
+    } else if (!EXACT && (opaque & 0x3Fu) == 0x3Fu) {
+        lanczos_x2_vpass<EXACT, S + 1, false>(win, W.o, V);
+        lanczos_x2_hpass_store<EXACT, false>(V, W, rs, off0 + row_bytes);
+    } else {
+        lanczos_x2_vpass<EXACT, S + 1, true>(win, W.o, V);
+        lanczos_x2_hpass_store<EXACT, true>(V, W, rs, off0 + row_bytes);
+    }
 }
 
 // Exact x2 Lanczos-3.  One wave owns a strip of 256 input columns (4 per lane; lanes 0
@@ -766,17 +794,22 @@ __global__ __launch_bounds__(256) void k_lanczos3_x2(const LanczosX2Args A)
         W.o[j] = vgpr(A.wxo[j]);
     }
     float win[6][16];
+    uint32_t opaque = 0;
 #pragma unroll
-    for (int j = 0; j < 6; ++j) cvt_row(resolve_row<BLEND>(load_row(r0 - 3 + j), A.t, A.sel), win[j]);
+    for (int j = 0; j < 6; ++j) {
+        const uint4 px = resolve_row<BLEND>(load_row(r0 - 3 + j), A.t, A.sel);
+        if (!EXACT) opaque = (opaque << 1) | row_is_opaque(px);
+        cvt_row(px, win[j]);
+    }
     RowRaw<BLEND> raw[2] = {load_row(r0 + 3), load_row(r0 + 4)};
     for (int rbase = r0; rbase < r_end; rbase += 6) {
         // 6-way unrolled so the rotating window indices are compile-time constants.
-        if (rbase + 0 < r_end) lanczos_x2_step<EXACT, BLEND, 0>(win, raw, rbase + 0, cl, lane_off, A, W, src, src_b, rs);
-        if (rbase + 1 < r_end) lanczos_x2_step<EXACT, BLEND, 1>(win, raw, rbase + 1, cl, lane_off, A, W, src, src_b, rs);
-        if (rbase + 2 < r_end) lanczos_x2_step<EXACT, BLEND, 2>(win, raw, rbase + 2, cl, lane_off, A, W, src, src_b, rs);
-        if (rbase + 3 < r_end) lanczos_x2_step<EXACT, BLEND, 3>(win, raw, rbase + 3, cl, lane_off, A, W, src, src_b, rs);
-        if (rbase + 4 < r_end) lanczos_x2_step<EXACT, BLEND, 4>(win, raw, rbase + 4, cl, lane_off, A, W, src, src_b, rs);
-        if (rbase + 5 < r_end) lanczos_x2_step<EXACT, BLEND, 5>(win, raw, rbase + 5, cl, lane_off, A, W, src, src_b, rs);
+        if (rbase + 0 < r_end) lanczos_x2_step<EXACT, BLEND, 0>(win, raw, opaque, rbase + 0, cl, lane_off, A, W, src, src_b, rs);
+        if (rbase + 1 < r_end) lanczos_x2_step<EXACT, BLEND, 1>(win, raw, opaque, rbase + 1, cl, lane_off, A, W, src, src_b, rs);
+        if (rbase + 2 < r_end) lanczos_x2_step<EXACT, BLEND, 2>(win, raw, opaque, rbase + 2, cl, lane_off, A, W, src, src_b, rs);
+        if (rbase + 3 < r_end) lanczos_x2_step<EXACT, BLEND, 3>(win, raw, opaque, rbase + 3, cl, lane_off, A, W, src, src_b, rs);
+        if (rbase + 4 < r_end) lanczos_x2_step<EXACT, BLEND, 4>(win, raw, opaque, rbase + 4, cl, lane_off, A, W, src, src_b, rs);
+        if (rbase + 5 < r_end) lanczos_x2_step<EXACT, BLEND, 5>(win, raw, opaque, rbase + 5, cl, lane_off, A, W, src, src_b, rs);
     }
 }
 

@@ -564,3 +564,33 @@ def test_random_shape_sweep(nsc, oracle_mod, alg):
             assert np.array_equal(got, want), (alg, (w, h), (ow, oh), u.kernel_variant)
         seen.add(u.kernel_variant)
     assert len(seen) >= (2 if alg != "fsr1" else 1), seen
+
+
+@pytest.mark.parametrize("alg", ["lanczos3", "bicubic"])
+def test_lanczos_x2_opaque_and_mixed_alpha_rows(nsc, oracle_mod, alg):
+    """The x2 kernel drops to 3 channels where the whole tap window of a wave is opaque; frames that are
+    opaque, opaque in bands, or opaque except for single pixels must all match the 4-channel result."""
+    filt = oracle_mod.FILTER_LANCZOS3 if alg == "lanczos3" else oracle_mod.FILTER_CATMULLROM
+    w, h = 520, 90  # three strips wide (two full + a ragged one), a few row blocks tall
+    base = oracle_mod.gen_noise(w, h, 77)
+    variants = {}
+    v = base.copy(); v[..., 3] = 255; variants["opaque"] = v
+    v = base.copy(); v[..., 3] = 255; v[20:27, :, 3] = base[20:27, :, 3]; variants["band"] = v
+    v = base.copy(); v[..., 3] = 255; v[40, 300, 3] = 254; v[0, 0, 3] = 0; v[h - 1, w - 1, 3] = 17; variants["pixels"] = v
+    v = base.copy(); v[..., 3] = 255; v[:, 248:256, 3] = 7; variants["strip_seam"] = v
+    for name, img in variants.items():
+        want = oracle_mod.resize(img, 2 * w, 2 * h, filt)
+        got, u = _up(nsc, alg, img, 2 * w, 2 * h)
+        assert u.kernel_variant == "lanczos3_x2_regwin"
+        assert _maxdiff(got, want) <= 1, name
+        opaque_out = want[..., 3] == 255  # wherever the CPU says 255, so must the GPU (constant or 4-channel path)
+        if name == "opaque":
+            assert opaque_out.all() and (got[..., 3] == 255).all()
+        # away from the non-opaque pixels' 6-tap footprint the 3-channel path wrote the constant
+        far = np.ones((2 * h, 2 * w), bool)
+        ys, xs = np.nonzero(img[..., 3] != 255)
+        for y, x in zip(ys.tolist(), xs.tolist()):
+            far[max(0, 2 * y - 8):2 * y + 10, max(0, 2 * x - 8):2 * x + 10] = False
+        assert (got[..., 3][far] == 255).all() and (want[..., 3][far] == 255).all(), name
+        got_e, _ = _up(nsc, alg, img, 2 * w, 2 * h, lanczos_mode="exact")
+        assert np.array_equal(got_e, want), name
