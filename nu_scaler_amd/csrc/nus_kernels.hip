@@ -622,8 +622,14 @@ __device__ __forceinline__ void cvt_row(const uint4 raw, float (&dst)[16])
 // then 255 on both the CPU and here -- the taps are normalised, sum(w) * 255 is within 1e-3 of 255 in
 // f32 -- so it is stored as a constant and a quarter of the per-pixel arithmetic is skipped.
 // Captured and rendered frames are opaque; frames with real alpha just take the 4-channel path.
+#ifndef NUS_OPAQUE_PATH
+#define NUS_OPAQUE_PATH 1 // dev macro: 0 builds the x2 kernel without the 3-channel path (A/B timing only)
+#endif
 __device__ __forceinline__ uint32_t row_is_opaque(const uint4 raw)
 {
+#if !NUS_OPAQUE_PATH
+    return 0u;
+#endif
     const bool lane_opaque = (raw.x & raw.y & raw.z & raw.w) >= 0xFF000000u;
     return __builtin_amdgcn_ballot_w64(!lane_opaque) == 0ull ? 1u : 0u;
 }
