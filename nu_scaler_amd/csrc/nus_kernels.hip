@@ -720,12 +720,16 @@ __device__ __forceinline__ void lanczos_x2_step(float (&win)[6][16], RowRaw<BLEN
     const uint32_t row_bytes = A.iw * 8; // output row: 2*iw pixels
     const uint32_t off0 = lane_off + (uint32_t)(2 * r) * row_bytes;
     const bool interior = r >= 4 && r + 5 <= (int)A.ih; // wave-uniform
+    // The 3-channel path is compiled into the plain FMA-mode kernel only: there it measures -6 % on opaque
+    // frames (profiles/r01_lanczos_opaque_path_ab.txt); in the blend variants the second code path costs
+    // the third wave per SIMD (175 VGPRs) and more than it saves, and EXACT is the register-hungry debug mode.
+    constexpr bool OP = !EXACT && BLEND == 0;
     float V[16];
     // `opaque`: bit j = input row (newest - j) is opaque; the six newest rows are this phase's taps
     if (!interior) {
         lanczos_x2_vpass_edge<EXACT, S>(win, A.wy6, 2 * (uint32_t)r, V);
         lanczos_x2_hpass_store<EXACT, true>(V, W, rs, off0);
-    } else if (!EXACT && (opaque & 0x3Fu) == 0x3Fu) { // wave-uniform; FMA mode only (EXACT is the register-hungry debug mode)
+    } else if (OP && (opaque & 0x3Fu) == 0x3Fu) { // wave-uniform
         lanczos_x2_vpass<EXACT, S, false>(win, W.e, V);
         lanczos_x2_hpass_store<EXACT, false>(V, W, rs, off0);
     } else {
@@ -736,7 +740,7 @@ __device__ __forceinline__ void lanczos_x2_step(float (&win)[6][16], RowRaw<BLEN
     // vmcnt retires in order, so that wait only sits behind stores at least a step old)
     {
         const uint4 px = resolve_row<BLEND>(raw[S & 1], A.t, A.sel);
-        if (!EXACT) opaque = (opaque << 1) | row_is_opaque(px);
+        if (OP) opaque = (opaque << 1) | row_is_opaque(px);
         cvt_row(px, win[S % 6]);
     }
     {
@@ -747,7 +751,7 @@ __device__ __forceinline__ void lanczos_x2_step(float (&win)[6][16], RowRaw<BLEN
     if (!interior) {
         lanczos_x2_vpass_edge<EXACT, S + 1>(win, A.wy6, 2 * (uint32_t)r + 1, V);
         lanczos_x2_hpass_store<EXACT, true>(V, W, rs, off0 + row_bytes);
-    } else if (!EXACT && (opaque & 0x3Fu) == 0x3Fu) {
+    } else if (OP && (opaque & 0x3Fu) == 0x3Fu) {
         lanczos_x2_vpass<EXACT, S + 1, false>(win, W.o, V);
         lanczos_x2_hpass_store<EXACT, false>(V, W, rs, off0 + row_bytes);
     } else {
@@ -804,7 +808,7 @@ __global__ __launch_bounds__(256) void k_lanczos3_x2(const LanczosX2Args A)
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
         const uint4 px = resolve_row<BLEND>(load_row(r0 - 3 + j), A.t, A.sel);
-        if (!EXACT) opaque = (opaque << 1) | row_is_opaque(px);
+        if (!EXACT && BLEND == 0) opaque = (opaque << 1) | row_is_opaque(px);
         cvt_row(px, win[j]);
     }
     RowRaw<BLEND> raw[2] = {load_row(r0 + 3), load_row(r0 + 4)};
