@@ -116,6 +116,45 @@ DEFK2(k_pk_mul, S_PK_MUL)
 DEFK2(k_pk_add, S_PK_ADD)
 DEFK2(k_pk_mov, S_PK_MOV)
 
+// mixes: do the two rate classes overlap (time = max) or serialise (time = sum)?
+#define REP4A(S) S(x0) S(x1) S(x2) S(x3)
+#define REP4B(S) S(x4) S(x5) S(x6) S(x7)
+#define DEFKMIX(NAME, SA, SB)                                                                              \
+    __global__ __launch_bounds__(256) void NAME(float *out, float a, float b, int iters, unsigned long long *clk) \
+    {                                                                                                      \
+        const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime(); \
+        float x0 = threadIdx.x, x1 = x0 + 1, x2 = x0 + 2, x3 = x0 + 3, x4 = x0 + 4, x5 = x0 + 5, x6 = x0 + 6, x7 = x0 + 7; \
+        float va = a + threadIdx.x * 0.0f, vb = b + threadIdx.x * 0.0f;                                   \
+        unsigned u = threadIdx.x * 2654435761u;                                                            \
+        asm volatile("" : "+v"(va), "+v"(vb), "+v"(u));                                                    \
+        for (int i = 0; i < iters; ++i) { SA(x0) SB(x4) SA(x1) SB(x5) SA(x2) SB(x6) SA(x3) SB(x7) }        \
+        if (blockIdx.x == 0 && threadIdx.x == 0) {                                                         \
+            clk[0] = __builtin_amdgcn_s_memtime() - c0;                                                    \
+            clk[1] = __builtin_amdgcn_s_memrealtime() - r0;                                                \
+        }                                                                                                  \
+        out[blockIdx.x * blockDim.x + threadIdx.x] = x0 + x1 + x2 + x3 + x4 + x5 + x6 + x7 + __uint_as_float(u); \
+    }
+DEFKMIX(k_mix_fma_cvtpk, S_FMAC_VV, S_CVTPK)
+DEFKMIX(k_mix_fma_dpp, S_FMAC_VV, S_DPP)
+DEFKMIX(k_mix_fma_mulsv, S_FMAC_VV, S_MUL_SV)
+DEFKMIX(k_mix_fma_fma, S_FMAC_VV, S_FMA_VVV_ACC)
+DEFKMIX(k_mix_fma_dpprow, S_FMAC_VV, S_DPP_ROW)
+DEFKMIX(k_mix_fma_cvtub, S_FMAC_VV, S_CVT_UB3)
+DEFKMIX(k_mix_fma_perm, S_FMAC_VV, S_PERM)
+DEFKMIX(k_mix_fma_lerp, S_FMAC_VV, S_LERP)
+#define S_BPERM(X) asm volatile("ds_bpermute_b32 %0, %1, %2\n" : "=v"(X) : "v"(u), "v"(va));
+DEFKMIX(k_mix_fma_bperm, S_FMAC_VV, S_BPERM)
+#define S_FMAC_DPPW(X) asm volatile("v_fmac_f32_dpp %0, %1, %2 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(X) : "v"(va), "v"(vb));
+DEFKMIX(k_mix_fma_fmadpp, S_FMAC_VV, S_FMAC_DPPW)
+DEFK(k_fmadppw, S_FMAC_DPPW)
+#define S_FMAC2_DPPW(X) S_FMAC_VV(X) S_FMAC_VV(X) S_FMAC_DPPW(X) S_FMAC_VV(X)
+DEFK(k_mix_3fma_1fmadpp, S_FMAC2_DPPW)
+// 3 fmac : 1 dpp
+#define S_FMAC3_DPP(X) S_FMAC_VV(X) S_FMAC_VV(X) S_FMAC_VV(X) S_DPP(X)
+DEFK(k_mix_3fma_1dpp, S_FMAC3_DPP)
+#define S_FMAC3_CVTPK(X) S_FMAC_VV(X) S_FMAC_VV(X) S_FMAC_VV(X) S_CVTPK(X)
+DEFK(k_mix_3fma_1cvtpk, S_FMAC3_CVTPK)
+
 typedef void (*kern_t)(float *, float, float, int, unsigned long long *);
 
 int main()
@@ -132,7 +171,15 @@ int main()
         {"v_fma_mix_f32 f16lo", k_mix_lo}, {"v_cvt_f32_f16", k_cvt_f16}, {"v_lerp_u8", k_lerp}, {"v_dot2_f32_f16", k_dot2},
         {"v_dot2c_f32_f16", k_dot2c}, {"v_mul_f32_sdwa", k_sdwa_mul},
         {"v_pk_fma_f32 (2 fma)", k_pk_fma}, {"v_pk_fma_f32 bcast lo", k_pk_fma_bcast}, {"v_pk_mul_f32", k_pk_mul},
-        {"v_pk_add_f32", k_pk_add}, {"v_pk_mov_b32", k_pk_mov}};
+        {"v_pk_add_f32", k_pk_add}, {"v_pk_mov_b32", k_pk_mov},
+        {"mix 4 fmac + 4 cvt_pk_u8", k_mix_fma_cvtpk}, {"mix 4 fmac + 4 mov_dpp", k_mix_fma_dpp},
+        {"mix 4 fmac + 4 mul s,v", k_mix_fma_mulsv}, {"mix 4 fmac + 4 fma", k_mix_fma_fma},
+        {"mix 4 fmac + 4 dpp row_shr", k_mix_fma_dpprow}, {"mix 4 fmac + 4 cvt_f32_ubyte3", k_mix_fma_cvtub},
+        {"mix 4 fmac + 4 v_perm", k_mix_fma_perm}, {"mix 4 fmac + 4 v_lerp_u8", k_mix_fma_lerp},
+        {"mix 4 fmac + 4 ds_bpermute", k_mix_fma_bperm}, {"mix 24 fmac + 8 dpp (x4 count)", k_mix_3fma_1dpp},
+        {"mix 24 fmac + 8 cvt_pk (x4 count)", k_mix_3fma_1cvtpk},
+        {"v_fmac_f32_dpp wave_shr", k_fmadppw}, {"mix 4 fmac + 4 fmac_dpp wave_shr", k_mix_fma_fmadpp},
+        {"mix 24 fmac + 8 fmac_dpp (x4 count)", k_mix_3fma_1fmadpp}};
     const int iters = 20000;
     for (int occ : {2048, 768}) { // 8 and 3 waves per SIMD
         for (auto &e : ks) {
