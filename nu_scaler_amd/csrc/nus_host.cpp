@@ -217,6 +217,8 @@ void HipUpscaler::release()
         if (s.h_out) (void)hipHostFree(s.h_out);
         if (s.k_begin) (void)hipEventDestroy(s.k_begin);
         if (s.k_end) (void)hipEventDestroy(s.k_end);
+        for (hipEvent_t ev : s.chunk_done)
+            if (ev) (void)hipEventDestroy(ev);
         if (s.stream) (void)hipStreamDestroy(s.stream);
         s = Slot();
     }
@@ -525,18 +527,28 @@ int HipUpscaler::upscale_batch(const uint8_t *const *ins, const size_t *in_lens,
         NUS_HIP(hipStreamCreateWithFlags(&S.stream, hipStreamNonBlocking));
         NUS_HIP(hipEventCreate(&S.k_begin));
         NUS_HIP(hipEventCreate(&S.k_end));
+        for (hipEvent_t &ev : S.chunk_done) NUS_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
         NUS_HIP(hipMalloc(reinterpret_cast<void **>(&S.d_in), in_bytes));
         NUS_HIP(hipMalloc(reinterpret_cast<void **>(&S.d_out), out_bytes));
         NUS_HIP(hipHostMalloc(reinterpret_cast<void **>(&S.h_in), in_bytes, hipHostMallocDefault));
         NUS_HIP(hipHostMalloc(reinterpret_cast<void **>(&S.h_out), out_bytes, hipHostMallocDefault));
     }
     // Frame i runs on slot i % nslots: stage -> H2D -> kernel -> D2H, all async on the
-    // slot's stream; the host only blocks when it needs a slot back.
+    // slot's stream; the host only blocks when it needs a slot back.  Pageable outputs come back
+    // in kOutChunks pieces: while piece k is copied out of the pinned buffer, piece k+1 is in flight.
+    const size_t chunk = ((out_bytes + kOutChunks - 1) / kOutChunks + 4095) & ~(size_t)4095;
     std::vector<bool> direct_out(n, false);
     auto retire = [&](size_t i) -> int {
         Slot &S = slots_[i % nslots];
-        NUS_HIP(hipStreamSynchronize(S.stream));
-        if (!direct_out[i]) memcpy(outs[i], S.h_out, out_bytes);
+        if (direct_out[i]) {
+            NUS_HIP(hipStreamSynchronize(S.stream));
+            return kOk;
+        }
+        int k = 0;
+        for (size_t off = 0; off < out_bytes; off += chunk, ++k) {
+            NUS_HIP(hipEventSynchronize(S.chunk_done[k]));
+            memcpy(outs[i] + off, S.h_out + off, out_bytes - off < chunk ? out_bytes - off : chunk);
+        }
         return kOk;
     };
     for (size_t i = 0; i < n; ++i) {
@@ -556,7 +568,16 @@ int HipUpscaler::upscale_batch(const uint8_t *const *ins, const size_t *in_lens,
         if (rc != kOk) return rc;
         NUS_HIP(hipEventRecord(S.k_end, S.stream));
         direct_out[i] = is_pinned_host(outs[i]);
-        NUS_HIP(hipMemcpyAsync(direct_out[i] ? outs[i] : S.h_out, S.d_out, out_bytes, hipMemcpyDeviceToHost, S.stream));
+        if (direct_out[i]) {
+            NUS_HIP(hipMemcpyAsync(outs[i], S.d_out, out_bytes, hipMemcpyDeviceToHost, S.stream));
+        } else {
+            int k = 0;
+            for (size_t off = 0; off < out_bytes; off += chunk, ++k) {
+                const size_t len = out_bytes - off < chunk ? out_bytes - off : chunk;
+                NUS_HIP(hipMemcpyAsync(S.h_out + off, S.d_out + off, len, hipMemcpyDeviceToHost, S.stream));
+                NUS_HIP(hipEventRecord(S.chunk_done[k], S.stream));
+            }
+        }
     }
     for (size_t i = n > (size_t)nslots ? n - nslots : 0; i < n; ++i) {
         int rc = retire(i);

@@ -108,11 +108,16 @@ public:
 
 private:
     static constexpr int kSlots = 3; // buffer_pool_size default (upscale/mod.rs:287-289)
+    // The output frame comes back in kOutChunks pieces so the host copy out of the pinned staging
+    // buffer overlaps the DMA of the next piece (the reference maps, copies to a Vec and copies again:
+    // upscale/mod.rs:1040-1057, lib.rs:111).
+    static constexpr int kOutChunks = 8;
     struct Slot {
         uint8_t *d_in = nullptr, *d_out = nullptr; // HBM
         uint8_t *h_in = nullptr, *h_out = nullptr; // pinned staging
         hipStream_t stream = nullptr;
         hipEvent_t k_begin = nullptr, k_end = nullptr;
+        hipEvent_t chunk_done[kOutChunks] = {}; // D2H of output chunk k has landed in h_out
     };
 
     int fail(int status, const std::string &msg);
