@@ -59,6 +59,16 @@ def parse_args():
     return ap.parse_args()
 
 
+def baseline_metric():
+    """BASELINE.json's metric string, verbatim (the file ships with the repo)."""
+    fallback = "Mpixels/sec (in+out) at 1080p\u21924K \u00d72 upscale + interp, 1/2/4/8 GPU"
+    try:
+        with open(os.path.join(ROOT, "BASELINE.json")) as f:
+            return json.load(f).get("metric", fallback)
+    except (OSError, ValueError):
+        return fallback
+
+
 def cpu_baseline(args, unit_pixels):
     """Time the CPU oracle on a bounded sample of the same workload (single thread, as the
     reference's BasicUpscaler runs; plus an all-cores OpenMP figure for context)."""
@@ -261,7 +271,7 @@ def main():
                         "WRITE_SIZE)*1024 from separate rocprofv3 --pmc passes, scaled to frames_per_launch",
             }
         out = {
-            "metric": "Mpixels/sec (in+out) at 1080p->4K x2 Lanczos-3 upscale + 1 interpolated frame",
+            "metric": baseline_metric(),
             "value": round(value, 1),
             "unit": "Mpix/s",
             "n_gpus": world,
