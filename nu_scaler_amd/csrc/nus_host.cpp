@@ -209,19 +209,7 @@ void HipUpscaler::release()
     for (hipEvent_t ev : prof_events_) (void)hipEventDestroy(ev);
     prof_events_.clear();
     prof_used_ = 0;
-    for (Slot &s : slots_) {
-        if (s.stream) (void)hipStreamSynchronize(s.stream);
-        if (s.d_in) (void)hipFree(s.d_in);
-        if (s.d_out) (void)hipFree(s.d_out);
-        if (s.h_in) (void)hipHostFree(s.h_in);
-        if (s.h_out) (void)hipHostFree(s.h_out);
-        if (s.k_begin) (void)hipEventDestroy(s.k_begin);
-        if (s.k_end) (void)hipEventDestroy(s.k_end);
-        for (hipEvent_t ev : s.chunk_done)
-            if (ev) (void)hipEventDestroy(ev);
-        if (s.stream) (void)hipStreamDestroy(s.stream);
-        s = Slot();
-    }
+    for (Slot &s : slots_) release_slot(s);
     initialized_ = false;
     have_ms_ = false;
 }
@@ -502,6 +490,41 @@ int HipUpscaler::upscale(const uint8_t *in, size_t in_len, uint8_t *out, size_t 
     return upscale_batch(ins, lens, 1, outs, out_cap);
 }
 
+// Stream, events, device frames and pinned staging of one pipeline slot: all or nothing.
+int HipUpscaler::ensure_slot(Slot &S, size_t in_bytes, size_t out_bytes)
+{
+    if (S.stream) return kOk;
+    auto make = [&]() -> int {
+        NUS_HIP(hipStreamCreateWithFlags(&S.stream, hipStreamNonBlocking));
+        NUS_HIP(hipEventCreate(&S.k_begin));
+        NUS_HIP(hipEventCreate(&S.k_end));
+        for (hipEvent_t &ev : S.chunk_done) NUS_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        NUS_HIP(hipMalloc(reinterpret_cast<void **>(&S.d_in), in_bytes));
+        NUS_HIP(hipMalloc(reinterpret_cast<void **>(&S.d_out), out_bytes));
+        NUS_HIP(hipHostMalloc(reinterpret_cast<void **>(&S.h_in), in_bytes, hipHostMallocDefault));
+        NUS_HIP(hipHostMalloc(reinterpret_cast<void **>(&S.h_out), out_bytes, hipHostMallocDefault));
+        return kOk;
+    };
+    const int rc = make();
+    if (rc != kOk) release_slot(S); // a half-built slot must not look usable to the next call
+    return rc;
+}
+
+void HipUpscaler::release_slot(Slot &s)
+{
+    if (s.stream) (void)hipStreamSynchronize(s.stream);
+    if (s.d_in) (void)hipFree(s.d_in);
+    if (s.d_out) (void)hipFree(s.d_out);
+    if (s.h_in) (void)hipHostFree(s.h_in);
+    if (s.h_out) (void)hipHostFree(s.h_out);
+    if (s.k_begin) (void)hipEventDestroy(s.k_begin);
+    if (s.k_end) (void)hipEventDestroy(s.k_end);
+    for (hipEvent_t ev : s.chunk_done)
+        if (ev) (void)hipEventDestroy(ev);
+    if (s.stream) (void)hipStreamDestroy(s.stream);
+    s = Slot();
+}
+
 int HipUpscaler::upscale_batch(const uint8_t *const *ins, const size_t *in_lens, size_t n, uint8_t *const *outs,
                                size_t out_cap_each)
 {
@@ -522,17 +545,23 @@ int HipUpscaler::upscale_batch(const uint8_t *const *ins, const size_t *in_lens,
     NUS_HIP(hipSetDevice(device_));
     const int nslots = n < (size_t)kSlots ? (int)n : kSlots;
     for (int s = 0; s < nslots; ++s) {
-        Slot &S = slots_[s];
-        if (S.stream) continue;
-        NUS_HIP(hipStreamCreateWithFlags(&S.stream, hipStreamNonBlocking));
-        NUS_HIP(hipEventCreate(&S.k_begin));
-        NUS_HIP(hipEventCreate(&S.k_end));
-        for (hipEvent_t &ev : S.chunk_done) NUS_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-        NUS_HIP(hipMalloc(reinterpret_cast<void **>(&S.d_in), in_bytes));
-        NUS_HIP(hipMalloc(reinterpret_cast<void **>(&S.d_out), out_bytes));
-        NUS_HIP(hipHostMalloc(reinterpret_cast<void **>(&S.h_in), in_bytes, hipHostMallocDefault));
-        NUS_HIP(hipHostMalloc(reinterpret_cast<void **>(&S.h_out), out_bytes, hipHostMallocDefault));
+        int rc = ensure_slot(slots_[s], in_bytes, out_bytes);
+        if (rc != kOk) return rc;
     }
+    // whatever way this call ends, nothing may still be reading the caller's input or writing its
+    // (pinned) output buffers afterwards
+    struct Drain {
+        Slot *slots;
+        int n;
+        bool armed = true;
+        ~Drain()
+        {
+            if (!armed) return;
+            for (int s = 0; s < n; ++s)
+                if (slots[s].stream) (void)hipStreamSynchronize(slots[s].stream);
+            (void)hipGetLastError();
+        }
+    } drain{slots_, nslots};
     // Frame i runs on slot i % nslots: stage -> H2D -> kernel -> D2H, all async on the
     // slot's stream; the host only blocks when it needs a slot back.  Pageable outputs come back
     // in kOutChunks pieces: while piece k is copied out of the pinned buffer, piece k+1 is in flight.
@@ -583,6 +612,7 @@ int HipUpscaler::upscale_batch(const uint8_t *const *ins, const size_t *in_lens,
         int rc = retire(i);
         if (rc != kOk) return rc;
     }
+    drain.armed = false; // every frame was retired above
     float ms = 0.0f;
     Slot &last = slots_[(n - 1) % nslots];
     if (hipEventElapsedTime(&ms, last.k_begin, last.k_end) == hipSuccess) {

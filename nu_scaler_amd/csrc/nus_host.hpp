@@ -123,6 +123,8 @@ private:
     int fail(int status, const std::string &msg);
     int fail_hip(hipError_t e, const char *what);
     int ensure_device();
+    int ensure_slot(Slot &s, size_t in_bytes, size_t out_bytes);
+    void release_slot(Slot &s);
     void release();
     int upload_tables();
     bool is_fsr() const { return algorithm_ == Algorithm::Fsr1 || algorithm_ == Algorithm::FsrEasu || algorithm_ == Algorithm::FsrRcas; }
