@@ -118,7 +118,7 @@ def build(force: bool = False) -> str:
     stale = (not os.path.exists(LIB_PATH)
              or os.path.getmtime(LIB_PATH) < max(os.path.getmtime(s) for s in srcs))
     if force or stale:
-        cmd = ["make", "-C", CSRC_DIR] + (["-B"] if force else [])
+        cmd = ["make", "-j4", "-C", CSRC_DIR] + (["-B"] if force else [])
         res = subprocess.run(cmd, capture_output=True, text=True)
         if res.returncode != 0:
             raise RuntimeError("building libnuscaler_hip.so failed:\n" + res.stdout + res.stderr)

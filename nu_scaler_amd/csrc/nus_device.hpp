@@ -1,0 +1,149 @@
+// nus_device.hpp -- device helpers shared by the kernel translation units (nus_k_*.hip), plus the
+// small host helpers their launchers use.  Everything sits in an anonymous namespace: each unit gets
+// its own copy, nothing is exported.
+//
+// All f32 arithmetic that must match the CPU oracle bit for bit is written with separate multiplies
+// and adds; every unit is compiled with -ffp-contract=off and fused multiply-adds appear only where
+// spelled __builtin_fmaf.  No MFMA: no stage is a dense contraction.  Pixels are moved as one u32
+// each, 16 bytes per lane per access wherever alignment allows.
+#pragma once
+
+#include "nus_kernels.hpp"
+
+#include <cstdlib>
+#include <type_traits>
+
+#pragma clang fp contract(off)
+
+namespace nus {
+
+namespace {
+
+constexpr int kWave = 64;
+
+__device__ __forceinline__ float ch_f32(uint32_t p, int c)
+{
+    return (float)((p >> (8 * c)) & 0xffu); // v_cvt_f32_ubyteN
+}
+
+// Rust `clamp(0,255) as u8` / `as u8` (truncate toward zero, saturate, NaN -> 0), inserted as byte c
+// of acc in two
+// instructions: v_floor_f32 makes the argument an integer (for negative inputs floor and trunc differ
+// but both saturate to 0), so v_cvt_pk_u8_f32's rounding mode no longer matters.
+__device__ __forceinline__ uint32_t pack_trunc_u8(float v, int c, uint32_t acc)
+{
+    return __builtin_amdgcn_cvt_pk_u8_f32(floorf(v), c, acc);
+}
+
+// f32::round (half away from zero) of a value clamped to [0,255].
+__device__ __forceinline__ uint32_t round_u8_exact(float v)
+{
+    float c = fminf(fmaxf(v, 0.0f), 255.0f);
+    float r = truncf(c);
+    if (c - r >= 0.5f) r += 1.0f;
+    return (uint32_t)r;
+}
+
+// FMA mode: v_cvt_pk_u8_f32 converts with round-to-nearest-EVEN and saturates to
+// [0,255] in one instruction (measured on gfx950: 0.5->0, 1.5->2, 2.5->2, 254.5->254,
+// -1->0, 256->255; tools/probe.hip).  It differs from f32::round only on exact .5
+// ties, well inside the +-1 LSB contract of this mode.
+__device__ __forceinline__ uint32_t pack_u8_rne(float v, int c, uint32_t acc)
+{
+    return __builtin_amdgcn_cvt_pk_u8_f32(v, c, acc);
+}
+
+template <bool EXACT>
+__device__ __forceinline__ float mac(float acc, float v, float w)
+{
+    if (EXACT) return acc + v * w;   // two roundings, as the CPU restatement
+    return __builtin_fmaf(v, w, acc); // one rounding
+}
+
+// Insert round(clamp(v)) as byte c of acc.
+template <bool EXACT>
+__device__ __forceinline__ uint32_t pack_u8(float v, int c, uint32_t acc)
+{
+    if (EXACT) return acc | (round_u8_exact(v) << (8 * c));
+    return pack_u8_rne(v, c, acc);
+}
+
+__device__ __forceinline__ uint32_t umin(uint32_t a, uint32_t b) { return a < b ? a : b; }
+
+// Input channel order.  Captured frames arrive as BGRA and the reference swizzles them on the CPU before
+// upscaling (nu_scaler_core/src/lib.rs:251-270); here every kernel passes the pixels it loads through one
+// v_perm_b32 whose selector `sel` is kSelRGBA (identity) or kSelBGRA (bytes 2,1,0,3), so a BGRA source
+// costs no extra pass over the frame (UpscaleLaunch::in_sel).
+#ifndef NUS_SWZ_ON_LOAD
+#define NUS_SWZ_ON_LOAD 1 // dev macro: 0 builds the loads without the v_perm_b32 (A/B timing of its cost only)
+#endif
+__device__ __forceinline__ uint32_t swz(uint32_t p, uint32_t sel)
+{
+#if NUS_SWZ_ON_LOAD
+    return __builtin_amdgcn_perm(p, p, sel);
+#else
+    return p;
+#endif
+}
+__device__ __forceinline__ uint4 swz4(const uint4 v, uint32_t sel)
+{
+    return make_uint4(swz(v.x, sel), swz(v.y, sel), swz(v.z, sel), swz(v.w, sel));
+}
+
+
+
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+// Correctly rounded x / y from z = RN(1/y) with one multiply and two FMAs (Markstein): q = RN(x z),
+// r = x - q y (exact in the FMA), result = RN(q + r z).  Equal to the IEEE quotient for every finite
+// x when y = 9 (checked exhaustively on the CPU) and for every y whose mantissa is not all ones;
+// those y take the real division.  Replaces ~11 slow-class instructions per division by 3 fast ones.
+__device__ __forceinline__ float div_by_recip(float x, float y, float z)
+{
+    const float q = x * z;
+    const float r = __builtin_fmaf(-y, q, x);
+    return __builtin_fmaf(r, z, q);
+}
+
+// u8 -> f32 / 255 (the Rgba8Unorm view of a frame); exact IEEE quotient via the reciprocal + 2 FMAs
+// (equal to x / 255.0f for all 256 inputs, checked on the CPU).
+__device__ __forceinline__ float4 unorm8(uint32_t p)
+{
+    const float z = 1.0f / 255.0f;
+    return make_float4(div_by_recip(ch_f32(p, 0), 255.0f, z), div_by_recip(ch_f32(p, 1), 255.0f, z),
+                       div_by_recip(ch_f32(p, 2), 255.0f, z), div_by_recip(ch_f32(p, 3), 255.0f, z));
+}
+
+// trunc((1-t) a + t b) per channel: the zero-flow in-between pixel (interpolation/mod.rs:407-411)
+__device__ __forceinline__ uint32_t blend_px(uint32_t a, uint32_t b, float t, float nt)
+{
+    uint32_t o = 0;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) o = pack_trunc_u8(nt * ch_f32(a, c) + t * ch_f32(b, c), c, o);
+    return o;
+}
+
+constexpr uint32_t kMaxGridZ = 65535;
+
+inline uint32_t cdiv(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
+
+// Frames go on grid.z (<= 65535 per launch); longer batches are issued in chunks.
+thread_local uint32_t g_chunk_first_frame = 0; // index of the chunk's first frame, for second inputs
+template <typename F>
+hipError_t for_frame_chunks(const UpscaleLaunch &L, F &&f)
+{
+    const size_t in_bytes = L.in_stride ? L.in_stride : (size_t)L.iw * L.ih * 4, out_bytes = (size_t)L.ow * L.oh * 4;
+    for (uint32_t done = 0; done < L.n_frames;) {
+        const uint32_t n = L.n_frames - done < kMaxGridZ ? L.n_frames - done : kMaxGridZ;
+        g_chunk_first_frame = done;
+        f(L.in + (size_t)done * in_bytes, L.out + (size_t)done * out_bytes, n);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+        done += n;
+    }
+    return hipSuccess;
+}
+
+} // namespace
+
+} // namespace nus

@@ -1,0 +1,396 @@
+// nus_k_flow.hip -- optical-flow front end: Gaussian pyramid + Horn-Schunck.
+#include "nus_device.hpp"
+
+namespace nus {
+
+namespace {
+
+// ---------------------------------------------------------------------------------
+// Optical-flow front end: Gaussian pyramid + Horn-Schunck
+// ---------------------------------------------------------------------------------
+// Images: f32 RGBA, one float4 (16 B) per pixel per lane; flows: float2 per pixel.
+// Straight per-pixel kernels with the shaders' exact expression order (no contraction).
+
+
+
+__global__ __launch_bounds__(256) void k_rgba8_to_f32(const uint32_t *__restrict__ in, float4 *__restrict__ out, size_t npx)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= npx) return;
+    const uint32_t p = in[i];
+    out[i] = unorm8(p);
+}
+
+__device__ __forceinline__ float4 blur5(const float4 m2, const float4 m1, const float4 c0, const float4 p1, const float4 p2)
+{
+    // gaussian_blur_h.wgsl:42-46: m2*W0 + m1*W1 + c*W2 + p1*W1 + p2*W0, left to right
+    const float W0 = 1.0f / 16.0f, W1 = 4.0f / 16.0f, W2 = 6.0f / 16.0f;
+    float4 r;
+    r.x = m2.x * W0 + m1.x * W1 + c0.x * W2 + p1.x * W1 + p2.x * W0;
+    r.y = m2.y * W0 + m1.y * W1 + c0.y * W2 + p1.y * W1 + p2.y * W0;
+    r.z = m2.z * W0 + m1.z * W1 + c0.z * W2 + p1.z * W1 + p2.z * W0;
+    r.w = m2.w * W0 + m1.w * W1 + c0.w * W2 + p1.w * W1 + p2.w * W0;
+    return r;
+}
+
+
+// blockDim = (64, 4)
+template <bool HORIZONTAL>
+__global__ __launch_bounds__(256) void k_blur(const float4 *__restrict__ in, float4 *__restrict__ out, int w, int h)
+{
+    const int x = blockIdx.x * kWave + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
+    if (x >= w || y >= h) return;
+    float4 t[5];
+#pragma unroll
+    for (int k = -2; k <= 2; ++k) {
+        const int xx = HORIZONTAL ? clampi(x + k, 0, w - 1) : x;
+        const int yy = HORIZONTAL ? y : clampi(y + k, 0, h - 1);
+        t[k + 2] = in[(size_t)yy * w + xx];
+    }
+    out[(size_t)y * w + x] = blur5(t[0], t[1], t[2], t[3], t[4]);
+}
+
+// downsample.wgsl:22-37, out = ((w+1)/2, (h+1)/2), source clamped at the far edge
+__global__ __launch_bounds__(256) void k_downsample(const float4 *__restrict__ in, float4 *__restrict__ out, int w, int h)
+{
+    const int ow = (w + 1) / 2, oh = (h + 1) / 2;
+    const int x = blockIdx.x * kWave + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
+    if (x >= ow || y >= oh) return;
+    const int x0 = 2 * x, y0 = 2 * y, x1 = min(x0 + 1, w - 1), y1 = min(y0 + 1, h - 1);
+    const float4 c00 = in[(size_t)y0 * w + x0], c10 = in[(size_t)y0 * w + x1];
+    const float4 c01 = in[(size_t)y1 * w + x0], c11 = in[(size_t)y1 * w + x1];
+    float4 r;
+    r.x = (c00.x + c10.x + c01.x + c11.x) * 0.25f;
+    r.y = (c00.y + c10.y + c01.y + c11.y) * 0.25f;
+    r.z = (c00.z + c10.z + c01.z + c11.z) * 0.25f;
+    r.w = (c00.w + c10.w + c01.w + c11.w) * 0.25f;
+    out[(size_t)y * ow + x] = r;
+}
+
+__device__ __forceinline__ float lum(const float4 c) { return (c.x + c.y + c.z) * 0.33333f; } // horn_schunck.wgsl:17-20
+
+// One Jacobi step, horn_schunck.wgsl:48-92.
+__global__ __launch_bounds__(256) void k_horn_schunck(const float4 *__restrict__ i1, const float4 *__restrict__ i2,
+                                                      const float2 *__restrict__ fin, float2 *__restrict__ fout,
+                                                      int w, int h, float lambda)
+{
+    const int x = blockIdx.x * kWave + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
+    if (x >= w || y >= h) return;
+    const int xp = min(x + 1, w - 1), xm = max(x, 1) - 1, yp = min(y + 1, h - 1), ym = max(y, 1) - 1;
+    const float ix = (lum(i1[(size_t)y * w + xp]) - lum(i1[(size_t)y * w + xm])) * 0.5f;
+    const float iy = (lum(i1[(size_t)yp * w + x]) - lum(i1[(size_t)ym * w + x])) * 0.5f;
+    const float it = lum(i2[(size_t)y * w + x]) - lum(i1[(size_t)y * w + x]);
+    float su = 0.0f, sv = 0.0f, count = 0.0f;
+#pragma unroll
+    for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+        for (int dx = -1; dx <= 1; ++dx) {
+            const float2 f = fin[(size_t)clampi(y + dy, 0, h - 1) * w + clampi(x + dx, 0, w - 1)];
+            su += f.x;
+            sv += f.y;
+            count += 1.0f;
+        }
+    const float ua = su / count, va = sv / count;
+    const float common = (ix * ua + iy * va + it) / (lambda + ix * ix + iy * iy);
+    fout[(size_t)y * w + x] = make_float2(ua - common * ix, va - common * iy);
+}
+
+// One pyramid level in one launch (build_pyramid's three dispatches, wgpu_interpolator.rs:1068-1085,
+// fused): a 64x16 output tile stages its (64+4)x(16+4) input region in LDS (converted from RGBA8
+// at level 0), runs the horizontal blur into a second LDS tile, the vertical blur from there, writes
+// the blurred level and, from the same tile, the 2x2-averaged input of the next level.  Each value
+// goes through exactly the arithmetic of k_blur<true>, k_blur<false> and k_downsample, so the
+// result is bit-identical to the three separate kernels while HBM sees the input once.
+constexpr int kPyrTW = 64, kPyrTH = 16;
+
+template <bool U8IN>
+__global__ __launch_bounds__(256) void k_pyramid_level(const void *__restrict__ in, float4 *__restrict__ level,
+                                                       float4 *__restrict__ next, int w, int h)
+{
+    __shared__ float4 s_a[(kPyrTH + 4) * (kPyrTW + 4)]; // input region; later the V-blurred tile
+    __shared__ float4 s_h[(kPyrTH + 4) * kPyrTW];        // H-blurred rows
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6; // 64 x 4
+    const int bx = blockIdx.x * kPyrTW, by = blockIdx.y * kPyrTH;
+    // stage input rows by-2 .. by+17, columns bx-2 .. bx+65, coordinates clamped into the image
+    for (int r = ty; r < kPyrTH + 4; r += 4) {
+        const int gy = clampi(by - 2 + r, 0, h - 1);
+        for (int c = tx; c < kPyrTW + 4; c += 64) {
+            const int gx = clampi(bx - 2 + c, 0, w - 1);
+            const size_t g = (size_t)gy * w + gx;
+            s_a[r * (kPyrTW + 4) + c] = U8IN ? unorm8(static_cast<const uint32_t *>(in)[g]) : static_cast<const float4 *>(in)[g];
+        }
+    }
+    __syncthreads();
+    // horizontal pass for the 20 staged rows.  The shader clamps x+-k into the image; the staged
+    // columns already hold clamp(bx-2+c), so column (tx+2)+k is the clamped neighbour as long as
+    // the output column itself is inside the image.
+    for (int r = ty; r < kPyrTH + 4; r += 4) {
+        const float4 *row = s_a + r * (kPyrTW + 4) + tx;
+        s_h[r * kPyrTW + tx] = blur5(row[0], row[1], row[2], row[3], row[4]);
+    }
+    __syncthreads();
+    // vertical pass -> blurred level; keep the tile in LDS (s_a is free now) for the downsample
+    const int gx = bx + tx;
+    for (int r = ty; r < kPyrTH; r += 4) {
+        const float4 v = blur5(s_h[r * kPyrTW + tx], s_h[(r + 1) * kPyrTW + tx], s_h[(r + 2) * kPyrTW + tx],
+                               s_h[(r + 3) * kPyrTW + tx], s_h[(r + 4) * kPyrTW + tx]);
+        s_a[r * kPyrTW + tx] = v;
+        const int gy = by + r;
+        if (gx < w && gy < h) level[(size_t)gy * w + gx] = v;
+    }
+    if (next == nullptr) return; // block-uniform
+    __syncthreads();
+    // 2x2 box average of the blurred tile (tile origin is even, so every 2x2 block is inside it)
+    const int ow = (w + 1) / 2, oh = (h + 1) / 2;
+    const int dxl = threadIdx.x & 31, dyl = threadIdx.x >> 5; // 32 x 8 outputs per tile
+    const int ox = bx / 2 + dxl, oy = by / 2 + dyl;
+    if (ox < ow && oy < oh) {
+        const int x0 = 2 * dxl, y0 = 2 * dyl;
+        const int x1 = min(bx + x0 + 1, w - 1) - bx, y1 = min(by + y0 + 1, h - 1) - by;
+        const float4 c00 = s_a[y0 * kPyrTW + x0], c10 = s_a[y0 * kPyrTW + x1];
+        const float4 c01 = s_a[y1 * kPyrTW + x0], c11 = s_a[y1 * kPyrTW + x1];
+        float4 r;
+        r.x = (c00.x + c10.x + c01.x + c11.x) * 0.25f;
+        r.y = (c00.y + c10.y + c01.y + c11.y) * 0.25f;
+        r.z = (c00.z + c10.z + c01.z + c11.z) * 0.25f;
+        r.w = (c00.w + c10.w + c01.w + c11.w) * 0.25f;
+        next[(size_t)oy * ow + ox] = r;
+    }
+}
+
+// Derivatives of one pyramid level, computed once per level instead of once per Jacobi step:
+// (ix, iy, it, lambda + ix*ix + iy*iy) with exactly the expressions of horn_schunck.wgsl:58-82.
+__global__ __launch_bounds__(256) void k_hs_prepare(const float4 *__restrict__ i1, const float4 *__restrict__ i2,
+                                                    float4 *__restrict__ coef, float *__restrict__ zinv, int w, int h,
+                                                    float lambda)
+{
+    const int x = blockIdx.x * kWave + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
+    if (x >= w || y >= h) return;
+    const int xp = min(x + 1, w - 1), xm = max(x, 1) - 1, yp = min(y + 1, h - 1), ym = max(y, 1) - 1;
+    const float ix = (lum(i1[(size_t)y * w + xp]) - lum(i1[(size_t)y * w + xm])) * 0.5f;
+    const float iy = (lum(i1[(size_t)yp * w + x]) - lum(i1[(size_t)ym * w + x])) * 0.5f;
+    const float it = lum(i2[(size_t)y * w + x]) - lum(i1[(size_t)y * w + x]);
+    const float den = lambda + ix * ix + iy * iy;
+    coef[(size_t)y * w + x] = make_float4(ix, iy, it, den);
+    zinv[(size_t)y * w + x] = 1.0f / den; // correctly rounded reciprocal, for div_by_recip
+}
+
+// K Jacobi steps per launch on an LDS tile (temporal blocking): a 32x32 output tile is loaded
+// with a K-cell halo of the current flow and the per-cell coefficients; step j updates the
+// cells whose 3x3 neighbourhood was valid after step j-1 (the region shrinks by one ring per
+// step, except at the image border where neighbours clamp inwards), ping-ponging between two
+// LDS flow buffers.  Same arithmetic and order as k_horn_schunck, so K launches of that
+// kernel and one launch of this one produce identical bits.
+
+struct HsCell {
+    float ix, iy, it, den, zinv;
+    bool plain_div; // mantissa of den all ones: Markstein's exception
+};
+
+// T x T output tile, K Jacobi steps per launch (temporal blocking); blockDim = 256 = 32 x 8 cells
+// per sweep.  Each thread owns the same (T+2K)^2 / 256 cells in every step, so their coefficients
+// live in registers and only the two ping-pong flow tiles are in LDS.
+template <int T, int K>
+__global__ __launch_bounds__(256) void k_hs_tiled(const float4 *__restrict__ coef, const float *__restrict__ zinv,
+                                                  const float2 *__restrict__ fin, float2 *__restrict__ fout, int w, int h)
+{
+    constexpr int R = T + 2 * K;
+    constexpr int NA = (R + 7) / 8, NB = (R + 31) / 32;
+    __shared__ float2 s_flow[2][R * R];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int x0 = blockIdx.x * T - K, y0 = blockIdx.y * T - K; // image coords of LDS cell (0,0)
+    HsCell cell[NA][NB];
+#pragma unroll
+    for (int a = 0; a < NA; ++a)
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            const int ly = ty + 8 * a, lx = tx + 32 * b;
+            if (ly < R && lx < R) {
+                const int gx = clampi(x0 + lx, 0, w - 1), gy = clampi(y0 + ly, 0, h - 1);
+                const size_t g = (size_t)gy * w + gx;
+                const float4 c = coef[g];
+                cell[a][b].ix = c.x;
+                cell[a][b].iy = c.y;
+                cell[a][b].it = c.z;
+                cell[a][b].den = c.w;
+                cell[a][b].zinv = zinv[g];
+                cell[a][b].plain_div = (__float_as_uint(c.w) & 0x7fffffu) == 0x7fffffu;
+                s_flow[0][ly * R + lx] = fin[g];
+            }
+        }
+    __syncthreads();
+    // tiles whose loaded region lies strictly inside the image need no clamping at all
+    const bool border = x0 < 0 || y0 < 0 || x0 + R > w || y0 + R > h; // block-uniform
+    int cur = 0;
+#pragma unroll 1
+    for (int j = 1; j <= K; ++j) {
+        // step j updates cells [j, R-j) of the tile (plus whatever the image border clamps inwards)
+#pragma unroll
+        for (int a = 0; a < NA; ++a)
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                const int ly = ty + 8 * a, lx = tx + 32 * b;
+                if (ly < j || ly >= R - j || lx < j || lx >= R - j) continue;
+                const int gx = x0 + lx, gy = y0 + ly;
+                if (border && (gx < 0 || gy < 0 || gx >= w || gy >= h)) continue;
+                float su = 0.0f, sv = 0.0f;
+#pragma unroll
+                for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+                    for (int dx = -1; dx <= 1; ++dx) {
+                        int nx = lx + dx, ny = ly + dy;
+                        if (border) {
+                            nx = clampi(gx + dx, 0, w - 1) - x0;
+                            ny = clampi(gy + dy, 0, h - 1) - y0;
+                        }
+                        const float2 f = s_flow[cur][ny * R + nx];
+                        su += f.x;
+                        sv += f.y;
+                    }
+                // sum / count with count == 9 (horn_schunck.wgsl:38-41)
+                const float ua = div_by_recip(su, 9.0f, 1.0f / 9.0f), va = div_by_recip(sv, 9.0f, 1.0f / 9.0f);
+                const HsCell &c = cell[a][b];
+                const float num = c.ix * ua + c.iy * va + c.it;
+                const float common = c.plain_div ? num / c.den : div_by_recip(num, c.den, c.zinv);
+                s_flow[cur ^ 1][ly * R + lx] = make_float2(ua - common * c.ix, va - common * c.iy);
+            }
+        __syncthreads();
+        cur ^= 1;
+    }
+    for (int ly = ty + K; ly < T + K; ly += 8)
+        for (int lx = tx + K; lx < T + K; lx += 32) {
+            const int gx = x0 + lx, gy = y0 + ly;
+            if (gx < w && gy < h) fout[(size_t)gy * w + gx] = s_flow[cur][ly * R + lx];
+        }
+}
+
+// flow_upsample.wgsl:27-36 (linear clamp-to-edge sampler in texel space), vectors * scale
+__global__ __launch_bounds__(256) void k_flow_upsample(const float2 *__restrict__ src, int sw, int sh,
+                                                       float2 *__restrict__ dst, int dw, int dh, float scale)
+{
+    const int x = blockIdx.x * kWave + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
+    if (x >= dw || y >= dh) return;
+    const float u = ((float)x + 0.5f) / (float)dw, v = ((float)y + 0.5f) / (float)dh;
+    const float sx = u * (float)sw - 0.5f, sy = v * (float)sh - 0.5f;
+    const float fx0 = floorf(sx), fy0 = floorf(sy);
+    const float fx = sx - fx0, fy = sy - fy0;
+    const int x0 = clampi((int)fx0, 0, sw - 1), x1 = clampi((int)fx0 + 1, 0, sw - 1);
+    const int y0 = clampi((int)fy0, 0, sh - 1), y1 = clampi((int)fy0 + 1, 0, sh - 1);
+    const float2 a = src[(size_t)y0 * sw + x0], b = src[(size_t)y0 * sw + x1];
+    const float2 c = src[(size_t)y1 * sw + x0], d = src[(size_t)y1 * sw + x1];
+    float2 r;
+    r.x = ((a.x * (1.0f - fx) + b.x * fx) * (1.0f - fy) + (c.x * (1.0f - fx) + d.x * fx) * fy) * scale;
+    r.y = ((a.y * (1.0f - fx) + b.y * fx) * (1.0f - fy) + (c.y * (1.0f - fx) + d.y * fx) * fy) * scale;
+    dst[(size_t)y * dw + x] = r;
+}
+
+} // namespace
+
+hipError_t launch_rgba8_to_f32(const uint8_t *in, float *out, uint32_t w, uint32_t h, hipStream_t stream)
+{
+    const size_t npx = (size_t)w * h;
+    hipLaunchKernelGGL(k_rgba8_to_f32, dim3((uint32_t)((npx + 255) / 256)), dim3(256), 0, stream,
+                       reinterpret_cast<const uint32_t *>(in), reinterpret_cast<float4 *>(out), npx);
+    return hipGetLastError();
+}
+
+hipError_t launch_blur(const float *in, float *out, uint32_t w, uint32_t h, bool horizontal, hipStream_t stream)
+{
+    const dim3 block(kWave, 4), grid(cdiv(w, kWave), cdiv(h, 4));
+    if (horizontal)
+        hipLaunchKernelGGL(k_blur<true>, grid, block, 0, stream, reinterpret_cast<const float4 *>(in), reinterpret_cast<float4 *>(out), (int)w, (int)h);
+    else
+        hipLaunchKernelGGL(k_blur<false>, grid, block, 0, stream, reinterpret_cast<const float4 *>(in), reinterpret_cast<float4 *>(out), (int)w, (int)h);
+    return hipGetLastError();
+}
+
+hipError_t launch_downsample(const float *in, float *out, uint32_t w, uint32_t h, hipStream_t stream)
+{
+    const dim3 block(kWave, 4), grid(cdiv((w + 1) / 2, kWave), cdiv((h + 1) / 2, 4));
+    hipLaunchKernelGGL(k_downsample, grid, block, 0, stream, reinterpret_cast<const float4 *>(in), reinterpret_cast<float4 *>(out), (int)w, (int)h);
+    return hipGetLastError();
+}
+
+hipError_t launch_horn_schunck(const float *i1, const float *i2, const float *flow_in, float *flow_out, uint32_t w,
+                               uint32_t h, float lambda, hipStream_t stream)
+{
+    const dim3 block(kWave, 4), grid(cdiv(w, kWave), cdiv(h, 4));
+    hipLaunchKernelGGL(k_horn_schunck, grid, block, 0, stream, reinterpret_cast<const float4 *>(i1),
+                       reinterpret_cast<const float4 *>(i2), reinterpret_cast<const float2 *>(flow_in),
+                       reinterpret_cast<float2 *>(flow_out), (int)w, (int)h, lambda);
+    return hipGetLastError();
+}
+
+// One fused pyramid level: `in` is RGBA8 (u8_input) or f32 RGBA; `next` may be null (last level).
+hipError_t launch_pyramid_level(const void *in, bool u8_input, float *level, float *next, uint32_t w, uint32_t h,
+                                hipStream_t stream)
+{
+    const dim3 block(256), grid(cdiv(w, kPyrTW), cdiv(h, kPyrTH));
+    if (u8_input)
+        hipLaunchKernelGGL(k_pyramid_level<true>, grid, block, 0, stream, in, reinterpret_cast<float4 *>(level),
+                           reinterpret_cast<float4 *>(next), (int)w, (int)h);
+    else
+        hipLaunchKernelGGL(k_pyramid_level<false>, grid, block, 0, stream, in, reinterpret_cast<float4 *>(level),
+                           reinterpret_cast<float4 *>(next), (int)w, (int)h);
+    return hipGetLastError();
+}
+
+// coef: w*h float4 followed by w*h floats (reciprocals) -> w*h*20 bytes
+hipError_t launch_hs_prepare(const float *i1, const float *i2, float *coef, uint32_t w, uint32_t h, float lambda,
+                             hipStream_t stream)
+{
+    const dim3 block(kWave, 4), grid(cdiv(w, kWave), cdiv(h, 4));
+    hipLaunchKernelGGL(k_hs_prepare, grid, block, 0, stream, reinterpret_cast<const float4 *>(i1),
+                       reinterpret_cast<const float4 *>(i2), reinterpret_cast<float4 *>(coef),
+                       coef + (size_t)w * h * 4, (int)w, (int)h, lambda);
+    return hipGetLastError();
+}
+
+// `iterations` Jacobi steps from *flow_a, ping-ponging with *flow_b; on return *flow_a holds the
+// result (the pointers are swapped as needed).  Steps are grouped 8 / 4 / 2 / 1 per launch; small
+// levels use 16x16 tiles so that the grid still covers the 256 CUs.
+hipError_t launch_hs_iterate(const float *coef, float **flow_a, float **flow_b, uint32_t w, uint32_t h,
+                             uint32_t iterations, hipStream_t stream)
+{
+    const bool small = (uint64_t)cdiv(w, 32) * cdiv(h, 32) < 1024;
+    const uint32_t T = small ? 16 : 32;
+    const dim3 block(256), grid(cdiv(w, T), cdiv(h, T));
+    auto c4 = reinterpret_cast<const float4 *>(coef);
+    const float *zi = coef + (size_t)w * h * 4;
+    uint32_t launches = (iterations + 7) / 8;
+    while (iterations > 0) {
+        auto fi = reinterpret_cast<const float2 *>(*flow_a);
+        auto fo = reinterpret_cast<float2 *>(*flow_b);
+        const uint32_t k = (iterations + launches - 1) / launches; // even split, 1..8 steps per launch
+#define NUS_HS(KK)                                                                                              \
+    case KK:                                                                                                    \
+        if (small)                                                                                              \
+            hipLaunchKernelGGL((k_hs_tiled<16, KK>), grid, block, 0, stream, c4, zi, fi, fo, (int)w, (int)h);   \
+        else                                                                                                    \
+            hipLaunchKernelGGL((k_hs_tiled<32, KK>), grid, block, 0, stream, c4, zi, fi, fo, (int)w, (int)h);   \
+        break;
+        switch (k) {
+            NUS_HS(1) NUS_HS(2) NUS_HS(3) NUS_HS(4) NUS_HS(5) NUS_HS(6) NUS_HS(7) NUS_HS(8)
+        }
+#undef NUS_HS
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+        iterations -= k;
+        --launches;
+        float *t = *flow_a;
+        *flow_a = *flow_b;
+        *flow_b = t;
+    }
+    return hipSuccess;
+}
+
+hipError_t launch_flow_upsample(const float *src, uint32_t sw, uint32_t sh, float *dst, uint32_t dw, uint32_t dh,
+                                float scale, hipStream_t stream)
+{
+    const dim3 block(kWave, 4), grid(cdiv(dw, kWave), cdiv(dh, 4));
+    hipLaunchKernelGGL(k_flow_upsample, grid, block, 0, stream, reinterpret_cast<const float2 *>(src), (int)sw, (int)sh,
+                       reinterpret_cast<float2 *>(dst), (int)dw, (int)dh, scale);
+    return hipGetLastError();
+}
+
+} // namespace nus

@@ -1,0 +1,158 @@
+// nus_k_interp.hip -- two-frame warp + blend and the BGRA -> RGBA swizzle.
+//   warp+blend nu_scaler_core/src/shaders/warp_blend.wgsl:18-47 (geometry),
+//              nu_scaler_core/src/interpolation/mod.rs:386-411, :467-510 (rounding)
+#include "nus_device.hpp"
+
+namespace nus {
+
+namespace {
+
+// ---------------------------------------------------------------------------------
+// Warp + blend
+// ---------------------------------------------------------------------------------
+
+// Zero flow (the live reference behaviour, wgpu_interpolator.rs:275-295): sample
+// positions are the pixel centres, so the bilinear samples are the pixels themselves
+// and the kernel is a streaming blend, 4 pixels (16 B) per lane.
+
+template <bool VEC>
+__global__ __launch_bounds__(256) void k_blend_zero_flow(
+    const uint8_t *__restrict__ a, const uint8_t *__restrict__ b, uint8_t *__restrict__ out,
+    size_t a_stride, size_t b_stride, size_t npx, float t, uint32_t sel)
+{
+    const float nt = 1.0f - t;
+    const uint32_t *pa = reinterpret_cast<const uint32_t *>(a + (size_t)blockIdx.y * a_stride);
+    const uint32_t *pb = reinterpret_cast<const uint32_t *>(b + (size_t)blockIdx.y * b_stride);
+    uint32_t *po = reinterpret_cast<uint32_t *>(out) + (size_t)blockIdx.y * npx;
+    const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * (VEC ? 4 : 1);
+    if (i >= npx) return;
+    if (VEC) {
+        const uint4 va = *reinterpret_cast<const uint4 *>(pa + i);
+        const uint4 vb = *reinterpret_cast<const uint4 *>(pb + i);
+        // per-channel arithmetic: swizzling the blended pixel equals blending swizzled inputs
+        *reinterpret_cast<uint4 *>(po + i) = swz4(make_uint4(blend_px(va.x, vb.x, t, nt), blend_px(va.y, vb.y, t, nt),
+                                                             blend_px(va.z, vb.z, t, nt), blend_px(va.w, vb.w, t, nt)), sel);
+    } else {
+        po[i] = swz(blend_px(pa[i], pb[i], t, nt), sel);
+    }
+}
+
+// interpolation/mod.rs:467-510: clamp, bilinear, truncate to u8 -- returned as the four truncated
+// channel values still in f32 (floor of a value in [0, 255]) so the blend needs no unpack.
+__device__ __forceinline__ float4 sample_trunc(const uint32_t *__restrict__ f, uint32_t w, uint32_t h, float x, float y)
+{
+    x = fminf(fmaxf(x, 0.0f), (float)(w - 1));
+    y = fminf(fmaxf(y, 0.0f), (float)(h - 1));
+    const float xfl = floorf(x), yfl = floorf(y);
+    const uint32_t x0 = (uint32_t)xfl, y0 = (uint32_t)yfl;
+    const uint32_t x1 = umin(x0 + 1, w - 1), y1 = umin(y0 + 1, h - 1);
+    const float xf = x - xfl, yf = y - yfl;
+    const float nxf = 1.0f - xf, nyf = 1.0f - yf;
+    const uint32_t p00 = f[(size_t)y0 * w + x0], p01 = f[(size_t)y0 * w + x1];
+    const uint32_t p10 = f[(size_t)y1 * w + x0], p11 = f[(size_t)y1 * w + x1];
+    float r[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const float top = ch_f32(p00, c) * nxf + ch_f32(p01, c) * xf;
+        const float bottom = ch_f32(p10, c) * nxf + ch_f32(p11, c) * xf;
+        const float value = top * nyf + bottom * yf;
+        r[c] = fminf(floorf(value), 255.0f); // `value as u8`; value >= 0 here
+    }
+    return make_float4(r[0], r[1], r[2], r[3]);
+}
+
+// Dense flow (2 x f32 per pixel, delta A -> B): A sampled at p - t*flow, B at
+// p + (1-t)*flow (warp_blend.wgsl:36-37 in texel space).  blockDim = (64, 4).
+__global__ __launch_bounds__(256) void k_warp_blend_flow(
+    const uint8_t *__restrict__ a, const uint8_t *__restrict__ b, const float *__restrict__ flow,
+    uint8_t *__restrict__ out, size_t a_stride, size_t b_stride, uint32_t w, uint32_t h, float t, uint32_t sel)
+{
+    const uint32_t y = __builtin_amdgcn_readfirstlane(blockIdx.y * 4 + threadIdx.y);
+    const uint32_t x = blockIdx.x * kWave + threadIdx.x;
+    if (y >= h || x >= w) return;
+    const size_t npx = (size_t)w * h;
+    const uint32_t *pa = reinterpret_cast<const uint32_t *>(a + (size_t)blockIdx.z * a_stride);
+    const uint32_t *pb = reinterpret_cast<const uint32_t *>(b + (size_t)blockIdx.z * b_stride);
+    const size_t idx = (size_t)y * w + x;
+    const float2 f = *reinterpret_cast<const float2 *>(flow + ((size_t)blockIdx.z * npx + idx) * 2);
+    float tv = t; // per-lane copy: scalar operands halve the VALU issue rate on gfx950
+    asm volatile("" : "+v"(tv));
+    const float nt = 1.0f - tv;
+    const float ax = (float)x - tv * f.x, ay = (float)y - tv * f.y;
+    const float bx = (float)x + nt * f.x, by = (float)y + nt * f.y;
+    const float4 sa = sample_trunc(pa, w, h, ax, ay);
+    const float4 sb = sample_trunc(pb, w, h, bx, by);
+    uint32_t o = 0;
+    o = pack_trunc_u8(nt * sa.x + tv * sb.x, 0, o);
+    o = pack_trunc_u8(nt * sa.y + tv * sb.y, 1, o);
+    o = pack_trunc_u8(nt * sa.z + tv * sb.z, 2, o);
+    o = pack_trunc_u8(nt * sa.w + tv * sb.w, 3, o);
+    reinterpret_cast<uint32_t *>(out)[(size_t)blockIdx.z * npx + idx] = swz(o, sel);
+}
+
+// ---------------------------------------------------------------------------------
+// BGRA -> RGBA swizzle of captured frames (nu_scaler_core/src/lib.rs:251-270), 4 px per lane
+// ---------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t swap_rb(uint32_t p)
+{
+    return __builtin_amdgcn_perm(p, p, 0x03000102u); // bytes (2, 1, 0, 3): one v_perm_b32
+}
+
+template <bool VEC>
+__global__ __launch_bounds__(256) void k_swizzle_bgra(const uint32_t *__restrict__ in, uint32_t *__restrict__ out, size_t npx)
+{
+    const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * (VEC ? 4 : 1);
+    if (i >= npx) return;
+    if (VEC) {
+        const uint4 v = *reinterpret_cast<const uint4 *>(in + i);
+        *reinterpret_cast<uint4 *>(out + i) = make_uint4(swap_rb(v.x), swap_rb(v.y), swap_rb(v.z), swap_rb(v.w));
+    } else {
+        out[i] = swap_rb(in[i]);
+    }
+}
+
+} // namespace
+
+hipError_t launch_swizzle_bgra(const uint8_t *in, uint8_t *out, size_t npx, hipStream_t stream)
+{
+    const bool vec = (npx % 4) == 0 && (reinterpret_cast<uintptr_t>(in) % 16) == 0 && (reinterpret_cast<uintptr_t>(out) % 16) == 0;
+    const size_t items = vec ? npx / 4 : npx;
+    const dim3 block(256), grid((uint32_t)((items + 255) / 256));
+    if (vec)
+        hipLaunchKernelGGL(k_swizzle_bgra<true>, grid, block, 0, stream, reinterpret_cast<const uint32_t *>(in), reinterpret_cast<uint32_t *>(out), npx);
+    else
+        hipLaunchKernelGGL(k_swizzle_bgra<false>, grid, block, 0, stream, reinterpret_cast<const uint32_t *>(in), reinterpret_cast<uint32_t *>(out), npx);
+    return hipGetLastError();
+}
+
+hipError_t launch_warp_blend(const WarpLaunch &L)
+{
+    const size_t npx = (size_t)L.w * L.h;
+    for (uint32_t done = 0; done < L.n_pairs;) {
+        const uint32_t n = L.n_pairs - done < kMaxGridZ ? L.n_pairs - done : kMaxGridZ;
+        const uint8_t *a = L.a + (size_t)done * L.a_stride;
+        const uint8_t *b = L.b + (size_t)done * L.b_stride;
+        uint8_t *out = L.out + (size_t)done * npx * 4;
+        if (L.flow == nullptr) {
+            const bool vec = (npx % 4) == 0 && (L.a_stride % 16) == 0 && (L.b_stride % 16) == 0 &&
+                             (reinterpret_cast<uintptr_t>(a) % 16) == 0 && (reinterpret_cast<uintptr_t>(b) % 16) == 0 &&
+                             (reinterpret_cast<uintptr_t>(out) % 16) == 0;
+            const size_t items = vec ? npx / 4 : npx;
+            const dim3 block(256), grid((uint32_t)((items + 255) / 256), n);
+            if (vec)
+                hipLaunchKernelGGL(k_blend_zero_flow<true>, grid, block, 0, L.stream, a, b, out, L.a_stride, L.b_stride, npx, L.t, L.in_sel);
+            else
+                hipLaunchKernelGGL(k_blend_zero_flow<false>, grid, block, 0, L.stream, a, b, out, L.a_stride, L.b_stride, npx, L.t, L.in_sel);
+        } else {
+            const dim3 block(kWave, 4), grid(cdiv(L.w, 64), cdiv(L.h, 4), n);
+            hipLaunchKernelGGL(k_warp_blend_flow, grid, block, 0, L.stream, a, b, L.flow + (size_t)done * npx * 2, out,
+                               L.a_stride, L.b_stride, L.w, L.h, L.t, L.in_sel);
+        }
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+        done += n;
+    }
+    return hipSuccess;
+}
+
+} // namespace nus

@@ -1,0 +1,573 @@
+// nus_k_upscale.hip -- nearest, bilinear and the any-scale separable resize kernels (gfx950, wave64).
+//
+// Reference arithmetic being reproduced (paths relative to the reference checkout):
+//   nearest    nu_scaler_core/src/upscale/mod.rs:184-206 == Nu_scale/src/upscale/common.rs:188-198
+//   bilinear   Nu_scale/src/upscale/common.rs:199-231 (CPU form, the oracle);
+//              nu_scaler_core/src/upscale/mod.rs:209-263 (WGSL form, optional variant)
+//   lanczos3 / catmull-rom / triangle
+//              image-0.24.9 imageops::resize as called at Nu_scale/src/upscale/common.rs:243-251
+#include "nus_device.hpp"
+
+namespace nus {
+
+namespace {
+
+// ---------------------------------------------------------------------------------
+// Nearest
+// ---------------------------------------------------------------------------------
+
+// Any scale.  blockDim = (64, 4): each wave owns a 256-px (VEC) or 64-px column segment and walks
+// `rows_per_wave` output rows; the gathered source pixels are kept in registers and re-fetched only
+// when the source row changes (an upscale stores each gathered row several times).
+template <bool VEC>
+__global__ __launch_bounds__(256) void k_nearest_table(
+    const uint32_t *__restrict__ in, uint32_t *__restrict__ out,
+    const uint32_t *__restrict__ sx, const uint32_t *__restrict__ sy,
+    uint32_t iw, uint32_t ow, uint32_t oh, uint32_t rows_per_wave, size_t in_frame_px, size_t out_frame_px, uint32_t sel)
+{
+    constexpr int N = VEC ? 4 : 1;
+    const uint32_t rb = __builtin_amdgcn_readfirstlane(blockIdx.y * 4 + threadIdx.y);
+    const uint32_t y_begin = rb * rows_per_wave;
+    const uint32_t x = (blockIdx.x * kWave + threadIdx.x) * N;
+    if (y_begin >= oh || x >= ow) return;
+    const uint32_t y_end = umin(y_begin + rows_per_wave, oh);
+    const uint32_t *base = in + (size_t)blockIdx.z * in_frame_px;
+    uint32_t *dst = out + (size_t)blockIdx.z * out_frame_px + x;
+    uint32_t s[N], o[N];
+    if (VEC) {
+        const uint4 v = *reinterpret_cast<const uint4 *>(sx + x);
+        s[0] = v.x; s[N > 1 ? 1 : 0] = v.y; s[N > 2 ? 2 : 0] = v.z; s[N > 3 ? 3 : 0] = v.w;
+    } else {
+        s[0] = sx[x];
+    }
+    uint32_t have = 0xffffffffu;
+    for (uint32_t y = y_begin; y < y_end; ++y) {
+        const uint32_t r = __builtin_amdgcn_readfirstlane(sy[y]);
+        if (r != have) { // wave-uniform
+            const uint32_t *src = base + (size_t)r * iw;
+#pragma unroll
+            for (int i = 0; i < N; ++i) o[i] = swz(src[s[i]], sel);
+            have = r;
+        }
+        if (VEC)
+            *reinterpret_cast<uint4 *>(dst + (size_t)y * ow) = make_uint4(o[0], o[N > 1 ? 1 : 0], o[N > 2 ? 2 : 0], o[N > 3 ? 3 : 0]);
+        else
+            dst[(size_t)y * ow] = o[0];
+    }
+}
+
+// Exact x2 (ow == 2*iw, oh == 2*ih, iw % 4 == 0): each lane reads 4 input pixels
+// (16 B) and writes the 2x2 replication as four 16-B stores.
+__global__ __launch_bounds__(256) void k_nearest_x2(
+    const uint32_t *__restrict__ in, uint32_t *__restrict__ out,
+    uint32_t iw, uint32_t ih, size_t in_frame_px, size_t out_frame_px, uint32_t sel)
+{
+    const uint32_t r = __builtin_amdgcn_readfirstlane(blockIdx.y * 4 + threadIdx.y);
+    const uint32_t k = (blockIdx.x * kWave + threadIdx.x) * 4;
+    if (r >= ih || k >= iw) return;
+    const uint32_t ow = iw * 2;
+    const uint4 p = swz4(*reinterpret_cast<const uint4 *>(in + (size_t)blockIdx.z * in_frame_px + (size_t)r * iw + k), sel);
+    const uint4 o0 = make_uint4(p.x, p.x, p.y, p.y);
+    const uint4 o1 = make_uint4(p.z, p.z, p.w, p.w);
+    uint32_t *d = out + (size_t)blockIdx.z * out_frame_px + (size_t)(2 * r) * ow + 2 * k;
+    *reinterpret_cast<uint4 *>(d) = o0;
+    *reinterpret_cast<uint4 *>(d + 4) = o1;
+    *reinterpret_cast<uint4 *>(d + ow) = o0;
+    *reinterpret_cast<uint4 *>(d + ow + 4) = o1;
+}
+
+// ---------------------------------------------------------------------------------
+// Bilinear
+// ---------------------------------------------------------------------------------
+
+// Horizontal lerp of one source row for the lane's N outputs (common.rs:221-222; upscale/mod.rs:255-256
+// for the WGSL form, whose texels are first divided by 255).
+template <int N, bool WGSL>
+__device__ __forceinline__ void bilinear_hrow(const uint32_t *__restrict__ row, const uint32_t (&xi)[N], const float (&xf)[N],
+                                              uint32_t iw, uint32_t sel, float (&h)[N * 4])
+{
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        const uint32_t p0 = swz(row[xi[i]], sel), p1 = swz(row[umin(xi[i] + 1, iw - 1)], sel);
+        const float dx = xf[i], ndx = 1.0f - dx;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            float a = ch_f32(p0, c), b = ch_f32(p1, c);
+            if (WGSL) {
+                a = div_by_recip(a, 255.0f, 1.0f / 255.0f); // == a / 255.0f for every u8 (checked on the CPU)
+                b = div_by_recip(b, 255.0f, 1.0f / 255.0f);
+            }
+            h[i * 4 + c] = a * ndx + b * dx;
+        }
+    }
+}
+
+// Any scale; coordinates come from host-built tables so no division runs here and the index /
+// fraction values are exactly the CPU's.  blockDim = (64, 4): each wave owns a column segment
+// (4 outputs per lane when VEC) and walks `rows_per_wave` output rows.  The horizontally lerped
+// source rows ("top" / "bottom" of common.rs:221-222) depend only on the source row, so they stay
+// in registers while consecutive output rows map to the same source rows -- on an upscale each is
+// reused for ~scale output rows -- and only the vertical lerp + pack runs per output pixel.
+template <bool VEC, bool WGSL>
+__global__ __launch_bounds__(256) void k_bilinear_table(
+    const uint32_t *__restrict__ in, uint32_t *__restrict__ out,
+    const uint32_t *__restrict__ x0t, const float *__restrict__ fxt,
+    const uint32_t *__restrict__ y0t, const float *__restrict__ fyt,
+    uint32_t iw, uint32_t ih, uint32_t ow, uint32_t oh, uint32_t rows_per_wave, size_t in_frame_px, size_t out_frame_px,
+    uint32_t sel)
+{
+    constexpr int N = VEC ? 4 : 1;
+    const uint32_t rb = __builtin_amdgcn_readfirstlane(blockIdx.y * 4 + threadIdx.y);
+    const uint32_t y_begin = rb * rows_per_wave;
+    const uint32_t x = (blockIdx.x * kWave + threadIdx.x) * N;
+    if (y_begin >= oh || x >= ow) return;
+    const uint32_t y_end = umin(y_begin + rows_per_wave, oh);
+    const uint32_t *base = in + (size_t)blockIdx.z * in_frame_px;
+    uint32_t *dst = out + (size_t)blockIdx.z * out_frame_px + x;
+    uint32_t xi[N];
+    float xf[N];
+    if (VEC) {
+        const uint4 a = *reinterpret_cast<const uint4 *>(x0t + x);
+        const float4 f = *reinterpret_cast<const float4 *>(fxt + x);
+        xi[0] = a.x; xi[N > 1 ? 1 : 0] = a.y; xi[N > 2 ? 2 : 0] = a.z; xi[N > 3 ? 3 : 0] = a.w;
+        xf[0] = f.x; xf[N > 1 ? 1 : 0] = f.y; xf[N > 2 ? 2 : 0] = f.z; xf[N > 3 ? 3 : 0] = f.w;
+    } else {
+        xi[0] = x0t[x];
+        xf[0] = fxt[x];
+    }
+    float ht[N * 4], hb[N * 4]; // lerped source rows top_row / bot_row
+    uint32_t top_row = 0xffffffffu, bot_row = 0xffffffffu;
+    for (uint32_t y = y_begin; y < y_end; ++y) {
+        const uint32_t y0 = __builtin_amdgcn_readfirstlane(y0t[y]);
+        const uint32_t y1 = umin(y0 + 1, ih - 1);
+        float dy = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(fyt[y])));
+        asm volatile("" : "+v"(dy)); // VGPR copy: scalar operands halve the VALU issue rate
+        const float ndy = 1.0f - dy;
+        if (y0 != top_row) { // wave-uniform
+            if (y0 == bot_row) {
+#pragma unroll
+                for (int k = 0; k < N * 4; ++k) ht[k] = hb[k];
+            } else {
+                bilinear_hrow<N, WGSL>(base + (size_t)y0 * iw, xi, xf, iw, sel, ht);
+            }
+            top_row = y0;
+        }
+        if (y1 != bot_row) {
+            if (y1 == y0) {
+#pragma unroll
+                for (int k = 0; k < N * 4; ++k) hb[k] = ht[k];
+            } else {
+                bilinear_hrow<N, WGSL>(base + (size_t)y1 * iw, xi, xf, iw, sel, hb);
+            }
+            bot_row = y1;
+        }
+        uint32_t o[N];
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            uint32_t px = 0;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const float v = ht[i * 4 + c] * ndy + hb[i * 4 + c] * dy;
+                // CPU form: clamp(0,255) as u8; WGSL form: u32(clamp(v,0,1)*255) -- the saturating pack clamps below
+                px = pack_trunc_u8(WGSL ? fminf(v, 1.0f) * 255.0f : v, c, px);
+            }
+            o[i] = px;
+        }
+        if (VEC)
+            *reinterpret_cast<uint4 *>(dst + (size_t)y * ow) = make_uint4(o[0], o[N > 1 ? 1 : 0], o[N > 2 ? 2 : 0], o[N > 3 ? 3 : 0]);
+        else
+            dst[(size_t)y * ow] = o[0];
+    }
+}
+
+// floor((a+b)/2) per byte: v_lerp_u8 with rounding bits 0.
+__device__ __forceinline__ uint32_t avg2_u8x4(uint32_t a, uint32_t b)
+{
+    return __builtin_amdgcn_lerp(a, b, 0u);
+}
+
+// floor((a+b+c+d)/4) per byte, exact: with l1 = floor((a+b)/2), l2 = floor((c+d)/2) the
+// lost half-units are the low bits of a^b and c^d; both set adds one unit to l1+l2.
+__device__ __forceinline__ uint32_t avg4_u8x4(uint32_t a, uint32_t b, uint32_t c, uint32_t d)
+{
+    const uint32_t l1 = __builtin_amdgcn_lerp(a, b, 0u);
+    const uint32_t l2 = __builtin_amdgcn_lerp(c, d, 0u);
+    return __builtin_amdgcn_lerp(l1, l2, (a ^ b) & (c ^ d));
+}
+
+// Exact x2, CPU arithmetic.  At x2 the fractions are 0 or 0.5, every product and sum
+// of common.rs:221-226 is exact in f32 and the truncation is a floor of a quarter
+// multiple, so the result equals these packed-u8 integer averages byte for byte
+// (requires (ow-1)*iw < 2^24 so that x*iw/ow is exact; checked by the host).
+// Each lane: 4 input pixels of rows r and r+1 -> 8x2 output pixels.
+__global__ __launch_bounds__(256) void k_bilinear_x2_int(
+    const uint32_t *__restrict__ in, uint32_t *__restrict__ out,
+    uint32_t iw, uint32_t ih, size_t in_frame_px, size_t out_frame_px, uint32_t sel)
+{
+    const uint32_t r = __builtin_amdgcn_readfirstlane(blockIdx.y * 4 + threadIdx.y);
+    const uint32_t k = (blockIdx.x * kWave + threadIdx.x) * 4;
+    if (r >= ih || k >= iw) return;
+    const uint32_t ow = iw * 2;
+    const uint32_t r1 = umin(r + 1, ih - 1);
+    const uint32_t k4 = umin(k + 4, iw - 1);
+    const uint32_t *base = in + (size_t)blockIdx.z * in_frame_px;
+    const uint32_t *rowp = base + (size_t)r * iw;
+    const uint32_t *rowq = base + (size_t)r1 * iw;
+    const uint4 pv = swz4(*reinterpret_cast<const uint4 *>(rowp + k), sel);
+    const uint4 qv = swz4(*reinterpret_cast<const uint4 *>(rowq + k), sel);
+    const uint32_t p[5] = {pv.x, pv.y, pv.z, pv.w, swz(rowp[k4], sel)};
+    const uint32_t q[5] = {qv.x, qv.y, qv.z, qv.w, swz(rowq[k4], sel)};
+    uint32_t top[8], bot[8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        top[2 * i] = p[i];
+        top[2 * i + 1] = avg2_u8x4(p[i], p[i + 1]);
+        bot[2 * i] = avg2_u8x4(p[i], q[i]);
+        bot[2 * i + 1] = avg4_u8x4(p[i], p[i + 1], q[i], q[i + 1]);
+    }
+    uint32_t *d = out + (size_t)blockIdx.z * out_frame_px + (size_t)(2 * r) * ow + 2 * k;
+    *reinterpret_cast<uint4 *>(d) = make_uint4(top[0], top[1], top[2], top[3]);
+    *reinterpret_cast<uint4 *>(d + 4) = make_uint4(top[4], top[5], top[6], top[7]);
+    *reinterpret_cast<uint4 *>(d + ow) = make_uint4(bot[0], bot[1], bot[2], bot[3]);
+    *reinterpret_cast<uint4 *>(d + ow + 4) = make_uint4(bot[4], bot[5], bot[6], bot[7]);
+}
+
+// ---------------------------------------------------------------------------------
+// Lanczos-3 (image-0.24.9 resize: vertical pass into f32, then horizontal pass)
+// ---------------------------------------------------------------------------------
+
+// Any scale, one output pixel per thread: for every horizontal tap column the vertical
+// sum is formed first (f32, tap order ascending), then the horizontal sum, exactly the
+// operation order of the two-pass CPU algorithm.  Also used for the first/last
+// `edge_cols` output columns next to the x2 kernel, whose interior weights do not
+// apply there.  blockDim = (64, 4).
+template <bool EXACT>
+__global__ __launch_bounds__(256) void k_lanczos_general(
+    const uint32_t *__restrict__ in, uint32_t *__restrict__ out,
+    const int32_t *__restrict__ lxt, const uint32_t *__restrict__ nxt, const float *__restrict__ wxt,
+    const int32_t *__restrict__ lyt, const uint32_t *__restrict__ nyt, const float *__restrict__ wyt,
+    uint32_t stride, uint32_t iw, uint32_t ow, uint32_t oh, uint32_t ncols, uint32_t split, uint32_t gap,
+    size_t in_frame_px, size_t out_frame_px, uint32_t sel)
+{
+    const uint32_t y = __builtin_amdgcn_readfirstlane(blockIdx.y * 4 + threadIdx.y);
+    const uint32_t i = blockIdx.x * kWave + threadIdx.x;
+    if (y >= oh || i >= ncols) return;
+    const uint32_t x = i < split ? i : i + gap;
+    const int32_t lx = lxt[x];
+    const uint32_t nx = nxt[x];
+    const int32_t ly = lyt[y];
+    const uint32_t ny = nyt[y];
+    const float *wx = wxt + (size_t)x * stride;
+    const float *wy = wyt + (size_t)y * stride;
+    const uint32_t *src = in + (size_t)blockIdx.z * in_frame_px + (size_t)ly * iw + lx;
+    float h0 = 0.0f, h1 = 0.0f, h2 = 0.0f, h3 = 0.0f;
+    for (uint32_t a = 0; a < nx; ++a) {
+        float v0 = 0.0f, v1 = 0.0f, v2 = 0.0f, v3 = 0.0f;
+        for (uint32_t b = 0; b < ny; ++b) {
+            const uint32_t p = swz(src[(size_t)b * iw + a], sel);
+            const float w = wy[b];
+            v0 = mac<EXACT>(v0, ch_f32(p, 0), w);
+            v1 = mac<EXACT>(v1, ch_f32(p, 1), w);
+            v2 = mac<EXACT>(v2, ch_f32(p, 2), w);
+            v3 = mac<EXACT>(v3, ch_f32(p, 3), w);
+        }
+        const float w = wx[a];
+        h0 = mac<EXACT>(h0, v0, w);
+        h1 = mac<EXACT>(h1, v1, w);
+        h2 = mac<EXACT>(h2, v2, w);
+        h3 = mac<EXACT>(h3, v3, w);
+    }
+    out[(size_t)blockIdx.z * out_frame_px + (size_t)y * ow + x] =
+        pack_u8<EXACT>(h3, 3, pack_u8<EXACT>(h2, 2, pack_u8<EXACT>(h1, 1, pack_u8<EXACT>(h0, 0, 0u))));
+}
+
+// Any scale, separable, two passes per output row through an LDS row (the data flow of
+// vertical_sample -> horizontal_sample with only ONE f32 row of the intermediate image alive):
+//   blockDim = (64, 4): the 4 waves own 4 adjacent output column segments (64*N columns each) of the
+//   same block of output rows; each wave has its own LDS row and never reads another wave's.
+//   per output row y:  V pass -- the lanes sweep the input columns their segment's taps touch and
+//                      store  V[col] = sum_j wy[y][j] * in[ly[y]+j][col]  (f32 x 4 channels) in LDS;
+//                      H pass -- each lane sums its outputs' taps from LDS (16-B reads), packs, stores.
+// Same f32 operation order as k_lanczos_general (and the CPU algorithm); replaces its nx*ny taps per
+// pixel by nx + ny/scale.  SMALL: every window has <= 8 taps (any upscale), weights stay in VGPRs.
+template <bool EXACT, bool VEC, bool SMALL>
+__global__ __launch_bounds__(256) void k_resize_rows(
+    const uint32_t *__restrict__ in, uint32_t *__restrict__ out,
+    const int32_t *__restrict__ lxt, const uint32_t *__restrict__ nxt, const float *__restrict__ wxt,
+    const int32_t *__restrict__ lyt, const uint32_t *__restrict__ nyt, const float *__restrict__ wyt,
+    uint32_t stride, uint32_t iw, uint32_t ow, uint32_t oh, uint32_t rows_per_block, uint32_t ncols_max,
+    size_t in_frame_px, size_t out_frame_px, uint32_t sel)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int N = VEC ? 4 : 1;
+    constexpr uint32_t SEGW = kWave * N;
+    float4 *s_v = reinterpret_cast<float4 *>(smem) + (size_t)threadIdx.y * (ncols_max + 8);
+    const uint32_t seg = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + threadIdx.y);
+    const uint32_t X0 = seg * SEGW;
+    if (X0 >= ow) return; // whole wave; no workgroup barriers below
+    const uint32_t Xlast = umin(X0 + SEGW, ow) - 1;
+    const int32_t cmin = lxt[X0];
+    const int32_t cmax = lxt[Xlast] + (int32_t)nxt[Xlast];
+    const uint32_t x = X0 + threadIdx.x * N;
+    const bool lane_active = x < ow;
+    const uint32_t y_begin = blockIdx.y * rows_per_block;
+    const uint32_t y_end = umin(y_begin + rows_per_block, oh);
+    const uint32_t *base = in + (size_t)blockIdx.z * in_frame_px;
+    uint32_t *dst = out + (size_t)blockIdx.z * out_frame_px + x;
+
+    if (threadIdx.x < 8) s_v[(cmax - cmin) + threadIdx.x] = make_float4(0.0f, 0.0f, 0.0f, 0.0f); // slack, see the H pass
+    // horizontal windows of this lane's outputs
+    int32_t hl[N];
+    uint32_t hn[N];
+    float hw[N][8];
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        const uint32_t xo = lane_active ? x + i : 0;
+        hl[i] = lxt[xo] - cmin;
+        hn[i] = nxt[xo];
+        if (SMALL) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) hw[i][k] = wxt[(size_t)xo * stride + k]; // zero padded beyond hn
+        }
+    }
+
+    for (uint32_t y = y_begin; y < y_end; ++y) {
+        const int32_t ly = lyt[y];
+        const uint32_t ny = nyt[y];
+        const float *wy = wyt + (size_t)y * stride;
+        {
+            float wv[8];
+            if (SMALL) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    wv[j] = wy[j];
+                    asm volatile("" : "+v"(wv[j])); // VGPR copy: scalar operands halve the VALU issue rate
+                }
+            }
+            const uint32_t *src = base + (size_t)ly * iw;
+            // V pass: 4 input columns per lane per sweep; all tap rows of a group are requested before
+            // the first is consumed (16-B loads where the group lies inside the row)
+            for (int32_t col = cmin + 4 * (int32_t)threadIdx.x; col < cmax; col += 4 * kWave) {
+                float v[4][4] = {{0.0f}};
+                const bool whole = col + 4 <= (int32_t)iw; // else: last group of the row, per-pixel loads
+                if (SMALL) {
+                    uint32_t p[8][4];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        if ((uint32_t)j < ny) { // wave-uniform
+                            const uint32_t *q = src + (size_t)j * iw + col;
+                            if (whole) {
+                                // dword-aligned 16-B load (global loads need no 16-B alignment)
+                                const uint4 t = *reinterpret_cast<const __attribute__((aligned(4))) uint4 *>(q);
+                                p[j][0] = t.x; p[j][1] = t.y; p[j][2] = t.z; p[j][3] = t.w;
+                            } else {
+#pragma unroll
+                                for (int m = 0; m < 4; ++m) p[j][m] = col + m < (int32_t)iw ? q[m] : 0u;
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        if ((uint32_t)j < ny) {
+#pragma unroll
+                            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                                for (int c = 0; c < 4; ++c) v[m][c] = mac<EXACT>(v[m][c], ch_f32(swz(p[j][m], sel), c), wv[j]);
+                        }
+                    }
+                } else {
+                    for (uint32_t j = 0; j < ny; ++j) {
+                        const uint32_t *q = src + (size_t)j * iw + col;
+                        const float w = wy[j];
+#pragma unroll
+                        for (int m = 0; m < 4; ++m) {
+                            const uint32_t px = swz(col + m < (int32_t)iw ? q[m] : 0u, sel);
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) v[m][c] = mac<EXACT>(v[m][c], ch_f32(px, c), w);
+                        }
+                    }
+                }
+#pragma unroll
+                for (int m = 0; m < 4; ++m)
+                    if (col + m < cmax) s_v[col - cmin + m] = make_float4(v[m][0], v[m][1], v[m][2], v[m][3]);
+            }
+        }
+        // A wave only ever reads the LDS row it wrote itself, and the LDS executes one wave's
+        // instructions in order: no workgroup barrier, just keep the compiler from reordering.
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (lane_active) {
+            uint32_t o[N];
+#pragma unroll
+            for (int i = 0; i < N; ++i) {
+                float h0 = 0.0f, h1 = 0.0f, h2 = 0.0f, h3 = 0.0f;
+                if (SMALL) {
+                    // all 8 slots, no per-lane branch: slots beyond the window carry weight 0 and read
+                    // finite values (the row has 8 zeroed slack entries), so they add +-0
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        const float4 v = s_v[hl[i] + k];
+                        h0 = mac<EXACT>(h0, v.x, hw[i][k]);
+                        h1 = mac<EXACT>(h1, v.y, hw[i][k]);
+                        h2 = mac<EXACT>(h2, v.z, hw[i][k]);
+                        h3 = mac<EXACT>(h3, v.w, hw[i][k]);
+                    }
+                } else {
+                    const float *wx = wxt + (size_t)(x + i) * stride;
+                    for (uint32_t k = 0; k < hn[i]; ++k) {
+                        const float4 v = s_v[hl[i] + (int32_t)k];
+                        const float w = wx[k];
+                        h0 = mac<EXACT>(h0, v.x, w);
+                        h1 = mac<EXACT>(h1, v.y, w);
+                        h2 = mac<EXACT>(h2, v.z, w);
+                        h3 = mac<EXACT>(h3, v.w, w);
+                    }
+                }
+                o[i] = pack_u8<EXACT>(h3, 3, pack_u8<EXACT>(h2, 2, pack_u8<EXACT>(h1, 1, pack_u8<EXACT>(h0, 0, 0u))));
+            }
+            if (VEC)
+                *reinterpret_cast<uint4 *>(dst + (size_t)y * ow) = make_uint4(o[0], o[N > 1 ? 1 : 0], o[N > 2 ? 2 : 0], o[N > 3 ? 3 : 0]);
+            else
+                dst[(size_t)y * ow] = o[0];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); // the next row's V pass overwrites s_v
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+} // namespace
+
+const char *variant_name(Variant v){
+    switch (v) {
+    case Variant::NearestTable: return "nearest_table";
+    case Variant::NearestX2: return "nearest_x2_vec16";
+    case Variant::BilinearTable: return "bilinear_table_f32";
+    case Variant::BilinearX2Int: return "bilinear_x2_packed_u8";
+    case Variant::LanczosGeneral: return "lanczos3_general";
+    case Variant::ResizeRows: return "resize_rows_lds";
+    case Variant::LanczosX2RegWin: return "lanczos3_x2_regwin";
+    case Variant::FsrEasu: return "fsr1_easu_tile";
+    case Variant::FsrRcas: return "fsr1_rcas_tile";
+    case Variant::Fsr1Fused: return "fsr1_easu_rcas_fused_lds";
+    }
+    return "?";
+}
+
+namespace {
+// Output rows per wave of the row-walking table kernels: tall enough that the lerped / gathered source
+// rows get reused, small enough that the launch still has a few thousand waves.
+uint32_t rows_per_wave_for(const UpscaleLaunch &L, uint32_t cols_per_wave, uint32_t n_frames)
+{
+    const uint64_t strips = cdiv(L.ow, cols_per_wave);
+    const uint64_t t = (uint64_t)L.oh * strips * n_frames / 8192;
+    return (uint32_t)(t < 8 ? 8 : (t > 64 ? 64 : t));
+}
+} // namespace
+
+hipError_t launch_nearest_table(const UpscaleLaunch &L, const DeviceTables &T)
+{
+    const bool vec = (L.ow % 4) == 0;
+    const size_t ipx = (size_t)L.iw * L.ih, opx = (size_t)L.ow * L.oh;
+    return for_frame_chunks(L, [&](const uint8_t *in, uint8_t *out, uint32_t n) {
+        const uint32_t rpw = rows_per_wave_for(L, vec ? 256 : 64, n);
+        const dim3 block(kWave, 4), grid(cdiv(L.ow, vec ? 256 : 64), cdiv(cdiv(L.oh, rpw), 4), n);
+        auto *i32 = reinterpret_cast<const uint32_t *>(in);
+        auto *o32 = reinterpret_cast<uint32_t *>(out);
+        if (vec)
+            hipLaunchKernelGGL(k_nearest_table<true>, grid, block, 0, L.stream, i32, o32, T.nn_sx, T.nn_sy, L.iw, L.ow, L.oh, rpw, ipx, opx, L.in_sel);
+        else
+            hipLaunchKernelGGL(k_nearest_table<false>, grid, block, 0, L.stream, i32, o32, T.nn_sx, T.nn_sy, L.iw, L.ow, L.oh, rpw, ipx, opx, L.in_sel);
+    });
+}
+
+hipError_t launch_nearest_x2(const UpscaleLaunch &L)
+{
+    const size_t ipx = (size_t)L.iw * L.ih, opx = (size_t)L.ow * L.oh;
+    return for_frame_chunks(L, [&](const uint8_t *in, uint8_t *out, uint32_t n) {
+        const dim3 block(kWave, 4), grid(cdiv(L.iw, 256), cdiv(L.ih, 4), n);
+        hipLaunchKernelGGL(k_nearest_x2, grid, block, 0, L.stream, reinterpret_cast<const uint32_t *>(in),
+                           reinterpret_cast<uint32_t *>(out), L.iw, L.ih, ipx, opx, L.in_sel);
+    });
+}
+
+hipError_t launch_bilinear_table(const UpscaleLaunch &L, const DeviceTables &T, bool wgsl_form)
+{
+    const bool vec = (L.ow % 4) == 0;
+    const size_t ipx = (size_t)L.iw * L.ih, opx = (size_t)L.ow * L.oh;
+    return for_frame_chunks(L, [&](const uint8_t *in, uint8_t *out, uint32_t n) {
+        const uint32_t rpw = rows_per_wave_for(L, vec ? 256 : 64, n);
+        const dim3 block(kWave, 4), grid(cdiv(L.ow, vec ? 256 : 64), cdiv(cdiv(L.oh, rpw), 4), n);
+        auto *i32 = reinterpret_cast<const uint32_t *>(in);
+        auto *o32 = reinterpret_cast<uint32_t *>(out);
+#define NUS_BL(V, W)                                                                                         \
+    hipLaunchKernelGGL((k_bilinear_table<V, W>), grid, block, 0, L.stream, i32, o32, T.bl_x0, T.bl_fx, T.bl_y0, \
+                       T.bl_fy, L.iw, L.ih, L.ow, L.oh, rpw, ipx, opx, L.in_sel)
+        if (vec && wgsl_form) NUS_BL(true, true);
+        else if (vec) NUS_BL(true, false);
+        else if (wgsl_form) NUS_BL(false, true);
+        else NUS_BL(false, false);
+#undef NUS_BL
+    });
+}
+
+hipError_t launch_bilinear_x2_int(const UpscaleLaunch &L)
+{
+    const size_t ipx = (size_t)L.iw * L.ih, opx = (size_t)L.ow * L.oh;
+    return for_frame_chunks(L, [&](const uint8_t *in, uint8_t *out, uint32_t n) {
+        const dim3 block(kWave, 4), grid(cdiv(L.iw, 256), cdiv(L.ih, 4), n);
+        hipLaunchKernelGGL(k_bilinear_x2_int, grid, block, 0, L.stream, reinterpret_cast<const uint32_t *>(in),
+                           reinterpret_cast<uint32_t *>(out), L.iw, L.ih, ipx, opx, L.in_sel);
+    });
+}
+
+hipError_t launch_lanczos_general(const UpscaleLaunch &L, const DeviceTables &T, bool exact, uint32_t edge_cols)
+{
+    const size_t ipx = (size_t)L.iw * L.ih, opx = (size_t)L.ow * L.oh;
+    uint32_t ncols = L.ow, split = L.ow, gap = 0;
+    if (edge_cols && 2 * edge_cols < L.ow) {
+        ncols = 2 * edge_cols;
+        split = edge_cols;
+        gap = L.ow - 2 * edge_cols;
+    }
+    return for_frame_chunks(L, [&](const uint8_t *in, uint8_t *out, uint32_t n) {
+        const dim3 block(kWave, 4), grid(cdiv(ncols, 64), cdiv(L.oh, 4), n);
+        auto *i32 = reinterpret_cast<const uint32_t *>(in);
+        auto *o32 = reinterpret_cast<uint32_t *>(out);
+        if (exact)
+            hipLaunchKernelGGL(k_lanczos_general<true>, grid, block, 0, L.stream, i32, o32, T.lz_lx, T.lz_nx, T.lz_wx,
+                               T.lz_ly, T.lz_ny, T.lz_wy, T.lz_stride, L.iw, L.ow, L.oh, ncols, split, gap, ipx, opx, L.in_sel);
+        else
+            hipLaunchKernelGGL(k_lanczos_general<false>, grid, block, 0, L.stream, i32, o32, T.lz_lx, T.lz_nx, T.lz_wx,
+                               T.lz_ly, T.lz_ny, T.lz_wy, T.lz_stride, L.iw, L.ow, L.oh, ncols, split, gap, ipx, opx, L.in_sel);
+    });
+}
+
+hipError_t launch_resize_rows(const UpscaleLaunch &L, const DeviceTables &T, bool exact, uint32_t ncols_max, bool small_taps)
+{
+    const bool vec = (L.ow % 4) == 0;
+    const size_t ipx = (size_t)L.iw * L.ih, opx = (size_t)L.ow * L.oh;
+    const uint32_t segw = vec ? 256 : 64;
+    const size_t lds = (size_t)4 * (ncols_max + 8) * sizeof(float4);
+    return for_frame_chunks(L, [&](const uint8_t *in, uint8_t *out, uint32_t n) {
+        const uint64_t blocks_x = cdiv(cdiv(L.ow, segw), 4);
+        uint64_t rpb = (uint64_t)L.oh * blocks_x * n / 4096; // a few thousand blocks per launch
+        rpb = rpb < 4 ? 4 : (rpb > 32 ? 32 : rpb);
+        const dim3 block(kWave, 4), grid((uint32_t)blocks_x, cdiv(L.oh, (uint32_t)rpb), n);
+        auto *i32 = reinterpret_cast<const uint32_t *>(in);
+        auto *o32 = reinterpret_cast<uint32_t *>(out);
+#define NUS_RR(E, V, S)                                                                                             \
+    hipLaunchKernelGGL((k_resize_rows<E, V, S>), grid, block, lds, L.stream, i32, o32, T.lz_lx, T.lz_nx, T.lz_wx, T.lz_ly, \
+                       T.lz_ny, T.lz_wy, T.lz_stride, L.iw, L.ow, L.oh, (uint32_t)rpb, ncols_max, ipx, opx, L.in_sel)
+        if (exact) {
+            if (vec) { if (small_taps) NUS_RR(true, true, true); else NUS_RR(true, true, false); }
+            else { if (small_taps) NUS_RR(true, false, true); else NUS_RR(true, false, false); }
+        } else {
+            if (vec) { if (small_taps) NUS_RR(false, true, true); else NUS_RR(false, true, false); }
+            else { if (small_taps) NUS_RR(false, false, true); else NUS_RR(false, false, false); }
+        }
+#undef NUS_RR
+    });
+}
+
+} // namespace nus
