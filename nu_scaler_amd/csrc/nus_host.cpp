@@ -257,6 +257,14 @@ void HipUpscaler::choose_variant()
                 variant_ = Variant::ResizeRows;
                 resize_ncols_max_ = widest;
                 resize_small_taps_ = tx_.lz_max_taps <= 8 && ty_.lz_max_taps <= 8;
+                // widest union of the windows of a lane's 4 outputs (union-window H pass, 4 outputs per lane)
+                resize_union_taps_ = 0;
+                if ((ow_ % 4) == 0 && resize_small_taps_) {
+                    for (uint32_t x0 = 0; x0 < ow_; x0 += 4) {
+                        const uint32_t u = (uint32_t)(tx_.lz_left[x0 + 3] - tx_.lz_left[x0]) + 8u;
+                        if (u > resize_union_taps_) resize_union_taps_ = u;
+                    }
+                }
             }
         }
         break;
@@ -393,7 +401,9 @@ int HipUpscaler::enqueue(const uint8_t *d_in, uint8_t *d_out, uint32_t n_frames,
     case Variant::BilinearTable: e = launch_bilinear_table(L, dt_, wgsl_bilinear_); break;
     case Variant::BilinearX2Int: e = launch_bilinear_x2_int(L); break;
     case Variant::LanczosGeneral: e = launch_lanczos_general(L, dt_, lanczos_exact_, 0); break;
-    case Variant::ResizeRows: e = launch_resize_rows(L, dt_, lanczos_exact_, resize_ncols_max_, resize_small_taps_); break;
+    case Variant::ResizeRows:
+        e = launch_resize_rows(L, dt_, lanczos_exact_, resize_ncols_max_, resize_small_taps_, resize_union_taps_);
+        break;
     case Variant::FsrEasu: e = launch_fsr1(L, 0, easu_sharpness(), rcas_sharpness()); break;
     case Variant::FsrRcas: e = launch_fsr1(L, 1, easu_sharpness(), rcas_sharpness()); break;
     case Variant::Fsr1Fused: e = launch_fsr1(L, 2, easu_sharpness(), rcas_sharpness()); break;

@@ -148,6 +148,7 @@ private:
     bool force_per_pixel_ = false; // resize: never use the LDS row kernel
     uint32_t resize_ncols_max_ = 0; // LDS row length of the ResizeRows variant
     bool resize_small_taps_ = false;
+    uint32_t resize_union_taps_ = 0; // widest union of the tap windows of 4 adjacent outputs (0: unused)
     uint32_t rows_per_wave_ = 0; // 0: pick from the batch size
     float easu_sharp_ = -1.0f, rcas_sharp_ = -1.0f; // < 0: derive from quality_
     bool bgra_ = false;

@@ -290,7 +290,14 @@ __global__ __launch_bounds__(256) void k_lanczos_general(
 //                      H pass -- each lane sums its outputs' taps from LDS (16-B reads), packs, stores.
 // Same f32 operation order as k_lanczos_general (and the CPU algorithm); replaces its nx*ny taps per
 // pixel by nx + ny/scale.  SMALL: every window has <= 8 taps (any upscale), weights stay in VGPRs.
-template <bool EXACT, bool VEC, bool SMALL>
+// UNION > 0 (needs VEC and SMALL): the tap windows of a lane's 4 adjacent outputs overlap almost
+// completely on an upscale, so the H pass reads their UNION (<= UNION columns) from LDS once into
+// registers and gives every output a UNION-long weight vector that is zero outside its own window --
+// 10-12 LDS reads per lane per row instead of 32 (the LDS pipe was the limiter), for ~40 % more FMAs
+// whose extra terms are exact +-0.  Same order of the non-zero terms, so the bits do not change.
+constexpr uint32_t kResizeSlack = 16; // zeroed LDS entries behind each row: windows may read past its end
+
+template <bool EXACT, bool VEC, bool SMALL, int UNION>
 __global__ __launch_bounds__(256) void k_resize_rows(
     const uint32_t *__restrict__ in, uint32_t *__restrict__ out,
     const int32_t *__restrict__ lxt, const uint32_t *__restrict__ nxt, const float *__restrict__ wxt,
@@ -301,7 +308,8 @@ __global__ __launch_bounds__(256) void k_resize_rows(
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int N = VEC ? 4 : 1;
     constexpr uint32_t SEGW = kWave * N;
-    float4 *s_v = reinterpret_cast<float4 *>(smem) + (size_t)threadIdx.y * (ncols_max + 8);
+    static_assert(UNION == 0 || (VEC && SMALL), "the union-window H pass needs 4 outputs per lane and <= 8 taps");
+    float4 *s_v = reinterpret_cast<float4 *>(smem) + (size_t)threadIdx.y * (ncols_max + kResizeSlack);
     const uint32_t seg = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + threadIdx.y);
     const uint32_t X0 = seg * SEGW;
     if (X0 >= ow) return; // whole wave; no workgroup barriers below
@@ -315,7 +323,7 @@ __global__ __launch_bounds__(256) void k_resize_rows(
     const uint32_t *base = in + (size_t)blockIdx.z * in_frame_px;
     uint32_t *dst = out + (size_t)blockIdx.z * out_frame_px + x;
 
-    if (threadIdx.x < 8) s_v[(cmax - cmin) + threadIdx.x] = make_float4(0.0f, 0.0f, 0.0f, 0.0f); // slack, see the H pass
+    if (threadIdx.x < kResizeSlack) s_v[(cmax - cmin) + threadIdx.x] = make_float4(0.0f, 0.0f, 0.0f, 0.0f); // slack, see the H pass
     // horizontal windows of this lane's outputs
     int32_t hl[N];
     uint32_t hn[N];
@@ -325,9 +333,25 @@ __global__ __launch_bounds__(256) void k_resize_rows(
         const uint32_t xo = lane_active ? x + i : 0;
         hl[i] = lxt[xo] - cmin;
         hn[i] = nxt[xo];
-        if (SMALL) {
+        if (SMALL && UNION == 0) {
 #pragma unroll
             for (int k = 0; k < 8; ++k) hw[i][k] = wxt[(size_t)xo * stride + k]; // zero padded beyond hn
+        }
+    }
+    // union window: weights of output i re-based to the first output's left column
+    constexpr int UW = UNION > 0 ? UNION : 1;
+    float hu[N][UW];
+    if (UNION > 0) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            const uint32_t xo = lane_active ? x + i : 0;
+            const int32_t shift = hl[i] - hl[0]; // >= 0: left edges do not decrease with x
+#pragma unroll
+            for (int j = 0; j < UW; ++j) {
+                const int32_t k = j - shift;
+                const float w = wxt[(size_t)xo * stride + (uint32_t)(k < 0 ? 0 : (k > 7 ? 7 : k))];
+                hu[i][j] = (k >= 0 && k < 8) ? w : 0.0f;
+            }
         }
     }
 
@@ -399,10 +423,23 @@ __global__ __launch_bounds__(256) void k_resize_rows(
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         if (lane_active) {
             uint32_t o[N];
+            float4 R[UW];
+            if (UNION > 0) {
+#pragma unroll
+                for (int j = 0; j < UW; ++j) R[j] = s_v[hl[0] + j];
+            }
 #pragma unroll
             for (int i = 0; i < N; ++i) {
                 float h0 = 0.0f, h1 = 0.0f, h2 = 0.0f, h3 = 0.0f;
-                if (SMALL) {
+                if (UNION > 0) {
+#pragma unroll
+                    for (int j = 0; j < UW; ++j) {
+                        h0 = mac<EXACT>(h0, R[j].x, hu[i][j]);
+                        h1 = mac<EXACT>(h1, R[j].y, hu[i][j]);
+                        h2 = mac<EXACT>(h2, R[j].z, hu[i][j]);
+                        h3 = mac<EXACT>(h3, R[j].w, hu[i][j]);
+                    }
+                } else if (SMALL) {
                     // all 8 slots, no per-lane branch: slots beyond the window carry weight 0 and read
                     // finite values (the row has 8 zeroed slack entries), so they add +-0
 #pragma unroll
@@ -543,12 +580,15 @@ hipError_t launch_lanczos_general(const UpscaleLaunch &L, const DeviceTables &T,
     });
 }
 
-hipError_t launch_resize_rows(const UpscaleLaunch &L, const DeviceTables &T, bool exact, uint32_t ncols_max, bool small_taps)
+hipError_t launch_resize_rows(const UpscaleLaunch &L, const DeviceTables &T, bool exact, uint32_t ncols_max, bool small_taps,
+                              uint32_t union_taps)
 {
     const bool vec = (L.ow % 4) == 0;
     const size_t ipx = (size_t)L.iw * L.ih, opx = (size_t)L.ow * L.oh;
     const uint32_t segw = vec ? 256 : 64;
-    const size_t lds = (size_t)4 * (ncols_max + 8) * sizeof(float4);
+    const size_t lds = (size_t)4 * (ncols_max + kResizeSlack) * sizeof(float4);
+    // union-window H pass: widest union of a lane's 4 windows, rounded up to an instantiated size
+    const int uni = (vec && small_taps && union_taps > 0 && union_taps <= 12) ? (union_taps <= 10 ? 10 : 12) : 0;
     return for_frame_chunks(L, [&](const uint8_t *in, uint8_t *out, uint32_t n) {
         const uint64_t blocks_x = cdiv(cdiv(L.ow, segw), 4);
         uint64_t rpb = (uint64_t)L.oh * blocks_x * n / 4096; // a few thousand blocks per launch
@@ -556,15 +596,19 @@ hipError_t launch_resize_rows(const UpscaleLaunch &L, const DeviceTables &T, boo
         const dim3 block(kWave, 4), grid((uint32_t)blocks_x, cdiv(L.oh, (uint32_t)rpb), n);
         auto *i32 = reinterpret_cast<const uint32_t *>(in);
         auto *o32 = reinterpret_cast<uint32_t *>(out);
-#define NUS_RR(E, V, S)                                                                                             \
-    hipLaunchKernelGGL((k_resize_rows<E, V, S>), grid, block, lds, L.stream, i32, o32, T.lz_lx, T.lz_nx, T.lz_wx, T.lz_ly, \
+#define NUS_RR(E, V, S, U)                                                                                             \
+    hipLaunchKernelGGL((k_resize_rows<E, V, S, U>), grid, block, lds, L.stream, i32, o32, T.lz_lx, T.lz_nx, T.lz_wx, T.lz_ly, \
                        T.lz_ny, T.lz_wy, T.lz_stride, L.iw, L.ow, L.oh, (uint32_t)rpb, ncols_max, ipx, opx, L.in_sel)
         if (exact) {
-            if (vec) { if (small_taps) NUS_RR(true, true, true); else NUS_RR(true, true, false); }
-            else { if (small_taps) NUS_RR(true, false, true); else NUS_RR(true, false, false); }
+            if (uni == 10) NUS_RR(true, true, true, 10);
+            else if (uni == 12) NUS_RR(true, true, true, 12);
+            else if (vec) { if (small_taps) NUS_RR(true, true, true, 0); else NUS_RR(true, true, false, 0); }
+            else { if (small_taps) NUS_RR(true, false, true, 0); else NUS_RR(true, false, false, 0); }
         } else {
-            if (vec) { if (small_taps) NUS_RR(false, true, true); else NUS_RR(false, true, false); }
-            else { if (small_taps) NUS_RR(false, false, true); else NUS_RR(false, false, false); }
+            if (uni == 10) NUS_RR(false, true, true, 10);
+            else if (uni == 12) NUS_RR(false, true, true, 12);
+            else if (vec) { if (small_taps) NUS_RR(false, true, true, 0); else NUS_RR(false, true, false, 0); }
+            else { if (small_taps) NUS_RR(false, false, true, 0); else NUS_RR(false, false, false, 0); }
         }
 #undef NUS_RR
     });

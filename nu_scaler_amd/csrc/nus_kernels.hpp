@@ -71,8 +71,9 @@ hipError_t launch_lanczos_general(const UpscaleLaunch &L, const DeviceTables &T,
                                   uint32_t edge_cols);
 // ncols_max: widest input-column footprint of a 64*N-column output segment (LDS row length);
 // small_taps: every tap window has <= 8 taps.
+// union_taps: widest union of the tap windows of 4 adjacent outputs (x % 4 == 0), 0 = unknown / do not use.
 hipError_t launch_resize_rows(const UpscaleLaunch &L, const DeviceTables &T, bool exact, uint32_t ncols_max,
-                              bool small_taps);
+                              bool small_taps, uint32_t union_taps);
 // main x2 kernel only: the first / last kLanczosX2EdgeCols output columns are NOT written;
 // follow it with launch_lanczos_x2_edges(L, T, exact).
 hipError_t launch_lanczos_x2(const UpscaleLaunch &L, const DeviceTables &T, bool exact,
