@@ -148,6 +148,11 @@ int HipUpscaler::set_option(const char *key, int64_t value)
         force_per_pixel_ = value != 0;
         return kOk;
     }
+    if (!strcmp(key, "force_rows")) {
+        if (initialized_) return fail(kInvalidArgument, "force_rows must be set before initialize");
+        force_rows_ = value != 0;
+        return kOk;
+    }
     if (!strcmp(key, "rows_per_wave")) {
         if (value < 0 || value > 4096) return fail(kInvalidArgument, "rows_per_wave out of range");
         rows_per_wave_ = (uint32_t)value;
@@ -264,6 +269,13 @@ void HipUpscaler::choose_variant()
                         const uint32_t u = (uint32_t)(tx_.lz_left[x0 + 3] - tx_.lz_left[x0]) + 8u;
                         if (u > resize_union_taps_) resize_union_taps_ = u;
                     }
+                    // register-window variant: up-scaling shapes whose first tap row moves by at most one per output row
+                    bool win_ok = ty_.lz_max_taps <= 7 && widest <= 192 && !force_rows_;
+                    for (uint32_t y = 1; win_ok && y < oh_; ++y) {
+                        const int32_t d = ty_.lz_left[y] - ty_.lz_left[y - 1];
+                        win_ok = d == 0 || d == 1;
+                    }
+                    if (win_ok) variant_ = Variant::ResizeWin;
                 }
             }
         }
@@ -401,6 +413,7 @@ int HipUpscaler::enqueue(const uint8_t *d_in, uint8_t *d_out, uint32_t n_frames,
     case Variant::BilinearTable: e = launch_bilinear_table(L, dt_, wgsl_bilinear_); break;
     case Variant::BilinearX2Int: e = launch_bilinear_x2_int(L); break;
     case Variant::LanczosGeneral: e = launch_lanczos_general(L, dt_, lanczos_exact_, 0); break;
+    case Variant::ResizeWin: e = launch_resize_win(L, dt_, lanczos_exact_, resize_ncols_max_, resize_union_taps_); break;
     case Variant::ResizeRows:
         e = launch_resize_rows(L, dt_, lanczos_exact_, resize_ncols_max_, resize_small_taps_, resize_union_taps_);
         break;

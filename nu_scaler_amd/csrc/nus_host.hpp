@@ -146,6 +146,7 @@ private:
     bool lanczos_exact_ = false;
     bool force_general_ = false;
     bool force_per_pixel_ = false; // resize: never use the LDS row kernel
+    bool force_rows_ = false;      // resize: never use the register-window variant of it
     uint32_t resize_ncols_max_ = 0; // LDS row length of the ResizeRows variant
     bool resize_small_taps_ = false;
     uint32_t resize_union_taps_ = 0; // widest union of the tap windows of 4 adjacent outputs (0: unused)

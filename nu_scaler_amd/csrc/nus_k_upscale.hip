@@ -473,6 +473,168 @@ __global__ __launch_bounds__(256) void k_resize_rows(
     }
 }
 
+// Up-scaling variant of k_resize_rows with the vertical taps served from registers, as in the x2 kernel:
+// on an upscale the first tap row ly[y] advances by 0 or 1 per output row (host-checked), so each lane
+// keeps a WR-row f32 window of its VC input columns whose row 0 is always ly[y]; an advance shifts the
+// window by one row (register moves) and converts the one new row, prefetched a step ahead.  The V
+// pass is then WR FMAs per value with no load, no u8->f32 convert and no index arithmetic in the chain;
+// rows of the window beyond the tap count carry weight 0 (the table is zero padded) and hold finite
+// pixels (row index clamped), so they add +-0.  H pass and LDS row exactly as in k_resize_rows.
+// Needs: ow % 4 == 0, <= WR vertical and <= 8 horizontal taps, segment footprint <= 64 * VC columns.
+constexpr int kResizeWinRows = 7; // Lanczos-3 on an upscale touches at most 7 input rows
+
+template <bool EXACT, int VC, int UNION>
+__global__ __launch_bounds__(256) void k_resize_win(
+    const uint32_t *__restrict__ in, uint32_t *__restrict__ out,
+    const int32_t *__restrict__ lxt, const uint32_t *__restrict__ nxt, const float *__restrict__ wxt,
+    const int32_t *__restrict__ lyt, const float *__restrict__ wyt,
+    uint32_t stride, uint32_t iw, uint32_t ih, uint32_t ow, uint32_t oh, uint32_t rows_per_block, uint32_t ncols_max,
+    size_t in_frame_px, size_t out_frame_px, uint32_t sel)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int N = 4, WR = kResizeWinRows;
+    constexpr uint32_t SEGW = kWave * N;
+    float4 *s_v = reinterpret_cast<float4 *>(smem) + (size_t)threadIdx.y * (ncols_max + kResizeSlack);
+    const uint32_t seg = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + threadIdx.y);
+    const uint32_t X0 = seg * SEGW;
+    if (X0 >= ow) return; // whole wave; no workgroup barriers below
+    const uint32_t Xlast = umin(X0 + SEGW, ow) - 1;
+    const int32_t cmin = lxt[X0];
+    const int32_t ncols = lxt[Xlast] + (int32_t)nxt[Xlast] - cmin; // <= 64 * VC (host-checked)
+    const uint32_t x = X0 + threadIdx.x * N;
+    const bool lane_active = x < ow;
+    const uint32_t y_begin = blockIdx.y * rows_per_block;
+    const uint32_t y_end = umin(y_begin + rows_per_block, oh);
+    const uint32_t *base = in + (size_t)blockIdx.z * in_frame_px;
+    uint32_t *dst = out + (size_t)blockIdx.z * out_frame_px + x;
+
+    if (threadIdx.x < kResizeSlack) s_v[ncols + threadIdx.x] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    // horizontal windows of this lane's 4 outputs
+    int32_t hl[N];
+    float hw[UNION > 0 ? 1 : N][8];
+    constexpr int UW = UNION > 0 ? UNION : 1;
+    float hu[UNION > 0 ? N : 1][UW];
+#pragma unroll
+    for (int i = 0; i < N; ++i) hl[i] = lxt[lane_active ? x + i : 0] - cmin;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        const uint32_t xo = lane_active ? x + i : 0;
+        if (UNION > 0) {
+            const int32_t shift = hl[i] - hl[0];
+#pragma unroll
+            for (int j = 0; j < UW; ++j) {
+                const int32_t k = j - shift;
+                const float w = wxt[(size_t)xo * stride + (uint32_t)(k < 0 ? 0 : (k > 7 ? 7 : k))];
+                hu[i][j] = (k >= 0 && k < 8) ? w : 0.0f;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) hw[i][k] = wxt[(size_t)xo * stride + k];
+        }
+    }
+
+    // this lane's VC input columns (clamped into the row: columns past the footprint are never read back)
+    uint32_t col[VC];
+#pragma unroll
+    for (int m = 0; m < VC; ++m) col[m] = umin((uint32_t)cmin + threadIdx.x * VC + m, iw - 1);
+    auto load_row = [&](int32_t r, uint32_t (&raw)[VC]) {
+        const uint32_t rr = (uint32_t)(r < 0 ? 0 : (r > (int32_t)ih - 1 ? (int32_t)ih - 1 : r));
+        const uint32_t *row = base + (size_t)rr * iw;
+#pragma unroll
+        for (int m = 0; m < VC; ++m) raw[m] = row[col[m]];
+    };
+    auto cvt = [&](const uint32_t (&raw)[VC], float (&dstrow)[VC * 4]) {
+#pragma unroll
+        for (int m = 0; m < VC; ++m) {
+            const uint32_t p = swz(raw[m], sel);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) dstrow[m * 4 + c] = ch_f32(p, c);
+        }
+    };
+
+    int32_t top = __builtin_amdgcn_readfirstlane(lyt[y_begin]);
+    float win[WR][VC * 4];
+    {
+        uint32_t raw[WR][VC];
+#pragma unroll
+        for (int j = 0; j < WR; ++j) load_row(top + j, raw[j]);
+#pragma unroll
+        for (int j = 0; j < WR; ++j) cvt(raw[j], win[j]);
+    }
+    uint32_t next[VC]; // row top + WR, requested one advance ahead
+    load_row(top + WR, next);
+
+    for (uint32_t y = y_begin; y < y_end; ++y) {
+        const int32_t ly = __builtin_amdgcn_readfirstlane(lyt[y]);
+        if (ly != top) { // wave-uniform; ly == top + 1 (host-checked)
+#pragma unroll
+            for (int j = 0; j + 1 < WR; ++j)
+#pragma unroll
+                for (int k = 0; k < VC * 4; ++k) win[j][k] = win[j + 1][k];
+            cvt(next, win[WR - 1]);
+            top = ly;
+            load_row(top + WR, next);
+        }
+        const float *wy = wyt + (size_t)y * stride;
+        float wv[WR];
+#pragma unroll
+        for (int j = 0; j < WR; ++j) {
+            wv[j] = wy[j]; // zero padded beyond the row's tap count
+            asm volatile("" : "+v"(wv[j])); // VGPR copy: scalar operands halve the VALU issue rate
+        }
+#pragma unroll
+        for (int m = 0; m < VC; ++m) {
+            float v[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                float acc = 0.0f;
+#pragma unroll
+                for (int j = 0; j < WR; ++j) acc = mac<EXACT>(acc, win[j][m * 4 + c], wv[j]);
+                v[c] = acc;
+            }
+            const int32_t ci = (int32_t)threadIdx.x * VC + m;
+            if (ci < ncols) s_v[ci] = make_float4(v[0], v[1], v[2], v[3]);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (lane_active) {
+            uint32_t o[N];
+            float4 R[UW];
+            if (UNION > 0) {
+#pragma unroll
+                for (int j = 0; j < UW; ++j) R[j] = s_v[hl[0] + j];
+            }
+#pragma unroll
+            for (int i = 0; i < N; ++i) {
+                float h0 = 0.0f, h1 = 0.0f, h2 = 0.0f, h3 = 0.0f;
+                if (UNION > 0) {
+#pragma unroll
+                    for (int j = 0; j < UW; ++j) {
+                        h0 = mac<EXACT>(h0, R[j].x, hu[i][j]);
+                        h1 = mac<EXACT>(h1, R[j].y, hu[i][j]);
+                        h2 = mac<EXACT>(h2, R[j].z, hu[i][j]);
+                        h3 = mac<EXACT>(h3, R[j].w, hu[i][j]);
+                    }
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        const float4 v = s_v[hl[i] + k];
+                        h0 = mac<EXACT>(h0, v.x, hw[i][k]);
+                        h1 = mac<EXACT>(h1, v.y, hw[i][k]);
+                        h2 = mac<EXACT>(h2, v.z, hw[i][k]);
+                        h3 = mac<EXACT>(h3, v.w, hw[i][k]);
+                    }
+                }
+                o[i] = pack_u8<EXACT>(h3, 3, pack_u8<EXACT>(h2, 2, pack_u8<EXACT>(h1, 1, pack_u8<EXACT>(h0, 0, 0u))));
+            }
+            *reinterpret_cast<uint4 *>(dst + (size_t)y * ow) = make_uint4(o[0], o[1], o[2], o[3]);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); // the next row's V pass overwrites s_v
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 } // namespace
 
 const char *variant_name(Variant v){
@@ -483,6 +645,7 @@ const char *variant_name(Variant v){
     case Variant::BilinearX2Int: return "bilinear_x2_packed_u8";
     case Variant::LanczosGeneral: return "lanczos3_general";
     case Variant::ResizeRows: return "resize_rows_lds";
+    case Variant::ResizeWin: return "resize_regwin_lds";
     case Variant::LanczosX2RegWin: return "lanczos3_x2_regwin";
     case Variant::FsrEasu: return "fsr1_easu_tile";
     case Variant::FsrRcas: return "fsr1_rcas_tile";
@@ -611,6 +774,37 @@ hipError_t launch_resize_rows(const UpscaleLaunch &L, const DeviceTables &T, boo
             else { if (small_taps) NUS_RR(false, false, true, 0); else NUS_RR(false, false, false, 0); }
         }
 #undef NUS_RR
+    });
+}
+
+hipError_t launch_resize_win(const UpscaleLaunch &L, const DeviceTables &T, bool exact, uint32_t ncols_max,
+                             uint32_t union_taps)
+{
+    const size_t ipx = (size_t)L.iw * L.ih, opx = (size_t)L.ow * L.oh;
+    const size_t lds = (size_t)4 * (ncols_max + kResizeSlack) * sizeof(float4);
+    const int vc = ncols_max <= 128 ? 2 : (ncols_max <= 192 ? 3 : 0); // 4 columns per lane: 256 VGPRs, slower than the LDS-row kernel
+    if (vc == 0 || (L.ow % 4) != 0) return hipErrorInvalidValue; // the host never selects this variant then
+    const int uni = (union_taps > 0 && union_taps <= 10) ? 10 : 0; // wider unions: plain 8-slot H pass (VGPR budget)
+    return for_frame_chunks(L, [&](const uint8_t *in, uint8_t *out, uint32_t n) {
+        const uint64_t blocks_x = cdiv(cdiv(L.ow, 256), 4);
+        uint64_t rpb = (uint64_t)L.oh * blocks_x * n / 4096; // a few thousand blocks per launch ...
+        rpb = rpb < 16 ? 16 : (rpb > 64 ? 64 : rpb);          // ... each tall enough to amortise its window fill
+        const dim3 block(kWave, 4), grid((uint32_t)blocks_x, cdiv(L.oh, (uint32_t)rpb), n);
+        auto *i32 = reinterpret_cast<const uint32_t *>(in);
+        auto *o32 = reinterpret_cast<uint32_t *>(out);
+#define NUS_RW(E, C, U)                                                                                              \
+    hipLaunchKernelGGL((k_resize_win<E, C, U>), grid, block, lds, L.stream, i32, o32, T.lz_lx, T.lz_nx, T.lz_wx, T.lz_ly, \
+                       T.lz_wy, T.lz_stride, L.iw, L.ih, L.ow, L.oh, (uint32_t)rpb, ncols_max, ipx, opx, L.in_sel)
+#define NUS_RW2(E)                                                       \
+    if (vc == 2) { if (uni) NUS_RW(E, 2, 10); else NUS_RW(E, 2, 0); }    \
+    else { if (uni) NUS_RW(E, 3, 10); else NUS_RW(E, 3, 0); }
+        if (exact) {
+            NUS_RW2(true)
+        } else {
+            NUS_RW2(false)
+        }
+#undef NUS_RW2
+#undef NUS_RW
     });
 }
 

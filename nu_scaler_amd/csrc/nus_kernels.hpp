@@ -54,6 +54,7 @@ enum class Variant : int {
     BilinearX2Int,    // exact x2, CPU arithmetic done in packed-u8 integer ops
     LanczosGeneral,   // any scale, direct separable evaluation per output pixel (fallback)
     ResizeRows,       // any scale, separable: V pass into an LDS row, H pass out of it
+    ResizeWin,        // up-scaling: V pass from a register row window (as the x2 kernel), H pass through the LDS row
     LanczosX2RegWin,  // exact x2, register sliding window + wave shifts
     FsrEasu,          // FSR1-style EASU alone (any scale)
     FsrRcas,          // FSR1-style RCAS alone (same size in and out)
@@ -74,6 +75,10 @@ hipError_t launch_lanczos_general(const UpscaleLaunch &L, const DeviceTables &T,
 // union_taps: widest union of the tap windows of 4 adjacent outputs (x % 4 == 0), 0 = unknown / do not use.
 hipError_t launch_resize_rows(const UpscaleLaunch &L, const DeviceTables &T, bool exact, uint32_t ncols_max,
                               bool small_taps, uint32_t union_taps);
+// Up-scaling variant (ow % 4 == 0, <= 7 vertical / <= 8 horizontal taps, first tap row advancing by <= 1
+// per output row, ncols_max <= 192): vertical taps from a register window.
+hipError_t launch_resize_win(const UpscaleLaunch &L, const DeviceTables &T, bool exact, uint32_t ncols_max,
+                             uint32_t union_taps);
 // main x2 kernel only: the first / last kLanczosX2EdgeCols output columns are NOT written;
 // follow it with launch_lanczos_x2_edges(L, T, exact).
 hipError_t launch_lanczos_x2(const UpscaleLaunch &L, const DeviceTables &T, bool exact,

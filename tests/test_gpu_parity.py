@@ -89,7 +89,7 @@ def test_lanczos_x2(nsc, oracle_mod, size):
     want = oracle_mod.lanczos3(img, 2 * w, 2 * h)
     out, u = _up(nsc, "lanczos3", img, 2 * w, 2 * h)
     # the register-window kernel needs >= 16 rows and columns; smaller frames take the general one
-    assert u.kernel_variant == ("lanczos3_x2_regwin" if w >= 16 and h >= 16 else "resize_rows_lds")
+    assert u.kernel_variant == ("lanczos3_x2_regwin" if w >= 16 and h >= 16 else "resize_regwin_lds")
     d = np.abs(out.astype(np.int16) - want.astype(np.int16))
     assert d.max() <= 1, f"FMA mode outside +-1 LSB (max {d.max()})"
     assert (d > 0).mean() < 1e-3
@@ -98,7 +98,9 @@ def test_lanczos_x2(nsc, oracle_mod, size):
     assert np.array_equal(out_e, want)
     # the general kernel agrees with the fast one (same weights, same op order)
     out_g, ug = _up(nsc, "lanczos3", img, 2 * w, 2 * h, lanczos_mode="exact", options={"force_general": 1})
-    assert ug.kernel_variant == "resize_rows_lds" and np.array_equal(out_g, want)
+    assert ug.kernel_variant == "resize_regwin_lds" and np.array_equal(out_g, want)
+    out_r, ur = _up(nsc, "lanczos3", img, 2 * w, 2 * h, lanczos_mode="exact", options={"force_general": 1, "force_rows": 1})
+    assert ur.kernel_variant == "resize_rows_lds" and np.array_equal(out_r, want)
     out_p, up_ = _up(nsc, "lanczos3", img, 2 * w, 2 * h, lanczos_mode="exact", options={"force_general": 1, "force_per_pixel": 1})
     assert up_.kernel_variant == "lanczos3_general" and np.array_equal(out_p, want)
     # every rows-per-wave split produces the same image
@@ -129,7 +131,8 @@ def test_bicubic_and_triangle_resize(nsc, oracle_mod, alg, filt, dims):
     want = oracle_mod.resize(img, ow, oh, filt)
     out, u = _up(nsc, alg, img, ow, oh)
     x2 = (ow, oh) == (2 * w, 2 * h) and w % 4 == 0 and w >= 16 and h >= 16
-    assert u.kernel_variant == ("lanczos3_x2_regwin" if x2 else "resize_rows_lds")
+    upscale_by4 = ow % 4 == 0 and ow >= w and oh >= h
+    assert u.kernel_variant == ("lanczos3_x2_regwin" if x2 else ("resize_regwin_lds" if upscale_by4 else "resize_rows_lds"))
     assert _maxdiff(out, want) <= 1
     out_e, _ = _up(nsc, alg, img, ow, oh, lanczos_mode="exact")
     assert np.array_equal(out_e, want)
@@ -471,6 +474,7 @@ def _bgra(img):
                                     ("lanczos3", {}), ("lanczos3", {"lanczos_mode": "exact"}), ("bicubic", {}),
                                     ("triangle", {}), ("fsr1", {}), ("easu", {})])
 @pytest.mark.parametrize("dims,opts", [(((252, 40), (504, 80)), {}), (((252, 40), (504, 80)), {"force_general": 1}),
+                                       (((252, 40), (504, 80)), {"force_general": 1, "force_rows": 1}),
                                        (((48, 27), (72, 41)), {}), (((64, 36), (128, 72)), {"force_per_pixel": 1, "force_general": 1}),
                                        (((100, 40), (30, 12)), {})])
 def test_bgra_input_equals_swizzle_then_upscale(nsc, oracle_mod, alg, kw, dims, opts):
@@ -594,3 +598,22 @@ def test_lanczos_x2_opaque_and_mixed_alpha_rows(nsc, oracle_mod, alg):
         assert (got[..., 3][far] == 255).all() and (want[..., 3][far] == 255).all(), name
         got_e, _ = _up(nsc, alg, img, 2 * w, 2 * h, lanczos_mode="exact")
         assert np.array_equal(got_e, want), name
+
+
+@pytest.mark.parametrize("alg,filt", [("lanczos3", 0), ("bicubic", 1), ("triangle", 2)])
+@pytest.mark.parametrize("dims", [((320, 180), (480, 270)), ((320, 180), (960, 540)), ((240, 135), (960, 540)),
+                                  ((640, 360), (960, 540)), ((100, 37), (1000, 99)), ((480, 270), (680, 384)), ((600, 40), (900, 41)),
+                                  ((255, 33), (1020, 200)), ((64, 64), (64, 64))])
+def test_resize_register_window_variant(nsc, oracle_mod, alg, filt, dims):
+    """Up-scaling shapes (x1 .. x10, ow % 4 == 0) take the register-window variant; it must equal the LDS-row
+    variant bit for bit in both modes, and the oracle in EXACT mode."""
+    (w, h), (ow, oh) = dims
+    img = oracle_mod.gen_noise(w, h, 91)
+    want = oracle_mod.resize(img, ow, oh, filt)
+    got_e, u = _up(nsc, alg, img, ow, oh, lanczos_mode="exact")
+    assert u.kernel_variant == "resize_regwin_lds"
+    assert np.array_equal(got_e, want)
+    got_f, _ = _up(nsc, alg, img, ow, oh)
+    ref_f, ur = _up(nsc, alg, img, ow, oh, options={"force_rows": 1})
+    assert ur.kernel_variant == "resize_rows_lds"
+    assert np.array_equal(got_f, ref_f) and _maxdiff(got_f, want) <= 1
