@@ -249,6 +249,20 @@ void HipUpscaler::choose_variant()
              // same ratio on both axes: the interior weights of the two passes are the same 12 numbers
              memcmp(&wx6_[(size_t)8 * 6], &wy6_[(size_t)8 * 6], 12 * sizeof(float)) == 0;
         variant_ = ok ? Variant::LanczosX2RegWin : Variant::LanczosGeneral;
+        // integer factors x3 / x4: the same register-window design (nus_k_lanczos_xs.hip)
+        xs_factor_ = 0;
+        for (uint32_t S = 3; !ok && S <= 4 && !force_general_; ++S) {
+            if (ow_ != S * iw_ || oh_ != S * ih_ || (iw_ % 4) != 0 || iw_ < 16 || ih_ < 16 ||
+                (uint64_t)ow_ * oh_ * 4 >= (1ull << 31))
+                continue;
+            if (lanczos_xs_phase_frame(tx_, S, wx6_) && lanczos_xs_phase_frame(ty_, S, wy6_) &&
+                lanczos_xs_interior_uniform(tx_, S, wx6_) && lanczos_xs_interior_uniform(ty_, S, wy6_) &&
+                memcmp(&wx6_[(size_t)8 * S * 6], &wy6_[(size_t)8 * S * 6], (size_t)S * 6 * sizeof(float)) == 0) {
+                xs_factor_ = S;
+                variant_ = Variant::LanczosXsRegWin;
+                ok = true;
+            }
+        }
         if (!ok && !force_per_pixel_) {
             // LDS row kernel: needs the widest segment footprint to fit the per-wave LDS row
             const uint32_t segw = (ow_ % 4) == 0 ? 256 : 64;
@@ -324,6 +338,16 @@ int HipUpscaler::upload_tables()
         UP(ty_.lz_ntaps, lz_ny);
         UP(ty_.lz_w, lz_wy);
         dt_.lz_stride = kResizeMaxTaps;
+        if (variant_ == Variant::LanczosXsRegWin) {
+            UP(wy6_, lz_wy6);
+            for (uint32_t p = 0; p < xs_factor_; ++p)
+                for (int j = 0; j < 6; ++j) dt_.lz_wxs[p][j] = wx6_[((size_t)8 * xs_factor_ + p) * 6 + j];
+            for (uint32_t q = 0; q < 4 * xs_factor_; ++q)
+                for (int j = 0; j < 6; ++j) {
+                    dt_.lz_wxs_left[q][j] = wx6_[(size_t)q * 6 + j];
+                    dt_.lz_wxs_right[q][j] = wx6_[((size_t)ow_ - 4 * xs_factor_ + q) * 6 + j];
+                }
+        }
         if (variant_ == Variant::LanczosX2RegWin) {
             UP(wy6_, lz_wy6);
             for (int j = 0; j < 6; ++j) {
@@ -420,6 +444,10 @@ int HipUpscaler::enqueue(const uint8_t *d_in, uint8_t *d_out, uint32_t n_frames,
     case Variant::FsrEasu: e = launch_fsr1(L, 0, easu_sharpness(), rcas_sharpness()); break;
     case Variant::FsrRcas: e = launch_fsr1(L, 1, easu_sharpness(), rcas_sharpness()); break;
     case Variant::Fsr1Fused: e = launch_fsr1(L, 2, easu_sharpness(), rcas_sharpness()); break;
+    case Variant::LanczosXsRegWin:
+        e = launch_lanczos_xs(L, dt_, lanczos_exact_, xs_factor_, rows_per_wave_);
+        if (e == hipSuccess) e = launch_lanczos_xs_edges(L, dt_, lanczos_exact_, xs_factor_); // border columns
+        break;
     case Variant::LanczosX2RegWin: {
         uint32_t th = rows_per_wave_;
         if (th == 0) {

@@ -25,6 +25,8 @@ struct DeviceTables {
     const float *lz_wy6 = nullptr;
     float lz_wxe[6] = {0}, lz_wxo[6] = {0}; // interior horizontal weights, even / odd outputs
     float lz_wx_left[48] = {0}, lz_wx_right[48] = {0}; // phase-frame weights of the 8 edge outputs per side
+    float lz_wxs[4][6] = {{0}};                        // integer factors x3 / x4: interior weights per phase
+    float lz_wxs_left[16][6] = {{0}}, lz_wxs_right[16][6] = {{0}}; // ... and of the 4 S edge outputs per side
 };
 
 // v_perm_b32 selectors applied to every loaded input pixel: RGBA8 as is, or BGRA8 (capture order,
@@ -56,6 +58,7 @@ enum class Variant : int {
     ResizeRows,       // any scale, separable: V pass into an LDS row, H pass out of it
     ResizeWin,        // up-scaling: V pass from a register row window (as the x2 kernel), H pass through the LDS row
     LanczosX2RegWin,  // exact x2, register sliding window + wave shifts
+    LanczosXsRegWin,  // exact x3 / x4, same design with S output rows per input row
     FsrEasu,          // FSR1-style EASU alone (any scale)
     FsrRcas,          // FSR1-style RCAS alone (same size in and out)
     Fsr1Fused,        // EASU tile (+1 px halo) in LDS, RCAS out of it
@@ -85,6 +88,11 @@ hipError_t launch_lanczos_x2(const UpscaleLaunch &L, const DeviceTables &T, bool
                              uint32_t rows_per_wave);
 
 hipError_t launch_lanczos_x2_edges(const UpscaleLaunch &L, const DeviceTables &T, bool exact);
+// exact x3 / x4 (factor): main kernel only, the first / last 4 * factor output columns are NOT written;
+// follow it with launch_lanczos_xs_edges(L, T, exact, factor).
+hipError_t launch_lanczos_xs(const UpscaleLaunch &L, const DeviceTables &T, bool exact, uint32_t factor,
+                             uint32_t rows_per_wave);
+hipError_t launch_lanczos_xs_edges(const UpscaleLaunch &L, const DeviceTables &T, bool exact, uint32_t factor);
 // FSR1-style passes (fsr.rs:24-260).  mode 0: EASU, 1: RCAS (iw == ow, ih == oh), 2: EASU then RCAS fused.
 hipError_t launch_fsr1(const UpscaleLaunch &L, int mode, float easu_sharpness, float rcas_sharpness);
 

@@ -159,6 +159,36 @@ bool lanczos_x2_interior_uniform(const AxisTables &t, const std::vector<float> &
     return true;
 }
 
+bool lanczos_xs_phase_frame(const AxisTables &t, uint32_t S, std::vector<float> &w6)
+{
+    if (S < 2 || t.out_n != S * t.in_n || t.lz_max_taps < 0) return false;
+    w6.assign((size_t)t.out_n * 6, 0.0f);
+    for (uint32_t o = 0; o < t.out_n; ++o) {
+        const uint32_t p = o % S;
+        const int32_t base = (int32_t)(o / S) - 3 + (2 * p + 1 > S ? 1 : 0);
+        const float *ws = t.lz_w.data() + (size_t)o * kResizeMaxTaps;
+        for (uint32_t i = 0; i < t.lz_ntaps[o]; ++i) {
+            const int32_t j = t.lz_left[o] + (int32_t)i - base;
+            if (j < 0 || j >= 6) {
+                if (ws[i] != 0.0f) return false;
+                continue;
+            }
+            w6[(size_t)o * 6 + j] = ws[i];
+        }
+    }
+    return true;
+}
+
+bool lanczos_xs_interior_uniform(const AxisTables &t, uint32_t S, const std::vector<float> &w6)
+{
+    if (t.in_n < 16) return false;
+    for (uint32_t o = 4 * S; o + 4 * S < t.out_n; ++o) {
+        const float *ref = w6.data() + (size_t)(8 * S + o % S) * 6;
+        if (std::memcmp(ref, w6.data() + (size_t)o * 6, 6 * sizeof(float)) != 0) return false;
+    }
+    return true;
+}
+
 namespace {
 
 const uint32_t kMagic = 0x4C53554Eu; // "NUSL"

@@ -56,6 +56,12 @@ bool lanczos_x2_phase_frame(const AxisTables &t, std::vector<float> &w6);
 // phase-frame weights as outputs 8 (even) and 9 (odd).
 bool lanczos_x2_interior_uniform(const AxisTables &t, const std::vector<float> &w6);
 
+// Integer factor S (out_n == S * in_n): the same frames for output o = S k + p, starting at
+// k - 3 + delta_p with delta_p = (2 p + 1 > S) (the output centre lies right of input pixel k).
+bool lanczos_xs_phase_frame(const AxisTables &t, uint32_t S, std::vector<float> &w6);
+// True when every interior output (k in [4, in_n - 5]) has the weights of output S * 8 + p of its phase.
+bool lanczos_xs_interior_uniform(const AxisTables &t, uint32_t S, const std::vector<float> &w6);
+
 // Serialisation for the multi-GPU LUT broadcast.
 std::vector<uint8_t> serialize_tables(const AxisTables &x, const AxisTables &y);
 bool deserialize_tables(const uint8_t *buf, size_t len, AxisTables &x, AxisTables &y, std::string &err);

@@ -601,7 +601,7 @@ def test_lanczos_x2_opaque_and_mixed_alpha_rows(nsc, oracle_mod, alg):
 
 
 @pytest.mark.parametrize("alg,filt", [("lanczos3", 0), ("bicubic", 1), ("triangle", 2)])
-@pytest.mark.parametrize("dims", [((320, 180), (480, 270)), ((320, 180), (960, 540)), ((240, 135), (960, 540)),
+@pytest.mark.parametrize("dims", [((320, 180), (480, 270)), ((320, 180), (960, 540)), ((250, 135), (1000, 540)),
                                   ((640, 360), (960, 540)), ((100, 37), (1000, 99)), ((480, 270), (680, 384)), ((600, 40), (900, 41)),
                                   ((255, 33), (1020, 200)), ((64, 64), (64, 64))])
 def test_resize_register_window_variant(nsc, oracle_mod, alg, filt, dims):
@@ -617,3 +617,36 @@ def test_resize_register_window_variant(nsc, oracle_mod, alg, filt, dims):
     ref_f, ur = _up(nsc, alg, img, ow, oh, options={"force_rows": 1})
     assert ur.kernel_variant == "resize_rows_lds"
     assert np.array_equal(got_f, ref_f) and _maxdiff(got_f, want) <= 1
+
+
+@pytest.mark.parametrize("alg,filt", [("lanczos3", 0), ("bicubic", 1), ("triangle", 2)])
+@pytest.mark.parametrize("factor", [3, 4])
+@pytest.mark.parametrize("size", [(64, 36), (252, 20), (256, 33), (16, 16), (500, 17), (1000, 50), (248, 40), (496, 19)])
+def test_resize_integer_factor_register_window(nsc, oracle_mod, alg, filt, factor, size):
+    """x3 / x4 (720p -> 4K, 540p -> 4K): the x2 kernel's register-window design with S rows per input row."""
+    w, h = size
+    ow, oh = factor * w, factor * h
+    img = oracle_mod.gen_noise(w, h, 93)
+    want = oracle_mod.resize(img, ow, oh, filt)
+    got_e, u = _up(nsc, alg, img, ow, oh, lanczos_mode="exact")
+    # x4: fixed interior weights per phase.  x3: the phase whose centre coincides with a pixel centre gets weights
+    # that depend on the f32 rounding of (o + 0.5) * (1/3) per column, so the host's uniformity check sends it
+    # to the any-scale register-window kernel instead.
+    assert u.kernel_variant == ("lanczos3_xs_regwin" if factor == 4 else "resize_regwin_lds")
+    assert np.array_equal(got_e, want)
+    got_f, _ = _up(nsc, alg, img, ow, oh)
+    # FMA mode packs with round-to-nearest-even; Triangle's dyadic weights put many sums on exact .5 ties,
+    # where that differs from f32::round by one count
+    assert _maxdiff(got_f, want) <= 1 and (got_f != want).mean() < (3e-2 if alg == "triangle" else 1e-3)
+    # the general kernels agree (same weights, same operation order)
+    ref_e, ug = _up(nsc, alg, img, ow, oh, lanczos_mode="exact", options={"force_general": 1})
+    assert ug.kernel_variant in ("resize_regwin_lds", "resize_rows_lds") and np.array_equal(ref_e, want)
+    for th in (1, 7, 24):
+        out_t, _ = _up(nsc, alg, img, ow, oh, lanczos_mode="exact", options={"rows_per_wave": th})
+        assert np.array_equal(out_t, want), th
+    # BGRA input
+    ub = nsc.PyWgpuUpscaler("quality", alg, lanczos_mode="exact")
+    ub.set_input_format("bgra")
+    ub.initialize(w, h, ow, oh)
+    got_b = np.frombuffer(ub.upscale(_bgra(img).tobytes()), np.uint8).reshape(oh, ow, 4)
+    assert np.array_equal(got_b, want)

@@ -149,9 +149,35 @@ DEFKMIX(k_mix_fma_fmadpp, S_FMAC_VV, S_FMAC_DPPW)
 DEFK(k_fmadppw, S_FMAC_DPPW)
 #define S_FMAC2_DPPW(X) S_FMAC_VV(X) S_FMAC_VV(X) S_FMAC_DPPW(X) S_FMAC_VV(X)
 DEFK(k_mix_3fma_1fmadpp, S_FMAC2_DPPW)
+// dependent chains: 8 FMAs on ONE accumulator (ILP 1), on two (ILP 2), on four (ILP 4)
+#define S_DEP1(X) asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(x0) : "v"(va), "v"(vb));
+DEFK(k_dep1, S_DEP1)
+#define REPDEP2 S_FMAC_VV(x0) S_FMAC_VV(x1) S_FMAC_VV(x0) S_FMAC_VV(x1) S_FMAC_VV(x0) S_FMAC_VV(x1) S_FMAC_VV(x0) S_FMAC_VV(x1)
+#define S_DEP2(X) REPDEP2
+#define REPDEP4 S_FMAC_VV(x0) S_FMAC_VV(x1) S_FMAC_VV(x2) S_FMAC_VV(x3) S_FMAC_VV(x0) S_FMAC_VV(x1) S_FMAC_VV(x2) S_FMAC_VV(x3)
 // 3 fmac : 1 dpp
 #define S_FMAC3_DPP(X) S_FMAC_VV(X) S_FMAC_VV(X) S_FMAC_VV(X) S_DPP(X)
 DEFK(k_mix_3fma_1dpp, S_FMAC3_DPP)
+__global__ __launch_bounds__(256) void k_dep2(float *out, float a, float b, int iters, unsigned long long *clk)
+{
+    const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    float x0 = threadIdx.x, x1 = x0 + 1, x2 = x0 + 2, x3 = x0 + 3;
+    float va = a + threadIdx.x * 0.0f, vb = b + threadIdx.x * 0.0f;
+    asm volatile("" : "+v"(va), "+v"(vb));
+    for (int i = 0; i < iters; ++i) { REPDEP2 REPDEP2 REPDEP2 REPDEP2 REPDEP2 REPDEP2 REPDEP2 REPDEP2 }
+    if (blockIdx.x == 0 && threadIdx.x == 0) { clk[0] = __builtin_amdgcn_s_memtime() - c0; clk[1] = __builtin_amdgcn_s_memrealtime() - r0; }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = x0 + x1 + x2 + x3;
+}
+__global__ __launch_bounds__(256) void k_dep4(float *out, float a, float b, int iters, unsigned long long *clk)
+{
+    const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    float x0 = threadIdx.x, x1 = x0 + 1, x2 = x0 + 2, x3 = x0 + 3;
+    float va = a + threadIdx.x * 0.0f, vb = b + threadIdx.x * 0.0f;
+    asm volatile("" : "+v"(va), "+v"(vb));
+    for (int i = 0; i < iters; ++i) { REPDEP4 REPDEP4 REPDEP4 REPDEP4 REPDEP4 REPDEP4 REPDEP4 REPDEP4 }
+    if (blockIdx.x == 0 && threadIdx.x == 0) { clk[0] = __builtin_amdgcn_s_memtime() - c0; clk[1] = __builtin_amdgcn_s_memrealtime() - r0; }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = x0 + x1 + x2 + x3;
+}
 #define S_FMAC3_CVTPK(X) S_FMAC_VV(X) S_FMAC_VV(X) S_FMAC_VV(X) S_CVTPK(X)
 DEFK(k_mix_3fma_1cvtpk, S_FMAC3_CVTPK)
 
@@ -178,10 +204,11 @@ int main()
         {"mix 4 fmac + 4 v_perm", k_mix_fma_perm}, {"mix 4 fmac + 4 v_lerp_u8", k_mix_fma_lerp},
         {"mix 4 fmac + 4 ds_bpermute", k_mix_fma_bperm}, {"mix 24 fmac + 8 dpp (x4 count)", k_mix_3fma_1dpp},
         {"mix 24 fmac + 8 cvt_pk (x4 count)", k_mix_3fma_1cvtpk},
+        {"fmac dependent chain (ILP 1)", k_dep1}, {"fmac 2 chains (ILP 2)", k_dep2}, {"fmac 4 chains (ILP 4)", k_dep4},
         {"v_fmac_f32_dpp wave_shr", k_fmadppw}, {"mix 4 fmac + 4 fmac_dpp wave_shr", k_mix_fma_fmadpp},
         {"mix 24 fmac + 8 fmac_dpp (x4 count)", k_mix_3fma_1fmadpp}};
     const int iters = 20000;
-    for (int occ : {2048, 768}) { // 8 and 3 waves per SIMD
+    for (int occ : {2048, 768, 512, 256}) { // 8, 3, 2 and 1 waves per SIMD
         for (auto &e : ks) {
             hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
             hipLaunchKernelGGL(e.k, dim3(occ), dim3(256), 0, 0, o, 1.0001f, 0.5f, 1000, clk);
