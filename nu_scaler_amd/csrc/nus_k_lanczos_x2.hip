@@ -126,7 +126,7 @@ __device__ __forceinline__ void lanczos_x2_vpass(const float (&win)[6][16], cons
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
         if (!ALPHA && (k & 3) == 3) continue; // V[alpha] is not read by the 3-channel horizontal pass
-        float acc = EXACT ? win[BASE % 6][k] * w[0] : __builtin_fmaf(win[BASE % 6][k], w[0], 0.0f);
+        float acc = win[BASE % 6][k] * w[0]; // == fma(.., 0) and a VOP2 instruction
 #pragma unroll
         for (int j = 1; j < 6; ++j) acc = mac<EXACT>(acc, win[(BASE + j) % 6][k], w[j]);
         V[k] = acc;
@@ -143,7 +143,7 @@ __device__ __forceinline__ void lanczos_x2_vpass_edge(const float (&win)[6][16],
     cfloat_p w = (cfloat_p)(uintptr_t)(wy6 + (size_t)__builtin_amdgcn_readfirstlane(oy) * 6);
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
-        float acc = EXACT ? win[BASE % 6][k] * w[0] : __builtin_fmaf(win[BASE % 6][k], w[0], 0.0f);
+        float acc = win[BASE % 6][k] * w[0]; // == fma(.., 0) and a VOP2 instruction
 #pragma unroll
         for (int j = 1; j < 6; ++j) acc = mac<EXACT>(acc, win[(BASE + j) % 6][k], w[j]);
         V[k] = acc;

@@ -62,7 +62,7 @@ __device__ __forceinline__ void xs_vpass(const float (&win)[6][16], const W &w, 
 {
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
-        float acc = EXACT ? win[0][k] * w[0] : __builtin_fmaf(win[0][k], w[0], 0.0f);
+        float acc = win[0][k] * w[0]; // == fma(.., 0) and a VOP2 instruction
 #pragma unroll
         for (int j = 1; j < 6; ++j) acc = mac<EXACT>(acc, win[j][k], w[j]);
         V[k] = acc;
