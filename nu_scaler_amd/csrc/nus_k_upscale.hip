@@ -533,10 +533,12 @@ __global__ __launch_bounds__(256) void k_resize_win(
         }
     }
 
-    // this lane's VC input columns (clamped into the row: columns past the footprint are never read back)
+    // this lane's VC input columns: lane, lane + 64, ... of the footprint, so that for each m the wave's loads
+    // are one contiguous 256 B and its LDS writes 64 consecutive float4 (no bank conflict); clamped into the
+    // row -- columns past the footprint are never read back
     uint32_t col[VC];
 #pragma unroll
-    for (int m = 0; m < VC; ++m) col[m] = umin((uint32_t)cmin + threadIdx.x * VC + m, iw - 1);
+    for (int m = 0; m < VC; ++m) col[m] = umin((uint32_t)cmin + threadIdx.x + kWave * m, iw - 1);
     auto load_row = [&](int32_t r, uint32_t (&raw)[VC]) {
         const uint32_t rr = (uint32_t)(r < 0 ? 0 : (r > (int32_t)ih - 1 ? (int32_t)ih - 1 : r));
         const uint32_t *row = base + (size_t)rr * iw;
@@ -592,7 +594,7 @@ __global__ __launch_bounds__(256) void k_resize_win(
                 for (int j = 0; j < WR; ++j) acc = mac<EXACT>(acc, win[j][m * 4 + c], wv[j]);
                 v[c] = acc;
             }
-            const int32_t ci = (int32_t)threadIdx.x * VC + m;
+            const int32_t ci = (int32_t)threadIdx.x + kWave * m;
             if (ci < ncols) s_v[ci] = make_float4(v[0], v[1], v[2], v[3]);
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
