@@ -650,3 +650,23 @@ def test_resize_integer_factor_register_window(nsc, oracle_mod, alg, filt, facto
     ub.initialize(w, h, ow, oh)
     got_b = np.frombuffer(ub.upscale(_bgra(img).tobytes()), np.uint8).reshape(oh, ow, 4)
     assert np.array_equal(got_b, want)
+
+
+@pytest.mark.parametrize("alg", ["lanczos3", "bicubic", "fsr1", "bilinear", "nearest"])
+@pytest.mark.parametrize("dims", [((64, 36), (256, 144)), ((64, 36), (96, 54)), ((64, 36), (192, 108)), ((96, 54), (64, 36))])
+def test_device_batch_every_variant(nsc, oracle_mod, alg, dims):
+    """n_frames > 1 through the device entry point (frames on the grid's z / y axis) for the x4, x1.5, x3 and
+    down-scaling variants: each frame must equal the single-frame host result."""
+    import torch
+    (w, h), (ow, oh) = dims
+    frames = np.stack([oracle_mod.gen_noise(w, h, 200 + k) for k in range(3)])
+    u = nsc.PyWgpuUpscaler("quality", alg)
+    u.initialize(w, h, ow, oh)
+    want = [np.frombuffer(u.upscale(f.tobytes()), np.uint8).reshape(oh, ow, 4) for f in frames]
+    d_in = torch.from_numpy(frames).cuda()
+    d_out = torch.zeros((3, oh, ow, 4), dtype=torch.uint8, device="cuda")
+    u.upscale_device(d_in.data_ptr(), d_out.data_ptr(), 3, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    got = d_out.cpu().numpy()
+    for k in range(3):
+        assert np.array_equal(got[k], want[k]), (alg, u.kernel_variant, k)
