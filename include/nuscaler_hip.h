@@ -137,7 +137,13 @@ int nus_upscaler_set_option(nus_upscaler *h, const char *key, int64_t value);
  * on the CPU before upscaling (nu_scaler_core/src/lib.rs:251-270); with NUS_FORMAT_BGRA8 the kernels
  * do it inside their loads (one v_perm_b32 per loaded pixel, no extra pass).  Output is always RGBA8.
  * May be called at any time. */
-typedef enum nus_pixel_format { NUS_FORMAT_RGBA8 = 0, NUS_FORMAT_BGRA8 = 1 } nus_pixel_format;
+typedef enum nus_pixel_format {
+    NUS_FORMAT_RGBA8 = 0,
+    NUS_FORMAT_BGRA8 = 1,
+    /* alpha byte undefined (BGRX / XRGB capture surfaces): read as 255, so the output alpha is 255 */
+    NUS_FORMAT_RGBX8 = 2,
+    NUS_FORMAT_BGRX8 = 3
+} nus_pixel_format;
 int nus_upscaler_set_input_format(nus_upscaler *h, int format);
 /* FSR1-style passes: the `sharpness` uniform of each shader (fsr.rs:35, :178), <= 1.  A negative
  * value keeps the default: EASU 0 (build-defined; the reference never assigns it), RCAS by quality

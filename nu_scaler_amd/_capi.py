@@ -23,7 +23,7 @@ ERR_OUT_OF_MEMORY = -7
 
 ALG_NEAREST, ALG_BILINEAR, ALG_LANCZOS3, ALG_BICUBIC, ALG_TRIANGLE = 0, 1, 2, 3, 4
 ALG_FSR1, ALG_FSR_EASU, ALG_FSR_RCAS = 5, 6, 7
-FORMAT_RGBA8, FORMAT_BGRA8 = 0, 1
+FORMAT_RGBA8, FORMAT_BGRA8, FORMAT_RGBX8, FORMAT_BGRX8 = 0, 1, 2, 3
 QUALITY_ULTRA_PERFORMANCE, QUALITY_ULTRA, QUALITY_QUALITY, QUALITY_BALANCED, QUALITY_PERFORMANCE, QUALITY_NATIVE = range(6)
 TECH_NONE, TECH_FSR, TECH_DLSS, TECH_WGPU, TECH_FALLBACK = range(5)
 WG_SQUARE_8X8, WG_SQUARE_16X16, WG_WIDE_32X8, WG_TALL_8X32 = range(4)

@@ -164,8 +164,8 @@ int HipUpscaler::set_option(const char *key, int64_t value)
 int HipUpscaler::set_input_format(int format)
 {
     std::lock_guard<std::mutex> lk(mu_);
-    if (format != 0 && format != 1) return fail(kInvalidArgument, "unknown input format");
-    bgra_ = format == 1;
+    if (format < 0 || format > 3) return fail(kInvalidArgument, "unknown input format");
+    in_format_ = format;
     return kOk;
 }
 
@@ -407,7 +407,7 @@ int HipUpscaler::enqueue(const uint8_t *d_in, uint8_t *d_out, uint32_t n_frames,
     L.oh = oh_;
     L.n_frames = n_frames;
     L.stream = stream;
-    L.in_sel = bgra_ ? kSelBGRA : kSelRGBA;
+    L.in_sel = input_selector(in_format_);
     if (blend) {
         L.in_stride = blend->a_stride;
         L.in_b = blend->b;
@@ -855,7 +855,7 @@ int HipFrameInterpolator::interpolate(const uint8_t *a, size_t a_len, const uint
     L.t = t;
     L.n_pairs = 1;
     L.stream = stream_;
-    L.in_sel = bgra_ ? kSelBGRA : kSelRGBA;
+    L.in_sel = input_selector(in_format_);
     NUS_HIP(hipEventRecord(k_begin_, stream_));
     hipError_t e = launch_warp_blend(L);
     if (e != hipSuccess) return fail_hip(e, "warp+blend launch");
@@ -900,7 +900,7 @@ int HipFrameInterpolator::interpolate_device(const void *d_a, size_t a_stride, c
     L.t = t;
     L.n_pairs = n_pairs;
     L.stream = stream;
-    L.in_sel = bgra_ ? kSelBGRA : kSelRGBA;
+    L.in_sel = input_selector(in_format_);
     hipError_t e = launch_warp_blend(L);
     if (e != hipSuccess) return fail_hip(e, "warp+blend launch");
     return kOk;
@@ -909,8 +909,8 @@ int HipFrameInterpolator::interpolate_device(const void *d_a, size_t a_stride, c
 int HipFrameInterpolator::set_input_format(int format)
 {
     std::lock_guard<std::mutex> lk(mu_);
-    if (format != 0 && format != 1) return fail(kInvalidArgument, "unknown input format");
-    bgra_ = format == 1;
+    if (format < 0 || format > 3) return fail(kInvalidArgument, "unknown input format");
+    in_format_ = format;
     return kOk;
 }
 

@@ -82,7 +82,7 @@ public:
     int set_bilinear_variant(int variant);
     int set_lanczos_mode(int mode);
     int set_option(const char *key, int64_t value);
-    // 0: RGBA8 (default), 1: BGRA8 -- captured frames, swizzled inside the kernels' loads
+    // nus_pixel_format: 0 RGBA8 (default), 1 BGRA8, 2 RGBX8, 3 BGRX8 -- swizzled / made opaque inside the kernels' loads
     // (the reference's CPU loop: nu_scaler_core/src/lib.rs:251-270).  Output is always RGBA8.
     int set_input_format(int format);
     // FSR1-style passes: negative value = keep the quality-derived default.
@@ -153,7 +153,7 @@ private:
     uint32_t resize_union_taps_ = 0; // widest union of the tap windows of 4 adjacent outputs (0: unused)
     uint32_t rows_per_wave_ = 0; // 0: pick from the batch size
     float easu_sharp_ = -1.0f, rcas_sharp_ = -1.0f; // < 0: derive from quality_
-    bool bgra_ = false;
+    int in_format_ = 0; // nus_pixel_format
     bool initialized_ = false;
     uint32_t iw_ = 0, ih_ = 0, ow_ = 0, oh_ = 0;
     Variant variant_ = Variant::NearestTable;
@@ -199,7 +199,7 @@ public:
     const char *name() const override { return "HipWarpBlendInterpolator"; }
     const char *last_error() const override { return error_.c_str(); }
     int set_device(int device);
-    int set_input_format(int format); // 0 RGBA8, 1 BGRA8 (both frames); output RGBA8
+    int set_input_format(int format); // nus_pixel_format of both frames; output RGBA8
     bool last_gpu_ms(double *ms) const;
     int wg_preset() const { return wg_preset_; }
 
@@ -213,7 +213,7 @@ private:
     int wg_preset_;
     int device_ = 0;
     bool device_ready_ = false;
-    bool bgra_ = false;
+    int in_format_ = 0; // nus_pixel_format
     size_t cap_bytes_ = 0;
     bool cap_flow_ = false;
     uint8_t *d_a_ = nullptr, *d_b_ = nullptr, *d_out_ = nullptr;

@@ -32,6 +32,18 @@ struct DeviceTables {
 // v_perm_b32 selectors applied to every loaded input pixel: RGBA8 as is, or BGRA8 (capture order,
 // nu_scaler_core/src/lib.rs:251-270) swizzled to RGBA on the way in.
 constexpr uint32_t kSelRGBA = 0x03020100u, kSelBGRA = 0x03000102u;
+// ... and the X variants (alpha byte undefined, as BGRX capture surfaces): selector byte 0x0D yields 0xFF, so the
+// pixel enters every kernel opaque and the output alpha is 255.
+constexpr uint32_t kSelRGBX = 0x0D020100u, kSelBGRX = 0x0D000102u;
+inline uint32_t input_selector(int format) // nus_pixel_format
+{
+    switch (format) {
+    case 1: return kSelBGRA;
+    case 2: return kSelRGBX;
+    case 3: return kSelBGRX;
+    default: return kSelRGBA;
+    }
+}
 
 struct UpscaleLaunch {
     const uint8_t *in = nullptr; // n_frames contiguous frames

@@ -74,9 +74,9 @@ class WgpuFrameInterpolator:
 
     def set_input_format(self, fmt: str) -> None:
         """"rgba" (default) or "bgra" for both input frames; the new frame is RGBA."""
-        f = {"rgba": C.FORMAT_RGBA8, "bgra": C.FORMAT_BGRA8}.get(str(fmt).lower())
+        f = {"rgba": C.FORMAT_RGBA8, "bgra": C.FORMAT_BGRA8, "rgbx": C.FORMAT_RGBX8, "bgrx": C.FORMAT_BGRX8}.get(str(fmt).lower())
         if f is None:
-            raise ValueError("input format must be 'rgba' or 'bgra'")
+            raise ValueError("input format must be 'rgba', 'bgra', 'rgbx' or 'bgrx'")
         self._raise(self._lib.nus_interp_set_input_format(self._h, f))
 
     def get_last_gpu_duration_ms(self) -> Optional[float]:

@@ -173,9 +173,9 @@ class PyWgpuUpscaler:
     def set_input_format(self, fmt: str) -> None:
         """"rgba" (default) or "bgra": captured frames are swizzled inside the kernels' loads
         (the reference's CPU loop, lib.rs:251-270).  The output is always RGBA."""
-        f = {"rgba": C.FORMAT_RGBA8, "bgra": C.FORMAT_BGRA8}.get(str(fmt).lower())
+        f = {"rgba": C.FORMAT_RGBA8, "bgra": C.FORMAT_BGRA8, "rgbx": C.FORMAT_RGBX8, "bgrx": C.FORMAT_BGRX8}.get(str(fmt).lower())
         if f is None:
-            raise ValueError("input format must be 'rgba' or 'bgra'")
+            raise ValueError("input format must be 'rgba', 'bgra', 'rgbx' or 'bgrx'")
         self._check(self._lib.nus_upscaler_set_input_format(self._h, f))
 
     def set_sharpness(self, easu: float = -1.0, rcas: float = -1.0) -> None:

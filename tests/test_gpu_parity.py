@@ -670,3 +670,39 @@ def test_device_batch_every_variant(nsc, oracle_mod, alg, dims):
     got = d_out.cpu().numpy()
     for k in range(3):
         assert np.array_equal(got[k], want[k]), (alg, u.kernel_variant, k)
+
+
+@pytest.mark.parametrize("alg,kw", [("nearest", {}), ("bilinear", {}), ("lanczos3", {}), ("lanczos3", {"lanczos_mode": "exact"}),
+                                    ("bicubic", {}), ("fsr1", {})])
+@pytest.mark.parametrize("dims", [((252, 40), (504, 80)), ((48, 27), (72, 41)), ((64, 36), (256, 144)), ((100, 40), (30, 12))])
+@pytest.mark.parametrize("fmt", ["rgbx", "bgrx"])
+def test_x_formats_read_alpha_as_opaque(nsc, oracle_mod, alg, kw, dims, fmt):
+    """RGBX / BGRX: the alpha byte of the input is undefined and read as 255 inside the loads, so the result is
+    the upscale of the opaque frame (and the x2 kernel takes its 3-channel path on every row)."""
+    (w, h), (ow, oh) = dims
+    img = oracle_mod.gen_noise(w, h, 47)  # random alpha bytes: must be ignored
+    opaque = img.copy()
+    opaque[..., 3] = 255
+    want, _ = _up(nsc, alg, opaque, ow, oh, **kw)
+    u = nsc.PyWgpuUpscaler("quality", alg, **kw)
+    u.set_input_format(fmt)
+    u.initialize(w, h, ow, oh)
+    src = img if fmt == "rgbx" else _bgra(img)
+    got = np.frombuffer(u.upscale(src.tobytes()), np.uint8).reshape(oh, ow, 4)
+    assert np.array_equal(got, want), (alg, fmt, u.kernel_variant)
+    assert (got[..., 3] == 255).all()
+
+
+def test_x_formats_interpolator(nsc, oracle_mod):
+    w, h = 130, 33
+    a, b = oracle_mod.gen_noise(w, h, 48), oracle_mod.gen_noise(w, h, 49)
+    ao, bo = a.copy(), b.copy()
+    ao[..., 3] = 255
+    bo[..., 3] = 255
+    flow = np.zeros((h, w, 2), np.float32)
+    flow[..., 0] = 0.75
+    it = nsc.WgpuFrameInterpolator()
+    it.set_input_format("bgrx")
+    for f in (None, flow):
+        got = np.frombuffer(it.interpolate_py(_bgra(a).tobytes(), _bgra(b).tobytes(), w, h, time_t=0.5, flow=f), np.uint8)
+        assert np.array_equal(got.reshape(h, w, 4), oracle_mod.warp_blend(ao, bo, f, 0.5))
