@@ -52,6 +52,8 @@ def main():
         u = nsc.PyWgpuUpscaler("quality", alg, **kw)
         for k, v in opts.items():
             u.set_option(k, v)
+        if os.environ.get("NUS_BENCH_FORMAT"):
+            u.set_input_format(os.environ["NUS_BENCH_FORMAT"])
         u.initialize(w, h, 2 * w, 2 * h)
         u.set_profiling(True)
         ms = timed(lambda: u.upscale_device(frames.data_ptr(), out.data_ptr(), n, s), args.reps)
