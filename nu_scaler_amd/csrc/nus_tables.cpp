@@ -278,6 +278,12 @@ bool deserialize_tables(const uint8_t *buf, size_t len, AxisTables &x, AxisTable
                     err = "table blob: tap window out of range";
                     return false;
                 }
+                // the segment kernels take a segment's footprint from its first and last output
+                if (o > 0 && (t->lz_left[o] < t->lz_left[o - 1] ||
+                              t->lz_left[o] + (int64_t)t->lz_ntaps[o] < t->lz_left[o - 1] + (int64_t)t->lz_ntaps[o - 1])) {
+                    err = "table blob: tap windows must not move backwards";
+                    return false;
+                }
             }
         }
     }

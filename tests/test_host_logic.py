@@ -189,6 +189,16 @@ def test_table_blob_roundtrip_and_validation(nsc):
     bad[off:off + 4] = (10 ** 6).to_bytes(4, "little")
     with pytest.raises(ValueError, match="out of range"):
         nsc.validate_tables_blob(bytes(bad), 320, 240, 640, 480)
+    # a tap window that starts left of its predecessor's: x-axis lz_left lives after nn_src, bl_i0, bl_frac
+    bad = bytearray(blob)
+    off = 8 + 16 + 3 * 640 * 4 + 100 * 4  # lz_left[100]
+    bad[off:off + 4] = (0).to_bytes(4, "little")
+    with pytest.raises(ValueError, match="backwards"):
+        nsc.validate_tables_blob(bytes(bad), 320, 240, 640, 480)
+    # every shape the tests use passes the monotonicity check (up, down, ragged, identity)
+    for dims in ((50, 31, 127, 64), (48, 27, 20, 11), (1, 1, 5, 3), (7, 5, 7, 5), (3840, 2160, 1920, 1080), (100, 40, 30, 12)):
+        for alg in ("lanczos3", "bicubic", "triangle"):
+            nsc.validate_tables_blob(nsc.build_tables_blob(*dims, algorithm=alg), *dims)
 
 
 def test_shard_frames_partition(nsc):
