@@ -742,6 +742,7 @@ HipFrameInterpolator::~HipFrameInterpolator()
     if (device_ready_) {
         if (k_begin_) (void)hipEventDestroy(k_begin_);
         if (k_end_) (void)hipEventDestroy(k_end_);
+        if (half_done_) (void)hipEventDestroy(half_done_);
         if (stream_) (void)hipStreamDestroy(stream_);
     }
 }
@@ -798,6 +799,7 @@ int HipFrameInterpolator::ensure(size_t frame_bytes, bool with_flow)
         NUS_HIP(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
         NUS_HIP(hipEventCreate(&k_begin_));
         NUS_HIP(hipEventCreate(&k_end_));
+        NUS_HIP(hipEventCreateWithFlags(&half_done_, hipEventDisableTiming));
         device_ready_ = true;
     }
     NUS_HIP(hipSetDevice(device_));
@@ -836,9 +838,11 @@ int HipFrameInterpolator::interpolate(const uint8_t *a, size_t a_len, const uint
     int rc = ensure(expected, flow != nullptr);
     if (rc != kOk) return rc;
     uint8_t *ha = h_stage_, *hb = h_stage_ + cap_bytes_, *ho = h_stage_ + 2 * cap_bytes_;
+    // stage A, start its DMA, stage B meanwhile (the reference uploads both synchronously:
+    // wgpu_interpolator.rs:253-321)
     memcpy(ha, a, expected);
-    memcpy(hb, b, expected);
     NUS_HIP(hipMemcpyAsync(d_a_, ha, expected, hipMemcpyHostToDevice, stream_));
+    memcpy(hb, b, expected);
     NUS_HIP(hipMemcpyAsync(d_b_, hb, expected, hipMemcpyHostToDevice, stream_));
     if (flow) {
         memcpy(h_flow_, flow, expected * 2);
@@ -860,9 +864,16 @@ int HipFrameInterpolator::interpolate(const uint8_t *a, size_t a_len, const uint
     hipError_t e = launch_warp_blend(L);
     if (e != hipSuccess) return fail_hip(e, "warp+blend launch");
     NUS_HIP(hipEventRecord(k_end_, stream_));
-    NUS_HIP(hipMemcpyAsync(ho, d_out_, expected, hipMemcpyDeviceToHost, stream_));
+    // the frame comes back in two halves: the host copy of the first overlaps the DMA of the second
+    const size_t half = (expected / 2 + 4095) & ~(size_t)4095;
+    const size_t first = half < expected ? half : expected;
+    NUS_HIP(hipMemcpyAsync(ho, d_out_, first, hipMemcpyDeviceToHost, stream_));
+    NUS_HIP(hipEventRecord(half_done_, stream_));
+    if (first < expected) NUS_HIP(hipMemcpyAsync(ho + first, d_out_ + first, expected - first, hipMemcpyDeviceToHost, stream_));
+    NUS_HIP(hipEventSynchronize(half_done_));
+    memcpy(out, ho, first);
     NUS_HIP(hipStreamSynchronize(stream_));
-    memcpy(out, ho, expected);
+    if (first < expected) memcpy(out + first, ho + first, expected - first);
     float ms = 0.0f;
     if (hipEventElapsedTime(&ms, k_begin_, k_end_) == hipSuccess) {
         have_ms_ = true;

@@ -221,7 +221,7 @@ private:
     uint8_t *h_stage_ = nullptr; // pinned: a | b | out
     float *h_flow_ = nullptr;    // pinned
     hipStream_t stream_ = nullptr;
-    hipEvent_t k_begin_ = nullptr, k_end_ = nullptr;
+    hipEvent_t k_begin_ = nullptr, k_end_ = nullptr, half_done_ = nullptr;
     bool have_ms_ = false;
     double last_ms_ = 0.0;
     std::string error_;
