@@ -554,14 +554,27 @@ __global__ __launch_bounds__(256) void k_resize_win(
         }
     };
 
+    // FMA mode: rows whose pixels are all opaque in this wave (bit j of `opq` = window row WR-1-j); an output
+    // row whose whole window is opaque skips the alpha channel and stores 255, as in the x2 kernel
+    constexpr bool OP = !EXACT;
+    auto row_opaque = [&](const uint32_t (&raw)[VC]) -> uint32_t {
+        uint32_t a = 0xFFFFFFFFu;
+#pragma unroll
+        for (int m = 0; m < VC; ++m) a &= swz(raw[m], sel);
+        return __builtin_amdgcn_ballot_w64(a < 0xFF000000u) == 0ull ? 1u : 0u;
+    };
     int32_t top = __builtin_amdgcn_readfirstlane(lyt[y_begin]);
     float win[WR][VC * 4];
+    uint32_t opq = 0;
     {
         uint32_t raw[WR][VC];
 #pragma unroll
         for (int j = 0; j < WR; ++j) load_row(top + j, raw[j]);
 #pragma unroll
-        for (int j = 0; j < WR; ++j) cvt(raw[j], win[j]);
+        for (int j = 0; j < WR; ++j) {
+            if (OP) opq = (opq << 1) | row_opaque(raw[j]);
+            cvt(raw[j], win[j]);
+        }
     }
     uint32_t next[VC]; // row top + WR, requested one advance ahead
     load_row(top + WR, next);
@@ -573,6 +586,7 @@ __global__ __launch_bounds__(256) void k_resize_win(
             for (int j = 0; j + 1 < WR; ++j)
 #pragma unroll
                 for (int k = 0; k < VC * 4; ++k) win[j][k] = win[j + 1][k];
+            if (OP) opq = (opq << 1) | row_opaque(next);
             cvt(next, win[WR - 1]);
             top = ly;
             load_row(top + WR, next);
@@ -584,11 +598,16 @@ __global__ __launch_bounds__(256) void k_resize_win(
             wv[j] = wy[j]; // zero padded beyond the row's tap count
             asm volatile("" : "+v"(wv[j])); // VGPR copy: scalar operands halve the VALU issue rate
         }
+        const bool skip_alpha = OP && (opq & ((1u << WR) - 1u)) == ((1u << WR) - 1u); // wave-uniform
 #pragma unroll
         for (int m = 0; m < VC; ++m) {
             float v[4];
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
+                if (c == 3 && skip_alpha) {
+                    v[3] = 0.0f;
+                    continue;
+                }
                 float acc = 0.0f;
 #pragma unroll
                 for (int j = 0; j < WR; ++j) acc = mac<EXACT>(acc, win[j][m * 4 + c], wv[j]);
@@ -616,7 +635,10 @@ __global__ __launch_bounds__(256) void k_resize_win(
                         h0 = mac<EXACT>(h0, R[j].x, hu[i][j]);
                         h1 = mac<EXACT>(h1, R[j].y, hu[i][j]);
                         h2 = mac<EXACT>(h2, R[j].z, hu[i][j]);
-                        h3 = mac<EXACT>(h3, R[j].w, hu[i][j]);
+                    }
+                    if (!skip_alpha) {
+#pragma unroll
+                        for (int j = 0; j < UW; ++j) h3 = mac<EXACT>(h3, R[j].w, hu[i][j]);
                     }
                 } else {
 #pragma unroll
@@ -625,10 +647,11 @@ __global__ __launch_bounds__(256) void k_resize_win(
                         h0 = mac<EXACT>(h0, v.x, hw[i][k]);
                         h1 = mac<EXACT>(h1, v.y, hw[i][k]);
                         h2 = mac<EXACT>(h2, v.z, hw[i][k]);
-                        h3 = mac<EXACT>(h3, v.w, hw[i][k]);
+                        if (!skip_alpha) h3 = mac<EXACT>(h3, v.w, hw[i][k]);
                     }
                 }
-                o[i] = pack_u8<EXACT>(h3, 3, pack_u8<EXACT>(h2, 2, pack_u8<EXACT>(h1, 1, pack_u8<EXACT>(h0, 0, 0u))));
+                const uint32_t rgb = pack_u8<EXACT>(h2, 2, pack_u8<EXACT>(h1, 1, pack_u8<EXACT>(h0, 0, 0u)));
+                o[i] = skip_alpha ? (rgb | 0xFF000000u) : pack_u8<EXACT>(h3, 3, rgb);
             }
             *reinterpret_cast<uint4 *>(dst + (size_t)y * ow) = make_uint4(o[0], o[1], o[2], o[3]);
         }

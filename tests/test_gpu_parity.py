@@ -706,3 +706,24 @@ def test_x_formats_interpolator(nsc, oracle_mod):
     for f in (None, flow):
         got = np.frombuffer(it.interpolate_py(_bgra(a).tobytes(), _bgra(b).tobytes(), w, h, time_t=0.5, flow=f), np.uint8)
         assert np.array_equal(got.reshape(h, w, 4), oracle_mod.warp_blend(ao, bo, f, 0.5))
+
+
+@pytest.mark.parametrize("alg", ["lanczos3", "bicubic"])
+@pytest.mark.parametrize("dims", [((320, 180), (480, 270)), ((320, 90), (960, 270)), ((256, 64), (1024, 256))])
+def test_resize_window_opaque_rows(nsc, oracle_mod, alg, dims):
+    """Any-scale register-window kernel: output rows whose 7-row window is opaque in the wave skip alpha and store
+    255; opaque, banded and single-pixel alpha must equal the LDS-row kernel (always 4 channels) bit for bit."""
+    (w, h), (ow, oh) = dims
+    base = oracle_mod.gen_noise(w, h, 78)
+    variants = {}
+    v = base.copy(); v[..., 3] = 255; variants["opaque"] = v
+    v = base.copy(); v[..., 3] = 255; v[h // 2:h // 2 + 5, :, 3] = base[h // 2:h // 2 + 5, :, 3]; variants["band"] = v
+    v = base.copy(); v[..., 3] = 255; v[h // 3, w // 2, 3] = 254; v[0, 0, 3] = 0; v[h - 1, w - 1, 3] = 9; variants["pixels"] = v
+    for name, img in variants.items():
+        got, u = _up(nsc, alg, img, ow, oh)
+        assert u.kernel_variant in ("resize_regwin_lds", "lanczos3_xs_regwin")
+        ref, ur = _up(nsc, alg, img, ow, oh, options={"force_general": 1, "force_rows": 1})
+        assert ur.kernel_variant == "resize_rows_lds"
+        assert np.array_equal(got, ref), name
+        if name == "opaque":
+            assert (got[..., 3] == 255).all()

@@ -12,7 +12,7 @@ from nu_scaler_amd import synthetic as syn
 iw, ih, ow, oh = (int(v) for v in (sys.argv[1:5] if len(sys.argv) >= 5 else (1280, 720, 1920, 1080)))
 n = int(sys.argv[5]) if len(sys.argv) > 5 else 64
 dev = torch.device("cuda:0")
-frames = syn.noise_stream_torch(n, iw, ih, dev)
+frames = (syn.gradient_stream_torch if os.environ.get("NUS_PATTERN") == "gradient" else syn.noise_stream_torch)(n, iw, ih, dev)
 out = torch.empty((n, oh, ow, 4), dtype=torch.uint8, device=dev)
 s = torch.cuda.current_stream().cuda_stream
 alg_bytes = (iw * ih + ow * oh) * 4
