@@ -55,13 +55,21 @@ __device__ __forceinline__ void cvt_row(const uint4 raw, float (&dst)[16])
         for (int c = 0; c < 4; ++c) dst[m * 4 + c] = ch_f32(px[m], c);
 }
 
+// 1 when every pixel of this input row held by the wave is opaque (cf. row_is_opaque in nus_k_lanczos_x2.hip)
+__device__ __forceinline__ uint32_t xs_row_is_opaque(const uint4 px)
+{
+    const bool lane_opaque = (px.x & px.y & px.z & px.w) >= 0xFF000000u;
+    return __builtin_amdgcn_ballot_w64(!lane_opaque) == 0ull ? 1u : 0u;
+}
+
 // Vertical pass of one output row: 6 taps from the window rows 0 .. 5.  W: VGPR weights (interior rows)
 // or a scalar pointer into the table (rows whose window is cut by the top / bottom border).
 template <bool EXACT, typename W>
-__device__ __forceinline__ void xs_vpass(const float (&win)[6][16], const W &w, float (&V)[16])
+__device__ __forceinline__ void xs_vpass(const float (&win)[6][16], const W &w, float (&V)[16], bool skip_alpha)
 {
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
+        if ((k & 3) == 3 && skip_alpha) continue; // wave-uniform; V[alpha] is then not read
         float acc = win[0][k] * w[0]; // == fma(.., 0) and a VOP2 instruction
 #pragma unroll
         for (int j = 1; j < 6; ++j) acc = mac<EXACT>(acc, win[j][k], w[j]);
@@ -74,13 +82,16 @@ __device__ __forceinline__ void xs_vpass(const float (&win)[6][16], const W &w, 
 // of e[] (e[3] is the lane's own first column).
 template <bool EXACT, int S>
 __device__ __forceinline__ void xs_hpass_store(const float (&V)[16], const float (&W)[S][6],
-                                               __amdgpu_buffer_rsrc_t rs, uint32_t off)
+                                               __amdgpu_buffer_rsrc_t rs, uint32_t off, bool skip_alpha)
 {
+    // skip_alpha (FMA mode, wave-uniform): the six tap rows are opaque in this wave, so alpha is the constant
+    // 255 (see row_is_opaque in nus_k_lanczos_x2.hip); v_cvt_pk_u8_f32 only ever replaces bytes 0..2 then
     uint32_t o[4 * S];
 #pragma unroll
-    for (int i = 0; i < 4 * S; ++i) o[i] = 0;
+    for (int i = 0; i < 4 * S; ++i) o[i] = skip_alpha ? 0xFF000000u : 0u;
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
+        if (c == 3 && skip_alpha) continue;
         float e[10]; // vertical sums of input columns c0-3 .. c0+6 for this channel
         e[0] = lane_up(V[1 * 4 + c]);
         e[1] = lane_up(V[2 * 4 + c]);
@@ -119,7 +130,7 @@ __device__ __forceinline__ void xs_hpass_store(const float (&V)[16], const float
 template <bool EXACT, int S>
 __device__ __forceinline__ void xs_step(float (&win)[6][16], uint4 &raw0, uint4 &raw1, int r, int cl, uint32_t lane_off,
                                         const LanczosXsArgs &A, const float (&W)[S][6], const uint8_t *src,
-                                        __amdgpu_buffer_rsrc_t rs)
+                                        __amdgpu_buffer_rsrc_t rs, uint32_t &opaque)
 {
     typedef const __attribute__((address_space(4))) float *cfloat_p;
     const uint32_t row_bytes = A.iw * 4 * S; // one output row
@@ -132,13 +143,14 @@ __device__ __forceinline__ void xs_step(float (&win)[6][16], uint4 &raw0, uint4 
 #pragma unroll
         for (int p = 0; p < S; ++p) {
             if (xs_delta(S, p) != (half == 1)) continue;
+            const bool skip_alpha = !EXACT && (opaque & 0x3Fu) == 0x3Fu; // bit j: window row 5-j is opaque
             if (interior) {
-                xs_vpass<EXACT>(win, W[p], V);
+                xs_vpass<EXACT>(win, W[p], V, skip_alpha);
             } else {
                 cfloat_p wt = (cfloat_p)(uintptr_t)(A.wy6 + (size_t)__builtin_amdgcn_readfirstlane((uint32_t)(S * r + p)) * 6);
-                xs_vpass<EXACT>(win, wt, V);
+                xs_vpass<EXACT>(win, wt, V, skip_alpha);
             }
-            xs_hpass_store<EXACT, S>(V, W, rs, off0 + (uint32_t)p * row_bytes);
+            xs_hpass_store<EXACT, S>(V, W, rs, off0 + (uint32_t)p * row_bytes, skip_alpha);
         }
         if (half == 0) {
             // row r-3 out, row r+3 in; then request row r+5
@@ -146,7 +158,11 @@ __device__ __forceinline__ void xs_step(float (&win)[6][16], uint4 &raw0, uint4 
             for (int j = 0; j < 5; ++j)
 #pragma unroll
                 for (int k = 0; k < 16; ++k) win[j][k] = win[j + 1][k];
-            cvt_row(swz4(raw0, A.sel), win[5]);
+            {
+                const uint4 px = swz4(raw0, A.sel);
+                if (!EXACT) opaque = (opaque << 1) | xs_row_is_opaque(px);
+                cvt_row(px, win[5]);
+            }
             raw0 = raw1;
             int rn = r + 5;
             rn = rn < (int)A.ih - 1 ? rn : (int)A.ih - 1;
@@ -190,10 +206,15 @@ __global__ __launch_bounds__(256) void k_lanczos3_xs(const LanczosXsArgs A)
             asm volatile("" : "+v"(W[p][j])); // VGPR copy: scalar operands halve the VALU issue rate
         }
     float win[6][16];
+    uint32_t opaque = 0;
 #pragma unroll
-    for (int j = 0; j < 6; ++j) cvt_row(swz4(load_row(r0 - 3 + j), A.sel), win[j]);
+    for (int j = 0; j < 6; ++j) {
+        const uint4 px = swz4(load_row(r0 - 3 + j), A.sel);
+        if (!EXACT) opaque = (opaque << 1) | xs_row_is_opaque(px);
+        cvt_row(px, win[j]);
+    }
     uint4 raw0 = load_row(r0 + 3), raw1 = load_row(r0 + 4);
-    for (int r = r0; r < r_end; ++r) xs_step<EXACT, S>(win, raw0, raw1, r, cl, lane_off, A, W, src, rs);
+    for (int r = r0; r < r_end; ++r) xs_step<EXACT, S>(win, raw0, raw1, r, cl, lane_off, A, W, src, rs, opaque);
 }
 
 // The 4 S left-most and right-most output columns (tap windows cut by the image border, weights
