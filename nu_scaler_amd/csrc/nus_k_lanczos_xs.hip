@@ -177,7 +177,10 @@ template <bool EXACT, int S>
 __global__ __launch_bounds__(256) void k_lanczos3_xs(const LanczosXsArgs A)
 {
     const int lane = threadIdx.x & (kWave - 1);
-    const uint32_t wave = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+    // each XCD gets a contiguous run of (frame, row block, strips), as in the x2 kernel
+    const uint32_t vid = xcd_contiguous_id(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
+    const uint32_t frame = vid / gridDim.x;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane((vid % gridDim.x) * 4 + (threadIdx.x >> 6));
     if (wave >= A.nstrips * A.nrowblocks) return;
     const uint32_t strip = wave % A.nstrips;
     const uint32_t rb = wave / A.nstrips;
@@ -185,9 +188,9 @@ __global__ __launch_bounds__(256) void k_lanczos3_xs(const LanczosXsArgs A)
     int cl = c < 0 ? 0 : c;
     cl = cl > (int)A.iw - 4 ? (int)A.iw - 4 : cl;
     const bool do_store = lane >= 1 && lane <= 62 && c >= 4 && c + 8 <= (int)A.iw;
-    const uint8_t *src = A.in + (size_t)blockIdx.y * A.in_frame_bytes;
+    const uint8_t *src = A.in + (size_t)frame * A.in_frame_bytes;
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-        A.out + (size_t)blockIdx.y * A.out_frame_bytes, 0, (uint32_t)A.out_frame_bytes, 0x00020000);
+        A.out + (size_t)frame * A.out_frame_bytes, 0, (uint32_t)A.out_frame_bytes, 0x00020000);
     const uint32_t lane_off = do_store ? (uint32_t)c * 4u * S : 0x80000000u;
     const int r0 = (int)(rb * A.th);
     const int r_end = (r0 + (int)A.th) < (int)A.ih ? (r0 + (int)A.th) : (int)A.ih;
