@@ -269,7 +269,7 @@ __global__ __launch_bounds__(256) void k_lanczos3_x2(const LanczosX2Args A)
     const int c = (int)(strip * kLanczosX2StripCols) - 4 + lane * 4; // first input column of this lane
     int cl = c < 0 ? 0 : c;
     cl = cl > (int)A.iw - 4 ? (int)A.iw - 4 : cl;
-    const bool do_store = lane >= 1 && lane <= 62 && c >= 4 && c + 8 <= (int)A.iw;
+    const bool do_store = lane >= 1 && lane <= (int)(kLanczosX2StripCols / 4) && c >= 4 && c + 8 <= (int)A.iw;
     const uint8_t *src = A.in + (size_t)frame * A.in_frame_bytes;
     const uint8_t *src_b = BLEND ? A.in_b + (size_t)frame * A.in_b_frame_bytes : src;
     // one buffer resource per output frame (< 2 GiB, checked by the host); non-storing lanes

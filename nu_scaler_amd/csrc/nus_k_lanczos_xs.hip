@@ -187,7 +187,7 @@ __global__ __launch_bounds__(256) void k_lanczos3_xs(const LanczosXsArgs A)
     const int c = (int)(strip * kLanczosX2StripCols) - 4 + lane * 4; // first input column of this lane
     int cl = c < 0 ? 0 : c;
     cl = cl > (int)A.iw - 4 ? (int)A.iw - 4 : cl;
-    const bool do_store = lane >= 1 && lane <= 62 && c >= 4 && c + 8 <= (int)A.iw;
+    const bool do_store = lane >= 1 && lane <= (int)(kLanczosX2StripCols / 4) && c >= 4 && c + 8 <= (int)A.iw;
     const uint8_t *src = A.in + (size_t)frame * A.in_frame_bytes;
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
         A.out + (size_t)frame * A.out_frame_bytes, 0, (uint32_t)A.out_frame_bytes, 0x00020000);

@@ -109,7 +109,7 @@ hipError_t launch_lanczos_xs_edges(const UpscaleLaunch &L, const DeviceTables &T
 hipError_t launch_fsr1(const UpscaleLaunch &L, int mode, float easu_sharpness, float rcas_sharpness);
 
 constexpr uint32_t kLanczosX2EdgeCols = 8; // output columns left to the general kernel per side
-constexpr uint32_t kLanczosX2StripCols = 248; // input columns produced per wave (62 lanes x 4)
+constexpr uint32_t kLanczosX2StripCols = 248; // input columns produced per wave (62 lanes x 4; 240 = whole 128-B output lines measured the same)
 
 struct WarpLaunch {
     const uint8_t *a = nullptr, *b = nullptr;
