@@ -284,12 +284,33 @@ void HipUpscaler::choose_variant()
                         if (u > resize_union_taps_) resize_union_taps_ = u;
                     }
                     // register-window variant: up-scaling shapes whose first tap row moves by at most one per output row
-                    bool win_ok = ty_.lz_max_taps <= 7 && widest <= 192 && !force_rows_;
+                    bool win_ok = ty_.lz_max_taps <= 7 && !force_rows_;
                     for (uint32_t y = 1; win_ok && y < oh_; ++y) {
                         const int32_t d = ty_.lz_left[y] - ty_.lz_left[y - 1];
                         win_ok = d == 0 || d == 1;
                     }
-                    if (win_ok) variant_ = Variant::ResizeWin;
+                    if (win_ok && widest <= 192) {
+                        variant_ = Variant::ResizeWin;
+                        win_outputs_per_lane_ = 4;
+                    } else if (win_ok) {
+                        // factors x1.0 .. x1.4: two outputs per lane, segments of 128 output columns
+                        uint32_t widest2 = 0, union2 = 0;
+                        for (uint32_t x0 = 0; x0 < ow_; x0 += 128) {
+                            const uint32_t xl = (x0 + 128 < ow_ ? x0 + 128 : ow_) - 1;
+                            const uint32_t span = (uint32_t)(tx_.lz_left[xl] + (int32_t)tx_.lz_ntaps[xl] - tx_.lz_left[x0]);
+                            if (span > widest2) widest2 = span;
+                        }
+                        for (uint32_t x0 = 0; x0 < ow_; x0 += 2) {
+                            const uint32_t u = (uint32_t)(tx_.lz_left[x0 + 1] - tx_.lz_left[x0]) + 8u;
+                            if (u > union2) union2 = u;
+                        }
+                        if (widest2 <= 192) {
+                            variant_ = Variant::ResizeWin;
+                            win_outputs_per_lane_ = 2;
+                            resize_ncols_max_ = widest2;
+                            resize_union_taps_ = union2;
+                        }
+                    }
                 }
             }
         }
@@ -437,7 +458,9 @@ int HipUpscaler::enqueue(const uint8_t *d_in, uint8_t *d_out, uint32_t n_frames,
     case Variant::BilinearTable: e = launch_bilinear_table(L, dt_, wgsl_bilinear_); break;
     case Variant::BilinearX2Int: e = launch_bilinear_x2_int(L); break;
     case Variant::LanczosGeneral: e = launch_lanczos_general(L, dt_, lanczos_exact_, 0); break;
-    case Variant::ResizeWin: e = launch_resize_win(L, dt_, lanczos_exact_, resize_ncols_max_, resize_union_taps_); break;
+    case Variant::ResizeWin:
+        e = launch_resize_win(L, dt_, lanczos_exact_, resize_ncols_max_, resize_union_taps_, win_outputs_per_lane_);
+        break;
     case Variant::ResizeRows:
         e = launch_resize_rows(L, dt_, lanczos_exact_, resize_ncols_max_, resize_small_taps_, resize_union_taps_);
         break;

@@ -150,6 +150,7 @@ private:
     uint32_t resize_ncols_max_ = 0; // LDS row length of the ResizeRows variant
     bool resize_small_taps_ = false;
     uint32_t xs_factor_ = 0;         // 3 / 4 when the integer-factor register-window kernel is selected
+    uint32_t win_outputs_per_lane_ = 4; // register-window resize: 4, or 2 for factors below ~x1.4
     uint32_t resize_union_taps_ = 0; // widest union of the tap windows of 4 adjacent outputs (0: unused)
     uint32_t rows_per_wave_ = 0; // 0: pick from the batch size
     float easu_sharp_ = -1.0f, rcas_sharp_ = -1.0f; // < 0: derive from quality_

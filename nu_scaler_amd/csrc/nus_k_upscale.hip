@@ -481,9 +481,11 @@ __global__ __launch_bounds__(256) void k_resize_rows(
 // rows of the window beyond the tap count carry weight 0 (the table is zero padded) and hold finite
 // pixels (row index clamped), so they add +-0.  H pass and LDS row exactly as in k_resize_rows.
 // Needs: ow % 4 == 0, <= WR vertical and <= 8 horizontal taps, segment footprint <= 64 * VC columns.
+// N outputs per lane: 4 (segments of 256 output columns; factors >= ~x1.4) or 2 (segments of 128: the
+// footprint of factors x1.0 .. x1.4 then still fits 3 columns per lane).
 constexpr int kResizeWinRows = 7; // Lanczos-3 on an upscale touches at most 7 input rows
 
-template <bool EXACT, int VC, int UNION>
+template <bool EXACT, int VC, int UNION, int N>
 __global__ __launch_bounds__(256) void k_resize_win(
     const uint32_t *__restrict__ in, uint32_t *__restrict__ out,
     const int32_t *__restrict__ lxt, const uint32_t *__restrict__ nxt, const float *__restrict__ wxt,
@@ -492,7 +494,8 @@ __global__ __launch_bounds__(256) void k_resize_win(
     size_t in_frame_px, size_t out_frame_px, uint32_t sel)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int N = 4, WR = kResizeWinRows;
+    constexpr int WR = kResizeWinRows;
+    static_assert(N == 4 || N == 2, "outputs per lane");
     constexpr uint32_t SEGW = kWave * N;
     float4 *s_v = reinterpret_cast<float4 *>(smem) + (size_t)threadIdx.y * (ncols_max + kResizeSlack);
     const uint32_t seg = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + threadIdx.y);
@@ -653,7 +656,10 @@ __global__ __launch_bounds__(256) void k_resize_win(
                 const uint32_t rgb = pack_u8<EXACT>(h2, 2, pack_u8<EXACT>(h1, 1, pack_u8<EXACT>(h0, 0, 0u)));
                 o[i] = skip_alpha ? (rgb | 0xFF000000u) : pack_u8<EXACT>(h3, 3, rgb);
             }
-            *reinterpret_cast<uint4 *>(dst + (size_t)y * ow) = make_uint4(o[0], o[1], o[2], o[3]);
+            if constexpr (N == 4)
+                *reinterpret_cast<uint4 *>(dst + (size_t)y * ow) = make_uint4(o[0], o[1], o[2], o[3]);
+            else
+                *reinterpret_cast<uint2 *>(dst + (size_t)y * ow) = make_uint2(o[0], o[1]);
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); // the next row's V pass overwrites s_v
         __builtin_amdgcn_wave_barrier();
@@ -804,32 +810,37 @@ hipError_t launch_resize_rows(const UpscaleLaunch &L, const DeviceTables &T, boo
 }
 
 hipError_t launch_resize_win(const UpscaleLaunch &L, const DeviceTables &T, bool exact, uint32_t ncols_max,
-                             uint32_t union_taps)
+                             uint32_t union_taps, uint32_t outputs_per_lane)
 {
     const size_t ipx = (size_t)L.iw * L.ih, opx = (size_t)L.ow * L.oh;
     const size_t lds = (size_t)4 * (ncols_max + kResizeSlack) * sizeof(float4);
     const int vc = ncols_max <= 128 ? 2 : (ncols_max <= 192 ? 3 : 0); // 4 columns per lane: 256 VGPRs, slower than the LDS-row kernel
-    if (vc == 0 || (L.ow % 4) != 0) return hipErrorInvalidValue; // the host never selects this variant then
+    if (vc == 0 || (L.ow % 4) != 0 || (outputs_per_lane != 4 && outputs_per_lane != 2)) return hipErrorInvalidValue;
     const int uni = (union_taps > 0 && union_taps <= 10) ? 10 : 0; // wider unions: plain 8-slot H pass (VGPR budget)
+    const uint32_t segw = 64 * outputs_per_lane;
     return for_frame_chunks(L, [&](const uint8_t *in, uint8_t *out, uint32_t n) {
-        const uint64_t blocks_x = cdiv(cdiv(L.ow, 256), 4);
+        const uint64_t blocks_x = cdiv(cdiv(L.ow, segw), 4);
         uint64_t rpb = (uint64_t)L.oh * blocks_x * n / 4096; // a few thousand blocks per launch ...
         rpb = rpb < 16 ? 16 : (rpb > 64 ? 64 : rpb);          // ... each tall enough to amortise its window fill
         const dim3 block(kWave, 4), grid((uint32_t)blocks_x, cdiv(L.oh, (uint32_t)rpb), n);
         auto *i32 = reinterpret_cast<const uint32_t *>(in);
         auto *o32 = reinterpret_cast<uint32_t *>(out);
-#define NUS_RW(E, C, U)                                                                                              \
-    hipLaunchKernelGGL((k_resize_win<E, C, U>), grid, block, lds, L.stream, i32, o32, T.lz_lx, T.lz_nx, T.lz_wx, T.lz_ly, \
+#define NUS_RW(E, C, U, NN)                                                                                              \
+    hipLaunchKernelGGL((k_resize_win<E, C, U, NN>), grid, block, lds, L.stream, i32, o32, T.lz_lx, T.lz_nx, T.lz_wx, T.lz_ly, \
                        T.lz_wy, T.lz_stride, L.iw, L.ih, L.ow, L.oh, (uint32_t)rpb, ncols_max, ipx, opx, L.in_sel)
-#define NUS_RW2(E)                                                       \
-    if (vc == 2) { if (uni) NUS_RW(E, 2, 10); else NUS_RW(E, 2, 0); }    \
-    else { if (uni) NUS_RW(E, 3, 10); else NUS_RW(E, 3, 0); }
+#define NUS_RW3(E, NN)                                                           \
+    if (vc == 2) { if (uni) NUS_RW(E, 2, 10, NN); else NUS_RW(E, 2, 0, NN); }    \
+    else { if (uni) NUS_RW(E, 3, 10, NN); else NUS_RW(E, 3, 0, NN); }
+#define NUS_RW2(E)                                  \
+    if (outputs_per_lane == 4) { NUS_RW3(E, 4) }    \
+    else { NUS_RW3(E, 2) }
         if (exact) {
             NUS_RW2(true)
         } else {
             NUS_RW2(false)
         }
 #undef NUS_RW2
+#undef NUS_RW3
 #undef NUS_RW
     });
 }

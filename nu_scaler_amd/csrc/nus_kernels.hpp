@@ -92,8 +92,9 @@ hipError_t launch_resize_rows(const UpscaleLaunch &L, const DeviceTables &T, boo
                               bool small_taps, uint32_t union_taps);
 // Up-scaling variant (ow % 4 == 0, <= 7 vertical / <= 8 horizontal taps, first tap row advancing by <= 1
 // per output row, ncols_max <= 192): vertical taps from a register window.
+// outputs_per_lane: 4 (segments of 256 output columns) or 2 (segments of 128); ncols_max and union_taps are for that width.
 hipError_t launch_resize_win(const UpscaleLaunch &L, const DeviceTables &T, bool exact, uint32_t ncols_max,
-                             uint32_t union_taps);
+                             uint32_t union_taps, uint32_t outputs_per_lane);
 // main x2 kernel only: the first / last kLanczosX2EdgeCols output columns are NOT written;
 // follow it with launch_lanczos_x2_edges(L, T, exact).
 hipError_t launch_lanczos_x2(const UpscaleLaunch &L, const DeviceTables &T, bool exact,

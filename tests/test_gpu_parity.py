@@ -603,6 +603,7 @@ def test_lanczos_x2_opaque_and_mixed_alpha_rows(nsc, oracle_mod, alg):
 @pytest.mark.parametrize("alg,filt", [("lanczos3", 0), ("bicubic", 1), ("triangle", 2)])
 @pytest.mark.parametrize("dims", [((320, 180), (480, 270)), ((320, 180), (960, 540)), ((250, 135), (1000, 540)),
                                   ((640, 360), (960, 540)), ((100, 37), (1000, 99)), ((480, 270), (680, 384)), ((600, 40), (900, 41)),
+                                  ((480, 270), (640, 360)), ((517, 40), (520, 41)), ((1000, 30), (1200, 36)),
                                   ((255, 33), (1020, 200)), ((64, 64), (64, 64))])
 def test_resize_register_window_variant(nsc, oracle_mod, alg, filt, dims):
     """Up-scaling shapes (x1 .. x10, ow % 4 == 0) take the register-window variant; it must equal the LDS-row
