@@ -261,3 +261,21 @@ def test_frame_buffer_timeout_and_threads(nsc):
     threading.Timer(0.05, lambda: fb.add_frame(bytes(16), 2, 2)).start()
     got = fb.pop_frame(timeout_ms=2000)
     assert got is not None and got[1:] == (2, 2, 0)
+
+
+def test_header_is_plain_c_and_links(nsc, tmp_path):
+    """include/nuscaler_hip.h compiles as strict C99 and a C program linked against libnuscaler_hip.so can drive the
+    boundary (tests/c_abi/abi_check.c; no compute calls, so it runs without a GPU)."""
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("gcc not available")
+    lib_dir = os.path.dirname(nsc._capi.LIB_PATH)
+    exe = str(tmp_path / "abi_check")
+    cmd = ["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"),
+           os.path.join(ROOT, "tests", "c_abi", "abi_check.c"), "-o", exe, "-L", lib_dir, "-lnuscaler_hip",
+           "-Wl,-rpath," + lib_dir]
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    assert res.returncode == 0, res.stderr
+    run = subprocess.run([exe], capture_output=True, text=True)
+    assert run.returncode == 0 and "abi_check ok" in run.stdout, run.stdout + run.stderr
