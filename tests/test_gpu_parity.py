@@ -728,3 +728,21 @@ def test_resize_window_opaque_rows(nsc, oracle_mod, alg, dims):
         assert np.array_equal(got, ref), name
         if name == "opaque":
             assert (got[..., 3] == 255).all()
+
+
+def test_c_program_through_the_boundary(nsc, tmp_path):
+    """A plain C caller (tests/c_abi/abi_upscale.c) upscales and interpolates through libnuscaler_hip.so."""
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("gcc not available")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib_dir = os.path.dirname(nsc._capi.LIB_PATH)
+    exe = str(tmp_path / "abi_upscale")
+    cmd = ["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-I", os.path.join(root, "include"),
+           os.path.join(root, "tests", "c_abi", "abi_upscale.c"), "-o", exe, "-L", lib_dir, "-lnuscaler_hip",
+           "-Wl,-rpath," + lib_dir]
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    assert res.returncode == 0, res.stderr
+    run = subprocess.run([exe], capture_output=True, text=True)
+    assert run.returncode == 0 and "abi_upscale ok" in run.stdout, run.stdout + run.stderr
