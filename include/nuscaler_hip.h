@@ -111,6 +111,9 @@ typedef struct nus_interp nus_interp;
 int nus_abi_version(void);
 /* Number of usable HIP devices (0 when none; never fails). */
 int nus_device_count(void);
+/* HBM of one device in bytes (hipMemGetInfo): what PyAdvancedWgpuUpscaler.get_vram_stats reports
+ * (nu_scaler_core/src/lib.rs:539-584, gpu/memory.rs:731-764).  NUS_ERR_NO_DEVICE without a device. */
+int nus_device_memory_info(int device, uint64_t *free_bytes, uint64_t *total_bytes);
 /* Thread-local message of the last failing call on this thread ("" if none). */
 const char *nus_last_error(void);
 const char *nus_status_string(int status);

@@ -18,7 +18,7 @@ from .interpolator import WgpuFrameInterpolator
 from .queue import FrameBuffer, swizzle_bgra_to_rgba_device
 from .stream import (FramePipeline, broadcast_blob, broadcast_tables, build_tables_blob, shard_frames,
                      validate_tables_blob)
-from .upscaler import PyAdvancedWgpuUpscaler, PyWgpuUpscaler, create_advanced_upscaler
+from .upscaler import PyAdvancedWgpuUpscaler, PyVramStats, PyWgpuUpscaler, create_advanced_upscaler
 
 # module constants of the reference's #[pymodule] (nu_scaler_core/src/lib.rs:746-761)
 QUALITY_ULTRA = _capi.QUALITY_ULTRA
@@ -38,7 +38,7 @@ def create_fsr_upscaler(_quality: str):
 
 
 __all__ = [
-    "PyWgpuUpscaler", "PyAdvancedWgpuUpscaler", "create_advanced_upscaler", "create_fsr_upscaler",
+    "PyWgpuUpscaler", "PyAdvancedWgpuUpscaler", "PyVramStats", "create_advanced_upscaler", "create_fsr_upscaler",
     "upscale_image_file", "interpolate_image_files",
     "WgpuFrameInterpolator", "FlowEstimator", "FrameBuffer", "swizzle_bgra_to_rgba_device", "FramePipeline", "shard_frames", "broadcast_tables",
     "broadcast_blob", "build_tables_blob", "validate_tables_blob",

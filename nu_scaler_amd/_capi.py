@@ -36,6 +36,7 @@ _f, _dp = ctypes.c_float, ctypes.POINTER(ctypes.c_double)
 SIGNATURES = [
     ("nus_abi_version", _i, []),
     ("nus_device_count", _i, []),
+    ("nus_device_memory_info", _i, [_i, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64)]),
     ("nus_last_error", _cp, []),
     ("nus_status_string", _cp, [_i]),
     ("nus_upscaler_create", _vp, [_i, _i]),

@@ -51,6 +51,25 @@ int nus_device_count(void)
     return n;
 }
 
+int nus_device_memory_info(int device, uint64_t *free_bytes, uint64_t *total_bytes)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n) {
+        (void)hipGetLastError();
+        nus::set_thread_error("nus_device_memory_info: no such HIP device");
+        return NUS_ERR_NO_DEVICE;
+    }
+    size_t f = 0, t = 0;
+    if (hipSetDevice(device) != hipSuccess || hipMemGetInfo(&f, &t) != hipSuccess) {
+        (void)hipGetLastError();
+        nus::set_thread_error("nus_device_memory_info: hipMemGetInfo failed");
+        return NUS_ERR_HIP;
+    }
+    if (free_bytes) *free_bytes = f;
+    if (total_bytes) *total_bytes = t;
+    return NUS_OK;
+}
+
 const char *nus_last_error(void) { return nus::thread_error(); }
 
 const char *nus_status_string(int status)

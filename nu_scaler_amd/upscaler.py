@@ -73,6 +73,7 @@ class PyWgpuUpscaler:
         if not self._h:
             raise RuntimeError(C.last_error())
         self._upscale_scale = 2.0  # lib.rs:65
+        self._device = int(device)
         self._check(self._lib.nus_upscaler_set_device(self._h, int(device)))
         self._check(self._lib.nus_upscaler_set_bilinear_variant(self._h, 1 if bilinear_variant == "wgsl" else 0))
         self._check(self._lib.nus_upscaler_set_lanczos_mode(self._h, 1 if lanczos_mode == "exact" else 0))
@@ -267,9 +268,34 @@ class PyAdvancedWgpuUpscaler(PyWgpuUpscaler):
         self._quality_str = q
         self._check(self._lib.nus_upscaler_set_quality(self._h, _QUALITY[q]))
 
+    def get_vram_stats(self) -> PyVramStats:
+        """lib.rs:539-549; the numbers come from hipMemGetInfo of this upscaler's device."""
+        free, total = ctypes.c_uint64(), ctypes.c_uint64()
+        if self._lib.nus_device_memory_info(self._device, ctypes.byref(free), ctypes.byref(total)) != C.OK:
+            raise RuntimeError("No GPU resources available")  # lib.rs:545-547
+        mb = 1024.0 * 1024.0
+        app = (self.input_size + self.output_size) * 3 / mb  # the three pipeline slots of this handle
+        return PyVramStats(total.value / mb, (total.value - free.value) / mb, free.value / mb, app)
+
+    def get_vram_usage_percent(self) -> float:
+        """lib.rs:571-584."""
+        return self.get_vram_stats().usage_percent
+
     def get_gpu_info(self) -> dict:
         return {"name": "AMD Instinct MI355X (HIP)", "vendor": "AMD", "backend": "HIP/gfx950",
                 "devices": C.device_count()}
+
+
+class PyVramStats:
+    """gpu/memory.rs:731-764: total_mb, used_mb, free_mb, app_allocated_mb, usage_percent."""
+
+    def __init__(self, total_mb: float, used_mb: float, free_mb: float, app_allocated_mb: float):
+        self.total_mb, self.used_mb, self.free_mb, self.app_allocated_mb = total_mb, used_mb, free_mb, app_allocated_mb
+        self.usage_percent = used_mb / total_mb * 100.0 if total_mb > 0.0 else 0.0
+
+    def __repr__(self) -> str:
+        return (f"PyVramStats(total_mb={self.total_mb:.0f}, used_mb={self.used_mb:.0f}, free_mb={self.free_mb:.0f}, "
+                f"usage_percent={self.usage_percent:.1f})")
 
 
 def create_advanced_upscaler(quality: str) -> PyAdvancedWgpuUpscaler:

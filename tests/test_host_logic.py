@@ -279,3 +279,20 @@ def test_header_is_plain_c_and_links(nsc, tmp_path):
     assert res.returncode == 0, res.stderr
     run = subprocess.run([exe], capture_output=True, text=True)
     assert run.returncode == 0 and "abi_check ok" in run.stdout, run.stdout + run.stderr
+
+
+def test_vram_stats_surface(nsc):
+    """PyAdvancedWgpuUpscaler.get_vram_stats / get_vram_usage_percent (lib.rs:539-584): present; without a GPU
+    they raise the reference's RuntimeError text, with one they report hipMemGetInfo."""
+    u = nsc.create_advanced_upscaler("quality")
+    assert hasattr(u, "get_vram_stats") and hasattr(u, "get_vram_usage_percent")
+    if nsc.device_count() == 0:
+        with pytest.raises(RuntimeError, match="No GPU resources available"):
+            u.get_vram_stats()
+    else:
+        st = u.get_vram_stats()
+        assert st.total_mb > 100_000 and 0.0 <= st.usage_percent <= 100.0
+        assert abs(st.total_mb - st.used_mb - st.free_mb) < 1.0
+        assert u.get_vram_usage_percent() == pytest.approx(st.usage_percent, abs=5.0)
+    s = nsc.PyVramStats(100.0, 25.0, 75.0, 1.0)
+    assert s.usage_percent == 25.0
