@@ -12,6 +12,7 @@ libamdhip64 (pulled in by libnuscaler_hip.so) is loaded first.
 """
 from . import _capi
 from ._capi import NuScalerLibraryError, build, device_count
+from .benchmark import PyBenchmarkResult, py_benchmark_upscaler, py_run_comparison_benchmark
 from .flow import FlowEstimator
 from .imagefile import interpolate_image_files, upscale_image_file
 from .interpolator import WgpuFrameInterpolator
@@ -40,6 +41,7 @@ def create_fsr_upscaler(_quality: str):
 __all__ = [
     "PyWgpuUpscaler", "PyAdvancedWgpuUpscaler", "PyVramStats", "create_advanced_upscaler", "create_fsr_upscaler",
     "upscale_image_file", "interpolate_image_files",
+    "PyBenchmarkResult", "py_benchmark_upscaler", "py_run_comparison_benchmark",
     "WgpuFrameInterpolator", "FlowEstimator", "FrameBuffer", "swizzle_bgra_to_rgba_device", "FramePipeline", "shard_frames", "broadcast_tables",
     "broadcast_blob", "build_tables_blob", "validate_tables_blob",
     "NuScalerLibraryError", "build", "device_count",

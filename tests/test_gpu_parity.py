@@ -746,3 +746,18 @@ def test_c_program_through_the_boundary(nsc, tmp_path):
     assert res.returncode == 0, res.stderr
     run = subprocess.run([exe], capture_output=True, text=True)
     assert run.returncode == 0 and "abi_upscale ok" in run.stdout, run.stdout + run.stderr
+
+
+def test_benchmark_api_runs(nsc):
+    """The reference's own benchmark entry points over the host path (benchmark.rs:70-272)."""
+    r = nsc.py_benchmark_upscaler("wgpu", "ultra", 256, 256, 2.0, 5)
+    assert (r.upscaler_name, r.technology, r.quality) == ("WgpuBilinearUpscaler", "Wgpu", "Ultra")
+    assert (r.output_width, r.output_height, r.frames_processed) == (512, 512, 5)
+    assert r.avg_frame_time_ms > 0 and abs(r.fps - 1000.0 / r.avg_frame_time_ms) < 1e-6 * r.fps
+    assert r.total_duration_ms >= r.avg_frame_time_ms * 5 * 0.99
+    r2 = nsc.py_benchmark_upscaler("no-such-tech", "no-such-quality", 100, 60, 1.5, 2)
+    assert (r2.upscaler_name, r2.technology, r2.quality, r2.output_width, r2.output_height) == \
+        ("WgpuNearestUpscaler", "Fallback", "Quality", 150, 90)
+    rs = nsc.py_run_comparison_benchmark(64, 64, 2.0, 2)
+    assert len(rs) == 16 and {x.technology for x in rs} == {"FSR", "DLSS", "Wgpu", "Fallback"}
+    assert all(x.upscaler_name == ("WgpuBilinearUpscaler" if x.technology == "Wgpu" else "WgpuNearestUpscaler") for x in rs)

@@ -296,3 +296,18 @@ def test_vram_stats_surface(nsc):
         assert u.get_vram_usage_percent() == pytest.approx(st.usage_percent, abs=5.0)
     s = nsc.PyVramStats(100.0, 25.0, 75.0, 1.0)
     assert s.usage_percent == 25.0
+
+
+def test_benchmark_api_surface(nsc):
+    """py_benchmark_upscaler / py_run_comparison_benchmark / PyBenchmarkResult (benchmark.rs:24-272): argument
+    defaults, output size rounding and error text; without a GPU the run fails loudly with the reference's prefix."""
+    from nu_scaler_amd import benchmark as b
+    assert b._round_half_away(2.5) == 3 and b._round_half_away(3.5) == 4 and b._round_half_away(479.4) == 479
+    if nsc.device_count() == 0:
+        with pytest.raises(RuntimeError, match="^Benchmark error: "):
+            nsc.py_benchmark_upscaler("wgpu", "quality", 64, 64, 2.0, 2)
+        assert nsc.py_run_comparison_benchmark(32, 32, 2.0, 1) == []
+    r = b.PyBenchmarkResult(upscaler_name="x", technology="Wgpu", quality="Quality", input_width=1, input_height=2,
+                            output_width=3, output_height=4, scale_factor=2.0, avg_frame_time_ms=1.0, fps=1000.0,
+                            frames_processed=5, total_duration_ms=5.0)
+    assert (r.input_width, r.output_height, r.frames_processed, r.technology) == (1, 4, 5, "Wgpu")
