@@ -130,3 +130,63 @@ def test_cli_upscale_and_interpolate_match_oracle(nsc, oracle_mod, tmp_path):
     assert cli.main(["interpolate", pa, pb, po, "--flow", "--t", "0.25"]) == 0
     assert read_png_independent(po).shape == (64, 64, 4)
     assert cli.main(["upscale", src, out, "--tech", "dlss"]) == 1
+
+
+def _native_cli(nsc):
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.dirname(nsc._capi.LIB_PATH)), "bin", "nu_scaler_cli")
+    if not os.path.exists(exe):
+        subprocess.run(["make", "-C", nsc._capi.CSRC_DIR, "../bin/nu_scaler_cli"], check=True, capture_output=True)
+    return exe
+
+
+@pytest.mark.parametrize("ch", [1, 2, 3, 4])
+def test_native_cli_png_codec(nsc, tmp_path, ch):
+    """nu_scaler_cli (C++ on the C ABI + zlib): its PNG decoder and encoder against the independent reader, every
+    filter type and colour type; usage and error exits.  No GPU involved."""
+    import subprocess
+    exe = _native_cli(nsc)
+    rng = np.random.default_rng(10 + ch)
+    img = rng.integers(0, 256, (13, 17, ch), dtype=np.uint8)
+    src, dst = str(tmp_path / "f.png"), str(tmp_path / "g.png")
+    _write_filtered_png(src, img, [0, 1, 2, 3, 4])
+    r = subprocess.run([exe, "png-copy", src, dst], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert np.array_equal(read_png_independent(dst), read_png_independent(src))
+    assert subprocess.run([exe, "--help"], capture_output=True).returncode == 0
+    assert subprocess.run([exe], capture_output=True).returncode == 2
+    r = subprocess.run([exe, "upscale", str(tmp_path / "missing.png"), dst], capture_output=True, text=True)
+    assert r.returncode == 1 and "error" in r.stderr
+    bad = tmp_path / "bad.png"
+    bad.write_bytes(b"hello")
+    r = subprocess.run([exe, "png-copy", str(bad), dst], capture_output=True, text=True)
+    assert r.returncode == 1 and "not a PNG" in r.stderr
+
+
+@pytest.mark.gpu
+def test_native_cli_upscale_and_interpolate_match_oracle(nsc, oracle_mod, tmp_path):
+    import subprocess
+    from nu_scaler_amd import imagefile
+    exe = _native_cli(nsc)
+    src = os.path.join(GOLDEN, "ref_test_input.png")
+    img = read_png_independent(src)
+    h, w = img.shape[:2]
+    cases = [(["--algorithm", "bilinear"], lambda: oracle_mod.bilinear(img, 2 * w, 2 * h), 0),
+             (["--algorithm", "nearest", "--scale", "1.5"], lambda: oracle_mod.nearest(img, int(w * 1.5), int(h * 1.5)), 0),
+             (["--quality", "ultra"], lambda: oracle_mod.lanczos3(img, 2 * w, 2 * h), 1),
+             (["--tech", "fsr", "--quality", "ultra"], lambda: oracle_mod.fsr1(img, 2 * w, 2 * h, 0.0, 0.8), 0),
+             (["--tech", "none"], lambda: img, 0)]
+    for extra, want, tol in cases:
+        out = str(tmp_path / "o.png")
+        r = subprocess.run([exe, "upscale", src, out] + extra, capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        got, exp = read_png_independent(out), want()
+        assert got.shape == exp.shape and int(np.abs(got.astype(int) - exp.astype(int)).max()) <= tol, extra
+    a, b = oracle_mod.gen_box(64, 64, (255, 0, 0, 255)), oracle_mod.gen_box(64, 64, (0, 0, 255, 255))
+    pa, pb, po = (str(tmp_path / n) for n in ("a.png", "b.png", "mid.png"))
+    imagefile.write_png(pa, 64, 64, a.tobytes())
+    imagefile.write_png(pb, 64, 64, b.tobytes())
+    assert subprocess.run([exe, "interpolate", pa, pb, po], capture_output=True).returncode == 0
+    assert np.array_equal(read_png_independent(po), oracle_mod.warp_blend(a, b, None, 0.5))
+    assert subprocess.run([exe, "interpolate", pa, pb, po, "--flow", "--t", "0.25"], capture_output=True).returncode == 0
+    assert subprocess.run([exe, "upscale", src, po, "--tech", "dlss"], capture_output=True).returncode == 1
