@@ -761,3 +761,41 @@ def test_benchmark_api_runs(nsc):
     rs = nsc.py_run_comparison_benchmark(64, 64, 2.0, 2)
     assert len(rs) == 16 and {x.technology for x in rs} == {"FSR", "DLSS", "Wgpu", "Fallback"}
     assert all(x.upscaler_name == ("WgpuBilinearUpscaler" if x.technology == "Wgpu" else "WgpuNearestUpscaler") for x in rs)
+
+
+def test_more_frames_than_one_grid_axis_holds(nsc, oracle_mod):
+    """66 000 frames in one device call: the launchers split the batch at 65 535 frames per grid axis; frames on
+    both sides of the split (and the second input of the fused blend) must line up."""
+    import torch
+    n, w, h = 66000, 16, 16
+    rng = np.random.default_rng(5)
+    frames = torch.from_numpy(rng.integers(0, 256, (n + 1, h, w, 4), dtype=np.uint8)).cuda()
+    out = torch.empty((n, 2 * h, 2 * w, 4), dtype=torch.uint8, device="cuda")
+    s = torch.cuda.current_stream().cuda_stream
+    probe = [0, 1, 65534, 65535, 65536, n - 1]
+    for alg in ("nearest", "bilinear", "lanczos3"):
+        u = nsc.PyWgpuUpscaler("quality", alg, lanczos_mode="exact")
+        u.initialize(w, h, 2 * w, 2 * h)
+        u.upscale_device(frames.data_ptr(), out.data_ptr(), n, s)
+        torch.cuda.synchronize()
+        for k in probe:
+            want = np.frombuffer(u.upscale(frames[k].cpu().numpy().tobytes()), np.uint8).reshape(2 * h, 2 * w, 4)
+            assert np.array_equal(out[k].cpu().numpy(), want), (alg, k)
+    # fused blend of (frame k, frame k+1) + upscale: the second input must advance with the chunk
+    u = nsc.PyWgpuUpscaler("quality", "lanczos3")
+    u.initialize(w, h, 2 * w, 2 * h)
+    fb = w * h * 4
+    u.upscale_blend_device(frames.data_ptr(), fb, frames.data_ptr() + fb, fb, 0.5, out.data_ptr(), n, s)
+    torch.cuda.synchronize()
+    for k in probe:
+        a, b = frames[k].cpu().numpy(), frames[k + 1].cpu().numpy()
+        mid = oracle_mod.warp_blend(a, b, None, 0.5)
+        want = np.frombuffer(u.upscale(mid.tobytes()), np.uint8).reshape(2 * h, 2 * w, 4)
+        assert np.array_equal(out[k].cpu().numpy(), want), ("fused", k)
+    it = nsc.WgpuFrameInterpolator()
+    mid_all = torch.empty((n, h, w, 4), dtype=torch.uint8, device="cuda")
+    it.interpolate_device(frames.data_ptr(), fb, frames.data_ptr() + fb, fb, 0, w, h, 0.5, mid_all.data_ptr(), n, s)
+    torch.cuda.synchronize()
+    for k in probe:
+        want = oracle_mod.warp_blend(frames[k].cpu().numpy(), frames[k + 1].cpu().numpy(), None, 0.5)
+        assert np.array_equal(mid_all[k].cpu().numpy(), want), ("interp", k)
