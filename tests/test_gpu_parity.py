@@ -799,3 +799,39 @@ def test_more_frames_than_one_grid_axis_holds(nsc, oracle_mod):
     for k in probe:
         want = oracle_mod.warp_blend(frames[k].cpu().numpy(), frames[k + 1].cpu().numpy(), None, 0.5)
         assert np.array_equal(mid_all[k].cpu().numpy(), want), ("interp", k)
+
+
+def test_reinitialise_and_destroy_do_not_leak_device_memory(nsc, oracle_mod):
+    """Re-initialising with new dimensions frees tables and the three pipeline slots (upscale/mod.rs:883-889 is a
+    full re-init too); once the handles are gone the device's free memory is where it was after the same cycle
+    had run once before (the first cycle also pays the runtime's one-off code-object and pool allocations)."""
+    import gc
+    import torch
+    probe = nsc.create_advanced_upscaler("quality")
+
+    def cycle(seed):
+        rng = np.random.default_rng(seed)
+        for alg in ("nearest", "bilinear", "lanczos3", "bicubic", "fsr1"):
+            u = nsc.PyWgpuUpscaler("quality", alg)
+            for _ in range(6):
+                w, h = int(rng.integers(16, 400)), int(rng.integers(16, 300))
+                f = float(rng.choice([1.5, 2.0, 3.0, 4.0]))
+                ow, oh = int(w * f), int(h * f)
+                u.initialize(w, h, ow, oh)
+                img = oracle_mod.gen_noise(w, h, 7)
+                assert len(u.upscale(img.tobytes())) == ow * oh * 4
+                assert len(u.upscale_batch([img.tobytes()] * 4)) == 4
+            del u
+        it = nsc.WgpuFrameInterpolator()
+        for (w, h) in ((64, 64), (640, 360), (1920, 1080), (100, 30)):
+            a = oracle_mod.gen_noise(w, h, 8)
+            it.interpolate_py(a.tobytes(), a.tobytes(), w, h, flow=np.zeros((h, w, 2), np.float32))
+        del it
+        gc.collect()
+        torch.cuda.synchronize()
+        return probe.get_vram_stats().free_mb
+
+    free1 = cycle(9)
+    free2 = cycle(9)
+    free3 = cycle(10)
+    assert abs(free2 - free1) < 32.0 and abs(free3 - free1) < 32.0, (free1, free2, free3)
