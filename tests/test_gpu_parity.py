@@ -835,3 +835,21 @@ def test_reinitialise_and_destroy_do_not_leak_device_memory(nsc, oracle_mod):
     free2 = cycle(9)
     free3 = cycle(10)
     assert abs(free2 - free1) < 32.0 and abs(free3 - free1) < 32.0, (free1, free2, free3)
+
+
+def test_8k_output_frames(nsc, oracle_mod):
+    """4K -> 8K (132 MB per output frame): nearest / bilinear bit-exact against the oracle, Lanczos-3 within 1 LSB
+    on a tile-sized sample plus full-frame properties (constant in -> constant out, alpha stays opaque)."""
+    w, h = 3840, 2160
+    img = oracle_mod.gen_gradient(w, h, 3)
+    for alg, ref in (("nearest", oracle_mod.nearest), ("bilinear", oracle_mod.bilinear)):
+        got, u = _up(nsc, alg, img, 2 * w, 2 * h)
+        assert np.array_equal(got, ref(img, 2 * w, 2 * h, threads=0)), alg
+    got, u = _up(nsc, "lanczos3", img, 2 * w, 2 * h)
+    assert u.kernel_variant == "lanczos3_x2_regwin"
+    want = oracle_mod.lanczos3(img, 2 * w, 2 * h, threads=0)
+    assert _maxdiff(got, want) <= 1 and (got != want).mean() < 1e-3
+    assert (got[..., 3] == 255).all()
+    flat = np.full((h, w, 4), 93, np.uint8)
+    got, _ = _up(nsc, "lanczos3", flat, 2 * w, 2 * h)
+    assert (got == 93).all()
