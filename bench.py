@@ -53,6 +53,9 @@ def parse_args():
     ap.add_argument("--overlap", action="store_true",
                     help="blend on a second stream, concurrent with the upscale of the real frames (measured: no gain, "
                          "the Lanczos kernel is SIMD-time bound and slows by what the blend takes)")
+    ap.add_argument("--motion", action="store_true",
+                    help="also time the motion-compensated step (per-pair pyramid + Horn-Schunck flow feeding the warp); "
+                         "informational leg config.motion_variant, never `value`")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo for rehearsal)")
     ap.add_argument("--force-device", type=int, default=-1,
                     help="rehearsal only: put every rank on this GPU (with --backend gloo on a 1-GPU box)")
@@ -272,6 +275,20 @@ def main():
     # the outputs must differ between units and be fully written (alpha stays 255)
     assert int(up_real[0, ..., 3].min()) == 255 and int(up_mid[count - 1, ..., 3].min()) == 255
 
+    # (after the check above: with a real flow the bilinear samples' truncation can take alpha to 254)
+    motion_ms = None
+    if args.motion and rank == 0:
+        flows = torch.empty((count, h, w, 2), dtype=torch.float32, device=dev)
+        pipe.step_motion(frames, flows, mid, up_real, up_mid, stream)
+        torch.cuda.synchronize()
+        tm = time.perf_counter()
+        for _ in range(2):
+            pipe.step_motion(frames, flows, mid, up_real, up_mid, stream)
+        torch.cuda.synchronize()
+        motion_ms = (time.perf_counter() - tm) / 2 * 1e3
+        del flows
+
+
     if rank == 0:
         total_units = n_units * world * args.steps
         value = total_units * pipe.unit_pixels / elapsed / 1e6
@@ -325,6 +342,11 @@ def main():
                             "informational, measured after the timed region on this rank only",
                     "ms_per_step": round(fused_ms, 4),
                     "Mpix_per_s_per_gpu_same_unit_pixels": round(n_units * pipe.unit_pixels / fused_ms / 1e3, 1)},
+                "motion_variant": None if motion_ms is None else {
+                    "what": "same step with a dense flow per pair (3-level pyramid, 50 + 10 + 10 Horn-Schunck steps) feeding "
+                            "the warp instead of zero flow; informational, this rank only",
+                    "ms_per_step": round(motion_ms, 3),
+                    "units_per_s_per_gpu": round(n_units / motion_ms * 1e3, 1)},
                 "frames_per_sec_per_gpu_4k_out": round(2 * n_units * args.steps / elapsed, 1),
                 "algorithmic_GBps": round(total_units * pipe.unit_bytes / elapsed / 1e9, 1),
             },
