@@ -173,10 +173,10 @@ int HipFlowEstimator::horn_schunck(const float *i1, const float *i2, const float
         NUS_HIP(hipMemsetAsync(slot_[2], 0, fb, stream_)); // compute_coarse_flow clears the flow (:1136-1154)
     float *f0 = static_cast<float *>(slot_[2]), *f1 = static_cast<float *>(slot_[3]);
     if (tiled_) {
-        if ((rc = reserve(ib + ib / 4, 4)) != kOk) return rc; // float4 coefficients + reciprocals
+        if ((rc = reserve(ib, 4)) != kOk) return rc; // 3 floats of coefficients per cell
         float *coef = static_cast<float *>(slot_[4]);
-        NUS_HIP(launch_hs_prepare(static_cast<const float *>(slot_[0]), static_cast<const float *>(slot_[1]), coef, w, h, lambda, stream_));
-        NUS_HIP(launch_hs_iterate(coef, &f0, &f1, w, h, iterations, stream_));
+        NUS_HIP(launch_hs_prepare(static_cast<const float *>(slot_[0]), static_cast<const float *>(slot_[1]), coef, w, h, stream_));
+        NUS_HIP(launch_hs_iterate(coef, lambda, &f0, &f1, w, h, iterations, stream_));
     } else {
         for (uint32_t i = 0; i < iterations; ++i) { // ping-pong as :1156-1193
             NUS_HIP(launch_horn_schunck(static_cast<const float *>(slot_[0]), static_cast<const float *>(slot_[1]), f0, f1, w, h, lambda, stream_));
@@ -235,8 +235,8 @@ int HipFlowEstimator::estimate_device(const void *d_a, const void *d_b, uint32_t
         ch = (ch + 1) / 2;
     }
     const size_t ib = (size_t)w * h * 16, fb = (size_t)w * h * 8;
-    // slot 1 doubles as the per-level coefficient buffer (float4 + reciprocal per cell) once the pyramids exist
-    if ((rc = reserve(ib, 0)) != kOk || (rc = reserve(ib + ib / 4, 1)) != kOk || (rc = reserve(fb, 2)) != kOk ||
+    // slot 1 doubles as the per-level coefficient buffer (3 floats per cell) once the pyramids exist
+    if ((rc = reserve(ib, 0)) != kOk || (rc = reserve(ib, 1)) != kOk || (rc = reserve(fb, 2)) != kOk ||
         (rc = reserve(fb, 3)) != kOk || (rc = reserve(total, 4)) != kOk || (rc = reserve(total, 5)) != kOk)
         return rc;
     float *cur = static_cast<float *>(slot_[0]), *tmp = static_cast<float *>(slot_[1]);
@@ -272,8 +272,8 @@ int HipFlowEstimator::estimate_device(const void *d_a, const void *d_b, uint32_t
         const float *i1 = reinterpret_cast<const float *>(pa + loff[l]), *i2 = reinterpret_cast<const float *>(pb + loff[l]);
         if (iters == 0) return kOk;
         if (tiled_) {
-            NUS_HIP(launch_hs_prepare(i1, i2, coef, lw[l], lh[l], lambda, stream));
-            NUS_HIP(launch_hs_iterate(coef, &f0, &f1, lw[l], lh[l], iters, stream));
+            NUS_HIP(launch_hs_prepare(i1, i2, coef, lw[l], lh[l], stream));
+            NUS_HIP(launch_hs_iterate(coef, lambda, &f0, &f1, lw[l], lh[l], iters, stream));
             return kOk;
         }
         for (uint32_t i = 0; i < iters; ++i) {

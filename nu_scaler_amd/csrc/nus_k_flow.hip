@@ -159,10 +159,11 @@ __global__ __launch_bounds__(256) void k_pyramid_level(const void *__restrict__ 
 }
 
 // Derivatives of one pyramid level, computed once per level instead of once per Jacobi step:
-// (ix, iy, it, lambda + ix*ix + iy*iy) with exactly the expressions of horn_schunck.wgsl:58-82.
+// (ix, iy, it) with exactly the expressions of horn_schunck.wgsl:58-82, 12 bytes per cell.  The
+// denominator lambda + ix*ix + iy*iy and its reciprocal are recomputed from them when a tile is
+// loaded (same expression, same rounding): cheaper than reading 8 more bytes per cell and halo cell.
 __global__ __launch_bounds__(256) void k_hs_prepare(const float4 *__restrict__ i1, const float4 *__restrict__ i2,
-                                                    float4 *__restrict__ coef, float *__restrict__ zinv, int w, int h,
-                                                    float lambda)
+                                                    float *__restrict__ coef, int w, int h)
 {
     const int x = blockIdx.x * kWave + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
     if (x >= w || y >= h) return;
@@ -170,9 +171,10 @@ __global__ __launch_bounds__(256) void k_hs_prepare(const float4 *__restrict__ i
     const float ix = (lum(i1[(size_t)y * w + xp]) - lum(i1[(size_t)y * w + xm])) * 0.5f;
     const float iy = (lum(i1[(size_t)yp * w + x]) - lum(i1[(size_t)ym * w + x])) * 0.5f;
     const float it = lum(i2[(size_t)y * w + x]) - lum(i1[(size_t)y * w + x]);
-    const float den = lambda + ix * ix + iy * iy;
-    coef[(size_t)y * w + x] = make_float4(ix, iy, it, den);
-    zinv[(size_t)y * w + x] = 1.0f / den; // correctly rounded reciprocal, for div_by_recip
+    float *c = coef + ((size_t)y * w + x) * 3;
+    c[0] = ix;
+    c[1] = iy;
+    c[2] = it;
 }
 
 // K Jacobi steps per launch on an LDS tile (temporal blocking): a 32x32 output tile is loaded
@@ -187,81 +189,97 @@ struct HsCell {
     bool plain_div; // mantissa of den all ones: Markstein's exception
 };
 
-// T x T output tile, K Jacobi steps per launch (temporal blocking); blockDim = 256 = 32 x 8 cells
-// per sweep.  Each thread owns the same (T+2K)^2 / 256 cells in every step, so their coefficients
-// live in registers and only the two ping-pong flow tiles are in LDS.
+// T x T output tile, K Jacobi steps per launch (temporal blocking).  A thread owns a vertical run
+// of N cells in one column of the (T+2K)^2 tile (R columns x 256/R runs): the 3 x (N+2) flow values
+// its cells' neighbourhoods cover are read from LDS once per step and shared between the N cells
+// (3(N+2)/N reads per cell instead of 9), lanes of a wave walk consecutive columns (consecutive
+// 8-byte LDS words), and nothing in a step is conditional except the final write, so the N sum
+// chains interleave.  Each thread owns the same cells in every step: their coefficients live in
+// registers and only the two ping-pong flow tiles are in LDS.  Step j may write the cells whose
+// distance to the tile edge ("ring") is >= j -- their 3x3 neighbourhood was valid after step j-1;
+// at the image border neighbours clamp inwards exactly as in k_horn_schunck.
 template <int T, int K>
-__global__ __launch_bounds__(256) void k_hs_tiled(const float4 *__restrict__ coef, const float *__restrict__ zinv,
+__global__ __launch_bounds__(256) void k_hs_tiled(const float *__restrict__ coef, float lambda,
                                                   const float2 *__restrict__ fin, float2 *__restrict__ fout, int w, int h)
 {
-    constexpr int R = T + 2 * K;
-    constexpr int NA = (R + 7) / 8, NB = (R + 31) / 32;
+    constexpr int R = T + 2 * K, RUNS = 256 / R, N = (R + RUNS - 1) / RUNS;
+    static_assert(RUNS >= 1 && RUNS * N >= R, "tile does not fit 256 threads");
     __shared__ float2 s_flow[2][R * R];
-    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int tid = threadIdx.x;
+    const int run = tid / R, lx = tid - run * R, ly0 = run * N;
     const int x0 = blockIdx.x * T - K, y0 = blockIdx.y * T - K; // image coords of LDS cell (0,0)
-    HsCell cell[NA][NB];
-#pragma unroll
-    for (int a = 0; a < NA; ++a)
-#pragma unroll
-        for (int b = 0; b < NB; ++b) {
-            const int ly = ty + 8 * a, lx = tx + 32 * b;
-            if (ly < R && lx < R) {
-                const int gx = clampi(x0 + lx, 0, w - 1), gy = clampi(y0 + ly, 0, h - 1);
-                const size_t g = (size_t)gy * w + gx;
-                const float4 c = coef[g];
-                cell[a][b].ix = c.x;
-                cell[a][b].iy = c.y;
-                cell[a][b].it = c.z;
-                cell[a][b].den = c.w;
-                cell[a][b].zinv = zinv[g];
-                cell[a][b].plain_div = (__float_as_uint(c.w) & 0x7fffffu) == 0x7fffffu;
-                s_flow[0][ly * R + lx] = fin[g];
-            }
-        }
-    __syncthreads();
     // tiles whose loaded region lies strictly inside the image need no clamping at all
     const bool border = x0 < 0 || y0 < 0 || x0 + R > w || y0 + R > h; // block-uniform
+    HsCell cell[N];
+    int ring[N]; // -1: never written (slot outside the tile or cell outside the image)
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        const int ly = ly0 + i;
+        ring[i] = -1;
+        if (run < RUNS && ly < R) {
+            const int gx = clampi(x0 + lx, 0, w - 1), gy = clampi(y0 + ly, 0, h - 1);
+            const size_t g = (size_t)gy * w + gx;
+            const float *c = coef + g * 3;
+            const float ix = c[0], iy = c[1], den = lambda + ix * ix + iy * iy;
+            cell[i].ix = ix;
+            cell[i].iy = iy;
+            cell[i].it = c[2];
+            cell[i].den = den;
+            cell[i].zinv = 1.0f / den; // correctly rounded reciprocal, for div_by_recip
+            cell[i].plain_div = (__float_as_uint(den) & 0x7fffffu) == 0x7fffffu;
+            s_flow[0][ly * R + lx] = fin[g];
+            if (gx == x0 + lx && gy == y0 + ly) ring[i] = min(min(lx, ly), min(R - 1 - lx, R - 1 - ly));
+        } else {
+            cell[i] = HsCell{0.0f, 0.0f, 0.0f, 1.0f, 1.0f, false};
+        }
+    }
+    // LDS columns / rows of the neighbourhood: clamped to the image (border tiles) and to the tile
+    // (only cells of ring 0, which are never written, and idle slots are affected by the latter)
+    const int gxc = clampi(x0 + lx, 0, w - 1);
+    int col[3], row[N + 2];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) col[d] = clampi((border ? clampi(gxc + d - 1, 0, w - 1) - x0 : lx + d - 1), 0, R - 1);
+#pragma unroll
+    for (int r = 0; r < N + 2; ++r) {
+        const int ly = ly0 + r - 1;
+        row[r] = clampi((border ? clampi(y0 + ly, 0, h - 1) - y0 : ly), 0, R - 1) * R;
+    }
+    __syncthreads();
     int cur = 0;
 #pragma unroll 1
     for (int j = 1; j <= K; ++j) {
-        // step j updates cells [j, R-j) of the tile (plus whatever the image border clamps inwards)
+        const float2 *src = s_flow[cur];
+        float2 f[N + 2][3];
 #pragma unroll
-        for (int a = 0; a < NA; ++a)
+        for (int r = 0; r < N + 2; ++r)
 #pragma unroll
-            for (int b = 0; b < NB; ++b) {
-                const int ly = ty + 8 * a, lx = tx + 32 * b;
-                if (ly < j || ly >= R - j || lx < j || lx >= R - j) continue;
-                const int gx = x0 + lx, gy = y0 + ly;
-                if (border && (gx < 0 || gy < 0 || gx >= w || gy >= h)) continue;
-                float su = 0.0f, sv = 0.0f;
+            for (int d = 0; d < 3; ++d) f[r][d] = src[row[r] + col[d]];
 #pragma unroll
-                for (int dy = -1; dy <= 1; ++dy)
+        for (int i = 0; i < N; ++i) {
+            float su = 0.0f, sv = 0.0f;
 #pragma unroll
-                    for (int dx = -1; dx <= 1; ++dx) {
-                        int nx = lx + dx, ny = ly + dy;
-                        if (border) {
-                            nx = clampi(gx + dx, 0, w - 1) - x0;
-                            ny = clampi(gy + dy, 0, h - 1) - y0;
-                        }
-                        const float2 f = s_flow[cur][ny * R + nx];
-                        su += f.x;
-                        sv += f.y;
-                    }
-                // sum / count with count == 9 (horn_schunck.wgsl:38-41)
-                const float ua = div_by_recip(su, 9.0f, 1.0f / 9.0f), va = div_by_recip(sv, 9.0f, 1.0f / 9.0f);
-                const HsCell &c = cell[a][b];
-                const float num = c.ix * ua + c.iy * va + c.it;
-                const float common = c.plain_div ? num / c.den : div_by_recip(num, c.den, c.zinv);
-                s_flow[cur ^ 1][ly * R + lx] = make_float2(ua - common * c.ix, va - common * c.iy);
-            }
+            for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                for (int d = 0; d < 3; ++d) {
+                    su += f[i + dy][d].x;
+                    sv += f[i + dy][d].y;
+                }
+            // sum / count with count == 9 (horn_schunck.wgsl:38-41)
+            const float ua = div_by_recip(su, 9.0f, 1.0f / 9.0f), va = div_by_recip(sv, 9.0f, 1.0f / 9.0f);
+            const HsCell &c = cell[i];
+            const float num = c.ix * ua + c.iy * va + c.it;
+            const float common = c.plain_div ? num / c.den : div_by_recip(num, c.den, c.zinv);
+            if (ring[i] >= j) s_flow[cur ^ 1][(ly0 + i) * R + lx] = make_float2(ua - common * c.ix, va - common * c.iy);
+        }
         __syncthreads();
         cur ^= 1;
     }
-    for (int ly = ty + K; ly < T + K; ly += 8)
-        for (int lx = tx + K; lx < T + K; lx += 32) {
-            const int gx = x0 + lx, gy = y0 + ly;
-            if (gx < w && gy < h) fout[(size_t)gy * w + gx] = s_flow[cur][ly * R + lx];
-        }
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        if (ring[i] < K) continue; // the T x T interior that lies inside the image
+        const int ly = ly0 + i;
+        fout[(size_t)(y0 + ly) * w + (x0 + lx)] = s_flow[cur][ly * R + lx];
+    }
 }
 
 // flow_upsample.wgsl:27-36 (linear clamp-to-edge sampler in texel space), vectors * scale
@@ -335,28 +353,24 @@ hipError_t launch_pyramid_level(const void *in, bool u8_input, float *level, flo
     return hipGetLastError();
 }
 
-// coef: w*h float4 followed by w*h floats (reciprocals) -> w*h*20 bytes
-hipError_t launch_hs_prepare(const float *i1, const float *i2, float *coef, uint32_t w, uint32_t h, float lambda,
-                             hipStream_t stream)
+// coef: 3 floats (ix, iy, it) per cell -> w*h*12 bytes
+hipError_t launch_hs_prepare(const float *i1, const float *i2, float *coef, uint32_t w, uint32_t h, hipStream_t stream)
 {
     const dim3 block(kWave, 4), grid(cdiv(w, kWave), cdiv(h, 4));
     hipLaunchKernelGGL(k_hs_prepare, grid, block, 0, stream, reinterpret_cast<const float4 *>(i1),
-                       reinterpret_cast<const float4 *>(i2), reinterpret_cast<float4 *>(coef),
-                       coef + (size_t)w * h * 4, (int)w, (int)h, lambda);
+                       reinterpret_cast<const float4 *>(i2), coef, (int)w, (int)h);
     return hipGetLastError();
 }
 
 // `iterations` Jacobi steps from *flow_a, ping-ponging with *flow_b; on return *flow_a holds the
 // result (the pointers are swapped as needed).  Steps are grouped 8 / 4 / 2 / 1 per launch; small
 // levels use 16x16 tiles so that the grid still covers the 256 CUs.
-hipError_t launch_hs_iterate(const float *coef, float **flow_a, float **flow_b, uint32_t w, uint32_t h,
+hipError_t launch_hs_iterate(const float *coef, float lambda, float **flow_a, float **flow_b, uint32_t w, uint32_t h,
                              uint32_t iterations, hipStream_t stream)
 {
     const bool small = (uint64_t)cdiv(w, 32) * cdiv(h, 32) < 1024;
     const uint32_t T = small ? 16 : 32;
     const dim3 block(256), grid(cdiv(w, T), cdiv(h, T));
-    auto c4 = reinterpret_cast<const float4 *>(coef);
-    const float *zi = coef + (size_t)w * h * 4;
     uint32_t launches = (iterations + 7) / 8;
     while (iterations > 0) {
         auto fi = reinterpret_cast<const float2 *>(*flow_a);
@@ -365,9 +379,9 @@ hipError_t launch_hs_iterate(const float *coef, float **flow_a, float **flow_b, 
 #define NUS_HS(KK)                                                                                              \
     case KK:                                                                                                    \
         if (small)                                                                                              \
-            hipLaunchKernelGGL((k_hs_tiled<16, KK>), grid, block, 0, stream, c4, zi, fi, fo, (int)w, (int)h);   \
+            hipLaunchKernelGGL((k_hs_tiled<16, KK>), grid, block, 0, stream, coef, lambda, fi, fo, (int)w, (int)h);   \
         else                                                                                                    \
-            hipLaunchKernelGGL((k_hs_tiled<32, KK>), grid, block, 0, stream, c4, zi, fi, fo, (int)w, (int)h);   \
+            hipLaunchKernelGGL((k_hs_tiled<32, KK>), grid, block, 0, stream, coef, lambda, fi, fo, (int)w, (int)h);   \
         break;
         switch (k) {
             NUS_HS(1) NUS_HS(2) NUS_HS(3) NUS_HS(4) NUS_HS(5) NUS_HS(6) NUS_HS(7) NUS_HS(8)

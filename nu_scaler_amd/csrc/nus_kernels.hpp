@@ -139,9 +139,8 @@ hipError_t launch_horn_schunck(const float *i1, const float *i2, const float *fl
 hipError_t launch_pyramid_level(const void *in, bool u8_input, float *level, float *next, uint32_t w, uint32_t h,
                                 hipStream_t stream);
 // Fast path of the same iteration: derivatives once per level, then K steps per launch in LDS.
-hipError_t launch_hs_prepare(const float *i1, const float *i2, float *coef, uint32_t w, uint32_t h, float lambda,
-                             hipStream_t stream);
-hipError_t launch_hs_iterate(const float *coef, float **flow_a, float **flow_b, uint32_t w, uint32_t h,
+hipError_t launch_hs_prepare(const float *i1, const float *i2, float *coef, uint32_t w, uint32_t h, hipStream_t stream);
+hipError_t launch_hs_iterate(const float *coef, float lambda, float **flow_a, float **flow_b, uint32_t w, uint32_t h,
                              uint32_t iterations, hipStream_t stream);
 hipError_t launch_flow_upsample(const float *src, uint32_t sw, uint32_t sh, float *dst, uint32_t dw, uint32_t dh,
                                 float scale, hipStream_t stream);
