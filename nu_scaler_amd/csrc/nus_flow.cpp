@@ -175,8 +175,8 @@ int HipFlowEstimator::horn_schunck(const float *i1, const float *i2, const float
     if (tiled_) {
         if ((rc = reserve(ib, 4)) != kOk) return rc; // 3 floats of coefficients per cell
         float *coef = static_cast<float *>(slot_[4]);
-        NUS_HIP(launch_hs_prepare(static_cast<const float *>(slot_[0]), static_cast<const float *>(slot_[1]), coef, w, h, stream_));
-        NUS_HIP(launch_hs_iterate(coef, lambda, &f0, &f1, w, h, iterations, stream_));
+        NUS_HIP(launch_hs_prepare(static_cast<const float *>(slot_[0]), static_cast<const float *>(slot_[1]), false, coef, w, h, stream_));
+        NUS_HIP(launch_hs_iterate(coef, lambda, &f0, &f1, w, h, iterations, false, nullptr, stream_));
     } else {
         for (uint32_t i = 0; i < iterations; ++i) { // ping-pong as :1156-1193
             NUS_HIP(launch_horn_schunck(static_cast<const float *>(slot_[0]), static_cast<const float *>(slot_[1]), f0, f1, w, h, lambda, stream_));
@@ -245,7 +245,9 @@ int HipFlowEstimator::estimate_device(const void *d_a, const void *d_b, uint32_t
         uint8_t *pyr = static_cast<uint8_t *>(slot_[4 + f]);
         const void *frame = f ? d_b : d_a;
         if (tiled_) {
-            // fused level kernel; the downsampled input of level l+1 ping-pongs between cur and tmp
+            // fused level kernel: writes the level's luminance plane (at the level's offset; the
+            // f32 RGBA level itself is not needed) and the downsampled input of level l+1, which
+            // ping-pongs between cur and tmp
             float *nxt[2] = {cur, tmp};
             const void *src = frame;
             for (uint32_t l = 0; l < nl; ++l) {
@@ -267,13 +269,16 @@ int HipFlowEstimator::estimate_device(const void *d_a, const void *d_b, uint32_t
     const uint8_t *pa = static_cast<const uint8_t *>(slot_[4]), *pb = static_cast<const uint8_t *>(slot_[5]);
     float *f0 = static_cast<float *>(slot_[2]), *f1 = static_cast<float *>(slot_[3]);
     const uint32_t L = nl - 1;
-    NUS_HIP(hipMemsetAsync(f0, 0, (size_t)lw[L] * lh[L] * 8, stream));
+    // compute_coarse_flow starts from zero flow (:1136-1154): the tiled kernel takes that as a null input;
+    // the last launch of the finest level writes the caller's buffer directly
+    bool zero = true;
     auto iterate = [&](uint32_t l, uint32_t iters) -> int {
         const float *i1 = reinterpret_cast<const float *>(pa + loff[l]), *i2 = reinterpret_cast<const float *>(pb + loff[l]);
         if (iters == 0) return kOk;
         if (tiled_) {
-            NUS_HIP(launch_hs_prepare(i1, i2, coef, lw[l], lh[l], stream));
-            NUS_HIP(launch_hs_iterate(coef, lambda, &f0, &f1, lw[l], lh[l], iters, stream));
+            NUS_HIP(launch_hs_prepare(i1, i2, true, coef, lw[l], lh[l], stream)); // tiled pyramids hold luminance planes
+            NUS_HIP(launch_hs_iterate(coef, lambda, &f0, &f1, lw[l], lh[l], iters, zero, l == 0 ? static_cast<float *>(d_flow_out) : nullptr, stream));
+            zero = false;
             return kOk;
         }
         for (uint32_t i = 0; i < iters; ++i) {
@@ -284,6 +289,10 @@ int HipFlowEstimator::estimate_device(const void *d_a, const void *d_b, uint32_t
         }
         return kOk;
     };
+    if (!tiled_ || coarse_iters == 0) {
+        NUS_HIP(hipMemsetAsync(f0, 0, (size_t)lw[L] * lh[L] * 8, stream));
+        zero = false;
+    }
     if ((rc = iterate(L, coarse_iters)) != kOk) return rc;
     for (int l = (int)L - 1; l >= 0; --l) {
         NUS_HIP(launch_flow_upsample(f0, lw[l + 1], lh[l + 1], f1, lw[l], lh[l], 2.0f, stream));
@@ -292,7 +301,7 @@ int HipFlowEstimator::estimate_device(const void *d_a, const void *d_b, uint32_t
         f1 = t;
         if ((rc = iterate((uint32_t)l, refine_iters)) != kOk) return rc;
     }
-    NUS_HIP(hipMemcpyAsync(d_flow_out, f0, fb, hipMemcpyDeviceToDevice, stream));
+    if (f0 != d_flow_out) NUS_HIP(hipMemcpyAsync(d_flow_out, f0, fb, hipMemcpyDeviceToDevice, stream));
     return kOk;
 }
 

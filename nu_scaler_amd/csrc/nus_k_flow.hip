@@ -98,13 +98,13 @@ __global__ __launch_bounds__(256) void k_horn_schunck(const float4 *__restrict__
 // One pyramid level in one launch (build_pyramid's three dispatches, wgpu_interpolator.rs:1068-1085,
 // fused): a 64x16 output tile stages its (64+4)x(16+4) input region in LDS (converted from RGBA8
 // at level 0), runs the horizontal blur into a second LDS tile, the vertical blur from there, writes
-// the blurred level and, from the same tile, the 2x2-averaged input of the next level.  Each value
+// the luminance of the blurred level (all Horn-Schunck reads of it, 4 B instead of 16 B per pixel) and, from the same tile, the 2x2-averaged input of the next level.  Each value
 // goes through exactly the arithmetic of k_blur<true>, k_blur<false> and k_downsample, so the
 // result is bit-identical to the three separate kernels while HBM sees the input once.
 constexpr int kPyrTW = 64, kPyrTH = 16;
 
 template <bool U8IN>
-__global__ __launch_bounds__(256) void k_pyramid_level(const void *__restrict__ in, float4 *__restrict__ level,
+__global__ __launch_bounds__(256) void k_pyramid_level(const void *__restrict__ in, float *__restrict__ level_lum,
                                                        float4 *__restrict__ next, int w, int h)
 {
     __shared__ float4 s_a[(kPyrTH + 4) * (kPyrTW + 4)]; // input region; later the V-blurred tile
@@ -136,7 +136,7 @@ __global__ __launch_bounds__(256) void k_pyramid_level(const void *__restrict__ 
                                s_h[(r + 3) * kPyrTW + tx], s_h[(r + 4) * kPyrTW + tx]);
         s_a[r * kPyrTW + tx] = v;
         const int gy = by + r;
-        if (gx < w && gy < h) level[(size_t)gy * w + gx] = v;
+        if (gx < w && gy < h) level_lum[(size_t)gy * w + gx] = lum(v);
     }
     if (next == nullptr) return; // block-uniform
     __syncthreads();
@@ -162,15 +162,20 @@ __global__ __launch_bounds__(256) void k_pyramid_level(const void *__restrict__ 
 // (ix, iy, it) with exactly the expressions of horn_schunck.wgsl:58-82, 12 bytes per cell.  The
 // denominator lambda + ix*ix + iy*iy and its reciprocal are recomputed from them when a tile is
 // loaded (same expression, same rounding): cheaper than reading 8 more bytes per cell and halo cell.
-__global__ __launch_bounds__(256) void k_hs_prepare(const float4 *__restrict__ i1, const float4 *__restrict__ i2,
+// IMG = float4 (RGBA level images) or float (luminance planes written by k_pyramid_level).
+__device__ __forceinline__ float lum_of(const float4 *img, size_t i) { return lum(img[i]); }
+__device__ __forceinline__ float lum_of(const float *img, size_t i) { return img[i]; }
+
+template <typename IMG>
+__global__ __launch_bounds__(256) void k_hs_prepare(const IMG *__restrict__ i1, const IMG *__restrict__ i2,
                                                     float *__restrict__ coef, int w, int h)
 {
     const int x = blockIdx.x * kWave + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
     if (x >= w || y >= h) return;
     const int xp = min(x + 1, w - 1), xm = max(x, 1) - 1, yp = min(y + 1, h - 1), ym = max(y, 1) - 1;
-    const float ix = (lum(i1[(size_t)y * w + xp]) - lum(i1[(size_t)y * w + xm])) * 0.5f;
-    const float iy = (lum(i1[(size_t)yp * w + x]) - lum(i1[(size_t)ym * w + x])) * 0.5f;
-    const float it = lum(i2[(size_t)y * w + x]) - lum(i1[(size_t)y * w + x]);
+    const float ix = (lum_of(i1, (size_t)y * w + xp) - lum_of(i1, (size_t)y * w + xm)) * 0.5f;
+    const float iy = (lum_of(i1, (size_t)yp * w + x) - lum_of(i1, (size_t)ym * w + x)) * 0.5f;
+    const float it = lum_of(i2, (size_t)y * w + x) - lum_of(i1, (size_t)y * w + x);
     float *c = coef + ((size_t)y * w + x) * 3;
     c[0] = ix;
     c[1] = iy;
@@ -227,7 +232,7 @@ __global__ __launch_bounds__(256) void k_hs_tiled(const float *__restrict__ coef
             cell[i].den = den;
             cell[i].zinv = 1.0f / den; // correctly rounded reciprocal, for div_by_recip
             cell[i].plain_div = (__float_as_uint(den) & 0x7fffffu) == 0x7fffffu;
-            s_flow[0][ly * R + lx] = fin[g];
+            s_flow[0][ly * R + lx] = fin ? fin[g] : make_float2(0.0f, 0.0f); // null = start from zero flow
             if (gx == x0 + lx && gy == y0 + ly) ring[i] = min(min(lx, ly), min(R - 1 - lx, R - 1 - ly));
         } else {
             cell[i] = HsCell{0.0f, 0.0f, 0.0f, 1.0f, 1.0f, false};
@@ -339,43 +344,51 @@ hipError_t launch_horn_schunck(const float *i1, const float *i2, const float *fl
     return hipGetLastError();
 }
 
-// One fused pyramid level: `in` is RGBA8 (u8_input) or f32 RGBA; `next` may be null (last level).
-hipError_t launch_pyramid_level(const void *in, bool u8_input, float *level, float *next, uint32_t w, uint32_t h,
+// One fused pyramid level: `in` is RGBA8 (u8_input) or f32 RGBA; writes the level's luminance plane
+// (w*h floats) and the f32 RGBA input of the next level; `next` may be null (last level).
+hipError_t launch_pyramid_level(const void *in, bool u8_input, float *level_lum, float *next, uint32_t w, uint32_t h,
                                 hipStream_t stream)
 {
     const dim3 block(256), grid(cdiv(w, kPyrTW), cdiv(h, kPyrTH));
     if (u8_input)
-        hipLaunchKernelGGL(k_pyramid_level<true>, grid, block, 0, stream, in, reinterpret_cast<float4 *>(level),
+        hipLaunchKernelGGL(k_pyramid_level<true>, grid, block, 0, stream, in, level_lum,
                            reinterpret_cast<float4 *>(next), (int)w, (int)h);
     else
-        hipLaunchKernelGGL(k_pyramid_level<false>, grid, block, 0, stream, in, reinterpret_cast<float4 *>(level),
+        hipLaunchKernelGGL(k_pyramid_level<false>, grid, block, 0, stream, in, level_lum,
                            reinterpret_cast<float4 *>(next), (int)w, (int)h);
     return hipGetLastError();
 }
 
 // coef: 3 floats (ix, iy, it) per cell -> w*h*12 bytes
-hipError_t launch_hs_prepare(const float *i1, const float *i2, float *coef, uint32_t w, uint32_t h, hipStream_t stream)
+hipError_t launch_hs_prepare(const float *i1, const float *i2, bool luminance_planes, float *coef, uint32_t w, uint32_t h,
+                             hipStream_t stream)
 {
     const dim3 block(kWave, 4), grid(cdiv(w, kWave), cdiv(h, 4));
-    hipLaunchKernelGGL(k_hs_prepare, grid, block, 0, stream, reinterpret_cast<const float4 *>(i1),
-                       reinterpret_cast<const float4 *>(i2), coef, (int)w, (int)h);
+    if (luminance_planes)
+        hipLaunchKernelGGL(k_hs_prepare<float>, grid, block, 0, stream, i1, i2, coef, (int)w, (int)h);
+    else
+        hipLaunchKernelGGL(k_hs_prepare<float4>, grid, block, 0, stream, reinterpret_cast<const float4 *>(i1),
+                           reinterpret_cast<const float4 *>(i2), coef, (int)w, (int)h);
     return hipGetLastError();
 }
 
-// `iterations` Jacobi steps from *flow_a, ping-ponging with *flow_b; on return *flow_a holds the
-// result (the pointers are swapped as needed).  Steps are grouped 8 / 4 / 2 / 1 per launch; small
+// `iterations` Jacobi steps from *flow_a (from zero flow without reading it if zero_start),
+// ping-ponging with *flow_b; on return *flow_a holds the result (the pointers are swapped as
+// needed; with final_out the last launch writes there and *flow_a == final_out).  Steps are grouped 8 / 4 / 2 / 1 per launch; small
 // levels use 16x16 tiles so that the grid still covers the 256 CUs.
 hipError_t launch_hs_iterate(const float *coef, float lambda, float **flow_a, float **flow_b, uint32_t w, uint32_t h,
-                             uint32_t iterations, hipStream_t stream)
+                             uint32_t iterations, bool zero_start, float *final_out, hipStream_t stream)
 {
     const bool small = (uint64_t)cdiv(w, 32) * cdiv(h, 32) < 1024;
     const uint32_t T = small ? 16 : 32;
     const dim3 block(256), grid(cdiv(w, T), cdiv(h, T));
     uint32_t launches = (iterations + 7) / 8;
     while (iterations > 0) {
-        auto fi = reinterpret_cast<const float2 *>(*flow_a);
-        auto fo = reinterpret_cast<float2 *>(*flow_b);
         const uint32_t k = (iterations + launches - 1) / launches; // even split, 1..8 steps per launch
+        if (final_out && launches == 1) *flow_b = final_out; // the last launch writes the caller's buffer
+        auto fi = zero_start ? nullptr : reinterpret_cast<const float2 *>(*flow_a);
+        auto fo = reinterpret_cast<float2 *>(*flow_b);
+        zero_start = false;
 #define NUS_HS(KK)                                                                                              \
     case KK:                                                                                                    \
         if (small)                                                                                              \

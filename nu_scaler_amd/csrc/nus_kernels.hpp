@@ -135,13 +135,16 @@ hipError_t launch_blur(const float *in, float *out, uint32_t w, uint32_t h, bool
 hipError_t launch_downsample(const float *in, float *out, uint32_t w, uint32_t h, hipStream_t stream);
 hipError_t launch_horn_schunck(const float *i1, const float *i2, const float *flow_in, float *flow_out, uint32_t w,
                                uint32_t h, float lambda, hipStream_t stream);
-// blur H + blur V + downsample of one level in one launch (LDS tile with a 2-pixel halo).
-hipError_t launch_pyramid_level(const void *in, bool u8_input, float *level, float *next, uint32_t w, uint32_t h,
+// blur H + blur V + downsample of one level in one launch (LDS tile with a 2-pixel halo); the level
+// itself is written as its luminance plane (w*h floats), which is all Horn-Schunck reads of it.
+hipError_t launch_pyramid_level(const void *in, bool u8_input, float *level_lum, float *next, uint32_t w, uint32_t h,
                                 hipStream_t stream);
 // Fast path of the same iteration: derivatives once per level, then K steps per launch in LDS.
-hipError_t launch_hs_prepare(const float *i1, const float *i2, float *coef, uint32_t w, uint32_t h, hipStream_t stream);
+// i1 / i2: f32 RGBA level images, or their luminance planes (luminance_planes).
+hipError_t launch_hs_prepare(const float *i1, const float *i2, bool luminance_planes, float *coef, uint32_t w, uint32_t h,
+                             hipStream_t stream);
 hipError_t launch_hs_iterate(const float *coef, float lambda, float **flow_a, float **flow_b, uint32_t w, uint32_t h,
-                             uint32_t iterations, hipStream_t stream);
+                             uint32_t iterations, bool zero_start, float *final_out, hipStream_t stream);
 hipError_t launch_flow_upsample(const float *src, uint32_t sw, uint32_t sh, float *dst, uint32_t dw, uint32_t dh,
                                 float scale, hipStream_t stream);
 

@@ -115,6 +115,29 @@ def test_flow_estimate_ragged_sizes(nsc, oracle_mod, size, levels):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("levels,coarse,refine", [(1, 9, 0), (1, 0, 0), (3, 0, 4), (3, 5, 0), (2, 17, 9)])
+def test_flow_estimate_iteration_edge_cases(nsc, oracle_mod, levels, coarse, refine):
+    """One level (the coarse launch writes the caller's buffer), no coarse steps (zero flow has to be
+    materialised), no refine steps (the upsampled flow is the result), launch splits of 9 and 17 steps."""
+    w, h = 96, 50
+    a, b = oracle_mod.gen_noise(w, h, 7), oracle_mod.gen_noise(w, h, 8)
+    fe = nsc.FlowEstimator(levels=levels, coarse_iterations=coarse, refine_iterations=refine)
+    want = oracle_mod.flow_estimate(a, b, levels, coarse, refine, fe.lambda_)
+    for tiled in (True, False):
+        fe.set_tiled(tiled)
+        assert np.array_equal(fe.estimate(a, b, w, h), want), (levels, coarse, refine, tiled)
+
+
+@pytest.mark.gpu
+def test_flow_estimate_large_tiles(nsc, oracle_mod):
+    """Big enough (>= 1024 tiles of 32x32) for the 32-wide tile kernel at level 0, ragged in both directions."""
+    w, h = 1037, 1029
+    a, b = oracle_mod.gen_noise(w, h, 11), oracle_mod.gen_noise(w, h, 12)
+    fe = nsc.FlowEstimator(levels=2, coarse_iterations=4, refine_iterations=5)
+    assert np.array_equal(fe.estimate(a, b, w, h), oracle_mod.flow_estimate(a, b, 2, 4, 5, fe.lambda_))
+
+
+@pytest.mark.gpu
 def test_flow_estimate_device_path(nsc, oracle_mod):
     import torch
 
