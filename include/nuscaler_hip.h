@@ -333,6 +333,13 @@ int nus_flow_estimate(nus_flow *h, const uint8_t *a, const uint8_t *b, uint32_t 
 int nus_flow_estimate_device(nus_flow *h, const void *d_a, const void *d_b, uint32_t w, uint32_t hgt,
                              uint32_t levels, uint32_t coarse_iters, uint32_t refine_iters, float lambda,
                              void *d_flow_out, void *stream);
+/* Flows between consecutive frames of a device-resident stream (what the interpolator's batch entry
+ * point consumes): d_frames = n_frames RGBA8 frames back to back, d_flows = n_frames - 1 flows,
+ * flow k = frame k -> frame k+1.  Same result as n_frames - 1 calls of nus_flow_estimate_device;
+ * each frame's pyramid is built once.  Enqueues on `stream`, no synchronisation. */
+int nus_flow_estimate_device_stream(nus_flow *h, const void *d_frames, uint32_t n_frames, uint32_t w, uint32_t hgt,
+                                    uint32_t levels, uint32_t coarse_iters, uint32_t refine_iters, float lambda,
+                                    void *d_flows, void *stream);
 
 #ifdef __cplusplus
 }

@@ -104,6 +104,7 @@ SIGNATURES = [
     ("nus_flow_upsample", _i, [_vp, _vp, _u32, _u32, _vp, _u32, _u32, _f]),
     ("nus_flow_estimate", _i, [_vp, _vp, _vp, _u32, _u32, _u32, _u32, _u32, _f, _vp]),
     ("nus_flow_estimate_device", _i, [_vp, _vp, _vp, _u32, _u32, _u32, _u32, _u32, _f, _vp, _vp]),
+    ("nus_flow_estimate_device_stream", _i, [_vp, _vp, _u32, _u32, _u32, _u32, _u32, _u32, _f, _vp, _vp]),
 ]
 
 

@@ -451,4 +451,13 @@ int nus_flow_estimate_device(nus_flow *h, const void *d_a, const void *d_b, uint
              : null_handle();
 }
 
+int nus_flow_estimate_device_stream(nus_flow *h, const void *d_frames, uint32_t n_frames, uint32_t w, uint32_t hgt,
+                                    uint32_t levels, uint32_t coarse_iters, uint32_t refine_iters, float lambda,
+                                    void *d_flows, void *stream)
+{
+    return h ? h->impl.estimate_device_stream(d_frames, n_frames, w, hgt, levels, coarse_iters, refine_iters, lambda,
+                                              d_flows, static_cast<hipStream_t>(stream))
+             : null_handle();
+}
+
 } // extern "C"

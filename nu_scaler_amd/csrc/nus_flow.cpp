@@ -210,26 +210,20 @@ int HipFlowEstimator::upsample(const float *src, uint32_t sw, uint32_t sh, float
 // Device workspace layout of one estimate (slots): 0 tmp / current input (w*h*16),
 // 1 blur temp (w*h*16), 2..3 flow ping-pong (w*h*8), 4 pyramid A, 5 pyramid B (all levels,
 // packed), 6..7 RGBA8 staging for the host entry point.
-int HipFlowEstimator::estimate_device(const void *d_a, const void *d_b, uint32_t w, uint32_t h, uint32_t levels,
-                                      uint32_t coarse_iters, uint32_t refine_iters, float lambda, void *d_flow_out,
-                                      hipStream_t stream)
+int HipFlowEstimator::plan(uint32_t w, uint32_t h, uint32_t levels, Pyramid &g)
 {
-    std::lock_guard<std::mutex> lk(mu_);
-    CHECK_DIMS(w, h);
-    if (!d_a || !d_b || !d_flow_out) return fail(kInvalidArgument, "flow: null device pointer");
     if (levels == 0 || levels > 12) return fail(kInvalidArgument, "flow: levels must be 1..12");
     int rc = ensure_device();
     if (rc != kOk) return rc;
     // level geometry (build_pyramid: next = (cur + 1) / 2, wgpu_interpolator.rs:1008-1009)
-    uint32_t lw[12], lh[12];
-    size_t loff[12], total = 0;
-    uint32_t nl = 0;
+    g.total = 0;
+    g.levels = 0;
     for (uint32_t l = 0, cw = w, ch = h; l < levels; ++l) {
-        lw[l] = cw;
-        lh[l] = ch;
-        loff[l] = total;
-        total += (size_t)cw * ch * 16;
-        nl = l + 1;
+        g.w[l] = cw;
+        g.h[l] = ch;
+        g.offset[l] = g.total;
+        g.total += (size_t)cw * ch * 16;
+        g.levels = l + 1;
         if (cw == 1 && ch == 1) break;
         cw = (cw + 1) / 2;
         ch = (ch + 1) / 2;
@@ -237,52 +231,64 @@ int HipFlowEstimator::estimate_device(const void *d_a, const void *d_b, uint32_t
     const size_t ib = (size_t)w * h * 16, fb = (size_t)w * h * 8;
     // slot 1 doubles as the per-level coefficient buffer (3 floats per cell) once the pyramids exist
     if ((rc = reserve(ib, 0)) != kOk || (rc = reserve(ib, 1)) != kOk || (rc = reserve(fb, 2)) != kOk ||
-        (rc = reserve(fb, 3)) != kOk || (rc = reserve(total, 4)) != kOk || (rc = reserve(total, 5)) != kOk)
+        (rc = reserve(fb, 3)) != kOk || (rc = reserve(g.total, 4)) != kOk || (rc = reserve(g.total, 5)) != kOk)
         return rc;
+    return kOk;
+}
+
+// Pyramid of one RGBA8 frame into slot `pyr_slot` (4 or 5).
+int HipFlowEstimator::build_pyramid(const void *frame, int pyr_slot, const Pyramid &g, hipStream_t stream)
+{
     float *cur = static_cast<float *>(slot_[0]), *tmp = static_cast<float *>(slot_[1]);
-    float *coef = tmp; // the blur temp is free once the pyramids exist
-    for (int f = 0; f < 2; ++f) {
-        uint8_t *pyr = static_cast<uint8_t *>(slot_[4 + f]);
-        const void *frame = f ? d_b : d_a;
-        if (tiled_) {
-            // fused level kernel: writes the level's luminance plane (at the level's offset; the
-            // f32 RGBA level itself is not needed) and the downsampled input of level l+1, which
-            // ping-pongs between cur and tmp
-            float *nxt[2] = {cur, tmp};
-            const void *src = frame;
-            for (uint32_t l = 0; l < nl; ++l) {
-                float *level = reinterpret_cast<float *>(pyr + loff[l]);
-                float *next = l + 1 < nl ? nxt[l & 1] : nullptr;
-                NUS_HIP(launch_pyramid_level(src, l == 0, level, next, lw[l], lh[l], stream));
-                src = next;
-            }
-        } else {
-            NUS_HIP(launch_rgba8_to_f32(static_cast<const uint8_t *>(frame), cur, w, h, stream));
-            for (uint32_t l = 0; l < nl; ++l) {
-                float *level = reinterpret_cast<float *>(pyr + loff[l]);
-                NUS_HIP(launch_blur(cur, tmp, lw[l], lh[l], true, stream));
-                NUS_HIP(launch_blur(tmp, level, lw[l], lh[l], false, stream));
-                if (l + 1 < nl) NUS_HIP(launch_downsample(level, cur, lw[l], lh[l], stream));
-            }
+    uint8_t *pyr = static_cast<uint8_t *>(slot_[pyr_slot]);
+    if (tiled_) {
+        // fused level kernel: writes the level's luminance plane (at the level's offset; the
+        // f32 RGBA level itself is not needed) and the downsampled input of level l+1, which
+        // ping-pongs between cur and tmp
+        float *nxt[2] = {cur, tmp};
+        const void *src = frame;
+        for (uint32_t l = 0; l < g.levels; ++l) {
+            float *level = reinterpret_cast<float *>(pyr + g.offset[l]);
+            float *next = l + 1 < g.levels ? nxt[l & 1] : nullptr;
+            NUS_HIP(launch_pyramid_level(src, l == 0, level, next, g.w[l], g.h[l], stream));
+            src = next;
         }
+        return kOk;
     }
-    const uint8_t *pa = static_cast<const uint8_t *>(slot_[4]), *pb = static_cast<const uint8_t *>(slot_[5]);
+    NUS_HIP(launch_rgba8_to_f32(static_cast<const uint8_t *>(frame), cur, g.w[0], g.h[0], stream));
+    for (uint32_t l = 0; l < g.levels; ++l) {
+        float *level = reinterpret_cast<float *>(pyr + g.offset[l]);
+        NUS_HIP(launch_blur(cur, tmp, g.w[l], g.h[l], true, stream));
+        NUS_HIP(launch_blur(tmp, level, g.w[l], g.h[l], false, stream));
+        if (l + 1 < g.levels) NUS_HIP(launch_downsample(level, cur, g.w[l], g.h[l], stream));
+    }
+    return kOk;
+}
+
+// Coarse-to-fine Horn-Schunck between the pyramids in slots `slot_a` and `slot_b`.
+int HipFlowEstimator::solve(int slot_a, int slot_b, const Pyramid &g, uint32_t coarse_iters, uint32_t refine_iters,
+                            float lambda, void *d_flow_out, hipStream_t stream)
+{
+    int rc;
+    const uint8_t *pa = static_cast<const uint8_t *>(slot_[slot_a]), *pb = static_cast<const uint8_t *>(slot_[slot_b]);
     float *f0 = static_cast<float *>(slot_[2]), *f1 = static_cast<float *>(slot_[3]);
-    const uint32_t L = nl - 1;
+    float *coef = static_cast<float *>(slot_[1]); // the blur temp is free once the pyramids exist
+    const uint32_t L = g.levels - 1;
     // compute_coarse_flow starts from zero flow (:1136-1154): the tiled kernel takes that as a null input;
     // the last launch of the finest level writes the caller's buffer directly
     bool zero = true;
     auto iterate = [&](uint32_t l, uint32_t iters) -> int {
-        const float *i1 = reinterpret_cast<const float *>(pa + loff[l]), *i2 = reinterpret_cast<const float *>(pb + loff[l]);
+        const float *i1 = reinterpret_cast<const float *>(pa + g.offset[l]), *i2 = reinterpret_cast<const float *>(pb + g.offset[l]);
         if (iters == 0) return kOk;
         if (tiled_) {
-            NUS_HIP(launch_hs_prepare(i1, i2, true, coef, lw[l], lh[l], stream)); // tiled pyramids hold luminance planes
-            NUS_HIP(launch_hs_iterate(coef, lambda, &f0, &f1, lw[l], lh[l], iters, zero, l == 0 ? static_cast<float *>(d_flow_out) : nullptr, stream));
+            NUS_HIP(launch_hs_prepare(i1, i2, true, coef, g.w[l], g.h[l], stream)); // tiled pyramids hold luminance planes
+            NUS_HIP(launch_hs_iterate(coef, lambda, &f0, &f1, g.w[l], g.h[l], iters, zero,
+                                      l == 0 ? static_cast<float *>(d_flow_out) : nullptr, stream));
             zero = false;
             return kOk;
         }
         for (uint32_t i = 0; i < iters; ++i) {
-            NUS_HIP(launch_horn_schunck(i1, i2, f0, f1, lw[l], lh[l], lambda, stream));
+            NUS_HIP(launch_horn_schunck(i1, i2, f0, f1, g.w[l], g.h[l], lambda, stream));
             float *t = f0;
             f0 = f1;
             f1 = t;
@@ -290,18 +296,58 @@ int HipFlowEstimator::estimate_device(const void *d_a, const void *d_b, uint32_t
         return kOk;
     };
     if (!tiled_ || coarse_iters == 0) {
-        NUS_HIP(hipMemsetAsync(f0, 0, (size_t)lw[L] * lh[L] * 8, stream));
+        NUS_HIP(hipMemsetAsync(f0, 0, (size_t)g.w[L] * g.h[L] * 8, stream));
         zero = false;
     }
     if ((rc = iterate(L, coarse_iters)) != kOk) return rc;
     for (int l = (int)L - 1; l >= 0; --l) {
-        NUS_HIP(launch_flow_upsample(f0, lw[l + 1], lh[l + 1], f1, lw[l], lh[l], 2.0f, stream));
+        NUS_HIP(launch_flow_upsample(f0, g.w[l + 1], g.h[l + 1], f1, g.w[l], g.h[l], 2.0f, stream));
         float *t = f0;
         f0 = f1;
         f1 = t;
         if ((rc = iterate((uint32_t)l, refine_iters)) != kOk) return rc;
     }
-    if (f0 != d_flow_out) NUS_HIP(hipMemcpyAsync(d_flow_out, f0, fb, hipMemcpyDeviceToDevice, stream));
+    if (f0 != d_flow_out)
+        NUS_HIP(hipMemcpyAsync(d_flow_out, f0, (size_t)g.w[0] * g.h[0] * 8, hipMemcpyDeviceToDevice, stream));
+    return kOk;
+}
+
+int HipFlowEstimator::estimate_device(const void *d_a, const void *d_b, uint32_t w, uint32_t h, uint32_t levels,
+                                      uint32_t coarse_iters, uint32_t refine_iters, float lambda, void *d_flow_out,
+                                      hipStream_t stream)
+{
+    std::lock_guard<std::mutex> lk(mu_);
+    CHECK_DIMS(w, h);
+    if (!d_a || !d_b || !d_flow_out) return fail(kInvalidArgument, "flow: null device pointer");
+    Pyramid g;
+    int rc = plan(w, h, levels, g);
+    if (rc != kOk || (rc = build_pyramid(d_a, 4, g, stream)) != kOk || (rc = build_pyramid(d_b, 5, g, stream)) != kOk) return rc;
+    return solve(4, 5, g, coarse_iters, refine_iters, lambda, d_flow_out, stream);
+}
+
+// Flows between consecutive frames of a device-resident stream: frame k+1's pyramid, built for the
+// pair (k, k+1), is frame A's pyramid of the pair (k+1, k+2), so each frame's pyramid is built once.
+int HipFlowEstimator::estimate_device_stream(const void *d_frames, uint32_t n_frames, uint32_t w, uint32_t h,
+                                             uint32_t levels, uint32_t coarse_iters, uint32_t refine_iters, float lambda,
+                                             void *d_flows, hipStream_t stream)
+{
+    std::lock_guard<std::mutex> lk(mu_);
+    CHECK_DIMS(w, h);
+    if (!d_frames || !d_flows) return fail(kInvalidArgument, "flow: null device pointer");
+    if (n_frames < 2) return fail(kInvalidArgument, "flow: a stream needs at least 2 frames");
+    Pyramid g;
+    int rc = plan(w, h, levels, g);
+    if (rc != kOk) return rc;
+    const uint8_t *frames = static_cast<const uint8_t *>(d_frames);
+    uint8_t *flows = static_cast<uint8_t *>(d_flows);
+    const size_t frame_bytes = (size_t)w * h * 4, flow_bytes = (size_t)w * h * 8;
+    if ((rc = build_pyramid(frames, 4, g, stream)) != kOk) return rc;
+    for (uint32_t k = 0; k + 1 < n_frames; ++k) {
+        const int slot_a = 4 + (int)(k & 1), slot_b = 5 - (int)(k & 1);
+        if ((rc = build_pyramid(frames + (size_t)(k + 1) * frame_bytes, slot_b, g, stream)) != kOk) return rc;
+        if ((rc = solve(slot_a, slot_b, g, coarse_iters, refine_iters, lambda, flows + (size_t)k * flow_bytes, stream)) != kOk)
+            return rc;
+    }
     return kOk;
 }
 

@@ -40,8 +40,20 @@ public:
     int estimate_device(const void *d_a, const void *d_b, uint32_t w, uint32_t h, uint32_t levels,
                         uint32_t coarse_iters, uint32_t refine_iters, float lambda, void *d_flow_out,
                         hipStream_t stream);
+    // n_frames consecutive RGBA8 frames -> n_frames - 1 flows (k -> k+1), each pyramid built once.
+    int estimate_device_stream(const void *d_frames, uint32_t n_frames, uint32_t w, uint32_t h, uint32_t levels,
+                               uint32_t coarse_iters, uint32_t refine_iters, float lambda, void *d_flows,
+                               hipStream_t stream);
 
 private:
+    struct Pyramid { // level geometry; levels are packed at `offset` (16 bytes per pixel reserved)
+        uint32_t levels = 0, w[12] = {0}, h[12] = {0};
+        size_t offset[12] = {0}, total = 0;
+    };
+    int plan(uint32_t w, uint32_t h, uint32_t levels, Pyramid &g); // geometry + workspace
+    int build_pyramid(const void *frame, int pyr_slot, const Pyramid &g, hipStream_t stream);
+    int solve(int slot_a, int slot_b, const Pyramid &g, uint32_t coarse_iters, uint32_t refine_iters, float lambda,
+              void *d_flow_out, hipStream_t stream);
     int fail(int status, const std::string &msg);
     int fail_hip(hipError_t e, const char *what);
     int ensure_device();

@@ -104,3 +104,11 @@ class FlowEstimator:
         self._check(self._lib.nus_flow_estimate_device(self._h, d_a, d_b, width, height, self.levels,
                                                        self.coarse_iterations, self.refine_iterations, self.lambda_,
                                                        d_flow_out, stream or None))
+
+    def estimate_device_stream(self, d_frames: int, n_frames: int, width: int, height: int, d_flows: int,
+                               stream: int = 0) -> None:
+        """`n_frames` consecutive RGBA8 frames on the device -> `n_frames - 1` flows (k -> k+1) at `d_flows`;
+        same result as one `estimate_device` per pair, each frame's pyramid built once."""
+        self._check(self._lib.nus_flow_estimate_device_stream(self._h, d_frames, n_frames, width, height, self.levels,
+                                                              self.coarse_iterations, self.refine_iterations,
+                                                              self.lambda_, d_flows, stream or None))

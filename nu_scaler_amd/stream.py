@@ -150,8 +150,8 @@ class FramePipeline:
                     coarse_iterations: int = 50, refine_iterations: int = 10) -> None:
         """Motion-compensated variant of `step`: a dense flow per pair from the
         pyramid + Horn-Schunck front end into `flows` ((n_units, h, w, 2) float32), then warp + blend with it
-        instead of the reference's zero flow.  The flow of each pair is estimated on its own (several launches
-        per pair), the warp and both upscales run once over the whole batch."""
+        instead of the reference's zero flow.  The flows are estimated pair by pair (several launches per pair,
+        each frame's pyramid built once), the warp and both upscales run once over the whole batch."""
         from .flow import FlowEstimator
 
         if getattr(self, "_flow", None) is None:
@@ -159,9 +159,7 @@ class FramePipeline:
         n = mid.shape[0]
         base = frames.data_ptr()
         fb = self.frame_bytes
-        fl = self.w * self.h * 8
-        for k in range(n):
-            self._flow.estimate_device(base + k * fb, base + (k + 1) * fb, self.w, self.h, flows.data_ptr() + k * fl, stream)
+        self._flow.estimate_device_stream(base, n + 1, self.w, self.h, flows.data_ptr(), stream)
         self.interp.interpolate_device(base, fb, base + fb, fb, flows.data_ptr(), self.w, self.h, self.t, mid.data_ptr(), n,
                                        stream)
         self.upscaler.upscale_device(base, up_real.data_ptr(), n, stream)

@@ -160,6 +160,28 @@ def test_flow_estimate_device_path(nsc, oracle_mod):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("n_frames", [2, 3, 5])
+def test_flow_estimate_device_stream_equals_pairwise(nsc, oracle_mod, n_frames):
+    """The stream entry point reuses frame k+1's pyramid for the next pair (alternating workspace slots):
+    every flow must still be the oracle's flow of its own pair."""
+    import torch
+
+    w, h = 97, 45
+    frames = np.stack([oracle_mod.gen_noise(w, h, 60 + k) for k in range(n_frames)])
+    dev = torch.device("cuda:0")
+    d_frames = torch.from_numpy(frames).to(dev)
+    d_flows = torch.full((n_frames - 1, h, w, 2), float("nan"), dtype=torch.float32, device=dev)
+    fe = nsc.FlowEstimator(levels=3, coarse_iterations=9, refine_iterations=3)
+    fe.estimate_device_stream(d_frames.data_ptr(), n_frames, w, h, d_flows.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    got = d_flows.cpu().numpy()
+    for k in range(n_frames - 1):
+        assert np.array_equal(got[k], oracle_mod.flow_estimate(frames[k], frames[k + 1], 3, 9, 3, fe.lambda_)), k
+    with pytest.raises(Exception):
+        fe.estimate_device_stream(d_frames.data_ptr(), 1, w, h, d_flows.data_ptr(), 0)
+
+
+@pytest.mark.gpu
 def test_pipeline_step_motion_matches_stage_by_stage_oracle(nsc, oracle_mod):
     """FramePipeline.step_motion: per-pair flow -> warp + blend with it -> x2 Lanczos of real and in-between frames,
     device-resident over a small stream; every stage equals the oracle's (bit-exact flow and warp)."""
