@@ -61,8 +61,39 @@ __device__ __forceinline__ float4 sample_trunc(const uint32_t *__restrict__ f, u
     return make_float4(r[0], r[1], r[2], r[3]);
 }
 
+// Same sample through a buffer resource of one frame: 32-bit offsets (one v_mad_u32_u24 per row instead of
+// 64-bit address arithmetic per texel) and ONE 8-byte load per row for the horizontal pair -- the pair starts
+// at min(x0, w-2), so at the right border (x0 == x1 == w-1) both texels are its second half.
+__device__ __forceinline__ float4 sample_trunc_pairs(__amdgpu_buffer_rsrc_t rs, uint32_t w, uint32_t h, float x, float y)
+{
+    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+    x = fminf(fmaxf(x, 0.0f), (float)(w - 1));
+    y = fminf(fmaxf(y, 0.0f), (float)(h - 1));
+    const float xfl = floorf(x), yfl = floorf(y);
+    const uint32_t x0 = (uint32_t)xfl, y0 = (uint32_t)yfl;
+    const uint32_t y1 = umin(y0 + 1, h - 1);
+    const float xf = x - xfl, yf = y - yfl;
+    const float nxf = 1.0f - xf, nyf = 1.0f - yf;
+    const uint32_t xb = umin(x0, w - 2); // w >= 2 (checked by the caller)
+    const u32x2 r0 = __builtin_amdgcn_raw_buffer_load_b64(rs, (y0 * w + xb) * 4u, 0, 0);
+    const u32x2 r1 = __builtin_amdgcn_raw_buffer_load_b64(rs, (y1 * w + xb) * 4u, 0, 0);
+    const bool first = x0 == xb; // else x0 == x1 == w-1: both are the pair's second texel
+    const uint32_t p00 = first ? r0.x : r0.y, p01 = r0.y, p10 = first ? r1.x : r1.y, p11 = r1.y;
+    float r[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const float top = ch_f32(p00, c) * nxf + ch_f32(p01, c) * xf;
+        const float bottom = ch_f32(p10, c) * nxf + ch_f32(p11, c) * xf;
+        const float value = top * nyf + bottom * yf;
+        r[c] = fminf(floorf(value), 255.0f); // `value as u8`; value >= 0 here
+    }
+    return make_float4(r[0], r[1], r[2], r[3]);
+}
+
 // Dense flow (2 x f32 per pixel, delta A -> B): A sampled at p - t*flow, B at
 // p + (1-t)*flow (warp_blend.wgsl:36-37 in texel space).  blockDim = (64, 4).
+// PAIRS: the frames are at least 2 pixels wide and < 4 GiB (host-checked): buffer-resource sampling above.
+template <bool PAIRS>
 __global__ __launch_bounds__(256) void k_warp_blend_flow(
     const uint8_t *__restrict__ a, const uint8_t *__restrict__ b, const float *__restrict__ flow,
     uint8_t *__restrict__ out, size_t a_stride, size_t b_stride, uint32_t w, uint32_t h, float t, uint32_t sel)
@@ -71,8 +102,7 @@ __global__ __launch_bounds__(256) void k_warp_blend_flow(
     const uint32_t x = blockIdx.x * kWave + threadIdx.x;
     if (y >= h || x >= w) return;
     const size_t npx = (size_t)w * h;
-    const uint32_t *pa = reinterpret_cast<const uint32_t *>(a + (size_t)blockIdx.z * a_stride);
-    const uint32_t *pb = reinterpret_cast<const uint32_t *>(b + (size_t)blockIdx.z * b_stride);
+    const uint8_t *fa = a + (size_t)blockIdx.z * a_stride, *fb = b + (size_t)blockIdx.z * b_stride;
     const size_t idx = (size_t)y * w + x;
     const float2 f = *reinterpret_cast<const float2 *>(flow + ((size_t)blockIdx.z * npx + idx) * 2);
     float tv = t; // per-lane copy: scalar operands halve the VALU issue rate on gfx950
@@ -80,8 +110,15 @@ __global__ __launch_bounds__(256) void k_warp_blend_flow(
     const float nt = 1.0f - tv;
     const float ax = (float)x - tv * f.x, ay = (float)y - tv * f.y;
     const float bx = (float)x + nt * f.x, by = (float)y + nt * f.y;
-    const float4 sa = sample_trunc(pa, w, h, ax, ay);
-    const float4 sb = sample_trunc(pb, w, h, bx, by);
+    float4 sa, sb;
+    if (PAIRS) {
+        const uint32_t frame_bytes = (uint32_t)(npx * 4);
+        sa = sample_trunc_pairs(__builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(fa), 0, frame_bytes, 0x00020000), w, h, ax, ay);
+        sb = sample_trunc_pairs(__builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(fb), 0, frame_bytes, 0x00020000), w, h, bx, by);
+    } else {
+        sa = sample_trunc(reinterpret_cast<const uint32_t *>(fa), w, h, ax, ay);
+        sb = sample_trunc(reinterpret_cast<const uint32_t *>(fb), w, h, bx, by);
+    }
     uint32_t o = 0;
     o = pack_trunc_u8(nt * sa.x + tv * sb.x, 0, o);
     o = pack_trunc_u8(nt * sa.y + tv * sb.y, 1, o);
@@ -145,8 +182,12 @@ hipError_t launch_warp_blend(const WarpLaunch &L)
                 hipLaunchKernelGGL(k_blend_zero_flow<false>, grid, block, 0, L.stream, a, b, out, L.a_stride, L.b_stride, npx, L.t, L.in_sel);
         } else {
             const dim3 block(kWave, 4), grid(cdiv(L.w, 64), cdiv(L.h, 4), n);
-            hipLaunchKernelGGL(k_warp_blend_flow, grid, block, 0, L.stream, a, b, L.flow + (size_t)done * npx * 2, out,
-                               L.a_stride, L.b_stride, L.w, L.h, L.t, L.in_sel);
+            if (L.w >= 2 && npx * 4 < (1ull << 32))
+                hipLaunchKernelGGL(k_warp_blend_flow<true>, grid, block, 0, L.stream, a, b, L.flow + (size_t)done * npx * 2, out,
+                                   L.a_stride, L.b_stride, L.w, L.h, L.t, L.in_sel);
+            else
+                hipLaunchKernelGGL(k_warp_blend_flow<false>, grid, block, 0, L.stream, a, b, L.flow + (size_t)done * npx * 2, out,
+                                   L.a_stride, L.b_stride, L.w, L.h, L.t, L.in_sel);
         }
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
