@@ -276,6 +276,24 @@ void HipUpscaler::choose_variant()
                 variant_ = Variant::ResizeRows;
                 resize_ncols_max_ = widest;
                 resize_small_taps_ = tx_.lz_max_taps <= 8 && ty_.lz_max_taps <= 8;
+                // vertical down-scaling: stream the input rows through 7 accumulator slots,
+                // if the windows allow it and a 64-column output segment's footprint fits 5 columns per lane
+                if (ih_ > oh_ && tx_.lz_max_taps <= 32 && !force_rows_) {
+                    bool down_ok = true;
+                    for (uint32_t y = 0; down_ok && y + 7 < oh_; ++y) // a slot's next window opens after its current one closed
+                        down_ok = ty_.lz_left[y + 7] > ty_.lz_left[y] + (int32_t)ty_.lz_ntaps[y] - 1;
+                    uint32_t widest64 = 0;
+                    for (uint32_t x0 = 0; x0 < ow_; x0 += 64) {
+                        const uint32_t xl = (x0 + 64 < ow_ ? x0 + 64 : ow_) - 1;
+                        const uint32_t span = (uint32_t)(tx_.lz_left[xl] + (int32_t)tx_.lz_ntaps[xl] - tx_.lz_left[x0]);
+                        if (span > widest64) widest64 = span;
+                    }
+                    if (down_ok && widest64 <= 320) {
+                        variant_ = Variant::ResizeDown;
+                        resize_ncols_max_ = widest64;
+                        break;
+                    }
+                }
                 // widest union of the windows of a lane's 4 outputs (union-window H pass, 4 outputs per lane)
                 resize_union_taps_ = 0;
                 if ((ow_ % 4) == 0 && resize_small_taps_) {
@@ -464,6 +482,7 @@ int HipUpscaler::enqueue(const uint8_t *d_in, uint8_t *d_out, uint32_t n_frames,
     case Variant::ResizeRows:
         e = launch_resize_rows(L, dt_, lanczos_exact_, resize_ncols_max_, resize_small_taps_, resize_union_taps_);
         break;
+    case Variant::ResizeDown: e = launch_resize_down(L, dt_, lanczos_exact_, resize_ncols_max_, tx_.lz_max_taps); break;
     case Variant::FsrEasu: e = launch_fsr1(L, 0, easu_sharpness(), rcas_sharpness()); break;
     case Variant::FsrRcas: e = launch_fsr1(L, 1, easu_sharpness(), rcas_sharpness()); break;
     case Variant::Fsr1Fused: e = launch_fsr1(L, 2, easu_sharpness(), rcas_sharpness()); break;

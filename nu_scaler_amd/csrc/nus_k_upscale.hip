@@ -677,6 +677,7 @@ const char *variant_name(Variant v){
     case Variant::LanczosGeneral: return "lanczos3_general";
     case Variant::ResizeRows: return "resize_rows_lds";
     case Variant::ResizeWin: return "resize_regwin_lds";
+    case Variant::ResizeDown: return "resize_down_stream";
     case Variant::LanczosX2RegWin: return "lanczos3_x2_regwin";
     case Variant::LanczosXsRegWin: return "lanczos3_xs_regwin";
     case Variant::FsrEasu: return "fsr1_easu_tile";

@@ -69,6 +69,7 @@ enum class Variant : int {
     LanczosGeneral,   // any scale, direct separable evaluation per output pixel (fallback)
     ResizeRows,       // any scale, separable: V pass into an LDS row, H pass out of it
     ResizeWin,        // up-scaling: V pass from a register row window (as the x2 kernel), H pass through the LDS row
+    ResizeDown,       // down-scaling: input rows streamed once into the vertical sums of the 7 output rows in flight
     LanczosX2RegWin,  // exact x2, register sliding window + wave shifts
     LanczosXsRegWin,  // exact x3 / x4, same design with S output rows per input row
     FsrEasu,          // FSR1-style EASU alone (any scale)
@@ -95,6 +96,11 @@ hipError_t launch_resize_rows(const UpscaleLaunch &L, const DeviceTables &T, boo
 // outputs_per_lane: 4 (segments of 256 output columns) or 2 (segments of 128); ncols_max and union_taps are for that width.
 hipError_t launch_resize_win(const UpscaleLaunch &L, const DeviceTables &T, bool exact, uint32_t ncols_max,
                              uint32_t union_taps, uint32_t outputs_per_lane);
+// Down-scaling variant (nus_k_resize_down.hip): ly[y+7] beyond the end of window y (so 7 accumulator
+// slots suffice), ncols_max = widest footprint of a 64-column output segment <= 320.
+// max_taps_x: widest horizontal window (<= 32).
+hipError_t launch_resize_down(const UpscaleLaunch &L, const DeviceTables &T, bool exact, uint32_t ncols_max,
+                              uint32_t max_taps_x);
 // main x2 kernel only: the first / last kLanczosX2EdgeCols output columns are NOT written;
 // follow it with launch_lanczos_x2_edges(L, T, exact).
 hipError_t launch_lanczos_x2(const UpscaleLaunch &L, const DeviceTables &T, bool exact,

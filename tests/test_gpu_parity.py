@@ -730,6 +730,47 @@ def test_resize_window_opaque_rows(nsc, oracle_mod, alg, dims):
             assert (got[..., 3] == 255).all()
 
 
+@pytest.mark.parametrize("alg,filt", [("lanczos3", 0), ("bicubic", 1), ("triangle", 2)])
+@pytest.mark.parametrize("dims", [((256, 128), (128, 64)), ((300, 157), (150, 78)), ((515, 90), (172, 30)), ((640, 200), (160, 50)),
+                                  ((200, 300), (133, 201)), ((130, 71), (129, 70)), ((97, 260), (61, 65)), ((70, 64), (33, 13)),
+                                  ((64, 900), (16, 300))])
+def test_resize_down_streaming_kernel(nsc, oracle_mod, alg, filt, dims):
+    """Down-scaling (captured frames resized to the target, capture/common.rs:56): input rows streamed once into
+    the vertical sums of the output rows in flight.  EXACT mode adds the taps in the oracle's order: 0 differences;
+    FMA mode: <= 1 LSB and the same bits as the LDS-row kernel."""
+    (w, h), (ow, oh) = dims
+    img = oracle_mod.gen_noise(w, h, 77)
+    want = oracle_mod.resize(img, ow, oh, filt)
+    got_e, u = _up(nsc, alg, img, ow, oh, lanczos_mode="exact")
+    assert u.kernel_variant == "resize_down_stream", u.kernel_variant
+    assert np.array_equal(got_e, want), (alg, dims, u.kernel_variant, _maxdiff(got_e, want))
+    got_f, uf = _up(nsc, alg, img, ow, oh)
+    ref_f, ur = _up(nsc, alg, img, ow, oh, options={"force_rows": 1})
+    assert ur.kernel_variant == "resize_rows_lds"
+    assert np.array_equal(got_f, ref_f) and _maxdiff(got_f, want) <= 1
+
+
+def test_resize_down_4k_to_1080p_batch(nsc, oracle_mod):
+    """The capture-resize case at full size, 3 frames through the device entry point; frame 0 against the oracle."""
+    import torch
+    w, h, ow, oh = 3840, 2160, 1920, 1080
+    frames = np.stack([oracle_mod.gen_noise(w, h, 300 + k) for k in range(3)])
+    u = nsc.PyWgpuUpscaler("quality", "lanczos3")
+    u.initialize(w, h, ow, oh)
+    assert u.kernel_variant == "resize_down_stream"
+    d_in = torch.from_numpy(frames).cuda()
+    d_out = torch.zeros((3, oh, ow, 4), dtype=torch.uint8, device="cuda")
+    u.upscale_device(d_in.data_ptr(), d_out.data_ptr(), 3, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    got = d_out.cpu().numpy()
+    assert _maxdiff(got[0], oracle_mod.resize(frames[0], ow, oh, 0)) <= 1
+    r = nsc.PyWgpuUpscaler("quality", "lanczos3")
+    r.set_option("force_rows", 1)
+    r.initialize(w, h, ow, oh)
+    for k in range(3):
+        assert np.array_equal(got[k], np.frombuffer(r.upscale(frames[k].tobytes()), np.uint8).reshape(oh, ow, 4)), k
+
+
 def test_c_program_through_the_boundary(nsc, tmp_path):
     """A plain C caller (tests/c_abi/abi_upscale.c) upscales and interpolates through libnuscaler_hip.so."""
     import shutil
