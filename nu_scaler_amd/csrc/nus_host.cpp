@@ -264,6 +264,22 @@ void HipUpscaler::choose_variant()
             }
         }
         if (!ok && !force_per_pixel_) {
+            // vertical down-scaling: stream the input rows through 7 accumulator slots,
+            // if the windows allow it and a 64-column output segment's footprint fits 5 columns per lane
+            if (ih_ > oh_ && tx_.lz_max_taps <= 32 && !force_rows_) {
+                const bool down_ok = build_down_stream_tables(ty_, down_rows_, down_done_);
+                uint32_t widest64 = 0;
+                for (uint32_t x0 = 0; x0 < ow_; x0 += 64) {
+                    const uint32_t xl = (x0 + 64 < ow_ ? x0 + 64 : ow_) - 1;
+                    const uint32_t span = (uint32_t)(tx_.lz_left[xl] + (int32_t)tx_.lz_ntaps[xl] - tx_.lz_left[x0]);
+                    if (span > widest64) widest64 = span;
+                }
+                if (down_ok && widest64 <= 320) {
+                    variant_ = Variant::ResizeDown;
+                    resize_ncols_max_ = widest64;
+                    break;
+                }
+            }
             // LDS row kernel: needs the widest segment footprint to fit the per-wave LDS row
             const uint32_t segw = (ow_ % 4) == 0 ? 256 : 64;
             uint32_t widest = 0;
@@ -276,24 +292,6 @@ void HipUpscaler::choose_variant()
                 variant_ = Variant::ResizeRows;
                 resize_ncols_max_ = widest;
                 resize_small_taps_ = tx_.lz_max_taps <= 8 && ty_.lz_max_taps <= 8;
-                // vertical down-scaling: stream the input rows through 7 accumulator slots,
-                // if the windows allow it and a 64-column output segment's footprint fits 5 columns per lane
-                if (ih_ > oh_ && tx_.lz_max_taps <= 32 && !force_rows_) {
-                    bool down_ok = true;
-                    for (uint32_t y = 0; down_ok && y + 7 < oh_; ++y) // a slot's next window opens after its current one closed
-                        down_ok = ty_.lz_left[y + 7] > ty_.lz_left[y] + (int32_t)ty_.lz_ntaps[y] - 1;
-                    uint32_t widest64 = 0;
-                    for (uint32_t x0 = 0; x0 < ow_; x0 += 64) {
-                        const uint32_t xl = (x0 + 64 < ow_ ? x0 + 64 : ow_) - 1;
-                        const uint32_t span = (uint32_t)(tx_.lz_left[xl] + (int32_t)tx_.lz_ntaps[xl] - tx_.lz_left[x0]);
-                        if (span > widest64) widest64 = span;
-                    }
-                    if (down_ok && widest64 <= 320) {
-                        variant_ = Variant::ResizeDown;
-                        resize_ncols_max_ = widest64;
-                        break;
-                    }
-                }
                 // widest union of the windows of a lane's 4 outputs (union-window H pass, 4 outputs per lane)
                 resize_union_taps_ = 0;
                 if ((ow_ % 4) == 0 && resize_small_taps_) {
@@ -377,6 +375,10 @@ int HipUpscaler::upload_tables()
         UP(ty_.lz_ntaps, lz_ny);
         UP(ty_.lz_w, lz_wy);
         dt_.lz_stride = kResizeMaxTaps;
+        if (variant_ == Variant::ResizeDown) {
+            UP(down_rows_, lz_down_rows);
+            UP(down_done_, lz_down_done);
+        }
         if (variant_ == Variant::LanczosXsRegWin) {
             UP(wy6_, lz_wy6);
             for (uint32_t p = 0; p < xs_factor_; ++p)

@@ -148,6 +148,8 @@ private:
     bool force_per_pixel_ = false; // resize: never use the LDS row kernel
     bool force_rows_ = false;      // resize: never use the register-window variant of it
     uint32_t resize_ncols_max_ = 0; // LDS row length of the ResizeRows variant
+    std::vector<uint32_t> down_rows_; // ResizeDown: per-input-row slot weights + completion (build_down_stream_tables)
+    std::vector<int32_t> down_done_;
     bool resize_small_taps_ = false;
     uint32_t xs_factor_ = 0;         // 3 / 4 when the integer-factor register-window kernel is selected
     uint32_t win_outputs_per_lane_ = 4; // register-window resize: 4, or 2 for factors below ~x1.4

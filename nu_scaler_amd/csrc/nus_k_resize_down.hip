@@ -15,28 +15,33 @@ constexpr uint32_t kDownSlack = 32; // zeroed LDS entries behind the row: the fi
 // gathering a 13..31-row window per output row, a wave walks DOWN THE INPUT ROWS ONCE and keeps the
 // vertical sums of the output rows in flight in registers:
 //   * lane l holds VC input columns (l, l+64, ..) of the wave's 64-output segment footprint;
-//   * NS = 7 accumulator slots; slot s serves output rows y_begin+s, +7, +14, ...  For each input row
-//     r and slot s with r inside the slot's window:  acc[s] += wy[y][r - ly[y]] * row r  -- taps are
-//     added in increasing row order, exactly the order of the per-output loop (bit-identical in
-//     EXACT mode, where mac is mul + add);
-//   * a row that completes a window (one per input row in the interior; the windows cut by the bottom
-//     border end together on the last row) writes its sums to the wave's LDS row; each lane then sums
-//     its output's horizontal taps from LDS, packs and stores; the slot restarts on its next output row.
-// Every input byte is read once per row block (+ the window fill of the block's first rows), every
-// vertical product is computed once, and no slot ever holds more than one open window (host-checked:
-// ly[y+7] > ly[y] + ny[y] - 1).
-constexpr int kDownSlots = 7;
+//   * 7 accumulator slots, output row y lives in slot y % 7.  The host lays the vertical weights out
+//     PER INPUT ROW (build_down_stream_tables): 7 weights -- the row's weight in each slot, 0 where it
+//     is outside that slot's window -- and the output row, if any, whose window ends on it.  One
+//     32-byte scalar load per input row replaces all per-slot window arithmetic; every slot takes
+//     acc[s] += w[s] * row.  Taps are added in increasing row order, exactly the order of the
+//     per-output loop, and an added +-0 changes nothing: bit-identical in EXACT mode (mul + add);
+//   * the row that completes a window writes the slot's sums to the wave's LDS row; each lane then
+//     sums its output's horizontal taps from LDS (weights in registers), packs and stores, and the
+//     slot is cleared.  Windows cut by the bottom border end together on the last input row: the
+//     table gives each of them a pseudo-row of zero weights behind it, so the loop never sees two.
+// A block of output rows starts at its first window's first row with cleared slots; windows of the
+// previous block that are still open there complete with partial sums and are dropped (y < y_begin).
+// Every input byte is read once per row block (+ that window fill), every vertical product is
+// computed once, and the host has checked that no slot ever holds two open windows.
+constexpr int kSlots = 7;          // == nus::kDownSlots (nus_tables.hpp)
+constexpr uint32_t kNone = 0xFFFFFFFFu;
 
 template <bool EXACT, int VC, int HT>
 __global__ __launch_bounds__(256) void k_resize_down(
     const uint32_t *__restrict__ in, uint32_t *__restrict__ out,
     const int32_t *__restrict__ lxt, const uint32_t *__restrict__ nxt, const float *__restrict__ wxt,
-    const int32_t *__restrict__ lyt, const uint32_t *__restrict__ nyt, const float *__restrict__ wyt,
-    uint32_t stride, uint32_t iw, uint32_t ow, uint32_t oh, uint32_t rows_per_block, uint32_t ncols_max,
+    const int32_t *__restrict__ lyt, const uint32_t *__restrict__ rowtab, const int32_t *__restrict__ done_row,
+    uint32_t stride, uint32_t iw, uint32_t ih, uint32_t ow, uint32_t oh, uint32_t rows_per_block, uint32_t ncols_max,
     size_t in_frame_px, size_t out_frame_px, uint32_t sel)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int NS = kDownSlots;
+    constexpr int NS = kSlots;
     float4 *s_v = reinterpret_cast<float4 *>(smem) + (size_t)threadIdx.y * (ncols_max + kDownSlack);
     const uint32_t seg = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + threadIdx.y);
     const uint32_t X0 = seg * kWave;
@@ -49,7 +54,7 @@ __global__ __launch_bounds__(256) void k_resize_down(
     const bool lane_active = x < ow;
     const uint32_t xo = lane_active ? x : X0;
     const int32_t hl = lxt[xo] - cmin;
-    // the lane's horizontal weights, zero beyond its window (HT >= the widest window, host-checked); an adding of
+    // the lane's horizontal weights, zero beyond its window (HT >= the widest window, host-checked); adding
     // +-0 leaves every sum as it is, so the fixed trip count does not change a bit
     float hw[HT];
     {
@@ -69,32 +74,23 @@ __global__ __launch_bounds__(256) void k_resize_down(
 #pragma unroll
     for (int m = 0; m < VC; ++m) col[m] = umin((uint32_t)cmin + threadIdx.x + kWave * m, iw - 1);
     auto load_row = [&](int32_t r, uint32_t (&raw)[VC]) {
-        const uint32_t *row = base + (size_t)r * iw;
+        const uint32_t *row = base + (size_t)umin((uint32_t)r, ih - 1) * iw; // pseudo-rows: any finite pixels
 #pragma unroll
         for (int m = 0; m < VC; ++m) raw[m] = row[col[m]];
     };
+    typedef uint32_t u32x8 __attribute__((ext_vector_type(8)));
+    auto load_tab = [&](int32_t r) { return *reinterpret_cast<const u32x8 *>(rowtab + (size_t)r * 8); }; // wave-uniform
 
-    // slots: output row, first tap row, tap count, offset of the row's weights (wave-uniform -> scalar registers)
-    uint32_t sy[NS], sn[NS], so[NS];
-    int32_t sl[NS];
     float acc[NS][VC * 4];
-    auto open_slot = [&](int s, uint32_t y) {
-        sy[s] = y;
-        const uint32_t yc = umin(y, oh - 1);
-        sl[s] = lyt[yc];
-        sn[s] = y < y_end ? nyt[yc] : 0u; // past the block: never inside
-        so[s] = yc * stride;
-    };
 #pragma unroll
-    for (int s = 0; s < NS; ++s) {
-        open_slot(s, y_begin + s);
+    for (int s = 0; s < NS; ++s)
 #pragma unroll
         for (int k = 0; k < VC * 4; ++k) acc[s][k] = 0.0f;
-    }
-    const int32_t r_first = sl[0];
-    const int32_t r_last = lyt[y_end - 1] + (int32_t)nyt[y_end - 1] - 1;
+    const int32_t r_first = lyt[y_begin];
+    const int32_t r_last = done_row[y_end - 1];
     uint32_t raw_next[VC];
     load_row(r_first, raw_next);
+    u32x8 tab_next = load_tab(r_first);
 
     for (int32_t r = r_first; r <= r_last; ++r) {
         float p[VC * 4];
@@ -104,30 +100,25 @@ __global__ __launch_bounds__(256) void k_resize_down(
 #pragma unroll
             for (int c = 0; c < 4; ++c) p[m * 4 + c] = ch_f32(px, c);
         }
-        if (r < r_last) load_row(r + 1, raw_next); // one row ahead
-        // this row's weight in every slot (0 where the row is outside the slot's window): scalar work and NS
-        // independent scalar loads up front, then NS x VC x 4 FMAs with no branch in between
-        float w[NS];
-        bool last[NS];
-#pragma unroll
-        for (int s = 0; s < NS; ++s) {
-            const uint32_t k = (uint32_t)(r - sl[s]);
-            const bool inside = k < sn[s]; // wave-uniform (k wraps to a huge value above the window)
-            const float ws = wyt[so[s] + (inside ? k : 0u)];
-            w[s] = inside ? ws : 0.0f;
-            last[s] = inside && k + 1 == sn[s]; // (a closed slot has sn == 0 and is never inside)
+        const u32x8 tab = tab_next;
+        if (r < r_last) { // one row ahead
+            load_row(r + 1, raw_next);
+            tab_next = load_tab(r + 1);
         }
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
-            asm volatile("" : "+v"(w[s])); // VGPR copy: scalar operands halve the VALU issue rate
+            float w = __uint_as_float(tab[s]);
+            asm volatile("" : "+v"(w)); // VGPR copy: scalar operands halve the VALU issue rate
 #pragma unroll
-            for (int q = 0; q < VC * 4; ++q) acc[s][q] = mac<EXACT>(acc[s][q], p[q], w[s]);
+            for (int q = 0; q < VC * 4; ++q) acc[s][q] = mac<EXACT>(acc[s][q], p[q], w);
         }
-        // completed windows (one per input row in the interior; the rows cut by the bottom border end together):
-        // sums -> LDS row, horizontal pass, store; the slot restarts NS output rows further down
+        const uint32_t comp = tab[7];
+        if (comp == kNone) continue; // wave-uniform
+        // the completed window -> LDS row; clear the slot
+        const uint32_t y = comp & 0x0FFFFFFFu, slot = comp >> 28;
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
-            if (!last[s]) continue; // wave-uniform
+            if (slot != (uint32_t)s) continue;
 #pragma unroll
             for (int m = 0; m < VC; ++m) {
                 const int32_t ci = (int32_t)threadIdx.x + kWave * m;
@@ -135,27 +126,26 @@ __global__ __launch_bounds__(256) void k_resize_down(
 #pragma unroll
                 for (int c = 0; c < 4; ++c) acc[s][m * 4 + c] = 0.0f;
             }
-            const uint32_t y = sy[s];
-            open_slot(s, y + NS);
-            // A wave only ever reads the LDS row it wrote itself, and the LDS executes one wave's
-            // instructions in order: no workgroup barrier, just keep the compiler from reordering.
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            float h0 = 0.0f, h1 = 0.0f, h2 = 0.0f, h3 = 0.0f;
-#pragma unroll
-            for (int k = 0; k < HT; ++k) { // taps beyond the lane's window: weight 0 times a finite LDS value
-                const float4 v = s_v[hl + k];
-                h0 = mac<EXACT>(h0, v.x, hw[k]);
-                h1 = mac<EXACT>(h1, v.y, hw[k]);
-                h2 = mac<EXACT>(h2, v.z, hw[k]);
-                h3 = mac<EXACT>(h3, v.w, hw[k]);
-            }
-            if (lane_active)
-                dst[(size_t)y * ow] = pack_u8<EXACT>(h3, 3, pack_u8<EXACT>(h2, 2, pack_u8<EXACT>(h1, 1, pack_u8<EXACT>(h0, 0, 0u))));
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); // the next completed row overwrites s_v
-            __builtin_amdgcn_wave_barrier();
         }
+        if (y < y_begin) continue; // a window of the previous block: its first rows were not seen here
+        // A wave only ever reads the LDS row it wrote itself, and the LDS executes one wave's
+        // instructions in order: no workgroup barrier, just keep the compiler from reordering.
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        float h0 = 0.0f, h1 = 0.0f, h2 = 0.0f, h3 = 0.0f;
+#pragma unroll
+        for (int k = 0; k < HT; ++k) { // taps beyond the lane's window: weight 0 times a finite LDS value
+            const float4 v = s_v[hl + k];
+            h0 = mac<EXACT>(h0, v.x, hw[k]);
+            h1 = mac<EXACT>(h1, v.y, hw[k]);
+            h2 = mac<EXACT>(h2, v.z, hw[k]);
+            h3 = mac<EXACT>(h3, v.w, hw[k]);
+        }
+        if (lane_active)
+            dst[(size_t)y * ow] = pack_u8<EXACT>(h3, 3, pack_u8<EXACT>(h2, 2, pack_u8<EXACT>(h1, 1, pack_u8<EXACT>(h0, 0, 0u))));
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); // the next completed row overwrites s_v
+        __builtin_amdgcn_wave_barrier();
     }
 }
 
@@ -165,7 +155,7 @@ hipError_t launch_resize_down(const UpscaleLaunch &L, const DeviceTables &T, boo
 {
     const size_t ipx = (size_t)L.iw * L.ih, opx = (size_t)L.ow * L.oh;
     const uint32_t vc = cdiv(ncols_max, kWave);
-    if (vc < 1 || vc > 5 || max_taps_x > 32) return hipErrorInvalidValue;
+    if (vc < 1 || vc > 5 || max_taps_x > 32 || !T.lz_down_rows || !T.lz_down_done) return hipErrorInvalidValue;
     const bool wide = max_taps_x > 16; // horizontal weights per lane: 16 or 32 registers
     const size_t lds = (size_t)4 * (ncols_max + kDownSlack) * sizeof(float4);
     return for_frame_chunks(L, [&](const uint8_t *in, uint8_t *out, uint32_t n) {
@@ -177,7 +167,8 @@ hipError_t launch_resize_down(const UpscaleLaunch &L, const DeviceTables &T, boo
         auto *o32 = reinterpret_cast<uint32_t *>(out);
 #define NUS_RD(E, C, H)                                                                                                     \
     hipLaunchKernelGGL((k_resize_down<E, C, H>), grid, block, lds, L.stream, i32, o32, T.lz_lx, T.lz_nx, T.lz_wx, T.lz_ly, \
-                       T.lz_ny, T.lz_wy, T.lz_stride, L.iw, L.ow, L.oh, (uint32_t)rpb, ncols_max, ipx, opx, L.in_sel)
+                       T.lz_down_rows, T.lz_down_done, T.lz_stride, L.iw, L.ih, L.ow, L.oh, (uint32_t)rpb, ncols_max, ipx,  \
+                       opx, L.in_sel)
 #define NUS_RD2(E, H)                        \
     switch (vc) {                            \
     case 1: NUS_RD(E, 1, H); break;          \

@@ -21,6 +21,9 @@ struct DeviceTables {
     const uint32_t *lz_nx = nullptr, *lz_ny = nullptr;
     const float *lz_wx = nullptr, *lz_wy = nullptr;
     uint32_t lz_stride = 0;
+    // down-scaling stream kernel: per input row 7 slot weights + completion word, and the completing row per output row
+    const uint32_t *lz_down_rows = nullptr;
+    const int32_t *lz_down_done = nullptr;
     // lanczos x2 fast path: per-output-row weights in the 6-tap phase frame [oh][6]
     const float *lz_wy6 = nullptr;
     float lz_wxe[6] = {0}, lz_wxo[6] = {0}; // interior horizontal weights, even / odd outputs
@@ -96,8 +99,8 @@ hipError_t launch_resize_rows(const UpscaleLaunch &L, const DeviceTables &T, boo
 // outputs_per_lane: 4 (segments of 256 output columns) or 2 (segments of 128); ncols_max and union_taps are for that width.
 hipError_t launch_resize_win(const UpscaleLaunch &L, const DeviceTables &T, bool exact, uint32_t ncols_max,
                              uint32_t union_taps, uint32_t outputs_per_lane);
-// Down-scaling variant (nus_k_resize_down.hip): ly[y+7] beyond the end of window y (so 7 accumulator
-// slots suffice), ncols_max = widest footprint of a 64-column output segment <= 320.
+// Down-scaling variant (nus_k_resize_down.hip): needs T.lz_down_rows / lz_down_done (build_down_stream_tables
+// succeeded: 7 accumulator slots suffice), ncols_max = widest footprint of a 64-column output segment <= 320.
 // max_taps_x: widest horizontal window (<= 32).
 hipError_t launch_resize_down(const UpscaleLaunch &L, const DeviceTables &T, bool exact, uint32_t ncols_max,
                               uint32_t max_taps_x);

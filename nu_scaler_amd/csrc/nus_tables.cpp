@@ -243,6 +243,36 @@ bool get_axis(const uint8_t *&p, const uint8_t *end, AxisTables &t)
 
 } // namespace
 
+bool build_down_stream_tables(const AxisTables &t, std::vector<uint32_t> &rows, std::vector<int32_t> &done_row)
+{
+    if (t.lz_max_taps <= 0 || t.out_n == 0 || t.out_n >= (1u << 28)) return false;
+    const uint32_t n = t.in_n, extra_cap = 2 * kDownSlots;
+    rows.assign((size_t)(n + extra_cap) * 8, 0u);
+    for (size_t r = 0; r < (size_t)n + extra_cap; ++r) rows[r * 8 + 7] = kDownNone;
+    done_row.assign(t.out_n, -1);
+    std::vector<int64_t> slot_free_from(kDownSlots, 0); // first input row a new window may occupy the slot from
+    uint32_t extra = 0;
+    for (uint32_t y = 0; y < t.out_n; ++y) {
+        const uint32_t slot = y % kDownSlots;
+        const int64_t left = t.lz_left[y], taps = t.lz_ntaps[y], end = left + taps - 1;
+        if (taps <= 0 || left < slot_free_from[slot] || end >= (int64_t)n) return false;
+        slot_free_from[slot] = end + 1;
+        for (int64_t k = 0; k < taps; ++k) {
+            const float w = t.lz_w[(size_t)y * kResizeMaxTaps + (size_t)k];
+            memcpy(&rows[(size_t)(left + k) * 8 + slot], &w, sizeof(w));
+        }
+        size_t at = (size_t)end;
+        if (rows[at * 8 + 7] != kDownNone) { // a second window ending on this row: only the far border does that
+            if (end != (int64_t)n - 1 || extra >= extra_cap) return false;
+            at = (size_t)n + extra++;
+        }
+        rows[at * 8 + 7] = (slot << 28) | y;
+        done_row[y] = (int32_t)at;
+    }
+    rows.resize((size_t)(n + extra) * 8);
+    return true;
+}
+
 std::vector<uint8_t> serialize_tables(const AxisTables &x, const AxisTables &y)
 {
     std::vector<uint8_t> b;

@@ -62,6 +62,15 @@ bool lanczos_xs_phase_frame(const AxisTables &t, uint32_t S, std::vector<float> 
 // True when every interior output (k in [4, in_n - 5]) has the weights of output S * 8 + p of its phase.
 bool lanczos_xs_interior_uniform(const AxisTables &t, uint32_t S, const std::vector<float> &w6);
 
+// Down-scaling stream tables for k_resize_down (7 accumulator slots, slot of output y = y % 7).
+// rows: (in_n + extra) x 8 words -- per input row the f32 weight it carries in each slot (0 where the row is
+// outside the window of the output that owns the slot), then one completion word: 0xFFFFFFFF, or (slot << 28 | y)
+// of the output whose window ends on this row.  Windows cut by the far border end together on the last input
+// row; all but the first get a pseudo-row of zero weights behind it, so every row completes at most one output.
+// done_row[y]: the (pseudo-)row on which y completes.  False if some window would need an occupied slot.
+constexpr uint32_t kDownSlots = 7, kDownNone = 0xFFFFFFFFu;
+bool build_down_stream_tables(const AxisTables &t, std::vector<uint32_t> &rows, std::vector<int32_t> &done_row);
+
 // Serialisation for the multi-GPU LUT broadcast.
 std::vector<uint8_t> serialize_tables(const AxisTables &x, const AxisTables &y);
 bool deserialize_tables(const uint8_t *buf, size_t len, AxisTables &x, AxisTables &y, std::string &err);

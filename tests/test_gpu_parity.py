@@ -132,7 +132,8 @@ def test_bicubic_and_triangle_resize(nsc, oracle_mod, alg, filt, dims):
     out, u = _up(nsc, alg, img, ow, oh)
     x2 = (ow, oh) == (2 * w, 2 * h) and w % 4 == 0 and w >= 16 and h >= 16
     upscale_by4 = ow % 4 == 0 and ow >= w and oh >= h
-    assert u.kernel_variant == ("lanczos3_x2_regwin" if x2 else ("resize_regwin_lds" if upscale_by4 else "resize_rows_lds"))
+    assert u.kernel_variant == ("lanczos3_x2_regwin" if x2 else ("resize_regwin_lds" if upscale_by4 else
+                                                                 ("resize_down_stream" if oh < h else "resize_rows_lds")))
     assert _maxdiff(out, want) <= 1
     out_e, _ = _up(nsc, alg, img, ow, oh, lanczos_mode="exact")
     assert np.array_equal(out_e, want)
