@@ -195,7 +195,7 @@ struct HsCell {
 };
 
 // T x T output tile, K Jacobi steps per launch (temporal blocking).  A thread owns a vertical run
-// of N cells in one column of the (T+2K)^2 tile (R columns x 256/R runs): the 3 x (N+2) flow values
+// of N cells in one column of the (T+2K)^2 tile (R columns x NT/R runs): the 3 x (N+2) flow values
 // its cells' neighbourhoods cover are read from LDS once per step and shared between the N cells
 // (3(N+2)/N reads per cell instead of 9), lanes of a wave walk consecutive columns (consecutive
 // 8-byte LDS words), and nothing in a step is conditional except the final write, so the N sum
@@ -203,12 +203,12 @@ struct HsCell {
 // registers and only the two ping-pong flow tiles are in LDS.  Step j may write the cells whose
 // distance to the tile edge ("ring") is >= j -- their 3x3 neighbourhood was valid after step j-1;
 // at the image border neighbours clamp inwards exactly as in k_horn_schunck.
-template <int T, int K>
-__global__ __launch_bounds__(256) void k_hs_tiled(const float *__restrict__ coef, float lambda,
+template <int T, int K, int NT>
+__global__ __launch_bounds__(NT) void k_hs_tiled(const float *__restrict__ coef, float lambda,
                                                   const float2 *__restrict__ fin, float2 *__restrict__ fout, int w, int h)
 {
-    constexpr int R = T + 2 * K, RUNS = 256 / R, N = (R + RUNS - 1) / RUNS;
-    static_assert(RUNS >= 1 && RUNS * N >= R, "tile does not fit 256 threads");
+    constexpr int R = T + 2 * K, RUNS = NT / R, N = (R + RUNS - 1) / RUNS;
+    static_assert(RUNS >= 1 && RUNS * N >= R, "tile does not fit the block");
     __shared__ float2 s_flow[2][R * R];
     const int tid = threadIdx.x;
     const int run = tid / R, lx = tid - run * R, ly0 = run * N;
@@ -374,14 +374,35 @@ hipError_t launch_hs_prepare(const float *i1, const float *i2, bool luminance_pl
 
 // `iterations` Jacobi steps from *flow_a (from zero flow without reading it if zero_start),
 // ping-ponging with *flow_b; on return *flow_a holds the result (the pointers are swapped as
-// needed; with final_out the last launch writes there and *flow_a == final_out).  Steps are grouped 8 / 4 / 2 / 1 per launch; small
-// levels use 16x16 tiles so that the grid still covers the 256 CUs.
+// needed; with final_out the last launch writes there and *flow_a == final_out).  Steps are split evenly
+// over ceil(iterations / 8) launches.  Tile shape by level size (tiles of 32x32 the level has):
+//   >= 1024 (1080p): 32-wide tiles, 256 threads (7 cells per thread, 5 tiles per CU by LDS);
+//   mid  (960x540):  NUS_HS_MID_T-wide tiles with NUS_HS_MID_THREADS threads;
+//   < 256 (480x270): 16-wide tiles, so that the grid still covers the 256 CUs, with 1024 threads of one cell
+//                    each: two tiles per CU leave the step's LDS round trip exposed unless the waves are many.
+#ifndef NUS_HS_BIG_THREADS
+#define NUS_HS_BIG_THREADS 256
+#endif
+#ifndef NUS_HS_MID_T
+#define NUS_HS_MID_T 32
+#endif
+#ifndef NUS_HS_MID_THREADS
+#define NUS_HS_MID_THREADS 1024
+#endif
+#ifndef NUS_HS_SMALL_T
+#define NUS_HS_SMALL_T 16
+#endif
+#ifndef NUS_HS_SMALL_THREADS
+#define NUS_HS_SMALL_THREADS 1024
+#endif
 hipError_t launch_hs_iterate(const float *coef, float lambda, float **flow_a, float **flow_b, uint32_t w, uint32_t h,
                              uint32_t iterations, bool zero_start, float *final_out, hipStream_t stream)
 {
-    const bool small = (uint64_t)cdiv(w, 32) * cdiv(h, 32) < 1024;
-    const uint32_t T = small ? 16 : 32;
-    const dim3 block(256), grid(cdiv(w, T), cdiv(h, T));
+    const uint64_t tiles32 = (uint64_t)cdiv(w, 32) * cdiv(h, 32);
+    const int cls = tiles32 >= 1024 ? 2 : (tiles32 >= 256 ? 1 : 0);
+    const uint32_t T = cls == 2 ? 32 : (cls == 1 ? NUS_HS_MID_T : NUS_HS_SMALL_T);
+    const uint32_t NT = cls == 2 ? NUS_HS_BIG_THREADS : (cls == 1 ? NUS_HS_MID_THREADS : NUS_HS_SMALL_THREADS);
+    const dim3 block(NT), grid(cdiv(w, T), cdiv(h, T));
     uint32_t launches = (iterations + 7) / 8;
     while (iterations > 0) {
         const uint32_t k = (iterations + launches - 1) / launches; // even split, 1..8 steps per launch
@@ -389,17 +410,18 @@ hipError_t launch_hs_iterate(const float *coef, float lambda, float **flow_a, fl
         auto fi = zero_start ? nullptr : reinterpret_cast<const float2 *>(*flow_a);
         auto fo = reinterpret_cast<float2 *>(*flow_b);
         zero_start = false;
-#define NUS_HS(KK)                                                                                              \
-    case KK:                                                                                                    \
-        if (small)                                                                                              \
-            hipLaunchKernelGGL((k_hs_tiled<16, KK>), grid, block, 0, stream, coef, lambda, fi, fo, (int)w, (int)h);   \
-        else                                                                                                    \
-            hipLaunchKernelGGL((k_hs_tiled<32, KK>), grid, block, 0, stream, coef, lambda, fi, fo, (int)w, (int)h);   \
+#define NUS_HS_L(TT, KK, TH) hipLaunchKernelGGL((k_hs_tiled<TT, KK, TH>), grid, block, 0, stream, coef, lambda, fi, fo, (int)w, (int)h)
+#define NUS_HS(KK)                                                    \
+    case KK:                                                          \
+        if (cls == 2) NUS_HS_L(32, KK, NUS_HS_BIG_THREADS);           \
+        else if (cls == 1) NUS_HS_L(NUS_HS_MID_T, KK, NUS_HS_MID_THREADS); \
+        else NUS_HS_L(NUS_HS_SMALL_T, KK, NUS_HS_SMALL_THREADS);      \
         break;
         switch (k) {
             NUS_HS(1) NUS_HS(2) NUS_HS(3) NUS_HS(4) NUS_HS(5) NUS_HS(6) NUS_HS(7) NUS_HS(8)
         }
 #undef NUS_HS
+#undef NUS_HS_L
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
         iterations -= k;

@@ -129,9 +129,11 @@ def test_flow_estimate_iteration_edge_cases(nsc, oracle_mod, levels, coarse, ref
 
 
 @pytest.mark.gpu
-def test_flow_estimate_large_tiles(nsc, oracle_mod):
-    """Big enough (>= 1024 tiles of 32x32) for the 32-wide tile kernel at level 0, ragged in both directions."""
-    w, h = 1037, 1029
+@pytest.mark.parametrize("size", [(1037, 1029), (613, 517)])
+def test_flow_estimate_large_tiles(nsc, oracle_mod, size):
+    """Level 0 big enough for the 32-wide tile kernel, ragged in both directions: >= 1024 tiles (256 threads per
+    tile) and 256..1023 tiles (1024 threads per tile); level 1 takes the next smaller class each time."""
+    w, h = size
     a, b = oracle_mod.gen_noise(w, h, 11), oracle_mod.gen_noise(w, h, 12)
     fe = nsc.FlowEstimator(levels=2, coarse_iterations=4, refine_iterations=5)
     assert np.array_equal(fe.estimate(a, b, w, h), oracle_mod.flow_estimate(a, b, 2, 4, 5, fe.lambda_))
