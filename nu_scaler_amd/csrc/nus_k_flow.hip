@@ -102,17 +102,22 @@ __global__ __launch_bounds__(256) void k_horn_schunck(const float4 *__restrict__
 // goes through exactly the arithmetic of k_blur<true>, k_blur<false> and k_downsample, so the
 // result is bit-identical to the three separate kernels while HBM sees the input once.
 constexpr int kPyrTW = 64, kPyrTH = 16;
+#ifndef NUS_PYR_THREADS
+#define NUS_PYR_THREADS 512
+#endif
+constexpr int kPyrThreads = NUS_PYR_THREADS; // 3 tiles per CU by LDS: twice the waves hide the LDS round trips of its phases
 
 template <bool U8IN>
-__global__ __launch_bounds__(256) void k_pyramid_level(const void *__restrict__ in, float *__restrict__ level_lum,
-                                                       float4 *__restrict__ next, int w, int h)
+__global__ __launch_bounds__(kPyrThreads) void k_pyramid_level(const void *__restrict__ in, float *__restrict__ level_lum,
+                                                               float4 *__restrict__ next, int w, int h)
 {
     __shared__ float4 s_a[(kPyrTH + 4) * (kPyrTW + 4)]; // input region; later the V-blurred tile
     __shared__ float4 s_h[(kPyrTH + 4) * kPyrTW];        // H-blurred rows
-    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6; // 64 x 4
+    constexpr int NW = kPyrThreads / 64;                  // waves per tile: each phase deals its rows to them
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     const int bx = blockIdx.x * kPyrTW, by = blockIdx.y * kPyrTH;
     // stage input rows by-2 .. by+17, columns bx-2 .. bx+65, coordinates clamped into the image
-    for (int r = ty; r < kPyrTH + 4; r += 4) {
+    for (int r = ty; r < kPyrTH + 4; r += NW) {
         const int gy = clampi(by - 2 + r, 0, h - 1);
         for (int c = tx; c < kPyrTW + 4; c += 64) {
             const int gx = clampi(bx - 2 + c, 0, w - 1);
@@ -124,14 +129,14 @@ __global__ __launch_bounds__(256) void k_pyramid_level(const void *__restrict__ 
     // horizontal pass for the 20 staged rows.  The shader clamps x+-k into the image; the staged
     // columns already hold clamp(bx-2+c), so column (tx+2)+k is the clamped neighbour as long as
     // the output column itself is inside the image.
-    for (int r = ty; r < kPyrTH + 4; r += 4) {
+    for (int r = ty; r < kPyrTH + 4; r += NW) {
         const float4 *row = s_a + r * (kPyrTW + 4) + tx;
         s_h[r * kPyrTW + tx] = blur5(row[0], row[1], row[2], row[3], row[4]);
     }
     __syncthreads();
     // vertical pass -> blurred level; keep the tile in LDS (s_a is free now) for the downsample
     const int gx = bx + tx;
-    for (int r = ty; r < kPyrTH; r += 4) {
+    for (int r = ty; r < kPyrTH; r += NW) {
         const float4 v = blur5(s_h[r * kPyrTW + tx], s_h[(r + 1) * kPyrTW + tx], s_h[(r + 2) * kPyrTW + tx],
                                s_h[(r + 3) * kPyrTW + tx], s_h[(r + 4) * kPyrTW + tx]);
         s_a[r * kPyrTW + tx] = v;
@@ -144,7 +149,7 @@ __global__ __launch_bounds__(256) void k_pyramid_level(const void *__restrict__ 
     const int ow = (w + 1) / 2, oh = (h + 1) / 2;
     const int dxl = threadIdx.x & 31, dyl = threadIdx.x >> 5; // 32 x 8 outputs per tile
     const int ox = bx / 2 + dxl, oy = by / 2 + dyl;
-    if (ox < ow && oy < oh) {
+    if (threadIdx.x < 256 && ox < ow && oy < oh) {
         const int x0 = 2 * dxl, y0 = 2 * dyl;
         const int x1 = min(bx + x0 + 1, w - 1) - bx, y1 = min(by + y0 + 1, h - 1) - by;
         const float4 c00 = s_a[y0 * kPyrTW + x0], c10 = s_a[y0 * kPyrTW + x1];
@@ -349,7 +354,7 @@ hipError_t launch_horn_schunck(const float *i1, const float *i2, const float *fl
 hipError_t launch_pyramid_level(const void *in, bool u8_input, float *level_lum, float *next, uint32_t w, uint32_t h,
                                 hipStream_t stream)
 {
-    const dim3 block(256), grid(cdiv(w, kPyrTW), cdiv(h, kPyrTH));
+    const dim3 block(kPyrThreads), grid(cdiv(w, kPyrTW), cdiv(h, kPyrTH));
     if (u8_input)
         hipLaunchKernelGGL(k_pyramid_level<true>, grid, block, 0, stream, in, level_lum,
                            reinterpret_cast<float4 *>(next), (int)w, (int)h);
