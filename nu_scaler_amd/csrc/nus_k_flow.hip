@@ -115,7 +115,9 @@ __global__ __launch_bounds__(kPyrThreads) void k_pyramid_level(const void *__res
     __shared__ float4 s_h[(kPyrTH + 4) * kPyrTW];        // H-blurred rows
     constexpr int NW = kPyrThreads / 64;                  // waves per tile: each phase deals its rows to them
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-    const int bx = blockIdx.x * kPyrTW, by = blockIdx.y * kPyrTH;
+    // each XCD takes a contiguous band of tiles: the 2-pixel halos neighbouring tiles share come out of its L2
+    const uint32_t vid = xcd_contiguous_id(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
+    const int bx = (int)(vid % gridDim.x) * kPyrTW, by = (int)(vid / gridDim.x) * kPyrTH;
     // stage input rows by-2 .. by+17, columns bx-2 .. bx+65, coordinates clamped into the image
     for (int r = ty; r < kPyrTH + 4; r += NW) {
         const int gy = clampi(by - 2 + r, 0, h - 1);
@@ -217,7 +219,10 @@ __global__ __launch_bounds__(NT) void k_hs_tiled(const float *__restrict__ coef,
     __shared__ float2 s_flow[2][R * R];
     const int tid = threadIdx.x;
     const int run = tid / R, lx = tid - run * R, ly0 = run * N;
-    const int x0 = blockIdx.x * T - K, y0 = blockIdx.y * T - K; // image coords of LDS cell (0,0)
+    // each XCD works through a contiguous band of tiles, so the halo cells neighbouring tiles both load come out of its L2
+    const uint32_t vid = xcd_contiguous_id(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
+    const int tile_x = (int)(vid % gridDim.x), tile_y = (int)(vid / gridDim.x);
+    const int x0 = tile_x * T - K, y0 = tile_y * T - K; // image coords of LDS cell (0,0)
     // tiles whose loaded region lies strictly inside the image need no clamping at all
     const bool border = x0 < 0 || y0 < 0 || x0 + R > w || y0 + R > h; // block-uniform
     HsCell cell[N];
