@@ -1,6 +1,8 @@
 // nus_host.cpp -- host classes above the gfx950 kernels.  See nus_host.hpp.
 #include "nus_host.hpp"
 
+#include "nus_copy.hpp"
+
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -671,7 +673,7 @@ int HipUpscaler::upscale_batch(const uint8_t *const *ins, const size_t *in_lens,
         int k = 0;
         for (size_t off = 0; off < out_bytes; off += chunk, ++k) {
             NUS_HIP(hipEventSynchronize(S.chunk_done[k]));
-            memcpy(outs[i] + off, S.h_out + off, out_bytes - off < chunk ? out_bytes - off : chunk);
+            parallel_copy(outs[i] + off, S.h_out + off, out_bytes - off < chunk ? out_bytes - off : chunk);
         }
         return kOk;
     };
@@ -683,7 +685,7 @@ int HipUpscaler::upscale_batch(const uint8_t *const *ins, const size_t *in_lens,
         Slot &S = slots_[i % nslots];
         const uint8_t *src = ins[i];
         if (!is_pinned_host(src)) {
-            memcpy(S.h_in, src, in_bytes);
+            parallel_copy(S.h_in, src, in_bytes);
             src = S.h_in;
         }
         NUS_HIP(hipMemcpyAsync(S.d_in, src, in_bytes, hipMemcpyHostToDevice, S.stream));
@@ -884,12 +886,12 @@ int HipFrameInterpolator::interpolate(const uint8_t *a, size_t a_len, const uint
     uint8_t *ha = h_stage_, *hb = h_stage_ + cap_bytes_, *ho = h_stage_ + 2 * cap_bytes_;
     // stage A, start its DMA, stage B meanwhile (the reference uploads both synchronously:
     // wgpu_interpolator.rs:253-321)
-    memcpy(ha, a, expected);
+    parallel_copy(ha, a, expected);
     NUS_HIP(hipMemcpyAsync(d_a_, ha, expected, hipMemcpyHostToDevice, stream_));
-    memcpy(hb, b, expected);
+    parallel_copy(hb, b, expected);
     NUS_HIP(hipMemcpyAsync(d_b_, hb, expected, hipMemcpyHostToDevice, stream_));
     if (flow) {
-        memcpy(h_flow_, flow, expected * 2);
+        parallel_copy(h_flow_, flow, expected * 2);
         NUS_HIP(hipMemcpyAsync(d_flow_, h_flow_, expected * 2, hipMemcpyHostToDevice, stream_));
     }
     WarpLaunch L;
@@ -915,9 +917,9 @@ int HipFrameInterpolator::interpolate(const uint8_t *a, size_t a_len, const uint
     NUS_HIP(hipEventRecord(half_done_, stream_));
     if (first < expected) NUS_HIP(hipMemcpyAsync(ho + first, d_out_ + first, expected - first, hipMemcpyDeviceToHost, stream_));
     NUS_HIP(hipEventSynchronize(half_done_));
-    memcpy(out, ho, first);
+    parallel_copy(out, ho, first);
     NUS_HIP(hipStreamSynchronize(stream_));
-    if (first < expected) memcpy(out + first, ho + first, expected - first);
+    if (first < expected) parallel_copy(out + first, ho + first, expected - first);
     float ms = 0.0f;
     if (hipEventElapsedTime(&ms, k_begin_, k_end_) == hipSuccess) {
         have_ms_ = true;

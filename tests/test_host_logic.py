@@ -281,6 +281,29 @@ def test_header_is_plain_c_and_links(nsc, tmp_path):
     assert run.returncode == 0 and "abi_check ok" in run.stdout, run.stdout + run.stderr
 
 
+def test_copy_pool_stress(tmp_path):
+    """The host path's helper threads for the staging copies (csrc/nus_copy.cpp): random sizes and alignments from
+    four threads at once, with the pool's default, no and seven workers (tests/c_abi/copy_pool_stress.cpp)."""
+    import shutil
+    import subprocess
+    if shutil.which("g++") is None:
+        pytest.skip("g++ not available")
+    src_dir = os.path.join(ROOT, "nu_scaler_amd", "csrc")
+    exe = str(tmp_path / "copy_pool_stress")
+    cmd = ["g++", "-O2", "-std=c++17", "-pthread", "-Wall", "-Wextra", "-I", src_dir,
+           os.path.join(ROOT, "tests", "c_abi", "copy_pool_stress.cpp"), os.path.join(src_dir, "nus_copy.cpp"), "-o", exe]
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    assert res.returncode == 0, res.stderr
+    for threads in (None, "0", "7"):
+        env = dict(os.environ)
+        if threads is not None:
+            env["NUS_COPY_THREADS"] = threads
+        run = subprocess.run([exe], capture_output=True, text=True, env=env, timeout=120)
+        assert run.returncode == 0 and "bad 0" in run.stdout, run.stdout + run.stderr
+        if threads is not None:
+            assert f"workers {threads} " in run.stdout
+
+
 def test_vram_stats_surface(nsc):
     """PyAdvancedWgpuUpscaler.get_vram_stats / get_vram_usage_percent (lib.rs:539-584): present; without a GPU
     they raise the reference's RuntimeError text, with one they report hipMemGetInfo."""
