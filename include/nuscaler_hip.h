@@ -20,6 +20,9 @@
  * calls upscale(&self) from rayon threads, upscale/mod.rs:619-624).
  * There is no CPU fallback: without a usable HIP device the compute entry points
  * fail with NUS_ERR_NO_DEVICE.
+ * Host entry points that take pageable buffers copy through pinned staging memory; copies of
+ * 1 MiB and more are split over a few process-wide helper threads started on first use
+ * (environment: NUS_COPY_THREADS=n, 0 = copy on the calling thread only).
  */
 #ifndef NUSCALER_HIP_H
 #define NUSCALER_HIP_H
