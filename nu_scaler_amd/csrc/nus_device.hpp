@@ -133,6 +133,18 @@ __device__ __forceinline__ uint32_t xcd_contiguous_id(uint32_t orig, uint32_t nw
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + orig / 8;
 }
 
+// The same for a 3-D grid (x fastest, as the dispatcher walks it): the (x, y, z) this workgroup should work on.
+struct GridPos {
+    uint32_t x, y, z;
+};
+__device__ __forceinline__ GridPos xcd_contiguous_pos()
+{
+    const uint32_t lin = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    const uint32_t vid = xcd_contiguous_id(lin, gridDim.x * gridDim.y * gridDim.z);
+    const uint32_t xy = gridDim.x * gridDim.y, r = vid % xy;
+    return GridPos{r % gridDim.x, r / gridDim.x, vid / xy};
+}
+
 constexpr uint32_t kMaxGridZ = 65535;
 
 inline uint32_t cdiv(uint32_t a, uint32_t b) { return (a + b - 1) / b; }

@@ -43,7 +43,8 @@ __global__ __launch_bounds__(256) void k_resize_down(
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int NS = kSlots;
     float4 *s_v = reinterpret_cast<float4 *>(smem) + (size_t)threadIdx.y * (ncols_max + kDownSlack);
-    const uint32_t seg = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + threadIdx.y);
+    const GridPos g = xcd_contiguous_pos(); // row blocks that share their window-fill rows behind one L2
+    const uint32_t seg = __builtin_amdgcn_readfirstlane(g.x * 4 + threadIdx.y);
     const uint32_t X0 = seg * kWave;
     if (X0 >= ow) return; // whole wave; no workgroup barriers below
     const uint32_t Xlast = umin(X0 + kWave, ow) - 1;
@@ -63,10 +64,10 @@ __global__ __launch_bounds__(256) void k_resize_down(
 #pragma unroll
         for (int k = 0; k < HT; ++k) hw[k] = (uint32_t)k < hn ? wx[(uint32_t)k < stride ? k : 0] : 0.0f;
     }
-    const uint32_t y_begin = blockIdx.y * rows_per_block;
+    const uint32_t y_begin = g.y * rows_per_block;
     const uint32_t y_end = umin(y_begin + rows_per_block, oh);
-    const uint32_t *base = in + (size_t)blockIdx.z * in_frame_px;
-    uint32_t *dst = out + (size_t)blockIdx.z * out_frame_px + x;
+    const uint32_t *base = in + (size_t)g.z * in_frame_px;
+    uint32_t *dst = out + (size_t)g.z * out_frame_px + x;
 
     // this lane's VC input columns: lane, lane + 64, ...: each load of the wave is one contiguous 256 B and
     // its LDS writes are 64 consecutive float4; clamped into the row (columns past the footprint are never read back)

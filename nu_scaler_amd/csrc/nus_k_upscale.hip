@@ -498,7 +498,8 @@ __global__ __launch_bounds__(256) void k_resize_win(
     static_assert(N == 4 || N == 2, "outputs per lane");
     constexpr uint32_t SEGW = kWave * N;
     float4 *s_v = reinterpret_cast<float4 *>(smem) + (size_t)threadIdx.y * (ncols_max + kResizeSlack);
-    const uint32_t seg = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + threadIdx.y);
+    const GridPos g = xcd_contiguous_pos(); // row blocks that share their window-fill rows behind one L2
+    const uint32_t seg = __builtin_amdgcn_readfirstlane(g.x * 4 + threadIdx.y);
     const uint32_t X0 = seg * SEGW;
     if (X0 >= ow) return; // whole wave; no workgroup barriers below
     const uint32_t Xlast = umin(X0 + SEGW, ow) - 1;
@@ -506,10 +507,10 @@ __global__ __launch_bounds__(256) void k_resize_win(
     const int32_t ncols = lxt[Xlast] + (int32_t)nxt[Xlast] - cmin; // <= 64 * VC (host-checked)
     const uint32_t x = X0 + threadIdx.x * N;
     const bool lane_active = x < ow;
-    const uint32_t y_begin = blockIdx.y * rows_per_block;
+    const uint32_t y_begin = g.y * rows_per_block;
     const uint32_t y_end = umin(y_begin + rows_per_block, oh);
-    const uint32_t *base = in + (size_t)blockIdx.z * in_frame_px;
-    uint32_t *dst = out + (size_t)blockIdx.z * out_frame_px + x;
+    const uint32_t *base = in + (size_t)g.z * in_frame_px;
+    uint32_t *dst = out + (size_t)g.z * out_frame_px + x;
 
     if (threadIdx.x < kResizeSlack) s_v[ncols + threadIdx.x] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     // horizontal windows of this lane's 4 outputs
