@@ -9,6 +9,8 @@
 #include <thread>
 #include <vector>
 
+#include <unistd.h>
+
 namespace nus {
 
 namespace {
@@ -28,11 +30,14 @@ struct Job {
 
 class CopyPool {
 public:
+    // Never destroyed: a forked child inherits the mutex / condition variables with the parent's waiters recorded in
+    // them, and destroying those would block for ever.  The owning process stops and joins its workers in shutdown().
     static CopyPool &instance()
     {
-        static CopyPool pool;
-        return pool;
+        static CopyPool *pool = new CopyPool;
+        return *pool;
     }
+    static void shutdown_at_unload() { instance().shutdown(); }
 
     int workers() const { return (int)threads_.size(); }
 
@@ -69,11 +74,14 @@ private:
         const unsigned hw = std::thread::hardware_concurrency();
         if (hw > 0 && (unsigned)(n < 0 ? 0 : n) + 1 > hw) n = (int)hw - 1;
         if (n > 8) n = 8;
+        owner_ = getpid();
         for (int i = 0; i < n; ++i) threads_.emplace_back([this] { worker(); });
+        if (n > 0) atexit(&CopyPool::shutdown_at_unload); // library unload / process exit: no thread may outlive the code
     }
 
-    ~CopyPool()
+    void shutdown()
     {
+        if (getpid() != owner_) return; // the workers did not survive a fork: nothing to stop
         {
             std::lock_guard<std::mutex> lk(m_);
             stop_ = true;
@@ -81,6 +89,7 @@ private:
         cv_work_.notify_all();
         for (std::thread &t : threads_)
             if (t.joinable()) t.join();
+        threads_.clear();
     }
 
     void run(Job &job)
@@ -122,6 +131,7 @@ private:
     unsigned long long generation_ = 0;
     bool stop_ = false;
     Job *job_ = nullptr;
+    pid_t owner_ = 0;
 };
 
 } // namespace

@@ -1,5 +1,6 @@
 // Host-only stress test of nu_scaler_amd/csrc/nus_copy.cpp (built and run by tests/test_host_logic.py):
-// copies of random sizes and alignments from several threads at once, every result compared with the source.
+// copies of random sizes and alignments from several threads at once, every result compared with the source;
+// then the same from a forked child.
 #include "nus_copy.hpp"
 
 #include <atomic>
@@ -8,6 +9,9 @@
 #include <cstring>
 #include <thread>
 #include <vector>
+
+#include <sys/wait.h>
+#include <unistd.h>
 
 static uint64_t splitmix(uint64_t &s)
 {
@@ -41,6 +45,15 @@ int main()
     std::vector<std::thread> threads;
     for (int t = 0; t < 4; ++t) threads.emplace_back(work, t);
     for (auto &t : threads) t.join();
+    // a forked child has the pool's state but none of its threads: it must still copy (alone) and exit cleanly
+    const pid_t pid = fork();
+    if (pid == 0) {
+        std::vector<uint8_t> a((size_t)5 << 20, 7), b((size_t)5 << 20, 0);
+        nus::parallel_copy(b.data(), a.data(), a.size());
+        return memcmp(a.data(), b.data(), a.size()) == 0 ? 0 : 3;
+    }
+    int status = 0;
+    if (pid < 0 || waitpid(pid, &status, 0) != pid || !WIFEXITED(status) || WEXITSTATUS(status) != 0) ++bad;
     printf("workers %d bad %d\n", nus::parallel_copy_workers(), bad.load());
     return bad.load() == 0 ? 0 : 1;
 }
