@@ -751,6 +751,39 @@ def test_resize_down_streaming_kernel(nsc, oracle_mod, alg, filt, dims):
     assert np.array_equal(got_f, ref_f) and _maxdiff(got_f, want) <= 1
 
 
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_resize_down_random_shapes(nsc, oracle_mod, seed):
+    """Random down-scaling shapes (ratios 1.02 .. 4.7 per axis, widths around the 64-column segment sizes, heights
+    around the row-block sizes) through the device batch entry point, whose frame count changes the rows per block;
+    EXACT mode, every frame against the oracle."""
+    import torch
+    rng = np.random.default_rng(900 + seed)
+    for case in range(14):
+        ow = int(rng.choice([rng.integers(1, 20), rng.integers(60, 70), rng.integers(125, 135), rng.integers(190, 260)]))
+        oh = int(rng.choice([rng.integers(1, 12), rng.integers(14, 20), rng.integers(30, 36), rng.integers(60, 140)]))
+        w = min(int(ow * rng.uniform(1.0, 4.7)) + int(rng.integers(0, 3)), 1200)
+        h = int(oh * rng.uniform(1.02, 4.7)) + 1
+        n = int(rng.choice([1, 2, 5]))
+        if (w * h) % 4 or (ow * oh) % 4:  # batched device frames must be multiples of 16 bytes
+            n = 1
+        alg, filt = [("lanczos3", 0), ("bicubic", 1), ("triangle", 2)][case % 3]
+        frames = np.stack([oracle_mod.gen_noise(w, h, 1000 * seed + 10 * case + k) for k in range(n)])
+        u = nsc.PyWgpuUpscaler("quality", alg, lanczos_mode="exact")
+        try:
+            u.initialize(w, h, ow, oh)
+        except RuntimeError as e:  # windows beyond 32 taps are refused by every resize kernel
+            assert "exceeds 32 taps" in str(e), (w, h, ow, oh, str(e))
+            continue
+        d_in = torch.from_numpy(frames).cuda()
+        d_out = torch.zeros((n, oh, ow, 4), dtype=torch.uint8, device="cuda")
+        u.upscale_device(d_in.data_ptr(), d_out.data_ptr(), n, torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        got = d_out.cpu().numpy()
+        for k in range(n):
+            want = oracle_mod.resize(frames[k], ow, oh, filt)
+            assert np.array_equal(got[k], want), ((w, h), (ow, oh), n, k, alg, u.kernel_variant, _maxdiff(got[k], want))
+
+
 def test_resize_down_4k_to_1080p_batch(nsc, oracle_mod):
     """The capture-resize case at full size, 3 frames through the device entry point; frame 0 against the oracle."""
     import torch
