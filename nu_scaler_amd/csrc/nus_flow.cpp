@@ -277,11 +277,11 @@ int HipFlowEstimator::solve(int slot_a, int slot_b, const Pyramid &g, uint32_t c
     // compute_coarse_flow starts from zero flow (:1136-1154): the tiled kernel takes that as a null input;
     // the last launch of the finest level writes the caller's buffer directly
     bool zero = true;
-    auto iterate = [&](uint32_t l, uint32_t iters) -> int {
+    auto iterate = [&](uint32_t l, uint32_t iters, bool prepared) -> int {
         const float *i1 = reinterpret_cast<const float *>(pa + g.offset[l]), *i2 = reinterpret_cast<const float *>(pb + g.offset[l]);
         if (iters == 0) return kOk;
         if (tiled_) {
-            NUS_HIP(launch_hs_prepare(i1, i2, true, coef, g.w[l], g.h[l], stream)); // tiled pyramids hold luminance planes
+            if (!prepared) NUS_HIP(launch_hs_prepare(i1, i2, true, coef, g.w[l], g.h[l], stream)); // tiled pyramids hold luminance planes
             NUS_HIP(launch_hs_iterate(coef, lambda, &f0, &f1, g.w[l], g.h[l], iters, zero,
                                       l == 0 ? static_cast<float *>(d_flow_out) : nullptr, stream));
             zero = false;
@@ -299,13 +299,18 @@ int HipFlowEstimator::solve(int slot_a, int slot_b, const Pyramid &g, uint32_t c
         NUS_HIP(hipMemsetAsync(f0, 0, (size_t)g.w[L] * g.h[L] * 8, stream));
         zero = false;
     }
-    if ((rc = iterate(L, coarse_iters)) != kOk) return rc;
+    if ((rc = iterate(L, coarse_iters, false)) != kOk) return rc;
     for (int l = (int)L - 1; l >= 0; --l) {
-        NUS_HIP(launch_flow_upsample(f0, g.w[l + 1], g.h[l + 1], f1, g.w[l], g.h[l], 2.0f, stream));
+        const bool fused_setup = tiled_ && refine_iters > 0; // the level's derivatives and the upsampled flow in one launch
+        if (fused_setup)
+            NUS_HIP(launch_hs_level_setup(reinterpret_cast<const float *>(pa + g.offset[l]), reinterpret_cast<const float *>(pb + g.offset[l]),
+                                          coef, g.w[l], g.h[l], f0, g.w[l + 1], g.h[l + 1], f1, 2.0f, stream));
+        else
+            NUS_HIP(launch_flow_upsample(f0, g.w[l + 1], g.h[l + 1], f1, g.w[l], g.h[l], 2.0f, stream));
         float *t = f0;
         f0 = f1;
         f1 = t;
-        if ((rc = iterate((uint32_t)l, refine_iters)) != kOk) return rc;
+        if ((rc = iterate((uint32_t)l, refine_iters, fused_setup)) != kOk) return rc;
     }
     if (f0 != d_flow_out)
         NUS_HIP(hipMemcpyAsync(d_flow_out, f0, (size_t)g.w[0] * g.h[0] * 8, hipMemcpyDeviceToDevice, stream));

@@ -174,11 +174,9 @@ __device__ __forceinline__ float lum_of(const float4 *img, size_t i) { return lu
 __device__ __forceinline__ float lum_of(const float *img, size_t i) { return img[i]; }
 
 template <typename IMG>
-__global__ __launch_bounds__(256) void k_hs_prepare(const IMG *__restrict__ i1, const IMG *__restrict__ i2,
-                                                    float *__restrict__ coef, int w, int h)
+__device__ __forceinline__ void hs_prepare_cell(const IMG *__restrict__ i1, const IMG *__restrict__ i2, float *__restrict__ coef,
+                                                int x, int y, int w, int h)
 {
-    const int x = blockIdx.x * kWave + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
-    if (x >= w || y >= h) return;
     const int xp = min(x + 1, w - 1), xm = max(x, 1) - 1, yp = min(y + 1, h - 1), ym = max(y, 1) - 1;
     const float ix = (lum_of(i1, (size_t)y * w + xp) - lum_of(i1, (size_t)y * w + xm)) * 0.5f;
     const float iy = (lum_of(i1, (size_t)yp * w + x) - lum_of(i1, (size_t)ym * w + x)) * 0.5f;
@@ -187,6 +185,15 @@ __global__ __launch_bounds__(256) void k_hs_prepare(const IMG *__restrict__ i1, 
     c[0] = ix;
     c[1] = iy;
     c[2] = it;
+}
+
+template <typename IMG>
+__global__ __launch_bounds__(256) void k_hs_prepare(const IMG *__restrict__ i1, const IMG *__restrict__ i2,
+                                                    float *__restrict__ coef, int w, int h)
+{
+    const int x = blockIdx.x * kWave + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
+    if (x >= w || y >= h) return;
+    hs_prepare_cell(i1, i2, coef, x, y, w, h);
 }
 
 // K Jacobi steps per launch on an LDS tile (temporal blocking): a 32x32 output tile is loaded
@@ -298,11 +305,9 @@ __global__ __launch_bounds__(NT) void k_hs_tiled(const float *__restrict__ coef,
 }
 
 // flow_upsample.wgsl:27-36 (linear clamp-to-edge sampler in texel space), vectors * scale
-__global__ __launch_bounds__(256) void k_flow_upsample(const float2 *__restrict__ src, int sw, int sh,
-                                                       float2 *__restrict__ dst, int dw, int dh, float scale)
+__device__ __forceinline__ float2 flow_upsample_cell(const float2 *__restrict__ src, int sw, int sh, int x, int y, int dw, int dh,
+                                                     float scale)
 {
-    const int x = blockIdx.x * kWave + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
-    if (x >= dw || y >= dh) return;
     const float u = ((float)x + 0.5f) / (float)dw, v = ((float)y + 0.5f) / (float)dh;
     const float sx = u * (float)sw - 0.5f, sy = v * (float)sh - 0.5f;
     const float fx0 = floorf(sx), fy0 = floorf(sy);
@@ -314,7 +319,28 @@ __global__ __launch_bounds__(256) void k_flow_upsample(const float2 *__restrict_
     float2 r;
     r.x = ((a.x * (1.0f - fx) + b.x * fx) * (1.0f - fy) + (c.x * (1.0f - fx) + d.x * fx) * fy) * scale;
     r.y = ((a.y * (1.0f - fx) + b.y * fx) * (1.0f - fy) + (c.y * (1.0f - fx) + d.y * fx) * fy) * scale;
-    dst[(size_t)y * dw + x] = r;
+    return r;
+}
+
+__global__ __launch_bounds__(256) void k_flow_upsample(const float2 *__restrict__ src, int sw, int sh,
+                                                       float2 *__restrict__ dst, int dw, int dh, float scale)
+{
+    const int x = blockIdx.x * kWave + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
+    if (x >= dw || y >= dh) return;
+    dst[(size_t)y * dw + x] = flow_upsample_cell(src, sw, sh, x, y, dw, dh, scale);
+}
+
+// What a refinement level needs before its Jacobi steps, in one launch: the derivatives of the level (k_hs_prepare on the
+// luminance planes) and the coarser level's flow upsampled onto it (k_flow_upsample) -- both per cell, independent.
+__global__ __launch_bounds__(256) void k_hs_level_setup(const float *__restrict__ l1, const float *__restrict__ l2,
+                                                        float *__restrict__ coef, int w, int h,
+                                                        const float2 *__restrict__ coarse, int cw, int ch,
+                                                        float2 *__restrict__ flow, float scale)
+{
+    const int x = blockIdx.x * kWave + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
+    if (x >= w || y >= h) return;
+    hs_prepare_cell(l1, l2, coef, x, y, w, h);
+    flow[(size_t)y * w + x] = flow_upsample_cell(coarse, cw, ch, x, y, w, h, scale);
 }
 
 } // namespace
@@ -379,6 +405,16 @@ hipError_t launch_hs_prepare(const float *i1, const float *i2, bool luminance_pl
     else
         hipLaunchKernelGGL(k_hs_prepare<float4>, grid, block, 0, stream, reinterpret_cast<const float4 *>(i1),
                            reinterpret_cast<const float4 *>(i2), coef, (int)w, (int)h);
+    return hipGetLastError();
+}
+
+// prepare (luminance planes) + upsample of the coarser flow in one launch
+hipError_t launch_hs_level_setup(const float *l1, const float *l2, float *coef, uint32_t w, uint32_t h, const float *coarse,
+                                 uint32_t cw, uint32_t ch, float *flow, float scale, hipStream_t stream)
+{
+    const dim3 block(kWave, 4), grid(cdiv(w, kWave), cdiv(h, 4));
+    hipLaunchKernelGGL(k_hs_level_setup, grid, block, 0, stream, l1, l2, coef, (int)w, (int)h,
+                       reinterpret_cast<const float2 *>(coarse), (int)cw, (int)ch, reinterpret_cast<float2 *>(flow), scale);
     return hipGetLastError();
 }
 

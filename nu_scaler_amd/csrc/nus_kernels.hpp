@@ -154,6 +154,9 @@ hipError_t launch_hs_prepare(const float *i1, const float *i2, bool luminance_pl
                              hipStream_t stream);
 hipError_t launch_hs_iterate(const float *coef, float lambda, float **flow_a, float **flow_b, uint32_t w, uint32_t h,
                              uint32_t iterations, bool zero_start, float *final_out, hipStream_t stream);
+// launch_hs_prepare on luminance planes + launch_flow_upsample of the coarser level's flow, one launch.
+hipError_t launch_hs_level_setup(const float *l1, const float *l2, float *coef, uint32_t w, uint32_t h, const float *coarse,
+                                 uint32_t cw, uint32_t ch, float *flow, float scale, hipStream_t stream);
 hipError_t launch_flow_upsample(const float *src, uint32_t sw, uint32_t sh, float *dst, uint32_t dw, uint32_t dh,
                                 float scale, hipStream_t stream);
 
