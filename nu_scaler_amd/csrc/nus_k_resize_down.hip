@@ -42,7 +42,12 @@ __global__ __launch_bounds__(256) void k_resize_down(
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int NS = kSlots;
-    float4 *s_v = reinterpret_cast<float4 *>(smem) + (size_t)threadIdx.y * (ncols_max + kDownSlack);
+    // per wave: the V row (ncols_max + slack float4), then the lanes' horizontal weights [HT][64] (registers are
+    // what limits the waves per SIMD here; a tap's weight is one conflict-free ds_read_b32 away)
+    const size_t wave_floats = (size_t)(ncols_max + kDownSlack) * 4 + (size_t)HT * kWave;
+    float *const wave_lds = reinterpret_cast<float *>(smem) + (size_t)threadIdx.y * wave_floats;
+    float4 *s_v = reinterpret_cast<float4 *>(wave_lds);
+    float *s_hw = wave_lds + (size_t)(ncols_max + kDownSlack) * 4 + threadIdx.x;
     const GridPos g = xcd_contiguous_pos(); // row blocks that share their window-fill rows behind one L2
     const uint32_t seg = __builtin_amdgcn_readfirstlane(g.x * 4 + threadIdx.y);
     const uint32_t X0 = seg * kWave;
@@ -57,12 +62,20 @@ __global__ __launch_bounds__(256) void k_resize_down(
     const int32_t hl = lxt[xo] - cmin;
     // the lane's horizontal weights, zero beyond its window (HT >= the widest window, host-checked); adding
     // +-0 leaves every sum as it is, so the fixed trip count does not change a bit
-    float hw[HT];
+    // With 3+ columns per lane the accumulators leave no room for HT weight registers next to the H pass's LDS reads
+    // (180 VGPRs, 2 waves per SIMD, and the kernel waits on HBM): the weights then live in LDS and the tap loop is rolled
+    // (128 VGPRs, 4 waves).  With 1-2 columns the registers are there and the unrolled loop is faster.
+    constexpr bool HW_LDS = VC >= 3;
+    float hw[HW_LDS ? 1 : HT];
     {
         const uint32_t hn = nxt[xo];
         const float *wx = wxt + (size_t)xo * stride;
 #pragma unroll
-        for (int k = 0; k < HT; ++k) hw[k] = (uint32_t)k < hn ? wx[(uint32_t)k < stride ? k : 0] : 0.0f;
+        for (int k = 0; k < HT; ++k) {
+            const float wk = (uint32_t)k < hn ? wx[(uint32_t)k < stride ? k : 0] : 0.0f;
+            if (HW_LDS) s_hw[k * kWave] = wk;
+            else hw[k] = wk;
+        }
     }
     const uint32_t y_begin = g.y * rows_per_block;
     const uint32_t y_end = umin(y_begin + rows_per_block, oh);
@@ -135,13 +148,26 @@ __global__ __launch_bounds__(256) void k_resize_down(
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         float h0 = 0.0f, h1 = 0.0f, h2 = 0.0f, h3 = 0.0f;
+        // taps beyond the lane's window: weight 0 times a finite LDS value
+        if (HW_LDS) {
+#pragma unroll 4
+            for (int k = 0; k < HT; ++k) {
+                const float4 v = s_v[hl + k];
+                const float wk = s_hw[k * kWave];
+                h0 = mac<EXACT>(h0, v.x, wk);
+                h1 = mac<EXACT>(h1, v.y, wk);
+                h2 = mac<EXACT>(h2, v.z, wk);
+                h3 = mac<EXACT>(h3, v.w, wk);
+            }
+        } else {
 #pragma unroll
-        for (int k = 0; k < HT; ++k) { // taps beyond the lane's window: weight 0 times a finite LDS value
-            const float4 v = s_v[hl + k];
-            h0 = mac<EXACT>(h0, v.x, hw[k]);
-            h1 = mac<EXACT>(h1, v.y, hw[k]);
-            h2 = mac<EXACT>(h2, v.z, hw[k]);
-            h3 = mac<EXACT>(h3, v.w, hw[k]);
+            for (int k = 0; k < HT; ++k) {
+                const float4 v = s_v[hl + k];
+                h0 = mac<EXACT>(h0, v.x, hw[k]);
+                h1 = mac<EXACT>(h1, v.y, hw[k]);
+                h2 = mac<EXACT>(h2, v.z, hw[k]);
+                h3 = mac<EXACT>(h3, v.w, hw[k]);
+            }
         }
         if (lane_active)
             dst[(size_t)y * ow] = pack_u8<EXACT>(h3, 3, pack_u8<EXACT>(h2, 2, pack_u8<EXACT>(h1, 1, pack_u8<EXACT>(h0, 0, 0u))));
@@ -158,7 +184,7 @@ hipError_t launch_resize_down(const UpscaleLaunch &L, const DeviceTables &T, boo
     const uint32_t vc = cdiv(ncols_max, kWave);
     if (vc < 1 || vc > 5 || max_taps_x > 32 || !T.lz_down_rows || !T.lz_down_done) return hipErrorInvalidValue;
     const bool wide = max_taps_x > 16; // horizontal weights per lane: 16 or 32 registers
-    const size_t lds = (size_t)4 * (ncols_max + kDownSlack) * sizeof(float4);
+    const size_t lds = (size_t)4 * ((size_t)(ncols_max + kDownSlack) * sizeof(float4) + (size_t)(wide ? 32 : 16) * kWave * sizeof(float));
     return for_frame_chunks(L, [&](const uint8_t *in, uint8_t *out, uint32_t n) {
         const uint64_t blocks_x = cdiv(cdiv(L.ow, kWave), 4);
         uint64_t rpb = (uint64_t)L.oh * blocks_x * n / 2048; // a couple of thousand blocks per launch ...
