@@ -486,7 +486,7 @@ __global__ __launch_bounds__(256) void k_resize_rows(
 constexpr int kResizeWinRows = 7; // Lanczos-3 on an upscale touches at most 7 input rows
 
 template <bool EXACT, int VC, int UNION, int N>
-__global__ __launch_bounds__(256) void k_resize_win(
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((UNION > 0 && VC == 3) ? 3 : 1))) void k_resize_win(
     const uint32_t *__restrict__ in, uint32_t *__restrict__ out,
     const int32_t *__restrict__ lxt, const uint32_t *__restrict__ nxt, const float *__restrict__ wxt,
     const int32_t *__restrict__ lyt, const float *__restrict__ wyt,
@@ -517,7 +517,15 @@ __global__ __launch_bounds__(256) void k_resize_win(
     int32_t hl[N];
     float hw[UNION > 0 ? 1 : N][8];
     constexpr int UW = UNION > 0 ? UNION : 1;
-    float hu[UNION > 0 ? N : 1][UW];
+    // With 3 columns per lane the window (84 VGPRs), the union window (40) and the N x UW union weights do not fit three
+    // waves per SIMD: the weights then live in LDS ([tap][lane] float4 over the lane's outputs, behind the four waves'
+    // rows) and the H pass walks the taps, one 16-byte read of the V row and one of the weights per tap, all N outputs
+    // accumulating side by side (each output still receives its terms in tap order: same bits).
+    constexpr bool HU_LDS = UNION > 0 && VC == 3;
+    float hu[(UNION > 0 && !HU_LDS) ? N : 1][UW];
+    float4 *const s_hu = reinterpret_cast<float4 *>(smem) + (size_t)4 * (ncols_max + kResizeSlack) +
+                         (size_t)threadIdx.y * (UW * kWave) + threadIdx.x;
+    float wtmp[N][UW];
 #pragma unroll
     for (int i = 0; i < N; ++i) hl[i] = lxt[lane_active ? x + i : 0] - cmin;
 #pragma unroll
@@ -529,12 +537,20 @@ __global__ __launch_bounds__(256) void k_resize_win(
             for (int j = 0; j < UW; ++j) {
                 const int32_t k = j - shift;
                 const float w = wxt[(size_t)xo * stride + (uint32_t)(k < 0 ? 0 : (k > 7 ? 7 : k))];
-                hu[i][j] = (k >= 0 && k < 8) ? w : 0.0f;
+                const float wj = (k >= 0 && k < 8) ? w : 0.0f;
+                if (HU_LDS) wtmp[i][j] = wj;
+                else hu[HU_LDS ? 0 : i][j] = wj;
             }
         } else {
 #pragma unroll
             for (int k = 0; k < 8; ++k) hw[i][k] = wxt[(size_t)xo * stride + k];
         }
+    }
+
+    if (HU_LDS) {
+#pragma unroll
+        for (int j = 0; j < UW; ++j)
+            s_hu[j * kWave] = make_float4(wtmp[0][j], wtmp[1][j], N > 2 ? wtmp[N > 2 ? 2 : 0][j] : 0.0f, N > 3 ? wtmp[N > 3 ? 3 : 0][j] : 0.0f);
     }
 
     // this lane's VC input columns: lane, lane + 64, ... of the footprint, so that for each m the wave's loads
@@ -625,6 +641,27 @@ __global__ __launch_bounds__(256) void k_resize_win(
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         if (lane_active) {
             uint32_t o[N];
+            if (HU_LDS) {
+                float h[N][4] = {{0.0f}};
+#pragma unroll
+                for (int j = 0; j < UW; ++j) {
+                    const float4 r = s_v[hl[0] + j];
+                    const float4 w4 = s_hu[j * kWave];
+                    const float wi[4] = {w4.x, w4.y, w4.z, w4.w};
+#pragma unroll
+                    for (int i = 0; i < N; ++i) {
+                        h[i][0] = mac<EXACT>(h[i][0], r.x, wi[i]);
+                        h[i][1] = mac<EXACT>(h[i][1], r.y, wi[i]);
+                        h[i][2] = mac<EXACT>(h[i][2], r.z, wi[i]);
+                        if (!skip_alpha) h[i][3] = mac<EXACT>(h[i][3], r.w, wi[i]);
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < N; ++i) {
+                    const uint32_t rgb = pack_u8<EXACT>(h[i][2], 2, pack_u8<EXACT>(h[i][1], 1, pack_u8<EXACT>(h[i][0], 0, 0u)));
+                    o[i] = skip_alpha ? (rgb | 0xFF000000u) : pack_u8<EXACT>(h[i][3], 3, rgb);
+                }
+            } else {
             float4 R[UW];
             if (UNION > 0) {
 #pragma unroll
@@ -636,13 +673,13 @@ __global__ __launch_bounds__(256) void k_resize_win(
                 if (UNION > 0) {
 #pragma unroll
                     for (int j = 0; j < UW; ++j) {
-                        h0 = mac<EXACT>(h0, R[j].x, hu[i][j]);
-                        h1 = mac<EXACT>(h1, R[j].y, hu[i][j]);
-                        h2 = mac<EXACT>(h2, R[j].z, hu[i][j]);
+                        h0 = mac<EXACT>(h0, R[j].x, hu[HU_LDS ? 0 : i][j]);
+                        h1 = mac<EXACT>(h1, R[j].y, hu[HU_LDS ? 0 : i][j]);
+                        h2 = mac<EXACT>(h2, R[j].z, hu[HU_LDS ? 0 : i][j]);
                     }
                     if (!skip_alpha) {
 #pragma unroll
-                        for (int j = 0; j < UW; ++j) h3 = mac<EXACT>(h3, R[j].w, hu[i][j]);
+                        for (int j = 0; j < UW; ++j) h3 = mac<EXACT>(h3, R[j].w, hu[HU_LDS ? 0 : i][j]);
                     }
                 } else {
 #pragma unroll
@@ -656,6 +693,7 @@ __global__ __launch_bounds__(256) void k_resize_win(
                 }
                 const uint32_t rgb = pack_u8<EXACT>(h2, 2, pack_u8<EXACT>(h1, 1, pack_u8<EXACT>(h0, 0, 0u)));
                 o[i] = skip_alpha ? (rgb | 0xFF000000u) : pack_u8<EXACT>(h3, 3, rgb);
+            }
             }
             if constexpr (N == 4)
                 *reinterpret_cast<uint4 *>(dst + (size_t)y * ow) = make_uint4(o[0], o[1], o[2], o[3]);
@@ -815,10 +853,12 @@ hipError_t launch_resize_win(const UpscaleLaunch &L, const DeviceTables &T, bool
                              uint32_t union_taps, uint32_t outputs_per_lane)
 {
     const size_t ipx = (size_t)L.iw * L.ih, opx = (size_t)L.ow * L.oh;
-    const size_t lds = (size_t)4 * (ncols_max + kResizeSlack) * sizeof(float4);
     const int vc = ncols_max <= 128 ? 2 : (ncols_max <= 192 ? 3 : 0); // 4 columns per lane: 256 VGPRs, slower than the LDS-row kernel
     if (vc == 0 || (L.ow % 4) != 0 || (outputs_per_lane != 4 && outputs_per_lane != 2)) return hipErrorInvalidValue;
     const int uni = (union_taps > 0 && union_taps <= 10) ? 10 : 0; // wider unions: plain 8-slot H pass (VGPR budget)
+    // the four waves' rows, then (3 columns per lane with the union H pass) their union weights: [tap][64] float4 per wave
+    const size_t lds = (size_t)4 * (ncols_max + kResizeSlack) * sizeof(float4) +
+                       ((vc == 3 && uni) ? (size_t)4 * uni * kWave * sizeof(float4) : 0);
     const uint32_t segw = 64 * outputs_per_lane;
     return for_frame_chunks(L, [&](const uint8_t *in, uint8_t *out, uint32_t n) {
         const uint64_t blocks_x = cdiv(cdiv(L.ow, segw), 4);
