@@ -641,13 +641,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((UNION > 0 
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         if (lane_active) {
             uint32_t o[N];
-            if (HU_LDS) {
+            if (UNION > 0 && (HU_LDS || EXACT)) { // (FMA mode with register weights: the output-outer form below allocates better)
+                // tap-outer: one 16-byte read of the V row per tap, all N outputs accumulating side by side (each output
+                // still receives its terms in tap order: same bits); nothing but the accumulators stays live
                 float h[N][4] = {{0.0f}};
 #pragma unroll
                 for (int j = 0; j < UW; ++j) {
                     const float4 r = s_v[hl[0] + j];
-                    const float4 w4 = s_hu[j * kWave];
-                    const float wi[4] = {w4.x, w4.y, w4.z, w4.w};
+                    float wi[4];
+                    if (HU_LDS) {
+                        const float4 w4 = s_hu[j * kWave];
+                        wi[0] = w4.x, wi[1] = w4.y, wi[2] = w4.z, wi[3] = w4.w;
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < N; ++i) wi[i] = hu[HU_LDS ? 0 : i][j];
+                    }
 #pragma unroll
                     for (int i = 0; i < N; ++i) {
                         h[i][0] = mac<EXACT>(h[i][0], r.x, wi[i]);
