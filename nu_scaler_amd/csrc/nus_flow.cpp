@@ -346,13 +346,85 @@ int HipFlowEstimator::estimate_device_stream(const void *d_frames, uint32_t n_fr
     const uint8_t *frames = static_cast<const uint8_t *>(d_frames);
     uint8_t *flows = static_cast<uint8_t *>(d_flows);
     const size_t frame_bytes = (size_t)w * h * 4, flow_bytes = (size_t)w * h * 8;
-    if ((rc = build_pyramid(frames, 4, g, stream)) != kOk) return rc;
-    for (uint32_t k = 0; k + 1 < n_frames; ++k) {
-        const int slot_a = 4 + (int)(k & 1), slot_b = 5 - (int)(k & 1);
-        if ((rc = build_pyramid(frames + (size_t)(k + 1) * frame_bytes, slot_b, g, stream)) != kOk) return rc;
-        if ((rc = solve(slot_a, slot_b, g, coarse_iters, refine_iters, lambda, flows + (size_t)k * flow_bytes, stream)) != kOk)
+    if (!tiled_) { // the shader-shaped kernels, pair by pair (each frame's pyramid still built once)
+        if ((rc = build_pyramid(frames, 4, g, stream)) != kOk) return rc;
+        for (uint32_t k = 0; k + 1 < n_frames; ++k) {
+            const int slot_a = 4 + (int)(k & 1), slot_b = 5 - (int)(k & 1);
+            if ((rc = build_pyramid(frames + (size_t)(k + 1) * frame_bytes, slot_b, g, stream)) != kOk) return rc;
+            if ((rc = solve(slot_a, slot_b, g, coarse_iters, refine_iters, lambda, flows + (size_t)k * flow_bytes, stream)) != kOk)
+                return rc;
+        }
+        return kOk;
+    }
+    // Tiled kernels: the pairs of a chunk go through every stage TOGETHER, one launch per stage with the pairs on the
+    // grid's z axis -- a 480x270 level of one pair is 510 tiles (two per CU, latency bound); of 32 pairs it fills the GPU.
+    const uint32_t n_pairs = n_frames - 1;
+    for (uint32_t c0 = 0; c0 < n_pairs; c0 += kStreamChunkPairs) {
+        const uint32_t pairs = n_pairs - c0 < kStreamChunkPairs ? n_pairs - c0 : kStreamChunkPairs;
+        if ((rc = solve_batch(frames + (size_t)c0 * frame_bytes, pairs, g, coarse_iters, refine_iters, lambda,
+                              flows + (size_t)c0 * flow_bytes, stream)) != kOk)
             return rc;
     }
+    return kOk;
+}
+
+// `pairs` + 1 consecutive RGBA8 frames -> `pairs` flows, every stage one launch over the whole chunk.
+// Workspace (grow-only slots): 0 / 1 the f32 RGBA inputs of the odd / even pyramid levels of all frames,
+// 2 / 3 flow ping-pong [pair][level cells], 4 luminance planes [level][frame][cells], 5 coefficients [pair][cells][3].
+int HipFlowEstimator::solve_batch(const uint8_t *d_frames, uint32_t pairs, const Pyramid &g, uint32_t coarse_iters,
+                                  uint32_t refine_iters, float lambda, uint8_t *d_flows, hipStream_t stream)
+{
+    int rc;
+    const uint32_t nf = pairs + 1, nl = g.levels, L = nl - 1;
+    size_t cells[12], lum_off[12], lum_total = 0;
+    for (uint32_t l = 0; l < nl; ++l) {
+        cells[l] = (size_t)g.w[l] * g.h[l];
+        lum_off[l] = lum_total;
+        lum_total += cells[l] * nf;
+    }
+    const size_t in_odd = nl > 1 ? cells[1] : 0, in_even = nl > 2 ? cells[2] : 0; // largest level input each buffer holds
+    if ((rc = reserve(in_odd * nf * 16, 0)) != kOk || (rc = reserve(in_even * nf * 16, 1)) != kOk ||
+        (rc = reserve(cells[0] * pairs * 8, 2)) != kOk || (rc = reserve(cells[0] * pairs * 8, 3)) != kOk ||
+        (rc = reserve(lum_total * 4, 4)) != kOk || (rc = reserve(cells[0] * pairs * 12, 5)) != kOk)
+        return rc;
+    float *level_in[2] = {static_cast<float *>(slot_[0]), static_cast<float *>(slot_[1])}; // input of level l: [(l - 1) & 1]
+    float *lum = static_cast<float *>(slot_[4]), *coef = static_cast<float *>(slot_[5]);
+    float *f0 = static_cast<float *>(slot_[2]), *f1 = static_cast<float *>(slot_[3]);
+    // pyramids of all frames, level by level
+    for (uint32_t l = 0; l < nl; ++l) {
+        const void *src = l == 0 ? static_cast<const void *>(d_frames) : level_in[(l - 1) & 1];
+        const size_t src_stride = l == 0 ? cells[0] * 4 /* bytes */ : cells[l] /* float4 */;
+        float *next = l + 1 < nl ? level_in[l & 1] : nullptr;
+        NUS_HIP(launch_pyramid_level(src, l == 0, lum + lum_off[l], next, g.w[l], g.h[l], stream, nf, src_stride, cells[l],
+                                     l + 1 < nl ? cells[l + 1] : 0));
+    }
+    float *const out = reinterpret_cast<float *>(d_flows);
+    auto iterate = [&](uint32_t l, uint32_t iters, bool zero) -> int {
+        NUS_HIP(launch_hs_iterate(coef, lambda, &f0, &f1, g.w[l], g.h[l], iters, zero, l == 0 ? out : nullptr, stream, pairs,
+                                  cells[l] * 3, cells[l], cells[0]));
+        return kOk;
+    };
+    // coarsest level: from zero flow (compute_coarse_flow, :1136-1154)
+    if (coarse_iters > 0) {
+        NUS_HIP(launch_hs_prepare(lum + lum_off[L], lum + lum_off[L] + cells[L], true, coef, g.w[L], g.h[L], stream, pairs, cells[L],
+                                  cells[L] * 3));
+        if ((rc = iterate(L, coarse_iters, true)) != kOk) return rc;
+    } else {
+        NUS_HIP(hipMemsetAsync(f0, 0, cells[L] * pairs * 8, stream));
+    }
+    for (int l = (int)L - 1; l >= 0; --l) {
+        const float *l1 = lum + lum_off[l];
+        if (refine_iters > 0)
+            NUS_HIP(launch_hs_level_setup(l1, l1 + cells[l], coef, g.w[l], g.h[l], f0, g.w[l + 1], g.h[l + 1], f1, 2.0f, stream, pairs,
+                                          cells[l], cells[l] * 3, cells[l + 1], cells[l]));
+        else
+            NUS_HIP(launch_flow_upsample(f0, g.w[l + 1], g.h[l + 1], f1, g.w[l], g.h[l], 2.0f, stream, pairs, cells[l + 1], cells[l]));
+        float *t = f0;
+        f0 = f1;
+        f1 = t;
+        if (refine_iters > 0 && (rc = iterate((uint32_t)l, refine_iters, false)) != kOk) return rc;
+    }
+    if (f0 != out) NUS_HIP(hipMemcpyAsync(out, f0, cells[0] * pairs * 8, hipMemcpyDeviceToDevice, stream));
     return kOk;
 }
 

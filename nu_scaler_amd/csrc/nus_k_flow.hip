@@ -108,16 +108,21 @@ constexpr int kPyrTW = 64, kPyrTH = 16;
 constexpr int kPyrThreads = NUS_PYR_THREADS; // 3 tiles per CU by LDS: twice the waves hide the LDS round trips of its phases
 
 template <bool U8IN>
-__global__ __launch_bounds__(kPyrThreads) void k_pyramid_level(const void *__restrict__ in, float *__restrict__ level_lum,
-                                                               float4 *__restrict__ next, int w, int h)
+__global__ __launch_bounds__(kPyrThreads) void k_pyramid_level(const void *__restrict__ in_all, size_t in_stride,
+                                                               float *__restrict__ lum_all, size_t lum_stride,
+                                                               float4 *__restrict__ next_all, size_t next_stride, int w, int h)
 {
     __shared__ float4 s_a[(kPyrTH + 4) * (kPyrTW + 4)]; // input region; later the V-blurred tile
     __shared__ float4 s_h[(kPyrTH + 4) * kPyrTW];        // H-blurred rows
     constexpr int NW = kPyrThreads / 64;                  // waves per tile: each phase deals its rows to them
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     // each XCD takes a contiguous band of tiles: the 2-pixel halos neighbouring tiles share come out of its L2
-    const uint32_t vid = xcd_contiguous_id(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
-    const int bx = (int)(vid % gridDim.x) * kPyrTW, by = (int)(vid / gridDim.x) * kPyrTH;
+    const GridPos gp = xcd_contiguous_pos(); // z: frame of the batch; strides in elements (bytes for the RGBA8 input)
+    const int bx = (int)gp.x * kPyrTW, by = (int)gp.y * kPyrTH;
+    const void *in = U8IN ? static_cast<const void *>(static_cast<const uint8_t *>(in_all) + gp.z * in_stride)
+                          : static_cast<const void *>(static_cast<const float4 *>(in_all) + gp.z * in_stride);
+    float *level_lum = lum_all + gp.z * lum_stride;
+    float4 *next = next_all ? next_all + gp.z * next_stride : nullptr;
     // stage input rows by-2 .. by+17, columns bx-2 .. bx+65, coordinates clamped into the image
     for (int r = ty; r < kPyrTH + 4; r += NW) {
         const int gy = clampi(by - 2 + r, 0, h - 1);
@@ -188,12 +193,12 @@ __device__ __forceinline__ void hs_prepare_cell(const IMG *__restrict__ i1, cons
 }
 
 template <typename IMG>
-__global__ __launch_bounds__(256) void k_hs_prepare(const IMG *__restrict__ i1, const IMG *__restrict__ i2,
-                                                    float *__restrict__ coef, int w, int h)
+__global__ __launch_bounds__(256) void k_hs_prepare(const IMG *__restrict__ i1, const IMG *__restrict__ i2, size_t img_stride,
+                                                    float *__restrict__ coef, size_t coef_stride, int w, int h)
 {
     const int x = blockIdx.x * kWave + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
     if (x >= w || y >= h) return;
-    hs_prepare_cell(i1, i2, coef, x, y, w, h);
+    hs_prepare_cell(i1 + blockIdx.z * img_stride, i2 + blockIdx.z * img_stride, coef + blockIdx.z * coef_stride, x, y, w, h);
 }
 
 // K Jacobi steps per launch on an LDS tile (temporal blocking): a 32x32 output tile is loaded
@@ -218,8 +223,9 @@ struct HsCell {
 // distance to the tile edge ("ring") is >= j -- their 3x3 neighbourhood was valid after step j-1;
 // at the image border neighbours clamp inwards exactly as in k_horn_schunck.
 template <int T, int K, int NT>
-__global__ __launch_bounds__(NT) void k_hs_tiled(const float *__restrict__ coef, float lambda,
-                                                  const float2 *__restrict__ fin, float2 *__restrict__ fout, int w, int h)
+__global__ __launch_bounds__(NT) void k_hs_tiled(const float *__restrict__ coef_all, size_t coef_stride, float lambda,
+                                                  const float2 *__restrict__ fin_all, size_t fin_stride,
+                                                  float2 *__restrict__ fout_all, size_t fout_stride, int w, int h)
 {
     constexpr int R = T + 2 * K, RUNS = NT / R, N = (R + RUNS - 1) / RUNS;
     static_assert(RUNS >= 1 && RUNS * N >= R, "tile does not fit the block");
@@ -227,8 +233,11 @@ __global__ __launch_bounds__(NT) void k_hs_tiled(const float *__restrict__ coef,
     const int tid = threadIdx.x;
     const int run = tid / R, lx = tid - run * R, ly0 = run * N;
     // each XCD works through a contiguous band of tiles, so the halo cells neighbouring tiles both load come out of its L2
-    const uint32_t vid = xcd_contiguous_id(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
-    const int tile_x = (int)(vid % gridDim.x), tile_y = (int)(vid / gridDim.x);
+    const GridPos gp = xcd_contiguous_pos(); // z: pair of the batch; strides in elements
+    const int tile_x = (int)gp.x, tile_y = (int)gp.y;
+    const float *coef = coef_all + gp.z * coef_stride;
+    const float2 *fin = fin_all ? fin_all + gp.z * fin_stride : nullptr;
+    float2 *fout = fout_all + gp.z * fout_stride;
     const int x0 = tile_x * T - K, y0 = tile_y * T - K; // image coords of LDS cell (0,0)
     // tiles whose loaded region lies strictly inside the image need no clamping at all
     const bool border = x0 < 0 || y0 < 0 || x0 + R > w || y0 + R > h; // block-uniform
@@ -322,25 +331,26 @@ __device__ __forceinline__ float2 flow_upsample_cell(const float2 *__restrict__ 
     return r;
 }
 
-__global__ __launch_bounds__(256) void k_flow_upsample(const float2 *__restrict__ src, int sw, int sh,
-                                                       float2 *__restrict__ dst, int dw, int dh, float scale)
+__global__ __launch_bounds__(256) void k_flow_upsample(const float2 *__restrict__ src, size_t src_stride, int sw, int sh,
+                                                       float2 *__restrict__ dst, size_t dst_stride, int dw, int dh, float scale)
 {
     const int x = blockIdx.x * kWave + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
     if (x >= dw || y >= dh) return;
-    dst[(size_t)y * dw + x] = flow_upsample_cell(src, sw, sh, x, y, dw, dh, scale);
+    dst[blockIdx.z * dst_stride + (size_t)y * dw + x] = flow_upsample_cell(src + blockIdx.z * src_stride, sw, sh, x, y, dw, dh, scale);
 }
 
 // What a refinement level needs before its Jacobi steps, in one launch: the derivatives of the level (k_hs_prepare on the
 // luminance planes) and the coarser level's flow upsampled onto it (k_flow_upsample) -- both per cell, independent.
-__global__ __launch_bounds__(256) void k_hs_level_setup(const float *__restrict__ l1, const float *__restrict__ l2,
-                                                        float *__restrict__ coef, int w, int h,
-                                                        const float2 *__restrict__ coarse, int cw, int ch,
-                                                        float2 *__restrict__ flow, float scale)
+__global__ __launch_bounds__(256) void k_hs_level_setup(const float *__restrict__ l1, const float *__restrict__ l2, size_t lum_stride,
+                                                        float *__restrict__ coef, size_t coef_stride, int w, int h,
+                                                        const float2 *__restrict__ coarse, size_t coarse_stride, int cw, int ch,
+                                                        float2 *__restrict__ flow, size_t flow_stride, float scale)
 {
     const int x = blockIdx.x * kWave + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
     if (x >= w || y >= h) return;
-    hs_prepare_cell(l1, l2, coef, x, y, w, h);
-    flow[(size_t)y * w + x] = flow_upsample_cell(coarse, cw, ch, x, y, w, h, scale);
+    const size_t z = blockIdx.z; // pair of the batch
+    hs_prepare_cell(l1 + z * lum_stride, l2 + z * lum_stride, coef + z * coef_stride, x, y, w, h);
+    flow[z * flow_stride + (size_t)y * w + x] = flow_upsample_cell(coarse + z * coarse_stride, cw, ch, x, y, w, h, scale);
 }
 
 } // namespace
@@ -380,52 +390,58 @@ hipError_t launch_horn_schunck(const float *i1, const float *i2, const float *fl
     return hipGetLastError();
 }
 
+// Batches: every launcher below takes `n` independent images / pairs on the grid's z axis, buffer b of item z at
+// b + z * stride (strides in elements of the buffer's type; bytes for an RGBA8 input).  n = 1 ignores the strides.
+
 // One fused pyramid level: `in` is RGBA8 (u8_input) or f32 RGBA; writes the level's luminance plane
 // (w*h floats) and the f32 RGBA input of the next level; `next` may be null (last level).
 hipError_t launch_pyramid_level(const void *in, bool u8_input, float *level_lum, float *next, uint32_t w, uint32_t h,
-                                hipStream_t stream)
+                                hipStream_t stream, uint32_t n, size_t in_stride, size_t lum_stride, size_t next_stride)
 {
-    const dim3 block(kPyrThreads), grid(cdiv(w, kPyrTW), cdiv(h, kPyrTH));
+    const dim3 block(kPyrThreads), grid(cdiv(w, kPyrTW), cdiv(h, kPyrTH), n);
     if (u8_input)
-        hipLaunchKernelGGL(k_pyramid_level<true>, grid, block, 0, stream, in, level_lum,
-                           reinterpret_cast<float4 *>(next), (int)w, (int)h);
+        hipLaunchKernelGGL(k_pyramid_level<true>, grid, block, 0, stream, in, in_stride, level_lum, lum_stride,
+                           reinterpret_cast<float4 *>(next), next_stride, (int)w, (int)h);
     else
-        hipLaunchKernelGGL(k_pyramid_level<false>, grid, block, 0, stream, in, level_lum,
-                           reinterpret_cast<float4 *>(next), (int)w, (int)h);
+        hipLaunchKernelGGL(k_pyramid_level<false>, grid, block, 0, stream, in, in_stride, level_lum, lum_stride,
+                           reinterpret_cast<float4 *>(next), next_stride, (int)w, (int)h);
     return hipGetLastError();
 }
 
 // coef: 3 floats (ix, iy, it) per cell -> w*h*12 bytes
 hipError_t launch_hs_prepare(const float *i1, const float *i2, bool luminance_planes, float *coef, uint32_t w, uint32_t h,
-                             hipStream_t stream)
+                             hipStream_t stream, uint32_t n, size_t img_stride, size_t coef_stride)
 {
-    const dim3 block(kWave, 4), grid(cdiv(w, kWave), cdiv(h, 4));
+    const dim3 block(kWave, 4), grid(cdiv(w, kWave), cdiv(h, 4), n);
     if (luminance_planes)
-        hipLaunchKernelGGL(k_hs_prepare<float>, grid, block, 0, stream, i1, i2, coef, (int)w, (int)h);
+        hipLaunchKernelGGL(k_hs_prepare<float>, grid, block, 0, stream, i1, i2, img_stride, coef, coef_stride, (int)w, (int)h);
     else
         hipLaunchKernelGGL(k_hs_prepare<float4>, grid, block, 0, stream, reinterpret_cast<const float4 *>(i1),
-                           reinterpret_cast<const float4 *>(i2), coef, (int)w, (int)h);
+                           reinterpret_cast<const float4 *>(i2), img_stride, coef, coef_stride, (int)w, (int)h);
     return hipGetLastError();
 }
 
 // prepare (luminance planes) + upsample of the coarser flow in one launch
 hipError_t launch_hs_level_setup(const float *l1, const float *l2, float *coef, uint32_t w, uint32_t h, const float *coarse,
-                                 uint32_t cw, uint32_t ch, float *flow, float scale, hipStream_t stream)
+                                 uint32_t cw, uint32_t ch, float *flow, float scale, hipStream_t stream, uint32_t n,
+                                 size_t lum_stride, size_t coef_stride, size_t coarse_stride, size_t flow_stride)
 {
-    const dim3 block(kWave, 4), grid(cdiv(w, kWave), cdiv(h, 4));
-    hipLaunchKernelGGL(k_hs_level_setup, grid, block, 0, stream, l1, l2, coef, (int)w, (int)h,
-                       reinterpret_cast<const float2 *>(coarse), (int)cw, (int)ch, reinterpret_cast<float2 *>(flow), scale);
+    const dim3 block(kWave, 4), grid(cdiv(w, kWave), cdiv(h, 4), n);
+    hipLaunchKernelGGL(k_hs_level_setup, grid, block, 0, stream, l1, l2, lum_stride, coef, coef_stride, (int)w, (int)h,
+                       reinterpret_cast<const float2 *>(coarse), coarse_stride, (int)cw, (int)ch,
+                       reinterpret_cast<float2 *>(flow), flow_stride, scale);
     return hipGetLastError();
 }
 
 // `iterations` Jacobi steps from *flow_a (from zero flow without reading it if zero_start),
 // ping-ponging with *flow_b; on return *flow_a holds the result (the pointers are swapped as
-// needed; with final_out the last launch writes there and *flow_a == final_out).  Steps are split evenly
-// over ceil(iterations / 8) launches.  Tile shape by level size (tiles of 32x32 the level has):
-//   >= 1024 (1080p): 32-wide tiles, 256 threads (7 cells per thread, 5 tiles per CU by LDS);
-//   mid  (960x540):  NUS_HS_MID_T-wide tiles with NUS_HS_MID_THREADS threads;
-//   < 256 (480x270): 16-wide tiles, so that the grid still covers the 256 CUs, with 1024 threads of one cell
-//                    each: two tiles per CU leave the step's LDS round trip exposed unless the waves are many.
+// needed; with final_out the last launch writes there -- item stride final_stride -- and *flow_a == final_out).
+// Steps are split evenly over the launches.  Tile shape by the number of 32x32 tiles the whole batch has:
+//   >= 1024 (1080p, or a batch of smaller levels): 32-wide tiles, 256 threads (7 cells per thread, 5 tiles per CU
+//            by LDS), at most 5 steps per launch (beyond that the tile's registers and LDS cost a wave per SIMD);
+//   >= 256  (one 960x540 level): 32-wide tiles with 1024 threads;
+//   < 256   (one 480x270 level): 16-wide tiles, so that the grid still covers the 256 CUs, with 1024 threads of one
+//            cell each: two tiles per CU leave the step's LDS round trip exposed unless the waves are many.
 #ifndef NUS_HS_BIG_THREADS
 #define NUS_HS_BIG_THREADS 256
 #endif
@@ -442,21 +458,29 @@ hipError_t launch_hs_level_setup(const float *l1, const float *l2, float *coef, 
 #define NUS_HS_SMALL_THREADS 1024
 #endif
 hipError_t launch_hs_iterate(const float *coef, float lambda, float **flow_a, float **flow_b, uint32_t w, uint32_t h,
-                             uint32_t iterations, bool zero_start, float *final_out, hipStream_t stream)
+                             uint32_t iterations, bool zero_start, float *final_out, hipStream_t stream, uint32_t n,
+                             size_t coef_stride, size_t flow_stride, size_t final_stride)
 {
-    const uint64_t tiles32 = (uint64_t)cdiv(w, 32) * cdiv(h, 32);
+    const uint64_t tiles32 = (uint64_t)cdiv(w, 32) * cdiv(h, 32) * n;
     const int cls = tiles32 >= 1024 ? 2 : (tiles32 >= 256 ? 1 : 0);
     const uint32_t T = cls == 2 ? 32 : (cls == 1 ? NUS_HS_MID_T : NUS_HS_SMALL_T);
     const uint32_t NT = cls == 2 ? NUS_HS_BIG_THREADS : (cls == 1 ? NUS_HS_MID_THREADS : NUS_HS_SMALL_THREADS);
-    const dim3 block(NT), grid(cdiv(w, T), cdiv(h, T));
-    uint32_t launches = (iterations + 7) / 8;
+    const dim3 block(NT), grid(cdiv(w, T), cdiv(h, T), n);
+    const uint32_t maxk = cls == 2 ? 5 : 8;
+    uint32_t launches = (iterations + maxk - 1) / maxk;
     while (iterations > 0) {
-        const uint32_t k = (iterations + launches - 1) / launches; // even split, 1..8 steps per launch
-        if (final_out && launches == 1) *flow_b = final_out; // the last launch writes the caller's buffer
+        const uint32_t k = (iterations + launches - 1) / launches; // even split, 1..maxk steps per launch
+        size_t out_stride = flow_stride;
+        if (final_out && launches == 1) { // the last launch writes the caller's buffer
+            *flow_b = final_out;
+            out_stride = final_stride;
+        }
         auto fi = zero_start ? nullptr : reinterpret_cast<const float2 *>(*flow_a);
         auto fo = reinterpret_cast<float2 *>(*flow_b);
         zero_start = false;
-#define NUS_HS_L(TT, KK, TH) hipLaunchKernelGGL((k_hs_tiled<TT, KK, TH>), grid, block, 0, stream, coef, lambda, fi, fo, (int)w, (int)h)
+#define NUS_HS_L(TT, KK, TH)                                                                                                  \
+    hipLaunchKernelGGL((k_hs_tiled<TT, KK, TH>), grid, block, 0, stream, coef, coef_stride, lambda, fi, flow_stride, fo, out_stride, \
+                       (int)w, (int)h)
 #define NUS_HS(KK)                                                    \
     case KK:                                                          \
         if (cls == 2) NUS_HS_L(32, KK, NUS_HS_BIG_THREADS);           \
@@ -480,11 +504,11 @@ hipError_t launch_hs_iterate(const float *coef, float lambda, float **flow_a, fl
 }
 
 hipError_t launch_flow_upsample(const float *src, uint32_t sw, uint32_t sh, float *dst, uint32_t dw, uint32_t dh,
-                                float scale, hipStream_t stream)
+                                float scale, hipStream_t stream, uint32_t n, size_t src_stride, size_t dst_stride)
 {
-    const dim3 block(kWave, 4), grid(cdiv(dw, kWave), cdiv(dh, 4));
-    hipLaunchKernelGGL(k_flow_upsample, grid, block, 0, stream, reinterpret_cast<const float2 *>(src), (int)sw, (int)sh,
-                       reinterpret_cast<float2 *>(dst), (int)dw, (int)dh, scale);
+    const dim3 block(kWave, 4), grid(cdiv(dw, kWave), cdiv(dh, 4), n);
+    hipLaunchKernelGGL(k_flow_upsample, grid, block, 0, stream, reinterpret_cast<const float2 *>(src), src_stride, (int)sw, (int)sh,
+                       reinterpret_cast<float2 *>(dst), dst_stride, (int)dw, (int)dh, scale);
     return hipGetLastError();
 }
 

@@ -162,10 +162,11 @@ def test_flow_estimate_device_path(nsc, oracle_mod):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n_frames", [2, 3, 5])
+@pytest.mark.parametrize("n_frames", [2, 3, 5, 35])
 def test_flow_estimate_device_stream_equals_pairwise(nsc, oracle_mod, n_frames):
-    """The stream entry point reuses frame k+1's pyramid for the next pair (alternating workspace slots):
-    every flow must still be the oracle's flow of its own pair."""
+    """The stream entry point takes chunks of up to 32 pairs through every stage together (pairs on the grid's z axis,
+    each frame's pyramid built once per chunk): every flow must still be the oracle's flow of its own pair -- also
+    with the shader-shaped kernels, which go pair by pair."""
     import torch
 
     w, h = 97, 45
@@ -174,11 +175,15 @@ def test_flow_estimate_device_stream_equals_pairwise(nsc, oracle_mod, n_frames):
     d_frames = torch.from_numpy(frames).to(dev)
     d_flows = torch.full((n_frames - 1, h, w, 2), float("nan"), dtype=torch.float32, device=dev)
     fe = nsc.FlowEstimator(levels=3, coarse_iterations=9, refine_iterations=3)
-    fe.estimate_device_stream(d_frames.data_ptr(), n_frames, w, h, d_flows.data_ptr(), torch.cuda.current_stream().cuda_stream)
-    torch.cuda.synchronize()
-    got = d_flows.cpu().numpy()
-    for k in range(n_frames - 1):
-        assert np.array_equal(got[k], oracle_mod.flow_estimate(frames[k], frames[k + 1], 3, 9, 3, fe.lambda_)), k
+    want = [oracle_mod.flow_estimate(frames[k], frames[k + 1], 3, 9, 3, fe.lambda_) for k in range(n_frames - 1)]
+    for tiled in (True, False):
+        fe.set_tiled(tiled)
+        d_flows.fill_(float("nan"))
+        fe.estimate_device_stream(d_frames.data_ptr(), n_frames, w, h, d_flows.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        got = d_flows.cpu().numpy()
+        for k in range(n_frames - 1):
+            assert np.array_equal(got[k], want[k]), (k, tiled)
     with pytest.raises(Exception):
         fe.estimate_device_stream(d_frames.data_ptr(), 1, w, h, d_flows.data_ptr(), 0)
 
