@@ -18,6 +18,7 @@ echo "sweep done"
 bash tools/flow_prof.sh > $out/flow_kernels.txt 2>&1
 cp $(find $root/gpurun_out/flowprof -name "*kernel_stats.csv" | head -1) $out/flow_front_end_kernel_stats.csv 2>/dev/null
 python3 tools/flow_bench.py 2>&1 | grep "flow estimate" >> $out/flow_kernels.txt
+bash tools/flow_stream_prof.sh 65 > $out/flow_stream_kernels.txt 2>&1
 python3 bench.py --no-pmc --steps 3 --warmup 1 --motion 2>/dev/null | tail -1 > $out/bench_motion.json
 echo "flow done"
 rm -rf $out/bench_prof
