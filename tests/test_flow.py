@@ -189,6 +189,25 @@ def test_flow_estimate_device_stream_equals_pairwise(nsc, oracle_mod, n_frames):
 
 
 @pytest.mark.gpu
+def test_flow_estimate_device_stream_big_batch(nsc, oracle_mod):
+    """A batch whose levels fall into different tile classes (>= 1024 tiles of 32x32 over the batch at level 0:
+    32-wide tiles with 256 threads; fewer at the coarser levels: 1024 threads per tile)."""
+    import torch
+
+    w, h, n_frames = 333, 262, 13
+    frames = np.stack([oracle_mod.gen_noise(w, h, 90 + k) for k in range(n_frames)])
+    dev = torch.device("cuda:0")
+    d_frames = torch.from_numpy(frames).to(dev)
+    d_flows = torch.full((n_frames - 1, h, w, 2), float("nan"), dtype=torch.float32, device=dev)
+    fe = nsc.FlowEstimator(levels=3, coarse_iterations=7, refine_iterations=6)
+    fe.estimate_device_stream(d_frames.data_ptr(), n_frames, w, h, d_flows.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    got = d_flows.cpu().numpy()
+    for k in range(n_frames - 1):
+        assert np.array_equal(got[k], oracle_mod.flow_estimate(frames[k], frames[k + 1], 3, 7, 6, fe.lambda_)), k
+
+
+@pytest.mark.gpu
 def test_pipeline_step_motion_matches_stage_by_stage_oracle(nsc, oracle_mod):
     """FramePipeline.step_motion: per-pair flow -> warp + blend with it -> x2 Lanczos of real and in-between frames,
     device-resident over a small stream; every stage equals the oracle's (bit-exact flow and warp)."""
