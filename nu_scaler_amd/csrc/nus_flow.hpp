@@ -54,8 +54,10 @@ private:
     int build_pyramid(const void *frame, int pyr_slot, const Pyramid &g, hipStream_t stream);
     int solve(int slot_a, int slot_b, const Pyramid &g, uint32_t coarse_iters, uint32_t refine_iters, float lambda,
               void *d_flow_out, hipStream_t stream);
-    // tiled kernels, a chunk of consecutive pairs per launch (pairs on the grid's z axis)
-    static constexpr uint32_t kStreamChunkPairs = 32;
+    // tiled kernels, a chunk of consecutive pairs per launch (pairs on the grid's z axis): as many as fit the
+    // workspace budget (88 MB per 1080p pair), at most 64 -- beyond that the launches gain nothing
+    static constexpr uint32_t kStreamMaxChunkPairs = 64;
+    static constexpr size_t kStreamWorkspaceBytes = (size_t)6 << 30;
     int solve_batch(const uint8_t *d_frames, uint32_t pairs, const Pyramid &g, uint32_t coarse_iters, uint32_t refine_iters,
                     float lambda, uint8_t *d_flows, hipStream_t stream);
     int fail(int status, const std::string &msg);
