@@ -1,4 +1,4 @@
-// nus_k_resize_down.hip -- separable resize for DOWN-scaling factors (tap windows of 9..31 rows): the
+// nus_k_resize_down.hip -- separable resize for vertical DOWN-scaling (tap windows of up to 31 rows): the
 // filters of image 0.24.9's imageops::resize as called at Nu_scale/src/upscale/common.rs:243-251 and
 // Nu_scale/src/capture/common.rs:56, :359-360 (captured frames are resized to the target with them).
 #include "nus_device.hpp"
@@ -22,7 +22,8 @@ constexpr uint32_t kDownSlack = 32; // zeroed LDS entries behind the row: the fi
 //     acc[s] += w[s] * row.  Taps are added in increasing row order, exactly the order of the
 //     per-output loop, and an added +-0 changes nothing: bit-identical in EXACT mode (mul + add);
 //   * the row that completes a window writes the slot's sums to the wave's LDS row; each lane then
-//     sums its output's horizontal taps from LDS (weights in registers), packs and stores, and the
+//     sums its output's horizontal taps from LDS (weights in registers, or in LDS when the accumulators
+//     leave no room for them: 3+ columns per lane), packs and stores, and the
 //     slot is cleared.  Windows cut by the bottom border end together on the last input row: the
 //     table gives each of them a pseudo-row of zero weights behind it, so the loop never sees two.
 // A block of output rows starts at its first window's first row with cleared slots; windows of the
