@@ -1,7 +1,9 @@
-// nus_host.cpp -- host classes above the gfx950 kernels.  See nus_host.hpp.
+// nus_host.cpp -- HipUpscaler and the factory: the host side of the upscaling path above the gfx950 kernels.
+// See nus_host.hpp.  (HipFrameInterpolator: nus_host_interp.cpp.)
 #include "nus_host.hpp"
 
 #include "nus_copy.hpp"
+#include "nus_host_util.hpp"
 
 #include <cstdarg>
 #include <cstdio>
@@ -11,39 +13,6 @@ namespace nus {
 
 namespace {
 thread_local std::string g_thread_error;
-
-std::string fmt(const char *f, ...) __attribute__((format(printf, 1, 2)));
-std::string fmt(const char *f, ...)
-{
-    char buf[512];
-    va_list ap;
-    va_start(ap, f);
-    vsnprintf(buf, sizeof buf, f, ap);
-    va_end(ap);
-    return buf;
-}
-
-// True when `p` is host memory the DMA engines can address directly
-// (hipHostMalloc / hipHostRegister); pageable memory goes through pinned staging.
-bool is_pinned_host(const void *p)
-{
-    hipPointerAttribute_t attr;
-    if (hipPointerGetAttributes(&attr, p) != hipSuccess) {
-        (void)hipGetLastError(); // pageable memory: not an error for us
-        return false;
-    }
-    return attr.type == hipMemoryTypeHost;
-}
-
-int device_count()
-{
-    int n = 0;
-    if (hipGetDeviceCount(&n) != hipSuccess) {
-        (void)hipGetLastError();
-        return 0;
-    }
-    return n;
-}
 } // namespace
 
 void set_thread_error(const std::string &msg) { g_thread_error = msg; }
@@ -70,12 +39,6 @@ int HipUpscaler::fail_hip(hipError_t e, const char *what)
     return fail(e == hipErrorOutOfMemory ? kOutOfMemory : kHipError,
                 fmt("HIP error in %s: %s", what, hipGetErrorString(e)));
 }
-
-#define NUS_HIP(call)                                   \
-    do {                                                \
-        hipError_t e_ = (call);                         \
-        if (e_ != hipSuccess) return fail_hip(e_, #call); \
-    } while (0)
 
 const char *HipUpscaler::name() const
 {
@@ -774,209 +737,6 @@ std::unique_ptr<HipUpscaler> UpscalerFactory::create_upscaler(Technology tech, Q
     // upscale/mod.rs:99-116: Wgpu -> bilinear, everything else -> nearest.
     const Algorithm a = tech == Technology::Wgpu ? Algorithm::Bilinear : Algorithm::Nearest;
     return std::unique_ptr<HipUpscaler>(new HipUpscaler(q, a));
-}
-
-// ---------------------------------------------------------------------------------
-// HipFrameInterpolator
-// ---------------------------------------------------------------------------------
-
-HipFrameInterpolator::HipFrameInterpolator(int wg_preset) : wg_preset_(wg_preset) {}
-
-HipFrameInterpolator::~HipFrameInterpolator()
-{
-    release();
-    if (device_ready_) {
-        if (k_begin_) (void)hipEventDestroy(k_begin_);
-        if (k_end_) (void)hipEventDestroy(k_end_);
-        if (half_done_) (void)hipEventDestroy(half_done_);
-        if (stream_) (void)hipStreamDestroy(stream_);
-    }
-}
-
-int HipFrameInterpolator::fail(int status, const std::string &msg)
-{
-    error_ = msg;
-    set_thread_error(msg);
-    return status;
-}
-
-int HipFrameInterpolator::fail_hip(hipError_t e, const char *what)
-{
-    (void)hipGetLastError();
-    return fail(e == hipErrorOutOfMemory ? kOutOfMemory : kHipError,
-                fmt("HIP error in %s: %s", what, hipGetErrorString(e)));
-}
-
-int HipFrameInterpolator::set_device(int device)
-{
-    std::lock_guard<std::mutex> lk(mu_);
-    if (device < 0) return fail(kInvalidArgument, "negative device index");
-    if (device_ready_) return fail(kInvalidArgument, "set_device must precede the first interpolation");
-    device_ = device;
-    return kOk;
-}
-
-void HipFrameInterpolator::release()
-{
-    if (!device_ready_) return;
-    (void)hipSetDevice(device_);
-    if (stream_) (void)hipStreamSynchronize(stream_);
-    if (d_a_) (void)hipFree(d_a_);
-    if (d_b_) (void)hipFree(d_b_);
-    if (d_out_) (void)hipFree(d_out_);
-    if (d_flow_) (void)hipFree(d_flow_);
-    if (h_stage_) (void)hipHostFree(h_stage_);
-    if (h_flow_) (void)hipHostFree(h_flow_);
-    d_a_ = d_b_ = d_out_ = nullptr;
-    d_flow_ = nullptr;
-    h_stage_ = nullptr;
-    h_flow_ = nullptr;
-    cap_bytes_ = 0;
-    cap_flow_ = false;
-}
-
-int HipFrameInterpolator::ensure(size_t frame_bytes, bool with_flow)
-{
-    if (!device_ready_) {
-        const int n = device_count();
-        if (n <= 0) return fail(kNoDevice, "no HIP device available (the gfx950 path has no CPU fallback)");
-        if (device_ >= n) return fail(kNoDevice, fmt("HIP device %d requested but only %d present", device_, n));
-        NUS_HIP(hipSetDevice(device_));
-        NUS_HIP(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
-        NUS_HIP(hipEventCreate(&k_begin_));
-        NUS_HIP(hipEventCreate(&k_end_));
-        NUS_HIP(hipEventCreateWithFlags(&half_done_, hipEventDisableTiming));
-        device_ready_ = true;
-    }
-    NUS_HIP(hipSetDevice(device_));
-    if (frame_bytes > cap_bytes_ || (with_flow && !cap_flow_)) {
-        // the reference reallocates its textures on every call (wgpu_interpolator.rs:253-321);
-        // here buffers persist and only grow.
-        const size_t want = frame_bytes > cap_bytes_ ? frame_bytes : cap_bytes_;
-        const bool flow = with_flow || cap_flow_;
-        release();
-        NUS_HIP(hipMalloc(reinterpret_cast<void **>(&d_a_), want));
-        NUS_HIP(hipMalloc(reinterpret_cast<void **>(&d_b_), want));
-        NUS_HIP(hipMalloc(reinterpret_cast<void **>(&d_out_), want));
-        NUS_HIP(hipHostMalloc(reinterpret_cast<void **>(&h_stage_), want * 3, hipHostMallocDefault));
-        if (flow) {
-            NUS_HIP(hipMalloc(reinterpret_cast<void **>(&d_flow_), want * 2));
-            NUS_HIP(hipHostMalloc(reinterpret_cast<void **>(&h_flow_), want * 2, hipHostMallocDefault));
-        }
-        cap_bytes_ = want;
-        cap_flow_ = flow;
-    }
-    return kOk;
-}
-
-int HipFrameInterpolator::interpolate(const uint8_t *a, size_t a_len, const uint8_t *b, size_t b_len, const float *flow,
-                                      uint32_t w, uint32_t h, float t, uint8_t *out, size_t out_cap)
-{
-    std::lock_guard<std::mutex> lk(mu_);
-    if (w == 0 || h == 0 || (uint64_t)w * h >= (1ull << 31)) return fail(kInvalidArgument, "interpolate: bad dimensions");
-    const size_t expected = (size_t)w * h * 4;
-    if (a_len != expected || b_len != expected)
-        // wgpu_interpolator.rs:234-237
-        return fail(kSizeMismatch, fmt("Expected %zu bytes per frame for %ux%ux4 RGBA, got frame_a: %zu bytes, frame_b: %zu bytes",
-                                       expected, w, h, a_len, b_len));
-    if (!a || !b || !out) return fail(kInvalidArgument, "interpolate: null frame pointer");
-    if (out_cap < expected) return fail(kInvalidArgument, "interpolate: output capacity too small");
-    int rc = ensure(expected, flow != nullptr);
-    if (rc != kOk) return rc;
-    uint8_t *ha = h_stage_, *hb = h_stage_ + cap_bytes_, *ho = h_stage_ + 2 * cap_bytes_;
-    // stage A, start its DMA, stage B meanwhile (the reference uploads both synchronously:
-    // wgpu_interpolator.rs:253-321)
-    parallel_copy(ha, a, expected);
-    NUS_HIP(hipMemcpyAsync(d_a_, ha, expected, hipMemcpyHostToDevice, stream_));
-    parallel_copy(hb, b, expected);
-    NUS_HIP(hipMemcpyAsync(d_b_, hb, expected, hipMemcpyHostToDevice, stream_));
-    if (flow) {
-        parallel_copy(h_flow_, flow, expected * 2);
-        NUS_HIP(hipMemcpyAsync(d_flow_, h_flow_, expected * 2, hipMemcpyHostToDevice, stream_));
-    }
-    WarpLaunch L;
-    L.a = d_a_;
-    L.b = d_b_;
-    L.flow = flow ? d_flow_ : nullptr;
-    L.out = d_out_;
-    L.a_stride = L.b_stride = expected;
-    L.w = w;
-    L.h = h;
-    L.t = t;
-    L.n_pairs = 1;
-    L.stream = stream_;
-    L.in_sel = input_selector(in_format_);
-    NUS_HIP(hipEventRecord(k_begin_, stream_));
-    hipError_t e = launch_warp_blend(L);
-    if (e != hipSuccess) return fail_hip(e, "warp+blend launch");
-    NUS_HIP(hipEventRecord(k_end_, stream_));
-    // the frame comes back in two halves: the host copy of the first overlaps the DMA of the second
-    const size_t half = (expected / 2 + 4095) & ~(size_t)4095;
-    const size_t first = half < expected ? half : expected;
-    NUS_HIP(hipMemcpyAsync(ho, d_out_, first, hipMemcpyDeviceToHost, stream_));
-    NUS_HIP(hipEventRecord(half_done_, stream_));
-    if (first < expected) NUS_HIP(hipMemcpyAsync(ho + first, d_out_ + first, expected - first, hipMemcpyDeviceToHost, stream_));
-    NUS_HIP(hipEventSynchronize(half_done_));
-    parallel_copy(out, ho, first);
-    NUS_HIP(hipStreamSynchronize(stream_));
-    if (first < expected) parallel_copy(out + first, ho + first, expected - first);
-    float ms = 0.0f;
-    if (hipEventElapsedTime(&ms, k_begin_, k_end_) == hipSuccess) {
-        have_ms_ = true;
-        last_ms_ = ms;
-    } else {
-        (void)hipGetLastError();
-    }
-    return kOk;
-}
-
-int HipFrameInterpolator::interpolate_device(const void *d_a, size_t a_stride, const void *d_b, size_t b_stride,
-                                             const void *d_flow, uint32_t w, uint32_t h, float t, void *d_out,
-                                             uint32_t n_pairs, hipStream_t stream)
-{
-    std::lock_guard<std::mutex> lk(mu_);
-    if (w == 0 || h == 0 || (uint64_t)w * h >= (1ull << 31)) return fail(kInvalidArgument, "interpolate_device: bad dimensions");
-    if (!d_a || !d_b || !d_out) return fail(kInvalidArgument, "interpolate_device: null device pointer");
-    if (n_pairs == 0) return kOk;
-    if ((reinterpret_cast<uintptr_t>(d_a) % 4) || (reinterpret_cast<uintptr_t>(d_b) % 4) ||
-        (reinterpret_cast<uintptr_t>(d_out) % 4) || (a_stride % 4) || (b_stride % 4) ||
-        (d_flow && reinterpret_cast<uintptr_t>(d_flow) % 8))
-        return fail(kInvalidArgument, "interpolate_device: pointers/strides must be pixel aligned");
-    const int n = device_count();
-    if (n <= 0) return fail(kNoDevice, "no HIP device available (the gfx950 path has no CPU fallback)");
-    NUS_HIP(hipSetDevice(device_));
-    WarpLaunch L;
-    L.a = static_cast<const uint8_t *>(d_a);
-    L.b = static_cast<const uint8_t *>(d_b);
-    L.flow = static_cast<const float *>(d_flow);
-    L.out = static_cast<uint8_t *>(d_out);
-    L.a_stride = a_stride;
-    L.b_stride = b_stride;
-    L.w = w;
-    L.h = h;
-    L.t = t;
-    L.n_pairs = n_pairs;
-    L.stream = stream;
-    L.in_sel = input_selector(in_format_);
-    hipError_t e = launch_warp_blend(L);
-    if (e != hipSuccess) return fail_hip(e, "warp+blend launch");
-    return kOk;
-}
-
-int HipFrameInterpolator::set_input_format(int format)
-{
-    std::lock_guard<std::mutex> lk(mu_);
-    if (format < 0 || format > 3) return fail(kInvalidArgument, "unknown input format");
-    in_format_ = format;
-    return kOk;
-}
-
-bool HipFrameInterpolator::last_gpu_ms(double *ms) const
-{
-    std::lock_guard<std::mutex> lk(mu_);
-    if (!have_ms_) return false;
-    if (ms) *ms = last_ms_;
-    return true;
 }
 
 } // namespace nus
