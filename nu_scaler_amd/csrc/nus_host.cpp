@@ -184,6 +184,95 @@ void HipUpscaler::release()
     have_ms_ = false;
 }
 
+// widest input-column footprint of a `segw`-column output segment (what one wave's LDS row / register columns must hold)
+uint32_t HipUpscaler::widest_footprint(uint32_t segw) const
+{
+    uint32_t widest = 0;
+    for (uint32_t x0 = 0; x0 < ow_; x0 += segw) {
+        const uint32_t xl = (x0 + segw < ow_ ? x0 + segw : ow_) - 1;
+        const uint32_t span = (uint32_t)(tx_.lz_left[xl] + (int32_t)tx_.lz_ntaps[xl] - tx_.lz_left[x0]);
+        if (span > widest) widest = span;
+    }
+    return widest;
+}
+
+// widest union of the 8-slot tap windows of `n` adjacent outputs (a lane's outputs in the union-window H pass); ow_ % n == 0
+uint32_t HipUpscaler::widest_union(uint32_t n) const
+{
+    uint32_t widest = 0;
+    for (uint32_t x0 = 0; x0 < ow_; x0 += n) {
+        const uint32_t u = (uint32_t)(tx_.lz_left[x0 + n - 1] - tx_.lz_left[x0]) + 8u;
+        if (u > widest) widest = u;
+    }
+    return widest;
+}
+
+// Kernel for the resize filters (Lanczos-3 / Catmull-Rom / Triangle), most specialised first.
+void HipUpscaler::choose_resize_variant(bool x2)
+{
+    variant_ = Variant::LanczosGeneral; // per-pixel fallback
+    xs_factor_ = 0;
+    resize_ncols_max_ = resize_union_taps_ = 0;
+    resize_small_taps_ = false;
+    win_outputs_per_lane_ = 4;
+    const bool addressable = (uint64_t)ow_ * oh_ * 4 < (1ull << 31); // buffer-resource addressing of the output frame
+    // exact x2: fixed interior weights; same ratio on both axes, so the two passes share the same 12 numbers
+    if (x2 && iw_ >= 16 && ih_ >= 16 && addressable && lanczos_x2_phase_frame(tx_, wx6_) && lanczos_x2_phase_frame(ty_, wy6_) &&
+        lanczos_x2_interior_uniform(tx_, wx6_) && lanczos_x2_interior_uniform(ty_, wy6_) &&
+        memcmp(&wx6_[(size_t)8 * 6], &wy6_[(size_t)8 * 6], 12 * sizeof(float)) == 0) {
+        variant_ = Variant::LanczosX2RegWin;
+        return;
+    }
+    // integer factors x3 / x4: the same register-window design (nus_k_lanczos_xs.hip), if the interior weights are uniform
+    for (uint32_t S = 3; S <= 4 && !force_general_; ++S) {
+        if (ow_ != S * iw_ || oh_ != S * ih_ || (iw_ % 4) != 0 || iw_ < 16 || ih_ < 16 || !addressable) continue;
+        if (lanczos_xs_phase_frame(tx_, S, wx6_) && lanczos_xs_phase_frame(ty_, S, wy6_) &&
+            lanczos_xs_interior_uniform(tx_, S, wx6_) && lanczos_xs_interior_uniform(ty_, S, wy6_) &&
+            memcmp(&wx6_[(size_t)8 * S * 6], &wy6_[(size_t)8 * S * 6], (size_t)S * 6 * sizeof(float)) == 0) {
+            xs_factor_ = S;
+            variant_ = Variant::LanczosXsRegWin;
+            return;
+        }
+    }
+    if (force_per_pixel_) return;
+    // vertical down-scaling: stream the input rows through 7 accumulator slots, if the windows allow it and a
+    // 64-column output segment's footprint fits 5 columns per lane
+    if (ih_ > oh_ && tx_.lz_max_taps <= 32 && !force_rows_) {
+        const uint32_t widest64 = widest_footprint(64);
+        if (build_down_stream_tables(ty_, down_rows_, down_done_) && widest64 <= 320) {
+            variant_ = Variant::ResizeDown;
+            resize_ncols_max_ = widest64;
+            return;
+        }
+    }
+    // LDS row kernel: the widest segment footprint must fit the per-wave LDS row (4 waves x 640 x 16 B = 40 KiB per block)
+    const uint32_t widest = widest_footprint((ow_ % 4) == 0 ? 256 : 64);
+    if (widest > 640) return;
+    variant_ = Variant::ResizeRows;
+    resize_ncols_max_ = widest;
+    resize_small_taps_ = tx_.lz_max_taps <= 8 && ty_.lz_max_taps <= 8;
+    if ((ow_ % 4) != 0 || !resize_small_taps_) return;
+    resize_union_taps_ = widest_union(4); // union-window H pass, 4 outputs per lane
+    // register-window variant: up-scaling shapes whose first tap row moves by at most one per output row
+    bool win_ok = ty_.lz_max_taps <= 7 && !force_rows_;
+    for (uint32_t y = 1; win_ok && y < oh_; ++y) {
+        const int32_t d = ty_.lz_left[y] - ty_.lz_left[y - 1];
+        win_ok = d == 0 || d == 1;
+    }
+    if (!win_ok) return;
+    if (widest <= 192) {
+        variant_ = Variant::ResizeWin;
+        return;
+    }
+    // factors x1.0 .. x1.4: two outputs per lane, segments of 128 output columns
+    const uint32_t widest2 = widest_footprint(128);
+    if (widest2 > 192) return;
+    variant_ = Variant::ResizeWin;
+    win_outputs_per_lane_ = 2;
+    resize_ncols_max_ = widest2;
+    resize_union_taps_ = widest_union(2);
+}
+
 void HipUpscaler::choose_variant()
 {
     const bool x2 = ow_ == 2 * iw_ && oh_ == 2 * ih_ && (iw_ % 4) == 0 && !force_general_;
@@ -207,96 +296,7 @@ void HipUpscaler::choose_variant()
     }
     case Algorithm::Lanczos3:
     case Algorithm::Bicubic:
-    case Algorithm::Triangle: {
-        bool ok = x2 && iw_ >= 16 && (uint64_t)ow_ * oh_ * 4 < (1ull << 31); // buffer-resource addressing
-        ok = ok && ih_ >= 16 && lanczos_x2_phase_frame(tx_, wx6_) && lanczos_x2_phase_frame(ty_, wy6_) &&
-             lanczos_x2_interior_uniform(tx_, wx6_) && lanczos_x2_interior_uniform(ty_, wy6_) &&
-             // same ratio on both axes: the interior weights of the two passes are the same 12 numbers
-             memcmp(&wx6_[(size_t)8 * 6], &wy6_[(size_t)8 * 6], 12 * sizeof(float)) == 0;
-        variant_ = ok ? Variant::LanczosX2RegWin : Variant::LanczosGeneral;
-        // integer factors x3 / x4: the same register-window design (nus_k_lanczos_xs.hip)
-        xs_factor_ = 0;
-        for (uint32_t S = 3; !ok && S <= 4 && !force_general_; ++S) {
-            if (ow_ != S * iw_ || oh_ != S * ih_ || (iw_ % 4) != 0 || iw_ < 16 || ih_ < 16 ||
-                (uint64_t)ow_ * oh_ * 4 >= (1ull << 31))
-                continue;
-            if (lanczos_xs_phase_frame(tx_, S, wx6_) && lanczos_xs_phase_frame(ty_, S, wy6_) &&
-                lanczos_xs_interior_uniform(tx_, S, wx6_) && lanczos_xs_interior_uniform(ty_, S, wy6_) &&
-                memcmp(&wx6_[(size_t)8 * S * 6], &wy6_[(size_t)8 * S * 6], (size_t)S * 6 * sizeof(float)) == 0) {
-                xs_factor_ = S;
-                variant_ = Variant::LanczosXsRegWin;
-                ok = true;
-            }
-        }
-        if (!ok && !force_per_pixel_) {
-            // vertical down-scaling: stream the input rows through 7 accumulator slots,
-            // if the windows allow it and a 64-column output segment's footprint fits 5 columns per lane
-            if (ih_ > oh_ && tx_.lz_max_taps <= 32 && !force_rows_) {
-                const bool down_ok = build_down_stream_tables(ty_, down_rows_, down_done_);
-                uint32_t widest64 = 0;
-                for (uint32_t x0 = 0; x0 < ow_; x0 += 64) {
-                    const uint32_t xl = (x0 + 64 < ow_ ? x0 + 64 : ow_) - 1;
-                    const uint32_t span = (uint32_t)(tx_.lz_left[xl] + (int32_t)tx_.lz_ntaps[xl] - tx_.lz_left[x0]);
-                    if (span > widest64) widest64 = span;
-                }
-                if (down_ok && widest64 <= 320) {
-                    variant_ = Variant::ResizeDown;
-                    resize_ncols_max_ = widest64;
-                    break;
-                }
-            }
-            // LDS row kernel: needs the widest segment footprint to fit the per-wave LDS row
-            const uint32_t segw = (ow_ % 4) == 0 ? 256 : 64;
-            uint32_t widest = 0;
-            for (uint32_t x0 = 0; x0 < ow_; x0 += segw) {
-                const uint32_t xl = (x0 + segw < ow_ ? x0 + segw : ow_) - 1;
-                const uint32_t span = (uint32_t)(tx_.lz_left[xl] + (int32_t)tx_.lz_ntaps[xl] - tx_.lz_left[x0]);
-                if (span > widest) widest = span;
-            }
-            if (widest <= 640) { // 4 waves x 640 x 16 B = 40 KiB of LDS per block
-                variant_ = Variant::ResizeRows;
-                resize_ncols_max_ = widest;
-                resize_small_taps_ = tx_.lz_max_taps <= 8 && ty_.lz_max_taps <= 8;
-                // widest union of the windows of a lane's 4 outputs (union-window H pass, 4 outputs per lane)
-                resize_union_taps_ = 0;
-                if ((ow_ % 4) == 0 && resize_small_taps_) {
-                    for (uint32_t x0 = 0; x0 < ow_; x0 += 4) {
-                        const uint32_t u = (uint32_t)(tx_.lz_left[x0 + 3] - tx_.lz_left[x0]) + 8u;
-                        if (u > resize_union_taps_) resize_union_taps_ = u;
-                    }
-                    // register-window variant: up-scaling shapes whose first tap row moves by at most one per output row
-                    bool win_ok = ty_.lz_max_taps <= 7 && !force_rows_;
-                    for (uint32_t y = 1; win_ok && y < oh_; ++y) {
-                        const int32_t d = ty_.lz_left[y] - ty_.lz_left[y - 1];
-                        win_ok = d == 0 || d == 1;
-                    }
-                    if (win_ok && widest <= 192) {
-                        variant_ = Variant::ResizeWin;
-                        win_outputs_per_lane_ = 4;
-                    } else if (win_ok) {
-                        // factors x1.0 .. x1.4: two outputs per lane, segments of 128 output columns
-                        uint32_t widest2 = 0, union2 = 0;
-                        for (uint32_t x0 = 0; x0 < ow_; x0 += 128) {
-                            const uint32_t xl = (x0 + 128 < ow_ ? x0 + 128 : ow_) - 1;
-                            const uint32_t span = (uint32_t)(tx_.lz_left[xl] + (int32_t)tx_.lz_ntaps[xl] - tx_.lz_left[x0]);
-                            if (span > widest2) widest2 = span;
-                        }
-                        for (uint32_t x0 = 0; x0 < ow_; x0 += 2) {
-                            const uint32_t u = (uint32_t)(tx_.lz_left[x0 + 1] - tx_.lz_left[x0]) + 8u;
-                            if (u > union2) union2 = u;
-                        }
-                        if (widest2 <= 192) {
-                            variant_ = Variant::ResizeWin;
-                            win_outputs_per_lane_ = 2;
-                            resize_ncols_max_ = widest2;
-                            resize_union_taps_ = union2;
-                        }
-                    }
-                }
-            }
-        }
-        break;
-    }
+    case Algorithm::Triangle: choose_resize_variant(x2); break;
     case Algorithm::Fsr1: variant_ = Variant::Fsr1Fused; break;
     case Algorithm::FsrEasu: variant_ = Variant::FsrEasu; break;
     case Algorithm::FsrRcas: variant_ = Variant::FsrRcas; break;

@@ -131,6 +131,9 @@ private:
     bool is_resize() const { return algorithm_ == Algorithm::Lanczos3 || algorithm_ == Algorithm::Bicubic || algorithm_ == Algorithm::Triangle; }
     ResizeFilter resize_filter() const;
     void choose_variant();
+    void choose_resize_variant(bool x2);
+    uint32_t widest_footprint(uint32_t segw) const;
+    uint32_t widest_union(uint32_t n) const;
     struct BlendSrc {
         const uint8_t *b = nullptr;
         size_t a_stride = 0, b_stride = 0;
