@@ -149,15 +149,19 @@ constexpr uint32_t kMaxGridZ = 65535;
 
 inline uint32_t cdiv(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
 
-// Frames go on grid.z (<= 65535 per launch); longer batches are issued in chunks.
-thread_local uint32_t g_chunk_first_frame = 0; // index of the chunk's first frame, for second inputs
+// Frames go on grid.z (<= 65535 per launch); longer batches are issued in chunks: f(in, out, n) per chunk.
+inline size_t launch_in_frame_bytes(const UpscaleLaunch &L) { return L.in_stride ? L.in_stride : (size_t)L.iw * L.ih * 4; }
+// index of the chunk's first frame (for kernels that take a second input per frame), from the chunk's input pointer
+inline size_t chunk_first_frame(const UpscaleLaunch &L, const uint8_t *chunk_in)
+{
+    return (size_t)(chunk_in - L.in) / launch_in_frame_bytes(L);
+}
 template <typename F>
 hipError_t for_frame_chunks(const UpscaleLaunch &L, F &&f)
 {
-    const size_t in_bytes = L.in_stride ? L.in_stride : (size_t)L.iw * L.ih * 4, out_bytes = (size_t)L.ow * L.oh * 4;
+    const size_t in_bytes = launch_in_frame_bytes(L), out_bytes = (size_t)L.ow * L.oh * 4;
     for (uint32_t done = 0; done < L.n_frames;) {
         const uint32_t n = L.n_frames - done < kMaxGridZ ? L.n_frames - done : kMaxGridZ;
-        g_chunk_first_frame = done;
         f(L.in + (size_t)done * in_bytes, L.out + (size_t)done * out_bytes, n);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;

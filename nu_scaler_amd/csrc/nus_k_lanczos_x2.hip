@@ -440,7 +440,7 @@ hipError_t launch_lanczos_x2(const UpscaleLaunch &L, const DeviceTables &T, bool
     static const uint32_t lds_pad = getenv("NUS_LDS_PAD_KB") ? (uint32_t)atoi(getenv("NUS_LDS_PAD_KB")) * 1024u : 0u;
     hipError_t e = for_frame_chunks(L, [&](const uint8_t *in, uint8_t *out, uint32_t n) {
         A.in = in;
-        A.in_b = L.in_b ? L.in_b + (size_t)g_chunk_first_frame * L.in_b_stride : nullptr;
+        A.in_b = L.in_b ? L.in_b + chunk_first_frame(L, in) * L.in_b_stride : nullptr;
         A.out = out;
         const dim3 block(256), grid(cdiv(nwaves, 4), n);
 #define NUS_LZ(E, B) hipLaunchKernelGGL((k_lanczos3_x2<E, B>), grid, block, lds_pad, L.stream, A)
@@ -472,7 +472,7 @@ hipError_t launch_lanczos_x2_edges(const UpscaleLaunch &L, const DeviceTables &T
     const int blend = L.in_b == nullptr ? 0 : (L.blend_t == 0.5f ? 1 : 2);
     return for_frame_chunks(L, [&](const uint8_t *in, uint8_t *out, uint32_t n) {
         A.in = in;
-        A.in_b = L.in_b ? L.in_b + (size_t)g_chunk_first_frame * L.in_b_stride : nullptr;
+        A.in_b = L.in_b ? L.in_b + chunk_first_frame(L, in) * L.in_b_stride : nullptr;
         A.out = out;
         const dim3 block(kWave), grid(cdiv(L.ih, kWave), 2, n);
 #define NUS_LZE(E, B) hipLaunchKernelGGL((k_lanczos3_x2_edges<E, B>), grid, block, 0, L.stream, A)
