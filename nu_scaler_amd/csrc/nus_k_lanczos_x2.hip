@@ -436,14 +436,12 @@ hipError_t launch_lanczos_x2(const UpscaleLaunch &L, const DeviceTables &T, bool
     A.sel = L.in_sel;
     const int blend = L.in_b == nullptr ? 0 : (L.blend_t == 0.5f ? 1 : 2);
     const uint32_t nwaves = A.nstrips * A.nrowblocks;
-    // dev knob: unused dynamic LDS per block, to study occupancy sensitivity (0 in production)
-    static const uint32_t lds_pad = getenv("NUS_LDS_PAD_KB") ? (uint32_t)atoi(getenv("NUS_LDS_PAD_KB")) * 1024u : 0u;
     hipError_t e = for_frame_chunks(L, [&](const uint8_t *in, uint8_t *out, uint32_t n) {
         A.in = in;
         A.in_b = L.in_b ? L.in_b + chunk_first_frame(L, in) * L.in_b_stride : nullptr;
         A.out = out;
         const dim3 block(256), grid(cdiv(nwaves, 4), n);
-#define NUS_LZ(E, B) hipLaunchKernelGGL((k_lanczos3_x2<E, B>), grid, block, lds_pad, L.stream, A)
+#define NUS_LZ(E, B) hipLaunchKernelGGL((k_lanczos3_x2<E, B>), grid, block, 0, L.stream, A)
         if (exact) {
             if (blend == 0) NUS_LZ(true, 0); else if (blend == 1) NUS_LZ(true, 1); else NUS_LZ(true, 2);
         } else {
