@@ -7,7 +7,7 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# NUS_LIB_PATH: dev override (timing-only ablation builds, tools/ablate.sh)
+# NUS_LIB_PATH: dev override (timing-only A/B builds, tools/lz_ab.sh)
 LIB_PATH = os.environ.get("NUS_LIB_PATH") or os.path.join(_HERE, "lib", "libnuscaler_hip.so")
 CSRC_DIR = os.path.join(_HERE, "csrc")
 
