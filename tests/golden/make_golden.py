@@ -56,6 +56,16 @@ def main():
     vec["warp_zero_t030"] = oracle.warp_blend(a, b, None, 0.3)
     vec["warp_flow_t050"] = oracle.warp_blend(a, b, flow, 0.5)
     vec["warp_flow_t025"] = oracle.warp_blend(a, b, flow, 0.25)
+    # "next rows" (SURVEY section 8f): the other resize filters, the x4 and down-scaling shapes, FSR1, the flow front end
+    small = oracle.gen_noise(24, 14, 0xBEEF)
+    vec["noise_24x14"] = small
+    vec["catmullrom_x2"] = oracle.resize(small, 48, 28, oracle.FILTER_CATMULLROM)
+    vec["triangle_x1p5"] = oracle.resize(small, 36, 21, oracle.FILTER_TRIANGLE)
+    vec["lanczos3_x4"] = oracle.lanczos3(small, 96, 56)
+    vec["lanczos3_half"] = oracle.lanczos3(noise, 24, 13)
+    vec["catmullrom_third"] = oracle.resize(noise, 16, 9, oracle.FILTER_CATMULLROM)
+    vec["fsr1_x2"] = oracle.fsr1(small, 48, 28, 0.0, 0.7)
+    vec["flow_l2_c5_r2"] = oracle.flow_estimate(a, b, 2, 5, 2, 0.02 ** 2)  # lambda: FlowEstimator's default
     np.savez_compressed(os.path.join(HERE, "oracle_vectors.npz"), **vec)
     print("wrote", len(vec), "arrays")
 

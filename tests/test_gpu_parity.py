@@ -187,6 +187,19 @@ def test_committed_oracle_vectors(nsc):
                        ("warp_flow_t025", flow, 0.25)):
         out = np.frombuffer(it.interpolate_py(a.tobytes(), b.tobytes(), w, h, time_t=t, flow=fl), np.uint8).reshape(h, w, 4)
         assert np.array_equal(out, v[key]), key
+    # next rows: EXACT mode reproduces the committed bytes, FMA mode stays within 1 LSB
+    small = v["noise_24x14"]
+    for alg, src, (ow, oh), key in (("bicubic", small, (48, 28), "catmullrom_x2"), ("triangle", small, (36, 21), "triangle_x1p5"),
+                                    ("lanczos3", small, (96, 56), "lanczos3_x4"), ("lanczos3", noise, (24, 13), "lanczos3_half"),
+                                    ("bicubic", noise, (16, 9), "catmullrom_third")):
+        assert np.array_equal(_up(nsc, alg, src, ow, oh, lanczos_mode="exact")[0], v[key]), key
+        assert _maxdiff(_up(nsc, alg, src, ow, oh)[0], v[key]) <= 1, key
+    u = nsc.PyWgpuUpscaler("quality", "fsr1")
+    u.set_sharpness(0.0, 0.7)
+    u.initialize(24, 14, 48, 28)
+    assert np.array_equal(np.frombuffer(u.upscale(small.tobytes()), np.uint8).reshape(28, 48, 4), v["fsr1_x2"])
+    fe = nsc.FlowEstimator(levels=2, coarse_iterations=5, refine_iterations=2)
+    assert np.array_equal(fe.estimate(a, b, w, h), v["flow_l2_c5_r2"])
 
 
 # ---- warp + blend ---------------------------------------------------------------------

@@ -94,6 +94,16 @@ def test_oracle_vectors_stable(oracle_mod):
     a, b, flow = v["warp_a"], v["warp_b"], v["warp_flow"]
     assert np.array_equal(v["warp_zero_t050"], oracle_mod.warp_blend(a, b, None, 0.5))
     assert np.array_equal(v["warp_flow_t025"], oracle_mod.warp_blend(a, b, flow, 0.25))
+    # next rows
+    small = v["noise_24x14"]
+    assert np.array_equal(small, oracle_mod.gen_noise(24, 14, 0xBEEF))
+    assert np.array_equal(v["catmullrom_x2"], oracle_mod.resize(small, 48, 28, oracle_mod.FILTER_CATMULLROM))
+    assert np.array_equal(v["triangle_x1p5"], oracle_mod.resize(small, 36, 21, oracle_mod.FILTER_TRIANGLE))
+    assert np.array_equal(v["lanczos3_x4"], oracle_mod.lanczos3(small, 96, 56))
+    assert np.array_equal(v["lanczos3_half"], oracle_mod.lanczos3(noise, 24, 13))
+    assert np.array_equal(v["catmullrom_third"], oracle_mod.resize(noise, 16, 9, oracle_mod.FILTER_CATMULLROM))
+    assert np.array_equal(v["fsr1_x2"], oracle_mod.fsr1(small, 48, 28, 0.0, 0.7))
+    assert np.array_equal(v["flow_l2_c5_r2"], oracle_mod.flow_estimate(a, b, 2, 5, 2, 0.02 ** 2))
 
 
 def test_lanczos_weights_sum_to_one_and_mirror(oracle_mod):
