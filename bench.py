@@ -9,20 +9,31 @@ Metric: Mpixels/s, input + output pixels of every kernel counted once each
 (26.9568 Mpix per unit).
 
   python bench.py --gpus N --steps K --warmup W
-  (N > 1: launched by torch.distributed.run, one rank per GPU, RCCL; frames are sharded
-   contiguously across ranks -- weak scaling, no data-path collective; the only
-   collective is the one-off broadcast of the filter tables.)
 
-Rank 0 prints ONE JSON line.  `roofline` is measured live for the dominant kernel
-(k_lanczos3_x2) with hipEvent pairs on the launch stream inside the timed region;
-`cpu_baseline` times the CPU oracle (a port of the reference's CPU algorithm -- the
-Rust reference cannot be built here) on a bounded sample of the same workload.
+N > 1: one rank per GPU over RCCL; frames are sharded contiguously across ranks (weak
+scaling, no data-path collective; the only collective is the one-off broadcast of the
+filter tables).  Launched by `python -m torch.distributed.run ... bench.py --gpus N`
+the ranks find WORLD_SIZE in the environment; started directly (`python bench.py --gpus 4`)
+this process only starts that launcher as a CHILD, relays rank 0's JSON line and the exit
+code, and never touches the GPU itself.
+
+Rank 0 prints ONE JSON line.  Inside it:
+  roofline       the dominant kernel (k_lanczos3_x2 + its edge-column pass), hipEvent pairs on
+                 the launch stream inside the timed region, against the 8 TB/s HBM peak;
+  cpu_baseline   the CPU oracle (a port of the reference's CPU algorithm -- the Rust reference
+                 cannot be built here), per algorithm, median of 10 after 2 warm-ups;
+  config.timed_output_check   frames of the TIMED output buffers compared with the oracle;
+  config.noise_variant        the same step on 4-channel noise (the kernel's other code path);
+  config.host_path            host bytes in -> host bytes out through the trait-shaped entry
+                              points (PCIe inclusive; never `value`).
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -33,7 +44,7 @@ if ROOT not in sys.path:
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 
 
-def parse_args():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -43,28 +54,64 @@ def parse_args():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--pattern", choices=["gradient", "noise"], default="gradient")
     ap.add_argument("--lanczos-mode", choices=["fma", "exact"], default="fma")
-    ap.add_argument("--cpu-baseline-units", type=int, default=-1,
-                    help="units timed on the CPU oracle; -1 = sized for ~15 s of single-thread work, 0 disables")
+    ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU oracle timing (N=1 only leg)")
     ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 --pmc traffic passes (N=1 only)")
     ap.add_argument("--no-profile", action="store_true", help="skip the in-loop hipEvent pairs")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the informational legs (fused / noise / motion / host path / copy ceiling)")
+    ap.add_argument("--no-check", action="store_true", help="skip the oracle check of the timed output buffers")
     ap.add_argument("--fused", action="store_true",
                     help="blend inside the second upscale's row loads (in-between frame never written to HBM); "
                          "same output frames, reported separately from the default 3-stage step")
     ap.add_argument("--overlap", action="store_true",
                     help="blend on a second stream, concurrent with the upscale of the real frames (measured: no gain, "
                          "the Lanczos kernel is SIMD-time bound and slows by what the blend takes)")
-    ap.add_argument("--motion", action="store_true",
-                    help="also time the motion-compensated step (per-pair pyramid + Horn-Schunck flow feeding the warp); "
-                         "informational leg config.motion_variant, never `value`")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo for rehearsal)")
     ap.add_argument("--force-device", type=int, default=-1,
                     help="rehearsal only: put every rank on this GPU (with --backend gloo on a 1-GPU box)")
-    return ap.parse_args()
+    return ap.parse_args(argv)
 
+
+# ---------------------------------------------------------------------------------------------
+# N > 1 started directly: launch the ranks as a child process tree (never exec, never touch HIP)
+# ---------------------------------------------------------------------------------------------
+
+def _free_port() -> int:
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_ranks(nproc: int, script: str, script_args, timeout=None):
+    """Start `python -m torch.distributed.run --nproc-per-node nproc script *script_args` as a child
+    process and wait for it.  Returns (returncode, [stdout lines]).  The caller has not imported
+    torch.cuda or loaded libnuscaler_hip.so: this process stays off the GPU, the ranks are its
+    grandchildren.  Rendezvous on 127.0.0.1 (the container hostname may not resolve)."""
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={int(nproc)}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), script, *script_args]
+    res = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True, timeout=timeout)
+    return res.returncode, res.stdout.splitlines()
+
+
+def main_launcher(args) -> int:
+    rc, lines = launch_ranks(args.gpus, os.path.abspath(__file__), sys.argv[1:])
+    for ln in lines:  # rank 0's JSON line (and nothing else: the ranks log to stderr)
+        print(ln, flush=True)
+    return rc
+
+
+# ---------------------------------------------------------------------------------------------
+# helpers of the worker
+# ---------------------------------------------------------------------------------------------
 
 def baseline_metric():
     """BASELINE.json's metric string, verbatim (the file ships with the repo)."""
-    fallback = "Mpixels/sec (in+out) at 1080p\u21924K \u00d72 upscale + interp, 1/2/4/8 GPU"
+    fallback = "Mpixels/sec (in+out) at 1080p→4K ×2 upscale + interp, 1/2/4/8 GPU"
     try:
         with open(os.path.join(ROOT, "BASELINE.json")) as f:
             return json.load(f).get("metric", fallback)
@@ -72,38 +119,75 @@ def baseline_metric():
         return fallback
 
 
+def _median(xs):
+    xs = sorted(xs)
+    n = len(xs)
+    return xs[n // 2] if n % 2 else 0.5 * (xs[n // 2 - 1] + xs[n // 2])
+
+
 def cpu_baseline(args, unit_pixels):
-    """Time the CPU oracle on a bounded sample of the same workload (single thread, as the
-    reference's BasicUpscaler runs; plus an all-cores OpenMP figure for context)."""
+    """Time the CPU oracle on the host cores of this box: every algorithm of the path on its own and the
+    combined unit, each as the median of 10 runs after 2 warm-ups, single
+    thread (how the reference's BasicUpscaler runs) and all cores (OpenMP row-parallel).
+    Bounded: a leg whose 12 runs would take more than ~4 s at full size runs on a strip of the frame
+    (full width, fewer rows -- every algorithm here is row-separable work); the rate is per pixel."""
     import oracle
 
     oracle.build()
     w, h = args.width, args.height
-
-    def run(n, threads):
-        frames = [oracle.gen_gradient(w, h, k) for k in range(n + 1)]
-        t0 = time.perf_counter()
-        for k in range(n):
-            mid = oracle.warp_blend(frames[k], frames[k + 1], None, 0.5, threads=threads)
-            oracle.lanczos3(frames[k], 2 * w, 2 * h, threads=threads)
-            oracle.lanczos3(mid, 2 * w, 2 * h, threads=threads)
-        return time.perf_counter() - t0
-
-    n = args.cpu_baseline_units
-    if n < 0:  # size the sample for ~15 s of single-thread work
-        t_unit = run(1, 1)
-        n = max(4, min(64, int(round(15.0 / max(t_unit, 1e-3)))))
-    t1 = run(n, 1)
+    a, b = oracle.gen_gradient(w, h, 0), oracle.gen_gradient(w, h, 1)
     cores = oracle.max_threads()
-    tn = run(n, 0) if cores > 1 else t1
+    t_start = time.perf_counter()
+
+    def timed(fn_of_rows, runs=10, warm=2, budget_s=4.0):
+        """fn_of_rows(rows) runs the leg on the top `rows` rows.  Returns (median seconds, rows used)."""
+        t0 = time.perf_counter()
+        fn_of_rows(h)
+        t_full = time.perf_counter() - t0
+        rows = h
+        if t_full * (runs + warm) > budget_s:
+            rows = max(64, int(h * budget_s / (t_full * (runs + warm))) // 8 * 8)
+        for _ in range(warm):
+            fn_of_rows(rows)
+        ts = []
+        for _ in range(runs):
+            t0 = time.perf_counter()
+            fn_of_rows(rows)
+            ts.append(time.perf_counter() - t0)
+        return _median(ts), rows
+
+    legs = {  # name -> (callable(rows, threads), in+out pixels per input row)
+        "nearest": (lambda r, th: oracle.nearest(a[:r], 2 * w, 2 * r, threads=th), 5 * w),
+        "bilinear": (lambda r, th: oracle.bilinear(a[:r], 2 * w, 2 * r, threads=th), 5 * w),
+        "lanczos3": (lambda r, th: oracle.lanczos3(a[:r], 2 * w, 2 * r, threads=th), 5 * w),
+        "warp_blend_zero_flow": (lambda r, th: oracle.warp_blend(a[:r], b[:r], None, 0.5, threads=th), 3 * w),
+    }
+    per_alg = {}
+    for name, (fn, pix_per_row) in legs.items():
+        t1, r1 = timed(lambda r: fn(r, 1))
+        tn, rn = timed(lambda r: fn(r, 0)) if cores > 1 else (t1, r1)
+        per_alg[name] = {"Mpix_per_s_1_thread": round(pix_per_row * r1 / t1 / 1e6, 1), "rows_1_thread": r1,
+                         "Mpix_per_s_all_cores": round(pix_per_row * rn / tn / 1e6, 1), "rows_all_cores": rn}
+
+    def unit(r, th):
+        mid = oracle.warp_blend(a[:r], b[:r], None, 0.5, threads=th)
+        oracle.lanczos3(a[:r], 2 * w, 2 * r, threads=th)
+        oracle.lanczos3(mid, 2 * w, 2 * r, threads=th)
+
+    unit_pix_per_row = unit_pixels / h
+    t1, r1 = timed(lambda r: unit(r, 1), budget_s=6.0)
+    tn, rn = timed(lambda r: unit(r, 0), budget_s=6.0) if cores > 1 else (t1, r1)
     return {
-        "value": round(n * unit_pixels / t1 / 1e6, 3),
+        "value": round(unit_pix_per_row * r1 / t1 / 1e6, 3),
         "unit": "Mpix/s",
         "cores": 1,
         "kind": "port",
-        "sample": f"{n} units of the same stream ({w}x{h}: zero-flow blend + 2x Lanczos-3 x2), oracle/nus_oracle.c "
-                  f"gcc -O2 -ffp-contract=off, {t1:.1f} s single thread",
-        "all_cores": {"value": round(n * unit_pixels / tn / 1e6, 3), "cores": cores, "seconds": round(tn, 2)},
+        "sample": f"the unit of the same stream (zero-flow blend + 2x Lanczos-3 x2) on the top {r1} rows of a {w}x{h} "
+                  f"frame pair, median of 10 runs after 2 warm-ups, {t1 * 1e3:.1f} ms per run; oracle/nus_oracle.c, "
+                  f"gcc -O2 -ffp-contract=off; per_algorithm: each algorithm alone, same protocol; "
+                  f"whole leg {time.perf_counter() - t_start:.1f} s",
+        "all_cores": {"value": round(unit_pix_per_row * rn / tn / 1e6, 3), "cores": cores, "rows": rn},
+        "per_algorithm": per_alg,
     }
 
 
@@ -116,7 +200,6 @@ def measure_traffic(frames_per_launch):
     import csv
     import glob
     import shutil
-    import subprocess
     import tempfile
 
     exe = shutil.which("rocprofv3")
@@ -133,14 +216,20 @@ def measure_traffic(frames_per_launch):
             res = subprocess.run(cmd, capture_output=True, text=True, timeout=240, cwd=tmp)
             if res.returncode != 0:
                 return None, f"rocprofv3 --pmc {counter} failed (rc {res.returncode})"
-            rows = []
+            rows = {"main": [], "edges": []}
             for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
                 for r in csv.DictReader(open(f)):
-                    if "k_lanczos3_x2<" in r["Kernel_Name"] and r["Counter_Name"] == counter:
-                        rows.append(float(r["Counter_Value"]))
-            if not rows:
+                    if r["Counter_Name"] != counter:
+                        continue
+                    if "k_lanczos3_x2<" in r["Kernel_Name"]:
+                        rows["main"].append(float(r["Counter_Value"]))
+                    elif "k_lanczos3_x2_edges<" in r["Kernel_Name"]:
+                        rows["edges"].append(float(r["Counter_Value"]))
+            if not rows["main"]:
                 return None, f"no {counter} rows for k_lanczos3_x2"
-            vals[counter] = sum(rows) / len(rows)
+            vals[counter] = sum(rows["main"]) / len(rows["main"])
+            if rows["edges"]:
+                vals[counter] += sum(rows["edges"]) / len(rows["edges"])
     except Exception as e:  # timeouts, missing files: traffic stays null
         return None, f"{type(e).__name__}: {e}"
     finally:
@@ -148,12 +237,81 @@ def measure_traffic(frames_per_launch):
     per_frame = (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0 / n_child
     detail = {"FETCH_SIZE_KiB_per_frame": round(vals["FETCH_SIZE"] / n_child, 1),
               "WRITE_SIZE_KiB_per_frame": round(vals["WRITE_SIZE"] / n_child, 1),
-              "fetch_correction": 2.0, "child_frames_per_launch": n_child}
+              "fetch_correction": 2.0, "child_frames_per_launch": n_child,
+              "kernels": "k_lanczos3_x2 + k_lanczos3_x2_edges"}
     return int(per_frame * frames_per_launch), detail
 
 
-def main():
-    args = parse_args()
+def check_timed_outputs(frames, up_real, up_mid, picks, w, h):
+    """Compare frames of the TIMED output buffers with the oracle (outside the timed region): the upscaled
+    real frame against oracle.lanczos3(frame k), the upscaled in-between frame against
+    oracle.lanczos3(oracle.warp_blend(frame k, frame k+1)).  Lanczos tolerance as in tests/: every sample
+    within 1 LSB and fewer than 0.1 % of the samples different.  Raises on mismatch."""
+    import numpy as np
+
+    import oracle
+
+    oracle.build()
+    report = []
+    for k in picks:
+        a = frames[k].cpu().numpy()
+        b = frames[k + 1].cpu().numpy()
+        mid = oracle.warp_blend(a, b, None, 0.5, threads=0)
+        for name, got_t, src in (("up_real", up_real, a), ("up_mid", up_mid, mid)):
+            want = oracle.lanczos3(src, 2 * w, 2 * h, threads=0).astype(np.int16)
+            got = got_t[k].cpu().numpy().astype(np.int16)
+            d = np.abs(got - want)
+            mx, frac = int(d.max()), float((d != 0).mean())
+            report.append({"frame": int(k), "buffer": name, "max_abs_diff": mx, "frac_differing": round(frac, 7)})
+            if mx > 1 or frac >= 1e-3:
+                raise SystemExit(f"bench.py: timed output {name}[{k}] differs from the oracle "
+                                 f"(max |diff| {mx}, {frac * 100:.4f} % of samples)")
+    return report
+
+
+def host_path_leg(nsc, syn, w, h, device):
+    """PCIe-inclusive rate through the trait-shaped host entry points (mode (ii) of BASELINE.md section 3):
+    `upscale(&[u8]) -> Vec<u8>` = nus_upscaler_upscale, `interpolate_py` = nus_interp_interpolate, host
+    buffers in and out.  Never `value`."""
+    frames = [syn.gradient_frame(w, h, k).tobytes() for k in range(12)]
+    u = nsc.PyWgpuUpscaler("quality", "lanczos3", device=device)
+    u.initialize(w, h, 2 * w, 2 * h)
+    out = bytearray(u.output_size)
+    for i in range(3):
+        u.upscale_into(frames[i], out)
+    ts = []
+    for i in range(12):
+        t0 = time.perf_counter()
+        u.upscale_into(frames[i % len(frames)], out)
+        ts.append(time.perf_counter() - t0)
+    up_ms = _median(ts) * 1e3
+    it = nsc.WgpuFrameInterpolator(device=device)
+    it.interpolate_py(frames[0], frames[1], w, h)
+    ts = []
+    for i in range(10):
+        t0 = time.perf_counter()
+        mid = it.interpolate_py(frames[i], frames[i + 1], w, h, time_t=0.5)
+        u.upscale_into(frames[i], out)
+        u.upscale_into(mid, out)
+        ts.append(time.perf_counter() - t0)
+    unit_ms = _median(ts) * 1e3
+    return {
+        "what": "host bytes in -> host bytes out through nus_upscaler_upscale / nus_interp_interpolate (PCIe and "
+                "staging copies included), one call at a time as the reference's GUI drives it; medians",
+        "upscale_1080p_to_4k_ms_per_frame": round(up_ms, 3),
+        "upscale_frames_per_s": round(1e3 / up_ms, 1),
+        "unit_ms": round(unit_ms, 3),
+        "unit_source_frames_per_s": round(1e3 / unit_ms, 1),
+        "unit_4k_output_frames_per_s": round(2e3 / unit_ms, 1),
+        "target_4k_output_frames_per_s": 60,
+    }
+
+
+# ---------------------------------------------------------------------------------------------
+# one rank
+# ---------------------------------------------------------------------------------------------
+
+def worker(args):
     import torch
     import torch.distributed as dist
 
@@ -163,6 +321,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE is {world}")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -189,14 +349,17 @@ def main():
     n_units = args.units
     start, count = nsc.shard_frames(n_units * world, world, rank)
     assert count == n_units
-    gen = syn.gradient_stream_torch if args.pattern == "gradient" else None
     frames = torch.empty((count + 1, h, w, 4), dtype=torch.uint8, device=dev)
-    for c0 in range(0, count + 1, 16):  # generate in chunks: int64 temporaries are 8x a frame
-        c1 = min(c0 + 16, count + 1)
-        if gen is not None:
-            frames[c0:c1] = gen(c1 - c0, w, h, dev, first=start + c0)
-        else:
-            frames[c0:c1] = syn.noise_stream_torch(c1 - c0, w, h, dev, seed=0x5EED + start + c0)
+
+    def fill(pattern):
+        for c0 in range(0, count + 1, 16):  # generate in chunks: int64 temporaries are 8x a frame
+            c1 = min(c0 + 16, count + 1)
+            if pattern == "gradient":
+                frames[c0:c1] = syn.gradient_stream_torch(c1 - c0, w, h, dev, first=start + c0)
+            else:
+                frames[c0:c1] = syn.noise_stream_torch(c1 - c0, w, h, dev, seed=0x5EED + start + c0)
+
+    fill(args.pattern)
     mid, up_real, up_mid = pipe.alloc(count, dev)
     stream = torch.cuda.current_stream().cuda_stream
 
@@ -229,29 +392,51 @@ def main():
         do_step()
     torch.cuda.synchronize()
     barrier()
-    elapsed = time.perf_counter() - t0
+    elapsed_local = time.perf_counter() - t0
 
     launches, kernel_ms = pipe.upscaler.profile_collect() if profile else (0, 0.0)
     pipe.upscaler.set_profiling(False)
 
-    # Informational second leg (never `value`): the same output frames with the blend fused into the
-    # second upscale's row loads, so the 1080p in-between frame is never written to HBM.
+    # max over ranks (and the spread, for the record)
+    per_rank = [elapsed_local]
+    if world > 1:
+        t = torch.tensor([elapsed_local], dtype=torch.float64, device=comm_dev)
+        gathered = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(gathered, t)
+        per_rank = [float(g.item()) for g in gathered]
+    elapsed = max(per_rank)
+
+    # The buffers the timed steps wrote, against the oracle -- before any other leg overwrites them.
+    timed_check = None
+    if rank == 0 and world == 1 and not args.no_check and args.pattern == "gradient" and args.lanczos_mode == "fma":
+        picks = sorted({0, count // 2 - 1 if count > 2 else 0, count - 1})
+        timed_check = {"tolerance": "max |diff| <= 1 LSB and < 0.1 % of samples differing (Lanczos FMA mode)",
+                       "frames": check_timed_outputs(frames, up_real, up_mid, picks, w, h)}
+    else:
+        # cheap sanity check: the outputs are fully written (alpha of the opaque stream stays 255)
+        assert args.pattern != "gradient" or (int(up_real[0, ..., 3].min()) == 255 and int(up_mid[count - 1, ..., 3].min()) == 255)
+
+    extras = rank == 0 and not args.no_extras and not args.fused and not args.overlap
+
+    # Informational (never `value`): same output frames with the blend fused into the second upscale's
+    # row loads, so the 1080p in-between frame is never written to HBM.
     fused_ms = None
-    if not args.fused and not args.overlap:
+    if extras:
         for _ in range(2):
             pipe.step_fused(frames, up_real, up_mid, stream)
         torch.cuda.synchronize()
         tf = time.perf_counter()
-        for _ in range(max(3, args.steps // 4)):
+        nf = max(3, args.steps // 4)
+        for _ in range(nf):
             pipe.step_fused(frames, up_real, up_mid, stream)
         torch.cuda.synchronize()
-        fused_ms = (time.perf_counter() - tf) / max(3, args.steps // 4) * 1e3
+        fused_ms = (time.perf_counter() - tf) / nf * 1e3
 
-    # Informational (never `value`): the on-box ceiling for these very bytes -- k_nearest_x2 reads the same
-    # 1080p frames and writes the same 4K frames with no arithmetic -- so roofline.frac can be read next
-    # to what the memory system of this box actually sustains, not only next to the 8 TB/s spec figure.
+    # Informational: the on-box ceiling for these very bytes -- k_nearest_x2 reads the same 1080p frames and
+    # writes the same 4K frames with no arithmetic -- so roofline.frac can be read next to what the memory
+    # system of this box sustains, not only next to the 8 TB/s spec figure.
     copy_ms = None
-    if rank == 0 and profile:
+    if extras and profile:
         nn = nsc.PyWgpuUpscaler("quality", "nearest", device=local_rank)
         nn.initialize(w, h, 2 * w, 2 * h)
         nn.set_profiling(True)
@@ -266,18 +451,9 @@ def main():
         copy_ms = nms / max(nl, 1)
         del nn
 
-    t = torch.tensor([elapsed], dtype=torch.float64, device=comm_dev)
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
-
-    # cheap sanity check outside the timed region: the stream is a 1 px/frame shift, so
-    # the outputs must differ between units and be fully written (alpha stays 255)
-    assert int(up_real[0, ..., 3].min()) == 255 and int(up_mid[count - 1, ..., 3].min()) == 255
-
-    # (after the check above: with a real flow the bilinear samples' truncation can take alpha to 254)
+    # Informational: the motion-compensated step (per-pair pyramid + Horn-Schunck flow feeding the warp)
     motion_ms = None
-    if args.motion and rank == 0:
+    if extras and world == 1:
         flows = torch.empty((count, h, w, 2), dtype=torch.float32, device=dev)
         pipe.step_motion(frames, flows, mid, up_real, up_mid, stream)
         torch.cuda.synchronize()
@@ -288,29 +464,65 @@ def main():
         motion_ms = (time.perf_counter() - tm) / 2 * 1e3
         del flows
 
+    # Informational: the same 3-stage step on the other pattern (gradient = opaque frames, the kernel's
+    # 3-channel path; noise = real alpha, its 4-channel path), with its own hipEvent bracket.
+    other = None
+    if extras and world == 1:
+        other_pattern = "noise" if args.pattern == "gradient" else "gradient"
+        fill(other_pattern)
+        for _ in range(2):
+            pipe.step(frames, mid, up_real, up_mid, stream)
+        torch.cuda.synchronize()
+        pipe.upscaler.set_profiling(profile)
+        pipe.upscaler.profile_collect()
+        no = max(3, args.steps // 4)
+        tn0 = time.perf_counter()
+        for _ in range(no):
+            pipe.step(frames, mid, up_real, up_mid, stream)
+        torch.cuda.synchronize()
+        o_ms = (time.perf_counter() - tn0) / no * 1e3
+        o_l, o_kms = pipe.upscaler.profile_collect() if profile else (0, 0.0)
+        pipe.upscaler.set_profiling(False)
+        other = (other_pattern, o_ms, o_l, o_kms)
+
+    host_path = None
+    if extras and world == 1:
+        del frames, mid, up_real, up_mid
+        torch.cuda.empty_cache()
+        host_path = host_path_leg(nsc, syn, w, h, local_rank)
 
     if rank == 0:
         total_units = n_units * world * args.steps
         value = total_units * pipe.unit_pixels / elapsed / 1e6
         up_bytes = (w * h + 4 * w * h) * 4  # algorithmic bytes of one upscaled frame
+
+        def roof(nl, kms):
+            achieved = up_bytes * count / (kms / 1e3 / nl) / 1e9
+            return achieved, round(achieved / HBM_PEAK_GBPS, 4), round(kms / nl, 4)
+
         roofline = None
         if launches:
-            per_launch_s = kernel_ms / 1e3 / launches
-            achieved = up_bytes * count / per_launch_s / 1e9
+            achieved, frac, avg_ms = roof(launches, kernel_ms)
             roofline = {
-                "bound": "hbm", "kernel": "k_lanczos3_x2", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
-                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
+                "bound": "hbm", "kernel": "k_lanczos3_x2 (+ k_lanczos3_x2_edges)", "achieved": round(achieved, 1),
+                "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": frac, "traffic": None,
                 "bytes_per_launch": up_bytes * count, "frames_per_launch": count, "launches": launches,
-                "avg_launch_ms": round(kernel_ms / launches, 4),
-                "note": "achieved = algorithmic bytes (8 294 400 R + 33 177 600 W per frame) / hipEvent time of the "
-                        "main kernel on its launch stream inside the timed region; traffic = (2*FETCH_SIZE + "
-                        "WRITE_SIZE)*1024 from separate rocprofv3 --pmc passes, scaled to frames_per_launch",
+                "avg_launch_ms": avg_ms, "pattern": args.pattern,
+                "note": "achieved = algorithmic bytes (8 294 400 R + 33 177 600 W per frame) / hipEvent time on the "
+                        "launch stream inside the timed region; the bracket holds BOTH launches that write the frames' "
+                        "bytes (the main kernel and its edge-column pass: rocprofv3 --stats shows them as two kernels); "
+                        "traffic = (2*FETCH_SIZE + WRITE_SIZE)*1024 of both from separate rocprofv3 --pmc passes, "
+                        "scaled to frames_per_launch",
             }
             if copy_ms:
                 ceiling = up_bytes * count / (copy_ms / 1e3) / 1e9
                 roofline["copy_ceiling"] = {
                     "GBps": round(ceiling, 1), "frac_of_ceiling": round(achieved / ceiling, 4),
                     "how": "k_nearest_x2 over the same frames (same bytes in and out, no arithmetic), hipEvent time"}
+            if other and other[2]:
+                o_ach, o_frac, o_avg = roof(other[2], other[3])
+                roofline["other_pattern"] = {"pattern": other[0], "achieved": round(o_ach, 1), "frac": o_frac,
+                                             "avg_launch_ms": o_avg}
         out = {
             "metric": baseline_metric(),
             "value": round(value, 1),
@@ -337,16 +549,27 @@ def main():
                             if args.overlap else "3 stages back to back on one stream",
                 "sharding": f"frame-parallel, contiguous shards, {world} rank(s), LUT broadcast {lut_bytes} B over "
                             f"{'RCCL' if nccl else args.backend}",
+                "lut_broadcast_bytes": lut_bytes,
+                "ms_per_step_by_rank": {"min": round(min(per_rank) / args.steps * 1e3, 4),
+                                        "max": round(max(per_rank) / args.steps * 1e3, 4)},
+                "timed_output_check": timed_check,
                 "fused_variant": None if fused_ms is None else {
                     "what": "same 4K outputs, blend fused into the second upscale (in-between frame not materialised); "
                             "informational, measured after the timed region on this rank only",
                     "ms_per_step": round(fused_ms, 4),
                     "Mpix_per_s_per_gpu_same_unit_pixels": round(n_units * pipe.unit_pixels / fused_ms / 1e3, 1)},
+                ("noise" if args.pattern == "gradient" else "gradient") + "_variant": None if other is None else {
+                    "what": f"the same 3-stage step on the {other[0]} stream (gradient = opaque frames, the x2 kernel's "
+                            f"3-channel path; noise = real alpha, its 4-channel path); informational, after the timed region",
+                    "ms_per_step": round(other[1], 4),
+                    "Mpix_per_s_per_gpu": round(n_units * pipe.unit_pixels / other[1] / 1e3, 1),
+                    "roofline_frac": None if not other[2] else roof(other[2], other[3])[1]},
                 "motion_variant": None if motion_ms is None else {
                     "what": "same step with a dense flow per pair (3-level pyramid, 50 + 10 + 10 Horn-Schunck steps) feeding "
                             "the warp instead of zero flow; informational, this rank only",
                     "ms_per_step": round(motion_ms, 3),
                     "units_per_s_per_gpu": round(n_units / motion_ms * 1e3, 1)},
+                "host_path": host_path,
                 "frames_per_sec_per_gpu_4k_out": round(2 * n_units * args.steps / elapsed, 1),
                 "algorithmic_GBps": round(total_units * pipe.unit_bytes / elapsed / 1e9, 1),
             },
@@ -356,12 +579,21 @@ def main():
             traffic, detail = measure_traffic(count)
             roofline["traffic"] = traffic
             roofline["traffic_detail"] = detail
-        if world == 1 and args.cpu_baseline_units != 0:
+        if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, pipe.unit_pixels)
         print(json.dumps(out), flush=True)
     if world > 1:
         barrier()
         dist.destroy_process_group()
+
+
+def main():
+    args = parse_args()
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(main_launcher(args))  # parent of the ranks: subprocess only, never the GPU
+    worker(args)
 
 
 if __name__ == "__main__":

@@ -112,18 +112,37 @@ class NuScalerLibraryError(ImportError):
     """libnuscaler_hip.so is missing or incomplete.  There is no CPU fallback."""
 
 
+def _source_digest() -> str:
+    """sha256 over the contents of every file the library is built from, in the order of the Makefile's
+    SRCS_ALL (content, not mtimes: a fresh checkout gives every file the same mtime, so timestamps cannot
+    tell a stale .so from a current one).  The Makefile writes the same digest next to the .so."""
+    import glob
+    import hashlib
+
+    names = []
+    for pat in ("*.hip", "*.cpp", "*.hpp", "cli/*.cpp", "cli/*.hpp"):
+        names += [os.path.relpath(f, CSRC_DIR) for f in glob.glob(os.path.join(CSRC_DIR, pat))]
+    names += ["Makefile", "../../include/nuscaler_hip.h"]
+    h = hashlib.sha256()
+    for n in sorted(set(names)):
+        with open(os.path.join(CSRC_DIR, n), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
 def build(force: bool = False) -> str:
-    """Compile libnuscaler_hip.so for gfx950 with hipcc (works without a GPU)."""
-    srcs = [os.path.join(CSRC_DIR, f) for f in os.listdir(CSRC_DIR)
-            if f.endswith((".hip", ".cpp", ".hpp"))]
-    srcs.append(os.path.join(_HERE, "..", "include", "nuscaler_hip.h"))
-    stale = (not os.path.exists(LIB_PATH)
-             or os.path.getmtime(LIB_PATH) < max(os.path.getmtime(s) for s in srcs))
-    if force or stale:
-        cmd = ["make", "-j4", "-C", CSRC_DIR] + (["-B"] if force else [])
-        res = subprocess.run(cmd, capture_output=True, text=True)
+    """Compile libnuscaler_hip.so for gfx950 with hipcc (works without a GPU).  The library is
+    rebuilt from scratch (`make -B`) unless the digest of the sources it was built from, kept
+    next to it, matches the sources on disk."""
+    stamp = LIB_PATH + ".srcsha256"
+    digest = _source_digest()
+    built_from = open(stamp).read().strip() if os.path.exists(stamp) else ""
+    if force or not os.path.exists(LIB_PATH) or built_from != digest:
+        res = subprocess.run(["make", "-j8", "-B", "-C", CSRC_DIR], capture_output=True, text=True)
         if res.returncode != 0:
             raise RuntimeError("building libnuscaler_hip.so failed:\n" + res.stdout + res.stderr)
+        if open(stamp).read().strip() != digest:
+            raise RuntimeError("Makefile and nu_scaler_amd._capi disagree on the source list (SRCS_ALL)")
     return LIB_PATH
 
 

@@ -420,7 +420,7 @@ int HipUpscaler::enqueue(const uint8_t *d_in, uint8_t *d_out, uint32_t n_frames,
         L.in_b_stride = blend->b_stride;
         L.blend_t = blend->t;
     }
-    // with profiling on, bracket the main kernel (not the Lanczos edge-column pass)
+    // with profiling on, bracket the frames' launches (main kernel and, for the x2 resize, its edge-column pass)
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
     if (profiling_) {
         if (prof_used_ + 2 > prof_events_.size()) {
@@ -472,12 +472,13 @@ int HipUpscaler::enqueue(const uint8_t *d_in, uint8_t *d_out, uint32_t n_frames,
     }
     }
     if (e != hipSuccess) return fail_hip(e, "kernel launch");
-    if (ev_end) NUS_HIP(hipEventRecord(ev_end, stream));
     if (lanczos_edges) {
         // first / last 8 output columns: renormalised edge weights, row-per-lane kernel
         e = launch_lanczos_x2_edges(L, dt_, lanczos_exact_);
         if (e != hipSuccess) return fail_hip(e, "kernel launch");
     }
+    // the bracket covers every launch that writes bytes of these frames (main kernel + edge columns)
+    if (ev_end) NUS_HIP(hipEventRecord(ev_end, stream));
     return kOk;
 }
 

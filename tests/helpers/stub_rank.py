@@ -1,0 +1,36 @@
+"""Stand-in for bench.py's worker under the launcher test: one rank of a gloo job on the CPU.
+Rank 0 prints ONE JSON line with what the launcher must relay."""
+import json
+import os
+import sys
+
+import torch
+import torch.distributed as dist
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+
+
+def main():
+    world = int(os.environ["WORLD_SIZE"])
+    rank = int(os.environ["RANK"])
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import nu_scaler_amd as nsc
+
+        blob = nsc.build_tables_blob(64, 36, 128, 72) if rank == 0 else b""
+        got = nsc.broadcast_blob(blob, src=0)
+        t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        start, count = nsc.shard_frames(10 * world, world, rank)
+        if "--fail" in sys.argv and rank == world - 1:
+            raise SystemExit(3)
+        if rank == 0:
+            print(json.dumps({"n_gpus": world, "max": float(t.item()), "lut": len(got), "argv": sys.argv[1:],
+                              "shard": [start, count]}), flush=True)
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -353,6 +353,40 @@ def test_config2_1080p_to_4k_lanczos(nsc, oracle_mod):
     assert (out_f == 173).all()
 
 
+def test_bench_launch_shape_1080p_batch_rows_per_wave_36(nsc, oracle_mod):
+    """The exact launch shape bench.py times: a device-resident batch at 1080p -> 4K with 36 input rows per
+    wave (what a 300-frame batch auto-selects, nus_host.cpp), on the opaque gradient stream (3-channel path)
+    and on noise (4-channel path), through upscale_device and through the fused upscale_blend_device."""
+    import torch
+
+    w, h, n = 1920, 1080, 8
+    dev = torch.device("cuda:0")
+    st = torch.cuda.current_stream().cuda_stream
+    for pattern in ("gradient", "noise"):
+        gen = (lambda k: oracle_mod.gen_gradient(w, h, k)) if pattern == "gradient" else (lambda k: oracle_mod.gen_noise(w, h, 900 + k))
+        frames_np = np.stack([gen(k) for k in range(n + 1)])
+        frames = torch.from_numpy(frames_np).to(dev)
+        u = nsc.PyWgpuUpscaler("quality", "lanczos3")
+        u.set_option("rows_per_wave", 36)
+        u.initialize(w, h, 2 * w, 2 * h)
+        assert u.kernel_variant == "lanczos3_x2_regwin"
+        out = torch.zeros((n, 2 * h, 2 * w, 4), dtype=torch.uint8, device=dev)
+        u.upscale_device(frames.data_ptr(), out.data_ptr(), n, st)
+        fused = torch.zeros((n, 2 * h, 2 * w, 4), dtype=torch.uint8, device=dev)
+        fb = w * h * 4
+        u.upscale_blend_device(frames.data_ptr(), fb, frames.data_ptr() + fb, fb, 0.5, fused.data_ptr(), n, st)
+        torch.cuda.synchronize()
+        for k in (0, 3, n - 1):
+            want = oracle_mod.lanczos3(frames_np[k], 2 * w, 2 * h, threads=0).astype(np.int16)
+            d = np.abs(out[k].cpu().numpy().astype(np.int16) - want)
+            assert d.max() <= 1 and (d > 0).mean() < 1e-3, (pattern, k, int(d.max()), float((d > 0).mean()))
+            mid = oracle_mod.warp_blend(frames_np[k], frames_np[k + 1], None, 0.5, threads=0)
+            want = oracle_mod.lanczos3(mid, 2 * w, 2 * h, threads=0).astype(np.int16)
+            d = np.abs(fused[k].cpu().numpy().astype(np.int16) - want)
+            assert d.max() <= 1 and (d > 0).mean() < 1e-3, (pattern, "fused", k, int(d.max()), float((d > 0).mean()))
+        del frames, out, fused
+
+
 def test_config3_1080p_interpolation(nsc, oracle_mod):
     a = oracle_mod.gen_gradient(1920, 1080, 0)
     b = oracle_mod.gen_gradient(1920, 1080, 1)
