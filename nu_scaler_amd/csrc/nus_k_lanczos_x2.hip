@@ -33,30 +33,108 @@ struct LanczosX2Args {
 // through HBM.  At t = 0.5 both products and the sum are exact and the truncation is a floor of a
 // half-integer: one v_lerp_u8 per pixel.
 
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
 template <int BLEND>
 struct RowRaw {
-    uint4 a, b;
+    u32x4 a, b;
 };
 template <>
 struct RowRaw<0> {
-    uint4 a;
+    u32x4 a;
 };
 
+// Row prefetches of the main loop.  gfx950 retires vector memory operations in issue order on ONE
+// counter (vmcnt) -- loads and stores together.  With ordinary loads the compiler, merging the three code
+// paths of a step (border rows / opaque rows / rows with alpha) around the loop's back edge, settled for
+// `s_waitcnt vmcnt(2)` / `vmcnt(3)` in front of every row conversion: each wave then drained all but its
+// two or three newest STORES once per step, one phase after issuing them, and the kernel's SIMD time and
+// its store time added up instead of overlapping (round 1: 0.47 of the HBM roofline).
+// So the prefetches are taken out of the compiler's sight and counted by hand:
+//  * a row is requested with an LDS-DMA load (global_load_lds_dwordx4: 16 B per lane straight into a
+//    per-wave 1-KiB LDS slot, no VGPR destination) issued from inline assembly -- the compiler's s_waitcnt
+//    insertion does not see it, and there is no destination register it could copy before the data is in;
+//  * before the slot is read (an ordinary ds_read_b128) the wave waits with a hand-counted
+//    `s_waitcnt vmcnt(N)`, N = the vector memory instructions issued since the row's request, which is the
+//    same on every path through a step (lanczos_x2_step); nothing else waits on vmcnt inside the loop.
+// tools/check_hidden_loads.py verifies both properties on the generated code (tests/test_kernel_asm.py).
+#ifndef NUS_LZ_ASM_LOADS
+#define NUS_LZ_ASM_LOADS 1 // dev macro: 0 = plain loads into registers, compiler-placed waits (A/B timing only)
+#endif
+#ifndef NUS_LZ_DEPTH
+#define NUS_LZ_DEPTH 2 // prefetch distance in steps (1, 2, 3 or 6: must divide the 6-way unrolled loop)
+#endif
+#ifndef NUS_LZ_WAIT_EARLY
+#define NUS_LZ_WAIT_EARLY 1 // 1: wait + LDS read between an even row's two passes (the read's latency hides behind the
+                            // horizontal pass); 0: after the even row's stores
+#endif
+#ifndef NUS_LZ_ABLATE
+#define NUS_LZ_ABLATE 0 // dev macro, timing only (wrong pixels): 1 no stores, 2 no arithmetic, 3 stores only (no loads either),
+                        // 5 every row request goes to the first 16 rows of frame 0 (cache hits), 6 no lane exchange, 7 no pack
+#endif
+constexpr int kLzDepth = NUS_LZ_DEPTH;
+static_assert(6 % kLzDepth == 0, "prefetch distance must divide 6");
+
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm" // m0 is a reserved register: nothing else in these kernels uses it
+// Request 16 B per lane from `base + off` (base wave-uniform, off < 4 GiB) into the 1-KiB LDS slot at
+// byte offset `lds` (wave-uniform): lane l lands at lds + 16 l.
+__device__ __forceinline__ void dma_row16(const uint8_t *base, uint32_t off, uint32_t lds)
+{
+    asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(off), "s"(base), "s"(lds) : "memory", "m0");
+}
+#pragma clang diagnostic pop
+
+// Wait until at most N of this wave's vector memory instructions are outstanding: in-order retirement, so
+// everything older than its N youngest has landed.  "memory": no load, store or LDS access moves across it.
+// BACK (for tools/check_hidden_loads.py): the wait is for the BACK-th most recent row request; 0 = all.
+template <int N, int BACK>
+__device__ __forceinline__ void wait_vmcnt()
+{
+    static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit counter on gfx9");
+    asm volatile("s_waitcnt vmcnt(%0) ; nus-wait back=%1" : : "n"(N), "n"(BACK) : "memory");
+}
+
+// LDS ring of one wave: kLzDepth slots of NL rows (NL = 2 when a pair is blended on load), 64 lanes x 16 B each.
 template <int BLEND>
-__device__ __forceinline__ RowRaw<BLEND> fetch_row(const uint8_t *pa, const uint8_t *pb, size_t off)
+struct RowRing {
+    static constexpr int NL = BLEND ? 2 : 1;
+    u32x4 (*slot)[64]; // [kLzDepth * NL][64], this wave's part of the block's LDS
+    uint32_t lds;      // its byte offset in LDS (wave-uniform)
+    int lane;
+
+    __device__ __forceinline__ void request(int k, const uint8_t *pa, const uint8_t *pb, uint32_t off) const
+    {
+        dma_row16(pa, off, lds + (uint32_t)(k * NL) * 1024u);
+        if constexpr (BLEND != 0) dma_row16(pb, off, lds + (uint32_t)(k * NL + 1) * 1024u);
+    }
+    __device__ __forceinline__ RowRaw<BLEND> read(int k) const
+    {
+        RowRaw<BLEND> r;
+        r.a = slot[k * NL][lane];
+        if constexpr (BLEND != 0) r.b = slot[k * NL + 1][lane];
+        return r;
+    }
+};
+
+// ordinary loads into registers (compiler-placed waits): the first window of a block, the edge kernel
+template <int BLEND>
+__device__ __forceinline__ RowRaw<BLEND> fetch_row_plain(const uint8_t *pa, const uint8_t *pb, size_t off)
 {
     RowRaw<BLEND> r;
-    r.a = *reinterpret_cast<const uint4 *>(pa + off);
-    if constexpr (BLEND != 0) r.b = *reinterpret_cast<const uint4 *>(pb + off);
+    r.a = *reinterpret_cast<const u32x4 *>(pa + off);
+    if constexpr (BLEND != 0) r.b = *reinterpret_cast<const u32x4 *>(pb + off);
     return r;
 }
+
+__device__ __forceinline__ uint4 as_uint4(const u32x4 v) { return make_uint4(v.x, v.y, v.z, v.w); }
 
 // (the blend is per channel, so the channel swizzle is applied once, to the blended pixel)
 template <int BLEND>
 __device__ __forceinline__ uint4 resolve_row(const RowRaw<BLEND> &r, float t, uint32_t sel)
 {
     if constexpr (BLEND == 0) {
-        return swz4(r.a, sel);
+        return swz4(as_uint4(r.a), sel);
     } else if constexpr (BLEND == 1) {
         return swz4(make_uint4(__builtin_amdgcn_lerp(r.a.x, r.b.x, 0u), __builtin_amdgcn_lerp(r.a.y, r.b.y, 0u),
                                __builtin_amdgcn_lerp(r.a.z, r.b.z, 0u), __builtin_amdgcn_lerp(r.a.w, r.b.w, 0u)), sel);
@@ -69,10 +147,16 @@ __device__ __forceinline__ uint4 resolve_row(const RowRaw<BLEND> &r, float t, ui
 
 __device__ __forceinline__ float lane_up(float v) // value of lane-1
 {
+#if NUS_LZ_ABLATE == 6
+    return v;
+#endif
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138 /*wave_shr:1*/, 0xF, 0xF, true));
 }
 __device__ __forceinline__ float lane_down(float v) // value of lane+1
 {
+#if NUS_LZ_ABLATE == 6
+    return v;
+#endif
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x130 /*wave_shl:1*/, 0xF, 0xF, true));
 }
 
@@ -123,6 +207,11 @@ __device__ __forceinline__ uint32_t row_is_opaque(const uint4 raw)
 template <bool EXACT, int BASE, bool ALPHA>
 __device__ __forceinline__ void lanczos_x2_vpass(const float (&win)[6][16], const float (&w)[6], float (&V)[16])
 {
+#if NUS_LZ_ABLATE == 2 || NUS_LZ_ABLATE == 3
+#pragma unroll
+    for (int k = 0; k < 16; ++k) V[k] = win[BASE % 6][k];
+    return;
+#endif
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
         if (!ALPHA && (k & 3) == 3) continue; // V[alpha] is not read by the 3-channel horizontal pass
@@ -150,13 +239,18 @@ __device__ __forceinline__ void lanczos_x2_vpass_edge(const float (&win)[6][16],
     }
 }
 
-// Horizontal pass of the lane's 8 output pixels, convert + pack, and the two 16-B stores.
+// Horizontal pass of the lane's 8 output pixels, convert + pack.
 template <bool EXACT, bool ALPHA>
-__device__ __forceinline__ void lanczos_x2_hpass_store(const float (&V)[16], const PhaseWeights &W,
-                                                       __amdgpu_buffer_rsrc_t rs, uint32_t off)
+__device__ __forceinline__ void lanczos_x2_hpass(const float (&V)[16], const PhaseWeights &W, uint32_t (&o)[8])
 {
     constexpr uint32_t a0 = ALPHA ? 0u : 0xFF000000u; // 3-channel path: opaque output
-    uint32_t o[8] = {a0, a0, a0, a0, a0, a0, a0, a0};
+#pragma unroll
+    for (int q = 0; q < 8; ++q) o[q] = a0;
+#if NUS_LZ_ABLATE == 2 || NUS_LZ_ABLATE == 3
+#pragma unroll
+    for (int q = 0; q < 8; ++q) o[q] = __float_as_uint(V[q]);
+    return;
+#endif
 #pragma unroll
     for (int c = 0; c < (ALPHA ? 4 : 3); ++c) {
         float e[10]; // vertical sums of input columns c0-3 .. c0+6 for this channel
@@ -179,70 +273,222 @@ __device__ __forceinline__ void lanczos_x2_hpass_store(const float (&V)[16], con
                 ae = mac<EXACT>(ae, e[m + j], W.e[j]);
                 ao = mac<EXACT>(ao, e[m + 1 + j], W.o[j]);
             }
+#if NUS_LZ_ABLATE == 7
+            o[2 * m] += __float_as_uint(ae);
+            o[2 * m + 1] += __float_as_uint(ao);
+#else
             o[2 * m] = pack_u8<EXACT>(ae, c, o[2 * m]);
             o[2 * m + 1] = pack_u8<EXACT>(ao, c, o[2 * m + 1]);
+#endif
         }
     }
-    // Buffer stores: lanes that must not write carry an offset beyond num_records and the
-    // hardware range check drops them.  Unlike an exec-masked store behind a branch the
-    // store instructions always issue, so the compiler can count them and wait for a
-    // prefetched input row with vmcnt(N) instead of draining every store with vmcnt(0).
-    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-    const u32x4 lo = {o[0], o[1], o[2], o[3]}, hi = {o[4], o[5], o[6], o[7]};
-    __builtin_amdgcn_raw_buffer_store_b128(lo, rs, off, 0, NUS_STORE_AUX);
-    __builtin_amdgcn_raw_buffer_store_b128(hi, rs, off + 16, 0, NUS_STORE_AUX);
+}
+
+// Where a wave's output row goes.  A lane computes 8 consecutive output pixels (32 B), but a store instruction in
+// which every lane writes 16 B at a 32-B stride leaves each 128-B line half written until the second
+// instruction fills the other half -- and on gfx950 such half-line writes, once HBM reads are in the mix,
+// cost almost twice the time of whole-line writes (tools/probe_rw_mix.hip: 10.4 vs 7.6 us per 1080p -> 4K
+// frame for the same bytes).  So the row's 2 KiB are turned round in LDS first -- each lane writes its 32 B at
+// 32 * lane, then reads 16 B at 16 * lane and at 1024 + 16 * lane -- and each store instruction writes one
+// contiguous KiB.  LDS instructions of one wave execute in order, so no barrier is involved.
+struct RowStore {
+    u32x4 *stage;          // this wave's 2 KiB of LDS (128 x 16 B)
+    uint32_t off_a, off_b; // byte offset of this lane's 16 B inside an output row for the two stores; pieces that
+                           // belong to halo lanes or to the edge kernel's columns sit at 2^31: the range check drops them
+    int lane;
+};
+
+#ifndef NUS_LZ_CONTIG_STORES
+#define NUS_LZ_CONTIG_STORES 1 // dev macro: 0 = each lane stores its own 2 x 16 B (A/B timing only)
+#endif
+
+// The two 16-B stores of an output row.  Buffer stores: lanes that must not write carry an offset beyond
+// num_records and the hardware range check drops them, so the store instructions issue on every path and
+// for every lane -- the hand-counted waits of the row prefetches (wait_vmcnt) rely on exactly two per phase.
+__device__ __forceinline__ void lanczos_x2_store(const uint32_t (&o)[8], __amdgpu_buffer_rsrc_t rs, const RowStore &st,
+                                                 uint32_t row_off)
+{
+#if NUS_LZ_ABLATE == 1
+#pragma unroll
+    for (int q = 0; q < 8; ++q) asm volatile("" : : "v"(o[q]));
+    return;
+#endif
+    u32x4 lo = {o[0], o[1], o[2], o[3]}, hi = {o[4], o[5], o[6], o[7]};
+#if NUS_LZ_CONTIG_STORES
+    st.stage[2 * st.lane] = lo;
+    st.stage[2 * st.lane + 1] = hi;
+    __builtin_amdgcn_wave_barrier(); // compiler only: the reads below see other lanes' writes (same wave, in-order LDS)
+    lo = st.stage[st.lane];
+    hi = st.stage[64 + st.lane];
+    __builtin_amdgcn_wave_barrier();
+#endif
+    __builtin_amdgcn_raw_buffer_store_b128(lo, rs, row_off + st.off_a, 0, NUS_STORE_AUX);
+    __builtin_amdgcn_raw_buffer_store_b128(hi, rs, row_off + st.off_b, 0, NUS_STORE_AUX);
+}
+
+#ifndef NUS_LZ_SPLIT_STORE
+#define NUS_LZ_SPLIT_STORE 0 // dev macro: 1 = pixel-half-outer horizontal pass, each 16-B store issued as soon as its 4 pixels exist
+#endif
+// Horizontal pass with the row's two stores spread: output pixels 0..3 (input columns m = 0, 1: taps e[0..7]) for
+// every channel, first store, then pixels 4..7 (m = 2, 3: taps e[2..9]), second store.
+template <bool EXACT, bool ALPHA>
+__device__ __forceinline__ void lanczos_x2_hpass_split(const float (&V)[16], const PhaseWeights &W, __amdgpu_buffer_rsrc_t rs,
+                                                       uint32_t off)
+{
+    constexpr uint32_t a0 = ALPHA ? 0u : 0xFF000000u;
+    constexpr int NC = ALPHA ? 4 : 3;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        uint32_t o[4] = {a0, a0, a0, a0};
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            float e[10];
+            e[0] = lane_up(V[1 * 4 + c]);
+            e[1] = lane_up(V[2 * 4 + c]);
+            e[2] = lane_up(V[3 * 4 + c]);
+            e[3] = V[0 * 4 + c];
+            e[4] = V[1 * 4 + c];
+            e[5] = V[2 * 4 + c];
+            e[6] = V[3 * 4 + c];
+            e[7] = lane_down(V[0 * 4 + c]);
+            e[8] = lane_down(V[1 * 4 + c]);
+            e[9] = lane_down(V[2 * 4 + c]);
+#pragma unroll
+            for (int mm = 0; mm < 2; ++mm) {
+                const int m = 2 * half + mm;
+                float ae = e[m] * W.e[0];
+                float ao = e[m + 1] * W.o[0];
+#pragma unroll
+                for (int j = 1; j < 6; ++j) {
+                    ae = mac<EXACT>(ae, e[m + j], W.e[j]);
+                    ao = mac<EXACT>(ao, e[m + 1 + j], W.o[j]);
+                }
+                o[2 * mm] = pack_u8<EXACT>(ae, c, o[2 * mm]);
+                o[2 * mm + 1] = pack_u8<EXACT>(ao, c, o[2 * mm + 1]);
+            }
+        }
+        const u32x4 v = {o[0], o[1], o[2], o[3]};
+        __builtin_amdgcn_raw_buffer_store_b128(v, rs, off + 16 * half, 0, NUS_STORE_AUX);
+    }
 }
 
 // One input row r -> output rows 2r (taps r-3..r+2) and 2r+1 (taps r-2..r+3).
-// At entry window slot (S+j)%6 holds input row r-3+j, j = 0..5, and raw[S&1] holds row r+3.
-// Row r-3 dies after the even phase, so row r+3 is converted into its slot BETWEEN the two
+// At entry window slot (S+j)%6 holds input row r-3+j, j = 0..5, and ring slot S % D holds row r+3 (requested D
+// steps ago).  Row r-3 dies after the even phase, so row r+3 is converted into its slot BETWEEN the two
 // phases: only 6 rows (96 VGPRs) are ever live, not 7.
+//
+// Vector memory instructions of a step, in issue order: 2 stores (even row), NL row requests (row r+3+D),
+// 2 stores (odd row) -- on every code path: the stores are range-checked buffer stores that always issue, and
+// they sit in the straight-line code after the paths have joined.  Issued since row r+3's requests when the
+// wave waits for it: the odd stores of step S-D (2), D-1 whole steps (4 + NL each) and, if the wait comes
+// after them, this step's even stores (2): N = 4 D + (D - 1) NL - (early ? 2 : 0).  Besides the row the wait
+// only covers stores at least D steps old.
 template <bool EXACT, int BLEND, int S>
-__device__ __forceinline__ void lanczos_x2_step(float (&win)[6][16], RowRaw<BLEND> (&raw)[2], uint32_t &opaque, int r, int cl,
-                                                uint32_t lane_off, const LanczosX2Args &A, const PhaseWeights &W,
-                                                const uint8_t *src, const uint8_t *src_b, __amdgpu_buffer_rsrc_t rs)
+__device__ __forceinline__ void lanczos_x2_step(float (&win)[6][16], const RowRing<BLEND> &ring, RowRaw<BLEND> (&raw)[2],
+                                                uint32_t &opaque, int r, uint32_t in_off, const RowStore &st,
+                                                const LanczosX2Args &A, const PhaseWeights &W, const uint8_t *src,
+                                                const uint8_t *src_b, __amdgpu_buffer_rsrc_t rs)
 {
+    constexpr int D = kLzDepth, NL = BLEND ? 2 : 1;
+    constexpr bool HIDDEN = NUS_LZ_ASM_LOADS != 0, EARLY = HIDDEN && NUS_LZ_WAIT_EARLY != 0;
     const uint32_t row_bytes = A.iw * 8; // output row: 2*iw pixels
-    const uint32_t off0 = lane_off + (uint32_t)(2 * r) * row_bytes;
+    const uint32_t off0 = (uint32_t)(2 * r) * row_bytes;
     const bool interior = r >= 4 && r + 5 <= (int)A.ih; // wave-uniform
     // The 3-channel path is compiled into the plain FMA-mode kernel only: there it measures -6 % on opaque
     // frames (profiles/r01_lanczos_opaque_path_ab.txt); in the blend variants the second code path costs
     // the third wave per SIMD (175 VGPRs) and more than it saves, and EXACT is the register-hungry debug mode.
     constexpr bool OP = !EXACT && BLEND == 0;
     float V[16];
+    uint32_t o[8];
+    RowRaw<BLEND> next; // row r+3
     // `opaque`: bit j = input row (newest - j) is opaque; the six newest rows are this phase's taps
-    if (!interior) {
+    const uint32_t path = !interior ? 0u : ((OP && (opaque & 0x3Fu) == 0x3Fu) ? 1u : 2u); // wave-uniform
+    if (path == 0)
         lanczos_x2_vpass_edge<EXACT, S>(win, A.wy6, 2 * (uint32_t)r, V);
-        lanczos_x2_hpass_store<EXACT, true>(V, W, rs, off0);
-    } else if (OP && (opaque & 0x3Fu) == 0x3Fu) { // wave-uniform
+    else if (path == 1)
         lanczos_x2_vpass<EXACT, S, false>(win, W.e, V);
-        lanczos_x2_hpass_store<EXACT, false>(V, W, rs, off0);
-    } else {
+    else
         lanczos_x2_vpass<EXACT, S, true>(win, W.e, V);
-        lanczos_x2_hpass_store<EXACT, true>(V, W, rs, off0);
+#if NUS_LZ_ABLATE == 1
+    if (EARLY) {
+        wait_vmcnt<(D - 1) * NL, (D - 1) * NL + 1>();
+        next = ring.read(S % D);
     }
-    // row r+3 in, then request row r+5 into the same buffer (consumed two steps from now;
-    // vmcnt retires in order, so that wait only sits behind stores at least a step old)
+#elif NUS_LZ_ABLATE == 3
+    next = RowRaw<BLEND>{};
+#else
+    if (EARLY) {
+        wait_vmcnt<4 * D + (D - 1) * NL - 2, (D - 1) * NL + 1>();
+        next = ring.read(S % D);
+    }
+#endif
+#if NUS_LZ_SPLIT_STORE
+    if (path == 1)
+        lanczos_x2_hpass_split<EXACT, false>(V, W, rs, off0 + st.off_a);
+    else
+        lanczos_x2_hpass_split<EXACT, true>(V, W, rs, off0 + st.off_a);
+#else
+    if (path == 1)
+        lanczos_x2_hpass<EXACT, false>(V, W, o);
+    else
+        lanczos_x2_hpass<EXACT, true>(V, W, o);
+    lanczos_x2_store(o, rs, st, off0); // after the paths have joined: straight-line code holds every memory instruction
+#endif
+    // row r+3 in, then request row r+3+D into the same slot
+    if (HIDDEN && !EARLY) {
+        wait_vmcnt<4 * D + (D - 1) * NL, (D - 1) * NL + 1>();
+        next = ring.read(S % D);
+    }
+    if (!HIDDEN) next = raw[S & 1];
     {
-        const uint4 px = resolve_row<BLEND>(raw[S & 1], A.t, A.sel);
+        const uint4 px = resolve_row<BLEND>(next, A.t, A.sel);
         if (OP) opaque = (opaque << 1) | row_is_opaque(px);
         cvt_row(px, win[S % 6]);
     }
     {
-        int rn = r + 5;
+        int rn = r + 3 + (HIDDEN ? D : 2);
         rn = rn < (int)A.ih - 1 ? rn : (int)A.ih - 1;
-        raw[S & 1] = fetch_row<BLEND>(src, src_b, ((size_t)rn * A.iw + cl) * 4);
+#if NUS_LZ_ABLATE == 5
+        const uint32_t off = in_off + (uint32_t)(rn & 15) * (A.iw * 4);
+        if (HIDDEN) ring.request(S % D, A.in, A.in, off);
+        else
+#elif NUS_LZ_ABLATE == 3
+        const uint32_t off = 0;
+        if (HIDDEN) {}
+        else
+#else
+        const uint32_t off = in_off + (uint32_t)rn * (A.iw * 4);
+        if (HIDDEN)
+            ring.request(S % D, src, src_b, off);
+        else
+#endif
+            raw[S & 1] = fetch_row_plain<BLEND>(src, src_b, off);
     }
-    if (!interior) {
+    const uint32_t path_o = !interior ? 0u : ((OP && (opaque & 0x3Fu) == 0x3Fu) ? 1u : 2u);
+#if NUS_LZ_SPLIT_STORE
+    if (path_o == 0) {
         lanczos_x2_vpass_edge<EXACT, S + 1>(win, A.wy6, 2 * (uint32_t)r + 1, V);
-        lanczos_x2_hpass_store<EXACT, true>(V, W, rs, off0 + row_bytes);
-    } else if (OP && (opaque & 0x3Fu) == 0x3Fu) {
+        lanczos_x2_hpass_split<EXACT, true>(V, W, rs, off0 + row_bytes + st.off_a);
+    } else if (path_o == 1) {
         lanczos_x2_vpass<EXACT, S + 1, false>(win, W.o, V);
-        lanczos_x2_hpass_store<EXACT, false>(V, W, rs, off0 + row_bytes);
+        lanczos_x2_hpass_split<EXACT, false>(V, W, rs, off0 + row_bytes + st.off_a);
     } else {
         lanczos_x2_vpass<EXACT, S + 1, true>(win, W.o, V);
-        lanczos_x2_hpass_store<EXACT, true>(V, W, rs, off0 + row_bytes);
+        lanczos_x2_hpass_split<EXACT, true>(V, W, rs, off0 + row_bytes + st.off_a);
     }
+#else
+    if (path_o == 0) {
+        lanczos_x2_vpass_edge<EXACT, S + 1>(win, A.wy6, 2 * (uint32_t)r + 1, V);
+        lanczos_x2_hpass<EXACT, true>(V, W, o);
+    } else if (path_o == 1) {
+        lanczos_x2_vpass<EXACT, S + 1, false>(win, W.o, V);
+        lanczos_x2_hpass<EXACT, false>(V, W, o);
+    } else {
+        lanczos_x2_vpass<EXACT, S + 1, true>(win, W.o, V);
+        lanczos_x2_hpass<EXACT, true>(V, W, o);
+    }
+    lanczos_x2_store(o, rs, st, off0 + row_bytes);
+#endif
 }
 
 // Exact x2 Lanczos-3.  One wave owns a strip of 256 input columns (4 per lane; lanes 0
@@ -269,21 +515,55 @@ __global__ __launch_bounds__(256) void k_lanczos3_x2(const LanczosX2Args A)
     const int c = (int)(strip * kLanczosX2StripCols) - 4 + lane * 4; // first input column of this lane
     int cl = c < 0 ? 0 : c;
     cl = cl > (int)A.iw - 4 ? (int)A.iw - 4 : cl;
-    const bool do_store = lane >= 1 && lane <= (int)(kLanczosX2StripCols / 4) && c >= 4 && c + 8 <= (int)A.iw;
     const uint8_t *src = A.in + (size_t)frame * A.in_frame_bytes;
     const uint8_t *src_b = BLEND ? A.in_b + (size_t)frame * A.in_b_frame_bytes : src;
-    // one buffer resource per output frame (< 2 GiB, checked by the host); non-storing lanes
-    // sit at offset 2^31, outside num_records for every row
+    // one buffer resource per output frame (< 2 GiB, checked by the host)
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
         A.out + (size_t)frame * A.out_frame_bytes, 0, (uint32_t)A.out_frame_bytes, 0x00020000);
-    const uint32_t lane_off = do_store ? (uint32_t)c * 8u : 0x80000000u;
+    // lane L computes the 8 output pixels of input columns c .. c+3; it stores them unless it is a halo lane or its
+    // columns are the edge kernel's
+    auto computes_stored_pixels = [&](int L) {
+        const int cc = (int)(strip * kLanczosX2StripCols) - 4 + L * 4;
+        return L >= 1 && L <= (int)(kLanczosX2StripCols / 4) && cc >= 4 && cc + 8 <= (int)A.iw;
+    };
+    RowStore st;
+    st.lane = lane;
+#if NUS_LZ_CONTIG_STORES
+    {
+        // after the turn in LDS this lane holds pixels 4 * lane .. +3 (first store) and 256 + 4 * lane .. +3 (second store) of
+        // the wave's 512-pixel span, i.e. half of what lanes lane / 2 and 32 + lane / 2 computed
+        const int span0 = ((int)(strip * kLanczosX2StripCols) - 4) * 8; // byte offset of the span in an output row (may be < 0)
+        st.off_a = computes_stored_pixels(lane >> 1) ? (uint32_t)(span0 + 16 * lane) : 0x80000000u;
+        st.off_b = computes_stored_pixels(32 + (lane >> 1)) ? (uint32_t)(span0 + 1024 + 16 * lane) : 0x80000000u;
+    }
+#else
+    st.off_a = computes_stored_pixels(lane) ? (uint32_t)c * 8u : 0x80000000u;
+    st.off_b = st.off_a + 16u;
+#endif
+    const uint32_t in_off = (uint32_t)cl * 4u; // the lane's byte offset inside an input row
     const int r0 = (int)(rb * A.th);
     const int r_end = (r0 + (int)A.th) < (int)A.ih ? (r0 + (int)A.th) : (int)A.ih;
     const int rmax = (int)A.ih - 1;
-    auto load_row = [&](int rr) {
+    auto row_off = [&](int rr) {
         rr = rr < 0 ? 0 : (rr > rmax ? rmax : rr);
-        return fetch_row<BLEND>(src, src_b, ((size_t)rr * A.iw + cl) * 4);
+        return in_off + (uint32_t)rr * (A.iw * 4);
     };
+    constexpr bool HIDDEN = NUS_LZ_ASM_LOADS != 0;
+    constexpr int NL = BLEND ? 2 : 1;
+    __shared__ u32x4 lds_rows[HIDDEN ? 4 : 1][HIDDEN ? kLzDepth * NL : 1][64];
+    RowRing<BLEND> ring;
+    {
+        const uint32_t w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+        ring.slot = lds_rows[HIDDEN ? w : 0];
+        ring.lds = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)&lds_rows[HIDDEN ? w : 0][0][0]);
+        ring.lane = lane;
+#if NUS_LZ_CONTIG_STORES
+        __shared__ u32x4 lds_stage[4][128]; // one output row (2 KiB) per wave, turned round between compute and store order
+        st.stage = lds_stage[w];
+#else
+        st.stage = nullptr;
+#endif
+    }
 
     PhaseWeights W;
 #pragma unroll
@@ -293,21 +573,42 @@ __global__ __launch_bounds__(256) void k_lanczos3_x2(const LanczosX2Args A)
     }
     float win[6][16];
     uint32_t opaque = 0;
+    RowRaw<BLEND> raw[2];
+    {
+        // the six rows of the first window (ordinary loads, all in flight together), then the first requests
+        RowRaw<BLEND> first[6];
 #pragma unroll
-    for (int j = 0; j < 6; ++j) {
-        const uint4 px = resolve_row<BLEND>(load_row(r0 - 3 + j), A.t, A.sel);
-        if (!EXACT && BLEND == 0) opaque = (opaque << 1) | row_is_opaque(px);
-        cvt_row(px, win[j]);
+        for (int j = 0; j < 6; ++j) first[j] = fetch_row_plain<BLEND>(src, src_b, row_off(r0 - 3 + j));
+        if (HIDDEN) {
+#pragma unroll
+            for (int j = 0; j < kLzDepth; ++j) ring.request(j, src, src_b, row_off(r0 + 3 + j));
+        } else {
+            raw[0] = fetch_row_plain<BLEND>(src, src_b, row_off(r0 + 3));
+            raw[1] = fetch_row_plain<BLEND>(src, src_b, row_off(r0 + 4));
+        }
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            const uint4 px = resolve_row<BLEND>(first[j], A.t, A.sel);
+            if (!EXACT && BLEND == 0) opaque = (opaque << 1) | row_is_opaque(px);
+            cvt_row(px, win[j]);
+        }
+        // the hand-counted waits of the loop assume that nothing older than its own instructions is outstanding
+        if (HIDDEN) wait_vmcnt<0, 0>();
     }
-    RowRaw<BLEND> raw[2] = {load_row(r0 + 3), load_row(r0 + 4)};
     for (int rbase = r0; rbase < r_end; rbase += 6) {
-        // 6-way unrolled so the rotating window indices are compile-time constants.
-        if (rbase + 0 < r_end) lanczos_x2_step<EXACT, BLEND, 0>(win, raw, opaque, rbase + 0, cl, lane_off, A, W, src, src_b, rs);
-        if (rbase + 1 < r_end) lanczos_x2_step<EXACT, BLEND, 1>(win, raw, opaque, rbase + 1, cl, lane_off, A, W, src, src_b, rs);
-        if (rbase + 2 < r_end) lanczos_x2_step<EXACT, BLEND, 2>(win, raw, opaque, rbase + 2, cl, lane_off, A, W, src, src_b, rs);
-        if (rbase + 3 < r_end) lanczos_x2_step<EXACT, BLEND, 3>(win, raw, opaque, rbase + 3, cl, lane_off, A, W, src, src_b, rs);
-        if (rbase + 4 < r_end) lanczos_x2_step<EXACT, BLEND, 4>(win, raw, opaque, rbase + 4, cl, lane_off, A, W, src, src_b, rs);
-        if (rbase + 5 < r_end) lanczos_x2_step<EXACT, BLEND, 5>(win, raw, opaque, rbase + 5, cl, lane_off, A, W, src, src_b, rs);
+        // 6-way unrolled so the rotating window indices are compile-time constants.  The block leaves the loop
+        // after its last row: a step is never skipped with a later one still to run, so every path through
+        // the loop carries the vector memory instructions the hand-counted waits assume.
+#define NUS_LZ_STEP(S) \
+        lanczos_x2_step<EXACT, BLEND, S>(win, ring, raw, opaque, rbase + S, in_off, st, A, W, src, src_b, rs); \
+        if (S < 5 && rbase + S + 1 >= r_end) break
+        NUS_LZ_STEP(0);
+        NUS_LZ_STEP(1);
+        NUS_LZ_STEP(2);
+        NUS_LZ_STEP(3);
+        NUS_LZ_STEP(4);
+        NUS_LZ_STEP(5);
+#undef NUS_LZ_STEP
     }
 }
 
@@ -405,8 +706,8 @@ __global__ __launch_bounds__(64) void k_lanczos3_x2_edges(const LanczosX2EdgeArg
         int rr = r - 3 + j;
         rr = rr < 0 ? 0 : (rr > rmax ? rmax : rr);
         const size_t off = ((size_t)rr * A.iw + col0) * 4;
-        raw[j][0] = resolve_row<BLEND>(fetch_row<BLEND>(src, src_b, off), A.t, A.sel);
-        raw[j][1] = resolve_row<BLEND>(fetch_row<BLEND>(src, src_b, off + 16), A.t, A.sel);
+        raw[j][0] = resolve_row<BLEND>(fetch_row_plain<BLEND>(src, src_b, off), A.t, A.sel);
+        raw[j][1] = resolve_row<BLEND>(fetch_row_plain<BLEND>(src, src_b, off + 16), A.t, A.sel);
     }
     if (side == 0)
         lanczos_x2_edge_rows<EXACT, 0>(A, raw, r, dst);

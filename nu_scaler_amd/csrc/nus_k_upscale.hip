@@ -54,24 +54,32 @@ __global__ __launch_bounds__(256) void k_nearest_table(
     }
 }
 
-// Exact x2 (ow == 2*iw, oh == 2*ih, iw % 4 == 0): each lane reads 4 input pixels
-// (16 B) and writes the 2x2 replication as four 16-B stores.
+// Exact x2 (ow == 2*iw, oh == 2*ih, iw % 4 == 0).  A wave covers 256 input pixels of one row = 512 output pixels
+// of two rows.  Lane L takes input pixels 2L, 2L+1 and 128 + 2L, 128 + 2L + 1 of that span (two 8-B loads), so
+// that its two 16-B stores per output row land at 16 L and at 1024 + 16 L: every store instruction of the
+// wave writes ONE CONTIGUOUS KiB.  The obvious mapping -- 4 adjacent input pixels per lane, two 16-B stores at
+// a 32-B lane stride -- leaves every 128-B line half written until the second instruction arrives, which on
+// gfx950 costs a write-heavy stream with reads in it a third of its rate (tools/probe_rw_mix.hip).
 __global__ __launch_bounds__(256) void k_nearest_x2(
     const uint32_t *__restrict__ in, uint32_t *__restrict__ out,
     uint32_t iw, uint32_t ih, size_t in_frame_px, size_t out_frame_px, uint32_t sel)
 {
     const uint32_t r = __builtin_amdgcn_readfirstlane(blockIdx.y * 4 + threadIdx.y);
-    const uint32_t k = (blockIdx.x * kWave + threadIdx.x) * 4;
-    if (r >= ih || k >= iw) return;
+    const uint32_t k0 = blockIdx.x * 256;
+    if (r >= ih) return;
     const uint32_t ow = iw * 2;
-    const uint4 p = swz4(*reinterpret_cast<const uint4 *>(in + (size_t)blockIdx.z * in_frame_px + (size_t)r * iw + k), sel);
-    const uint4 o0 = make_uint4(p.x, p.x, p.y, p.y);
-    const uint4 o1 = make_uint4(p.z, p.z, p.w, p.w);
-    uint32_t *d = out + (size_t)blockIdx.z * out_frame_px + (size_t)(2 * r) * ow + 2 * k;
-    *reinterpret_cast<uint4 *>(d) = o0;
-    *reinterpret_cast<uint4 *>(d + 4) = o1;
-    *reinterpret_cast<uint4 *>(d + ow) = o0;
-    *reinterpret_cast<uint4 *>(d + ow + 4) = o1;
+    const uint32_t *src = in + (size_t)blockIdx.z * in_frame_px + (size_t)r * iw;
+    uint32_t *d = out + (size_t)blockIdx.z * out_frame_px + (size_t)(2 * r) * ow;
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        const uint32_t k = k0 + 128 * g + 2 * threadIdx.x;
+        if (k >= iw) continue;
+        const uint2 p2 = *reinterpret_cast<const uint2 *>(src + k);
+        const uint32_t p0 = swz(p2.x, sel), p1 = swz(p2.y, sel);
+        const uint4 o = make_uint4(p0, p0, p1, p1);
+        *reinterpret_cast<uint4 *>(d + 2 * k) = o;
+        *reinterpret_cast<uint4 *>(d + ow + 2 * k) = o;
+    }
 }
 
 // ---------------------------------------------------------------------------------
@@ -197,6 +205,10 @@ __device__ __forceinline__ uint32_t avg4_u8x4(uint32_t a, uint32_t b, uint32_t c
 // of common.rs:221-226 is exact in f32 and the truncation is a floor of a quarter
 // multiple, so the result equals these packed-u8 integer averages byte for byte
 // (requires (ow-1)*iw < 2^24 so that x*iw/ow is exact; checked by the host).
+// (The two-groups-per-lane mapping of k_nearest_x2, which makes every store instruction one contiguous KiB, was measured
+// here too -- with 8-B + 4-B loads and with one 12-B buffer load per group and row -- and lost 4-7 % to this form on two
+// boxes: profiles/r02_x2_store_shape_ab.txt.  These waves live for one row; the half-line stores that cost the
+// row-walking resize kernel a third of its rate do not cost them.)
 // Each lane: 4 input pixels of rows r and r+1 -> 8x2 output pixels.
 __global__ __launch_bounds__(256) void k_bilinear_x2_int(
     const uint32_t *__restrict__ in, uint32_t *__restrict__ out,
