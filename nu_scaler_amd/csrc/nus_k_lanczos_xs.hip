@@ -80,9 +80,20 @@ __device__ __forceinline__ void xs_vpass(const float (&win)[6][16], const W &w, 
 // Horizontal pass of one output row: the lane's 4 S output pixels (4 input columns x S phases),
 // convert + pack, S 16-B stores.  Output pixel S m + p reads frame columns m + delta_p .. m + delta_p + 5
 // of e[] (e[3] is the lane's own first column).
+// Where a wave's output row goes: as in the x2 kernel (RowStore there) the row's S KiB are turned round in LDS --
+// every lane writes the 16 S bytes it computed at 16 S * lane, then reads 16 B at 1024 q + 16 * lane for store q --
+// so that each store instruction writes one contiguous KiB instead of a 16-B piece of every 16 S bytes
+// (tools/probe_rw_mix.hip: partly written lines cost a write-heavy stream with reads in it a third of its rate).
+template <int S>
+struct XsStore {
+    uint4 *stage;    // this wave's S KiB of LDS
+    uint32_t off[S]; // byte offset of this lane's 16 B inside an output row, per store; 2^31 = dropped by the range check
+    int lane;
+};
+
 template <bool EXACT, int S>
 __device__ __forceinline__ void xs_hpass_store(const float (&V)[16], const float (&W)[S][6],
-                                               __amdgpu_buffer_rsrc_t rs, uint32_t off, bool skip_alpha)
+                                               __amdgpu_buffer_rsrc_t rs, const XsStore<S> &st, uint32_t row_off, bool skip_alpha)
 {
     // skip_alpha (FMA mode, wave-uniform): the six tap rows are opaque in this wave, so alpha is the constant
     // 255 (see row_is_opaque in nus_k_lanczos_x2.hip); v_cvt_pk_u8_f32 only ever replaces bytes 0..2 then
@@ -114,13 +125,18 @@ __device__ __forceinline__ void xs_hpass_store(const float (&V)[16], const float
             }
         }
     }
-    // range-checked buffer stores: lanes that must not write sit beyond num_records (see the x2 kernel)
+    // range-checked buffer stores: pieces that must not be written sit beyond num_records (see the x2 kernel)
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 #pragma unroll
+    for (int q = 0; q < S; ++q) st.stage[S * st.lane + q] = make_uint4(o[4 * q], o[4 * q + 1], o[4 * q + 2], o[4 * q + 3]);
+    __builtin_amdgcn_wave_barrier(); // compiler only: same wave, LDS instructions execute in order
+#pragma unroll
     for (int q = 0; q < S; ++q) {
-        const u32x4 v = {o[4 * q], o[4 * q + 1], o[4 * q + 2], o[4 * q + 3]};
-        __builtin_amdgcn_raw_buffer_store_b128(v, rs, off + 16 * q, 0, NUS_STORE_AUX);
+        const uint4 t = st.stage[64 * q + st.lane];
+        const u32x4 v = {t.x, t.y, t.z, t.w};
+        __builtin_amdgcn_raw_buffer_store_b128(v, rs, row_off + st.off[q], 0, NUS_STORE_AUX);
     }
+    __builtin_amdgcn_wave_barrier();
 }
 
 // One input row r -> output rows S r .. S r + S - 1.  At entry window row j holds input row r-3+j,
@@ -128,13 +144,13 @@ __device__ __forceinline__ void xs_hpass_store(const float (&V)[16], const float
 // the step's code instead of six (at S = 4 six copies are ~16k instructions, more than the instruction
 // cache), for 80 register moves per step that is 3 % of its work.
 template <bool EXACT, int S>
-__device__ __forceinline__ void xs_step(float (&win)[6][16], uint4 &raw0, uint4 &raw1, int r, int cl, uint32_t lane_off,
+__device__ __forceinline__ void xs_step(float (&win)[6][16], uint4 &raw0, uint4 &raw1, int r, int cl, const XsStore<S> &st,
                                         const LanczosXsArgs &A, const float (&W)[S][6], const uint8_t *src,
                                         __amdgpu_buffer_rsrc_t rs, uint32_t &opaque)
 {
     typedef const __attribute__((address_space(4))) float *cfloat_p;
     const uint32_t row_bytes = A.iw * 4 * S; // one output row
-    const uint32_t off0 = lane_off + (uint32_t)(S * r) * row_bytes;
+    const uint32_t off0 = (uint32_t)(S * r) * row_bytes;
     const bool interior = r >= 4 && r + 5 <= (int)A.ih; // wave-uniform
     float V[16];
 #pragma unroll
@@ -150,7 +166,7 @@ __device__ __forceinline__ void xs_step(float (&win)[6][16], uint4 &raw0, uint4 
                 cfloat_p wt = (cfloat_p)(uintptr_t)(A.wy6 + (size_t)__builtin_amdgcn_readfirstlane((uint32_t)(S * r + p)) * 6);
                 xs_vpass<EXACT>(win, wt, V, skip_alpha);
             }
-            xs_hpass_store<EXACT, S>(V, W, rs, off0 + (uint32_t)p * row_bytes, skip_alpha);
+            xs_hpass_store<EXACT, S>(V, W, rs, st, off0 + (uint32_t)p * row_bytes, skip_alpha);
         }
         if (half == 0) {
             // row r-3 out, row r+3 in; then request row r+5
@@ -187,11 +203,25 @@ __global__ __launch_bounds__(256) void k_lanczos3_xs(const LanczosXsArgs A)
     const int c = (int)(strip * kLanczosX2StripCols) - 4 + lane * 4; // first input column of this lane
     int cl = c < 0 ? 0 : c;
     cl = cl > (int)A.iw - 4 ? (int)A.iw - 4 : cl;
-    const bool do_store = lane >= 1 && lane <= (int)(kLanczosX2StripCols / 4) && c >= 4 && c + 8 <= (int)A.iw;
     const uint8_t *src = A.in + (size_t)frame * A.in_frame_bytes;
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
         A.out + (size_t)frame * A.out_frame_bytes, 0, (uint32_t)A.out_frame_bytes, 0x00020000);
-    const uint32_t lane_off = do_store ? (uint32_t)c * 4u * S : 0x80000000u;
+    // lane L computes the 4 S output pixels of input columns c .. c+3 and they are stored unless it is a halo lane or its
+    // columns are the edge kernel's; after the turn in LDS this lane holds, for store q, 16 B computed by lane (64 q + lane) / S
+    auto computes_stored_pixels = [&](int L) {
+        const int cc = (int)(strip * kLanczosX2StripCols) - 4 + L * 4;
+        return L >= 1 && L <= (int)(kLanczosX2StripCols / 4) && cc >= 4 && cc + 8 <= (int)A.iw;
+    };
+    __shared__ uint4 lds_stage[4][64 * S];
+    XsStore<S> st;
+    st.stage = lds_stage[__builtin_amdgcn_readfirstlane(threadIdx.x >> 6)];
+    st.lane = lane;
+    {
+        const int span0 = ((int)(strip * kLanczosX2StripCols) - 4) * 4 * S; // byte offset of the wave's span in an output row
+#pragma unroll
+        for (int q = 0; q < S; ++q)
+            st.off[q] = computes_stored_pixels((64 * q + lane) / S) ? (uint32_t)(span0 + 1024 * q + 16 * lane) : 0x80000000u;
+    }
     const int r0 = (int)(rb * A.th);
     const int r_end = (r0 + (int)A.th) < (int)A.ih ? (r0 + (int)A.th) : (int)A.ih;
     const int rmax = (int)A.ih - 1;
@@ -217,7 +247,7 @@ __global__ __launch_bounds__(256) void k_lanczos3_xs(const LanczosXsArgs A)
         cvt_row(px, win[j]);
     }
     uint4 raw0 = load_row(r0 + 3), raw1 = load_row(r0 + 4);
-    for (int r = r0; r < r_end; ++r) xs_step<EXACT, S>(win, raw0, raw1, r, cl, lane_off, A, W, src, rs, opaque);
+    for (int r = r0; r < r_end; ++r) xs_step<EXACT, S>(win, raw0, raw1, r, cl, st, A, W, src, rs, opaque);
 }
 
 // The 4 S left-most and right-most output columns (tap windows cut by the image border, weights
