@@ -223,16 +223,26 @@ void HipUpscaler::choose_resize_variant(bool x2)
         variant_ = Variant::LanczosX2RegWin;
         return;
     }
-    // integer factors x3 / x4: the same register-window design (nus_k_lanczos_xs.hip), if the interior weights are uniform
+    // integer factors x3 / x4: the same register-window design (nus_k_lanczos_xs.hip).  x4: the interior weights are
+    // uniform (one set per phase, the same numbers on both axes).  x3: they move with the binade of the coordinate
+    // (nus_tables.hpp), so every lane / row takes the set of its class
+    xs_cls_x_.clear(), xs_cls_y_.clear(), xs_wcls_x_.clear(), xs_wcls_y_.clear();
     for (uint32_t S = 3; S <= 4 && !force_general_; ++S) {
         if (ow_ != S * iw_ || oh_ != S * ih_ || (iw_ % 4) != 0 || iw_ < 16 || ih_ < 16 || !addressable) continue;
-        if (lanczos_xs_phase_frame(tx_, S, wx6_) && lanczos_xs_phase_frame(ty_, S, wy6_) &&
-            lanczos_xs_interior_uniform(tx_, S, wx6_) && lanczos_xs_interior_uniform(ty_, S, wy6_) &&
+        if (!lanczos_xs_phase_frame(tx_, S, wx6_) || !lanczos_xs_phase_frame(ty_, S, wy6_)) continue;
+        if (lanczos_xs_interior_uniform(tx_, S, wx6_) && lanczos_xs_interior_uniform(ty_, S, wy6_) &&
             memcmp(&wx6_[(size_t)8 * S * 6], &wy6_[(size_t)8 * S * 6], (size_t)S * 6 * sizeof(float)) == 0) {
             xs_factor_ = S;
             variant_ = Variant::LanczosXsRegWin;
             return;
         }
+        if (S == 3 && lanczos_xs_weight_classes(tx_, S, wx6_, true, xs_cls_x_, xs_wcls_x_) &&
+            lanczos_xs_weight_classes(ty_, S, wy6_, false, xs_cls_y_, xs_wcls_y_)) {
+            xs_factor_ = S;
+            variant_ = Variant::LanczosXsRegWin;
+            return;
+        }
+        xs_cls_x_.clear(), xs_cls_y_.clear(), xs_wcls_x_.clear(), xs_wcls_y_.clear();
     }
     if (force_per_pixel_) return;
     // vertical down-scaling: stream the input rows through 7 accumulator slots, if the windows allow it and a
@@ -346,6 +356,12 @@ int HipUpscaler::upload_tables()
         }
         if (variant_ == Variant::LanczosXsRegWin) {
             UP(wy6_, lz_wy6);
+            if (!xs_cls_x_.empty()) {
+                UP(xs_cls_x_, lz_xs_cls_x);
+                UP(xs_cls_y_, lz_xs_cls_y);
+                UP(xs_wcls_x_, lz_xs_wcls_x);
+                UP(xs_wcls_y_, lz_xs_wcls_y);
+            }
             for (uint32_t p = 0; p < xs_factor_; ++p)
                 for (int j = 0; j < 6; ++j) dt_.lz_wxs[p][j] = wx6_[((size_t)8 * xs_factor_ + p) * 6 + j];
             for (uint32_t q = 0; q < 4 * xs_factor_; ++q)

@@ -165,6 +165,8 @@ private:
     Variant variant_ = Variant::NearestTable;
     AxisTables tx_, ty_;
     std::vector<float> wy6_, wx6_;
+    std::vector<uint32_t> xs_cls_x_, xs_cls_y_; // x3: weight class per input index, and the classes' weights
+    std::vector<float> xs_wcls_x_, xs_wcls_y_;
     DeviceTables dt_;
     std::vector<void *> table_allocs_;
     Slot slots_[kSlots];

@@ -30,7 +30,11 @@ struct LanczosXsArgs {
     const uint8_t *in;
     uint8_t *out;
     const float *wy6;      // [oh][6] vertical weights in the phase frame of each output row
-    float w[kXsMaxS][6];   // interior weights of phase p (same numbers on both axes, host-checked)
+    float w[kXsMaxS][6];   // interior weights of phase p (same numbers on both axes, host-checked); CLS: unused
+    // CLS (x3): the interior weights depend on the binade of the coordinate (nus_tables.hpp): class of every input
+    // column / row, and the weights of each class [class][S][6]
+    const uint32_t *cls_x, *cls_y;
+    const float *wcls_x, *wcls_y;
     uint32_t sel;          // input channel order
     uint32_t iw, ih;
     uint32_t nstrips, nrowblocks, th;
@@ -143,12 +147,27 @@ __device__ __forceinline__ void xs_hpass_store(const float (&V)[16], const float
 // raw0 / raw1 hold rows r+3 / r+4.  Unlike the x2 kernel the window is shifted, not rotated: one copy of
 // the step's code instead of six (at S = 4 six copies are ~16k instructions, more than the instruction
 // cache), for 80 register moves per step that is 3 % of its work.
-template <bool EXACT, int S>
+template <bool EXACT, int S, bool CLS>
 __device__ __forceinline__ void xs_step(float (&win)[6][16], uint4 &raw0, uint4 &raw1, int r, int cl, const XsStore<S> &st,
-                                        const LanczosXsArgs &A, const float (&W)[S][6], const uint8_t *src,
-                                        __amdgpu_buffer_rsrc_t rs, uint32_t &opaque)
+                                        const LanczosXsArgs &A, const float (&W)[S][6], float (&Wv)[S][6], uint32_t &row_cls,
+                                        const uint8_t *src, __amdgpu_buffer_rsrc_t rs, uint32_t &opaque)
 {
     typedef const __attribute__((address_space(4))) float *cfloat_p;
+    if (CLS) {
+        // vertical weights of this row's class: VGPR copies, reloaded when the class changes (a few times per frame)
+        const uint32_t cy = __builtin_amdgcn_readfirstlane(A.cls_y[r < 0 ? 0 : r]);
+        if (cy != row_cls) { // wave-uniform
+            row_cls = cy;
+            cfloat_p wt = (cfloat_p)(uintptr_t)(A.wcls_y + (size_t)cy * (S * 6));
+#pragma unroll
+            for (int p = 0; p < S; ++p)
+#pragma unroll
+                for (int j = 0; j < 6; ++j) {
+                    Wv[p][j] = wt[p * 6 + j];
+                    asm volatile("" : "+v"(Wv[p][j]));
+                }
+        }
+    }
     const uint32_t row_bytes = A.iw * 4 * S; // one output row
     const uint32_t off0 = (uint32_t)(S * r) * row_bytes;
     const bool interior = r >= 4 && r + 5 <= (int)A.ih; // wave-uniform
@@ -161,7 +180,7 @@ __device__ __forceinline__ void xs_step(float (&win)[6][16], uint4 &raw0, uint4 
             if (xs_delta(S, p) != (half == 1)) continue;
             const bool skip_alpha = !EXACT && (opaque & 0x3Fu) == 0x3Fu; // bit j: window row 5-j is opaque
             if (interior) {
-                xs_vpass<EXACT>(win, W[p], V, skip_alpha);
+                xs_vpass<EXACT>(win, CLS ? Wv[p] : W[p], V, skip_alpha);
             } else {
                 cfloat_p wt = (cfloat_p)(uintptr_t)(A.wy6 + (size_t)__builtin_amdgcn_readfirstlane((uint32_t)(S * r + p)) * 6);
                 xs_vpass<EXACT>(win, wt, V, skip_alpha);
@@ -189,7 +208,7 @@ __device__ __forceinline__ void xs_step(float (&win)[6][16], uint4 &raw0, uint4 
 
 // One wave owns a strip of 256 input columns (4 per lane; lanes 0 and 63 are halo lanes, lanes 1..62
 // produce 248 input = 248 S output columns) and walks `th` input rows with a 6-row f32 window.
-template <bool EXACT, int S>
+template <bool EXACT, int S, bool CLS>
 __global__ __launch_bounds__(256) void k_lanczos3_xs(const LanczosXsArgs A)
 {
     const int lane = threadIdx.x & (kWave - 1);
@@ -230,14 +249,20 @@ __global__ __launch_bounds__(256) void k_lanczos3_xs(const LanczosXsArgs A)
         return *reinterpret_cast<const uint4 *>(src + ((size_t)rr * A.iw + cl) * 4);
     };
 
-    float W[S][6];
+    float W[S][6], Wv[S][6];
+    uint32_t row_cls = 0xffffffffu;
+    {
+        // CLS: the lane's 4 columns share a class (host-checked); lanes that do not store take class 0
+        const uint32_t cx = CLS && c >= 4 && c + 8 <= (int)A.iw ? A.cls_x[c] : 0u;
 #pragma unroll
-    for (int p = 0; p < S; ++p)
+        for (int p = 0; p < S; ++p)
 #pragma unroll
-        for (int j = 0; j < 6; ++j) {
-            W[p][j] = A.w[p][j];
-            asm volatile("" : "+v"(W[p][j])); // VGPR copy: scalar operands halve the VALU issue rate
-        }
+            for (int j = 0; j < 6; ++j) {
+                W[p][j] = CLS ? A.wcls_x[(size_t)cx * (S * 6) + p * 6 + j] : A.w[p][j];
+                asm volatile("" : "+v"(W[p][j])); // VGPR copy: scalar operands halve the VALU issue rate
+                Wv[p][j] = 0.0f;
+            }
+    }
     float win[6][16];
     uint32_t opaque = 0;
 #pragma unroll
@@ -247,7 +272,7 @@ __global__ __launch_bounds__(256) void k_lanczos3_xs(const LanczosXsArgs A)
         cvt_row(px, win[j]);
     }
     uint4 raw0 = load_row(r0 + 3), raw1 = load_row(r0 + 4);
-    for (int r = r0; r < r_end; ++r) xs_step<EXACT, S>(win, raw0, raw1, r, cl, st, A, W, src, rs, opaque);
+    for (int r = r0; r < r_end; ++r) xs_step<EXACT, S, CLS>(win, raw0, raw1, r, cl, st, A, W, Wv, row_cls, src, rs, opaque);
 }
 
 // The 4 S left-most and right-most output columns (tap windows cut by the image border, weights
@@ -360,6 +385,12 @@ hipError_t launch_lanczos_xs(const UpscaleLaunch &L, const DeviceTables &T, bool
     A.wy6 = T.lz_wy6;
     for (uint32_t p = 0; p < factor; ++p)
         for (int j = 0; j < 6; ++j) A.w[p][j] = T.lz_wxs[p][j];
+    A.cls_x = T.lz_xs_cls_x;
+    A.cls_y = T.lz_xs_cls_y;
+    A.wcls_x = T.lz_xs_wcls_x;
+    A.wcls_y = T.lz_xs_wcls_y;
+    const bool cls = A.cls_x != nullptr;
+    if (cls && factor != 3) return hipErrorInvalidValue; // only x3 is instantiated with weight classes
     A.sel = L.in_sel;
     A.iw = L.iw;
     A.ih = L.ih;
@@ -373,17 +404,13 @@ hipError_t launch_lanczos_xs(const UpscaleLaunch &L, const DeviceTables &T, bool
         A.in = in;
         A.out = out;
         const dim3 block(256), grid(cdiv(nwaves, 4), n);
+#define NUS_XS(E, F, C) hipLaunchKernelGGL((k_lanczos3_xs<E, F, C>), grid, block, 0, L.stream, A)
         if (exact) {
-            if (factor == 3)
-                hipLaunchKernelGGL((k_lanczos3_xs<true, 3>), grid, block, 0, L.stream, A);
-            else
-                hipLaunchKernelGGL((k_lanczos3_xs<true, 4>), grid, block, 0, L.stream, A);
+            if (factor == 4) NUS_XS(true, 4, false); else if (cls) NUS_XS(true, 3, true); else NUS_XS(true, 3, false);
         } else {
-            if (factor == 3)
-                hipLaunchKernelGGL((k_lanczos3_xs<false, 3>), grid, block, 0, L.stream, A);
-            else
-                hipLaunchKernelGGL((k_lanczos3_xs<false, 4>), grid, block, 0, L.stream, A);
+            if (factor == 4) NUS_XS(false, 4, false); else if (cls) NUS_XS(false, 3, true); else NUS_XS(false, 3, false);
         }
+#undef NUS_XS
     });
 }
 

@@ -30,6 +30,9 @@ struct DeviceTables {
     float lz_wx_left[48] = {0}, lz_wx_right[48] = {0}; // phase-frame weights of the 8 edge outputs per side
     float lz_wxs[4][6] = {{0}};                        // integer factors x3 / x4: interior weights per phase
     float lz_wxs_left[16][6] = {{0}}, lz_wxs_right[16][6] = {{0}}; // ... and of the 4 S edge outputs per side
+    // x3: interior weights by class of the input index (nus_tables.hpp: lanczos_xs_weight_classes); null at x4
+    const uint32_t *lz_xs_cls_x = nullptr, *lz_xs_cls_y = nullptr; // [iw], [ih]
+    const float *lz_xs_wcls_x = nullptr, *lz_xs_wcls_y = nullptr;  // [classes][S][6]
 };
 
 // v_perm_b32 selectors applied to every loaded input pixel: RGBA8 as is, or BGRA8 (capture order,

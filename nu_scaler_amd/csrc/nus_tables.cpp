@@ -189,6 +189,30 @@ bool lanczos_xs_interior_uniform(const AxisTables &t, uint32_t S, const std::vec
     return true;
 }
 
+bool lanczos_xs_weight_classes(const AxisTables &t, uint32_t S, const std::vector<float> &w6, bool lanes,
+                               std::vector<uint32_t> &cls, std::vector<float> &classes)
+{
+    if (t.in_n < 16 || (lanes && (t.in_n % 4) != 0)) return false;
+    const size_t frame = (size_t)S * 6;
+    cls.assign(t.in_n, 0);
+    classes.clear();
+    for (uint32_t k = 4; k + 4 < t.in_n; ++k) {
+        const float *w = w6.data() + (size_t)k * frame; // outputs S k .. S k + S - 1
+        uint32_t c = 0;
+        const uint32_t n = (uint32_t)(classes.size() / frame);
+        for (; c < n; ++c)
+            if (std::memcmp(classes.data() + (size_t)c * frame, w, frame * sizeof(float)) == 0) break;
+        if (c == n) {
+            if (n == kXsMaxClasses) return false;
+            classes.insert(classes.end(), w, w + frame);
+        }
+        cls[k] = c;
+    }
+    for (uint32_t k = 4; lanes && k + 8 <= t.in_n; k += 4) // a lane's 4 columns share a class
+        if (cls[k] != cls[k + 1] || cls[k] != cls[k + 2] || cls[k] != cls[k + 3]) return false;
+    return !classes.empty();
+}
+
 namespace {
 
 const uint32_t kMagic = 0x4C53554Eu; // "NUSL"

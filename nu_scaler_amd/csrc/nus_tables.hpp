@@ -61,6 +61,14 @@ bool lanczos_x2_interior_uniform(const AxisTables &t, const std::vector<float> &
 bool lanczos_xs_phase_frame(const AxisTables &t, uint32_t S, std::vector<float> &w6);
 // True when every interior output (k in [4, in_n - 5]) has the weights of output S * 8 + p of its phase.
 bool lanczos_xs_interior_uniform(const AxisTables &t, uint32_t S, const std::vector<float> &w6);
+// When they do not (x3: (o + 0.5) * fl(1/3) is rounded in f32, so the fractional position of a sample -- and with it
+// every weight -- moves with the binade of the coordinate): group the interior input indices by the exact bits of
+// their S phase frames.  cls[k] = class of input index k (0 for the border indices, whose weights the kernels take
+// elsewhere), classes[c][p][j] = the weights.  False if there are more than kXsMaxClasses classes or, with `lanes`
+// (the horizontal axis), if one of the aligned groups of 4 input indices (one lane's columns) spans two classes.
+constexpr uint32_t kXsMaxClasses = 16;
+bool lanczos_xs_weight_classes(const AxisTables &t, uint32_t S, const std::vector<float> &w6, bool lanes,
+                               std::vector<uint32_t> &cls, std::vector<float> &classes);
 
 // Down-scaling stream tables for k_resize_down (7 accumulator slots, slot of output y = y % 7).
 // rows: (in_n + extra) x 8 words -- per input row the f32 weight it carries in each slot (0 where the row is

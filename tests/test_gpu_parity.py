@@ -659,11 +659,12 @@ def test_resize_register_window_variant(nsc, oracle_mod, alg, filt, dims):
     (w, h), (ow, oh) = dims
     img = oracle_mod.gen_noise(w, h, 91)
     want = oracle_mod.resize(img, ow, oh, filt)
-    got_e, u = _up(nsc, alg, img, ow, oh, lanczos_mode="exact")
+    gen = {"force_general": 1} if (ow, oh) == (3 * w, 3 * h) else {}  # exact x3 has its own kernel: ask for this one
+    got_e, u = _up(nsc, alg, img, ow, oh, lanczos_mode="exact", options=dict(gen))
     assert u.kernel_variant == "resize_regwin_lds"
     assert np.array_equal(got_e, want)
-    got_f, _ = _up(nsc, alg, img, ow, oh)
-    ref_f, ur = _up(nsc, alg, img, ow, oh, options={"force_rows": 1})
+    got_f, _ = _up(nsc, alg, img, ow, oh, options=dict(gen))
+    ref_f, ur = _up(nsc, alg, img, ow, oh, options=dict(gen, force_rows=1))
     assert ur.kernel_variant == "resize_rows_lds"
     assert np.array_equal(got_f, ref_f) and _maxdiff(got_f, want) <= 1
 
@@ -678,12 +679,13 @@ def test_resize_integer_factor_register_window(nsc, oracle_mod, alg, filt, facto
     img = oracle_mod.gen_noise(w, h, 93)
     want = oracle_mod.resize(img, ow, oh, filt)
     got_e, u = _up(nsc, alg, img, ow, oh, lanczos_mode="exact")
-    # x4: fixed interior weights per phase.  x3: the phase whose centre coincides with a pixel centre gets weights
-    # that depend on the f32 rounding of (o + 0.5) * (1/3) per column, so the host's uniformity check sends it
-    # to the any-scale register-window kernel instead.
-    assert u.kernel_variant == ("lanczos3_xs_regwin" if factor == 4 else "resize_regwin_lds")
+    # x4: one set of interior weights per phase.  x3: (o + 0.5) * fl(1/3) is rounded in f32, so the weights move with
+    # the binade of the coordinate; the host groups the input indices into weight classes and every lane / row of
+    # the same kernel takes the set of its class (exact: EXACT mode stays at 0 differences).
+    assert u.kernel_variant == "lanczos3_xs_regwin"
     assert np.array_equal(got_e, want)
-    got_f, _ = _up(nsc, alg, img, ow, oh)
+    got_f, uf = _up(nsc, alg, img, ow, oh)
+    assert uf.kernel_variant == "lanczos3_xs_regwin"
     # FMA mode packs with round-to-nearest-even; Triangle's dyadic weights put many sums on exact .5 ties,
     # where that differs from f32::round by one count
     assert _maxdiff(got_f, want) <= 1 and (got_f != want).mean() < (3e-2 if alg == "triangle" else 1e-3)
@@ -699,6 +701,33 @@ def test_resize_integer_factor_register_window(nsc, oracle_mod, alg, filt, facto
     ub.initialize(w, h, ow, oh)
     got_b = np.frombuffer(ub.upscale(_bgra(img).tobytes()), np.uint8).reshape(oh, ow, 4)
     assert np.array_equal(got_b, want)
+
+
+def test_720p_to_4k_x3_takes_the_fixed_weight_kernel(nsc, oracle_mod):
+    """The other headline resolution pair: 1280x720 -> 3840x2160 is exact x3.  Its weights are not uniform (they move
+    with the binade of the sample coordinate), so the register-window kernel takes them per weight class; both
+    modes against the oracle at full size, and a device batch."""
+    import torch
+
+    w, h, ow, oh = 1280, 720, 3840, 2160
+    img = oracle_mod.gen_noise(w, h, 77)
+    want = oracle_mod.lanczos3(img, ow, oh, threads=0)
+    got_f, uf = _up(nsc, "lanczos3", img, ow, oh)
+    assert uf.kernel_variant == "lanczos3_xs_regwin"
+    d = np.abs(got_f.astype(np.int16) - want.astype(np.int16))
+    assert d.max() <= 1 and (d > 0).mean() < 1e-3
+    got_e, ue = _up(nsc, "lanczos3", img, ow, oh, lanczos_mode="exact")
+    assert ue.kernel_variant == "lanczos3_xs_regwin" and np.array_equal(got_e, want)
+    n = 3
+    frames_np = np.stack([oracle_mod.gen_gradient(w, h, k) for k in range(n)])
+    frames = torch.from_numpy(frames_np).to("cuda:0")
+    out = torch.zeros((n, oh, ow, 4), dtype=torch.uint8, device="cuda:0")
+    uf.upscale_device(frames.data_ptr(), out.data_ptr(), n, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    for k in range(n):
+        wk = oracle_mod.lanczos3(frames_np[k], ow, oh, threads=0).astype(np.int16)
+        dk = np.abs(out[k].cpu().numpy().astype(np.int16) - wk)
+        assert dk.max() <= 1 and (dk > 0).mean() < 1e-3, k
 
 
 @pytest.mark.parametrize("alg", ["lanczos3", "bicubic", "fsr1", "bilinear", "nearest"])
