@@ -741,12 +741,15 @@ int HipUpscaler::import_tables(const void *buf, size_t len)
     NUS_HIP(hipDeviceSynchronize());
     if (is_resize() && (x.filter != resize_filter() || y.filter != resize_filter()))
         return fail(kInvalidArgument, "import_tables: tables were built for a different resize filter");
+    if (is_resize() && (x.lz_max_taps < 0 || y.lz_max_taps < 0))
+        return fail(kUnsupported, "import_tables: Lanczos window too wide");
+    // every check has passed: only now replace the tables this upscaler runs on
     tx_ = std::move(x);
     ty_ = std::move(y);
-    if (is_resize() && (tx_.lz_max_taps < 0 || ty_.lz_max_taps < 0))
-        return fail(kUnsupported, "import_tables: Lanczos window too wide");
     choose_variant();
-    return upload_tables();
+    const int rc = upload_tables();
+    if (rc != kOk) initialized_ = false; // the device tables are gone: the upscaler must be initialised again
+    return rc;
 }
 
 std::unique_ptr<HipUpscaler> UpscalerFactory::create_upscaler(Technology tech, Quality q)

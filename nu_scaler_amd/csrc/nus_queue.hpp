@@ -52,13 +52,20 @@ public:
         return frames_.empty() ? nullptr : frames_.back();
     }
 
-    // Oldest frame, removed from the queue (FIFO consumption for a stream that must not skip).
-    std::shared_ptr<QueuedFrame> pop(int64_t timeout_ms = 0)
+    // Oldest frame, removed from the queue (FIFO consumption for a stream that must not skip) -- but only if the
+    // caller can take it: the size is checked against `max_bytes` UNDER the queue's lock, so a frame the caller's
+    // buffer cannot hold stays queued (`too_big` is set) instead of being popped and lost.
+    std::shared_ptr<QueuedFrame> pop(int64_t timeout_ms = 0, size_t max_bytes = SIZE_MAX, bool *too_big = nullptr)
     {
+        if (too_big) *too_big = false;
         std::unique_lock<std::mutex> lk(mu_);
         if (frames_.empty() && timeout_ms > 0)
             cv_.wait_for(lk, std::chrono::milliseconds(timeout_ms), [&] { return !frames_.empty(); });
         if (frames_.empty()) return nullptr;
+        if (frames_.front()->data.size() > max_bytes) {
+            if (too_big) *too_big = true;
+            return nullptr;
+        }
         auto f = frames_.front();
         frames_.pop_front();
         return f;

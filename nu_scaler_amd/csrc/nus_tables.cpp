@@ -320,13 +320,16 @@ bool deserialize_tables(const uint8_t *buf, size_t len, AxisTables &x, AxisTable
         return false;
     }
     // indices must stay inside the source axis: the kernels trust them
-    for (const AxisTables *t : {&x, &y}) {
+    for (AxisTables *t : {&x, &y}) {
+        uint32_t max_taps = 0;
         for (uint32_t o = 0; o < t->out_n; ++o) {
             if (t->nn_src[o] >= t->in_n || t->bl_i0[o] >= t->in_n) {
                 err = "table blob: index out of range";
                 return false;
             }
             if (t->lz_max_taps >= 0) {
+                if (o == 0) max_taps = 0;
+                max_taps = t->lz_ntaps[o] > max_taps ? t->lz_ntaps[o] : max_taps;
                 if (t->lz_left[o] < 0 || t->lz_ntaps[o] == 0 || t->lz_ntaps[o] > kResizeMaxTaps ||
                     (uint64_t)t->lz_left[o] + t->lz_ntaps[o] > t->in_n) {
                     err = "table blob: tap window out of range";
@@ -340,6 +343,8 @@ bool deserialize_tables(const uint8_t *buf, size_t len, AxisTables &x, AxisTable
                 }
             }
         }
+        // the widest window drives the kernel choice: take it from the windows themselves, not from the blob's header
+        if (t->lz_max_taps >= 0) t->lz_max_taps = (int32_t)max_taps;
     }
     return true;
 }

@@ -263,6 +263,57 @@ def test_frame_buffer_timeout_and_threads(nsc):
     assert got is not None and got[1:] == (2, 2, 0)
 
 
+def test_frame_queue_pop_keeps_a_frame_the_buffer_cannot_hold(nsc):
+    """pop checks the oldest frame against the caller's buffer under the queue's lock and only then removes it:
+    with mixed frame sizes a too-small buffer gets an error and the frame stays queued (the old code
+    sized the buffer against the NEWEST frame, then popped the OLDEST)."""
+    import ctypes
+
+    from nu_scaler_amd import _capi as C
+
+    L = C.lib()
+    q = L.nus_frame_queue_create(4)
+    big = bytes(range(256)) * 4      # 16 x 16 RGBA
+    small = bytes([7]) * (2 * 2 * 4)  # 2 x 2
+    try:
+        assert L.nus_frame_queue_add(q, big, 16, 16) == 0
+        assert L.nus_frame_queue_add(q, small, 2, 2) == 0
+        w, h, seq = ctypes.c_uint32(), ctypes.c_uint32(), ctypes.c_uint64()
+        buf = ctypes.create_string_buffer(64)  # holds the newest (small) frame but not the oldest
+        r = L.nus_frame_queue_pop(q, 0, buf, 64, ctypes.byref(w), ctypes.byref(h), ctypes.byref(seq))
+        assert r == C.ERR_INVALID_ARGUMENT and b"too small" in L.nus_last_error()
+        assert L.nus_frame_queue_size(q) == 2, "the oldest frame must still be queued"
+        buf = ctypes.create_string_buffer(1024)
+        assert L.nus_frame_queue_pop(q, 0, buf, 1024, ctypes.byref(w), ctypes.byref(h), ctypes.byref(seq)) == 1
+        assert (w.value, h.value, seq.value) == (16, 16, 0) and buf.raw[:1024] == big
+        assert L.nus_frame_queue_pop(q, 0, buf, 1024, ctypes.byref(w), ctypes.byref(h), ctypes.byref(seq)) == 1
+        assert (w.value, h.value, seq.value) == (2, 2, 1) and buf.raw[:16] == small
+        assert L.nus_frame_queue_pop(q, 0, buf, 1024, ctypes.byref(w), ctypes.byref(h), ctypes.byref(seq)) == 0
+        # a NULL buffer never pops
+        assert L.nus_frame_queue_add(q, small, 2, 2) >= 0
+        assert L.nus_frame_queue_pop(q, 0, None, 0, None, None, None) == C.ERR_INVALID_ARGUMENT
+        assert L.nus_frame_queue_size(q) == 1
+    finally:
+        L.nus_frame_queue_destroy(q)
+
+
+def test_no_exception_crosses_the_c_boundary(nsc):
+    """An allocation that cannot succeed (a 1 PiB frame copy) comes back as NUS_ERR_OUT_OF_MEMORY, not as a C++
+    exception unwinding through a C / Rust / ctypes caller."""
+    from nu_scaler_amd import _capi as C
+
+    L = C.lib()
+    q = L.nus_frame_queue_create(2)
+    try:
+        px = bytes(16)
+        r = L.nus_frame_queue_add(q, px, 1 << 24, 1 << 24)  # 2^50 bytes: beyond the address space, fails before any copy
+        assert r == C.ERR_OUT_OF_MEMORY, r
+        assert b"out of memory" in L.nus_last_error()
+        assert L.nus_frame_queue_size(q) == 0
+    finally:
+        L.nus_frame_queue_destroy(q)
+
+
 def test_header_is_plain_c_and_links(nsc, tmp_path):
     """include/nuscaler_hip.h compiles as strict C99 and a C program linked against libnuscaler_hip.so can drive the
     boundary (tests/c_abi/abi_check.c; no compute calls, so it runs without a GPU)."""
