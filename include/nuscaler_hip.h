@@ -252,6 +252,15 @@ void nus_interp_destroy(nus_interp *h);
 int nus_interp_set_device(nus_interp *h, int device);
 /* Channel order of BOTH input frames (see nus_upscaler_set_input_format); the new frame is RGBA8. */
 int nus_interp_set_input_format(nus_interp *h, int format);
+/* Element type of the flow field nus_interp_interpolate_device reads: NUS_FLOW_F32 (default, 2 x f32 per pixel,
+ * the Rg32Float layout of wgpu_interpolator.rs:1211, :1418) or NUS_FLOW_F16 (2 x IEEE half per pixel, the
+ * Rg16Float texture the reference's live path binds, wgpu_interpolator.rs:276: half the flow bytes).  Each
+ * half is widened to f32 exactly and the arithmetic is the same.  The host entry point always takes f32. */
+typedef enum nus_flow_format {
+    NUS_FLOW_F32 = 0,
+    NUS_FLOW_F16 = 1
+} nus_flow_format;
+int nus_interp_set_flow_format(nus_interp *h, int format);
 
 /* interpolate_py (wgpu_interpolator.rs:215-491): host frames in, host frame out.
  * flow == NULL -> zero flow (the live reference behaviour); otherwise w*h*2 floats
@@ -266,7 +275,8 @@ int nus_interp_interpolate(nus_interp *h, const uint8_t *a, size_t a_len,
 /* Device-resident path: n_pairs independent pairs; pair i reads
  * d_a + i*a_stride, d_b + i*b_stride (byte strides; a sliding stream uses
  * d_b = d_a + frame_bytes with both strides = frame_bytes), optional
- * d_flow + i*w*h*8, writes d_out + i*w*h*4.  Enqueued on `stream`, no sync. */
+ * d_flow + i*w*h*8 (NUS_FLOW_F32; i*w*h*4 and 4-byte alignment with NUS_FLOW_F16), writes d_out + i*w*h*4.
+ * Enqueued on `stream`, no sync. */
 int nus_interp_interpolate_device(nus_interp *h, const void *d_a, size_t a_stride,
                                   const void *d_b, size_t b_stride,
                                   const void *d_flow, uint32_t w, uint32_t hgt,

@@ -79,6 +79,7 @@ SIGNATURES = [
     ("nus_interp_destroy", None, [_vp]),
     ("nus_interp_set_device", _i, [_vp, _i]),
     ("nus_interp_set_input_format", _i, [_vp, _i]),
+    ("nus_interp_set_flow_format", _i, [_vp, _i]),
     ("nus_interp_interpolate", _i, [_vp, _vp, _sz, _vp, _sz, _vp, _u32, _u32, _f, _vp, _sz]),
     ("nus_interp_interpolate_device", _i, [_vp, _vp, _sz, _vp, _sz, _vp, _u32, _u32, _f, _vp, _u32, _vp]),
     ("nus_interp_last_gpu_ms", _i, [_vp, _dp]),

@@ -395,6 +395,11 @@ int nus_interp_set_input_format(nus_interp *h, int format)
     return guarded<int>("nus_interp_set_input_format", [&]() -> int { return h ? h->impl.set_input_format(format) : null_handle(); });
 }
 
+int nus_interp_set_flow_format(nus_interp *h, int format)
+{
+    return guarded<int>("nus_interp_set_flow_format", [&]() -> int { return h ? h->impl.set_flow_format(format) : null_handle(); });
+}
+
 int nus_interp_interpolate(nus_interp *h, const uint8_t *a, size_t a_len, const uint8_t *b, size_t b_len,
                            const float *flow, uint32_t w, uint32_t hgt, float t, uint8_t *out, size_t out_cap)
 {

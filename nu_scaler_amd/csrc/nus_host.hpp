@@ -208,6 +208,7 @@ public:
     const char *last_error() const override { return error_.c_str(); }
     int set_device(int device);
     int set_input_format(int format); // nus_pixel_format of both frames; output RGBA8
+    int set_flow_format(int format);  // nus_flow_format of the device flow field
     bool last_gpu_ms(double *ms) const;
     int wg_preset() const { return wg_preset_; }
 
@@ -225,6 +226,7 @@ private:
     size_t cap_bytes_ = 0;
     bool cap_flow_ = false;
     uint8_t *d_a_ = nullptr, *d_b_ = nullptr, *d_out_ = nullptr;
+    bool flow_half_ = false; // interpolate_device reads 2 x f16 per pixel
     float *d_flow_ = nullptr;
     uint8_t *h_stage_ = nullptr; // pinned: a | b | out
     float *h_flow_ = nullptr;    // pinned

@@ -173,7 +173,7 @@ int HipFrameInterpolator::interpolate_device(const void *d_a, size_t a_stride, c
     if (n_pairs == 0) return kOk;
     if ((reinterpret_cast<uintptr_t>(d_a) % 4) || (reinterpret_cast<uintptr_t>(d_b) % 4) ||
         (reinterpret_cast<uintptr_t>(d_out) % 4) || (a_stride % 4) || (b_stride % 4) ||
-        (d_flow && reinterpret_cast<uintptr_t>(d_flow) % 8))
+        (d_flow && reinterpret_cast<uintptr_t>(d_flow) % (flow_half_ ? 4 : 8)))
         return fail(kInvalidArgument, "interpolate_device: pointers/strides must be pixel aligned");
     const int n = device_count();
     if (n <= 0) return fail(kNoDevice, "no HIP device available (the gfx950 path has no CPU fallback)");
@@ -182,6 +182,7 @@ int HipFrameInterpolator::interpolate_device(const void *d_a, size_t a_stride, c
     L.a = static_cast<const uint8_t *>(d_a);
     L.b = static_cast<const uint8_t *>(d_b);
     L.flow = static_cast<const float *>(d_flow);
+    L.flow_half = flow_half_;
     L.out = static_cast<uint8_t *>(d_out);
     L.a_stride = a_stride;
     L.b_stride = b_stride;
@@ -193,6 +194,14 @@ int HipFrameInterpolator::interpolate_device(const void *d_a, size_t a_stride, c
     L.in_sel = input_selector(in_format_);
     hipError_t e = launch_warp_blend(L);
     if (e != hipSuccess) return fail_hip(e, "warp+blend launch");
+    return kOk;
+}
+
+int HipFrameInterpolator::set_flow_format(int format)
+{
+    std::lock_guard<std::mutex> lk(mu_);
+    if (format != 0 && format != 1) return fail(kInvalidArgument, "unknown flow format");
+    flow_half_ = format == 1;
     return kOk;
 }
 

@@ -3,6 +3,8 @@
 //              nu_scaler_core/src/interpolation/mod.rs:386-411, :467-510 (rounding)
 #include "nus_device.hpp"
 
+#include <hip/hip_fp16.h>
+
 namespace nus {
 
 namespace {
@@ -93,9 +95,11 @@ __device__ __forceinline__ float4 sample_trunc_pairs(__amdgpu_buffer_rsrc_t rs, 
 // Dense flow (2 x f32 per pixel, delta A -> B): A sampled at p - t*flow, B at
 // p + (1-t)*flow (warp_blend.wgsl:36-37 in texel space).  blockDim = (64, 4).
 // PAIRS: the frames are at least 2 pixels wide and < 4 GiB (host-checked): buffer-resource sampling above.
-template <bool PAIRS>
+// HALF: the flow field is 2 x f16 per pixel -- the Rg16Float texture the reference's live path binds
+// (wgpu_interpolator.rs:276) -- widened to f32 on load (exact), then the same arithmetic: half the flow bytes.
+template <bool PAIRS, bool HALF>
 __global__ __launch_bounds__(256) void k_warp_blend_flow(
-    const uint8_t *__restrict__ a, const uint8_t *__restrict__ b, const float *__restrict__ flow,
+    const uint8_t *__restrict__ a, const uint8_t *__restrict__ b, const void *__restrict__ flow,
     uint8_t *__restrict__ out, size_t a_stride, size_t b_stride, uint32_t w, uint32_t h, float t, uint32_t sel)
 {
     const uint32_t y = __builtin_amdgcn_readfirstlane(blockIdx.y * 4 + threadIdx.y);
@@ -104,7 +108,13 @@ __global__ __launch_bounds__(256) void k_warp_blend_flow(
     const size_t npx = (size_t)w * h;
     const uint8_t *fa = a + (size_t)blockIdx.z * a_stride, *fb = b + (size_t)blockIdx.z * b_stride;
     const size_t idx = (size_t)y * w + x;
-    const float2 f = *reinterpret_cast<const float2 *>(flow + ((size_t)blockIdx.z * npx + idx) * 2);
+    float2 f;
+    if (HALF) {
+        const __half2 hf = reinterpret_cast<const __half2 *>(flow)[(size_t)blockIdx.z * npx + idx];
+        f = make_float2(__low2float(hf), __high2float(hf));
+    } else {
+        f = reinterpret_cast<const float2 *>(flow)[(size_t)blockIdx.z * npx + idx];
+    }
     float tv = t; // per-lane copy: scalar operands halve the VALU issue rate on gfx950
     asm volatile("" : "+v"(tv));
     const float nt = 1.0f - tv;
@@ -182,12 +192,14 @@ hipError_t launch_warp_blend(const WarpLaunch &L)
                 hipLaunchKernelGGL(k_blend_zero_flow<false>, grid, block, 0, L.stream, a, b, out, L.a_stride, L.b_stride, npx, L.t, L.in_sel);
         } else {
             const dim3 block(kWave, 4), grid(cdiv(L.w, 64), cdiv(L.h, 4), n);
-            if (L.w >= 2 && npx * 4 < (1ull << 32))
-                hipLaunchKernelGGL(k_warp_blend_flow<true>, grid, block, 0, L.stream, a, b, L.flow + (size_t)done * npx * 2, out,
-                                   L.a_stride, L.b_stride, L.w, L.h, L.t, L.in_sel);
-            else
-                hipLaunchKernelGGL(k_warp_blend_flow<false>, grid, block, 0, L.stream, a, b, L.flow + (size_t)done * npx * 2, out,
-                                   L.a_stride, L.b_stride, L.w, L.h, L.t, L.in_sel);
+            const bool pairs = L.w >= 2 && npx * 4 < (1ull << 32);
+            const void *fl = reinterpret_cast<const uint8_t *>(L.flow) + (size_t)done * npx * (L.flow_half ? 4 : 8);
+#define NUS_WB(P, H) hipLaunchKernelGGL((k_warp_blend_flow<P, H>), grid, block, 0, L.stream, a, b, fl, out, L.a_stride, L.b_stride, L.w, L.h, L.t, L.in_sel)
+            if (pairs && L.flow_half) NUS_WB(true, true);
+            else if (pairs) NUS_WB(true, false);
+            else if (L.flow_half) NUS_WB(false, true);
+            else NUS_WB(false, false);
+#undef NUS_WB
         }
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;

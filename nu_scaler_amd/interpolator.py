@@ -79,6 +79,14 @@ class WgpuFrameInterpolator:
             raise ValueError("input format must be 'rgba', 'bgra', 'rgbx' or 'bgrx'")
         self._raise(self._lib.nus_interp_set_input_format(self._h, f))
 
+    def set_flow_format(self, fmt: str) -> None:
+        """Element type of the device flow field `interpolate_device` reads: "f32" (default, 2 x f32 per pixel) or
+        "f16" (2 x half per pixel: the Rg16Float texture of wgpu_interpolator.rs:276, half the bytes)."""
+        f = {"f32": 0, "f16": 1}.get(str(fmt).lower())
+        if f is None:
+            raise ValueError("flow format must be 'f32' or 'f16'")
+        self._raise(self._lib.nus_interp_set_flow_format(self._h, f))
+
     def get_last_gpu_duration_ms(self) -> Optional[float]:
         """wgpu_interpolator.rs:494-497: None until an interpolation has run."""
         ms = ctypes.c_double()

@@ -236,6 +236,47 @@ def test_warp_constant_flow_recovers_shifted_stream(nsc, oracle_mod):
     assert np.array_equal(out, oracle_mod.warp_blend(a, b, flow, 0.5))
 
 
+def test_warp_blend_with_f16_flow_field(nsc, oracle_mod):
+    """NUS_FLOW_F16: the Rg16Float flow layout of the reference's live path (wgpu_interpolator.rs:276).  Each half widens
+    to f32 exactly, so the result equals the oracle run on the f16-rounded flow bit for bit; against the unrounded f32
+    flow it stays within one count almost everywhere (a quarter-pixel flow has ~1e-3 px of f16 rounding)."""
+    import torch
+
+    w, h, n = 130, 33, 3
+    rng = np.random.default_rng(12)
+    frames_np = np.stack([oracle_mod.gen_noise(w, h, 300 + i) for i in range(n + 1)])
+    flow32 = (rng.random((n, h, w, 2)) * 8.0 - 4.0).astype(np.float32)
+    flow16 = flow32.astype(np.float16)
+    dev = torch.device("cuda:0")
+    frames = torch.from_numpy(frames_np).to(dev)
+    d_flow16 = torch.from_numpy(flow16).to(dev)
+    out = torch.zeros((n, h, w, 4), dtype=torch.uint8, device=dev)
+    it = nsc.WgpuFrameInterpolator()
+    it.set_flow_format("f16")
+    fb = w * h * 4
+    it.interpolate_device(frames.data_ptr(), fb, frames.data_ptr() + fb, fb, d_flow16.data_ptr(), w, h, 0.5, out.data_ptr(), n,
+                          torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    got = out.cpu().numpy()
+    for i in range(n):
+        want = oracle_mod.warp_blend(frames_np[i], frames_np[i + 1], flow16[i].astype(np.float32), 0.5)
+        assert np.array_equal(got[i], want), i
+        full = oracle_mod.warp_blend(frames_np[i], frames_np[i + 1], flow32[i], 0.5)
+        # noise frames: a sample position moved by the flow's f16 rounding (up to 2e-3 px) changes a truncated sample by a
+        # count now and then; never by more than a few
+        d = np.abs(got[i].astype(np.int16) - full.astype(np.int16))
+        assert d.max() <= 2 and (d > 0).mean() < 0.15, (i, int(d.max()), float((d > 0).mean()))
+    # back to f32: the same entry point reads 8 bytes per pixel again
+    it.set_flow_format("f32")
+    d_flow32 = torch.from_numpy(flow32).to(dev)
+    it.interpolate_device(frames.data_ptr(), fb, frames.data_ptr() + fb, fb, d_flow32.data_ptr(), w, h, 0.5, out.data_ptr(), n,
+                          torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert np.array_equal(out[0].cpu().numpy(), oracle_mod.warp_blend(frames_np[0], frames_np[1], flow32[0], 0.5))
+    with pytest.raises(ValueError):
+        it.set_flow_format("bf16")
+
+
 def test_interp_size_mismatch_raises_valueerror(nsc):
     it = nsc.WgpuFrameInterpolator()
     with pytest.raises(ValueError, match="Expected 64 bytes per frame for 4x4x4 RGBA"):

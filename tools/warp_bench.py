@@ -21,7 +21,10 @@ const[..., 0] = -1.0
 g = torch.Generator(device=dev).manual_seed(3)
 coarse = torch.randn((n, 2, h // 40, w // 40), generator=g, device=dev) * 4.0
 smooth = torch.nn.functional.interpolate(coarse, size=(h, w), mode="bilinear").permute(0, 2, 3, 1).contiguous()
-for name, flow in (("constant (-1, 0)", const), ("smooth random, sigma 4 px", smooth)):
+cases = [("constant (-1, 0)", const, "f32"), ("smooth random, sigma 4 px", smooth, "f32"),
+         ("smooth random, f16 flow field", smooth.to(torch.float16), "f16")]
+for name, flow, fmt in cases:
+    it.set_flow_format(fmt)
     run = lambda: it.interpolate_device(frames.data_ptr(), fb, frames.data_ptr() + fb, fb, flow.data_ptr(), w, h, 0.5, mid.data_ptr(), n, s)
     for _ in range(2):
         run()
@@ -33,4 +36,5 @@ for name, flow in (("constant (-1, 0)", const), ("smooth random, sigma 4 px", sm
     e1.record()
     torch.cuda.synchronize()
     us = e0.elapsed_time(e1) / 5 / n * 1e3
-    print(f"warp_blend_flow {name:28s} {us:7.2f} us/pair  {5 * fb / us / 1e6:5.2f} TB/s algorithmic")
+    nb = (5 if fmt == "f32" else 4) * fb
+    print(f"warp_blend_flow {name:32s} {us:7.2f} us/pair  {nb / us / 1e6:5.2f} TB/s algorithmic")
