@@ -298,6 +298,9 @@ struct RowStore {
     int lane;
 };
 
+#ifndef NUS_LZ_STORE_PRIO
+#define NUS_LZ_STORE_PRIO 0
+#endif
 #ifndef NUS_LZ_CONTIG_STORES
 #define NUS_LZ_CONTIG_STORES 1 // dev macro: 0 = each lane stores its own 2 x 16 B (A/B timing only)
 #endif
@@ -314,6 +317,9 @@ __device__ __forceinline__ void lanczos_x2_store(const uint32_t (&o)[8], __amdgp
     return;
 #endif
     u32x4 lo = {o[0], o[1], o[2], o[3]}, hi = {o[4], o[5], o[6], o[7]};
+#if NUS_LZ_STORE_PRIO
+    __builtin_amdgcn_s_setprio(NUS_LZ_STORE_PRIO); // dev macro: the turn-round + stores at raised wave priority
+#endif
 #if NUS_LZ_CONTIG_STORES
     st.stage[2 * st.lane] = lo;
     st.stage[2 * st.lane + 1] = hi;
@@ -324,6 +330,9 @@ __device__ __forceinline__ void lanczos_x2_store(const uint32_t (&o)[8], __amdgp
 #endif
     __builtin_amdgcn_raw_buffer_store_b128(lo, rs, row_off + st.off_a, 0, NUS_STORE_AUX);
     __builtin_amdgcn_raw_buffer_store_b128(hi, rs, row_off + st.off_b, 0, NUS_STORE_AUX);
+#if NUS_LZ_STORE_PRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
 }
 
 #ifndef NUS_LZ_SPLIT_STORE

@@ -8,7 +8,8 @@ rm -rf $out && mkdir -p $out
 cd $root
 python3 bench.py > $out/bench_n1.log 2>&1 && tail -1 $out/bench_n1.log > $out/bench_n1.json
 echo "bench done: $(cut -c1-120 $out/bench_n1.json)"
-(cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $out/bench_prof -o b -- python3 $root/bench.py --no-pmc --steps 10 --warmup 2 > $out/bench_prof.log 2>&1)
+(cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $out/bench_prof -o b -- python3 $root/bench.py --no-pmc --no-cpu-baseline --no-extras --no-check --steps 20 --warmup 3 > $out/bench_prof.log 2>&1)
+tail -1 $out/bench_prof.log > $out/bench_under_rocprof.json
 cp $(find $out/bench_prof -name "*kernel_stats.csv" | head -1) $out/bench_n1_kernel_stats.csv 2>/dev/null
 echo "bench profile done"
 for pat in gradient noise; do python3 tools/quick_bench.py --frames 300 --reps 5 --pattern $pat 2>&1 | grep -v amdgpu.ids; done > $out/quick_bench_kernels.txt
@@ -19,7 +20,6 @@ bash tools/flow_prof.sh > $out/flow_kernels.txt 2>&1
 cp $(find $root/gpurun_out/flowprof -name "*kernel_stats.csv" | head -1) $out/flow_front_end_kernel_stats.csv 2>/dev/null
 python3 tools/flow_bench.py 2>&1 | grep "flow estimate" >> $out/flow_kernels.txt
 bash tools/flow_stream_prof.sh 65 > $out/flow_stream_kernels.txt 2>&1
-python3 bench.py --no-pmc --steps 3 --warmup 1 --motion 2>/dev/null | tail -1 > $out/bench_motion.json
 echo "flow done"
 rm -rf $out/bench_prof
 ls -la $out
