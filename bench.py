@@ -100,8 +100,8 @@ def launch_ranks(nproc: int, script: str, script_args, timeout=None):
 
 def main_launcher(args) -> int:
     rc, lines = launch_ranks(args.gpus, os.path.abspath(__file__), sys.argv[1:])
-    for ln in lines:  # rank 0's JSON line (and nothing else: the ranks log to stderr)
-        print(ln, flush=True)
+    for ln in lines:  # rank 0's JSON line on stdout; whatever else the ranks or gloo wrote there goes to stderr
+        print(ln, flush=True, file=sys.stdout if ln.startswith("{") else sys.stderr)
     return rc
 
 

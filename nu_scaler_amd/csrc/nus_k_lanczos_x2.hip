@@ -298,9 +298,6 @@ struct RowStore {
     int lane;
 };
 
-#ifndef NUS_LZ_STORE_PRIO
-#define NUS_LZ_STORE_PRIO 0
-#endif
 #ifndef NUS_LZ_CONTIG_STORES
 #define NUS_LZ_CONTIG_STORES 1 // dev macro: 0 = each lane stores its own 2 x 16 B (A/B timing only)
 #endif
@@ -317,9 +314,6 @@ __device__ __forceinline__ void lanczos_x2_store(const uint32_t (&o)[8], __amdgp
     return;
 #endif
     u32x4 lo = {o[0], o[1], o[2], o[3]}, hi = {o[4], o[5], o[6], o[7]};
-#if NUS_LZ_STORE_PRIO
-    __builtin_amdgcn_s_setprio(NUS_LZ_STORE_PRIO); // dev macro: the turn-round + stores at raised wave priority
-#endif
 #if NUS_LZ_CONTIG_STORES
     st.stage[2 * st.lane] = lo;
     st.stage[2 * st.lane + 1] = hi;
@@ -330,55 +324,6 @@ __device__ __forceinline__ void lanczos_x2_store(const uint32_t (&o)[8], __amdgp
 #endif
     __builtin_amdgcn_raw_buffer_store_b128(lo, rs, row_off + st.off_a, 0, NUS_STORE_AUX);
     __builtin_amdgcn_raw_buffer_store_b128(hi, rs, row_off + st.off_b, 0, NUS_STORE_AUX);
-#if NUS_LZ_STORE_PRIO
-    __builtin_amdgcn_s_setprio(0);
-#endif
-}
-
-#ifndef NUS_LZ_SPLIT_STORE
-#define NUS_LZ_SPLIT_STORE 0 // dev macro: 1 = pixel-half-outer horizontal pass, each 16-B store issued as soon as its 4 pixels exist
-#endif
-// Horizontal pass with the row's two stores spread: output pixels 0..3 (input columns m = 0, 1: taps e[0..7]) for
-// every channel, first store, then pixels 4..7 (m = 2, 3: taps e[2..9]), second store.
-template <bool EXACT, bool ALPHA>
-__device__ __forceinline__ void lanczos_x2_hpass_split(const float (&V)[16], const PhaseWeights &W, __amdgpu_buffer_rsrc_t rs,
-                                                       uint32_t off)
-{
-    constexpr uint32_t a0 = ALPHA ? 0u : 0xFF000000u;
-    constexpr int NC = ALPHA ? 4 : 3;
-#pragma unroll
-    for (int half = 0; half < 2; ++half) {
-        uint32_t o[4] = {a0, a0, a0, a0};
-#pragma unroll
-        for (int c = 0; c < NC; ++c) {
-            float e[10];
-            e[0] = lane_up(V[1 * 4 + c]);
-            e[1] = lane_up(V[2 * 4 + c]);
-            e[2] = lane_up(V[3 * 4 + c]);
-            e[3] = V[0 * 4 + c];
-            e[4] = V[1 * 4 + c];
-            e[5] = V[2 * 4 + c];
-            e[6] = V[3 * 4 + c];
-            e[7] = lane_down(V[0 * 4 + c]);
-            e[8] = lane_down(V[1 * 4 + c]);
-            e[9] = lane_down(V[2 * 4 + c]);
-#pragma unroll
-            for (int mm = 0; mm < 2; ++mm) {
-                const int m = 2 * half + mm;
-                float ae = e[m] * W.e[0];
-                float ao = e[m + 1] * W.o[0];
-#pragma unroll
-                for (int j = 1; j < 6; ++j) {
-                    ae = mac<EXACT>(ae, e[m + j], W.e[j]);
-                    ao = mac<EXACT>(ao, e[m + 1 + j], W.o[j]);
-                }
-                o[2 * mm] = pack_u8<EXACT>(ae, c, o[2 * mm]);
-                o[2 * mm + 1] = pack_u8<EXACT>(ao, c, o[2 * mm + 1]);
-            }
-        }
-        const u32x4 v = {o[0], o[1], o[2], o[3]};
-        __builtin_amdgcn_raw_buffer_store_b128(v, rs, off + 16 * half, 0, NUS_STORE_AUX);
-    }
 }
 
 // One input row r -> output rows 2r (taps r-3..r+2) and 2r+1 (taps r-2..r+3).
@@ -431,18 +376,11 @@ __device__ __forceinline__ void lanczos_x2_step(float (&win)[6][16], const RowRi
         next = ring.read(S % D);
     }
 #endif
-#if NUS_LZ_SPLIT_STORE
-    if (path == 1)
-        lanczos_x2_hpass_split<EXACT, false>(V, W, rs, off0 + st.off_a);
-    else
-        lanczos_x2_hpass_split<EXACT, true>(V, W, rs, off0 + st.off_a);
-#else
     if (path == 1)
         lanczos_x2_hpass<EXACT, false>(V, W, o);
     else
         lanczos_x2_hpass<EXACT, true>(V, W, o);
     lanczos_x2_store(o, rs, st, off0); // after the paths have joined: straight-line code holds every memory instruction
-#endif
     // row r+3 in, then request row r+3+D into the same slot
     if (HIDDEN && !EARLY) {
         wait_vmcnt<4 * D + (D - 1) * NL, (D - 1) * NL + 1>();
@@ -474,18 +412,6 @@ __device__ __forceinline__ void lanczos_x2_step(float (&win)[6][16], const RowRi
             raw[S & 1] = fetch_row_plain<BLEND>(src, src_b, off);
     }
     const uint32_t path_o = !interior ? 0u : ((OP && (opaque & 0x3Fu) == 0x3Fu) ? 1u : 2u);
-#if NUS_LZ_SPLIT_STORE
-    if (path_o == 0) {
-        lanczos_x2_vpass_edge<EXACT, S + 1>(win, A.wy6, 2 * (uint32_t)r + 1, V);
-        lanczos_x2_hpass_split<EXACT, true>(V, W, rs, off0 + row_bytes + st.off_a);
-    } else if (path_o == 1) {
-        lanczos_x2_vpass<EXACT, S + 1, false>(win, W.o, V);
-        lanczos_x2_hpass_split<EXACT, false>(V, W, rs, off0 + row_bytes + st.off_a);
-    } else {
-        lanczos_x2_vpass<EXACT, S + 1, true>(win, W.o, V);
-        lanczos_x2_hpass_split<EXACT, true>(V, W, rs, off0 + row_bytes + st.off_a);
-    }
-#else
     if (path_o == 0) {
         lanczos_x2_vpass_edge<EXACT, S + 1>(win, A.wy6, 2 * (uint32_t)r + 1, V);
         lanczos_x2_hpass<EXACT, true>(V, W, o);
@@ -497,7 +423,6 @@ __device__ __forceinline__ void lanczos_x2_step(float (&win)[6][16], const RowRi
         lanczos_x2_hpass<EXACT, true>(V, W, o);
     }
     lanczos_x2_store(o, rs, st, off0 + row_bytes);
-#endif
 }
 
 // Exact x2 Lanczos-3.  One wave owns a strip of 256 input columns (4 per lane; lanes 0

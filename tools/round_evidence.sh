@@ -9,7 +9,7 @@ cd $root
 python3 bench.py > $out/bench_n1.log 2>&1 && tail -1 $out/bench_n1.log > $out/bench_n1.json
 echo "bench done: $(cut -c1-120 $out/bench_n1.json)"
 (cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $out/bench_prof -o b -- python3 $root/bench.py --no-pmc --no-cpu-baseline --no-extras --no-check --steps 20 --warmup 3 > $out/bench_prof.log 2>&1)
-tail -1 $out/bench_prof.log > $out/bench_under_rocprof.json
+grep "^{" $out/bench_prof.log | tail -1 > $out/bench_under_rocprof.json
 cp $(find $out/bench_prof -name "*kernel_stats.csv" | head -1) $out/bench_n1_kernel_stats.csv 2>/dev/null
 echo "bench profile done"
 for pat in gradient noise; do python3 tools/quick_bench.py --frames 300 --reps 5 --pattern $pat 2>&1 | grep -v amdgpu.ids; done > $out/quick_bench_kernels.txt
