@@ -295,6 +295,7 @@ struct RowStore {
     u32x4 *stage;          // this wave's 2 KiB of LDS (128 x 16 B)
     uint32_t off_a, off_b; // byte offset of this lane's 16 B inside an output row for the two stores; pieces that
                            // belong to halo lanes or to the edge kernel's columns sit at 2^31: the range check drops them
+    int idx_a, idx_b;      // which 16-B pieces of the stage this lane reads back
     int lane;
 };
 
@@ -318,8 +319,8 @@ __device__ __forceinline__ void lanczos_x2_store(const uint32_t (&o)[8], __amdgp
     st.stage[2 * st.lane] = lo;
     st.stage[2 * st.lane + 1] = hi;
     __builtin_amdgcn_wave_barrier(); // compiler only: the reads below see other lanes' writes (same wave, in-order LDS)
-    lo = st.stage[st.lane];
-    hi = st.stage[64 + st.lane];
+    lo = st.stage[st.idx_a];
+    hi = st.stage[st.idx_b];
     __builtin_amdgcn_wave_barrier();
 #endif
     __builtin_amdgcn_raw_buffer_store_b128(lo, rs, row_off + st.off_a, 0, NUS_STORE_AUX);
@@ -425,16 +426,18 @@ __device__ __forceinline__ void lanczos_x2_step(float (&win)[6][16], const RowRi
     lanczos_x2_store(o, rs, st, off0 + row_bytes);
 }
 
-// Exact x2 Lanczos-3.  One wave owns a strip of 256 input columns (4 per lane; lanes 0
-// and 63 are halo lanes, lanes 1..62 produce 248 input = 496 output columns) and walks
-// `th` input rows, keeping a 6-row f32 window of its columns in registers:
+// Exact x2 Lanczos-3.  One wave loads a strip of 256 input columns (4 per lane); lanes 1 .. 60 produce the
+// strip's 240 input = 480 output columns, lanes 0 and 61 are their halo, lanes 62 / 63 idle (a strip of 240
+// makes every output row of a strip 15 whole 128-B lines).  The wave walks `th` input rows, keeping a 6-row
+// f32 window of its columns in registers:
+//   row prefetch   : LDS-DMA into a per-wave ring, D steps ahead, hand-counted vmcnt waits (see RowRing)
 //   vertical pass  : 6 taps from the register window
 //   horizontal pass: 6 taps over the lane's own 4 columns + 3 columns from each
 //                    neighbouring lane, fetched with wave_shr/wave_shl DPP moves
-// so every input byte is read once per strip-row-block and no LDS round trip or
-// barrier is needed.  Output: 2 x 16-B stores per lane per output row (2 KiB per wave).
-// The 8 left-most and right-most output columns (renormalised edge weights) are left
-// to k_lanczos3_x2_edges.
+//   store          : the row's 2 KiB are turned round in LDS, two stores of one contiguous KiB each (RowStore)
+// so every input byte is read once per strip-row-block and no workgroup barrier is needed.
+// The 8 left-most and right-most output columns (renormalised edge weights) belong to
+// k_lanczos3_x2_edges, which is launched behind this kernel and overwrites what it wrote there.
 template <bool EXACT, int BLEND>
 __global__ __launch_bounds__(256) void k_lanczos3_x2(const LanczosX2Args A)
 {
@@ -456,23 +459,39 @@ __global__ __launch_bounds__(256) void k_lanczos3_x2(const LanczosX2Args A)
         A.out + (size_t)frame * A.out_frame_bytes, 0, (uint32_t)A.out_frame_bytes, 0x00020000);
     // lane L computes the 8 output pixels of input columns c .. c+3; it stores them unless it is a halo lane or its
     // columns are the edge kernel's
+#ifndef NUS_LZ_ALIGNED_STORES
+#define NUS_LZ_ALIGNED_STORES 1 // the two stores start at the first STORING lane's pixels, not at the halo lane's, and the main
+                                // kernel also writes the (wrong: interior weights) edge columns, which the edge pass, launched
+                                // behind it, overwrites: with 240-column strips every store instruction covers whole 128-B
+                                // lines (0 = dev macro, A/B: -3 % on the opaque stream, profiles/r02_lanczos_x2_variants_ab.txt)
+#endif
     auto computes_stored_pixels = [&](int L) {
         const int cc = (int)(strip * kLanczosX2StripCols) - 4 + L * 4;
+#if NUS_LZ_ALIGNED_STORES
+        return L >= 1 && L <= (int)(kLanczosX2StripCols / 4) && cc >= 0 && cc + 4 <= (int)A.iw;
+#else
         return L >= 1 && L <= (int)(kLanczosX2StripCols / 4) && cc >= 4 && cc + 8 <= (int)A.iw;
+#endif
     };
     RowStore st;
     st.lane = lane;
 #if NUS_LZ_CONTIG_STORES
     {
-        // after the turn in LDS this lane holds pixels 4 * lane .. +3 (first store) and 256 + 4 * lane .. +3 (second store) of
-        // the wave's 512-pixel span, i.e. half of what lanes lane / 2 and 32 + lane / 2 computed
+        // after the turn in LDS this lane holds 16 B of the wave's 512-pixel span for each store: SKIP bytes into the span
+        // for the first store, 1024 further for the second; they were computed by lanes (SKIP + 16 lane) / 32 and
+        // (SKIP + 1024 + 16 lane) / 32
+        constexpr int SKIP = NUS_LZ_ALIGNED_STORES ? 32 : 0;
         const int span0 = ((int)(strip * kLanczosX2StripCols) - 4) * 8; // byte offset of the span in an output row (may be < 0)
-        st.off_a = computes_stored_pixels(lane >> 1) ? (uint32_t)(span0 + 16 * lane) : 0x80000000u;
-        st.off_b = computes_stored_pixels(32 + (lane >> 1)) ? (uint32_t)(span0 + 1024 + 16 * lane) : 0x80000000u;
+        const int pa = SKIP + 16 * lane, pb = SKIP + 1024 + 16 * lane;
+        st.idx_a = pa / 16;
+        st.idx_b = pb / 16 < 128 ? pb / 16 : 127; // (pieces past the span belong to no lane and are dropped)
+        st.off_a = computes_stored_pixels(pa / 32) ? (uint32_t)(span0 + pa) : 0x80000000u;
+        st.off_b = pb / 32 < 64 && computes_stored_pixels(pb / 32) ? (uint32_t)(span0 + pb) : 0x80000000u;
     }
 #else
     st.off_a = computes_stored_pixels(lane) ? (uint32_t)c * 8u : 0x80000000u;
     st.off_b = st.off_a + 16u;
+    st.idx_a = st.idx_b = 0;
 #endif
     const uint32_t in_off = (uint32_t)cl * 4u; // the lane's byte offset inside an input row
     const int r0 = (int)(rb * A.th);

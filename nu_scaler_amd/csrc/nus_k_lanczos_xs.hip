@@ -206,8 +206,8 @@ __device__ __forceinline__ void xs_step(float (&win)[6][16], uint4 &raw0, uint4 
     }
 }
 
-// One wave owns a strip of 256 input columns (4 per lane; lanes 0 and 63 are halo lanes, lanes 1..62
-// produce 248 input = 248 S output columns) and walks `th` input rows with a 6-row f32 window.
+// One wave loads a strip of 256 input columns (4 per lane; lanes 1 .. 60 produce the strip's 240 input = 240 S output
+// columns, lanes 0 and 61 are their halo) and walks `th` input rows with a 6-row f32 window.
 template <bool EXACT, int S, bool CLS>
 __global__ __launch_bounds__(256) void k_lanczos3_xs(const LanczosXsArgs A)
 {

@@ -122,7 +122,11 @@ hipError_t launch_lanczos_xs_edges(const UpscaleLaunch &L, const DeviceTables &T
 hipError_t launch_fsr1(const UpscaleLaunch &L, int mode, float easu_sharpness, float rcas_sharpness);
 
 constexpr uint32_t kLanczosX2EdgeCols = 8; // output columns left to the general kernel per side
-constexpr uint32_t kLanczosX2StripCols = 248; // input columns produced per wave (62 lanes x 4; 240 = whole 128-B output lines measured the same)
+#ifndef NUS_LZ_STRIP_COLS
+#define NUS_LZ_STRIP_COLS 240 // 60 storing lanes: a strip's output rows are whole 128-B lines (x2: 1920 B = 15 lines; 1080p is 8
+                             // strips exactly); 248 = all 62 non-halo lanes storing, strip joints in mid-line (dev macro, A/B)
+#endif
+constexpr uint32_t kLanczosX2StripCols = NUS_LZ_STRIP_COLS; // input columns produced per wave (lanes 1 .. StripCols / 4, 4 columns each)
 
 struct WarpLaunch {
     const uint8_t *a = nullptr, *b = nullptr;
