@@ -321,7 +321,8 @@ typedef struct nus_flow nus_flow;
 nus_flow *nus_flow_create(void);
 void nus_flow_destroy(nus_flow *h);
 int nus_flow_set_device(nus_flow *h, int device);
-/* 1 (default): derivatives once per level and several Jacobi steps per launch on LDS tiles;
+/* 1 (default): derivatives once per level and several Jacobi steps per launch, the kernel chosen by
+ * the size of the batch (2: always the LDS-tile kernel, 3: always the register-pipelined one);
  * 0: one plain kernel per step, the shader's structure.  Results are bit-identical. */
 int nus_flow_set_tiled(nus_flow *h, int enabled);
 const char *nus_flow_last_error(const nus_flow *h);

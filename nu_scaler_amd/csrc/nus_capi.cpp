@@ -516,7 +516,7 @@ int nus_flow_set_device(nus_flow *h, int device)
 }
 int nus_flow_set_tiled(nus_flow *h, int enabled)
 {
-    return guarded<int>("nus_flow_set_tiled", [&]() -> int { return h ? h->impl.set_tiled(enabled != 0) : null_handle(); });
+    return guarded<int>("nus_flow_set_tiled", [&]() -> int { return h ? h->impl.set_tiled(enabled) : null_handle(); });
 }
 const char *nus_flow_last_error(const nus_flow *h) { return h ? h->impl.last_error() : "null handle"; }
 

@@ -42,10 +42,12 @@ int HipFlowEstimator::fail_hip(hipError_t e, const char *what)
                 std::string("HIP error in ") + what + ": " + hipGetErrorString(e));
 }
 
-int HipFlowEstimator::set_tiled(bool on)
+int HipFlowEstimator::set_tiled(int mode)
 {
     std::lock_guard<std::mutex> lk(mu_);
-    tiled_ = on;
+    if (mode < 0 || mode > 3) return fail(kInvalidArgument, "set_tiled: 0 plain, 1 multi-step (kernel chosen by size), 2 LDS tiles, 3 streamed");
+    tiled_ = mode != 0;
+    jacobi_ = mode == 2 ? kJacobiTiles : (mode == 3 ? kJacobiStream : kJacobiAuto);
     return kOk;
 }
 
@@ -176,7 +178,7 @@ int HipFlowEstimator::horn_schunck(const float *i1, const float *i2, const float
         if ((rc = reserve(ib, 4)) != kOk) return rc; // 3 floats of coefficients per cell
         float *coef = static_cast<float *>(slot_[4]);
         NUS_HIP(launch_hs_prepare(static_cast<const float *>(slot_[0]), static_cast<const float *>(slot_[1]), false, coef, w, h, stream_));
-        NUS_HIP(launch_hs_iterate(coef, lambda, &f0, &f1, w, h, iterations, false, nullptr, stream_));
+        NUS_HIP(launch_hs_iterate(coef, lambda, &f0, &f1, w, h, iterations, false, nullptr, stream_, 1, 0, 0, 0, jacobi_));
     } else {
         for (uint32_t i = 0; i < iterations; ++i) { // ping-pong as :1156-1193
             NUS_HIP(launch_horn_schunck(static_cast<const float *>(slot_[0]), static_cast<const float *>(slot_[1]), f0, f1, w, h, lambda, stream_));
@@ -283,7 +285,7 @@ int HipFlowEstimator::solve(int slot_a, int slot_b, const Pyramid &g, uint32_t c
         if (tiled_) {
             if (!prepared) NUS_HIP(launch_hs_prepare(i1, i2, true, coef, g.w[l], g.h[l], stream)); // tiled pyramids hold luminance planes
             NUS_HIP(launch_hs_iterate(coef, lambda, &f0, &f1, g.w[l], g.h[l], iters, zero,
-                                      l == 0 ? static_cast<float *>(d_flow_out) : nullptr, stream));
+                                      l == 0 ? static_cast<float *>(d_flow_out) : nullptr, stream, 1, 0, 0, 0, jacobi_));
             zero = false;
             return kOk;
         }
@@ -405,7 +407,7 @@ int HipFlowEstimator::solve_batch(const uint8_t *d_frames, uint32_t pairs, const
     float *const out = reinterpret_cast<float *>(d_flows);
     auto iterate = [&](uint32_t l, uint32_t iters, bool zero) -> int {
         NUS_HIP(launch_hs_iterate(coef, lambda, &f0, &f1, g.w[l], g.h[l], iters, zero, l == 0 ? out : nullptr, stream, pairs,
-                                  cells[l] * 3, cells[l], cells[0]));
+                                  cells[l] * 3, cells[l], cells[0], jacobi_));
         return kOk;
     };
     // coarsest level: from zero flow (compute_coarse_flow, :1136-1154)

@@ -23,7 +23,7 @@ public:
     int set_device(int device);
     // true (default): derivatives once per level + K Jacobi steps per launch in LDS; false: one
     // plain kernel per step (the shader's structure).  Bit-identical results.
-    int set_tiled(bool on);
+    int set_tiled(int mode); // 0 plain per-step kernel, 1 multi-step kernel chosen by size, 2 LDS tiles, 3 streamed
     const char *last_error() const { return error_.c_str(); }
 
     // Primitives on host buffers (parity tests, integration).  f32 RGBA images, float2 flows.
@@ -70,6 +70,7 @@ private:
     int device_ = 0;
     bool ready_ = false;
     bool tiled_ = true;
+    int jacobi_ = 0; // JacobiKernel
     hipStream_t stream_ = nullptr;
     static constexpr int kSlotCount = 8;
     void *slot_[kSlotCount] = {nullptr};

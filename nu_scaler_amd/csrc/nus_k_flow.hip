@@ -1,5 +1,7 @@
 // nus_k_flow.hip -- optical-flow front end: Gaussian pyramid + Horn-Schunck.
 #include "nus_device.hpp"
+#include <algorithm>
+#include <type_traits>
 
 namespace nus {
 
@@ -313,6 +315,141 @@ __global__ __launch_bounds__(NT) void k_hs_tiled(const float *__restrict__ coef_
     }
 }
 
+// ---- K Jacobi steps per launch, pipelined through registers ("streamed") -------------------------
+// A wave owns a strip of 64 columns (lane = column; the outer K on each side are halo, so 64 - 2K
+// columns are written) and walks down the rows [lo, hi) of its row block ONCE.  The K steps run as
+// K stages of a pipeline one row apart: when row r of level j (the flow after j steps; level 0 is the
+// input) arrives, stage j+1 can finish row r-1 of level j+1, which is that level's next arrival, and
+// so on down the stages in the same pass of the loop.  Per level a lane keeps, of its own column and
+// both neighbouring columns, the row before (r-1) and the running sum of the row before that (r-2):
+// exactly the operands the 9-term sum of row r-1 still needs, in the order k_horn_schunck adds them
+// (rows top to bottom, columns left to right, starting from 0.0f).  The left / right neighbours come
+// from the neighbouring lanes (wave_shr / wave_shl DPP moves) once per row and level, the
+// coefficients of a row are loaded once per launch and travel down a K-deep register delay line.
+// No LDS, no barriers; HBM traffic is 20 B in + 8 B out per cell per launch (plus the halo columns).
+//
+// Borders.  Rows: a level's first arrival (row lo) also stands in for row lo-1 and, after row hi-1,
+// one more "arrival" repeats that row: at the image border this is the clamp of
+// horn_schunck.wgsl:30-36, at a row-block border it makes rows wrong that lie in the K-row halo
+// (the wrong region grows by one row per stage and reaches row lo+K-1 / hi-K at most).  Columns:
+// a lane whose column is the image's first / last takes itself as left / right neighbour; at a strip
+// border the wrong values stay inside the K halo lanes the same way.  Same arithmetic and order as
+// k_horn_schunck and k_hs_tiled, so all three produce identical bits.
+struct HsRow {
+    float ul, uc, ur, vl, vc, vr; // one row of a level: this lane's column and both neighbours
+};
+struct HsCoef {
+    float ix, iy, it, den, zinv;
+};
+
+__device__ __forceinline__ float hs_lane_up(float v) // value of lane-1
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138 /*wave_shr:1*/, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float hs_lane_down(float v) // value of lane+1
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x130 /*wave_shl:1*/, 0xF, 0xF, true));
+}
+
+template <int K>
+__global__ __launch_bounds__(256) void k_hs_stream(const float *__restrict__ coef_all, size_t coef_stride, float lambda,
+                                                   const float2 *__restrict__ fin_all, size_t fin_stride,
+                                                   float2 *__restrict__ fout_all, size_t fout_stride, int w, int h, int strips,
+                                                   int row_blocks, int rows_per_block)
+{
+    constexpr int U = kWave - 2 * K; // columns a wave writes
+    const int lane = threadIdx.x & (kWave - 1);
+    const int g = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6)); // wave-uniform, in an SGPR
+    if (g >= strips * row_blocks) return;
+    const int rb = g / strips, strip = g - rb * strips;
+    const float *coef = coef_all + blockIdx.y * coef_stride;
+    const float2 *fin = fin_all ? fin_all + blockIdx.y * fin_stride : nullptr; // null = start from zero flow
+    float2 *fout = fout_all + blockIdx.y * fout_stride;
+    const int x = strip * U - K + lane, xc = clampi(x, 0, w - 1);
+    const bool self_l = x <= 0, self_r = x >= w - 1;
+    const bool writer = lane >= K && lane < kWave - K && x < w;
+    const int y0 = rb * rows_per_block, y1 = min(y0 + rows_per_block, h);
+    const int lo = max(y0 - K, 0), hi = min(y1 + K, h);
+
+    HsRow prev[K];      // level j: its newest row so far
+    float pu[K], pv[K]; // level j: 0 + l + c + r of the row before that one
+    HsCoef cf[K + 1];   // cf[d]: coefficients of row t - d (cf[0] is only the way in)
+
+    auto load_flow = [&](int r) -> float2 { return fin ? fin[(size_t)min(r, hi - 1) * w + xc] : make_float2(0.0f, 0.0f); };
+    auto load_coef = [&](int r, float &a, float &b, float &c) {
+        const float *p = coef + ((size_t)min(r, hi - 1) * w + xc) * 3;
+        a = p[0], b = p[1], c = p[2];
+    };
+    float2 nf = load_flow(lo);
+    float nix, niy, nit;
+    load_coef(lo, nix, niy, nit);
+
+    // One pass of the pipeline: row t of the input arrives, every level that has a row to take takes it.
+    // STEADY (lo + K <= t < hi): every level has a real arrival and an earlier row -- no conditions.
+    auto pass = [&](int t, auto steady_tag) {
+        constexpr bool STEADY = decltype(steady_tag)::value;
+        const float2 pf = load_flow(t + 1); // next pass's row: in flight during this pass
+        float pix, piy, pit;
+        load_coef(t + 1, pix, piy, pit);
+        {
+            const float den = lambda + nix * nix + niy * niy;
+            cf[0] = HsCoef{nix, niy, nit, den, 1.0f / den}; // correctly rounded reciprocal, for div_by_recip
+        }
+        float2 arr = nf; // level 0's arrival: row t of the input flow
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+            const int r = t - j; // the row arriving at level j in this pass
+            if (!STEADY) {
+                if (r < lo) break;    // the pipeline is still filling (wave-uniform)
+                if (r > hi) continue; // this level is done, deeper ones are draining
+            }
+            HsRow n;
+            if (!STEADY && r == hi) {
+                n = prev[j]; // past the last row: it repeats
+            } else {
+                n.uc = arr.x, n.vc = arr.y;
+                const float ul = hs_lane_up(arr.x), ur = hs_lane_down(arr.x), vl = hs_lane_up(arr.y), vr = hs_lane_down(arr.y);
+                n.ul = self_l ? arr.x : ul, n.ur = self_r ? arr.x : ur;
+                n.vl = self_l ? arr.y : vl, n.vr = self_r ? arr.y : vr;
+            }
+            if (!STEADY && r == lo) { // first row: also the row above it
+                prev[j] = n;
+                float su = 0.0f, sv = 0.0f;
+                su += n.ul, sv += n.vl, su += n.uc, sv += n.vc, su += n.ur, sv += n.vr;
+                pu[j] = su, pv[j] = sv;
+                break; // deeper levels have nothing yet
+            }
+            // row r-1 of level j+1 (horn_schunck.wgsl:26-50): the sum continues over rows r-1 and r
+            const HsRow b = prev[j];
+            float su = pu[j], sv = pv[j];
+            su += b.ul, sv += b.vl, su += b.uc, sv += b.vc, su += b.ur, sv += b.vr;
+            su += n.ul, sv += n.vl, su += n.uc, sv += n.vc, su += n.ur, sv += n.vr;
+            const float ua = div_by_recip(su, 9.0f, 1.0f / 9.0f), va = div_by_recip(sv, 9.0f, 1.0f / 9.0f);
+            const HsCoef c = cf[j + 1]; // row r-1 entered j+1 passes ago
+            const float num = c.ix * ua + c.iy * va + c.it;
+            const bool plain_div = (__float_as_uint(c.den) & 0x7fffffu) == 0x7fffffu; // Markstein's exception
+            const float common = plain_div ? num / c.den : div_by_recip(num, c.den, c.zinv);
+            arr = make_float2(ua - common * c.ix, va - common * c.iy);
+            // the row that was newest becomes the row above
+            float qu = 0.0f, qv = 0.0f;
+            qu += b.ul, qv += b.vl, qu += b.uc, qv += b.vc, qu += b.ur, qv += b.vr;
+            pu[j] = qu, pv[j] = qv;
+            prev[j] = n;
+            if (j == K - 1) {
+                const int y = r - 1;
+                if (y >= y0 && y < y1 && writer) fout[(size_t)y * w + x] = arr;
+            }
+        }
+#pragma unroll
+        for (int d = K; d >= 1; --d) cf[d] = cf[d - 1];
+        nf = pf, nix = pix, niy = piy, nit = pit;
+    };
+    int t = lo;
+    for (; t < min(lo + K, hi + K); ++t) pass(t, std::false_type{}); // fill
+    for (; t < hi; ++t) pass(t, std::true_type{});
+    for (; t < hi + K; ++t) pass(t, std::false_type{}); // drain
+}
+
 // flow_upsample.wgsl:27-36 (linear clamp-to-edge sampler in texel space), vectors * scale
 __device__ __forceinline__ float2 flow_upsample_cell(const float2 *__restrict__ src, int sw, int sh, int x, int y, int dw, int dh,
                                                      float scale)
@@ -457,10 +594,78 @@ hipError_t launch_hs_level_setup(const float *l1, const float *l2, float *coef, 
 #ifndef NUS_HS_SMALL_THREADS
 #define NUS_HS_SMALL_THREADS 1024
 #endif
+#ifndef NUS_HS_STREAM_MAXK
+#define NUS_HS_STREAM_MAXK 5 // steps per launch of the streamed kernel (registers: 8 per level + 5 per delay-line row)
+#endif
+#ifndef NUS_HS_STREAM_MIN_ROWS
+#define NUS_HS_STREAM_MIN_ROWS 64 // shortest row block: 2K halo rows and the K passes of pipeline fill are paid per block
+#endif
+#ifndef NUS_HS_STREAM_WAVES
+#define NUS_HS_STREAM_WAVES 5120 // waves a launch aims for: row blocks are made shorter until there are this many
+#endif
+#ifndef NUS_HS_STREAM_MIN_WAVES
+#define NUS_HS_STREAM_MIN_WAVES 1024 // below this the LDS tiles fill the chip better
+#endif
+
+// The streamed kernel's launch shape for a level: strips of 64 - 2K columns, row blocks as tall as still gives the
+// chip about eight waves per CU.  row_blocks == 0: not enough independent strips, use the LDS tiles.
+struct HsStreamShape {
+    uint32_t strips, row_blocks, rows_per_block;
+};
+static HsStreamShape hs_stream_shape(uint32_t w, uint32_t h, uint32_t n, uint32_t k, bool force)
+{
+    HsStreamShape s{cdiv(w, kWave - 2 * k), 1, h};
+    const uint64_t columns = (uint64_t)s.strips * n;
+    const uint32_t want = (uint32_t)std::min<uint64_t>((NUS_HS_STREAM_WAVES + columns - 1) / columns, std::max<uint32_t>(h / NUS_HS_STREAM_MIN_ROWS, 1));
+    s.rows_per_block = cdiv(h, want);
+    s.row_blocks = cdiv(h, s.rows_per_block);
+    if (!force && columns * s.row_blocks < NUS_HS_STREAM_MIN_WAVES) s.row_blocks = 0;
+    return s;
+}
+
 hipError_t launch_hs_iterate(const float *coef, float lambda, float **flow_a, float **flow_b, uint32_t w, uint32_t h,
                              uint32_t iterations, bool zero_start, float *final_out, hipStream_t stream, uint32_t n,
-                             size_t coef_stride, size_t flow_stride, size_t final_stride)
+                             size_t coef_stride, size_t flow_stride, size_t final_stride, int kernel)
 {
+    if (kernel != kJacobiTiles && hs_stream_shape(w, h, n, NUS_HS_STREAM_MAXK, kernel == kJacobiStream).row_blocks != 0) {
+        uint32_t launches = (iterations + NUS_HS_STREAM_MAXK - 1) / NUS_HS_STREAM_MAXK;
+        while (iterations > 0) {
+            const uint32_t k = (iterations + launches - 1) / launches; // even split, 1..MAXK steps per launch
+            size_t out_stride = flow_stride;
+            if (final_out && launches == 1) { // the last launch writes the caller's buffer
+                *flow_b = final_out;
+                out_stride = final_stride;
+            }
+            auto fi = zero_start ? nullptr : reinterpret_cast<const float2 *>(*flow_a);
+            auto fo = reinterpret_cast<float2 *>(*flow_b);
+            zero_start = false;
+            const HsStreamShape sh = hs_stream_shape(w, h, n, k, true);
+            const dim3 block(256), grid(cdiv(sh.strips * sh.row_blocks, 4), n);
+#define NUS_HSS(KK)                                                                                                             \
+    case KK:                                                                                                                    \
+        hipLaunchKernelGGL((k_hs_stream<KK>), grid, block, 0, stream, coef, coef_stride, lambda, fi, flow_stride, fo, out_stride, \
+                           (int)w, (int)h, (int)sh.strips, (int)sh.row_blocks, (int)sh.rows_per_block);                         \
+        break;
+            switch (k) {
+                NUS_HSS(1) NUS_HSS(2) NUS_HSS(3) NUS_HSS(4) NUS_HSS(5)
+#if NUS_HS_STREAM_MAXK > 5
+                NUS_HSS(6) NUS_HSS(7) NUS_HSS(8)
+#endif
+#if NUS_HS_STREAM_MAXK > 8
+                NUS_HSS(9) NUS_HSS(10)
+#endif
+            }
+#undef NUS_HSS
+            hipError_t e = hipGetLastError();
+            if (e != hipSuccess) return e;
+            iterations -= k;
+            --launches;
+            float *t = *flow_a;
+            *flow_a = *flow_b;
+            *flow_b = t;
+        }
+        return hipSuccess;
+    }
     const uint64_t tiles32 = (uint64_t)cdiv(w, 32) * cdiv(h, 32) * n;
     const int cls = tiles32 >= 1024 ? 2 : (tiles32 >= 256 ? 1 : 0);
     const uint32_t T = cls == 2 ? 32 : (cls == 1 ? NUS_HS_MID_T : NUS_HS_SMALL_T);

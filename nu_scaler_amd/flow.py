@@ -31,9 +31,10 @@ class FlowEstimator:
         if h:
             self._lib.nus_flow_destroy(h)
 
-    def set_tiled(self, enabled: bool) -> None:
-        """True (default): LDS-tiled multi-step Horn-Schunck; False: one plain kernel per step."""
-        self._check(self._lib.nus_flow_set_tiled(self._h, int(bool(enabled))))
+    def set_tiled(self, enabled) -> None:
+        """True / 1 (default): multi-step Horn-Schunck kernels (2: always LDS tiles, 3: always the
+        register-pipelined kernel); False / 0: one plain kernel per step.  Same bits either way."""
+        self._check(self._lib.nus_flow_set_tiled(self._h, int(enabled)))
 
     def _check(self, status: int) -> None:
         if status != C.OK:

@@ -72,12 +72,28 @@ def test_flow_primitives_match_oracle(nsc, oracle_mod, size):
     f0 = rng.standard_normal((h, w, 2)).astype(np.float32)
     for fin, it in ((None, 1), (None, 4), (f0, 3), (f0, 15), (None, 8)):
         want = oracle_mod.horn_schunck(img, img2, fin, iterations=it, lam=4e-4)
-        for tiled in (True, False):  # LDS-tiled multi-step kernel and the plain per-step kernel
+        for tiled in (1, 2, 3, 0):  # multi-step kernel by size, LDS tiles, register-pipelined strips, plain per-step kernel
             fe.set_tiled(tiled)
             got = fe.horn_schunck(img, img2, fin, iterations=it, lambda_=4e-4)
             assert np.array_equal(got, want), (size, it, tiled)
     for (dw, dh, sc) in ((2 * w, 2 * h, 2.0), (2 * w - 1, 2 * h - 1, 2.0), (w, h, 1.0), (3 * w + 1, h + 2, 0.5)):
         assert np.array_equal(fe.upsample(f0, dw, dh, sc), oracle_mod.flow_upsample(f0, dw, dh, sc)), (dw, dh)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("size", [(200, 300), (54, 129), (55, 128), (117, 257)])
+def test_horn_schunck_streamed_kernel_row_blocks_and_strips(nsc, oracle_mod, size):
+    """The register-pipelined kernel forced onto images tall enough for several row blocks (each with a K-row halo
+    whose rows are wrong by construction and must never be written) and widths at / one past a strip boundary."""
+    w, h = size
+    fe = nsc.FlowEstimator()
+    img = oracle_mod.rgba8_to_f32(oracle_mod.gen_noise(w, h, 5))
+    img2 = oracle_mod.rgba8_to_f32(oracle_mod.gen_noise(w, h, 6))
+    f0 = np.random.default_rng(w * h).standard_normal((h, w, 2)).astype(np.float32)
+    fe.set_tiled(3)
+    for fin, it in ((None, 1), (f0, 5), (f0, 7), (None, 12)):
+        want = oracle_mod.horn_schunck(img, img2, fin, iterations=it, lam=4e-4)
+        assert np.array_equal(fe.horn_schunck(img, img2, fin, iterations=it, lambda_=4e-4), want), (size, it)
 
 
 @pytest.mark.gpu
@@ -109,7 +125,7 @@ def test_flow_estimate_ragged_sizes(nsc, oracle_mod, size, levels):
     a, b = oracle_mod.gen_noise(w, h, 41), oracle_mod.gen_noise(w, h, 42)
     fe = nsc.FlowEstimator(levels=levels, coarse_iterations=11, refine_iterations=3)
     want = oracle_mod.flow_estimate(a, b, levels, 11, 3, fe.lambda_)
-    for tiled in (True, False):
+    for tiled in (1, 2, 3, 0):
         fe.set_tiled(tiled)
         assert np.array_equal(fe.estimate(a, b, w, h), want), (size, levels, tiled)
 
@@ -123,7 +139,7 @@ def test_flow_estimate_iteration_edge_cases(nsc, oracle_mod, levels, coarse, ref
     a, b = oracle_mod.gen_noise(w, h, 7), oracle_mod.gen_noise(w, h, 8)
     fe = nsc.FlowEstimator(levels=levels, coarse_iterations=coarse, refine_iterations=refine)
     want = oracle_mod.flow_estimate(a, b, levels, coarse, refine, fe.lambda_)
-    for tiled in (True, False):
+    for tiled in (1, 2, 3, 0):
         fe.set_tiled(tiled)
         assert np.array_equal(fe.estimate(a, b, w, h), want), (levels, coarse, refine, tiled)
 
@@ -176,7 +192,7 @@ def test_flow_estimate_device_stream_equals_pairwise(nsc, oracle_mod, n_frames):
     d_flows = torch.full((n_frames - 1, h, w, 2), float("nan"), dtype=torch.float32, device=dev)
     fe = nsc.FlowEstimator(levels=3, coarse_iterations=9, refine_iterations=3)
     want = [oracle_mod.flow_estimate(frames[k], frames[k + 1], 3, 9, 3, fe.lambda_) for k in range(n_frames - 1)]
-    for tiled in (True, False):
+    for tiled in (1, 2, 3, 0):
         fe.set_tiled(tiled)
         d_flows.fill_(float("nan"))
         fe.estimate_device_stream(d_frames.data_ptr(), n_frames, w, h, d_flows.data_ptr(), torch.cuda.current_stream().cuda_stream)

@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Time nus_flow_estimate_device_stream on a device-resident 1080p stream (dev tool): flow_stream_bench.py [frames]"""
+"""Time nus_flow_estimate_device_stream on a device-resident 1080p stream (dev tool): flow_stream_bench.py [frames] [modes: 1 by size, 2 LDS tiles, 3 streamed ...]"""
 import os
 import sys
 
@@ -16,13 +16,22 @@ frames = syn.gradient_stream_torch(n, w, h, dev) // 2 + syn.noise_stream_torch(n
 flows = torch.empty((n - 1, h, w, 2), dtype=torch.float32, device=dev)
 fe = nsc.FlowEstimator(levels=3, coarse_iterations=50, refine_iterations=10)
 s = torch.cuda.current_stream().cuda_stream
-fe.estimate_device_stream(frames.data_ptr(), n, w, h, flows.data_ptr(), s)
-torch.cuda.synchronize()
-e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-reps = 3
-e0.record()
-for _ in range(reps):
-    fe.estimate_device_stream(frames.data_ptr(), n, w, h, flows.data_ptr(), s)
-e1.record()
-torch.cuda.synchronize()
-print(f"flow stream 1080p, {n} frames: {e0.elapsed_time(e1) / reps / (n - 1) * 1e3:.1f} us per pair")
+modes = [int(m) for m in sys.argv[2:]] or [1]
+ref = None
+for rnd in range(3 if len(modes) > 1 else 1):  # interleaved rounds when several kernels are compared
+    for mode in modes:
+        fe.set_tiled(mode)
+        fe.estimate_device_stream(frames.data_ptr(), n, w, h, flows.data_ptr(), s)
+        torch.cuda.synchronize()
+        if ref is None:
+            ref = flows.clone()
+        same = bool(torch.equal(flows, ref))
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        reps = 3
+        e0.record()
+        for _ in range(reps):
+            fe.estimate_device_stream(frames.data_ptr(), n, w, h, flows.data_ptr(), s)
+        e1.record()
+        torch.cuda.synchronize()
+        print(f"flow stream 1080p, {n} frames, kernel mode {mode}: {e0.elapsed_time(e1) / reps / (n - 1) * 1e3:.1f} us per pair"
+              f"{'' if same else '  OUTPUT DIFFERS from the first mode'}", flush=True)
