@@ -252,7 +252,7 @@ int HipFlowEstimator::build_pyramid(const void *frame, int pyr_slot, const Pyram
         for (uint32_t l = 0; l < g.levels; ++l) {
             float *level = reinterpret_cast<float *>(pyr + g.offset[l]);
             float *next = l + 1 < g.levels ? nxt[l & 1] : nullptr;
-            NUS_HIP(launch_pyramid_level(src, l == 0, level, next, g.w[l], g.h[l], stream));
+            NUS_HIP(launch_pyramid_level(src, l == 0, level, next, g.w[l], g.h[l], stream, 1, 0, 0, 0, jacobi_));
             src = next;
         }
         return kOk;
@@ -402,7 +402,7 @@ int HipFlowEstimator::solve_batch(const uint8_t *d_frames, uint32_t pairs, const
         const size_t src_stride = l == 0 ? cells[0] * 4 /* bytes */ : cells[l] /* float4 */;
         float *next = l + 1 < nl ? level_in[l & 1] : nullptr;
         NUS_HIP(launch_pyramid_level(src, l == 0, lum + lum_off[l], next, g.w[l], g.h[l], stream, nf, src_stride, cells[l],
-                                     l + 1 < nl ? cells[l + 1] : 0));
+                                     l + 1 < nl ? cells[l + 1] : 0, jacobi_));
     }
     float *const out = reinterpret_cast<float *>(d_flows);
     auto iterate = [&](uint32_t l, uint32_t iters, bool zero) -> int {

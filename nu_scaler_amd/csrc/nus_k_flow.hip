@@ -172,6 +172,112 @@ __global__ __launch_bounds__(kPyrThreads) void k_pyramid_level(const void *__res
     }
 }
 
+__device__ __forceinline__ float hs_lane_up(float v) // value of lane-1
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138 /*wave_shr:1*/, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float hs_lane_down(float v) // value of lane+1
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x130 /*wave_shl:1*/, 0xF, 0xF, true));
+}
+
+// ---- The same pyramid level without LDS ("streamed"), for batches --------------------------------
+// A wave owns a strip of 128 columns -- two adjacent columns per lane, the outer lanes are the 2-column
+// halo, so 124 columns are written -- and walks down its row block once.  Per input row: both pixels
+// converted, the horizontal blur taken from the lane's own two values and the neighbouring lanes' (one
+// wave_shr and one wave_shl DPP move per value), the result kept in a five-row register window that the
+// vertical blur reads; the 2x2 box average pairs the lane's own two columns of an even and an odd row.
+// Rows and columns outside the image are loaded with clamped coordinates, which is exactly what the
+// shaders' clamped taps read (gaussian_blur_{h,v}.wgsl:31-40), so no tap is conditional.  Same
+// expressions in the same order as k_pyramid_level: identical bits.  HBM traffic as there; no LDS, no barrier.
+__device__ __forceinline__ float4 lane_up4(const float4 v)
+{
+    return make_float4(hs_lane_up(v.x), hs_lane_up(v.y), hs_lane_up(v.z), hs_lane_up(v.w));
+}
+__device__ __forceinline__ float4 lane_down4(const float4 v)
+{
+    return make_float4(hs_lane_down(v.x), hs_lane_down(v.y), hs_lane_down(v.z), hs_lane_down(v.w));
+}
+
+template <bool U8IN>
+__global__ __launch_bounds__(256) void k_pyramid_stream(const void *__restrict__ in_all, size_t in_stride,
+                                                        float *__restrict__ lum_all, size_t lum_stride,
+                                                        float4 *__restrict__ next_all, size_t next_stride, int w, int h,
+                                                        int strips, int row_blocks, int rows_per_block)
+{
+    constexpr int U = 2 * kWave - 4; // columns a wave writes
+    using Raw = typename std::conditional<U8IN, uint32_t, float4>::type;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int g = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+    if (g >= strips * row_blocks) return;
+    const int rb = g / strips, strip = g - rb * strips;
+    const Raw *in = U8IN ? reinterpret_cast<const Raw *>(static_cast<const uint8_t *>(in_all) + blockIdx.y * in_stride)
+                         : static_cast<const Raw *>(in_all) + blockIdx.y * in_stride;
+    float *level_lum = lum_all + blockIdx.y * lum_stride;
+    float4 *next = next_all ? next_all + blockIdx.y * next_stride : nullptr;
+    const int xa = strip * U - 2 + 2 * lane, xb = xa + 1; // this lane's columns (xa is even)
+    const int ca = clampi(xa, 0, w - 1), cb = clampi(xb, 0, w - 1);
+    const bool writer = lane >= 1 && lane <= kWave - 2;
+    const int y0 = rb * rows_per_block, y1 = min(y0 + rows_per_block, h); // rows_per_block is even
+    const int ow = (w + 1) / 2;
+
+    auto convert = [](Raw p) -> float4 {
+        if constexpr (U8IN) return unorm8(p);
+        else return p;
+    };
+    float4 hba[5], hbb[5];   // H-blurred rows r-4 .. r of both columns (slots rotate with the row)
+    float4 keep_a = make_float4(0.0f, 0.0f, 0.0f, 0.0f), keep_b = keep_a; // the blurred even row of a 2x2 block, until its odd row is there
+    Raw na = in[(size_t)clampi(y0 - 2, 0, h - 1) * w + ca], nb = in[(size_t)clampi(y0 - 2, 0, h - 1) * w + cb];
+
+    // input row r arrives in window slot P; from the fifth row on, level row r - 2 leaves
+    auto step = [&](int r, auto slot_tag) {
+        constexpr int P = decltype(slot_tag)::value;
+        const float4 a = convert(na), b = convert(nb);
+        {
+            const size_t row = (size_t)clampi(r + 1, 0, h - 1) * w; // next row: in flight during this one
+            na = in[row + ca], nb = in[row + cb];
+        }
+        const float4 la = lane_up4(a), lb = lane_up4(b), ra = lane_down4(a), rb4 = lane_down4(b);
+        hba[P] = blur5(la, lb, a, b, ra);  // columns xa-2 .. xa+2
+        hbb[P] = blur5(lb, a, b, ra, rb4); // columns xb-2 .. xb+2
+        const int y = r - 2;
+        if (y < y0) return; // the window is still filling (wave-uniform)
+        const float4 va = blur5(hba[(P + 1) % 5], hba[(P + 2) % 5], hba[(P + 3) % 5], hba[(P + 4) % 5], hba[P]);
+        const float4 vb = blur5(hbb[(P + 1) % 5], hbb[(P + 2) % 5], hbb[(P + 3) % 5], hbb[(P + 4) % 5], hbb[P]);
+        if (writer) {
+            float *dst = level_lum + (size_t)y * w;
+            if (xa < w) dst[xa] = lum(va);
+            if (xb < w) dst[xb] = lum(vb);
+        }
+        if (next == nullptr) return;
+        const bool even = (y & 1) == 0;
+        if (even) keep_a = va, keep_b = vb; // the upper row of a 2x2 block waits for the lower one
+        if (even && y != h - 1) return;     // (odd height: the last row pairs with itself)
+        // downsample.wgsl:22-37: (c00 + c10 + c01 + c11) * 0.25, the far column / row clamped into the image
+        const bool dup = xb > w - 1;
+        const float4 c00 = keep_a, c01 = va;
+        const float4 c10 = dup ? keep_a : keep_b, c11 = dup ? va : vb;
+        float4 o;
+        o.x = (c00.x + c10.x + c01.x + c11.x) * 0.25f;
+        o.y = (c00.y + c10.y + c01.y + c11.y) * 0.25f;
+        o.z = (c00.z + c10.z + c01.z + c11.z) * 0.25f;
+        o.w = (c00.w + c10.w + c01.w + c11.w) * 0.25f;
+        if (writer && xa < w) next[(size_t)(y >> 1) * ow + (xa >> 1)] = o;
+    };
+    const int end = y1 + 1; // last input row taken (clamped into the image by the loads)
+    for (int r = y0 - 2; r <= end; r += 5) {
+        step(r, std::integral_constant<int, 0>{});
+        if (r + 1 > end) break;
+        step(r + 1, std::integral_constant<int, 1>{});
+        if (r + 2 > end) break;
+        step(r + 2, std::integral_constant<int, 2>{});
+        if (r + 3 > end) break;
+        step(r + 3, std::integral_constant<int, 3>{});
+        if (r + 4 > end) break;
+        step(r + 4, std::integral_constant<int, 4>{});
+    }
+}
+
 // Derivatives of one pyramid level, computed once per level instead of once per Jacobi step:
 // (ix, iy, it) with exactly the expressions of horn_schunck.wgsl:58-82, 12 bytes per cell.  The
 // denominator lambda + ix*ix + iy*iy and its reciprocal are recomputed from them when a tile is
@@ -341,15 +447,6 @@ struct HsRow {
 struct HsCoef {
     float ix, iy, it, den, zinv;
 };
-
-__device__ __forceinline__ float hs_lane_up(float v) // value of lane-1
-{
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138 /*wave_shr:1*/, 0xF, 0xF, true));
-}
-__device__ __forceinline__ float hs_lane_down(float v) // value of lane+1
-{
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x130 /*wave_shl:1*/, 0xF, 0xF, true));
-}
 
 template <int K>
 __global__ __launch_bounds__(256) void k_hs_stream(const float *__restrict__ coef_all, size_t coef_stride, float lambda,
@@ -532,9 +629,36 @@ hipError_t launch_horn_schunck(const float *i1, const float *i2, const float *fl
 
 // One fused pyramid level: `in` is RGBA8 (u8_input) or f32 RGBA; writes the level's luminance plane
 // (w*h floats) and the f32 RGBA input of the next level; `next` may be null (last level).
+#ifndef NUS_PYR_STREAM_WAVES
+#define NUS_PYR_STREAM_WAVES 8192 // waves a launch of the streamed pyramid kernel aims for
+#endif
+#ifndef NUS_PYR_STREAM_MIN_ROWS
+#define NUS_PYR_STREAM_MIN_ROWS 32 // shortest row block (4 halo rows are blurred horizontally per block)
+#endif
+
 hipError_t launch_pyramid_level(const void *in, bool u8_input, float *level_lum, float *next, uint32_t w, uint32_t h,
-                                hipStream_t stream, uint32_t n, size_t in_stride, size_t lum_stride, size_t next_stride)
+                                hipStream_t stream, uint32_t n, size_t in_stride, size_t lum_stride, size_t next_stride, int kernel)
 {
+    if (kernel != kJacobiTiles) {
+        const uint32_t strips = cdiv(w, 2 * kWave - 4);
+        const uint64_t columns = (uint64_t)strips * n;
+        const uint32_t want = (uint32_t)std::min<uint64_t>((NUS_PYR_STREAM_WAVES + columns - 1) / columns,
+                                                           std::max<uint32_t>(h / NUS_PYR_STREAM_MIN_ROWS, 1));
+        const uint32_t rows_per_block = (cdiv(h, want) + 1) & ~1u; // even: a 2x2 block never straddles two row blocks
+        const uint32_t row_blocks = cdiv(h, rows_per_block);
+        if (kernel == kJacobiStream || columns * row_blocks >= 2048) {
+            const dim3 block(256), grid(cdiv(strips * row_blocks, 4), n);
+            if (u8_input)
+                hipLaunchKernelGGL(k_pyramid_stream<true>, grid, block, 0, stream, in, in_stride, level_lum, lum_stride,
+                                   reinterpret_cast<float4 *>(next), next_stride, (int)w, (int)h, (int)strips, (int)row_blocks,
+                                   (int)rows_per_block);
+            else
+                hipLaunchKernelGGL(k_pyramid_stream<false>, grid, block, 0, stream, in, in_stride, level_lum, lum_stride,
+                                   reinterpret_cast<float4 *>(next), next_stride, (int)w, (int)h, (int)strips, (int)row_blocks,
+                                   (int)rows_per_block);
+            return hipGetLastError();
+        }
+    }
     const dim3 block(kPyrThreads), grid(cdiv(w, kPyrTW), cdiv(h, kPyrTH), n);
     if (u8_input)
         hipLaunchKernelGGL(k_pyramid_level<true>, grid, block, 0, stream, in, in_stride, level_lum, lum_stride,

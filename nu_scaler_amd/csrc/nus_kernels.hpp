@@ -156,9 +156,11 @@ hipError_t launch_horn_schunck(const float *i1, const float *i2, const float *fl
 // b + z * stride (strides in elements of the buffer's type; bytes for an RGBA8 input).  n = 1 ignores the strides.
 // blur H + blur V + downsample of one level in one launch (LDS tile with a 2-pixel halo); the level
 // itself is written as its luminance plane (w*h floats), which is all Horn-Schunck reads of it.
+// `kernel`: LDS-tile or register-pipelined ("streamed") form of the pyramid and the multi-step Jacobi kernels
+enum JacobiKernel { kJacobiAuto = 0, kJacobiTiles = 1, kJacobiStream = 2 };
 hipError_t launch_pyramid_level(const void *in, bool u8_input, float *level_lum, float *next, uint32_t w, uint32_t h,
                                 hipStream_t stream, uint32_t n = 1, size_t in_stride = 0, size_t lum_stride = 0,
-                                size_t next_stride = 0);
+                                size_t next_stride = 0, int kernel = 0);
 // Fast path of the same iteration: derivatives once per level, then K steps per launch in LDS.
 // i1 / i2: f32 RGBA level images, or their luminance planes (luminance_planes).
 hipError_t launch_hs_prepare(const float *i1, const float *i2, bool luminance_planes, float *coef, uint32_t w, uint32_t h,
@@ -168,8 +170,6 @@ hipError_t launch_hs_level_setup(const float *l1, const float *l2, float *coef, 
                                  uint32_t cw, uint32_t ch, float *flow, float scale, hipStream_t stream, uint32_t n = 1,
                                  size_t lum_stride = 0, size_t coef_stride = 0, size_t coarse_stride = 0,
                                  size_t flow_stride = 0);
-// `kernel`: which multi-step Jacobi kernel launch_hs_iterate uses
-enum JacobiKernel { kJacobiAuto = 0, kJacobiTiles = 1, kJacobiStream = 2 };
 hipError_t launch_hs_iterate(const float *coef, float lambda, float **flow_a, float **flow_b, uint32_t w, uint32_t h,
                              uint32_t iterations, bool zero_start, float *final_out, hipStream_t stream, uint32_t n = 1,
                              size_t coef_stride = 0, size_t flow_stride = 0, size_t final_stride = 0, int kernel = 0);

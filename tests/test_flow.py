@@ -119,7 +119,8 @@ def test_flow_estimate_matches_oracle_and_improves_interpolation(nsc, oracle_mod
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("size,levels", [((67, 35), 3), ((130, 17), 4), ((64, 16), 2), ((33, 33), 6), ((5, 3), 3)])
+@pytest.mark.parametrize("size,levels", [((67, 35), 3), ((130, 17), 4), ((64, 16), 2), ((33, 33), 6), ((5, 3), 3),
+                                         ((131, 203), 3), ((249, 130), 2)])  # several strips / row blocks of the streamed kernels
 def test_flow_estimate_ragged_sizes(nsc, oracle_mod, size, levels):
     w, h = size
     a, b = oracle_mod.gen_noise(w, h, 41), oracle_mod.gen_noise(w, h, 42)
