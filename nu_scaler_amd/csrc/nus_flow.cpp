@@ -405,22 +405,26 @@ int HipFlowEstimator::solve_batch(const uint8_t *d_frames, uint32_t pairs, const
                                      l + 1 < nl ? cells[l + 1] : 0, jacobi_));
     }
     float *const out = reinterpret_cast<float *>(d_flows);
+    // A level whose Jacobi steps run in the streamed kernel needs no coefficient planes: that kernel takes the
+    // derivatives from the luminance planes of the pair's two frames (consecutive planes of the level) as it goes.
+    auto from_planes = [&](uint32_t l) { return hs_iterate_streams(g.w[l], g.h[l], pairs, jacobi_); };
     auto iterate = [&](uint32_t l, uint32_t iters, bool zero) -> int {
         NUS_HIP(launch_hs_iterate(coef, lambda, &f0, &f1, g.w[l], g.h[l], iters, zero, l == 0 ? out : nullptr, stream, pairs,
-                                  cells[l] * 3, cells[l], cells[0], jacobi_));
+                                  cells[l] * 3, cells[l], cells[0], jacobi_, from_planes(l) ? lum + lum_off[l] : nullptr, cells[l]));
         return kOk;
     };
     // coarsest level: from zero flow (compute_coarse_flow, :1136-1154)
     if (coarse_iters > 0) {
-        NUS_HIP(launch_hs_prepare(lum + lum_off[L], lum + lum_off[L] + cells[L], true, coef, g.w[L], g.h[L], stream, pairs, cells[L],
-                                  cells[L] * 3));
+        if (!from_planes(L))
+            NUS_HIP(launch_hs_prepare(lum + lum_off[L], lum + lum_off[L] + cells[L], true, coef, g.w[L], g.h[L], stream, pairs,
+                                      cells[L], cells[L] * 3));
         if ((rc = iterate(L, coarse_iters, true)) != kOk) return rc;
     } else {
         NUS_HIP(hipMemsetAsync(f0, 0, cells[L] * pairs * 8, stream));
     }
     for (int l = (int)L - 1; l >= 0; --l) {
         const float *l1 = lum + lum_off[l];
-        if (refine_iters > 0)
+        if (refine_iters > 0 && !from_planes((uint32_t)l))
             NUS_HIP(launch_hs_level_setup(l1, l1 + cells[l], coef, g.w[l], g.h[l], f0, g.w[l + 1], g.h[l + 1], f1, 2.0f, stream, pairs,
                                           cells[l], cells[l] * 3, cells[l + 1], cells[l]));
         else

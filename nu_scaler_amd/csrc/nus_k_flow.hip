@@ -448,7 +448,7 @@ struct HsCoef {
     float ix, iy, it, den, zinv;
 };
 
-template <int K>
+template <int K, bool LUM>
 __global__ __launch_bounds__(256) void k_hs_stream(const float *__restrict__ coef_all, size_t coef_stride, float lambda,
                                                    const float2 *__restrict__ fin_all, size_t fin_stride,
                                                    float2 *__restrict__ fout_all, size_t fout_stride, int w, int h, int strips,
@@ -473,13 +473,29 @@ __global__ __launch_bounds__(256) void k_hs_stream(const float *__restrict__ coe
     HsCoef cf[K + 1];   // cf[d]: coefficients of row t - d (cf[0] is only the way in)
 
     auto load_flow = [&](int r) -> float2 { return fin ? fin[(size_t)min(r, hi - 1) * w + xc] : make_float2(0.0f, 0.0f); };
+    // Where a row's (ix, iy, it) come from.  !LUM: the coefficient planes k_hs_prepare wrote (coef_all: 3 floats per
+    // cell).  LUM: the two luminance planes themselves (coef_all = frame 1's plane, frame 2's one coef_stride
+    // floats further on, pairs coef_stride apart as well: consecutive frames of a batch) -- hs_prepare_cell's
+    // expressions on a three-row window of frame 1 (rows clamped into the image by the loads, the neighbouring
+    // columns from the neighbouring lanes), so the 12 B per cell of coefficients are never written or read.
     auto load_coef = [&](int r, float &a, float &b, float &c) {
-        const float *p = coef + ((size_t)min(r, hi - 1) * w + xc) * 3;
-        a = p[0], b = p[1], c = p[2];
+        if constexpr (LUM) {
+            a = coef[(size_t)clampi(r + 1, 0, h - 1) * w + xc];               // frame 1, row r + 1
+            b = coef[coef_stride + (size_t)clampi(r, 0, h - 1) * w + xc];     // frame 2, row r
+            c = 0.0f;
+        } else {
+            const float *p = coef + ((size_t)min(r, hi - 1) * w + xc) * 3;
+            a = p[0], b = p[1], c = p[2];
+        }
     };
     float2 nf = load_flow(lo);
-    float nix, niy, nit;
+    float nix, niy, nit; // !LUM: row t's (ix, iy, it).  LUM: nix = frame 1 row t + 1, niy = frame 2 row t
     load_coef(lo, nix, niy, nit);
+    float l1_above = 0.0f, l1_row = 0.0f; // LUM: frame 1, rows t - 1 and t
+    if constexpr (LUM) {
+        l1_above = coef[(size_t)clampi(lo - 1, 0, h - 1) * w + xc];
+        l1_row = coef[(size_t)lo * w + xc];
+    }
 
     // One pass of the pipeline: row t of the input arrives, every level that has a row to take takes it.
     // STEADY (lo + K <= t < hi): every level has a real arrival and an earlier row -- no conditions.
@@ -489,8 +505,16 @@ __global__ __launch_bounds__(256) void k_hs_stream(const float *__restrict__ coe
         float pix, piy, pit;
         load_coef(t + 1, pix, piy, pit);
         {
-            const float den = lambda + nix * nix + niy * niy;
-            cf[0] = HsCoef{nix, niy, nit, den, 1.0f / den}; // correctly rounded reciprocal, for div_by_recip
+            float ix = nix, iy = niy, it = nit;
+            if constexpr (LUM) { // horn_schunck.wgsl:58-82, as hs_prepare_cell
+                const float left = hs_lane_up(l1_row), right = hs_lane_down(l1_row);
+                ix = ((self_r ? l1_row : right) - (self_l ? l1_row : left)) * 0.5f;
+                iy = (nix - l1_above) * 0.5f;
+                it = niy - l1_row;
+                l1_above = l1_row, l1_row = nix;
+            }
+            const float den = lambda + ix * ix + iy * iy;
+            cf[0] = HsCoef{ix, iy, it, den, 1.0f / den}; // correctly rounded reciprocal, for div_by_recip
         }
         float2 arr = nf; // level 0's arrival: row t of the input flow
 #pragma unroll
@@ -747,11 +771,20 @@ static HsStreamShape hs_stream_shape(uint32_t w, uint32_t h, uint32_t n, uint32_
     return s;
 }
 
+// true: launch_hs_iterate will run the streamed kernel for this level -- which can take the derivatives from the
+// luminance planes (lum1), so the caller need not have k_hs_prepare's coefficient planes written
+bool hs_iterate_streams(uint32_t w, uint32_t h, uint32_t n, int kernel)
+{
+    return kernel != kJacobiTiles && hs_stream_shape(w, h, n, NUS_HS_STREAM_MAXK, kernel == kJacobiStream).row_blocks != 0;
+}
+
 hipError_t launch_hs_iterate(const float *coef, float lambda, float **flow_a, float **flow_b, uint32_t w, uint32_t h,
                              uint32_t iterations, bool zero_start, float *final_out, hipStream_t stream, uint32_t n,
-                             size_t coef_stride, size_t flow_stride, size_t final_stride, int kernel)
+                             size_t coef_stride, size_t flow_stride, size_t final_stride, int kernel, const float *lum1,
+                             size_t lum_stride)
 {
-    if (kernel != kJacobiTiles && hs_stream_shape(w, h, n, NUS_HS_STREAM_MAXK, kernel == kJacobiStream).row_blocks != 0) {
+    if (hs_iterate_streams(w, h, n, kernel)) {
+        if (lum1) coef = lum1, coef_stride = lum_stride; // the kernel takes the derivatives from the planes themselves
         uint32_t launches = (iterations + NUS_HS_STREAM_MAXK - 1) / NUS_HS_STREAM_MAXK;
         while (iterations > 0) {
             const uint32_t k = (iterations + launches - 1) / launches; // even split, 1..MAXK steps per launch
@@ -767,8 +800,12 @@ hipError_t launch_hs_iterate(const float *coef, float lambda, float **flow_a, fl
             const dim3 block(256), grid(cdiv(sh.strips * sh.row_blocks, 4), n);
 #define NUS_HSS(KK)                                                                                                             \
     case KK:                                                                                                                    \
-        hipLaunchKernelGGL((k_hs_stream<KK>), grid, block, 0, stream, coef, coef_stride, lambda, fi, flow_stride, fo, out_stride, \
-                           (int)w, (int)h, (int)sh.strips, (int)sh.row_blocks, (int)sh.rows_per_block);                         \
+        if (lum1)                                                                                                               \
+            hipLaunchKernelGGL((k_hs_stream<KK, true>), grid, block, 0, stream, coef, coef_stride, lambda, fi, flow_stride, fo,  \
+                               out_stride, (int)w, (int)h, (int)sh.strips, (int)sh.row_blocks, (int)sh.rows_per_block);         \
+        else                                                                                                                    \
+            hipLaunchKernelGGL((k_hs_stream<KK, false>), grid, block, 0, stream, coef, coef_stride, lambda, fi, flow_stride, fo, \
+                               out_stride, (int)w, (int)h, (int)sh.strips, (int)sh.row_blocks, (int)sh.rows_per_block);         \
         break;
             switch (k) {
                 NUS_HSS(1) NUS_HSS(2) NUS_HSS(3) NUS_HSS(4) NUS_HSS(5)
