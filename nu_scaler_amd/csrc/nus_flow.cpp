@@ -391,8 +391,15 @@ int HipFlowEstimator::solve_batch(const uint8_t *d_frames, uint32_t pairs, const
     const size_t in_odd = nl > 1 ? cells[1] : 0, in_even = nl > 2 ? cells[2] : 0; // largest level input each buffer holds
     if ((rc = reserve(in_odd * nf * 16, 0)) != kOk || (rc = reserve(in_even * nf * 16, 1)) != kOk ||
         (rc = reserve(cells[0] * pairs * 8, 2)) != kOk || (rc = reserve(cells[0] * pairs * 8, 3)) != kOk ||
-        (rc = reserve(lum_total * 4, 4)) != kOk || (rc = reserve(cells[0] * pairs * 12, 5)) != kOk)
+        (rc = reserve(lum_total * 4, 4)) != kOk)
         return rc;
+    // A level whose Jacobi steps run in the streamed kernel needs no coefficient planes: that kernel takes the
+    // derivatives from the luminance planes of the pair's two frames (consecutive planes of the level) as it goes.
+    auto from_planes = [&](uint32_t l) { return hs_iterate_streams(g.w[l], g.h[l], pairs, jacobi_); };
+    size_t coef_cells = 0;
+    for (uint32_t l = 0; l < nl; ++l)
+        if (!from_planes(l) && cells[l] > coef_cells) coef_cells = cells[l];
+    if (coef_cells != 0 && (rc = reserve(coef_cells * pairs * 12, 5)) != kOk) return rc;
     float *level_in[2] = {static_cast<float *>(slot_[0]), static_cast<float *>(slot_[1])}; // input of level l: [(l - 1) & 1]
     float *lum = static_cast<float *>(slot_[4]), *coef = static_cast<float *>(slot_[5]);
     float *f0 = static_cast<float *>(slot_[2]), *f1 = static_cast<float *>(slot_[3]);
@@ -405,12 +412,12 @@ int HipFlowEstimator::solve_batch(const uint8_t *d_frames, uint32_t pairs, const
                                      l + 1 < nl ? cells[l + 1] : 0, jacobi_));
     }
     float *const out = reinterpret_cast<float *>(d_flows);
-    // A level whose Jacobi steps run in the streamed kernel needs no coefficient planes: that kernel takes the
-    // derivatives from the luminance planes of the pair's two frames (consecutive planes of the level) as it goes.
-    auto from_planes = [&](uint32_t l) { return hs_iterate_streams(g.w[l], g.h[l], pairs, jacobi_); };
-    auto iterate = [&](uint32_t l, uint32_t iters, bool zero) -> int {
+    // `coarse`: the level continues the flow of level l + 1 in f0, which the first launch upsamples as it loads it
+    auto iterate = [&](uint32_t l, uint32_t iters, bool zero, bool coarse) -> int {
         NUS_HIP(launch_hs_iterate(coef, lambda, &f0, &f1, g.w[l], g.h[l], iters, zero, l == 0 ? out : nullptr, stream, pairs,
-                                  cells[l] * 3, cells[l], cells[0], jacobi_, from_planes(l) ? lum + lum_off[l] : nullptr, cells[l]));
+                                  cells[l] * 3, cells[l], cells[0], jacobi_, from_planes(l) ? lum + lum_off[l] : nullptr, cells[l],
+                                  coarse ? f0 : nullptr, coarse ? g.w[l + 1] : 0, coarse ? g.h[l + 1] : 0, 2.0f,
+                                  coarse ? cells[l + 1] : 0));
         return kOk;
     };
     // coarsest level: from zero flow (compute_coarse_flow, :1136-1154)
@@ -418,13 +425,17 @@ int HipFlowEstimator::solve_batch(const uint8_t *d_frames, uint32_t pairs, const
         if (!from_planes(L))
             NUS_HIP(launch_hs_prepare(lum + lum_off[L], lum + lum_off[L] + cells[L], true, coef, g.w[L], g.h[L], stream, pairs,
                                       cells[L], cells[L] * 3));
-        if ((rc = iterate(L, coarse_iters, true)) != kOk) return rc;
+        if ((rc = iterate(L, coarse_iters, true, false)) != kOk) return rc;
     } else {
         NUS_HIP(hipMemsetAsync(f0, 0, cells[L] * pairs * 8, stream));
     }
     for (int l = (int)L - 1; l >= 0; --l) {
         const float *l1 = lum + lum_off[l];
-        if (refine_iters > 0 && !from_planes((uint32_t)l))
+        if (refine_iters > 0 && from_planes((uint32_t)l)) { // derivatives and upsampled flow both computed inside the Jacobi kernel
+            if ((rc = iterate((uint32_t)l, refine_iters, false, true)) != kOk) return rc;
+            continue;
+        }
+        if (refine_iters > 0)
             NUS_HIP(launch_hs_level_setup(l1, l1 + cells[l], coef, g.w[l], g.h[l], f0, g.w[l + 1], g.h[l + 1], f1, 2.0f, stream, pairs,
                                           cells[l], cells[l] * 3, cells[l + 1], cells[l]));
         else
@@ -432,7 +443,7 @@ int HipFlowEstimator::solve_batch(const uint8_t *d_frames, uint32_t pairs, const
         float *t = f0;
         f0 = f1;
         f1 = t;
-        if (refine_iters > 0 && (rc = iterate((uint32_t)l, refine_iters, false)) != kOk) return rc;
+        if (refine_iters > 0 && (rc = iterate((uint32_t)l, refine_iters, false, false)) != kOk) return rc;
     }
     if (f0 != out) NUS_HIP(hipMemcpyAsync(out, f0, cells[0] * pairs * 8, hipMemcpyDeviceToDevice, stream));
     return kOk;

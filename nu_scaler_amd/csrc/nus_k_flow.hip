@@ -421,6 +421,24 @@ __global__ __launch_bounds__(NT) void k_hs_tiled(const float *__restrict__ coef_
     }
 }
 
+// flow_upsample.wgsl:27-36 (linear clamp-to-edge sampler in texel space), vectors * scale
+__device__ __forceinline__ float2 flow_upsample_cell(const float2 *__restrict__ src, int sw, int sh, int x, int y, int dw, int dh,
+                                                     float scale)
+{
+    const float u = ((float)x + 0.5f) / (float)dw, v = ((float)y + 0.5f) / (float)dh;
+    const float sx = u * (float)sw - 0.5f, sy = v * (float)sh - 0.5f;
+    const float fx0 = floorf(sx), fy0 = floorf(sy);
+    const float fx = sx - fx0, fy = sy - fy0;
+    const int x0 = clampi((int)fx0, 0, sw - 1), x1 = clampi((int)fx0 + 1, 0, sw - 1);
+    const int y0 = clampi((int)fy0, 0, sh - 1), y1 = clampi((int)fy0 + 1, 0, sh - 1);
+    const float2 a = src[(size_t)y0 * sw + x0], b = src[(size_t)y0 * sw + x1];
+    const float2 c = src[(size_t)y1 * sw + x0], d = src[(size_t)y1 * sw + x1];
+    float2 r;
+    r.x = ((a.x * (1.0f - fx) + b.x * fx) * (1.0f - fy) + (c.x * (1.0f - fx) + d.x * fx) * fy) * scale;
+    r.y = ((a.y * (1.0f - fx) + b.y * fx) * (1.0f - fy) + (c.y * (1.0f - fx) + d.y * fx) * fy) * scale;
+    return r;
+}
+
 // ---- K Jacobi steps per launch, pipelined through registers ("streamed") -------------------------
 // A wave owns a strip of 64 columns (lane = column; the outer K on each side are halo, so 64 - 2K
 // columns are written) and walks down the rows [lo, hi) of its row block ONCE.  The K steps run as
@@ -448,11 +466,18 @@ struct HsCoef {
     float ix, iy, it, den, zinv;
 };
 
-template <int K, bool LUM>
+struct HsCoarse { // UPS: the flow a level starts from is the coarser level's, upsampled as it is loaded
+    const float2 *flow;
+    size_t stride;
+    int w, h;
+    float scale;
+};
+
+template <int K, bool LUM, bool UPS>
 __global__ __launch_bounds__(256) void k_hs_stream(const float *__restrict__ coef_all, size_t coef_stride, float lambda,
                                                    const float2 *__restrict__ fin_all, size_t fin_stride,
                                                    float2 *__restrict__ fout_all, size_t fout_stride, int w, int h, int strips,
-                                                   int row_blocks, int rows_per_block)
+                                                   int row_blocks, int rows_per_block, HsCoarse coarse)
 {
     constexpr int U = kWave - 2 * K; // columns a wave writes
     const int lane = threadIdx.x & (kWave - 1);
@@ -472,7 +497,12 @@ __global__ __launch_bounds__(256) void k_hs_stream(const float *__restrict__ coe
     float pu[K], pv[K]; // level j: 0 + l + c + r of the row before that one
     HsCoef cf[K + 1];   // cf[d]: coefficients of row t - d (cf[0] is only the way in)
 
-    auto load_flow = [&](int r) -> float2 { return fin ? fin[(size_t)min(r, hi - 1) * w + xc] : make_float2(0.0f, 0.0f); };
+    auto load_flow = [&](int r) -> float2 {
+        if constexpr (UPS) // k_flow_upsample's cell, not written out first (flow_upsample.wgsl)
+            return flow_upsample_cell(coarse.flow + blockIdx.y * coarse.stride, coarse.w, coarse.h, xc, min(r, hi - 1), w, h, coarse.scale);
+        else
+            return fin ? fin[(size_t)min(r, hi - 1) * w + xc] : make_float2(0.0f, 0.0f);
+    };
     // Where a row's (ix, iy, it) come from.  !LUM: the coefficient planes k_hs_prepare wrote (coef_all: 3 floats per
     // cell).  LUM: the two luminance planes themselves (coef_all = frame 1's plane, frame 2's one coef_stride
     // floats further on, pairs coef_stride apart as well: consecutive frames of a batch) -- hs_prepare_cell's
@@ -569,24 +599,6 @@ __global__ __launch_bounds__(256) void k_hs_stream(const float *__restrict__ coe
     for (; t < min(lo + K, hi + K); ++t) pass(t, std::false_type{}); // fill
     for (; t < hi; ++t) pass(t, std::true_type{});
     for (; t < hi + K; ++t) pass(t, std::false_type{}); // drain
-}
-
-// flow_upsample.wgsl:27-36 (linear clamp-to-edge sampler in texel space), vectors * scale
-__device__ __forceinline__ float2 flow_upsample_cell(const float2 *__restrict__ src, int sw, int sh, int x, int y, int dw, int dh,
-                                                     float scale)
-{
-    const float u = ((float)x + 0.5f) / (float)dw, v = ((float)y + 0.5f) / (float)dh;
-    const float sx = u * (float)sw - 0.5f, sy = v * (float)sh - 0.5f;
-    const float fx0 = floorf(sx), fy0 = floorf(sy);
-    const float fx = sx - fx0, fy = sy - fy0;
-    const int x0 = clampi((int)fx0, 0, sw - 1), x1 = clampi((int)fx0 + 1, 0, sw - 1);
-    const int y0 = clampi((int)fy0, 0, sh - 1), y1 = clampi((int)fy0 + 1, 0, sh - 1);
-    const float2 a = src[(size_t)y0 * sw + x0], b = src[(size_t)y0 * sw + x1];
-    const float2 c = src[(size_t)y1 * sw + x0], d = src[(size_t)y1 * sw + x1];
-    float2 r;
-    r.x = ((a.x * (1.0f - fx) + b.x * fx) * (1.0f - fy) + (c.x * (1.0f - fx) + d.x * fx) * fy) * scale;
-    r.y = ((a.y * (1.0f - fx) + b.y * fx) * (1.0f - fy) + (c.y * (1.0f - fx) + d.y * fx) * fy) * scale;
-    return r;
 }
 
 __global__ __launch_bounds__(256) void k_flow_upsample(const float2 *__restrict__ src, size_t src_stride, int sw, int sh,
@@ -781,7 +793,7 @@ bool hs_iterate_streams(uint32_t w, uint32_t h, uint32_t n, int kernel)
 hipError_t launch_hs_iterate(const float *coef, float lambda, float **flow_a, float **flow_b, uint32_t w, uint32_t h,
                              uint32_t iterations, bool zero_start, float *final_out, hipStream_t stream, uint32_t n,
                              size_t coef_stride, size_t flow_stride, size_t final_stride, int kernel, const float *lum1,
-                             size_t lum_stride)
+                             size_t lum_stride, const float *coarse, uint32_t cw, uint32_t ch, float coarse_scale, size_t coarse_stride)
 {
     if (hs_iterate_streams(w, h, n, kernel)) {
         if (lum1) coef = lum1, coef_stride = lum_stride; // the kernel takes the derivatives from the planes themselves
@@ -797,15 +809,22 @@ hipError_t launch_hs_iterate(const float *coef, float lambda, float **flow_a, fl
             auto fo = reinterpret_cast<float2 *>(*flow_b);
             zero_start = false;
             const HsStreamShape sh = hs_stream_shape(w, h, n, k, true);
+            // the first launch of a level that continues a coarser one takes that level's flow, upsampled as it is loaded
+            const bool ups = coarse != nullptr && lum1 != nullptr;
+            const HsCoarse hc{reinterpret_cast<const float2 *>(coarse), coarse_stride, (int)cw, (int)ch, coarse_scale};
+            coarse = nullptr;
             const dim3 block(256), grid(cdiv(sh.strips * sh.row_blocks, 4), n);
+#define NUS_HSS_L(KK, LL, UU)                                                                                               \
+    hipLaunchKernelGGL((k_hs_stream<KK, LL, UU>), grid, block, 0, stream, coef, coef_stride, lambda, fi, flow_stride, fo, out_stride, \
+                       (int)w, (int)h, (int)sh.strips, (int)sh.row_blocks, (int)sh.rows_per_block, hc)
 #define NUS_HSS(KK)                                                                                                             \
     case KK:                                                                                                                    \
-        if (lum1)                                                                                                               \
-            hipLaunchKernelGGL((k_hs_stream<KK, true>), grid, block, 0, stream, coef, coef_stride, lambda, fi, flow_stride, fo,  \
-                               out_stride, (int)w, (int)h, (int)sh.strips, (int)sh.row_blocks, (int)sh.rows_per_block);         \
+        if (lum1 && ups)                                                                                                        \
+            NUS_HSS_L(KK, true, true);                                                                                          \
+        else if (lum1)                                                                                                          \
+            NUS_HSS_L(KK, true, false);                                                                                         \
         else                                                                                                                    \
-            hipLaunchKernelGGL((k_hs_stream<KK, false>), grid, block, 0, stream, coef, coef_stride, lambda, fi, flow_stride, fo, \
-                               out_stride, (int)w, (int)h, (int)sh.strips, (int)sh.row_blocks, (int)sh.rows_per_block);         \
+            NUS_HSS_L(KK, false, false);                                                                                        \
         break;
             switch (k) {
                 NUS_HSS(1) NUS_HSS(2) NUS_HSS(3) NUS_HSS(4) NUS_HSS(5)
@@ -817,6 +836,7 @@ hipError_t launch_hs_iterate(const float *coef, float lambda, float **flow_a, fl
 #endif
             }
 #undef NUS_HSS
+#undef NUS_HSS_L
             hipError_t e = hipGetLastError();
             if (e != hipSuccess) return e;
             iterations -= k;

@@ -173,7 +173,8 @@ hipError_t launch_hs_level_setup(const float *l1, const float *l2, float *coef, 
 hipError_t launch_hs_iterate(const float *coef, float lambda, float **flow_a, float **flow_b, uint32_t w, uint32_t h,
                              uint32_t iterations, bool zero_start, float *final_out, hipStream_t stream, uint32_t n = 1,
                              size_t coef_stride = 0, size_t flow_stride = 0, size_t final_stride = 0, int kernel = 0,
-                             const float *lum1 = nullptr, size_t lum_stride = 0);
+                             const float *lum1 = nullptr, size_t lum_stride = 0, const float *coarse = nullptr, uint32_t cw = 0,
+                             uint32_t ch = 0, float coarse_scale = 0.0f, size_t coarse_stride = 0);
 bool hs_iterate_streams(uint32_t w, uint32_t h, uint32_t n, int kernel);
 hipError_t launch_flow_upsample(const float *src, uint32_t sw, uint32_t sh, float *dst, uint32_t dw, uint32_t dh,
                                 float scale, hipStream_t stream, uint32_t n = 1, size_t src_stride = 0, size_t dst_stride = 0);
