@@ -95,9 +95,12 @@ __device__ __forceinline__ uint4 swz4(const uint4 v, uint32_t sel)
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
 // Correctly rounded x / y from z = RN(1/y) with one multiply and two FMAs (Markstein): q = RN(x z),
-// r = x - q y (exact in the FMA), result = RN(q + r z).  Equal to the IEEE quotient for every finite
-// x when y = 9 (checked exhaustively on the CPU) and for every y whose mantissa is not all ones;
-// those y take the real division.  Replaces ~11 slow-class instructions per division by 3 fast ones.
+// r = x - q y (exact in the FMA), result = RN(q + r z).  Equal to the IEEE quotient for every y whose
+// mantissa is not all ones (Markstein's theorem) and, checked exhaustively over every mantissa of x on the
+// CPU (tests/test_div_by_recip.py), also for the all-ones mantissa -- the theorem's exception is not needed
+// for this sequence -- and for y = 9 and y = 255, as long as quotient and remainder stay in the normal range
+// (the sequence is invariant under scaling x or y by powers of two).  Replaces ~11 slow-class instructions
+// per division by 3 fast ones.
 __device__ __forceinline__ float div_by_recip(float x, float y, float z)
 {
     const float q = x * z;

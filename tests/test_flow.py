@@ -81,10 +81,11 @@ def test_flow_primitives_match_oracle(nsc, oracle_mod, size):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("size", [(200, 300), (54, 129), (55, 128), (117, 257)])
+@pytest.mark.parametrize("size", [(200, 300), (64, 129), (65, 128), (118, 90), (119, 257), (173, 70)])
 def test_horn_schunck_streamed_kernel_row_blocks_and_strips(nsc, oracle_mod, size):
     """The register-pipelined kernel forced onto images tall enough for several row blocks (each with a K-row halo
-    whose rows are wrong by construction and must never be written) and widths at / one past a strip boundary."""
+    whose rows are wrong by construction and must never be written) and widths of one strip, two overlapping strips and
+    at / one past the width where a third strip appears (118 with five steps per launch)."""
     w, h = size
     fe = nsc.FlowEstimator()
     img = oracle_mod.rgba8_to_f32(oracle_mod.gen_noise(w, h, 5))
