@@ -361,10 +361,19 @@ int HipFlowEstimator::estimate_device_stream(const void *d_frames, uint32_t n_fr
     // Tiled kernels: the pairs of a chunk go through every stage TOGETHER, one launch per stage with the pairs on the
     // grid's z axis -- a 480x270 level of one pair is 510 tiles (two per CU, latency bound); of 64 pairs it fills the GPU.
     const uint32_t n_pairs = n_frames - 1;
-    // per pair: luminance planes 4/3 x 4 B, level inputs (1/4 + 1/16) x 16 B, coefficients 12 B, two flows 16 B per pixel
-    const size_t per_pair = (size_t)w * h * 43;
-    uint32_t chunk = (uint32_t)(kStreamWorkspaceBytes / per_pair);
-    chunk = chunk < 1 ? 1 : (chunk > kStreamMaxChunkPairs ? kStreamMaxChunkPairs : chunk);
+    // per pair: luminance planes 4/3 x 4 B, level inputs (1/4 + 1/16) x 16 B, two flows 16 B per pixel -- and 12 B of
+    // coefficients if some level's Jacobi steps run on LDS tiles (the streamed kernel takes them from the planes)
+    auto chunk_for = [&](size_t bytes_per_pixel) {
+        const uint32_t c = (uint32_t)(kStreamWorkspaceBytes / ((size_t)w * h * bytes_per_pixel));
+        return c < 1 ? 1u : (c > kStreamMaxChunkPairs ? kStreamMaxChunkPairs : c);
+    };
+    uint32_t chunk = chunk_for(31);
+    if (chunk > n_pairs) chunk = n_pairs;
+    for (uint32_t l = 0; l < g.levels; ++l)
+        if (!hs_iterate_streams(g.w[l], g.h[l], chunk, jacobi_)) {
+            chunk = chunk_for(43);
+            break;
+        }
     for (uint32_t c0 = 0; c0 < n_pairs; c0 += chunk) {
         const uint32_t pairs = n_pairs - c0 < chunk ? n_pairs - c0 : chunk;
         if ((rc = solve_batch(frames + (size_t)c0 * frame_bytes, pairs, g, coarse_iters, refine_iters, lambda,

@@ -54,9 +54,10 @@ private:
     int build_pyramid(const void *frame, int pyr_slot, const Pyramid &g, hipStream_t stream);
     int solve(int slot_a, int slot_b, const Pyramid &g, uint32_t coarse_iters, uint32_t refine_iters, float lambda,
               void *d_flow_out, hipStream_t stream);
-    // tiled kernels, a chunk of consecutive pairs per launch (pairs on the grid's z axis): as many as fit the
-    // workspace budget (88 MB per 1080p pair), at most 64 -- beyond that the launches gain nothing
-    static constexpr uint32_t kStreamMaxChunkPairs = 64;
+    // multi-step kernels, a chunk of consecutive pairs per launch (pairs on the grid's y / z axis): as many as fit the
+    // workspace budget (64 MB per 1080p pair, 88 MB with coefficient planes), at most 100 -- 1080p: 93 pairs;
+    // 64 -> 100 pairs per chunk: 76 -> 71 us per pair on a 300-pair stream (profiles/r02_flow_jacobi_streamed_ab.txt)
+    static constexpr uint32_t kStreamMaxChunkPairs = 100;
     static constexpr size_t kStreamWorkspaceBytes = (size_t)6 << 30;
     int solve_batch(const uint8_t *d_frames, uint32_t pairs, const Pyramid &g, uint32_t coarse_iters, uint32_t refine_iters,
                     float lambda, uint8_t *d_flows, hipStream_t stream);

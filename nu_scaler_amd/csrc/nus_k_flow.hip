@@ -761,25 +761,36 @@ hipError_t launch_hs_level_setup(const float *l1, const float *l2, float *coef, 
 #ifndef NUS_HS_STREAM_MIN_ROWS
 #define NUS_HS_STREAM_MIN_ROWS 64 // shortest row block: 2K halo rows and the K passes of pipeline fill are paid per block
 #endif
-#ifndef NUS_HS_STREAM_WAVES
-#define NUS_HS_STREAM_WAVES 5120 // waves a launch aims for: row blocks are made shorter until there are this many
+#ifndef NUS_HS_STREAM_MIN_ROWS
+#define NUS_HS_STREAM_MIN_ROWS 32 // shortest row block: 2K halo rows and the K passes of pipeline fill are paid per block
 #endif
 #ifndef NUS_HS_STREAM_MIN_WAVES
 #define NUS_HS_STREAM_MIN_WAVES 1024 // below this the LDS tiles fill the chip better
 #endif
 
-// The streamed kernel's launch shape for a level: strips of 64 - 2K columns, row blocks as tall as still gives the
-// chip about eight waves per CU.  row_blocks == 0: not enough independent strips, use the LDS tiles.
+// The streamed kernel's launch shape for a level: strips of 64 - 2K columns, cut into row blocks.  The kernel is bound
+// by instruction issue and all its waves take the same time, so a launch costs (waves per SIMD, rounded up) x (passes
+// per wave = rows of a block + 2K halo rows + K passes of fill); the number of row blocks minimises that among the
+// shapes with at least three waves per SIMD (fewer do not cover each other's latencies).
+// row_blocks == 0: not enough independent strips, use the LDS tiles.
 struct HsStreamShape {
     uint32_t strips, row_blocks, rows_per_block;
 };
 static HsStreamShape hs_stream_shape(uint32_t w, uint32_t h, uint32_t n, uint32_t k, bool force)
 {
+    constexpr uint64_t kSimds = 1024; // 256 CUs x 4
     HsStreamShape s{cdiv(w, kWave - 2 * k), 1, h};
     const uint64_t columns = (uint64_t)s.strips * n;
-    const uint32_t want = (uint32_t)std::min<uint64_t>((NUS_HS_STREAM_WAVES + columns - 1) / columns, std::max<uint32_t>(h / NUS_HS_STREAM_MIN_ROWS, 1));
-    s.rows_per_block = cdiv(h, want);
-    s.row_blocks = cdiv(h, s.rows_per_block);
+    const uint32_t max_blocks = std::max<uint32_t>(h / NUS_HS_STREAM_MIN_ROWS, 1);
+    uint64_t best = ~0ull;
+    for (uint32_t rb = 1; rb <= max_blocks; ++rb) {
+        const uint32_t rows = cdiv(h, rb);
+        if (cdiv(h, rows) != rb) continue; // the same blocks as a smaller count
+        const uint64_t waves = columns * rb;
+        if (waves < 3 * kSimds && rb != max_blocks) continue;
+        const uint64_t cost = ((waves + kSimds - 1) / kSimds) * (rows + 3 * k);
+        if (cost < best) best = cost, s.row_blocks = rb, s.rows_per_block = rows;
+    }
     if (!force && columns * s.row_blocks < NUS_HS_STREAM_MIN_WAVES) s.row_blocks = 0;
     return s;
 }
