@@ -7,10 +7,10 @@ cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $out -o fl -- python3 $root/tools/flow_bench.py "$@" > $out.log 2>&1 || tail -3 $out.log
 f=$(find $out -name "*kernel_stats.csv" | head -1)
 python3 - "$f" <<'PY'
-import csv, sys
+import csv, re, sys
 for r in csv.DictReader(open(sys.argv[1])):
     n = r["Name"]
     if "nus::" in n or "rocclr" in n:
-        short = n.split("::")[-1].split("(")[0] if "rocclr" not in n else n
+        short = (re.search(r"k_\w+(<[^>]*>)?", n) or re.search(r".*", n)).group(0) if "rocclr" not in n else n
         print(f"{short:36s} calls {int(r['Calls']):4d}  avg {float(r['AverageNs'])/1e3:8.2f} us  {float(r['Percentage']):5.1f} %")
 PY
