@@ -761,9 +761,6 @@ hipError_t launch_hs_level_setup(const float *l1, const float *l2, float *coef, 
 #ifndef NUS_HS_STREAM_MIN_ROWS
 #define NUS_HS_STREAM_MIN_ROWS 64 // shortest row block: 2K halo rows and the K passes of pipeline fill are paid per block
 #endif
-#ifndef NUS_HS_STREAM_MIN_ROWS
-#define NUS_HS_STREAM_MIN_ROWS 32 // shortest row block: 2K halo rows and the K passes of pipeline fill are paid per block
-#endif
 #ifndef NUS_HS_STREAM_MIN_WAVES
 #define NUS_HS_STREAM_MIN_WAVES 1024 // below this the LDS tiles fill the chip better
 #endif

@@ -17,14 +17,17 @@ flow = torch.empty((h, w, 2), dtype=torch.float32, device=dev)
 fe = nsc.FlowEstimator(levels=levels, coarse_iterations=ci, refine_iterations=ri)
 s = torch.cuda.current_stream().cuda_stream
 a, b = frames[0].data_ptr(), frames[1].data_ptr()
-for _ in range(2):
-    fe.estimate_device(a, b, w, h, flow.data_ptr(), s)
-torch.cuda.synchronize()
-e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-n = 10
-e0.record()
-for _ in range(n):
-    fe.estimate_device(a, b, w, h, flow.data_ptr(), s)
-e1.record()
-torch.cuda.synchronize()
-print(f"flow estimate 1080p levels={levels} coarse={ci} refine={ri}: {e0.elapsed_time(e1)/n*1e3:.1f} us per pair")
+modes = [int(m) for m in sys.argv[4:]] or [1]  # nus_flow_set_tiled: 1 kernels by size, 2 LDS tiles, 3 streamed
+for mode in modes:
+    fe.set_tiled(mode)
+    for _ in range(2):
+        fe.estimate_device(a, b, w, h, flow.data_ptr(), s)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    n = 10
+    e0.record()
+    for _ in range(n):
+        fe.estimate_device(a, b, w, h, flow.data_ptr(), s)
+    e1.record()
+    torch.cuda.synchronize()
+    print(f"flow estimate 1080p levels={levels} coarse={ci} refine={ri} kernel mode {mode}: {e0.elapsed_time(e1)/n*1e3:.1f} us per pair")
