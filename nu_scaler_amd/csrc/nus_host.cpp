@@ -244,6 +244,16 @@ void HipUpscaler::choose_resize_variant(bool x2)
         }
         xs_cls_x_.clear(), xs_cls_y_.clear(), xs_wcls_x_.clear(), xs_wcls_y_.clear();
     }
+    // x3/2 (720p -> 1080p, 1440p -> 4K): the same design with three output rows per input row pair (nus_k_lanczos_r32.hip);
+    // weights by class of the input pair on both axes, as at x3
+    if (!force_general_ && 2 * (uint64_t)ow_ == 3 * (uint64_t)iw_ && 2 * (uint64_t)oh_ == 3 * (uint64_t)ih_ && (iw_ % 8) == 0 &&
+        (ih_ % 2) == 0 && iw_ >= 32 && ih_ >= 16 && addressable && lanczos_r32_phase_frame(tx_, wx6_) &&
+        lanczos_r32_phase_frame(ty_, wy6_) && lanczos_r32_weight_classes(tx_, wx6_, true, xs_cls_x_, xs_wcls_x_) &&
+        lanczos_r32_weight_classes(ty_, wy6_, false, xs_cls_y_, xs_wcls_y_)) {
+        variant_ = Variant::LanczosR32RegWin;
+        return;
+    }
+    xs_cls_x_.clear(), xs_cls_y_.clear(), xs_wcls_x_.clear(), xs_wcls_y_.clear();
     if (force_per_pixel_) return;
     // vertical down-scaling: stream the input rows through 7 accumulator slots, if the windows allow it and a
     // 64-column output segment's footprint fits 5 columns per lane
@@ -370,6 +380,13 @@ int HipUpscaler::upload_tables()
                     dt_.lz_wxs_right[q][j] = wx6_[((size_t)ow_ - 4 * xs_factor_ + q) * 6 + j];
                 }
         }
+        if (variant_ == Variant::LanczosR32RegWin) {
+            UP(wy6_, lz_wy6);
+            UP(xs_cls_x_, lz_xs_cls_x);
+            UP(xs_cls_y_, lz_xs_cls_y);
+            UP(xs_wcls_x_, lz_xs_wcls_x);
+            UP(xs_wcls_y_, lz_xs_wcls_y);
+        }
         if (variant_ == Variant::LanczosX2RegWin) {
             UP(wy6_, lz_wy6);
             for (int j = 0; j < 6; ++j) {
@@ -469,6 +486,10 @@ int HipUpscaler::enqueue(const uint8_t *d_in, uint8_t *d_out, uint32_t n_frames,
     case Variant::FsrEasu: e = launch_fsr1(L, 0, easu_sharpness(), rcas_sharpness()); break;
     case Variant::FsrRcas: e = launch_fsr1(L, 1, easu_sharpness(), rcas_sharpness()); break;
     case Variant::Fsr1Fused: e = launch_fsr1(L, 2, easu_sharpness(), rcas_sharpness()); break;
+    case Variant::LanczosR32RegWin:
+        e = launch_lanczos_r32(L, dt_, lanczos_exact_, rows_per_wave_);
+        if (e == hipSuccess) e = launch_lanczos_general(L, dt_, lanczos_exact_, 12); // border columns
+        break;
     case Variant::LanczosXsRegWin:
         e = launch_lanczos_xs(L, dt_, lanczos_exact_, xs_factor_, rows_per_wave_);
         if (e == hipSuccess) e = launch_lanczos_xs_edges(L, dt_, lanczos_exact_, xs_factor_); // border columns

@@ -1,0 +1,307 @@
+// nus_k_lanczos_r32.hip -- separable resize (Lanczos-3, Catmull-Rom, Triangle) at the factor 3/2 on both axes
+// (720p -> 1080p, 1440p -> 4K, 1080p -> 1620p): the register-window design of nus_k_lanczos_x2.hip /
+// nus_k_lanczos_xs.hip with three output rows per PAIR of input rows and three horizontal phases per pair of
+// input columns.  image-0.24.9 imageops::resize as called at Nu_scale/src/upscale/common.rs:243-251 (vertical
+// pass into f32, then horizontal pass).
+//
+// At 3/2 the output o = 3 g + p (phase p = 0, 1, 2) belongs to the input pair g = (2g, 2g+1): its centre lies at
+// 2g - 1/6, 2g + 1/2, 2g + 7/6 and its taps inside the 6-slot frame that starts at input index 2g - 3 + p
+// (host-checked for every output, border windows included: slots outside the image carry weight 0).  Vertically
+// a wave therefore walks the input rows in pairs: phase 0 reads the window rows r-3 .. r+2, the window moves one
+// row, phase 1 reads r-2 .. r+3, it moves again, phase 2 reads r-1 .. r+4 -- which is also the window of the
+// next pair's phase 0.  Horizontally a lane's 4 columns (two pairs) give 6 outputs whose frames start 0, 1, 2, 2,
+// 3, 4 columns into the 10 columns it holds after the lane exchange (its own 4 plus 3 from each neighbour).
+// The weights of a phase move with the binade of the sample coordinate ((o + 0.5) * fl(2/3) is rounded in f32), so
+// every lane / row pair takes the weight set of its class (nus_tables.hpp: lanczos_r32_weight_classes).
+// The 12 left-most and right-most output columns (border-renormalised weights) are left to k_lanczos_general.
+#ifndef NUS_STORE_AUX
+#define NUS_STORE_AUX 0
+#endif
+#include "nus_device.hpp"
+
+namespace nus {
+
+namespace {
+
+struct LanczosR32Args {
+    const uint8_t *in;
+    uint8_t *out;
+    const float *wy6;               // [oh][6] vertical weights in the phase frame of each output row
+    const uint32_t *cls_x, *cls_y;  // weight class of every input column pair / row pair
+    const float *wcls_x, *wcls_y;   // [class][3][6]
+    uint32_t sel;                   // input channel order
+    uint32_t iw, ih;
+    uint32_t nstrips, nrowblocks, th; // th: input rows per wave, even
+    size_t in_frame_bytes, out_frame_bytes;
+};
+
+__device__ __forceinline__ float r32_lane_up(float v) // value of lane-1
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138 /*wave_shr:1*/, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float r32_lane_down(float v) // value of lane+1
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x130 /*wave_shl:1*/, 0xF, 0xF, true));
+}
+
+__device__ __forceinline__ void r32_cvt_row(const uint4 raw, float (&dst)[16])
+{
+    const uint32_t px[4] = {raw.x, raw.y, raw.z, raw.w};
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) dst[m * 4 + c] = ch_f32(px[m], c);
+}
+
+// 1 when every pixel of this input row held by the wave is opaque (cf. row_is_opaque in nus_k_lanczos_x2.hip)
+__device__ __forceinline__ uint32_t r32_row_is_opaque(const uint4 px)
+{
+    const bool lane_opaque = (px.x & px.y & px.z & px.w) >= 0xFF000000u;
+    return __builtin_amdgcn_ballot_w64(!lane_opaque) == 0ull ? 1u : 0u;
+}
+
+// Vertical pass of one output row: 6 taps from the window rows 0 .. 5.  W: VGPR weights (interior rows)
+// or a scalar pointer into the table (rows whose window is cut by the top / bottom border).
+template <bool EXACT, typename W>
+__device__ __forceinline__ void r32_vpass(const float (&win)[6][16], const W &w, float (&V)[16], bool skip_alpha)
+{
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        if ((k & 3) == 3 && skip_alpha) continue; // wave-uniform; V[alpha] is then not read
+        float acc = win[0][k] * w[0]; // == fma(.., 0) and a VOP2 instruction
+#pragma unroll
+        for (int j = 1; j < 6; ++j) acc = mac<EXACT>(acc, win[j][k], w[j]);
+        V[k] = acc;
+    }
+}
+
+// Where a wave's output row goes: as in the x2 / xs kernels the row is turned round in LDS -- every lane writes the 24
+// bytes (6 pixels) it computed at 24 * lane, then reads 16 B at 1024 q + 16 * lane for store q -- so that a store
+// instruction writes contiguous bytes (tools/probe_rw_mix.hip).  The wave's span is 64 x 24 = 1536 B: one full store
+// and one of 32 lanes.
+struct R32Store {
+    uint2 *stage;    // this wave's 1.5 KiB of LDS
+    uint32_t off[2]; // byte offset of this lane's 16 B inside an output row, per store; 2^31 = dropped by the range check
+    int lane;
+};
+
+// Horizontal pass of one output row: the lane's 6 output pixels (2 input pairs x 3 phases), convert + pack, stores.
+// Output 3 m + p (pair m of the lane, phase p) reads the columns e[2 m + p] .. e[2 m + p + 5] (e[3] is the lane's own
+// first column).
+template <bool EXACT>
+__device__ __forceinline__ void r32_hpass_store(const float (&V)[16], const float (&W)[3][6], __amdgpu_buffer_rsrc_t rs,
+                                                const R32Store &st, uint32_t row_off, bool skip_alpha)
+{
+    // skip_alpha (FMA mode, wave-uniform): the six tap rows are opaque in this wave, so alpha is the constant
+    // 255 (see row_is_opaque in nus_k_lanczos_x2.hip); v_cvt_pk_u8_f32 only ever replaces bytes 0..2 then
+    uint32_t o[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) o[i] = skip_alpha ? 0xFF000000u : 0u;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        if (c == 3 && skip_alpha) continue;
+        float e[10]; // vertical sums of input columns c0-3 .. c0+6 for this channel
+        e[0] = r32_lane_up(V[1 * 4 + c]);
+        e[1] = r32_lane_up(V[2 * 4 + c]);
+        e[2] = r32_lane_up(V[3 * 4 + c]);
+        e[3] = V[0 * 4 + c];
+        e[4] = V[1 * 4 + c];
+        e[5] = V[2 * 4 + c];
+        e[6] = V[3 * 4 + c];
+        e[7] = r32_lane_down(V[0 * 4 + c]);
+        e[8] = r32_lane_down(V[1 * 4 + c]);
+        e[9] = r32_lane_down(V[2 * 4 + c]);
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+                float a = e[2 * m + p] * W[p][0];
+#pragma unroll
+                for (int j = 1; j < 6; ++j) a = mac<EXACT>(a, e[2 * m + p + j], W[p][j]);
+                o[3 * m + p] = pack_u8<EXACT>(a, c, o[3 * m + p]);
+            }
+        }
+    }
+    // range-checked buffer stores: pieces that must not be written sit beyond num_records (see the x2 kernel)
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+    for (int q = 0; q < 3; ++q) st.stage[3 * st.lane + q] = make_uint2(o[2 * q], o[2 * q + 1]);
+    __builtin_amdgcn_wave_barrier(); // compiler only: same wave, LDS instructions execute in order
+    const uint4 *stage4 = reinterpret_cast<const uint4 *>(st.stage);
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int i = 64 * q + st.lane;
+        const uint4 t = stage4[i < 96 ? i : 95]; // (lanes 32 .. 63 of the second store hold nothing: dropped by their offset)
+        const u32x4 v = {t.x, t.y, t.z, t.w};
+        __builtin_amdgcn_raw_buffer_store_b128(v, rs, row_off + st.off[q], 0, NUS_STORE_AUX);
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+
+// One input row pair (r, r+1), r even -> output rows 3 r / 2 .. 3 r / 2 + 2.  At entry window row j holds input row
+// r-3+j and raw0 / raw1 hold rows r+3 / r+4; the window is shifted, not rotated (one copy of the step's code).
+template <bool EXACT>
+__device__ __forceinline__ void r32_step(float (&win)[6][16], uint4 &raw0, uint4 &raw1, int r, int cl, const R32Store &st,
+                                         const LanczosR32Args &A, const float (&W)[3][6], float (&Wv)[3][6], uint32_t &row_cls,
+                                         const uint8_t *src, __amdgpu_buffer_rsrc_t rs, uint32_t &opaque)
+{
+    typedef const __attribute__((address_space(4))) float *cfloat_p;
+    {
+        // vertical weights of this row pair's class: VGPR copies, reloaded when the class changes (a few times per frame)
+        const uint32_t cy = __builtin_amdgcn_readfirstlane(A.cls_y[r >> 1]);
+        if (cy != row_cls) { // wave-uniform
+            row_cls = cy;
+            cfloat_p wt = (cfloat_p)(uintptr_t)(A.wcls_y + (size_t)cy * 18);
+#pragma unroll
+            for (int p = 0; p < 3; ++p)
+#pragma unroll
+                for (int j = 0; j < 6; ++j) {
+                    Wv[p][j] = wt[p * 6 + j];
+                    asm volatile("" : "+v"(Wv[p][j]));
+                }
+        }
+    }
+    const uint32_t row_bytes = A.iw * 6; // one output row: 1.5 iw pixels
+    const uint32_t oy0 = 3u * (uint32_t)(r >> 1);
+    const bool interior = r >= 4 && r + 6 <= (int)A.ih; // wave-uniform: rows r-3 .. r+4 exist and the pair is not a border pair
+    float V[16];
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+        const bool skip_alpha = !EXACT && (opaque & 0x3Fu) == 0x3Fu; // bit j: window row 5-j is opaque
+        if (interior) {
+            r32_vpass<EXACT>(win, Wv[p], V, skip_alpha);
+        } else {
+            cfloat_p wt = (cfloat_p)(uintptr_t)(A.wy6 + (size_t)__builtin_amdgcn_readfirstlane(oy0 + (uint32_t)p) * 6);
+            r32_vpass<EXACT>(win, wt, V, skip_alpha);
+        }
+        r32_hpass_store<EXACT>(V, W, rs, st, (oy0 + (uint32_t)p) * row_bytes, skip_alpha);
+        if (p < 2) {
+            // the oldest row out, row r+3+p in; then request row r+5+p
+#pragma unroll
+            for (int j = 0; j < 5; ++j)
+#pragma unroll
+                for (int k = 0; k < 16; ++k) win[j][k] = win[j + 1][k];
+            uint4 &raw = p == 0 ? raw0 : raw1;
+            {
+                const uint4 px = swz4(raw, A.sel);
+                if (!EXACT) opaque = (opaque << 1) | r32_row_is_opaque(px);
+                r32_cvt_row(px, win[5]);
+            }
+            int rn = r + 5 + p;
+            rn = rn < (int)A.ih - 1 ? rn : (int)A.ih - 1;
+            raw = *reinterpret_cast<const uint4 *>(src + ((size_t)rn * A.iw + cl) * 4);
+        }
+    }
+}
+
+// One wave loads a strip of 256 input columns (4 per lane; lanes 2 .. 61 produce the strip's 240 input = 360 output
+// columns -- a 48-byte pair of lanes is three 16-byte store pieces, so the stored range starts and ends on an even lane --,
+// lanes 1 and 62 are their halo) and walks `th` input rows with a 6-row f32 window.
+constexpr int kR32StripCols = 240;
+
+template <bool EXACT>
+__global__ __launch_bounds__(256) void k_lanczos3_r32(const LanczosR32Args A)
+{
+    const int lane = threadIdx.x & (kWave - 1);
+    // each XCD gets a contiguous run of (frame, row block, strips), as in the x2 kernel
+    const uint32_t vid = xcd_contiguous_id(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
+    const uint32_t frame = vid / gridDim.x;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane((vid % gridDim.x) * 4 + (threadIdx.x >> 6));
+    if (wave >= A.nstrips * A.nrowblocks) return;
+    const uint32_t strip = wave % A.nstrips;
+    const uint32_t rb = wave / A.nstrips;
+    const int c = (int)(strip * kR32StripCols) - 8 + lane * 4; // first input column of this lane
+    int cl = c < 0 ? 0 : c;
+    cl = cl > (int)A.iw - 4 ? (int)A.iw - 4 : cl;
+    const uint8_t *src = A.in + (size_t)frame * A.in_frame_bytes;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+        A.out + (size_t)frame * A.out_frame_bytes, 0, (uint32_t)A.out_frame_bytes, 0x00020000);
+    // lane L computes the 6 output pixels of input columns c .. c+3; they are stored unless it is a halo lane or its
+    // columns are among the 8 first / last of the image (the 12 edge output columns per side: k_lanczos_general)
+    auto computes_stored_pixels = [&](int L) {
+        const int cc = (int)(strip * kR32StripCols) - 8 + L * 4;
+        return L >= 2 && L < 2 + kR32StripCols / 4 && cc >= 8 && cc + 12 <= (int)A.iw;
+    };
+    __shared__ uint2 lds_stage[4][64 * 3];
+    R32Store st;
+    st.stage = lds_stage[__builtin_amdgcn_readfirstlane(threadIdx.x >> 6)];
+    st.lane = lane;
+    {
+        // the wave's span starts at lane 0's pixels: byte 6 (c of lane 0) of an output row; a 16-byte piece at byte b of the
+        // span holds pixels of lanes b / 24 and (b + 15) / 24, which are both stored or both not (even-lane boundaries)
+        const int span0 = ((int)(strip * kR32StripCols) - 8) * 6;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int b = 1024 * q + 16 * lane;
+            const bool ok = b + 16 <= 64 * 24 && computes_stored_pixels(b / 24) && computes_stored_pixels((b + 15) / 24);
+            st.off[q] = ok ? (uint32_t)(span0 + b) : 0x80000000u;
+        }
+    }
+    const int r0 = (int)(rb * A.th); // even
+    const int r_end = (r0 + (int)A.th) < (int)A.ih ? (r0 + (int)A.th) : (int)A.ih;
+    const int rmax = (int)A.ih - 1;
+    auto load_row = [&](int rr) {
+        rr = rr < 0 ? 0 : (rr > rmax ? rmax : rr);
+        return *reinterpret_cast<const uint4 *>(src + ((size_t)rr * A.iw + cl) * 4);
+    };
+
+    float W[3][6], Wv[3][6];
+    uint32_t row_cls = 0xffffffffu;
+    {
+        // the lane's two column pairs share a class (host-checked); lanes that do not store take class 0
+        const uint32_t cx = c >= 8 && c + 12 <= (int)A.iw ? A.cls_x[c >> 1] : 0u;
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                W[p][j] = A.wcls_x[(size_t)cx * 18 + p * 6 + j];
+                asm volatile("" : "+v"(W[p][j])); // VGPR copy: scalar operands halve the VALU issue rate
+                Wv[p][j] = 0.0f;
+            }
+    }
+    float win[6][16];
+    uint32_t opaque = 0;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        const uint4 px = swz4(load_row(r0 - 3 + j), A.sel);
+        if (!EXACT) opaque = (opaque << 1) | r32_row_is_opaque(px);
+        r32_cvt_row(px, win[j]);
+    }
+    uint4 raw0 = load_row(r0 + 3), raw1 = load_row(r0 + 4);
+    for (int r = r0; r < r_end; r += 2) r32_step<EXACT>(win, raw0, raw1, r, cl, st, A, W, Wv, row_cls, src, rs, opaque);
+}
+
+} // namespace
+
+hipError_t launch_lanczos_r32(const UpscaleLaunch &L, const DeviceTables &T, bool exact, uint32_t rows_per_wave)
+{
+    if (2 * (uint64_t)L.ow != 3 * (uint64_t)L.iw || 2 * (uint64_t)L.oh != 3 * (uint64_t)L.ih || (L.iw % 4) != 0 || (L.ih % 2) != 0 ||
+        T.lz_xs_cls_x == nullptr)
+        return hipErrorInvalidValue;
+    LanczosR32Args A;
+    A.wy6 = T.lz_wy6;
+    A.cls_x = T.lz_xs_cls_x;
+    A.cls_y = T.lz_xs_cls_y;
+    A.wcls_x = T.lz_xs_wcls_x;
+    A.wcls_y = T.lz_xs_wcls_y;
+    A.sel = L.in_sel;
+    A.iw = L.iw;
+    A.ih = L.ih;
+    A.nstrips = cdiv(L.iw, kR32StripCols);
+    A.th = rows_per_wave ? (rows_per_wave + 1) & ~1u : 24;
+    A.nrowblocks = cdiv(L.ih, A.th);
+    A.in_frame_bytes = (size_t)L.iw * L.ih * 4;
+    A.out_frame_bytes = (size_t)L.ow * L.oh * 4;
+    const uint32_t nwaves = A.nstrips * A.nrowblocks;
+    return for_frame_chunks(L, [&](const uint8_t *in, uint8_t *out, uint32_t n) {
+        A.in = in;
+        A.out = out;
+        const dim3 block(256), grid(cdiv(nwaves, 4), n);
+        if (exact)
+            hipLaunchKernelGGL(k_lanczos3_r32<true>, grid, block, 0, L.stream, A);
+        else
+            hipLaunchKernelGGL(k_lanczos3_r32<false>, grid, block, 0, L.stream, A);
+    });
+}
+
+} // namespace nus

@@ -78,6 +78,7 @@ enum class Variant : int {
     ResizeDown,       // down-scaling: input rows streamed once into the vertical sums of the 7 output rows in flight
     LanczosX2RegWin,  // exact x2, register sliding window + wave shifts
     LanczosXsRegWin,  // exact x3 / x4, same design with S output rows per input row
+    LanczosR32RegWin, // exact x3/2, same design: three output rows per pair of input rows
     FsrEasu,          // FSR1-style EASU alone (any scale)
     FsrRcas,          // FSR1-style RCAS alone (same size in and out)
     Fsr1Fused,        // EASU tile (+1 px halo) in LDS, RCAS out of it
@@ -118,6 +119,9 @@ hipError_t launch_lanczos_x2_edges(const UpscaleLaunch &L, const DeviceTables &T
 hipError_t launch_lanczos_xs(const UpscaleLaunch &L, const DeviceTables &T, bool exact, uint32_t factor,
                              uint32_t rows_per_wave);
 hipError_t launch_lanczos_xs_edges(const UpscaleLaunch &L, const DeviceTables &T, bool exact, uint32_t factor);
+// exact x3/2 (2 ow == 3 iw, 2 oh == 3 ih, iw % 8 == 0, ih even): main kernel only, the first / last 12 output columns are
+// NOT written; follow it with launch_lanczos_general(L, T, exact, 12).
+hipError_t launch_lanczos_r32(const UpscaleLaunch &L, const DeviceTables &T, bool exact, uint32_t rows_per_wave);
 // FSR1-style passes (fsr.rs:24-260).  mode 0: EASU, 1: RCAS (iw == ow, ih == oh), 2: EASU then RCAS fused.
 hipError_t launch_fsr1(const UpscaleLaunch &L, int mode, float easu_sharpness, float rcas_sharpness);
 

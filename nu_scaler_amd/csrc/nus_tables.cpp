@@ -213,6 +213,50 @@ bool lanczos_xs_weight_classes(const AxisTables &t, uint32_t S, const std::vecto
     return !classes.empty();
 }
 
+bool lanczos_r32_phase_frame(const AxisTables &t, std::vector<float> &w6)
+{
+    if ((t.in_n & 1) != 0 || 2 * (uint64_t)t.out_n != 3 * (uint64_t)t.in_n || t.lz_max_taps < 0) return false;
+    w6.assign((size_t)t.out_n * 6, 0.0f);
+    for (uint32_t o = 0; o < t.out_n; ++o) {
+        const int32_t base = 2 * (int32_t)(o / 3) - 3 + (int32_t)(o % 3);
+        const float *ws = t.lz_w.data() + (size_t)o * kResizeMaxTaps;
+        for (uint32_t i = 0; i < t.lz_ntaps[o]; ++i) {
+            const int32_t j = t.lz_left[o] + (int32_t)i - base;
+            if (j < 0 || j >= 6) {
+                if (ws[i] != 0.0f) return false;
+                continue;
+            }
+            w6[(size_t)o * 6 + j] = ws[i];
+        }
+    }
+    return true;
+}
+
+bool lanczos_r32_weight_classes(const AxisTables &t, const std::vector<float> &w6, bool lanes, std::vector<uint32_t> &cls,
+                                std::vector<float> &classes)
+{
+    if (t.in_n < 16 || (lanes && (t.in_n % 4) != 0)) return false;
+    const uint32_t pairs = t.in_n / 2;
+    const size_t frame = 3 * 6;
+    cls.assign(pairs, 0);
+    classes.clear();
+    for (uint32_t g = 2; g + 2 < pairs; ++g) {
+        const float *w = w6.data() + (size_t)g * frame; // outputs 3 g .. 3 g + 2
+        uint32_t c = 0;
+        const uint32_t n = (uint32_t)(classes.size() / frame);
+        for (; c < n; ++c)
+            if (std::memcmp(classes.data() + (size_t)c * frame, w, frame * sizeof(float)) == 0) break;
+        if (c == n) {
+            if (n == kXsMaxClasses) return false;
+            classes.insert(classes.end(), w, w + frame);
+        }
+        cls[g] = c;
+    }
+    for (uint32_t g = 2; lanes && g + 4 <= pairs; g += 2) // a lane's columns 2g .. 2g+3 share a class
+        if (cls[g] != cls[g + 1]) return false;
+    return !classes.empty();
+}
+
 namespace {
 
 const uint32_t kMagic = 0x4C53554Eu; // "NUSL"

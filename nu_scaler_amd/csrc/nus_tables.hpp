@@ -70,6 +70,15 @@ constexpr uint32_t kXsMaxClasses = 16;
 bool lanczos_xs_weight_classes(const AxisTables &t, uint32_t S, const std::vector<float> &w6, bool lanes,
                                std::vector<uint32_t> &cls, std::vector<float> &classes);
 
+// Factor 3/2 (2 out_n == 3 in_n, in_n even): output o = 3 g + p belongs to the input pair g = (2g, 2g+1) and its taps
+// lie in the 6-slot frame that starts at 2 g - 3 + p (the output centres sit at 2g - 1/6, 2g + 1/2, 2g + 7/6).
+bool lanczos_r32_phase_frame(const AxisTables &t, std::vector<float> &w6);
+// Weight classes as lanczos_xs_weight_classes, per input PAIR: cls[g], classes[c][p][j] (3 phases).  `lanes`: the two
+// pairs of an aligned group of 4 input indices (one lane's columns) must share a class.  Pairs 0, 1 and the last two
+// (frames cut by the border) are class 0 and not compared.
+bool lanczos_r32_weight_classes(const AxisTables &t, const std::vector<float> &w6, bool lanes, std::vector<uint32_t> &cls,
+                                std::vector<float> &classes);
+
 // Down-scaling stream tables for k_resize_down (7 accumulator slots, slot of output y = y % 7).
 // rows: (in_n + extra) x 8 words -- per input row the f32 weight it carries in each slot (0 where the row is
 // outside the window of the output that owns the slot), then one completion word: 0xFFFFFFFF, or (slot << 28 | y)

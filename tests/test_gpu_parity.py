@@ -131,9 +131,10 @@ def test_bicubic_and_triangle_resize(nsc, oracle_mod, alg, filt, dims):
     want = oracle_mod.resize(img, ow, oh, filt)
     out, u = _up(nsc, alg, img, ow, oh)
     x2 = (ow, oh) == (2 * w, 2 * h) and w % 4 == 0 and w >= 16 and h >= 16
+    r32 = (2 * ow, 2 * oh) == (3 * w, 3 * h) and w % 8 == 0 and h % 2 == 0 and w >= 32 and h >= 16
     upscale_by4 = ow % 4 == 0 and ow >= w and oh >= h
-    assert u.kernel_variant == ("lanczos3_x2_regwin" if x2 else ("resize_regwin_lds" if upscale_by4 else
-                                                                 ("resize_down_stream" if oh < h else "resize_rows_lds")))
+    assert u.kernel_variant == ("lanczos3_x2_regwin" if x2 else "lanczos3_r32_regwin" if r32 else
+                                ("resize_regwin_lds" if upscale_by4 else ("resize_down_stream" if oh < h else "resize_rows_lds")))
     assert _maxdiff(out, want) <= 1
     out_e, _ = _up(nsc, alg, img, ow, oh, lanczos_mode="exact")
     assert np.array_equal(out_e, want)
@@ -700,7 +701,8 @@ def test_resize_register_window_variant(nsc, oracle_mod, alg, filt, dims):
     (w, h), (ow, oh) = dims
     img = oracle_mod.gen_noise(w, h, 91)
     want = oracle_mod.resize(img, ow, oh, filt)
-    gen = {"force_general": 1} if (ow, oh) == (3 * w, 3 * h) else {}  # exact x3 has its own kernel: ask for this one
+    # exact x3 and x3/2 have their own kernels: ask for this one
+    gen = {"force_general": 1} if (ow, oh) == (3 * w, 3 * h) or (2 * ow, 2 * oh) == (3 * w, 3 * h) else {}
     got_e, u = _up(nsc, alg, img, ow, oh, lanczos_mode="exact", options=dict(gen))
     assert u.kernel_variant == "resize_regwin_lds"
     assert np.array_equal(got_e, want)
@@ -742,6 +744,75 @@ def test_resize_integer_factor_register_window(nsc, oracle_mod, alg, filt, facto
     ub.initialize(w, h, ow, oh)
     got_b = np.frombuffer(ub.upscale(_bgra(img).tobytes()), np.uint8).reshape(oh, ow, 4)
     assert np.array_equal(got_b, want)
+
+
+@pytest.mark.parametrize("alg,filt", [("lanczos3", 0), ("bicubic", 1), ("triangle", 2)])
+@pytest.mark.parametrize("size", [(64, 36), (32, 16), (256, 34), (248, 40), (496, 18), (480, 270), (1000, 50), (744, 22)])
+def test_resize_factor_three_halves_register_window(nsc, oracle_mod, alg, filt, size):
+    """x3/2 (720p -> 1080p, 1440p -> 4K): the register-window design with three output rows per pair of input rows and
+    three horizontal phases per pair of columns; weights per class of the input pair (they move with the binade of the
+    sample coordinate).  EXACT mode: 0 differences; FMA mode: the bits of the general kernel (same order of operations)."""
+    w, h = size
+    ow, oh = 3 * w // 2, 3 * h // 2
+    img = oracle_mod.gen_noise(w, h, 95)
+    want = oracle_mod.resize(img, ow, oh, filt)
+    got_e, u = _up(nsc, alg, img, ow, oh, lanczos_mode="exact")
+    assert u.kernel_variant == "lanczos3_r32_regwin"
+    assert np.array_equal(got_e, want)
+    got_f, uf = _up(nsc, alg, img, ow, oh)
+    assert uf.kernel_variant == "lanczos3_r32_regwin"
+    # FMA mode packs with round-to-nearest-even; Triangle's weights put many sums on exact .5 ties (see the x3 / x4 test)
+    assert _maxdiff(got_f, want) <= 1 and (got_f != want).mean() < (5e-2 if alg == "triangle" else 1e-3)
+    ref_f, ug = _up(nsc, alg, img, ow, oh, options={"force_general": 1})
+    assert ug.kernel_variant in ("resize_regwin_lds", "resize_rows_lds") and np.array_equal(got_f, ref_f)
+    for th in (2, 6, 24, 37):
+        out_t, _ = _up(nsc, alg, img, ow, oh, lanczos_mode="exact", options={"rows_per_wave": th})
+        assert np.array_equal(out_t, want), th
+    # opaque frames (the 3-channel path) and BGRA input
+    opq = img.copy()
+    opq[..., 3] = 255
+    got_o, _ = _up(nsc, alg, opq, ow, oh)
+    ref_o, _ = _up(nsc, alg, opq, ow, oh, options={"force_general": 1})
+    assert np.array_equal(got_o, ref_o) and (got_o[..., 3] == 255).all()
+    ub = nsc.PyWgpuUpscaler("quality", alg, lanczos_mode="exact")
+    ub.set_input_format("bgra")
+    ub.initialize(w, h, ow, oh)
+    got_b = np.frombuffer(ub.upscale(_bgra(img).tobytes()), np.uint8).reshape(oh, ow, 4)
+    assert np.array_equal(got_b, want)
+
+
+def test_1440p_to_4k_takes_the_three_halves_kernel(nsc, oracle_mod):
+    """2560x1440 -> 3840x2160 at full size, both modes against the oracle, and a device batch."""
+    import torch
+
+    w, h, ow, oh = 2560, 1440, 3840, 2160
+    img = oracle_mod.gen_noise(w, h, 79)
+    want = oracle_mod.lanczos3(img, ow, oh, threads=0)
+    got_f, uf = _up(nsc, "lanczos3", img, ow, oh)
+    assert uf.kernel_variant == "lanczos3_r32_regwin"
+    d = np.abs(got_f.astype(np.int16) - want.astype(np.int16))
+    assert d.max() <= 1 and (d > 0).mean() < 1e-3
+    got_e, ue = _up(nsc, "lanczos3", img, ow, oh, lanczos_mode="exact")
+    assert ue.kernel_variant == "lanczos3_r32_regwin" and np.array_equal(got_e, want)
+    n = 3
+    frames_np = np.stack([oracle_mod.gen_gradient(w, h, k) for k in range(n)])
+    frames = torch.from_numpy(frames_np).to("cuda:0")
+    out = torch.zeros((n, oh, ow, 4), dtype=torch.uint8, device="cuda:0")
+    uf.upscale_device(frames.data_ptr(), out.data_ptr(), n, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    ug = nsc.PyWgpuUpscaler("quality", "lanczos3")
+    ug.set_option("force_general", 1)
+    ug.initialize(w, h, ow, oh)
+    assert ug.kernel_variant == "resize_regwin_lds"
+    for k in range(n):
+        got_k = out[k].cpu().numpy()
+        wk = oracle_mod.lanczos3(frames_np[k], ow, oh, threads=0).astype(np.int16)
+        dk = np.abs(got_k.astype(np.int16) - wk)
+        # the smooth gradient puts many sums of the FMA mode within a rounding of a .5 tie: more 1-LSB differences than on noise,
+        # the same ones as the general kernel's (same order of operations)
+        assert dk.max() <= 1 and (dk > 0).mean() < 1e-2, k
+        ref_k = np.frombuffer(ug.upscale(frames_np[k].tobytes()), np.uint8).reshape(oh, ow, 4)
+        assert np.array_equal(got_k, ref_k), k
 
 
 def test_720p_to_4k_x3_takes_the_fixed_weight_kernel(nsc, oracle_mod):
@@ -840,7 +911,7 @@ def test_resize_window_opaque_rows(nsc, oracle_mod, alg, dims):
     v = base.copy(); v[..., 3] = 255; v[h // 3, w // 2, 3] = 254; v[0, 0, 3] = 0; v[h - 1, w - 1, 3] = 9; variants["pixels"] = v
     for name, img in variants.items():
         got, u = _up(nsc, alg, img, ow, oh)
-        assert u.kernel_variant in ("resize_regwin_lds", "lanczos3_xs_regwin")
+        assert u.kernel_variant in ("resize_regwin_lds", "lanczos3_xs_regwin", "lanczos3_r32_regwin")
         ref, ur = _up(nsc, alg, img, ow, oh, options={"force_general": 1, "force_rows": 1})
         assert ur.kernel_variant == "resize_rows_lds"
         assert np.array_equal(got, ref), name
