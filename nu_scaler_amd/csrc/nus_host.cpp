@@ -381,6 +381,11 @@ int HipUpscaler::upload_tables()
                 }
         }
         if (variant_ == Variant::LanczosR32RegWin) {
+            for (uint32_t q = 0; q < 12; ++q)
+                for (int j = 0; j < 6; ++j) {
+                    dt_.lz_wxs_left[q][j] = wx6_[(size_t)q * 6 + j];
+                    dt_.lz_wxs_right[q][j] = wx6_[((size_t)ow_ - 12 + q) * 6 + j];
+                }
             UP(wy6_, lz_wy6);
             UP(xs_cls_x_, lz_xs_cls_x);
             UP(xs_cls_y_, lz_xs_cls_y);
@@ -486,10 +491,17 @@ int HipUpscaler::enqueue(const uint8_t *d_in, uint8_t *d_out, uint32_t n_frames,
     case Variant::FsrEasu: e = launch_fsr1(L, 0, easu_sharpness(), rcas_sharpness()); break;
     case Variant::FsrRcas: e = launch_fsr1(L, 1, easu_sharpness(), rcas_sharpness()); break;
     case Variant::Fsr1Fused: e = launch_fsr1(L, 2, easu_sharpness(), rcas_sharpness()); break;
-    case Variant::LanczosR32RegWin:
-        e = launch_lanczos_r32(L, dt_, lanczos_exact_, rows_per_wave_);
-        if (e == hipSuccess) e = launch_lanczos_general(L, dt_, lanczos_exact_, 12); // border columns
+    case Variant::LanczosR32RegWin: {
+        uint32_t th = rows_per_wave_;
+        if (th == 0) { // as at x2: enough waves to fill the chip a few times over, tall enough to amortise the 7 halo rows
+            const uint64_t rows_total = (uint64_t)ih_ * ((iw_ + 239) / 240) * n_frames;
+            const uint64_t t = rows_total / 8192;
+            th = (uint32_t)(t < 12 ? 12 : (t > 120 ? 120 : t));
+        }
+        e = launch_lanczos_r32(L, dt_, lanczos_exact_, th);
+        if (e == hipSuccess) e = launch_lanczos_r32_edges(L, dt_, lanczos_exact_); // border columns
         break;
+    }
     case Variant::LanczosXsRegWin:
         e = launch_lanczos_xs(L, dt_, lanczos_exact_, xs_factor_, rows_per_wave_);
         if (e == hipSuccess) e = launch_lanczos_xs_edges(L, dt_, lanczos_exact_, xs_factor_); // border columns

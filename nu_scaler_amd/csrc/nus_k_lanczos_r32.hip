@@ -13,7 +13,7 @@
 // 3, 4 columns into the 10 columns it holds after the lane exchange (its own 4 plus 3 from each neighbour).
 // The weights of a phase move with the binade of the sample coordinate ((o + 0.5) * fl(2/3) is rounded in f32), so
 // every lane / row pair takes the weight set of its class (nus_tables.hpp: lanczos_r32_weight_classes).
-// The 12 left-most and right-most output columns (border-renormalised weights) are left to k_lanczos_general.
+// The 12 left-most and right-most output columns (border-renormalised weights) belong to k_lanczos3_r32_edges.
 #ifndef NUS_STORE_AUX
 #define NUS_STORE_AUX 0
 #endif
@@ -217,7 +217,7 @@ __global__ __launch_bounds__(256) void k_lanczos3_r32(const LanczosR32Args A)
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
         A.out + (size_t)frame * A.out_frame_bytes, 0, (uint32_t)A.out_frame_bytes, 0x00020000);
     // lane L computes the 6 output pixels of input columns c .. c+3; they are stored unless it is a halo lane or its
-    // columns are among the 8 first / last of the image (the 12 edge output columns per side: k_lanczos_general)
+    // columns are among the 8 first / last of the image (the 12 edge output columns per side: k_lanczos3_r32_edges)
     auto computes_stored_pixels = [&](int L) {
         const int cc = (int)(strip * kR32StripCols) - 8 + L * 4;
         return L >= 2 && L < 2 + kR32StripCols / 4 && cc >= 8 && cc + 12 <= (int)A.iw;
@@ -271,6 +271,105 @@ __global__ __launch_bounds__(256) void k_lanczos3_r32(const LanczosR32Args A)
     for (int r = r0; r < r_end; r += 2) r32_step<EXACT>(win, raw0, raw1, r, cl, st, A, W, Wv, row_cls, src, rs, opaque);
 }
 
+// The 12 left-most and right-most output columns (tap windows cut by the image border, weights renormalised).  As in
+// the x2 / xs edge kernels lanes map to input ROWS -- here to row pairs: each lane produces the 12 x 3 output pixels of
+// its pair from an 8-row x 12-column input patch, so the horizontal weights are wave-uniform (kernel arguments) and the
+// vertical ones per lane (the table holds the border rows' renormalised weights).  Same order of operations as the main
+// kernel and k_lanczos_general: vertical sums first, taps ascending.
+struct LanczosR32EdgeArgs {
+    const uint8_t *in;
+    uint8_t *out;
+    const float *wy6;
+    float wx[2][12][6]; // [side][output column of that side][frame slot], 0 outside the image
+    uint32_t sel;
+    uint32_t iw, ih;
+    size_t in_frame_bytes, out_frame_bytes;
+};
+
+__device__ __forceinline__ uint32_t r32_px_of(const uint4 (&row)[3], int col)
+{
+    const uint4 &v = row[col >> 2];
+    switch (col & 3) {
+    case 0: return v.x;
+    case 1: return v.y;
+    case 2: return v.z;
+    default: return v.w;
+    }
+}
+
+template <bool EXACT, int SIDE>
+__device__ __forceinline__ void r32_edge_rows(const LanczosR32EdgeArgs &A, const uint4 (&raw)[8][3], int r, uint32_t *dst_frame)
+{
+    const uint32_t ow = A.iw / 2 * 3;
+#pragma unroll
+    for (int p = 0; p < 3; ++p) { // rows r-3+p .. r+2+p of the patch
+        const uint32_t oy = 3u * (uint32_t)(r >> 1) + (uint32_t)p;
+        const float *wvp = A.wy6 + (size_t)oy * 6;
+        float wv[6];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) wv[j] = wvp[j];
+        float V[12][4];
+#pragma unroll
+        for (int col = 0; col < 12; ++col)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                float acc = ch_f32(r32_px_of(raw[p], col), c) * wv[0];
+#pragma unroll
+                for (int j = 1; j < 6; ++j) acc = mac<EXACT>(acc, ch_f32(r32_px_of(raw[p + j], col), c), wv[j]);
+                V[col][c] = acc;
+            }
+        uint32_t o[12];
+#pragma unroll
+        for (int q = 0; q < 12; ++q) {
+            // patch-local column of frame slot 0: left side 2 (q / 3) - 3 + q % 3; right side (the patch starts at iw - 12, its
+            // outputs at pair iw / 2 - 4): 1 + 2 (q / 3) + q % 3
+            const int l0 = SIDE == 0 ? 2 * (q / 3) - 3 + q % 3 : 1 + 2 * (q / 3) + q % 3;
+            uint32_t px = 0;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                float acc = 0.0f;
+#pragma unroll
+                for (int j = 0; j < 6; ++j) {
+                    int li = l0 + j;
+                    li = li < 0 ? 0 : (li > 11 ? 11 : li); // slots outside the image carry weight 0
+                    const float w = A.wx[SIDE][q][j];
+                    acc = j == 0 ? V[li][c] * w : mac<EXACT>(acc, V[li][c], w);
+                }
+                px = pack_u8<EXACT>(acc, c, px);
+            }
+            o[q] = px;
+        }
+        uint32_t *d4 = dst_frame + (size_t)oy * ow + (SIDE == 0 ? 0 : ow - 12);
+#pragma unroll
+        for (int q = 0; q < 3; ++q) *reinterpret_cast<uint4 *>(d4 + 4 * q) = make_uint4(o[4 * q], o[4 * q + 1], o[4 * q + 2], o[4 * q + 3]);
+    }
+}
+
+template <bool EXACT>
+__global__ __launch_bounds__(64) void k_lanczos3_r32_edges(const LanczosR32EdgeArgs A)
+{
+    const int r = 2 * (int)(blockIdx.x * kWave + threadIdx.x); // this lane's row pair
+    if (r >= (int)A.ih) return;
+    const int side = blockIdx.y; // 0: left, 1: right (wave-uniform)
+    const int col0 = side ? (int)A.iw - 12 : 0;
+    const int rmax = (int)A.ih - 1;
+    const uint8_t *src = A.in + (size_t)blockIdx.z * A.in_frame_bytes;
+    uint32_t *dst = reinterpret_cast<uint32_t *>(A.out + (size_t)blockIdx.z * A.out_frame_bytes);
+    uint4 raw[8][3];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        int rr = r - 3 + j;
+        rr = rr < 0 ? 0 : (rr > rmax ? rmax : rr);
+        const size_t off = ((size_t)rr * A.iw + col0) * 4;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) raw[j][k] = swz4(*reinterpret_cast<const uint4 *>(src + off + 16 * k), A.sel);
+    }
+    if (side == 0)
+        r32_edge_rows<EXACT, 0>(A, raw, r, dst);
+    else
+        r32_edge_rows<EXACT, 1>(A, raw, r, dst);
+}
+
 } // namespace
 
 hipError_t launch_lanczos_r32(const UpscaleLaunch &L, const DeviceTables &T, bool exact, uint32_t rows_per_wave)
@@ -301,6 +400,31 @@ hipError_t launch_lanczos_r32(const UpscaleLaunch &L, const DeviceTables &T, boo
             hipLaunchKernelGGL(k_lanczos3_r32<true>, grid, block, 0, L.stream, A);
         else
             hipLaunchKernelGGL(k_lanczos3_r32<false>, grid, block, 0, L.stream, A);
+    });
+}
+
+hipError_t launch_lanczos_r32_edges(const UpscaleLaunch &L, const DeviceTables &T, bool exact)
+{
+    LanczosR32EdgeArgs A;
+    A.wy6 = T.lz_wy6;
+    for (int q = 0; q < 12; ++q)
+        for (int j = 0; j < 6; ++j) {
+            A.wx[0][q][j] = T.lz_wxs_left[q][j];
+            A.wx[1][q][j] = T.lz_wxs_right[q][j];
+        }
+    A.sel = L.in_sel;
+    A.iw = L.iw;
+    A.ih = L.ih;
+    A.in_frame_bytes = (size_t)L.iw * L.ih * 4;
+    A.out_frame_bytes = (size_t)L.ow * L.oh * 4;
+    return for_frame_chunks(L, [&](const uint8_t *in, uint8_t *out, uint32_t n) {
+        A.in = in;
+        A.out = out;
+        const dim3 block(kWave), grid(cdiv(L.ih / 2, kWave), 2, n);
+        if (exact)
+            hipLaunchKernelGGL(k_lanczos3_r32_edges<true>, grid, block, 0, L.stream, A);
+        else
+            hipLaunchKernelGGL(k_lanczos3_r32_edges<false>, grid, block, 0, L.stream, A);
     });
 }
 

@@ -120,8 +120,9 @@ hipError_t launch_lanczos_xs(const UpscaleLaunch &L, const DeviceTables &T, bool
                              uint32_t rows_per_wave);
 hipError_t launch_lanczos_xs_edges(const UpscaleLaunch &L, const DeviceTables &T, bool exact, uint32_t factor);
 // exact x3/2 (2 ow == 3 iw, 2 oh == 3 ih, iw % 8 == 0, ih even): main kernel only, the first / last 12 output columns are
-// NOT written; follow it with launch_lanczos_general(L, T, exact, 12).
+// NOT written; follow it with launch_lanczos_r32_edges(L, T, exact).
 hipError_t launch_lanczos_r32(const UpscaleLaunch &L, const DeviceTables &T, bool exact, uint32_t rows_per_wave);
+hipError_t launch_lanczos_r32_edges(const UpscaleLaunch &L, const DeviceTables &T, bool exact);
 // FSR1-style passes (fsr.rs:24-260).  mode 0: EASU, 1: RCAS (iw == ow, ih == oh), 2: EASU then RCAS fused.
 hipError_t launch_fsr1(const UpscaleLaunch &L, int mode, float easu_sharpness, float rcas_sharpness);
 

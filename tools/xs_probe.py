@@ -1,5 +1,6 @@
 #!/usr/bin/env python
-"""Timing of the integer-factor kernel (dev tool): python tools/xs_probe.py [frames] [rows_per_wave ...]"""
+"""Timing of the fixed-factor kernels against rows per wave (dev tool): python tools/xs_probe.py [frames] [rows_per_wave ...]
+NUS_DIMS=iwxih:owxoh picks another size (default 960x540:3840x2160), NUS_PATTERN=gradient the opaque stream."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -8,8 +9,8 @@ from nu_scaler_amd import synthetic as syn
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 ths = [int(v) for v in sys.argv[2:]] or [0]
 dev = torch.device("cuda:0")
-iw, ih, ow, oh = 960, 540, 3840, 2160
-frames = syn.noise_stream_torch(n, iw, ih, dev)
+(iw, ih), (ow, oh) = [tuple(int(v) for v in part.split("x")) for part in os.environ.get("NUS_DIMS", "960x540:3840x2160").split(":")]
+frames = (syn.gradient_stream_torch if os.environ.get("NUS_PATTERN") == "gradient" else syn.noise_stream_torch)(n, iw, ih, dev)
 out = torch.empty((n, oh, ow, 4), dtype=torch.uint8, device=dev)
 s = torch.cuda.current_stream().cuda_stream
 for th in ths:
