@@ -254,6 +254,15 @@ void HipUpscaler::choose_resize_variant(bool x2)
         return;
     }
     xs_cls_x_.clear(), xs_cls_y_.clear(), xs_wcls_x_.clear(), xs_wcls_y_.clear();
+    // x4/3 (1080p -> 1440p): four output rows per group of three input rows (nus_k_lanczos_r43.hip); the ratio 3/4 is exact in
+    // f32, so the interior weights are uniform (one set per phase, the same numbers on both axes), as at x2 and x4
+    if (!force_general_ && 3 * (uint64_t)ow_ == 4 * (uint64_t)iw_ && 3 * (uint64_t)oh_ == 4 * (uint64_t)ih_ && (iw_ % 12) == 0 &&
+        (ih_ % 3) == 0 && iw_ >= 48 && ih_ >= 18 && addressable && lanczos_r43_phase_frame(tx_, wx6_) &&
+        lanczos_r43_phase_frame(ty_, wy6_) && lanczos_r43_interior_uniform(tx_, wx6_) && lanczos_r43_interior_uniform(ty_, wy6_) &&
+        memcmp(&wx6_[(size_t)8 * 6], &wy6_[(size_t)8 * 6], 24 * sizeof(float)) == 0) {
+        variant_ = Variant::LanczosR43RegWin;
+        return;
+    }
     if (force_per_pixel_) return;
     // vertical down-scaling: stream the input rows through 7 accumulator slots, if the windows allow it and a
     // 64-column output segment's footprint fits 5 columns per lane
@@ -380,6 +389,16 @@ int HipUpscaler::upload_tables()
                     dt_.lz_wxs_right[q][j] = wx6_[((size_t)ow_ - 4 * xs_factor_ + q) * 6 + j];
                 }
         }
+        if (variant_ == Variant::LanczosR43RegWin) {
+            for (uint32_t p = 0; p < 4; ++p)
+                for (int j = 0; j < 6; ++j) dt_.lz_wxs[p][j] = wx6_[((size_t)8 + p) * 6 + j];
+            for (uint32_t q = 0; q < 8; ++q)
+                for (int j = 0; j < 6; ++j) {
+                    dt_.lz_wxs_left[q][j] = wx6_[(size_t)q * 6 + j];
+                    dt_.lz_wxs_right[q][j] = wx6_[((size_t)ow_ - 8 + q) * 6 + j];
+                }
+            UP(wy6_, lz_wy6);
+        }
         if (variant_ == Variant::LanczosR32RegWin) {
             for (uint32_t q = 0; q < 12; ++q)
                 for (int j = 0; j < 6; ++j) {
@@ -491,6 +510,17 @@ int HipUpscaler::enqueue(const uint8_t *d_in, uint8_t *d_out, uint32_t n_frames,
     case Variant::FsrEasu: e = launch_fsr1(L, 0, easu_sharpness(), rcas_sharpness()); break;
     case Variant::FsrRcas: e = launch_fsr1(L, 1, easu_sharpness(), rcas_sharpness()); break;
     case Variant::Fsr1Fused: e = launch_fsr1(L, 2, easu_sharpness(), rcas_sharpness()); break;
+    case Variant::LanczosR43RegWin: {
+        uint32_t th = rows_per_wave_;
+        if (th == 0) {
+            const uint64_t rows_total = (uint64_t)ih_ * ((iw_ + 185) / 186) * n_frames;
+            const uint64_t t = rows_total / 8192;
+            th = (uint32_t)(t < 12 ? 12 : (t > 120 ? 120 : t));
+        }
+        e = launch_lanczos_r43(L, dt_, lanczos_exact_, th);
+        if (e == hipSuccess) e = launch_lanczos_r43_edges(L, dt_, lanczos_exact_); // border columns
+        break;
+    }
     case Variant::LanczosR32RegWin: {
         uint32_t th = rows_per_wave_;
         if (th == 0) { // as at x2: enough waves to fill the chip a few times over, tall enough to amortise the 7 halo rows

@@ -257,6 +257,7 @@ const char *variant_name(Variant v){
     case Variant::LanczosX2RegWin: return "lanczos3_x2_regwin";
     case Variant::LanczosXsRegWin: return "lanczos3_xs_regwin";
     case Variant::LanczosR32RegWin: return "lanczos3_r32_regwin";
+    case Variant::LanczosR43RegWin: return "lanczos3_r43_regwin";
     case Variant::FsrEasu: return "fsr1_easu_tile";
     case Variant::FsrRcas: return "fsr1_rcas_tile";
     case Variant::Fsr1Fused: return "fsr1_easu_rcas_fused_lds";

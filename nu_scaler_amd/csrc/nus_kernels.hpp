@@ -79,6 +79,7 @@ enum class Variant : int {
     LanczosX2RegWin,  // exact x2, register sliding window + wave shifts
     LanczosXsRegWin,  // exact x3 / x4, same design with S output rows per input row
     LanczosR32RegWin, // exact x3/2, same design: three output rows per pair of input rows
+    LanczosR43RegWin, // exact x4/3, same design: four output rows per group of three input rows
     FsrEasu,          // FSR1-style EASU alone (any scale)
     FsrRcas,          // FSR1-style RCAS alone (same size in and out)
     Fsr1Fused,        // EASU tile (+1 px halo) in LDS, RCAS out of it
@@ -123,6 +124,10 @@ hipError_t launch_lanczos_xs_edges(const UpscaleLaunch &L, const DeviceTables &T
 // NOT written; follow it with launch_lanczos_r32_edges(L, T, exact).
 hipError_t launch_lanczos_r32(const UpscaleLaunch &L, const DeviceTables &T, bool exact, uint32_t rows_per_wave);
 hipError_t launch_lanczos_r32_edges(const UpscaleLaunch &L, const DeviceTables &T, bool exact);
+// exact x4/3 (3 ow == 4 iw, 3 oh == 4 ih, iw % 12 == 0): main kernel only, the first / last 8 output columns are NOT written;
+// follow it with launch_lanczos_r43_edges(L, T, exact).
+hipError_t launch_lanczos_r43(const UpscaleLaunch &L, const DeviceTables &T, bool exact, uint32_t rows_per_wave);
+hipError_t launch_lanczos_r43_edges(const UpscaleLaunch &L, const DeviceTables &T, bool exact);
 // FSR1-style passes (fsr.rs:24-260).  mode 0: EASU, 1: RCAS (iw == ow, ih == oh), 2: EASU then RCAS fused.
 hipError_t launch_fsr1(const UpscaleLaunch &L, int mode, float easu_sharpness, float rcas_sharpness);
 

@@ -232,6 +232,35 @@ bool lanczos_r32_phase_frame(const AxisTables &t, std::vector<float> &w6)
     return true;
 }
 
+bool lanczos_r43_phase_frame(const AxisTables &t, std::vector<float> &w6)
+{
+    if ((t.in_n % 3) != 0 || 3 * (uint64_t)t.out_n != 4 * (uint64_t)t.in_n || t.lz_max_taps < 0) return false;
+    w6.assign((size_t)t.out_n * 6, 0.0f);
+    for (uint32_t o = 0; o < t.out_n; ++o) {
+        const int32_t base = 3 * (int32_t)(o / 4) - 3 + (int32_t)(o % 4);
+        const float *ws = t.lz_w.data() + (size_t)o * kResizeMaxTaps;
+        for (uint32_t i = 0; i < t.lz_ntaps[o]; ++i) {
+            const int32_t j = t.lz_left[o] + (int32_t)i - base;
+            if (j < 0 || j >= 6) {
+                if (ws[i] != 0.0f) return false;
+                continue;
+            }
+            w6[(size_t)o * 6 + j] = ws[i];
+        }
+    }
+    return true;
+}
+
+bool lanczos_r43_interior_uniform(const AxisTables &t, const std::vector<float> &w6)
+{
+    if (t.in_n < 18) return false;
+    for (uint32_t o = 8; o + 8 < t.out_n; ++o) {
+        const float *ref = w6.data() + (size_t)(8 + o % 4) * 6;
+        if (std::memcmp(ref, w6.data() + (size_t)o * 6, 6 * sizeof(float)) != 0) return false;
+    }
+    return true;
+}
+
 bool lanczos_r32_weight_classes(const AxisTables &t, const std::vector<float> &w6, bool lanes, std::vector<uint32_t> &cls,
                                 std::vector<float> &classes)
 {

@@ -79,6 +79,12 @@ bool lanczos_r32_phase_frame(const AxisTables &t, std::vector<float> &w6);
 bool lanczos_r32_weight_classes(const AxisTables &t, const std::vector<float> &w6, bool lanes, std::vector<uint32_t> &cls,
                                 std::vector<float> &classes);
 
+// Factor 4/3 (3 out_n == 4 in_n): output o = 4 g + p belongs to the input group g = (3g .. 3g+2), frame start 3 g - 3 + p.
+// The ratio 3/4 and every sample centre are exact in f32: the interior outputs of a phase share one set of weights.
+bool lanczos_r43_phase_frame(const AxisTables &t, std::vector<float> &w6);
+// True when every output of the groups 2 .. in_n / 3 - 3 has the weights of output 8 + p of its phase.
+bool lanczos_r43_interior_uniform(const AxisTables &t, const std::vector<float> &w6);
+
 // Down-scaling stream tables for k_resize_down (7 accumulator slots, slot of output y = y % 7).
 // rows: (in_n + extra) x 8 words -- per input row the f32 weight it carries in each slot (0 where the row is
 // outside the window of the output that owns the slot), then one completion word: 0xFFFFFFFF, or (slot << 28 | y)

@@ -132,8 +132,9 @@ def test_bicubic_and_triangle_resize(nsc, oracle_mod, alg, filt, dims):
     out, u = _up(nsc, alg, img, ow, oh)
     x2 = (ow, oh) == (2 * w, 2 * h) and w % 4 == 0 and w >= 16 and h >= 16
     r32 = (2 * ow, 2 * oh) == (3 * w, 3 * h) and w % 8 == 0 and h % 2 == 0 and w >= 32 and h >= 16
+    r43 = (3 * ow, 3 * oh) == (4 * w, 4 * h) and w % 12 == 0 and h % 3 == 0 and w >= 48 and h >= 18
     upscale_by4 = ow % 4 == 0 and ow >= w and oh >= h
-    assert u.kernel_variant == ("lanczos3_x2_regwin" if x2 else "lanczos3_r32_regwin" if r32 else
+    assert u.kernel_variant == ("lanczos3_x2_regwin" if x2 else "lanczos3_r32_regwin" if r32 else "lanczos3_r43_regwin" if r43 else
                                 ("resize_regwin_lds" if upscale_by4 else ("resize_down_stream" if oh < h else "resize_rows_lds")))
     assert _maxdiff(out, want) <= 1
     out_e, _ = _up(nsc, alg, img, ow, oh, lanczos_mode="exact")
@@ -701,8 +702,8 @@ def test_resize_register_window_variant(nsc, oracle_mod, alg, filt, dims):
     (w, h), (ow, oh) = dims
     img = oracle_mod.gen_noise(w, h, 91)
     want = oracle_mod.resize(img, ow, oh, filt)
-    # exact x3 and x3/2 have their own kernels: ask for this one
-    gen = {"force_general": 1} if (ow, oh) == (3 * w, 3 * h) or (2 * ow, 2 * oh) == (3 * w, 3 * h) else {}
+    # exact x3, x3/2 and x4/3 have their own kernels: ask for this one
+    gen = {"force_general": 1} if (ow, oh) == (3 * w, 3 * h) or (2 * ow, 2 * oh) == (3 * w, 3 * h) or (3 * ow, 3 * oh) == (4 * w, 4 * h) else {}
     got_e, u = _up(nsc, alg, img, ow, oh, lanczos_mode="exact", options=dict(gen))
     assert u.kernel_variant == "resize_regwin_lds"
     assert np.array_equal(got_e, want)
@@ -779,6 +780,51 @@ def test_resize_factor_three_halves_register_window(nsc, oracle_mod, alg, filt, 
     ub.initialize(w, h, ow, oh)
     got_b = np.frombuffer(ub.upscale(_bgra(img).tobytes()), np.uint8).reshape(oh, ow, 4)
     assert np.array_equal(got_b, want)
+
+
+@pytest.mark.parametrize("alg,filt", [("lanczos3", 0), ("bicubic", 1), ("triangle", 2)])
+@pytest.mark.parametrize("size", [(48, 18), (96, 36), (192, 21), (372, 33), (384, 45), (564, 24), (960, 54), (1116, 30)])
+def test_resize_factor_four_thirds_register_window(nsc, oracle_mod, alg, filt, size):
+    """x4/3 (1080p -> 1440p): four output rows per group of three input rows, four phases per group of three columns, one lane
+    per column group (12 bytes in, 16 contiguous bytes out); the ratio 3/4 is exact in f32, so one set of weights per phase.
+    EXACT mode: 0 differences; FMA mode: the bits of the general kernel."""
+    w, h = size
+    ow, oh = 4 * w // 3, 4 * h // 3
+    img = oracle_mod.gen_noise(w, h, 96)
+    want = oracle_mod.resize(img, ow, oh, filt)
+    got_e, u = _up(nsc, alg, img, ow, oh, lanczos_mode="exact")
+    assert u.kernel_variant == "lanczos3_r43_regwin"
+    assert np.array_equal(got_e, want)
+    got_f, uf = _up(nsc, alg, img, ow, oh)
+    assert uf.kernel_variant == "lanczos3_r43_regwin"
+    assert _maxdiff(got_f, want) <= 1 and (got_f != want).mean() < (5e-2 if alg == "triangle" else 1e-3)
+    ref_f, ug = _up(nsc, alg, img, ow, oh, options={"force_general": 1})
+    assert ug.kernel_variant in ("resize_regwin_lds", "resize_rows_lds") and np.array_equal(got_f, ref_f)
+    for th in (3, 7, 24, 40):
+        out_t, _ = _up(nsc, alg, img, ow, oh, lanczos_mode="exact", options={"rows_per_wave": th})
+        assert np.array_equal(out_t, want), th
+    opq = img.copy()
+    opq[..., 3] = 255
+    got_o, _ = _up(nsc, alg, opq, ow, oh)
+    ref_o, _ = _up(nsc, alg, opq, ow, oh, options={"force_general": 1})
+    assert np.array_equal(got_o, ref_o) and (got_o[..., 3] == 255).all()
+    ub = nsc.PyWgpuUpscaler("quality", alg, lanczos_mode="exact")
+    ub.set_input_format("bgra")
+    ub.initialize(w, h, ow, oh)
+    got_b = np.frombuffer(ub.upscale(_bgra(img).tobytes()), np.uint8).reshape(oh, ow, 4)
+    assert np.array_equal(got_b, want)
+
+
+def test_1080p_to_1440p_takes_the_four_thirds_kernel(nsc, oracle_mod):
+    w, h, ow, oh = 1920, 1080, 2560, 1440
+    img = oracle_mod.gen_noise(w, h, 80)
+    want = oracle_mod.lanczos3(img, ow, oh, threads=0)
+    got_f, uf = _up(nsc, "lanczos3", img, ow, oh)
+    assert uf.kernel_variant == "lanczos3_r43_regwin"
+    d = np.abs(got_f.astype(np.int16) - want.astype(np.int16))
+    assert d.max() <= 1 and (d > 0).mean() < 1e-3
+    got_e, ue = _up(nsc, "lanczos3", img, ow, oh, lanczos_mode="exact")
+    assert ue.kernel_variant == "lanczos3_r43_regwin" and np.array_equal(got_e, want)
 
 
 def test_1440p_to_4k_takes_the_three_halves_kernel(nsc, oracle_mod):
@@ -911,7 +957,7 @@ def test_resize_window_opaque_rows(nsc, oracle_mod, alg, dims):
     v = base.copy(); v[..., 3] = 255; v[h // 3, w // 2, 3] = 254; v[0, 0, 3] = 0; v[h - 1, w - 1, 3] = 9; variants["pixels"] = v
     for name, img in variants.items():
         got, u = _up(nsc, alg, img, ow, oh)
-        assert u.kernel_variant in ("resize_regwin_lds", "lanczos3_xs_regwin", "lanczos3_r32_regwin")
+        assert u.kernel_variant in ("resize_regwin_lds", "lanczos3_xs_regwin", "lanczos3_r32_regwin", "lanczos3_r43_regwin")
         ref, ur = _up(nsc, alg, img, ow, oh, options={"force_general": 1, "force_rows": 1})
         assert ur.kernel_variant == "resize_rows_lds"
         assert np.array_equal(got, ref), name
