@@ -126,6 +126,17 @@ __device__ __forceinline__ uint32_t blend_px(uint32_t a, uint32_t b, float t, fl
     return o;
 }
 
+// The value a neighbouring lane holds, by a DPP move (no LDS round trip): wave_up = lane - 1's, wave_down = lane + 1's.
+// Lane 0 / lane 63, which have no such neighbour, get 0 -- the row-walking kernels keep those lanes as halo.
+__device__ __forceinline__ float wave_up(float v)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138 /*wave_shr:1*/, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float wave_down(float v)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x130 /*wave_shl:1*/, 0xF, 0xF, true));
+}
+
 // XCD-aware workgroup order.  The dispatcher deals consecutive workgroups round-robin to the 8 XCDs (blocks b and
 // b + 8 share one, observed behaviour, speed only), each with its own L2.  This bijective remap hands every XCD a
 // CONTIGUOUS range of virtual workgroup ids, so that workgroups which re-read each other's halo rows / columns

@@ -172,14 +172,6 @@ __global__ __launch_bounds__(kPyrThreads) void k_pyramid_level(const void *__res
     }
 }
 
-__device__ __forceinline__ float hs_lane_up(float v) // value of lane-1
-{
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138 /*wave_shr:1*/, 0xF, 0xF, true));
-}
-__device__ __forceinline__ float hs_lane_down(float v) // value of lane+1
-{
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x130 /*wave_shl:1*/, 0xF, 0xF, true));
-}
 
 // ---- The same pyramid level without LDS ("streamed"), for batches --------------------------------
 // A wave owns a strip of 128 columns -- two adjacent columns per lane, the outer lanes are the 2-column
@@ -192,11 +184,11 @@ __device__ __forceinline__ float hs_lane_down(float v) // value of lane+1
 // expressions in the same order as k_pyramid_level: identical bits.  HBM traffic as there; no LDS, no barrier.
 __device__ __forceinline__ float4 lane_up4(const float4 v)
 {
-    return make_float4(hs_lane_up(v.x), hs_lane_up(v.y), hs_lane_up(v.z), hs_lane_up(v.w));
+    return make_float4(wave_up(v.x), wave_up(v.y), wave_up(v.z), wave_up(v.w));
 }
 __device__ __forceinline__ float4 lane_down4(const float4 v)
 {
-    return make_float4(hs_lane_down(v.x), hs_lane_down(v.y), hs_lane_down(v.z), hs_lane_down(v.w));
+    return make_float4(wave_down(v.x), wave_down(v.y), wave_down(v.z), wave_down(v.w));
 }
 
 template <bool U8IN>
@@ -538,7 +530,7 @@ __global__ __launch_bounds__(256) void k_hs_stream(const float *__restrict__ coe
         {
             float ix = nix, iy = niy, it = nit;
             if constexpr (LUM) { // horn_schunck.wgsl:58-82, as hs_prepare_cell
-                const float left = hs_lane_up(l1_row), right = hs_lane_down(l1_row);
+                const float left = wave_up(l1_row), right = wave_down(l1_row);
                 ix = ((self_r ? l1_row : right) - (self_l ? l1_row : left)) * 0.5f;
                 iy = (nix - l1_above) * 0.5f;
                 it = niy - l1_row;
@@ -560,7 +552,7 @@ __global__ __launch_bounds__(256) void k_hs_stream(const float *__restrict__ coe
                 n = prev[j]; // past the last row: it repeats
             } else {
                 n.uc = arr.x, n.vc = arr.y;
-                const float ul = hs_lane_up(arr.x), ur = hs_lane_down(arr.x), vl = hs_lane_up(arr.y), vr = hs_lane_down(arr.y);
+                const float ul = wave_up(arr.x), ur = wave_down(arr.x), vl = wave_up(arr.y), vr = wave_down(arr.y);
                 n.ul = self_l ? arr.x : ul, n.ur = self_r ? arr.x : ur;
                 n.vl = self_l ? arr.y : vl, n.vr = self_r ? arr.y : vr;
             }

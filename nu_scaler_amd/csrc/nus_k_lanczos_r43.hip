@@ -34,14 +34,6 @@ struct LanczosR43Args {
     size_t in_frame_bytes, out_frame_bytes;
 };
 
-__device__ __forceinline__ float r43_lane_up(float v) // value of lane-1
-{
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138 /*wave_shr:1*/, 0xF, 0xF, true));
-}
-__device__ __forceinline__ float r43_lane_down(float v) // value of lane+1
-{
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x130 /*wave_shl:1*/, 0xF, 0xF, true));
-}
 
 struct Px3 {
     uint32_t x, y, z;
@@ -93,15 +85,15 @@ __device__ __forceinline__ void r43_hpass_store(const float (&V)[12], const floa
     for (int c = 0; c < 4; ++c) {
         if (c == 3 && skip_alpha) continue;
         float e[9]; // vertical sums of input columns c0-3 .. c0+5 for this channel
-        e[0] = r43_lane_up(V[0 * 4 + c]);
-        e[1] = r43_lane_up(V[1 * 4 + c]);
-        e[2] = r43_lane_up(V[2 * 4 + c]);
+        e[0] = wave_up(V[0 * 4 + c]);
+        e[1] = wave_up(V[1 * 4 + c]);
+        e[2] = wave_up(V[2 * 4 + c]);
         e[3] = V[0 * 4 + c];
         e[4] = V[1 * 4 + c];
         e[5] = V[2 * 4 + c];
-        e[6] = r43_lane_down(V[0 * 4 + c]);
-        e[7] = r43_lane_down(V[1 * 4 + c]);
-        e[8] = r43_lane_down(V[2 * 4 + c]);
+        e[6] = wave_down(V[0 * 4 + c]);
+        e[7] = wave_down(V[1 * 4 + c]);
+        e[8] = wave_down(V[2 * 4 + c]);
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
             // phase 3's frame is columns c0 .. c0+5: slots 0 .. 5 are e[3] .. e[8]

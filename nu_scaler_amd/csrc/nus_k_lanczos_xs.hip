@@ -41,14 +41,6 @@ struct LanczosXsArgs {
     size_t in_frame_bytes, out_frame_bytes;
 };
 
-__device__ __forceinline__ float lane_up(float v) // value of lane-1
-{
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138 /*wave_shr:1*/, 0xF, 0xF, true));
-}
-__device__ __forceinline__ float lane_down(float v) // value of lane+1
-{
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x130 /*wave_shl:1*/, 0xF, 0xF, true));
-}
 
 __device__ __forceinline__ void cvt_row(const uint4 raw, float (&dst)[16])
 {
@@ -108,16 +100,16 @@ __device__ __forceinline__ void xs_hpass_store(const float (&V)[16], const float
     for (int c = 0; c < 4; ++c) {
         if (c == 3 && skip_alpha) continue;
         float e[10]; // vertical sums of input columns c0-3 .. c0+6 for this channel
-        e[0] = lane_up(V[1 * 4 + c]);
-        e[1] = lane_up(V[2 * 4 + c]);
-        e[2] = lane_up(V[3 * 4 + c]);
+        e[0] = wave_up(V[1 * 4 + c]);
+        e[1] = wave_up(V[2 * 4 + c]);
+        e[2] = wave_up(V[3 * 4 + c]);
         e[3] = V[0 * 4 + c];
         e[4] = V[1 * 4 + c];
         e[5] = V[2 * 4 + c];
         e[6] = V[3 * 4 + c];
-        e[7] = lane_down(V[0 * 4 + c]);
-        e[8] = lane_down(V[1 * 4 + c]);
-        e[9] = lane_down(V[2 * 4 + c]);
+        e[7] = wave_down(V[0 * 4 + c]);
+        e[8] = wave_down(V[1 * 4 + c]);
+        e[9] = wave_down(V[2 * 4 + c]);
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
 #pragma unroll
