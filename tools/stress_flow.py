@@ -1,0 +1,31 @@
+#!/usr/bin/env python
+"""Random sizes / pyramid depths / iteration counts / batch lengths through nus_flow_estimate_device_stream in every kernel mode
+(by size, streamed, LDS tiles) against the oracle, bit for bit (dev tool, run on the GPU box: python tools/stress_flow.py)."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+import nu_scaler_amd as nsc
+import oracle as orc
+rng = np.random.default_rng(11)
+bad = cases = 0
+dev = torch.device("cuda:0")
+for _ in range(24):
+    w = int(rng.integers(20, 420)); h = int(rng.integers(12, 300)); levels = int(rng.integers(1, 5))
+    ci = int(rng.integers(0, 24)); ri = int(rng.integers(0, 13)); n = int(rng.integers(2, 6))
+    frames = np.stack([orc.gen_noise(w, h, int(rng.integers(1, 999))) for _ in range(n)])
+    fe = nsc.FlowEstimator(levels=levels, coarse_iterations=ci, refine_iterations=ri)
+    want = [orc.flow_estimate(frames[k], frames[k + 1], levels, ci, ri, fe.lambda_) for k in range(n - 1)]
+    d_frames = torch.from_numpy(frames).to(dev)
+    d_flows = torch.empty((n - 1, h, w, 2), dtype=torch.float32, device=dev)
+    for mode in (1, 3, 2):
+        fe.set_tiled(mode)
+        d_flows.fill_(float("nan"))
+        fe.estimate_device_stream(d_frames.data_ptr(), n, w, h, d_flows.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        got = d_flows.cpu().numpy()
+        ok = all(np.array_equal(got[k], want[k]) for k in range(n - 1))
+        cases += 1
+        if not ok:
+            bad += 1
+            print("MISMATCH", w, h, levels, ci, ri, n, mode)
+print(f"{cases} cases, {bad} mismatches")
