@@ -969,7 +969,7 @@ def test_resize_window_opaque_rows(nsc, oracle_mod, alg, dims):
 @pytest.mark.parametrize("dims", [((256, 128), (128, 64)), ((300, 157), (150, 78)), ((515, 90), (172, 30)), ((640, 200), (160, 50)),
                                   ((200, 300), (133, 201)), ((130, 71), (129, 70)), ((97, 260), (61, 65)), ((70, 64), (33, 13)),
                                   ((64, 900), (16, 300)),
-                                  # exactly 1/2 on both axes: k_resize_down2 (58 outputs per wave: one, two, three segments, a 1-wide one)
+                                  # exactly 1/2 on both axes (4K -> 1080p's ratio), widths around the 64-output segments
                                   ((232, 60), (116, 30)), ((234, 62), (117, 31)), ((1000, 44), (500, 22)), ((116, 300), (58, 150))])
 def test_resize_down_streaming_kernel(nsc, oracle_mod, alg, filt, dims):
     """Down-scaling (captured frames resized to the target, capture/common.rs:56): input rows streamed once into
