@@ -321,6 +321,13 @@ void HipUpscaler::choose_variant()
             }
         }
         variant_ = ok ? Variant::BilinearX2Int : Variant::BilinearTable;
+        // x3/2, CPU form: i0 = 2 (o / 3) + (o % 3 == 2) and fraction 0 at o % 3 == 0 on both axes
+        bool r32 = !ok && !wgsl_bilinear_ && !force_general_ && 2 * (uint64_t)ow_ == 3 * (uint64_t)iw_ &&
+                   2 * (uint64_t)oh_ == 3 * (uint64_t)ih_ && (iw_ & 1) == 0 && (ih_ & 1) == 0;
+        for (const AxisTables *t : {&tx_, &ty_})
+            for (uint32_t o = 0; r32 && o < t->out_n; ++o)
+                r32 = t->bl_i0[o] == 2 * (o / 3) + (o % 3 == 2 ? 1u : 0u) && (o % 3 != 0 || t->bl_frac[o] == 0.0f);
+        if (r32) variant_ = Variant::BilinearR32;
         break;
     }
     case Algorithm::Lanczos3:
@@ -499,6 +506,7 @@ int HipUpscaler::enqueue(const uint8_t *d_in, uint8_t *d_out, uint32_t n_frames,
     case Variant::NearestX2: e = launch_nearest_x2(L); break;
     case Variant::BilinearTable: e = launch_bilinear_table(L, dt_, wgsl_bilinear_); break;
     case Variant::BilinearX2Int: e = launch_bilinear_x2_int(L); break;
+    case Variant::BilinearR32: e = launch_bilinear_r32(L, dt_); break;
     case Variant::LanczosGeneral: e = launch_lanczos_general(L, dt_, lanczos_exact_, 0); break;
     case Variant::ResizeWin:
         e = launch_resize_win(L, dt_, lanczos_exact_, resize_ncols_max_, resize_union_taps_, win_outputs_per_lane_);

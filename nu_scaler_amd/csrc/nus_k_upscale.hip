@@ -244,12 +244,88 @@ __global__ __launch_bounds__(256) void k_bilinear_x2_int(
 
 } // namespace
 
+// Bilinear, CPU form, at exactly 3/2 on both axes -- the factor the reference's benchmark entry points default to
+// (nu_scaler_py/nu_scaler/benchmark.py:63) with the algorithm its AMD path falls back to (gpu/detector.rs:181-190).
+// Output 3 g + p samples the input pair g: x0 = 2g, 2g, 2g+1 with fractions 0, ~2/3, ~1/3 (host-checked: the tables'
+// indices have exactly this shape and phase 0's fraction is 0, so its lerp p00 * 1 + p10 * 0 is p00 itself; the other
+// fractions are rounded in f32 and come per lane / per row from the tables).  A lane owns one input pair: 8 + 4 bytes
+// in (its two pixels and the next one, clamped at the row's end as the CPU clamps x1), 3 output pixels = 12 contiguous
+// bytes out; rows likewise in pairs, three output rows each, the horizontally lerped rows kept in registers.  Same
+// expressions as k_bilinear_table (common.rs:221-227), about 0.6 of its instructions per pixel.
+__global__ __launch_bounds__(256) void k_bilinear_r32(
+    const uint32_t *__restrict__ in, uint32_t *__restrict__ out, const float *__restrict__ fxt, const float *__restrict__ fyt,
+    uint32_t iw, uint32_t ih, uint32_t ow, uint32_t pairs_per_wave, size_t in_frame_px, size_t out_frame_px, uint32_t sel)
+{
+    const uint32_t g = blockIdx.x * kWave + threadIdx.x; // this lane's input column pair
+    const uint32_t rb = __builtin_amdgcn_readfirstlane(blockIdx.y * 4 + threadIdx.y);
+    const uint32_t m_begin = rb * pairs_per_wave, m_end = umin(m_begin + pairs_per_wave, ih / 2);
+    if (m_begin >= m_end || 2 * g >= iw) return;
+    const uint32_t *base = in + (size_t)blockIdx.z * in_frame_px;
+    uint32_t *dst = out + (size_t)blockIdx.z * out_frame_px + 3 * g;
+    const float dx1 = fxt[3 * g + 1], dx2 = fxt[3 * g + 2], ndx1 = 1.0f - dx1, ndx2 = 1.0f - dx2;
+    const uint32_t c2 = umin(2 * g + 2, iw - 1);
+    struct Raw {
+        uint2 ab;
+        uint32_t c;
+    };
+    auto fetch = [&](uint32_t r) {
+        const uint32_t *row = base + (size_t)umin(r, ih - 1) * iw;
+        return Raw{*reinterpret_cast<const uint2 *>(row + 2 * g), row[c2]};
+    };
+    // the lane's three horizontally lerped values of one source row: h[4 p + c]
+    auto hrow = [&](const Raw &t, float (&h)[12]) {
+        const uint32_t pa = swz(t.ab.x, sel), pb = swz(t.ab.y, sel), pc = swz(t.c, sel);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float a = ch_f32(pa, c), b = ch_f32(pb, c), d = ch_f32(pc, c);
+            h[c] = a;                        // a * (1 - 0) + b * 0
+            h[4 + c] = a * ndx1 + b * dx1;   // top = p00 * (1 - dx) + p10 * dx
+            h[8 + c] = b * ndx2 + d * dx2;
+        }
+    };
+    auto emit = [&](uint32_t y, const float (&v)[12]) {
+        uint32_t o[3];
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            uint32_t px = 0;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) px = pack_trunc_u8(v[4 * p + c], c, px); // clamp(0, 255) as u8
+            o[p] = px;
+        }
+        uint32_t *d = dst + (size_t)y * ow;
+        d[0] = o[0], d[1] = o[1], d[2] = o[2];
+    };
+    float ha[12], hb[12], hc[12]; // source rows 2m, 2m+1, 2m+2
+    hrow(fetch(2 * m_begin), ha);
+    Raw nb = fetch(2 * m_begin + 1), nc = fetch(2 * m_begin + 2);
+    for (uint32_t m = m_begin; m < m_end; ++m) {
+        hrow(nb, hb);
+        hrow(nc, hc);
+        if (m + 1 < m_end) nb = fetch(2 * m + 3), nc = fetch(2 * m + 4); // the next pair's rows: in flight during this one
+        float dy1 = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(fyt[3 * m + 1])));
+        float dy2 = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(fyt[3 * m + 2])));
+        asm volatile("" : "+v"(dy1), "+v"(dy2)); // VGPR copies: scalar operands halve the VALU issue rate
+        const float ndy1 = 1.0f - dy1, ndy2 = 1.0f - dy2;
+        emit(3 * m, ha); // top * (1 - 0) + bottom * 0
+        float v[12];
+#pragma unroll
+        for (int k = 0; k < 12; ++k) v[k] = ha[k] * ndy1 + hb[k] * dy1;
+        emit(3 * m + 1, v);
+#pragma unroll
+        for (int k = 0; k < 12; ++k) v[k] = hb[k] * ndy2 + hc[k] * dy2;
+        emit(3 * m + 2, v);
+#pragma unroll
+        for (int k = 0; k < 12; ++k) ha[k] = hc[k];
+    }
+}
+
 const char *variant_name(Variant v){
     switch (v) {
     case Variant::NearestTable: return "nearest_table";
     case Variant::NearestX2: return "nearest_x2_vec16";
     case Variant::BilinearTable: return "bilinear_table_f32";
     case Variant::BilinearX2Int: return "bilinear_x2_packed_u8";
+    case Variant::BilinearR32: return "bilinear_r32_f32";
     case Variant::LanczosGeneral: return "lanczos3_general";
     case Variant::ResizeRows: return "resize_rows_lds";
     case Variant::ResizeWin: return "resize_regwin_lds";
@@ -319,6 +395,20 @@ hipError_t launch_bilinear_table(const UpscaleLaunch &L, const DeviceTables &T, 
         else if (wgsl_form) NUS_BL(false, true);
         else NUS_BL(false, false);
 #undef NUS_BL
+    });
+}
+
+hipError_t launch_bilinear_r32(const UpscaleLaunch &L, const DeviceTables &T)
+{
+    if (2 * (uint64_t)L.ow != 3 * (uint64_t)L.iw || 2 * (uint64_t)L.oh != 3 * (uint64_t)L.ih || (L.iw & 1) || (L.ih & 1)) return hipErrorInvalidValue;
+    const size_t ipx = (size_t)L.iw * L.ih, opx = (size_t)L.ow * L.oh;
+    return for_frame_chunks(L, [&](const uint8_t *in, uint8_t *out, uint32_t n) {
+        const uint32_t strips = cdiv(L.iw / 2, kWave);
+        uint64_t ppw = (uint64_t)(L.ih / 2) * strips * n / 8192; // row pairs per wave: a few thousand waves per launch
+        ppw = ppw < 4 ? 4 : (ppw > 32 ? 32 : ppw);
+        const dim3 block(kWave, 4), grid(strips, cdiv(cdiv(L.ih / 2, (uint32_t)ppw), 4), n);
+        hipLaunchKernelGGL(k_bilinear_r32, grid, block, 0, L.stream, reinterpret_cast<const uint32_t *>(in),
+                           reinterpret_cast<uint32_t *>(out), T.bl_fx, T.bl_fy, L.iw, L.ih, L.ow, (uint32_t)ppw, ipx, opx, L.in_sel);
     });
 }
 

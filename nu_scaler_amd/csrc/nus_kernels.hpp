@@ -72,6 +72,7 @@ enum class Variant : int {
     NearestX2,        // exact x2, 16-B loads/stores
     BilinearTable,    // any scale, f32, CPU or WGSL arithmetic
     BilinearX2Int,    // exact x2, CPU arithmetic done in packed-u8 integer ops
+    BilinearR32,      // exact x3/2, CPU form: one input pair per lane, three outputs, row pairs
     LanczosGeneral,   // any scale, direct separable evaluation per output pixel (fallback)
     ResizeRows,       // any scale, separable: V pass into an LDS row, H pass out of it
     ResizeWin,        // up-scaling: V pass from a register row window (as the x2 kernel), H pass through the LDS row
@@ -91,6 +92,8 @@ hipError_t launch_nearest_table(const UpscaleLaunch &L, const DeviceTables &T);
 hipError_t launch_nearest_x2(const UpscaleLaunch &L);
 hipError_t launch_bilinear_table(const UpscaleLaunch &L, const DeviceTables &T, bool wgsl_form);
 hipError_t launch_bilinear_x2_int(const UpscaleLaunch &L);
+// exact x3/2, CPU form (host-checked table shape: i0 = 2 (o / 3) + (o % 3 == 2), fraction 0 at o % 3 == 0)
+hipError_t launch_bilinear_r32(const UpscaleLaunch &L, const DeviceTables &T);
 // edge_only: evaluate only the first and last `edge_cols` output columns.
 hipError_t launch_lanczos_general(const UpscaleLaunch &L, const DeviceTables &T, bool exact,
                                   uint32_t edge_cols);

@@ -81,6 +81,28 @@ def test_bilinear_general_bit_exact(nsc, oracle_mod, dims):
     assert np.array_equal(out_w, oracle_mod.bilinear_wgsl(img, ow, oh))
 
 
+@pytest.mark.parametrize("size", [(2, 2), (4, 6), (64, 36), (66, 38), (126, 20), (128, 22), (130, 24), (500, 40), (1280, 720)])
+def test_bilinear_three_halves_kernel(nsc, oracle_mod, size):
+    """x3/2 in the CPU form -- the scale the reference's benchmark entry points default to -- has its own kernel (one input
+    pair per lane, three outputs; row pairs): bit-exact against the oracle and the table-driven kernel; the WGSL form keeps
+    the table kernel."""
+    w, h = size
+    ow, oh = 3 * w // 2, 3 * h // 2
+    img = oracle_mod.gen_noise(w, h, 18)
+    want = oracle_mod.bilinear(img, ow, oh)
+    out, u = _up(nsc, "bilinear", img, ow, oh)
+    assert u.kernel_variant == "bilinear_r32_f32"
+    assert np.array_equal(out, want)
+    out_g, ug = _up(nsc, "bilinear", img, ow, oh, options={"force_general": 1})
+    assert ug.kernel_variant == "bilinear_table_f32" and np.array_equal(out_g, want)
+    out_w, uw = _up(nsc, "bilinear", img, ow, oh, bilinear_variant="wgsl")
+    assert uw.kernel_variant == "bilinear_table_f32" and np.array_equal(out_w, oracle_mod.bilinear_wgsl(img, ow, oh))
+    ub = nsc.PyWgpuUpscaler("quality", "bilinear")
+    ub.set_input_format("bgra")
+    ub.initialize(w, h, ow, oh)
+    assert np.array_equal(np.frombuffer(ub.upscale(_bgra(img).tobytes()), np.uint8).reshape(oh, ow, 4), want)
+
+
 @pytest.mark.parametrize("size", [(64, 36), (320, 240), (252, 20), (256, 33), (16, 1), (500, 7), (1000, 50), (248, 40), (496, 9),
                                   (16, 16), (20, 17), (1916, 23), (128, 97)])
 def test_lanczos_x2(nsc, oracle_mod, size):
