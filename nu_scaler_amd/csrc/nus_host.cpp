@@ -308,6 +308,13 @@ void HipUpscaler::choose_variant()
     switch (algorithm_) {
     case Algorithm::Nearest:
         variant_ = x2 ? Variant::NearestX2 : Variant::NearestTable;
+        if (!x2 && !force_general_ && 2 * (uint64_t)ow_ == 3 * (uint64_t)iw_ && 2 * (uint64_t)oh_ == 3 * (uint64_t)ih_ && (iw_ & 1) == 0 &&
+            (ih_ & 1) == 0) {
+            bool r32 = true; // source index 2 (o / 3) + (o % 3 == 2) on both axes
+            for (const AxisTables *t : {&tx_, &ty_})
+                for (uint32_t o = 0; r32 && o < t->out_n; ++o) r32 = t->nn_src[o] == 2 * (o / 3) + (o % 3 == 2 ? 1u : 0u);
+            if (r32) variant_ = Variant::NearestR32;
+        }
         break;
     case Algorithm::Bilinear: {
         // The packed-integer x2 kernel is valid iff the CPU-form tables are exactly
@@ -504,6 +511,7 @@ int HipUpscaler::enqueue(const uint8_t *d_in, uint8_t *d_out, uint32_t n_frames,
     switch (variant_) {
     case Variant::NearestTable: e = launch_nearest_table(L, dt_); break;
     case Variant::NearestX2: e = launch_nearest_x2(L); break;
+    case Variant::NearestR32: e = launch_nearest_r32(L); break;
     case Variant::BilinearTable: e = launch_bilinear_table(L, dt_, wgsl_bilinear_); break;
     case Variant::BilinearX2Int: e = launch_bilinear_x2_int(L); break;
     case Variant::BilinearR32: e = launch_bilinear_r32(L, dt_); break;

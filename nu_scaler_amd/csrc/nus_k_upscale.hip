@@ -244,6 +244,25 @@ __global__ __launch_bounds__(256) void k_bilinear_x2_int(
 
 } // namespace
 
+// Nearest neighbour at exactly 3/2 on both axes (the reference benchmark's default scale; the algorithm every technology
+// but Wgpu falls back to, upscale/mod.rs:102-115): source index (3g + p) * iw / ow = 2g + {0, 0, 1} (host-checked on the
+// tables), so a lane copies its input pair into three outputs -- 8 bytes in, 12 contiguous bytes out -- and a row pair into
+// three rows.
+__global__ __launch_bounds__(256) void k_nearest_r32(const uint32_t *__restrict__ in, uint32_t *__restrict__ out, uint32_t iw,
+                                                     uint32_t ih, uint32_t ow, size_t in_frame_px, size_t out_frame_px, uint32_t sel)
+{
+    const uint32_t g = blockIdx.x * kWave + threadIdx.x;                                   // input column pair
+    const uint32_t m = __builtin_amdgcn_readfirstlane(blockIdx.y * 4 + threadIdx.y);      // input row pair
+    if (2 * g >= iw || 2 * m >= ih) return;
+    const uint32_t *src = in + (size_t)blockIdx.z * in_frame_px + (size_t)(2 * m) * iw + 2 * g;
+    uint32_t *d = out + (size_t)blockIdx.z * out_frame_px + (size_t)(3 * m) * ow + 3 * g;
+    const uint2 r0 = *reinterpret_cast<const uint2 *>(src), r1 = *reinterpret_cast<const uint2 *>(src + iw);
+    const uint32_t a0 = swz(r0.x, sel), b0 = swz(r0.y, sel), a1 = swz(r1.x, sel), b1 = swz(r1.y, sel);
+    d[0] = a0, d[1] = a0, d[2] = b0;
+    d[ow] = a0, d[ow + 1] = a0, d[ow + 2] = b0;
+    d[2 * (size_t)ow] = a1, d[2 * (size_t)ow + 1] = a1, d[2 * (size_t)ow + 2] = b1;
+}
+
 // Bilinear, CPU form, at exactly 3/2 on both axes -- the factor the reference's benchmark entry points default to
 // (nu_scaler_py/nu_scaler/benchmark.py:63) with the algorithm its AMD path falls back to (gpu/detector.rs:181-190).
 // Output 3 g + p samples the input pair g: x0 = 2g, 2g, 2g+1 with fractions 0, ~2/3, ~1/3 (host-checked: the tables'
@@ -323,6 +342,7 @@ const char *variant_name(Variant v){
     switch (v) {
     case Variant::NearestTable: return "nearest_table";
     case Variant::NearestX2: return "nearest_x2_vec16";
+    case Variant::NearestR32: return "nearest_r32";
     case Variant::BilinearTable: return "bilinear_table_f32";
     case Variant::BilinearX2Int: return "bilinear_x2_packed_u8";
     case Variant::BilinearR32: return "bilinear_r32_f32";
@@ -365,6 +385,17 @@ hipError_t launch_nearest_table(const UpscaleLaunch &L, const DeviceTables &T)
             hipLaunchKernelGGL(k_nearest_table<true>, grid, block, 0, L.stream, i32, o32, T.nn_sx, T.nn_sy, L.iw, L.ow, L.oh, rpw, ipx, opx, L.in_sel);
         else
             hipLaunchKernelGGL(k_nearest_table<false>, grid, block, 0, L.stream, i32, o32, T.nn_sx, T.nn_sy, L.iw, L.ow, L.oh, rpw, ipx, opx, L.in_sel);
+    });
+}
+
+hipError_t launch_nearest_r32(const UpscaleLaunch &L)
+{
+    if (2 * (uint64_t)L.ow != 3 * (uint64_t)L.iw || 2 * (uint64_t)L.oh != 3 * (uint64_t)L.ih || (L.iw & 1) || (L.ih & 1)) return hipErrorInvalidValue;
+    const size_t ipx = (size_t)L.iw * L.ih, opx = (size_t)L.ow * L.oh;
+    return for_frame_chunks(L, [&](const uint8_t *in, uint8_t *out, uint32_t n) {
+        const dim3 block(kWave, 4), grid(cdiv(L.iw / 2, kWave), cdiv(L.ih / 2, 4), n);
+        hipLaunchKernelGGL(k_nearest_r32, grid, block, 0, L.stream, reinterpret_cast<const uint32_t *>(in),
+                           reinterpret_cast<uint32_t *>(out), L.iw, L.ih, L.ow, ipx, opx, L.in_sel);
     });
 }
 

@@ -70,6 +70,7 @@ struct UpscaleLaunch {
 enum class Variant : int {
     NearestTable = 0, // any scale, index tables
     NearestX2,        // exact x2, 16-B loads/stores
+    NearestR32,       // exact x3/2: an input pair per lane copied into three outputs, a row pair into three rows
     BilinearTable,    // any scale, f32, CPU or WGSL arithmetic
     BilinearX2Int,    // exact x2, CPU arithmetic done in packed-u8 integer ops
     BilinearR32,      // exact x3/2, CPU form: one input pair per lane, three outputs, row pairs
@@ -90,6 +91,7 @@ const char *variant_name(Variant v);
 
 hipError_t launch_nearest_table(const UpscaleLaunch &L, const DeviceTables &T);
 hipError_t launch_nearest_x2(const UpscaleLaunch &L);
+hipError_t launch_nearest_r32(const UpscaleLaunch &L); // exact x3/2 (host-checked table shape: source index 2 (o / 3) + (o % 3 == 2))
 hipError_t launch_bilinear_table(const UpscaleLaunch &L, const DeviceTables &T, bool wgsl_form);
 hipError_t launch_bilinear_x2_int(const UpscaleLaunch &L);
 // exact x3/2, CPU form (host-checked table shape: i0 = 2 (o / 3) + (o % 3 == 2), fraction 0 at o % 3 == 0)

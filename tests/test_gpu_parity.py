@@ -101,6 +101,12 @@ def test_bilinear_three_halves_kernel(nsc, oracle_mod, size):
     ub.set_input_format("bgra")
     ub.initialize(w, h, ow, oh)
     assert np.array_equal(np.frombuffer(ub.upscale(_bgra(img).tobytes()), np.uint8).reshape(oh, ow, 4), want)
+    # nearest neighbour at the same factor: an input pair per lane copied into three outputs, a row pair into three rows
+    want_n = oracle_mod.nearest(img, ow, oh)
+    out_n, un = _up(nsc, "nearest", img, ow, oh)
+    assert un.kernel_variant == "nearest_r32" and np.array_equal(out_n, want_n)
+    out_ng, ung = _up(nsc, "nearest", img, ow, oh, options={"force_general": 1})
+    assert ung.kernel_variant == "nearest_table" and np.array_equal(out_ng, want_n)
 
 
 @pytest.mark.parametrize("size", [(64, 36), (320, 240), (252, 20), (256, 33), (16, 1), (500, 7), (1000, 50), (248, 40), (496, 9),
