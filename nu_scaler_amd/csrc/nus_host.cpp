@@ -302,19 +302,33 @@ void HipUpscaler::choose_resize_variant(bool x2)
     resize_union_taps_ = widest_union(2);
 }
 
+// One of the small rational factors P/Q the fixed-ratio nearest / bilinear kernels are built for, with tables of exactly the
+// shape they assume on both axes: source index Q (o / P) + (o % P) Q / P and, for bilinear, fraction 0 where the phase lands
+// on a pixel ((o % P) Q % P == 0).
+bool HipUpscaler::ratio_shape(bool bilinear) const
+{
+    static const uint32_t kRatios[][2] = {{3, 2}, {4, 3}, {3, 1}, {4, 1}};
+    for (const auto &r : kRatios) {
+        const uint32_t P = r[0], Q = r[1];
+        if ((uint64_t)ow_ * Q != (uint64_t)iw_ * P || (uint64_t)oh_ * Q != (uint64_t)ih_ * P || iw_ % Q != 0 || ih_ % Q != 0) continue;
+        bool ok = true;
+        for (const AxisTables *t : {&tx_, &ty_})
+            for (uint32_t o = 0; ok && o < t->out_n; ++o) {
+                const uint32_t want = Q * (o / P) + (o % P) * Q / P;
+                ok = bilinear ? (t->bl_i0[o] == want && (((o % P) * Q) % P != 0 || t->bl_frac[o] == 0.0f)) : t->nn_src[o] == want;
+            }
+        return ok;
+    }
+    return false;
+}
+
 void HipUpscaler::choose_variant()
 {
     const bool x2 = ow_ == 2 * iw_ && oh_ == 2 * ih_ && (iw_ % 4) == 0 && !force_general_;
     switch (algorithm_) {
     case Algorithm::Nearest:
         variant_ = x2 ? Variant::NearestX2 : Variant::NearestTable;
-        if (!x2 && !force_general_ && 2 * (uint64_t)ow_ == 3 * (uint64_t)iw_ && 2 * (uint64_t)oh_ == 3 * (uint64_t)ih_ && (iw_ & 1) == 0 &&
-            (ih_ & 1) == 0) {
-            bool r32 = true; // source index 2 (o / 3) + (o % 3 == 2) on both axes
-            for (const AxisTables *t : {&tx_, &ty_})
-                for (uint32_t o = 0; r32 && o < t->out_n; ++o) r32 = t->nn_src[o] == 2 * (o / 3) + (o % 3 == 2 ? 1u : 0u);
-            if (r32) variant_ = Variant::NearestR32;
-        }
+        if (!x2 && !force_general_ && ratio_shape(false)) variant_ = Variant::NearestRatio;
         break;
     case Algorithm::Bilinear: {
         // The packed-integer x2 kernel is valid iff the CPU-form tables are exactly
@@ -328,13 +342,7 @@ void HipUpscaler::choose_variant()
             }
         }
         variant_ = ok ? Variant::BilinearX2Int : Variant::BilinearTable;
-        // x3/2, CPU form: i0 = 2 (o / 3) + (o % 3 == 2) and fraction 0 at o % 3 == 0 on both axes
-        bool r32 = !ok && !wgsl_bilinear_ && !force_general_ && 2 * (uint64_t)ow_ == 3 * (uint64_t)iw_ &&
-                   2 * (uint64_t)oh_ == 3 * (uint64_t)ih_ && (iw_ & 1) == 0 && (ih_ & 1) == 0;
-        for (const AxisTables *t : {&tx_, &ty_})
-            for (uint32_t o = 0; r32 && o < t->out_n; ++o)
-                r32 = t->bl_i0[o] == 2 * (o / 3) + (o % 3 == 2 ? 1u : 0u) && (o % 3 != 0 || t->bl_frac[o] == 0.0f);
-        if (r32) variant_ = Variant::BilinearR32;
+        if (!ok && !wgsl_bilinear_ && !force_general_ && ratio_shape(true)) variant_ = Variant::BilinearRatio;
         break;
     }
     case Algorithm::Lanczos3:
@@ -511,10 +519,10 @@ int HipUpscaler::enqueue(const uint8_t *d_in, uint8_t *d_out, uint32_t n_frames,
     switch (variant_) {
     case Variant::NearestTable: e = launch_nearest_table(L, dt_); break;
     case Variant::NearestX2: e = launch_nearest_x2(L); break;
-    case Variant::NearestR32: e = launch_nearest_r32(L); break;
+    case Variant::NearestRatio: e = launch_nearest_ratio(L); break;
     case Variant::BilinearTable: e = launch_bilinear_table(L, dt_, wgsl_bilinear_); break;
     case Variant::BilinearX2Int: e = launch_bilinear_x2_int(L); break;
-    case Variant::BilinearR32: e = launch_bilinear_r32(L, dt_); break;
+    case Variant::BilinearRatio: e = launch_bilinear_ratio(L, dt_); break;
     case Variant::LanczosGeneral: e = launch_lanczos_general(L, dt_, lanczos_exact_, 0); break;
     case Variant::ResizeWin:
         e = launch_resize_win(L, dt_, lanczos_exact_, resize_ncols_max_, resize_union_taps_, win_outputs_per_lane_);

@@ -131,6 +131,7 @@ private:
     bool is_resize() const { return algorithm_ == Algorithm::Lanczos3 || algorithm_ == Algorithm::Bicubic || algorithm_ == Algorithm::Triangle; }
     ResizeFilter resize_filter() const;
     void choose_variant();
+    bool ratio_shape(bool bilinear) const; // tables have the shape of the fixed-ratio nearest / bilinear kernels
     void choose_resize_variant(bool x2);
     uint32_t widest_footprint(uint32_t segw) const;
     uint32_t widest_union(uint32_t n) const;

@@ -244,97 +244,139 @@ __global__ __launch_bounds__(256) void k_bilinear_x2_int(
 
 } // namespace
 
-// Nearest neighbour at exactly 3/2 on both axes (the reference benchmark's default scale; the algorithm every technology
-// but Wgpu falls back to, upscale/mod.rs:102-115): source index (3g + p) * iw / ow = 2g + {0, 0, 1} (host-checked on the
-// tables), so a lane copies its input pair into three outputs -- 8 bytes in, 12 contiguous bytes out -- and a row pair into
-// three rows.
-__global__ __launch_bounds__(256) void k_nearest_r32(const uint32_t *__restrict__ in, uint32_t *__restrict__ out, uint32_t iw,
-                                                     uint32_t ih, uint32_t ow, size_t in_frame_px, size_t out_frame_px, uint32_t sel)
+// ---- Nearest and bilinear (CPU form) at the small rational factors P/Q (3/2, 4/3, 3, 4) ---------------------------
+// Output o = P g + p samples the input group g = (Q g .. Q g + Q - 1): source index Q g + p Q / P (integer division) --
+// host-checked on the tables for every output.  3/2 is the factor the reference's benchmark entry points default to
+// (nu_scaler_py/nu_scaler/benchmark.py:63); nearest is what every technology but Wgpu falls back to
+// (upscale/mod.rs:102-115), bilinear what its AMD path does (gpu/detector.rs:181-190).
+// A lane owns one group of columns: Q pixels in (plus the next one for the bilinear pairs, clamped at the row's end as the
+// CPU clamps x1), P pixels = 4 P contiguous bytes out; rows likewise in groups of Q, P output rows each.
+template <int P, int Q>
+struct RatioPx {
+    uint32_t px[Q + 1];
+};
+
+template <int P, int Q>
+__device__ __forceinline__ RatioPx<P, Q> ratio_fetch(const uint32_t *row, uint32_t g, uint32_t iw)
 {
-    const uint32_t g = blockIdx.x * kWave + threadIdx.x;                                   // input column pair
-    const uint32_t m = __builtin_amdgcn_readfirstlane(blockIdx.y * 4 + threadIdx.y);      // input row pair
-    if (2 * g >= iw || 2 * m >= ih) return;
-    const uint32_t *src = in + (size_t)blockIdx.z * in_frame_px + (size_t)(2 * m) * iw + 2 * g;
-    uint32_t *d = out + (size_t)blockIdx.z * out_frame_px + (size_t)(3 * m) * ow + 3 * g;
-    const uint2 r0 = *reinterpret_cast<const uint2 *>(src), r1 = *reinterpret_cast<const uint2 *>(src + iw);
-    const uint32_t a0 = swz(r0.x, sel), b0 = swz(r0.y, sel), a1 = swz(r1.x, sel), b1 = swz(r1.y, sel);
-    d[0] = a0, d[1] = a0, d[2] = b0;
-    d[ow] = a0, d[ow + 1] = a0, d[ow + 2] = b0;
-    d[2 * (size_t)ow] = a1, d[2 * (size_t)ow + 1] = a1, d[2 * (size_t)ow + 2] = b1;
+    RatioPx<P, Q> t;
+    const uint32_t *p = row + Q * g;
+    if constexpr (Q == 2) {
+        const uint2 v = *reinterpret_cast<const uint2 *>(p);
+        t.px[0] = v.x, t.px[1] = v.y;
+    } else {
+#pragma unroll
+        for (int k = 0; k < Q; ++k) t.px[k] = p[k];
+    }
+    t.px[Q] = row[umin(Q * g + Q, iw - 1)];
+    return t;
 }
 
-// Bilinear, CPU form, at exactly 3/2 on both axes -- the factor the reference's benchmark entry points default to
-// (nu_scaler_py/nu_scaler/benchmark.py:63) with the algorithm its AMD path falls back to (gpu/detector.rs:181-190).
-// Output 3 g + p samples the input pair g: x0 = 2g, 2g, 2g+1 with fractions 0, ~2/3, ~1/3 (host-checked: the tables'
-// indices have exactly this shape and phase 0's fraction is 0, so its lerp p00 * 1 + p10 * 0 is p00 itself; the other
-// fractions are rounded in f32 and come per lane / per row from the tables).  A lane owns one input pair: 8 + 4 bytes
-// in (its two pixels and the next one, clamped at the row's end as the CPU clamps x1), 3 output pixels = 12 contiguous
-// bytes out; rows likewise in pairs, three output rows each, the horizontally lerped rows kept in registers.  Same
-// expressions as k_bilinear_table (common.rs:221-227), about 0.6 of its instructions per pixel.
-__global__ __launch_bounds__(256) void k_bilinear_r32(
-    const uint32_t *__restrict__ in, uint32_t *__restrict__ out, const float *__restrict__ fxt, const float *__restrict__ fyt,
-    uint32_t iw, uint32_t ih, uint32_t ow, uint32_t pairs_per_wave, size_t in_frame_px, size_t out_frame_px, uint32_t sel)
+template <int P>
+__device__ __forceinline__ void ratio_store(uint32_t *d, const uint32_t (&o)[P])
 {
-    const uint32_t g = blockIdx.x * kWave + threadIdx.x; // this lane's input column pair
+    if constexpr (P == 4) {
+        *reinterpret_cast<uint4 *>(d) = make_uint4(o[0], o[1], o[2], o[3]);
+    } else {
+#pragma unroll
+        for (int k = 0; k < P; ++k) d[k] = o[k]; // (merged into one global_store_dwordx3)
+    }
+}
+
+template <int P, int Q>
+__global__ __launch_bounds__(256) void k_nearest_ratio(const uint32_t *__restrict__ in, uint32_t *__restrict__ out, uint32_t iw,
+                                                       uint32_t ih, uint32_t ow, size_t in_frame_px, size_t out_frame_px, uint32_t sel)
+{
+    const uint32_t g = blockIdx.x * kWave + threadIdx.x;                              // input column group
+    const uint32_t m = __builtin_amdgcn_readfirstlane(blockIdx.y * 4 + threadIdx.y); // input row group
+    if (Q * g >= iw || Q * m >= ih) return;
+    const uint32_t *src = in + (size_t)blockIdx.z * in_frame_px + (size_t)(Q * m) * iw;
+    uint32_t *d = out + (size_t)blockIdx.z * out_frame_px + (size_t)(P * m) * ow + P * g;
+    uint32_t o[Q][P];
+#pragma unroll
+    for (int r = 0; r < Q; ++r) {
+        const RatioPx<P, Q> t = ratio_fetch<P, Q>(src + (size_t)r * iw, g, iw);
+#pragma unroll
+        for (int p = 0; p < P; ++p) o[r][p] = swz(t.px[p * Q / P], sel);
+    }
+#pragma unroll
+    for (int p = 0; p < P; ++p) ratio_store<P>(d + (size_t)p * ow, o[p * Q / P]);
+}
+
+// Bilinear: the fractions of the phases that do not land on a pixel are rounded in f32 and come per lane / per row from
+// the tables; a phase with p Q % P == 0 lands on a pixel, its fraction is 0 (host-checked) and its lerp
+// p00 * 1 + p10 * 0 is p00 itself.  The horizontally lerped rows of a row group stay in registers.  Same expressions as
+// k_bilinear_table (common.rs:221-227) otherwise; at 3/2 about 0.6 of its instructions per pixel.
+template <int P, int Q>
+__global__ __launch_bounds__(256) void k_bilinear_ratio(
+    const uint32_t *__restrict__ in, uint32_t *__restrict__ out, const float *__restrict__ fxt, const float *__restrict__ fyt,
+    uint32_t iw, uint32_t ih, uint32_t ow, uint32_t groups_per_wave, size_t in_frame_px, size_t out_frame_px, uint32_t sel)
+{
+    const uint32_t g = blockIdx.x * kWave + threadIdx.x; // this lane's input column group
     const uint32_t rb = __builtin_amdgcn_readfirstlane(blockIdx.y * 4 + threadIdx.y);
-    const uint32_t m_begin = rb * pairs_per_wave, m_end = umin(m_begin + pairs_per_wave, ih / 2);
-    if (m_begin >= m_end || 2 * g >= iw) return;
+    const uint32_t m_begin = rb * groups_per_wave, m_end = umin(m_begin + groups_per_wave, ih / Q);
+    if (m_begin >= m_end || Q * g >= iw) return;
     const uint32_t *base = in + (size_t)blockIdx.z * in_frame_px;
-    uint32_t *dst = out + (size_t)blockIdx.z * out_frame_px + 3 * g;
-    const float dx1 = fxt[3 * g + 1], dx2 = fxt[3 * g + 2], ndx1 = 1.0f - dx1, ndx2 = 1.0f - dx2;
-    const uint32_t c2 = umin(2 * g + 2, iw - 1);
-    struct Raw {
-        uint2 ab;
-        uint32_t c;
-    };
-    auto fetch = [&](uint32_t r) {
-        const uint32_t *row = base + (size_t)umin(r, ih - 1) * iw;
-        return Raw{*reinterpret_cast<const uint2 *>(row + 2 * g), row[c2]};
-    };
-    // the lane's three horizontally lerped values of one source row: h[4 p + c]
-    auto hrow = [&](const Raw &t, float (&h)[12]) {
-        const uint32_t pa = swz(t.ab.x, sel), pb = swz(t.ab.y, sel), pc = swz(t.c, sel);
+    uint32_t *dst = out + (size_t)blockIdx.z * out_frame_px + P * g;
+    float dx[P], ndx[P];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const float a = ch_f32(pa, c), b = ch_f32(pb, c), d = ch_f32(pc, c);
-            h[c] = a;                        // a * (1 - 0) + b * 0
-            h[4 + c] = a * ndx1 + b * dx1;   // top = p00 * (1 - dx) + p10 * dx
-            h[8 + c] = b * ndx2 + d * dx2;
+    for (int p = 0; p < P; ++p) dx[p] = fxt[P * g + p], ndx[p] = 1.0f - dx[p];
+    auto fetch = [&](uint32_t r) { return ratio_fetch<P, Q>(base + (size_t)umin(r, ih - 1) * iw, g, iw); };
+    // the lane's P horizontally lerped values of one source row: h[4 p + c]
+    auto hrow = [&](const RatioPx<P, Q> &t, float (&h)[4 * P]) {
+        float f[Q + 1][4];
+#pragma unroll
+        for (int k = 0; k <= Q; ++k) {
+            const uint32_t px = swz(t.px[k], sel);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) f[k][c] = ch_f32(px, c);
         }
-    };
-    auto emit = [&](uint32_t y, const float (&v)[12]) {
-        uint32_t o[3];
 #pragma unroll
-        for (int p = 0; p < 3; ++p) {
+        for (int p = 0; p < P; ++p)
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                h[4 * p + c] = (p * Q % P == 0) ? f[p * Q / P][c]                                         // a * (1 - 0) + b * 0
+                                                : f[p * Q / P][c] * ndx[p] + f[p * Q / P + 1][c] * dx[p]; // top = p00 * (1 - dx) + p10 * dx
+    };
+    auto emit = [&](uint32_t y, const float (&v)[4 * P]) {
+        uint32_t o[P];
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
             uint32_t px = 0;
 #pragma unroll
             for (int c = 0; c < 4; ++c) px = pack_trunc_u8(v[4 * p + c], c, px); // clamp(0, 255) as u8
             o[p] = px;
         }
-        uint32_t *d = dst + (size_t)y * ow;
-        d[0] = o[0], d[1] = o[1], d[2] = o[2];
+        ratio_store<P>(dst + (size_t)y * ow, o);
     };
-    float ha[12], hb[12], hc[12]; // source rows 2m, 2m+1, 2m+2
-    hrow(fetch(2 * m_begin), ha);
-    Raw nb = fetch(2 * m_begin + 1), nc = fetch(2 * m_begin + 2);
+    float h[Q + 1][4 * P]; // source rows Q m .. Q m + Q
+    hrow(fetch(Q * m_begin), h[0]);
+    RatioPx<P, Q> nxt[Q];
+#pragma unroll
+    for (int k = 0; k < Q; ++k) nxt[k] = fetch(Q * m_begin + 1 + k);
     for (uint32_t m = m_begin; m < m_end; ++m) {
-        hrow(nb, hb);
-        hrow(nc, hc);
-        if (m + 1 < m_end) nb = fetch(2 * m + 3), nc = fetch(2 * m + 4); // the next pair's rows: in flight during this one
-        float dy1 = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(fyt[3 * m + 1])));
-        float dy2 = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(fyt[3 * m + 2])));
-        asm volatile("" : "+v"(dy1), "+v"(dy2)); // VGPR copies: scalar operands halve the VALU issue rate
-        const float ndy1 = 1.0f - dy1, ndy2 = 1.0f - dy2;
-        emit(3 * m, ha); // top * (1 - 0) + bottom * 0
-        float v[12];
 #pragma unroll
-        for (int k = 0; k < 12; ++k) v[k] = ha[k] * ndy1 + hb[k] * dy1;
-        emit(3 * m + 1, v);
+        for (int k = 0; k < Q; ++k) hrow(nxt[k], h[1 + k]);
+        if (m + 1 < m_end) { // the next group's rows: in flight during this one
 #pragma unroll
-        for (int k = 0; k < 12; ++k) v[k] = hb[k] * ndy2 + hc[k] * dy2;
-        emit(3 * m + 2, v);
+            for (int k = 0; k < Q; ++k) nxt[k] = fetch(Q * (m + 1) + 1 + k);
+        }
 #pragma unroll
-        for (int k = 0; k < 12; ++k) ha[k] = hc[k];
+        for (int p = 0; p < P; ++p) {
+            if (p * Q % P == 0) {
+                emit(P * m + p, h[p * Q / P]); // top * (1 - 0) + bottom * 0
+            } else {
+                float dy = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(fyt[P * m + p])));
+                asm volatile("" : "+v"(dy)); // VGPR copy: scalar operands halve the VALU issue rate
+                const float ndy = 1.0f - dy;
+                float v[4 * P];
+#pragma unroll
+                for (int k = 0; k < 4 * P; ++k) v[k] = h[p * Q / P][k] * ndy + h[p * Q / P + 1][k] * dy;
+                emit(P * m + p, v);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 4 * P; ++k) h[0][k] = h[Q][k];
     }
 }
 
@@ -342,10 +384,10 @@ const char *variant_name(Variant v){
     switch (v) {
     case Variant::NearestTable: return "nearest_table";
     case Variant::NearestX2: return "nearest_x2_vec16";
-    case Variant::NearestR32: return "nearest_r32";
+    case Variant::NearestRatio: return "nearest_ratio";
     case Variant::BilinearTable: return "bilinear_table_f32";
     case Variant::BilinearX2Int: return "bilinear_x2_packed_u8";
-    case Variant::BilinearR32: return "bilinear_r32_f32";
+    case Variant::BilinearRatio: return "bilinear_ratio_f32";
     case Variant::LanczosGeneral: return "lanczos3_general";
     case Variant::ResizeRows: return "resize_rows_lds";
     case Variant::ResizeWin: return "resize_regwin_lds";
@@ -388,14 +430,37 @@ hipError_t launch_nearest_table(const UpscaleLaunch &L, const DeviceTables &T)
     });
 }
 
-hipError_t launch_nearest_r32(const UpscaleLaunch &L)
+// (P, Q) of the fixed-ratio nearest / bilinear kernels for this launch, or false
+static bool ratio_of(const UpscaleLaunch &L, uint32_t &P, uint32_t &Q)
 {
-    if (2 * (uint64_t)L.ow != 3 * (uint64_t)L.iw || 2 * (uint64_t)L.oh != 3 * (uint64_t)L.ih || (L.iw & 1) || (L.ih & 1)) return hipErrorInvalidValue;
+    static const uint32_t kRatios[][2] = {{3, 2}, {4, 3}, {3, 1}, {4, 1}};
+    for (const auto &r : kRatios)
+        if ((uint64_t)L.ow * r[1] == (uint64_t)L.iw * r[0] && (uint64_t)L.oh * r[1] == (uint64_t)L.ih * r[0] && L.iw % r[1] == 0 &&
+            L.ih % r[1] == 0) {
+            P = r[0], Q = r[1];
+            return true;
+        }
+    return false;
+}
+
+#define NUS_RATIO_DISPATCH(CALL)                 \
+    if (P == 3 && Q == 2) { CALL(3, 2); }        \
+    else if (P == 4 && Q == 3) { CALL(4, 3); }   \
+    else if (P == 3 && Q == 1) { CALL(3, 1); }   \
+    else { CALL(4, 1); }
+
+hipError_t launch_nearest_ratio(const UpscaleLaunch &L)
+{
+    uint32_t P = 0, Q = 0;
+    if (!ratio_of(L, P, Q)) return hipErrorInvalidValue;
     const size_t ipx = (size_t)L.iw * L.ih, opx = (size_t)L.ow * L.oh;
     return for_frame_chunks(L, [&](const uint8_t *in, uint8_t *out, uint32_t n) {
-        const dim3 block(kWave, 4), grid(cdiv(L.iw / 2, kWave), cdiv(L.ih / 2, 4), n);
-        hipLaunchKernelGGL(k_nearest_r32, grid, block, 0, L.stream, reinterpret_cast<const uint32_t *>(in),
-                           reinterpret_cast<uint32_t *>(out), L.iw, L.ih, L.ow, ipx, opx, L.in_sel);
+        const dim3 block(kWave, 4), grid(cdiv(L.iw / Q, kWave), cdiv(L.ih / Q, 4), n);
+#define NUS_NR(PP, QQ)                                                                                                          \
+    hipLaunchKernelGGL((k_nearest_ratio<PP, QQ>), grid, block, 0, L.stream, reinterpret_cast<const uint32_t *>(in),             \
+                       reinterpret_cast<uint32_t *>(out), L.iw, L.ih, L.ow, ipx, opx, L.in_sel)
+        NUS_RATIO_DISPATCH(NUS_NR)
+#undef NUS_NR
     });
 }
 
@@ -429,17 +494,21 @@ hipError_t launch_bilinear_table(const UpscaleLaunch &L, const DeviceTables &T, 
     });
 }
 
-hipError_t launch_bilinear_r32(const UpscaleLaunch &L, const DeviceTables &T)
+hipError_t launch_bilinear_ratio(const UpscaleLaunch &L, const DeviceTables &T)
 {
-    if (2 * (uint64_t)L.ow != 3 * (uint64_t)L.iw || 2 * (uint64_t)L.oh != 3 * (uint64_t)L.ih || (L.iw & 1) || (L.ih & 1)) return hipErrorInvalidValue;
+    uint32_t P = 0, Q = 0;
+    if (!ratio_of(L, P, Q)) return hipErrorInvalidValue;
     const size_t ipx = (size_t)L.iw * L.ih, opx = (size_t)L.ow * L.oh;
     return for_frame_chunks(L, [&](const uint8_t *in, uint8_t *out, uint32_t n) {
-        const uint32_t strips = cdiv(L.iw / 2, kWave);
-        uint64_t ppw = (uint64_t)(L.ih / 2) * strips * n / 8192; // row pairs per wave: a few thousand waves per launch
-        ppw = ppw < 4 ? 4 : (ppw > 32 ? 32 : ppw);
-        const dim3 block(kWave, 4), grid(strips, cdiv(cdiv(L.ih / 2, (uint32_t)ppw), 4), n);
-        hipLaunchKernelGGL(k_bilinear_r32, grid, block, 0, L.stream, reinterpret_cast<const uint32_t *>(in),
-                           reinterpret_cast<uint32_t *>(out), T.bl_fx, T.bl_fy, L.iw, L.ih, L.ow, (uint32_t)ppw, ipx, opx, L.in_sel);
+        const uint32_t strips = cdiv(L.iw / Q, kWave);
+        uint64_t gpw = (uint64_t)(L.ih / Q) * strips * n / 8192; // row groups per wave: a few thousand waves per launch
+        gpw = gpw < 4 ? 4 : (gpw > 32 ? 32 : gpw);
+        const dim3 block(kWave, 4), grid(strips, cdiv(cdiv(L.ih / Q, (uint32_t)gpw), 4), n);
+#define NUS_BR(PP, QQ)                                                                                                          \
+    hipLaunchKernelGGL((k_bilinear_ratio<PP, QQ>), grid, block, 0, L.stream, reinterpret_cast<const uint32_t *>(in),            \
+                       reinterpret_cast<uint32_t *>(out), T.bl_fx, T.bl_fy, L.iw, L.ih, L.ow, (uint32_t)gpw, ipx, opx, L.in_sel)
+        NUS_RATIO_DISPATCH(NUS_BR)
+#undef NUS_BR
     });
 }
 

@@ -70,10 +70,10 @@ struct UpscaleLaunch {
 enum class Variant : int {
     NearestTable = 0, // any scale, index tables
     NearestX2,        // exact x2, 16-B loads/stores
-    NearestR32,       // exact x3/2: an input pair per lane copied into three outputs, a row pair into three rows
+    NearestRatio,     // exact x3/2, x4/3, x3, x4: an input group per lane copied into P outputs, a row group into P rows
     BilinearTable,    // any scale, f32, CPU or WGSL arithmetic
     BilinearX2Int,    // exact x2, CPU arithmetic done in packed-u8 integer ops
-    BilinearR32,      // exact x3/2, CPU form: one input pair per lane, three outputs, row pairs
+    BilinearRatio,    // exact x3/2, x4/3, x3, x4, CPU form: one input group per lane, P outputs, row groups
     LanczosGeneral,   // any scale, direct separable evaluation per output pixel (fallback)
     ResizeRows,       // any scale, separable: V pass into an LDS row, H pass out of it
     ResizeWin,        // up-scaling: V pass from a register row window (as the x2 kernel), H pass through the LDS row
@@ -91,11 +91,11 @@ const char *variant_name(Variant v);
 
 hipError_t launch_nearest_table(const UpscaleLaunch &L, const DeviceTables &T);
 hipError_t launch_nearest_x2(const UpscaleLaunch &L);
-hipError_t launch_nearest_r32(const UpscaleLaunch &L); // exact x3/2 (host-checked table shape: source index 2 (o / 3) + (o % 3 == 2))
+hipError_t launch_nearest_ratio(const UpscaleLaunch &L); // exact x3/2, x4/3, x3, x4 (host-checked table shape: source index Q (o / P) + (o % P) Q / P)
 hipError_t launch_bilinear_table(const UpscaleLaunch &L, const DeviceTables &T, bool wgsl_form);
 hipError_t launch_bilinear_x2_int(const UpscaleLaunch &L);
-// exact x3/2, CPU form (host-checked table shape: i0 = 2 (o / 3) + (o % 3 == 2), fraction 0 at o % 3 == 0)
-hipError_t launch_bilinear_r32(const UpscaleLaunch &L, const DeviceTables &T);
+// exact x3/2, x4/3, x3, x4, CPU form (host-checked table shape: i0 = Q (o / P) + (o % P) Q / P, fraction 0 where (o % P) Q % P == 0)
+hipError_t launch_bilinear_ratio(const UpscaleLaunch &L, const DeviceTables &T);
 // edge_only: evaluate only the first and last `edge_cols` output columns.
 hipError_t launch_lanczos_general(const UpscaleLaunch &L, const DeviceTables &T, bool exact,
                                   uint32_t edge_cols);

@@ -81,17 +81,21 @@ def test_bilinear_general_bit_exact(nsc, oracle_mod, dims):
     assert np.array_equal(out_w, oracle_mod.bilinear_wgsl(img, ow, oh))
 
 
-@pytest.mark.parametrize("size", [(2, 2), (4, 6), (64, 36), (66, 38), (126, 20), (128, 22), (130, 24), (500, 40), (1280, 720)])
-def test_bilinear_three_halves_kernel(nsc, oracle_mod, size):
-    """x3/2 in the CPU form -- the scale the reference's benchmark entry points default to -- has its own kernel (one input
-    pair per lane, three outputs; row pairs): bit-exact against the oracle and the table-driven kernel; the WGSL form keeps
-    the table kernel."""
-    w, h = size
-    ow, oh = 3 * w // 2, 3 * h // 2
+@pytest.mark.parametrize("ratio", [(3, 2), (4, 3), (3, 1), (4, 1)])
+@pytest.mark.parametrize("groups", [(1, 1), (2, 3), (32, 18), (33, 19), (63, 10), (64, 11), (65, 12), (250, 20), (640, 360)])
+def test_nearest_and_bilinear_fixed_ratio_kernels(nsc, oracle_mod, ratio, groups):
+    """The small rational factors (x3/2 -- the scale the reference's benchmark entry points default to --, x4/3, x3, x4) have
+    their own nearest and CPU-form bilinear kernels (one input group per lane, P outputs; row groups): bit-exact against the
+    oracle and the table-driven kernels; the WGSL form keeps the table kernel."""
+    P, Q = ratio
+    w, h = Q * groups[0], Q * groups[1]
+    if (P, Q) == (4, 1) and w * h > 100000:
+        pytest.skip("covered by the smaller sizes")
+    ow, oh = P * groups[0], P * groups[1]
     img = oracle_mod.gen_noise(w, h, 18)
     want = oracle_mod.bilinear(img, ow, oh)
     out, u = _up(nsc, "bilinear", img, ow, oh)
-    assert u.kernel_variant == "bilinear_r32_f32"
+    assert u.kernel_variant == "bilinear_ratio_f32"
     assert np.array_equal(out, want)
     out_g, ug = _up(nsc, "bilinear", img, ow, oh, options={"force_general": 1})
     assert ug.kernel_variant == "bilinear_table_f32" and np.array_equal(out_g, want)
@@ -101,10 +105,9 @@ def test_bilinear_three_halves_kernel(nsc, oracle_mod, size):
     ub.set_input_format("bgra")
     ub.initialize(w, h, ow, oh)
     assert np.array_equal(np.frombuffer(ub.upscale(_bgra(img).tobytes()), np.uint8).reshape(oh, ow, 4), want)
-    # nearest neighbour at the same factor: an input pair per lane copied into three outputs, a row pair into three rows
     want_n = oracle_mod.nearest(img, ow, oh)
     out_n, un = _up(nsc, "nearest", img, ow, oh)
-    assert un.kernel_variant == "nearest_r32" and np.array_equal(out_n, want_n)
+    assert un.kernel_variant == "nearest_ratio" and np.array_equal(out_n, want_n)
     out_ng, ung = _up(nsc, "nearest", img, ow, oh, options={"force_general": 1})
     assert ung.kernel_variant == "nearest_table" and np.array_equal(out_ng, want_n)
 
