@@ -244,7 +244,8 @@ __global__ __launch_bounds__(256) void k_bilinear_x2_int(
 
 } // namespace
 
-// ---- Nearest and bilinear (CPU form) at the small rational factors P/Q (3/2, 4/3, 3, 4) ---------------------------
+// ---- Nearest and bilinear (CPU form) at the small rational factors P/Q (3/2, 4/3, 3, 4; 2 where the x2 kernels' --------
+// ---- width % 4 == 0 does not hold) ------------------------------------------------------------------------------------
 // Output o = P g + p samples the input group g = (Q g .. Q g + Q - 1): source index Q g + p Q / P (integer division) --
 // host-checked on the tables for every output.  3/2 is the factor the reference's benchmark entry points default to
 // (nu_scaler_py/nu_scaler/benchmark.py:63); nearest is what every technology but Wgpu falls back to
@@ -433,7 +434,7 @@ hipError_t launch_nearest_table(const UpscaleLaunch &L, const DeviceTables &T)
 // (P, Q) of the fixed-ratio nearest / bilinear kernels for this launch, or false
 static bool ratio_of(const UpscaleLaunch &L, uint32_t &P, uint32_t &Q)
 {
-    static const uint32_t kRatios[][2] = {{3, 2}, {4, 3}, {3, 1}, {4, 1}};
+    static const uint32_t kRatios[][2] = {{3, 2}, {4, 3}, {3, 1}, {4, 1}, {2, 1}};
     for (const auto &r : kRatios)
         if ((uint64_t)L.ow * r[1] == (uint64_t)L.iw * r[0] && (uint64_t)L.oh * r[1] == (uint64_t)L.ih * r[0] && L.iw % r[1] == 0 &&
             L.ih % r[1] == 0) {
@@ -447,7 +448,8 @@ static bool ratio_of(const UpscaleLaunch &L, uint32_t &P, uint32_t &Q)
     if (P == 3 && Q == 2) { CALL(3, 2); }        \
     else if (P == 4 && Q == 3) { CALL(4, 3); }   \
     else if (P == 3 && Q == 1) { CALL(3, 1); }   \
-    else { CALL(4, 1); }
+    else if (P == 4 && Q == 1) { CALL(4, 1); }   \
+    else { CALL(2, 1); }
 
 hipError_t launch_nearest_ratio(const UpscaleLaunch &L)
 {

@@ -81,7 +81,7 @@ def test_bilinear_general_bit_exact(nsc, oracle_mod, dims):
     assert np.array_equal(out_w, oracle_mod.bilinear_wgsl(img, ow, oh))
 
 
-@pytest.mark.parametrize("ratio", [(3, 2), (4, 3), (3, 1), (4, 1)])
+@pytest.mark.parametrize("ratio", [(3, 2), (4, 3), (3, 1), (4, 1), (2, 1)])
 @pytest.mark.parametrize("groups", [(1, 1), (2, 3), (32, 18), (33, 19), (63, 10), (64, 11), (65, 12), (250, 20), (640, 360)])
 def test_nearest_and_bilinear_fixed_ratio_kernels(nsc, oracle_mod, ratio, groups):
     """The small rational factors (x3/2 -- the scale the reference's benchmark entry points default to --, x4/3, x3, x4) have
@@ -91,6 +91,10 @@ def test_nearest_and_bilinear_fixed_ratio_kernels(nsc, oracle_mod, ratio, groups
     w, h = Q * groups[0], Q * groups[1]
     if (P, Q) == (4, 1) and w * h > 100000:
         pytest.skip("covered by the smaller sizes")
+    if (P, Q) == (2, 1):
+        if w % 4 == 0:
+            pytest.skip("x2 at widths % 4 == 0 has its own kernels")
+        # (x2 at the other widths -- 1366x768 -- takes the fixed-ratio kernels)
     ow, oh = P * groups[0], P * groups[1]
     img = oracle_mod.gen_noise(w, h, 18)
     want = oracle_mod.bilinear(img, ow, oh)
