@@ -39,4 +39,17 @@ for kind in ("r32", "r43", "x3", "x4", "x2"):
         if not ok:
             bad += 1
             print("MISMATCH", kind, alg, w, h, th, u.kernel_variant)
+# nearest / bilinear (CPU form) on the fixed-ratio kernels: bit-exact
+for (P, Q) in ((3, 2), (4, 3), (3, 1), (4, 1), (2, 1)):
+    for _ in range(10):
+        gw = int(rng.integers(1, 400)); gh = int(rng.integers(1, 120))
+        w, h, ow, oh = Q * gw, Q * gh, P * gw, P * gh
+        img = orc.gen_noise(w, h, int(rng.integers(1, 1000)))
+        for alg, want in (("nearest", orc.nearest(img, ow, oh)), ("bilinear", orc.bilinear(img, ow, oh))):
+            u = nsc.PyWgpuUpscaler("quality", alg); u.initialize(w, h, ow, oh)
+            got = np.frombuffer(u.upscale(img.tobytes()), np.uint8).reshape(oh, ow, 4)
+            cases += 1
+            if not np.array_equal(got, want):
+                bad += 1
+                print("MISMATCH", alg, P, Q, w, h, u.kernel_variant)
 print(f"{cases} cases, {bad} mismatches")
