@@ -97,44 +97,57 @@ __device__ __forceinline__ float4 sample_trunc_pairs(__amdgpu_buffer_rsrc_t rs, 
 // PAIRS: the frames are at least 2 pixels wide and < 4 GiB (host-checked): buffer-resource sampling above.
 // HALF: the flow field is 2 x f16 per pixel -- the Rg16Float texture the reference's live path binds
 // (wgpu_interpolator.rs:276) -- widened to f32 on load (exact), then the same arithmetic: half the flow bytes.
+#ifndef NUS_WARP_ROWS
+#define NUS_WARP_ROWS 4 // pixels per thread (rows y, y + 4, y + 8, y + 12 of the block's 16): independent chains of flow load -> gathers -> blend, their loads in flight together
+#endif
 template <bool PAIRS, bool HALF>
 __global__ __launch_bounds__(256) void k_warp_blend_flow(
     const uint8_t *__restrict__ a, const uint8_t *__restrict__ b, const void *__restrict__ flow,
     uint8_t *__restrict__ out, size_t a_stride, size_t b_stride, uint32_t w, uint32_t h, float t, uint32_t sel)
 {
-    const uint32_t y = __builtin_amdgcn_readfirstlane(blockIdx.y * 4 + threadIdx.y);
+    constexpr int R = NUS_WARP_ROWS;
+    const uint32_t ybase = __builtin_amdgcn_readfirstlane(blockIdx.y * (4 * R) + threadIdx.y);
     const uint32_t x = blockIdx.x * kWave + threadIdx.x;
-    if (y >= h || x >= w) return;
+    if (ybase >= h || x >= w) return;
     const size_t npx = (size_t)w * h;
     const uint8_t *fa = a + (size_t)blockIdx.z * a_stride, *fb = b + (size_t)blockIdx.z * b_stride;
-    const size_t idx = (size_t)y * w + x;
-    float2 f;
-    if (HALF) {
-        const __half2 hf = reinterpret_cast<const __half2 *>(flow)[(size_t)blockIdx.z * npx + idx];
-        f = make_float2(__low2float(hf), __high2float(hf));
-    } else {
-        f = reinterpret_cast<const float2 *>(flow)[(size_t)blockIdx.z * npx + idx];
-    }
     float tv = t; // per-lane copy: scalar operands halve the VALU issue rate on gfx950
     asm volatile("" : "+v"(tv));
     const float nt = 1.0f - tv;
-    const float ax = (float)x - tv * f.x, ay = (float)y - tv * f.y;
-    const float bx = (float)x + nt * f.x, by = (float)y + nt * f.y;
-    float4 sa, sb;
-    if (PAIRS) {
-        const uint32_t frame_bytes = (uint32_t)(npx * 4);
-        sa = sample_trunc_pairs(__builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(fa), 0, frame_bytes, 0x00020000), w, h, ax, ay);
-        sb = sample_trunc_pairs(__builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(fb), 0, frame_bytes, 0x00020000), w, h, bx, by);
-    } else {
-        sa = sample_trunc(reinterpret_cast<const uint32_t *>(fa), w, h, ax, ay);
-        sb = sample_trunc(reinterpret_cast<const uint32_t *>(fb), w, h, bx, by);
+    float2 f[R];
+#pragma unroll
+    for (int k = 0; k < R; ++k) { // the flow vectors of all the thread's pixels first
+        const uint32_t y = umin(ybase + 4 * k, h - 1);
+        const size_t idx = (size_t)y * w + x;
+        if (HALF) {
+            const __half2 hf = reinterpret_cast<const __half2 *>(flow)[(size_t)blockIdx.z * npx + idx];
+            f[k] = make_float2(__low2float(hf), __high2float(hf));
+        } else {
+            f[k] = reinterpret_cast<const float2 *>(flow)[(size_t)blockIdx.z * npx + idx];
+        }
     }
-    uint32_t o = 0;
-    o = pack_trunc_u8(nt * sa.x + tv * sb.x, 0, o);
-    o = pack_trunc_u8(nt * sa.y + tv * sb.y, 1, o);
-    o = pack_trunc_u8(nt * sa.z + tv * sb.z, 2, o);
-    o = pack_trunc_u8(nt * sa.w + tv * sb.w, 3, o);
-    reinterpret_cast<uint32_t *>(out)[(size_t)blockIdx.z * npx + idx] = swz(o, sel);
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+        const uint32_t y = ybase + 4 * k;
+        if (y >= h) break; // wave-uniform
+        const float ax = (float)x - tv * f[k].x, ay = (float)y - tv * f[k].y;
+        const float bx = (float)x + nt * f[k].x, by = (float)y + nt * f[k].y;
+        float4 sa, sb;
+        if (PAIRS) {
+            const uint32_t frame_bytes = (uint32_t)(npx * 4);
+            sa = sample_trunc_pairs(__builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(fa), 0, frame_bytes, 0x00020000), w, h, ax, ay);
+            sb = sample_trunc_pairs(__builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(fb), 0, frame_bytes, 0x00020000), w, h, bx, by);
+        } else {
+            sa = sample_trunc(reinterpret_cast<const uint32_t *>(fa), w, h, ax, ay);
+            sb = sample_trunc(reinterpret_cast<const uint32_t *>(fb), w, h, bx, by);
+        }
+        uint32_t o = 0;
+        o = pack_trunc_u8(nt * sa.x + tv * sb.x, 0, o);
+        o = pack_trunc_u8(nt * sa.y + tv * sb.y, 1, o);
+        o = pack_trunc_u8(nt * sa.z + tv * sb.z, 2, o);
+        o = pack_trunc_u8(nt * sa.w + tv * sb.w, 3, o);
+        reinterpret_cast<uint32_t *>(out)[(size_t)blockIdx.z * npx + (size_t)y * w + x] = swz(o, sel);
+    }
 }
 
 // ---------------------------------------------------------------------------------
@@ -191,7 +204,7 @@ hipError_t launch_warp_blend(const WarpLaunch &L)
             else
                 hipLaunchKernelGGL(k_blend_zero_flow<false>, grid, block, 0, L.stream, a, b, out, L.a_stride, L.b_stride, npx, L.t, L.in_sel);
         } else {
-            const dim3 block(kWave, 4), grid(cdiv(L.w, 64), cdiv(L.h, 4), n);
+            const dim3 block(kWave, 4), grid(cdiv(L.w, 64), cdiv(L.h, 4 * NUS_WARP_ROWS), n);
             const bool pairs = L.w >= 2 && npx * 4 < (1ull << 32);
             const void *fl = reinterpret_cast<const uint8_t *>(L.flow) + (size_t)done * npx * (L.flow_half ? 4 : 8);
 #define NUS_WB(P, H) hipLaunchKernelGGL((k_warp_blend_flow<P, H>), grid, block, 0, L.stream, a, b, fl, out, L.a_stride, L.b_stride, L.w, L.h, L.t, L.in_sel)
