@@ -60,6 +60,21 @@ __device__ __forceinline__ float mac(float acc, float v, float w)
     return __builtin_fmaf(v, w, acc); // one rounding
 }
 
+// The same, with the EXACT product consumed where it is formed: left to itself the compiler batches the products of a tap
+// loop ahead of the additions (k_lanczos3_x2 EXACT: 310 VGPRs, one wave per SIMD; with this 234, two waves, 29.9 -> 23.0 us per
+// 1080p -> 4K frame; x3/2 36.6 -> 27.5).  Not for the x3 / x4 kernel, which is faster with the batches (profiles/
+// r02_lanczos_exact_mode_products.txt).
+template <bool EXACT>
+__device__ __forceinline__ float mac_tight(float acc, float v, float w)
+{
+    if (EXACT) {
+        float p = v * w;
+        asm volatile("" : "+v"(p));
+        return acc + p;
+    }
+    return __builtin_fmaf(v, w, acc);
+}
+
 // Insert round(clamp(v)) as byte c of acc.
 template <bool EXACT>
 __device__ __forceinline__ uint32_t pack_u8(float v, int c, uint32_t acc)

@@ -217,7 +217,7 @@ __device__ __forceinline__ void lanczos_x2_vpass(const float (&win)[6][16], cons
         if (!ALPHA && (k & 3) == 3) continue; // V[alpha] is not read by the 3-channel horizontal pass
         float acc = win[BASE % 6][k] * w[0]; // == fma(.., 0) and a VOP2 instruction
 #pragma unroll
-        for (int j = 1; j < 6; ++j) acc = mac<EXACT>(acc, win[(BASE + j) % 6][k], w[j]);
+        for (int j = 1; j < 6; ++j) acc = mac_tight<EXACT>(acc, win[(BASE + j) % 6][k], w[j]);
         V[k] = acc;
     }
 }
@@ -234,7 +234,7 @@ __device__ __forceinline__ void lanczos_x2_vpass_edge(const float (&win)[6][16],
     for (int k = 0; k < 16; ++k) {
         float acc = win[BASE % 6][k] * w[0]; // == fma(.., 0) and a VOP2 instruction
 #pragma unroll
-        for (int j = 1; j < 6; ++j) acc = mac<EXACT>(acc, win[(BASE + j) % 6][k], w[j]);
+        for (int j = 1; j < 6; ++j) acc = mac_tight<EXACT>(acc, win[(BASE + j) % 6][k], w[j]);
         V[k] = acc;
     }
 }
@@ -270,8 +270,8 @@ __device__ __forceinline__ void lanczos_x2_hpass(const float (&V)[16], const Pha
             float ao = e[m + 1] * W.o[0];
 #pragma unroll
             for (int j = 1; j < 6; ++j) {
-                ae = mac<EXACT>(ae, e[m + j], W.e[j]);
-                ao = mac<EXACT>(ao, e[m + 1 + j], W.o[j]);
+                ae = mac_tight<EXACT>(ae, e[m + j], W.e[j]);
+                ao = mac_tight<EXACT>(ao, e[m + 1 + j], W.o[j]);
             }
 #if NUS_LZ_ABLATE == 7
             o[2 * m] += __float_as_uint(ae);
@@ -612,7 +612,7 @@ __device__ __forceinline__ void lanczos_x2_edge_rows(const LanczosX2EdgeArgs &A,
             for (int c = 0; c < 4; ++c) {
                 float acc = ch_f32(px_of(raw[phase], col), c) * wv[0];
 #pragma unroll
-                for (int j = 1; j < 6; ++j) acc = mac<EXACT>(acc, ch_f32(px_of(raw[phase + j], col), c), wv[j]);
+                for (int j = 1; j < 6; ++j) acc = mac_tight<EXACT>(acc, ch_f32(px_of(raw[phase + j], col), c), wv[j]);
                 V[col][c] = acc;
             }
         uint32_t o[8];
@@ -630,7 +630,7 @@ __device__ __forceinline__ void lanczos_x2_edge_rows(const LanczosX2EdgeArgs &A,
                     int li = l0 + j;
                     li = li < 0 ? 0 : (li > 7 ? 7 : li); // taps outside the image carry weight 0
                     const float w = A.wx[SIDE][q * 6 + j];
-                    acc = j == 0 ? V[li][c] * w : mac<EXACT>(acc, V[li][c], w);
+                    acc = j == 0 ? V[li][c] * w : mac_tight<EXACT>(acc, V[li][c], w);
                 }
                 px = pack_u8<EXACT>(acc, c, px);
             }

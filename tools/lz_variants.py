@@ -18,7 +18,7 @@ vp, u32, i64 = ctypes.c_void_p, ctypes.c_uint32, ctypes.c_int64
 
 
 class Lib:
-    def __init__(self, path, th, alg=2, dims=(1920, 1080, 3840, 2160)):
+    def __init__(self, path, th, alg=2, dims=(1920, 1080, 3840, 2160), exact=False):
         L = ctypes.CDLL(os.path.abspath(path))
         L.nus_upscaler_create.restype = vp
         L.nus_upscaler_create.argtypes = [ctypes.c_int, ctypes.c_int]
@@ -33,6 +33,9 @@ class Lib:
         self.h = L.nus_upscaler_create(alg, 2)
         if th:
             assert L.nus_upscaler_set_option(self.h, b"rows_per_wave", th) == 0
+        if exact:
+            L.nus_upscaler_set_lanczos_mode.argtypes = [vp, ctypes.c_int]
+            assert L.nus_upscaler_set_lanczos_mode(self.h, 1) == 0
         assert L.nus_upscaler_initialize(self.h, *dims) == 0, L.nus_upscaler_last_error(self.h)
         L.nus_upscaler_set_profiling(self.h, 1)
 
@@ -54,13 +57,14 @@ def main():
     ap.add_argument("--alg", default="lanczos3", help="nearest, bilinear, lanczos3, bicubic, triangle")
     ap.add_argument("--dims", default="1920x1080:3840x2160")
     ap.add_argument("--patterns", default="gradient,noise")
+    ap.add_argument("--exact", action="store_true", help="the resize filters' EXACT mode (separate multiply and add, as the CPU)")
     ap.add_argument("libs", nargs="+")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     n = a.frames
     alg = {"nearest": 0, "bilinear": 1, "lanczos3": 2, "bicubic": 3, "triangle": 4}[a.alg]
     (iw, ih), (ow, oh) = [tuple(int(v) for v in part.split("x")) for part in a.dims.split(":")]
-    libs = [(s.split("=")[0], Lib(s.split("=")[1], a.th, alg, (iw, ih, ow, oh))) for s in a.libs]
+    libs = [(s.split("=")[0], Lib(s.split("=")[1], a.th, alg, (iw, ih, ow, oh), a.exact)) for s in a.libs]
     out = torch.empty((n, oh, ow, 4), dtype=torch.uint8, device=dev)
     mb = (iw * ih + ow * oh) * 4 / 1e6
     st = torch.cuda.current_stream().cuda_stream
