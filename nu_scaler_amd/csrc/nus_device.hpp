@@ -64,7 +64,7 @@ __device__ __forceinline__ float mac(float acc, float v, float w)
 // loop ahead of the additions (k_lanczos3_x2 EXACT: 310 VGPRs, one wave per SIMD; with this 234, two waves, 29.9 -> 23.0 us per
 // 1080p -> 4K frame; x3/2 36.6 -> 27.5).  Not for the x3 / x4 kernel, which is faster with the batches (profiles/
 // r02_lanczos_exact_mode_products.txt).
-template <bool EXACT>
+template <bool EXACT, bool PIN_FMA = false>
 __device__ __forceinline__ float mac_tight(float acc, float v, float w)
 {
     if (EXACT) {
@@ -72,7 +72,11 @@ __device__ __forceinline__ float mac_tight(float acc, float v, float w)
         asm volatile("" : "+v"(p));
         return acc + p;
     }
-    return __builtin_fmaf(v, w, acc);
+    // PIN_FMA: the fused operations in program order too (one tap chain after the other).  k_lanczos3_r43: 192 -> 153 VGPRs,
+    // a third wave per SIMD, 6.7 -> 6.1 us per 1080p -> 1440p frame; the x3/2 kernel needs MORE registers that way, x2 the same.
+    float r = __builtin_fmaf(v, w, acc);
+    if (PIN_FMA) asm volatile("" : "+v"(r));
+    return r;
 }
 
 // Insert round(clamp(v)) as byte c of acc.

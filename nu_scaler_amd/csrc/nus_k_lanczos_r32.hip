@@ -307,7 +307,7 @@ __device__ __forceinline__ void r32_edge_rows(const LanczosR32EdgeArgs &A, const
             for (int c = 0; c < 4; ++c) {
                 float acc = ch_f32(r32_px_of(raw[p], col), c) * wv[0];
 #pragma unroll
-                for (int j = 1; j < 6; ++j) acc = mac_tight<EXACT>(acc, ch_f32(r32_px_of(raw[p + j], col), c), wv[j]);
+                for (int j = 1; j < 6; ++j) acc = mac<EXACT>(acc, ch_f32(r32_px_of(raw[p + j], col), c), wv[j]);
                 V[col][c] = acc;
             }
         uint32_t o[12];
@@ -325,7 +325,7 @@ __device__ __forceinline__ void r32_edge_rows(const LanczosR32EdgeArgs &A, const
                     int li = l0 + j;
                     li = li < 0 ? 0 : (li > 11 ? 11 : li); // slots outside the image carry weight 0
                     const float w = A.wx[SIDE][q][j];
-                    acc = j == 0 ? V[li][c] * w : mac_tight<EXACT>(acc, V[li][c], w);
+                    acc = j == 0 ? V[li][c] * w : mac<EXACT>(acc, V[li][c], w);
                 }
                 px = pack_u8<EXACT>(acc, c, px);
             }

@@ -65,7 +65,7 @@ __device__ __forceinline__ void r43_vpass(const float (&win)[6][12], const W &w,
         if ((k & 3) == 3 && skip_alpha) continue; // wave-uniform; V[alpha] is then not read
         float acc = win[0][k] * w[0]; // == fma(.., 0) and a VOP2 instruction
 #pragma unroll
-        for (int j = 1; j < 6; ++j) acc = mac_tight<EXACT>(acc, win[j][k], w[j]);
+        for (int j = 1; j < 6; ++j) acc = mac_tight<EXACT, true>(acc, win[j][k], w[j]);
         V[k] = acc;
     }
 }
@@ -99,7 +99,7 @@ __device__ __forceinline__ void r43_hpass_store(const float (&V)[12], const floa
             // phase 3's frame is columns c0 .. c0+5: slots 0 .. 5 are e[3] .. e[8]
             float a = e[p] * W[p][0];
 #pragma unroll
-            for (int j = 1; j < 6; ++j) a = mac_tight<EXACT>(a, e[p + j], W[p][j]);
+            for (int j = 1; j < 6; ++j) a = mac_tight<EXACT, true>(a, e[p + j], W[p][j]);
             o[p] = pack_u8<EXACT>(a, c, o[p]);
         }
     }
@@ -249,7 +249,7 @@ __device__ __forceinline__ void r43_edge_rows(const LanczosR43EdgeArgs &A, const
             for (int c = 0; c < 4; ++c) {
                 float acc = ch_f32(r43_px_of(raw[p], col), c) * wv[0];
 #pragma unroll
-                for (int j = 1; j < 6; ++j) acc = mac_tight<EXACT>(acc, ch_f32(r43_px_of(raw[p + j], col), c), wv[j]);
+                for (int j = 1; j < 6; ++j) acc = mac<EXACT>(acc, ch_f32(r43_px_of(raw[p + j], col), c), wv[j]);
                 V[col][c] = acc;
             }
         uint32_t o[8];
@@ -267,7 +267,7 @@ __device__ __forceinline__ void r43_edge_rows(const LanczosR43EdgeArgs &A, const
                     int li = l0 + j;
                     li = li < 0 ? 0 : (li > 11 ? 11 : li); // slots outside the image carry weight 0
                     const float w = A.wx[SIDE][q][j];
-                    acc = j == 0 ? V[li][c] * w : mac_tight<EXACT>(acc, V[li][c], w);
+                    acc = j == 0 ? V[li][c] * w : mac<EXACT>(acc, V[li][c], w);
                 }
                 px = pack_u8<EXACT>(acc, c, px);
             }

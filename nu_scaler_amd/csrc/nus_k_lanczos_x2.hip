@@ -612,7 +612,7 @@ __device__ __forceinline__ void lanczos_x2_edge_rows(const LanczosX2EdgeArgs &A,
             for (int c = 0; c < 4; ++c) {
                 float acc = ch_f32(px_of(raw[phase], col), c) * wv[0];
 #pragma unroll
-                for (int j = 1; j < 6; ++j) acc = mac_tight<EXACT>(acc, ch_f32(px_of(raw[phase + j], col), c), wv[j]);
+                for (int j = 1; j < 6; ++j) acc = mac<EXACT>(acc, ch_f32(px_of(raw[phase + j], col), c), wv[j]);
                 V[col][c] = acc;
             }
         uint32_t o[8];
@@ -630,7 +630,7 @@ __device__ __forceinline__ void lanczos_x2_edge_rows(const LanczosX2EdgeArgs &A,
                     int li = l0 + j;
                     li = li < 0 ? 0 : (li > 7 ? 7 : li); // taps outside the image carry weight 0
                     const float w = A.wx[SIDE][q * 6 + j];
-                    acc = j == 0 ? V[li][c] * w : mac_tight<EXACT>(acc, V[li][c], w);
+                    acc = j == 0 ? V[li][c] * w : mac<EXACT>(acc, V[li][c], w);
                 }
                 px = pack_u8<EXACT>(acc, c, px);
             }
