@@ -47,8 +47,10 @@ HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICR
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    # defaults: ~3 s of timed region on one MI355X (6-7 ms per 300-unit step), so `value` is what the step
+    # sustains at the clocks the board settles to under it, not what a cold GPU does for a tenth of a second
+    ap.add_argument("--steps", type=int, default=450)
+    ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--units", type=int, default=300, help="source frames per GPU per step (the 300-frame stream)")
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
@@ -60,6 +62,8 @@ def parse_args(argv=None):
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the informational legs (fused / noise / motion / host path / copy ceiling)")
     ap.add_argument("--no-check", action="store_true", help="skip the oracle check of the timed output buffers")
+    ap.add_argument("--sustained-seconds", type=float, default=6.0,
+                    help="length of the sustained leg after the timed region (0 = skip; N=1 only)")
     ap.add_argument("--fused", action="store_true",
                     help="blend inside the second upscale's row loads (in-between frame never written to HBM); "
                          "same output frames, reported separately from the default 3-stage step")
@@ -307,6 +311,101 @@ def host_path_leg(nsc, syn, w, h, device):
     }
 
 
+class ClockSampler:
+    """Board clock / power while a leg runs: a thread of THIS process starts a fresh `rocm-smi` child per sample
+    (read-only query; the child never touches HIP) and, where readable, also reads the amdgpu sysfs files."""
+
+    def __init__(self, period_s=0.6):
+        import threading
+
+        self.period = period_s
+        self.samples = []  # (seconds since start, sclk MHz or None, W or None)
+        self._stop = threading.Event()
+        self._thread = threading.Thread(target=self._run, daemon=True)
+        self.t0 = time.perf_counter()
+        self.tool = None
+
+    @staticmethod
+    def _parse(text):
+        import re
+
+        sclk = re.search(r"sclk[^\n]*?\((\d+)\s*Mhz\)", text, re.I)
+        watts = re.search(r"Power \(W\):\s*([0-9.]+)", text)
+        return (int(sclk.group(1)) if sclk else None, float(watts.group(1)) if watts else None)
+
+    def _run(self):
+        import shutil
+
+        exe = shutil.which("rocm-smi")
+        self.tool = "rocm-smi --showpower --showclocks -d 0" if exe else None
+        while exe and not self._stop.is_set():
+            t = time.perf_counter() - self.t0
+            try:
+                res = subprocess.run([exe, "--showpower", "--showclocks", "-d", "0"], capture_output=True, text=True, timeout=15)
+                sclk, watts = self._parse(res.stdout)
+                if sclk is not None or watts is not None:
+                    self.samples.append((round(t, 2), sclk, watts))
+            except Exception:
+                pass
+            self._stop.wait(self.period)
+
+    def start(self):
+        self.t0 = time.perf_counter()
+        self._thread.start()
+        return self
+
+    def stop(self):
+        self._stop.set()
+        self._thread.join(timeout=20)
+        return self.samples
+
+
+def sustained_leg(torch, do_step, upscaler, seconds, tail_s=3.0, batch=20):
+    """The same step for `seconds` of wall time, in batches of `batch` steps with one synchronize each; reports the
+    rate over the last `tail_s` seconds (whole batches) next to the rate of the first second, the hipEvent brackets
+    of the upscale launches in that tail, and the board's clock / power sampled meanwhile."""
+    upscaler.set_profiling(True)
+    upscaler.profile_collect()
+    sampler = ClockSampler().start()
+    marks = []  # (seconds at the end of the batch, steps so far, launches in the batch, their ms)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    n = 0
+    while True:
+        for _ in range(batch):
+            do_step()
+        torch.cuda.synchronize()
+        now = time.perf_counter() - t0
+        n += batch
+        nl, ms = upscaler.profile_collect()
+        marks.append((now, n, nl, ms))
+        if now >= seconds:
+            break
+    samples = sampler.stop()
+    upscaler.set_profiling(False)
+    total = marks[-1][0]
+    first = next(m for m in marks if m[0] >= min(1.0, total))
+    k0 = max(i for i, m in enumerate(marks) if m[0] <= max(total - tail_s, 0.0) or i == 0)
+    tail = marks[k0 + 1:] or marks[-1:]
+    tail_steps = tail[-1][1] - marks[k0][1]
+    tail_seconds = tail[-1][0] - marks[k0][0]
+    tail_launches = sum(m[2] for m in tail)
+    tail_ms = sum(m[3] for m in tail)
+    in_tail = [sm for sm in samples if sm[0] >= marks[k0][0]]
+    return {
+        "seconds": round(total, 2), "steps": n,
+        "ms_per_step_first_second": round(first[0] / first[1] * 1e3, 4),
+        "ms_per_step_tail": round(tail_seconds / max(tail_steps, 1) * 1e3, 4),
+        "tail_seconds": round(tail_seconds, 2), "tail_steps": tail_steps,
+        "tail_upscale_launches": tail_launches, "tail_upscale_avg_launch_ms": round(tail_ms / max(tail_launches, 1), 4),
+        "clock_power_samples": {"tool": sampler.tool, "t_s__sclk_MHz__W": samples,
+                                "tail_mean_sclk_MHz": (round(sum(x[1] for x in in_tail if x[1]) / max(1, sum(1 for x in in_tail if x[1])))
+                                                       if any(x[1] for x in in_tail) else None),
+                                "tail_mean_W": (round(sum(x[2] for x in in_tail if x[2]) / max(1, sum(1 for x in in_tail if x[2])), 1)
+                                                if any(x[2] for x in in_tail) else None)},
+    }
+
+
 # ---------------------------------------------------------------------------------------------
 # one rank
 # ---------------------------------------------------------------------------------------------
@@ -416,6 +515,12 @@ def worker(args):
         # cheap sanity check: the outputs are fully written (alpha of the opaque stream stays 255)
         assert args.pattern != "gradient" or (int(up_real[0, ..., 3].min()) == 255 and int(up_mid[count - 1, ..., 3].min()) == 255)
 
+    # What the very same step sustains for seconds (N=1 only; never `value`): ms per step over the last 3 s,
+    # hipEvent brackets of the upscale launches in that tail, board clock and power sampled meanwhile.
+    sustained = None
+    if rank == 0 and world == 1 and args.sustained_seconds > 0:
+        sustained = sustained_leg(torch, do_step, pipe.upscaler, args.sustained_seconds)
+
     extras = rank == 0 and not args.no_extras and not args.fused and not args.overlap
 
     # Informational (never `value`): same output frames with the blend fused into the second upscale's
@@ -514,6 +619,12 @@ def worker(args):
                         "traffic = (2*FETCH_SIZE + WRITE_SIZE)*1024 of both from separate rocprofv3 --pmc passes, "
                         "scaled to frames_per_launch",
             }
+            if sustained and sustained["tail_upscale_launches"]:
+                s_ach = up_bytes * count / (sustained["tail_upscale_avg_launch_ms"] / 1e3) / 1e9
+                roofline["sustained"] = {
+                    "achieved": round(s_ach, 1), "frac": round(s_ach / HBM_PEAK_GBPS, 4),
+                    "avg_launch_ms": sustained["tail_upscale_avg_launch_ms"],
+                    "what": "the same bracket over the last seconds of config.sustained (after the timed region)"}
             if copy_ms:
                 ceiling = up_bytes * count / (copy_ms / 1e3) / 1e9
                 roofline["copy_ceiling"] = {
@@ -553,6 +664,8 @@ def worker(args):
                 "ms_per_step_by_rank": {"min": round(min(per_rank) / args.steps * 1e3, 4),
                                         "max": round(max(per_rank) / args.steps * 1e3, 4)},
                 "timed_output_check": timed_check,
+                "timed_region_s": round(elapsed, 3),
+                "sustained": sustained,
                 "fused_variant": None if fused_ms is None else {
                     "what": "same 4K outputs, blend fused into the second upscale (in-between frame not materialised); "
                             "informational, measured after the timed region on this rank only",

@@ -56,13 +56,17 @@ def validate_tables_blob(blob: bytes, in_w: int, in_h: int, out_w: int, out_h: i
         raise ValueError(C.last_error())
 
 
-def broadcast_blob(blob, src: int = 0, device=None) -> bytes:
+def broadcast_blob(blob, src: int = 0, device=None, force: bool = False) -> bytes:
     """Broadcast a byte blob from rank `src` (RCCL over xGMI with the nccl backend and a
-    cuda `device`; gloo on CPU).  Returns the blob on every rank."""
+    cuda `device`; gloo on CPU).  Returns the blob on every rank.  A world of one returns the blob
+    untouched unless `force` is set: then the two broadcasts are issued on the one-rank communicator
+    all the same (tests/test_rccl_one_rank.py drives RCCL this way on a 1-GPU box)."""
     import torch
     import torch.distributed as dist
 
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()):
+        return bytes(blob)
+    if dist.get_world_size() == 1 and not force:
         return bytes(blob)
     rank = dist.get_rank()
     n = torch.tensor([len(blob) if rank == src else 0], dtype=torch.int64, device=device)
@@ -77,16 +81,19 @@ def broadcast_blob(blob, src: int = 0, device=None) -> bytes:
     return t.cpu().numpy().tobytes()
 
 
-def broadcast_tables(upscaler: PyWgpuUpscaler, src: int = 0, device=None) -> int:
+def broadcast_tables(upscaler: PyWgpuUpscaler, src: int = 0, device=None, force: bool = False) -> int:
     """Broadcast rank `src`'s filter / index tables to every rank so all GPUs use
-    bit-identical weights.  Returns the blob size (0 when not distributed)."""
+    bit-identical weights.  Returns the blob size (0 when not distributed).  `force`: also on a
+    world of one, and the source rank re-imports what came back through the collective."""
     import torch.distributed as dist
 
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()):
+        return 0
+    if dist.get_world_size() == 1 and not force:
         return 0
     rank = dist.get_rank()
-    blob = broadcast_blob(upscaler.export_tables() if rank == src else b"", src, device)
-    if rank != src:
+    blob = broadcast_blob(upscaler.export_tables() if rank == src else b"", src, device, force)
+    if rank != src or force:
         upscaler.import_tables(blob)
     return len(blob)
 
