@@ -190,6 +190,21 @@ int nus_upscaler_upscale_device(nus_upscaler *h, const void *d_in, void *d_out,
 int nus_upscaler_upscale_blend_device(nus_upscaler *h, const void *d_a, size_t a_stride, const void *d_b,
                                       size_t b_stride, float t, void *d_out, uint32_t n_frames, void *stream);
 
+/* The whole step of the GUI's frame loop for a batch of pairs in ONE launch (nu_scaler_py/nu_scaler/main.py:999-1008 interpolates
+ * and then upscales; the BASELINE metric upscales the real frame too): for unit i, with A_i = d_a + i*a_stride and
+ * B_i = d_b + i*b_stride (stride 0 = tightly packed frames),
+ *   d_out_real[i] = upscale(A_i)                       what nus_upscaler_upscale_device writes,
+ *   d_mid[i]      = blend(A_i, B_i) at t, zero flow    what nus_interp_interpolate_device writes (d_mid may be NULL),
+ *   d_out_mid[i]  = upscale(blend(A_i, B_i))           what nus_upscaler_upscale_blend_device writes,
+ * bit for bit.  Every (frame, row block, strip) is walked by two waves of the same kernel side by side -- one on A_i alone, one
+ * blending A_i and B_i on load -- so each input row reaches HBM's bus about once per step instead of four times and the
+ * in-between frame is written, never re-read.  Exact-x2 resize kernels (Lanczos-3 / bicubic / triangle) only; otherwise
+ * NUS_ERR_UNSUPPORTED and the caller runs the three stages separately.  Enqueue only, no allocation.
+ * Option "unit_order" (nus_upscaler_set_option): 1 = row-block-major wave order (default), 0 = frame-major. */
+int nus_upscaler_upscale_unit_device(nus_upscaler *h, const void *d_a, size_t a_stride, const void *d_b, size_t b_stride,
+                                     float t, void *d_mid, void *d_out_real, void *d_out_mid, uint32_t n_units,
+                                     void *stream);
+
 const char *nus_upscaler_name(const nus_upscaler *h); /* "WgpuNearestUpscaler" / "WgpuBilinearUpscaler" (mod.rs:1060-1066) / "Hip{Lanczos3,Bicubic,Triangle}Upscaler" */
 int nus_upscaler_algorithm(const nus_upscaler *h);
 int nus_upscaler_quality(const nus_upscaler *h);
@@ -261,6 +276,25 @@ typedef enum nus_flow_format {
     NUS_FLOW_F16 = 1
 } nus_flow_format;
 int nus_interp_set_flow_format(nus_interp *h, int format);
+
+/* trait FrameInterpolator (nu_scaler_core/src/interpolation/mod.rs:29-44) -- the shape the dead-code trait gives an
+ * interpolator, next to the live pyclass's per-call form below:
+ *   initialize(width, height)          :31  buffers for that frame size up front; same size again = no-op (:306-308)
+ *   interpolate(frame1, frame2, t)     :34  frames of the initialize() size, zero flow; before initialize:
+ *                                           NUS_ERR_NOT_INITIALIZED, "Interpolator not initialized" (:368-370)
+ *   name()                             :37
+ *   set_quality(q) / quality()         :40-43  nus_interp_quality_level; kept and reported, arithmetic unchanged */
+typedef enum nus_interp_quality_level {
+    NUS_INTERP_QUALITY_HIGH = 0, /* InterpolationQuality::High   (interpolation/mod.rs:8-14) */
+    NUS_INTERP_QUALITY_MEDIUM = 1,
+    NUS_INTERP_QUALITY_LOW = 2
+} nus_interp_quality_level;
+int nus_interp_initialize(nus_interp *h, uint32_t width, uint32_t height);
+int nus_interp_interpolate_frames(nus_interp *h, const uint8_t *frame1, size_t len1, const uint8_t *frame2, size_t len2,
+                                  float t, uint8_t *out, size_t out_cap);
+const char *nus_interp_name(const nus_interp *h);
+int nus_interp_set_quality(nus_interp *h, int quality);
+int nus_interp_quality(const nus_interp *h);
 
 /* interpolate_py (wgpu_interpolator.rs:215-491): host frames in, host frame out.
  * flow == NULL -> zero flow (the live reference behaviour); otherwise w*h*2 floats

@@ -54,6 +54,7 @@ SIGNATURES = [
     ("nus_upscaler_upscale_batch", _i, [_vp, _vp, _vp, _sz, _vp, _sz]),
     ("nus_upscaler_upscale_device", _i, [_vp, _vp, _vp, _u32, _vp]),
     ("nus_upscaler_upscale_blend_device", _i, [_vp, _vp, _sz, _vp, _sz, _f, _vp, _u32, _vp]),
+    ("nus_upscaler_upscale_unit_device", _i, [_vp, _vp, _sz, _vp, _sz, _f, _vp, _vp, _vp, _u32, _vp]),
     ("nus_upscaler_name", _cp, [_vp]),
     ("nus_upscaler_algorithm", _i, [_vp]),
     ("nus_upscaler_quality", _i, [_vp]),
@@ -80,6 +81,11 @@ SIGNATURES = [
     ("nus_interp_set_device", _i, [_vp, _i]),
     ("nus_interp_set_input_format", _i, [_vp, _i]),
     ("nus_interp_set_flow_format", _i, [_vp, _i]),
+    ("nus_interp_initialize", _i, [_vp, _u32, _u32]),
+    ("nus_interp_interpolate_frames", _i, [_vp, _vp, _sz, _vp, _sz, _f, _vp, _sz]),
+    ("nus_interp_name", _cp, [_vp]),
+    ("nus_interp_set_quality", _i, [_vp, _i]),
+    ("nus_interp_quality", _i, [_vp]),
     ("nus_interp_interpolate", _i, [_vp, _vp, _sz, _vp, _sz, _vp, _u32, _u32, _f, _vp, _sz]),
     ("nus_interp_interpolate_device", _i, [_vp, _vp, _sz, _vp, _sz, _vp, _u32, _u32, _f, _vp, _u32, _vp]),
     ("nus_interp_last_gpu_ms", _i, [_vp, _dp]),

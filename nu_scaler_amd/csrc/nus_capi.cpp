@@ -217,6 +217,16 @@ int nus_upscaler_upscale_blend_device(nus_upscaler *h, const void *d_a, size_t a
     });
 }
 
+int nus_upscaler_upscale_unit_device(nus_upscaler *h, const void *d_a, size_t a_stride, const void *d_b, size_t b_stride, float t,
+                                     void *d_mid, void *d_out_real, void *d_out_mid, uint32_t n_units, void *stream)
+{
+    return guarded<int>("nus_upscaler_upscale_unit_device", [&]() -> int {
+        return h ? h->impl.upscale_unit_device(d_a, a_stride, d_b, b_stride, t, d_mid, d_out_real, d_out_mid, n_units,
+                                               static_cast<hipStream_t>(stream))
+                 : null_handle();
+    });
+}
+
 const char *nus_upscaler_name(const nus_upscaler *h) { return h ? h->impl.name() : ""; }
 int nus_upscaler_algorithm(const nus_upscaler *h) { return h ? static_cast<int>(h->impl.algorithm()) : null_handle(); }
 int nus_upscaler_quality(const nus_upscaler *h) { return h ? static_cast<int>(h->impl.quality()) : null_handle(); }
@@ -399,6 +409,29 @@ int nus_interp_set_flow_format(nus_interp *h, int format)
 {
     return guarded<int>("nus_interp_set_flow_format", [&]() -> int { return h ? h->impl.set_flow_format(format) : null_handle(); });
 }
+
+int nus_interp_initialize(nus_interp *h, uint32_t width, uint32_t height)
+{
+    return guarded<int>("nus_interp_initialize", [&]() -> int { return h ? h->impl.initialize(width, height) : null_handle(); });
+}
+
+int nus_interp_interpolate_frames(nus_interp *h, const uint8_t *frame1, size_t len1, const uint8_t *frame2, size_t len2, float t,
+                                  uint8_t *out, size_t out_cap)
+{
+    return guarded<int>("nus_interp_interpolate_frames", [&]() -> int {
+        return h ? h->impl.interpolate_frames(frame1, len1, frame2, len2, t, out, out_cap) : null_handle();
+    });
+}
+
+int nus_interp_set_quality(nus_interp *h, int quality)
+{
+    return guarded<int>("nus_interp_set_quality", [&]() -> int {
+        return h ? h->impl.set_quality(static_cast<nus::InterpolationQuality>(quality)) : null_handle();
+    });
+}
+
+int nus_interp_quality(const nus_interp *h) { return h ? static_cast<int>(h->impl.quality()) : null_handle(); }
+const char *nus_interp_name(const nus_interp *h) { return h ? h->impl.name() : ""; }
 
 int nus_interp_interpolate(nus_interp *h, const uint8_t *a, size_t a_len, const uint8_t *b, size_t b_len,
                            const float *flow, uint32_t w, uint32_t hgt, float t, uint8_t *out, size_t out_cap)

@@ -123,6 +123,11 @@ int HipUpscaler::set_option(const char *key, int64_t value)
         rows_per_wave_ = (uint32_t)value;
         return kOk;
     }
+    if (!strcmp(key, "unit_order")) { // wave order of upscale_unit_device: 0 frame-major, 1 row-block-major (default)
+        if (value != 0 && value != 1) return fail(kInvalidArgument, "unit_order must be 0 or 1");
+        unit_order_ = (uint32_t)value;
+        return kOk;
+    }
     return fail(kInvalidArgument, fmt("unknown option '%s'", key));
 }
 
@@ -481,7 +486,8 @@ int HipUpscaler::initialize(uint32_t in_w, uint32_t in_h, uint32_t out_w, uint32
     return kOk;
 }
 
-int HipUpscaler::enqueue(const uint8_t *d_in, uint8_t *d_out, uint32_t n_frames, hipStream_t stream, const BlendSrc *blend)
+int HipUpscaler::enqueue(const uint8_t *d_in, uint8_t *d_out, uint32_t n_frames, hipStream_t stream, const BlendSrc *blend,
+                         const UnitDst *unit)
 {
     UpscaleLaunch L;
     L.in = d_in;
@@ -565,11 +571,19 @@ int HipUpscaler::enqueue(const uint8_t *d_in, uint8_t *d_out, uint32_t n_frames,
         if (th == 0) {
             // enough waves to fill 256 CUs a few times over, tall enough to amortise the 6 halo rows
             const uint64_t nstrips = (iw_ + kLanczosX2StripCols - 1) / kLanczosX2StripCols;
-            const uint64_t rows_total = (uint64_t)ih_ * nstrips * n_frames;
+            const uint64_t rows_total = (uint64_t)ih_ * nstrips * n_frames * (unit ? 2 : 1);
             uint64_t t = rows_total / 8192;
             th = (uint32_t)(t < 8 ? 8 : (t > 36 ? 36 : t));
         }
-        e = launch_lanczos_x2(L, dt_, lanczos_exact_, th);
+        if (unit) {
+            UnitOutputs U;
+            U.out_mid = unit->out_mid;
+            U.mid = unit->mid;
+            U.order = unit_order_;
+            e = launch_lanczos_x2_unit(L, dt_, lanczos_exact_, th, U);
+        } else {
+            e = launch_lanczos_x2(L, dt_, lanczos_exact_, th);
+        }
         lanczos_edges = true;
         break;
     }
@@ -577,6 +591,13 @@ int HipUpscaler::enqueue(const uint8_t *d_in, uint8_t *d_out, uint32_t n_frames,
     if (e != hipSuccess) return fail_hip(e, "kernel launch");
     if (lanczos_edges) {
         // first / last 8 output columns: renormalised edge weights, row-per-lane kernel
+        if (unit) { // the real frames' edge columns come from A alone, the in-between frames' from the blended pair
+            UpscaleLaunch R = L;
+            R.in_b = nullptr;
+            e = launch_lanczos_x2_edges(R, dt_, lanczos_exact_);
+            if (e != hipSuccess) return fail_hip(e, "kernel launch");
+            L.out = unit->out_mid;
+        }
         e = launch_lanczos_x2_edges(L, dt_, lanczos_exact_);
         if (e != hipSuccess) return fail_hip(e, "kernel launch");
     }
@@ -644,6 +665,37 @@ int HipUpscaler::upscale_blend_device(const void *d_a, size_t a_stride, const vo
     bs.b_stride = b_stride;
     bs.t = t;
     return enqueue(static_cast<const uint8_t *>(d_a), static_cast<uint8_t *>(d_out), n_frames, stream, &bs);
+}
+
+int HipUpscaler::upscale_unit_device(const void *d_a, size_t a_stride, const void *d_b, size_t b_stride, float t, void *d_mid,
+                                     void *d_out_real, void *d_out_mid, uint32_t n_units, hipStream_t stream)
+{
+    std::lock_guard<std::mutex> lk(mu_);
+    if (!initialized_) return fail(kNotInitialized, "Upscaler not initialized. Call initialize() first.");
+    if (variant_ != Variant::LanczosX2RegWin)
+        return fail(kUnsupported, "upscale_unit_device: only the exact-x2 resize kernels run the whole step in one launch; "
+                                  "run interpolate + upscale separately for this configuration");
+    if (!d_a || !d_b || !d_out_real || !d_out_mid) return fail(kInvalidArgument, "upscale_unit_device: null device pointer");
+    if (!(t >= 0.0f && t <= 1.0f)) return fail(kInvalidArgument, "upscale_unit_device: t must be in [0, 1]");
+    if (n_units == 0) return kOk;
+    auto misaligned = [](const void *p) { return (reinterpret_cast<uintptr_t>(p) % 16) != 0; };
+    if (misaligned(d_a) || misaligned(d_b) || misaligned(d_mid) || misaligned(d_out_real) || misaligned(d_out_mid) ||
+        (a_stride % 16) || (b_stride % 16) ||
+        (n_units > 1 && (((size_t)ow_ * oh_ * 4) % 16 || ((size_t)iw_ * ih_ * 4) % 16)))
+        return fail(kInvalidArgument, "upscale_unit_device: pointers, strides and frame sizes must be multiples of 16 bytes");
+    const size_t in_bytes = (size_t)iw_ * ih_ * 4;
+    if ((a_stride && a_stride < in_bytes) || (b_stride && b_stride < in_bytes))
+        return fail(kInvalidArgument, "upscale_unit_device: frame stride smaller than a frame");
+    NUS_HIP(hipSetDevice(device_));
+    BlendSrc bs;
+    bs.b = static_cast<const uint8_t *>(d_b);
+    bs.a_stride = a_stride ? a_stride : in_bytes;
+    bs.b_stride = b_stride ? b_stride : in_bytes;
+    bs.t = t;
+    UnitDst ud;
+    ud.out_mid = static_cast<uint8_t *>(d_out_mid);
+    ud.mid = static_cast<uint8_t *>(d_mid);
+    return enqueue(static_cast<const uint8_t *>(d_a), static_cast<uint8_t *>(d_out_real), n_units, stream, &bs, &ud);
 }
 
 int HipUpscaler::upscale(const uint8_t *in, size_t in_len, uint8_t *out, size_t out_cap)

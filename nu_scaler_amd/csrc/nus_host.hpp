@@ -78,6 +78,12 @@ public:
     int upscale_blend_device(const void *d_a, size_t a_stride, const void *d_b, size_t b_stride, float t, void *d_out,
                              uint32_t n_frames, hipStream_t stream);
 
+    // One whole pipeline step in one launch of the x2 resize kernel: for every pair (A_i, B_i) the up-scaled real frame A_i
+    // (d_out_real), the zero-flow in-between frame at t (d_mid, input-size frames; may be null) and the up-scaled in-between
+    // frame (d_out_mid).  The same bytes as interpolate_device + 2 x upscale_device; x2 resize kernels only.
+    int upscale_unit_device(const void *d_a, size_t a_stride, const void *d_b, size_t b_stride, float t, void *d_mid,
+                            void *d_out_real, void *d_out_mid, uint32_t n_units, hipStream_t stream);
+
     int set_device(int device);
     int set_bilinear_variant(int variant);
     int set_lanczos_mode(int mode);
@@ -140,7 +146,11 @@ private:
         size_t a_stride = 0, b_stride = 0;
         float t = 0.5f;
     };
-    int enqueue(const uint8_t *d_in, uint8_t *d_out, uint32_t n_frames, hipStream_t stream, const BlendSrc *blend = nullptr);
+    struct UnitDst { // upscale_unit_device: the two extra outputs of the one-launch step
+        uint8_t *out_mid = nullptr, *mid = nullptr;
+    };
+    int enqueue(const uint8_t *d_in, uint8_t *d_out, uint32_t n_frames, hipStream_t stream, const BlendSrc *blend = nullptr,
+                const UnitDst *unit = nullptr);
 
     mutable std::mutex mu_;
     Quality quality_;
@@ -159,6 +169,7 @@ private:
     uint32_t win_outputs_per_lane_ = 4; // register-window resize: 4, or 2 for factors below ~x1.4
     uint32_t resize_union_taps_ = 0; // widest union of the tap windows of 4 adjacent outputs (0: unused)
     uint32_t rows_per_wave_ = 0; // 0: pick from the batch size
+    uint32_t unit_order_ = 1;    // wave order of the unit launch: 0 frame-major, 1 row-block-major (option "unit_order")
     float easu_sharp_ = -1.0f, rcas_sharp_ = -1.0f; // < 0: derive from quality_
     int in_format_ = 0; // nus_pixel_format
     bool initialized_ = false;
@@ -184,13 +195,24 @@ struct UpscalerFactory {
     static std::unique_ptr<HipUpscaler> create_upscaler(Technology tech, Quality q);
 };
 
-// trait FrameInterpolator shape (interpolation/mod.rs:29-44).
+// InterpolationQuality (interpolation/mod.rs:6-15).
+enum class InterpolationQuality : int { High = 0, Medium = 1, Low = 2 };
+
+// trait FrameInterpolator (interpolation/mod.rs:29-44): initialize(width, height), interpolate(frame1, frame2, t),
+// name, set_quality, quality.  `interpolate` keeps the live pyclass's argument list (dimensions per call, optional
+// flow: wgpu_interpolator.rs:215-225), of which the trait's is the special case "dimensions from initialize, no flow":
+// interpolate_frames.
 class FrameInterpolator {
 public:
     virtual ~FrameInterpolator() = default;
+    virtual int initialize(uint32_t width, uint32_t height) = 0;
     virtual int interpolate(const uint8_t *a, size_t a_len, const uint8_t *b, size_t b_len, const float *flow,
                             uint32_t w, uint32_t h, float t, uint8_t *out, size_t out_cap) = 0;
+    virtual int interpolate_frames(const uint8_t *frame1, size_t len1, const uint8_t *frame2, size_t len2, float t,
+                                   uint8_t *out, size_t out_cap) = 0;
     virtual const char *name() const = 0;
+    virtual int set_quality(InterpolationQuality q) = 0;
+    virtual InterpolationQuality quality() const = 0;
     virtual const char *last_error() const = 0;
 };
 
@@ -201,8 +223,18 @@ public:
     HipFrameInterpolator(const HipFrameInterpolator &) = delete;
     HipFrameInterpolator &operator=(const HipFrameInterpolator &) = delete;
 
+    // allocates the device buffers and pinned staging for width x height frames up front (interpolation/mod.rs:305-452
+    // builds its buffers here); calling it again with the same size is a no-op, as there
+    int initialize(uint32_t width, uint32_t height) override;
     int interpolate(const uint8_t *a, size_t a_len, const uint8_t *b, size_t b_len, const float *flow, uint32_t w,
                     uint32_t h, float t, uint8_t *out, size_t out_cap) override;
+    // the trait's own form: frames of the initialize() size, zero flow ("Interpolator not initialized" before it:
+    // interpolation/mod.rs:368-370)
+    int interpolate_frames(const uint8_t *frame1, size_t len1, const uint8_t *frame2, size_t len2, float t, uint8_t *out,
+                           size_t out_cap) override;
+    // the quality level is kept and reported; like the upscaler's (upscale/mod.rs:1072-1077) it does not change the arithmetic
+    int set_quality(InterpolationQuality q) override;
+    InterpolationQuality quality() const override { return quality_; }
     int interpolate_device(const void *d_a, size_t a_stride, const void *d_b, size_t b_stride, const void *d_flow,
                            uint32_t w, uint32_t h, float t, void *d_out, uint32_t n_pairs, hipStream_t stream);
     const char *name() const override { return "HipWarpBlendInterpolator"; }
@@ -221,6 +253,8 @@ private:
 
     mutable std::mutex mu_;
     int wg_preset_;
+    InterpolationQuality quality_ = InterpolationQuality::Medium;
+    uint32_t init_w_ = 0, init_h_ = 0; // initialize(): 0 = not called
     int device_ = 0;
     bool device_ready_ = false;
     int in_format_ = 0; // nus_pixel_format

@@ -102,6 +102,42 @@ int HipFrameInterpolator::ensure(size_t frame_bytes, bool with_flow)
     return kOk;
 }
 
+int HipFrameInterpolator::initialize(uint32_t width, uint32_t height)
+{
+    std::lock_guard<std::mutex> lk(mu_);
+    if (width == 0 || height == 0 || (uint64_t)width * height >= (1ull << 31))
+        return fail(kInvalidArgument, "initialize: bad dimensions");
+    if (init_w_ == width && init_h_ == height) return kOk; // interpolation/mod.rs:306-308
+    const int rc = ensure((size_t)width * height * 4, false);
+    if (rc != kOk) return rc;
+    init_w_ = width;
+    init_h_ = height;
+    error_.clear();
+    return kOk;
+}
+
+int HipFrameInterpolator::interpolate_frames(const uint8_t *frame1, size_t len1, const uint8_t *frame2, size_t len2, float t,
+                                             uint8_t *out, size_t out_cap)
+{
+    uint32_t w, h;
+    {
+        std::lock_guard<std::mutex> lk(mu_);
+        if (init_w_ == 0) return fail(kNotInitialized, "Interpolator not initialized"); // interpolation/mod.rs:368-370
+        w = init_w_;
+        h = init_h_;
+    }
+    return interpolate(frame1, len1, frame2, len2, nullptr, w, h, t, out, out_cap);
+}
+
+int HipFrameInterpolator::set_quality(InterpolationQuality q)
+{
+    std::lock_guard<std::mutex> lk(mu_);
+    if (q != InterpolationQuality::High && q != InterpolationQuality::Medium && q != InterpolationQuality::Low)
+        return fail(kInvalidArgument, "unknown interpolation quality");
+    quality_ = q;
+    return kOk;
+}
+
 int HipFrameInterpolator::interpolate(const uint8_t *a, size_t a_len, const uint8_t *b, size_t b_len, const float *flow,
                                       uint32_t w, uint32_t h, float t, uint8_t *out, size_t out_cap)
 {

@@ -24,6 +24,11 @@ struct LanczosX2Args {
     uint32_t iw, ih;
     uint32_t nstrips, nrowblocks, th;
     size_t in_frame_bytes, in_b_frame_bytes, out_frame_bytes; // byte strides between consecutive frames
+    // UNIT kernels only (one launch per pipeline step, see k_lanczos3_x2): second 4K output (the up-scaled in-between frames),
+    // the in-between frames themselves (may be null), frames of the launch and the order the waves walk them in
+    uint8_t *out_mid;
+    uint8_t *mid;
+    uint32_t nframes, order;
 };
 
 // Input rows of the x2 kernels.  BLEND 0: the frame itself.  BLEND 1 / 2: the zero-flow in-between
@@ -71,6 +76,9 @@ struct RowRaw<0> {
 #ifndef NUS_LZ_ABLATE
 #define NUS_LZ_ABLATE 0 // dev macro, timing only (wrong pixels): 1 no stores, 2 no arithmetic, 3 stores only (no loads either),
                         // 5 every row request goes to the first 16 rows of frame 0 (cache hits), 6 no lane exchange, 7 no pack
+#endif
+#if (NUS_LZ_ABLATE != 0 || !NUS_LZ_ASM_LOADS) && !defined(NUS_DEV_BUILD)
+#error "timing-only dev macros of k_lanczos3_x2 (wrong pixels / A-B forms) need -DNUS_DEV_BUILD: never in a product build"
 #endif
 constexpr int kLzDepth = NUS_LZ_DEPTH;
 static_assert(6 % kLzDepth == 0, "prefetch distance must divide 6");
@@ -194,6 +202,13 @@ __device__ __forceinline__ void cvt_row(const uint4 raw, float (&dst)[16])
 #ifndef NUS_OPAQUE_PATH
 #define NUS_OPAQUE_PATH 1 // dev macro: 0 builds the x2 kernel without the 3-channel path (A/B timing only)
 #endif
+#ifndef NUS_BLEND_OPAQUE_PATH
+#define NUS_BLEND_OPAQUE_PATH 1 // dev macro: 0 = the blend variants without the 3-channel path, as in round 2 (A/B timing only)
+#endif
+#if (!NUS_OPAQUE_PATH || !NUS_BLEND_OPAQUE_PATH) && !defined(NUS_DEV_BUILD)
+#error "timing-only dev macros of k_lanczos3_x2 need -DNUS_DEV_BUILD: never in a product build"
+#endif
+#define NUS_LZ_BLEND_OPAQUE_PATH_OK(BLEND) ((BLEND) == 0 || NUS_BLEND_OPAQUE_PATH != 0)
 __device__ __forceinline__ uint32_t row_is_opaque(const uint4 raw)
 {
 #if !NUS_OPAQUE_PATH
@@ -338,21 +353,41 @@ __device__ __forceinline__ void lanczos_x2_store(const uint32_t (&o)[8], __amdgp
 // wave waits for it: the odd stores of step S-D (2), D-1 whole steps (4 + NL each) and, if the wait comes
 // after them, this step's even stores (2): N = 4 D + (D - 1) NL - (early ? 2 : 0).  Besides the row the wait
 // only covers stores at least D steps old.
-template <bool EXACT, int BLEND, int S>
+//
+// UNIT kernels (the in-between frames are an output too): one more store per step, the row just resolved (row r+3, while it
+// belongs to this wave's row block: MidStore), between the even stores and the requests -- M = 1 more instruction per
+// whole step in the count: N = 4 D + (D - 1)(NL + M) - (early ? 2 : 0).
+struct MidStore {
+    __amdgpu_buffer_rsrc_t rs; // the in-between frame (num_records 0 in the real-frame role and without a buffer: every store dropped)
+    uint32_t lane_off;         // this lane's 16 B inside a row; 2^31 for halo lanes and lanes beyond the image
+    int r_end;                 // rows below r_end are the wave's own
+};
+
+template <bool UNIT>
+__device__ __forceinline__ void lanczos_x2_store_mid(const uint4 px, const MidStore &ms, int row, uint32_t row_bytes_in)
+{
+    if constexpr (UNIT) {
+        // not the wave's row: an offset that stays out of range (and below 2^32) with either kind of lane_off added
+        const uint32_t row_off = row < ms.r_end ? (uint32_t)row * row_bytes_in : 0x7FFFFFF0u;
+        u32x4 v = {px.x, px.y, px.z, px.w};
+        __builtin_amdgcn_raw_buffer_store_b128(v, ms.rs, row_off + ms.lane_off, 0, NUS_STORE_AUX);
+    }
+}
+
+template <bool EXACT, int BLEND, bool UNIT, int S>
 __device__ __forceinline__ void lanczos_x2_step(float (&win)[6][16], const RowRing<BLEND> &ring, RowRaw<BLEND> (&raw)[2],
                                                 uint32_t &opaque, int r, uint32_t in_off, const RowStore &st,
                                                 const LanczosX2Args &A, const PhaseWeights &W, const uint8_t *src,
-                                                const uint8_t *src_b, __amdgpu_buffer_rsrc_t rs)
+                                                const uint8_t *src_b, __amdgpu_buffer_rsrc_t rs, float t, const MidStore &ms)
 {
-    constexpr int D = kLzDepth, NL = BLEND ? 2 : 1;
+    constexpr int D = kLzDepth, NL = BLEND ? 2 : 1, M = UNIT ? 1 : 0;
     constexpr bool HIDDEN = NUS_LZ_ASM_LOADS != 0, EARLY = HIDDEN && NUS_LZ_WAIT_EARLY != 0;
     const uint32_t row_bytes = A.iw * 8; // output row: 2*iw pixels
     const uint32_t off0 = (uint32_t)(2 * r) * row_bytes;
     const bool interior = r >= 4 && r + 5 <= (int)A.ih; // wave-uniform
-    // The 3-channel path is compiled into the plain FMA-mode kernel only: there it measures -6 % on opaque
-    // frames (profiles/r01_lanczos_opaque_path_ab.txt); in the blend variants the second code path costs
-    // the third wave per SIMD (175 VGPRs) and more than it saves, and EXACT is the register-hungry debug mode.
-    constexpr bool OP = !EXACT && BLEND == 0;
+    // The 3-channel path is compiled into the FMA-mode kernels (plain and blend variants: 164 - 166 VGPRs, three waves per SIMD
+    // since the LDS-DMA ring took the in-flight rows out of the registers); EXACT is the register-hungry verification mode.
+    constexpr bool OP = !EXACT && NUS_LZ_BLEND_OPAQUE_PATH_OK(BLEND);
     float V[16];
     uint32_t o[8];
     RowRaw<BLEND> next; // row r+3
@@ -366,14 +401,14 @@ __device__ __forceinline__ void lanczos_x2_step(float (&win)[6][16], const RowRi
         lanczos_x2_vpass<EXACT, S, true>(win, W.e, V);
 #if NUS_LZ_ABLATE == 1
     if (EARLY) {
-        wait_vmcnt<(D - 1) * NL, (D - 1) * NL + 1>();
+        wait_vmcnt<(D - 1) * (NL + M), (D - 1) * NL + 1>();
         next = ring.read(S % D);
     }
 #elif NUS_LZ_ABLATE == 3
     next = RowRaw<BLEND>{};
 #else
     if (EARLY) {
-        wait_vmcnt<4 * D + (D - 1) * NL - 2, (D - 1) * NL + 1>();
+        wait_vmcnt<4 * D + (D - 1) * (NL + M) - 2, (D - 1) * NL + 1>();
         next = ring.read(S % D);
     }
 #endif
@@ -384,14 +419,15 @@ __device__ __forceinline__ void lanczos_x2_step(float (&win)[6][16], const RowRi
     lanczos_x2_store(o, rs, st, off0); // after the paths have joined: straight-line code holds every memory instruction
     // row r+3 in, then request row r+3+D into the same slot
     if (HIDDEN && !EARLY) {
-        wait_vmcnt<4 * D + (D - 1) * NL, (D - 1) * NL + 1>();
+        wait_vmcnt<4 * D + (D - 1) * (NL + M), (D - 1) * NL + 1>();
         next = ring.read(S % D);
     }
     if (!HIDDEN) next = raw[S & 1];
     {
-        const uint4 px = resolve_row<BLEND>(next, A.t, A.sel);
+        const uint4 px = resolve_row<BLEND>(next, t, A.sel);
         if (OP) opaque = (opaque << 1) | row_is_opaque(px);
         cvt_row(px, win[S % 6]);
+        lanczos_x2_store_mid<UNIT>(px, ms, r + 3, A.iw * 4);
     }
     {
         int rn = r + 3 + (HIDDEN ? D : 2);
@@ -438,25 +474,71 @@ __device__ __forceinline__ void lanczos_x2_step(float (&win)[6][16], const RowRi
 // so every input byte is read once per strip-row-block and no workgroup barrier is needed.
 // The 8 left-most and right-most output columns (renormalised edge weights) belong to
 // k_lanczos3_x2_edges, which is launched behind this kernel and overwrites what it wrote there.
-template <bool EXACT, int BLEND>
+//
+// UNIT = true (BLEND 1 / 2 only): ONE launch does a whole pipeline step over a batch of pairs (A_k, B_k) -- the up-scaled real
+// frame, the up-scaled in-between frame and the in-between frame itself -- with the very same instruction stream.  Every
+// (frame, row block, strip) is walked by two waves, and what tells them apart sits in SGPRs only:
+//   role 0 (real frame)      : both row streams come from A_k (the blend of a row with itself is the row: v_lerp_u8(a, a) = a,
+//                              and t = 0 at BLEND 2), output to A.out, in-between stores dropped (num_records 0);
+//   role 1 (in-between frame): rows of A_k and B_k blended on load as in the BLEND kernels, output to A.out_mid, and each
+//                              resolved row of the wave's own block stored to A.mid.
+// The two waves of a (frame, row block, strip) run side by side (consecutive workgroups of one XCD), so A_k's rows reach the
+// second of them from cache, and with order = 1 (row-block-major) so do the rows of B_k = A_(k+1): the step reads every input
+// row from HBM about once where three launches (blend, upscale, upscale) read it four times, and writes nothing twice.
+template <bool EXACT, int BLEND, bool UNIT>
 __global__ __launch_bounds__(256) void k_lanczos3_x2(const LanczosX2Args A)
 {
+    static_assert(!UNIT || BLEND != 0, "the unit kernel is a blend kernel whose real-frame role blends a row with itself");
     const int lane = threadIdx.x & (kWave - 1);
     // each XCD gets a contiguous run of (frame, row block, strips): neighbouring waves' halo rows and columns in its L2
     const uint32_t vid = xcd_contiguous_id(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
-    const uint32_t frame = vid / gridDim.x;
-    const uint32_t wave = __builtin_amdgcn_readfirstlane((vid % gridDim.x) * 4 + (threadIdx.x >> 6));
-    if (wave >= A.nstrips * A.nrowblocks) return;
-    const uint32_t strip = wave % A.nstrips;
-    const uint32_t rb = wave / A.nstrips;
+    uint32_t frame, strip, rb, role = 0;
+    if constexpr (UNIT) {
+        // 1-D grid over nframes x nrowblocks x 2 roles x nstrips waves
+        const uint32_t gw = __builtin_amdgcn_readfirstlane(vid * 4 + (threadIdx.x >> 6));
+        const uint32_t per_rb = 2 * A.nstrips; // waves of one (frame, row block): the strips of role 0, then those of role 1
+        if (gw >= per_rb * A.nrowblocks * A.nframes) return;
+        const uint32_t grp = gw / per_rb, in_grp = gw % per_rb;
+        if (A.order == 0) { // frame-major: row blocks of a frame in a run (vertical neighbours share their halo rows in L2)
+            frame = grp / A.nrowblocks;
+            rb = grp % A.nrowblocks;
+        } else { // row-block-major: the same row block of consecutive frames in a run (B_k = A_(k+1) shared as well)
+            rb = grp / A.nframes;
+            frame = grp % A.nframes;
+        }
+        role = in_grp / A.nstrips;
+        strip = in_grp % A.nstrips;
+    } else {
+        frame = vid / gridDim.x;
+        const uint32_t wave = __builtin_amdgcn_readfirstlane((vid % gridDim.x) * 4 + (threadIdx.x >> 6));
+        if (wave >= A.nstrips * A.nrowblocks) return;
+        strip = wave % A.nstrips;
+        rb = wave / A.nstrips;
+    }
     const int c = (int)(strip * kLanczosX2StripCols) - 4 + lane * 4; // first input column of this lane
     int cl = c < 0 ? 0 : c;
     cl = cl > (int)A.iw - 4 ? (int)A.iw - 4 : cl;
     const uint8_t *src = A.in + (size_t)frame * A.in_frame_bytes;
     const uint8_t *src_b = BLEND ? A.in_b + (size_t)frame * A.in_b_frame_bytes : src;
+    float t = A.t;
+    uint8_t *out = A.out;
+    MidStore ms;
+    if constexpr (UNIT) {
+        const bool real = role == 0; // wave-uniform
+        src_b = real ? src : src_b;
+        t = real ? 0.0f : t; // BLEND 2: 1 * a + 0 * a = a exactly
+        out = real ? A.out : A.out_mid;
+        const bool owner = lane >= 1 && lane <= (int)(kLanczosX2StripCols / 4) && c >= 0 && c + 4 <= (int)A.iw;
+        ms.lane_off = owner ? (uint32_t)c * 4u : 0x80000000u;
+        ms.rs = __builtin_amdgcn_make_buffer_rsrc(A.mid + (size_t)frame * A.in_frame_bytes, 0,
+                                                  real || A.mid == nullptr ? 0u : A.iw * A.ih * 4u, 0x00020000);
+    } else {
+        ms.lane_off = 0;
+        ms.rs = __builtin_amdgcn_make_buffer_rsrc(nullptr, 0, 0, 0x00020000);
+    }
     // one buffer resource per output frame (< 2 GiB, checked by the host)
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-        A.out + (size_t)frame * A.out_frame_bytes, 0, (uint32_t)A.out_frame_bytes, 0x00020000);
+        out + (size_t)frame * A.out_frame_bytes, 0, (uint32_t)A.out_frame_bytes, 0x00020000);
     // lane L computes the 8 output pixels of input columns c .. c+3; it stores them unless it is a halo lane or its
     // columns are the edge kernel's
 #ifndef NUS_LZ_ALIGNED_STORES
@@ -497,6 +579,7 @@ __global__ __launch_bounds__(256) void k_lanczos3_x2(const LanczosX2Args A)
     const int r0 = (int)(rb * A.th);
     const int r_end = (r0 + (int)A.th) < (int)A.ih ? (r0 + (int)A.th) : (int)A.ih;
     const int rmax = (int)A.ih - 1;
+    ms.r_end = r_end;
     auto row_off = [&](int rr) {
         rr = rr < 0 ? 0 : (rr > rmax ? rmax : rr);
         return in_off + (uint32_t)rr * (A.iw * 4);
@@ -541,9 +624,10 @@ __global__ __launch_bounds__(256) void k_lanczos3_x2(const LanczosX2Args A)
         }
 #pragma unroll
         for (int j = 0; j < 6; ++j) {
-            const uint4 px = resolve_row<BLEND>(first[j], A.t, A.sel);
-            if (!EXACT && BLEND == 0) opaque = (opaque << 1) | row_is_opaque(px);
+            const uint4 px = resolve_row<BLEND>(first[j], t, A.sel);
+            if (!EXACT && NUS_LZ_BLEND_OPAQUE_PATH_OK(BLEND)) opaque = (opaque << 1) | row_is_opaque(px);
             cvt_row(px, win[j]);
+            if (j >= 3) lanczos_x2_store_mid<UNIT>(px, ms, r0 - 3 + j, A.iw * 4); // rows r0 .. r0+2 (the loop stores r0+3 ..)
         }
         // the hand-counted waits of the loop assume that nothing older than its own instructions is outstanding
         if (HIDDEN) wait_vmcnt<0, 0>();
@@ -553,7 +637,7 @@ __global__ __launch_bounds__(256) void k_lanczos3_x2(const LanczosX2Args A)
         // after its last row: a step is never skipped with a later one still to run, so every path through
         // the loop carries the vector memory instructions the hand-counted waits assume.
 #define NUS_LZ_STEP(S) \
-        lanczos_x2_step<EXACT, BLEND, S>(win, ring, raw, opaque, rbase + S, in_off, st, A, W, src, src_b, rs); \
+        lanczos_x2_step<EXACT, BLEND, UNIT, S>(win, ring, raw, opaque, rbase + S, in_off, st, A, W, src, src_b, rs, t, ms); \
         if (S < 5 && rbase + S + 1 >= r_end) break
         NUS_LZ_STEP(0);
         NUS_LZ_STEP(1);
@@ -672,7 +756,7 @@ __global__ __launch_bounds__(64) void k_lanczos3_x2_edges(const LanczosX2EdgeArg
 
 hipError_t launch_lanczos_x2(const UpscaleLaunch &L, const DeviceTables &T, bool exact, uint32_t rows_per_wave)
 {
-    LanczosX2Args A;
+    LanczosX2Args A{};
     A.wy6 = T.lz_wy6;
     for (int j = 0; j < 6; ++j) {
         A.wxe[j] = T.lz_wxe[j];
@@ -695,7 +779,7 @@ hipError_t launch_lanczos_x2(const UpscaleLaunch &L, const DeviceTables &T, bool
         A.in_b = L.in_b ? L.in_b + chunk_first_frame(L, in) * L.in_b_stride : nullptr;
         A.out = out;
         const dim3 block(256), grid(cdiv(nwaves, 4), n);
-#define NUS_LZ(E, B) hipLaunchKernelGGL((k_lanczos3_x2<E, B>), grid, block, 0, L.stream, A)
+#define NUS_LZ(E, B) hipLaunchKernelGGL((k_lanczos3_x2<E, B, false>), grid, block, 0, L.stream, A)
         if (exact) {
             if (blend == 0) NUS_LZ(true, 0); else if (blend == 1) NUS_LZ(true, 1); else NUS_LZ(true, 2);
         } else {
@@ -704,6 +788,50 @@ hipError_t launch_lanczos_x2(const UpscaleLaunch &L, const DeviceTables &T, bool
 #undef NUS_LZ
     });
     return e;
+}
+
+// One pipeline step in one launch (see k_lanczos3_x2, UNIT): L.in / L.in_b are the frames A_k / B_k of the pairs, L.out the
+// up-scaled real frames, U.out_mid the up-scaled in-between frames, U.mid the in-between frames themselves (may be null).
+// Follow it with launch_lanczos_x2_edges for both outputs.
+hipError_t launch_lanczos_x2_unit(const UpscaleLaunch &L, const DeviceTables &T, bool exact, uint32_t rows_per_wave,
+                                  const UnitOutputs &U)
+{
+    if (L.in_b == nullptr || U.out_mid == nullptr) return hipErrorInvalidValue;
+    LanczosX2Args A{};
+    A.wy6 = T.lz_wy6;
+    for (int j = 0; j < 6; ++j) {
+        A.wxe[j] = T.lz_wxe[j];
+        A.wxo[j] = T.lz_wxo[j];
+    }
+    A.iw = L.iw;
+    A.ih = L.ih;
+    A.nstrips = cdiv(L.iw, kLanczosX2StripCols);
+    A.th = rows_per_wave ? rows_per_wave : 32;
+    A.nrowblocks = cdiv(L.ih, A.th);
+    A.in_frame_bytes = L.in_stride ? L.in_stride : (size_t)L.iw * L.ih * 4;
+    A.in_b_frame_bytes = L.in_b_stride;
+    A.out_frame_bytes = (size_t)L.ow * L.oh * 4;
+    A.t = L.blend_t;
+    A.sel = L.in_sel;
+    A.in = L.in;
+    A.in_b = L.in_b;
+    A.out = L.out;
+    A.out_mid = U.out_mid;
+    A.mid = U.mid;
+    A.nframes = L.n_frames;
+    A.order = U.order;
+    const uint64_t nwaves = (uint64_t)2 * A.nstrips * A.nrowblocks * L.n_frames;
+    if (nwaves / 4 + 1 >= (1ull << 31)) return hipErrorInvalidValue;
+    const dim3 block(256), grid((uint32_t)((nwaves + 3) / 4));
+    const bool half = L.blend_t == 0.5f;
+#define NUS_LZU(E, B) hipLaunchKernelGGL((k_lanczos3_x2<E, B, true>), grid, block, 0, L.stream, A)
+    if (exact) {
+        if (half) NUS_LZU(true, 1); else NUS_LZU(true, 2);
+    } else {
+        if (half) NUS_LZU(false, 1); else NUS_LZU(false, 2);
+    }
+#undef NUS_LZU
+    return hipGetLastError();
 }
 
 hipError_t launch_lanczos_x2_edges(const UpscaleLaunch &L, const DeviceTables &T, bool exact)

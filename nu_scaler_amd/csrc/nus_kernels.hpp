@@ -120,6 +120,17 @@ hipError_t launch_lanczos_x2(const UpscaleLaunch &L, const DeviceTables &T, bool
                              uint32_t rows_per_wave);
 
 hipError_t launch_lanczos_x2_edges(const UpscaleLaunch &L, const DeviceTables &T, bool exact);
+// One pipeline step over n_frames pairs (L.in = A_k, L.in_b = B_k) in ONE launch of the x2 kernel: L.out = the up-scaled real
+// frames, out_mid = the up-scaled in-between frames (blend of the pair at L.blend_t), mid = the in-between frames themselves
+// (n_frames tightly packed input-size frames; may be null).  order: 0 = frame-major, 1 = row-block-major wave order.
+// Main kernel only: follow it with launch_lanczos_x2_edges for both outputs.
+struct UnitOutputs {
+    uint8_t *out_mid = nullptr;
+    uint8_t *mid = nullptr;
+    uint32_t order = 1;
+};
+hipError_t launch_lanczos_x2_unit(const UpscaleLaunch &L, const DeviceTables &T, bool exact, uint32_t rows_per_wave,
+                                  const UnitOutputs &U);
 // exact x3 / x4 (factor): main kernel only, the first / last 4 * factor output columns are NOT written;
 // follow it with launch_lanczos_xs_edges(L, T, exact, factor).
 hipError_t launch_lanczos_xs(const UpscaleLaunch &L, const DeviceTables &T, bool exact, uint32_t factor,

@@ -67,6 +67,34 @@ class WgpuFrameInterpolator:
         self._raise(st)
         return out
 
+    # -- trait FrameInterpolator (nu_scaler_core/src/interpolation/mod.rs:29-44; dead code in the reference, same shape here)
+    def initialize(self, width: int, height: int) -> None:
+        self._raise(self._lib.nus_interp_initialize(self._h, int(width), int(height)))
+
+    def interpolate(self, frame1, frame2, t: float) -> bytes:
+        """Frames of the initialize() size, zero flow; RuntimeError("Interpolator not initialized") before it."""
+        a_addr, a_len, ka = _as_buffer(frame1)
+        b_addr, b_len, kb = _as_buffer(frame2)
+        out, oarr, oaddr = _out_buffer(a_len)
+        st = self._lib.nus_interp_interpolate_frames(self._h, a_addr, a_len, b_addr, b_len, float(t), oaddr, a_len)
+        del oarr, ka, kb
+        self._raise(st)
+        return out
+
+    @property
+    def name(self) -> str:
+        return self._lib.nus_interp_name(self._h).decode()
+
+    _QUALITY = {"high": 0, "medium": 1, "low": 2}
+
+    def set_quality(self, quality) -> None:
+        q = self._QUALITY.get(str(quality).lower(), quality)
+        self._raise(self._lib.nus_interp_set_quality(self._h, int(q)))
+
+    @property
+    def quality(self) -> str:
+        return ("high", "medium", "low")[self._lib.nus_interp_quality(self._h)]
+
     def interpolate_device(self, d_a: int, a_stride: int, d_b: int, b_stride: int, d_flow: int, width: int,
                            height: int, time_t: float, d_out: int, n_pairs: int = 1, stream: int = 0) -> None:
         self._raise(self._lib.nus_interp_interpolate_device(self._h, d_a, a_stride, d_b, b_stride, d_flow or None,

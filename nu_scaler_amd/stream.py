@@ -153,6 +153,16 @@ class FramePipeline:
         self.upscaler.upscale_device(base, up_real.data_ptr(), n, stream)
         self.upscaler.upscale_blend_device(base, fb, base + fb, fb, self.t, up_mid.data_ptr(), n, stream)
 
+    def step_unit(self, frames, mid, up_real, up_mid, stream: int = 0) -> None:
+        """The same three outputs as `step` from ONE launch of the x2 resize kernel (plus the two edge-column passes): two waves
+        per (frame, row block, strip) side by side, one up-scaling frame k, one blending frames k and k+1 on load, storing
+        the in-between rows and up-scaling them (nus_upscaler_upscale_unit_device).  Bit-identical to `step`."""
+        n = up_real.shape[0]
+        base = frames.data_ptr()
+        fb = self.frame_bytes
+        self.upscaler.upscale_unit_device(base, fb, base + fb, fb, self.t, 0 if mid is None else mid.data_ptr(),
+                                          up_real.data_ptr(), up_mid.data_ptr(), n, stream)
+
     def step_motion(self, frames, flows, mid, up_real, up_mid, stream: int = 0, levels: int = 3,
                     coarse_iterations: int = 50, refine_iterations: int = 10) -> None:
         """Motion-compensated variant of `step`: a dense flow per pair from the

@@ -51,14 +51,23 @@ def _as_buffer(data):
     return ctypes.addressof(arr), len(mv), (arr, mv)
 
 
+_PyBytes_FromStringAndSize = ctypes.pythonapi.PyBytes_FromStringAndSize
+_PyBytes_FromStringAndSize.restype = ctypes.py_object
+_PyBytes_FromStringAndSize.argtypes = [ctypes.c_char_p, ctypes.c_ssize_t]
+_PyBytes_AsString = ctypes.pythonapi.PyBytes_AsString
+_PyBytes_AsString.restype = ctypes.c_void_p
+_PyBytes_AsString.argtypes = [ctypes.py_object]
+
+
 def _out_buffer(size: int):
-    """Fresh output buffer the C side writes into: (bytes, keepalive, address).  The bytes object is
-    allocated zero-filled (calloc) and filled in place before anyone else can see it -- what pyo3's
-    PyBytes::new does with one copy less -- so returning it costs no second 33 MB copy."""
-    out = bytes(size)
+    """Fresh output `bytes` the C side fills: (bytes, keepalive, address).  The CPython idiom for building a bytes object in
+    place -- PyBytes_FromStringAndSize(NULL, n) returns an uninitialised object "whose contents may be filled in" through
+    PyBytes_AsString as long as nobody else holds a reference yet -- which is what pyo3's PyBytes::new_with does for the
+    reference's own return value; no second 33 MB copy, and no write through a pointer to an object that is already shared."""
     if size == 0:
-        return out, None, None
-    return out, out, ctypes.cast(ctypes.c_char_p(out), ctypes.c_void_p).value
+        return b"", None, None
+    out = _PyBytes_FromStringAndSize(None, size)
+    return out, out, _PyBytes_AsString(out)
 
 
 class PyWgpuUpscaler:
@@ -145,6 +154,12 @@ class PyWgpuUpscaler:
         """Fused zero-flow interpolate + upscale of the in-between frame (exact-x2 resize kernels)."""
         self._check(self._lib.nus_upscaler_upscale_blend_device(self._h, d_a, a_stride, d_b, b_stride, float(time_t),
                                                                 d_out, n_frames, stream or None))
+
+    def upscale_unit_device(self, d_a: int, a_stride: int, d_b: int, b_stride: int, time_t: float, d_mid: int,
+                            d_out_real: int, d_out_mid: int, n_units: int = 1, stream: int = 0) -> None:
+        """One pipeline step in one launch: upscale(A), blend(A, B) (d_mid, 0 = not wanted) and upscale(blend(A, B))."""
+        self._check(self._lib.nus_upscaler_upscale_unit_device(self._h, d_a, a_stride, d_b, b_stride, float(time_t),
+                                                               d_mid or None, d_out_real, d_out_mid, n_units, stream or None))
 
     # -- wgpu-only knobs: accepted and ignored (lib.rs:115-137)
     def reload_shader(self, path: str) -> None:

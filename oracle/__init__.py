@@ -65,6 +65,8 @@ def lib() -> ctypes.CDLL:
         L.orc_bilinear_mt.restype = None
         L.orc_lanczos3_mt.argtypes = up + [ctypes.c_int]
         L.orc_lanczos3_mt.restype = ctypes.c_int
+        L.orc_resize_mt.argtypes = up + [ctypes.c_int, ctypes.c_int]
+        L.orc_resize_mt.restype = ctypes.c_int
         L.orc_warp_blend_mt.argtypes = [u8p, u8p, u8p, u32, u32, ctypes.c_float, u8p, ctypes.c_int]
         L.orc_warp_blend_mt.restype = None
         f32p = ctypes.c_void_p
@@ -134,8 +136,10 @@ def bilinear_wgsl(img, ow, oh):
     return _upscale(lib().orc_bilinear_wgsl, img, ow, oh)
 
 
-def resize(img, ow, oh, filt: int = FILTER_LANCZOS3):
-    return _upscale(lib().orc_resize, img, ow, oh, filt)
+def resize(img, ow, oh, filt: int = FILTER_LANCZOS3, threads: int = 1):
+    if threads == 1:
+        return _upscale(lib().orc_resize, img, ow, oh, filt)
+    return _upscale(lib().orc_resize_mt, img, ow, oh, filt, threads)
 
 
 def lanczos3(img, ow, oh, threads: int = 1):

@@ -278,8 +278,7 @@ static int resize_impl(const uint8_t *in, uint32_t iw, uint32_t ih,
     float *tmp = (float *)malloc((size_t)iw * oh * 4 * sizeof(float));
     if (!tmp) return -1;
     int rc = 0;
-    (void)threads;
-#pragma omp parallel for schedule(static) num_threads(threads) if (threads > 1)
+    (void)threads; /* always the one-thread loop: the many-core baseline is resize_rows_mt below */
     for (uint32_t oy = 0; oy < oh; ++oy) {
         float ws[ORC_MAX_TAPS];
         int32_t left;
@@ -303,7 +302,6 @@ static int resize_impl(const uint8_t *in, uint32_t iw, uint32_t ih,
     /* horizontal_sample: f32 image (iw x oh) -> u8 image (ow x oh), clamp then
      * round-to-nearest (f32::round: half away from zero).  Loop order as in the
      * crate: outx outermost (weights computed once per output column), y inside. */
-#pragma omp parallel for schedule(static) num_threads(threads) if (threads > 1)
     for (uint32_t ox = 0; ox < ow; ++ox) {
         float ws[ORC_MAX_TAPS];
         int32_t left;
@@ -327,6 +325,102 @@ static int resize_impl(const uint8_t *in, uint32_t iw, uint32_t ih,
         }
     }
     free(tmp);
+    return rc;
+}
+
+/* The all-cores form of the CPU baseline (bench.py's cpu_baseline.all_cores; orc_*_mt with threads != 1): the same two passes,
+ * the same operations in the same order per output sample -- so the same bits as resize_impl (asserted over sizes, filters and
+ * thread counts in tests/test_oracle_golden.py) -- laid out for many cores: every thread takes a block of OUTPUT ROWS, runs the
+ * vertical pass of a row into its own f32 row (iw x 4 floats, cache resident) and the horizontal pass straight out of it, with
+ * the per-column windows and weights computed once up front.  resize_impl itself (one thread, the crate's loop order: whole
+ * f32 intermediate image, output column outermost) stays as the oracle; its OpenMP pragmas walked that column-major loop with
+ * every thread striding through the whole f32 image, and 128 cores gave 1.6x. */
+static int resize_rows_mt(const uint8_t *in, uint32_t iw, uint32_t ih, uint8_t *out, uint32_t ow, uint32_t oh, int filter,
+                          int threads)
+{
+    float (*kernel)(float);
+    float support;
+    if (filter_params(filter, &kernel, &support)) return -1;
+    if (iw == 0 || ih == 0 || ow == 0 || oh == 0) return -1;
+    if (iw == ow && ih == oh) {
+        memcpy(out, in, (size_t)iw * ih * 4);
+        return 0;
+    }
+    /* horizontal windows: widest first, then left / count / weights per output column */
+    uint32_t maxn = 0;
+    {
+        float ws[ORC_MAX_TAPS];
+        int32_t left;
+        for (uint32_t ox = 0; ox < ow; ++ox) {
+            uint32_t n = axis_taps(iw, ow, ox, kernel, support, &left, ws, ORC_MAX_TAPS);
+            if (n > ORC_MAX_TAPS) return -1;
+            if (n > maxn) maxn = n;
+        }
+    }
+    int32_t *hl = (int32_t *)malloc((size_t)ow * sizeof(int32_t));
+    uint32_t *hn = (uint32_t *)malloc((size_t)ow * sizeof(uint32_t));
+    float *hw = (float *)malloc((size_t)ow * maxn * sizeof(float));
+    if (!hl || !hn || !hw) { free(hl); free(hn); free(hw); return -1; }
+    for (uint32_t ox = 0; ox < ow; ++ox) {
+        float ws[ORC_MAX_TAPS];
+        hn[ox] = axis_taps(iw, ow, ox, kernel, support, &hl[ox], ws, ORC_MAX_TAPS);
+        memcpy(hw + (size_t)ox * maxn, ws, hn[ox] * sizeof(float));
+    }
+    int rc = 0;
+#pragma omp parallel num_threads(threads)
+    {
+        float *row = (float *)malloc((size_t)iw * 4 * sizeof(float));
+        if (!row) {
+#pragma omp atomic write
+            rc = -1;
+        }
+#pragma omp for schedule(static)
+        for (uint32_t oy = 0; oy < oh; ++oy) {
+            if (!row) continue;
+            float ws[ORC_MAX_TAPS];
+            int32_t left;
+            uint32_t n = axis_taps(ih, oh, oy, kernel, support, &left, ws, ORC_MAX_TAPS);
+            if (n > ORC_MAX_TAPS) {
+#pragma omp atomic write
+                rc = -1;
+                continue;
+            }
+            for (uint32_t x = 0; x < iw; ++x) { /* vertical_sample of this row, as in resize_impl */
+                float t0 = 0.0f, t1 = 0.0f, t2 = 0.0f, t3 = 0.0f;
+                for (uint32_t i = 0; i < n; ++i) {
+                    const uint8_t *p = in + ((size_t)(left + (int32_t)i) * iw + x) * 4;
+                    float w = ws[i];
+                    t0 += (float)p[0] * w;
+                    t1 += (float)p[1] * w;
+                    t2 += (float)p[2] * w;
+                    t3 += (float)p[3] * w;
+                }
+                float *q = row + (size_t)x * 4;
+                q[0] = t0; q[1] = t1; q[2] = t2; q[3] = t3;
+            }
+            for (uint32_t ox = 0; ox < ow; ++ox) { /* horizontal_sample of this row */
+                const float *w6 = hw + (size_t)ox * maxn;
+                const uint32_t hnn = hn[ox];
+                const int32_t l = hl[ox];
+                float t0 = 0.0f, t1 = 0.0f, t2 = 0.0f, t3 = 0.0f;
+                for (uint32_t i = 0; i < hnn; ++i) {
+                    const float *p = row + (size_t)(l + (int32_t)i) * 4;
+                    float w = w6[i];
+                    t0 += p[0] * w;
+                    t1 += p[1] * w;
+                    t2 += p[2] * w;
+                    t3 += p[3] * w;
+                }
+                uint8_t *o = out + ((size_t)oy * ow + ox) * 4;
+                o[0] = (uint8_t)roundf(f32_clamp(t0, 0.0f, 255.0f));
+                o[1] = (uint8_t)roundf(f32_clamp(t1, 0.0f, 255.0f));
+                o[2] = (uint8_t)roundf(f32_clamp(t2, 0.0f, 255.0f));
+                o[3] = (uint8_t)roundf(f32_clamp(t3, 0.0f, 255.0f));
+            }
+        }
+        free(row);
+    }
+    free(hl); free(hn); free(hw);
     return rc;
 }
 
@@ -740,10 +834,16 @@ void orc_bilinear_mt(const uint8_t *in, uint32_t iw, uint32_t ih,
     ROW_PARALLEL(oh, threads, bilinear_rows(in, iw, ih, out, ow, oh, y_begin, y_end));
 }
 
+int orc_resize_mt(const uint8_t *in, uint32_t iw, uint32_t ih,
+                  uint8_t *out, uint32_t ow, uint32_t oh, int filter, int threads)
+{
+    return resize_rows_mt(in, iw, ih, out, ow, oh, filter, pick_threads(threads));
+}
+
 int orc_lanczos3_mt(const uint8_t *in, uint32_t iw, uint32_t ih,
                     uint8_t *out, uint32_t ow, uint32_t oh, int threads)
 {
-    return resize_impl(in, iw, ih, out, ow, oh, 0, pick_threads(threads));
+    return resize_rows_mt(in, iw, ih, out, ow, oh, 0, pick_threads(threads));
 }
 
 void orc_warp_blend_mt(const uint8_t *a, const uint8_t *b, const float *flow,

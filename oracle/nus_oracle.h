@@ -99,6 +99,9 @@ void orc_bilinear_mt(const uint8_t *in, uint32_t iw, uint32_t ih,
                      uint8_t *out, uint32_t ow, uint32_t oh, int threads);
 int orc_lanczos3_mt(const uint8_t *in, uint32_t iw, uint32_t ih,
                     uint8_t *out, uint32_t ow, uint32_t oh, int threads);
+/* any filter of orc_resize; row blocks per thread, bit-identical to orc_resize (tests/test_oracle_golden.py) */
+int orc_resize_mt(const uint8_t *in, uint32_t iw, uint32_t ih,
+                  uint8_t *out, uint32_t ow, uint32_t oh, int filter, int threads);
 void orc_warp_blend_mt(const uint8_t *a, const uint8_t *b, const float *flow,
                        uint32_t w, uint32_t h, float t, uint8_t *out, int threads);
 int orc_max_threads(void);

@@ -89,6 +89,47 @@ impl HipFrameInterpolator {
         Ok(result.into())
     }
 
+    // -- the shape of `trait FrameInterpolator` (`interpolation/mod.rs:29-44`): initialize / interpolate / name / quality
+    fn initialize(&self, width: u32, height: u32) -> PyResult<()> {
+        let rc = unsafe { sys::nus_interp_initialize(self.h, width, height) };
+        if rc != sys::NUS_OK {
+            let msg = unsafe { CStr::from_ptr(sys::nus_interp_last_error(self.h)) }.to_string_lossy().into_owned();
+            return Err(PyRuntimeError::new_err(msg));
+        }
+        Ok(())
+    }
+
+    fn interpolate<'py>(&self, py: Python<'py>, frame1: &'py PyBytes, frame2: &'py PyBytes, t: f32) -> PyResult<Py<PyBytes>> {
+        let (a, b) = (frame1.as_bytes(), frame2.as_bytes());
+        let h = self.h;
+        let result = PyBytes::new_bound_with(py, a.len(), |out: &mut [u8]| {
+            let rc = unsafe { sys::nus_interp_interpolate_frames(h, a.as_ptr(), a.len(), b.as_ptr(), b.len(), t, out.as_mut_ptr(), out.len()) };
+            if rc != sys::NUS_OK {
+                let msg = unsafe { CStr::from_ptr(sys::nus_interp_last_error(h)) }.to_string_lossy().into_owned();
+                return Err(PyRuntimeError::new_err(msg)); // "Interpolator not initialized" before initialize()
+            }
+            Ok(())
+        })?;
+        Ok(result.into())
+    }
+
+    #[getter]
+    fn name(&self) -> String {
+        unsafe { CStr::from_ptr(sys::nus_interp_name(self.h)) }.to_string_lossy().into_owned()
+    }
+
+    fn set_quality(&self, quality: i32) -> PyResult<()> {
+        if unsafe { sys::nus_interp_set_quality(self.h, quality) } != sys::NUS_OK {
+            return Err(PyValueError::new_err("unknown interpolation quality"));
+        }
+        Ok(())
+    }
+
+    #[getter]
+    fn quality(&self) -> i32 {
+        unsafe { sys::nus_interp_quality(self.h) }
+    }
+
     /// `get_last_gpu_duration_ms` (`wgpu_interpolator.rs:494-497`): hipEvent time of the last warp + blend launch.
     fn get_last_gpu_duration_ms(&self) -> Option<f64> {
         let mut ms = 0.0f64;

@@ -207,6 +207,14 @@ def test_reference_interp_fixture(nsc, oracle_mod, golden):
     out = np.frombuffer(it.interpolate_py(a.tobytes(), b.tobytes(), 64, 64, time_t=0.5), np.uint8).reshape(64, 64, 4)
     assert np.array_equal(out, golden["interp_half"])
     assert it.get_last_gpu_duration_ms() is not None
+    # the same through the shape of trait FrameInterpolator (interpolation/mod.rs:29-44): initialize, then interpolate(f1, f2, t)
+    tr = nsc.WgpuFrameInterpolator()
+    tr.initialize(64, 64)
+    tr.initialize(64, 64)  # same size again: no-op
+    out = np.frombuffer(tr.interpolate(a.tobytes(), b.tobytes(), 0.5), np.uint8).reshape(64, 64, 4)
+    assert np.array_equal(out, golden["interp_half"])
+    with pytest.raises(ValueError, match="Expected 16384 bytes per frame for 64x64x4 RGBA"):
+        tr.interpolate(a.tobytes()[:-4], b.tobytes()[:-4], 0.5)
 
 
 def test_committed_oracle_vectors(nsc):

@@ -113,6 +113,38 @@ def test_interpolator_validation_without_gpu(nsc):
     nsc.WgpuFrameInterpolator("no-such-preset")  # defaults to Wide32x8 like the reference
 
 
+def test_interpolator_trait_shape_without_gpu(nsc):
+    """trait FrameInterpolator (interpolation/mod.rs:29-44): name, set_quality / quality, and interpolate before
+    initialize -> "Interpolator not initialized" (:368-370)."""
+    it = nsc.WgpuFrameInterpolator()
+    assert it.name == "HipWarpBlendInterpolator"
+    assert it.quality == "medium"
+    for q in ("high", "low", "medium"):
+        it.set_quality(q)
+        assert it.quality == q
+    with pytest.raises(RuntimeError, match="unknown interpolation quality"):
+        it.set_quality(7)
+    with pytest.raises(RuntimeError, match="Interpolator not initialized"):
+        it.interpolate(b"\0" * 64, b"\0" * 64, 0.5)
+    with pytest.raises(RuntimeError, match="bad dimensions"):
+        it.initialize(0, 4)
+
+
+def test_fresh_output_bytes_are_built_in_place(nsc):
+    """The output `bytes` of upscale / interpolate_py is created with PyBytes_FromStringAndSize(NULL, n) and filled
+    before anyone else sees it: a new object per call, of the right size, unrelated to earlier ones."""
+    from nu_scaler_amd.upscaler import _out_buffer
+
+    a, ka, addr_a = _out_buffer(1 << 16)
+    b, kb, addr_b = _out_buffer(1 << 16)
+    assert isinstance(a, bytes) and len(a) == 1 << 16 and a is not b and addr_a != addr_b
+    import ctypes
+
+    ctypes.memset(addr_a, 0x5A, len(a))
+    assert a == b"\x5a" * (1 << 16)
+    assert _out_buffer(0)[0] == b""
+
+
 @pytest.mark.skipif(os.environ.get("NUS_EXPECT_GPU") == "1", reason="GPU box")
 def test_no_cpu_fallback(nsc):
     """Without a HIP device the compute path must fail loudly, never fall back."""

@@ -121,3 +121,17 @@ def test_mt_variants_equal_single_thread(oracle_mod):
     assert np.array_equal(oracle_mod.nearest(img, 128, 72), oracle_mod.nearest(img, 128, 72, threads=4))
     a, b = img, oracle_mod.gen_noise(64, 36, 9)
     assert np.array_equal(oracle_mod.warp_blend(a, b, None, 0.5), oracle_mod.warp_blend(a, b, None, 0.5, threads=4))
+
+
+@pytest.mark.parametrize("filt", [0, 1, 2])
+def test_many_core_resize_is_bit_identical_to_the_oracle(oracle_mod, filt):
+    """bench.py's all-cores CPU baseline (orc_resize_mt / orc_lanczos3_mt: row blocks per thread, per-column weights
+    computed once, a per-thread f32 row) against the one-thread oracle loop: same bytes at every size, scale
+    direction and thread count."""
+    for (iw, ih, ow, oh) in [(64, 36, 128, 72), (97, 41, 194, 82), (120, 50, 77, 31), (33, 20, 100, 57), (48, 48, 48, 48)]:
+        img = oracle_mod.gen_noise(iw, ih, 1000 + iw)
+        want = oracle_mod.resize(img, ow, oh, filt)
+        for threads in (2, 3, 0):
+            assert np.array_equal(oracle_mod.resize(img, ow, oh, filt, threads=threads), want), (filt, iw, ih, ow, oh, threads)
+    big = oracle_mod.gen_gradient(640, 360, 3)
+    assert np.array_equal(oracle_mod.lanczos3(big, 1280, 720, threads=0), oracle_mod.lanczos3(big, 1280, 720))

@@ -15,7 +15,7 @@ for spec in "$@"; do
     git show "${flags#@}:$CS/$UNIT.hip" > tools/_ablate/src_$name.hip
     src=tools/_ablate/src_$name.hip; flags=""
   fi
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wno-unused-function -x hip -I$CS -Iinclude $flags \
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wno-unused-function -x hip -I$CS -Iinclude -DNUS_DEV_BUILD $flags \
       -c -o tools/_ablate/lz_$name.o $src &
 done
 wait
