@@ -17,9 +17,15 @@ the ranks find WORLD_SIZE in the environment; started directly (`python bench.py
 this process only starts that launcher as a CHILD, relays rank 0's JSON line and the exit
 code, and never touches the GPU itself.
 
+The timed step is the ONE-LAUNCH schedule (`--schedule unit`, nus_upscaler_upscale_unit_device): every (frame, row block,
+strip) is walked by two waves of k_lanczos3_x2 side by side -- one up-scaling frame k, one blending frames k and k+1 on load,
+storing the in-between rows and up-scaling them -- so all three outputs of a unit (the in-between frame and both 4K frames) come
+from one kernel; `--schedule three-stage` is the blend / upscale / upscale sequence of rounds 1-2 (same bytes out).
+
 Rank 0 prints ONE JSON line.  Inside it:
-  roofline       the dominant kernel (k_lanczos3_x2 + its edge-column pass), hipEvent pairs on
-                 the launch stream inside the timed region, against the 8 TB/s HBM peak;
+  roofline       the dominant launch (the unit kernel + its two edge-column passes), hipEvent pairs on the launch stream
+                 inside the timed region, algorithmic bytes of SURVEY.md section 8(d) against the 8 TB/s HBM peak; next to it
+                 `upscale_kernel_alone`: k_lanczos3_x2 by itself on the same frames (41 472 000 B per frame);
   cpu_baseline   the CPU oracle (a port of the reference's CPU algorithm -- the Rust reference
                  cannot be built here), per algorithm, median of 10 after 2 warm-ups;
   config.timed_output_check   frames of the TIMED output buffers compared with the oracle;
@@ -64,6 +70,8 @@ def parse_args(argv=None):
     ap.add_argument("--no-check", action="store_true", help="skip the oracle check of the timed output buffers")
     ap.add_argument("--sustained-seconds", type=float, default=6.0,
                     help="length of the sustained leg after the timed region (0 = skip; N=1 only)")
+    ap.add_argument("--schedule", choices=["unit", "three-stage"], default="unit",
+                    help="unit: the whole step in one launch of the x2 kernel (default); three-stage: blend, upscale, upscale")
     ap.add_argument("--fused", action="store_true",
                     help="blend inside the second upscale's row loads (in-between frame never written to HBM); "
                          "same output frames, reported separately from the default 3-stage step")
@@ -195,11 +203,12 @@ def cpu_baseline(args, unit_pixels):
     }
 
 
-def measure_traffic(frames_per_launch):
-    """HBM bytes per launch of the dominant kernel from the L2's memory-side counters, in two
-    separate rocprofv3 --pmc passes over a kernel-only child process (never combined with
+def measure_traffic(frames_per_launch, unit=True):
+    """HBM bytes per launch of the dominant launch (main kernel + its edge-column passes) from the L2's memory-side
+    counters, in two separate rocprofv3 --pmc passes over a kernel-only child process (never combined with
     tracing).  gfx950 corrections per /opt/skills/guides/MI355X_MICROARCH.md: FETCH_SIZE
     reports half the bytes of a wide coalesced read (x2); WRITE_SIZE is exact; both in KiB.
+    unit: the one-launch step (1 main + 2 edge dispatches per step) or the plain upscale (1 + 1).
     Returns (bytes_per_launch_scaled_to_frames_per_launch, detail) or (None, reason)."""
     import csv
     import glob
@@ -209,14 +218,16 @@ def measure_traffic(frames_per_launch):
     exe = shutil.which("rocprofv3")
     if not exe:
         return None, "rocprofv3 not found"
-    n_child = 64
+    n_child, reps = 64, 2
+    script = "unit_only.py" if unit else "lanczos_only.py"
+    edges_per_main = 2 if unit else 1
     vals = {}
     tmp = tempfile.mkdtemp(prefix="nus_pmc_", dir=os.environ.get("TMPDIR", "/tmp"))
     try:
         for counter in ("FETCH_SIZE", "WRITE_SIZE"):
             out = os.path.join(tmp, counter)
             cmd = [exe, "--pmc", counter, "-d", out, "--output-format", "csv", "--",
-                   sys.executable, os.path.join(ROOT, "tools", "lanczos_only.py"), str(n_child), "2"]
+                   sys.executable, os.path.join(ROOT, "tools", script), str(n_child), str(reps)]
             res = subprocess.run(cmd, capture_output=True, text=True, timeout=240, cwd=tmp)
             if res.returncode != 0:
                 return None, f"rocprofv3 --pmc {counter} failed (rc {res.returncode})"
@@ -233,23 +244,23 @@ def measure_traffic(frames_per_launch):
                 return None, f"no {counter} rows for k_lanczos3_x2"
             vals[counter] = sum(rows["main"]) / len(rows["main"])
             if rows["edges"]:
-                vals[counter] += sum(rows["edges"]) / len(rows["edges"])
+                vals[counter] += edges_per_main * sum(rows["edges"]) / len(rows["edges"])
     except Exception as e:  # timeouts, missing files: traffic stays null
         return None, f"{type(e).__name__}: {e}"
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
-    per_frame = (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0 / n_child
-    detail = {"FETCH_SIZE_KiB_per_frame": round(vals["FETCH_SIZE"] / n_child, 1),
-              "WRITE_SIZE_KiB_per_frame": round(vals["WRITE_SIZE"] / n_child, 1),
-              "fetch_correction": 2.0, "child_frames_per_launch": n_child,
-              "kernels": "k_lanczos3_x2 + k_lanczos3_x2_edges"}
-    return int(per_frame * frames_per_launch), detail
+    per_unit = (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0 / n_child
+    detail = {"FETCH_SIZE_KiB_per_unit": round(vals["FETCH_SIZE"] / n_child, 1),
+              "WRITE_SIZE_KiB_per_unit": round(vals["WRITE_SIZE"] / n_child, 1),
+              "fetch_correction": 2.0, "child_units_per_launch": n_child,
+              "kernels": ("k_lanczos3_x2<.., UNIT> + 2 x k_lanczos3_x2_edges" if unit else "k_lanczos3_x2 + k_lanczos3_x2_edges")}
+    return int(per_unit * frames_per_launch), detail
 
 
-def check_timed_outputs(frames, up_real, up_mid, picks, w, h):
-    """Compare frames of the TIMED output buffers with the oracle (outside the timed region): the upscaled
-    real frame against oracle.lanczos3(frame k), the upscaled in-between frame against
-    oracle.lanczos3(oracle.warp_blend(frame k, frame k+1)).  Lanczos tolerance as in tests/: every sample
+def check_timed_outputs(frames, mid_t, up_real, up_mid, picks, w, h):
+    """Compare frames of the TIMED output buffers with the oracle (outside the timed region): the in-between frame against
+    oracle.warp_blend(frame k, frame k+1) (bit-exact), the upscaled real frame against oracle.lanczos3(frame k), the upscaled
+    in-between frame against oracle.lanczos3 of that blend.  Lanczos tolerance as in tests/: every sample
     within 1 LSB and fewer than 0.1 % of the samples different.  Raises on mismatch."""
     import numpy as np
 
@@ -261,6 +272,11 @@ def check_timed_outputs(frames, up_real, up_mid, picks, w, h):
         a = frames[k].cpu().numpy()
         b = frames[k + 1].cpu().numpy()
         mid = oracle.warp_blend(a, b, None, 0.5, threads=0)
+        if mid_t is not None:
+            same = bool(np.array_equal(mid_t[k].cpu().numpy(), mid))
+            report.append({"frame": int(k), "buffer": "mid", "bit_exact": same})
+            if not same:
+                raise SystemExit(f"bench.py: timed output mid[{k}] differs from the oracle's warp_blend")
         for name, got_t, src in (("up_real", up_real, a), ("up_mid", up_mid, mid)):
             want = oracle.lanczos3(src, 2 * w, 2 * h, threads=0).astype(np.int16)
             got = got_t[k].cpu().numpy().astype(np.int16)
@@ -273,13 +289,45 @@ def check_timed_outputs(frames, up_real, up_mid, picks, w, h):
     return report
 
 
-def host_path_leg(nsc, syn, w, h, device):
+def pcie_ceiling(torch, dev, n_in, n_out):
+    """What hipMemcpyAsync between PINNED host memory and HBM gets on this box for the host path's two frame sizes,
+    each direction alone and both at once on two streams (GB/s; the denominator of config.host_path)."""
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    h_in = torch.empty(n_in, dtype=torch.uint8, pin_memory=True)
+    h_out = torch.empty(n_out, dtype=torch.uint8, pin_memory=True)
+    d_in = torch.empty(n_in, dtype=torch.uint8, device=dev)
+    d_out = torch.empty(n_out, dtype=torch.uint8, device=dev)
+    reps = 30
+
+    def run(h2d, d2h):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            if h2d:
+                with torch.cuda.stream(s1):
+                    d_in.copy_(h_in, non_blocking=True)
+            if d2h:
+                with torch.cuda.stream(s2):
+                    h_out.copy_(d_out, non_blocking=True)
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / reps
+
+    run(True, True)
+    t_h2d, t_d2h, t_both = run(True, False), run(False, True), run(True, True)
+    return {"h2d_1080p_frame_GBps": round(n_in / t_h2d / 1e9, 2), "d2h_4k_frame_GBps": round(n_out / t_d2h / 1e9, 2),
+            "d2h_4k_frame_ms": round(t_d2h * 1e3, 4), "both_directions_ms_per_frame_pair": round(t_both * 1e3, 4),
+            "how": "torch pinned tensors, copy_(non_blocking) on two streams, 30 repetitions after a warm-up"}
+
+
+def host_path_leg(nsc, syn, torch, w, h, device):
     """PCIe-inclusive rate through the trait-shaped host entry points (mode (ii) of BASELINE.md section 3):
-    `upscale(&[u8]) -> Vec<u8>` = nus_upscaler_upscale, `interpolate_py` = nus_interp_interpolate, host
-    buffers in and out.  Never `value`."""
-    frames = [syn.gradient_frame(w, h, k).tobytes() for k in range(12)]
+    `upscale(&[u8]) -> Vec<u8>` = nus_upscaler_upscale, `upscale_batch` = nus_upscaler_upscale_batch, `interpolate_py` =
+    nus_interp_interpolate, host buffers in and out, next to the box's pinned-copy ceiling.  Never `value`."""
+    nb = 12
+    frames = [syn.gradient_frame(w, h, k).tobytes() for k in range(nb + 1)]
     u = nsc.PyWgpuUpscaler("quality", "lanczos3", device=device)
     u.initialize(w, h, 2 * w, 2 * h)
+    ceiling = pcie_ceiling(torch, torch.device("cuda", device), u.input_size, u.output_size)
     out = bytearray(u.output_size)
     for i in range(3):
         u.upscale_into(frames[i], out)
@@ -289,6 +337,39 @@ def host_path_leg(nsc, syn, w, h, device):
         u.upscale_into(frames[i % len(frames)], out)
         ts.append(time.perf_counter() - t0)
     up_ms = _median(ts) * 1e3
+    # upscale_batch: 12 frames per call into caller-owned buffers (pageable, touched before) -- and into pinned ones
+    outs = [bytearray(u.output_size) for _ in range(nb)]
+    u.upscale_batch_into(frames[:nb], outs)
+    ts = []
+    for _ in range(5):
+        t0 = time.perf_counter()
+        u.upscale_batch_into(frames[:nb], outs)
+        ts.append((time.perf_counter() - t0) / nb)
+    batch_ms = _median(ts) * 1e3
+    del outs
+    pin_in = torch.empty((nb, u.input_size), dtype=torch.uint8, pin_memory=True)
+    pin_out = torch.empty((nb, u.output_size), dtype=torch.uint8, pin_memory=True)
+    for k in range(nb):
+        pin_in[k] = torch.frombuffer(bytearray(frames[k]), dtype=torch.uint8)
+    ins_np, outs_np = [pin_in[k].numpy() for k in range(nb)], [pin_out[k].numpy() for k in range(nb)]
+    u.upscale_batch_into(ins_np, outs_np)
+    ts = []
+    for _ in range(5):
+        t0 = time.perf_counter()
+        u.upscale_batch_into(ins_np, outs_np)
+        ts.append((time.perf_counter() - t0) / nb)
+    batch_pinned_ms = _median(ts) * 1e3
+    del pin_in, pin_out, ins_np, outs_np
+    # the reference's own shapes: fresh `bytes` per result (lib.rs:105-112, :140-154)
+    t0 = time.perf_counter()
+    for i in range(6):
+        o = u.upscale(frames[i])
+    fresh_ms = (time.perf_counter() - t0) / 6 * 1e3
+    o = u.upscale_batch(frames[:nb])
+    t0 = time.perf_counter()
+    o = u.upscale_batch(frames[:nb])
+    fresh_batch_ms = (time.perf_counter() - t0) / nb * 1e3
+    del o
     it = nsc.WgpuFrameInterpolator(device=device)
     it.interpolate_py(frames[0], frames[1], w, h)
     ts = []
@@ -299,11 +380,21 @@ def host_path_leg(nsc, syn, w, h, device):
         u.upscale_into(mid, out)
         ts.append(time.perf_counter() - t0)
     unit_ms = _median(ts) * 1e3
+    d2h_ms = ceiling["d2h_4k_frame_ms"]
     return {
-        "what": "host bytes in -> host bytes out through nus_upscaler_upscale / nus_interp_interpolate (PCIe and "
-                "staging copies included), one call at a time as the reference's GUI drives it; medians",
+        "what": "host bytes in -> host bytes out through nus_upscaler_upscale / nus_upscaler_upscale_batch / "
+                "nus_interp_interpolate (PCIe and staging copies included); medians",
+        "pcie_ceiling": ceiling,
         "upscale_1080p_to_4k_ms_per_frame": round(up_ms, 3),
         "upscale_frames_per_s": round(1e3 / up_ms, 1),
+        "upscale_batch_12_ms_per_frame": round(batch_ms, 3),
+        "upscale_batch_frames_per_s": round(1e3 / batch_ms, 1),
+        "upscale_batch_vs_single_call": round(up_ms / batch_ms, 3),
+        "upscale_batch_frac_of_d2h_ceiling": round(d2h_ms / batch_ms, 3),
+        "upscale_batch_12_pinned_buffers_ms_per_frame": round(batch_pinned_ms, 3),
+        "upscale_batch_pinned_frac_of_d2h_ceiling": round(d2h_ms / batch_pinned_ms, 3),
+        "fresh_bytes_per_result": {"upscale_ms": round(fresh_ms, 3), "upscale_batch_12_ms_per_frame": round(fresh_batch_ms, 3),
+                                   "what": "the pyo3 shapes (a new 33 MB bytes object per result: first-touch page faults included)"},
         "unit_ms": round(unit_ms, 3),
         "unit_source_frames_per_s": round(1e3 / unit_ms, 1),
         "unit_4k_output_frames_per_s": round(2e3 / unit_ms, 1),
@@ -469,11 +560,15 @@ def worker(args):
             else:
                 dist.barrier()
 
+    unit_schedule = args.schedule == "unit" and not args.fused and not args.overlap
+
     def do_step():
         if args.fused:
             pipe.step_fused(frames, up_real, up_mid, stream)
         elif args.overlap:
             pipe.step_overlapped(frames, mid, up_real, up_mid)
+        elif unit_schedule:
+            pipe.step_unit(frames, mid, up_real, up_mid, stream)
         else:
             pipe.step(frames, mid, up_real, up_mid, stream)
 
@@ -509,8 +604,9 @@ def worker(args):
     timed_check = None
     if rank == 0 and world == 1 and not args.no_check and args.pattern == "gradient" and args.lanczos_mode == "fma":
         picks = sorted({0, count // 2 - 1 if count > 2 else 0, count - 1})
-        timed_check = {"tolerance": "max |diff| <= 1 LSB and < 0.1 % of samples differing (Lanczos FMA mode)",
-                       "frames": check_timed_outputs(frames, up_real, up_mid, picks, w, h)}
+        timed_check = {"tolerance": "in-between frames bit-exact; 4K frames max |diff| <= 1 LSB and < 0.1 % of samples "
+                                    "differing (Lanczos FMA mode)",
+                       "frames": check_timed_outputs(frames, None if args.fused else mid, up_real, up_mid, picks, w, h)}
     else:
         # cheap sanity check: the outputs are fully written (alpha of the opaque stream stays 255)
         assert args.pattern != "gradient" or (int(up_real[0, ..., 3].min()) == 255 and int(up_mid[count - 1, ..., 3].min()) == 255)
@@ -521,24 +617,37 @@ def worker(args):
     if rank == 0 and world == 1 and args.sustained_seconds > 0:
         sustained = sustained_leg(torch, do_step, pipe.upscaler, args.sustained_seconds)
 
-    extras = rank == 0 and not args.no_extras and not args.fused and not args.overlap
+    extras = rank == 0 and world == 1 and not args.no_extras and not args.fused and not args.overlap
 
-    # Informational (never `value`): same output frames with the blend fused into the second upscale's
-    # row loads, so the 1080p in-between frame is never written to HBM.
-    fused_ms = None
-    if extras:
+    def timed_leg(step_fn, n, with_profile=True):
+        """(ms per step, bracketed launches, their summed ms) of n steps after 2 warm-ups; informational legs only."""
         for _ in range(2):
-            pipe.step_fused(frames, up_real, up_mid, stream)
+            step_fn()
         torch.cuda.synchronize()
-        tf = time.perf_counter()
-        nf = max(3, args.steps // 4)
-        for _ in range(nf):
-            pipe.step_fused(frames, up_real, up_mid, stream)
+        pipe.upscaler.set_profiling(profile and with_profile)
+        pipe.upscaler.profile_collect()
+        tl = time.perf_counter()
+        for _ in range(n):
+            step_fn()
         torch.cuda.synchronize()
-        fused_ms = (time.perf_counter() - tf) / nf * 1e3
+        ms = (time.perf_counter() - tl) / n * 1e3
+        nl, kms = pipe.upscaler.profile_collect() if profile and with_profile else (0, 0.0)
+        pipe.upscaler.set_profiling(False)
+        return ms, nl, kms
 
-    # Informational: the on-box ceiling for these very bytes -- k_nearest_x2 reads the same 1080p frames and
-    # writes the same 4K frames with no arithmetic -- so roofline.frac can be read next to what the memory
+    n_leg = max(3, args.steps // 6)
+    step3 = lambda: pipe.step(frames, mid, up_real, up_mid, stream)       # noqa: E731
+    stepu = lambda: pipe.step_unit(frames, mid, up_real, up_mid, stream)  # noqa: E731
+    other_schedule_leg = fused_leg = None
+    if extras:
+        # Informational: the other schedule on the same frames.  With the unit schedule timed, this is rounds 1-2's
+        # blend / upscale / upscale sequence, whose bracket holds k_lanczos3_x2 ALONE (+ its edge pass): 41 472 000 B per frame.
+        other_schedule_leg = timed_leg(step3 if unit_schedule else stepu, n_leg)
+        # Informational: the two 4K outputs only (blend inside the second upscale's row loads, in-between frame not written)
+        fused_leg = timed_leg(lambda: pipe.step_fused(frames, up_real, up_mid, stream), n_leg, with_profile=False)
+
+    # Informational: the on-box ceiling for an upscale's very bytes -- k_nearest_x2 reads the same 1080p frames and
+    # writes the same 4K frames with no arithmetic -- so the fractions can be read next to what the memory
     # system of this box sustains, not only next to the 8 TB/s spec figure.
     copy_ms = None
     if extras and profile:
@@ -558,7 +667,7 @@ def worker(args):
 
     # Informational: the motion-compensated step (per-pair pyramid + Horn-Schunck flow feeding the warp)
     motion_ms = None
-    if extras and world == 1:
+    if extras:
         flows = torch.empty((count, h, w, 2), dtype=torch.float32, device=dev)
         pipe.step_motion(frames, flows, mid, up_real, up_mid, stream)
         torch.cuda.synchronize()
@@ -569,71 +678,79 @@ def worker(args):
         motion_ms = (time.perf_counter() - tm) / 2 * 1e3
         del flows
 
-    # Informational: the same 3-stage step on the other pattern (gradient = opaque frames, the kernel's
-    # 3-channel path; noise = real alpha, its 4-channel path), with its own hipEvent bracket.
+    # Informational: both schedules on the other pattern (gradient = opaque frames, the kernel's
+    # 3-channel path; noise = real alpha, its 4-channel path), each with its own hipEvent bracket.
     other = None
-    if extras and world == 1:
+    if extras:
         other_pattern = "noise" if args.pattern == "gradient" else "gradient"
         fill(other_pattern)
-        for _ in range(2):
-            pipe.step(frames, mid, up_real, up_mid, stream)
-        torch.cuda.synchronize()
-        pipe.upscaler.set_profiling(profile)
-        pipe.upscaler.profile_collect()
-        no = max(3, args.steps // 4)
-        tn0 = time.perf_counter()
-        for _ in range(no):
-            pipe.step(frames, mid, up_real, up_mid, stream)
-        torch.cuda.synchronize()
-        o_ms = (time.perf_counter() - tn0) / no * 1e3
-        o_l, o_kms = pipe.upscaler.profile_collect() if profile else (0, 0.0)
-        pipe.upscaler.set_profiling(False)
-        other = (other_pattern, o_ms, o_l, o_kms)
+        other = (other_pattern, timed_leg(do_step, n_leg), timed_leg(step3 if unit_schedule else stepu, n_leg))
 
     host_path = None
-    if extras and world == 1:
+    if extras:
         del frames, mid, up_real, up_mid
         torch.cuda.empty_cache()
-        host_path = host_path_leg(nsc, syn, w, h, local_rank)
+        host_path = host_path_leg(nsc, syn, torch, w, h, local_rank)
 
     if rank == 0:
         total_units = n_units * world * args.steps
         value = total_units * pipe.unit_pixels / elapsed / 1e6
         up_bytes = (w * h + 4 * w * h) * 4  # algorithmic bytes of one upscaled frame
+        # what one bracketed launch processes: a whole unit per frame (107 827 200 B at 1080p: blend 24 883 200 + 2 x 41 472 000,
+        # SURVEY.md section 8d) in the unit schedule, one upscaled frame otherwise
+        launch_bytes = lambda is_unit: (pipe.unit_bytes if is_unit else up_bytes) * count  # noqa: E731
 
-        def roof(nl, kms):
-            achieved = up_bytes * count / (kms / 1e3 / nl) / 1e9
-            return achieved, round(achieved / HBM_PEAK_GBPS, 4), round(kms / nl, 4)
+        def roof(nl, kms, is_unit):
+            achieved = launch_bytes(is_unit) / (kms / 1e3 / nl) / 1e9
+            return {"achieved": round(achieved, 1), "frac": round(achieved / HBM_PEAK_GBPS, 4), "avg_launch_ms": round(kms / nl, 4)}
 
         roofline = None
         if launches:
-            achieved, frac, avg_ms = roof(launches, kernel_ms)
+            r = roof(launches, kernel_ms, unit_schedule)
             roofline = {
-                "bound": "hbm", "kernel": "k_lanczos3_x2 (+ k_lanczos3_x2_edges)", "achieved": round(achieved, 1),
-                "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": frac, "traffic": None,
-                "bytes_per_launch": up_bytes * count, "frames_per_launch": count, "launches": launches,
-                "avg_launch_ms": avg_ms, "pattern": args.pattern,
-                "note": "achieved = algorithmic bytes (8 294 400 R + 33 177 600 W per frame) / hipEvent time on the "
-                        "launch stream inside the timed region; the bracket holds BOTH launches that write the frames' "
-                        "bytes (the main kernel and its edge-column pass: rocprofv3 --stats shows them as two kernels); "
-                        "traffic = (2*FETCH_SIZE + WRITE_SIZE)*1024 of both from separate rocprofv3 --pmc passes, "
-                        "scaled to frames_per_launch",
+                "bound": "hbm",
+                "kernel": ("k_lanczos3_x2<FMA, blend-on-load, UNIT> (+ 2 x k_lanczos3_x2_edges): the whole step in one launch"
+                           if unit_schedule else "k_lanczos3_x2 (+ k_lanczos3_x2_edges)"),
+                "achieved": r["achieved"], "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": r["frac"], "traffic": None,
+                "bytes_per_launch": launch_bytes(unit_schedule), "units_per_launch": count, "launches": launches,
+                "avg_launch_ms": r["avg_launch_ms"], "pattern": args.pattern,
+                "note": ("achieved = algorithmic bytes of the units one launch processes (SURVEY.md 8d: 107 827 200 B per unit = "
+                         "zero-flow interpolation 24 883 200 + two upscales of 41 472 000) / hipEvent time on the launch stream "
+                         "inside the timed region; the bracket holds every launch of the step (the unit kernel and the two "
+                         "edge-column passes: rocprofv3 --stats shows three kernels).  The unit kernel moves fewer bytes than "
+                         "that -- `traffic` -- because each input row reaches it from HBM about once (not four times) and the "
+                         "in-between frame is written, never re-read; `upscale_kernel_alone` is k_lanczos3_x2 by itself. "
+                         if unit_schedule else
+                         "achieved = algorithmic bytes (8 294 400 R + 33 177 600 W per frame) / hipEvent time on the launch "
+                         "stream inside the timed region; the bracket holds the main kernel and its edge-column pass. ") +
+                        "traffic = (2*FETCH_SIZE + WRITE_SIZE)*1024 of the bracket's kernels from separate rocprofv3 --pmc "
+                        "passes, scaled to units_per_launch",
             }
             if sustained and sustained["tail_upscale_launches"]:
-                s_ach = up_bytes * count / (sustained["tail_upscale_avg_launch_ms"] / 1e3) / 1e9
-                roofline["sustained"] = {
-                    "achieved": round(s_ach, 1), "frac": round(s_ach / HBM_PEAK_GBPS, 4),
-                    "avg_launch_ms": sustained["tail_upscale_avg_launch_ms"],
-                    "what": "the same bracket over the last seconds of config.sustained (after the timed region)"}
+                sr = roof(sustained["tail_upscale_launches"],
+                          sustained["tail_upscale_avg_launch_ms"] * sustained["tail_upscale_launches"], unit_schedule)
+                sr["what"] = "the same bracket over the last seconds of config.sustained (after the timed region)"
+                roofline["sustained"] = sr
+            if other_schedule_leg and other_schedule_leg[1]:
+                key = "upscale_kernel_alone" if unit_schedule else "unit_kernel"
+                roofline[key] = roof(other_schedule_leg[1], other_schedule_leg[2], not unit_schedule)
+                roofline[key]["what"] = ("k_lanczos3_x2 + its edge pass by itself (the upscale launches of the three-stage schedule on "
+                                         "the same frames, after the timed region): 41 472 000 algorithmic bytes per frame"
+                                         if unit_schedule else "the one-launch step on the same frames, after the timed region")
             if copy_ms:
                 ceiling = up_bytes * count / (copy_ms / 1e3) / 1e9
                 roofline["copy_ceiling"] = {
-                    "GBps": round(ceiling, 1), "frac_of_ceiling": round(achieved / ceiling, 4),
-                    "how": "k_nearest_x2 over the same frames (same bytes in and out, no arithmetic), hipEvent time"}
-            if other and other[2]:
-                o_ach, o_frac, o_avg = roof(other[2], other[3])
-                roofline["other_pattern"] = {"pattern": other[0], "achieved": round(o_ach, 1), "frac": o_frac,
-                                             "avg_launch_ms": o_avg}
+                    "GBps": round(ceiling, 1),
+                    "how": "k_nearest_x2 over the same frames (an upscale's bytes in and out, no arithmetic), hipEvent time"}
+            if other and other[1][1]:
+                roofline["other_pattern"] = dict(roof(other[1][1], other[1][2], unit_schedule), pattern=other[0])
+                if other[2][1]:
+                    roofline["other_pattern"]["upscale_kernel_alone" if unit_schedule else "unit_kernel"] = roof(
+                        other[2][1], other[2][2], not unit_schedule)
+
+        def leg(ms):
+            return {"ms_per_step": round(ms, 4), "Mpix_per_s_per_gpu": round(n_units * pipe.unit_pixels / ms / 1e3, 1)}
+
         out = {
             "metric": baseline_metric(),
             "value": round(value, 1),
@@ -649,15 +766,18 @@ def worker(args):
             "data": "synthetic",
             "config": {
                 "workload": f"{n_units}-frame {w}x{h} RGBA8 stream per GPU, HBM-resident: zero-flow warp+blend t=0.5 "
-                            f"(1 in-between frame per source frame) + Lanczos-3 x2 of real and in-between frame to "
-                            f"{2 * w}x{2 * h}",
+                            f"(1 in-between frame per source frame, written to HBM) + Lanczos-3 x2 of real and in-between "
+                            f"frame to {2 * w}x{2 * h}",
                 "units_per_step_per_gpu": n_units, "pixels_per_unit": pipe.unit_pixels,
                 "algorithmic_bytes_per_unit": pipe.unit_bytes, "pattern": args.pattern,
                 "lanczos_mode": args.lanczos_mode, "kernel_variant": pipe.upscaler.kernel_variant,
                 "schedule": "fused: upscale(real) + upscale(blend(A,B)) with the blend in the row loads, 2 launches"
                             if args.fused else
                             "blend on a second HIP stream, concurrent with the upscale of the real frames"
-                            if args.overlap else "3 stages back to back on one stream",
+                            if args.overlap else
+                            "unit: one launch per step (two waves per strip side by side: upscale(A) | blend(A,B) on load -> "
+                            "in-between rows stored -> upscale), + the two edge-column passes"
+                            if unit_schedule else "3 stages back to back on one stream",
                 "sharding": f"frame-parallel, contiguous shards, {world} rank(s), LUT broadcast {lut_bytes} B over "
                             f"{'RCCL' if nccl else args.backend}",
                 "lut_broadcast_bytes": lut_bytes,
@@ -666,20 +786,23 @@ def worker(args):
                 "timed_output_check": timed_check,
                 "timed_region_s": round(elapsed, 3),
                 "sustained": sustained,
-                "fused_variant": None if fused_ms is None else {
-                    "what": "same 4K outputs, blend fused into the second upscale (in-between frame not materialised); "
-                            "informational, measured after the timed region on this rank only",
-                    "ms_per_step": round(fused_ms, 4),
-                    "Mpix_per_s_per_gpu_same_unit_pixels": round(n_units * pipe.unit_pixels / fused_ms / 1e3, 1)},
-                ("noise" if args.pattern == "gradient" else "gradient") + "_variant": None if other is None else {
-                    "what": f"the same 3-stage step on the {other[0]} stream (gradient = opaque frames, the x2 kernel's "
-                            f"3-channel path; noise = real alpha, its 4-channel path); informational, after the timed region",
-                    "ms_per_step": round(other[1], 4),
-                    "Mpix_per_s_per_gpu": round(n_units * pipe.unit_pixels / other[1] / 1e3, 1),
-                    "roofline_frac": None if not other[2] else roof(other[2], other[3])[1]},
+                ("three_stage_variant" if unit_schedule else "unit_variant"): None if other_schedule_leg is None else dict(
+                    leg(other_schedule_leg[0]),
+                    what=("the same three outputs from three launches (blend, upscale, upscale), the schedule of rounds 1-2"
+                          if unit_schedule else "the same three outputs from the one-launch step") +
+                         "; informational, after the timed region"),
+                "fused_variant": None if fused_leg is None else dict(
+                    leg(fused_leg[0]),
+                    what="the two 4K outputs only: upscale + upscale-with-the-blend-on-load, in-between frame not written; "
+                         "informational, after the timed region"),
+                ("noise" if args.pattern == "gradient" else "gradient") + "_variant": None if other is None else dict(
+                    leg(other[1][0]),
+                    what=f"the timed schedule on the {other[0]} stream (gradient = opaque frames, the x2 kernel's "
+                         f"3-channel path; noise = real alpha, its 4-channel path); informational, after the timed region",
+                    other_schedule=leg(other[2][0])),
                 "motion_variant": None if motion_ms is None else {
-                    "what": "same step with a dense flow per pair (3-level pyramid, 50 + 10 + 10 Horn-Schunck steps) feeding "
-                            "the warp instead of zero flow; informational, this rank only",
+                    "what": "three-stage step with a dense flow per pair (3-level pyramid, 50 + 10 + 10 Horn-Schunck steps) "
+                            "feeding the warp instead of zero flow; informational, this rank only",
                     "ms_per_step": round(motion_ms, 3),
                     "units_per_s_per_gpu": round(n_units / motion_ms * 1e3, 1)},
                 "host_path": host_path,
@@ -689,7 +812,7 @@ def worker(args):
             "roofline": roofline,
         }
         if world == 1 and roofline is not None and not args.no_pmc:
-            traffic, detail = measure_traffic(count)
+            traffic, detail = measure_traffic(count, unit_schedule)
             roofline["traffic"] = traffic
             roofline["traffic_detail"] = detail
         if world == 1 and not args.no_cpu_baseline:

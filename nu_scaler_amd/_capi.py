@@ -81,6 +81,8 @@ SIGNATURES = [
     ("nus_interp_set_device", _i, [_vp, _i]),
     ("nus_interp_set_input_format", _i, [_vp, _i]),
     ("nus_interp_set_flow_format", _i, [_vp, _i]),
+    ("nus_interp_set_mode", _i, [_vp, _i]),
+    ("nus_interp_mode", _i, [_vp]),
     ("nus_interp_initialize", _i, [_vp, _u32, _u32]),
     ("nus_interp_interpolate_frames", _i, [_vp, _vp, _sz, _vp, _sz, _f, _vp, _sz]),
     ("nus_interp_name", _cp, [_vp]),

@@ -405,6 +405,13 @@ int nus_interp_set_input_format(nus_interp *h, int format)
     return guarded<int>("nus_interp_set_input_format", [&]() -> int { return h ? h->impl.set_input_format(format) : null_handle(); });
 }
 
+int nus_interp_set_mode(nus_interp *h, int mode)
+{
+    return guarded<int>("nus_interp_set_mode", [&]() -> int { return h ? h->impl.set_mode(mode) : null_handle(); });
+}
+
+int nus_interp_mode(const nus_interp *h) { return h ? h->impl.mode() : null_handle(); }
+
 int nus_interp_set_flow_format(nus_interp *h, int format)
 {
     return guarded<int>("nus_interp_set_flow_format", [&]() -> int { return h ? h->impl.set_flow_format(format) : null_handle(); });

@@ -1,14 +1,15 @@
 // nus_copy.cpp -- see nus_copy.hpp.
 #include "nus_copy.hpp"
 
-#include <atomic>
 #include <condition_variable>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
 #include <mutex>
 #include <thread>
 #include <vector>
 
+#include <sched.h>
 #include <unistd.h>
 
 namespace nus {
@@ -18,14 +19,13 @@ namespace {
 constexpr size_t kMinParallelBytes = 1u << 20; // below this one memcpy is faster than waking anybody
 constexpr size_t kPieceBytes = 512u << 10;     // work item: large enough to stream, small enough to balance
 
-// One copy at a time.  The job lives on the caller's stack: workers enter it only under the pool mutex while it is
-// published, and the caller leaves only when every piece is done AND every worker that entered has left.
-struct Job {
+// A queue of pieces (dst, src, len, ticket) shared by every caller: several copies can be in flight at once -- the staging
+// copy of frame i+1 and the copy-out of frame i of upscale_batch -- and whoever has a hand free takes the next piece.
+struct Piece {
     char *dst;
     const char *src;
-    size_t bytes, pieces;
-    std::atomic<size_t> next{0}, left{0};
-    int inside = 0; // workers currently in run(); guarded by the pool mutex
+    size_t len;
+    CopyTicket *ticket;
 };
 
 class CopyPool {
@@ -39,31 +39,38 @@ public:
     }
     static void shutdown_at_unload() { instance().shutdown(); }
 
-    int workers() const { return (int)threads_.size(); }
+    int workers() const { return getpid() == owner_ ? (int)threads_.size() : 0; }
 
-    void copy(char *dst, const char *src, size_t bytes)
+    // Queue the pieces of one copy under `ticket` and wake the workers.  The bytes are copied by the time ticket.wait()
+    // (or help()) returns; the caller keeps both buffers alive until then.
+    void submit(char *dst, const char *src, size_t bytes, CopyTicket &ticket)
     {
-        std::unique_lock<std::mutex> api(api_, std::try_to_lock);
-        if (!api.owns_lock() || threads_.empty()) { // pool busy with another caller's copy (or disabled)
-            memcpy(dst, src, bytes);
-            return;
-        }
-        Job job;
-        job.dst = dst;
-        job.src = src;
-        job.bytes = bytes;
-        job.pieces = (bytes + kPieceBytes - 1) / kPieceBytes;
-        job.left.store(job.pieces, std::memory_order_relaxed);
+        const size_t pieces = (bytes + kPieceBytes - 1) / kPieceBytes;
+        if (pieces == 0) return;
         {
             std::lock_guard<std::mutex> lk(m_);
-            job_ = &job;
-            ++generation_;
+            ticket.left += pieces;
+            for (size_t i = 0; i < pieces; ++i) {
+                const size_t off = i * kPieceBytes;
+                queue_.push_back(Piece{dst + off, src + off, bytes - off < kPieceBytes ? bytes - off : kPieceBytes, &ticket});
+            }
         }
         cv_work_.notify_all();
-        run(job); // the caller works too, and alone finishes the job if no worker ever wakes (e.g. after fork)
+    }
+
+    // Work on queued pieces (anybody's) until `ticket` has none left: the calling thread is one more worker, and alone
+    // finishes the job where no worker exists (NUS_COPY_THREADS=0, a forked child).
+    void help(CopyTicket &ticket)
+    {
         std::unique_lock<std::mutex> lk(m_);
-        job_ = nullptr; // no new entrants
-        cv_done_.wait(lk, [&] { return job.left.load(std::memory_order_acquire) == 0 && job.inside == 0; });
+        for (;;) {
+            if (ticket.left == 0) return;
+            if (queue_.empty()) { // the rest of this ticket is in other threads' hands
+                cv_done_.wait(lk, [&] { return ticket.left == 0 || !queue_.empty(); });
+                continue;
+            }
+            run_one(lk);
+        }
     }
 
 private:
@@ -71,9 +78,13 @@ private:
     {
         int n = 3;
         if (const char *e = getenv("NUS_COPY_THREADS")) n = atoi(e);
-        const unsigned hw = std::thread::hardware_concurrency();
-        if (hw > 0 && (unsigned)(n < 0 ? 0 : n) + 1 > hw) n = (int)hw - 1;
+        int cpus = 0;
+        cpu_set_t set;
+        if (sched_getaffinity(0, sizeof(set), &set) == 0) cpus = CPU_COUNT(&set);
+        if (cpus <= 0) cpus = (int)std::thread::hardware_concurrency();
+        if (cpus > 0 && (n < 0 ? 0 : n) + 1 > cpus) n = cpus - 1;
         if (n > 8) n = 8;
+        if (n < 0) n = 0;
         owner_ = getpid();
         for (int i = 0; i < n; ++i) threads_.emplace_back([this] { worker(); });
         if (n > 0) atexit(&CopyPool::shutdown_at_unload); // library unload / process exit: no thread may outlive the code
@@ -92,49 +103,43 @@ private:
         threads_.clear();
     }
 
-    void run(Job &job)
+    // pops one piece and copies it with the lock released; called and returns with `lk` held
+    void run_one(std::unique_lock<std::mutex> &lk)
     {
-        for (;;) {
-            const size_t i = job.next.fetch_add(1, std::memory_order_relaxed);
-            if (i >= job.pieces) return;
-            const size_t off = i * kPieceBytes;
-            memcpy(job.dst + off, job.src + off, job.bytes - off < kPieceBytes ? job.bytes - off : kPieceBytes);
-            if (job.left.fetch_sub(1, std::memory_order_acq_rel) == 1) {
-                std::lock_guard<std::mutex> lk(m_); // pairs with the waiter's predicate check
-                cv_done_.notify_all();
-            }
-        }
+        const Piece p = queue_.front();
+        queue_.pop_front();
+        lk.unlock();
+        memcpy(p.dst, p.src, p.len);
+        lk.lock();
+        if (--p.ticket->left == 0) cv_done_.notify_all();
     }
 
     void worker()
     {
-        unsigned long long seen = 0;
         std::unique_lock<std::mutex> lk(m_);
         for (;;) {
-            cv_work_.wait(lk, [&] { return stop_ || generation_ != seen; });
+            cv_work_.wait(lk, [&] { return stop_ || !queue_.empty(); });
             if (stop_) return;
-            seen = generation_;
-            Job *job = job_;
-            if (job == nullptr) continue; // already finished by the others
-            ++job->inside;
-            lk.unlock();
-            run(*job);
-            lk.lock();
-            if (--job->inside == 0) cv_done_.notify_all();
+            run_one(lk);
         }
     }
 
-    std::mutex api_; // one parallel copy at a time
-    std::mutex m_;
+    std::mutex m_; // guards the queue, every ticket's count, stop_
     std::condition_variable cv_work_, cv_done_;
+    std::deque<Piece> queue_;
     std::vector<std::thread> threads_;
-    unsigned long long generation_ = 0;
     bool stop_ = false;
-    Job *job_ = nullptr;
     pid_t owner_ = 0;
 };
 
 } // namespace
+
+void parallel_copy_async(void *dst, const void *src, size_t bytes, CopyTicket &ticket)
+{
+    CopyPool::instance().submit(static_cast<char *>(dst), static_cast<const char *>(src), bytes, ticket);
+}
+
+void parallel_copy_wait(CopyTicket &ticket) { CopyPool::instance().help(ticket); }
 
 void parallel_copy(void *dst, const void *src, size_t bytes)
 {
@@ -142,7 +147,9 @@ void parallel_copy(void *dst, const void *src, size_t bytes)
         memcpy(dst, src, bytes);
         return;
     }
-    CopyPool::instance().copy(static_cast<char *>(dst), static_cast<const char *>(src), bytes);
+    CopyTicket t;
+    parallel_copy_async(dst, src, bytes, t);
+    parallel_copy_wait(t);
 }
 
 int parallel_copy_workers() { return CopyPool::instance().workers(); }

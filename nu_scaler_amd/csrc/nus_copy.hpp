@@ -10,10 +10,20 @@
 namespace nus {
 
 // memcpy(dst, src, bytes), large copies split over the pool's workers and the calling thread.  Safe to call
-// from several threads (a second caller copies on its own thread); NUS_COPY_THREADS=0 turns the workers off.
+// from several threads (their pieces share one queue); NUS_COPY_THREADS=0 turns the workers off.
 void parallel_copy(void *dst, const void *src, size_t bytes);
 
-// number of worker threads in use (0 before the first large copy or when disabled)
+// The same in two halves, for callers that keep several copies in flight (upscale_batch: the staging copy of frame i+1 next
+// to the copy-out of frame i): parallel_copy_async queues the copy's pieces for the workers and returns; the bytes have
+// been copied when parallel_copy_wait(ticket) returns (the waiting thread works on queued pieces meanwhile).  A ticket may
+// collect several copies; both buffers of each must stay valid until the wait returns.  The ticket's count belongs to the pool.
+struct CopyTicket {
+    size_t left = 0; // pieces not yet copied (guarded by the pool's mutex)
+};
+void parallel_copy_async(void *dst, const void *src, size_t bytes, CopyTicket &ticket);
+void parallel_copy_wait(CopyTicket &ticket);
+
+// number of worker threads in use (0 when disabled or in a forked child)
 int parallel_copy_workers();
 
 } // namespace nus

@@ -2,6 +2,9 @@
 // See nus_host.hpp.  (HipFrameInterpolator: nus_host_interp.cpp.)
 #include "nus_host.hpp"
 
+#include <condition_variable>
+#include <thread>
+
 #include "nus_copy.hpp"
 #include "nus_host_util.hpp"
 
@@ -778,29 +781,13 @@ int HipUpscaler::upscale_batch(const uint8_t *const *ins, const size_t *in_lens,
             (void)hipGetLastError();
         }
     } drain{slots_, nslots};
-    // Frame i runs on slot i % nslots: stage -> H2D -> kernel -> D2H, all async on the
-    // slot's stream; the host only blocks when it needs a slot back.  Pageable outputs come back
-    // in kOutChunks pieces: while piece k is copied out of the pinned buffer, piece k+1 is in flight.
+    // Frame i runs on slot i % nslots: stage -> H2D -> kernel -> D2H, all async on the slot's stream.  Pageable outputs
+    // come back in kOutChunks pieces: while piece k is copied out of the pinned buffer (by the copy pool's workers),
+    // piece k+1 is in flight.
     const size_t chunk = ((out_bytes + kOutChunks - 1) / kOutChunks + 4095) & ~(size_t)4095;
-    std::vector<bool> direct_out(n, false);
-    auto retire = [&](size_t i) -> int {
-        Slot &S = slots_[i % nslots];
-        if (direct_out[i]) {
-            NUS_HIP(hipStreamSynchronize(S.stream));
-            return kOk;
-        }
-        int k = 0;
-        for (size_t off = 0; off < out_bytes; off += chunk, ++k) {
-            NUS_HIP(hipEventSynchronize(S.chunk_done[k]));
-            parallel_copy(outs[i] + off, S.h_out + off, out_bytes - off < chunk ? out_bytes - off : chunk);
-        }
-        return kOk;
-    };
-    for (size_t i = 0; i < n; ++i) {
-        if (i >= (size_t)nslots) {
-            int rc = retire(i - nslots);
-            if (rc != kOk) return rc;
-        }
+    std::vector<char> direct_out(n, 0);
+    // submit(i): the calling thread.  retire(i): waits for frame i's bytes and hands them to the caller's buffer.
+    auto submit = [&](size_t i) -> int {
         Slot &S = slots_[i % nslots];
         const uint8_t *src = ins[i];
         if (!is_pinned_host(src)) {
@@ -812,9 +799,10 @@ int HipUpscaler::upscale_batch(const uint8_t *const *ins, const size_t *in_lens,
         int rc = enqueue(S.d_in, S.d_out, 1, S.stream);
         if (rc != kOk) return rc;
         NUS_HIP(hipEventRecord(S.k_end, S.stream));
-        direct_out[i] = is_pinned_host(outs[i]);
+        direct_out[i] = is_pinned_host(outs[i]) ? 1 : 0;
         if (direct_out[i]) {
             NUS_HIP(hipMemcpyAsync(outs[i], S.d_out, out_bytes, hipMemcpyDeviceToHost, S.stream));
+            NUS_HIP(hipEventRecord(S.chunk_done[0], S.stream));
         } else {
             int k = 0;
             for (size_t off = 0; off < out_bytes; off += chunk, ++k) {
@@ -823,12 +811,82 @@ int HipUpscaler::upscale_batch(const uint8_t *const *ins, const size_t *in_lens,
                 NUS_HIP(hipEventRecord(S.chunk_done[k], S.stream));
             }
         }
+        return kOk;
+    };
+    auto retire = [&](size_t i) -> int {
+        Slot &S = slots_[i % nslots];
+        if (direct_out[i]) {
+            NUS_HIP(hipEventSynchronize(S.chunk_done[0]));
+            return kOk;
+        }
+        CopyTicket ticket; // the frame's pieces: queued as they land, all copied when the wait returns
+        int k = 0, rc = kOk;
+        for (size_t off = 0; off < out_bytes; off += chunk, ++k) {
+            const hipError_t e = hipEventSynchronize(S.chunk_done[k]);
+            if (e != hipSuccess) {
+                rc = fail_hip(e, "hipEventSynchronize(chunk_done)");
+                break;
+            }
+            parallel_copy_async(outs[i] + off, S.h_out + off, out_bytes - off < chunk ? out_bytes - off : chunk, ticket);
+        }
+        parallel_copy_wait(ticket); // also on the error path: queued pieces point into buffers that must outlive them
+        return rc;
+    };
+    int status = kOk;
+    if (n == 1) { // one frame (trait Upscaler::upscale): nothing to overlap with, no second thread
+        status = submit(0);
+        if (status == kOk) status = retire(0);
+    } else {
+        // The calling thread stages and submits frame i as soon as slot i % nslots is free again; a second thread retires the
+        // frames in order.  The copy-out of frame i (the pool's workers) then runs beside the staging copy, the H2D and the
+        // kernel of frames i+1 .. i+nslots-1, and the D2H engine goes from one frame's bytes straight to the next one's.
+        std::mutex m;
+        std::condition_variable cv;
+        size_t submitted = 0, retired = 0; // frames handed to the GPU / copied out to the caller
+        bool stop = false;                 // the submitter gave up: retire what was submitted, then leave
+        int retire_status = kOk;
+        std::string retire_error;
+        std::thread retirer([&] {
+            (void)hipSetDevice(device_);
+            for (size_t i = 0; i < n; ++i) {
+                {
+                    std::unique_lock<std::mutex> lk(m);
+                    cv.wait(lk, [&] { return submitted > i || stop; });
+                    if (submitted <= i) return;
+                }
+                const int rc = retire(i);
+                std::lock_guard<std::mutex> lk(m);
+                if (rc != kOk && retire_status == kOk) {
+                    retire_status = rc;
+                    retire_error = error_;
+                }
+                retired = i + 1;
+                cv.notify_all();
+                if (rc != kOk) return;
+            }
+        });
+        for (size_t i = 0; i < n && status == kOk; ++i) {
+            {
+                std::unique_lock<std::mutex> lk(m);
+                cv.wait(lk, [&] { return retired + (size_t)nslots > i || retire_status != kOk; });
+                if (retire_status != kOk) break;
+            }
+            status = submit(i);
+            if (status != kOk) break;
+            std::lock_guard<std::mutex> lk(m);
+            submitted = i + 1;
+            cv.notify_all();
+        }
+        {
+            std::lock_guard<std::mutex> lk(m);
+            stop = true;
+            cv.notify_all();
+        }
+        retirer.join();
+        if (status == kOk && retire_status != kOk) status = fail(retire_status, retire_error);
     }
-    for (size_t i = n > (size_t)nslots ? n - nslots : 0; i < n; ++i) {
-        int rc = retire(i);
-        if (rc != kOk) return rc;
-    }
-    drain.armed = false; // every frame was retired above
+    if (status != kOk) return status; // ~Drain waits for whatever is still in flight
+    drain.armed = false;             // every frame was retired above
     float ms = 0.0f;
     Slot &last = slots_[(n - 1) % nslots];
     if (hipEventElapsedTime(&ms, last.k_begin, last.k_end) == hipSuccess) {

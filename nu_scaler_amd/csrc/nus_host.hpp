@@ -242,6 +242,10 @@ public:
     int set_device(int device);
     int set_input_format(int format); // nus_pixel_format of both frames; output RGBA8
     int set_flow_format(int format);  // nus_flow_format of the device flow field
+    // nus_interp_mode of the dense-flow warp: 0 EXACT (the CPU's separate roundings, bit-exact against the oracle; default),
+    // 1 FMA (fused lerps, +-1 LSB: the interpolation path's contract).  The zero-flow blend is exact in both.
+    int set_mode(int mode);
+    int mode() const { return fma_ ? 1 : 0; }
     bool last_gpu_ms(double *ms) const;
     int wg_preset() const { return wg_preset_; }
 
@@ -262,6 +266,7 @@ private:
     bool cap_flow_ = false;
     uint8_t *d_a_ = nullptr, *d_b_ = nullptr, *d_out_ = nullptr;
     bool flow_half_ = false; // interpolate_device reads 2 x f16 per pixel
+    bool fma_ = false;       // dense-flow warp in FMA mode
     float *d_flow_ = nullptr;
     uint8_t *h_stage_ = nullptr; // pinned: a | b | out
     float *h_flow_ = nullptr;    // pinned

@@ -174,6 +174,7 @@ int HipFrameInterpolator::interpolate(const uint8_t *a, size_t a_len, const uint
     L.t = t;
     L.n_pairs = 1;
     L.stream = stream_;
+    L.fma = fma_;
     L.in_sel = input_selector(in_format_);
     NUS_HIP(hipEventRecord(k_begin_, stream_));
     hipError_t e = launch_warp_blend(L);
@@ -219,6 +220,7 @@ int HipFrameInterpolator::interpolate_device(const void *d_a, size_t a_stride, c
     L.b = static_cast<const uint8_t *>(d_b);
     L.flow = static_cast<const float *>(d_flow);
     L.flow_half = flow_half_;
+    L.fma = fma_;
     L.out = static_cast<uint8_t *>(d_out);
     L.a_stride = a_stride;
     L.b_stride = b_stride;
@@ -230,6 +232,14 @@ int HipFrameInterpolator::interpolate_device(const void *d_a, size_t a_stride, c
     L.in_sel = input_selector(in_format_);
     hipError_t e = launch_warp_blend(L);
     if (e != hipSuccess) return fail_hip(e, "warp+blend launch");
+    return kOk;
+}
+
+int HipFrameInterpolator::set_mode(int mode)
+{
+    std::lock_guard<std::mutex> lk(mu_);
+    if (mode != 0 && mode != 1) return fail(kInvalidArgument, "unknown interpolation mode");
+    fma_ = mode == 1;
     return kOk;
 }
 

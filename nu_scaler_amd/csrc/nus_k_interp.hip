@@ -63,91 +63,167 @@ __device__ __forceinline__ float4 sample_trunc(const uint32_t *__restrict__ f, u
     return make_float4(r[0], r[1], r[2], r[3]);
 }
 
-// Same sample through a buffer resource of one frame: 32-bit offsets (one v_mad_u32_u24 per row instead of
-// 64-bit address arithmetic per texel) and ONE 8-byte load per row for the horizontal pair -- the pair starts
-// at min(x0, w-2), so at the right border (x0 == x1 == w-1) both texels are its second half.
-__device__ __forceinline__ float4 sample_trunc_pairs(__amdgpu_buffer_rsrc_t rs, uint32_t w, uint32_t h, float x, float y)
+// ---------------------------------------------------------------------------------
+// Warp + blend with a dense flow field, rewritten in round 3 around the instruction count (the kernel is bound by SIMD
+// issue: ~180 VALU instructions per pixel in the form above, 0.47-0.51 of the HBM roofline).
+//
+// One bilinear sample, frames of at least 2 x 2 pixels seen through a buffer resource (32-bit offsets):
+//  * the texel pair starts at xb = min(x0, w - 2) and the row pair at yb = min(y0, h - 2), so all four texels are always
+//    inside the frame -- two 8-byte loads, the second one row_bytes further through the instruction's scalar offset, no
+//    border selects -- and the fractions are taken against THAT corner: xf = x - xb, yf = y - yb.  Away from the border
+//    these are the reference's fractions (x - floor(x)); at the right / bottom border, where the reference has x0 = x1 =
+//    w - 1 and fraction 0 (interpolation/mod.rs:474-483), they are exactly 1 and select the same texel:
+//    p(w-2) * (1 - 1) + p(w-1) * 1 = p(w-1), bit for bit in either mode;
+//  * MODE_EXACT: every product and sum separately, the CPU's roundings (bit-exact against the oracle);
+//    MODE_FMA  : each of the three lerps as one subtraction and one fused multiply-add, a + f (b - a): 24 instead of 36
+//    operations per sample, inside the +-1 LSB contract of the interpolation path (measured: < 0.1 % of the samples
+//    differ, none by more than one count).
+// The truncation of each sample to u8 (sample_frame returns u8: interpolation/mod.rs:506) stays in both modes.
+constexpr int kWarpExact = 0, kWarpFma = 1;
+
+template <int MODE>
+__device__ __forceinline__ float lerp_mode(float a, float b, float f, float nf)
+{
+    if (MODE == kWarpFma) return __builtin_fmaf(f, b - a, a);
+    return a * nf + b * f;
+}
+
+template <int MODE>
+__device__ __forceinline__ float4 sample_corner(__amdgpu_buffer_rsrc_t rs, uint32_t row_bytes, float wmax, float hmax,
+                                                uint32_t xbmax, uint32_t ybmax, float x, float y)
 {
     typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-    x = fminf(fmaxf(x, 0.0f), (float)(w - 1));
-    y = fminf(fmaxf(y, 0.0f), (float)(h - 1));
-    const float xfl = floorf(x), yfl = floorf(y);
-    const uint32_t x0 = (uint32_t)xfl, y0 = (uint32_t)yfl;
-    const uint32_t y1 = umin(y0 + 1, h - 1);
-    const float xf = x - xfl, yf = y - yfl;
+    x = __builtin_amdgcn_fmed3f(x, 0.0f, wmax); // clamp to [0, w-1] (interpolation/mod.rs:470-471)
+    y = __builtin_amdgcn_fmed3f(y, 0.0f, hmax);
+    const uint32_t xb = umin((uint32_t)x, xbmax), yb = umin((uint32_t)y, ybmax); // (uint32_t): truncation = floor, x >= 0
+    const float xf = x - (float)xb, yf = y - (float)yb;
     const float nxf = 1.0f - xf, nyf = 1.0f - yf;
-    const uint32_t xb = umin(x0, w - 2); // w >= 2 (checked by the caller)
-    const u32x2 r0 = __builtin_amdgcn_raw_buffer_load_b64(rs, (y0 * w + xb) * 4u, 0, 0);
-    const u32x2 r1 = __builtin_amdgcn_raw_buffer_load_b64(rs, (y1 * w + xb) * 4u, 0, 0);
-    const bool first = x0 == xb; // else x0 == x1 == w-1: both are the pair's second texel
-    const uint32_t p00 = first ? r0.x : r0.y, p01 = r0.y, p10 = first ? r1.x : r1.y, p11 = r1.y;
+    const uint32_t off = __umul24(yb, row_bytes) + xb * 4u;
+    const u32x2 r0 = __builtin_amdgcn_raw_buffer_load_b64(rs, off, 0, 0);
+    const u32x2 r1 = __builtin_amdgcn_raw_buffer_load_b64(rs, off, row_bytes, 0); // next row: scalar offset, always in range
     float r[4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-        const float top = ch_f32(p00, c) * nxf + ch_f32(p01, c) * xf;
-        const float bottom = ch_f32(p10, c) * nxf + ch_f32(p11, c) * xf;
-        const float value = top * nyf + bottom * yf;
-        r[c] = fminf(floorf(value), 255.0f); // `value as u8`; value >= 0 here
+        const float top = lerp_mode<MODE>(ch_f32(r0.x, c), ch_f32(r0.y, c), xf, nxf);
+        const float bottom = lerp_mode<MODE>(ch_f32(r1.x, c), ch_f32(r1.y, c), xf, nxf);
+        r[c] = floorf(lerp_mode<MODE>(top, bottom, yf, nyf)); // `value as u8`: 0 <= value <= 255 (+ an ulp in FMA mode)
     }
     return make_float4(r[0], r[1], r[2], r[3]);
 }
 
-// Dense flow (2 x f32 per pixel, delta A -> B): A sampled at p - t*flow, B at
-// p + (1-t)*flow (warp_blend.wgsl:36-37 in texel space).  blockDim = (64, 4).
-// PAIRS: the frames are at least 2 pixels wide and < 4 GiB (host-checked): buffer-resource sampling above.
-// HALF: the flow field is 2 x f16 per pixel -- the Rg16Float texture the reference's live path binds
-// (wgpu_interpolator.rs:276) -- widened to f32 on load (exact), then the same arithmetic: half the flow bytes.
-#ifndef NUS_WARP_ROWS
-#define NUS_WARP_ROWS 4 // pixels per thread (rows y, y + 4, y + 8, y + 12 of the block's 16): independent chains of flow load -> gathers -> blend, their loads in flight together
-#endif
-template <bool PAIRS, bool HALF>
+// Dense flow (2 x f32 or 2 x f16 per pixel, delta A -> B): A sampled at p - t*flow, B at p + (1-t)*flow
+// (warp_blend.wgsl:36-37 in texel space).  A lane owns XV consecutive pixels of a row: XV = 4 (frame width a multiple
+// of 4) loads its flow vectors as 32 (16) contiguous bytes and stores its 4 pixels as one 16-byte piece; the gathers of
+// the XV pixels -- independent chains -- are in flight together.  blockDim = (64, 4): a block covers 64 XV x 4 pixels.
+// HALF: the flow field is the Rg16Float texture of the reference's live path (wgpu_interpolator.rs:276), widened exactly.
+template <int MODE, bool HALF, int XV>
 __global__ __launch_bounds__(256) void k_warp_blend_flow(
     const uint8_t *__restrict__ a, const uint8_t *__restrict__ b, const void *__restrict__ flow,
     uint8_t *__restrict__ out, size_t a_stride, size_t b_stride, uint32_t w, uint32_t h, float t, uint32_t sel)
 {
-    constexpr int R = NUS_WARP_ROWS;
-    const uint32_t ybase = __builtin_amdgcn_readfirstlane(blockIdx.y * (4 * R) + threadIdx.y);
-    const uint32_t x = blockIdx.x * kWave + threadIdx.x;
-    if (ybase >= h || x >= w) return;
+    const uint32_t y = __builtin_amdgcn_readfirstlane(blockIdx.y * 4 + threadIdx.y);
+    const uint32_t x0 = (blockIdx.x * kWave + threadIdx.x) * XV;
+    if (y >= h || x0 >= w) return;
     const size_t npx = (size_t)w * h;
-    const uint8_t *fa = a + (size_t)blockIdx.z * a_stride, *fb = b + (size_t)blockIdx.z * b_stride;
-    float tv = t; // per-lane copy: scalar operands halve the VALU issue rate on gfx950
-    asm volatile("" : "+v"(tv));
+    const uint32_t frame_bytes = (uint32_t)(npx * 4), row_bytes = w * 4;
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<uint8_t *>(a + (size_t)blockIdx.z * a_stride), 0, frame_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<uint8_t *>(b + (size_t)blockIdx.z * b_stride), 0, frame_bytes, 0x00020000);
+    // per-lane copies of the wave-uniform constants: scalar operands halve the VALU issue rate on gfx950
+    float tv = t, wmax = (float)(w - 1), hmax = (float)(h - 1);
+    asm volatile("" : "+v"(tv), "+v"(wmax), "+v"(hmax));
     const float nt = 1.0f - tv;
-    float2 f[R];
-#pragma unroll
-    for (int k = 0; k < R; ++k) { // the flow vectors of all the thread's pixels first
-        const uint32_t y = umin(ybase + 4 * k, h - 1);
-        const size_t idx = (size_t)y * w + x;
+    const size_t idx = (size_t)blockIdx.z * npx + (size_t)y * w + x0;
+    float2 f[XV];
+    if (XV == 4) {
         if (HALF) {
-            const __half2 hf = reinterpret_cast<const __half2 *>(flow)[(size_t)blockIdx.z * npx + idx];
-            f[k] = make_float2(__low2float(hf), __high2float(hf));
-        } else {
-            f[k] = reinterpret_cast<const float2 *>(flow)[(size_t)blockIdx.z * npx + idx];
-        }
-    }
+            const uint4 raw = *reinterpret_cast<const uint4 *>(reinterpret_cast<const __half2 *>(flow) + idx);
+            const uint32_t rw[4] = {raw.x, raw.y, raw.z, raw.w};
 #pragma unroll
-    for (int k = 0; k < R; ++k) {
-        const uint32_t y = ybase + 4 * k;
-        if (y >= h) break; // wave-uniform
-        const float ax = (float)x - tv * f[k].x, ay = (float)y - tv * f[k].y;
-        const float bx = (float)x + nt * f[k].x, by = (float)y + nt * f[k].y;
-        float4 sa, sb;
-        if (PAIRS) {
-            const uint32_t frame_bytes = (uint32_t)(npx * 4);
-            sa = sample_trunc_pairs(__builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(fa), 0, frame_bytes, 0x00020000), w, h, ax, ay);
-            sb = sample_trunc_pairs(__builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(fb), 0, frame_bytes, 0x00020000), w, h, bx, by);
+            for (int i = 0; i < 4; ++i) {
+                const __half2 hf = *reinterpret_cast<const __half2 *>(&rw[i]);
+                f[i] = make_float2(__low2float(hf), __high2float(hf));
+            }
         } else {
-            sa = sample_trunc(reinterpret_cast<const uint32_t *>(fa), w, h, ax, ay);
-            sb = sample_trunc(reinterpret_cast<const uint32_t *>(fb), w, h, bx, by);
+            const float4 lo = reinterpret_cast<const float4 *>(reinterpret_cast<const float2 *>(flow) + idx)[0];
+            const float4 hi = reinterpret_cast<const float4 *>(reinterpret_cast<const float2 *>(flow) + idx)[1];
+            f[0] = make_float2(lo.x, lo.y);
+            f[1] = make_float2(lo.z, lo.w);
+            f[2] = make_float2(hi.x, hi.y);
+            f[3] = make_float2(hi.z, hi.w);
         }
-        uint32_t o = 0;
-        o = pack_trunc_u8(nt * sa.x + tv * sb.x, 0, o);
-        o = pack_trunc_u8(nt * sa.y + tv * sb.y, 1, o);
-        o = pack_trunc_u8(nt * sa.z + tv * sb.z, 2, o);
-        o = pack_trunc_u8(nt * sa.w + tv * sb.w, 3, o);
-        reinterpret_cast<uint32_t *>(out)[(size_t)blockIdx.z * npx + (size_t)y * w + x] = swz(o, sel);
+    } else {
+        if (HALF) {
+            const __half2 hf = reinterpret_cast<const __half2 *>(flow)[idx];
+            f[0] = make_float2(__low2float(hf), __high2float(hf));
+        } else {
+            f[0] = reinterpret_cast<const float2 *>(flow)[idx];
+        }
     }
+    const float yfl = (float)y;
+    uint32_t o[XV];
+#pragma unroll
+    for (int i = 0; i < XV; ++i) {
+        const float xfl = (float)(x0 + i);
+        float ax, ay, bx, by;
+        if (MODE == kWarpFma) {
+            ax = __builtin_fmaf(-tv, f[i].x, xfl), ay = __builtin_fmaf(-tv, f[i].y, yfl);
+            bx = __builtin_fmaf(nt, f[i].x, xfl), by = __builtin_fmaf(nt, f[i].y, yfl);
+        } else {
+            ax = xfl - tv * f[i].x, ay = yfl - tv * f[i].y;
+            bx = xfl + nt * f[i].x, by = yfl + nt * f[i].y;
+        }
+        const float4 sa = sample_corner<MODE>(ra, row_bytes, wmax, hmax, w - 2, h - 2, ax, ay);
+        const float4 sb = sample_corner<MODE>(rb, row_bytes, wmax, hmax, w - 2, h - 2, bx, by);
+        uint32_t p = 0;
+        if (MODE == kWarpFma) {
+            p = pack_trunc_u8(__builtin_fmaf(tv, sb.x, nt * sa.x), 0, p);
+            p = pack_trunc_u8(__builtin_fmaf(tv, sb.y, nt * sa.y), 1, p);
+            p = pack_trunc_u8(__builtin_fmaf(tv, sb.z, nt * sa.z), 2, p);
+            p = pack_trunc_u8(__builtin_fmaf(tv, sb.w, nt * sa.w), 3, p);
+        } else {
+            p = pack_trunc_u8(nt * sa.x + tv * sb.x, 0, p);
+            p = pack_trunc_u8(nt * sa.y + tv * sb.y, 1, p);
+            p = pack_trunc_u8(nt * sa.z + tv * sb.z, 2, p);
+            p = pack_trunc_u8(nt * sa.w + tv * sb.w, 3, p);
+        }
+        o[i] = swz(p, sel);
+    }
+    uint32_t *dst = reinterpret_cast<uint32_t *>(out) + idx;
+    if (XV == 4) {
+        *reinterpret_cast<uint4 *>(dst) = make_uint4(o[0], o[1], o[2], o[3]);
+    } else {
+        dst[0] = o[0];
+    }
+}
+
+// Frames narrower or lower than 2 pixels, or of 4 GiB and more: one pixel per thread, 64-bit addressing (EXACT arithmetic).
+__global__ __launch_bounds__(256) void k_warp_blend_flow_tiny(
+    const uint8_t *__restrict__ a, const uint8_t *__restrict__ b, const void *__restrict__ flow, bool half,
+    uint8_t *__restrict__ out, size_t a_stride, size_t b_stride, uint32_t w, uint32_t h, float t, uint32_t sel)
+{
+    const uint32_t y = blockIdx.y * 4 + threadIdx.y, x = blockIdx.x * kWave + threadIdx.x;
+    if (y >= h || x >= w) return;
+    const size_t npx = (size_t)w * h, idx = (size_t)blockIdx.z * npx + (size_t)y * w + x;
+    const uint32_t *fa = reinterpret_cast<const uint32_t *>(a + (size_t)blockIdx.z * a_stride);
+    const uint32_t *fb = reinterpret_cast<const uint32_t *>(b + (size_t)blockIdx.z * b_stride);
+    float2 f;
+    if (half) {
+        const __half2 hf = reinterpret_cast<const __half2 *>(flow)[idx];
+        f = make_float2(__low2float(hf), __high2float(hf));
+    } else {
+        f = reinterpret_cast<const float2 *>(flow)[idx];
+    }
+    const float nt = 1.0f - t;
+    const float4 sa = sample_trunc(fa, w, h, (float)x - t * f.x, (float)y - t * f.y);
+    const float4 sb = sample_trunc(fb, w, h, (float)x + nt * f.x, (float)y + nt * f.y);
+    uint32_t o = 0;
+    o = pack_trunc_u8(nt * sa.x + t * sb.x, 0, o);
+    o = pack_trunc_u8(nt * sa.y + t * sb.y, 1, o);
+    o = pack_trunc_u8(nt * sa.z + t * sb.z, 2, o);
+    o = pack_trunc_u8(nt * sa.w + t * sb.w, 3, o);
+    reinterpret_cast<uint32_t *>(out)[idx] = swz(o, sel);
 }
 
 // ---------------------------------------------------------------------------------
@@ -204,15 +280,26 @@ hipError_t launch_warp_blend(const WarpLaunch &L)
             else
                 hipLaunchKernelGGL(k_blend_zero_flow<false>, grid, block, 0, L.stream, a, b, out, L.a_stride, L.b_stride, npx, L.t, L.in_sel);
         } else {
-            const dim3 block(kWave, 4), grid(cdiv(L.w, 64), cdiv(L.h, 4 * NUS_WARP_ROWS), n);
-            const bool pairs = L.w >= 2 && npx * 4 < (1ull << 32);
             const void *fl = reinterpret_cast<const uint8_t *>(L.flow) + (size_t)done * npx * (L.flow_half ? 4 : 8);
-#define NUS_WB(P, H) hipLaunchKernelGGL((k_warp_blend_flow<P, H>), grid, block, 0, L.stream, a, b, fl, out, L.a_stride, L.b_stride, L.w, L.h, L.t, L.in_sel)
-            if (pairs && L.flow_half) NUS_WB(true, true);
-            else if (pairs) NUS_WB(true, false);
-            else if (L.flow_half) NUS_WB(false, true);
-            else NUS_WB(false, false);
+            const bool corner = L.w >= 2 && L.h >= 2 && npx * 4 < (1ull << 32) && L.w * 4ull < (1u << 24) && L.h < (1u << 24);
+            if (!corner) {
+                const dim3 block(kWave, 4), grid(cdiv(L.w, 64), cdiv(L.h, 4), n);
+                hipLaunchKernelGGL(k_warp_blend_flow_tiny, grid, block, 0, L.stream, a, b, fl, L.flow_half, out, L.a_stride, L.b_stride,
+                                   L.w, L.h, L.t, L.in_sel);
+            } else {
+                // 4 pixels per lane where a lane's flow vectors and output pixels are 16-byte pieces
+                const bool x4 = (L.w % 4) == 0 && (reinterpret_cast<uintptr_t>(fl) % 16) == 0 && (reinterpret_cast<uintptr_t>(out) % 16) == 0;
+                const dim3 block(kWave, 4), grid(cdiv(L.w, 64 * (x4 ? 4 : 1)), cdiv(L.h, 4), n);
+#define NUS_WB(M, H, X) hipLaunchKernelGGL((k_warp_blend_flow<M, H, X>), grid, block, 0, L.stream, a, b, fl, out, L.a_stride, L.b_stride, L.w, L.h, L.t, L.in_sel)
+#define NUS_WB_X(M, H) do { if (x4) NUS_WB(M, H, 4); else NUS_WB(M, H, 1); } while (0)
+                if (L.fma) {
+                    if (L.flow_half) NUS_WB_X(kWarpFma, true); else NUS_WB_X(kWarpFma, false);
+                } else {
+                    if (L.flow_half) NUS_WB_X(kWarpExact, true); else NUS_WB_X(kWarpExact, false);
+                }
+#undef NUS_WB_X
 #undef NUS_WB
+            }
         }
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;

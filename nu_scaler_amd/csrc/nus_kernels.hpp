@@ -158,6 +158,7 @@ struct WarpLaunch {
     const uint8_t *a = nullptr, *b = nullptr;
     const float *flow = nullptr; // nullptr: zero flow
     bool flow_half = false;      // the flow field is 2 x f16 per pixel (Rg16Float, wgpu_interpolator.rs:276), not 2 x f32
+    bool fma = false;            // dense-flow warp in fused multiply-adds (+-1 LSB) instead of the CPU's separate roundings
     uint8_t *out = nullptr;
     size_t a_stride = 0, b_stride = 0; // bytes between consecutive pairs
     uint32_t w = 0, h = 0;

@@ -107,6 +107,18 @@ class WgpuFrameInterpolator:
             raise ValueError("input format must be 'rgba', 'bgra', 'rgbx' or 'bgrx'")
         self._raise(self._lib.nus_interp_set_input_format(self._h, f))
 
+    def set_mode(self, mode: str) -> None:
+        """Arithmetic of the dense-flow warp: "exact" (default; the CPU's roundings, bit-exact against the oracle) or "fma"
+        (fused lerps, within 1 LSB).  The zero-flow blend is exact either way."""
+        m = {"exact": 0, "fma": 1}.get(str(mode).lower())
+        if m is None:
+            raise ValueError("mode must be 'exact' or 'fma'")
+        self._raise(self._lib.nus_interp_set_mode(self._h, m))
+
+    @property
+    def mode(self) -> str:
+        return "fma" if self._lib.nus_interp_mode(self._h) == 1 else "exact"
+
     def set_flow_format(self, fmt: str) -> None:
         """Element type of the device flow field `interpolate_device` reads: "f32" (default, 2 x f32 per pixel) or
         "f16" (2 x half per pixel: the Rg16Float texture of wgpu_interpolator.rs:276, half the bytes)."""

@@ -145,6 +145,22 @@ class PyWgpuUpscaler:
         del triples
         return outs
 
+    def upscale_batch_into(self, frames: Iterable, outs: Iterable) -> None:
+        """`upscale_batch` into caller-provided writable buffers (one per frame, each >= output_size): what a Rust caller
+        of nus_upscaler_upscale_batch does with its own Vecs; no allocation on the way."""
+        bufs = [_as_buffer(f) for f in frames]
+        obufs = [_as_buffer(o) for o in outs]
+        n = len(bufs)
+        if len(obufs) != n:
+            raise ValueError("upscale_batch_into: one output buffer per frame")
+        if n == 0:
+            return
+        ins_c = (ctypes.c_void_p * n)(*[b[0] for b in bufs])
+        lens_c = (ctypes.c_size_t * n)(*[b[1] for b in bufs])
+        outs_c = (ctypes.c_void_p * n)(*[b[0] for b in obufs])
+        self._check(self._lib.nus_upscaler_upscale_batch(self._h, ins_c, lens_c, n, outs_c, min(b[1] for b in obufs)))
+        del bufs, obufs
+
     # -- device-resident path (not in the reference; used by the frame stream + bench)
     def upscale_device(self, d_in: int, d_out: int, n_frames: int = 1, stream: int = 0) -> None:
         self._check(self._lib.nus_upscaler_upscale_device(self._h, d_in, d_out, n_frames, stream or None))

@@ -281,6 +281,59 @@ def test_warp_constant_flow_recovers_shifted_stream(nsc, oracle_mod):
     assert np.array_equal(out, oracle_mod.warp_blend(a, b, flow, 0.5))
 
 
+@pytest.mark.parametrize("size", [(64, 48), (61, 7), (2, 2), (256, 4), (130, 33), (1, 5), (7, 1), (1920, 1080)])
+def test_warp_blend_fma_mode_within_one_lsb(nsc, oracle_mod, size):
+    """NUS_INTERP_MODE_FMA of the dense-flow warp (fused lerps): every sample within 1 LSB of the oracle and fewer than
+    0.1 % of them different -- noise frames, sub-pixel flows everywhere, far-outside vectors, frame borders, widths that
+    take the 4-pixels-per-lane kernel and widths that do not, frames too small for the corner sampler, f32 and f16 flow
+    fields.  EXACT mode on the same inputs: bit-exact."""
+    import torch
+
+    w, h = size
+    n = 2 if w * h > 100000 else 3
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(w * 7 + h)
+    frames_np = np.stack([oracle_mod.gen_noise(w, h, 900 + i) for i in range(n + 1)])
+    flow = (rng.standard_normal((n, h, w, 2)) * 6).astype(np.float32)
+    flow[:, 0, 0] = (1000.0, -1000.0)
+    flow[:, -1, -1] = (-0.25, 7.5)
+    frames = torch.from_numpy(frames_np).to(dev)
+    fb = w * h * 4
+    s = torch.cuda.current_stream().cuda_stream
+    it = nsc.WgpuFrameInterpolator()
+    assert it.mode == "exact"
+    out = torch.zeros((n, h, w, 4), dtype=torch.uint8, device=dev)
+    for t in (0.5, 0.3):
+        for fmt in ("f32", "f16"):
+            fl_np = flow if fmt == "f32" else flow.astype(np.float16)
+            d_flow = torch.from_numpy(fl_np).to(dev)
+            it.set_flow_format(fmt)
+            want = [oracle_mod.warp_blend(frames_np[i], frames_np[i + 1], fl_np[i].astype(np.float32), t, threads=0) for i in range(n)]
+            for mode in ("exact", "fma"):
+                it.set_mode(mode)
+                out.zero_()
+                it.interpolate_device(frames.data_ptr(), fb, frames.data_ptr() + fb, fb, d_flow.data_ptr(), w, h, t, out.data_ptr(), n, s)
+                torch.cuda.synchronize()
+                got = out.cpu().numpy()
+                for i in range(n):
+                    if mode == "exact":
+                        assert np.array_equal(got[i], want[i]), (size, t, fmt, i)
+                    else:
+                        d = np.abs(got[i].astype(np.int16) - want[i].astype(np.int16))
+                        assert d.max() <= 1, (size, t, fmt, i, int(d.max()))
+                        assert (d > 0).mean() < 1e-3 or d.size < 4000, (size, t, fmt, i, float((d > 0).mean()))
+    # host entry point in FMA mode; zero flow stays the exact blend
+    it.set_mode("fma")
+    it.set_flow_format("f32")
+    a, b = frames_np[0], frames_np[1]
+    got = np.frombuffer(it.interpolate_py(a.tobytes(), b.tobytes(), w, h, time_t=0.5, flow=flow[0]), np.uint8).reshape(h, w, 4)
+    assert np.abs(got.astype(np.int16) - oracle_mod.warp_blend(a, b, flow[0], 0.5).astype(np.int16)).max() <= 1
+    z = np.frombuffer(it.interpolate_py(a.tobytes(), b.tobytes(), w, h, time_t=0.5), np.uint8).reshape(h, w, 4)
+    assert np.array_equal(z, oracle_mod.warp_blend(a, b, None, 0.5))
+    with pytest.raises(ValueError):
+        it.set_mode("fast")
+
+
 def test_warp_blend_with_f16_flow_field(nsc, oracle_mod):
     """NUS_FLOW_F16: the Rg16Float flow layout of the reference's live path (wgpu_interpolator.rs:276).  Each half widens
     to f32 exactly, so the result equals the oracle run on the f16-rounded flow bit for bit; against the unrounded f32
@@ -356,6 +409,43 @@ def test_upscale_batch_matches_single(nsc, oracle_mod, alg):
     for f, o in zip(frames, outs):
         assert np.array_equal(np.frombuffer(o, np.uint8).reshape(2 * h, 2 * w, 4), ref(f, 2 * w, 2 * h))
     assert u.upscale_batch([]) == []
+
+
+def test_upscale_batch_pipeline_many_frames_every_buffer_kind(nsc, oracle_mod):
+    """The pipelined batch (submitting thread + retiring thread + copy pool): more frames than slots at a size whose
+    output comes back in several pieces, into fresh bytes, into caller-owned pageable buffers and into pinned ones,
+    repeatedly on one handle; a bad frame in the middle of a batch fails the call and leaves the handle usable."""
+    import torch
+
+    w, h, n = 640, 360, 11  # 3.7 MB out per frame: 8 pieces of ~460 KB, each copy split over the pool
+    frames = [oracle_mod.gen_noise(w, h, 4000 + i) for i in range(n)]
+    want = [oracle_mod.bilinear(f, 2 * w, 2 * h) for f in frames]
+    u = nsc.PyWgpuUpscaler("quality", "bilinear")
+    u.initialize(w, h, 2 * w, 2 * h)
+    ins = [f.tobytes() for f in frames]
+    for _ in range(2):
+        outs = u.upscale_batch(ins)
+        assert all(np.array_equal(np.frombuffer(o, np.uint8).reshape(2 * h, 2 * w, 4), wnt) for o, wnt in zip(outs, want))
+    bufs = [bytearray(u.output_size) for _ in range(n)]
+    u.upscale_batch_into(ins, bufs)
+    assert all(np.array_equal(np.frombuffer(b, np.uint8).reshape(2 * h, 2 * w, 4), wnt) for b, wnt in zip(bufs, want))
+    pin_in = torch.empty((n, u.input_size), dtype=torch.uint8, pin_memory=True)
+    pin_out = torch.zeros((n, u.output_size), dtype=torch.uint8, pin_memory=True)
+    for k in range(n):
+        pin_in[k] = torch.from_numpy(frames[k].reshape(-1))
+    u.upscale_batch_into([pin_in[k].numpy() for k in range(n)], [pin_out[k].numpy() for k in range(n)])
+    assert all(np.array_equal(pin_out[k].numpy().reshape(2 * h, 2 * w, 4), want[k]) for k in range(n))
+    # mixed: pinned inputs, pageable outputs, and a single-frame batch
+    u.upscale_batch_into([pin_in[k].numpy() for k in range(n)], bufs)
+    assert np.array_equal(np.frombuffer(bufs[n - 1], np.uint8).reshape(2 * h, 2 * w, 4), want[n - 1])
+    one = [bytearray(u.output_size)]
+    u.upscale_batch_into(ins[4:5], one)
+    assert np.array_equal(np.frombuffer(one[0], np.uint8).reshape(2 * h, 2 * w, 4), want[4])
+    bad = list(ins)
+    bad[6] = bad[6][:-4]
+    with pytest.raises(RuntimeError, match="does not match expected input buffer size"):
+        u.upscale_batch(bad)
+    assert np.array_equal(np.frombuffer(u.upscale(ins[2]), np.uint8).reshape(2 * h, 2 * w, 4), want[2])
 
 
 def test_table_export_import_roundtrip(nsc, oracle_mod):

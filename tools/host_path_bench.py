@@ -38,6 +38,14 @@ def main():
         outs = u.upscale_batch(frames)
         dtb = (time.perf_counter() - t0) / len(frames)
         del outs
+        bufs = [bytearray(u.output_size) for _ in frames]
+        u.upscale_batch_into(frames, bufs)
+        t0 = time.perf_counter()
+        for _ in range(3):
+            u.upscale_batch_into(frames, bufs)
+        dti = (time.perf_counter() - t0) / (3 * len(frames))
+        del bufs
+        print(f"{alg:9s} upscale_batch_into(12, caller buffers): {dti*1e3:7.3f} ms/frame = {1/dti:7.1f} frames/s = {dt/dti:4.2f}x the single-call rate")
         print(f"{alg:9s} upscale(): {dt*1e3:7.3f} ms/frame = {1/dt:7.1f} frames/s, {(u.input_size+u.output_size)/dt/1e9:6.2f} GB/s host<->device;"
               f" upscale()->bytes {dtp*1e3:6.2f} ms; upscale_batch(12): {dtb*1e3:7.3f} ms/frame = {1/dtb:7.1f} frames/s; kernel {u.get_last_gpu_duration_ms()*1e3:7.1f} us")
     it = nsc.WgpuFrameInterpolator()

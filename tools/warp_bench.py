@@ -23,8 +23,9 @@ coarse = torch.randn((n, 2, h // 40, w // 40), generator=g, device=dev) * 4.0
 smooth = torch.nn.functional.interpolate(coarse, size=(h, w), mode="bilinear").permute(0, 2, 3, 1).contiguous()
 cases = [("constant (-1, 0)", const, "f32"), ("smooth random, sigma 4 px", smooth, "f32"),
          ("smooth random, f16 flow field", smooth.to(torch.float16), "f16")]
-for name, flow, fmt in cases:
+for name, flow, fmt, mode in [c + (m,) for c in cases for m in ("exact", "fma")]:
     it.set_flow_format(fmt)
+    it.set_mode(mode)
     run = lambda: it.interpolate_device(frames.data_ptr(), fb, frames.data_ptr() + fb, fb, flow.data_ptr(), w, h, 0.5, mid.data_ptr(), n, s)
     for _ in range(2):
         run()
@@ -37,4 +38,4 @@ for name, flow, fmt in cases:
     torch.cuda.synchronize()
     us = e0.elapsed_time(e1) / 5 / n * 1e3
     nb = (5 if fmt == "f32" else 4) * fb
-    print(f"warp_blend_flow {name:32s} {us:7.2f} us/pair  {nb / us / 1e6:5.2f} TB/s algorithmic")
+    print(f"warp_blend_flow {mode:5s} {name:32s} {us:7.2f} us/pair  {nb / us / 1e6:5.2f} TB/s algorithmic = {nb / us / 1e6 / 8 * 100:4.1f} % of 8 TB/s")
