@@ -70,6 +70,9 @@ def parse_args(argv=None):
     ap.add_argument("--no-check", action="store_true", help="skip the oracle check of the timed output buffers")
     ap.add_argument("--sustained-seconds", type=float, default=6.0,
                     help="length of the sustained leg after the timed region (0 = skip; N=1 only)")
+    ap.add_argument("--host-fed-seconds", type=float, default=1.5,
+                    help="length of the host-fed leg (mode ii: every rank feeds its GPU from host memory through "
+                         "nus_upscaler_upscale_batch at the same time; 0 = skip)")
     ap.add_argument("--schedule", choices=["unit", "three-stage"], default="unit",
                     help="unit: the whole step in one launch of the x2 kernel (default); three-stage: blend, upscale, upscale")
     ap.add_argument("--fused", action="store_true",
@@ -137,6 +140,31 @@ def _median(xs):
     return xs[n // 2] if n % 2 else 0.5 * (xs[n // 2 - 1] + xs[n // 2])
 
 
+def usable_cpus():
+    """CPUs this process may actually keep busy: its affinity mask, capped by the cgroup's CFS quota (cpu.max: quota / period).
+    A GPU box's job gets a share of the host (16 CPUs per GPU on this pool); more OpenMP threads than that burn the quota in
+    the first milliseconds of every 100 ms period and sleep through the rest of it (a 1080p Lanczos pass: 4 ms on 64 threads,
+    8.4 ms on 16, 100-200 ms on 256 -- profiles/r03_cpu_baseline_threads.txt)."""
+    n = len(os.sched_getaffinity(0))
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            with open(path) as f:
+                parts = f.read().split()
+            if path.endswith("cpu.max"):
+                if parts[0] != "max":
+                    n = min(n, max(1, int(int(parts[0]) / int(parts[1]) + 0.5)))
+            else:
+                quota = int(parts[0])
+                with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+                    period = int(f.read().split()[0])
+                if quota > 0:
+                    n = min(n, max(1, int(quota / period + 0.5)))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return n
+
+
 def cpu_baseline(args, unit_pixels):
     """Time the CPU oracle on the host cores of this box: every algorithm of the path on its own and the
     combined unit, each as the median of 10 runs after 2 warm-ups, single
@@ -148,7 +176,7 @@ def cpu_baseline(args, unit_pixels):
     oracle.build()
     w, h = args.width, args.height
     a, b = oracle.gen_gradient(w, h, 0), oracle.gen_gradient(w, h, 1)
-    cores = oracle.max_threads()
+    cores = min(oracle.max_threads(), usable_cpus())
     t_start = time.perf_counter()
 
     def timed(fn_of_rows, runs=10, warm=2, budget_s=4.0):
@@ -177,7 +205,7 @@ def cpu_baseline(args, unit_pixels):
     per_alg = {}
     for name, (fn, pix_per_row) in legs.items():
         t1, r1 = timed(lambda r: fn(r, 1))
-        tn, rn = timed(lambda r: fn(r, 0)) if cores > 1 else (t1, r1)
+        tn, rn = timed(lambda r: fn(r, cores)) if cores > 1 else (t1, r1)
         per_alg[name] = {"Mpix_per_s_1_thread": round(pix_per_row * r1 / t1 / 1e6, 1), "rows_1_thread": r1,
                          "Mpix_per_s_all_cores": round(pix_per_row * rn / tn / 1e6, 1), "rows_all_cores": rn}
 
@@ -188,7 +216,7 @@ def cpu_baseline(args, unit_pixels):
 
     unit_pix_per_row = unit_pixels / h
     t1, r1 = timed(lambda r: unit(r, 1), budget_s=6.0)
-    tn, rn = timed(lambda r: unit(r, 0), budget_s=6.0) if cores > 1 else (t1, r1)
+    tn, rn = timed(lambda r: unit(r, cores), budget_s=6.0) if cores > 1 else (t1, r1)
     return {
         "value": round(unit_pix_per_row * r1 / t1 / 1e6, 3),
         "unit": "Mpix/s",
@@ -198,7 +226,9 @@ def cpu_baseline(args, unit_pixels):
                   f"frame pair, median of 10 runs after 2 warm-ups, {t1 * 1e3:.1f} ms per run; oracle/nus_oracle.c, "
                   f"gcc -O2 -ffp-contract=off; per_algorithm: each algorithm alone, same protocol; "
                   f"whole leg {time.perf_counter() - t_start:.1f} s",
-        "all_cores": {"value": round(unit_pix_per_row * rn / tn / 1e6, 3), "cores": cores, "rows": rn},
+        "all_cores": {"value": round(unit_pix_per_row * rn / tn / 1e6, 3), "cores": cores, "rows": rn,
+                      "what": "OpenMP row blocks on the CPUs this job may keep busy (affinity mask capped by the cgroup's CPU quota); "
+                              f"the host has {os.cpu_count()} hardware threads"},
         "per_algorithm": per_alg,
     }
 
@@ -271,14 +301,15 @@ def check_timed_outputs(frames, mid_t, up_real, up_mid, picks, w, h):
     for k in picks:
         a = frames[k].cpu().numpy()
         b = frames[k + 1].cpu().numpy()
-        mid = oracle.warp_blend(a, b, None, 0.5, threads=0)
+        th = usable_cpus()
+        mid = oracle.warp_blend(a, b, None, 0.5, threads=th)
         if mid_t is not None:
             same = bool(np.array_equal(mid_t[k].cpu().numpy(), mid))
             report.append({"frame": int(k), "buffer": "mid", "bit_exact": same})
             if not same:
                 raise SystemExit(f"bench.py: timed output mid[{k}] differs from the oracle's warp_blend")
         for name, got_t, src in (("up_real", up_real, a), ("up_mid", up_mid, mid)):
-            want = oracle.lanczos3(src, 2 * w, 2 * h, threads=0).astype(np.int16)
+            want = oracle.lanczos3(src, 2 * w, 2 * h, threads=th).astype(np.int16)
             got = got_t[k].cpu().numpy().astype(np.int16)
             d = np.abs(got - want)
             mx, frac = int(d.max()), float((d != 0).mean())
@@ -400,6 +431,28 @@ def host_path_leg(nsc, syn, torch, w, h, device):
         "unit_4k_output_frames_per_s": round(2e3 / unit_ms, 1),
         "target_4k_output_frames_per_s": 60,
     }
+
+
+def host_fed_leg(nsc, syn, w, h, device, seconds, barrier):
+    """Mode (ii) of SURVEY.md 8(d)/(e), on every rank at once: a host-resident shard of the stream (12 pageable 1080p frames)
+    goes through nus_upscaler_upscale_batch -- one submitting host thread, three slot streams per GPU, H2D / kernel / D2H
+    pipelined, outputs into caller-owned pageable 4K buffers -- for `seconds` of wall time between two barriers.
+    Returns this rank's 4K frames per second."""
+    nb = 12
+    frames = [syn.gradient_frame(w, h, k).tobytes() for k in range(nb)]
+    u = nsc.PyWgpuUpscaler("quality", "lanczos3", device=device)
+    u.initialize(w, h, 2 * w, 2 * h)
+    outs = [bytearray(u.output_size) for _ in range(nb)]
+    u.upscale_batch_into(frames, outs)  # allocates the slots, touches the buffers
+    barrier()
+    t0 = time.perf_counter()
+    n = 0
+    while time.perf_counter() - t0 < seconds:
+        u.upscale_batch_into(frames, outs)
+        n += nb
+    dt = time.perf_counter() - t0
+    barrier()
+    return n / dt
 
 
 class ClockSampler:
@@ -617,6 +670,26 @@ def worker(args):
     if rank == 0 and world == 1 and args.sustained_seconds > 0:
         sustained = sustained_leg(torch, do_step, pipe.upscaler, args.sustained_seconds)
 
+    # Mode (ii): every rank feeds its own GPU from host memory at the same time (any N; never `value`)
+    host_fed = None
+    if args.host_fed_seconds > 0 and not args.no_extras:
+        rate = host_fed_leg(nsc, syn, w, h, local_rank, args.host_fed_seconds, barrier)
+        rates = [rate]
+        if world > 1:
+            tr = torch.tensor([rate], dtype=torch.float64, device=comm_dev)
+            got = [torch.zeros_like(tr) for _ in range(world)]
+            dist.all_gather(got, tr)
+            rates = [float(g.item()) for g in got]
+        frame_mb = (w * h + 4 * w * h) * 4 / 1e6
+        host_fed = {
+            "what": "mode (ii): each rank pushes a host-resident shard (12 pageable 1080p frames per call, outputs into pageable "
+                    "4K buffers) through nus_upscaler_upscale_batch -- one submitting thread + a retiring thread + the copy pool, "
+                    "three slot streams per GPU -- all ranks at the same time, between two barriers",
+            "seconds": args.host_fed_seconds, "frames_4k_per_s_total": round(sum(rates), 1),
+            "frames_4k_per_s_per_gpu": {"min": round(min(rates), 1), "max": round(max(rates), 1)},
+            "host_device_GBps_total": round(sum(rates) * frame_mb / 1e3, 2),
+            "target_4k_frames_per_s_per_gpu": 60}
+
     extras = rank == 0 and world == 1 and not args.no_extras and not args.fused and not args.overlap
 
     def timed_leg(step_fn, n, with_profile=True):
@@ -669,6 +742,7 @@ def worker(args):
     motion_ms = None
     if extras:
         flows = torch.empty((count, h, w, 2), dtype=torch.float32, device=dev)
+        pipe.interp.set_mode("fma")  # the dense-flow warp in its product mode (+-1 LSB, as Lanczos); zero flow is exact either way
         pipe.step_motion(frames, flows, mid, up_real, up_mid, stream)
         torch.cuda.synchronize()
         tm = time.perf_counter()
@@ -676,6 +750,7 @@ def worker(args):
             pipe.step_motion(frames, flows, mid, up_real, up_mid, stream)
         torch.cuda.synchronize()
         motion_ms = (time.perf_counter() - tm) / 2 * 1e3
+        pipe.interp.set_mode("exact")
         del flows
 
     # Informational: both schedules on the other pattern (gradient = opaque frames, the kernel's
@@ -686,10 +761,10 @@ def worker(args):
         fill(other_pattern)
         other = (other_pattern, timed_leg(do_step, n_leg), timed_leg(step3 if unit_schedule else stepu, n_leg))
 
+    # (the device buffers stay allocated meanwhile: on this ROCm stack, copies in both directions at once take 1.8x as long
+    # in a process that has just returned 25 GB to the driver -- profiles/r03_host_path_process_state.txt)
     host_path = None
     if extras:
-        del frames, mid, up_real, up_mid
-        torch.cuda.empty_cache()
         host_path = host_path_leg(nsc, syn, torch, w, h, local_rank)
 
     if rank == 0:
@@ -802,10 +877,11 @@ def worker(args):
                     other_schedule=leg(other[2][0])),
                 "motion_variant": None if motion_ms is None else {
                     "what": "three-stage step with a dense flow per pair (3-level pyramid, 50 + 10 + 10 Horn-Schunck steps) "
-                            "feeding the warp instead of zero flow; informational, this rank only",
+                            "feeding the warp (FMA mode) instead of zero flow; informational, this rank only",
                     "ms_per_step": round(motion_ms, 3),
                     "units_per_s_per_gpu": round(n_units / motion_ms * 1e3, 1)},
                 "host_path": host_path,
+                "host_fed": host_fed,
                 "frames_per_sec_per_gpu_4k_out": round(2 * n_units * args.steps / elapsed, 1),
                 "algorithmic_GBps": round(total_units * pipe.unit_bytes / elapsed / 1e9, 1),
             },

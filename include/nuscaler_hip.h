@@ -279,8 +279,9 @@ int nus_interp_set_flow_format(nus_interp *h, int format);
 /* Arithmetic of the dense-flow warp (flow != NULL), as nus_upscaler_set_lanczos_mode for the resize filters:
  *   NUS_INTERP_MODE_EXACT (default)  every product and sum rounded separately, as the CPU code of
  *                                    interpolation/mod.rs:467-510 and :386-411 -- bit-exact against the oracle;
- *   NUS_INTERP_MODE_FMA              each bilinear lerp as a + f (b - a) with one fused multiply-add, the blend likewise:
- *                                    within 1 LSB of EXACT (fewer than 0.1 % of the samples differ), 0.8x the instructions.
+ *   NUS_INTERP_MODE_FMA              each bilinear lerp as a + f (b - a) with one fused multiply-add (the blend of the two
+ *                                    truncated samples keeps the CPU's roundings): within 1 LSB of EXACT, fewer than 0.1 % of
+ *                                    the samples differ, 0.8x the instructions.
  * The zero-flow path (the reference's live behaviour) is the same exact streaming blend in both modes. */
 typedef enum nus_interp_mode_t { NUS_INTERP_MODE_EXACT = 0, NUS_INTERP_MODE_FMA = 1 } nus_interp_mode_t;
 int nus_interp_set_mode(nus_interp *h, int mode);

@@ -75,16 +75,18 @@ __device__ __forceinline__ float4 sample_trunc(const uint32_t *__restrict__ f, u
 //    w - 1 and fraction 0 (interpolation/mod.rs:474-483), they are exactly 1 and select the same texel:
 //    p(w-2) * (1 - 1) + p(w-1) * 1 = p(w-1), bit for bit in either mode;
 //  * MODE_EXACT: every product and sum separately, the CPU's roundings (bit-exact against the oracle);
-//    MODE_FMA  : each of the three lerps as one subtraction and one fused multiply-add, a + f (b - a): 24 instead of 36
-//    operations per sample, inside the +-1 LSB contract of the interpolation path (measured: < 0.1 % of the samples
-//    differ, none by more than one count).
+//    MODE_FMA  : each of the three lerps of a sample as one multiply and one fused multiply-add, fma(b, f, a (1 - f)): 24
+//    instead of 36 operations per sample (and the sample positions as one FMA each), inside the +-1 LSB contract of the
+//    interpolation path (measured on noise frames with random flows: < 0.1 % of the samples differ, none by more than
+//    one count).  The blend of the two samples is exact in both modes (see the kernel).
 // The truncation of each sample to u8 (sample_frame returns u8: interpolation/mod.rs:506) stays in both modes.
 constexpr int kWarpExact = 0, kWarpFma = 1;
 
 template <int MODE>
 __device__ __forceinline__ float lerp_mode(float a, float b, float f, float nf)
 {
-    if (MODE == kWarpFma) return __builtin_fmaf(f, b - a, a);
+    if (MODE == kWarpFma) return __builtin_fmaf(b, f, a * nf); // (the form a + f (b - a) makes the compiler subtract the packed
+                                                               // bytes and convert the difference: two slow-class instructions)
     return a * nf + b * f;
 }
 
@@ -112,18 +114,28 @@ __device__ __forceinline__ float4 sample_corner(__amdgpu_buffer_rsrc_t rs, uint3
 }
 
 // Dense flow (2 x f32 or 2 x f16 per pixel, delta A -> B): A sampled at p - t*flow, B at p + (1-t)*flow
-// (warp_blend.wgsl:36-37 in texel space).  A lane owns XV consecutive pixels of a row: XV = 4 (frame width a multiple
-// of 4) loads its flow vectors as 32 (16) contiguous bytes and stores its 4 pixels as one 16-byte piece; the gathers of
-// the XV pixels -- independent chains -- are in flight together.  blockDim = (64, 4): a block covers 64 XV x 4 pixels.
+// (warp_blend.wgsl:36-37 in texel space).  A thread owns XV consecutive pixels in each of RV rows (rows y, y + 4, .. of the
+// block's 4 RV): its flow vectors are loaded first, then the gathers of its pixels -- independent chains -- are in flight
+// together.  XV = 2 (frame width even): the two flow vectors of a row are one 16-byte (8-byte) load, the two pixels one
+// 8-byte store, and a wave's gathers stay on few cache lines.  blockDim = (64, 4): a block covers 64 XV x 4 RV pixels.
 // HALF: the flow field is the Rg16Float texture of the reference's live path (wgpu_interpolator.rs:276), widened exactly.
-template <int MODE, bool HALF, int XV>
+// Measured on one box, 1080p, us per pair, EXACT / FMA (profiles/r03_warp_kernel_layouts_ab.txt): the round-2 kernel (1 x 4, border
+// selects) 10.7 / -; 1 x 4 9.6-10.4 / 8.5-8.7; 4 x 1 11.2-13.1 / 11.1-13.1 (a wave's gathers spread over four times the
+// cache lines: the kernel stops being bound by its arithmetic); 2 x 2: 8.7-9.3 / 7.9-8.5.
+#ifndef NUS_WARP_XV
+#define NUS_WARP_XV 2
+#endif
+#ifndef NUS_WARP_RV
+#define NUS_WARP_RV 2
+#endif
+template <int MODE, bool HALF, int XV, int RV>
 __global__ __launch_bounds__(256) void k_warp_blend_flow(
     const uint8_t *__restrict__ a, const uint8_t *__restrict__ b, const void *__restrict__ flow,
     uint8_t *__restrict__ out, size_t a_stride, size_t b_stride, uint32_t w, uint32_t h, float t, uint32_t sel)
 {
-    const uint32_t y = __builtin_amdgcn_readfirstlane(blockIdx.y * 4 + threadIdx.y);
+    const uint32_t ybase = __builtin_amdgcn_readfirstlane(blockIdx.y * (4 * RV) + threadIdx.y);
     const uint32_t x0 = (blockIdx.x * kWave + threadIdx.x) * XV;
-    if (y >= h || x0 >= w) return;
+    if (ybase >= h || x0 >= w) return;
     const size_t npx = (size_t)w * h;
     const uint32_t frame_bytes = (uint32_t)(npx * 4), row_bytes = w * 4;
     const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(
@@ -134,67 +146,90 @@ __global__ __launch_bounds__(256) void k_warp_blend_flow(
     float tv = t, wmax = (float)(w - 1), hmax = (float)(h - 1);
     asm volatile("" : "+v"(tv), "+v"(wmax), "+v"(hmax));
     const float nt = 1.0f - tv;
-    const size_t idx = (size_t)blockIdx.z * npx + (size_t)y * w + x0;
-    float2 f[XV];
-    if (XV == 4) {
-        if (HALF) {
-            const uint4 raw = *reinterpret_cast<const uint4 *>(reinterpret_cast<const __half2 *>(flow) + idx);
-            const uint32_t rw[4] = {raw.x, raw.y, raw.z, raw.w};
+    const size_t frame0 = (size_t)blockIdx.z * npx;
+    float2 f[RV][XV];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const __half2 hf = *reinterpret_cast<const __half2 *>(&rw[i]);
-                f[i] = make_float2(__low2float(hf), __high2float(hf));
+    for (int j = 0; j < RV; ++j) { // the flow vectors of all the thread's pixels first (rows past the frame: the last row's)
+        const size_t idx = frame0 + (size_t)umin(ybase + 4 * j, h - 1) * w + x0;
+        if (XV == 4) {
+            if (HALF) {
+                const uint4 raw = *reinterpret_cast<const uint4 *>(reinterpret_cast<const __half2 *>(flow) + idx);
+                const uint32_t rw[4] = {raw.x, raw.y, raw.z, raw.w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const __half2 hf = *reinterpret_cast<const __half2 *>(&rw[i]);
+                    f[j][i] = make_float2(__low2float(hf), __high2float(hf));
+                }
+            } else {
+                const float4 lo = reinterpret_cast<const float4 *>(reinterpret_cast<const float2 *>(flow) + idx)[0];
+                const float4 hi = reinterpret_cast<const float4 *>(reinterpret_cast<const float2 *>(flow) + idx)[1];
+                f[j][0] = make_float2(lo.x, lo.y);
+                f[j][1] = make_float2(lo.z, lo.w);
+                f[j][2] = make_float2(hi.x, hi.y);
+                f[j][3] = make_float2(hi.z, hi.w);
+            }
+        } else if (XV == 2) { // (w even, host-checked: the pair is 16-byte / 8-byte aligned)
+            if (HALF) {
+                const uint2 raw = *reinterpret_cast<const uint2 *>(reinterpret_cast<const __half2 *>(flow) + idx);
+                const __half2 h0 = *reinterpret_cast<const __half2 *>(&raw.x), h1 = *reinterpret_cast<const __half2 *>(&raw.y);
+                f[j][0] = make_float2(__low2float(h0), __high2float(h0));
+                f[j][1] = make_float2(__low2float(h1), __high2float(h1));
+            } else {
+                const float4 v = *reinterpret_cast<const float4 *>(reinterpret_cast<const float2 *>(flow) + idx);
+                f[j][0] = make_float2(v.x, v.y);
+                f[j][1] = make_float2(v.z, v.w);
             }
         } else {
-            const float4 lo = reinterpret_cast<const float4 *>(reinterpret_cast<const float2 *>(flow) + idx)[0];
-            const float4 hi = reinterpret_cast<const float4 *>(reinterpret_cast<const float2 *>(flow) + idx)[1];
-            f[0] = make_float2(lo.x, lo.y);
-            f[1] = make_float2(lo.z, lo.w);
-            f[2] = make_float2(hi.x, hi.y);
-            f[3] = make_float2(hi.z, hi.w);
-        }
-    } else {
-        if (HALF) {
-            const __half2 hf = reinterpret_cast<const __half2 *>(flow)[idx];
-            f[0] = make_float2(__low2float(hf), __high2float(hf));
-        } else {
-            f[0] = reinterpret_cast<const float2 *>(flow)[idx];
+#pragma unroll
+            for (int i = 0; i < XV; ++i) {
+                if (HALF) {
+                    const __half2 hf = reinterpret_cast<const __half2 *>(flow)[idx + i];
+                    f[j][i] = make_float2(__low2float(hf), __high2float(hf));
+                } else {
+                    f[j][i] = reinterpret_cast<const float2 *>(flow)[idx + i];
+                }
+            }
         }
     }
-    const float yfl = (float)y;
-    uint32_t o[XV];
 #pragma unroll
-    for (int i = 0; i < XV; ++i) {
-        const float xfl = (float)(x0 + i);
-        float ax, ay, bx, by;
-        if (MODE == kWarpFma) {
-            ax = __builtin_fmaf(-tv, f[i].x, xfl), ay = __builtin_fmaf(-tv, f[i].y, yfl);
-            bx = __builtin_fmaf(nt, f[i].x, xfl), by = __builtin_fmaf(nt, f[i].y, yfl);
-        } else {
-            ax = xfl - tv * f[i].x, ay = yfl - tv * f[i].y;
-            bx = xfl + nt * f[i].x, by = yfl + nt * f[i].y;
-        }
-        const float4 sa = sample_corner<MODE>(ra, row_bytes, wmax, hmax, w - 2, h - 2, ax, ay);
-        const float4 sb = sample_corner<MODE>(rb, row_bytes, wmax, hmax, w - 2, h - 2, bx, by);
-        uint32_t p = 0;
-        if (MODE == kWarpFma) {
-            p = pack_trunc_u8(__builtin_fmaf(tv, sb.x, nt * sa.x), 0, p);
-            p = pack_trunc_u8(__builtin_fmaf(tv, sb.y, nt * sa.y), 1, p);
-            p = pack_trunc_u8(__builtin_fmaf(tv, sb.z, nt * sa.z), 2, p);
-            p = pack_trunc_u8(__builtin_fmaf(tv, sb.w, nt * sa.w), 3, p);
-        } else {
+    for (int j = 0; j < RV; ++j) {
+        const uint32_t y = ybase + 4 * j;
+        if (y >= h) break; // wave-uniform
+        const float yfl = (float)y;
+        uint32_t o[XV];
+#pragma unroll
+        for (int i = 0; i < XV; ++i) {
+            const float xfl = (float)(x0 + i);
+            float ax, ay, bx, by;
+            if (MODE == kWarpFma) {
+                ax = __builtin_fmaf(-tv, f[j][i].x, xfl), ay = __builtin_fmaf(-tv, f[j][i].y, yfl);
+                bx = __builtin_fmaf(nt, f[j][i].x, xfl), by = __builtin_fmaf(nt, f[j][i].y, yfl);
+            } else {
+                ax = xfl - tv * f[j][i].x, ay = yfl - tv * f[j][i].y;
+                bx = xfl + nt * f[j][i].x, by = yfl + nt * f[j][i].y;
+            }
+            const float4 sa = sample_corner<MODE>(ra, row_bytes, wmax, hmax, w - 2, h - 2, ax, ay);
+            const float4 sb = sample_corner<MODE>(rb, row_bytes, wmax, hmax, w - 2, h - 2, bx, by);
+            // the blend of the two truncated samples keeps the CPU's three roundings in both modes: with integer operands and
+            // a t like 0.3 a tenth of the exact results are integers themselves (0.7 * 10 + 0.3 * 20 = 13), and there the
+            // truncation turns any other rounding sequence into a count of difference (measured: 0.25 % of the samples with a
+            // fused blend)
+            uint32_t p = 0;
             p = pack_trunc_u8(nt * sa.x + tv * sb.x, 0, p);
             p = pack_trunc_u8(nt * sa.y + tv * sb.y, 1, p);
             p = pack_trunc_u8(nt * sa.z + tv * sb.z, 2, p);
             p = pack_trunc_u8(nt * sa.w + tv * sb.w, 3, p);
+            o[i] = swz(p, sel);
         }
-        o[i] = swz(p, sel);
-    }
-    uint32_t *dst = reinterpret_cast<uint32_t *>(out) + idx;
-    if (XV == 4) {
-        *reinterpret_cast<uint4 *>(dst) = make_uint4(o[0], o[1], o[2], o[3]);
-    } else {
-        dst[0] = o[0];
+        uint32_t *dst = reinterpret_cast<uint32_t *>(out) + frame0 + (size_t)y * w + x0;
+        if (XV == 4) {
+            *reinterpret_cast<uint4 *>(dst) = make_uint4(o[0], o[1], o[2], o[3]);
+        } else if (XV == 2) {
+            *reinterpret_cast<uint2 *>(dst) = make_uint2(o[0], o[1]);
+        } else {
+#pragma unroll
+            for (int i = 0; i < XV; ++i) dst[i] = o[i];
+        }
     }
 }
 
@@ -287,11 +322,13 @@ hipError_t launch_warp_blend(const WarpLaunch &L)
                 hipLaunchKernelGGL(k_warp_blend_flow_tiny, grid, block, 0, L.stream, a, b, fl, L.flow_half, out, L.a_stride, L.b_stride,
                                    L.w, L.h, L.t, L.in_sel);
             } else {
-                // 4 pixels per lane where a lane's flow vectors and output pixels are 16-byte pieces
-                const bool x4 = (L.w % 4) == 0 && (reinterpret_cast<uintptr_t>(fl) % 16) == 0 && (reinterpret_cast<uintptr_t>(out) % 16) == 0;
-                const dim3 block(kWave, 4), grid(cdiv(L.w, 64 * (x4 ? 4 : 1)), cdiv(L.h, 4), n);
-#define NUS_WB(M, H, X) hipLaunchKernelGGL((k_warp_blend_flow<M, H, X>), grid, block, 0, L.stream, a, b, fl, out, L.a_stride, L.b_stride, L.w, L.h, L.t, L.in_sel)
-#define NUS_WB_X(M, H) do { if (x4) NUS_WB(M, H, 4); else NUS_WB(M, H, 1); } while (0)
+                constexpr int XV = NUS_WARP_XV, RV = NUS_WARP_RV;
+                const uintptr_t align = XV == 4 ? 16 : 8; // of the thread's output pixels (its f16 flow vectors: the same bytes)
+                const bool xv_ok = XV == 1 || ((L.w % XV) == 0 && (reinterpret_cast<uintptr_t>(fl) % 16) == 0 &&
+                                               (reinterpret_cast<uintptr_t>(out) % align) == 0);
+                const dim3 block(kWave, 4), grid(cdiv(L.w, 64 * (xv_ok ? XV : 1)), cdiv(L.h, 4 * RV), n);
+#define NUS_WB(M, H, X) hipLaunchKernelGGL((k_warp_blend_flow<M, H, X, RV>), grid, block, 0, L.stream, a, b, fl, out, L.a_stride, L.b_stride, L.w, L.h, L.t, L.in_sel)
+#define NUS_WB_X(M, H) do { if (xv_ok) NUS_WB(M, H, XV); else NUS_WB(M, H, 1); } while (0)
                 if (L.fma) {
                     if (L.flow_half) NUS_WB_X(kWarpFma, true); else NUS_WB_X(kWarpFma, false);
                 } else {
