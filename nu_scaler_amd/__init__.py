@@ -11,7 +11,7 @@ BEFORE this package: torch ships its own HIP runtime and fails to see the GPU if
 libamdhip64 (pulled in by libnuscaler_hip.so) is loaded first.
 """
 from . import _capi
-from ._capi import NuScalerLibraryError, build, device_count
+from ._capi import NuScalerLibraryError, PinnedBuffer, build, device_count
 from .benchmark import PyBenchmarkResult, py_benchmark_upscaler, py_run_comparison_benchmark
 from .flow import FlowEstimator
 from .imagefile import interpolate_image_files, upscale_image_file
@@ -44,7 +44,7 @@ __all__ = [
     "PyBenchmarkResult", "py_benchmark_upscaler", "py_run_comparison_benchmark",
     "WgpuFrameInterpolator", "FlowEstimator", "FrameBuffer", "swizzle_bgra_to_rgba_device", "FramePipeline", "shard_frames", "broadcast_tables",
     "broadcast_blob", "build_tables_blob", "validate_tables_blob",
-    "NuScalerLibraryError", "build", "device_count",
+    "NuScalerLibraryError", "PinnedBuffer", "build", "device_count",
     "QUALITY_ULTRA", "QUALITY_QUALITY", "QUALITY_BALANCED", "QUALITY_PERFORMANCE",
     "TECH_FSR", "TECH_DLSS", "TECH_WGPU", "TECH_FALLBACK",
     "VENDOR_NVIDIA", "VENDOR_AMD", "VENDOR_INTEL", "VENDOR_OTHER",

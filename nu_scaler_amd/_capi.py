@@ -37,6 +37,8 @@ SIGNATURES = [
     ("nus_abi_version", _i, []),
     ("nus_device_count", _i, []),
     ("nus_device_memory_info", _i, [_i, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64)]),
+    ("nus_host_pin", _i, [_vp, _sz]),
+    ("nus_host_unpin", _i, [_vp]),
     ("nus_last_error", _cp, []),
     ("nus_status_string", _cp, [_i]),
     ("nus_upscaler_create", _vp, [_i, _i]),
@@ -190,3 +192,38 @@ def last_error() -> str:
 
 def device_count() -> int:
     return int(lib().nus_device_count())
+
+
+class PinnedBuffer:
+    """A writable buffer (bytearray, numpy array, ...) pinned for the DMA engines while the object lives / inside a `with`:
+    the host entry points then copy straight from / into it (nus_host_pin / nus_host_unpin).  Keep the object as long as the
+    buffer is handed to upscale / upscale_batch / interpolate calls; do not resize the buffer meanwhile."""
+
+    def __init__(self, buffer):
+        mv = memoryview(buffer)
+        if mv.readonly or not mv.c_contiguous:
+            raise TypeError("PinnedBuffer needs a writable C-contiguous buffer")
+        self.buffer = buffer
+        self._arr = (ctypes.c_ubyte * mv.nbytes).from_buffer(mv.cast("B"))
+        self._addr = ctypes.addressof(self._arr)
+        if lib().nus_host_pin(self._addr, mv.nbytes) != OK:
+            self._addr = None
+            raise RuntimeError(last_error())
+
+    def unpin(self) -> None:
+        addr, self._addr = self._addr, None
+        if addr is not None:
+            lib().nus_host_unpin(addr)
+            self._arr = None
+
+    def __enter__(self):
+        return self.buffer
+
+    def __exit__(self, *exc):
+        self.unpin()
+
+    def __del__(self):
+        try:
+            self.unpin()
+        except Exception:
+            pass

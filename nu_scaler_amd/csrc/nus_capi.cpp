@@ -87,6 +87,44 @@ int nus_device_count(void)
     return n;
 }
 
+int nus_host_pin(void *buffer, size_t bytes)
+{
+    return guarded<int>("nus_host_pin", [&]() -> int {
+        if (!buffer || bytes == 0) {
+            nus::set_thread_error("nus_host_pin: null buffer");
+            return NUS_ERR_INVALID_ARGUMENT;
+        }
+        if (nus_device_count() <= 0) {
+            nus::set_thread_error("nus_host_pin: no HIP device available");
+            return NUS_ERR_NO_DEVICE;
+        }
+        const hipError_t e = hipHostRegister(buffer, bytes, hipHostRegisterPortable);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            nus::set_thread_error(std::string("nus_host_pin: hipHostRegister failed: ") + hipGetErrorString(e));
+            return e == hipErrorOutOfMemory ? NUS_ERR_OUT_OF_MEMORY : NUS_ERR_HIP;
+        }
+        return NUS_OK;
+    });
+}
+
+int nus_host_unpin(void *buffer)
+{
+    return guarded<int>("nus_host_unpin", [&]() -> int {
+        if (!buffer) {
+            nus::set_thread_error("nus_host_unpin: null buffer");
+            return NUS_ERR_INVALID_ARGUMENT;
+        }
+        const hipError_t e = hipHostUnregister(buffer);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            nus::set_thread_error(std::string("nus_host_unpin: hipHostUnregister failed: ") + hipGetErrorString(e));
+            return NUS_ERR_HIP;
+        }
+        return NUS_OK;
+    });
+}
+
 int nus_device_memory_info(int device, uint64_t *free_bytes, uint64_t *total_bytes)
 {
     return guarded<int>("nus_device_memory_info", [&]() -> int {

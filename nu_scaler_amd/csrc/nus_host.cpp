@@ -188,6 +188,10 @@ void HipUpscaler::release()
     prof_events_.clear();
     prof_used_ = 0;
     for (Slot &s : slots_) release_slot(s);
+    for (hipStream_t *st : {&s_in_, &s_k_, &s_out_}) {
+        if (*st) (void)hipStreamDestroy(*st);
+        *st = nullptr;
+    }
     initialized_ = false;
     have_ms_ = false;
 }
@@ -709,19 +713,29 @@ int HipUpscaler::upscale(const uint8_t *in, size_t in_len, uint8_t *out, size_t 
     return upscale_batch(ins, lens, 1, outs, out_cap);
 }
 
-// Stream, events, device frames and pinned staging of one pipeline slot: all or nothing.
+int HipUpscaler::ensure_streams()
+{
+    if (s_in_ && s_k_ && s_out_) return kOk;
+    if (!s_in_) NUS_HIP(hipStreamCreateWithFlags(&s_in_, hipStreamNonBlocking));
+    if (!s_k_) NUS_HIP(hipStreamCreateWithFlags(&s_k_, hipStreamNonBlocking));
+    if (!s_out_) NUS_HIP(hipStreamCreateWithFlags(&s_out_, hipStreamNonBlocking));
+    return kOk;
+}
+
+// Events, device frames and pinned staging of one pipeline slot: all or nothing.
 int HipUpscaler::ensure_slot(Slot &S, size_t in_bytes, size_t out_bytes)
 {
-    if (S.stream) return kOk;
+    if (S.d_in) return kOk;
     auto make = [&]() -> int {
-        NUS_HIP(hipStreamCreateWithFlags(&S.stream, hipStreamNonBlocking));
         NUS_HIP(hipEventCreate(&S.k_begin));
         NUS_HIP(hipEventCreate(&S.k_end));
+        NUS_HIP(hipEventCreateWithFlags(&S.in_done, hipEventDisableTiming));
+        NUS_HIP(hipEventCreateWithFlags(&S.out_done, hipEventDisableTiming));
         for (hipEvent_t &ev : S.chunk_done) NUS_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-        NUS_HIP(hipMalloc(reinterpret_cast<void **>(&S.d_in), in_bytes));
-        NUS_HIP(hipMalloc(reinterpret_cast<void **>(&S.d_out), out_bytes));
         NUS_HIP(hipHostMalloc(reinterpret_cast<void **>(&S.h_in), in_bytes, hipHostMallocDefault));
         NUS_HIP(hipHostMalloc(reinterpret_cast<void **>(&S.h_out), out_bytes, hipHostMallocDefault));
+        NUS_HIP(hipMalloc(reinterpret_cast<void **>(&S.d_out), out_bytes));
+        NUS_HIP(hipMalloc(reinterpret_cast<void **>(&S.d_in), in_bytes)); // last: d_in set = the slot is complete
         return kOk;
     };
     const int rc = make();
@@ -731,16 +745,16 @@ int HipUpscaler::ensure_slot(Slot &S, size_t in_bytes, size_t out_bytes)
 
 void HipUpscaler::release_slot(Slot &s)
 {
-    if (s.stream) (void)hipStreamSynchronize(s.stream);
+    for (hipStream_t st : {s_in_, s_k_, s_out_})
+        if (st) (void)hipStreamSynchronize(st);
     if (s.d_in) (void)hipFree(s.d_in);
     if (s.d_out) (void)hipFree(s.d_out);
     if (s.h_in) (void)hipHostFree(s.h_in);
     if (s.h_out) (void)hipHostFree(s.h_out);
-    if (s.k_begin) (void)hipEventDestroy(s.k_begin);
-    if (s.k_end) (void)hipEventDestroy(s.k_end);
+    for (hipEvent_t ev : {s.k_begin, s.k_end, s.in_done, s.out_done})
+        if (ev) (void)hipEventDestroy(ev);
     for (hipEvent_t ev : s.chunk_done)
         if (ev) (void)hipEventDestroy(ev);
-    if (s.stream) (void)hipStreamDestroy(s.stream);
     s = Slot();
 }
 
@@ -763,6 +777,10 @@ int HipUpscaler::upscale_batch(const uint8_t *const *ins, const size_t *in_lens,
                                           out_cap_each, out_bytes, ow_, oh_));
     NUS_HIP(hipSetDevice(device_));
     const int nslots = n < (size_t)kSlots ? (int)n : kSlots;
+    {
+        int rc = ensure_streams();
+        if (rc != kOk) return rc;
+    }
     for (int s = 0; s < nslots; ++s) {
         int rc = ensure_slot(slots_[s], in_bytes, out_bytes);
         if (rc != kOk) return rc;
@@ -770,23 +788,24 @@ int HipUpscaler::upscale_batch(const uint8_t *const *ins, const size_t *in_lens,
     // whatever way this call ends, nothing may still be reading the caller's input or writing its
     // (pinned) output buffers afterwards
     struct Drain {
-        Slot *slots;
-        int n;
+        hipStream_t st[3];
         bool armed = true;
         ~Drain()
         {
             if (!armed) return;
-            for (int s = 0; s < n; ++s)
-                if (slots[s].stream) (void)hipStreamSynchronize(slots[s].stream);
+            for (hipStream_t s : st)
+                if (s) (void)hipStreamSynchronize(s);
             (void)hipGetLastError();
         }
-    } drain{slots_, nslots};
-    // Frame i runs on slot i % nslots: stage -> H2D -> kernel -> D2H, all async on the slot's stream.  Pageable outputs
-    // come back in kOutChunks pieces: while piece k is copied out of the pinned buffer (by the copy pool's workers),
-    // piece k+1 is in flight.
+    } drain{{s_in_, s_k_, s_out_}};
+    // Frame i uses slot i % nslots: stage -> H2D (copy-in stream) -> kernel (compute stream) -> D2H (copy-out stream),
+    // chained by the slot's events.  Pageable outputs come back in kOutChunks pieces: while piece k is copied out of the
+    // pinned buffer (by the copy pool's workers), piece k+1 is in flight.
     const size_t chunk = ((out_bytes + kOutChunks - 1) / kOutChunks + 4095) & ~(size_t)4095;
     std::vector<char> direct_out(n, 0);
     // submit(i): the calling thread.  retire(i): waits for frame i's bytes and hands them to the caller's buffer.
+    // A slot is submitted to again only after its previous frame has been retired (so its D2H, hence its kernel and its
+    // H2D, are complete): no stream needs to wait for an earlier frame's events.
     auto submit = [&](size_t i) -> int {
         Slot &S = slots_[i % nslots];
         const uint8_t *src = ins[i];
@@ -794,29 +813,33 @@ int HipUpscaler::upscale_batch(const uint8_t *const *ins, const size_t *in_lens,
             parallel_copy(S.h_in, src, in_bytes);
             src = S.h_in;
         }
-        NUS_HIP(hipMemcpyAsync(S.d_in, src, in_bytes, hipMemcpyHostToDevice, S.stream));
-        NUS_HIP(hipEventRecord(S.k_begin, S.stream));
-        int rc = enqueue(S.d_in, S.d_out, 1, S.stream);
+        NUS_HIP(hipMemcpyAsync(S.d_in, src, in_bytes, hipMemcpyHostToDevice, s_in_));
+        NUS_HIP(hipEventRecord(S.in_done, s_in_));
+        NUS_HIP(hipStreamWaitEvent(s_k_, S.in_done, 0));
+        NUS_HIP(hipEventRecord(S.k_begin, s_k_));
+        int rc = enqueue(S.d_in, S.d_out, 1, s_k_);
         if (rc != kOk) return rc;
-        NUS_HIP(hipEventRecord(S.k_end, S.stream));
+        NUS_HIP(hipEventRecord(S.k_end, s_k_));
+        NUS_HIP(hipStreamWaitEvent(s_out_, S.k_end, 0));
         direct_out[i] = is_pinned_host(outs[i]) ? 1 : 0;
         if (direct_out[i]) {
-            NUS_HIP(hipMemcpyAsync(outs[i], S.d_out, out_bytes, hipMemcpyDeviceToHost, S.stream));
-            NUS_HIP(hipEventRecord(S.chunk_done[0], S.stream));
+            NUS_HIP(hipMemcpyAsync(outs[i], S.d_out, out_bytes, hipMemcpyDeviceToHost, s_out_));
         } else {
             int k = 0;
             for (size_t off = 0; off < out_bytes; off += chunk, ++k) {
                 const size_t len = out_bytes - off < chunk ? out_bytes - off : chunk;
-                NUS_HIP(hipMemcpyAsync(S.h_out + off, S.d_out + off, len, hipMemcpyDeviceToHost, S.stream));
-                NUS_HIP(hipEventRecord(S.chunk_done[k], S.stream));
+                NUS_HIP(hipMemcpyAsync(S.h_out + off, S.d_out + off, len, hipMemcpyDeviceToHost, s_out_));
+                NUS_HIP(hipEventRecord(S.chunk_done[k], s_out_));
             }
         }
+        NUS_HIP(hipEventRecord(S.out_done, s_out_));
+        S.used = true;
         return kOk;
     };
     auto retire = [&](size_t i) -> int {
         Slot &S = slots_[i % nslots];
         if (direct_out[i]) {
-            NUS_HIP(hipEventSynchronize(S.chunk_done[0]));
+            NUS_HIP(hipEventSynchronize(S.out_done));
             return kOk;
         }
         CopyTicket ticket; // the frame's pieces: queued as they land, all copied when the wait returns

@@ -121,14 +121,22 @@ private:
     struct Slot {
         uint8_t *d_in = nullptr, *d_out = nullptr; // HBM
         uint8_t *h_in = nullptr, *h_out = nullptr; // pinned staging
-        hipStream_t stream = nullptr;
-        hipEvent_t k_begin = nullptr, k_end = nullptr;
-        hipEvent_t chunk_done[kOutChunks] = {}; // D2H of output chunk k has landed in h_out
+        hipEvent_t in_done = nullptr;               // the frame's H2D has landed in d_in           (copy-in stream)
+        hipEvent_t k_begin = nullptr, k_end = nullptr; // around its kernel launches                 (compute stream)
+        hipEvent_t chunk_done[kOutChunks] = {};     // D2H of output chunk k has landed in h_out    (copy-out stream)
+        hipEvent_t out_done = nullptr;              // ... of the whole frame
+        bool used = false;                          // events have been recorded at least once
     };
+    // "one host thread + 3 streams per GPU": every H2D goes down the copy-in stream, every kernel down the compute stream,
+    // every D2H down the copy-out stream, tied together per frame by the slot's events -- so the copies of consecutive frames
+    // sit back to back in ONE queue per direction (0.60 ms per 4K frame on the D2H engine) instead of alternating between the
+    // queues of per-slot streams (0.73 ms per frame measured that way, round 3).
+    hipStream_t s_in_ = nullptr, s_k_ = nullptr, s_out_ = nullptr;
 
     int fail(int status, const std::string &msg);
     int fail_hip(hipError_t e, const char *what);
     int ensure_device();
+    int ensure_streams();
     int ensure_slot(Slot &s, size_t in_bytes, size_t out_bytes);
     void release_slot(Slot &s);
     void release();

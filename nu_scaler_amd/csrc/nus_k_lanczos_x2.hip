@@ -104,40 +104,23 @@ __device__ __forceinline__ void wait_vmcnt()
 }
 
 // LDS ring of one wave: kLzDepth slots of NL rows (NL = 2 when a pair is blended on load), 64 lanes x 16 B each.
-#ifndef NUS_LZ_UNIT_ONE_DMA
-#define NUS_LZ_UNIT_ONE_DMA 0 // dev macro (A/B timing): 1 = UNIT kernels, real-frame role: request row A once and read it back as both
-                              // halves of the pair, the second request's place in the in-order vmcnt count kept by a store the range
-                              // check drops.  0 (product) = request A twice: the same instruction stream in both roles, which is what
-                              // tools/check_hidden_loads.py can verify path by path
-#endif
 template <int BLEND>
 struct RowRing {
     static constexpr int NL = BLEND ? 2 : 1;
     u32x4 (*slot)[64]; // [kLzDepth * NL][64], this wave's part of the block's LDS
     uint32_t lds;      // its byte offset in LDS (wave-uniform)
     int lane;
-    // UNIT kernels: the real-frame role blends row A with itself.  b_slot = 0: the second half of a pair is read from A's
-    // own slot and never requested (wave-uniform); 1: the B row, in the slot after A's.
-    int b_slot = 1;
 
     __device__ __forceinline__ void request(int k, const uint8_t *pa, const uint8_t *pb, uint32_t off) const
     {
         dma_row16(pa, off, lds + (uint32_t)(k * NL) * 1024u);
-        if constexpr (BLEND != 0) {
-            if (b_slot != 0) {
-                dma_row16(pb, off, lds + (uint32_t)(k * NL + 1) * 1024u);
-            } else {
-                // one vector memory instruction all the same -- the hand-counted waits rely on NL per request on every path --
-                // that moves nothing: a store through a resource of zero records
-                __builtin_amdgcn_raw_buffer_store_b32(0u, __builtin_amdgcn_make_buffer_rsrc(nullptr, 0, 0, 0x00020000), 0, 0, 0);
-            }
-        }
+        if constexpr (BLEND != 0) dma_row16(pb, off, lds + (uint32_t)(k * NL + 1) * 1024u);
     }
     __device__ __forceinline__ RowRaw<BLEND> read(int k) const
     {
         RowRaw<BLEND> r;
         r.a = slot[k * NL][lane];
-        if constexpr (BLEND != 0) r.b = (slot + b_slot)[k * NL][lane];
+        if constexpr (BLEND != 0) r.b = slot[k * NL + 1][lane];
         return r;
     }
 };
@@ -222,7 +205,7 @@ __device__ __forceinline__ void cvt_row(const uint4 raw, float (&dst)[16])
 #ifndef NUS_BLEND_OPAQUE_PATH
 #define NUS_BLEND_OPAQUE_PATH 1 // dev macro: 0 = the blend variants without the 3-channel path, as in round 2 (A/B timing only)
 #endif
-#if (!NUS_OPAQUE_PATH || !NUS_BLEND_OPAQUE_PATH || NUS_LZ_UNIT_ONE_DMA) && !defined(NUS_DEV_BUILD)
+#if (!NUS_OPAQUE_PATH || !NUS_BLEND_OPAQUE_PATH) && !defined(NUS_DEV_BUILD)
 #error "timing-only dev macros of k_lanczos3_x2 need -DNUS_DEV_BUILD: never in a product build"
 #endif
 #define NUS_LZ_BLEND_OPAQUE_PATH_OK(BLEND) ((BLEND) == 0 || NUS_BLEND_OPAQUE_PATH != 0)
@@ -488,7 +471,10 @@ __device__ __forceinline__ void lanczos_x2_step(float (&win)[6][16], const RowRi
 //   horizontal pass: 6 taps over the lane's own 4 columns + 3 columns from each
 //                    neighbouring lane, fetched with wave_shr/wave_shl DPP moves
 //   store          : the row's 2 KiB are turned round in LDS, two stores of one contiguous KiB each (RowStore)
-// so every input byte is read once per strip-row-block and no workgroup barrier is needed.
+// so every input byte is read once per strip-row-block and no workgroup barrier is needed.  (The 6 halo rows two vertically
+// neighbouring row blocks share are requested a whole block apart in time; letting odd row blocks walk bottom-up through a
+// vertical mirror of the frame, so that both readers of a halo reach it together, was built and measured in round 3: outputs
+// identical, 9.31 against 9.41 us per frame, nothing on the unit step -- profiles/r03_lanczos_mirrored_row_blocks_ab.txt; not kept.)
 // The 8 left-most and right-most output columns (renormalised edge weights) belong to
 // k_lanczos3_x2_edges, which is launched behind this kernel and overwrites what it wrote there.
 //
@@ -496,7 +482,9 @@ __device__ __forceinline__ void lanczos_x2_step(float (&win)[6][16], const RowRi
 // frame, the up-scaled in-between frame and the in-between frame itself -- with the very same instruction stream.  Every
 // (frame, row block, strip) is walked by two waves, and what tells them apart sits in SGPRs only:
 //   role 0 (real frame)      : both row streams come from A_k (the blend of a row with itself is the row: v_lerp_u8(a, a) = a,
-//                              and t = 0 at BLEND 2), output to A.out, in-between stores dropped (num_records 0);
+//                              and t = 0 at BLEND 2), output to A.out, in-between stores dropped (num_records 0).  (Requesting
+//                              the row once and keeping the second request's place in the vmcnt count with a dropped store was
+//                              measured: -0.5 %, profiles/r03_unit_kernel_one_dma_ab.txt; not worth a second instruction stream);
 //   role 1 (in-between frame): rows of A_k and B_k blended on load as in the BLEND kernels, output to A.out_mid, and each
 //                              resolved row of the wave's own block stored to A.mid.
 // The two waves of a (frame, row block, strip) run side by side (consecutive workgroups of one XCD), so A_k's rows reach the
@@ -539,12 +527,10 @@ __global__ __launch_bounds__(256) void k_lanczos3_x2(const LanczosX2Args A)
     const uint8_t *src_b = BLEND ? A.in_b + (size_t)frame * A.in_b_frame_bytes : src;
     float t = A.t;
     uint8_t *out = A.out;
-    int ring_b_slot = 1;
     MidStore ms;
     if constexpr (UNIT) {
         const bool real = role == 0; // wave-uniform
         src_b = real ? src : src_b;
-        ring_b_slot = real && NUS_LZ_UNIT_ONE_DMA ? 0 : 1;
         t = real ? 0.0f : t; // BLEND 2: 1 * a + 0 * a = a exactly
         out = real ? A.out : A.out_mid;
         const bool owner = lane >= 1 && lane <= (int)(kLanczosX2StripCols / 4) && c >= 0 && c + 4 <= (int)A.iw;
@@ -612,7 +598,6 @@ __global__ __launch_bounds__(256) void k_lanczos3_x2(const LanczosX2Args A)
         ring.slot = lds_rows[HIDDEN ? w : 0];
         ring.lds = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)&lds_rows[HIDDEN ? w : 0][0][0]);
         ring.lane = lane;
-        ring.b_slot = ring_b_slot;
 #if NUS_LZ_CONTIG_STORES
         __shared__ u32x4 lds_stage[4][128]; // one output row (2 KiB) per wave, turned round between compute and store order
         st.stage = lds_stage[w];
