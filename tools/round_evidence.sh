@@ -1,19 +1,27 @@
 #!/bin/bash
 # Collects the round's judged evidence on the GPU box into gpurun_out/evidence/ (copy what you keep into profiles/):
-# the bench line, rocprofv3 --stats of the same command, the per-kernel quick bench (both patterns), the general-factor
-# sweep and the flow front end's kernel breakdown.
+# the bench line, rocprofv3 --stats of the same command, the schedules side by side, the per-kernel quick bench (both patterns),
+# the warp kernel, the general-factor sweep, the flow front end's kernel breakdown, the 2-rank rehearsal.
 root=${GRAFT_REPO_ROOT:-/root/repo}
 out=$root/gpurun_out/evidence
 rm -rf $out && mkdir -p $out
 cd $root
 python3 bench.py > $out/bench_n1.log 2>&1 && tail -1 $out/bench_n1.log > $out/bench_n1.json
-echo "bench done: $(cut -c1-120 $out/bench_n1.json)"
-(cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $out/bench_prof -o b -- python3 $root/bench.py --no-pmc --no-cpu-baseline --no-extras --no-check --steps 20 --warmup 3 > $out/bench_prof.log 2>&1)
+echo "bench done: $(cut -c1-160 $out/bench_n1.json)"
+(cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $out/bench_prof -o b -- python3 $root/bench.py --no-pmc --no-cpu-baseline --no-extras --no-check --sustained-seconds 0 --steps 450 --warmup 30 > $out/bench_prof.log 2>&1)
 grep "^{" $out/bench_prof.log | tail -1 > $out/bench_under_rocprof.json
 cp $(find $out/bench_prof -name "*kernel_stats.csv" | head -1) $out/bench_n1_kernel_stats.csv 2>/dev/null
-echo "bench profile done"
+echo "bench profile done"; head -6 $out/bench_n1_kernel_stats.csv
+(cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $out/bench3_prof -o b -- python3 $root/bench.py --schedule three-stage --no-pmc --no-cpu-baseline --no-extras --no-check --sustained-seconds 0 --steps 200 --warmup 30 > $out/bench3_prof.log 2>&1)
+grep "^{" $out/bench3_prof.log | tail -1 > $out/bench_three_stage_under_rocprof.json
+cp $(find $out/bench3_prof -name "*kernel_stats.csv" | head -1) $out/bench_three_stage_kernel_stats.csv 2>/dev/null
+echo "three-stage profile done"
+python3 tools/unit_bench.py 2>&1 | grep -v amdgpu.ids > $out/unit_step_schedules.txt
+echo "schedules done"
 for pat in gradient noise; do python3 tools/quick_bench.py --frames 300 --reps 5 --pattern $pat 2>&1 | grep -v amdgpu.ids; done > $out/quick_bench_kernels.txt
 echo "quick bench done"
+python3 tools/warp_bench.py 2>&1 | grep -v amdgpu.ids > $out/warp_kernel.txt
+python3 tools/host_path_bench.py 2>&1 | grep -v amdgpu.ids > $out/host_path.txt
 python3 tools/general_sweep.py > $out/general_scale_sweep.txt 2>&1
 echo "sweep done"
 bash tools/flow_prof.sh > $out/flow_kernels.txt 2>&1
@@ -21,5 +29,7 @@ cp $(find $root/gpurun_out/flowprof -name "*kernel_stats.csv" | head -1) $out/fl
 python3 tools/flow_bench.py 2>&1 | grep "flow estimate" >> $out/flow_kernels.txt
 bash tools/flow_stream_prof.sh 65 > $out/flow_stream_kernels.txt 2>&1
 echo "flow done"
-rm -rf $out/bench_prof
+python3 bench.py --gpus 2 --backend gloo --force-device 0 --steps 30 --warmup 3 --units 100 --sustained-seconds 0 > $out/bench_n2_gloo.log 2>&1; grep "^{" $out/bench_n2_gloo.log | tail -1 > $out/bench_rehearsal_n2_gloo_one_gpu.json
+echo "rehearsal done: $(cut -c1-120 $out/bench_rehearsal_n2_gloo_one_gpu.json)"
+rm -rf $out/bench_prof $out/bench3_prof
 ls -la $out
