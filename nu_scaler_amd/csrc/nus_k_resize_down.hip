@@ -8,6 +8,12 @@ namespace nus {
 
 namespace {
 
+#ifndef NUS_DOWN_DEPTH
+#define NUS_DOWN_DEPTH 4 // input rows in flight per wave through the LDS-DMA ring (power of two); 0 = round 2's form: the next
+                         // row in registers (dev macro, A/B timing)
+#endif
+constexpr int kDownDepth = NUS_DOWN_DEPTH;
+static_assert(kDownDepth == 0 || (kDownDepth & (kDownDepth - 1)) == 0, "ring depth must be a power of two");
 constexpr uint32_t kDownSlack = 32; // zeroed LDS entries behind the row: the fixed-length horizontal loop reads up to HT - 1 past a window
 
 // Streaming form of vertical_sample -> horizontal_sample for ratio >= 1.  On a down-scale every input
@@ -33,6 +39,23 @@ constexpr uint32_t kDownSlack = 32; // zeroed LDS entries behind the row: the fi
 constexpr int kSlots = 7;          // == nus::kDownSlots (nus_tables.hpp)
 constexpr uint32_t kNone = 0xFFFFFFFFu;
 
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm" // m0 is a reserved register: nothing else in this kernel uses it
+// Request 4 B per lane from `base + off` (base wave-uniform, off < 4 GiB) into the 256-byte LDS piece at byte offset `lds`
+// (wave-uniform): lane l lands at lds + 4 l.  No VGPR destination, invisible to the compiler's s_waitcnt insertion.
+__device__ __forceinline__ void dma_row4(const void *base, uint32_t off, uint32_t lds)
+{
+    asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dword %0, %1" : : "v"(off), "s"(base), "s"(lds) : "memory", "m0");
+}
+#pragma clang diagnostic pop
+// Wait until at most N of this wave's vector memory instructions are outstanding (they retire in issue order).
+template <int N>
+__device__ __forceinline__ void down_wait_vmcnt()
+{
+    static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit counter on gfx9");
+    asm volatile("s_waitcnt vmcnt(%0)" : : "n"(N) : "memory");
+}
+
 template <bool EXACT, int VC, int HT>
 __global__ __launch_bounds__(256) void k_resize_down(
     const uint32_t *__restrict__ in, uint32_t *__restrict__ out,
@@ -45,10 +68,14 @@ __global__ __launch_bounds__(256) void k_resize_down(
     constexpr int NS = kSlots;
     // per wave: the V row (ncols_max + slack float4), then the lanes' horizontal weights [HT][64] (registers are
     // what limits the waves per SIMD here; a tap's weight is one conflict-free ds_read_b32 away)
-    const size_t wave_floats = (size_t)(ncols_max + kDownSlack) * 4 + (size_t)HT * kWave;
+    constexpr int D = kDownDepth;
+    const size_t wave_floats = (size_t)(ncols_max + kDownSlack) * 4 + (size_t)HT * kWave + (size_t)D * VC * kWave;
     float *const wave_lds = reinterpret_cast<float *>(smem) + (size_t)threadIdx.y * wave_floats;
     float4 *s_v = reinterpret_cast<float4 *>(wave_lds);
     float *s_hw = wave_lds + (size_t)(ncols_max + kDownSlack) * 4 + threadIdx.x;
+    // row ring: D slots of VC pieces of 64 pixels (lane l's column m of the row in slot k at [(k VC + m) 64 + l])
+    uint32_t *s_ring = reinterpret_cast<uint32_t *>(wave_lds + (size_t)(ncols_max + kDownSlack) * 4 + (size_t)HT * kWave);
+    const uint32_t ring_lds = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)s_ring);
     const GridPos g = xcd_contiguous_pos(); // row blocks that share their window-fill rows behind one L2
     const uint32_t seg = __builtin_amdgcn_readfirstlane(g.x * 4 + threadIdx.y);
     const uint32_t X0 = seg * kWave;
@@ -103,11 +130,38 @@ __global__ __launch_bounds__(256) void k_resize_down(
         for (int k = 0; k < VC * 4; ++k) acc[s][k] = 0.0f;
     const int32_t r_first = lyt[y_begin];
     const int32_t r_last = done_row[y_end - 1];
+    // Row prefetch.  A down-scale reads 4 ratio^2 input bytes per output byte, and with the next row in registers (round 2)
+    // a wave had VC loads of 256 B in flight: 16 waves per CU = 12 KB per CU, at ~2 us of HBM latency ~1.5 TB/s for the
+    // chip -- 4K -> 1080p took 23.6 us per frame where its 41.5 MB need 9 and its arithmetic 11.  Now the rows come
+    // through a per-wave LDS-DMA ring as in k_lanczos3_x2: row r + D is requested (VC pieces of 256 B, no VGPR destination)
+    // as soon as row r has been read out of its slot, and before the read the wave waits with s_waitcnt vmcnt((D - 1) VC):
+    // everything but the requests of the D - 1 younger rows has landed.  The stores of completed output rows sit in the
+    // same in-order count; not counting them makes the wait stricter (it may also cover a younger row's request), never
+    // looser.  Registers: none (128 VGPRs, 4 waves per SIMD as before at 3 columns per lane).
+    uint32_t col_off[VC]; // byte offset of the lane's column m inside a row
+#pragma unroll
+    for (int m = 0; m < VC; ++m) col_off[m] = col[m] * 4u;
+    auto request_row = [&](int32_t r, uint32_t slot) {
+        const uint32_t ro = umin((uint32_t)r, ih - 1) * (iw * 4u); // pseudo-rows: any finite pixels
+#pragma unroll
+        for (int m = 0; m < VC; ++m) dma_row4(base, ro + col_off[m], ring_lds + (slot * VC + m) * (kWave * 4u));
+    };
     uint32_t raw_next[VC];
-    load_row(r_first, raw_next);
+    if (D > 0) {
+        for (int k = 0; k < D; ++k) request_row(r_first + k < r_last ? r_first + k : r_last, (uint32_t)k);
+    } else {
+        load_row(r_first, raw_next);
+    }
     u32x8 tab_next = load_tab(r_first);
 
     for (int32_t r = r_first; r <= r_last; ++r) {
+        if (D > 0) {
+            const uint32_t slot = (uint32_t)(r - r_first) & (uint32_t)(D > 0 ? D - 1 : 0);
+            down_wait_vmcnt<(D > 0 ? (D - 1) * VC : 0)>();
+#pragma unroll
+            for (int m = 0; m < VC; ++m) raw_next[m] = s_ring[(slot * VC + m) * kWave + threadIdx.x];
+            request_row(r + D < r_last ? r + D : r_last, slot); // (past the block: its last row again, never read)
+        }
         float p[VC * 4];
 #pragma unroll
         for (int m = 0; m < VC; ++m) {
@@ -117,7 +171,7 @@ __global__ __launch_bounds__(256) void k_resize_down(
         }
         const u32x8 tab = tab_next;
         if (r < r_last) { // one row ahead
-            load_row(r + 1, raw_next);
+            if (D == 0) load_row(r + 1, raw_next);
             tab_next = load_tab(r + 1);
         }
 #pragma unroll
@@ -185,7 +239,9 @@ hipError_t launch_resize_down(const UpscaleLaunch &L, const DeviceTables &T, boo
     const uint32_t vc = cdiv(ncols_max, kWave);
     if (vc < 1 || vc > 5 || max_taps_x > 32 || !T.lz_down_rows || !T.lz_down_done) return hipErrorInvalidValue;
     const bool wide = max_taps_x > 16; // horizontal weights per lane: 16 or 32 registers
-    const size_t lds = (size_t)4 * ((size_t)(ncols_max + kDownSlack) * sizeof(float4) + (size_t)(wide ? 32 : 16) * kWave * sizeof(float));
+    const size_t lds = (size_t)4 * ((size_t)(ncols_max + kDownSlack) * sizeof(float4) + (size_t)(wide ? 32 : 16) * kWave * sizeof(float) +
+                                    (size_t)kDownDepth * vc * kWave * sizeof(uint32_t));
+    if ((uint64_t)L.iw * L.ih * 4 >= (1ull << 32)) return hipErrorInvalidValue; // 32-bit row offsets (frames < 2 GiB: host-checked)
     return for_frame_chunks(L, [&](const uint8_t *in, uint8_t *out, uint32_t n) {
         const uint64_t blocks_x = cdiv(cdiv(L.ow, kWave), 4);
         uint64_t rpb = (uint64_t)L.oh * blocks_x * n / 2048; // a couple of thousand blocks per launch ...

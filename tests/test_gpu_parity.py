@@ -441,6 +441,21 @@ def test_upscale_batch_pipeline_many_frames_every_buffer_kind(nsc, oracle_mod):
     one = [bytearray(u.output_size)]
     u.upscale_batch_into(ins[4:5], one)
     assert np.array_equal(np.frombuffer(one[0], np.uint8).reshape(2 * h, 2 * w, 4), want[4])
+    # caller-owned buffers pinned in place (nus_host_pin): the DMA engines write straight into the bytearrays
+    pinned = [nsc.PinnedBuffer(b) for b in bufs]
+    for b in bufs:
+        b[:] = bytes(len(b))
+    u.upscale_batch_into(ins, bufs)
+    assert all(np.array_equal(np.frombuffer(b, np.uint8).reshape(2 * h, 2 * w, 4), wnt) for b, wnt in zip(bufs, want))
+    with pinned[0] as b0:  # context-manager form: unpinned on exit, the buffer stays usable
+        u.upscale_into(ins[3], b0)
+        assert np.array_equal(np.frombuffer(b0, np.uint8).reshape(2 * h, 2 * w, 4), want[3])
+    for pb in pinned:
+        pb.unpin()
+    u.upscale_batch_into(ins, bufs)  # pageable again
+    assert np.array_equal(np.frombuffer(bufs[1], np.uint8).reshape(2 * h, 2 * w, 4), want[1])
+    with pytest.raises(TypeError):
+        nsc.PinnedBuffer(b"read-only")
     bad = list(ins)
     bad[6] = bad[6][:-4]
     with pytest.raises(RuntimeError, match="does not match expected input buffer size"):
