@@ -442,9 +442,13 @@ __device__ __forceinline__ void lanczos_x2_step(float (&win)[6][16], const RowRi
         else
 #else
         const uint32_t off = in_off + (uint32_t)rn * (A.iw * 4);
-        if (HIDDEN)
+        if (HIDDEN) {
+            // the slot is requested again only when its reads have RETURNED (the converted row is an operand of this empty
+            // statement, and volatile statements keep their order): nothing orders a queued ds_read behind a later LDS-DMA write
+            // (seen in k_resize_down, whose waves keep the LDS busy: profiles/r03_resize_down_lds_dma_ring_ab.txt)
+            asm volatile("" : : "v"(win[S % 6][0]), "v"(win[S % 6][15]) : "memory");
             ring.request(S % D, src, src_b, off);
-        else
+        } else
 #endif
             raw[S & 1] = fetch_row_plain<BLEND>(src, src_b, off);
     }

@@ -12,7 +12,15 @@ namespace {
 #define NUS_DOWN_DEPTH 4 // input rows in flight per wave through the LDS-DMA ring (power of two); 0 = round 2's form: the next
                          // row in registers (dev macro, A/B timing)
 #endif
+#ifndef NUS_DOWN_RING_MAX_VC
+#define NUS_DOWN_RING_MAX_VC 2 // the ring serves the shapes with up to this many columns per lane (ratios up to ~x1.8 down);
+                               // wider footprints keep the next row in registers: measured per shape in
+                               // profiles/r03_resize_down_lds_dma_ring_ab.txt (1080p -> 720p 7.7 -> 6.9 us, 1440p -> 1080p 17.2 ->
+                               // 16.2; 4K -> 1080p 22.5 -> 23.0, 4K -> 720p 20.6 -> 22.0: those are bound by their arithmetic and
+                               // their LDS passes, not by the rows in flight)
+#endif
 constexpr int kDownDepth = NUS_DOWN_DEPTH;
+constexpr int down_depth(int vc) { return vc <= NUS_DOWN_RING_MAX_VC ? kDownDepth : 0; }
 static_assert(kDownDepth == 0 || (kDownDepth & (kDownDepth - 1)) == 0, "ring depth must be a power of two");
 constexpr uint32_t kDownSlack = 32; // zeroed LDS entries behind the row: the fixed-length horizontal loop reads up to HT - 1 past a window
 
@@ -49,11 +57,20 @@ __device__ __forceinline__ void dma_row4(const void *base, uint32_t off, uint32_
 }
 #pragma clang diagnostic pop
 // Wait until at most N of this wave's vector memory instructions are outstanding (they retire in issue order).
-template <int N>
+// BACK (for tools/check_hidden_loads.py): the wait is for the BACK-th most recent row piece.
+template <int N, int BACK>
 __device__ __forceinline__ void down_wait_vmcnt()
 {
     static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit counter on gfx9");
-    asm volatile("s_waitcnt vmcnt(%0)" : : "n"(N) : "memory");
+    asm volatile("s_waitcnt vmcnt(%0) ; nus-wait back=%1" : : "n"(N), "n"(BACK) : "memory");
+}
+// The reads of a ring slot must have RETURNED before the slot is requested again: nothing orders a queued ds_read behind a
+// later LDS-DMA write, and with 16 waves per CU running their horizontal passes out of LDS the read can sit in the LDS queue
+// longer than a request that hits in L1 takes to land (seen as a wrong input row for some lanes of a wave, a few hundred
+// pixels per 4K -> 1080p batch, never on a single frame).
+__device__ __forceinline__ void down_reads_done()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)" : : : "memory");
 }
 
 template <bool EXACT, int VC, int HT>
@@ -68,13 +85,15 @@ __global__ __launch_bounds__(256) void k_resize_down(
     constexpr int NS = kSlots;
     // per wave: the V row (ncols_max + slack float4), then the lanes' horizontal weights [HT][64] (registers are
     // what limits the waves per SIMD here; a tap's weight is one conflict-free ds_read_b32 away)
-    constexpr int D = kDownDepth;
-    const size_t wave_floats = (size_t)(ncols_max + kDownSlack) * 4 + (size_t)HT * kWave + (size_t)D * VC * kWave;
-    float *const wave_lds = reinterpret_cast<float *>(smem) + (size_t)threadIdx.y * wave_floats;
+    constexpr int D = down_depth(VC);
+    // the four waves' row rings first (LDS-DMA takes its LDS address from M0: keep it a small offset), then per wave the rest
+    constexpr size_t ring_floats = (size_t)D * VC * kWave;
+    const size_t wave_floats = (size_t)(ncols_max + kDownSlack) * 4 + (size_t)HT * kWave;
+    float *const wave_lds = reinterpret_cast<float *>(smem) + 4 * ring_floats + (size_t)threadIdx.y * wave_floats;
     float4 *s_v = reinterpret_cast<float4 *>(wave_lds);
     float *s_hw = wave_lds + (size_t)(ncols_max + kDownSlack) * 4 + threadIdx.x;
     // row ring: D slots of VC pieces of 64 pixels (lane l's column m of the row in slot k at [(k VC + m) 64 + l])
-    uint32_t *s_ring = reinterpret_cast<uint32_t *>(wave_lds + (size_t)(ncols_max + kDownSlack) * 4 + (size_t)HT * kWave);
+    uint32_t *s_ring = reinterpret_cast<uint32_t *>(smem) + (size_t)threadIdx.y * ring_floats;
     const uint32_t ring_lds = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)s_ring);
     const GridPos g = xcd_contiguous_pos(); // row blocks that share their window-fill rows behind one L2
     const uint32_t seg = __builtin_amdgcn_readfirstlane(g.x * 4 + threadIdx.y);
@@ -130,14 +149,13 @@ __global__ __launch_bounds__(256) void k_resize_down(
         for (int k = 0; k < VC * 4; ++k) acc[s][k] = 0.0f;
     const int32_t r_first = lyt[y_begin];
     const int32_t r_last = done_row[y_end - 1];
-    // Row prefetch.  A down-scale reads 4 ratio^2 input bytes per output byte, and with the next row in registers (round 2)
-    // a wave had VC loads of 256 B in flight: 16 waves per CU = 12 KB per CU, at ~2 us of HBM latency ~1.5 TB/s for the
-    // chip -- 4K -> 1080p took 23.6 us per frame where its 41.5 MB need 9 and its arithmetic 11.  Now the rows come
-    // through a per-wave LDS-DMA ring as in k_lanczos3_x2: row r + D is requested (VC pieces of 256 B, no VGPR destination)
-    // as soon as row r has been read out of its slot, and before the read the wave waits with s_waitcnt vmcnt((D - 1) VC):
-    // everything but the requests of the D - 1 younger rows has landed.  The stores of completed output rows sit in the
-    // same in-order count; not counting them makes the wait stricter (it may also cover a younger row's request), never
-    // looser.  Registers: none (128 VGPRs, 4 waves per SIMD as before at 3 columns per lane).
+    // Row prefetch.  With up to NUS_DOWN_RING_MAX_VC columns per lane the rows come through a per-wave LDS-DMA ring as in
+    // k_lanczos3_x2 (D > 0): row r + D is requested (VC pieces of 256 B, no VGPR destination) once row r has been read out of
+    // its slot AND the reads have returned (down_reads_done), and before the read the wave waits with s_waitcnt
+    // vmcnt((D - 1) VC): everything but the requests of the D - 1 younger rows has landed.  The stores of completed output
+    // rows sit in the same in-order count; not counting them makes the wait stricter (it may also cover a younger row's
+    // request), never looser.  Wider footprints (D == 0) keep round 2's form, the next row in registers: they are bound by
+    // their arithmetic and LDS passes, and the ring bought nothing there (NUS_DOWN_RING_MAX_VC).
     uint32_t col_off[VC]; // byte offset of the lane's column m inside a row
 #pragma unroll
     for (int m = 0; m < VC; ++m) col_off[m] = col[m] * 4u;
@@ -157,9 +175,10 @@ __global__ __launch_bounds__(256) void k_resize_down(
     for (int32_t r = r_first; r <= r_last; ++r) {
         if (D > 0) {
             const uint32_t slot = (uint32_t)(r - r_first) & (uint32_t)(D > 0 ? D - 1 : 0);
-            down_wait_vmcnt<(D > 0 ? (D - 1) * VC : 0)>();
+            down_wait_vmcnt<(D > 0 ? (D - 1) * VC : 0), (D > 0 ? (D - 1) * VC + 1 : 1)>();
 #pragma unroll
             for (int m = 0; m < VC; ++m) raw_next[m] = s_ring[(slot * VC + m) * kWave + threadIdx.x];
+            down_reads_done();
             request_row(r + D < r_last ? r + D : r_last, slot); // (past the block: its last row again, never read)
         }
         float p[VC * 4];
@@ -240,7 +259,7 @@ hipError_t launch_resize_down(const UpscaleLaunch &L, const DeviceTables &T, boo
     if (vc < 1 || vc > 5 || max_taps_x > 32 || !T.lz_down_rows || !T.lz_down_done) return hipErrorInvalidValue;
     const bool wide = max_taps_x > 16; // horizontal weights per lane: 16 or 32 registers
     const size_t lds = (size_t)4 * ((size_t)(ncols_max + kDownSlack) * sizeof(float4) + (size_t)(wide ? 32 : 16) * kWave * sizeof(float) +
-                                    (size_t)kDownDepth * vc * kWave * sizeof(uint32_t));
+                                    (size_t)down_depth((int)vc) * vc * kWave * sizeof(uint32_t));
     if ((uint64_t)L.iw * L.ih * 4 >= (1ull << 32)) return hipErrorInvalidValue; // 32-bit row offsets (frames < 2 GiB: host-checked)
     return for_frame_chunks(L, [&](const uint8_t *in, uint8_t *out, uint32_t n) {
         const uint64_t blocks_x = cdiv(cdiv(L.ow, kWave), 4);

@@ -49,6 +49,39 @@ def test_hand_counted_waits_of_every_instantiation(kernel_asm):
         assert r["hand_waits"] == 7, (name, r["hand_waits"])
 
 
+def test_resize_down_row_ring_waits():
+    """k_resize_down's LDS-DMA row ring (footprints of up to two columns per lane): its one hand-placed wait per row must retire
+    the row it is about to read on every path -- stores of completed output rows sit between the requests on some paths only, so
+    the wait is conservative rather than tight -- the slot's reads are waited for before the slot is requested again, and the
+    instantiations without the ring have no hidden requests at all."""
+    import re
+
+    import check_hidden_loads as chk
+
+    out = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-x", "hip",
+                          "--cuda-device-only", "-S", "-I", CSRC, "-I", os.path.join(ROOT, "include"), "-o", "-",
+                          os.path.join(CSRC, "nus_k_resize_down.hip")], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr
+    bodies = list(chk.kernel_bodies(out.stdout, "k_resize_downIL"))
+    assert len(bodies) == 20, len(bodies)  # EXACT x VC 1..5 x HT {16, 32}
+    ringed = 0
+    for name, body in bodies:
+        vc = int(re.search(r"k_resize_downILb[01]ELi(\d)E", name).group(1))
+        r = chk.check(body, cap=12, kmax=8)
+        assert r["errors"] == [], (name, r["errors"][:3])
+        if vc <= 2:
+            ringed += 1
+            assert r["requests"] == 5 * vc and r["hand_waits"] == 1, (name, r["requests"], r["hand_waits"])  # 4 rows ahead + 1 per step
+            for t, counts in r["waits_not_tight"].items():  # every path has AT LEAST the N instructions the wait relies on
+                n = int(re.search(r"vmcnt\((\d+)\)", t).group(1))
+                assert min(counts) >= n, (name, t, counts)
+            # the reads of a slot return before the slot is requested again
+            assert re.search(r"ds_read\w*_b32[^\n]*\n(?:[^\n]*\n){0,12}?[^\n]*s_waitcnt lgkmcnt\(0\)[^\n]*\n(?:[^\n]*\n){0,6}?[^\n]*global_load_lds_dword", body), name
+        else:
+            assert r["requests"] == 0 and r["hand_waits"] == 0, name
+    assert ringed == 8
+
+
 def test_checker_catches_a_wait_that_is_too_loose():
     import check_hidden_loads as chk
 

@@ -106,7 +106,12 @@ def blocks_of(ins):
     return blocks, succ
 
 
-def check(body):
+def check(body, cap=CAP, kmax=KMAX):
+    """cap / kmax: ages are counted up to `cap` and the `kmax` most recent requests are tracked.  The defaults suit kernels whose
+    loop issues the same instructions on every path (k_lanczos3_x2: the tightness of every wait is checked too); a kernel with
+    stores on some paths only (k_resize_down: its waits are deliberately conservative) needs just "never fewer than N" and gets a
+    small cap so that the path histories stay few."""
+    CAP, KMAX = cap, kmax  # noqa: N806 (shadow the module defaults below)
     ins = parse(body)
     if not ins:
         return {"errors": ["empty kernel body"], "requests": 0, "hand_waits": 0, "compiler_vmcnt_waits_in_loops": [],
