@@ -869,7 +869,7 @@ int HipUpscaler::upscale_batch(const uint8_t *const *ins, const size_t *in_lens,
         bool stop = false;                 // the submitter gave up: retire what was submitted, then leave
         int retire_status = kOk;
         std::string retire_error;
-        std::thread retirer([&] {
+        auto retire_all = [&] {
             (void)hipSetDevice(device_);
             for (size_t i = 0; i < n; ++i) {
                 {
@@ -877,17 +877,42 @@ int HipUpscaler::upscale_batch(const uint8_t *const *ins, const size_t *in_lens,
                     cv.wait(lk, [&] { return submitted > i || stop; });
                     if (submitted <= i) return;
                 }
-                const int rc = retire(i);
+                int rc;
+                try {
+                    rc = retire(i);
+                } catch (...) { // (an allocation failing while an error text is built: no exception may leave a thread)
+                    rc = kOutOfMemory;
+                }
                 std::lock_guard<std::mutex> lk(m);
                 if (rc != kOk && retire_status == kOk) {
                     retire_status = rc;
-                    retire_error = error_;
+                    try {
+                        retire_error = error_;
+                    } catch (...) {
+                    }
                 }
                 retired = i + 1;
                 cv.notify_all();
                 if (rc != kOk) return;
             }
-        });
+        };
+        // the retiring thread is told to stop and joined on EVERY way out of this scope (an exception on the submitting
+        // side included): a joinable std::thread must not reach its destructor
+        struct Retirer {
+            std::thread t;
+            std::mutex &m;
+            std::condition_variable &cv;
+            bool &stop;
+            ~Retirer()
+            {
+                {
+                    std::lock_guard<std::mutex> lk(m);
+                    stop = true;
+                }
+                cv.notify_all();
+                if (t.joinable()) t.join();
+            }
+        } retirer{std::thread(retire_all), m, cv, stop};
         for (size_t i = 0; i < n && status == kOk; ++i) {
             {
                 std::unique_lock<std::mutex> lk(m);
@@ -903,9 +928,9 @@ int HipUpscaler::upscale_batch(const uint8_t *const *ins, const size_t *in_lens,
         {
             std::lock_guard<std::mutex> lk(m);
             stop = true;
-            cv.notify_all();
         }
-        retirer.join();
+        cv.notify_all();
+        retirer.t.join();
         if (status == kOk && retire_status != kOk) status = fail(retire_status, retire_error);
     }
     if (status != kOk) return status; // ~Drain waits for whatever is still in flight
