@@ -352,8 +352,9 @@ def pcie_ceiling(torch, dev, n_in, n_out):
 
 def host_path_leg(nsc, syn, torch, w, h, device):
     """PCIe-inclusive rate through the trait-shaped host entry points (mode (ii) of BASELINE.md section 3):
-    `upscale(&[u8]) -> Vec<u8>` = nus_upscaler_upscale, `upscale_batch` = nus_upscaler_upscale_batch, `interpolate_py` =
-    nus_interp_interpolate, host buffers in and out, next to the box's pinned-copy ceiling.  Never `value`."""
+    `upscale(&[u8]) -> Vec<u8>` = nus_upscaler_upscale, `upscale_batch` = nus_upscaler_upscale_batch, the persistent ring
+    nus_upscaler_stream_*, `interpolate_py` = nus_interp_interpolate, host buffers in and out, next to the box's pinned-copy
+    ceiling.  Never `value`."""
     nb = 12
     frames = [syn.gradient_frame(w, h, k).tobytes() for k in range(nb + 1)]
     u = nsc.PyWgpuUpscaler("quality", "lanczos3", device=device)
@@ -377,6 +378,16 @@ def host_path_leg(nsc, syn, torch, w, h, device):
         u.upscale_batch_into(frames[:nb], outs)
         ts.append((time.perf_counter() - t0) / nb)
     batch_ms = _median(ts) * 1e3
+    # the persistent ring: the same frames submitted one at a time, three in flight (nus_upscaler_stream_*)
+    u.stream_open()
+    ts = []
+    for _ in range(5):
+        t0 = time.perf_counter()
+        tickets = [u.stream_submit(frames[k], outs[k]) for k in range(nb)]
+        u.stream_wait(tickets[-1])
+        ts.append((time.perf_counter() - t0) / nb)
+    u.stream_close()
+    stream_ms = _median(ts[1:]) * 1e3
     del outs
     pin_in = torch.empty((nb, u.input_size), dtype=torch.uint8, pin_memory=True)
     pin_out = torch.empty((nb, u.output_size), dtype=torch.uint8, pin_memory=True)
@@ -425,6 +436,8 @@ def host_path_leg(nsc, syn, torch, w, h, device):
         "upscale_batch_frames_per_s": round(1e3 / batch_ms, 1),
         "upscale_batch_vs_single_call": round(up_ms / batch_ms, 3),
         "upscale_batch_frac_of_d2h_ceiling": round(d2h_ms / batch_ms, 3),
+        "stream_ring_ms_per_frame": round(stream_ms, 3),
+        "stream_ring_frames_per_s": round(1e3 / stream_ms, 1),
         "upscale_batch_12_pinned_buffers_ms_per_frame": round(batch_pinned_ms, 3),
         "upscale_batch_pinned_frac_of_d2h_ceiling": round(d2h_ms / batch_pinned_ms, 3),
         "fresh_bytes_per_result": {"upscale_ms": round(fresh_ms, 3), "upscale_batch_12_ms_per_frame": round(fresh_batch_ms, 3),

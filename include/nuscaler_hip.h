@@ -182,6 +182,22 @@ int nus_upscaler_upscale_batch(nus_upscaler *h, const uint8_t *const *ins,
                                const size_t *in_lens, size_t n,
                                uint8_t *const *outs, size_t out_cap_each);
 
+/* A persistent ring over the same three pipeline slots, for callers that get their frames one at a time (a capture loop: the
+ * legacy app's FrameBuffer feeding upscale(), Nu_scale/src/capture/frame_buffer.rs:11-50, Nu_scale/src/lib.rs:107-190):
+ *   stream_open    starts the ring (NUS_ERR_NOT_INITIALIZED before initialize; one stream per upscaler);
+ *   stream_submit  stages and enqueues one frame and returns -- it blocks only while 3 frames are in flight -- with a
+ *                  ticket (0, 1, 2 ...); `out` must stay valid until that ticket has been waited for (or the stream closed);
+ *   stream_wait    returns when the frame with that ticket is in its `out` buffer (frames complete in submission order; may
+ *                  be called from another thread than stream_submit);
+ *   stream_close   waits for everything in flight and stops the ring (also done by initialize and destroy).
+ * While a stream is open, nus_upscaler_upscale / _upscale_batch on the same handle fail (the slots are in use).  H2D of frame
+ * i+1, the kernel of frame i and the D2H / copy-out of frame i-1 overlap exactly as inside nus_upscaler_upscale_batch. */
+int nus_upscaler_stream_open(nus_upscaler *h);
+int nus_upscaler_stream_submit(nus_upscaler *h, const uint8_t *in, size_t in_len, uint8_t *out, size_t out_cap,
+                               uint64_t *ticket);
+int nus_upscaler_stream_wait(nus_upscaler *h, uint64_t ticket);
+int nus_upscaler_stream_close(nus_upscaler *h);
+
 /* Device-resident path: d_in holds n_frames contiguous input frames already in HBM,
  * d_out receives n_frames contiguous output frames.  Enqueued on `stream`
  * (a hipStream_t, NULL = default stream); does not synchronise. */

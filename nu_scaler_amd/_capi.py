@@ -54,6 +54,10 @@ SIGNATURES = [
     ("nus_upscaler_initialize", _i, [_vp, _u32, _u32, _u32, _u32]),
     ("nus_upscaler_upscale", _i, [_vp, _vp, _sz, _vp, _sz]),
     ("nus_upscaler_upscale_batch", _i, [_vp, _vp, _vp, _sz, _vp, _sz]),
+    ("nus_upscaler_stream_open", _i, [_vp]),
+    ("nus_upscaler_stream_submit", _i, [_vp, _vp, _sz, _vp, _sz, ctypes.POINTER(ctypes.c_uint64)]),
+    ("nus_upscaler_stream_wait", _i, [_vp, ctypes.c_uint64]),
+    ("nus_upscaler_stream_close", _i, [_vp]),
     ("nus_upscaler_upscale_device", _i, [_vp, _vp, _vp, _u32, _vp]),
     ("nus_upscaler_upscale_blend_device", _i, [_vp, _vp, _sz, _vp, _sz, _f, _vp, _u32, _vp]),
     ("nus_upscaler_upscale_unit_device", _i, [_vp, _vp, _sz, _vp, _sz, _f, _vp, _vp, _vp, _u32, _vp]),

@@ -241,6 +241,27 @@ int nus_upscaler_upscale_batch(nus_upscaler *h, const uint8_t *const *ins, const
     return guarded<int>("nus_upscaler_upscale_batch", [&]() -> int { return h ? h->impl.upscale_batch(ins, in_lens, n, outs, out_cap_each) : null_handle(); });
 }
 
+int nus_upscaler_stream_open(nus_upscaler *h)
+{
+    return guarded<int>("nus_upscaler_stream_open", [&]() -> int { return h ? h->impl.stream_open() : null_handle(); });
+}
+
+int nus_upscaler_stream_submit(nus_upscaler *h, const uint8_t *in, size_t in_len, uint8_t *out, size_t out_cap, uint64_t *ticket)
+{
+    return guarded<int>("nus_upscaler_stream_submit",
+                        [&]() -> int { return h ? h->impl.stream_submit(in, in_len, out, out_cap, ticket) : null_handle(); });
+}
+
+int nus_upscaler_stream_wait(nus_upscaler *h, uint64_t ticket)
+{
+    return guarded<int>("nus_upscaler_stream_wait", [&]() -> int { return h ? h->impl.stream_wait(ticket) : null_handle(); });
+}
+
+int nus_upscaler_stream_close(nus_upscaler *h)
+{
+    return guarded<int>("nus_upscaler_stream_close", [&]() -> int { return h ? h->impl.stream_close() : null_handle(); });
+}
+
 int nus_upscaler_upscale_device(nus_upscaler *h, const void *d_in, void *d_out, uint32_t n_frames, void *stream)
 {
     return guarded<int>("nus_upscaler_upscale_device", [&]() -> int { return h ? h->impl.upscale_device(d_in, d_out, n_frames, static_cast<hipStream_t>(stream)) : null_handle(); });

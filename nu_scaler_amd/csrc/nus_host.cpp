@@ -180,6 +180,15 @@ int HipUpscaler::ensure_device()
 
 void HipUpscaler::release()
 {
+    if (ring_.open) { // (initialize() again or the destructor with a stream still open: stop its thread first)
+        {
+            std::lock_guard<std::mutex> rl(ring_.m);
+            ring_.stop = true;
+        }
+        ring_.cv.notify_all();
+        if (ring_.thread.joinable()) ring_.thread.join();
+        ring_.open = false;
+    }
     if (device_count() > 0) (void)hipSetDevice(device_);
     for (void *p : table_allocs_) (void)hipFree(p);
     table_allocs_.clear();
@@ -758,11 +767,193 @@ void HipUpscaler::release_slot(Slot &s)
     s = Slot();
 }
 
+// One frame into a free slot: stage (unless the caller's buffer is pinned) -> H2D -> kernel -> D2H, all asynchronous, each on
+// its own stream.  Pageable outputs come back in kOutChunks pieces: while piece k is copied out of the pinned buffer (by
+// the copy pool's workers), piece k+1 is in flight.  *direct: the D2H goes straight into the caller's (pinned) buffer.
+int HipUpscaler::submit_frame(Slot &S, const uint8_t *in, uint8_t *out, bool *direct)
+{
+    const size_t in_bytes = (size_t)iw_ * ih_ * 4, out_bytes = (size_t)ow_ * oh_ * 4;
+    const size_t chunk = ((out_bytes + kOutChunks - 1) / kOutChunks + 4095) & ~(size_t)4095;
+    const uint8_t *src = in;
+    if (!is_pinned_host(src)) {
+        parallel_copy(S.h_in, src, in_bytes);
+        src = S.h_in;
+    }
+    NUS_HIP(hipMemcpyAsync(S.d_in, src, in_bytes, hipMemcpyHostToDevice, s_in_));
+    NUS_HIP(hipEventRecord(S.in_done, s_in_));
+    NUS_HIP(hipStreamWaitEvent(s_k_, S.in_done, 0));
+    NUS_HIP(hipEventRecord(S.k_begin, s_k_));
+    int rc = enqueue(S.d_in, S.d_out, 1, s_k_);
+    if (rc != kOk) return rc;
+    NUS_HIP(hipEventRecord(S.k_end, s_k_));
+    NUS_HIP(hipStreamWaitEvent(s_out_, S.k_end, 0));
+    *direct = is_pinned_host(out);
+    if (*direct) {
+        NUS_HIP(hipMemcpyAsync(out, S.d_out, out_bytes, hipMemcpyDeviceToHost, s_out_));
+    } else {
+        int k = 0;
+        for (size_t off = 0; off < out_bytes; off += chunk, ++k) {
+            const size_t len = out_bytes - off < chunk ? out_bytes - off : chunk;
+            NUS_HIP(hipMemcpyAsync(S.h_out + off, S.d_out + off, len, hipMemcpyDeviceToHost, s_out_));
+            NUS_HIP(hipEventRecord(S.chunk_done[k], s_out_));
+        }
+    }
+    NUS_HIP(hipEventRecord(S.out_done, s_out_));
+    S.used = true;
+    return kOk;
+}
+
+// Waits for the slot's frame and hands its bytes to `out`.  Runs on the retiring thread: touches no member but the slot, and
+// reports an error's text through *err instead of error_.
+int HipUpscaler::retire_frame(Slot &S, uint8_t *out, bool direct, std::string *err) const
+{
+    const size_t out_bytes = (size_t)ow_ * oh_ * 4;
+    const size_t chunk = ((out_bytes + kOutChunks - 1) / kOutChunks + 4095) & ~(size_t)4095;
+    auto hip_failed = [&](hipError_t e, const char *what) {
+        (void)hipGetLastError();
+        if (err) *err = fmt("HIP error in %s: %s", what, hipGetErrorString(e));
+        return e == hipErrorOutOfMemory ? kOutOfMemory : kHipError;
+    };
+    if (direct) {
+        const hipError_t e = hipEventSynchronize(S.out_done);
+        return e == hipSuccess ? kOk : hip_failed(e, "hipEventSynchronize(out_done)");
+    }
+    CopyTicket ticket; // the frame's pieces: queued as they land, all copied when the wait returns
+    int k = 0, rc = kOk;
+    for (size_t off = 0; off < out_bytes; off += chunk, ++k) {
+        const hipError_t e = hipEventSynchronize(S.chunk_done[k]);
+        if (e != hipSuccess) {
+            rc = hip_failed(e, "hipEventSynchronize(chunk_done)");
+            break;
+        }
+        parallel_copy_async(out + off, S.h_out + off, out_bytes - off < chunk ? out_bytes - off : chunk, ticket);
+    }
+    parallel_copy_wait(ticket); // also on the error path: queued pieces point into buffers that must outlive them
+    return rc;
+}
+
+// ---- persistent ring: frames go in one at a time and come out in order, up to kSlots in flight ---------------------------
+// (the shape of a capture loop: Nu_scale/src/capture/frame_buffer.rs:11-50 feeding upscale(); rayon's fan-out over a batch is
+// upscale_batch above).  The retiring thread lives from stream_open to stream_close and touches only the ring's own state.
+
+int HipUpscaler::stream_open()
+{
+    std::lock_guard<std::mutex> lk(mu_);
+    if (!initialized_) return fail(kNotInitialized, "Upscaler not initialized. Call initialize() first.");
+    if (ring_.open) return fail(kInvalidArgument, "stream_open: a stream is already open on this upscaler");
+    NUS_HIP(hipSetDevice(device_));
+    int rc = ensure_streams();
+    for (int s = 0; s < kSlots && rc == kOk; ++s) rc = ensure_slot(slots_[s], (size_t)iw_ * ih_ * 4, (size_t)ow_ * oh_ * 4);
+    if (rc != kOk) return rc;
+    {
+        std::lock_guard<std::mutex> rl(ring_.m);
+        ring_.submitted = ring_.retired = 0;
+        ring_.stop = false;
+        ring_.status = kOk;
+        ring_.error.clear();
+    }
+    ring_.thread = std::thread([this] {
+        (void)hipSetDevice(device_);
+        for (uint64_t i = 0;; ++i) {
+            Ring::Item item;
+            {
+                std::unique_lock<std::mutex> rl(ring_.m);
+                ring_.cv.wait(rl, [&] { return ring_.submitted > i || ring_.stop; });
+                if (ring_.submitted <= i) return; // stop, and nothing left in flight
+                item = ring_.items[i % kSlots];
+            }
+            std::string err;
+            int rc;
+            try {
+                rc = retire_frame(slots_[i % kSlots], item.out, item.direct, &err);
+            } catch (...) {
+                rc = kOutOfMemory;
+            }
+            std::lock_guard<std::mutex> rl(ring_.m);
+            if (rc != kOk && ring_.status == kOk) {
+                ring_.status = rc;
+                ring_.error.swap(err);
+            }
+            ring_.retired = i + 1;
+            ring_.cv.notify_all();
+        }
+    });
+    ring_.open = true;
+    return kOk;
+}
+
+int HipUpscaler::stream_submit(const uint8_t *in, size_t in_len, uint8_t *out, size_t out_cap, uint64_t *ticket)
+{
+    std::lock_guard<std::mutex> lk(mu_);
+    if (!ring_.open) return fail(kInvalidArgument, "stream_submit: no stream is open (call stream_open first)");
+    if (!in || !out) return fail(kInvalidArgument, "stream_submit: null frame pointer");
+    const size_t in_bytes = (size_t)iw_ * ih_ * 4, out_bytes = (size_t)ow_ * oh_ * 4;
+    if (in_len != in_bytes)
+        return fail(kSizeMismatch, fmt("Input data size (%zu) does not match expected input buffer size (%zu for %ux%u)", in_len,
+                                       in_bytes, iw_, ih_));
+    if (out_cap < out_bytes)
+        return fail(kInvalidArgument, fmt("Output capacity (%zu) is smaller than the output frame (%zu for %ux%u)", out_cap,
+                                          out_bytes, ow_, oh_));
+    uint64_t i;
+    {
+        std::unique_lock<std::mutex> rl(ring_.m);
+        if (ring_.status != kOk) return fail(ring_.status, ring_.error);
+        i = ring_.submitted;
+        ring_.cv.wait(rl, [&] { return ring_.retired + (uint64_t)kSlots > i || ring_.status != kOk; }); // a free slot
+        if (ring_.status != kOk) return fail(ring_.status, ring_.error);
+    }
+    NUS_HIP(hipSetDevice(device_));
+    bool direct = false;
+    const int rc = submit_frame(slots_[i % kSlots], in, out, &direct);
+    if (rc != kOk) return rc; // nothing was queued for the retiring thread: the ring stays consistent
+    {
+        std::lock_guard<std::mutex> rl(ring_.m);
+        ring_.items[i % kSlots] = Ring::Item{out, direct};
+        ring_.submitted = i + 1;
+    }
+    ring_.cv.notify_all();
+    if (ticket) *ticket = i;
+    return kOk;
+}
+
+int HipUpscaler::stream_wait(uint64_t ticket)
+{
+    // (not under mu_: a second thread may wait for results while the first one is blocked in stream_submit)
+    std::unique_lock<std::mutex> rl(ring_.m);
+    if (ticket >= ring_.submitted) {
+        set_thread_error("stream_wait: no such frame has been submitted");
+        return kInvalidArgument;
+    }
+    ring_.cv.wait(rl, [&] { return ring_.retired > ticket || ring_.status != kOk; });
+    if (ring_.retired > ticket) return kOk;
+    set_thread_error(ring_.error);
+    return ring_.status;
+}
+
+int HipUpscaler::stream_close()
+{
+    std::lock_guard<std::mutex> lk(mu_);
+    if (!ring_.open) return kOk;
+    {
+        std::lock_guard<std::mutex> rl(ring_.m);
+        ring_.stop = true; // the thread first retires everything that was submitted
+    }
+    ring_.cv.notify_all();
+    if (ring_.thread.joinable()) ring_.thread.join();
+    ring_.open = false;
+    for (hipStream_t st : {s_in_, s_k_, s_out_})
+        if (st) (void)hipStreamSynchronize(st);
+    (void)hipGetLastError();
+    std::lock_guard<std::mutex> rl(ring_.m);
+    return ring_.status == kOk ? kOk : fail(ring_.status, ring_.error);
+}
+
 int HipUpscaler::upscale_batch(const uint8_t *const *ins, const size_t *in_lens, size_t n, uint8_t *const *outs,
                                size_t out_cap_each)
 {
     std::lock_guard<std::mutex> lk(mu_);
     if (!initialized_) return fail(kNotInitialized, "Upscaler not initialized. Call initialize() first.");
+    if (ring_.open) return fail(kInvalidArgument, "upscale: a stream is open on this upscaler (its slots are in use); close it first");
     if (n == 0) return kOk;
     if (!ins || !in_lens || !outs) return fail(kInvalidArgument, "upscale: null argument");
     const size_t in_bytes = (size_t)iw_ * ih_ * 4, out_bytes = (size_t)ow_ * oh_ * 4;
@@ -799,61 +990,19 @@ int HipUpscaler::upscale_batch(const uint8_t *const *ins, const size_t *in_lens,
         }
     } drain{{s_in_, s_k_, s_out_}};
     // Frame i uses slot i % nslots: stage -> H2D (copy-in stream) -> kernel (compute stream) -> D2H (copy-out stream),
-    // chained by the slot's events.  Pageable outputs come back in kOutChunks pieces: while piece k is copied out of the
-    // pinned buffer (by the copy pool's workers), piece k+1 is in flight.
-    const size_t chunk = ((out_bytes + kOutChunks - 1) / kOutChunks + 4095) & ~(size_t)4095;
+    // chained by the slot's events (submit_frame / retire_frame).  A slot is submitted to again only after its previous frame
+    // has been retired (so its D2H, hence its kernel and its H2D, are complete): no stream needs to wait for an earlier frame.
     std::vector<char> direct_out(n, 0);
-    // submit(i): the calling thread.  retire(i): waits for frame i's bytes and hands them to the caller's buffer.
-    // A slot is submitted to again only after its previous frame has been retired (so its D2H, hence its kernel and its
-    // H2D, are complete): no stream needs to wait for an earlier frame's events.
     auto submit = [&](size_t i) -> int {
-        Slot &S = slots_[i % nslots];
-        const uint8_t *src = ins[i];
-        if (!is_pinned_host(src)) {
-            parallel_copy(S.h_in, src, in_bytes);
-            src = S.h_in;
-        }
-        NUS_HIP(hipMemcpyAsync(S.d_in, src, in_bytes, hipMemcpyHostToDevice, s_in_));
-        NUS_HIP(hipEventRecord(S.in_done, s_in_));
-        NUS_HIP(hipStreamWaitEvent(s_k_, S.in_done, 0));
-        NUS_HIP(hipEventRecord(S.k_begin, s_k_));
-        int rc = enqueue(S.d_in, S.d_out, 1, s_k_);
-        if (rc != kOk) return rc;
-        NUS_HIP(hipEventRecord(S.k_end, s_k_));
-        NUS_HIP(hipStreamWaitEvent(s_out_, S.k_end, 0));
-        direct_out[i] = is_pinned_host(outs[i]) ? 1 : 0;
-        if (direct_out[i]) {
-            NUS_HIP(hipMemcpyAsync(outs[i], S.d_out, out_bytes, hipMemcpyDeviceToHost, s_out_));
-        } else {
-            int k = 0;
-            for (size_t off = 0; off < out_bytes; off += chunk, ++k) {
-                const size_t len = out_bytes - off < chunk ? out_bytes - off : chunk;
-                NUS_HIP(hipMemcpyAsync(S.h_out + off, S.d_out + off, len, hipMemcpyDeviceToHost, s_out_));
-                NUS_HIP(hipEventRecord(S.chunk_done[k], s_out_));
-            }
-        }
-        NUS_HIP(hipEventRecord(S.out_done, s_out_));
-        S.used = true;
-        return kOk;
+        bool direct = false;
+        const int rc = submit_frame(slots_[i % nslots], ins[i], outs[i], &direct);
+        direct_out[i] = direct ? 1 : 0;
+        return rc;
     };
     auto retire = [&](size_t i) -> int {
-        Slot &S = slots_[i % nslots];
-        if (direct_out[i]) {
-            NUS_HIP(hipEventSynchronize(S.out_done));
-            return kOk;
-        }
-        CopyTicket ticket; // the frame's pieces: queued as they land, all copied when the wait returns
-        int k = 0, rc = kOk;
-        for (size_t off = 0; off < out_bytes; off += chunk, ++k) {
-            const hipError_t e = hipEventSynchronize(S.chunk_done[k]);
-            if (e != hipSuccess) {
-                rc = fail_hip(e, "hipEventSynchronize(chunk_done)");
-                break;
-            }
-            parallel_copy_async(outs[i] + off, S.h_out + off, out_bytes - off < chunk ? out_bytes - off : chunk, ticket);
-        }
-        parallel_copy_wait(ticket); // also on the error path: queued pieces point into buffers that must outlive them
-        return rc;
+        std::string err;
+        const int rc = retire_frame(slots_[i % nslots], outs[i], direct_out[i] != 0, &err);
+        return rc == kOk ? kOk : fail(rc, err);
     };
     int status = kOk;
     if (n == 1) { // one frame (trait Upscaler::upscale): nothing to overlap with, no second thread

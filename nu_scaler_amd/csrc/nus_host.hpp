@@ -14,8 +14,10 @@
 
 #include <cstdint>
 #include <memory>
+#include <condition_variable>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "nus_kernels.hpp"
@@ -71,6 +73,14 @@ public:
     // upscale_batch (upscale/mod.rs:609-640): H2D / kernel / D2H pipelined over slots.
     int upscale_batch(const uint8_t *const *ins, const size_t *in_lens, size_t n, uint8_t *const *outs,
                       size_t out_cap_each);
+    // Persistent ring over the same slots: frames go in one at a time (stream_submit blocks only while kSlots frames are in
+    // flight), come out in submission order, and stream_wait(ticket) returns once frame `ticket` is in its output buffer.
+    // The capture loop's shape (Nu_scale/src/capture/frame_buffer.rs:11-50 -> upscale); while a stream is open the other host
+    // entry points of this upscaler are refused.  stream_wait may be called from another thread than stream_submit.
+    int stream_open();
+    int stream_submit(const uint8_t *in, size_t in_len, uint8_t *out, size_t out_cap, uint64_t *ticket);
+    int stream_wait(uint64_t ticket);
+    int stream_close();
     // frames already resident in HBM; enqueue only.
     int upscale_device(const void *d_in, void *d_out, uint32_t n_frames, hipStream_t stream);
     // Fused "interpolate (zero flow) then upscale the in-between frame": unit i reads frame
@@ -138,6 +148,23 @@ private:
     int ensure_device();
     int ensure_streams();
     int ensure_slot(Slot &s, size_t in_bytes, size_t out_bytes);
+    int submit_frame(Slot &s, const uint8_t *in, uint8_t *out, bool *direct);
+    int retire_frame(Slot &s, uint8_t *out, bool direct, std::string *err) const;
+    struct Ring { // state of an open stream (stream_open .. stream_close); its own mutex, never held together with a HIP call
+        struct Item {
+            uint8_t *out = nullptr;
+            bool direct = false;
+        };
+        bool open = false; // guarded by mu_
+        std::thread thread;
+        std::mutex m;
+        std::condition_variable cv;
+        uint64_t submitted = 0, retired = 0;
+        bool stop = false;
+        int status = 0;
+        std::string error;
+        Item items[kSlots];
+    } ring_;
     void release_slot(Slot &s);
     void release();
     int upload_tables();

@@ -161,6 +161,33 @@ class PyWgpuUpscaler:
         self._check(self._lib.nus_upscaler_upscale_batch(self._h, ins_c, lens_c, n, outs_c, min(b[1] for b in obufs)))
         del bufs, obufs
 
+    # -- persistent ring (nus_upscaler_stream_*): frames in one at a time, results in order, three in flight
+    def stream_open(self) -> None:
+        self._stream_keep = {}
+        self._check(self._lib.nus_upscaler_stream_open(self._h))
+
+    def stream_submit(self, frame, out) -> int:
+        """Stage and enqueue one frame; `out` is a writable buffer of output_size bytes that receives it.  Returns the frame's
+        ticket; blocks only while three frames are in flight."""
+        addr, n, keep = _as_buffer(frame)
+        oaddr, on, okeep = _as_buffer(out)
+        t = ctypes.c_uint64()
+        self._check(self._lib.nus_upscaler_stream_submit(self._h, addr, n, oaddr, on, ctypes.byref(t)))
+        self._stream_keep[t.value] = (keep, okeep)  # both buffers stay alive until the frame has been waited for
+        return t.value
+
+    def stream_wait(self, ticket: int) -> None:
+        st = self._lib.nus_upscaler_stream_wait(self._h, int(ticket))
+        for k in [k for k in self._stream_keep if k <= ticket]:
+            del self._stream_keep[k]
+        if st != C.OK:
+            raise RuntimeError(C.last_error())
+
+    def stream_close(self) -> None:
+        st = self._lib.nus_upscaler_stream_close(self._h)
+        self._stream_keep = {}
+        self._check(st)
+
     # -- device-resident path (not in the reference; used by the frame stream + bench)
     def upscale_device(self, d_in: int, d_out: int, n_frames: int = 1, stream: int = 0) -> None:
         self._check(self._lib.nus_upscaler_upscale_device(self._h, d_in, d_out, n_frames, stream or None))

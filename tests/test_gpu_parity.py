@@ -463,6 +463,57 @@ def test_upscale_batch_pipeline_many_frames_every_buffer_kind(nsc, oracle_mod):
     assert np.array_equal(np.frombuffer(u.upscale(ins[2]), np.uint8).reshape(2 * h, 2 * w, 4), want[2])
 
 
+def test_stream_ring_frames_in_one_at_a_time(nsc, oracle_mod):
+    """The persistent ring (nus_upscaler_stream_*): 20 frames submitted one by one with three in flight, results in order into
+    caller-owned buffers (pageable and pinned), waited for from another thread; the other host entry points are refused while
+    the stream is open; closing with frames in flight completes them; re-opening works."""
+    import threading
+
+    w, h, n = 320, 180, 20
+    frames = [oracle_mod.gen_noise(w, h, 7000 + i) for i in range(n)]
+    want = [oracle_mod.bilinear(f, 2 * w, 2 * h) for f in frames]
+    u = nsc.PyWgpuUpscaler("quality", "bilinear")
+    u.initialize(w, h, 2 * w, 2 * h)
+    outs = [bytearray(u.output_size) for _ in range(n)]
+    pin = nsc.PinnedBuffer(outs[5])
+    u.stream_open()
+    with pytest.raises(RuntimeError, match="already open"):
+        u.stream_open()
+    with pytest.raises(RuntimeError, match="a stream is open"):
+        u.upscale(frames[0].tobytes())
+    done = []
+
+    def waiter(tickets):
+        for t in tickets:
+            u.stream_wait(t)
+            done.append(t)
+
+    tickets = [u.stream_submit(frames[i].tobytes(), outs[i]) for i in range(8)]
+    assert tickets == list(range(8))
+    th = threading.Thread(target=waiter, args=(tickets,))
+    th.start()
+    tickets2 = [u.stream_submit(frames[i].tobytes(), outs[i]) for i in range(8, n)]  # submits while the other thread waits
+    th.join()
+    assert done == list(range(8))
+    with pytest.raises(RuntimeError, match="does not match expected input buffer size"):
+        u.stream_submit(frames[0].tobytes()[:-4], outs[0])
+    u.stream_wait(tickets2[-3])
+    with pytest.raises(RuntimeError, match="no such frame"):
+        u.stream_wait(n + 5)
+    u.stream_close()  # the last two frames were still in flight
+    pin.unpin()
+    for i in range(n):
+        assert np.array_equal(np.frombuffer(outs[i], np.uint8).reshape(2 * h, 2 * w, 4), want[i]), i
+    assert np.array_equal(np.frombuffer(u.upscale(frames[3].tobytes()), np.uint8).reshape(2 * h, 2 * w, 4), want[3])
+    u.stream_open()
+    out = bytearray(u.output_size)
+    u.stream_wait(u.stream_submit(frames[9].tobytes(), out))
+    assert np.array_equal(np.frombuffer(out, np.uint8).reshape(2 * h, 2 * w, 4), want[9])
+    u.initialize(w, h, 2 * w, 2 * h)  # re-initialising closes the stream
+    with pytest.raises(RuntimeError, match="no stream is open"):
+        u.stream_submit(frames[0].tobytes(), out)
+
+
 def test_table_export_import_roundtrip(nsc, oracle_mod):
     img = oracle_mod.gen_noise(64, 36, 3)
     u1 = nsc.PyWgpuUpscaler("quality", "lanczos3", lanczos_mode="exact")

@@ -105,6 +105,16 @@ def test_not_initialized_error_text(nsc):
     assert u.get_last_gpu_duration_ms() is None and u.input_size == 0
 
 
+def test_stream_ring_needs_an_initialized_upscaler_and_an_open_stream(nsc):
+    """nus_upscaler_stream_*: error paths that need no GPU."""
+    u = nsc.PyWgpuUpscaler("quality", "nearest")
+    with pytest.raises(RuntimeError, match="not initialized"):
+        u.stream_open()
+    with pytest.raises(RuntimeError, match="no stream is open"):
+        u.stream_submit(b"\0" * 16, bytearray(64))
+    u.stream_close()  # closing what is not open is not an error
+
+
 def test_interpolator_validation_without_gpu(nsc):
     it = nsc.WgpuFrameInterpolator("wide")
     assert it.get_last_gpu_duration_ms() is None
