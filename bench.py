@@ -141,28 +141,13 @@ def _median(xs):
 
 
 def usable_cpus():
-    """CPUs this process may actually keep busy: its affinity mask, capped by the cgroup's CFS quota (cpu.max: quota / period).
+    """CPUs this process may actually keep busy (oracle.usable_cpus: the affinity mask capped by the cgroup's CPU quota).
     A GPU box's job gets a share of the host (16 CPUs per GPU on this pool); more OpenMP threads than that burn the quota in
     the first milliseconds of every 100 ms period and sleep through the rest of it (a 1080p Lanczos pass: 4 ms on 64 threads,
     8.4 ms on 16, 100-200 ms on 256 -- profiles/r03_cpu_baseline_threads.txt)."""
-    n = len(os.sched_getaffinity(0))
-    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
-        try:
-            with open(path) as f:
-                parts = f.read().split()
-            if path.endswith("cpu.max"):
-                if parts[0] != "max":
-                    n = min(n, max(1, int(int(parts[0]) / int(parts[1]) + 0.5)))
-            else:
-                quota = int(parts[0])
-                with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
-                    period = int(f.read().split()[0])
-                if quota > 0:
-                    n = min(n, max(1, int(quota / period + 0.5)))
-            break
-        except (OSError, ValueError, IndexError):
-            continue
-    return n
+    import oracle
+
+    return oracle.usable_cpus()
 
 
 def cpu_baseline(args, unit_pixels):

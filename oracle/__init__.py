@@ -123,13 +123,13 @@ def _upscale(fn, img, ow, oh, *extra):
 def nearest(img, ow, oh, threads: int = 1):
     if threads == 1:
         return _upscale(lib().orc_nearest, img, ow, oh)
-    return _upscale(lib().orc_nearest_mt, img, ow, oh, threads)
+    return _upscale(lib().orc_nearest_mt, img, ow, oh, _threads(threads))
 
 
 def bilinear(img, ow, oh, threads: int = 1):
     if threads == 1:
         return _upscale(lib().orc_bilinear, img, ow, oh)
-    return _upscale(lib().orc_bilinear_mt, img, ow, oh, threads)
+    return _upscale(lib().orc_bilinear_mt, img, ow, oh, _threads(threads))
 
 
 def bilinear_wgsl(img, ow, oh):
@@ -139,13 +139,13 @@ def bilinear_wgsl(img, ow, oh):
 def resize(img, ow, oh, filt: int = FILTER_LANCZOS3, threads: int = 1):
     if threads == 1:
         return _upscale(lib().orc_resize, img, ow, oh, filt)
-    return _upscale(lib().orc_resize_mt, img, ow, oh, filt, threads)
+    return _upscale(lib().orc_resize_mt, img, ow, oh, filt, _threads(threads))
 
 
 def lanczos3(img, ow, oh, threads: int = 1):
     if threads == 1:
         return _upscale(lib().orc_lanczos3, img, ow, oh)
-    return _upscale(lib().orc_lanczos3_mt, img, ow, oh, threads)
+    return _upscale(lib().orc_lanczos3_mt, img, ow, oh, _threads(threads))
 
 
 def resize_axis(in_n: int, out_n: int, filt: int = FILTER_LANCZOS3, max_taps: int = 32):
@@ -174,7 +174,7 @@ def warp_blend(a, b, flow, t: float, threads: int = 1):
     if threads == 1:
         lib().orc_warp_blend(_ptr(a), _ptr(b), fp, w, h, t, _ptr(out))
     else:
-        lib().orc_warp_blend_mt(_ptr(a), _ptr(b), fp, w, h, t, _ptr(out), threads)
+        lib().orc_warp_blend_mt(_ptr(a), _ptr(b), fp, w, h, t, _ptr(out), _threads(threads))
     return out
 
 
@@ -194,8 +194,39 @@ def fsr1(img, ow, oh, easu_sharpness: float = 0.0, rcas_sharpness: float = 0.7):
     return _upscale(lib().orc_fsr1, img, ow, oh, easu_sharpness, rcas_sharpness)
 
 
+def usable_cpus() -> int:
+    """CPUs this process may actually keep busy: its affinity mask capped by the cgroup's CFS quota (cpu.max).  On the GPU boxes
+    a job gets 16 of the host's 256 hardware threads; an OpenMP team of 256 burns that quota in the first milliseconds of every
+    100-ms period (and its threads count against the job's process limit)."""
+    import os
+
+    n = len(os.sched_getaffinity(0))
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            with open(path) as f:
+                parts = f.read().split()
+            if path.endswith("cpu.max"):
+                if parts[0] != "max":
+                    n = min(n, max(1, int(int(parts[0]) / int(parts[1]) + 0.5)))
+            else:
+                quota = int(parts[0])
+                with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+                    period = int(f.read().split()[0])
+                if quota > 0:
+                    n = min(n, max(1, int(quota / period + 0.5)))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return n
+
+
 def max_threads() -> int:
-    return int(lib().orc_max_threads())
+    """What `threads=0` means: the OpenMP maximum, capped by the CPUs the job may keep busy."""
+    return max(1, min(int(lib().orc_max_threads()), usable_cpus()))
+
+
+def _threads(threads: int) -> int:
+    return max_threads() if threads <= 0 else int(threads)
 
 
 def gen_gradient(w: int, h: int, shift: int = 0):
