@@ -36,6 +36,48 @@ struct LanczosR32Args {
 };
 
 
+// Row prefetches: as in nus_k_lanczos_x2.hip the rows are requested with LDS-DMA loads issued from inline assembly (16 B per
+// lane straight into a per-wave 1-KiB LDS slot, no VGPR destination, invisible to the compiler's s_waitcnt insertion) and
+// waited for with hand-counted `s_waitcnt vmcnt(N)` -- gfx950 retires loads and stores in issue order on one counter, and the
+// compiler's own waits in front of a row conversion drained all but the newest stores once per step.
+// tools/check_hidden_loads.py verifies the counts on the generated code (tests/test_kernel_asm.py).
+#ifndef NUS_R32_DEPTH
+#define NUS_R32_DEPTH 2 // prefetch distance in steps (a step = two input rows = two requests)
+#endif
+#ifndef NUS_R32_WAIT_EARLY
+#define NUS_R32_WAIT_EARLY 1 // 1: wait + LDS read at the start of the phase whose end the row is converted at; 0: at its end
+#endif
+constexpr int kR32Depth = NUS_R32_DEPTH;
+
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm" // m0 is a reserved register: nothing else in this kernel uses it
+__device__ __forceinline__ void r32_dma_row16(const uint8_t *base, uint32_t off, uint32_t lds)
+{
+    asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(off), "s"(base), "s"(lds) : "memory", "m0");
+}
+#pragma clang diagnostic pop
+
+// at most N vector memory instructions outstanding; BACK (for the checker): the BACK-th most recent request has landed
+template <int N, int BACK>
+__device__ __forceinline__ void r32_wait_vmcnt()
+{
+    static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit counter on gfx9");
+    asm volatile("s_waitcnt vmcnt(%0) ; nus-wait back=%1" : : "n"(N), "n"(BACK) : "memory");
+}
+
+// LDS ring of one wave: 2 kR32Depth slots of one row (64 lanes x 16 B).  `pos` walks the slot pairs.
+struct R32Ring {
+    const uint8_t *base; // this wave's ring as a generic pointer (reads)
+    uint32_t lds;        // its byte offset in LDS (wave-uniform; requests)
+    int lane;
+};
+
+__device__ __forceinline__ float r32_vgpr(float s)
+{
+    asm volatile("" : "+v"(s));
+    return s;
+}
+
 __device__ __forceinline__ void r32_cvt_row(const uint4 raw, float (&dst)[16])
 {
     const uint32_t px[4] = {raw.x, raw.y, raw.z, raw.w};
@@ -52,21 +94,6 @@ __device__ __forceinline__ uint32_t r32_row_is_opaque(const uint4 px)
     return __builtin_amdgcn_ballot_w64(!lane_opaque) == 0ull ? 1u : 0u;
 }
 
-// Vertical pass of one output row: 6 taps from the window rows 0 .. 5.  W: VGPR weights (interior rows)
-// or a scalar pointer into the table (rows whose window is cut by the top / bottom border).
-template <bool EXACT, typename W>
-__device__ __forceinline__ void r32_vpass(const float (&win)[6][16], const W &w, float (&V)[16], bool skip_alpha)
-{
-#pragma unroll
-    for (int k = 0; k < 16; ++k) {
-        if ((k & 3) == 3 && skip_alpha) continue; // wave-uniform; V[alpha] is then not read
-        float acc = win[0][k] * w[0]; // == fma(.., 0) and a VOP2 instruction
-#pragma unroll
-        for (int j = 1; j < 6; ++j) acc = mac_tight<EXACT>(acc, win[j][k], w[j]);
-        V[k] = acc;
-    }
-}
-
 // Where a wave's output row goes: as in the x2 / xs kernels the row is turned round in LDS -- every lane writes the 24
 // bytes (6 pixels) it computed at 24 * lane, then reads 16 B at 1024 q + 16 * lane for store q -- so that a store
 // instruction writes contiguous bytes (tools/probe_rw_mix.hip).  The wave's span is 64 x 24 = 1536 B: one full store
@@ -77,12 +104,14 @@ struct R32Store {
     int lane;
 };
 
-// Horizontal pass of one output row: the lane's 6 output pixels (2 input pairs x 3 phases), convert + pack, stores.
-// Output 3 m + p (pair m of the lane, phase p) reads the columns e[2 m + p] .. e[2 m + p + 5] (e[3] is the lane's own
-// first column).
-template <bool EXACT>
-__device__ __forceinline__ void r32_hpass_store(const float (&V)[16], const float (&W)[3][6], __amdgpu_buffer_rsrc_t rs,
-                                                const R32Store &st, uint32_t row_off, bool skip_alpha)
+// One output row: per channel the vertical pass of the lane's 4 columns (6 taps from window slots B .. B+5 mod 6), the
+// lane exchange (3 columns from each neighbour) and the horizontal pass of the lane's 6 output pixels (2 input pairs x 3
+// phases; output 3 m + p reads the columns e[2 m + p] .. e[2 m + p + 5], e[3] is the lane's own first column), convert +
+// pack; then the row's turn through LDS and its two stores.  Channel by channel so that only 4 vertical sums are live.
+// WV: VGPR weights (interior rows) or a scalar pointer into the table (rows whose window is cut by the top / bottom border).
+template <bool EXACT, int B, typename WV>
+__device__ __forceinline__ void r32_row(const float (&win)[6][16], const WV &wv, const float (&W)[3][6], __amdgpu_buffer_rsrc_t rs,
+                                        const R32Store &st, uint32_t row_off, bool skip_alpha)
 {
     // skip_alpha (FMA mode, wave-uniform): the six tap rows are opaque in this wave, so alpha is the constant
     // 255 (see row_is_opaque in nus_k_lanczos_x2.hip); v_cvt_pk_u8_f32 only ever replaces bytes 0..2 then
@@ -92,17 +121,25 @@ __device__ __forceinline__ void r32_hpass_store(const float (&V)[16], const floa
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
         if (c == 3 && skip_alpha) continue;
+        float v[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            float acc = win[B % 6][m * 4 + c] * wv[0]; // == fma(.., 0) and a VOP2 instruction
+#pragma unroll
+            for (int j = 1; j < 6; ++j) acc = mac_tight<EXACT>(acc, win[(B + j) % 6][m * 4 + c], wv[j]);
+            v[m] = acc;
+        }
         float e[10]; // vertical sums of input columns c0-3 .. c0+6 for this channel
-        e[0] = wave_up(V[1 * 4 + c]);
-        e[1] = wave_up(V[2 * 4 + c]);
-        e[2] = wave_up(V[3 * 4 + c]);
-        e[3] = V[0 * 4 + c];
-        e[4] = V[1 * 4 + c];
-        e[5] = V[2 * 4 + c];
-        e[6] = V[3 * 4 + c];
-        e[7] = wave_down(V[0 * 4 + c]);
-        e[8] = wave_down(V[1 * 4 + c]);
-        e[9] = wave_down(V[2 * 4 + c]);
+        e[0] = wave_up(v[1]);
+        e[1] = wave_up(v[2]);
+        e[2] = wave_up(v[3]);
+        e[3] = v[0];
+        e[4] = v[1];
+        e[5] = v[2];
+        e[6] = v[3];
+        e[7] = wave_down(v[0]);
+        e[8] = wave_down(v[1]);
+        e[9] = wave_down(v[2]);
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
 #pragma unroll
@@ -114,7 +151,8 @@ __device__ __forceinline__ void r32_hpass_store(const float (&V)[16], const floa
             }
         }
     }
-    // range-checked buffer stores: pieces that must not be written sit beyond num_records (see the x2 kernel)
+    // range-checked buffer stores: pieces that must not be written sit beyond num_records (see the x2 kernel), so both
+    // stores issue on every path and for every lane -- the hand-counted waits rely on exactly two per output row
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 #pragma unroll
     for (int q = 0; q < 3; ++q) st.stage[3 * st.lane + q] = make_uint2(o[2 * q], o[2 * q + 1]);
@@ -130,60 +168,84 @@ __device__ __forceinline__ void r32_hpass_store(const float (&V)[16], const floa
     __builtin_amdgcn_wave_barrier();
 }
 
-// One input row pair (r, r+1), r even -> output rows 3 r / 2 .. 3 r / 2 + 2.  At entry window row j holds input row
-// r-3+j and raw0 / raw1 hold rows r+3 / r+4; the window is shifted, not rotated (one copy of the step's code).
-template <bool EXACT>
-__device__ __forceinline__ void r32_step(float (&win)[6][16], uint4 &raw0, uint4 &raw1, int r, int cl, const R32Store &st,
-                                         const LanczosR32Args &A, const float (&W)[3][6], float (&Wv)[3][6], uint32_t &row_cls,
+// Vertical weights of the current row pair's class: 18 numbers that change a few times per frame, kept in SGPRs; each
+// phase copies its six into VGPRs (a scalar operand halves an FMA's issue rate; 18 more VGPRs would cost the third wave).
+struct R32RowWeights {
+    float w[3][6];
+    uint32_t cls;
+};
+
+// One input row pair (r, r+1), r even -> output rows 3 r / 2 .. 3 r / 2 + 2.  At entry window slot (S + j) % 6 holds input
+// row r-3+j and the ring's slot pair at `pos` holds rows r+3 / r+4 (requested kR32Depth steps ago).  Phase p reads the slots
+// S+p .. S+p+5; row r-3+p dies with it and row r+3+p is converted into its slot: the window rotates, 3 steps unrolled.
+//
+// Vector memory instructions of a step, in issue order and on every path: 2 stores (phase 0), request of row r+3+2D,
+// 2 stores (phase 1), request of row r+4+2D, 2 stores (phase 2).  Issued since the request of row r+3 when the wave waits
+// for it at the END of phase 0: the rest of that step (5), D-1 whole steps (8 each), this step's first stores (2):
+// N = 8 D - 1; waiting at the START of the phase: N = 8 D - 3.  The same two numbers hold for row r+4 around phase 1
+// (2 + 8 (D - 1) + 5 and 2 + 8 (D - 1) + 3).  Either request is the 2 D-th most recent one when it is waited for.
+template <bool EXACT, int S>
+__device__ __forceinline__ void r32_step(float (&win)[6][16], const R32Ring &ring, uint32_t &pos, int r, uint32_t in_off,
+                                         const R32Store &st, const LanczosR32Args &A, const float (&W)[3][6], R32RowWeights &RW,
                                          const uint8_t *src, __amdgpu_buffer_rsrc_t rs, uint32_t &opaque)
 {
     typedef const __attribute__((address_space(4))) float *cfloat_p;
+    constexpr int D = kR32Depth;
+    constexpr bool EARLY = NUS_R32_WAIT_EARLY != 0;
     {
-        // vertical weights of this row pair's class: VGPR copies, reloaded when the class changes (a few times per frame)
+        // vertical weights of this row pair's class, reloaded when the class changes
         const uint32_t cy = __builtin_amdgcn_readfirstlane(A.cls_y[r >> 1]);
-        if (cy != row_cls) { // wave-uniform
-            row_cls = cy;
+        if (cy != RW.cls) { // wave-uniform
+            RW.cls = cy;
             cfloat_p wt = (cfloat_p)(uintptr_t)(A.wcls_y + (size_t)cy * 18);
 #pragma unroll
             for (int p = 0; p < 3; ++p)
 #pragma unroll
-                for (int j = 0; j < 6; ++j) {
-                    Wv[p][j] = wt[p * 6 + j];
-                    asm volatile("" : "+v"(Wv[p][j]));
-                }
+                for (int j = 0; j < 6; ++j) RW.w[p][j] = wt[p * 6 + j];
         }
     }
     const uint32_t row_bytes = A.iw * 6; // one output row: 1.5 iw pixels
     const uint32_t oy0 = 3u * (uint32_t)(r >> 1);
     const bool interior = r >= 4 && r + 6 <= (int)A.ih; // wave-uniform: rows r-3 .. r+4 exist and the pair is not a border pair
-    float V[16];
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 #pragma unroll
     for (int p = 0; p < 3; ++p) {
-        const bool skip_alpha = !EXACT && (opaque & 0x3Fu) == 0x3Fu; // bit j: window row 5-j is opaque
+        u32x4 next;
+        const uint32_t slot = pos + (uint32_t)p * 1024u; // p < 2: the ring slot of row r+3+p
+        if (p < 2 && EARLY) {
+            r32_wait_vmcnt<8 * D - 3, 2 * D>();
+            next = *reinterpret_cast<const u32x4 *>(ring.base + slot + 16 * ring.lane);
+        }
+        const bool skip_alpha = !EXACT && (opaque & 0x3Fu) == 0x3Fu; // bit j: the row j before the newest is opaque
         if (interior) {
-            r32_vpass<EXACT>(win, Wv[p], V, skip_alpha);
+            float wv[6];
+#pragma unroll
+            for (int j = 0; j < 6; ++j) wv[j] = r32_vgpr(RW.w[p][j]);
+            r32_row<EXACT, S + p>(win, wv, W, rs, st, (oy0 + (uint32_t)p) * row_bytes, skip_alpha);
         } else {
             cfloat_p wt = (cfloat_p)(uintptr_t)(A.wy6 + (size_t)__builtin_amdgcn_readfirstlane(oy0 + (uint32_t)p) * 6);
-            r32_vpass<EXACT>(win, wt, V, skip_alpha);
+            r32_row<EXACT, S + p>(win, wt, W, rs, st, (oy0 + (uint32_t)p) * row_bytes, skip_alpha);
         }
-        r32_hpass_store<EXACT>(V, W, rs, st, (oy0 + (uint32_t)p) * row_bytes, skip_alpha);
         if (p < 2) {
-            // the oldest row out, row r+3+p in; then request row r+5+p
-#pragma unroll
-            for (int j = 0; j < 5; ++j)
-#pragma unroll
-                for (int k = 0; k < 16; ++k) win[j][k] = win[j + 1][k];
-            uint4 &raw = p == 0 ? raw0 : raw1;
-            {
-                const uint4 px = swz4(raw, A.sel);
-                if (!EXACT) opaque = (opaque << 1) | r32_row_is_opaque(px);
-                r32_cvt_row(px, win[5]);
+            // the oldest row out, row r+3+p in; then request row r+3+p+2D into the same ring slot
+            if (!EARLY) {
+                r32_wait_vmcnt<8 * D - 1, 2 * D>();
+                next = *reinterpret_cast<const u32x4 *>(ring.base + slot + 16 * ring.lane);
             }
-            int rn = r + 5 + p;
+            {
+                const uint4 px = swz4(make_uint4(next.x, next.y, next.z, next.w), A.sel);
+                if (!EXACT) opaque = (opaque << 1) | r32_row_is_opaque(px);
+                r32_cvt_row(px, win[(S + p) % 6]);
+            }
+            int rn = r + 3 + p + 2 * D;
             rn = rn < (int)A.ih - 1 ? rn : (int)A.ih - 1;
-            raw = *reinterpret_cast<const uint4 *>(src + ((size_t)rn * A.iw + cl) * 4);
+            // the slot is requested again only when its read has RETURNED (the converted row is an operand of this empty
+            // statement): nothing orders a queued ds_read behind a later LDS-DMA write (see the x2 kernel)
+            asm volatile("" : : "v"(win[(S + p) % 6][0]), "v"(win[(S + p) % 6][15]) : "memory");
+            r32_dma_row16(src, in_off + (uint32_t)rn * (A.iw * 4), ring.lds + slot);
         }
     }
+    pos = pos + 2048u == (uint32_t)(2 * D) * 1024u ? 0u : pos + 2048u;
 }
 
 // One wave loads a strip of 256 input columns (4 per lane; lanes 2 .. 61 produce the strip's 240 input = 360 output
@@ -214,9 +276,16 @@ __global__ __launch_bounds__(256) void k_lanczos3_r32(const LanczosR32Args A)
         const int cc = (int)(strip * kR32StripCols) - 8 + L * 4;
         return L >= 2 && L < 2 + kR32StripCols / 4 && cc >= 8 && cc + 12 <= (int)A.iw;
     };
+    // (the rings come first in the block's LDS: an LDS-DMA slot address is M0 + a 12-bit instruction offset of 0)
+    __shared__ uint4 lds_rows[4][2 * kR32Depth][64];
     __shared__ uint2 lds_stage[4][64 * 3];
+    const uint32_t w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    R32Ring ring;
+    ring.base = reinterpret_cast<const uint8_t *>(&lds_rows[w][0][0]);
+    ring.lds = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)&lds_rows[w][0][0]);
+    ring.lane = lane;
     R32Store st;
-    st.stage = lds_stage[__builtin_amdgcn_readfirstlane(threadIdx.x >> 6)];
+    st.stage = lds_stage[w];
     st.lane = lane;
     {
         // the wave's span starts at lane 0's pixels: byte 6 (c of lane 0) of an output row; a 16-byte piece at byte b of the
@@ -229,16 +298,18 @@ __global__ __launch_bounds__(256) void k_lanczos3_r32(const LanczosR32Args A)
             st.off[q] = ok ? (uint32_t)(span0 + b) : 0x80000000u;
         }
     }
+    const uint32_t in_off = (uint32_t)cl * 4u; // the lane's byte offset inside an input row
     const int r0 = (int)(rb * A.th); // even
     const int r_end = (r0 + (int)A.th) < (int)A.ih ? (r0 + (int)A.th) : (int)A.ih;
     const int rmax = (int)A.ih - 1;
-    auto load_row = [&](int rr) {
+    auto row_off = [&](int rr) {
         rr = rr < 0 ? 0 : (rr > rmax ? rmax : rr);
-        return *reinterpret_cast<const uint4 *>(src + ((size_t)rr * A.iw + cl) * 4);
+        return in_off + (uint32_t)rr * (A.iw * 4);
     };
 
-    float W[3][6], Wv[3][6];
-    uint32_t row_cls = 0xffffffffu;
+    float W[3][6];
+    R32RowWeights RW;
+    RW.cls = 0xffffffffu;
     {
         // the lane's two column pairs share a class (host-checked); lanes that do not store take class 0
         const uint32_t cx = c >= 8 && c + 12 <= (int)A.iw ? A.cls_x[c >> 1] : 0u;
@@ -246,21 +317,41 @@ __global__ __launch_bounds__(256) void k_lanczos3_r32(const LanczosR32Args A)
         for (int p = 0; p < 3; ++p)
 #pragma unroll
             for (int j = 0; j < 6; ++j) {
-                W[p][j] = A.wcls_x[(size_t)cx * 18 + p * 6 + j];
-                asm volatile("" : "+v"(W[p][j])); // VGPR copy: scalar operands halve the VALU issue rate
-                Wv[p][j] = 0.0f;
+                W[p][j] = r32_vgpr(A.wcls_x[(size_t)cx * 18 + p * 6 + j]); // VGPR copy: scalar operands halve the VALU issue rate
+                RW.w[p][j] = 0.0f;
             }
     }
     float win[6][16];
     uint32_t opaque = 0;
+    {
+        // the six rows of the first window (ordinary loads, all in flight together), then the first requests
+        uint4 first[6];
 #pragma unroll
-    for (int j = 0; j < 6; ++j) {
-        const uint4 px = swz4(load_row(r0 - 3 + j), A.sel);
-        if (!EXACT) opaque = (opaque << 1) | r32_row_is_opaque(px);
-        r32_cvt_row(px, win[j]);
+        for (int j = 0; j < 6; ++j) first[j] = *reinterpret_cast<const uint4 *>(src + row_off(r0 - 3 + j));
+#pragma unroll
+        for (int j = 0; j < 2 * kR32Depth; ++j) r32_dma_row16(src, row_off(r0 + 3 + j), ring.lds + (uint32_t)j * 1024u);
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            const uint4 px = swz4(first[j], A.sel);
+            if (!EXACT) opaque = (opaque << 1) | r32_row_is_opaque(px);
+            r32_cvt_row(px, win[j]);
+        }
+        // the hand-counted waits of the loop assume that nothing older than its own instructions is outstanding
+        r32_wait_vmcnt<0, 0>();
     }
-    uint4 raw0 = load_row(r0 + 3), raw1 = load_row(r0 + 4);
-    for (int r = r0; r < r_end; r += 2) r32_step<EXACT>(win, raw0, raw1, r, cl, st, A, W, Wv, row_cls, src, rs, opaque);
+    uint32_t pos = 0;
+    for (int rbase = r0; rbase < r_end; rbase += 6) {
+        // 3 steps unrolled so the rotating window indices are compile-time constants.  The block leaves the loop after its
+        // last row pair: a step is never skipped with a later one still to run, so every path through the loop carries the
+        // vector memory instructions the hand-counted waits assume.
+#define NUS_R32_STEP(S) \
+        r32_step<EXACT, S>(win, ring, pos, rbase + S, in_off, st, A, W, RW, src, rs, opaque); \
+        if (S < 4 && rbase + S + 2 >= r_end) break
+        NUS_R32_STEP(0);
+        NUS_R32_STEP(2);
+        NUS_R32_STEP(4);
+#undef NUS_R32_STEP
+    }
 }
 
 // The 12 left-most and right-most output columns (tap windows cut by the image border, weights renormalised).  As in
