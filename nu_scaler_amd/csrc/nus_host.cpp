@@ -569,19 +569,34 @@ int HipUpscaler::enqueue(const uint8_t *d_in, uint8_t *d_out, uint32_t n_frames,
     }
     case Variant::LanczosR32RegWin: {
         uint32_t th = rows_per_wave_;
-        if (th == 0) { // as at x2: enough waves to fill the chip a few times over, tall enough to amortise the 7 halo rows
+        if (th == 0) {
+            // as at x2: enough waves to fill the chip (3 per SIMD) a few times over, tall enough to amortise the 8 halo rows; the
+            // kernel's time is flat from 24 to 96 rows per wave on a batch, so the row blocks are made equal rather than tall
+            // (a last block of a few rows costs more than anything else here: profiles/r03_lanczos_r32_rework_ab.txt)
             const uint64_t rows_total = (uint64_t)ih_ * ((iw_ + 239) / 240) * n_frames;
-            const uint64_t t = rows_total / 8192;
-            th = (uint32_t)(t < 12 ? 12 : (t > 120 ? 120 : t));
+            uint64_t t = rows_total / 12288;
+            t = t < 12 ? 12 : (t > 48 ? 48 : t);
+            const uint64_t blocks = (ih_ + t - 1) / t;
+            th = (uint32_t)((ih_ + blocks - 1) / blocks + 1) & ~1u;
         }
         e = launch_lanczos_r32(L, dt_, lanczos_exact_, th);
         if (e == hipSuccess) e = launch_lanczos_r32_edges(L, dt_, lanczos_exact_); // border columns
         break;
     }
     case Variant::LanczosXsRegWin:
-        e = launch_lanczos_xs(L, dt_, lanczos_exact_, xs_factor_, rows_per_wave_);
+    {
+        uint32_t th = rows_per_wave_;
+        if (th == 0) { // short, equal row blocks: 12 - 16 rows per wave measured best at x3 and x4 on batches (24 - 36: + 4 %)
+            const uint64_t rows_total = (uint64_t)ih_ * ((iw_ + kLanczosX2StripCols - 1) / kLanczosX2StripCols) * n_frames;
+            uint64_t t = rows_total / 16384;
+            t = t < 8 ? 8 : (t > 16 ? 16 : t);
+            const uint64_t blocks = (ih_ + t - 1) / t;
+            th = (uint32_t)((ih_ + blocks - 1) / blocks);
+        }
+        e = launch_lanczos_xs(L, dt_, lanczos_exact_, xs_factor_, th);
         if (e == hipSuccess) e = launch_lanczos_xs_edges(L, dt_, lanczos_exact_, xs_factor_); // border columns
         break;
+    }
     case Variant::LanczosX2RegWin: {
         uint32_t th = rows_per_wave_;
         if (th == 0) {

@@ -47,6 +47,9 @@ struct LanczosR32Args {
 #ifndef NUS_R32_WAIT_EARLY
 #define NUS_R32_WAIT_EARLY 1 // 1: wait + LDS read at the start of the phase whose end the row is converted at; 0: at its end
 #endif
+#ifndef NUS_R32_PIN_FMA
+#define NUS_R32_PIN_FMA 1 // the fused operations pinned in program order (mac_tight<.., true>): -5 % on 4-channel input, -4 % at 720p
+#endif
 constexpr int kR32Depth = NUS_R32_DEPTH;
 
 #pragma clang diagnostic push
@@ -108,9 +111,8 @@ struct R32Store {
 // lane exchange (3 columns from each neighbour) and the horizontal pass of the lane's 6 output pixels (2 input pairs x 3
 // phases; output 3 m + p reads the columns e[2 m + p] .. e[2 m + p + 5], e[3] is the lane's own first column), convert +
 // pack; then the row's turn through LDS and its two stores.  Channel by channel so that only 4 vertical sums are live.
-// WV: VGPR weights (interior rows) or a scalar pointer into the table (rows whose window is cut by the top / bottom border).
-template <bool EXACT, int B, typename WV>
-__device__ __forceinline__ void r32_row(const float (&win)[6][16], const WV &wv, const float (&W)[3][6], __amdgpu_buffer_rsrc_t rs,
+template <bool EXACT, int B>
+__device__ __forceinline__ void r32_row(const float (&win)[6][16], const float (&wv)[6], const float (&W)[3][6], __amdgpu_buffer_rsrc_t rs,
                                         const R32Store &st, uint32_t row_off, bool skip_alpha)
 {
     // skip_alpha (FMA mode, wave-uniform): the six tap rows are opaque in this wave, so alpha is the constant
@@ -126,7 +128,7 @@ __device__ __forceinline__ void r32_row(const float (&win)[6][16], const WV &wv,
         for (int m = 0; m < 4; ++m) {
             float acc = win[B % 6][m * 4 + c] * wv[0]; // == fma(.., 0) and a VOP2 instruction
 #pragma unroll
-            for (int j = 1; j < 6; ++j) acc = mac_tight<EXACT>(acc, win[(B + j) % 6][m * 4 + c], wv[j]);
+            for (int j = 1; j < 6; ++j) acc = mac_tight<EXACT, NUS_R32_PIN_FMA != 0>(acc, win[(B + j) % 6][m * 4 + c], wv[j]);
             v[m] = acc;
         }
         float e[10]; // vertical sums of input columns c0-3 .. c0+6 for this channel
@@ -146,7 +148,7 @@ __device__ __forceinline__ void r32_row(const float (&win)[6][16], const WV &wv,
             for (int p = 0; p < 3; ++p) {
                 float a = e[2 * m + p] * W[p][0];
 #pragma unroll
-                for (int j = 1; j < 6; ++j) a = mac_tight<EXACT>(a, e[2 * m + p + j], W[p][j]);
+                for (int j = 1; j < 6; ++j) a = mac_tight<EXACT, NUS_R32_PIN_FMA != 0>(a, e[2 * m + p + j], W[p][j]);
                 o[3 * m + p] = pack_u8<EXACT>(a, c, o[3 * m + p]);
             }
         }
@@ -169,7 +171,8 @@ __device__ __forceinline__ void r32_row(const float (&win)[6][16], const WV &wv,
 }
 
 // Vertical weights of the current row pair's class: 18 numbers that change a few times per frame, kept in SGPRs; each
-// phase copies its six into VGPRs (a scalar operand halves an FMA's issue rate; 18 more VGPRs would cost the third wave).
+// phase copies its six into VGPRs (a scalar operand halves an FMA's issue rate; all 18 resident in VGPRs: 163 instead of 145
+// registers and no faster, profiles/r03_lanczos_r32_rework_ab.txt).
 struct R32RowWeights {
     float w[3][6];
     uint32_t cls;
@@ -184,17 +187,82 @@ struct R32RowWeights {
 // for it at the END of phase 0: the rest of that step (5), D-1 whole steps (8 each), this step's first stores (2):
 // N = 8 D - 1; waiting at the START of the phase: N = 8 D - 3.  The same two numbers hold for row r+4 around phase 1
 // (2 + 8 (D - 1) + 5 and 2 + 8 (D - 1) + 3).  Either request is the 2 D-th most recent one when it is waited for.
-template <bool EXACT, int S>
-__device__ __forceinline__ void r32_step(float (&win)[6][16], const R32Ring &ring, uint32_t &pos, int r, uint32_t in_off,
-                                         const R32Store &st, const LanczosR32Args &A, const float (&W)[3][6], R32RowWeights &RW,
-                                         const uint8_t *src, __amdgpu_buffer_rsrc_t rs, uint32_t &opaque)
+struct R32StepCtx {
+    const LanczosR32Args &A;
+    const R32Ring &ring;
+    const R32Store &st;
+    const uint8_t *src;
+    __amdgpu_buffer_rsrc_t rs;
+    uint32_t in_off;
+};
+
+// phase P of a step (see r32_step): output row 3 r / 2 + P from the window slots S+P .. S+P+5, then (P < 2) row r+3+P in
+template <bool EXACT, int S, int P>
+__device__ __forceinline__ void r32_phase(float (&win)[6][16], const R32StepCtx &C, uint32_t pos, int r, bool interior,
+                                          const float (&W)[3][6], const R32RowWeights &RW, uint32_t &opaque)
 {
     typedef const __attribute__((address_space(4))) float *cfloat_p;
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
     constexpr int D = kR32Depth;
     constexpr bool EARLY = NUS_R32_WAIT_EARLY != 0;
+    const LanczosR32Args &A = C.A;
+    const uint32_t row_bytes = A.iw * 6; // one output row: 1.5 iw pixels
+    const uint32_t oy = 3u * (uint32_t)(r >> 1) + (uint32_t)P;
+    u32x4 next = {0u, 0u, 0u, 0u};
+    const uint32_t slot = pos + (uint32_t)P * 1024u; // P < 2: the ring slot of row r+3+P
+    if (P < 2 && EARLY) {
+        r32_wait_vmcnt<8 * D - 3, 2 * D>();
+        next = *reinterpret_cast<const u32x4 *>(C.ring.base + slot + 16 * C.ring.lane);
+    }
+    const bool skip_alpha = !EXACT && (opaque & 0x3Fu) == 0x3Fu; // bit j: the row j before the newest is opaque
+    // vertical weights of this output row: the class's (SGPRs) or, next to the top / bottom border where the window is cut and
+    // renormalised, the row's own from the table; one copy of the row's code either way, its stores on every path
+    float wv[6];
+    {
+        float ws[6];
+        if (interior) {
+#pragma unroll
+            for (int j = 0; j < 6; ++j) ws[j] = RW.w[P][j];
+        } else {
+            cfloat_p wt = (cfloat_p)(uintptr_t)(A.wy6 + (size_t)__builtin_amdgcn_readfirstlane(oy) * 6);
+#pragma unroll
+            for (int j = 0; j < 6; ++j) ws[j] = wt[j];
+        }
+#pragma unroll
+        for (int j = 0; j < 6; ++j) wv[j] = r32_vgpr(ws[j]);
+    }
+    r32_row<EXACT, S + P>(win, wv, W, C.rs, C.st, oy * row_bytes, skip_alpha);
+    if (P < 2) {
+        // the oldest row out, row r+3+P in; then request row r+3+P+2D into the same ring slot
+        if (!EARLY) {
+            r32_wait_vmcnt<8 * D - 1, 2 * D>();
+            next = *reinterpret_cast<const u32x4 *>(C.ring.base + slot + 16 * C.ring.lane);
+        }
+        {
+            const uint4 px = swz4(make_uint4(next.x, next.y, next.z, next.w), A.sel);
+            if (!EXACT) opaque = (opaque << 1) | r32_row_is_opaque(px);
+            r32_cvt_row(px, win[(S + P) % 6]);
+        }
+        int rn = r + 3 + P + 2 * D;
+        rn = rn < (int)A.ih - 1 ? rn : (int)A.ih - 1;
+        // the slot is requested again only when its read has RETURNED (the converted row is an operand of this empty
+        // statement): nothing orders a queued ds_read behind a later LDS-DMA write (see the x2 kernel)
+        asm volatile("" : : "v"(win[(S + P) % 6][0]), "v"(win[(S + P) % 6][15]) : "memory");
+        r32_dma_row16(C.src, C.in_off + (uint32_t)rn * (A.iw * 4), C.ring.lds + slot);
+    }
+}
+
+template <bool EXACT, int S>
+__device__ __forceinline__ void r32_step(float (&win)[6][16], const R32StepCtx &C, uint32_t &pos, int r, const float (&W)[3][6],
+                                         R32RowWeights &RW, uint32_t &opaque)
+{
+    typedef const __attribute__((address_space(4))) float *cfloat_p;
+    const LanczosR32Args &A = C.A;
     {
         // vertical weights of this row pair's class, reloaded when the class changes
-        const uint32_t cy = __builtin_amdgcn_readfirstlane(A.cls_y[r >> 1]);
+        // (a scalar load: a vector load here would make the compiler wait for vmcnt(0) -- every store of the wave -- once per step)
+        typedef const __attribute__((address_space(4))) uint32_t *cu32_p;
+        const uint32_t cy = ((cu32_p)(uintptr_t)A.cls_y)[r >> 1];
         if (cy != RW.cls) { // wave-uniform
             RW.cls = cy;
             cfloat_p wt = (cfloat_p)(uintptr_t)(A.wcls_y + (size_t)cy * 18);
@@ -204,48 +272,11 @@ __device__ __forceinline__ void r32_step(float (&win)[6][16], const R32Ring &rin
                 for (int j = 0; j < 6; ++j) RW.w[p][j] = wt[p * 6 + j];
         }
     }
-    const uint32_t row_bytes = A.iw * 6; // one output row: 1.5 iw pixels
-    const uint32_t oy0 = 3u * (uint32_t)(r >> 1);
     const bool interior = r >= 4 && r + 6 <= (int)A.ih; // wave-uniform: rows r-3 .. r+4 exist and the pair is not a border pair
-    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-#pragma unroll
-    for (int p = 0; p < 3; ++p) {
-        u32x4 next;
-        const uint32_t slot = pos + (uint32_t)p * 1024u; // p < 2: the ring slot of row r+3+p
-        if (p < 2 && EARLY) {
-            r32_wait_vmcnt<8 * D - 3, 2 * D>();
-            next = *reinterpret_cast<const u32x4 *>(ring.base + slot + 16 * ring.lane);
-        }
-        const bool skip_alpha = !EXACT && (opaque & 0x3Fu) == 0x3Fu; // bit j: the row j before the newest is opaque
-        if (interior) {
-            float wv[6];
-#pragma unroll
-            for (int j = 0; j < 6; ++j) wv[j] = r32_vgpr(RW.w[p][j]);
-            r32_row<EXACT, S + p>(win, wv, W, rs, st, (oy0 + (uint32_t)p) * row_bytes, skip_alpha);
-        } else {
-            cfloat_p wt = (cfloat_p)(uintptr_t)(A.wy6 + (size_t)__builtin_amdgcn_readfirstlane(oy0 + (uint32_t)p) * 6);
-            r32_row<EXACT, S + p>(win, wt, W, rs, st, (oy0 + (uint32_t)p) * row_bytes, skip_alpha);
-        }
-        if (p < 2) {
-            // the oldest row out, row r+3+p in; then request row r+3+p+2D into the same ring slot
-            if (!EARLY) {
-                r32_wait_vmcnt<8 * D - 1, 2 * D>();
-                next = *reinterpret_cast<const u32x4 *>(ring.base + slot + 16 * ring.lane);
-            }
-            {
-                const uint4 px = swz4(make_uint4(next.x, next.y, next.z, next.w), A.sel);
-                if (!EXACT) opaque = (opaque << 1) | r32_row_is_opaque(px);
-                r32_cvt_row(px, win[(S + p) % 6]);
-            }
-            int rn = r + 3 + p + 2 * D;
-            rn = rn < (int)A.ih - 1 ? rn : (int)A.ih - 1;
-            // the slot is requested again only when its read has RETURNED (the converted row is an operand of this empty
-            // statement): nothing orders a queued ds_read behind a later LDS-DMA write (see the x2 kernel)
-            asm volatile("" : : "v"(win[(S + p) % 6][0]), "v"(win[(S + p) % 6][15]) : "memory");
-            r32_dma_row16(src, in_off + (uint32_t)rn * (A.iw * 4), ring.lds + slot);
-        }
-    }
-    pos = pos + 2048u == (uint32_t)(2 * D) * 1024u ? 0u : pos + 2048u;
+    r32_phase<EXACT, S, 0>(win, C, pos, r, interior, W, RW, opaque);
+    r32_phase<EXACT, S, 1>(win, C, pos, r, interior, W, RW, opaque);
+    r32_phase<EXACT, S, 2>(win, C, pos, r, interior, W, RW, opaque);
+    pos = pos + 2048u == (uint32_t)(2 * kR32Depth) * 1024u ? 0u : pos + 2048u;
 }
 
 // One wave loads a strip of 256 input columns (4 per lane; lanes 2 .. 61 produce the strip's 240 input = 360 output
@@ -313,11 +344,14 @@ __global__ __launch_bounds__(256) void k_lanczos3_r32(const LanczosR32Args A)
     {
         // the lane's two column pairs share a class (host-checked); lanes that do not store take class 0
         const uint32_t cx = c >= 8 && c + 12 <= (int)A.iw ? A.cls_x[c >> 1] : 0u;
+        float w18[18];
+#pragma unroll
+        for (int i = 0; i < 18; ++i) w18[i] = A.wcls_x[(size_t)cx * 18 + i]; // all in flight together
 #pragma unroll
         for (int p = 0; p < 3; ++p)
 #pragma unroll
             for (int j = 0; j < 6; ++j) {
-                W[p][j] = r32_vgpr(A.wcls_x[(size_t)cx * 18 + p * 6 + j]); // VGPR copy: scalar operands halve the VALU issue rate
+                W[p][j] = r32_vgpr(w18[p * 6 + j]); // VGPR copy: scalar operands halve the VALU issue rate
                 RW.w[p][j] = 0.0f;
             }
     }
@@ -340,12 +374,13 @@ __global__ __launch_bounds__(256) void k_lanczos3_r32(const LanczosR32Args A)
         r32_wait_vmcnt<0, 0>();
     }
     uint32_t pos = 0;
+    const R32StepCtx C = {A, ring, st, src, rs, in_off};
     for (int rbase = r0; rbase < r_end; rbase += 6) {
         // 3 steps unrolled so the rotating window indices are compile-time constants.  The block leaves the loop after its
         // last row pair: a step is never skipped with a later one still to run, so every path through the loop carries the
         // vector memory instructions the hand-counted waits assume.
 #define NUS_R32_STEP(S) \
-        r32_step<EXACT, S>(win, ring, pos, rbase + S, in_off, st, A, W, RW, src, rs, opaque); \
+        r32_step<EXACT, S>(win, C, pos, rbase + S, W, RW, opaque); \
         if (S < 4 && rbase + S + 2 >= r_end) break
         NUS_R32_STEP(0);
         NUS_R32_STEP(2);

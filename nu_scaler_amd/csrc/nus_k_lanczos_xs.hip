@@ -42,6 +42,61 @@ struct LanczosXsArgs {
 };
 
 
+// Row prefetches: as in nus_k_lanczos_x2.hip / nus_k_lanczos_r32.hip the rows are requested with LDS-DMA loads issued from
+// inline assembly (16 B per lane straight into a per-wave 1-KiB LDS slot, invisible to the compiler's s_waitcnt insertion)
+// and waited for with hand-counted `s_waitcnt vmcnt(N)`; tools/check_hidden_loads.py verifies the counts on the generated
+// code (tests/test_kernel_asm.py).
+#ifndef NUS_XS_DEPTH
+#define NUS_XS_DEPTH 2 // prefetch distance in steps (a step = one input row = one request, S x S stores)
+#endif
+#ifndef NUS_XS_WAIT_EARLY
+#define NUS_XS_WAIT_EARLY 1 // 1: wait + LDS read at the start of the step; 0: where the row is converted
+#endif
+#ifndef NUS_XS_PIN_FMA
+#define NUS_XS_PIN_FMA 1 // FMA mode: the fused operations pinned in program order
+#endif
+#ifndef NUS_XS_S4_WAVES
+#define NUS_XS_S4_WAVES 2 // waves per SIMD the x4 FMA-mode kernel is compiled for: 185 VGPRs.  (3: 168 and 13 spilled dwords, whose
+                          // reloads bring vmcnt waits -- drains of the wave's stores -- back into the loop: 10.1 - 11.5 against 8.7 - 9.7 us
+                          // per 540p -> 4K frame, profiles/r03_lanczos_xs_rework_ab.txt)
+#endif
+constexpr int kXsDepth = NUS_XS_DEPTH;
+
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm" // m0 is a reserved register: nothing else in this kernel uses it
+__device__ __forceinline__ void xs_dma_row16(const uint8_t *base, uint32_t off, uint32_t lds)
+{
+    asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(off), "s"(base), "s"(lds) : "memory", "m0");
+}
+#pragma clang diagnostic pop
+
+// at most N vector memory instructions outstanding; BACK (for the checker): the BACK-th most recent request has landed
+template <int N, int BACK>
+__device__ __forceinline__ void xs_wait_vmcnt()
+{
+    static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit counter on gfx9");
+    asm volatile("s_waitcnt vmcnt(%0) ; nus-wait back=%1" : : "n"(N), "n"(BACK) : "memory");
+}
+
+struct XsRing {
+    const uint8_t *base; // this wave's kXsDepth slots of one row (64 lanes x 16 B) as a generic pointer (reads)
+    uint32_t lds;        // their byte offset in LDS (wave-uniform; requests)
+    int lane;
+};
+
+__device__ __forceinline__ float xs_vgpr(float s)
+{
+    asm volatile("" : "+v"(s));
+    return s;
+}
+
+template <bool EXACT>
+__device__ __forceinline__ float xs_mac(float acc, float v, float w)
+{
+    if (EXACT) return mac<true>(acc, v, w); // (this kernel is faster with the compiler's batches of products, nus_device.hpp)
+    return mac_tight<false, NUS_XS_PIN_FMA != 0>(acc, v, w);
+}
+
 __device__ __forceinline__ void cvt_row(const uint4 raw, float (&dst)[16])
 {
     const uint32_t px[4] = {raw.x, raw.y, raw.z, raw.w};
@@ -58,24 +113,6 @@ __device__ __forceinline__ uint32_t xs_row_is_opaque(const uint4 px)
     return __builtin_amdgcn_ballot_w64(!lane_opaque) == 0ull ? 1u : 0u;
 }
 
-// Vertical pass of one output row: 6 taps from the window rows 0 .. 5.  W: VGPR weights (interior rows)
-// or a scalar pointer into the table (rows whose window is cut by the top / bottom border).
-template <bool EXACT, typename W>
-__device__ __forceinline__ void xs_vpass(const float (&win)[6][16], const W &w, float (&V)[16], bool skip_alpha)
-{
-#pragma unroll
-    for (int k = 0; k < 16; ++k) {
-        if ((k & 3) == 3 && skip_alpha) continue; // wave-uniform; V[alpha] is then not read
-        float acc = win[0][k] * w[0]; // == fma(.., 0) and a VOP2 instruction
-#pragma unroll
-        for (int j = 1; j < 6; ++j) acc = mac<EXACT>(acc, win[j][k], w[j]);
-        V[k] = acc;
-    }
-}
-
-// Horizontal pass of one output row: the lane's 4 S output pixels (4 input columns x S phases),
-// convert + pack, S 16-B stores.  Output pixel S m + p reads frame columns m + delta_p .. m + delta_p + 5
-// of e[] (e[3] is the lane's own first column).
 // Where a wave's output row goes: as in the x2 kernel (RowStore there) the row's S KiB are turned round in LDS --
 // every lane writes the 16 S bytes it computed at 16 S * lane, then reads 16 B at 1024 q + 16 * lane for store q --
 // so that each store instruction writes one contiguous KiB instead of a 16-B piece of every 16 S bytes
@@ -87,9 +124,13 @@ struct XsStore {
     int lane;
 };
 
+// One output row: per channel the vertical pass of the lane's 4 columns (6 taps, window rows 0 .. 5), the lane exchange
+// (3 columns from each neighbour) and the horizontal pass of the lane's 4 S output pixels (output S m + p reads frame
+// columns m + delta_p .. m + delta_p + 5 of e[], e[3] is the lane's own first column), convert + pack; then the row's turn
+// through LDS and its S stores.  Channel by channel so that only 4 vertical sums are live.
 template <bool EXACT, int S>
-__device__ __forceinline__ void xs_hpass_store(const float (&V)[16], const float (&W)[S][6],
-                                               __amdgpu_buffer_rsrc_t rs, const XsStore<S> &st, uint32_t row_off, bool skip_alpha)
+__device__ __forceinline__ void xs_row(const float (&win)[6][16], const float (&wv)[6], const float (&W)[S][6],
+                                       __amdgpu_buffer_rsrc_t rs, const XsStore<S> &st, uint32_t row_off, bool skip_alpha)
 {
     // skip_alpha (FMA mode, wave-uniform): the six tap rows are opaque in this wave, so alpha is the constant
     // 255 (see row_is_opaque in nus_k_lanczos_x2.hip); v_cvt_pk_u8_f32 only ever replaces bytes 0..2 then
@@ -99,29 +140,38 @@ __device__ __forceinline__ void xs_hpass_store(const float (&V)[16], const float
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
         if (c == 3 && skip_alpha) continue;
+        float v[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            float acc = win[0][m * 4 + c] * wv[0]; // == fma(.., 0) and a VOP2 instruction
+#pragma unroll
+            for (int j = 1; j < 6; ++j) acc = xs_mac<EXACT>(acc, win[j][m * 4 + c], wv[j]);
+            v[m] = acc;
+        }
         float e[10]; // vertical sums of input columns c0-3 .. c0+6 for this channel
-        e[0] = wave_up(V[1 * 4 + c]);
-        e[1] = wave_up(V[2 * 4 + c]);
-        e[2] = wave_up(V[3 * 4 + c]);
-        e[3] = V[0 * 4 + c];
-        e[4] = V[1 * 4 + c];
-        e[5] = V[2 * 4 + c];
-        e[6] = V[3 * 4 + c];
-        e[7] = wave_down(V[0 * 4 + c]);
-        e[8] = wave_down(V[1 * 4 + c]);
-        e[9] = wave_down(V[2 * 4 + c]);
+        e[0] = wave_up(v[1]);
+        e[1] = wave_up(v[2]);
+        e[2] = wave_up(v[3]);
+        e[3] = v[0];
+        e[4] = v[1];
+        e[5] = v[2];
+        e[6] = v[3];
+        e[7] = wave_down(v[0]);
+        e[8] = wave_down(v[1]);
+        e[9] = wave_down(v[2]);
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
 #pragma unroll
             for (int p = 0; p < S; ++p) {
                 float a = e[m + (xs_delta(S, p) ? 1 : 0)] * W[p][0];
 #pragma unroll
-                for (int j = 1; j < 6; ++j) a = mac<EXACT>(a, e[m + (xs_delta(S, p) ? 1 : 0) + j], W[p][j]);
+                for (int j = 1; j < 6; ++j) a = xs_mac<EXACT>(a, e[m + (xs_delta(S, p) ? 1 : 0) + j], W[p][j]);
                 o[S * m + p] = pack_u8<EXACT>(a, c, o[S * m + p]);
             }
         }
     }
-    // range-checked buffer stores: pieces that must not be written sit beyond num_records (see the x2 kernel)
+    // range-checked buffer stores: pieces that must not be written sit beyond num_records (see the x2 kernel), so all S
+    // stores issue on every path and for every lane -- the hand-counted waits rely on exactly S per output row
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 #pragma unroll
     for (int q = 0; q < S; ++q) st.stage[S * st.lane + q] = make_uint4(o[4 * q], o[4 * q + 1], o[4 * q + 2], o[4 * q + 3]);
@@ -135,35 +185,56 @@ __device__ __forceinline__ void xs_hpass_store(const float (&V)[16], const float
     __builtin_amdgcn_wave_barrier();
 }
 
-// One input row r -> output rows S r .. S r + S - 1.  At entry window row j holds input row r-3+j,
-// raw0 / raw1 hold rows r+3 / r+4.  Unlike the x2 kernel the window is shifted, not rotated: one copy of
-// the step's code instead of six (at S = 4 six copies are ~16k instructions, more than the instruction
-// cache), for 80 register moves per step that is 3 % of its work.
+// CLS: vertical weights of the current row's class, S x 6 numbers that change a few times per frame, kept in SGPRs; each
+// output row copies its six into VGPRs (a scalar operand halves an FMA's issue rate).  Without classes the interior vertical
+// weights are the horizontal ones (W, already in VGPRs).
+template <int S>
+struct XsRowWeights {
+    float w[S][6];
+    uint32_t cls;
+};
+
+// One input row r -> output rows S r .. S r + S - 1.  At entry window row j holds input row r-3+j and ring slot `pos` holds
+// row r+3 (requested kXsDepth steps ago).  Unlike the x2 kernel the window is shifted, not rotated: one copy of the step's
+// code instead of six (at S = 4 six copies are ~16k instructions, more than the instruction cache), for 80 register moves
+// per step that is 3 - 5 % of its work.
+//
+// Vector memory instructions of a step, in issue order and on every path: n0 S stores (the n0 = 2 phases whose frame is
+// rows r-3 .. r+2), the request of row r+3+D, (S - n0) S stores (the phases whose frame is rows r-2 .. r+3).  Issued since the
+// request of row r+3 when the wave waits for it where it is converted: the rest of that step ((S - n0) S), D-1 whole
+// steps (S S + 1 each), this step's first stores (n0 S): N = D (S S + 1) - 1; at the START of the step: N - n0 S.
 template <bool EXACT, int S, bool CLS>
-__device__ __forceinline__ void xs_step(float (&win)[6][16], uint4 &raw0, uint4 &raw1, int r, int cl, const XsStore<S> &st,
-                                        const LanczosXsArgs &A, const float (&W)[S][6], float (&Wv)[S][6], uint32_t &row_cls,
+__device__ __forceinline__ void xs_step(float (&win)[6][16], const XsRing &ring, uint32_t &pos, int r, uint32_t in_off,
+                                        const XsStore<S> &st, const LanczosXsArgs &A, const float (&W)[S][6], XsRowWeights<S> &RW,
                                         const uint8_t *src, __amdgpu_buffer_rsrc_t rs, uint32_t &opaque)
 {
     typedef const __attribute__((address_space(4))) float *cfloat_p;
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    constexpr int D = kXsDepth, N0 = 2;
+    static_assert(xs_delta(S, 0) == false && xs_delta(S, 1) == false && xs_delta(S, 2) == true, "two phases before the window moves");
+    constexpr bool EARLY = NUS_XS_WAIT_EARLY != 0;
     if (CLS) {
-        // vertical weights of this row's class: VGPR copies, reloaded when the class changes (a few times per frame)
-        const uint32_t cy = __builtin_amdgcn_readfirstlane(A.cls_y[r < 0 ? 0 : r]);
-        if (cy != row_cls) { // wave-uniform
-            row_cls = cy;
+        // vertical weights of this row's class, reloaded when the class changes (a scalar load: a vector load here would make
+        // the compiler wait for vmcnt(0) -- every store of the wave -- once per step)
+        typedef const __attribute__((address_space(4))) uint32_t *cu32_p;
+        const uint32_t cy = ((cu32_p)(uintptr_t)A.cls_y)[r < 0 ? 0 : r];
+        if (cy != RW.cls) { // wave-uniform
+            RW.cls = cy;
             cfloat_p wt = (cfloat_p)(uintptr_t)(A.wcls_y + (size_t)cy * (S * 6));
 #pragma unroll
             for (int p = 0; p < S; ++p)
 #pragma unroll
-                for (int j = 0; j < 6; ++j) {
-                    Wv[p][j] = wt[p * 6 + j];
-                    asm volatile("" : "+v"(Wv[p][j]));
-                }
+                for (int j = 0; j < 6; ++j) RW.w[p][j] = wt[p * 6 + j];
         }
     }
     const uint32_t row_bytes = A.iw * 4 * S; // one output row
     const uint32_t off0 = (uint32_t)(S * r) * row_bytes;
     const bool interior = r >= 4 && r + 5 <= (int)A.ih; // wave-uniform
-    float V[16];
+    u32x4 next = {0u, 0u, 0u, 0u};
+    if (EARLY) {
+        xs_wait_vmcnt<D * (S * S + 1) - 1 - N0 * S, D>();
+        next = *reinterpret_cast<const u32x4 *>(ring.base + pos + 16 * ring.lane);
+    }
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
         // half 0: phases whose frame is rows r-3 .. r+2; half 1 (after the shift): rows r-2 .. r+3
@@ -171,37 +242,63 @@ __device__ __forceinline__ void xs_step(float (&win)[6][16], uint4 &raw0, uint4 
         for (int p = 0; p < S; ++p) {
             if (xs_delta(S, p) != (half == 1)) continue;
             const bool skip_alpha = !EXACT && (opaque & 0x3Fu) == 0x3Fu; // bit j: window row 5-j is opaque
-            if (interior) {
-                xs_vpass<EXACT>(win, CLS ? Wv[p] : W[p], V, skip_alpha);
+            // vertical weights of this output row: the interior ones or, next to the top / bottom border where the window is cut
+            // and renormalised, the row's own from the table; one copy of the row's code either way, its stores on every path
+            float wv[6];
+            if (CLS) {
+                float ws[6];
+                if (interior) {
+#pragma unroll
+                    for (int j = 0; j < 6; ++j) ws[j] = RW.w[p][j];
+                } else {
+                    cfloat_p wt = (cfloat_p)(uintptr_t)(A.wy6 + (size_t)__builtin_amdgcn_readfirstlane((uint32_t)(S * r + p)) * 6);
+#pragma unroll
+                    for (int j = 0; j < 6; ++j) ws[j] = wt[j];
+                }
+#pragma unroll
+                for (int j = 0; j < 6; ++j) wv[j] = xs_vgpr(ws[j]);
             } else {
-                cfloat_p wt = (cfloat_p)(uintptr_t)(A.wy6 + (size_t)__builtin_amdgcn_readfirstlane((uint32_t)(S * r + p)) * 6);
-                xs_vpass<EXACT>(win, wt, V, skip_alpha);
+                if (interior) {
+#pragma unroll
+                    for (int j = 0; j < 6; ++j) wv[j] = W[p][j];
+                } else {
+                    cfloat_p wt = (cfloat_p)(uintptr_t)(A.wy6 + (size_t)__builtin_amdgcn_readfirstlane((uint32_t)(S * r + p)) * 6);
+#pragma unroll
+                    for (int j = 0; j < 6; ++j) wv[j] = xs_vgpr(wt[j]);
+                }
             }
-            xs_hpass_store<EXACT, S>(V, W, rs, st, off0 + (uint32_t)p * row_bytes, skip_alpha);
+            xs_row<EXACT, S>(win, wv, W, rs, st, off0 + (uint32_t)p * row_bytes, skip_alpha);
         }
         if (half == 0) {
-            // row r-3 out, row r+3 in; then request row r+5
+            // row r-3 out, row r+3 in; then request row r+3+D into the same ring slot
+            if (!EARLY) {
+                xs_wait_vmcnt<D * (S * S + 1) - 1, D>();
+                next = *reinterpret_cast<const u32x4 *>(ring.base + pos + 16 * ring.lane);
+            }
 #pragma unroll
             for (int j = 0; j < 5; ++j)
 #pragma unroll
                 for (int k = 0; k < 16; ++k) win[j][k] = win[j + 1][k];
             {
-                const uint4 px = swz4(raw0, A.sel);
+                const uint4 px = swz4(make_uint4(next.x, next.y, next.z, next.w), A.sel);
                 if (!EXACT) opaque = (opaque << 1) | xs_row_is_opaque(px);
                 cvt_row(px, win[5]);
             }
-            raw0 = raw1;
-            int rn = r + 5;
+            int rn = r + 3 + D;
             rn = rn < (int)A.ih - 1 ? rn : (int)A.ih - 1;
-            raw1 = *reinterpret_cast<const uint4 *>(src + ((size_t)rn * A.iw + cl) * 4);
+            // the slot is requested again only when its read has RETURNED (the converted row is an operand of this empty
+            // statement): nothing orders a queued ds_read behind a later LDS-DMA write (see the x2 kernel)
+            asm volatile("" : : "v"(win[5][0]), "v"(win[5][15]) : "memory");
+            xs_dma_row16(src, in_off + (uint32_t)rn * (A.iw * 4), ring.lds + pos);
         }
     }
+    pos = pos + 1024u == (uint32_t)D * 1024u ? 0u : pos + 1024u;
 }
 
 // One wave loads a strip of 256 input columns (4 per lane; lanes 1 .. 60 produce the strip's 240 input = 240 S output
 // columns, lanes 0 and 61 are their halo) and walks `th` input rows with a 6-row f32 window.
 template <bool EXACT, int S, bool CLS>
-__global__ __launch_bounds__(256) void k_lanczos3_xs(const LanczosXsArgs A)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EXACT ? 1 : (S == 4 ? NUS_XS_S4_WAVES : 3)))) void k_lanczos3_xs(const LanczosXsArgs A)
 {
     const int lane = threadIdx.x & (kWave - 1);
     // each XCD gets a contiguous run of (frame, row block, strips), as in the x2 kernel
@@ -223,9 +320,16 @@ __global__ __launch_bounds__(256) void k_lanczos3_xs(const LanczosXsArgs A)
         const int cc = (int)(strip * kLanczosX2StripCols) - 4 + L * 4;
         return L >= 1 && L <= (int)(kLanczosX2StripCols / 4) && cc >= 4 && cc + 8 <= (int)A.iw;
     };
+    // (the rings come first in the block's LDS: an LDS-DMA slot address is M0 + a 12-bit instruction offset of 0)
+    __shared__ uint4 lds_rows[4][kXsDepth][64];
     __shared__ uint4 lds_stage[4][64 * S];
+    const uint32_t w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    XsRing ring;
+    ring.base = reinterpret_cast<const uint8_t *>(&lds_rows[w][0][0]);
+    ring.lds = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)&lds_rows[w][0][0]);
+    ring.lane = lane;
     XsStore<S> st;
-    st.stage = lds_stage[__builtin_amdgcn_readfirstlane(threadIdx.x >> 6)];
+    st.stage = lds_stage[w];
     st.lane = lane;
     {
         const int span0 = ((int)(strip * kLanczosX2StripCols) - 4) * 4 * S; // byte offset of the wave's span in an output row
@@ -233,38 +337,52 @@ __global__ __launch_bounds__(256) void k_lanczos3_xs(const LanczosXsArgs A)
         for (int q = 0; q < S; ++q)
             st.off[q] = computes_stored_pixels((64 * q + lane) / S) ? (uint32_t)(span0 + 1024 * q + 16 * lane) : 0x80000000u;
     }
+    const uint32_t in_off = (uint32_t)cl * 4u; // the lane's byte offset inside an input row
     const int r0 = (int)(rb * A.th);
     const int r_end = (r0 + (int)A.th) < (int)A.ih ? (r0 + (int)A.th) : (int)A.ih;
     const int rmax = (int)A.ih - 1;
-    auto load_row = [&](int rr) {
+    auto row_off = [&](int rr) {
         rr = rr < 0 ? 0 : (rr > rmax ? rmax : rr);
-        return *reinterpret_cast<const uint4 *>(src + ((size_t)rr * A.iw + cl) * 4);
+        return in_off + (uint32_t)rr * (A.iw * 4);
     };
 
-    float W[S][6], Wv[S][6];
-    uint32_t row_cls = 0xffffffffu;
+    float W[S][6];
+    XsRowWeights<S> RW;
+    RW.cls = 0xffffffffu;
     {
         // CLS: the lane's 4 columns share a class (host-checked); lanes that do not store take class 0
         const uint32_t cx = CLS && c >= 4 && c + 8 <= (int)A.iw ? A.cls_x[c] : 0u;
+        float w0[S * 6];
+#pragma unroll
+        for (int i = 0; i < S * 6; ++i) w0[i] = CLS ? A.wcls_x[(size_t)cx * (S * 6) + i] : A.w[i / 6][i % 6]; // all in flight together
 #pragma unroll
         for (int p = 0; p < S; ++p)
 #pragma unroll
             for (int j = 0; j < 6; ++j) {
-                W[p][j] = CLS ? A.wcls_x[(size_t)cx * (S * 6) + p * 6 + j] : A.w[p][j];
-                asm volatile("" : "+v"(W[p][j])); // VGPR copy: scalar operands halve the VALU issue rate
-                Wv[p][j] = 0.0f;
+                W[p][j] = xs_vgpr(w0[p * 6 + j]); // VGPR copy: scalar operands halve the VALU issue rate
+                RW.w[p][j] = 0.0f;
             }
     }
     float win[6][16];
     uint32_t opaque = 0;
+    {
+        // the six rows of the first window (ordinary loads, all in flight together), then the first requests
+        uint4 first[6];
 #pragma unroll
-    for (int j = 0; j < 6; ++j) {
-        const uint4 px = swz4(load_row(r0 - 3 + j), A.sel);
-        if (!EXACT) opaque = (opaque << 1) | xs_row_is_opaque(px);
-        cvt_row(px, win[j]);
+        for (int j = 0; j < 6; ++j) first[j] = *reinterpret_cast<const uint4 *>(src + row_off(r0 - 3 + j));
+#pragma unroll
+        for (int j = 0; j < kXsDepth; ++j) xs_dma_row16(src, row_off(r0 + 3 + j), ring.lds + (uint32_t)j * 1024u);
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            const uint4 px = swz4(first[j], A.sel);
+            if (!EXACT) opaque = (opaque << 1) | xs_row_is_opaque(px);
+            cvt_row(px, win[j]);
+        }
+        // the hand-counted waits of the loop assume that nothing older than its own instructions is outstanding
+        xs_wait_vmcnt<0, 0>();
     }
-    uint4 raw0 = load_row(r0 + 3), raw1 = load_row(r0 + 4);
-    for (int r = r0; r < r_end; ++r) xs_step<EXACT, S, CLS>(win, raw0, raw1, r, cl, st, A, W, Wv, row_cls, src, rs, opaque);
+    uint32_t pos = 0;
+    for (int r = r0; r < r_end; ++r) xs_step<EXACT, S, CLS>(win, ring, pos, r, in_off, st, A, W, RW, src, rs, opaque);
 }
 
 // The 4 S left-most and right-most output columns (tap windows cut by the image border, weights

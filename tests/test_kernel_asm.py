@@ -49,6 +49,46 @@ def test_hand_counted_waits_of_every_instantiation(kernel_asm):
         assert r["hand_waits"] == 7, (name, r["hand_waits"])
 
 
+def test_lanczos_r32_row_ring_waits():
+    """k_lanczos3_r32 (x3/2: 720p -> 1080p, 1440p -> 4K) carries the same scheme: two row requests and six stores per step of two
+    input rows, one hand-counted wait per request, tight on every path; nothing else waits on vmcnt inside its loop (the row
+    pair's weight class is read with a scalar load for that reason)."""
+    import check_hidden_loads as chk
+
+    out = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-x", "hip",
+                          "--cuda-device-only", "-S", "-I", CSRC, "-I", os.path.join(ROOT, "include"), "-o", "-",
+                          os.path.join(CSRC, "nus_k_lanczos_r32.hip")], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr
+    bodies = list(chk.kernel_bodies(out.stdout, "k_lanczos3_r32IL"))
+    assert len(bodies) == 2, [n for n, _ in bodies]  # EXACT, FMA
+    for name, body in bodies:
+        r = chk.check(body)
+        assert r["errors"] == [], (name, r["errors"][:3])
+        assert r["compiler_vmcnt_waits_in_loops"] == [], (name, r["compiler_vmcnt_waits_in_loops"][:3])
+        assert r["waits_not_tight"] == {}, (name, r["waits_not_tight"])
+        # 3 unrolled steps x 2 requests + the first 2 D of a block; one hand wait per request + the drain at loop entry
+        assert r["requests"] == 10 and r["hand_waits"] == 7, (name, r["requests"], r["hand_waits"])
+
+
+def test_lanczos_xs_row_ring_waits():
+    """k_lanczos3_xs (x3, x4: 720p / 540p -> 4K): one row request and S x S stores per step, one hand-counted wait per step,
+    tight on every path of all six instantiations, no other vmcnt wait inside the loop."""
+    import check_hidden_loads as chk
+
+    out = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-x", "hip",
+                          "--cuda-device-only", "-S", "-I", CSRC, "-I", os.path.join(ROOT, "include"), "-o", "-",
+                          os.path.join(CSRC, "nus_k_lanczos_xs.hip")], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr
+    bodies = list(chk.kernel_bodies(out.stdout, "k_lanczos3_xsIL"))
+    assert len(bodies) == 6, [n for n, _ in bodies]  # EXACT x {x4, x3 with weight classes, x3 without}
+    for name, body in bodies:
+        r = chk.check(body)
+        assert r["errors"] == [], (name, r["errors"][:3])
+        assert r["compiler_vmcnt_waits_in_loops"] == [], (name, r["compiler_vmcnt_waits_in_loops"][:3])
+        assert r["waits_not_tight"] == {}, (name, r["waits_not_tight"])
+        assert r["requests"] == 3 and r["hand_waits"] == 2, (name, r["requests"], r["hand_waits"])  # first D = 2 + 1 per step; drain + 1
+
+
 def test_resize_down_row_ring_waits():
     """k_resize_down's LDS-DMA row ring (footprints of up to two columns per lane): its one hand-placed wait per row must retire
     the row it is about to read on every path -- stores of completed output rows sit between the requests on some paths only, so
