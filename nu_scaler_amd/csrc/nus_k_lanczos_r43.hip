@@ -55,26 +55,49 @@ __device__ __forceinline__ uint32_t r43_row_is_opaque(const Px3 px)
     return __builtin_amdgcn_ballot_w64(!lane_opaque) == 0ull ? 1u : 0u;
 }
 
-// Vertical pass of one output row: 6 taps from the window rows 0 .. 5.  W: VGPR weights (interior rows)
-// or a scalar pointer into the table (rows whose window is cut by the top / bottom border).
-template <bool EXACT, typename W>
-__device__ __forceinline__ void r43_vpass(const float (&win)[6][12], const W &w, float (&V)[12], bool skip_alpha)
+// Row prefetches: as in nus_k_lanczos_x2.hip / nus_k_lanczos_r32.hip the rows are requested with LDS-DMA loads issued from
+// inline assembly (here 12 B per lane, global_load_lds_dwordx3, straight into a per-wave 1-KiB LDS slot -- the 12 bytes of
+// lane l land at 16 l, the fourth dword is left alone: tools/probe_lds_dma_x3.hip --, invisible to the compiler's s_waitcnt
+// insertion) and waited for with hand-counted `s_waitcnt vmcnt(N)`; tools/check_hidden_loads.py verifies
+// the counts on the generated code (tests/test_kernel_asm.py).
+#ifndef NUS_R43_DEPTH
+#define NUS_R43_DEPTH 1 // prefetch distance in steps (a step = three input rows = three requests, four stores)
+#endif
+#ifndef NUS_R43_WAIT_EARLY
+#define NUS_R43_WAIT_EARLY 1 // 1: wait + LDS read at the start of the phase whose end the row is converted at; 0: at its end
+#endif
+constexpr int kR43Depth = NUS_R43_DEPTH;
+constexpr uint32_t kR43SlotBytes = 1024; // 64 lanes x 16 B (12 used)
+
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm" // m0 is a reserved register: nothing else in this kernel uses it
+__device__ __forceinline__ void r43_dma_row12(const uint8_t *base, uint32_t off, uint32_t lds)
 {
-#pragma unroll
-    for (int k = 0; k < 12; ++k) {
-        if ((k & 3) == 3 && skip_alpha) continue; // wave-uniform; V[alpha] is then not read
-        float acc = win[0][k] * w[0]; // == fma(.., 0) and a VOP2 instruction
-#pragma unroll
-        for (int j = 1; j < 6; ++j) acc = mac_tight<EXACT, true>(acc, win[j][k], w[j]);
-        V[k] = acc;
-    }
+    asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx3 %0, %1" : : "v"(off), "s"(base), "s"(lds) : "memory", "m0");
+}
+#pragma clang diagnostic pop
+
+// at most N vector memory instructions outstanding; BACK (for the checker): the BACK-th most recent request has landed
+template <int N, int BACK>
+__device__ __forceinline__ void r43_wait_vmcnt()
+{
+    static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit counter on gfx9");
+    asm volatile("s_waitcnt vmcnt(%0) ; nus-wait back=%1" : : "n"(N), "n"(BACK) : "memory");
 }
 
-// Horizontal pass of one output row: the lane's 4 output pixels, convert + pack, one 16-byte store.  Output p reads
-// the columns e[p] .. e[p + 5] (e[3] is the lane's own first column).
-template <bool EXACT>
-__device__ __forceinline__ void r43_hpass_store(const float (&V)[12], const float (&W)[4][6], __amdgpu_buffer_rsrc_t rs,
-                                                uint32_t off, bool skip_alpha)
+struct R43Ring {
+    const uint8_t *base; // this wave's 3 kR43Depth slots of one row (64 lanes x 16 B) as a generic pointer (reads)
+    uint32_t lds;        // their byte offset in LDS (wave-uniform; requests)
+    int lane;
+};
+
+// One output row: per channel the vertical pass of the lane's 3 columns (6 taps from window slots B .. B+5 mod 6), the lane
+// exchange (3 columns from each neighbour) and the horizontal pass of the lane's 4 output pixels (output p reads the columns
+// e[p] .. e[p + 5], e[3] is the lane's own first column), convert + pack; one 16-byte store.  Channel by channel so that only
+// 3 vertical sums are live.  wv: the row's vertical weights in VGPRs.
+template <bool EXACT, int B>
+__device__ __forceinline__ void r43_row(const float (&win)[6][12], const float (&wv)[6], const float (&W)[4][6],
+                                        __amdgpu_buffer_rsrc_t rs, uint32_t off, bool skip_alpha)
 {
     // skip_alpha (FMA mode, wave-uniform): the six tap rows are opaque in this wave, so alpha is the constant
     // 255 (see row_is_opaque in nus_k_lanczos_x2.hip); v_cvt_pk_u8_f32 only ever replaces bytes 0..2 then
@@ -84,16 +107,24 @@ __device__ __forceinline__ void r43_hpass_store(const float (&V)[12], const floa
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
         if (c == 3 && skip_alpha) continue;
+        float v[3];
+#pragma unroll
+        for (int m = 0; m < 3; ++m) {
+            float acc = win[B % 6][m * 4 + c] * wv[0]; // == fma(.., 0) and a VOP2 instruction
+#pragma unroll
+            for (int j = 1; j < 6; ++j) acc = mac_tight<EXACT, true>(acc, win[(B + j) % 6][m * 4 + c], wv[j]);
+            v[m] = acc;
+        }
         float e[9]; // vertical sums of input columns c0-3 .. c0+5 for this channel
-        e[0] = wave_up(V[0 * 4 + c]);
-        e[1] = wave_up(V[1 * 4 + c]);
-        e[2] = wave_up(V[2 * 4 + c]);
-        e[3] = V[0 * 4 + c];
-        e[4] = V[1 * 4 + c];
-        e[5] = V[2 * 4 + c];
-        e[6] = wave_down(V[0 * 4 + c]);
-        e[7] = wave_down(V[1 * 4 + c]);
-        e[8] = wave_down(V[2 * 4 + c]);
+        e[0] = wave_up(v[0]);
+        e[1] = wave_up(v[1]);
+        e[2] = wave_up(v[2]);
+        e[3] = v[0];
+        e[4] = v[1];
+        e[5] = v[2];
+        e[6] = wave_down(v[0]);
+        e[7] = wave_down(v[1]);
+        e[8] = wave_down(v[2]);
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
             // phase 3's frame is columns c0 .. c0+5: slots 0 .. 5 are e[3] .. e[8]
@@ -103,50 +134,100 @@ __device__ __forceinline__ void r43_hpass_store(const float (&V)[12], const floa
             o[p] = pack_u8<EXACT>(a, c, o[p]);
         }
     }
-    // range-checked buffer store: a lane that must not write has its offset beyond num_records (see the x2 kernel)
+    // range-checked buffer store: a lane that must not write has its offset beyond num_records (see the x2 kernel), so the
+    // store issues on every path and for every lane -- the hand-counted waits rely on exactly one per output row
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
     const u32x4 v = {o[0], o[1], o[2], o[3]};
     __builtin_amdgcn_raw_buffer_store_b128(v, rs, off, 0, NUS_STORE_AUX);
 }
 
-// One group of input rows (r, r+1, r+2), r a multiple of 3 -> output rows 4 r / 3 .. 4 r / 3 + 3.  At entry window row j
-// holds input row r-3+j and raw[0..2] hold rows r+3 .. r+5; the window is shifted, not rotated (one copy of the step's code).
-template <bool EXACT>
-__device__ __forceinline__ void r43_step(float (&win)[6][12], Px3 (&raw)[3], int r, int cl, uint32_t lane_off, const LanczosR43Args &A,
-                                         const float (&W)[4][6], const uint8_t *src, __amdgpu_buffer_rsrc_t rs, uint32_t &opaque)
+__device__ __forceinline__ Px3 r43_ring_read(const R43Ring &ring, uint32_t slot)
+{
+    const uint4 v = *reinterpret_cast<const uint4 *>(ring.base + slot + 16 * ring.lane); // (.w: whatever the LDS held)
+    return Px3{v.x, v.y, v.z};
+}
+
+struct R43StepCtx {
+    const LanczosR43Args &A;
+    const R43Ring &ring;
+    const uint8_t *src;
+    __amdgpu_buffer_rsrc_t rs;
+    uint32_t in_off, lane_off;
+};
+
+// phase P of a step (see r43_step): output row 4 r / 3 + P from the window slots S+P .. S+P+5, then (P < 3) row r+3+P in
+template <bool EXACT, int S, int P>
+__device__ __forceinline__ void r43_phase(float (&win)[6][12], const R43StepCtx &C, uint32_t pos, int r, bool interior,
+                                          const float (&W)[4][6], uint32_t &opaque)
 {
     typedef const __attribute__((address_space(4))) float *cfloat_p;
+    constexpr int D = kR43Depth;
+    constexpr bool EARLY = NUS_R43_WAIT_EARLY != 0;
+    const LanczosR43Args &A = C.A;
     const uint32_t row_bytes = A.iw / 3 * 16; // one output row: 4 iw / 3 pixels
-    const uint32_t oy0 = 4u * (uint32_t)(r / 3);
-    const bool interior = r >= 3 && r + 6 <= (int)A.ih; // wave-uniform: rows r-3 .. r+5 exist, none of the frames is cut
-    float V[12];
+    const uint32_t oy = 4u * (uint32_t)(r / 3) + (uint32_t)P;
+    Px3 next = {0u, 0u, 0u};
+    const uint32_t slot = pos + (uint32_t)P * kR43SlotBytes; // P < 3: the ring slot of row r+3+P
+    if (P < 3 && EARLY) {
+        r43_wait_vmcnt<7 * D - 2, 3 * D>();
+        next = r43_ring_read(C.ring, slot);
+    }
+    const bool skip_alpha = !EXACT && (opaque & 0x3Fu) == 0x3Fu; // bit j: the row j before the newest is opaque
+    // vertical weights of this output row: the phase's interior ones (the horizontal weights, already in VGPRs) or, next to the
+    // top / bottom border where the window is cut and renormalised, the row's own from the table; one copy of the row's code
+    float wv[6];
+    if (interior) {
 #pragma unroll
-    for (int p = 0; p < 4; ++p) {
-        const bool skip_alpha = !EXACT && (opaque & 0x3Fu) == 0x3Fu; // bit j: window row 5-j is opaque
-        if (interior) {
-            r43_vpass<EXACT>(win, W[p], V, skip_alpha);
-        } else {
-            cfloat_p wt = (cfloat_p)(uintptr_t)(A.wy6 + (size_t)__builtin_amdgcn_readfirstlane(oy0 + (uint32_t)p) * 6);
-            r43_vpass<EXACT>(win, wt, V, skip_alpha);
-        }
-        r43_hpass_store<EXACT>(V, W, rs, lane_off == 0x80000000u ? lane_off : (oy0 + (uint32_t)p) * row_bytes + lane_off, skip_alpha);
-        if (p < 3) {
-            // the oldest row out, row r+3+p in; then request row r+6+p
+        for (int j = 0; j < 6; ++j) wv[j] = W[P][j];
+    } else {
+        cfloat_p wt = (cfloat_p)(uintptr_t)(A.wy6 + (size_t)__builtin_amdgcn_readfirstlane(oy) * 6);
 #pragma unroll
-            for (int j = 0; j < 5; ++j)
-#pragma unroll
-                for (int k = 0; k < 12; ++k) win[j][k] = win[j + 1][k];
-            {
-                const uint4 s4 = swz4(make_uint4(raw[p].x, raw[p].y, raw[p].z, 0xFF000000u), A.sel);
-                const Px3 px = {s4.x, s4.y, s4.z};
-                if (!EXACT) opaque = (opaque << 1) | r43_row_is_opaque(px);
-                r43_cvt_row(px, win[5]);
-            }
-            int rn = r + 6 + p;
-            rn = rn < (int)A.ih - 1 ? rn : (int)A.ih - 1;
-            raw[p] = *reinterpret_cast<const Px3 *>(src + ((size_t)rn * A.iw + cl) * 4);
+        for (int j = 0; j < 6; ++j) {
+            wv[j] = wt[j];
+            asm volatile("" : "+v"(wv[j]));
         }
     }
+    r43_row<EXACT, S + P>(win, wv, W, C.rs, C.lane_off == 0x80000000u ? C.lane_off : oy * row_bytes + C.lane_off, skip_alpha);
+    if (P < 3) {
+        // the oldest row out, row r+3+P in; then request row r+3+P+3D into the same ring slot
+        if (!EARLY) {
+            r43_wait_vmcnt<7 * D - 1, 3 * D>();
+            next = r43_ring_read(C.ring, slot);
+        }
+        {
+            const uint4 s4 = swz4(make_uint4(next.x, next.y, next.z, 0xFF000000u), A.sel);
+            const Px3 px = {s4.x, s4.y, s4.z};
+            if (!EXACT) opaque = (opaque << 1) | r43_row_is_opaque(px);
+            r43_cvt_row(px, win[(S + P) % 6]);
+        }
+        int rn = r + 3 + P + 3 * D;
+        rn = rn < (int)A.ih - 1 ? rn : (int)A.ih - 1;
+        // the slot is requested again only when its read has RETURNED (the converted row is an operand of this empty
+        // statement): nothing orders a queued ds_read behind a later LDS-DMA write (see the x2 kernel)
+        asm volatile("" : : "v"(win[(S + P) % 6][0]), "v"(win[(S + P) % 6][11]) : "memory");
+        r43_dma_row12(C.src, C.in_off + (uint32_t)rn * (A.iw * 4), C.ring.lds + slot);
+    }
+}
+
+// One group of input rows (r, r+1, r+2), r a multiple of 3 -> output rows 4 r / 3 .. 4 r / 3 + 3.  At entry window slot
+// (S + j) % 6 holds input row r-3+j and the ring's slot triple at `pos` holds rows r+3 .. r+5 (requested kR43Depth steps ago).
+// Phase p reads the slots S+p .. S+p+5; row r-3+p dies with it and row r+3+p is converted into its slot: the window rotates,
+// 2 steps unrolled (round 2 shifted it: 180 register moves per step).
+//
+// Vector memory instructions of a step, in issue order and on every path: store, request, store, request, store, request,
+// store.  Issued since the request of row r+3+p when the wave waits for it at the END of phase p: 7 D - 1 for each p (the rest
+// of that step, D-1 whole steps of 7, this step up to the wait); at the START of the phase: 7 D - 2.  The request is the
+// 3 D-th most recent one then.
+template <bool EXACT, int S>
+__device__ __forceinline__ void r43_step(float (&win)[6][12], const R43StepCtx &C, uint32_t &pos, int r, const float (&W)[4][6],
+                                         uint32_t &opaque)
+{
+    const bool interior = r >= 3 && r + 6 <= (int)C.A.ih; // wave-uniform: rows r-3 .. r+5 exist, none of the frames is cut
+    r43_phase<EXACT, S, 0>(win, C, pos, r, interior, W, opaque);
+    r43_phase<EXACT, S, 1>(win, C, pos, r, interior, W, opaque);
+    r43_phase<EXACT, S, 2>(win, C, pos, r, interior, W, opaque);
+    r43_phase<EXACT, S, 3>(win, C, pos, r, interior, W, opaque);
+    pos = pos + 3 * kR43SlotBytes == (uint32_t)(3 * kR43Depth) * kR43SlotBytes ? 0u : pos + 3 * kR43SlotBytes;
 }
 
 // One wave loads a strip of 192 input columns (3 per lane; lanes 1 .. 62 produce the strip's 186 input = 248 output
@@ -174,17 +255,20 @@ __global__ __launch_bounds__(256) void k_lanczos3_r43(const LanczosR43Args A)
     // image (the 8 edge output columns per side: k_lanczos3_r43_edges)
     const bool stores = lane >= 1 && lane <= kR43StripCols / 3 && c >= 6 && c + 9 <= (int)A.iw;
     const uint32_t lane_off = stores ? (uint32_t)(c / 3) * 16u : 0x80000000u; // byte offset of its 16 B inside an output row
+    const uint32_t in_off = (uint32_t)cl * 4u;                               // and of its 12 B inside an input row
     const int r0 = (int)(rb * A.th); // a multiple of 3
     const int r_end = (r0 + (int)A.th) < (int)A.ih ? (r0 + (int)A.th) : (int)A.ih;
     const int rmax = (int)A.ih - 1;
-    auto load_row = [&](int rr) {
+    auto row_off = [&](int rr) {
         rr = rr < 0 ? 0 : (rr > rmax ? rmax : rr);
-        return *reinterpret_cast<const Px3 *>(src + ((size_t)rr * A.iw + cl) * 4);
+        return in_off + (uint32_t)rr * (A.iw * 4);
     };
-    auto swz3 = [&](const Px3 p) {
-        const uint4 s4 = swz4(make_uint4(p.x, p.y, p.z, 0xFF000000u), A.sel);
-        return Px3{s4.x, s4.y, s4.z};
-    };
+    __shared__ uint4 lds_rows[4][3 * kR43Depth][64];
+    const uint32_t w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    R43Ring ring;
+    ring.base = reinterpret_cast<const uint8_t *>(&lds_rows[w][0][0]);
+    ring.lds = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)&lds_rows[w][0][0]);
+    ring.lane = lane;
 
     float W[4][6];
 #pragma unroll
@@ -196,14 +280,32 @@ __global__ __launch_bounds__(256) void k_lanczos3_r43(const LanczosR43Args A)
         }
     float win[6][12];
     uint32_t opaque = 0;
+    {
+        // the six rows of the first window (ordinary loads, all in flight together), then the first requests
+        Px3 first[6];
 #pragma unroll
-    for (int j = 0; j < 6; ++j) {
-        const Px3 px = swz3(load_row(r0 - 3 + j));
-        if (!EXACT) opaque = (opaque << 1) | r43_row_is_opaque(px);
-        r43_cvt_row(px, win[j]);
+        for (int j = 0; j < 6; ++j) first[j] = *reinterpret_cast<const Px3 *>(src + row_off(r0 - 3 + j));
+#pragma unroll
+        for (int j = 0; j < 3 * kR43Depth; ++j) r43_dma_row12(src, row_off(r0 + 3 + j), ring.lds + (uint32_t)j * kR43SlotBytes);
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            const uint4 s4 = swz4(make_uint4(first[j].x, first[j].y, first[j].z, 0xFF000000u), A.sel);
+            const Px3 px = {s4.x, s4.y, s4.z};
+            if (!EXACT) opaque = (opaque << 1) | r43_row_is_opaque(px);
+            r43_cvt_row(px, win[j]);
+        }
+        // the hand-counted waits of the loop assume that nothing older than its own instructions is outstanding
+        r43_wait_vmcnt<0, 0>();
     }
-    Px3 raw[3] = {load_row(r0 + 3), load_row(r0 + 4), load_row(r0 + 5)};
-    for (int r = r0; r < r_end; r += 3) r43_step<EXACT>(win, raw, r, cl, lane_off, A, W, src, rs, opaque);
+    uint32_t pos = 0;
+    const R43StepCtx C = {A, ring, src, rs, in_off, lane_off};
+    for (int rbase = r0; rbase < r_end; rbase += 6) {
+        // 2 steps unrolled so the rotating window indices are compile-time constants; the block leaves the loop after its last
+        // row group, so every path through the loop carries the vector memory instructions the hand-counted waits assume
+        r43_step<EXACT, 0>(win, C, pos, rbase, W, opaque);
+        if (rbase + 3 >= r_end) break;
+        r43_step<EXACT, 3>(win, C, pos, rbase + 3, W, opaque);
+    }
 }
 
 // The 8 left-most and right-most output columns (tap windows cut by the image border, weights renormalised).  As in the

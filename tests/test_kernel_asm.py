@@ -70,6 +70,27 @@ def test_lanczos_r32_row_ring_waits():
         assert r["requests"] == 10 and r["hand_waits"] == 7, (name, r["requests"], r["hand_waits"])
 
 
+def test_lanczos_r43_row_ring_waits():
+    """k_lanczos3_r43 (x4/3: 1080p -> 1440p): three 12-byte row requests (global_load_lds_dwordx3) and four stores per step,
+    one hand-counted wait per request, tight on every path."""
+    import check_hidden_loads as chk
+
+    out = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-x", "hip",
+                          "--cuda-device-only", "-S", "-I", CSRC, "-I", os.path.join(ROOT, "include"), "-o", "-",
+                          os.path.join(CSRC, "nus_k_lanczos_r43.hip")], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr
+    bodies = list(chk.kernel_bodies(out.stdout, "k_lanczos3_r43IL"))
+    assert len(bodies) == 2, [n for n, _ in bodies]  # EXACT, FMA
+    for name, body in bodies:
+        r = chk.check(body)
+        assert r["errors"] == [], (name, r["errors"][:3])
+        assert r["compiler_vmcnt_waits_in_loops"] == [], (name, r["compiler_vmcnt_waits_in_loops"][:3])
+        assert r["waits_not_tight"] == {}, (name, r["waits_not_tight"])
+        # 2 unrolled steps x 3 requests + the first 3 D of a block; one hand wait per request + the drain at loop entry
+        assert r["requests"] == 9 and r["hand_waits"] == 7, (name, r["requests"], r["hand_waits"])
+        assert "global_load_lds_dwordx3" in body
+
+
 def test_lanczos_xs_row_ring_waits():
     """k_lanczos3_xs (x3, x4: 720p / 540p -> 4K): one row request and S x S stores per step, one hand-counted wait per step,
     tight on every path of all six instantiations, no other vmcnt wait inside the loop."""
