@@ -121,6 +121,12 @@ int HipUpscaler::set_option(const char *key, int64_t value)
         force_rows_ = value != 0;
         return kOk;
     }
+    if (!strcmp(key, "down_seg_width")) { // output columns per wave of the down-scaling kernel; 0 = the host's choice
+        if (initialized_) return fail(kInvalidArgument, "down_seg_width must be set before initialize");
+        if (value < 0 || value > 64) return fail(kInvalidArgument, "down_seg_width out of range");
+        down_seg_width_ = (uint32_t)value;
+        return kOk;
+    }
     if (!strcmp(key, "rows_per_wave")) {
         if (value < 0 || value > 4096) return fail(kInvalidArgument, "rows_per_wave out of range");
         rows_per_wave_ = (uint32_t)value;
@@ -291,7 +297,27 @@ void HipUpscaler::choose_resize_variant(bool x2)
         const uint32_t widest64 = widest_footprint(64);
         if (build_down_stream_tables(ty_, down_rows_, down_done_) && widest64 <= 320) {
             variant_ = Variant::ResizeDown;
+            // Output columns per wave: every lane carries ceil(footprint / 64) input columns through the vertical pass whether
+            // the segment fills them or not, so a slightly narrower segment whose footprint fits one column per lane fewer is
+            // cheaper (2x down: 58 outputs over 128 columns instead of 64 over 140 = 3 columns per lane, a third of them idle).
+            // Cost per output column ~ (vertical FMAs of a lane per output row + its horizontal pass: an LDS read and 4 FMAs per
+            // tap of the compiled trip count, priced at 10) / width, calibrated on profiles/r03_resize_down_segment_width_ab.txt
+            // (4K -> 1080p: 58 columns 16.9 us against 20.1 at 64; 4K -> 720p, 32-tap passes: 64 stays, 57 is 4 % slower).
+            down_seg_w_ = 64;
             resize_ncols_max_ = widest64;
+            if (down_seg_width_ == 0) {
+                const double rows_per_out = (double)ih_ / oh_;
+                double best = 0.0;
+                for (uint32_t w = 64; w >= 40; --w) {
+                    const uint32_t fp = widest_footprint(w);
+                    const double cost = (28.0 * ((fp + 63) / 64) * rows_per_out + 10.0 * (tx_.lz_max_taps > 16 ? 32 : 16) + 30.0) / w;
+                    if (w == 64 || cost < best * 0.97) best = cost, down_seg_w_ = w, resize_ncols_max_ = fp;
+                }
+            } else { // option "down_seg_width" (tests, A/B timing)
+                down_seg_w_ = down_seg_width_ > 64 ? 64 : down_seg_width_;
+                resize_ncols_max_ = widest_footprint(down_seg_w_);
+                if (resize_ncols_max_ > 320) down_seg_w_ = 64, resize_ncols_max_ = widest64;
+            }
             return;
         }
     }
@@ -552,7 +578,7 @@ int HipUpscaler::enqueue(const uint8_t *d_in, uint8_t *d_out, uint32_t n_frames,
     case Variant::ResizeRows:
         e = launch_resize_rows(L, dt_, lanczos_exact_, resize_ncols_max_, resize_small_taps_, resize_union_taps_);
         break;
-    case Variant::ResizeDown: e = launch_resize_down(L, dt_, lanczos_exact_, resize_ncols_max_, tx_.lz_max_taps); break;
+    case Variant::ResizeDown: e = launch_resize_down(L, dt_, lanczos_exact_, resize_ncols_max_, tx_.lz_max_taps, down_seg_w_); break;
     case Variant::FsrEasu: e = launch_fsr1(L, 0, easu_sharpness(), rcas_sharpness()); break;
     case Variant::FsrRcas: e = launch_fsr1(L, 1, easu_sharpness(), rcas_sharpness()); break;
     case Variant::Fsr1Fused: e = launch_fsr1(L, 2, easu_sharpness(), rcas_sharpness()); break;

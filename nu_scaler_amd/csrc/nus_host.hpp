@@ -197,6 +197,8 @@ private:
     bool force_per_pixel_ = false; // resize: never use the LDS row kernel
     bool force_rows_ = false;      // resize: never use the register-window variant of it
     uint32_t resize_ncols_max_ = 0; // LDS row length of the ResizeRows variant
+    uint32_t down_seg_w_ = 64;      // ResizeDown: output columns per wave (choose_resize_variant)
+    uint32_t down_seg_width_ = 0;   // option "down_seg_width": 0 = chosen by cost
     std::vector<uint32_t> down_rows_; // ResizeDown: per-input-row slot weights + completion (build_down_stream_tables)
     std::vector<int32_t> down_done_;
     bool resize_small_taps_ = false;

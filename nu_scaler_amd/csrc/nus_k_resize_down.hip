@@ -79,7 +79,7 @@ __global__ __launch_bounds__(256) void k_resize_down(
     const int32_t *__restrict__ lxt, const uint32_t *__restrict__ nxt, const float *__restrict__ wxt,
     const int32_t *__restrict__ lyt, const uint32_t *__restrict__ rowtab, const int32_t *__restrict__ done_row,
     uint32_t stride, uint32_t iw, uint32_t ih, uint32_t ow, uint32_t oh, uint32_t rows_per_block, uint32_t ncols_max,
-    size_t in_frame_px, size_t out_frame_px, uint32_t sel)
+    size_t in_frame_px, size_t out_frame_px, uint32_t sel, uint32_t seg_w)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int NS = kSlots;
@@ -97,14 +97,17 @@ __global__ __launch_bounds__(256) void k_resize_down(
     const uint32_t ring_lds = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)s_ring);
     const GridPos g = xcd_contiguous_pos(); // row blocks that share their window-fill rows behind one L2
     const uint32_t seg = __builtin_amdgcn_readfirstlane(g.x * 4 + threadIdx.y);
-    const uint32_t X0 = seg * kWave;
+    // a wave's segment is seg_w <= 64 output columns: the host picks the width whose footprint fills whole columns-per-lane
+    // (2x down: 58 outputs over 128 input columns, VC = 2, instead of 64 over 140, VC = 3 with a third of the lanes' vertical
+    // work wasted)
+    const uint32_t X0 = seg * seg_w;
     if (X0 >= ow) return; // whole wave; no workgroup barriers below
-    const uint32_t Xlast = umin(X0 + kWave, ow) - 1;
+    const uint32_t Xlast = umin(X0 + seg_w, ow) - 1;
     const int32_t cmin = lxt[X0];
     const int32_t ncols = lxt[Xlast] + (int32_t)nxt[Xlast] - cmin; // <= 64 * VC (host-checked)
     if (threadIdx.x < kDownSlack) s_v[ncols + threadIdx.x] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     const uint32_t x = X0 + threadIdx.x;
-    const bool lane_active = x < ow;
+    const bool lane_active = threadIdx.x < seg_w && x < ow;
     const uint32_t xo = lane_active ? x : X0;
     const int32_t hl = lxt[xo] - cmin;
     // the lane's horizontal weights, zero beyond its window (HT >= the widest window, host-checked); adding
@@ -252,8 +255,10 @@ __global__ __launch_bounds__(256) void k_resize_down(
 
 } // namespace
 
-hipError_t launch_resize_down(const UpscaleLaunch &L, const DeviceTables &T, bool exact, uint32_t ncols_max, uint32_t max_taps_x)
+hipError_t launch_resize_down(const UpscaleLaunch &L, const DeviceTables &T, bool exact, uint32_t ncols_max, uint32_t max_taps_x,
+                              uint32_t seg_w)
 {
+    if (seg_w < 1 || seg_w > kWave) return hipErrorInvalidValue;
     const size_t ipx = (size_t)L.iw * L.ih, opx = (size_t)L.ow * L.oh;
     const uint32_t vc = cdiv(ncols_max, kWave);
     if (vc < 1 || vc > 5 || max_taps_x > 32 || !T.lz_down_rows || !T.lz_down_done) return hipErrorInvalidValue;
@@ -262,7 +267,7 @@ hipError_t launch_resize_down(const UpscaleLaunch &L, const DeviceTables &T, boo
                                     (size_t)down_depth((int)vc) * vc * kWave * sizeof(uint32_t));
     if ((uint64_t)L.iw * L.ih * 4 >= (1ull << 32)) return hipErrorInvalidValue; // 32-bit row offsets (frames < 2 GiB: host-checked)
     return for_frame_chunks(L, [&](const uint8_t *in, uint8_t *out, uint32_t n) {
-        const uint64_t blocks_x = cdiv(cdiv(L.ow, kWave), 4);
+        const uint64_t blocks_x = cdiv(cdiv(L.ow, seg_w), 4);
         uint64_t rpb = (uint64_t)L.oh * blocks_x * n / 2048; // a couple of thousand blocks per launch ...
         rpb = rpb < 16 ? 16 : (rpb > 64 ? 64 : rpb);          // ... each tall enough to amortise its window fill
         const dim3 block(kWave, 4), grid((uint32_t)blocks_x, cdiv(L.oh, (uint32_t)rpb), n);
@@ -271,7 +276,7 @@ hipError_t launch_resize_down(const UpscaleLaunch &L, const DeviceTables &T, boo
 #define NUS_RD(E, C, H)                                                                                                     \
     hipLaunchKernelGGL((k_resize_down<E, C, H>), grid, block, lds, L.stream, i32, o32, T.lz_lx, T.lz_nx, T.lz_wx, T.lz_ly, \
                        T.lz_down_rows, T.lz_down_done, T.lz_stride, L.iw, L.ih, L.ow, L.oh, (uint32_t)rpb, ncols_max, ipx,  \
-                       opx, L.in_sel)
+                       opx, L.in_sel, seg_w)
 #define NUS_RD2(E, H)                        \
     switch (vc) {                            \
     case 1: NUS_RD(E, 1, H); break;          \

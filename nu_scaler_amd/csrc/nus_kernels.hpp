@@ -110,10 +110,10 @@ hipError_t launch_resize_rows(const UpscaleLaunch &L, const DeviceTables &T, boo
 hipError_t launch_resize_win(const UpscaleLaunch &L, const DeviceTables &T, bool exact, uint32_t ncols_max,
                              uint32_t union_taps, uint32_t outputs_per_lane);
 // Down-scaling variant (nus_k_resize_down.hip): needs T.lz_down_rows / lz_down_done (build_down_stream_tables
-// succeeded: 7 accumulator slots suffice), ncols_max = widest footprint of a 64-column output segment <= 320.
-// max_taps_x: widest horizontal window (<= 32).
+// succeeded: 7 accumulator slots suffice), seg_w = output columns per wave (<= 64), ncols_max = widest footprint of a
+// seg_w-column output segment <= 320.  max_taps_x: widest horizontal window (<= 32).
 hipError_t launch_resize_down(const UpscaleLaunch &L, const DeviceTables &T, bool exact, uint32_t ncols_max,
-                              uint32_t max_taps_x);
+                              uint32_t max_taps_x, uint32_t seg_w);
 // main x2 kernel only: the first / last kLanczosX2EdgeCols output columns are NOT written;
 // follow it with launch_lanczos_x2_edges(L, T, exact).
 hipError_t launch_lanczos_x2(const UpscaleLaunch &L, const DeviceTables &T, bool exact,

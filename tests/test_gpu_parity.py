@@ -1186,6 +1186,23 @@ def test_resize_down_streaming_kernel(nsc, oracle_mod, alg, filt, dims):
     assert np.array_equal(got_f, ref_f) and _maxdiff(got_f, want) <= 1
 
 
+@pytest.mark.parametrize("dims", [((464, 64), (232, 32)), ((700, 90), (233, 30)), ((300, 157), (150, 78))])
+def test_resize_down_segment_widths(nsc, oracle_mod, dims):
+    """The down-scaling kernel's output columns per wave (option down_seg_width; by default the host takes the width whose
+    footprint fills whole columns per lane, e.g. 58 at exactly 1/2): every width gives the oracle's bits."""
+    (w, h), (ow, oh) = dims
+    img = oracle_mod.gen_noise(w, h, 78)
+    want = oracle_mod.resize(img, ow, oh, 0)
+    for sw in (0, 64, 58, 57, 50, 41, 1):
+        got, u = _up(nsc, "lanczos3", img, ow, oh, lanczos_mode="exact", options={"down_seg_width": sw})
+        assert u.kernel_variant == "resize_down_stream"
+        assert np.array_equal(got, want), (dims, sw, _maxdiff(got, want))
+    u = nsc.PyWgpuUpscaler("quality", "lanczos3")
+    u.initialize(w, h, ow, oh)
+    with pytest.raises(Exception):
+        u.set_option("down_seg_width", 58)  # before initialize only
+
+
 @pytest.mark.parametrize("seed", [1, 2, 3])
 def test_resize_down_random_shapes(nsc, oracle_mod, seed):
     """Random down-scaling shapes (ratios 1.02 .. 4.7 per axis, widths around the 64-column segment sizes, heights
