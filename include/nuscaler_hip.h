@@ -145,7 +145,8 @@ int nus_upscaler_set_lanczos_mode(nus_upscaler *h, int mode);
 /* Tuning / test knobs: "force_general" (0/1, before initialize: never pick an x2
  * fast path), "force_per_pixel" (0/1, before initialize: resize without the LDS row kernel),
  * "force_rows" (0/1, before initialize: resize without the register-window variant of it),
- * "rows_per_wave" (Lanczos x2 kernel: input rows per wave, 0 = auto). */
+ * "rows_per_wave" (fixed-factor resize kernels: input rows per wave, 0 = auto), "unit_order" (below),
+ * "down_seg_width" (0..64, before initialize: output columns per wave of the down-scaling kernel, 0 = auto). */
 int nus_upscaler_set_option(nus_upscaler *h, const char *key, int64_t value);
 /* Channel order of the input frames.  Captured frames arrive as BGRA and the reference swizzles them
  * on the CPU before upscaling (nu_scaler_core/src/lib.rs:251-270); with NUS_FORMAT_BGRA8 the kernels
