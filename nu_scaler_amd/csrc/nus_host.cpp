@@ -121,6 +121,16 @@ int HipUpscaler::set_option(const char *key, int64_t value)
         force_rows_ = value != 0;
         return kOk;
     }
+    if (!strcmp(key, "single_out_plan")) { // how upscale() cuts a pageable output frame into D2H pieces (plan_chunks)
+        if (value < 0 || value > 3) return fail(kInvalidArgument, "single_out_plan out of range");
+        single_out_plan_ = (int)value;
+        return kOk;
+    }
+    if (!strcmp(key, "batch_out_chunks")) { // D2H pieces per pageable output frame of upscale_batch / the stream ring
+        if (value < 1 || value > kOutChunks) return fail(kInvalidArgument, "batch_out_chunks out of range");
+        batch_out_chunks_ = (int)value;
+        return kOk;
+    }
     if (!strcmp(key, "down_seg_width")) { // output columns per wave of the down-scaling kernel; 0 = the host's choice
         if (initialized_) return fail(kInvalidArgument, "down_seg_width must be set before initialize");
         if (value < 0 || value > 64) return fail(kInvalidArgument, "down_seg_width out of range");
@@ -813,10 +823,40 @@ void HipUpscaler::release_slot(Slot &s)
 // One frame into a free slot: stage (unless the caller's buffer is pinned) -> H2D -> kernel -> D2H, all asynchronous, each on
 // its own stream.  Pageable outputs come back in kOutChunks pieces: while piece k is copied out of the pinned buffer (by
 // the copy pool's workers), piece k+1 is in flight.  *direct: the D2H goes straight into the caller's (pinned) buffer.
-int HipUpscaler::submit_frame(Slot &S, const uint8_t *in, uint8_t *out, bool *direct)
+void HipUpscaler::plan_chunks(Slot &S, size_t out_bytes, bool alone) const
+{
+    auto page = [](size_t v) { return (v + 4095) & ~(size_t)4095; };
+    int n = 0;
+    size_t end[kOutChunks];
+    if (alone && (single_out_plan_ == 1 || single_out_plan_ == 2)) {
+        // halves: the copy-out of a piece has the whole DMA of the next, smaller one to finish in; what is left after the last
+        // DMA is the copy of an eighth (a sixteenth) of the frame
+        const int parts = single_out_plan_ == 1 ? 4 : 5;
+        size_t off = 0;
+        for (int k = 0; k < parts - 1; ++k) {
+            off += page(out_bytes >> (k + 1)); // 1/2, 1/4, ... ; the last piece is what remains
+            end[n++] = off;
+        }
+        end[n++] = out_bytes;
+    } else {
+        int parts = alone ? (single_out_plan_ == 3 ? 4 : kOutChunks) : batch_out_chunks_;
+        parts = parts < 1 ? 1 : (parts > kOutChunks ? kOutChunks : parts);
+        const size_t chunk = page((out_bytes + parts - 1) / parts);
+        for (size_t off = chunk; off < out_bytes; off += chunk) end[n++] = off;
+        end[n++] = out_bytes;
+    }
+    // (tiny frames: pieces that would start at or past the end are dropped)
+    S.nchunks = 0;
+    size_t prev = 0;
+    for (int k = 0; k < n; ++k) {
+        const size_t e = end[k] < out_bytes ? end[k] : out_bytes;
+        if (e > prev || (k == n - 1 && S.nchunks == 0)) S.chunk_end[S.nchunks++] = e, prev = e;
+    }
+}
+
+int HipUpscaler::submit_frame(Slot &S, const uint8_t *in, uint8_t *out, bool *direct, bool alone)
 {
     const size_t in_bytes = (size_t)iw_ * ih_ * 4, out_bytes = (size_t)ow_ * oh_ * 4;
-    const size_t chunk = ((out_bytes + kOutChunks - 1) / kOutChunks + 4095) & ~(size_t)4095;
     const uint8_t *src = in;
     if (!is_pinned_host(src)) {
         parallel_copy(S.h_in, src, in_bytes);
@@ -834,11 +874,12 @@ int HipUpscaler::submit_frame(Slot &S, const uint8_t *in, uint8_t *out, bool *di
     if (*direct) {
         NUS_HIP(hipMemcpyAsync(out, S.d_out, out_bytes, hipMemcpyDeviceToHost, s_out_));
     } else {
-        int k = 0;
-        for (size_t off = 0; off < out_bytes; off += chunk, ++k) {
-            const size_t len = out_bytes - off < chunk ? out_bytes - off : chunk;
-            NUS_HIP(hipMemcpyAsync(S.h_out + off, S.d_out + off, len, hipMemcpyDeviceToHost, s_out_));
+        plan_chunks(S, out_bytes, alone);
+        size_t off = 0;
+        for (int k = 0; k < S.nchunks; ++k) {
+            NUS_HIP(hipMemcpyAsync(S.h_out + off, S.d_out + off, S.chunk_end[k] - off, hipMemcpyDeviceToHost, s_out_));
             NUS_HIP(hipEventRecord(S.chunk_done[k], s_out_));
+            off = S.chunk_end[k];
         }
     }
     NUS_HIP(hipEventRecord(S.out_done, s_out_));
@@ -850,8 +891,6 @@ int HipUpscaler::submit_frame(Slot &S, const uint8_t *in, uint8_t *out, bool *di
 // reports an error's text through *err instead of error_.
 int HipUpscaler::retire_frame(Slot &S, uint8_t *out, bool direct, std::string *err) const
 {
-    const size_t out_bytes = (size_t)ow_ * oh_ * 4;
-    const size_t chunk = ((out_bytes + kOutChunks - 1) / kOutChunks + 4095) & ~(size_t)4095;
     auto hip_failed = [&](hipError_t e, const char *what) {
         (void)hipGetLastError();
         if (err) *err = fmt("HIP error in %s: %s", what, hipGetErrorString(e));
@@ -862,14 +901,16 @@ int HipUpscaler::retire_frame(Slot &S, uint8_t *out, bool direct, std::string *e
         return e == hipSuccess ? kOk : hip_failed(e, "hipEventSynchronize(out_done)");
     }
     CopyTicket ticket; // the frame's pieces: queued as they land, all copied when the wait returns
-    int k = 0, rc = kOk;
-    for (size_t off = 0; off < out_bytes; off += chunk, ++k) {
+    int rc = kOk;
+    size_t off = 0;
+    for (int k = 0; k < S.nchunks; ++k) {
         const hipError_t e = hipEventSynchronize(S.chunk_done[k]);
         if (e != hipSuccess) {
             rc = hip_failed(e, "hipEventSynchronize(chunk_done)");
             break;
         }
-        parallel_copy_async(out + off, S.h_out + off, out_bytes - off < chunk ? out_bytes - off : chunk, ticket);
+        parallel_copy_async(out + off, S.h_out + off, S.chunk_end[k] - off, ticket);
+        off = S.chunk_end[k];
     }
     parallel_copy_wait(ticket); // also on the error path: queued pieces point into buffers that must outlive them
     return rc;
@@ -947,7 +988,7 @@ int HipUpscaler::stream_submit(const uint8_t *in, size_t in_len, uint8_t *out, s
     }
     NUS_HIP(hipSetDevice(device_));
     bool direct = false;
-    const int rc = submit_frame(slots_[i % kSlots], in, out, &direct);
+    const int rc = submit_frame(slots_[i % kSlots], in, out, &direct, false);
     if (rc != kOk) return rc; // nothing was queued for the retiring thread: the ring stays consistent
     {
         std::lock_guard<std::mutex> rl(ring_.m);
@@ -1038,7 +1079,7 @@ int HipUpscaler::upscale_batch(const uint8_t *const *ins, const size_t *in_lens,
     std::vector<char> direct_out(n, 0);
     auto submit = [&](size_t i) -> int {
         bool direct = false;
-        const int rc = submit_frame(slots_[i % nslots], ins[i], outs[i], &direct);
+        const int rc = submit_frame(slots_[i % nslots], ins[i], outs[i], &direct, n == 1);
         direct_out[i] = direct ? 1 : 0;
         return rc;
     };

@@ -136,7 +136,16 @@ private:
         hipEvent_t chunk_done[kOutChunks] = {};     // D2H of output chunk k has landed in h_out    (copy-out stream)
         hipEvent_t out_done = nullptr;              // ... of the whole frame
         bool used = false;                          // events have been recorded at least once
+        int nchunks = 0;                            // pieces of the frame in flight (pageable output) ...
+        size_t chunk_end[kOutChunks] = {};          // ... and where each ends (set by submit_frame, read by retire_frame)
     };
+    // How a pageable output frame is cut into D2H pieces.  Every piece costs the copy engine ~17 us of dead time (the event
+    // between two copies of one stream: profiles/r03_host_path_copy_timeline.txt), and buys overlap of the copy out of the
+    // pinned buffer with the next piece's DMA -- which a frame that is alone in the pipeline needs (trait Upscaler::upscale)
+    // and a frame with others behind it does not (their DMA is what its copy-out overlaps with).
+    int single_out_plan_ = 0;   // option "single_out_plan": 0 = 8 equal pieces (rounds 1-2), 1 = 1/2 1/4 1/8 1/8, 2 = 1/2 1/4 1/8 1/16 1/16, 3 = 4 equal
+    int batch_out_chunks_ = 2;  // option "batch_out_chunks": equal pieces per frame of upscale_batch / the stream ring
+    void plan_chunks(Slot &s, size_t out_bytes, bool alone) const;
     // "one host thread + 3 streams per GPU": every H2D goes down the copy-in stream, every kernel down the compute stream,
     // every D2H down the copy-out stream, tied together per frame by the slot's events -- so the copies of consecutive frames
     // sit back to back in ONE queue per direction (0.60 ms per 4K frame on the D2H engine) instead of alternating between the
@@ -148,7 +157,7 @@ private:
     int ensure_device();
     int ensure_streams();
     int ensure_slot(Slot &s, size_t in_bytes, size_t out_bytes);
-    int submit_frame(Slot &s, const uint8_t *in, uint8_t *out, bool *direct);
+    int submit_frame(Slot &s, const uint8_t *in, uint8_t *out, bool *direct, bool alone);
     int retire_frame(Slot &s, uint8_t *out, bool direct, std::string *err) const;
     struct Ring { // state of an open stream (stream_open .. stream_close); its own mutex, never held together with a HIP call
         struct Item {

@@ -1257,6 +1257,32 @@ def test_resize_down_4k_to_1080p_batch(nsc, oracle_mod):
         assert np.array_equal(got[k], np.frombuffer(r.upscale(frames[k].tobytes()), np.uint8).reshape(oh, ow, 4)), k
 
 
+def test_output_piece_plans_give_the_same_bytes(nsc, oracle_mod):
+    """A pageable output frame comes back in pieces (options single_out_plan for upscale(), batch_out_chunks for upscale_batch and
+    the stream ring): every plan returns the same bytes, on a frame whose size is no multiple of anything and on a tiny one."""
+    for (w, h) in ((333, 217), (5, 3), (1920, 1080)):
+        img = oracle_mod.gen_noise(w, h, 5)
+        want = oracle_mod.nearest(img, 2 * w, 2 * h)
+        frames = [img.tobytes()] * 5
+        for plan in (0, 1, 2, 3):
+            u = nsc.PyWgpuUpscaler("quality", "nearest")
+            u.set_option("single_out_plan", plan)
+            u.initialize(w, h, 2 * w, 2 * h)
+            got = np.frombuffer(u.upscale(img.tobytes()), np.uint8).reshape(2 * h, 2 * w, 4)
+            assert np.array_equal(got, want), (w, h, plan)
+        for chunks in (1, 2, 3, 8):
+            u = nsc.PyWgpuUpscaler("quality", "nearest")
+            u.set_option("batch_out_chunks", chunks)
+            u.initialize(w, h, 2 * w, 2 * h)
+            for out in u.upscale_batch(frames):
+                assert np.array_equal(np.frombuffer(out, np.uint8).reshape(2 * h, 2 * w, 4), want), (w, h, chunks)
+    u = nsc.PyWgpuUpscaler("quality", "nearest")
+    with pytest.raises(Exception):
+        u.set_option("batch_out_chunks", 9)
+    with pytest.raises(Exception):
+        u.set_option("single_out_plan", 4)
+
+
 def test_c_program_through_the_boundary(nsc, tmp_path):
     """A plain C caller (tests/c_abi/abi_upscale.c) upscales and interpolates through libnuscaler_hip.so."""
     import shutil
