@@ -671,26 +671,6 @@ def worker(args):
     if rank == 0 and world == 1 and args.sustained_seconds > 0:
         sustained = sustained_leg(torch, do_step, pipe.upscaler, args.sustained_seconds)
 
-    # Mode (ii): every rank feeds its own GPU from host memory at the same time (any N; never `value`)
-    host_fed = None
-    if args.host_fed_seconds > 0 and not args.no_extras:
-        rate = host_fed_leg(nsc, syn, w, h, local_rank, args.host_fed_seconds, barrier)
-        rates = [rate]
-        if world > 1:
-            tr = torch.tensor([rate], dtype=torch.float64, device=comm_dev)
-            got = [torch.zeros_like(tr) for _ in range(world)]
-            dist.all_gather(got, tr)
-            rates = [float(g.item()) for g in got]
-        frame_mb = (w * h + 4 * w * h) * 4 / 1e6
-        host_fed = {
-            "what": "mode (ii): each rank pushes a host-resident shard (12 pageable 1080p frames per call, outputs into pageable "
-                    "4K buffers) through nus_upscaler_upscale_batch -- one submitting thread + a retiring thread + the copy pool, "
-                    "three slot streams per GPU -- all ranks at the same time, between two barriers",
-            "seconds": args.host_fed_seconds, "frames_4k_per_s_total": round(sum(rates), 1),
-            "frames_4k_per_s_per_gpu": {"min": round(min(rates), 1), "max": round(max(rates), 1)},
-            "host_device_GBps_total": round(sum(rates) * frame_mb / 1e3, 2),
-            "target_4k_frames_per_s_per_gpu": 60}
-
     extras = rank == 0 and world == 1 and not args.no_extras and not args.fused and not args.overlap
 
     def timed_leg(step_fn, n, with_profile=True):
@@ -767,6 +747,27 @@ def worker(args):
     host_path = None
     if extras:
         host_path = host_path_leg(nsc, syn, torch, w, h, local_rank)
+
+    # Mode (ii): every rank feeds its own GPU from host memory at the same time (any N; never `value`).  After the other host
+    # legs: the same place in the process's life as config.host_path's batch figure
+    host_fed = None
+    if args.host_fed_seconds > 0 and not args.no_extras:
+        rate = host_fed_leg(nsc, syn, w, h, local_rank, args.host_fed_seconds, barrier)
+        rates = [rate]
+        if world > 1:
+            tr = torch.tensor([rate], dtype=torch.float64, device=comm_dev)
+            got = [torch.zeros_like(tr) for _ in range(world)]
+            dist.all_gather(got, tr)
+            rates = [float(g.item()) for g in got]
+        frame_mb = (w * h + 4 * w * h) * 4 / 1e6
+        host_fed = {
+            "what": "mode (ii): each rank pushes a host-resident shard (12 pageable 1080p frames per call, outputs into pageable "
+                    "4K buffers) through nus_upscaler_upscale_batch -- one submitting thread + a retiring thread + the copy pool, "
+                    "three slot streams per GPU -- all ranks at the same time, between two barriers",
+            "seconds": args.host_fed_seconds, "frames_4k_per_s_total": round(sum(rates), 1),
+            "frames_4k_per_s_per_gpu": {"min": round(min(rates), 1), "max": round(max(rates), 1)},
+            "host_device_GBps_total": round(sum(rates) * frame_mb / 1e3, 2),
+            "target_4k_frames_per_s_per_gpu": 60}
 
     if rank == 0:
         total_units = n_units * world * args.steps
