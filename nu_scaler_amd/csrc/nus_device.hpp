@@ -53,6 +53,17 @@ __device__ __forceinline__ uint32_t pack_u8_rne(float v, int c, uint32_t acc)
     return __builtin_amdgcn_cvt_pk_u8_f32(v, c, acc);
 }
 
+// p[i] for a wave-uniform index, as a SCALAR load.  Written as `readfirstlane(p[i])` the compiler issues a vector load and
+// waits for vmcnt(0) before the value can be used -- and vector memory operations retire in order, so every store the wave has
+// in flight is drained with it, once per output row in the row-walking kernels (round 3: tools/check_hidden_loads.py lists such
+// waits; k_lanczos3_r32 / _xs / k_resize_win / k_bilinear_table / k_nearest_table all had one).
+template <typename T>
+__device__ __forceinline__ T uniform_load(const T *p, size_t i)
+{
+    typedef const __attribute__((address_space(4))) T *cptr;
+    return ((cptr)(uintptr_t)p)[i];
+}
+
 template <bool EXACT>
 __device__ __forceinline__ float mac(float acc, float v, float w)
 {

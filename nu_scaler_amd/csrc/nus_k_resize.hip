@@ -264,6 +264,28 @@ __global__ __launch_bounds__(256) void k_resize_rows(
 // footprint of factors x1.0 .. x1.4 then still fits 3 columns per lane).
 constexpr int kResizeWinRows = 7; // Lanczos-3 on an upscale touches at most 7 input rows
 
+// Row prefetch of k_resize_win (round 3): as in k_resize_down the rows come through a per-wave LDS-DMA ring -- VC pieces of 64
+// pixels per row, requested kWinDepth window advances ahead from inline assembly (no VGPR destination, invisible to the
+// compiler's s_waitcnt insertion) -- and are waited for with a hand-placed `s_waitcnt vmcnt(N)`.  With ordinary loads the compiler
+// waited for vmcnt(0) -- every store of the wave -- once per output row (tools/check_hidden_loads.py lists such waits).
+#ifndef NUS_WIN_DEPTH
+#define NUS_WIN_DEPTH 2
+#endif
+constexpr int kWinDepth = NUS_WIN_DEPTH;
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm" // m0 is a reserved register: nothing else in this kernel uses it
+__device__ __forceinline__ void win_dma_row4(const void *base, uint32_t off, uint32_t lds)
+{
+    asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dword %0, %1" : : "v"(off), "s"(base), "s"(lds) : "memory", "m0");
+}
+#pragma clang diagnostic pop
+template <int N, int BACK>
+__device__ __forceinline__ void win_wait_vmcnt()
+{
+    static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit counter on gfx9");
+    asm volatile("s_waitcnt vmcnt(%0) ; nus-wait back=%1" : : "n"(N), "n"(BACK) : "memory");
+}
+
 template <bool EXACT, int VC, int UNION, int N>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((UNION > 0 && VC == 3) ? 3 : 1))) void k_resize_win(
     const uint32_t *__restrict__ in, uint32_t *__restrict__ out,
@@ -276,7 +298,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((UNION > 0 
     constexpr int WR = kResizeWinRows;
     static_assert(N == 4 || N == 2, "outputs per lane");
     constexpr uint32_t SEGW = kWave * N;
-    float4 *s_v = reinterpret_cast<float4 *>(smem) + (size_t)threadIdx.y * (ncols_max + kResizeSlack);
+    // The ring serves every shape but the one whose union weights live in LDS (3 columns per lane + union H pass: 51 KB per block,
+    // three blocks per CU; 6 KB of ring would leave room for two: 1080p -> 1800p 18.4 -> 21.9 us).  That shape keeps the next row
+    // in registers, requested one advance ahead with ordinary loads.
+    constexpr bool RING = !(UNION > 0 && VC == 3);
+    constexpr int D = RING ? kWinDepth : 0;
+    // the four waves' row rings first (LDS-DMA takes its LDS address from M0: keep it a small offset), then the rest
+    constexpr size_t ring_bytes = (size_t)4 * D * VC * kWave * sizeof(uint32_t);
+    uint32_t *s_ring = reinterpret_cast<uint32_t *>(smem) + (size_t)threadIdx.y * (D * VC * kWave);
+    const uint32_t ring_lds = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)s_ring);
+    float4 *s_v = reinterpret_cast<float4 *>(smem + ring_bytes) + (size_t)threadIdx.y * (ncols_max + kResizeSlack);
     const GridPos g = xcd_contiguous_pos(); // row blocks that share their window-fill rows behind one L2
     const uint32_t seg = __builtin_amdgcn_readfirstlane(g.x * 4 + threadIdx.y);
     const uint32_t X0 = seg * SEGW;
@@ -302,7 +333,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((UNION > 0 
     // accumulating side by side (each output still receives its terms in tap order: same bits).
     constexpr bool HU_LDS = UNION > 0 && VC == 3;
     float hu[(UNION > 0 && !HU_LDS) ? N : 1][UW];
-    float4 *const s_hu = reinterpret_cast<float4 *>(smem) + (size_t)4 * (ncols_max + kResizeSlack) +
+    float4 *const s_hu = reinterpret_cast<float4 *>(smem + ring_bytes) + (size_t)4 * (ncols_max + kResizeSlack) +
                          (size_t)threadIdx.y * (UW * kWave) + threadIdx.x;
     float wtmp[N][UW];
 #pragma unroll
@@ -362,7 +393,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((UNION > 0 
         for (int m = 0; m < VC; ++m) a &= swz(raw[m], sel);
         return __builtin_amdgcn_ballot_w64(a < 0xFF000000u) == 0ull ? 1u : 0u;
     };
-    int32_t top = __builtin_amdgcn_readfirstlane(lyt[y_begin]);
+    // (scalar loads of the per-row table: a vector load + readfirstlane makes the compiler wait for vmcnt(0) every row)
+    typedef const __attribute__((address_space(4))) int32_t *ci32_p;
+    ci32_p lyt_s = (ci32_p)(uintptr_t)lyt;
+    int32_t top = lyt_s[y_begin];
+    uint32_t col_off[VC]; // byte offset of the lane's column m inside a row
+#pragma unroll
+    for (int m = 0; m < VC; ++m) col_off[m] = col[m] * 4u;
+    auto request_row = [&](int32_t r, uint32_t slot) {
+        const uint32_t rr = (uint32_t)(r < 0 ? 0 : (r > (int32_t)ih - 1 ? (int32_t)ih - 1 : r));
+#pragma unroll
+        for (int m = 0; m < VC; ++m) win_dma_row4(base, rr * (iw * 4u) + col_off[m], ring_lds + (slot * VC + m) * (kWave * 4u));
+    };
     float win[WR][VC * 4];
     uint32_t opq = 0;
     {
@@ -375,12 +417,35 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((UNION > 0 
             cvt(raw[j], win[j]);
         }
     }
-    uint32_t next[VC]; // row top + WR, requested one advance ahead
-    load_row(top + WR, next);
+    // rows top + WR .. top + WR + D - 1, requested D advances ahead; the hand-placed waits of the loop assume that nothing older
+    // than these requests is outstanding
+    uint32_t next[VC]; // !RING: row top + WR, requested one advance ahead
+    if (RING) {
+#pragma unroll
+        for (int k = 0; k < D; ++k) request_row(top + WR + k, (uint32_t)k);
+        win_wait_vmcnt<0, 0>(); // (the count below needs the D stores that follow a request: not yet there for these first rows)
+    } else {
+        load_row(top + WR, next);
+    }
+    uint32_t adv = 0; // window advances so far: row top + WR sits in ring slot adv % D
 
     for (uint32_t y = y_begin; y < y_end; ++y) {
-        const int32_t ly = __builtin_amdgcn_readfirstlane(lyt[y]);
+        const int32_t ly = lyt_s[y];
         if (ly != top) { // wave-uniform; ly == top + 1 (host-checked)
+            // Issued since the request of row top + WR: the VC pieces of the D - 1 rows behind it and at least one store per
+            // output row -- and an advance happens at most once per output row, so at least D stores: with (D - 1) VC + D
+            // instructions allowed outstanding the row has landed (more stores in between make the wait stricter, never looser)
+            if (RING) {
+                const uint32_t slot = adv % (uint32_t)(D > 0 ? D : 1);
+                win_wait_vmcnt<(D > 0 ? (D - 1) * VC + D : 0), (D > 0 ? (D - 1) * VC + 1 : 1)>();
+#pragma unroll
+                for (int m = 0; m < VC; ++m) next[m] = s_ring[(slot * VC + m) * kWave + threadIdx.x];
+                // the slot is requested again only when its reads have RETURNED (nothing orders a queued ds_read behind a later
+                // LDS-DMA write: see k_resize_down)
+                asm volatile("s_waitcnt lgkmcnt(0)" : : : "memory");
+                request_row(ly + WR + D - 1, slot);
+                ++adv;
+            }
 #pragma unroll
             for (int j = 0; j + 1 < WR; ++j)
 #pragma unroll
@@ -388,7 +453,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((UNION > 0 
             if (OP) opq = (opq << 1) | row_opaque(next);
             cvt(next, win[WR - 1]);
             top = ly;
-            load_row(top + WR, next);
+            if (!RING) load_row(top + WR, next);
         }
         const float *wy = wyt + (size_t)y * stride;
         float wv[WR];
@@ -558,7 +623,8 @@ hipError_t launch_resize_win(const UpscaleLaunch &L, const DeviceTables &T, bool
     if (vc == 0 || (L.ow % 4) != 0 || (outputs_per_lane != 4 && outputs_per_lane != 2)) return hipErrorInvalidValue;
     const int uni = (union_taps > 0 && union_taps <= 10) ? 10 : 0; // wider unions: plain 8-slot H pass (VGPR budget)
     // the four waves' rows, then (3 columns per lane with the union H pass) their union weights: [tap][64] float4 per wave
-    const size_t lds = (size_t)4 * (ncols_max + kResizeSlack) * sizeof(float4) +
+    const size_t lds = ((vc == 3 && uni) ? 0 : (size_t)4 * kWinDepth * vc * kWave * sizeof(uint32_t)) + // (the row rings: see the kernel)
+                       (size_t)4 * (ncols_max + kResizeSlack) * sizeof(float4) +
                        ((vc == 3 && uni) ? (size_t)4 * uni * kWave * sizeof(float4) : 0);
     const uint32_t segw = 64 * outputs_per_lane;
     return for_frame_chunks(L, [&](const uint8_t *in, uint8_t *out, uint32_t n) {

@@ -40,7 +40,7 @@ __global__ __launch_bounds__(256) void k_nearest_table(
     }
     uint32_t have = 0xffffffffu;
     for (uint32_t y = y_begin; y < y_end; ++y) {
-        const uint32_t r = __builtin_amdgcn_readfirstlane(sy[y]);
+        const uint32_t r = uniform_load(sy, y);
         if (r != have) { // wave-uniform
             const uint32_t *src = base + (size_t)r * iw;
 #pragma unroll
@@ -144,9 +144,9 @@ __global__ __launch_bounds__(256) void k_bilinear_table(
     float ht[N * 4], hb[N * 4]; // lerped source rows top_row / bot_row
     uint32_t top_row = 0xffffffffu, bot_row = 0xffffffffu;
     for (uint32_t y = y_begin; y < y_end; ++y) {
-        const uint32_t y0 = __builtin_amdgcn_readfirstlane(y0t[y]);
+        const uint32_t y0 = uniform_load(y0t, y);
         const uint32_t y1 = umin(y0 + 1, ih - 1);
-        float dy = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(fyt[y])));
+        float dy = uniform_load(fyt, y);
         asm volatile("" : "+v"(dy)); // VGPR copy: scalar operands halve the VALU issue rate
         const float ndy = 1.0f - dy;
         if (y0 != top_row) { // wave-uniform
@@ -367,7 +367,7 @@ __global__ __launch_bounds__(256) void k_bilinear_ratio(
             if (p * Q % P == 0) {
                 emit(P * m + p, h[p * Q / P]); // top * (1 - 0) + bottom * 0
             } else {
-                float dy = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(fyt[P * m + p])));
+                float dy = uniform_load(fyt, (size_t)(P * m + p));
                 asm volatile("" : "+v"(dy)); // VGPR copy: scalar operands halve the VALU issue rate
                 const float ndy = 1.0f - dy;
                 float v[4 * P];

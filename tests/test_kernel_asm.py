@@ -110,6 +110,39 @@ def test_lanczos_xs_row_ring_waits():
         assert r["requests"] == 3 and r["hand_waits"] == 2, (name, r["requests"], r["hand_waits"])  # first D = 2 + 1 per step; drain + 1
 
 
+def test_resize_win_row_ring_waits():
+    """k_resize_win (every up-scaling factor without a kernel of its own): rows through an LDS-DMA ring, requested two window
+    advances ahead; the one hand-placed wait relies on at least D stores between a request and its use (an advance happens at most
+    once per output row): never fewer on any path, no compiler-placed vmcnt wait left in the loop.  The shape whose union weights
+    fill the LDS (3 columns per lane + union H pass) keeps ordinary loads and has no hidden requests."""
+    import re
+
+    import check_hidden_loads as chk
+
+    out = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-x", "hip",
+                          "--cuda-device-only", "-S", "-I", CSRC, "-I", os.path.join(ROOT, "include"), "-o", "-",
+                          os.path.join(CSRC, "nus_k_resize.hip")], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr
+    bodies = list(chk.kernel_bodies(out.stdout, "k_resize_winIL"))
+    assert len(bodies) == 16, len(bodies)  # EXACT x VC {2, 3} x UNION {0, 10} x N {4, 2}
+    ringed = 0
+    for name, body in bodies:
+        vc, uni = (int(v) for v in re.search(r"k_resize_winILb[01]ELi(\d)ELi(\d+)E", name).groups())
+        r = chk.check(body, cap=16, kmax=8)
+        assert r["errors"] == [], (name, r["errors"][:3])
+        if vc == 3 and uni:
+            assert r["requests"] == 0 and r["hand_waits"] == 0, name
+            continue
+        ringed += 1
+        assert r["requests"] == 3 * vc and r["hand_waits"] == 2, (name, r["requests"], r["hand_waits"])  # first 2 rows + 1 per advance
+        assert r["compiler_vmcnt_waits_in_loops"] == [], (name, r["compiler_vmcnt_waits_in_loops"][:3])
+        for t, counts in r["waits_not_tight"].items():
+            n = int(re.search(r"vmcnt\((\d+)\)", t).group(1))
+            assert min(counts) >= n, (name, t, counts)
+        assert re.search(r"s_waitcnt lgkmcnt\(0\)[^\n]*\n(?:[^\n]*\n){0,16}?[^\n]*global_load_lds_dword", body), name
+    assert ringed == 12
+
+
 def test_resize_down_row_ring_waits():
     """k_resize_down's LDS-DMA row ring (footprints of up to two columns per lane): its one hand-placed wait per row must retire
     the row it is about to read on every path -- stores of completed output rows sit between the requests on some paths only, so

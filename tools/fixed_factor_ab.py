@@ -19,7 +19,7 @@ def worker(iw, ih, ow, oh, n, ths):
     s = torch.cuda.current_stream().cuda_stream
     out = torch.empty((n, oh, ow, 4), dtype=torch.uint8, device=dev)
     res = []
-    warm = nsc.PyWgpuUpscaler("quality", "lanczos3")  # clocks and caches settle before the first timed configuration
+    warm = nsc.PyWgpuUpscaler("quality", os.environ.get("NUS_AB_ALG", "lanczos3"))  # clocks and caches settle before the first timed configuration
     warm.initialize(iw, ih, ow, oh)
     frames = syn.gradient_stream_torch(n, iw, ih, dev)
     for _ in range(20):
@@ -28,7 +28,7 @@ def worker(iw, ih, ow, oh, n, ths):
     for pat, gen in (("gradient", syn.gradient_stream_torch), ("noise", syn.noise_stream_torch)):
         frames = gen(n, iw, ih, dev)
         for th in ths:
-            u = nsc.PyWgpuUpscaler("quality", "lanczos3")
+            u = nsc.PyWgpuUpscaler("quality", os.environ.get("NUS_AB_ALG", "lanczos3"))
             if th:
                 u.set_option("rows_per_wave", th)
             u.initialize(iw, ih, ow, oh)
