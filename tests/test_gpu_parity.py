@@ -1203,6 +1203,35 @@ def test_resize_down_segment_widths(nsc, oracle_mod, dims):
         u.set_option("down_seg_width", 58)  # before initialize only
 
 
+@pytest.mark.parametrize("dims", [((464, 128), (232, 64)), ((300, 157), (150, 78)), ((384, 216), (256, 144)), ((256, 200), (200, 150))])
+def test_resize_down_opaque_and_mixed_alpha_rows(nsc, oracle_mod, dims):
+    """FMA mode of the down-scaling kernel on opaque frames, frames whose alpha starts at some row (inside a window, inside a row
+    block) and a single transparent pixel: the bits of the LDS-row kernel, within 1 LSB of the oracle; opaque in, opaque out.
+    (Written for a 3-channel path for opaque frames -- three channels and one alpha sum per slot until the first row with real
+    alpha -- which was built in round 3 and measured SLOWER, 18.0 -> 23.2 us per 4K -> 1080p frame, 19.9 -> 35.4 with alpha:
+    profiles/r03_resize_down_opaque_path_ab.txt; the test stays as the guard for any later attempt.)"""
+    (w, h), (ow, oh) = dims
+    base = oracle_mod.gen_noise(w, h, 41)
+    cases = {"opaque": base.copy(), "alpha_from_row": base.copy(), "one_pixel": base.copy(), "alpha_top_only": base.copy()}
+    cases["opaque"][..., 3] = 255
+    cases["alpha_from_row"][: h // 2 + 3, :, 3] = 255
+    cases["one_pixel"][..., 3] = 255
+    cases["one_pixel"][h // 3, w // 2, 3] = 7
+    cases["alpha_top_only"][5:, :, 3] = 255
+    for name, img in cases.items():
+        got, u = _up(nsc, "lanczos3", img, ow, oh)
+        assert u.kernel_variant == "resize_down_stream"
+        ref, ur = _up(nsc, "lanczos3", img, ow, oh, options={"force_rows": 1})
+        assert ur.kernel_variant == "resize_rows_lds"
+        assert np.array_equal(got, ref), (name, dims, _maxdiff(got, ref))
+        assert _maxdiff(got, oracle_mod.resize(img, ow, oh, 0)) <= 1, name
+        if name == "opaque":
+            assert (got[..., 3] == 255).all()
+        for sw in (64, 40):
+            got_w, _ = _up(nsc, "lanczos3", img, ow, oh, options={"down_seg_width": sw})
+            assert np.array_equal(got_w, ref), (name, dims, sw)
+
+
 @pytest.mark.parametrize("seed", [1, 2, 3])
 def test_resize_down_random_shapes(nsc, oracle_mod, seed):
     """Random down-scaling shapes (ratios 1.02 .. 4.7 per axis, widths around the 64-column segment sizes, heights
