@@ -121,6 +121,11 @@ int HipUpscaler::set_option(const char *key, int64_t value)
         force_rows_ = value != 0;
         return kOk;
     }
+    if (!strcmp(key, "single_bands")) { // 1: a frame alone in the pipeline goes through it in row bands (default), 0: whole
+        if (value != 0 && value != 1) return fail(kInvalidArgument, "single_bands must be 0 or 1");
+        single_bands_ = (int)value;
+        return kOk;
+    }
     if (!strcmp(key, "single_out_plan")) { // how upscale() cuts a pageable output frame into D2H pieces (plan_chunks)
         if (value < 0 || value > 3) return fail(kInvalidArgument, "single_out_plan out of range");
         single_out_plan_ = (int)value;
@@ -538,12 +543,35 @@ int HipUpscaler::initialize(uint32_t in_w, uint32_t in_h, uint32_t out_w, uint32
     return kOk;
 }
 
+// rows per wave of the x2 resize kernel when the caller has not set them: enough waves to fill 256 CUs a few times over, tall
+// enough to amortise the 6 halo rows
+uint32_t HipUpscaler::lanczos_x2_rows_per_wave(uint32_t n_frames, bool unit) const
+{
+    if (rows_per_wave_) return rows_per_wave_;
+    const uint64_t nstrips = (iw_ + kLanczosX2StripCols - 1) / kLanczosX2StripCols;
+    const uint64_t rows_total = (uint64_t)ih_ * nstrips * n_frames * (unit ? 2 : 1);
+    const uint64_t t = rows_total / 8192;
+    return (uint32_t)(t < 8 ? 8 : (t > 36 ? 36 : t));
+}
+
+uint32_t HipUpscaler::band_alignment(uint32_t n_frames) const
+{
+    switch (variant_) {
+    case Variant::LanczosX2RegWin: return lanczos_x2_rows_per_wave(n_frames, false);
+    case Variant::NearestX2:
+    case Variant::BilinearX2Int: return 4;
+    default: return 0;
+    }
+}
+
 int HipUpscaler::enqueue(const uint8_t *d_in, uint8_t *d_out, uint32_t n_frames, hipStream_t stream, const BlendSrc *blend,
-                         const UnitDst *unit)
+                         const UnitDst *unit, uint32_t row0, uint32_t rows)
 {
     UpscaleLaunch L;
     L.in = d_in;
     L.out = d_out;
+    L.row0 = row0;
+    L.rows = rows;
     L.iw = iw_;
     L.ih = ih_;
     L.ow = ow_;
@@ -636,14 +664,7 @@ int HipUpscaler::enqueue(const uint8_t *d_in, uint8_t *d_out, uint32_t n_frames,
         break;
     }
     case Variant::LanczosX2RegWin: {
-        uint32_t th = rows_per_wave_;
-        if (th == 0) {
-            // enough waves to fill 256 CUs a few times over, tall enough to amortise the 6 halo rows
-            const uint64_t nstrips = (iw_ + kLanczosX2StripCols - 1) / kLanczosX2StripCols;
-            const uint64_t rows_total = (uint64_t)ih_ * nstrips * n_frames * (unit ? 2 : 1);
-            uint64_t t = rows_total / 8192;
-            th = (uint32_t)(t < 8 ? 8 : (t > 36 ? 36 : t));
-        }
+        const uint32_t th = lanczos_x2_rows_per_wave(n_frames, unit != nullptr);
         if (unit) {
             UnitOutputs U;
             U.out_mid = unit->out_mid;
@@ -794,6 +815,8 @@ int HipUpscaler::ensure_slot(Slot &S, size_t in_bytes, size_t out_bytes)
         NUS_HIP(hipEventCreateWithFlags(&S.in_done, hipEventDisableTiming));
         NUS_HIP(hipEventCreateWithFlags(&S.out_done, hipEventDisableTiming));
         for (hipEvent_t &ev : S.chunk_done) NUS_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        for (hipEvent_t &ev : S.band_in) NUS_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        for (hipEvent_t &ev : S.band_k) NUS_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
         NUS_HIP(hipHostMalloc(reinterpret_cast<void **>(&S.h_in), in_bytes, hipHostMallocDefault));
         NUS_HIP(hipHostMalloc(reinterpret_cast<void **>(&S.h_out), out_bytes, hipHostMallocDefault));
         NUS_HIP(hipMalloc(reinterpret_cast<void **>(&S.d_out), out_bytes));
@@ -816,6 +839,10 @@ void HipUpscaler::release_slot(Slot &s)
     for (hipEvent_t ev : {s.k_begin, s.k_end, s.in_done, s.out_done})
         if (ev) (void)hipEventDestroy(ev);
     for (hipEvent_t ev : s.chunk_done)
+        if (ev) (void)hipEventDestroy(ev);
+    for (hipEvent_t ev : s.band_in)
+        if (ev) (void)hipEventDestroy(ev);
+    for (hipEvent_t ev : s.band_k)
         if (ev) (void)hipEventDestroy(ev);
     s = Slot();
 }
@@ -854,9 +881,66 @@ void HipUpscaler::plan_chunks(Slot &S, size_t out_bytes, bool alone) const
     }
 }
 
+// The same for a frame that is alone in the pipeline, band by band (see kBands): band b is rows [k0, k1) of the input, a
+// multiple of `align` rows; its upload carries the tap rows the kernel reads below k1 (kBandHalo, and the band after it starts
+// that much later), its download is output rows [2 k0, 2 k1) in two pieces.
+int HipUpscaler::submit_frame_banded(Slot &S, const uint8_t *in, uint8_t *out, bool *direct, uint32_t align)
+{
+    constexpr uint32_t kBandHalo = 4; // >= 3 tap rows below a row (Lanczos-3 at x2), 1 for bilinear
+    const size_t in_row = (size_t)iw_ * 4, out_row = (size_t)ow_ * 4, out_bytes = out_row * oh_;
+    const uint32_t band_rows = ((ih_ + kBands - 1) / kBands + align - 1) / align * align;
+    const bool in_pinned = is_pinned_host(in);
+    *direct = is_pinned_host(out);
+    S.nchunks = 0;
+    int b = 0;
+    for (uint32_t k0 = 0; k0 < ih_; k0 += band_rows, ++b) {
+        const uint32_t k1 = k0 + band_rows < ih_ ? k0 + band_rows : ih_;
+        const uint32_t h0 = k0 == 0 ? 0 : (k0 + kBandHalo < ih_ ? k0 + kBandHalo : ih_);
+        const uint32_t h1 = k1 == ih_ ? ih_ : (k1 + kBandHalo < ih_ ? k1 + kBandHalo : ih_);
+        if (h1 > h0) {
+            const size_t off = (size_t)h0 * in_row, len = (size_t)(h1 - h0) * in_row;
+            if (!in_pinned) parallel_copy(S.h_in + off, in + off, len);
+            NUS_HIP(hipMemcpyAsync(S.d_in + off, (in_pinned ? in : S.h_in) + off, len, hipMemcpyHostToDevice, s_in_));
+        }
+        NUS_HIP(hipEventRecord(S.band_in[b], s_in_));
+        NUS_HIP(hipStreamWaitEvent(s_k_, S.band_in[b], 0));
+        if (b == 0) NUS_HIP(hipEventRecord(S.k_begin, s_k_));
+        const int rc = enqueue(S.d_in, S.d_out, 1, s_k_, nullptr, nullptr, k0, k1 - k0);
+        if (rc != kOk) return rc;
+        if (k1 == ih_) NUS_HIP(hipEventRecord(S.k_end, s_k_));
+        NUS_HIP(hipEventRecord(S.band_k[b], s_k_));
+        NUS_HIP(hipStreamWaitEvent(s_out_, S.band_k[b], 0));
+        const size_t o0 = (size_t)2 * k0 * out_row, o1 = (size_t)2 * k1 * out_row;
+        if (*direct) {
+            NUS_HIP(hipMemcpyAsync(out + o0, S.d_out + o0, o1 - o0, hipMemcpyDeviceToHost, s_out_));
+        } else {
+            const size_t mid = (o0 + (o1 - o0) / 2 + 4095) & ~(size_t)4095;
+            const size_t ends[2] = {mid < o1 ? mid : o1, o1};
+            size_t off = o0;
+            for (size_t e : ends) {
+                if (e <= off) continue;
+                NUS_HIP(hipMemcpyAsync(S.h_out + off, S.d_out + off, e - off, hipMemcpyDeviceToHost, s_out_));
+                NUS_HIP(hipEventRecord(S.chunk_done[S.nchunks], s_out_));
+                S.chunk_end[S.nchunks++] = e;
+                off = e;
+            }
+        }
+    }
+    (void)out_bytes;
+    NUS_HIP(hipEventRecord(S.in_done, s_in_));
+    NUS_HIP(hipEventRecord(S.out_done, s_out_));
+    S.used = true;
+    return kOk;
+}
+
 int HipUpscaler::submit_frame(Slot &S, const uint8_t *in, uint8_t *out, bool *direct, bool alone)
 {
     const size_t in_bytes = (size_t)iw_ * ih_ * 4, out_bytes = (size_t)ow_ * oh_ * 4;
+    if (alone && single_bands_ && !profiling_ && out_bytes >= ((size_t)8 << 20)) {
+        const uint32_t align = band_alignment(1);
+        if (align && (uint64_t)align * kBands * 2 <= ih_ && ow_ == 2 * iw_ && oh_ == 2 * ih_)
+            return submit_frame_banded(S, in, out, direct, align);
+    }
     const uint8_t *src = in;
     if (!is_pinned_host(src)) {
         parallel_copy(S.h_in, src, in_bytes);

@@ -128,6 +128,11 @@ private:
     // buffer overlaps the DMA of the next piece (the reference maps, copies to a Vec and copies again:
     // upscale/mod.rs:1040-1057, lib.rs:111).
     static constexpr int kOutChunks = 8;
+    // A frame that is alone in the pipeline (trait Upscaler::upscale) goes through it in kBands row bands where the kernel can
+    // be launched on a row range (the exact-x2 kernels): staging copy, H2D and kernel of band b+1 run while band b's output is
+    // already on its way back, so the D2H engine -- what bounds the call -- starts after a quarter of the upload instead of all
+    // of it (option "single_bands": 0 turns it off).
+    static constexpr int kBands = 4;
     struct Slot {
         uint8_t *d_in = nullptr, *d_out = nullptr; // HBM
         uint8_t *h_in = nullptr, *h_out = nullptr; // pinned staging
@@ -136,6 +141,7 @@ private:
         hipEvent_t chunk_done[kOutChunks] = {};     // D2H of output chunk k has landed in h_out    (copy-out stream)
         hipEvent_t out_done = nullptr;              // ... of the whole frame
         bool used = false;                          // events have been recorded at least once
+        hipEvent_t band_in[kBands] = {}, band_k[kBands] = {}; // banded single frame: H2D / kernel of band b done
         int nchunks = 0;                            // pieces of the frame in flight (pageable output) ...
         size_t chunk_end[kOutChunks] = {};          // ... and where each ends (set by submit_frame, read by retire_frame)
     };
@@ -146,6 +152,10 @@ private:
     int single_out_plan_ = 0;   // option "single_out_plan": 0 = 8 equal pieces (rounds 1-2), 1 = 1/2 1/4 1/8 1/8, 2 = 1/2 1/4 1/8 1/16 1/16, 3 = 4 equal
     int batch_out_chunks_ = 2;  // option "batch_out_chunks": equal pieces per frame of upscale_batch / the stream ring
     void plan_chunks(Slot &s, size_t out_bytes, bool alone) const;
+    int single_bands_ = 1;      // option "single_bands"
+    uint32_t band_alignment(uint32_t n_frames) const; // rows a band must be a multiple of; 0 = the variant has no row-range launch
+    uint32_t lanczos_x2_rows_per_wave(uint32_t n_frames, bool unit) const;
+    int submit_frame_banded(Slot &s, const uint8_t *in, uint8_t *out, bool *direct, uint32_t align);
     // "one host thread + 3 streams per GPU": every H2D goes down the copy-in stream, every kernel down the compute stream,
     // every D2H down the copy-out stream, tied together per frame by the slot's events -- so the copies of consecutive frames
     // sit back to back in ONE queue per direction (0.60 ms per 4K frame on the D2H engine) instead of alternating between the
@@ -194,7 +204,7 @@ private:
         uint8_t *out_mid = nullptr, *mid = nullptr;
     };
     int enqueue(const uint8_t *d_in, uint8_t *d_out, uint32_t n_frames, hipStream_t stream, const BlendSrc *blend = nullptr,
-                const UnitDst *unit = nullptr);
+                const UnitDst *unit = nullptr, uint32_t row0 = 0, uint32_t rows = 0);
 
     mutable std::mutex mu_;
     Quality quality_;

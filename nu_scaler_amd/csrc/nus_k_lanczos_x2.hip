@@ -29,6 +29,7 @@ struct LanczosX2Args {
     uint8_t *out_mid;
     uint8_t *mid;
     uint32_t nframes, order;
+    uint32_t rb0; // plain kernels: first row block of the launch (UpscaleLaunch::row0 / th); nrowblocks counts from there
 };
 
 // Input rows of the x2 kernels.  BLEND 0: the frame itself.  BLEND 1 / 2: the zero-flow in-between
@@ -522,7 +523,7 @@ __global__ __launch_bounds__(256) void k_lanczos3_x2(const LanczosX2Args A)
         const uint32_t wave = __builtin_amdgcn_readfirstlane((vid % gridDim.x) * 4 + (threadIdx.x >> 6));
         if (wave >= A.nstrips * A.nrowblocks) return;
         strip = wave % A.nstrips;
-        rb = wave / A.nstrips;
+        rb = wave / A.nstrips + A.rb0;
     }
     const int c = (int)(strip * kLanczosX2StripCols) - 4 + lane * 4; // first input column of this lane
     int cl = c < 0 ? 0 : c;
@@ -673,6 +674,7 @@ struct LanczosX2EdgeArgs {
     float wx[2][48]; // [side][output column 0..7 of that side][tap 0..5], phase frame, 0 outside the image
     uint32_t iw, ih;
     size_t in_frame_bytes, in_b_frame_bytes, out_frame_bytes;
+    uint32_t row0, row_end; // input rows of this launch (UpscaleLaunch::row0 / rows)
 };
 
 __device__ __forceinline__ uint32_t px_of(const uint4 (&row)[2], int col)
@@ -738,8 +740,8 @@ __device__ __forceinline__ void lanczos_x2_edge_rows(const LanczosX2EdgeArgs &A,
 template <bool EXACT, int BLEND>
 __global__ __launch_bounds__(64) void k_lanczos3_x2_edges(const LanczosX2EdgeArgs A)
 {
-    const int r = (int)(blockIdx.x * kWave + threadIdx.x);
-    if (r >= (int)A.ih) return;
+    const int r = (int)(A.row0 + blockIdx.x * kWave + threadIdx.x);
+    if (r >= (int)A.row_end) return;
     const int side = blockIdx.y; // 0: left, 1: right (wave-uniform)
     const int col0 = side ? (int)A.iw - 8 : 0;
     const int rmax = (int)A.ih - 1;
@@ -776,6 +778,14 @@ hipError_t launch_lanczos_x2(const UpscaleLaunch &L, const DeviceTables &T, bool
     A.nstrips = cdiv(L.iw, kLanczosX2StripCols);
     A.th = rows_per_wave ? rows_per_wave : 32;
     A.nrowblocks = cdiv(L.ih, A.th);
+    A.rb0 = 0;
+    if (L.rows) { // a band of the frame: whole row blocks from row0 on (the last block of the frame may be short)
+        if (L.row0 % A.th != 0 || L.row0 >= L.ih) return hipErrorInvalidValue;
+        const uint32_t row_end = L.row0 + L.rows < L.ih ? L.row0 + L.rows : L.ih;
+        if (row_end != L.ih && row_end % A.th != 0) return hipErrorInvalidValue;
+        A.rb0 = L.row0 / A.th;
+        A.nrowblocks = cdiv(row_end - L.row0, A.th);
+    }
     A.in_frame_bytes = L.in_stride ? L.in_stride : (size_t)L.iw * L.ih * 4;
     A.in_b_frame_bytes = L.in_b_stride;
     A.out_frame_bytes = (size_t)L.ow * L.oh * 4;
@@ -858,12 +868,14 @@ hipError_t launch_lanczos_x2_edges(const UpscaleLaunch &L, const DeviceTables &T
     A.out_frame_bytes = (size_t)L.ow * L.oh * 4;
     A.t = L.blend_t;
     A.sel = L.in_sel;
+    A.row0 = L.rows ? L.row0 : 0;
+    A.row_end = L.rows ? (L.row0 + L.rows < L.ih ? L.row0 + L.rows : L.ih) : L.ih;
     const int blend = L.in_b == nullptr ? 0 : (L.blend_t == 0.5f ? 1 : 2);
     return for_frame_chunks(L, [&](const uint8_t *in, uint8_t *out, uint32_t n) {
         A.in = in;
         A.in_b = L.in_b ? L.in_b + chunk_first_frame(L, in) * L.in_b_stride : nullptr;
         A.out = out;
-        const dim3 block(kWave), grid(cdiv(L.ih, kWave), 2, n);
+        const dim3 block(kWave), grid(cdiv(A.row_end - A.row0, kWave), 2, n);
 #define NUS_LZE(E, B) hipLaunchKernelGGL((k_lanczos3_x2_edges<E, B>), grid, block, 0, L.stream, A)
         if (exact) {
             if (blend == 0) NUS_LZE(true, 0); else if (blend == 1) NUS_LZE(true, 1); else NUS_LZE(true, 2);

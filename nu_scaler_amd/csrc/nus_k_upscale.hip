@@ -62,11 +62,11 @@ __global__ __launch_bounds__(256) void k_nearest_table(
 // gfx950 costs a write-heavy stream with reads in it a third of its rate (tools/probe_rw_mix.hip).
 __global__ __launch_bounds__(256) void k_nearest_x2(
     const uint32_t *__restrict__ in, uint32_t *__restrict__ out,
-    uint32_t iw, uint32_t ih, size_t in_frame_px, size_t out_frame_px, uint32_t sel)
+    uint32_t iw, uint32_t ih, size_t in_frame_px, size_t out_frame_px, uint32_t sel, uint32_t row0, uint32_t row_end)
 {
-    const uint32_t r = __builtin_amdgcn_readfirstlane(blockIdx.y * 4 + threadIdx.y);
+    const uint32_t r = __builtin_amdgcn_readfirstlane(row0 + blockIdx.y * 4 + threadIdx.y);
     const uint32_t k0 = blockIdx.x * 256;
-    if (r >= ih) return;
+    if (r >= row_end) return; // (row_end <= ih)
     const uint32_t ow = iw * 2;
     const uint32_t *src = in + (size_t)blockIdx.z * in_frame_px + (size_t)r * iw;
     uint32_t *d = out + (size_t)blockIdx.z * out_frame_px + (size_t)(2 * r) * ow;
@@ -212,11 +212,11 @@ __device__ __forceinline__ uint32_t avg4_u8x4(uint32_t a, uint32_t b, uint32_t c
 // Each lane: 4 input pixels of rows r and r+1 -> 8x2 output pixels.
 __global__ __launch_bounds__(256) void k_bilinear_x2_int(
     const uint32_t *__restrict__ in, uint32_t *__restrict__ out,
-    uint32_t iw, uint32_t ih, size_t in_frame_px, size_t out_frame_px, uint32_t sel)
+    uint32_t iw, uint32_t ih, size_t in_frame_px, size_t out_frame_px, uint32_t sel, uint32_t row0, uint32_t row_end)
 {
-    const uint32_t r = __builtin_amdgcn_readfirstlane(blockIdx.y * 4 + threadIdx.y);
+    const uint32_t r = __builtin_amdgcn_readfirstlane(row0 + blockIdx.y * 4 + threadIdx.y);
     const uint32_t k = (blockIdx.x * kWave + threadIdx.x) * 4;
-    if (r >= ih || k >= iw) return;
+    if (r >= row_end || k >= iw) return; // (row_end <= ih; row r + 1 is read from the frame, clamped at ITS last row)
     const uint32_t ow = iw * 2;
     const uint32_t r1 = umin(r + 1, ih - 1);
     const uint32_t k4 = umin(k + 4, iw - 1);
@@ -470,9 +470,10 @@ hipError_t launch_nearest_x2(const UpscaleLaunch &L)
 {
     const size_t ipx = (size_t)L.iw * L.ih, opx = (size_t)L.ow * L.oh;
     return for_frame_chunks(L, [&](const uint8_t *in, uint8_t *out, uint32_t n) {
-        const dim3 block(kWave, 4), grid(cdiv(L.iw, 256), cdiv(L.ih, 4), n);
+        const uint32_t r0 = L.rows ? L.row0 : 0, r1 = L.rows ? (L.row0 + L.rows < L.ih ? L.row0 + L.rows : L.ih) : L.ih;
+        const dim3 block(kWave, 4), grid(cdiv(L.iw, 256), cdiv(r1 - r0, 4), n);
         hipLaunchKernelGGL(k_nearest_x2, grid, block, 0, L.stream, reinterpret_cast<const uint32_t *>(in),
-                           reinterpret_cast<uint32_t *>(out), L.iw, L.ih, ipx, opx, L.in_sel);
+                           reinterpret_cast<uint32_t *>(out), L.iw, L.ih, ipx, opx, L.in_sel, r0, r1);
     });
 }
 
@@ -518,9 +519,10 @@ hipError_t launch_bilinear_x2_int(const UpscaleLaunch &L)
 {
     const size_t ipx = (size_t)L.iw * L.ih, opx = (size_t)L.ow * L.oh;
     return for_frame_chunks(L, [&](const uint8_t *in, uint8_t *out, uint32_t n) {
-        const dim3 block(kWave, 4), grid(cdiv(L.iw, 256), cdiv(L.ih, 4), n);
+        const uint32_t r0 = L.rows ? L.row0 : 0, r1 = L.rows ? (L.row0 + L.rows < L.ih ? L.row0 + L.rows : L.ih) : L.ih;
+        const dim3 block(kWave, 4), grid(cdiv(L.iw, 256), cdiv(r1 - r0, 4), n);
         hipLaunchKernelGGL(k_bilinear_x2_int, grid, block, 0, L.stream, reinterpret_cast<const uint32_t *>(in),
-                           reinterpret_cast<uint32_t *>(out), L.iw, L.ih, ipx, opx, L.in_sel);
+                           reinterpret_cast<uint32_t *>(out), L.iw, L.ih, ipx, opx, L.in_sel, r0, r1);
     });
 }
 

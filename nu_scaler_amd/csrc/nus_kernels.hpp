@@ -64,6 +64,11 @@ struct UpscaleLaunch {
     size_t in_b_stride = 0;
     float blend_t = 0.5f;
     uint32_t in_sel = kSelRGBA; // input channel order
+    // Exact-x2 kernels only (nearest, bilinear, the resize filters): input rows [row0, row0 + rows) of the frame instead of all
+    // of it (rows == 0: all).  The kernels still see the whole frame -- tap rows beyond the range are read, not clamped -- so the
+    // host path can upscale a frame band by band while the rest of it is still on the bus (HipUpscaler::upscale).  row0 must be
+    // a multiple of the kernel's rows per wave (launch_lanczos_x2's rows_per_wave; 4 for the others).
+    uint32_t row0 = 0, rows = 0;
 };
 
 // Kernel variants (chosen once at initialize).

@@ -1286,6 +1286,36 @@ def test_resize_down_4k_to_1080p_batch(nsc, oracle_mod):
         assert np.array_equal(got[k], np.frombuffer(r.upscale(frames[k].tobytes()), np.uint8).reshape(oh, ow, 4)), k
 
 
+@pytest.mark.parametrize("alg", ["nearest", "bilinear", "lanczos3", "bicubic"])
+def test_single_frame_in_row_bands(nsc, oracle_mod, alg):
+    """upscale() of one frame through the exact-x2 kernels goes band by band (option single_bands, on by default for outputs of
+    8 MB and more): the same bytes as the whole-frame path and the oracle's, for heights that are no multiple of anything, rows
+    per wave set by the caller, pinned and pageable buffers."""
+    for (w, h) in ((1024, 1027), (1600, 700)):
+        img = oracle_mod.gen_noise(w, h, 61)
+        ow, oh = 2 * w, 2 * h
+        whole, uw = _up(nsc, alg, img, ow, oh, options={"single_bands": 0})
+        if alg == "nearest":
+            assert np.array_equal(whole, oracle_mod.nearest(img, ow, oh))
+        elif alg == "bilinear":
+            assert np.array_equal(whole, oracle_mod.bilinear(img, ow, oh))
+        for th in (0, 7, 24, 40):
+            opts = {"single_bands": 1}
+            if th and alg in ("lanczos3", "bicubic"):
+                opts["rows_per_wave"] = th
+            got, u = _up(nsc, alg, img, ow, oh, options=opts)
+            assert u.kernel_variant == uw.kernel_variant
+            assert np.array_equal(got, whole), (alg, w, h, th, _maxdiff(got, whole))
+        u = nsc.PyWgpuUpscaler("quality", alg)
+        u.initialize(w, h, ow, oh)
+        src, dst = bytearray(img.tobytes()), bytearray(u.output_size)
+        with nsc.PinnedBuffer(src), nsc.PinnedBuffer(dst):
+            u.upscale_into(src, dst)
+        assert np.array_equal(np.frombuffer(dst, np.uint8).reshape(oh, ow, 4), whole), (alg, "pinned")
+    with pytest.raises(Exception):
+        nsc.PyWgpuUpscaler("quality", alg).set_option("single_bands", 2)
+
+
 def test_output_piece_plans_give_the_same_bytes(nsc, oracle_mod):
     """A pageable output frame comes back in pieces (options single_out_plan for upscale(), batch_out_chunks for upscale_batch and
     the stream ring): every plan returns the same bytes, on a frame whose size is no multiple of anything and on a tiny one."""

@@ -23,6 +23,22 @@ def make(**opts):
 
 
 for rep in range(2):
+    for alg in ("lanczos3", "bilinear"):
+        line = []
+        for bands in (0, 1):
+            u = nsc.PyWgpuUpscaler("quality", alg)
+            u.set_option("single_bands", bands)
+            u.initialize(w, h, 2 * w, 2 * h)
+            out = bytearray(u.output_size)
+            u.upscale_into(frames[0], out)
+            best, ts = 1e9, []
+            for _ in range(4):
+                t0 = time.perf_counter()
+                for i in range(12):
+                    u.upscale_into(frames[i], out)
+                best = min(best, (time.perf_counter() - t0) / 12)
+            line.append(f"single_bands {bands}: {best*1e3:.3f}")
+        print(f"upscale() {alg:9s} " + "   ".join(line), flush=True)
     line = []
     for plan in (0, 1, 2, 3):
         u = make(single_out_plan=plan)
