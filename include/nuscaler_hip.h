@@ -146,7 +146,10 @@ int nus_upscaler_set_lanczos_mode(nus_upscaler *h, int mode);
  * fast path), "force_per_pixel" (0/1, before initialize: resize without the LDS row kernel),
  * "force_rows" (0/1, before initialize: resize without the register-window variant of it),
  * "rows_per_wave" (fixed-factor resize kernels: input rows per wave, 0 = auto), "unit_order" (below),
- * "down_seg_width" (0..64, before initialize: output columns per wave of the down-scaling kernel, 0 = auto). */
+ * "down_seg_width" (0..64, before initialize: output columns per wave of the down-scaling kernel, 0 = auto),
+ * host path: "single_bands" (1 = nus_upscaler_upscale sends one frame through the pipeline in row bands where the
+ * kernel allows it, default; 0 = whole), "single_out_plan" (0..3) / "batch_out_chunks" (1..8): how a pageable
+ * output frame is cut into device-to-host pieces when it is alone in the pipeline / has others behind it. */
 int nus_upscaler_set_option(nus_upscaler *h, const char *key, int64_t value);
 /* Channel order of the input frames.  Captured frames arrive as BGRA and the reference swizzles them
  * on the CPU before upscaling (nu_scaler_core/src/lib.rs:251-270); with NUS_FORMAT_BGRA8 the kernels
