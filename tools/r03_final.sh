@@ -10,4 +10,5 @@ timeout -k 10 200 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | grep
 timeout -k 10 600 python3 tools/stress_unit_step.py 120 777 2>&1 | tail -2
 timeout -k 10 600 python3 tools/stress_fixed_factors.py 2>&1 | tail -2
 timeout -k 10 600 python3 tools/stress_flow.py 2>&1 | tail -2
+timeout -k 10 900 python3 tools/stress_batch_consistency.py 2>&1 | tail -1
 bash tools/round_evidence.sh
