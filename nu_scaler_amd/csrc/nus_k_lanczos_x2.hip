@@ -220,7 +220,9 @@ __device__ __forceinline__ uint32_t row_is_opaque(const uint4 raw)
 }
 
 // Vertical pass of one output row: 6 taps from window slots BASE .. BASE+5 (mod 6).
-template <bool EXACT, int BASE, bool ALPHA>
+// NARROW: the filter's outermost taps (slots 0 and 5 of both phases) carry weight 0 on both axes (Catmull-Rom at x2: four taps;
+// host-checked) and are skipped -- adding v * 0 changes no sum, so the bits are those of the six-tap form.
+template <bool EXACT, int BASE, bool ALPHA, bool NARROW = false>
 __device__ __forceinline__ void lanczos_x2_vpass(const float (&win)[6][16], const float (&w)[6], float (&V)[16])
 {
 #if NUS_LZ_ABLATE == 2 || NUS_LZ_ABLATE == 3
@@ -231,9 +233,10 @@ __device__ __forceinline__ void lanczos_x2_vpass(const float (&win)[6][16], cons
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
         if (!ALPHA && (k & 3) == 3) continue; // V[alpha] is not read by the 3-channel horizontal pass
-        float acc = win[BASE % 6][k] * w[0]; // == fma(.., 0) and a VOP2 instruction
+        constexpr int J0 = NARROW ? 1 : 0, J1 = NARROW ? 5 : 6;
+        float acc = win[(BASE + J0) % 6][k] * w[J0]; // == fma(.., 0) and a VOP2 instruction
 #pragma unroll
-        for (int j = 1; j < 6; ++j) acc = mac_tight<EXACT>(acc, win[(BASE + j) % 6][k], w[j]);
+        for (int j = J0 + 1; j < J1; ++j) acc = mac_tight<EXACT>(acc, win[(BASE + j) % 6][k], w[j]);
         V[k] = acc;
     }
 }
@@ -256,7 +259,7 @@ __device__ __forceinline__ void lanczos_x2_vpass_edge(const float (&win)[6][16],
 }
 
 // Horizontal pass of the lane's 8 output pixels, convert + pack.
-template <bool EXACT, bool ALPHA>
+template <bool EXACT, bool ALPHA, bool NARROW = false>
 __device__ __forceinline__ void lanczos_x2_hpass(const float (&V)[16], const PhaseWeights &W, uint32_t (&o)[8])
 {
     constexpr uint32_t a0 = ALPHA ? 0u : 0xFF000000u; // 3-channel path: opaque output
@@ -269,8 +272,8 @@ __device__ __forceinline__ void lanczos_x2_hpass(const float (&V)[16], const Pha
 #endif
 #pragma unroll
     for (int c = 0; c < (ALPHA ? 4 : 3); ++c) {
-        float e[10]; // vertical sums of input columns c0-3 .. c0+6 for this channel
-        e[0] = lane_up(V[1 * 4 + c]);
+        float e[10]; // vertical sums of input columns c0-3 .. c0+6 for this channel (NARROW: e[0] and e[9] are not read)
+        e[0] = NARROW ? 0.0f : lane_up(V[1 * 4 + c]);
         e[1] = lane_up(V[2 * 4 + c]);
         e[2] = lane_up(V[3 * 4 + c]);
         e[3] = V[0 * 4 + c];
@@ -279,13 +282,14 @@ __device__ __forceinline__ void lanczos_x2_hpass(const float (&V)[16], const Pha
         e[6] = V[3 * 4 + c];
         e[7] = lane_down(V[0 * 4 + c]);
         e[8] = lane_down(V[1 * 4 + c]);
-        e[9] = lane_down(V[2 * 4 + c]);
+        e[9] = NARROW ? 0.0f : lane_down(V[2 * 4 + c]);
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
-            float ae = e[m] * W.e[0];
-            float ao = e[m + 1] * W.o[0];
+            constexpr int J0 = NARROW ? 1 : 0, J1 = NARROW ? 5 : 6;
+            float ae = e[m + J0] * W.e[J0];
+            float ao = e[m + 1 + J0] * W.o[J0];
 #pragma unroll
-            for (int j = 1; j < 6; ++j) {
+            for (int j = J0 + 1; j < J1; ++j) {
                 ae = mac_tight<EXACT>(ae, e[m + j], W.e[j]);
                 ao = mac_tight<EXACT>(ao, e[m + 1 + j], W.o[j]);
             }
@@ -375,7 +379,7 @@ __device__ __forceinline__ void lanczos_x2_store_mid(const uint4 px, const MidSt
     }
 }
 
-template <bool EXACT, int BLEND, bool UNIT, int S>
+template <bool EXACT, int BLEND, bool UNIT, int S, bool NARROW = false>
 __device__ __forceinline__ void lanczos_x2_step(float (&win)[6][16], const RowRing<BLEND> &ring, RowRaw<BLEND> (&raw)[2],
                                                 uint32_t &opaque, int r, uint32_t in_off, const RowStore &st,
                                                 const LanczosX2Args &A, const PhaseWeights &W, const uint8_t *src,
@@ -397,9 +401,9 @@ __device__ __forceinline__ void lanczos_x2_step(float (&win)[6][16], const RowRi
     if (path == 0)
         lanczos_x2_vpass_edge<EXACT, S>(win, A.wy6, 2 * (uint32_t)r, V);
     else if (path == 1)
-        lanczos_x2_vpass<EXACT, S, false>(win, W.e, V);
+        lanczos_x2_vpass<EXACT, S, false, NARROW>(win, W.e, V);
     else
-        lanczos_x2_vpass<EXACT, S, true>(win, W.e, V);
+        lanczos_x2_vpass<EXACT, S, true, NARROW>(win, W.e, V);
 #if NUS_LZ_ABLATE == 1
     if (EARLY) {
         wait_vmcnt<(D - 1) * (NL + M), (D - 1) * NL + 1>();
@@ -414,9 +418,9 @@ __device__ __forceinline__ void lanczos_x2_step(float (&win)[6][16], const RowRi
     }
 #endif
     if (path == 1)
-        lanczos_x2_hpass<EXACT, false>(V, W, o);
+        lanczos_x2_hpass<EXACT, false, NARROW>(V, W, o);
     else
-        lanczos_x2_hpass<EXACT, true>(V, W, o);
+        lanczos_x2_hpass<EXACT, true, NARROW>(V, W, o);
     lanczos_x2_store(o, rs, st, off0); // after the paths have joined: straight-line code holds every memory instruction
     // row r+3 in, then request row r+3+D into the same slot
     if (HIDDEN && !EARLY) {
@@ -456,13 +460,13 @@ __device__ __forceinline__ void lanczos_x2_step(float (&win)[6][16], const RowRi
     const uint32_t path_o = !interior ? 0u : ((OP && (opaque & 0x3Fu) == 0x3Fu) ? 1u : 2u);
     if (path_o == 0) {
         lanczos_x2_vpass_edge<EXACT, S + 1>(win, A.wy6, 2 * (uint32_t)r + 1, V);
-        lanczos_x2_hpass<EXACT, true>(V, W, o);
+        lanczos_x2_hpass<EXACT, true, NARROW>(V, W, o);
     } else if (path_o == 1) {
-        lanczos_x2_vpass<EXACT, S + 1, false>(win, W.o, V);
-        lanczos_x2_hpass<EXACT, false>(V, W, o);
+        lanczos_x2_vpass<EXACT, S + 1, false, NARROW>(win, W.o, V);
+        lanczos_x2_hpass<EXACT, false, NARROW>(V, W, o);
     } else {
-        lanczos_x2_vpass<EXACT, S + 1, true>(win, W.o, V);
-        lanczos_x2_hpass<EXACT, true>(V, W, o);
+        lanczos_x2_vpass<EXACT, S + 1, true, NARROW>(win, W.o, V);
+        lanczos_x2_hpass<EXACT, true, NARROW>(V, W, o);
     }
     lanczos_x2_store(o, rs, st, off0 + row_bytes);
 }
@@ -495,7 +499,10 @@ __device__ __forceinline__ void lanczos_x2_step(float (&win)[6][16], const RowRi
 // The two waves of a (frame, row block, strip) run side by side (consecutive workgroups of one XCD), so A_k's rows reach the
 // second of them from cache, and with order = 1 (row-block-major) so do the rows of B_k = A_(k+1): the step reads every input
 // row from HBM about once where three launches (blend, upscale, upscale) read it four times, and writes nothing twice.
-template <bool EXACT, int BLEND, bool UNIT>
+// (NARROW: the compiler gives the four-tap form 215 registers, two waves per SIMD; held to three (168 registers) it spills 49
+// dwords, whose reloads bring vmcnt waits back into the loop: 9.7 against 7.7 - 8.0 us per frame.  Left as the compiler has it.
+// The six-tap instantiations are instruction for instruction what they were before the parameter existed.)
+template <bool EXACT, int BLEND, bool UNIT, bool NARROW = false>
 __global__ __launch_bounds__(256) void k_lanczos3_x2(const LanczosX2Args A)
 {
     static_assert(!UNIT || BLEND != 0, "the unit kernel is a blend kernel whose real-frame role blends a row with itself");
@@ -647,7 +654,7 @@ __global__ __launch_bounds__(256) void k_lanczos3_x2(const LanczosX2Args A)
         // after its last row: a step is never skipped with a later one still to run, so every path through
         // the loop carries the vector memory instructions the hand-counted waits assume.
 #define NUS_LZ_STEP(S) \
-        lanczos_x2_step<EXACT, BLEND, UNIT, S>(win, ring, raw, opaque, rbase + S, in_off, st, A, W, src, src_b, rs, t, ms); \
+        lanczos_x2_step<EXACT, BLEND, UNIT, S, NARROW>(win, ring, raw, opaque, rbase + S, in_off, st, A, W, src, src_b, rs, t, ms); \
         if (S < 5 && rbase + S + 1 >= r_end) break
         NUS_LZ_STEP(0);
         NUS_LZ_STEP(1);
@@ -792,6 +799,11 @@ hipError_t launch_lanczos_x2(const UpscaleLaunch &L, const DeviceTables &T, bool
     A.t = L.blend_t;
     A.sel = L.in_sel;
     const int blend = L.in_b == nullptr ? 0 : (L.blend_t == 0.5f ? 1 : 2);
+#ifndef NUS_LZ_NARROW
+#define NUS_LZ_NARROW 1 // dev macro: 0 = Catmull-Rom / Triangle through the six-tap instantiations (A/B timing)
+#endif
+    // (the interior vertical weights are the horizontal ones: host-checked; the border rows take their own from the table)
+    const bool narrow = NUS_LZ_NARROW && blend == 0 && A.wxe[0] == 0.0f && A.wxe[5] == 0.0f && A.wxo[0] == 0.0f && A.wxo[5] == 0.0f;
     const uint32_t nwaves = A.nstrips * A.nrowblocks;
     hipError_t e = for_frame_chunks(L, [&](const uint8_t *in, uint8_t *out, uint32_t n) {
         A.in = in;
@@ -799,7 +811,12 @@ hipError_t launch_lanczos_x2(const UpscaleLaunch &L, const DeviceTables &T, bool
         A.out = out;
         const dim3 block(256), grid(cdiv(nwaves, 4), n);
 #define NUS_LZ(E, B) hipLaunchKernelGGL((k_lanczos3_x2<E, B, false>), grid, block, 0, L.stream, A)
-        if (exact) {
+        if (narrow) { // Catmull-Rom / Triangle: the outermost taps of both phases are 0 on both axes -- four taps per pass
+            if (exact)
+                hipLaunchKernelGGL((k_lanczos3_x2<true, 0, false, true>), grid, block, 0, L.stream, A);
+            else
+                hipLaunchKernelGGL((k_lanczos3_x2<false, 0, false, true>), grid, block, 0, L.stream, A);
+        } else if (exact) {
             if (blend == 0) NUS_LZ(true, 0); else if (blend == 1) NUS_LZ(true, 1); else NUS_LZ(true, 2);
         } else {
             if (blend == 0) NUS_LZ(false, 0); else if (blend == 1) NUS_LZ(false, 1); else NUS_LZ(false, 2);

@@ -2,7 +2,7 @@
 generates: every `s_waitcnt vmcnt(N)` the kernel places by hand must retire the row request it is for on
 every path through the unrolled loop, be tight (not drain younger stores), and be the only vmcnt wait inside
 the loop.  tools/check_hidden_loads.py does the control-flow analysis; this test compiles the kernel source
-to assembly (no GPU needed) and runs it for all ten instantiations (EXACT x BLEND, plus the one-launch UNIT forms of the blend kernels)."""
+to assembly (no GPU needed) and runs it for all twelve instantiations (EXACT x BLEND, plus the one-launch UNIT forms of the blend kernels)."""
 import os
 import subprocess
 import sys
@@ -37,7 +37,7 @@ def test_hand_counted_waits_of_every_instantiation(kernel_asm):
     import check_hidden_loads as chk
 
     bodies = list(chk.kernel_bodies(kernel_asm, "k_lanczos3_x2IL"))
-    assert len(bodies) == 10, [n for n, _ in bodies]  # EXACT x BLEND, + EXACT x BLEND {1, 2} x UNIT
+    assert len(bodies) == 12, [n for n, _ in bodies]  # EXACT x BLEND, + EXACT x BLEND {1, 2} x UNIT, + EXACT x NARROW (4 taps)
     for name, body in bodies:
         r = chk.check(body)
         blend = "ELi0E" not in name
