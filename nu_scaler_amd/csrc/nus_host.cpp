@@ -1073,7 +1073,13 @@ int HipUpscaler::stream_submit(const uint8_t *in, size_t in_len, uint8_t *out, s
     NUS_HIP(hipSetDevice(device_));
     bool direct = false;
     const int rc = submit_frame(slots_[i % kSlots], in, out, &direct, false);
-    if (rc != kOk) return rc; // nothing was queued for the retiring thread: the ring stays consistent
+    if (rc != kOk) { // nothing was queued for the retiring thread: the ring stays consistent.  Copies of this frame may be
+                     // queued on the caller's (pinned) buffers already: nothing of it may be in flight when the call returns
+        for (hipStream_t st : {s_in_, s_k_, s_out_})
+            if (st) (void)hipStreamSynchronize(st);
+        (void)hipGetLastError();
+        return rc;
+    }
     {
         std::lock_guard<std::mutex> rl(ring_.m);
         ring_.items[i % kSlots] = Ring::Item{out, direct};
@@ -1092,8 +1098,10 @@ int HipUpscaler::stream_wait(uint64_t ticket)
         set_thread_error("stream_wait: no such frame has been submitted");
         return kInvalidArgument;
     }
-    ring_.cv.wait(rl, [&] { return ring_.retired > ticket || ring_.status != kOk; });
-    if (ring_.retired > ticket) return kOk;
+    // Always until THIS frame has been retired, sticky error or not: the retiring thread keeps retiring after a failure (it
+    // always advances `retired`), and until it has passed `ticket` a D2H or a pool worker may still be writing `out`.
+    ring_.cv.wait(rl, [&] { return ring_.retired > ticket; });
+    if (ring_.status == kOk) return kOk;
     set_thread_error(ring_.error);
     return ring_.status;
 }
@@ -1167,15 +1175,19 @@ int HipUpscaler::upscale_batch(const uint8_t *const *ins, const size_t *in_lens,
         direct_out[i] = direct ? 1 : 0;
         return rc;
     };
-    auto retire = [&](size_t i) -> int {
-        std::string err;
-        const int rc = retire_frame(slots_[i % nslots], outs[i], direct_out[i] != 0, &err);
-        return rc == kOk ? kOk : fail(rc, err);
+    // (also runs on the retiring thread: the error text stays in *err there; fail() -- error_ and the thread-local text -- is
+    // for the calling thread only, after the join)
+    auto retire = [&](size_t i, std::string *err) -> int {
+        return retire_frame(slots_[i % nslots], outs[i], direct_out[i] != 0, err);
     };
     int status = kOk;
     if (n == 1) { // one frame (trait Upscaler::upscale): nothing to overlap with, no second thread
         status = submit(0);
-        if (status == kOk) status = retire(0);
+        if (status == kOk) {
+            std::string err;
+            status = retire(0, &err);
+            if (status != kOk) status = fail(status, err);
+        }
     } else {
         // The calling thread stages and submits frame i as soon as slot i % nslots is free again; a second thread retires the
         // frames in order.  The copy-out of frame i (the pool's workers) then runs beside the staging copy, the H2D and the
@@ -1195,18 +1207,16 @@ int HipUpscaler::upscale_batch(const uint8_t *const *ins, const size_t *in_lens,
                     if (submitted <= i) return;
                 }
                 int rc;
+                std::string err;
                 try {
-                    rc = retire(i);
+                    rc = retire(i, &err);
                 } catch (...) { // (an allocation failing while an error text is built: no exception may leave a thread)
                     rc = kOutOfMemory;
                 }
                 std::lock_guard<std::mutex> lk(m);
                 if (rc != kOk && retire_status == kOk) {
                     retire_status = rc;
-                    try {
-                        retire_error = error_;
-                    } catch (...) {
-                    }
+                    retire_error.swap(err);
                 }
                 retired = i + 1;
                 cv.notify_all();

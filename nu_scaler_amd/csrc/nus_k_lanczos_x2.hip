@@ -547,7 +547,8 @@ __global__ __launch_bounds__(256) void k_lanczos3_x2(const LanczosX2Args A)
         out = real ? A.out : A.out_mid;
         const bool owner = lane >= 1 && lane <= (int)(kLanczosX2StripCols / 4) && c >= 0 && c + 4 <= (int)A.iw;
         ms.lane_off = owner ? (uint32_t)c * 4u : 0x80000000u;
-        ms.rs = __builtin_amdgcn_make_buffer_rsrc(A.mid + (size_t)frame * A.in_frame_bytes, 0,
+        // the in-between frames are tightly packed whatever the stride of the source frames (nuscaler_hip.h: d_mid)
+        ms.rs = __builtin_amdgcn_make_buffer_rsrc(A.mid + (size_t)frame * ((size_t)A.iw * A.ih * 4u), 0,
                                                   real || A.mid == nullptr ? 0u : A.iw * A.ih * 4u, 0x00020000);
     } else {
         ms.lane_off = 0;

@@ -51,6 +51,21 @@ def _as_buffer(data):
     return ctypes.addressof(arr), len(mv), (arr, mv)
 
 
+def _as_out_buffer(out, need: int):
+    """Borrow a caller-provided OUTPUT buffer: it must be writable (a `bytes` would be mutated in place, any other read-only
+    buffer would be copied and the result lost in the temporary) and hold at least `need` bytes."""
+    mv = memoryview(out)
+    if mv.readonly:
+        raise TypeError("output buffer must be writable (bytearray, numpy array, PinnedBuffer, ...), not " + type(out).__name__)
+    if not mv.c_contiguous:
+        raise TypeError("output buffer must be C-contiguous")
+    mv = mv.cast("B")
+    if len(mv) < need:
+        raise ValueError(f"output buffer holds {len(mv)} bytes, the output frame needs {need}")
+    arr = (ctypes.c_ubyte * len(mv)).from_buffer(mv)
+    return ctypes.addressof(arr), len(mv), (arr, mv)
+
+
 _PyBytes_FromStringAndSize = ctypes.pythonapi.PyBytes_FromStringAndSize
 _PyBytes_FromStringAndSize.restype = ctypes.py_object
 _PyBytes_FromStringAndSize.argtypes = [ctypes.c_char_p, ctypes.c_ssize_t]
@@ -124,7 +139,7 @@ class PyWgpuUpscaler:
     def upscale_into(self, input, out) -> None:
         """Zero-copy variant: writes into a caller-provided writable buffer."""
         addr, n, keep = _as_buffer(input)
-        oaddr, on, okeep = _as_buffer(out)
+        oaddr, on, okeep = _as_out_buffer(out, self.output_size)
         self._check(self._lib.nus_upscaler_upscale(self._h, addr, n, oaddr, on))
         del keep, okeep
 
@@ -149,7 +164,8 @@ class PyWgpuUpscaler:
         """`upscale_batch` into caller-provided writable buffers (one per frame, each >= output_size): what a Rust caller
         of nus_upscaler_upscale_batch does with its own Vecs; no allocation on the way."""
         bufs = [_as_buffer(f) for f in frames]
-        obufs = [_as_buffer(o) for o in outs]
+        need = self.output_size
+        obufs = [_as_out_buffer(o, need) for o in outs]
         n = len(bufs)
         if len(obufs) != n:
             raise ValueError("upscale_batch_into: one output buffer per frame")
@@ -170,7 +186,7 @@ class PyWgpuUpscaler:
         """Stage and enqueue one frame; `out` is a writable buffer of output_size bytes that receives it.  Returns the frame's
         ticket; blocks only while three frames are in flight."""
         addr, n, keep = _as_buffer(frame)
-        oaddr, on, okeep = _as_buffer(out)
+        oaddr, on, okeep = _as_out_buffer(out, self.output_size)
         t = ctypes.c_uint64()
         self._check(self._lib.nus_upscaler_stream_submit(self._h, addr, n, oaddr, on, ctypes.byref(t)))
         self._stream_keep[t.value] = (keep, okeep)  # both buffers stay alive until the frame has been waited for

@@ -140,6 +140,20 @@ def test_interpolator_trait_shape_without_gpu(nsc):
         it.initialize(0, 4)
 
 
+def test_output_buffers_must_be_writable(nsc):
+    """upscale_into / upscale_batch_into / stream_submit refuse read-only outputs: a `bytes` would be mutated in place, any
+    other read-only buffer copied and the result lost (raised before any library call: no GPU needed)."""
+    u = nsc.PyWgpuUpscaler("quality", "nearest")
+    frame = bytes(16)
+    for bad in (bytes(64), memoryview(bytearray(64)).toreadonly()):
+        with pytest.raises(TypeError, match="writable"):
+            u.upscale_into(frame, bad)
+        with pytest.raises(TypeError, match="writable"):
+            u.upscale_batch_into([frame], [bad])
+        with pytest.raises(TypeError, match="writable"):
+            u.stream_submit(frame, bad)
+
+
 def test_fresh_output_bytes_are_built_in_place(nsc):
     """The output `bytes` of upscale / interpolate_py is created with PyBytes_FromStringAndSize(NULL, n) and filled
     before anyone else sees it: a new object per call, of the right size, unrelated to earlier ones."""

@@ -163,3 +163,34 @@ def test_unit_step_errors(nsc):
         u.upscale_unit_device(x.data_ptr() + 4, 0, x.data_ptr(), 0, 0.5, 0, x.data_ptr(), x.data_ptr(), 1, 0)
     with pytest.raises(RuntimeError, match=r"t must be in \[0, 1\]"):
         u.upscale_unit_device(x.data_ptr(), 0, x.data_ptr(), 0, 1.5, 0, x.data_ptr(), x.data_ptr(), 1, 0)
+
+
+def test_unit_step_strided_source_frames_keep_mid_packed(nsc, oracle_mod):
+    """a_stride = b_stride = 2 frames (A_k and B_k interleaved in one pool): the in-between frames still land tightly packed
+    in d_mid (nuscaler_hip.h), nothing is written behind frame n-1, and all outputs equal the packed call's."""
+    import torch
+
+    w, h, n = 496, 40, 4
+    dev = torch.device("cuda:0")
+    fb = w * h * 4
+    s = torch.cuda.current_stream().cuda_stream
+    pool_np = np.stack([oracle_mod.gen_noise(w, h, 300 + i) for i in range(2 * n)])
+    pool = torch.from_numpy(pool_np).to(dev)
+    a, b = pool[0::2].contiguous(), pool[1::2].contiguous()
+    u = nsc.PyWgpuUpscaler("quality", "lanczos3")
+    u.set_option("rows_per_wave", 12)
+    u.initialize(w, h, 2 * w, 2 * h)
+    want_mid = torch.zeros((n, h, w, 4), dtype=torch.uint8, device=dev)
+    want_real = torch.zeros((n, 2 * h, 2 * w, 4), dtype=torch.uint8, device=dev)
+    want_up_mid = torch.zeros_like(want_real)
+    u.upscale_unit_device(a.data_ptr(), 0, b.data_ptr(), 0, 0.5, want_mid.data_ptr(), want_real.data_ptr(), want_up_mid.data_ptr(), n, s)
+    mid = torch.full((2 * n, h, w, 4), 0xAB, dtype=torch.uint8, device=dev)  # n frames + n guard frames
+    up_real, up_mid = torch.zeros_like(want_real), torch.zeros_like(want_real)
+    u.upscale_unit_device(pool.data_ptr(), 2 * fb, pool.data_ptr() + fb, 2 * fb, 0.5, mid.data_ptr(), up_real.data_ptr(),
+                          up_mid.data_ptr(), n, s)
+    torch.cuda.synchronize()
+    assert torch.equal(mid[:n], want_mid)
+    assert bool((mid[n:] == 0xAB).all()), "in-between frames written at the source stride"
+    assert torch.equal(up_real, want_real) and torch.equal(up_mid, want_up_mid)
+    for i in range(n):
+        assert np.array_equal(mid[i].cpu().numpy(), oracle_mod.warp_blend(pool_np[2 * i], pool_np[2 * i + 1], None, 0.5))

@@ -1,7 +1,7 @@
 #!/bin/bash
 # SQ counters of k_lanczos3_x2 for several builds of the library on one box: tools/sq_compare.sh <pattern> name=lib.so ...
 pat=$1; shift
-root=$GRAFT_REPO_ROOT; cd /tmp && export TMPDIR=/tmp
+root=${GRAFT_REPO_ROOT:-/root/repo}; cd /tmp && export TMPDIR=/tmp
 for spec in "$@"; do
   name="${spec%%=*}"; lib="${spec#*=}"
   out=$root/gpurun_out/sqc_${name}_$pat; rm -rf $out; mkdir -p $out

@@ -1,7 +1,7 @@
 #!/bin/bash
 # SQ counter passes over the Lanczos x2 kernel alone (separate --pmc runs, kernel-trace only).
 pat=${1:-gradient}
-root=$GRAFT_REPO_ROOT; out=$root/gpurun_out/sq_$pat; mkdir -p $out
+root=${GRAFT_REPO_ROOT:-/root/repo}; out=$root/gpurun_out/sq_$pat; mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
 i=0
 for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM" \

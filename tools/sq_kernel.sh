@@ -1,7 +1,7 @@
 #!/bin/bash
 # SQ counter passes for one kernel name substring: tools/sq_kernel.sh <substr> -- <python script args...>
 sub=$1; shift; shift
-root=$GRAFT_REPO_ROOT; out=$root/gpurun_out/sqk_$sub; rm -rf $out; mkdir -p $out
+root=${GRAFT_REPO_ROOT:-/root/repo}; out=$root/gpurun_out/sqk_$sub; rm -rf $out; mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
 i=0
 for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_WAIT_INST_ANY" \

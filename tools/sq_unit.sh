@@ -1,6 +1,6 @@
 #!/bin/bash
 # SQ counter passes over the one-launch pipeline step (k_lanczos3_x2<.., UNIT>), gradient and noise: tools/sq_unit.sh
-root=$GRAFT_REPO_ROOT
+root=${GRAFT_REPO_ROOT:-/root/repo}
 cd /tmp && export TMPDIR=/tmp
 for pat in gradient noise; do
   out=$root/gpurun_out/sq_unit_$pat; rm -rf $out; mkdir -p $out

@@ -1,7 +1,7 @@
 #!/bin/bash
 # one --pmc pass: VALU instruction count + busy cycles of the Lanczos x2 kernel (optionally another library via NUS_LIB_PATH)
 pat=${1:-gradient}; tag=${2:-main}
-root=$GRAFT_REPO_ROOT; out=$root/gpurun_out/sqv_${tag}_$pat; mkdir -p $out
+root=${GRAFT_REPO_ROOT:-/root/repo}; out=$root/gpurun_out/sqv_${tag}_$pat; mkdir -p $out
 [ -n "$NUS_LIB_PATH" ] && export NUS_LIB_PATH=$root/$NUS_LIB_PATH
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --pmc SQ_INSTS_VALU SQ_BUSY_CYCLES SQ_INSTS_SALU SQ_WAIT_INST_ANY --kernel-trace -d $out --output-format csv -- python3 $root/tools/lanczos_only.py 64 2 $pat > $out.log 2>&1 || tail -3 $out.log
