@@ -32,6 +32,13 @@ Rank 0 prints ONE JSON line.  Inside it:
   config.noise_variant        the same step on 4-channel noise (the kernel's other code path);
   config.host_path            host bytes in -> host bytes out through the trait-shaped entry
                               points (PCIe inclusive; never `value`).
+  config.placement / per_rank / per_rank_check   what happened on EVERY rank: the NUMA node and CPUs it was bound to before
+                              its first HIP call, its time, its bracket, its clocks, and two frames of ITS shard (all three
+                              output buffers) against the oracle -- gathered, so rank 0's line can show an outlier.
+  roofline.copy_ceiling       what hipMemcpyDtoDAsync, a 16-B-per-lane stream copy and a 1 R : 4 W stream get on this box
+                              (SURVEY.md 8d's on-box ceiling), and `roofline.moved`: the bytes the kernel really moves
+                              (`traffic`) against them;  roofline.config3: BASELINE config 3, the plain Lanczos stream,
+                              sustained for seconds by itself.
 """
 from __future__ import annotations
 
@@ -69,7 +76,7 @@ def parse_args(argv=None):
                     help="skip the informational legs (fused / noise / motion / host path / copy ceiling)")
     ap.add_argument("--no-check", action="store_true", help="skip the oracle check of the timed output buffers")
     ap.add_argument("--sustained-seconds", type=float, default=6.0,
-                    help="length of the sustained leg after the timed region (0 = skip; N=1 only)")
+                    help="length of the sustained leg after the timed region (0 = skip; every rank at the same time)")
     ap.add_argument("--host-fed-seconds", type=float, default=1.5,
                     help="length of the host-fed leg (mode ii: every rank feeds its GPU from host memory through "
                          "nus_upscaler_upscale_batch at the same time; 0 = skip)")
@@ -81,6 +88,10 @@ def parse_args(argv=None):
     ap.add_argument("--overlap", action="store_true",
                     help="blend on a second stream, concurrent with the upscale of the real frames (measured: no gain, "
                          "the Lanczos kernel is SIMD-time bound and slows by what the blend takes)")
+    ap.add_argument("--config3-seconds", type=float, default=3.0,
+                    help="length of the BASELINE-config-3 leg (the plain 300-frame Lanczos stream, back to back, per pattern; "
+                         "0 = skip; N=1 only)")
+    ap.add_argument("--no-bind", action="store_true", help="do not bind the rank to its GPU's NUMA node")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo for rehearsal)")
     ap.add_argument("--force-device", type=int, default=-1,
                     help="rehearsal only: put every rank on this GPU (with --backend gloo on a 1-GPU box)")
@@ -106,7 +117,7 @@ def launch_ranks(nproc: int, script: str, script_args, timeout=None):
     grandchildren.  Rendezvous on 127.0.0.1 (the container hostname may not resolve)."""
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL needs it on this driver
-    env.setdefault("OMP_NUM_THREADS", "4")
+    env.setdefault("OMP_NUM_THREADS", "4")  # torchrun's own default is 1; each rank re-sizes it from its CPU share (placement)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={int(nproc)}",
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), script, *script_args]
     res = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True, timeout=timeout)
@@ -272,37 +283,72 @@ def measure_traffic(frames_per_launch, unit=True):
     return int(per_unit * frames_per_launch), detail
 
 
-def check_timed_outputs(frames, mid_t, up_real, up_mid, picks, w, h):
-    """Compare frames of the TIMED output buffers with the oracle (outside the timed region): the in-between frame against
-    oracle.warp_blend(frame k, frame k+1) (bit-exact), the upscaled real frame against oracle.lanczos3(frame k), the upscaled
-    in-between frame against oracle.lanczos3 of that blend.  Lanczos tolerance as in tests/: every sample
-    within 1 LSB and fewer than 0.1 % of the samples different.  Raises on mismatch."""
+def check_timed_outputs(frames, mid_t, up_real, up_mid, picks, w, h, first_frame=0, threads=0):
+    """Compare frames of the TIMED output buffers with the oracle (outside the timed region).  The source frames are
+    REGENERATED on the host (the stream is deterministic: frame `first_frame + k` of the global stream, oracle.gen_gradient) and
+    the rank's device-resident input is compared with them first, so a rank holding the wrong shard cannot pass; then the
+    in-between frame against oracle.warp_blend(frame k, frame k+1) (bit-exact), the upscaled real frame against
+    oracle.lanczos3(frame k), the upscaled in-between frame against oracle.lanczos3 of that blend.  Lanczos tolerance as in
+    tests/: every sample within 1 LSB and fewer than 0.1 % of the samples different.  Never raises on a mismatch: returns
+    (report, summary) -- the caller gathers the summaries of all ranks before anybody gives up (a rank that left early would
+    hang the others in the next collective)."""
     import numpy as np
 
     import oracle
 
     oracle.build()
+    th = threads or usable_cpus()
     report = []
+    summary = {"ok": 1.0, "input_ok": 1.0, "mid_exact": 1.0, "max_abs_diff": 0.0, "frac_differing": 0.0, "frames": float(len(picks))}
     for k in picks:
-        a = frames[k].cpu().numpy()
-        b = frames[k + 1].cpu().numpy()
-        th = usable_cpus()
+        a, b = oracle.gen_gradient(w, h, first_frame + k), oracle.gen_gradient(w, h, first_frame + k + 1)
+        same_in = bool(np.array_equal(frames[k].cpu().numpy(), a) and np.array_equal(frames[k + 1].cpu().numpy(), b))
+        report.append({"frame": int(k), "stream_frame": int(first_frame + k), "buffer": "input", "bit_exact": same_in})
+        if not same_in:
+            summary["input_ok"] = summary["ok"] = 0.0
         mid = oracle.warp_blend(a, b, None, 0.5, threads=th)
         if mid_t is not None:
             same = bool(np.array_equal(mid_t[k].cpu().numpy(), mid))
             report.append({"frame": int(k), "buffer": "mid", "bit_exact": same})
             if not same:
-                raise SystemExit(f"bench.py: timed output mid[{k}] differs from the oracle's warp_blend")
+                summary["mid_exact"] = summary["ok"] = 0.0
         for name, got_t, src in (("up_real", up_real, a), ("up_mid", up_mid, mid)):
             want = oracle.lanczos3(src, 2 * w, 2 * h, threads=th).astype(np.int16)
             got = got_t[k].cpu().numpy().astype(np.int16)
             d = np.abs(got - want)
             mx, frac = int(d.max()), float((d != 0).mean())
             report.append({"frame": int(k), "buffer": name, "max_abs_diff": mx, "frac_differing": round(frac, 7)})
+            summary["max_abs_diff"] = max(summary["max_abs_diff"], float(mx))
+            summary["frac_differing"] = max(summary["frac_differing"], frac)
             if mx > 1 or frac >= 1e-3:
-                raise SystemExit(f"bench.py: timed output {name}[{k}] differs from the oracle "
-                                 f"(max |diff| {mx}, {frac * 100:.4f} % of samples)")
-    return report
+                summary["ok"] = 0.0
+    return report, summary
+
+
+def gather_rows(row, world, dist=None, torch=None, comm_dev=None):
+    """Every rank's row of numbers on every rank: ONE all_gather of a float64 vector (keys sorted; None travels as NaN).
+    world == 1: no collective.  Used for everything rank 0's line says about the other ranks."""
+    keys = sorted(row)
+    if world == 1:
+        return [dict(row)]
+    vals = [float("nan") if row[k] is None else float(row[k]) for k in keys]
+    t = torch.tensor(vals, dtype=torch.float64, device=comm_dev)
+    got = [torch.zeros_like(t) for _ in range(world)]
+    dist.all_gather(got, t)
+    rows = []
+    for g in got:
+        rows.append({k: (None if x != x else x) for k, x in zip(keys, g.cpu().tolist())})
+    return rows
+
+
+def spread(rows, key, digits=4):
+    """{min, max, by_rank} of one gathered column (None where no rank has it)."""
+    xs = [r.get(key) for r in rows]
+    have = [x for x in xs if x is not None]
+    if not have:
+        return None
+    return {"min": round(min(have), digits), "max": round(max(have), digits),
+            "by_rank": [None if x is None else round(x, digits) for x in xs]}
 
 
 def pcie_ceiling(torch, dev, n_in, n_out):
@@ -457,14 +503,19 @@ def host_fed_leg(nsc, syn, w, h, device, seconds, barrier):
 
 
 class ClockSampler:
-    """Board clock / power while a leg runs: a thread of THIS process starts a fresh `rocm-smi` child per sample
-    (read-only query; the child never touches HIP) and, where readable, also reads the amdgpu sysfs files."""
+    """Clocks (sclk, mclk, fclk) and power of THIS rank's GPU while a leg runs, sampled by a thread of this process.
+    The GPU is found by its PCI address (placement.query_gpu_pci: HIP's device order is not rocm-smi's on a host where the job
+    sees one GPU of eight): first the amdgpu sysfs files of that address (no child process: pp_dpm_sclk / _mclk / _fclk, the
+    hwmon power sensor), else a fresh `rocm-smi` child per sample (read-only query; the child never touches HIP) on the index
+    `rocm-smi --showbus` lists that address under, else on `-d <fallback_index>`."""
 
-    def __init__(self, period_s=0.6):
+    def __init__(self, bdf=None, period_s=0.6, fallback_index=0):
         import threading
 
         self.period = period_s
-        self.samples = []  # (seconds since start, sclk MHz or None, W or None)
+        self.bdf = bdf
+        self.fallback_index = fallback_index
+        self.samples = []  # (seconds since start, sclk MHz, W, mclk MHz, fclk MHz), None where unreadable
         self._stop = threading.Event()
         self._thread = threading.Thread(target=self._run, daemon=True)
         self.t0 = time.perf_counter()
@@ -474,22 +525,91 @@ class ClockSampler:
     def _parse(text):
         import re
 
-        sclk = re.search(r"sclk[^\n]*?\((\d+)\s*Mhz\)", text, re.I)
+        def clk(name):
+            m = re.search(name + r"[^\n]*?\((\d+)\s*Mhz\)", text, re.I)
+            return int(m.group(1)) if m else None
+
         watts = re.search(r"Power \(W\):\s*([0-9.]+)", text)
-        return (int(sclk.group(1)) if sclk else None, float(watts.group(1)) if watts else None)
+        return clk("sclk"), (float(watts.group(1)) if watts else None), clk("mclk"), clk("fclk")
+
+    @staticmethod
+    def _dpm_current(path):
+        """'1: 2100Mhz *' -> 2100 (the level the star marks)."""
+        import re
+
+        try:
+            with open(path) as f:
+                for line in f:
+                    if "*" in line:
+                        m = re.search(r"(\d+)\s*Mhz", line, re.I)
+                        return int(m.group(1)) if m else None
+        except OSError:
+            pass
+        return None
+
+    def _sysfs_paths(self):
+        import glob
+
+        if not self.bdf:
+            return None
+        base = os.path.join("/sys/bus/pci/devices", self.bdf)
+        if self._dpm_current(os.path.join(base, "pp_dpm_sclk")) is None:
+            return None
+        power = None
+        for name in ("power1_average", "power1_input"):
+            found = glob.glob(os.path.join(base, "hwmon", "hwmon*", name))
+            if found:
+                power = found[0]
+                break
+        return {"base": base, "power": power}
+
+    def _sysfs_sample(self, paths):
+        watts = None
+        if paths["power"]:
+            try:
+                with open(paths["power"]) as f:
+                    watts = round(int(f.read().strip()) / 1e6, 1)
+            except (OSError, ValueError):
+                pass
+        b = paths["base"]
+        return (self._dpm_current(os.path.join(b, "pp_dpm_sclk")), watts, self._dpm_current(os.path.join(b, "pp_dpm_mclk")),
+                self._dpm_current(os.path.join(b, "pp_dpm_fclk")))
+
+    def _smi_index(self, exe):
+        import re
+
+        if not self.bdf:
+            return self.fallback_index
+        try:
+            res = subprocess.run([exe, "--showbus"], capture_output=True, text=True, timeout=15)
+            for m in re.finditer(r"GPU\[(\d+)\][^\n]*?PCI Bus:\s*([0-9a-fA-F:.]+)", res.stdout):
+                if m.group(2).lower() == self.bdf.lower():
+                    return int(m.group(1))
+        except Exception:
+            pass
+        return self.fallback_index
 
     def _run(self):
         import shutil
 
+        paths = self._sysfs_paths()
         exe = shutil.which("rocm-smi")
-        self.tool = "rocm-smi --showpower --showclocks -d 0" if exe else None
-        while exe and not self._stop.is_set():
+        if paths:
+            self.tool = f"sysfs {paths['base']}/pp_dpm_{{sclk,mclk,fclk}} + {paths['power'] or 'no power sensor'}"
+        elif exe:
+            idx = self._smi_index(exe)
+            self.tool = f"rocm-smi --showpower --showclocks -d {idx} (PCI {self.bdf or 'unknown'})"
+        while (paths or exe) and not self._stop.is_set():
             t = time.perf_counter() - self.t0
             try:
-                res = subprocess.run([exe, "--showpower", "--showclocks", "-d", "0"], capture_output=True, text=True, timeout=15)
-                sclk, watts = self._parse(res.stdout)
-                if sclk is not None or watts is not None:
-                    self.samples.append((round(t, 2), sclk, watts))
+                if paths:
+                    smp = self._sysfs_sample(paths)
+                else:
+                    res = subprocess.run([exe, "--showpower", "--showclocks", "-d", str(idx)], capture_output=True, text=True,
+                                         timeout=15)
+                    smp = self._parse(res.stdout)
+                if any(x is not None for x in smp):
+                    self.samples.append((round(t, 2),) + tuple(smp))
             except Exception:
                 pass
             self._stop.wait(self.period)
@@ -504,14 +624,19 @@ class ClockSampler:
         self._thread.join(timeout=20)
         return self.samples
 
+    @staticmethod
+    def mean(samples, col, digits=0):
+        xs = [s[col] for s in samples if s[col] is not None]
+        return round(sum(xs) / len(xs), digits) if xs else None
 
-def sustained_leg(torch, do_step, upscaler, seconds, tail_s=3.0, batch=20):
+
+def sustained_leg(torch, do_step, upscaler, seconds, tail_s=3.0, batch=20, bdf=None, device_index=0):
     """The same step for `seconds` of wall time, in batches of `batch` steps with one synchronize each; reports the
     rate over the last `tail_s` seconds (whole batches) next to the rate of the first second, the hipEvent brackets
-    of the upscale launches in that tail, and the board's clock / power sampled meanwhile."""
+    of the upscale launches in that tail, and the board's clocks (sclk, mclk, fclk) / power sampled meanwhile."""
     upscaler.set_profiling(True)
     upscaler.profile_collect()
-    sampler = ClockSampler().start()
+    sampler = ClockSampler(bdf, fallback_index=device_index).start()
     marks = []  # (seconds at the end of the batch, steps so far, launches in the batch, their ms)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -543,12 +668,93 @@ def sustained_leg(torch, do_step, upscaler, seconds, tail_s=3.0, batch=20):
         "ms_per_step_tail": round(tail_seconds / max(tail_steps, 1) * 1e3, 4),
         "tail_seconds": round(tail_seconds, 2), "tail_steps": tail_steps,
         "tail_upscale_launches": tail_launches, "tail_upscale_avg_launch_ms": round(tail_ms / max(tail_launches, 1), 4),
-        "clock_power_samples": {"tool": sampler.tool, "t_s__sclk_MHz__W": samples,
-                                "tail_mean_sclk_MHz": (round(sum(x[1] for x in in_tail if x[1]) / max(1, sum(1 for x in in_tail if x[1])))
-                                                       if any(x[1] for x in in_tail) else None),
-                                "tail_mean_W": (round(sum(x[2] for x in in_tail if x[2]) / max(1, sum(1 for x in in_tail if x[2])), 1)
-                                                if any(x[2] for x in in_tail) else None)},
+        "clock_power_samples": {"tool": sampler.tool, "t_s__sclk_MHz__W__mclk_MHz__fclk_MHz": samples,
+                                "tail_mean_sclk_MHz": ClockSampler.mean(in_tail, 1), "tail_mean_W": ClockSampler.mean(in_tail, 2, 1),
+                                "tail_mean_mclk_MHz": ClockSampler.mean(in_tail, 3), "tail_mean_fclk_MHz": ClockSampler.mean(in_tail, 4)},
     }
+
+
+def box_calibration(nsc, torch, dev, stream, scratch_src, scratch_dst):
+    """The denominators of this box (an on-box copy ceiling next to the 8 TB/s spec figure), each ONE plain
+    launch of nus_probe_device on the launch stream between two events, median of 5 after a warm-up: hipMemcpyDtoDAsync and a
+    16-B-per-lane stream copy over >= 2 GB (read + written bytes counted), a write-only and a read-only stream, the 1 R : 4 W
+    mix of a x2 upscale, and the f32 FMA rate of VGPR-only v_fmac chains at 8 waves per SIMD (nothing touches memory).
+    scratch_src / scratch_dst: device tensors the probes may overwrite (the bench's own output buffers, after the check)."""
+    L = nsc._capi.lib()
+    src, dst = scratch_src.reshape(-1), scratch_dst.reshape(-1)
+    copy_bytes = min(src.numel(), dst.numel(), 4 << 30) // 4096 * 4096
+    mix_bytes = min(src.numel(), dst.numel() // 4, 2 << 30) // 4096 * 4096
+    valu_iters = 20000
+
+    def timed(kind, nbytes, iters=0, reps=5):
+        ts = []
+        for i in range(reps + 1):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            if L.nus_probe_device(kind, src.data_ptr(), dst.data_ptr(), nbytes, iters, stream or None) != 0:
+                raise RuntimeError(nsc._capi.last_error())
+            e1.record()
+            e1.synchronize()
+            if i:
+                ts.append(e0.elapsed_time(e1) * 1e-3)
+        return _median(ts)
+
+    t_dtod, t_copy = timed(0, copy_bytes), timed(1, copy_bytes)
+    t_wr, t_rd = timed(2, copy_bytes), timed(3, copy_bytes)
+    t_mix = timed(4, mix_bytes)
+    t_valu = timed(5, 0, valu_iters)
+    fmas = nsc_probe_valu_lanes() * 16 * valu_iters
+    return {
+        "hipMemcpyDtoDAsync_GBps": round(2 * copy_bytes / t_dtod / 1e9, 1),
+        "stream_copy_float4_GBps": round(2 * copy_bytes / t_copy / 1e9, 1),
+        "write_only_GBps": round(copy_bytes / t_wr / 1e9, 1),
+        "read_only_GBps": round(copy_bytes / t_rd / 1e9, 1),
+        "one_read_four_writes_GBps": round(5 * mix_bytes / t_mix / 1e9, 1),
+        "valu_fma_f32_TFLOPs": round(2 * fmas / t_valu / 1e12, 2),
+        "bytes": {"copy": copy_bytes, "one_read_four_writes_read": mix_bytes},
+        "how": "nus_probe_device (nus_k_probe.hip): one plain launch per figure on the launch stream between two events, median "
+               "of 5 after a warm-up; copies count read + written bytes; valu = 2048 blocks x 256 lanes x 16 chains x "
+               f"{valu_iters} v_fmac_f32, operands in VGPRs",
+    }
+
+
+def nsc_probe_valu_lanes():
+    return 2048 * 256  # kProbeValuBlocks x 256 (nus_kernels.hpp)
+
+
+def config3_leg(torch, upscaler, frames, up_real, count, stream, seconds, bdf, device_index, up_bytes):
+    """BASELINE config 3 by itself: the 300-frame stream through the plain Lanczos-3 x2 kernel, launch after launch, for
+    `seconds`; the hipEvent brackets of the last two thirds, clocks and power meanwhile."""
+    upscaler.set_profiling(True)
+    for _ in range(3):
+        upscaler.upscale_device(frames.data_ptr(), up_real.data_ptr(), count, stream)
+    torch.cuda.synchronize()
+    upscaler.profile_collect()
+    sampler = ClockSampler(bdf, fallback_index=device_index).start()
+    t0 = time.perf_counter()
+    marks = []
+    while True:
+        for _ in range(20):
+            upscaler.upscale_device(frames.data_ptr(), up_real.data_ptr(), count, stream)
+        torch.cuda.synchronize()
+        nl, ms = upscaler.profile_collect()
+        marks.append((time.perf_counter() - t0, nl, ms))
+        if marks[-1][0] >= seconds:
+            break
+    samples = sampler.stop()
+    upscaler.set_profiling(False)
+    total = marks[-1][0]
+    tail = [m for m in marks if m[0] > total / 3.0] or marks[-1:]
+    t_start = max([m[0] for m in marks if m[0] <= total / 3.0] or [0.0])
+    nl, ms = sum(m[1] for m in tail), sum(m[2] for m in tail)
+    in_tail = [s for s in samples if s[0] >= t_start]
+    avg = ms / max(nl, 1)
+    achieved = up_bytes * count / (avg / 1e3) / 1e9
+    return {"seconds": round(total, 2), "launches_in_tail": nl, "avg_launch_ms": round(avg, 4),
+            "us_per_frame": round(avg * 1e3 / count, 3), "achieved": round(achieved, 1), "frac": round(achieved / HBM_PEAK_GBPS, 4),
+            "wall_ms_per_launch_tail": round((total - t_start) / max(nl, 1) * 1e3, 4),
+            "tail_mean_sclk_MHz": ClockSampler.mean(in_tail, 1), "tail_mean_W": ClockSampler.mean(in_tail, 2, 1),
+            "tail_mean_mclk_MHz": ClockSampler.mean(in_tail, 3), "tail_mean_fclk_MHz": ClockSampler.mean(in_tail, 4)}
 
 
 # ---------------------------------------------------------------------------------------------
@@ -556,26 +762,38 @@ def sustained_leg(torch, do_step, upscaler, seconds, tail_s=3.0, batch=20):
 # ---------------------------------------------------------------------------------------------
 
 def worker(args):
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE is {world}")
+    device_index = args.force_device if args.force_device >= 0 else local_rank
+
+    # Before this process makes its first HIP call: onto the CPUs of its GPU's NUMA node (a disjoint run of whole cores per
+    # rank), host threads sized to the rank's share of the CPUs the job may keep busy (copy pool, OpenMP teams).  The GPU's PCI
+    # address is asked of a child process; never a re-exec.
+    from nu_scaler_amd import placement as plc
+
+    if args.no_bind:
+        place = plc.bind_rank(device_index, local_world, apply=False)
+        place.update(bound=False, why_not="--no-bind")
+    else:
+        place = plc.bind_rank(device_index, local_world, slot=local_rank if args.force_device >= 0 else None)
+
     import torch
     import torch.distributed as dist
 
     import nu_scaler_amd as nsc
     from nu_scaler_amd import synthetic as syn
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE is {world}")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
-    if args.force_device >= 0:
-        local_rank = args.force_device
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(device_index)
+    dev = torch.device("cuda", device_index)
     nccl = args.backend == "nccl"
     comm_dev = dev if nccl else torch.device("cpu")  # gloo rehearsal: collectives on host tensors
     if world > 1:
@@ -583,9 +801,11 @@ def worker(args):
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group(args.backend, rank=rank, world_size=world)
+    bdf = place.get("gpu_bdf")
+    my_cpus = max(1, int(place.get("cpus_per_rank") or 1))
 
     w, h = args.width, args.height
-    pipe = nsc.FramePipeline(w, h, 2, "lanczos3", 0.5, device=local_rank, lanczos_mode=args.lanczos_mode)
+    pipe = nsc.FramePipeline(w, h, 2, "lanczos3", 0.5, device=device_index, lanczos_mode=args.lanczos_mode)
     # shared LUTs: rank 0's tables to everyone (RCCL over xGMI), so all GPUs use identical weights
     lut_bytes = nsc.broadcast_tables(pipe.upscaler, 0, comm_dev)
 
@@ -610,9 +830,12 @@ def worker(args):
     def barrier():
         if world > 1:
             if nccl:
-                dist.barrier(device_ids=[local_rank])
+                dist.barrier(device_ids=[device_index])
             else:
                 dist.barrier()
+
+    def gather(row):
+        return gather_rows(row, world, dist, torch, comm_dev)
 
     unit_schedule = args.schedule == "unit" and not args.fused and not args.overlap
 
@@ -645,33 +868,50 @@ def worker(args):
     launches, kernel_ms = pipe.upscaler.profile_collect() if profile else (0, 0.0)
     pipe.upscaler.set_profiling(False)
 
-    # max over ranks (and the spread, for the record)
-    per_rank = [elapsed_local]
-    if world > 1:
-        t = torch.tensor([elapsed_local], dtype=torch.float64, device=comm_dev)
-        gathered = [torch.zeros_like(t) for _ in range(world)]
-        dist.all_gather(gathered, t)
-        per_rank = [float(g.item()) for g in gathered]
-    elapsed = max(per_rank)
-
-    # The buffers the timed steps wrote, against the oracle -- before any other leg overwrites them.
-    timed_check = None
-    if rank == 0 and world == 1 and not args.no_check and args.pattern == "gradient" and args.lanczos_mode == "fma":
-        picks = sorted({0, count // 2 - 1 if count > 2 else 0, count - 1})
-        timed_check = {"tolerance": "in-between frames bit-exact; 4K frames max |diff| <= 1 LSB and < 0.1 % of samples "
-                                    "differing (Lanczos FMA mode)",
-                       "frames": check_timed_outputs(frames, None if args.fused else mid, up_real, up_mid, picks, w, h)}
+    # The buffers the timed steps wrote, against the oracle -- on EVERY rank, each on frames of ITS shard regenerated on the
+    # host, before any other leg overwrites them.  Nobody raises before the summaries have been gathered.
+    checkable = not args.no_check and args.pattern == "gradient" and args.lanczos_mode == "fma"
+    check_report, check = None, {"ok": None, "input_ok": None, "mid_exact": None, "max_abs_diff": None, "frac_differing": None,
+                                 "frames": None}
+    if checkable:
+        picks = sorted({0, count // 2 - 1 if count > 2 else 0, count - 1}) if world == 1 else sorted({0, count - 1})
+        check_report, check = check_timed_outputs(frames, None if args.fused else mid, up_real, up_mid, picks, w, h,
+                                                  first_frame=start, threads=my_cpus)
     else:
         # cheap sanity check: the outputs are fully written (alpha of the opaque stream stays 255)
         assert args.pattern != "gradient" or (int(up_real[0, ..., 3].min()) == 255 and int(up_mid[count - 1, ..., 3].min()) == 255)
 
-    # What the very same step sustains for seconds (N=1 only; never `value`): ms per step over the last 3 s,
-    # hipEvent brackets of the upscale launches in that tail, board clock and power sampled meanwhile.
+    # What the very same step sustains for seconds, on every rank at the same time (never `value`): ms per step over the last
+    # 3 s, hipEvent brackets of the upscale launches in that tail, the rank's own GPU's clocks and power sampled meanwhile.
     sustained = None
-    if rank == 0 and world == 1 and args.sustained_seconds > 0:
-        sustained = sustained_leg(torch, do_step, pipe.upscaler, args.sustained_seconds)
+    if args.sustained_seconds > 0:
+        barrier()
+        sustained = sustained_leg(torch, do_step, pipe.upscaler, args.sustained_seconds, bdf=bdf, device_index=device_index)
+        barrier()
 
-    extras = rank == 0 and world == 1 and not args.no_extras and not args.fused and not args.overlap
+    unit_launch_bytes = pipe.unit_bytes if unit_schedule else (w * h + 4 * w * h) * 4
+    cps = (sustained or {}).get("clock_power_samples", {})
+    row = {
+        "elapsed_s": elapsed_local,
+        "bracket_ms": (kernel_ms / launches) if launches else None,
+        "frac": (unit_launch_bytes * count / (kernel_ms / launches / 1e3) / 1e9 / HBM_PEAK_GBPS) if launches else None,
+        "check_ok": check["ok"], "check_input_ok": check["input_ok"], "check_mid_exact": check["mid_exact"],
+        "check_max_abs_diff": check["max_abs_diff"], "check_frac_differing": check["frac_differing"], "check_frames": check["frames"],
+        "sustained_ms_per_step": (sustained or {}).get("ms_per_step_tail"),
+        "sustained_bracket_ms": (sustained or {}).get("tail_upscale_avg_launch_ms") or None,
+        "sclk_MHz": cps.get("tail_mean_sclk_MHz"), "mclk_MHz": cps.get("tail_mean_mclk_MHz"),
+        "fclk_MHz": cps.get("tail_mean_fclk_MHz"), "W": cps.get("tail_mean_W"),
+        "numa_node": place.get("numa_node"), "bound": 1.0 if place.get("bound") else 0.0, "cpus_per_rank": my_cpus,
+        "n_cpus_in_mask": place.get("n_cpus_in_mask"), "copy_threads": place.get("copy_threads"),
+        "first_frame": start,
+    }
+    rows = gather(row)
+    per_rank = [r["elapsed_s"] for r in rows]
+    elapsed = max(per_rank)
+    check_failed = checkable and any(r["check_ok"] != 1.0 for r in rows)
+
+    solo = rank == 0 and world == 1
+    extras = solo and not args.no_extras and not args.fused and not args.overlap
 
     def timed_leg(step_fn, n, with_profile=True):
         """(ms per step, bracketed launches, their summed ms) of n steps after 2 warm-ups; informational legs only."""
@@ -689,7 +929,7 @@ def worker(args):
         pipe.upscaler.set_profiling(False)
         return ms, nl, kms
 
-    n_leg = max(3, args.steps // 6)
+    n_leg = max(3, min(args.steps, 450) // 6, 25 if solo else 3)
     step3 = lambda: pipe.step(frames, mid, up_real, up_mid, stream)       # noqa: E731
     stepu = lambda: pipe.step_unit(frames, mid, up_real, up_mid, stream)  # noqa: E731
     other_schedule_leg = fused_leg = None
@@ -700,12 +940,20 @@ def worker(args):
         # Informational: the two 4K outputs only (blend inside the second upscale's row loads, in-between frame not written)
         fused_leg = timed_leg(lambda: pipe.step_fused(frames, up_real, up_mid, stream), n_leg, with_profile=False)
 
-    # Informational: the on-box ceiling for an upscale's very bytes -- k_nearest_x2 reads the same 1080p frames and
-    # writes the same 4K frames with no arithmetic -- so the fractions can be read next to what the memory
-    # system of this box sustains, not only next to the 8 TB/s spec figure.
+    # The denominators of THIS box, on every rank (a few milliseconds of plain kernels over the output buffers, which the
+    # check is done with): copy ceilings and the f32 FMA rate -- boxes of one pool differ by 7-15 % on one binary.
+    calib = None
+    if not args.no_extras and profile:
+        calib = box_calibration(nsc, torch, dev, stream, up_mid, up_real)
+    crow = {k: (calib or {}).get(k) for k in ("hipMemcpyDtoDAsync_GBps", "stream_copy_float4_GBps", "write_only_GBps",
+                                              "read_only_GBps", "one_read_four_writes_GBps", "valu_fma_f32_TFLOPs")}
+    crows = gather(crow)
+
+    # Informational: the on-box ceiling for an upscale's very bytes AND access pattern -- k_nearest_x2 reads the same 1080p
+    # frames and writes the same 4K frames with no arithmetic.
     copy_ms = None
     if extras and profile:
-        nn = nsc.PyWgpuUpscaler("quality", "nearest", device=local_rank)
+        nn = nsc.PyWgpuUpscaler("quality", "nearest", device=device_index)
         nn.initialize(w, h, 2 * w, 2 * h)
         nn.set_profiling(True)
         for _ in range(2):
@@ -734,6 +982,13 @@ def worker(args):
         pipe.interp.set_mode("exact")
         del flows
 
+    up_bytes = (w * h + 4 * w * h) * 4  # algorithmic bytes of one upscaled frame
+    # BASELINE config 3 by itself, this pattern: the plain Lanczos stream back to back for seconds
+    config3 = {}
+    if extras and profile and args.config3_seconds > 0:
+        config3[args.pattern] = config3_leg(torch, pipe.upscaler, frames, up_real, count, stream, args.config3_seconds, bdf,
+                                            device_index, up_bytes)
+
     # Informational: both schedules on the other pattern (gradient = opaque frames, the kernel's
     # 3-channel path; noise = real alpha, its 4-channel path), each with its own hipEvent bracket.
     other = None
@@ -741,38 +996,44 @@ def worker(args):
         other_pattern = "noise" if args.pattern == "gradient" else "gradient"
         fill(other_pattern)
         other = (other_pattern, timed_leg(do_step, n_leg), timed_leg(step3 if unit_schedule else stepu, n_leg))
+        if profile and args.config3_seconds > 0:
+            config3[other_pattern] = config3_leg(torch, pipe.upscaler, frames, up_real, count, stream, args.config3_seconds, bdf,
+                                                 device_index, up_bytes)
 
     # (the device buffers stay allocated meanwhile: on this ROCm stack, copies in both directions at once take 1.8x as long
     # in a process that has just returned 25 GB to the driver -- profiles/r03_host_path_process_state.txt)
     host_path = None
     if extras:
-        host_path = host_path_leg(nsc, syn, torch, w, h, local_rank)
+        host_path = host_path_leg(nsc, syn, torch, w, h, device_index)
 
     # Mode (ii): every rank feeds its own GPU from host memory at the same time (any N; never `value`).  After the other host
     # legs: the same place in the process's life as config.host_path's batch figure
     host_fed = None
     if args.host_fed_seconds > 0 and not args.no_extras:
-        rate = host_fed_leg(nsc, syn, w, h, local_rank, args.host_fed_seconds, barrier)
-        rates = [rate]
-        if world > 1:
-            tr = torch.tensor([rate], dtype=torch.float64, device=comm_dev)
-            got = [torch.zeros_like(tr) for _ in range(world)]
-            dist.all_gather(got, tr)
-            rates = [float(g.item()) for g in got]
+        rate = host_fed_leg(nsc, syn, w, h, device_index, args.host_fed_seconds, barrier)
+        hrows = gather({"rate": rate, "numa_node": place.get("numa_node"), "bound": 1.0 if place.get("bound") else 0.0})
+        rates = [r["rate"] for r in hrows]
         frame_mb = (w * h + 4 * w * h) * 4 / 1e6
+        by_node = {}
+        for r in hrows:
+            key = "unknown" if r["numa_node"] is None else str(int(r["numa_node"]))
+            by_node[key] = round(by_node.get(key, 0.0) + r["rate"] * frame_mb / 1e3, 2)
         host_fed = {
             "what": "mode (ii): each rank pushes a host-resident shard (12 pageable 1080p frames per call, outputs into pageable "
                     "4K buffers) through nus_upscaler_upscale_batch -- one submitting thread + a retiring thread + the copy pool, "
                     "three slot streams per GPU -- all ranks at the same time, between two barriers",
             "seconds": args.host_fed_seconds, "frames_4k_per_s_total": round(sum(rates), 1),
-            "frames_4k_per_s_per_gpu": {"min": round(min(rates), 1), "max": round(max(rates), 1)},
+            "frames_4k_per_s_per_gpu": {"min": round(min(rates), 1), "max": round(max(rates), 1),
+                                        "by_rank": [round(x, 1) for x in rates]},
             "host_device_GBps_total": round(sum(rates) * frame_mb / 1e3, 2),
+            "host_device_GBps_by_numa_node": by_node,
+            "fed_from_numa_node_by_rank": [None if r["numa_node"] is None else int(r["numa_node"]) for r in hrows],
+            "bound_by_rank": [bool(r["bound"]) for r in hrows],
             "target_4k_frames_per_s_per_gpu": 60}
 
     if rank == 0:
         total_units = n_units * world * args.steps
         value = total_units * pipe.unit_pixels / elapsed / 1e6
-        up_bytes = (w * h + 4 * w * h) * 4  # algorithmic bytes of one upscaled frame
         # what one bracketed launch processes: a whole unit per frame (107 827 200 B at 1080p: blend 24 883 200 + 2 x 41 472 000,
         # SURVEY.md section 8d) in the unit schedule, one upscaled frame otherwise
         launch_bytes = lambda is_unit: (pipe.unit_bytes if is_unit else up_bytes) * count  # noqa: E731
@@ -791,12 +1052,14 @@ def worker(args):
                 "achieved": r["achieved"], "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": r["frac"], "traffic": None,
                 "bytes_per_launch": launch_bytes(unit_schedule), "units_per_launch": count, "launches": launches,
                 "avg_launch_ms": r["avg_launch_ms"], "pattern": args.pattern,
+                "frac_by_rank": spread(rows, "frac"),
                 "note": ("achieved = algorithmic bytes of the units one launch processes (SURVEY.md 8d: 107 827 200 B per unit = "
                          "zero-flow interpolation 24 883 200 + two upscales of 41 472 000) / hipEvent time on the launch stream "
                          "inside the timed region; the bracket holds every launch of the step (the unit kernel and the two "
                          "edge-column passes: rocprofv3 --stats shows three kernels).  The unit kernel moves fewer bytes than "
-                         "that -- `traffic` -- because each input row reaches it from HBM about once (not four times) and the "
-                         "in-between frame is written, never re-read; `upscale_kernel_alone` is k_lanczos3_x2 by itself. "
+                         "that -- `traffic`, and `moved` = traffic / the same time: the fraction is earned by NOT moving bytes "
+                         "(each input row reaches the kernel from HBM about once, not four times; the in-between frame is "
+                         "written, never re-read); `upscale_kernel_alone` is k_lanczos3_x2 by itself. "
                          if unit_schedule else
                          "achieved = algorithmic bytes (8 294 400 R + 33 177 600 W per frame) / hipEvent time on the launch "
                          "stream inside the timed region; the bracket holds the main kernel and its edge-column pass. ") +
@@ -814,11 +1077,21 @@ def worker(args):
                 roofline[key]["what"] = ("k_lanczos3_x2 + its edge pass by itself (the upscale launches of the three-stage schedule on "
                                          "the same frames, after the timed region): 41 472 000 algorithmic bytes per frame"
                                          if unit_schedule else "the one-launch step on the same frames, after the timed region")
-            if copy_ms:
-                ceiling = up_bytes * count / (copy_ms / 1e3) / 1e9
-                roofline["copy_ceiling"] = {
-                    "GBps": round(ceiling, 1),
-                    "how": "k_nearest_x2 over the same frames (an upscale's bytes in and out, no arithmetic), hipEvent time"}
+            if calib or copy_ms:
+                cc = dict(calib or {})
+                if copy_ms:
+                    cc["k_nearest_x2_GBps"] = round(up_bytes * count / (copy_ms / 1e3) / 1e9, 1)
+                    cc["GBps"] = cc["k_nearest_x2_GBps"]  # (the key rounds 1-3 reported)
+                    cc["k_nearest_x2_how"] = ("k_nearest_x2 over the same frames (an upscale's bytes in and out in its own access "
+                                              "pattern, no arithmetic), hipEvent time")
+                cc["by_rank"] = {k: spread(crows, k, 2) for k in crow} if world > 1 else None
+                roofline["copy_ceiling"] = cc
+            if config3:
+                roofline["config3"] = dict(
+                    config3,
+                    what="BASELINE config 3 by itself: the 300-frame stream through k_lanczos3_x2 (+ its edge pass), launch after "
+                         "launch for seconds, nothing in between; hipEvent brackets of the last two thirds; 41 472 000 "
+                         "algorithmic bytes per frame against the 8 TB/s peak")
             if other and other[1][1]:
                 roofline["other_pattern"] = dict(roof(other[1][1], other[1][2], unit_schedule), pattern=other[0])
                 if other[2][1]:
@@ -828,6 +1101,16 @@ def worker(args):
         def leg(ms):
             return {"ms_per_step": round(ms, 4), "Mpix_per_s_per_gpu": round(n_units * pipe.unit_pixels / ms / 1e3, 1)}
 
+        per_rank_check = None
+        if checkable:
+            per_rank_check = {
+                "tolerance": "source frames regenerated on the host and equal to the rank's device-resident input; in-between "
+                             "frames bit-exact; 4K frames max |diff| <= 1 LSB and < 0.1 % of samples differing (Lanczos FMA mode)",
+                "all_ok": not check_failed,
+                "by_rank": [{"rank": i, "ok": r["check_ok"] == 1.0, "first_stream_frame": int(r["first_frame"]),
+                             "frames_checked": int(r["check_frames"] or 0), "input_ok": r["check_input_ok"] == 1.0,
+                             "mid_bit_exact": r["check_mid_exact"] == 1.0, "max_abs_diff": r["check_max_abs_diff"],
+                             "frac_differing": r["check_frac_differing"]} for i, r in enumerate(rows)]}
         out = {
             "metric": baseline_metric(),
             "value": round(value, 1),
@@ -859,8 +1142,28 @@ def worker(args):
                             f"{'RCCL' if nccl else args.backend}",
                 "lut_broadcast_bytes": lut_bytes,
                 "ms_per_step_by_rank": {"min": round(min(per_rank) / args.steps * 1e3, 4),
-                                        "max": round(max(per_rank) / args.steps * 1e3, 4)},
-                "timed_output_check": timed_check,
+                                        "max": round(max(per_rank) / args.steps * 1e3, 4),
+                                        "by_rank": [round(x / args.steps * 1e3, 4) for x in per_rank]},
+                "placement": {
+                    "rank0": place,
+                    "numa_node_by_rank": [None if r["numa_node"] is None else int(r["numa_node"]) for r in rows],
+                    "bound_by_rank": [bool(r["bound"]) for r in rows],
+                    "cpus_per_rank": [int(r["cpus_per_rank"]) for r in rows],
+                    "n_cpus_in_mask_by_rank": [None if r["n_cpus_in_mask"] is None else int(r["n_cpus_in_mask"]) for r in rows],
+                    "copy_threads_by_rank": [None if r["copy_threads"] is None else int(r["copy_threads"]) for r in rows],
+                    "how": "nu_scaler_amd/placement.py: PCI address of the rank's HIP device from a child process, NUMA node and "
+                           "local CPUs from sysfs, os.sched_setaffinity to a disjoint run of whole cores before the first HIP "
+                           "call; copy pool / OpenMP sized to the rank's share of the CPUs the job may keep busy"},
+                "per_rank": {
+                    "bracket_ms": spread(rows, "bracket_ms"), "sustained_ms_per_step": spread(rows, "sustained_ms_per_step"),
+                    "sustained_bracket_ms": spread(rows, "sustained_bracket_ms"),
+                    "sclk_MHz": spread(rows, "sclk_MHz", 0), "mclk_MHz": spread(rows, "mclk_MHz", 0),
+                    "fclk_MHz": spread(rows, "fclk_MHz", 0), "W": spread(rows, "W", 1),
+                    "what": "every rank's own numbers (all_gather): hipEvent bracket of the timed region, the sustained leg's "
+                            "tail on all ranks at the same time, that rank's GPU's clocks and power in that tail"},
+                "per_rank_check": per_rank_check,
+                "timed_output_check": None if check_report is None else {
+                    "tolerance": per_rank_check["tolerance"], "rank": 0, "frames": check_report},
                 "timed_region_s": round(elapsed, 3),
                 "sustained": sustained,
                 ("three_stage_variant" if unit_schedule else "unit_variant"): None if other_schedule_leg is None else dict(
@@ -877,6 +1180,11 @@ def worker(args):
                     what=f"the timed schedule on the {other[0]} stream (gradient = opaque frames, the x2 kernel's "
                          f"3-channel path; noise = real alpha, its 4-channel path); informational, after the timed region",
                     other_schedule=leg(other[2][0])),
+                "lanczos_stream_alone": None if not config3 else {
+                    p: {"ms_per_300_frames": c["avg_launch_ms"], "us_per_frame": c["us_per_frame"],
+                        "frames_per_s": round(count / (c["avg_launch_ms"] / 1e3), 1),
+                        "Mpix_per_s": round(count * 5 * w * h / (c["avg_launch_ms"] / 1e3) / 1e6, 1),
+                        "sclk_MHz": c["tail_mean_sclk_MHz"], "W": c["tail_mean_W"]} for p, c in config3.items()},
                 "motion_variant": None if motion_ms is None else {
                     "what": "three-stage step with a dense flow per pair (3-level pyramid, 50 + 10 + 10 Horn-Schunck steps) "
                             "feeding the warp (FMA mode) instead of zero flow; informational, this rank only",
@@ -893,12 +1201,26 @@ def worker(args):
             traffic, detail = measure_traffic(count, unit_schedule)
             roofline["traffic"] = traffic
             roofline["traffic_detail"] = detail
+            if traffic:
+                t_s = roofline["avg_launch_ms"] / 1e3
+                moved = traffic / t_s / 1e9
+                cc = roofline.get("copy_ceiling") or {}
+                roofline["moved"] = {
+                    "GBps": round(moved, 1), "frac_of_peak": round(moved / HBM_PEAK_GBPS, 4),
+                    "frac_of_copy_ceiling": {k: round(moved / cc[k], 4) for k in
+                                             ("stream_copy_float4_GBps", "hipMemcpyDtoDAsync_GBps", "one_read_four_writes_GBps",
+                                              "k_nearest_x2_GBps") if cc.get(k)},
+                    "what": "the bytes the bracket's kernels really move through HBM (`traffic`, PMC) / the bracket's time: the "
+                            "HBM-throughput reading of the same launch, next to `frac` (algorithmic bytes, SURVEY.md 8d)"}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, pipe.unit_pixels)
         print(json.dumps(out), flush=True)
     if world > 1:
         barrier()
         dist.destroy_process_group()
+    if check_failed:
+        bad = [i for i, r in enumerate(rows) if r["check_ok"] != 1.0]
+        raise SystemExit(f"bench.py: timed outputs differ from the oracle on rank(s) {bad} (config.per_rank_check)")
 
 
 def main():

@@ -125,6 +125,15 @@ int nus_device_memory_info(int device, uint64_t *free_bytes, uint64_t *total_byt
  * caller's buffer by itself: it cannot know when the memory is given back. */
 int nus_host_pin(void *buffer, size_t bytes);
 int nus_host_unpin(void *buffer);
+/* Calibration of the box a measurement runs on (not in the reference; bench.py's denominators next to the 8 TB/s spec figure --
+ * SURVEY.md section 8(d) "on-box copy ceiling" -- never on the product path).  Enqueues ONE plain kernel (or the runtime's
+ * copy) on `stream`; the caller brackets it with events.  kind: 0 hipMemcpyDtoDAsync of `bytes`; 1 stream copy, 16 B per lane,
+ * read one write one; 2 write-only stream of `bytes` into d_dst; 3 read-only stream of `bytes` from d_src (d_dst: >= 4 bytes of
+ * device memory); 4 one read : four writes -- `bytes` read from d_src, 4 * `bytes` written to d_dst, each store instruction one
+ * contiguous KiB per wave (the byte mix of a x2 upscale with no arithmetic); 5 VGPR-only f32 FMA chains, nothing touches
+ * memory: 2048 blocks x 256 lanes x 16 chains x `iters` FMAs (d_dst: >= 2 MiB, never written).  Pointers 16-byte aligned,
+ * `bytes` a multiple of 16. */
+int nus_probe_device(int kind, const void *d_src, void *d_dst, size_t bytes, uint32_t iters, void *stream);
 /* Thread-local message of the last failing call on this thread ("" if none). */
 const char *nus_last_error(void);
 const char *nus_status_string(int status);

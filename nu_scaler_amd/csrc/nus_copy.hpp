@@ -23,6 +23,12 @@ struct CopyTicket {
 void parallel_copy_async(void *dst, const void *src, size_t bytes, CopyTicket &ticket);
 void parallel_copy_wait(CopyTicket &ticket);
 
+// Ask the workers to make the pages of a (pageable, writable) buffer present while something else is going on -- the output
+// buffer of a frame while the frame is on the GPU: a result buffer fresh from the allocator otherwise takes its first-touch
+// faults inside the copy-out.  Contents are never changed; already-present pages cost a page-table walk.  Nothing is queued
+// for small buffers or when the pool has no workers.  Wait for `ticket` (parallel_copy_wait) before the buffer may go away.
+void parallel_populate_async(void *dst, size_t bytes, CopyTicket &ticket);
+
 // number of worker threads in use (0 when disabled or in a forked child)
 int parallel_copy_workers();
 

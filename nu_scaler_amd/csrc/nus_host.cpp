@@ -926,9 +926,9 @@ int HipUpscaler::submit_frame_banded(Slot &S, const uint8_t *in, uint8_t *out, b
             }
         }
     }
-    (void)out_bytes;
     NUS_HIP(hipEventRecord(S.in_done, s_in_));
     NUS_HIP(hipEventRecord(S.out_done, s_out_));
+    if (!*direct) parallel_populate_async(out, out_bytes, S.populate); // (after the last band is on its way: see submit_frame)
     S.used = true;
     return kOk;
 }
@@ -967,6 +967,10 @@ int HipUpscaler::submit_frame(Slot &S, const uint8_t *in, uint8_t *out, bool *di
         }
     }
     NUS_HIP(hipEventRecord(S.out_done, s_out_));
+    // Everything of the frame is queued: while it is on the GPU and on the wire the pool's workers make the caller's output
+    // pages present (a result buffer fresh from the allocator -- the Vec / PyBytes `upscale` returns -- is 8 100 first-touch
+    // faults that would otherwise be taken inside the copy-out; resident pages cost a page-table walk).
+    if (!*direct) parallel_populate_async(out, out_bytes, S.populate);
     S.used = true;
     return kOk;
 }
@@ -984,6 +988,10 @@ int HipUpscaler::retire_frame(Slot &S, uint8_t *out, bool direct, std::string *e
         const hipError_t e = hipEventSynchronize(S.out_done);
         return e == hipSuccess ? kOk : hip_failed(e, "hipEventSynchronize(out_done)");
     }
+    struct PopulateDone { // on every way out: queued populate requests point into `out`
+        CopyTicket &t;
+        ~PopulateDone() { parallel_copy_wait(t); }
+    } populate_done{S.populate};
     CopyTicket ticket; // the frame's pieces: queued as they land, all copied when the wait returns
     int rc = kOk;
     size_t off = 0;

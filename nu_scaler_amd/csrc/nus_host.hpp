@@ -21,6 +21,7 @@
 #include <vector>
 
 #include "nus_kernels.hpp"
+#include "nus_copy.hpp"
 #include "nus_tables.hpp"
 
 namespace nus {
@@ -144,6 +145,7 @@ private:
         hipEvent_t band_in[kBands] = {}, band_k[kBands] = {}; // banded single frame: H2D / kernel of band b done
         int nchunks = 0;                            // pieces of the frame in flight (pageable output) ...
         size_t chunk_end[kOutChunks] = {};          // ... and where each ends (set by submit_frame, read by retire_frame)
+        CopyTicket populate;                        // the caller's (pageable) output buffer being made resident meanwhile
     };
     // How a pageable output frame is cut into D2H pieces.  Every piece costs the copy engine ~17 us of dead time (the event
     // between two copies of one stream: profiles/r03_host_path_copy_timeline.txt), and buys overlap of the copy out of the

@@ -186,6 +186,12 @@ int HipFrameInterpolator::interpolate(const uint8_t *a, size_t a_len, const uint
     NUS_HIP(hipMemcpyAsync(ho, d_out_, first, hipMemcpyDeviceToHost, stream_));
     NUS_HIP(hipEventRecord(half_done_, stream_));
     if (first < expected) NUS_HIP(hipMemcpyAsync(ho + first, d_out_ + first, expected - first, hipMemcpyDeviceToHost, stream_));
+    // while the pair is on the GPU: the pages of a result buffer fresh from the allocator (what interpolate_py returns)
+    struct Populate {
+        CopyTicket t;
+        ~Populate() { parallel_copy_wait(t); } // on every way out: queued requests point into `out`
+    } populate;
+    parallel_populate_async(out, expected, populate.t);
     NUS_HIP(hipEventSynchronize(half_done_));
     parallel_copy(out, ho, first);
     NUS_HIP(hipStreamSynchronize(stream_));

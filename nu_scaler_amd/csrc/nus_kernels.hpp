@@ -211,4 +211,10 @@ bool hs_iterate_streams(uint32_t w, uint32_t h, uint32_t n, int kernel);
 hipError_t launch_flow_upsample(const float *src, uint32_t sw, uint32_t sh, float *dst, uint32_t dw, uint32_t dh,
                                 float scale, hipStream_t stream, uint32_t n = 1, size_t src_stride = 0, size_t dst_stride = 0);
 
+// Box calibration (nus_k_probe.hip; bench.py's denominators, not on the product path): kind 0 hipMemcpyDtoDAsync, 1 stream
+// copy, 2 write-only, 3 read-only (d_dst: 4 bytes of device memory), 4 one read : four writes (d_dst holds 4 * bytes),
+// 5 VGPR-only FMA chains (kProbeValuBlocks blocks of 256 lanes, 16 chains of `iters` FMAs each; d_dst: that many floats).
+constexpr uint32_t kProbeValuBlocks = 2048;
+hipError_t launch_probe(int kind, const void *d_src, void *d_dst, size_t bytes, uint32_t iters, hipStream_t stream);
+
 } // namespace nus

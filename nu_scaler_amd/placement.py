@@ -1,0 +1,225 @@
+"""Where a rank's host threads run: next to its GPU.
+
+One process per GPU.  A rank's host side -- the submitting thread, the retiring thread, the copy
+pool and the pinned staging buffers they touch first -- belongs on the NUMA node its GPU hangs off: on the two-socket hosts of
+this pool a 1080p frame goes up at 26 GB/s from the far socket and at 53.7 GB/s from the near one
+(profiles/r03_numa_pinned_copy_probe.txt), and eight unbound ranks would each measure their placement luck.
+
+`bind_rank` must run BEFORE the process makes its first HIP call (threads the runtime starts and pages the process touches
+afterwards inherit the mask): the GPU's PCI address is therefore asked of a short-lived CHILD process (it initialises HIP, this
+process does not), the node and its CPUs come from sysfs, and the mask is set with os.sched_setaffinity -- never a re-exec.
+Everything degrades to "not bound" with the reason recorded: a bench line must say what happened on every rank, not guess.
+
+The reference has no counterpart (one GPU, one process: nu_scaler_core/src/gpu/detector.rs:136-165 picks the adapter)."""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+from typing import Dict, List, Optional, Sequence
+
+_PCI_QUERY = r"""
+import ctypes, json, os, sys
+out = []
+try:
+    hip = None
+    for name in ("libamdhip64.so", "/opt/rocm/lib/libamdhip64.so", "libamdhip64.so.7", "libamdhip64.so.6"):
+        try:
+            hip = ctypes.CDLL(name)
+            break
+        except OSError:
+            continue
+    if hip is None:
+        raise OSError("libamdhip64.so not found")
+    n = ctypes.c_int(0)
+    if hip.hipGetDeviceCount(ctypes.byref(n)) != 0:
+        raise OSError("hipGetDeviceCount failed")
+    for i in range(n.value):
+        buf = ctypes.create_string_buffer(64)
+        out.append(buf.value.decode().lower() if hip.hipDeviceGetPCIBusId(buf, 64, i) == 0 else None)  # sysfs: lower case
+    print(json.dumps({"bdf": out}))
+except Exception as e:
+    print(json.dumps({"bdf": out, "error": "%s: %s" % (type(e).__name__, e)}))
+"""
+
+
+def parse_cpulist(text: str) -> List[int]:
+    """'0-3,8,10-11' -> [0, 1, 2, 3, 8, 10, 11] (the kernel's cpulist format)."""
+    cpus: List[int] = []
+    for part in text.strip().split(","):
+        part = part.strip()
+        if not part:
+            continue
+        if "-" in part:
+            a, b = part.split("-", 1)
+            cpus.extend(range(int(a), int(b) + 1))
+        else:
+            cpus.append(int(part))
+    return sorted(set(cpus))
+
+
+def format_cpulist(cpus: Sequence[int]) -> str:
+    cpus = sorted(set(int(c) for c in cpus))
+    runs, i = [], 0
+    while i < len(cpus):
+        j = i
+        while j + 1 < len(cpus) and cpus[j + 1] == cpus[j] + 1:
+            j += 1
+        runs.append(str(cpus[i]) if i == j else f"{cpus[i]}-{cpus[j]}")
+        i = j + 1
+    return ",".join(runs)
+
+
+def cgroup_cpu_quota() -> Optional[float]:
+    """CPUs' worth of CFS quota of this process's cgroup (cpu.max / cpu.cfs_quota_us), None = unlimited or unreadable."""
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            q, p = f.read().split()[:2]
+        return None if q == "max" else int(q) / int(p)
+    except (OSError, ValueError, IndexError):
+        pass
+    try:
+        with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f:
+            q = int(f.read().split()[0])
+        with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+            p = int(f.read().split()[0])
+        return q / p if q > 0 else None
+    except (OSError, ValueError, IndexError):
+        return None
+
+
+def usable_cpus() -> int:
+    """CPUs this process may keep busy: its affinity mask capped by the cgroup's CPU quota (a GPU box of this pool gives a job
+    16 CPUs' worth of the host's 256 hardware threads)."""
+    n = len(os.sched_getaffinity(0))
+    q = cgroup_cpu_quota()
+    return n if q is None else max(1, min(n, int(q + 0.5)))
+
+
+def query_gpu_pci(timeout: float = 60.0) -> Dict:
+    """PCI addresses ('0000:d9:00.0') of the HIP devices in HIP's own order, honouring HIP_/ROCR_VISIBLE_DEVICES exactly as
+    this process will -- asked of a child process, so that this one has still made no HIP call."""
+    try:
+        res = subprocess.run([sys.executable, "-c", _PCI_QUERY], capture_output=True, text=True, timeout=timeout)
+        import json
+
+        for line in reversed(res.stdout.splitlines()):
+            if line.startswith("{"):
+                return json.loads(line)
+        return {"bdf": [], "error": f"no answer from the query child (rc {res.returncode})"}
+    except Exception as e:  # a missing interpreter, a timeout: placement is best effort
+        return {"bdf": [], "error": f"{type(e).__name__}: {e}"}
+
+
+def pci_numa(bdf: str, sysfs: str = "/sys") -> Dict:
+    """NUMA node and local CPUs of a PCI device from sysfs; node -1 / None when the platform does not say."""
+    base = os.path.join(sysfs, "bus", "pci", "devices", bdf)
+    info: Dict = {"bdf": bdf, "numa_node": None, "local_cpus": []}
+    try:
+        with open(os.path.join(base, "numa_node")) as f:
+            info["numa_node"] = int(f.read().strip())
+    except (OSError, ValueError):
+        pass
+    try:
+        with open(os.path.join(base, "local_cpulist")) as f:
+            info["local_cpus"] = parse_cpulist(f.read())
+    except (OSError, ValueError):
+        pass
+    return info
+
+
+def _core_of(cpu: int, sysfs: str) -> int:
+    """The lowest sibling of `cpu`'s physical core (so that SMT siblings are dealt out together); the CPU itself if unknown."""
+    try:
+        with open(os.path.join(sysfs, "devices", "system", "cpu", f"cpu{cpu}", "topology", "thread_siblings_list")) as f:
+            return parse_cpulist(f.read())[0]
+    except (OSError, ValueError, IndexError):
+        return cpu
+
+
+def plan_binding(devices: Sequence[Dict], local_rank: int, local_world: int, mask: Sequence[int],
+                 quota: Optional[float] = None, sysfs: str = "/sys", device_of_rank: Optional[Sequence[int]] = None) -> Dict:
+    """Pure planning step (no side effects; tests drive it with made-up topologies).
+
+    devices[i] = pci_numa() of HIP device i; rank r uses device device_of_rank[r] (default: r).  The ranks whose GPUs share
+    a node share that node's CPUs (those of them in `mask`), dealt out in whole physical cores, contiguous runs, in rank
+    order; a rank whose GPU's node is unknown, or whose node has fewer cores in the mask than ranks, keeps the mask it has.
+    cpus_per_rank = what the rank may keep busy: its slice, capped by its share of the cgroup quota."""
+    mask = sorted(set(int(c) for c in mask))
+    in_mask = set(mask)
+    dor = list(device_of_rank) if device_of_rank is not None else list(range(max(local_world, local_rank + 1)))
+    share = max(1, len(mask) // max(1, local_world))
+    if quota is not None:
+        share = max(1, min(share, int(quota / max(1, local_world) + 0.5)))
+    plan = {"bound": False, "why_not": None, "gpu_bdf": None, "numa_node": None, "cpus": mask, "cpus_per_rank": share,
+            "ranks_on_node": None}
+    if not (0 <= local_rank < len(dor)) or not (0 <= dor[local_rank] < len(devices)):
+        plan["why_not"] = f"no PCI address for the HIP device of local rank {local_rank} ({len(devices)} reported)"
+        return plan
+    dev = devices[dor[local_rank]]
+    plan["gpu_bdf"], plan["numa_node"] = dev.get("bdf"), dev.get("numa_node")
+    if dev.get("numa_node") is None or dev.get("numa_node") < 0 or not dev.get("local_cpus"):
+        plan["why_not"] = "sysfs gives no NUMA node / local CPUs for this GPU"
+        return plan
+    local = [c for c in dev["local_cpus"] if c in in_mask]
+    if not local:
+        plan["why_not"] = "none of the GPU's local CPUs is in this process's affinity mask"
+        return plan
+    peers = [r for r in range(min(local_world, len(dor)))
+             if 0 <= dor[r] < len(devices) and devices[dor[r]].get("numa_node") == dev["numa_node"]]
+    if local_rank not in peers:
+        peers = sorted(peers + [local_rank])
+    plan["ranks_on_node"] = len(peers)
+    cores: Dict[int, List[int]] = {}
+    for c in local:
+        cores.setdefault(_core_of(c, sysfs), []).append(c)
+    core_ids = sorted(cores)
+    if len(core_ids) < len(peers):
+        plan["why_not"] = f"{len(core_ids)} local cores in the mask for {len(peers)} ranks on node {dev['numa_node']}"
+        return plan
+    k = peers.index(local_rank)
+    per = len(core_ids) // len(peers)
+    mine = core_ids[k * per:(k + 1) * per]
+    cpus = sorted(c for core in mine for c in cores[core])
+    plan.update(bound=True, cpus=cpus)
+    cap = len(cpus)
+    if quota is not None:
+        cap = max(1, min(cap, int(quota / max(1, local_world) + 0.5)))
+    plan["cpus_per_rank"] = cap
+    return plan
+
+
+def thread_budget(cpus_per_rank: int) -> Dict[str, int]:
+    """Host threads of one rank inside its CPU share: the submitting and the retiring thread of the host path always exist;
+    the copy pool gets what is left, up to the 3 workers it has by default (nus_copy.cpp); OpenMP teams (the checker's) take
+    the whole share -- they never run beside the host path."""
+    return {"copy_threads": max(0, min(3, int(cpus_per_rank) - 2)), "omp_threads": max(1, int(cpus_per_rank))}
+
+
+def bind_rank(device_index: int, local_world: int, sysfs: str = "/sys", apply: bool = True, slot: Optional[int] = None) -> Dict:
+    """Bind this process to the NUMA node of HIP device `device_index` (see the module text) and size its host threads: sets
+    the affinity mask, NUS_COPY_THREADS (read once by the library's copy pool when it starts) and OMP_NUM_THREADS.  Returns the
+    report that goes into the bench line.  Call before the first HIP call of the process.  `slot`: the rank's position among
+    the node's ranks when several ranks share ONE device (a rehearsal on a 1-GPU box); default: rank r uses device r."""
+    q = query_gpu_pci()
+    devices = [pci_numa(b, sysfs) if b else {"bdf": None, "numa_node": None, "local_cpus": []} for b in q.get("bdf", [])]
+    mask = sorted(os.sched_getaffinity(0))
+    quota = cgroup_cpu_quota()
+    if slot is None:
+        plan = plan_binding(devices, device_index, local_world, mask, quota, sysfs)
+    else:
+        plan = plan_binding(devices, slot, local_world, mask, quota, sysfs, device_of_rank=[device_index] * max(local_world, slot + 1))
+    if q.get("error") and not plan["why_not"]:
+        plan["why_not"] = q["error"]
+    if apply and plan["bound"]:
+        try:
+            os.sched_setaffinity(0, plan["cpus"])
+        except OSError as e:
+            plan.update(bound=False, why_not=f"sched_setaffinity: {e}", cpus=mask)
+    budget = thread_budget(plan["cpus_per_rank"])
+    if apply:
+        os.environ["NUS_COPY_THREADS"] = str(budget["copy_threads"])
+        os.environ["OMP_NUM_THREADS"] = str(budget["omp_threads"])
+    return {"bound": plan["bound"], "why_not": plan["why_not"], "gpu_bdf": plan["gpu_bdf"], "numa_node": plan["numa_node"],
+            "cpus": format_cpulist(plan["cpus"]), "n_cpus_in_mask": len(plan["cpus"]), "cpus_per_rank": plan["cpus_per_rank"],
+            "ranks_on_node": plan["ranks_on_node"], "cgroup_cpu_quota": quota, "local_world": local_world, **budget}

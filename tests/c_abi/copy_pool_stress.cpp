@@ -10,6 +10,7 @@
 #include <thread>
 #include <vector>
 
+#include <sys/mman.h>
 #include <sys/wait.h>
 #include <unistd.h>
 
@@ -45,6 +46,32 @@ int main()
     std::vector<std::thread> threads;
     for (int t = 0; t < 4; ++t) threads.emplace_back(work, t);
     for (auto &t : threads) t.join();
+    // populate requests (parallel_populate_async: the pages of a result buffer made present while its frame is on the GPU)
+    // racing with copies into the SAME fresh anonymous mapping: no byte of the copy may be lost or changed, untouched
+    // bytes stay zero, and the ticket drains
+    for (int round = 0; round < 12; ++round) {
+        uint64_t seed = 0xB00 + round;
+        const size_t n = ((size_t)6 << 20) + (splitmix(seed) % ((size_t)20 << 20)), off = splitmix(seed) % 4096;
+        char *fresh = static_cast<char *>(mmap(nullptr, n + 8192, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0));
+        if (fresh == MAP_FAILED) { ++bad; break; }
+        std::vector<uint8_t> src(n);
+        for (size_t i = 0; i + 8 <= n; i += 8) {
+            const uint64_t v = splitmix(seed) | 1;
+            memcpy(&src[i], &v, 8);
+        }
+        nus::CopyTicket pop, cp;
+        nus::parallel_populate_async(fresh + off, n, pop);
+        const size_t half = n / 2;
+        nus::parallel_copy_async(fresh + off, src.data(), half, cp);       // first half while the populate pieces are queued
+        nus::parallel_copy_wait(cp);
+        nus::parallel_populate_async(fresh + off, n, pop);                  // again, now partly resident
+        nus::parallel_copy_async(fresh + off + half, src.data() + half, n - half - 4096, cp); // the last 4 KiB stay untouched
+        nus::parallel_copy_wait(cp);
+        nus::parallel_copy_wait(pop);
+        if (pop.left != 0 || memcmp(fresh + off, src.data(), n - 4096) != 0) ++bad;
+        for (size_t i = n - 4096; i < n; ++i) bad += fresh[off + i] != 0;
+        munmap(fresh, n + 8192);
+    }
     // a forked child has the pool's state but none of its threads: it must still copy (alone) and exit cleanly
     const pid_t pid = fork();
     if (pid == 0) {

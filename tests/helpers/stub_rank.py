@@ -22,11 +22,20 @@ def main():
         t = torch.tensor([float(rank + 1)], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         start, count = nsc.shard_frames(10 * world, world, rank)
+        # what bench.py's worker gathers about every rank (one all_gather of a float64 vector; None travels as NaN)
+        import bench
+        from nu_scaler_amd import placement
+
+        place = placement.bind_rank(0, world, apply=False, slot=rank)
+        rows = bench.gather_rows({"elapsed_s": 1.0 + rank, "check_ok": 1.0, "sclk_MHz": None if rank else 2100.0,
+                                  "cpus_per_rank": place["cpus_per_rank"], "first_frame": start}, world, dist, torch,
+                                 torch.device("cpu"))
         if "--fail" in sys.argv and rank == world - 1:
             raise SystemExit(3)
         if rank == 0:
             print(json.dumps({"n_gpus": world, "max": float(t.item()), "lut": len(got), "argv": sys.argv[1:],
-                              "shard": [start, count]}), flush=True)
+                              "shard": [start, count], "rows": rows, "elapsed": bench.spread(rows, "elapsed_s"),
+                              "sclk": bench.spread(rows, "sclk_MHz", 0)}), flush=True)
         dist.barrier()
     finally:
         dist.destroy_process_group()

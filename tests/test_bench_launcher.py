@@ -29,6 +29,13 @@ def test_launch_ranks_world2_gloo_relays_rank0_json(nsc):
     assert out[0]["argv"] == ["--steps", "3"]
     assert out[0]["shard"] == [0, 10]
     assert out[0]["lut"] == len(nsc.build_tables_blob(64, 36, 128, 72))
+    # the per-rank rows every rank holds after the gather: rank order, None preserved, the spread rank 0 prints
+    rows = out[0]["rows"]
+    assert [r["elapsed_s"] for r in rows] == [1.0, 2.0] and [r["first_frame"] for r in rows] == [0.0, 10.0]
+    assert rows[0]["sclk_MHz"] == 2100.0 and rows[1]["sclk_MHz"] is None
+    assert out[0]["elapsed"] == {"min": 1.0, "max": 2.0, "by_rank": [1.0, 2.0]}
+    assert out[0]["sclk"] == {"min": 2100.0, "max": 2100.0, "by_rank": [2100.0, None]}
+    assert all(r["cpus_per_rank"] >= 1 for r in rows)
 
 
 def test_launch_ranks_propagates_failure():
@@ -70,3 +77,47 @@ def test_worker_rejects_world_size_mismatch():
                          capture_output=True, text=True, timeout=300)
     assert res.returncode != 0
     assert "--gpus 4 but WORLD_SIZE is 2" in res.stderr
+
+
+def test_rank_check_regenerates_its_shard_and_never_raises(oracle_mod):
+    """bench.check_timed_outputs on host tensors: a rank's frames are regenerated from their position in the GLOBAL stream, so a
+    rank holding the wrong shard fails `input_ok`; a damaged output fails `ok`; nothing raises (the summaries are gathered
+    first, then every rank exits)."""
+    import numpy as np
+    import torch
+
+    bench = _bench()
+    w, h, first = 64, 24, 300  # rank 1 of a 300-units-per-rank job
+    src = [oracle_mod.gen_gradient(w, h, first + k) for k in range(3)]
+    frames = torch.from_numpy(np.stack(src))
+    mids = [oracle_mod.warp_blend(src[k], src[k + 1], None, 0.5) for k in range(2)]
+    mid = torch.from_numpy(np.stack(mids))
+    up_real = torch.from_numpy(np.stack([oracle_mod.lanczos3(src[k], 2 * w, 2 * h) for k in range(2)]))
+    up_mid = torch.from_numpy(np.stack([oracle_mod.lanczos3(m, 2 * w, 2 * h) for m in mids]))
+    report, summ = bench.check_timed_outputs(frames, mid, up_real, up_mid, [0, 1], w, h, first_frame=first, threads=2)
+    assert summ == {"ok": 1.0, "input_ok": 1.0, "mid_exact": 1.0, "max_abs_diff": 0.0, "frac_differing": 0.0, "frames": 2.0}
+    assert {r["buffer"] for r in report} == {"input", "mid", "up_real", "up_mid"}
+    _, wrong_shard = bench.check_timed_outputs(frames, mid, up_real, up_mid, [0, 1], w, h, first_frame=0, threads=2)
+    assert wrong_shard["input_ok"] == 0.0 and wrong_shard["ok"] == 0.0
+    bad = up_mid.clone()
+    bad[1, 5, 7, 2] ^= 0x40
+    _, damaged = bench.check_timed_outputs(frames, mid, up_real, bad, [0, 1], w, h, first_frame=first, threads=2)
+    assert damaged["ok"] == 0.0 and damaged["input_ok"] == 1.0 and damaged["max_abs_diff"] >= 2
+    bad_mid = mid.clone()
+    bad_mid[0, 0, 0, 0] ^= 1
+    _, damaged = bench.check_timed_outputs(frames, bad_mid, up_real, up_mid, [0], w, h, first_frame=first, threads=2)
+    assert damaged["ok"] == 0.0 and damaged["mid_exact"] == 0.0
+
+
+def test_clock_sampler_parses_rocm_smi_and_sysfs(tmp_path):
+    bench = _bench()
+    text = ("GPU[3]\t\t: fclk clock level: 0: (2000Mhz)\nGPU[3]\t\t: mclk clock level: 3: (1900Mhz)\n"
+            "GPU[3]\t\t: sclk clock level: 1: (2338Mhz)\nGPU[3]\t\t: socclk clock level: 0: (28Mhz)\n"
+            "GPU[3]\t\t: Current Socket Graphics Package Power (W): 1350.0\n")
+    assert bench.ClockSampler._parse(text) == (2338, 1350.0, 1900, 2000)
+    f = tmp_path / "pp_dpm_sclk"
+    f.write_text("0: 132Mhz\n1: 2120Mhz *\n2: 2400Mhz\n")
+    assert bench.ClockSampler._dpm_current(str(f)) == 2120
+    assert bench.ClockSampler._dpm_current(str(tmp_path / "missing")) is None
+    assert bench.ClockSampler.mean([(0.0, 2000, None), (0.6, 2100, 1300.0)], 1) == 2050
+    assert bench.ClockSampler.mean([(0.0, 2000, None)], 2, 1) is None

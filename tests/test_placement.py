@@ -1,0 +1,98 @@
+"""Per-rank CPU placement (nu_scaler_amd/placement.py): the planning step on made-up topologies (no GPU, no real sysfs), the
+cpulist helpers, and that bind_rank degrades to "not bound" with a reason on a box without a HIP device."""
+import os
+
+import pytest
+
+
+def _fake_sysfs(root, gpus, siblings):
+    """gpus: {bdf: (node, cpulist)}; siblings: {cpu: 'a,b'}"""
+    for bdf, (node, cpulist) in gpus.items():
+        d = os.path.join(root, "bus", "pci", "devices", bdf)
+        os.makedirs(d, exist_ok=True)
+        open(os.path.join(d, "numa_node"), "w").write(f"{node}\n")
+        open(os.path.join(d, "local_cpulist"), "w").write(cpulist + "\n")
+    for cpu, sib in siblings.items():
+        d = os.path.join(root, "devices", "system", "cpu", f"cpu{cpu}", "topology")
+        os.makedirs(d, exist_ok=True)
+        open(os.path.join(d, "thread_siblings_list"), "w").write(sib + "\n")
+
+
+def test_cpulist_round_trip(nsc):
+    from nu_scaler_amd import placement as p
+
+    assert p.parse_cpulist("0-3,8,10-11\n") == [0, 1, 2, 3, 8, 10, 11]
+    assert p.format_cpulist([11, 10, 8, 3, 2, 1, 0]) == "0-3,8,10-11"
+    assert p.parse_cpulist("") == [] and p.format_cpulist([]) == ""
+
+
+def test_plan_eight_gpus_two_sockets(nsc, tmp_path):
+    """The host shape of this pool (profiles/r03_numa_pinned_copy_probe.txt): 2 x 64 cores with SMT, GPUs 0-3 on node 0,
+    4-7 on node 1.  Every rank gets a disjoint run of whole cores (both hardware threads) of ITS GPU's node."""
+    from nu_scaler_amd import placement as p
+
+    gpus = {f"0000:{0x10 + 8 * i:02x}:00.0": (0 if i < 4 else 1, "0-63,128-191" if i < 4 else "64-127,192-255") for i in range(8)}
+    _fake_sysfs(str(tmp_path), gpus, {c: f"{c % 128},{c % 128 + 128}" for c in range(256)})
+    devices = [p.pci_numa(b, str(tmp_path)) for b in sorted(gpus)]
+    seen = set()
+    for r in range(8):
+        plan = p.plan_binding(devices, r, 8, range(256), quota=None, sysfs=str(tmp_path))
+        assert plan["bound"] and plan["numa_node"] == (0 if r < 4 else 1) and plan["ranks_on_node"] == 4
+        cpus = plan["cpus"]
+        assert len(cpus) == 32 and plan["cpus_per_rank"] == 32
+        assert all(((c % 128) + 128 if c < 128 else c - 128) in cpus for c in cpus), "SMT siblings stay together"
+        assert set(cpus) <= set(devices[r]["local_cpus"]) and not (set(cpus) & seen)
+        seen |= set(cpus)
+    # a CPU quota for the whole job caps what a rank may keep busy, not where it runs
+    plan = p.plan_binding(devices, 5, 8, range(256), quota=16.0, sysfs=str(tmp_path))
+    assert plan["bound"] and len(plan["cpus"]) == 32 and plan["cpus_per_rank"] == 2
+    assert p.thread_budget(2) == {"copy_threads": 0, "omp_threads": 2}
+    assert p.thread_budget(16) == {"copy_threads": 3, "omp_threads": 16}
+
+
+def test_plan_one_gpu_box_and_rehearsal(nsc, tmp_path):
+    """One GPU of a shared host: the rank takes the whole local CPU list; two rehearsal ranks on that ONE device split it."""
+    from nu_scaler_amd import placement as p
+
+    _fake_sysfs(str(tmp_path), {"0000:d9:00.0": (1, "64-127,192-255")}, {})
+    devices = [p.pci_numa("0000:d9:00.0", str(tmp_path))]
+    plan = p.plan_binding(devices, 0, 1, range(256), quota=16.0, sysfs=str(tmp_path))
+    assert plan["bound"] and p.format_cpulist(plan["cpus"]) == "64-127,192-255" and plan["cpus_per_rank"] == 16
+    a = p.plan_binding(devices, 0, 2, range(256), None, str(tmp_path), device_of_rank=[0, 0])
+    b = p.plan_binding(devices, 1, 2, range(256), None, str(tmp_path), device_of_rank=[0, 0])
+    assert a["bound"] and b["bound"] and not (set(a["cpus"]) & set(b["cpus"])) and len(a["cpus"]) == len(b["cpus"]) == 64
+
+
+def test_plan_degrades_with_a_reason(nsc, tmp_path):
+    from nu_scaler_amd import placement as p
+
+    _fake_sysfs(str(tmp_path), {"0000:05:00.0": (-1, "0-7")}, {})
+    unknown = [p.pci_numa("0000:05:00.0", str(tmp_path))]
+    plan = p.plan_binding(unknown, 0, 1, range(8))
+    assert not plan["bound"] and "NUMA" in plan["why_not"] and plan["cpus"] == list(range(8)) and plan["cpus_per_rank"] == 8
+    plan = p.plan_binding([], 0, 2, range(8), quota=4.0)
+    assert not plan["bound"] and "no PCI address" in plan["why_not"] and plan["cpus_per_rank"] == 2
+    far = [{"bdf": "0000:05:00.0", "numa_node": 1, "local_cpus": [64, 65]}]
+    plan = p.plan_binding(far, 0, 1, range(8))
+    assert not plan["bound"] and "affinity mask" in plan["why_not"]
+
+
+def test_bind_rank_without_a_gpu_reports_and_changes_nothing(nsc, monkeypatch):
+    """No HIP device in this container: the query child says so, the mask stays, the thread budget is still set."""
+    import torch
+
+    from nu_scaler_amd import placement as p
+
+    if torch.cuda.is_available():
+        pytest.skip("needs a box without a GPU")
+    monkeypatch.delenv("NUS_COPY_THREADS", raising=False)  # (both are restored to what they were when the test ends)
+    monkeypatch.setenv("OMP_NUM_THREADS", os.environ.get("OMP_NUM_THREADS", "0"))
+    if os.environ["OMP_NUM_THREADS"] == "0":
+        monkeypatch.delenv("OMP_NUM_THREADS")
+    before = os.sched_getaffinity(0)
+    rep = p.bind_rank(0, 2)
+    assert os.sched_getaffinity(0) == before
+    assert rep["bound"] is False and rep["why_not"] and rep["local_world"] == 2
+    assert rep["cpus_per_rank"] == max(1, min(len(before) // 2, int((p.cgroup_cpu_quota() or 1e9) / 2 + 0.5)))
+    assert os.environ["NUS_COPY_THREADS"] == str(rep["copy_threads"])
+    assert os.environ["OMP_NUM_THREADS"] == str(rep["omp_threads"])
