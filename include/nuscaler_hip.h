@@ -21,8 +21,11 @@
  * There is no CPU fallback: without a usable HIP device the compute entry points
  * fail with NUS_ERR_NO_DEVICE.
  * Host entry points that take pageable buffers copy through pinned staging memory; copies of
- * 1 MiB and more are split over a few process-wide helper threads started on first use
- * (environment: NUS_COPY_THREADS=n, 0 = copy on the calling thread only).
+ * 1 MiB and more are split over a few process-wide helper threads started on first use (up to 6, fewer where the process's
+ * CPU mask or cgroup quota is smaller; environment: NUS_COPY_THREADS=n, 0 = copy on the calling thread only).  The same
+ * threads make the pages of a pageable OUTPUT buffer present while its frame is on the GPU (a result buffer fresh from the
+ * allocator -- the Vec / PyBytes of the trait's `upscale` -- otherwise takes its first-touch faults inside the copy-out);
+ * buffer contents are never touched before the frame's bytes arrive.
  */
 #ifndef NUSCALER_HIP_H
 #define NUSCALER_HIP_H

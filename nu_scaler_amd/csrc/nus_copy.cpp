@@ -9,9 +9,11 @@
 #include <thread>
 #include <vector>
 
+#include <algorithm>
 #include <atomic>
 #include <cerrno>
 #include <cstdint>
+#include <cstdio>
 
 #include <sched.h>
 #include <sys/mman.h>
@@ -86,18 +88,23 @@ public:
         cv_work_.notify_all();
     }
 
-    // Queue "make these pages present" requests (see populate_pages) under `ticket`.
+    // Queue "make these pages present" requests (see populate_pages) under `ticket`: pieces cut at 2-MiB ADDRESS boundaries, so
+    // that with transparent huge pages each request faults whole huge pages in.
     void submit_populate(char *dst, size_t bytes, CopyTicket &ticket)
     {
-        const size_t pieces = (bytes + kPopulateBytes - 1) / kPopulateBytes;
-        if (pieces == 0) return;
+        if (bytes == 0) return;
+        std::vector<Piece> pieces;
+        const uintptr_t a = reinterpret_cast<uintptr_t>(dst), end = a + bytes;
+        for (uintptr_t lo = a; lo < end;) {
+            const uintptr_t hi = std::min<uintptr_t>((lo / kPopulateBytes + 1) * kPopulateBytes, end);
+            pieces.push_back(Piece{reinterpret_cast<char *>(lo), nullptr, (size_t)(hi - lo), &ticket});
+            lo = hi;
+        }
         {
             std::lock_guard<std::mutex> lk(m_);
-            ticket.left += pieces;
-            for (size_t i = 0; i < pieces; ++i) {
-                const size_t off = i * kPopulateBytes;
-                queue_.push_back(Piece{dst + off, nullptr, bytes - off < kPopulateBytes ? bytes - off : kPopulateBytes, &ticket});
-            }
+            ticket.left += pieces.size();
+            ticket.low = true;
+            for (const Piece &p : pieces) queue_lo_.push_back(p); // behind every copy: a copy is somebody's critical path
         }
         cv_work_.notify_all();
     }
@@ -109,8 +116,9 @@ public:
         std::unique_lock<std::mutex> lk(m_);
         for (;;) {
             if (ticket.left == 0) return;
-            if (queue_.empty()) { // the rest of this ticket is in other threads' hands
-                cv_done_.wait(lk, [&] { return ticket.left == 0 || !queue_.empty(); });
+            // (a thread waiting for a copy does not pick up populate requests: its copy is on a frame's critical path)
+            if (queue_.empty() && (!ticket.low || queue_lo_.empty())) { // the rest of this ticket is in other threads' hands
+                cv_done_.wait(lk, [&] { return ticket.left == 0 || !queue_.empty() || (ticket.low && !queue_lo_.empty()); });
                 continue;
             }
             run_one(lk);
@@ -120,12 +128,26 @@ public:
 private:
     CopyPool()
     {
-        int n = 3;
-        if (const char *e = getenv("NUS_COPY_THREADS")) n = atoi(e);
+        // Default: 6 workers where the process has the CPUs for them next to the submitting and the retiring thread of the
+        // host path -- its affinity mask, capped by the cgroup's CPU quota (a GPU box of this pool gives a job 16 CPUs' worth of
+        // a 256-thread host).  Three were enough while the pool only copied; since it also makes fresh result buffers present
+        // (populate_pages) a batch of fresh outputs goes 1.05 -> 0.72 ms per frame with six (profiles/r04_host_path_pool_threads.txt).
+        int n = 6;
+        const bool from_env = getenv("NUS_COPY_THREADS") != nullptr;
+        if (from_env) n = atoi(getenv("NUS_COPY_THREADS"));
         int cpus = 0;
         cpu_set_t set;
         if (sched_getaffinity(0, sizeof(set), &set) == 0) cpus = CPU_COUNT(&set);
         if (cpus <= 0) cpus = (int)std::thread::hardware_concurrency();
+        if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+            long long quota = 0, period = 0;
+            if (fscanf(f, "%lld %lld", &quota, &period) == 2 && quota > 0 && period > 0) {
+                const int q = (int)((quota + period / 2) / period);
+                if (q >= 1 && (cpus <= 0 || q < cpus)) cpus = q;
+            }
+            fclose(f);
+        }
+        if (cpus > 0 && !from_env && n + 2 > cpus) n = cpus - 2; // leave the two threads of the host path their CPUs
         if (cpus > 0 && (n < 0 ? 0 : n) + 1 > cpus) n = cpus - 1;
         if (n > 8) n = 8;
         if (n < 0) n = 0;
@@ -150,8 +172,9 @@ private:
     // pops one piece and copies it with the lock released; called and returns with `lk` held
     void run_one(std::unique_lock<std::mutex> &lk)
     {
-        const Piece p = queue_.front();
-        queue_.pop_front();
+        std::deque<Piece> &q = queue_.empty() ? queue_lo_ : queue_;
+        const Piece p = q.front();
+        q.pop_front();
         lk.unlock();
         if (p.src)
             memcpy(p.dst, p.src, p.len);
@@ -165,7 +188,7 @@ private:
     {
         std::unique_lock<std::mutex> lk(m_);
         for (;;) {
-            cv_work_.wait(lk, [&] { return stop_ || !queue_.empty(); });
+            cv_work_.wait(lk, [&] { return stop_ || !queue_.empty() || !queue_lo_.empty(); });
             if (stop_) return;
             run_one(lk);
         }
@@ -173,7 +196,8 @@ private:
 
     std::mutex m_; // guards the queue, every ticket's count, stop_
     std::condition_variable cv_work_, cv_done_;
-    std::deque<Piece> queue_;
+    std::deque<Piece> queue_;    // copies
+    std::deque<Piece> queue_lo_; // populate requests: taken when no copy is waiting
     std::vector<std::thread> threads_;
     bool stop_ = false;
     pid_t owner_ = 0;
@@ -188,11 +212,40 @@ void parallel_copy_async(void *dst, const void *src, size_t bytes, CopyTicket &t
 
 void parallel_copy_wait(CopyTicket &ticket) { CopyPool::instance().help(ticket); }
 
+bool parallel_populate_prepare(void *dst, size_t bytes)
+{
+    if (bytes < kMinParallelBytes) return false; // a small buffer's few faults are cheaper than a wake-up
+    if (CopyPool::instance().workers() == 0) return false; // nobody to run beside the frame: the copy-out takes the faults as before
+    const uintptr_t a = reinterpret_cast<uintptr_t>(dst);
+    const uintptr_t lo = (a + 4095) & ~(uintptr_t)4095, hi = (a + bytes) & ~(uintptr_t)4095;
+    if (hi <= lo) return false;
+    // Resident already (a buffer the caller re-uses)?  One page per 2 MiB and the last one, asked of mincore (shared lock, a
+    // fraction of a microsecond each): then there is nothing to do, and nothing may be done -- see below.
+    bool resident = true;
+    for (uintptr_t q = lo; resident && q < hi; q = (q / kPopulateBytes + 1) * kPopulateBytes) {
+        unsigned char vec = 0;
+        resident = mincore(reinterpret_cast<void *>(q), 4096, &vec) == 0 && (vec & 1);
+    }
+    if (resident) {
+        unsigned char vec = 0;
+        resident = mincore(reinterpret_cast<void *>(hi - 4096), 4096, &vec) == 0 && (vec & 1);
+    }
+    if (resident) return false;
+    // A fresh mapping: ask for transparent huge pages on its whole pages (a hint on the mapping; a no-op where THP is off) -- 16
+    // huge-page faults instead of 8 100 small ones for a 4K frame, and a copy that misses the TLB 512 times less often
+    // (33 MB made present and copied into by 4 threads on a GPU box: 1.95 ms through first-touch faults in the copy, 1.46 with
+    // MADV_POPULATE_WRITE first, 0.82 with the hint as well: profiles/r04_host_fresh_result_pages.txt).  One call for the whole
+    // range, and only for fresh mappings: madvise takes the address space's lock exclusively, i.e. waits for every populate
+    // request in flight -- issued per frame on resident buffers it serialised a batch (0.75 -> 1.48 ms per frame).
+    (void)madvise(reinterpret_cast<void *>(lo), hi - lo, MADV_HUGEPAGE);
+    return true;
+}
+
 void parallel_populate_async(void *dst, size_t bytes, CopyTicket &ticket)
 {
-    if (bytes < kMinParallelBytes) return; // a small buffer's few faults are cheaper than a wake-up
+    if (bytes == 0) return;
     CopyPool &pool = CopyPool::instance();
-    if (pool.workers() == 0) return; // nobody to run beside the frame: the copy-out takes the faults as before
+    if (pool.workers() == 0) return;
     pool.submit_populate(static_cast<char *>(dst), bytes, ticket);
 }
 

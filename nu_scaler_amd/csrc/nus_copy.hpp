@@ -19,14 +19,20 @@ void parallel_copy(void *dst, const void *src, size_t bytes);
 // collect several copies; both buffers of each must stay valid until the wait returns.  The ticket's count belongs to the pool.
 struct CopyTicket {
     size_t left = 0; // pieces not yet copied (guarded by the pool's mutex)
+    bool low = false; // holds populate requests (the pool's low-priority queue)
 };
 void parallel_copy_async(void *dst, const void *src, size_t bytes, CopyTicket &ticket);
 void parallel_copy_wait(CopyTicket &ticket);
 
-// Ask the workers to make the pages of a (pageable, writable) buffer present while something else is going on -- the output
-// buffer of a frame while the frame is on the GPU: a result buffer fresh from the allocator otherwise takes its first-touch
-// faults inside the copy-out.  Contents are never changed; already-present pages cost a page-table walk.  Nothing is queued
-// for small buffers or when the pool has no workers.  Wait for `ticket` (parallel_copy_wait) before the buffer may go away.
+// The pages of a (pageable, writable) output buffer made present while something else is going on -- while its frame is staged,
+// uploaded, computed and on the wire back: a result buffer fresh from the allocator (the Vec / PyBytes the trait's `upscale`
+// returns) otherwise takes its first-touch faults inside the copy-out.  Two steps:
+//   parallel_populate_prepare  (calling thread, BEFORE any request for other buffers of the same call is queued where possible)
+//       false: nothing to do -- the buffer is small, resident already (sampled with mincore), or the pool has no workers;
+//       true: the mapping is fresh; it has been given the transparent-huge-page hint and wants populate requests;
+//   parallel_populate_async    queues the requests in the pool's LOW-priority queue (idle workers take them; a thread waiting
+//       for a copy never does).  Contents are never changed.  Wait for `ticket` (parallel_copy_wait) before the buffer may go away.
+bool parallel_populate_prepare(void *dst, size_t bytes);
 void parallel_populate_async(void *dst, size_t bytes, CopyTicket &ticket);
 
 // number of worker threads in use (0 when disabled or in a forked child)

@@ -884,13 +884,15 @@ void HipUpscaler::plan_chunks(Slot &S, size_t out_bytes, bool alone) const
 // The same for a frame that is alone in the pipeline, band by band (see kBands): band b is rows [k0, k1) of the input, a
 // multiple of `align` rows; its upload carries the tap rows the kernel reads below k1 (kBandHalo, and the band after it starts
 // that much later), its download is output rows [2 k0, 2 k1) in two pieces.
-int HipUpscaler::submit_frame_banded(Slot &S, const uint8_t *in, uint8_t *out, bool *direct, uint32_t align)
+int HipUpscaler::submit_frame_banded(Slot &S, const uint8_t *in, uint8_t *out, bool *direct, uint32_t align, int populate)
 {
     constexpr uint32_t kBandHalo = 4; // >= 3 tap rows below a row (Lanczos-3 at x2), 1 for bilinear
     const size_t in_row = (size_t)iw_ * 4, out_row = (size_t)ow_ * 4, out_bytes = out_row * oh_;
     const uint32_t band_rows = ((ih_ + kBands - 1) / kBands + align - 1) / align * align;
     const bool in_pinned = is_pinned_host(in);
     *direct = is_pinned_host(out);
+    if (!*direct && (populate > 0 || (populate < 0 && parallel_populate_prepare(out, out_bytes))))
+        parallel_populate_async(out, out_bytes, S.populate); // see submit_frame
     S.nchunks = 0;
     int b = 0;
     for (uint32_t k0 = 0; k0 < ih_; k0 += band_rows, ++b) {
@@ -928,19 +930,35 @@ int HipUpscaler::submit_frame_banded(Slot &S, const uint8_t *in, uint8_t *out, b
     }
     NUS_HIP(hipEventRecord(S.in_done, s_in_));
     NUS_HIP(hipEventRecord(S.out_done, s_out_));
-    if (!*direct) parallel_populate_async(out, out_bytes, S.populate); // (after the last band is on its way: see submit_frame)
     S.used = true;
     return kOk;
 }
 
-int HipUpscaler::submit_frame(Slot &S, const uint8_t *in, uint8_t *out, bool *direct, bool alone)
+int HipUpscaler::submit_frame(Slot &S, const uint8_t *in, uint8_t *out, bool *direct, bool alone, int populate)
+{
+    const int rc = submit_frame_inner(S, in, out, direct, alone, populate);
+    // a frame that was not submitted is never retired: its populate requests (they point into `out`) end here
+    if (rc != kOk) parallel_copy_wait(S.populate);
+    return rc;
+}
+
+int HipUpscaler::submit_frame_inner(Slot &S, const uint8_t *in, uint8_t *out, bool *direct, bool alone, int populate)
 {
     const size_t in_bytes = (size_t)iw_ * ih_ * 4, out_bytes = (size_t)ow_ * oh_ * 4;
     if (alone && single_bands_ && !profiling_ && out_bytes >= ((size_t)8 << 20)) {
         const uint32_t align = band_alignment(1);
         if (align && (uint64_t)align * kBands * 2 <= ih_ && ow_ == 2 * iw_ && oh_ == 2 * ih_)
-            return submit_frame_banded(S, in, out, direct, align);
+            return submit_frame_banded(S, in, out, direct, align, populate);
     }
+    // First of all, and in the pool's low-priority queue (behind every copy): while the frame is staged, uploaded, computed and
+    // on the wire back, idle workers make the caller's output pages present -- a result buffer fresh from the allocator (the Vec /
+    // PyBytes `upscale` returns) is 8 100 first-touch faults, or 16 huge-page faults, that would otherwise be taken inside the
+    // copy-out; pages that are resident already cost a page-table walk.
+    // `populate`: 1 = the caller has prepared the buffer (upscale_batch does that for all its outputs before the first request
+    // is queued: parallel_populate_prepare), 0 = it found it resident, -1 = find out here.
+    *direct = is_pinned_host(out);
+    if (!*direct && (populate > 0 || (populate < 0 && parallel_populate_prepare(out, out_bytes))))
+        parallel_populate_async(out, out_bytes, S.populate);
     const uint8_t *src = in;
     if (!is_pinned_host(src)) {
         parallel_copy(S.h_in, src, in_bytes);
@@ -954,7 +972,6 @@ int HipUpscaler::submit_frame(Slot &S, const uint8_t *in, uint8_t *out, bool *di
     if (rc != kOk) return rc;
     NUS_HIP(hipEventRecord(S.k_end, s_k_));
     NUS_HIP(hipStreamWaitEvent(s_out_, S.k_end, 0));
-    *direct = is_pinned_host(out);
     if (*direct) {
         NUS_HIP(hipMemcpyAsync(out, S.d_out, out_bytes, hipMemcpyDeviceToHost, s_out_));
     } else {
@@ -967,10 +984,6 @@ int HipUpscaler::submit_frame(Slot &S, const uint8_t *in, uint8_t *out, bool *di
         }
     }
     NUS_HIP(hipEventRecord(S.out_done, s_out_));
-    // Everything of the frame is queued: while it is on the GPU and on the wire the pool's workers make the caller's output
-    // pages present (a result buffer fresh from the allocator -- the Vec / PyBytes `upscale` returns -- is 8 100 first-touch
-    // faults that would otherwise be taken inside the copy-out; resident pages cost a page-table walk).
-    if (!*direct) parallel_populate_async(out, out_bytes, S.populate);
     S.used = true;
     return kOk;
 }
@@ -1177,9 +1190,14 @@ int HipUpscaler::upscale_batch(const uint8_t *const *ins, const size_t *in_lens,
     // chained by the slot's events (submit_frame / retire_frame).  A slot is submitted to again only after its previous frame
     // has been retired (so its D2H, hence its kernel and its H2D, are complete): no stream needs to wait for an earlier frame.
     std::vector<char> direct_out(n, 0);
+    // Output buffers fresh from the allocator (the Vecs / PyBytes of the trait's `upscale_batch`) are found and given their
+    // huge-page hint here, before the first populate request exists: the hint takes the address space's lock exclusively.
+    std::vector<signed char> populate(n, 0);
+    for (size_t i = 0; i < n; ++i)
+        populate[i] = !is_pinned_host(outs[i]) && parallel_populate_prepare(outs[i], out_bytes) ? 1 : 0;
     auto submit = [&](size_t i) -> int {
         bool direct = false;
-        const int rc = submit_frame(slots_[i % nslots], ins[i], outs[i], &direct, n == 1);
+        const int rc = submit_frame(slots_[i % nslots], ins[i], outs[i], &direct, n == 1, populate[i]);
         direct_out[i] = direct ? 1 : 0;
         return rc;
     };

@@ -157,7 +157,7 @@ private:
     int single_bands_ = 1;      // option "single_bands"
     uint32_t band_alignment(uint32_t n_frames) const; // rows a band must be a multiple of; 0 = the variant has no row-range launch
     uint32_t lanczos_x2_rows_per_wave(uint32_t n_frames, bool unit) const;
-    int submit_frame_banded(Slot &s, const uint8_t *in, uint8_t *out, bool *direct, uint32_t align);
+    int submit_frame_banded(Slot &s, const uint8_t *in, uint8_t *out, bool *direct, uint32_t align, int populate);
     // "one host thread + 3 streams per GPU": every H2D goes down the copy-in stream, every kernel down the compute stream,
     // every D2H down the copy-out stream, tied together per frame by the slot's events -- so the copies of consecutive frames
     // sit back to back in ONE queue per direction (0.60 ms per 4K frame on the D2H engine) instead of alternating between the
@@ -169,7 +169,8 @@ private:
     int ensure_device();
     int ensure_streams();
     int ensure_slot(Slot &s, size_t in_bytes, size_t out_bytes);
-    int submit_frame(Slot &s, const uint8_t *in, uint8_t *out, bool *direct, bool alone);
+    int submit_frame(Slot &s, const uint8_t *in, uint8_t *out, bool *direct, bool alone, int populate = -1);
+    int submit_frame_inner(Slot &s, const uint8_t *in, uint8_t *out, bool *direct, bool alone, int populate);
     int retire_frame(Slot &s, uint8_t *out, bool direct, std::string *err) const;
     struct Ring { // state of an open stream (stream_open .. stream_close); its own mutex, never held together with a HIP call
         struct Item {

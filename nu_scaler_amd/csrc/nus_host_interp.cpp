@@ -153,6 +153,13 @@ int HipFrameInterpolator::interpolate(const uint8_t *a, size_t a_len, const uint
     int rc = ensure(expected, flow != nullptr);
     if (rc != kOk) return rc;
     uint8_t *ha = h_stage_, *hb = h_stage_ + cap_bytes_, *ho = h_stage_ + 2 * cap_bytes_;
+    // while the pair is staged, uploaded and on the GPU, idle workers of the copy pool make the pages of the result buffer
+    // present (a buffer fresh from the allocator -- what interpolate_py returns -- otherwise takes its faults in the copy-out)
+    struct Populate {
+        CopyTicket t;
+        ~Populate() { parallel_copy_wait(t); } // on every way out: queued requests point into `out`
+    } populate;
+    if (parallel_populate_prepare(out, expected)) parallel_populate_async(out, expected, populate.t);
     // stage A, start its DMA, stage B meanwhile (the reference uploads both synchronously:
     // wgpu_interpolator.rs:253-321)
     parallel_copy(ha, a, expected);
@@ -186,12 +193,6 @@ int HipFrameInterpolator::interpolate(const uint8_t *a, size_t a_len, const uint
     NUS_HIP(hipMemcpyAsync(ho, d_out_, first, hipMemcpyDeviceToHost, stream_));
     NUS_HIP(hipEventRecord(half_done_, stream_));
     if (first < expected) NUS_HIP(hipMemcpyAsync(ho + first, d_out_ + first, expected - first, hipMemcpyDeviceToHost, stream_));
-    // while the pair is on the GPU: the pages of a result buffer fresh from the allocator (what interpolate_py returns)
-    struct Populate {
-        CopyTicket t;
-        ~Populate() { parallel_copy_wait(t); } // on every way out: queued requests point into `out`
-    } populate;
-    parallel_populate_async(out, expected, populate.t);
     NUS_HIP(hipEventSynchronize(half_done_));
     parallel_copy(out, ho, first);
     NUS_HIP(hipStreamSynchronize(stream_));

@@ -2,9 +2,14 @@
 // kernel of the 1080p -> 4K path.  image-0.24.9 imageops::resize as called at
 // Nu_scale/src/upscale/common.rs:243-251 (vertical pass into f32, then horizontal pass).
 
-// cache-policy bits of the output stores (0 = default, 2 = nt); tuning knob
+// Cache-policy bits of the output stores (buffer-store aux operand on gfx950: 1 sc0, 2 nt, 16 sc1).  nt: nothing this kernel
+// writes is read again by it, and the 75 MB a unit writes otherwise push the input rows -- which three waves read -- out of
+// the L2.  With every store instruction writing one contiguous KiB (round 2) nt is a gain: one-launch step 6.05 -> 5.81 ms
+// (-4 %) on a box with a low copy ceiling, 5.79 -> 5.67 (-2 %) on a fast one, the plain kernel -2.5 % on both
+// (profiles/r04_x2_cache_policy_sweep.txt; sc1 / sc0 variants and nt on the row REQUESTS, which loses 5-7 %, next to it).
+// (Round 1 had measured nt stores 1.6-1.8x slower -- on 16-byte pieces at a 32-byte stride.)
 #ifndef NUS_STORE_AUX
-#define NUS_STORE_AUX 0
+#define NUS_STORE_AUX 2
 #endif
 #include "nus_device.hpp"
 
@@ -88,9 +93,21 @@ static_assert(6 % kLzDepth == 0, "prefetch distance must divide 6");
 #pragma clang diagnostic ignored "-Winline-asm" // m0 is a reserved register: nothing else in these kernels uses it
 // Request 16 B per lane from `base + off` (base wave-uniform, off < 4 GiB) into the 1-KiB LDS slot at
 // byte offset `lds` (wave-uniform): lane l lands at lds + 16 l.
+#ifndef NUS_LZ_LOAD_POLICY
+#define NUS_LZ_LOAD_POLICY 0 // cache policy of the row requests: 0 default, 1 nt, 2 sc1, 3 sc0 sc1 (tuning knob)
+#endif
+#if NUS_LZ_LOAD_POLICY == 1
+#define NUS_LZ_LOAD_MOD " nt"
+#elif NUS_LZ_LOAD_POLICY == 2
+#define NUS_LZ_LOAD_MOD " sc1"
+#elif NUS_LZ_LOAD_POLICY == 3
+#define NUS_LZ_LOAD_MOD " sc0 sc1"
+#else
+#define NUS_LZ_LOAD_MOD ""
+#endif
 __device__ __forceinline__ void dma_row16(const uint8_t *base, uint32_t off, uint32_t lds)
 {
-    asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(off), "s"(base), "s"(lds) : "memory", "m0");
+    asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1" NUS_LZ_LOAD_MOD : : "v"(off), "s"(base), "s"(lds) : "memory", "m0");
 }
 #pragma clang diagnostic pop
 

@@ -191,9 +191,9 @@ def plan_binding(devices: Sequence[Dict], local_rank: int, local_world: int, mas
 
 def thread_budget(cpus_per_rank: int) -> Dict[str, int]:
     """Host threads of one rank inside its CPU share: the submitting and the retiring thread of the host path always exist;
-    the copy pool gets what is left, up to the 3 workers it has by default (nus_copy.cpp); OpenMP teams (the checker's) take
+    the copy pool gets what is left, up to the 6 workers it has by default (nus_copy.cpp); OpenMP teams (the checker's) take
     the whole share -- they never run beside the host path."""
-    return {"copy_threads": max(0, min(3, int(cpus_per_rank) - 2)), "omp_threads": max(1, int(cpus_per_rank))}
+    return {"copy_threads": max(0, min(6, int(cpus_per_rank) - 2)), "omp_threads": max(1, int(cpus_per_rank))}
 
 
 def bind_rank(device_index: int, local_world: int, sysfs: str = "/sys", apply: bool = True, slot: Optional[int] = None) -> Dict:

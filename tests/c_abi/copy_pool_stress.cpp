@@ -60,6 +60,7 @@ int main()
             memcpy(&src[i], &v, 8);
         }
         nus::CopyTicket pop, cp;
+        if (nus::parallel_copy_workers() > 0 && !nus::parallel_populate_prepare(fresh + off, n)) ++bad; // fresh: wants requests
         nus::parallel_populate_async(fresh + off, n, pop);
         const size_t half = n / 2;
         nus::parallel_copy_async(fresh + off, src.data(), half, cp);       // first half while the populate pieces are queued
@@ -69,6 +70,7 @@ int main()
         nus::parallel_copy_wait(cp);
         nus::parallel_copy_wait(pop);
         if (pop.left != 0 || memcmp(fresh + off, src.data(), n - 4096) != 0) ++bad;
+        if (nus::parallel_populate_prepare(fresh + off, n)) ++bad; // resident now: nothing to do
         for (size_t i = n - 4096; i < n; ++i) bad += fresh[off + i] != 0;
         munmap(fresh, n + 8192);
     }

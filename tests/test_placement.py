@@ -47,7 +47,8 @@ def test_plan_eight_gpus_two_sockets(nsc, tmp_path):
     plan = p.plan_binding(devices, 5, 8, range(256), quota=16.0, sysfs=str(tmp_path))
     assert plan["bound"] and len(plan["cpus"]) == 32 and plan["cpus_per_rank"] == 2
     assert p.thread_budget(2) == {"copy_threads": 0, "omp_threads": 2}
-    assert p.thread_budget(16) == {"copy_threads": 3, "omp_threads": 16}
+    assert p.thread_budget(16) == {"copy_threads": 6, "omp_threads": 16}
+    assert p.thread_budget(5) == {"copy_threads": 3, "omp_threads": 5}
 
 
 def test_plan_one_gpu_box_and_rehearsal(nsc, tmp_path):
