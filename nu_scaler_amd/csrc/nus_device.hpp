@@ -21,6 +21,33 @@ namespace {
 
 constexpr int kWave = 64;
 
+// Output pixels are written once and never read back by the kernel that writes them.  Streaming (nt) stores keep them from
+// pushing the kernel's INPUT out of the L2 -- a gain for the kernels whose waves re-read input (row-walking resize kernels,
+// the replicating nearest / fixed-ratio kernels: -2 ... -26 %), a loss for the packed-u8 bilinear x2 kernel (+5-10 %), the
+// blend (+3 %) and the warp (+7 %): chosen per kernel, measured in one run (profiles/r04_nt_stores_by_kernel.txt).
+// NUS_NT_STORES = 0 builds plain stores everywhere (A/B knob).
+#ifndef NUS_NT_STORES
+#define NUS_NT_STORES 1
+#endif
+typedef uint32_t nus_u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t nus_u32x2 __attribute__((ext_vector_type(2)));
+template <bool NT>
+__device__ __forceinline__ void store_out16(uint32_t *dst, const uint4 v)
+{
+    if constexpr (NT && NUS_NT_STORES)
+        __builtin_nontemporal_store(nus_u32x4{v.x, v.y, v.z, v.w}, reinterpret_cast<nus_u32x4 *>(dst));
+    else
+        *reinterpret_cast<uint4 *>(dst) = v;
+}
+template <bool NT>
+__device__ __forceinline__ void store_out8(uint32_t *dst, const uint2 v)
+{
+    if constexpr (NT && NUS_NT_STORES)
+        __builtin_nontemporal_store(nus_u32x2{v.x, v.y}, reinterpret_cast<nus_u32x2 *>(dst));
+    else
+        *reinterpret_cast<uint2 *>(dst) = v;
+}
+
 __device__ __forceinline__ float ch_f32(uint32_t p, int c)
 {
     return (float)((p >> (8 * c)) & 0xffu); // v_cvt_f32_ubyteN

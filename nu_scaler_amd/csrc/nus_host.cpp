@@ -147,6 +147,11 @@ int HipUpscaler::set_option(const char *key, int64_t value)
         rows_per_wave_ = (uint32_t)value;
         return kOk;
     }
+    if (!strcmp(key, "edge_stream")) { // 1: the x2 edge-column pass of a batch runs beside the main kernel on a second stream
+        if (value != 0 && value != 1) return fail(kInvalidArgument, "edge_stream must be 0 or 1");
+        edge_stream_ = (int)value;
+        return kOk;
+    }
     if (!strcmp(key, "unit_order")) { // wave order of upscale_unit_device: 0 frame-major, 1 row-block-major (default)
         if (value != 0 && value != 1) return fail(kInvalidArgument, "unit_order must be 0 or 1");
         unit_order_ = (uint32_t)value;
@@ -218,9 +223,13 @@ void HipUpscaler::release()
     prof_events_.clear();
     prof_used_ = 0;
     for (Slot &s : slots_) release_slot(s);
-    for (hipStream_t *st : {&s_in_, &s_k_, &s_out_}) {
+    for (hipStream_t *st : {&s_in_, &s_k_, &s_out_, &s_edge_}) {
         if (*st) (void)hipStreamDestroy(*st);
         *st = nullptr;
+    }
+    for (hipEvent_t *ev : {&ev_fork_, &ev_join_}) {
+        if (*ev) (void)hipEventDestroy(*ev);
+        *ev = nullptr;
     }
     initialized_ = false;
     have_ms_ = false;
@@ -538,6 +547,11 @@ int HipUpscaler::initialize(uint32_t in_w, uint32_t in_h, uint32_t out_w, uint32
     choose_variant();
     rc = upload_tables();
     if (rc != kOk) return rc;
+    if (variant_ == Variant::LanczosX2RegWin) { // the edge stream of enqueue(): made here so that enqueue allocates nothing
+        NUS_HIP(hipStreamCreateWithFlags(&s_edge_, hipStreamNonBlocking));
+        NUS_HIP(hipEventCreateWithFlags(&ev_fork_, hipEventDisableTiming));
+        NUS_HIP(hipEventCreateWithFlags(&ev_join_, hipEventDisableTiming));
+    }
     initialized_ = true;
     error_.clear();
     return kOk;
@@ -600,8 +614,16 @@ int HipUpscaler::enqueue(const uint8_t *d_in, uint8_t *d_out, uint32_t n_frames,
         prof_used_ += 2;
         NUS_HIP(hipEventRecord(ev_begin, stream));
     }
+    // (see below: the x2 resize kernels' edge-column pass of a batch runs beside the main kernel; the fork point is here, in
+    // front of the main kernel's launch)
+    constexpr uint32_t kEdgeBesideMinFrames = 8; // below that the event operations cost more than the pass
+    const bool beside = variant_ == Variant::LanczosX2RegWin && edge_stream_ && s_edge_ && ev_fork_ && ev_join_ &&
+                        n_frames >= kEdgeBesideMinFrames;
+    if (beside) {
+        NUS_HIP(hipEventRecord(ev_fork_, stream));
+        NUS_HIP(hipStreamWaitEvent(s_edge_, ev_fork_, 0));
+    }
     hipError_t e = hipSuccess;
-    bool lanczos_edges = false;
     switch (variant_) {
     case Variant::NearestTable: e = launch_nearest_table(L, dt_); break;
     case Variant::NearestX2: e = launch_nearest_x2(L); break;
@@ -664,6 +686,26 @@ int HipUpscaler::enqueue(const uint8_t *d_in, uint8_t *d_out, uint32_t n_frames,
         break;
     }
     case Variant::LanczosX2RegWin: {
+        // First / last 8 output columns: renormalised edge weights, row-per-lane kernel.  The main kernel leaves those columns
+        // alone, so the pass depends only on what the caller's stream held before this call.  For a batch it is forked onto the
+        // edge stream, launched FIRST (its single-wave blocks are on the GPU when the main kernel's blocks arrive and drain
+        // beside them; launched second they would wait for the main grid to run dry) and joins the caller's stream behind the
+        // main kernel.
+        {
+            const hipStream_t es = beside ? s_edge_ : stream;
+            UpscaleLaunch E = L;
+            E.stream = es;
+            if (unit) { // the real frames' edge columns come from A alone, the in-between frames' from the blended pair
+                UpscaleLaunch R = E;
+                R.in_b = nullptr;
+                e = launch_lanczos_x2_edges(R, dt_, lanczos_exact_);
+                if (e != hipSuccess) return fail_hip(e, "kernel launch");
+                E.out = unit->out_mid;
+            }
+            e = launch_lanczos_x2_edges(E, dt_, lanczos_exact_);
+            if (e != hipSuccess) return fail_hip(e, "kernel launch");
+            if (beside) NUS_HIP(hipEventRecord(ev_join_, s_edge_));
+        }
         const uint32_t th = lanczos_x2_rows_per_wave(n_frames, unit != nullptr);
         if (unit) {
             UnitOutputs U;
@@ -674,23 +716,14 @@ int HipUpscaler::enqueue(const uint8_t *d_in, uint8_t *d_out, uint32_t n_frames,
         } else {
             e = launch_lanczos_x2(L, dt_, lanczos_exact_, th);
         }
-        lanczos_edges = true;
         break;
     }
     }
-    if (e != hipSuccess) return fail_hip(e, "kernel launch");
-    if (lanczos_edges) {
-        // first / last 8 output columns: renormalised edge weights, row-per-lane kernel
-        if (unit) { // the real frames' edge columns come from A alone, the in-between frames' from the blended pair
-            UpscaleLaunch R = L;
-            R.in_b = nullptr;
-            e = launch_lanczos_x2_edges(R, dt_, lanczos_exact_);
-            if (e != hipSuccess) return fail_hip(e, "kernel launch");
-            L.out = unit->out_mid;
-        }
-        e = launch_lanczos_x2_edges(L, dt_, lanczos_exact_);
-        if (e != hipSuccess) return fail_hip(e, "kernel launch");
+    if (e != hipSuccess) {
+        if (beside) (void)hipStreamSynchronize(s_edge_); // nothing of a failed call stays in flight on the side stream
+        return fail_hip(e, "kernel launch");
     }
+    if (beside) NUS_HIP(hipStreamWaitEvent(stream, ev_join_, 0)); // the frames are complete when both kernels are
     // the bracket covers every launch that writes bytes of these frames (main kernel + edge columns)
     if (ev_end) NUS_HIP(hipEventRecord(ev_end, stream));
     return kOk;

@@ -163,6 +163,13 @@ private:
     // sit back to back in ONE queue per direction (0.60 ms per 4K frame on the D2H engine) instead of alternating between the
     // queues of per-slot streams (0.73 ms per frame measured that way, round 3).
     hipStream_t s_in_ = nullptr, s_k_ = nullptr, s_out_ = nullptr;
+    // The edge-column pass of the exact-x2 resize kernels writes columns the main kernel does not touch (round 4), so for batches
+    // it is forked onto this stream -- begin event on the caller's stream, edge pass here, join event back -- and runs beside the
+    // main kernel instead of behind it as a launch of 34 single-wave blocks per frame that cannot fill the GPU (3 % of the
+    // one-launch step).  Created by initialize(); enqueue() allocates nothing.  Option "edge_stream": 0 = same stream.
+    hipStream_t s_edge_ = nullptr;
+    hipEvent_t ev_fork_ = nullptr, ev_join_ = nullptr;
+    int edge_stream_ = 1;
 
     int fail(int status, const std::string &msg);
     int fail_hip(hipError_t e, const char *what);

@@ -32,8 +32,8 @@ __global__ __launch_bounds__(256) void k_blend_zero_flow(
         const uint4 va = *reinterpret_cast<const uint4 *>(pa + i);
         const uint4 vb = *reinterpret_cast<const uint4 *>(pb + i);
         // per-channel arithmetic: swizzling the blended pixel equals blending swizzled inputs
-        *reinterpret_cast<uint4 *>(po + i) = swz4(make_uint4(blend_px(va.x, vb.x, t, nt), blend_px(va.y, vb.y, t, nt),
-                                                             blend_px(va.z, vb.z, t, nt), blend_px(va.w, vb.w, t, nt)), sel);
+        store_out16<false>(po + i, swz4(make_uint4(blend_px(va.x, vb.x, t, nt), blend_px(va.y, vb.y, t, nt),
+                                                             blend_px(va.z, vb.z, t, nt), blend_px(va.w, vb.w, t, nt)), sel));
     } else {
         po[i] = swz(blend_px(pa[i], pb[i], t, nt), sel);
     }
@@ -223,9 +223,9 @@ __global__ __launch_bounds__(256) void k_warp_blend_flow(
         }
         uint32_t *dst = reinterpret_cast<uint32_t *>(out) + frame0 + (size_t)y * w + x0;
         if (XV == 4) {
-            *reinterpret_cast<uint4 *>(dst) = make_uint4(o[0], o[1], o[2], o[3]);
+            store_out16<false>(dst, make_uint4(o[0], o[1], o[2], o[3]));
         } else if (XV == 2) {
-            *reinterpret_cast<uint2 *>(dst) = make_uint2(o[0], o[1]);
+            store_out8<false>(dst, make_uint2(o[0], o[1]));
         } else {
 #pragma unroll
             for (int i = 0; i < XV; ++i) dst[i] = o[i];
@@ -276,7 +276,7 @@ __global__ __launch_bounds__(256) void k_swizzle_bgra(const uint32_t *__restrict
     if (i >= npx) return;
     if (VEC) {
         const uint4 v = *reinterpret_cast<const uint4 *>(in + i);
-        *reinterpret_cast<uint4 *>(out + i) = make_uint4(swap_rb(v.x), swap_rb(v.y), swap_rb(v.z), swap_rb(v.w));
+        store_out16<false>(out + i, make_uint4(swap_rb(v.x), swap_rb(v.y), swap_rb(v.z), swap_rb(v.w)));
     } else {
         out[i] = swap_rb(in[i]);
     }

@@ -15,7 +15,7 @@
 // every lane / row pair takes the weight set of its class (nus_tables.hpp: lanczos_r32_weight_classes).
 // The 12 left-most and right-most output columns (border-renormalised weights) belong to k_lanczos3_r32_edges.
 #ifndef NUS_STORE_AUX
-#define NUS_STORE_AUX 0
+#define NUS_STORE_AUX 2 // nt: see nus_k_lanczos_x2.hip; this kernel -8 ... -17 % (profiles/r04_nt_stores_by_kernel.txt)
 #endif
 #include "nus_device.hpp"
 

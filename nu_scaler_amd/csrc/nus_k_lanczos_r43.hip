@@ -15,7 +15,7 @@
 // moves one row, phase 1, ..., phase 3 reads r .. r+5, which is also the window of the next group's phase 0.
 // The 8 left-most and right-most output columns (border-renormalised weights) belong to k_lanczos3_r43_edges.
 #ifndef NUS_STORE_AUX
-#define NUS_STORE_AUX 0
+#define NUS_STORE_AUX 2 // nt: see nus_k_lanczos_x2.hip; this kernel -8 ... -17 % (profiles/r04_nt_stores_by_kernel.txt)
 #endif
 #include "nus_device.hpp"
 

@@ -577,14 +577,19 @@ __global__ __launch_bounds__(256) void k_lanczos3_x2(const LanczosX2Args A)
     // lane L computes the 8 output pixels of input columns c .. c+3; it stores them unless it is a halo lane or its
     // columns are the edge kernel's
 #ifndef NUS_LZ_ALIGNED_STORES
-#define NUS_LZ_ALIGNED_STORES 1 // the two stores start at the first STORING lane's pixels, not at the halo lane's, and the main
-                                // kernel also writes the (wrong: interior weights) edge columns, which the edge pass, launched
-                                // behind it, overwrites: with 240-column strips every store instruction covers whole 128-B
-                                // lines (0 = dev macro, A/B: -3 % on the opaque stream, profiles/r02_lanczos_x2_variants_ab.txt)
+#define NUS_LZ_ALIGNED_STORES 1 // the two stores start at the first STORING lane's pixels, not at the halo lane's: with 240-column
+                                // strips every store instruction covers whole 128-B lines (0 = dev macro, A/B: -3 % on the opaque
+                                // stream together with the edge-column overwrite, profiles/r02_lanczos_x2_variants_ab.txt)
+#endif
+#ifndef NUS_LZ_MAIN_WRITES_EDGES
+#define NUS_LZ_MAIN_WRITES_EDGES 0 // rounds 2-3 (1): the main kernel also wrote the 8 edge columns per side (wrong: interior
+                                   // weights) and the edge pass, launched BEHIND it, overwrote them.  Round 4 (0): it leaves them
+                                   // alone (the two 16-byte pieces per row end are range-checked away), so the edge pass depends
+                                   // on nothing the main kernel does and runs BESIDE it on a second stream (HipUpscaler::enqueue).
 #endif
     auto computes_stored_pixels = [&](int L) {
         const int cc = (int)(strip * kLanczosX2StripCols) - 4 + L * 4;
-#if NUS_LZ_ALIGNED_STORES
+#if NUS_LZ_ALIGNED_STORES && NUS_LZ_MAIN_WRITES_EDGES
         return L >= 1 && L <= (int)(kLanczosX2StripCols / 4) && cc >= 0 && cc + 4 <= (int)A.iw;
 #else
         return L >= 1 && L <= (int)(kLanczosX2StripCols / 4) && cc >= 4 && cc + 8 <= (int)A.iw;

@@ -12,7 +12,7 @@
 // cover every frame.  The 4 S left-most and right-most output columns (border-renormalised weights)
 // are left to k_lanczos_general.
 #ifndef NUS_STORE_AUX
-#define NUS_STORE_AUX 0
+#define NUS_STORE_AUX 2 // nt: see nus_k_lanczos_x2.hip; this kernel -8 ... -17 % (profiles/r04_nt_stores_by_kernel.txt)
 #endif
 #include "nus_device.hpp"
 

@@ -48,7 +48,7 @@ __global__ __launch_bounds__(256) void k_nearest_table(
             have = r;
         }
         if (VEC)
-            *reinterpret_cast<uint4 *>(dst + (size_t)y * ow) = make_uint4(o[0], o[N > 1 ? 1 : 0], o[N > 2 ? 2 : 0], o[N > 3 ? 3 : 0]);
+            store_out16<true>(dst + (size_t)y * ow, make_uint4(o[0], o[N > 1 ? 1 : 0], o[N > 2 ? 2 : 0], o[N > 3 ? 3 : 0]));
         else
             dst[(size_t)y * ow] = o[0];
     }
@@ -77,8 +77,8 @@ __global__ __launch_bounds__(256) void k_nearest_x2(
         const uint2 p2 = *reinterpret_cast<const uint2 *>(src + k);
         const uint32_t p0 = swz(p2.x, sel), p1 = swz(p2.y, sel);
         const uint4 o = make_uint4(p0, p0, p1, p1);
-        *reinterpret_cast<uint4 *>(d + 2 * k) = o;
-        *reinterpret_cast<uint4 *>(d + ow + 2 * k) = o;
+        store_out16<true>(d + 2 * k, o);
+        store_out16<true>(d + ow + 2 * k, o);
     }
 }
 
@@ -180,7 +180,7 @@ __global__ __launch_bounds__(256) void k_bilinear_table(
             o[i] = px;
         }
         if (VEC)
-            *reinterpret_cast<uint4 *>(dst + (size_t)y * ow) = make_uint4(o[0], o[N > 1 ? 1 : 0], o[N > 2 ? 2 : 0], o[N > 3 ? 3 : 0]);
+            store_out16<false>(dst + (size_t)y * ow, make_uint4(o[0], o[N > 1 ? 1 : 0], o[N > 2 ? 2 : 0], o[N > 3 ? 3 : 0]));
         else
             dst[(size_t)y * ow] = o[0];
     }
@@ -236,10 +236,10 @@ __global__ __launch_bounds__(256) void k_bilinear_x2_int(
         bot[2 * i + 1] = avg4_u8x4(p[i], p[i + 1], q[i], q[i + 1]);
     }
     uint32_t *d = out + (size_t)blockIdx.z * out_frame_px + (size_t)(2 * r) * ow + 2 * k;
-    *reinterpret_cast<uint4 *>(d) = make_uint4(top[0], top[1], top[2], top[3]);
-    *reinterpret_cast<uint4 *>(d + 4) = make_uint4(top[4], top[5], top[6], top[7]);
-    *reinterpret_cast<uint4 *>(d + ow) = make_uint4(bot[0], bot[1], bot[2], bot[3]);
-    *reinterpret_cast<uint4 *>(d + ow + 4) = make_uint4(bot[4], bot[5], bot[6], bot[7]);
+    store_out16<false>(d, make_uint4(top[0], top[1], top[2], top[3]));
+    store_out16<false>(d + 4, make_uint4(top[4], top[5], top[6], top[7]));
+    store_out16<false>(d + ow, make_uint4(bot[0], bot[1], bot[2], bot[3]));
+    store_out16<false>(d + ow + 4, make_uint4(bot[4], bot[5], bot[6], bot[7]));
 }
 
 } // namespace
@@ -277,7 +277,7 @@ template <int P>
 __device__ __forceinline__ void ratio_store(uint32_t *d, const uint32_t (&o)[P])
 {
     if constexpr (P == 4) {
-        *reinterpret_cast<uint4 *>(d) = make_uint4(o[0], o[1], o[2], o[3]);
+        store_out16<true>(d, make_uint4(o[0], o[1], o[2], o[3]));
     } else {
 #pragma unroll
         for (int k = 0; k < P; ++k) d[k] = o[k]; // (merged into one global_store_dwordx3)
