@@ -409,6 +409,17 @@ int nus_flow_set_device(nus_flow *h, int device);
  * the size of the batch (2: always the LDS-tile kernel, 3: always the register-pipelined one);
  * 0: one plain kernel per step, the shader's structure.  Results are bit-identical. */
 int nus_flow_set_tiled(nus_flow *h, int enabled);
+/* Arithmetic of the estimators' Horn-Schunck steps, as nus_upscaler_set_lanczos_mode / nus_interp_set_mode have it for their
+ * kernels.  NUS_FLOW_EXACT (default): every stage bit-identical to the oracle's restatement of the shaders.  NUS_FLOW_FAST: the
+ * Jacobi steps with separable 3x3 sums, a multiply by 1/9, a precomputed reciprocal of lambda + Ix^2 + Iy^2 and FMAs
+ * (shaders/horn_schunck.wgsl:24-92 in its cheapest f32 form; every level in the register-pipelined kernel) -- the flow within
+ * 1e-3 px of the exact one, the frame interpolated with it within 1 LSB on < 0.1 % of its samples; 2.2x fewer instructions per
+ * step.  The reference never runs this front end (wgpu_interpolator.rs:1156-1203 is unwired), so neither mode has a fixture.
+ * The primitives below are always exact. */
+#define NUS_FLOW_EXACT 0
+#define NUS_FLOW_FAST 1
+int nus_flow_set_mode(nus_flow *h, int mode);
+int nus_flow_mode(const nus_flow *h);
 const char *nus_flow_last_error(const nus_flow *h);
 
 /* primitives on host buffers */

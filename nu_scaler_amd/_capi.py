@@ -112,6 +112,8 @@ SIGNATURES = [
     ("nus_flow_destroy", None, [_vp]),
     ("nus_flow_set_device", _i, [_vp, _i]),
     ("nus_flow_set_tiled", _i, [_vp, _i]),
+    ("nus_flow_set_mode", _i, [_vp, _i]),
+    ("nus_flow_mode", _i, [_vp]),
     ("nus_flow_last_error", _cp, [_vp]),
     ("nus_flow_rgba8_to_f32", _i, [_vp, _vp, _u32, _u32, _vp]),
     ("nus_flow_blur", _i, [_vp, _vp, _u32, _u32, _vp]),

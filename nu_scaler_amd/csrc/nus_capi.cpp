@@ -638,6 +638,11 @@ int nus_flow_set_tiled(nus_flow *h, int enabled)
 {
     return guarded<int>("nus_flow_set_tiled", [&]() -> int { return h ? h->impl.set_tiled(enabled) : null_handle(); });
 }
+int nus_flow_set_mode(nus_flow *h, int mode)
+{
+    return guarded<int>("nus_flow_set_mode", [&]() -> int { return h ? h->impl.set_mode(mode) : null_handle(); });
+}
+int nus_flow_mode(const nus_flow *h) { return h ? h->impl.mode() : NUS_ERR_INVALID_ARGUMENT; }
 const char *nus_flow_last_error(const nus_flow *h) { return h ? h->impl.last_error() : "null handle"; }
 
 int nus_flow_rgba8_to_f32(nus_flow *h, const uint8_t *in, uint32_t w, uint32_t hgt, float *out)

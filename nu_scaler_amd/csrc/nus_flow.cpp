@@ -51,6 +51,14 @@ int HipFlowEstimator::set_tiled(int mode)
     return kOk;
 }
 
+int HipFlowEstimator::set_mode(int mode)
+{
+    std::lock_guard<std::mutex> lk(mu_);
+    if (mode != 0 && mode != 1) return fail(kInvalidArgument, "set_mode: 0 exact, 1 fast");
+    fast_ = mode == 1;
+    return kOk;
+}
+
 int HipFlowEstimator::set_device(int device)
 {
     std::lock_guard<std::mutex> lk(mu_);
@@ -328,7 +336,16 @@ int HipFlowEstimator::estimate_device(const void *d_a, const void *d_b, uint32_t
     if (!d_a || !d_b || !d_flow_out) return fail(kInvalidArgument, "flow: null device pointer");
     Pyramid g;
     int rc = plan(w, h, levels, g);
-    if (rc != kOk || (rc = build_pyramid(d_a, 4, g, stream)) != kOk || (rc = build_pyramid(d_b, 5, g, stream)) != kOk) return rc;
+    if (rc != kOk) return rc;
+    if (fast_) { // the FAST Jacobi kernel lives in the batch solver: the pair as a stream of two frames
+        const size_t fb = (size_t)w * h * 4;
+        if ((rc = reserve(2 * fb, 8)) != kOk) return rc;
+        uint8_t *two = static_cast<uint8_t *>(slot_[8]);
+        NUS_HIP(hipMemcpyAsync(two, d_a, fb, hipMemcpyDeviceToDevice, stream));
+        NUS_HIP(hipMemcpyAsync(two + fb, d_b, fb, hipMemcpyDeviceToDevice, stream));
+        return solve_batch(two, 1, g, coarse_iters, refine_iters, lambda, static_cast<uint8_t *>(d_flow_out), stream);
+    }
+    if ((rc = build_pyramid(d_a, 4, g, stream)) != kOk || (rc = build_pyramid(d_b, 5, g, stream)) != kOk) return rc;
     return solve(4, 5, g, coarse_iters, refine_iters, lambda, d_flow_out, stream);
 }
 
@@ -348,7 +365,7 @@ int HipFlowEstimator::estimate_device_stream(const void *d_frames, uint32_t n_fr
     const uint8_t *frames = static_cast<const uint8_t *>(d_frames);
     uint8_t *flows = static_cast<uint8_t *>(d_flows);
     const size_t frame_bytes = (size_t)w * h * 4, flow_bytes = (size_t)w * h * 8;
-    if (!tiled_) { // the shader-shaped kernels, pair by pair (each frame's pyramid still built once)
+    if (!tiled_ && !fast_) { // the shader-shaped kernels, pair by pair (each frame's pyramid still built once)
         if ((rc = build_pyramid(frames, 4, g, stream)) != kOk) return rc;
         for (uint32_t k = 0; k + 1 < n_frames; ++k) {
             const int slot_a = 4 + (int)(k & 1), slot_b = 5 - (int)(k & 1);
@@ -370,7 +387,7 @@ int HipFlowEstimator::estimate_device_stream(const void *d_frames, uint32_t n_fr
     uint32_t chunk = chunk_for(31);
     if (chunk > n_pairs) chunk = n_pairs;
     for (uint32_t l = 0; l < g.levels; ++l)
-        if (!hs_iterate_streams(g.w[l], g.h[l], chunk, jacobi_)) {
+        if (!hs_iterate_streams(g.w[l], g.h[l], chunk, fast_ ? kJacobiStreamFast : jacobi_)) {
             chunk = chunk_for(43);
             break;
         }
@@ -390,6 +407,7 @@ int HipFlowEstimator::solve_batch(const uint8_t *d_frames, uint32_t pairs, const
                                   uint32_t refine_iters, float lambda, uint8_t *d_flows, hipStream_t stream)
 {
     int rc;
+    const int jacobi = fast_ ? kJacobiStreamFast : jacobi_; // FAST: k_hs_stream_fast on every level, derivatives from the planes
     const uint32_t nf = pairs + 1, nl = g.levels, L = nl - 1;
     size_t cells[12], lum_off[12], lum_total = 0;
     for (uint32_t l = 0; l < nl; ++l) {
@@ -404,7 +422,7 @@ int HipFlowEstimator::solve_batch(const uint8_t *d_frames, uint32_t pairs, const
         return rc;
     // A level whose Jacobi steps run in the streamed kernel needs no coefficient planes: that kernel takes the
     // derivatives from the luminance planes of the pair's two frames (consecutive planes of the level) as it goes.
-    auto from_planes = [&](uint32_t l) { return hs_iterate_streams(g.w[l], g.h[l], pairs, jacobi_); };
+    auto from_planes = [&](uint32_t l) { return hs_iterate_streams(g.w[l], g.h[l], pairs, jacobi); };
     size_t coef_cells = 0;
     for (uint32_t l = 0; l < nl; ++l)
         if (!from_planes(l) && cells[l] > coef_cells) coef_cells = cells[l];
@@ -418,13 +436,13 @@ int HipFlowEstimator::solve_batch(const uint8_t *d_frames, uint32_t pairs, const
         const size_t src_stride = l == 0 ? cells[0] * 4 /* bytes */ : cells[l] /* float4 */;
         float *next = l + 1 < nl ? level_in[l & 1] : nullptr;
         NUS_HIP(launch_pyramid_level(src, l == 0, lum + lum_off[l], next, g.w[l], g.h[l], stream, nf, src_stride, cells[l],
-                                     l + 1 < nl ? cells[l + 1] : 0, jacobi_));
+                                     l + 1 < nl ? cells[l + 1] : 0, jacobi));
     }
     float *const out = reinterpret_cast<float *>(d_flows);
     // `coarse`: the level continues the flow of level l + 1 in f0, which the first launch upsamples as it loads it
     auto iterate = [&](uint32_t l, uint32_t iters, bool zero, bool coarse) -> int {
         NUS_HIP(launch_hs_iterate(coef, lambda, &f0, &f1, g.w[l], g.h[l], iters, zero, l == 0 ? out : nullptr, stream, pairs,
-                                  cells[l] * 3, cells[l], cells[0], jacobi_, from_planes(l) ? lum + lum_off[l] : nullptr, cells[l],
+                                  cells[l] * 3, cells[l], cells[0], jacobi, from_planes(l) ? lum + lum_off[l] : nullptr, cells[l],
                                   coarse ? f0 : nullptr, coarse ? g.w[l + 1] : 0, coarse ? g.h[l + 1] : 0, 2.0f,
                                   coarse ? cells[l + 1] : 0));
         return kOk;

@@ -37,6 +37,11 @@ public:
     // Full estimator: RGBA8 frames -> dense flow (w*h*2 floats, pixel delta A -> B).
     int estimate(const uint8_t *a, const uint8_t *b, uint32_t w, uint32_t h, uint32_t levels, uint32_t coarse_iters,
                  uint32_t refine_iters, float lambda, float *flow_out);
+    // 0 EXACT (default): every stage bit-identical to the oracle's restatement of the shaders; 1 FAST: the Jacobi steps of the
+    // estimators (estimate, estimate_device, estimate_device_stream) in separable sums / reciprocals / FMAs -- flow within 1e-3 px.
+    // The primitives (blur, downsample, horn_schunck, upsample) are always exact.
+    int set_mode(int mode);
+    int mode() const { return fast_ ? 1 : 0; }
     int estimate_device(const void *d_a, const void *d_b, uint32_t w, uint32_t h, uint32_t levels,
                         uint32_t coarse_iters, uint32_t refine_iters, float lambda, void *d_flow_out,
                         hipStream_t stream);
@@ -72,8 +77,9 @@ private:
     bool ready_ = false;
     bool tiled_ = true;
     int jacobi_ = 0; // JacobiKernel
+    bool fast_ = false; // set_mode(1): the estimator's Jacobi steps in FAST arithmetic (k_hs_stream_fast), every level streamed
     hipStream_t stream_ = nullptr;
-    static constexpr int kSlotCount = 8;
+    static constexpr int kSlotCount = 9; // 0-5 pyramids / flows / planes, 6-7 the host entry point's frames, 8 the FAST pair
     void *slot_[kSlotCount] = {nullptr};
     size_t slot_cap_[kSlotCount] = {0};
     std::string error_;

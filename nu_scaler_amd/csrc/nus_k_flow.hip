@@ -594,6 +594,124 @@ __global__ __launch_bounds__(256) void k_hs_stream(const float *__restrict__ coe
     for (; t < hi + K; ++t) pass(t, std::false_type{}); // drain
 }
 
+// ---- The same pipeline in FAST arithmetic (nus_flow_set_mode(NUS_FLOW_FAST)) ------------------------------------------
+// k_hs_stream reproduces, operation for operation, arithmetic the reference never executes (compute_coarse_flow is not wired
+// into interpolate_py, wgpu_interpolator.rs:1156-1203; no fixture exists): 9-term sums in the shader's order, true divisions
+// (as exact reciprocal sequences).  This kernel computes the same Jacobi step in the cheapest f32 form:
+//   * the 3x3 sum separably -- the vertical sum of a column's rows r-2, r-1, r first (own column only: a level keeps two rows of
+//     (u, v) instead of three columns of them and two running sums), then left + centre + right of that sum across lanes
+//     (4 DPP moves per step as before, 8 adds instead of 18); the clamp of horn_schunck.wgsl:30-36 is separable, so the border
+//     cells take exactly the cells the shader takes;
+//   * the mean as a multiply by 1/9, the update as  u' = ua - num * gx,  gx = ix / (lambda + ix^2 + iy^2)  precomputed per
+//     cell when its row enters the pipeline (one v_rcp_f32 per cell and launch), num = fma(ix, ua, fma(iy, va, it)).
+// ~22 f32 operations + 9 register moves per cell and step where the exact kernel has ~60.  Contract (tests/test_flow.py): the
+// flow of the full estimator within 1e-3 px of orc_flow_estimate's at 1080p, the frame interpolated with it within 1 LSB and
+// on < 0.1 % of the samples different.  Always takes the derivatives from the luminance planes (LUM of k_hs_stream).
+#ifndef NUS_HS_FAST_AHEAD
+#define NUS_HS_FAST_AHEAD 2 // passes between a row's request and its use in k_hs_stream_fast
+#endif
+struct HsFastCoef {
+    float ix, iy, it, gx, gy;
+};
+
+template <int K, bool UPS>
+__global__ __launch_bounds__(256) void k_hs_stream_fast(const float *__restrict__ lum_all, size_t lum_stride, float lambda,
+                                                        const float2 *__restrict__ fin_all, size_t fin_stride,
+                                                        float2 *__restrict__ fout_all, size_t fout_stride, int w, int h, int strips,
+                                                        int row_blocks, int rows_per_block, HsCoarse coarse)
+{
+    constexpr int U = kWave - 2 * K; // columns a wave writes
+    const int lane = threadIdx.x & (kWave - 1);
+    const int g = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6)); // wave-uniform, in an SGPR
+    if (g >= strips * row_blocks) return;
+    const int rb = g / strips, strip = g - rb * strips;
+    const float *lum1 = lum_all + blockIdx.y * lum_stride; // frame 1's plane; frame 2's follows lum_stride floats further on
+    const float2 *fin = fin_all ? fin_all + blockIdx.y * fin_stride : nullptr; // null = start from zero flow
+    float2 *fout = fout_all + blockIdx.y * fout_stride;
+    const int x = strip * U - K + lane, xc = clampi(x, 0, w - 1);
+    const bool self_l = x <= 0, self_r = x >= w - 1;
+    const bool writer = lane >= K && lane < kWave - K && x < w;
+    const int y0 = rb * rows_per_block, y1 = min(y0 + rows_per_block, h);
+    const int lo = max(y0 - K, 0), hi = min(y1 + K, h);
+
+    float2 a1[K], a2[K];   // level j: its rows r-1 and r-2 (this lane's column)
+    HsFastCoef cf[K + 1];  // cf[d]: coefficients of row t - d (cf[0] is only the way in)
+
+    auto load_flow = [&](int r) -> float2 {
+        if constexpr (UPS)
+            return flow_upsample_cell(coarse.flow + blockIdx.y * coarse.stride, coarse.w, coarse.h, xc, min(r, hi - 1), w, h, coarse.scale);
+        else
+            return fin ? fin[(size_t)min(r, hi - 1) * w + xc] : make_float2(0.0f, 0.0f);
+    };
+    // rows are requested NUS_HS_FAST_AHEAD passes before they are used: a FAST pass is short (~120 instructions), and with one row
+    // in flight per wave the launch was bound by memory latency, not by bandwidth or instruction issue
+    constexpr int AH = NUS_HS_FAST_AHEAD;
+    float2 qf[AH];
+    float q1[AH], q2[AH]; // q*[d]: row t + d's flow, frame 1's row t + d + 1, frame 2's row t + d (d = 0: this pass's)
+#pragma unroll
+    for (int d = 0; d < AH; ++d) {
+        qf[d] = load_flow(lo + d);
+        q1[d] = lum1[(size_t)clampi(lo + d + 1, 0, h - 1) * w + xc];
+        q2[d] = lum1[lum_stride + (size_t)clampi(lo + d, 0, h - 1) * w + xc];
+    }
+    float l1_above = lum1[(size_t)clampi(lo - 1, 0, h - 1) * w + xc], l1_row = lum1[(size_t)lo * w + xc]; // frame 1, rows t - 1, t
+    const float ninth = 1.0f / 9.0f;
+
+    auto pass = [&](int t, auto steady_tag) {
+        constexpr bool STEADY = decltype(steady_tag)::value;
+        const float2 nf = qf[0];
+        const float n1 = q1[0], n2 = q2[0];
+        const float2 pf = load_flow(t + AH); // in flight during this pass and the next AH - 1
+        const float p1 = lum1[(size_t)clampi(t + AH + 1, 0, h - 1) * w + xc];
+        const float p2 = lum1[lum_stride + (size_t)clampi(t + AH, 0, h - 1) * w + xc];
+        {
+            const float left = wave_up(l1_row), right = wave_down(l1_row);
+            const float ix = ((self_r ? l1_row : right) - (self_l ? l1_row : left)) * 0.5f;
+            const float iy = (n1 - l1_above) * 0.5f;
+            const float it = n2 - l1_row;
+            l1_above = l1_row, l1_row = n1;
+            const float rinv = __builtin_amdgcn_rcpf(__builtin_fmaf(iy, iy, __builtin_fmaf(ix, ix, lambda)));
+            cf[0] = HsFastCoef{ix, iy, it, ix * rinv, iy * rinv};
+        }
+        float2 arr = nf; // level 0's arrival: row t of the input flow
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+            const int r = t - j; // the row arriving at level j in this pass
+            if (!STEADY) {
+                if (r < lo) break;    // the pipeline is still filling (wave-uniform)
+                if (r > hi) continue; // this level is done, deeper ones are draining
+                if (r == hi) arr = a1[j]; // past the last row: it repeats
+                if (r == lo) { // first row: also the row above it
+                    a1[j] = arr, a2[j] = arr;
+                    break; // deeper levels have nothing yet
+                }
+            }
+            // row r-1 of level j+1: vertical sum of rows r-2, r-1, r of this column, then left + centre + right of it
+            const float su = (a2[j].x + a1[j].x) + arr.x, sv = (a2[j].y + a1[j].y) + arr.y;
+            const float lu = wave_up(su), ru = wave_down(su), lv = wave_up(sv), rv = wave_down(sv);
+            const float ua = (((self_l ? su : lu) + su) + (self_r ? su : ru)) * ninth;
+            const float va = (((self_l ? sv : lv) + sv) + (self_r ? sv : rv)) * ninth;
+            const HsFastCoef c = cf[j + 1]; // row r-1 entered j+1 passes ago
+            const float num = __builtin_fmaf(c.ix, ua, __builtin_fmaf(c.iy, va, c.it));
+            a2[j] = a1[j], a1[j] = arr;
+            arr = make_float2(__builtin_fmaf(-num, c.gx, ua), __builtin_fmaf(-num, c.gy, va));
+            if (j == K - 1) {
+                const int y = r - 1;
+                if (y >= y0 && y < y1 && writer) fout[(size_t)y * w + x] = arr;
+            }
+        }
+#pragma unroll
+        for (int d = K; d >= 1; --d) cf[d] = cf[d - 1];
+#pragma unroll
+        for (int d = 0; d + 1 < AH; ++d) qf[d] = qf[d + 1], q1[d] = q1[d + 1], q2[d] = q2[d + 1];
+        qf[AH - 1] = pf, q1[AH - 1] = p1, q2[AH - 1] = p2;
+    };
+    int t = lo;
+    for (; t < min(lo + K, hi + K); ++t) pass(t, std::false_type{}); // fill
+    for (; t < hi; ++t) pass(t, std::true_type{});
+    for (; t < hi + K; ++t) pass(t, std::false_type{}); // drain
+}
+
 __global__ __launch_bounds__(256) void k_flow_upsample(const float2 *__restrict__ src, size_t src_stride, int sw, int sh,
                                                        float2 *__restrict__ dst, size_t dst_stride, int dw, int dh, float scale)
 {
@@ -675,7 +793,7 @@ hipError_t launch_pyramid_level(const void *in, bool u8_input, float *level_lum,
                                                            std::max<uint32_t>(h / NUS_PYR_STREAM_MIN_ROWS, 1));
         const uint32_t rows_per_block = (cdiv(h, want) + 1) & ~1u; // even: a 2x2 block never straddles two row blocks
         const uint32_t row_blocks = cdiv(h, rows_per_block);
-        if (kernel == kJacobiStream || columns * row_blocks >= 2048) {
+        if (kernel == kJacobiStream || kernel == kJacobiStreamFast || columns * row_blocks >= 2048) {
             const dim3 block(256), grid(cdiv(strips * row_blocks, 4), n);
             if (u8_input)
                 hipLaunchKernelGGL(k_pyramid_stream<true>, grid, block, 0, stream, in, in_stride, level_lum, lum_stride,
@@ -750,6 +868,9 @@ hipError_t launch_hs_level_setup(const float *l1, const float *l2, float *coef, 
 #ifndef NUS_HS_STREAM_MAXK
 #define NUS_HS_STREAM_MAXK 5 // steps per launch of the streamed kernel (registers: 8 per level + 5 per delay-line row)
 #endif
+#ifndef NUS_HS_FAST_MAXK
+#define NUS_HS_FAST_MAXK 5 // steps per launch of k_hs_stream_fast (registers: 4 per level + 5 per delay-line row)
+#endif
 #ifndef NUS_HS_STREAM_MIN_ROWS
 #define NUS_HS_STREAM_MIN_ROWS 64 // shortest row block: 2K halo rows and the K passes of pipeline fill are paid per block
 #endif
@@ -788,7 +909,8 @@ static HsStreamShape hs_stream_shape(uint32_t w, uint32_t h, uint32_t n, uint32_
 // luminance planes (lum1), so the caller need not have k_hs_prepare's coefficient planes written
 bool hs_iterate_streams(uint32_t w, uint32_t h, uint32_t n, int kernel)
 {
-    return kernel != kJacobiTiles && hs_stream_shape(w, h, n, NUS_HS_STREAM_MAXK, kernel == kJacobiStream).row_blocks != 0;
+    return kernel != kJacobiTiles &&
+           hs_stream_shape(w, h, n, NUS_HS_STREAM_MAXK, kernel == kJacobiStream || kernel == kJacobiStreamFast).row_blocks != 0;
 }
 
 hipError_t launch_hs_iterate(const float *coef, float lambda, float **flow_a, float **flow_b, uint32_t w, uint32_t h,
@@ -796,6 +918,50 @@ hipError_t launch_hs_iterate(const float *coef, float lambda, float **flow_a, fl
                              size_t coef_stride, size_t flow_stride, size_t final_stride, int kernel, const float *lum1,
                              size_t lum_stride, const float *coarse, uint32_t cw, uint32_t ch, float coarse_scale, size_t coarse_stride)
 {
+    if (kernel == kJacobiStreamFast) { // FAST arithmetic (k_hs_stream_fast): always streamed, always from the luminance planes
+        if (lum1 == nullptr) return hipErrorInvalidValue;
+        uint32_t launches = (iterations + NUS_HS_FAST_MAXK - 1) / NUS_HS_FAST_MAXK;
+        while (iterations > 0) {
+            const uint32_t k = (iterations + launches - 1) / launches; // even split, 1..MAXK steps per launch
+            size_t out_stride = flow_stride;
+            if (final_out && launches == 1) { // the last launch writes the caller's buffer
+                *flow_b = final_out;
+                out_stride = final_stride;
+            }
+            auto fi = zero_start ? nullptr : reinterpret_cast<const float2 *>(*flow_a);
+            auto fo = reinterpret_cast<float2 *>(*flow_b);
+            zero_start = false;
+            const HsStreamShape sh = hs_stream_shape(w, h, n, k, true);
+            const bool ups = coarse != nullptr; // the first launch of a level takes the coarser level's flow, upsampled as it loads it
+            const HsCoarse hc{reinterpret_cast<const float2 *>(coarse), coarse_stride, (int)cw, (int)ch, coarse_scale};
+            coarse = nullptr;
+            const dim3 block(256), grid(cdiv(sh.strips * sh.row_blocks, 4), n);
+#define NUS_HSF(KK)                                                                                                                  \
+    case KK:                                                                                                                         \
+        if (ups)                                                                                                                     \
+            hipLaunchKernelGGL((k_hs_stream_fast<KK, true>), grid, block, 0, stream, lum1, lum_stride, lambda, fi, flow_stride, fo,   \
+                               out_stride, (int)w, (int)h, (int)sh.strips, (int)sh.row_blocks, (int)sh.rows_per_block, hc);           \
+        else                                                                                                                         \
+            hipLaunchKernelGGL((k_hs_stream_fast<KK, false>), grid, block, 0, stream, lum1, lum_stride, lambda, fi, flow_stride, fo,  \
+                               out_stride, (int)w, (int)h, (int)sh.strips, (int)sh.row_blocks, (int)sh.rows_per_block, hc);           \
+        break;
+            switch (k) {
+                NUS_HSF(1) NUS_HSF(2) NUS_HSF(3) NUS_HSF(4) NUS_HSF(5)
+#if NUS_HS_FAST_MAXK > 5
+                NUS_HSF(6) NUS_HSF(7) NUS_HSF(8) NUS_HSF(9) NUS_HSF(10)
+#endif
+            }
+#undef NUS_HSF
+            hipError_t e = hipGetLastError();
+            if (e != hipSuccess) return e;
+            iterations -= k;
+            --launches;
+            float *t = *flow_a;
+            *flow_a = *flow_b;
+            *flow_b = t;
+        }
+        return hipSuccess;
+    }
     if (hs_iterate_streams(w, h, n, kernel)) {
         if (lum1) coef = lum1, coef_stride = lum_stride; // the kernel takes the derivatives from the planes themselves
         uint32_t launches = (iterations + NUS_HS_STREAM_MAXK - 1) / NUS_HS_STREAM_MAXK;

@@ -189,7 +189,7 @@ hipError_t launch_horn_schunck(const float *i1, const float *i2, const float *fl
 // blur H + blur V + downsample of one level in one launch (LDS tile with a 2-pixel halo); the level
 // itself is written as its luminance plane (w*h floats), which is all Horn-Schunck reads of it.
 // `kernel`: LDS-tile or register-pipelined ("streamed") form of the pyramid and the multi-step Jacobi kernels
-enum JacobiKernel { kJacobiAuto = 0, kJacobiTiles = 1, kJacobiStream = 2 };
+enum JacobiKernel { kJacobiAuto = 0, kJacobiTiles = 1, kJacobiStream = 2, kJacobiStreamFast = 3 }; // Fast: k_hs_stream_fast, every level
 hipError_t launch_pyramid_level(const void *in, bool u8_input, float *level_lum, float *next, uint32_t w, uint32_t h,
                                 hipStream_t stream, uint32_t n = 1, size_t in_stride = 0, size_t lum_stride = 0,
                                 size_t next_stride = 0, int kernel = 0);

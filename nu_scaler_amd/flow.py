@@ -36,6 +36,18 @@ class FlowEstimator:
         register-pipelined kernel); False / 0: one plain kernel per step.  Same bits either way."""
         self._check(self._lib.nus_flow_set_tiled(self._h, int(enabled)))
 
+    def set_mode(self, mode: str) -> None:
+        """"exact" (default): every stage bit-identical to the oracle; "fast": the estimators' Jacobi steps in separable sums,
+        reciprocals and FMAs (flow within 1e-3 px; nus_flow_set_mode)."""
+        m = {"exact": 0, "fast": 1}.get(str(mode).lower())
+        if m is None:
+            raise ValueError("mode must be 'exact' or 'fast'")
+        self._check(self._lib.nus_flow_set_mode(self._h, m))
+
+    @property
+    def mode(self) -> str:
+        return "fast" if self._lib.nus_flow_mode(self._h) == 1 else "exact"
+
     def _check(self, status: int) -> None:
         if status != C.OK:
             raise RuntimeError(self._lib.nus_flow_last_error(self._h).decode("utf-8", "replace"))

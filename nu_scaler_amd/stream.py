@@ -164,7 +164,7 @@ class FramePipeline:
                                           up_real.data_ptr(), up_mid.data_ptr(), n, stream)
 
     def step_motion(self, frames, flows, mid, up_real, up_mid, stream: int = 0, levels: int = 3,
-                    coarse_iterations: int = 50, refine_iterations: int = 10) -> None:
+                    coarse_iterations: int = 50, refine_iterations: int = 10, flow_mode: str = "exact") -> None:
         """Motion-compensated variant of `step`: a dense flow per pair from the
         pyramid + Horn-Schunck front end into `flows` ((n_units, h, w, 2) float32), then warp + blend with it
         instead of the reference's zero flow.  The flows are estimated pair by pair (several launches per pair,
@@ -173,6 +173,8 @@ class FramePipeline:
 
         if getattr(self, "_flow", None) is None:
             self._flow = FlowEstimator(levels, coarse_iterations, refine_iterations, device=self.upscaler._device)
+        if self._flow.mode != flow_mode:
+            self._flow.set_mode(flow_mode)  # "fast": the Jacobi steps in separable sums / reciprocals / FMAs (flow within 1e-3 px)
         n = mid.shape[0]
         base = frames.data_ptr()
         fb = self.frame_bytes

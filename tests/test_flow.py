@@ -249,3 +249,83 @@ def test_pipeline_step_motion_matches_stage_by_stage_oracle(nsc, oracle_mod):
         assert np.array_equal(mid[k].cpu().numpy(), want_mid), k
         assert np.array_equal(up_mid[k].cpu().numpy(), oracle_mod.lanczos3(want_mid, 2 * w, 2 * h)), k
         assert np.array_equal(up_real[k].cpu().numpy(), oracle_mod.lanczos3(frames[k], 2 * w, 2 * h)), k
+
+
+# ---- FAST mode of the estimators (nus_flow_set_mode): tolerance against the exact oracle ---------------------------------
+
+def _flow_close(got, want, tol=1e-3):
+    d = np.abs(got.astype(np.float64) - want.astype(np.float64))
+    return float(d.max()) <= tol, float(d.max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("w,h,levels,coarse,refine", [(97, 45, 3, 9, 3), (333, 262, 3, 7, 6), (160, 90, 4, 30, 8), (613, 517, 2, 11, 5),
+                                                       (64, 64, 1, 13, 0), (129, 70, 2, 1, 1)])
+def test_flow_fast_mode_within_a_thousandth_of_a_pixel(nsc, oracle_mod, w, h, levels, coarse, refine):
+    """FAST mode (separable 3x3 sums, multiply by 1/9, precomputed reciprocal, FMAs; every level in the register-pipelined
+    kernel): the flow of every estimator entry point within 1e-3 px of the exact oracle's, on smooth moving content and on
+    noise (large gradients, chaotic flow), ragged sizes, step counts that split into launches of 1..5 steps, several pairs."""
+    import torch
+
+    dev = torch.device("cuda:0")
+    for kind in ("smooth", "noise"):
+        n_frames = 4
+        frames = np.stack([_smooth(w, h, 1.3 * k) if kind == "smooth" else oracle_mod.gen_noise(w, h, 200 + k) for k in range(n_frames)])
+        fe = nsc.FlowEstimator(levels=levels, coarse_iterations=coarse, refine_iterations=refine)
+        assert fe.mode == "exact"
+        fe.set_mode("fast")
+        assert fe.mode == "fast"
+        want = [oracle_mod.flow_estimate(frames[k], frames[k + 1], levels, coarse, refine, fe.lambda_) for k in range(n_frames - 1)]
+        d_frames = torch.from_numpy(frames).to(dev)
+        d_flows = torch.full((n_frames - 1, h, w, 2), float("nan"), dtype=torch.float32, device=dev)
+        s = torch.cuda.current_stream().cuda_stream
+        fe.estimate_device_stream(d_frames.data_ptr(), n_frames, w, h, d_flows.data_ptr(), s)
+        torch.cuda.synchronize()
+        got = d_flows.cpu().numpy()
+        assert np.isfinite(got).all()
+        for k in range(n_frames - 1):
+            ok, mx = _flow_close(got[k], want[k])
+            assert ok, (kind, "stream", k, mx)
+        one = torch.full((h, w, 2), float("nan"), dtype=torch.float32, device=dev)
+        fe.estimate_device(d_frames[1].data_ptr(), d_frames[2].data_ptr(), w, h, one.data_ptr(), s)
+        torch.cuda.synchronize()
+        assert np.array_equal(one.cpu().numpy(), got[1]), (kind, "a pair alone = the same pair inside a stream")
+        assert np.array_equal(fe.estimate(frames[0], frames[1], w, h), got[0]), (kind, "host entry point")
+        fe.set_mode("exact")  # and back: bit-exact again
+        assert np.array_equal(fe.estimate(frames[0], frames[1], w, h), want[0])
+    with pytest.raises(ValueError):
+        fe.set_mode("sloppy")
+
+
+@pytest.mark.gpu
+def test_flow_fast_mode_1080p_contract(nsc, oracle_mod):
+    """The contract of nus_flow_set_mode(NUS_FLOW_FAST) at the size it is for: 1080p, 3 levels, 50 + 10 + 10 steps -- flow within
+    1e-3 px of orc_flow_estimate, and the frame interpolated with it within 1 LSB of the frame interpolated with the exact
+    flow, on fewer than 0.1 % of the samples."""
+    import torch
+
+    w, h = 1920, 1080
+    dev = torch.device("cuda:0")
+    a, b = _smooth(w, h, 0.0), _smooth(w, h, 1.75)
+    rng = np.random.default_rng(7)
+    for img in (a, b):  # sensor-like noise on top: the flow is not a clean constant
+        img[..., :3] = np.clip(img[..., :3].astype(np.int16) + rng.integers(-3, 4, size=(h, w, 3)), 0, 255).astype(np.uint8)
+    fe = nsc.FlowEstimator(levels=3, coarse_iterations=50, refine_iterations=10)
+    want = oracle_mod.flow_estimate(a, b, 3, 50, 10, fe.lambda_)
+    fe.set_mode("fast")
+    frames = torch.from_numpy(np.stack([a, b])).to(dev)
+    flow = torch.empty((1, h, w, 2), dtype=torch.float32, device=dev)
+    s = torch.cuda.current_stream().cuda_stream
+    fe.estimate_device_stream(frames.data_ptr(), 2, w, h, flow.data_ptr(), s)
+    torch.cuda.synchronize()
+    got = flow[0].cpu().numpy()
+    ok, mx = _flow_close(got, want)
+    assert ok, mx
+    it = nsc.WgpuFrameInterpolator()
+    out = torch.empty((h, w, 4), dtype=torch.uint8, device=dev)
+    fb = w * h * 4
+    it.interpolate_device(frames.data_ptr(), fb, frames.data_ptr() + fb, fb, flow.data_ptr(), w, h, 0.5, out.data_ptr(), 1, s)
+    torch.cuda.synchronize()
+    ref = oracle_mod.warp_blend(a, b, want, 0.5)
+    d = np.abs(out.cpu().numpy().astype(np.int16) - ref.astype(np.int16))
+    assert d.max() <= 1 and (d > 0).mean() < 1e-3, (int(d.max()), float((d > 0).mean()))

@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Time nus_flow_estimate_device_stream on a device-resident 1080p stream (dev tool): flow_stream_bench.py [frames] [modes: 1 by size, 2 LDS tiles, 3 streamed ...]"""
+"""Time nus_flow_estimate_device_stream on a device-resident 1080p stream (dev tool): flow_stream_bench.py [frames] [modes: 1 by size, 2 LDS tiles, 3 streamed, 9 = FAST arithmetic (nus_flow_set_mode) ...]"""
 import os
 import sys
 
@@ -20,12 +20,14 @@ modes = [int(m) for m in sys.argv[2:]] or [1]
 ref = None
 for rnd in range(3 if len(modes) > 1 else 1):  # interleaved rounds when several kernels are compared
     for mode in modes:
-        fe.set_tiled(mode)
+        fe.set_mode("fast" if mode == 9 else "exact")
+        fe.set_tiled(1 if mode == 9 else mode)
         fe.estimate_device_stream(frames.data_ptr(), n, w, h, flows.data_ptr(), s)
         torch.cuda.synchronize()
         if ref is None:
             ref = flows.clone()
         same = bool(torch.equal(flows, ref))
+        maxdiff = float((flows - ref).abs().max())
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         reps = 3
         e0.record()
@@ -34,4 +36,4 @@ for rnd in range(3 if len(modes) > 1 else 1):  # interleaved rounds when several
         e1.record()
         torch.cuda.synchronize()
         print(f"flow stream 1080p, {n} frames, kernel mode {mode}: {e0.elapsed_time(e1) / reps / (n - 1) * 1e3:.1f} us per pair"
-              f"{'' if same else '  OUTPUT DIFFERS from the first mode'}", flush=True)
+              f"{'' if same else f'  output differs from the first mode: max |d| = {maxdiff:.2e} px'}", flush=True)
