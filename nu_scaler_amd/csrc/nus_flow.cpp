@@ -1,6 +1,8 @@
 // nus_flow.cpp -- see nus_flow.hpp.
 #include "nus_flow.hpp"
 
+#include <cstdlib>
+
 #include <cstring>
 
 #include "nus_host.hpp"
@@ -435,6 +437,11 @@ int HipFlowEstimator::solve_batch(const uint8_t *d_frames, uint32_t pairs, const
         const void *src = l == 0 ? static_cast<const void *>(d_frames) : level_in[(l - 1) & 1];
         const size_t src_stride = l == 0 ? cells[0] * 4 /* bytes */ : cells[l] /* float4 */;
         float *next = l + 1 < nl ? level_in[l & 1] : nullptr;
+        if (fast_ && !getenv("NUS_FLOW_FAST_EXACT_PYRAMID")) { // luminance only (the variable: dev switch, bisecting): one float per pixel between the levels (the buffers are sized for four)
+            NUS_HIP(launch_pyramid_level_fast(src, l == 0, lum + lum_off[l], next, g.w[l], g.h[l], stream, nf, src_stride, cells[l],
+                                              l + 1 < nl ? cells[l + 1] : 0));
+            continue;
+        }
         NUS_HIP(launch_pyramid_level(src, l == 0, lum + lum_off[l], next, g.w[l], g.h[l], stream, nf, src_stride, cells[l],
                                      l + 1 < nl ? cells[l + 1] : 0, jacobi));
     }

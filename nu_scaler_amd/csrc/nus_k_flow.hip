@@ -270,6 +270,155 @@ __global__ __launch_bounds__(256) void k_pyramid_stream(const void *__restrict__
     }
 }
 
+// ---- The pyramid in FAST arithmetic: luminance only (nus_flow_set_mode(NUS_FLOW_FAST)) -----------------------------------
+// Horn-Schunck reads nothing of a level but its luminance (horn_schunck.wgsl:17-20), and blur, box average and luminance are
+// all linear: the luminance of the blurred RGBA level is the blurred luminance up to rounding.  This kernel therefore carries
+// ONE float per pixel through the pyramid instead of four (level 0: RGBA8 in, luminance plane + the next level's quarter-size
+// luminance input out: 18.7 MB per 1080p frame where the exact kernel moves 24.9; a quarter of its arithmetic) with FMAs in
+// the 5-tap sums.  Same walk as k_pyramid_stream, FOUR adjacent columns per lane (one 16-byte load and store per row; the
+// two halo columns per side are the neighbouring lanes' inner two values, 4 DPP moves per row): a wave writes 248 columns.
+// Columns / rows outside the image take the clamped pixel, as the shaders' taps do; waves that touch the left or right image
+// border (wave-uniform test) load and store their four columns one by one, the others vector-wide.
+__device__ __forceinline__ float blur5_fast(float m2, float m1, float c0, float p1, float p2)
+{
+    const float W0 = 1.0f / 16.0f, W1 = 4.0f / 16.0f, W2 = 6.0f / 16.0f;
+    return __builtin_fmaf(p2, W0, __builtin_fmaf(p1, W1, __builtin_fmaf(c0, W2, __builtin_fmaf(m1, W1, m2 * W0))));
+}
+
+#ifndef NUS_PYR_FAST_AHEAD
+#define NUS_PYR_FAST_AHEAD 2
+#endif
+template <bool U8IN>
+__global__ __launch_bounds__(256) void k_pyramid_fast(const void *__restrict__ in_all, size_t in_stride,
+                                                      float *__restrict__ lum_all, size_t lum_stride,
+                                                      float *__restrict__ next_all, size_t next_stride, int w, int h, int strips,
+                                                      int row_blocks, int rows_per_block)
+{
+    constexpr int U = 4 * kWave - 8; // columns a wave writes
+    const int lane = threadIdx.x & (kWave - 1);
+    const int g = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+    if (g >= strips * row_blocks) return;
+    const int rb = g / strips, strip = g - rb * strips;
+    const uint32_t *in8 = U8IN ? reinterpret_cast<const uint32_t *>(static_cast<const uint8_t *>(in_all) + blockIdx.y * in_stride) : nullptr;
+    const float *inf = U8IN ? nullptr : static_cast<const float *>(in_all) + blockIdx.y * in_stride;
+    float *level_lum = lum_all + blockIdx.y * lum_stride;
+    float *next = next_all ? next_all + blockIdx.y * next_stride : nullptr;
+    const int xa = strip * U - 4 + 4 * lane; // this lane's first column (a multiple of 4)
+    const bool writer = lane >= 1 && lane <= kWave - 2;
+    // vector-wide rows need all four columns inside the image (and the wave's other lanes too: wave-uniform choice)
+    const bool plain = __builtin_amdgcn_readfirstlane((int)(strip * U - 4 >= 0 && strip * U - 4 + 4 * kWave <= w)) != 0;
+    int cx[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) cx[i] = clampi(xa + i, 0, w - 1);
+    const int y0 = rb * rows_per_block, y1 = min(y0 + rows_per_block, h); // rows_per_block is even
+    const int ow = (w + 1) / 2;
+    const float kLum8 = 0.33333f / 255.0f; // (r + g + b) / 255 * 0.33333
+
+    struct Raw {
+        uint4 u;
+        float4 f;
+    };
+    // border waves: one vector load at the nearest in-image position (w >= 4), the clamped columns picked out of it afterwards
+    const int xv = w >= 4 ? clampi(xa, 0, w - 4) : 0;
+    auto fetch = [&](int r) -> Raw {
+        Raw v;
+        const size_t row = (size_t)clampi(r, 0, h - 1) * w;
+        if (plain || w >= 4) {
+            const size_t at = row + (plain ? xa : xv);
+            // one 16-byte load of a 4-byte-aligned address (a row starts wherever y * w puts it)
+            typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
+            typedef float f32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
+            if constexpr (U8IN) {
+                const u32x4_a4 q = *reinterpret_cast<const u32x4_a4 *>(in8 + at);
+                v.u = make_uint4(q.x, q.y, q.z, q.w);
+            } else {
+                const f32x4_a4 q = *reinterpret_cast<const f32x4_a4 *>(inf + at);
+                v.f = make_float4(q.x, q.y, q.z, q.w);
+            }
+        } else {
+            if constexpr (U8IN) v.u = make_uint4(in8[row + cx[0]], in8[row + cx[1]], in8[row + cx[2]], in8[row + cx[3]]);
+            else v.f = make_float4(inf[row + cx[0]], inf[row + cx[1]], inf[row + cx[2]], inf[row + cx[3]]);
+        }
+        return v;
+    };
+    auto pick = [](const float (&l)[4], int i) { return i == 0 ? l[0] : (i == 1 ? l[1] : (i == 2 ? l[2] : l[3])); };
+    auto lum8 = [&](uint32_t p) { return ((ch_f32(p, 0) + ch_f32(p, 1)) + ch_f32(p, 2)) * kLum8; };
+    auto convert = [&](const Raw &v, float (&l)[4]) {
+        if constexpr (U8IN) l[0] = lum8(v.u.x), l[1] = lum8(v.u.y), l[2] = lum8(v.u.z), l[3] = lum8(v.u.w);
+        else l[0] = v.f.x, l[1] = v.f.y, l[2] = v.f.z, l[3] = v.f.w;
+    };
+    float hb[5][4];  // H-blurred rows r-4 .. r of the lane's four columns (slots rotate with the row)
+    float keep[4] = {0.0f, 0.0f, 0.0f, 0.0f}; // the blurred even row of a 2x2 block, until its odd row is there
+    constexpr int AH = NUS_PYR_FAST_AHEAD; // rows in flight per lane
+    Raw nx[AH];
+#pragma unroll
+    for (int d = 0; d < AH; ++d) nx[d] = fetch(y0 - 2 + d);
+
+    auto step = [&](int r, auto slot_tag) {
+        constexpr int P = decltype(slot_tag)::value;
+        float l[4];
+        convert(nx[0], l);
+#pragma unroll
+        for (int d = 0; d + 1 < AH; ++d) nx[d] = nx[d + 1];
+        nx[AH - 1] = fetch(r + AH); // in flight during this row and the next AH - 1
+        if (!plain && w >= 4) { // (wave-uniform) the loaded columns are xv .. xv + 3; this lane's are the clamped cx[]
+            const float q[4] = {l[0], l[1], l[2], l[3]};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) l[i] = pick(q, cx[i] - xv);
+        }
+        const float m2 = wave_up(l[2]), m1 = wave_up(l[3]), p1 = wave_down(l[0]), p2 = wave_down(l[1]);
+        hb[P][0] = blur5_fast(m2, m1, l[0], l[1], l[2]);
+        hb[P][1] = blur5_fast(m1, l[0], l[1], l[2], l[3]);
+        hb[P][2] = blur5_fast(l[0], l[1], l[2], l[3], p1);
+        hb[P][3] = blur5_fast(l[1], l[2], l[3], p1, p2);
+        const int y = r - 2;
+        if (y < y0) return; // the window is still filling (wave-uniform)
+        float v[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            v[i] = blur5_fast(hb[(P + 1) % 5][i], hb[(P + 2) % 5][i], hb[(P + 3) % 5][i], hb[(P + 4) % 5][i], hb[P][i]);
+        if (writer) {
+            float *dst = level_lum + (size_t)y * w;
+            if (plain) {
+                dst[xa] = v[0], dst[xa + 1] = v[1], dst[xa + 2] = v[2], dst[xa + 3] = v[3]; // (merged into one 16-byte store where aligned)
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (xa + i >= 0 && xa + i < w) dst[xa + i] = v[i];
+            }
+        }
+        if (next == nullptr) return;
+        const bool even = (y & 1) == 0;
+        if (even) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) keep[i] = v[i]; // the upper row of a 2x2 block waits for the lower one
+        }
+        if (even && y != h - 1) return; // (odd height: the last row pairs with itself)
+        // downsample.wgsl:22-37: the 2x2 mean of the BLURRED level; its far column clamps to the level's last column (a lane's
+        // value for a column outside the image is the blur at a virtual position, not that pixel)
+        const bool d0 = xa + 1 > w - 1, d1 = xa + 3 > w - 1;
+        const float o0 = ((keep[0] + (d0 ? keep[0] : keep[1])) + (v[0] + (d0 ? v[0] : v[1]))) * 0.25f;
+        const float o1 = ((keep[2] + (d1 ? keep[2] : keep[3])) + (v[2] + (d1 ? v[2] : v[3]))) * 0.25f;
+        if (writer && xa >= 0) {
+            float *dst = next + (size_t)(y >> 1) * ow + (xa >> 1);
+            if (xa < w) dst[0] = o0;
+            if (xa + 2 < w) dst[1] = o1;
+        }
+    };
+    const int end = y1 + 1; // last input row taken (clamped into the image by the loads)
+    for (int r = y0 - 2; r <= end; r += 5) {
+        step(r, std::integral_constant<int, 0>{});
+        if (r + 1 > end) break;
+        step(r + 1, std::integral_constant<int, 1>{});
+        if (r + 2 > end) break;
+        step(r + 2, std::integral_constant<int, 2>{});
+        if (r + 3 > end) break;
+        step(r + 3, std::integral_constant<int, 3>{});
+        if (r + 4 > end) break;
+        step(r + 4, std::integral_constant<int, 4>{});
+    }
+}
+
 // Derivatives of one pyramid level, computed once per level instead of once per Jacobi step:
 // (ix, iy, it) with exactly the expressions of horn_schunck.wgsl:58-82, 12 bytes per cell.  The
 // denominator lambda + ix*ix + iy*iy and its reciprocal are recomputed from them when a tile is
@@ -637,20 +786,77 @@ __global__ __launch_bounds__(256) void k_hs_stream_fast(const float *__restrict_
     float2 a1[K], a2[K];   // level j: its rows r-1 and r-2 (this lane's column)
     HsFastCoef cf[K + 1];  // cf[d]: coefficients of row t - d (cf[0] is only the way in)
 
+    // UPS: the level starts from the coarser level's flow, sampled as flow_upsample.wgsl:27-36 samples it (linear, clamp to edge,
+    // texel space) while it is loaded.  The column part of the sample position is this lane's for the whole launch (the shader's own
+    // expressions, once), and so is the horizontal interpolation of a COARSE row: a wave walks down the fine rows, the pair of
+    // coarse rows a fine row lies between advances by one every other row -- so a coarse row is loaded (2 texels per lane) and
+    // interpolated in x once, kept as `hb` (the lower of the pair) / `ha` (the upper), and the next one is requested when the pair
+    // advances, two fine rows before it is needed.  A fine row then costs its row position (an FMA with the ratio of the heights
+    // instead of a division) and one interpolation in y.  Loading 4 texels per fine row instead made the launch that opens a
+    // level 25 % SLOWER than the ones that read a full-resolution flow, although it moves 25 % fewer bytes.
+    const float2 *csrc = UPS ? coarse.flow + blockIdx.y * coarse.stride : nullptr;
+    int cx0 = 0, cx1 = 0, cy = 0; // cy (wave-uniform): the coarse row in hb
+    float cfx = 0.0f, cry = 0.0f;
+    float2 ha = make_float2(0.0f, 0.0f), hb = ha, ra = ha, rb2 = ha; // ra / rb2: texels x0 / x1 of coarse row cy + 1, in flight
+    auto coarse_row_pos = [&](int r, int &y0c, int &y1c) -> float { // fine row r -> its coarse rows and the fraction between them
+        const float sy = __builtin_fmaf((float)min(r, hi - 1) + 0.5f, cry, -0.5f), fy0 = floorf(sy);
+        y0c = __builtin_amdgcn_readfirstlane(clampi((int)fy0, 0, coarse.h - 1));
+        y1c = __builtin_amdgcn_readfirstlane(clampi((int)fy0 + 1, 0, coarse.h - 1));
+        return sy - fy0;
+    };
+    auto lerp_x = [&](const float2 a, const float2 b) {
+        return make_float2(__builtin_fmaf(cfx, b.x - a.x, a.x), __builtin_fmaf(cfx, b.y - a.y, a.y));
+    };
+    auto request_coarse = [&](int yc) {
+        const float2 *row = csrc + (size_t)min(yc, coarse.h - 1) * coarse.w;
+        ra = row[cx0], rb2 = row[cx1];
+    };
+    if constexpr (UPS) {
+        const float u = ((float)xc + 0.5f) / (float)w, sx = u * (float)coarse.w - 0.5f, fx0 = floorf(sx);
+        cfx = sx - fx0;
+        cx0 = clampi((int)fx0, 0, coarse.w - 1), cx1 = clampi((int)fx0 + 1, 0, coarse.w - 1);
+        cry = (float)coarse.h / (float)h;
+        int y0c, y1c;
+        (void)coarse_row_pos(lo, y0c, y1c);
+        cy = y1c;
+        request_coarse(y0c);
+        ha = lerp_x(ra, rb2);
+        request_coarse(y1c);
+        hb = lerp_x(ra, rb2);
+        request_coarse(cy + 1);
+    }
+    // the upsampled flow of fine row r (rows are asked for in increasing order)
+    auto upsampled_row = [&](int r) -> float2 {
+        int y0c, y1c;
+        const float fy = coarse_row_pos(r, y0c, y1c);
+        if (y1c > cy) { // (wave-uniform) the pair advances: the requested row comes in, the one after it is requested
+            ha = hb;
+            hb = lerp_x(ra, rb2);
+            cy = cy + 1;
+            request_coarse(cy + 1);
+        }
+        const float2 top = y0c == cy ? hb : ha; // (the clamped first / last pair: both rows the same)
+        return make_float2(__builtin_fmaf(fy, hb.x - top.x, top.x) * coarse.scale, __builtin_fmaf(fy, hb.y - top.y, top.y) * coarse.scale);
+    };
     auto load_flow = [&](int r) -> float2 {
-        if constexpr (UPS)
-            return flow_upsample_cell(coarse.flow + blockIdx.y * coarse.stride, coarse.w, coarse.h, xc, min(r, hi - 1), w, h, coarse.scale);
-        else
+        if constexpr (UPS) {
+#if defined(NUS_HS_FAST_UPS_EXACT) // dev macro: the shader's own expressions (bisecting)
+            return flow_upsample_cell(csrc, coarse.w, coarse.h, xc, min(r, hi - 1), w, h, coarse.scale);
+#else
+            return upsampled_row(r);
+#endif
+        } else {
             return fin ? fin[(size_t)min(r, hi - 1) * w + xc] : make_float2(0.0f, 0.0f);
+        }
     };
     // rows are requested NUS_HS_FAST_AHEAD passes before they are used: a FAST pass is short (~120 instructions), and with one row
     // in flight per wave the launch was bound by memory latency, not by bandwidth or instruction issue
     constexpr int AH = NUS_HS_FAST_AHEAD;
-    float2 qf[AH];
+    float2 qf[AH]; // (UPS: unused -- the upsampled row comes out of registers when it is due, see upsampled_row)
     float q1[AH], q2[AH]; // q*[d]: row t + d's flow, frame 1's row t + d + 1, frame 2's row t + d (d = 0: this pass's)
 #pragma unroll
     for (int d = 0; d < AH; ++d) {
-        qf[d] = load_flow(lo + d);
+        if constexpr (!UPS) qf[d] = load_flow(lo + d);
         q1[d] = lum1[(size_t)clampi(lo + d + 1, 0, h - 1) * w + xc];
         q2[d] = lum1[lum_stride + (size_t)clampi(lo + d, 0, h - 1) * w + xc];
     }
@@ -659,9 +865,10 @@ __global__ __launch_bounds__(256) void k_hs_stream_fast(const float *__restrict_
 
     auto pass = [&](int t, auto steady_tag) {
         constexpr bool STEADY = decltype(steady_tag)::value;
-        const float2 nf = qf[0];
+        float2 nf, pf = make_float2(0.0f, 0.0f);
+        if constexpr (UPS) nf = load_flow(t);
+        else nf = qf[0], pf = load_flow(t + AH); // in flight during this pass and the next AH - 1
         const float n1 = q1[0], n2 = q2[0];
-        const float2 pf = load_flow(t + AH); // in flight during this pass and the next AH - 1
         const float p1 = lum1[(size_t)clampi(t + AH + 1, 0, h - 1) * w + xc];
         const float p2 = lum1[lum_stride + (size_t)clampi(t + AH, 0, h - 1) * w + xc];
         {
@@ -703,8 +910,12 @@ __global__ __launch_bounds__(256) void k_hs_stream_fast(const float *__restrict_
 #pragma unroll
         for (int d = K; d >= 1; --d) cf[d] = cf[d - 1];
 #pragma unroll
-        for (int d = 0; d + 1 < AH; ++d) qf[d] = qf[d + 1], q1[d] = q1[d + 1], q2[d] = q2[d + 1];
-        qf[AH - 1] = pf, q1[AH - 1] = p1, q2[AH - 1] = p2;
+        for (int d = 0; d + 1 < AH; ++d) {
+            if constexpr (!UPS) qf[d] = qf[d + 1];
+            q1[d] = q1[d + 1], q2[d] = q2[d + 1];
+        }
+        if constexpr (!UPS) qf[AH - 1] = pf;
+        q1[AH - 1] = p1, q2[AH - 1] = p2;
     };
     int t = lo;
     for (; t < min(lo + K, hi + K); ++t) pass(t, std::false_type{}); // fill
@@ -782,6 +993,27 @@ hipError_t launch_horn_schunck(const float *i1, const float *i2, const float *fl
 #ifndef NUS_PYR_STREAM_MIN_ROWS
 #define NUS_PYR_STREAM_MIN_ROWS 32 // shortest row block (4 halo rows are blurred horizontally per block)
 #endif
+
+// FAST pyramid level (k_pyramid_fast): luminance only.  `in`: RGBA8 frames (level 0; in_stride in bytes) or the previous level's
+// quarter-size luminance output (floats; in_stride in floats); `next`: this level's output for the next one (floats), or null.
+hipError_t launch_pyramid_level_fast(const void *in, bool u8_input, float *level_lum, float *next, uint32_t w, uint32_t h,
+                                     hipStream_t stream, uint32_t n, size_t in_stride, size_t lum_stride, size_t next_stride)
+{
+    const uint32_t strips = cdiv(w, 4 * kWave - 8);
+    const uint64_t columns = (uint64_t)strips * n;
+    const uint32_t want = (uint32_t)std::min<uint64_t>((NUS_PYR_STREAM_WAVES + columns - 1) / columns,
+                                                       std::max<uint32_t>(h / NUS_PYR_STREAM_MIN_ROWS, 1));
+    const uint32_t rows_per_block = (cdiv(h, want) + 1) & ~1u; // even: a 2x2 block never straddles two row blocks
+    const uint32_t row_blocks = cdiv(h, rows_per_block);
+    const dim3 block(256), grid(cdiv(strips * row_blocks, 4), n);
+    if (u8_input)
+        hipLaunchKernelGGL(k_pyramid_fast<true>, grid, block, 0, stream, in, in_stride, level_lum, lum_stride, next, next_stride, (int)w,
+                           (int)h, (int)strips, (int)row_blocks, (int)rows_per_block);
+    else
+        hipLaunchKernelGGL(k_pyramid_fast<false>, grid, block, 0, stream, in, in_stride, level_lum, lum_stride, next, next_stride, (int)w,
+                           (int)h, (int)strips, (int)row_blocks, (int)rows_per_block);
+    return hipGetLastError();
+}
 
 hipError_t launch_pyramid_level(const void *in, bool u8_input, float *level_lum, float *next, uint32_t w, uint32_t h,
                                 hipStream_t stream, uint32_t n, size_t in_stride, size_t lum_stride, size_t next_stride, int kernel)

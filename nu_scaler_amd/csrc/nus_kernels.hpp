@@ -195,6 +195,8 @@ hipError_t launch_pyramid_level(const void *in, bool u8_input, float *level_lum,
                                 size_t next_stride = 0, int kernel = 0);
 // Fast path of the same iteration: derivatives once per level, then K steps per launch in LDS.
 // i1 / i2: f32 RGBA level images, or their luminance planes (luminance_planes).
+hipError_t launch_pyramid_level_fast(const void *in, bool u8_input, float *level_lum, float *next, uint32_t w, uint32_t h,
+                                     hipStream_t stream, uint32_t n, size_t in_stride, size_t lum_stride, size_t next_stride);
 hipError_t launch_hs_prepare(const float *i1, const float *i2, bool luminance_planes, float *coef, uint32_t w, uint32_t h,
                              hipStream_t stream, uint32_t n = 1, size_t img_stride = 0, size_t coef_stride = 0);
 // launch_hs_prepare on luminance planes + launch_flow_upsample of the coarser level's flow, one launch.
