@@ -565,6 +565,11 @@ uint32_t HipUpscaler::lanczos_x2_rows_per_wave(uint32_t n_frames, bool unit) con
     const uint64_t nstrips = (iw_ + kLanczosX2StripCols - 1) / kLanczosX2StripCols;
     const uint64_t rows_total = (uint64_t)ih_ * nstrips * n_frames * (unit ? 2 : 1);
     const uint64_t t = rows_total / 8192;
+    // The one-launch step of a big batch walks 108 rows per wave (10 row blocks per 1080p frame: 6 halo rows per 108 instead of
+    // per 36) as long as that leaves a dozen rounds of resident waves: +1.2 % on the 300-unit step
+    // (profiles/r04_unit_step_rows_per_wave.txt); the plain kernel gains nothing beyond 36.
+    const uint64_t big = unit ? rows_total / (3072 * 12) : 0;
+    if (big > 36) return (uint32_t)(big > 108 ? 108 : big);
     return (uint32_t)(t < 8 ? 8 : (t > 36 ? 36 : t));
 }
 

@@ -6,8 +6,9 @@ this pool a 1080p frame goes up at 26 GB/s from the far socket and at 53.7 GB/s 
 (profiles/r03_numa_pinned_copy_probe.txt), and eight unbound ranks would each measure their placement luck.
 
 `bind_rank` must run BEFORE the process makes its first HIP call (threads the runtime starts and pages the process touches
-afterwards inherit the mask): the GPU's PCI address is therefore asked of a short-lived CHILD process (it initialises HIP, this
-process does not), the node and its CPUs come from sysfs, and the mask is set with os.sched_setaffinity -- never a re-exec.
+afterwards inherit the mask): the GPU's PCI address therefore comes from the KFD topology in sysfs, read the way ROCr reads it
+(`enumerate_gpus_sysfs`; only if that fails from a short-lived CHILD process that initialises HIP in this one's stead), the node
+and its CPUs from the PCI device's sysfs entry, and the mask is set with os.sched_setaffinity -- never a re-exec.
 Everything degrades to "not bound" with the reason recorded: a bench line must say what happened on every rank, not guess.
 
 The reference has no counterpart (one GPU, one process: nu_scaler_core/src/gpu/detector.rs:136-165 picks the adapter)."""
@@ -94,6 +95,60 @@ def usable_cpus() -> int:
     n = len(os.sched_getaffinity(0))
     q = cgroup_cpu_quota()
     return n if q is None else max(1, min(n, int(q + 0.5)))
+
+
+def _index_list(text: Optional[str]) -> Optional[List[int]]:
+    """'0,2,3' -> [0, 2, 3]; None if unset; raises ValueError on anything else (UUIDs: the caller asks HIP instead)."""
+    if text is None or text.strip() == "":
+        return None
+    return [int(p) for p in text.split(",") if p.strip() != ""]
+
+
+def enumerate_gpus_sysfs(sysfs: str = "/sys", dev: str = "/dev", environ=None) -> Dict:
+    """PCI addresses of the HIP devices in HIP's order WITHOUT touching HIP or starting a process: the KFD topology
+    (/sys/class/kfd/kfd/topology/nodes/N/properties: GPU nodes have simd_count > 0, in the order ROCr enumerates them; domain
+    and location_id give the PCI address), filtered as ROCr filters it (a node whose /dev/dri/renderD<minor> this process may
+    not open does not exist for it: how a job sees one GPU of eight), then ROCR_VISIBLE_DEVICES and HIP_VISIBLE_DEVICES as index
+    lists.  {"bdf": [...]} or {"bdf": [], "error": why} -- then the caller may fall back to query_gpu_pci()."""
+    env = os.environ if environ is None else environ
+    base = os.path.join(sysfs, "class", "kfd", "kfd", "topology", "nodes")
+    try:
+        nodes = sorted((int(n) for n in os.listdir(base) if n.isdigit()))
+    except OSError as e:
+        return {"bdf": [], "error": f"KFD topology unreadable: {e}"}
+    gpus: List[str] = []
+    for n in nodes:
+        props: Dict[str, int] = {}
+        try:
+            with open(os.path.join(base, str(n), "properties")) as f:
+                for line in f:
+                    parts = line.split()
+                    if len(parts) == 2 and parts[1].lstrip("-").isdigit():
+                        props[parts[0]] = int(parts[1])
+        except PermissionError:
+            continue  # the device cgroup hides the properties of a GPU that is not this job's (seen on the 1-GPU boxes: EPERM)
+        except OSError as e:
+            return {"bdf": [], "error": f"KFD node {n}: {e}"}
+        if props.get("simd_count", 0) <= 0:
+            continue  # a CPU node
+        minor = props.get("drm_render_minor", -1)
+        if minor >= 0 and not os.access(os.path.join(dev, "dri", f"renderD{minor}"), os.R_OK | os.W_OK):
+            continue  # not this job's GPU
+        loc = props.get("location_id", 0)
+        gpus.append(f"{props.get('domain', 0):04x}:{(loc >> 8) & 0xff:02x}:{(loc >> 3) & 0x1f:02x}.{loc & 7}")
+    if not gpus:
+        return {"bdf": [], "error": "no accessible GPU node in the KFD topology"}
+    try:
+        for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES"):  # HIP's list indexes what ROCr's list left
+            idx = _index_list(env.get(var))
+            if idx is not None:
+                gpus = [gpus[i] for i in idx if 0 <= i < len(gpus)]
+        if env.get("CUDA_VISIBLE_DEVICES") and not env.get("HIP_VISIBLE_DEVICES"):
+            idx = _index_list(env.get("CUDA_VISIBLE_DEVICES"))
+            gpus = [gpus[i] for i in idx if 0 <= i < len(gpus)]
+    except ValueError:
+        return {"bdf": [], "error": "a *_VISIBLE_DEVICES variable is not an index list"}
+    return {"bdf": gpus, "how": "sysfs (KFD topology)"}
 
 
 def query_gpu_pci(timeout: float = 60.0) -> Dict:
@@ -201,7 +256,12 @@ def bind_rank(device_index: int, local_world: int, sysfs: str = "/sys", apply: b
     the affinity mask, NUS_COPY_THREADS (read once by the library's copy pool when it starts) and OMP_NUM_THREADS.  Returns the
     report that goes into the bench line.  Call before the first HIP call of the process.  `slot`: the rank's position among
     the node's ranks when several ranks share ONE device (a rehearsal on a 1-GPU box); default: rank r uses device r."""
-    q = query_gpu_pci()
+    # sysfs first: no process is started and nothing initialises HIP (eight ranks asking eight short-lived children to open
+    # every GPU of the node is sixteen processes on the GPUs for a moment); the child only where the topology cannot be read
+    q = enumerate_gpus_sysfs(sysfs)
+    if not q.get("bdf"):
+        q2 = query_gpu_pci()
+        q = q2 if q2.get("bdf") else {"bdf": [], "error": f"{q.get('error')}; {q2.get('error')}"}
     devices = [pci_numa(b, sysfs) if b else {"bdf": None, "numa_node": None, "local_cpus": []} for b in q.get("bdf", [])]
     mask = sorted(os.sched_getaffinity(0))
     quota = cgroup_cpu_quota()

@@ -31,8 +31,19 @@ def build(force: bool = False) -> str:
     stale = (not os.path.exists(_LIB_PATH)
              or os.path.getmtime(_LIB_PATH) < max(os.path.getmtime(src), os.path.getmtime(hdr)))
     if force or stale:
-        subprocess.run(["make", "-C", _HERE, "-B" if force else "-s", "liboracle.so"],
-                       check=True, capture_output=True)
+        # several ranks of one job may get here together (bench.py checks every rank's outputs): one builds, the others wait
+        import fcntl
+
+        with open(os.path.join(_HERE, ".build.lock"), "w") as lock:
+            fcntl.flock(lock, fcntl.LOCK_EX)
+            try:
+                still = (force or not os.path.exists(_LIB_PATH)
+                         or os.path.getmtime(_LIB_PATH) < max(os.path.getmtime(src), os.path.getmtime(hdr)))
+                if still:
+                    subprocess.run(["make", "-C", _HERE, "-B" if force else "-s", "liboracle.so"],
+                                   check=True, capture_output=True)
+            finally:
+                fcntl.flock(lock, fcntl.LOCK_UN)
     return _LIB_PATH
 
 

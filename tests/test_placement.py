@@ -97,3 +97,28 @@ def test_bind_rank_without_a_gpu_reports_and_changes_nothing(nsc, monkeypatch):
     assert rep["cpus_per_rank"] == max(1, min(len(before) // 2, int((p.cgroup_cpu_quota() or 1e9) / 2 + 0.5)))
     assert os.environ["NUS_COPY_THREADS"] == str(rep["copy_threads"])
     assert os.environ["OMP_NUM_THREADS"] == str(rep["omp_threads"])
+
+
+def test_enumerate_gpus_from_the_kfd_topology(nsc, tmp_path):
+    """HIP's device order without HIP: GPU nodes of the KFD topology whose render node the process may open, then the
+    *_VISIBLE_DEVICES index lists (ROCr's first, HIP's on what is left)."""
+    from nu_scaler_amd import placement as p
+
+    sysfs, dev = tmp_path / "sys", tmp_path / "dev"
+    nodes = sysfs / "class" / "kfd" / "kfd" / "topology" / "nodes"
+    (dev / "dri").mkdir(parents=True)
+    # two CPU nodes, then four GPUs; the job may open the render nodes of GPUs 1, 2 and 3 only
+    specs = [(0, 0, -1, 0), (0, 0, -1, 0), (1216, 0x0500, 128, 0), (1216, 0xa400, 129, 0), (1216, 0xd900, 130, 0), (1216, 0x1508, 131, 1)]
+    for n, (simd, loc, minor, domain) in enumerate(specs):
+        d = nodes / str(n)
+        d.mkdir(parents=True)
+        (d / "properties").write_text(f"cpu_cores_count 0\nsimd_count {simd}\nlocation_id {loc}\ndomain {domain}\n"
+                                      f"drm_render_minor {minor}\nname_is_text x\n")
+        if minor in (129, 130, 131):
+            (dev / "dri" / f"renderD{minor}").write_text("")
+    got = p.enumerate_gpus_sysfs(str(sysfs), str(dev), environ={})
+    assert got["bdf"] == ["0000:a4:00.0", "0000:d9:00.0", "0001:15:01.0"]
+    assert p.enumerate_gpus_sysfs(str(sysfs), str(dev), environ={"ROCR_VISIBLE_DEVICES": "2,0"})["bdf"] == ["0001:15:01.0", "0000:a4:00.0"]
+    assert p.enumerate_gpus_sysfs(str(sysfs), str(dev), environ={"ROCR_VISIBLE_DEVICES": "2,0", "HIP_VISIBLE_DEVICES": "1"})["bdf"] == ["0000:a4:00.0"]
+    assert "index list" in p.enumerate_gpus_sysfs(str(sysfs), str(dev), environ={"HIP_VISIBLE_DEVICES": "GPU-abc"})["error"]
+    assert p.enumerate_gpus_sysfs(str(tmp_path / "nothing"), str(dev), environ={})["bdf"] == []

@@ -117,9 +117,11 @@ def test_unit_step_bgra_input_and_other_filters(nsc, oracle_mod):
         assert torch.equal(mid, want_mid) and torch.equal(up_real, want_real) and torch.equal(up_mid, want_up_mid), alg
 
 
-def test_unit_step_1080p_bench_shape(nsc, oracle_mod):
-    """The launch shape bench.py times (1080p -> 4K, 36 rows per wave, a sliding stream) on the opaque gradient and on
-    noise: all three outputs against the oracle (Lanczos FMA mode: <= 1 LSB, < 0.1 % of the samples different)."""
+@pytest.mark.parametrize("rows_per_wave", [108, 36])
+def test_unit_step_1080p_bench_shape(nsc, oracle_mod, rows_per_wave):
+    """The launch shape bench.py times (1080p -> 4K, 108 rows per wave for its 300-unit batches, 36 for smaller ones, a sliding
+    stream) on the opaque gradient and on noise: all three outputs against the oracle (Lanczos FMA mode: <= 1 LSB, < 0.1 % of the
+    samples different)."""
     import torch
 
     w, h, n = 1920, 1080, 6
@@ -129,7 +131,7 @@ def test_unit_step_1080p_bench_shape(nsc, oracle_mod):
         frames_np = np.stack([gen(k) for k in range(n + 1)])
         frames = torch.from_numpy(frames_np).to(dev)
         pipe = nsc.FramePipeline(w, h, 2, "lanczos3", 0.5)
-        pipe.upscaler.set_option("rows_per_wave", 36)
+        pipe.upscaler.set_option("rows_per_wave", rows_per_wave)
         mid, up_real, up_mid = pipe.alloc(n, dev)
         for tns in (mid, up_real, up_mid):
             tns.zero_()

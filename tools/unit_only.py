@@ -16,7 +16,7 @@ dev = torch.device("cuda:0")
 w, h = 1920, 1080
 frames = (syn.noise_stream_torch if pattern == "noise" else syn.gradient_stream_torch)(n + 1, w, h, dev)
 pipe = nsc.FramePipeline(w, h, 2, "lanczos3", 0.5)
-pipe.upscaler.set_option("rows_per_wave", 36)  # what the bench's 300-unit batches select
+pipe.upscaler.set_option("rows_per_wave", 108)  # what the bench's 300-unit batches select (HipUpscaler::lanczos_x2_rows_per_wave)
 mid, up_real, up_mid = pipe.alloc(n, dev)
 for _ in range(reps):
     pipe.step_unit(frames, mid, up_real, up_mid, 0)
