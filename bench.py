@@ -1154,9 +1154,10 @@ def worker(args):
                     "cpus_per_rank": [int(r["cpus_per_rank"]) for r in rows],
                     "n_cpus_in_mask_by_rank": [None if r["n_cpus_in_mask"] is None else int(r["n_cpus_in_mask"]) for r in rows],
                     "copy_threads_by_rank": [None if r["copy_threads"] is None else int(r["copy_threads"]) for r in rows],
-                    "how": "nu_scaler_amd/placement.py: PCI address of the rank's HIP device from a child process, NUMA node and "
-                           "local CPUs from sysfs, os.sched_setaffinity to a disjoint run of whole cores before the first HIP "
-                           "call; copy pool / OpenMP sized to the rank's share of the CPUs the job may keep busy"},
+                    "how": "nu_scaler_amd/placement.py: PCI address of the rank's HIP device from the KFD topology in sysfs (a "
+                           "HIP-query child process only if that cannot be read), NUMA node and local CPUs from the PCI device's "
+                           "sysfs entry, os.sched_setaffinity to a disjoint run of whole cores before the first HIP call; copy "
+                           "pool / OpenMP sized to the rank's share of the CPUs the job may keep busy"},
                 "per_rank": {
                     "bracket_ms": spread(rows, "bracket_ms"), "sustained_ms_per_step": spread(rows, "sustained_ms_per_step"),
                     "sustained_bracket_ms": spread(rows, "sustained_bracket_ms"),

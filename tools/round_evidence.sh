@@ -6,7 +6,9 @@ root=${GRAFT_REPO_ROOT:-/root/repo}
 out=$root/gpurun_out/evidence
 rm -rf $out && mkdir -p $out
 cd $root
-python3 bench.py > $out/bench_n1.log 2>&1 && tail -1 $out/bench_n1.log > $out/bench_n1.json
+python3 bench.py --gpus 1 --steps 20 --warmup 5 > $out/bench_driver_command.log 2>&1 && grep "^{" $out/bench_driver_command.log | tail -1 > $out/bench_driver_command_steps20.json
+echo "driver command done: $(cut -c1-200 $out/bench_driver_command_steps20.json)"
+python3 bench.py > $out/bench_n1.log 2>&1 && grep "^{" $out/bench_n1.log | tail -1 > $out/bench_n1.json
 echo "bench done: $(cut -c1-160 $out/bench_n1.json)"
 (cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $out/bench_prof -o b -- python3 $root/bench.py --no-pmc --no-cpu-baseline --no-extras --no-check --sustained-seconds 0 --steps 450 --warmup 30 > $out/bench_prof.log 2>&1)
 grep "^{" $out/bench_prof.log | tail -1 > $out/bench_under_rocprof.json
@@ -27,9 +29,25 @@ echo "sweep done"
 bash tools/flow_prof.sh > $out/flow_kernels.txt 2>&1
 cp $(find $root/gpurun_out/flowprof -name "*kernel_stats.csv" | head -1) $out/flow_front_end_kernel_stats.csv 2>/dev/null
 python3 tools/flow_bench.py 2>&1 | grep "flow estimate" >> $out/flow_kernels.txt
-bash tools/flow_stream_prof.sh 65 > $out/flow_stream_kernels.txt 2>&1
+bash tools/flow_stream_prof.sh 101 3 > $out/flow_stream_kernels.txt 2>&1
+bash tools/flow_stream_prof.sh 101 9 > $out/flow_stream_kernels_fast_mode.txt 2>&1
+python3 tools/flow_stream_bench.py 101 3 9 2>&1 | grep "flow stream" > $out/flow_stream_exact_vs_fast.txt
 echo "flow done"
-python3 bench.py --gpus 2 --backend gloo --force-device 0 --steps 30 --warmup 3 --units 100 --sustained-seconds 0 > $out/bench_n2_gloo.log 2>&1; grep "^{" $out/bench_n2_gloo.log | tail -1 > $out/bench_rehearsal_n2_gloo_one_gpu.json
+python3 tools/edge_stream_ab.py 2>&1 | grep -v amdgpu > $out/edge_stream_ab.txt
+(cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --output-format csv -d $out/edge_prof -o e -- python3 $root/tools/unit_only.py 300 3 > $out/edge_prof.log 2>&1)
+python3 - "$(find $out/edge_prof -name "*kernel_trace.csv" | head -1)" > $out/unit_step_kernel_timeline.txt <<'PY'
+import csv, sys
+rows = [r for r in csv.DictReader(open(sys.argv[1])) if "k_lanczos3_x2" in r["Kernel_Name"]]
+t0 = min(int(r["Start_Timestamp"]) for r in rows)
+print("# rocprofv3 --kernel-trace of tools/unit_only.py 300 3: the one-launch step's three kernels, start / end in us from the first start")
+print("# (the edge-column passes run on the upscaler's second stream BESIDE the unit kernel: their durations overlap it and must not be added to it)")
+for r in sorted(rows, key=lambda r: int(r["Start_Timestamp"])):
+    s_, e_ = (int(r["Start_Timestamp"]) - t0) / 1e3, (int(r["End_Timestamp"]) - t0) / 1e3
+    name = "edges" if "_edges" in r["Kernel_Name"] else "unit "
+    print(f"{name}  queue {r.get('Queue_Id', '?'):>3s}  start {s_:10.1f}  end {e_:10.1f}  duration {e_ - s_:8.1f} us")
+PY
+rm -rf $out/edge_prof
+python3 bench.py --gpus 2 --backend gloo --force-device 0 --steps 30 --warmup 3 --units 100 --sustained-seconds 2 > $out/bench_n2_gloo.log 2>&1; grep "^{" $out/bench_n2_gloo.log | tail -1 > $out/bench_rehearsal_n2_gloo_one_gpu.json
 echo "rehearsal done: $(cut -c1-120 $out/bench_rehearsal_n2_gloo_one_gpu.json)"
-rm -rf $out/bench_prof $out/bench3_prof
+rm -rf $out/bench_prof $out/bench3_prof $root/gpurun_out/flowsprof $root/gpurun_out/flowprof
 ls -la $out
