@@ -339,7 +339,11 @@ int HipFlowEstimator::estimate_device(const void *d_a, const void *d_b, uint32_t
     Pyramid g;
     int rc = plan(w, h, levels, g);
     if (rc != kOk) return rc;
-    if (fast_) { // the FAST Jacobi kernel lives in the batch solver: the pair as a stream of two frames
+    // FAST arithmetic lives in the batch solver's register-pipelined kernels, which need a batch (or a frame) big enough to fill
+    // the GPU; a single 1080p pair is 576 waves -- the LDS-tile kernels of the exact path are 2.7x faster there (220 against
+    // 605 us), and their result satisfies FAST's contract trivially.  So a pair alone takes the FAST kernels only where the
+    // finest level would stream anyway, or where the streamed kernel is forced (set_tiled(3)).
+    if (fast_ && (jacobi_ == kJacobiStream || (jacobi_ == kJacobiAuto && hs_iterate_streams(g.w[0], g.h[0], 1, kJacobiAuto)))) {
         const size_t fb = (size_t)w * h * 4;
         if ((rc = reserve(2 * fb, 8)) != kOk) return rc;
         uint8_t *two = static_cast<uint8_t *>(slot_[8]);
@@ -389,7 +393,7 @@ int HipFlowEstimator::estimate_device_stream(const void *d_frames, uint32_t n_fr
     uint32_t chunk = chunk_for(31);
     if (chunk > n_pairs) chunk = n_pairs;
     for (uint32_t l = 0; l < g.levels; ++l)
-        if (!hs_iterate_streams(g.w[l], g.h[l], chunk, fast_ ? kJacobiStreamFast : jacobi_)) {
+        if (!hs_iterate_streams(g.w[l], g.h[l], chunk, fast_ && jacobi_ == kJacobiStream ? kJacobiStreamFast : jacobi_)) {
             chunk = chunk_for(43);
             break;
         }
@@ -409,7 +413,18 @@ int HipFlowEstimator::solve_batch(const uint8_t *d_frames, uint32_t pairs, const
                                   uint32_t refine_iters, float lambda, uint8_t *d_flows, hipStream_t stream)
 {
     int rc;
-    const int jacobi = fast_ ? kJacobiStreamFast : jacobi_; // FAST: k_hs_stream_fast on every level, derivatives from the planes
+    // The Jacobi kernel of a level.  FAST: k_hs_stream_fast where the level's batch would stream anyway (or the streamed kernel
+    // is forced), the exact LDS-tile kernel -- on the FAST pyramid's planes -- where it would not (a small batch's coarse levels).
+    auto level_kernel = [&](uint32_t l) -> int {
+        if (!fast_ || jacobi_ == kJacobiTiles) return jacobi_;
+        if (jacobi_ == kJacobiStream) return kJacobiStreamFast;
+        return hs_iterate_streams(g.w[l], g.h[l], pairs, kJacobiAuto) ? kJacobiStreamFast : kJacobiTiles;
+    };
+    // The luminance-only pyramid streams rows per wave as well: where level 0 of the batch is too small for that, the exact
+    // LDS-tile pyramid runs instead (its planes serve either Jacobi kernel).
+    const bool fast_pyramid = fast_ && !getenv("NUS_FLOW_FAST_EXACT_PYRAMID") &&
+                              (jacobi_ == kJacobiStream || level_kernel(0) == kJacobiStreamFast);
+    const int jacobi = fast_ ? (fast_pyramid ? kJacobiStream : kJacobiTiles) : jacobi_; // (for the exact pyramid launcher's choice)
     const uint32_t nf = pairs + 1, nl = g.levels, L = nl - 1;
     size_t cells[12], lum_off[12], lum_total = 0;
     for (uint32_t l = 0; l < nl; ++l) {
@@ -424,7 +439,7 @@ int HipFlowEstimator::solve_batch(const uint8_t *d_frames, uint32_t pairs, const
         return rc;
     // A level whose Jacobi steps run in the streamed kernel needs no coefficient planes: that kernel takes the
     // derivatives from the luminance planes of the pair's two frames (consecutive planes of the level) as it goes.
-    auto from_planes = [&](uint32_t l) { return hs_iterate_streams(g.w[l], g.h[l], pairs, jacobi); };
+    auto from_planes = [&](uint32_t l) { return hs_iterate_streams(g.w[l], g.h[l], pairs, level_kernel(l)); };
     size_t coef_cells = 0;
     for (uint32_t l = 0; l < nl; ++l)
         if (!from_planes(l) && cells[l] > coef_cells) coef_cells = cells[l];
@@ -437,7 +452,7 @@ int HipFlowEstimator::solve_batch(const uint8_t *d_frames, uint32_t pairs, const
         const void *src = l == 0 ? static_cast<const void *>(d_frames) : level_in[(l - 1) & 1];
         const size_t src_stride = l == 0 ? cells[0] * 4 /* bytes */ : cells[l] /* float4 */;
         float *next = l + 1 < nl ? level_in[l & 1] : nullptr;
-        if (fast_ && !getenv("NUS_FLOW_FAST_EXACT_PYRAMID")) { // luminance only (the variable: dev switch, bisecting): one float per pixel between the levels (the buffers are sized for four)
+        if (fast_pyramid) { // luminance only (NUS_FLOW_FAST_EXACT_PYRAMID: dev switch, bisecting): one float per pixel between the levels (the buffers are sized for four)
             NUS_HIP(launch_pyramid_level_fast(src, l == 0, lum + lum_off[l], next, g.w[l], g.h[l], stream, nf, src_stride, cells[l],
                                               l + 1 < nl ? cells[l + 1] : 0));
             continue;
@@ -449,7 +464,7 @@ int HipFlowEstimator::solve_batch(const uint8_t *d_frames, uint32_t pairs, const
     // `coarse`: the level continues the flow of level l + 1 in f0, which the first launch upsamples as it loads it
     auto iterate = [&](uint32_t l, uint32_t iters, bool zero, bool coarse) -> int {
         NUS_HIP(launch_hs_iterate(coef, lambda, &f0, &f1, g.w[l], g.h[l], iters, zero, l == 0 ? out : nullptr, stream, pairs,
-                                  cells[l] * 3, cells[l], cells[0], jacobi, from_planes(l) ? lum + lum_off[l] : nullptr, cells[l],
+                                  cells[l] * 3, cells[l], cells[0], level_kernel(l), from_planes(l) ? lum + lum_off[l] : nullptr, cells[l],
                                   coarse ? f0 : nullptr, coarse ? g.w[l + 1] : 0, coarse ? g.h[l + 1] : 0, 2.0f,
                                   coarse ? cells[l + 1] : 0));
         return kOk;

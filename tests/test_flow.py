@@ -279,19 +279,27 @@ def test_flow_fast_mode_within_a_thousandth_of_a_pixel(nsc, oracle_mod, w, h, le
         d_frames = torch.from_numpy(frames).to(dev)
         d_flows = torch.full((n_frames - 1, h, w, 2), float("nan"), dtype=torch.float32, device=dev)
         s = torch.cuda.current_stream().cuda_stream
-        fe.estimate_device_stream(d_frames.data_ptr(), n_frames, w, h, d_flows.data_ptr(), s)
-        torch.cuda.synchronize()
-        got = d_flows.cpu().numpy()
-        assert np.isfinite(got).all()
-        for k in range(n_frames - 1):
-            ok, mx = _flow_close(got[k], want[k])
-            assert ok, (kind, "stream", k, mx)
-        one = torch.full((h, w, 2), float("nan"), dtype=torch.float32, device=dev)
-        fe.estimate_device(d_frames[1].data_ptr(), d_frames[2].data_ptr(), w, h, one.data_ptr(), s)
-        torch.cuda.synchronize()
-        assert np.array_equal(one.cpu().numpy(), got[1]), (kind, "a pair alone = the same pair inside a stream")
-        assert np.array_equal(fe.estimate(frames[0], frames[1], w, h), got[0]), (kind, "host entry point")
+        # kernels by size (1): a batch this small takes the exact LDS-tile kernels, whose result meets the contract trivially;
+        # streamed kernel forced (3): the FAST kernels themselves -- k_pyramid_fast, k_hs_stream_fast -- at these ragged sizes
+        for tiled in (3, 1):
+            fe.set_tiled(tiled)
+            d_flows.fill_(float("nan"))
+            fe.estimate_device_stream(d_frames.data_ptr(), n_frames, w, h, d_flows.data_ptr(), s)
+            torch.cuda.synchronize()
+            got = d_flows.cpu().numpy()
+            assert np.isfinite(got).all()
+            for k in range(n_frames - 1):
+                ok, mx = _flow_close(got[k], want[k])
+                assert ok, (kind, "stream", tiled, k, mx)
+            if tiled == 3:
+                assert any(not np.array_equal(got[k], want[k]) for k in range(n_frames - 1)), "the FAST kernels did not run"
+            one = torch.full((h, w, 2), float("nan"), dtype=torch.float32, device=dev)
+            fe.estimate_device(d_frames[1].data_ptr(), d_frames[2].data_ptr(), w, h, one.data_ptr(), s)
+            torch.cuda.synchronize()
+            assert np.array_equal(one.cpu().numpy(), got[1]), (kind, tiled, "a pair alone = the same pair inside a stream")
+            assert np.array_equal(fe.estimate(frames[0], frames[1], w, h), got[0]), (kind, tiled, "host entry point")
         fe.set_mode("exact")  # and back: bit-exact again
+        fe.set_tiled(1)
         assert np.array_equal(fe.estimate(frames[0], frames[1], w, h), want[0])
     with pytest.raises(ValueError):
         fe.set_mode("sloppy")

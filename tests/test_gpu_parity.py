@@ -1465,3 +1465,42 @@ def test_8k_output_frames(nsc, oracle_mod):
     flat = np.full((h, w, 4), 93, np.uint8)
     got, _ = _up(nsc, "lanczos3", flat, 2 * w, 2 * h)
     assert (got == 93).all()
+
+
+@pytest.mark.gpu
+def test_lanczos_x2_edge_pass_beside_the_main_kernel(nsc, oracle_mod):
+    """Batches of >= 8 frames fork the edge-column pass onto the upscaler's second stream (option edge_stream, default 1); the
+    main kernel leaves the 8 edge columns per side alone.  Same bytes as with the pass on the caller's stream, every frame's
+    edge AND interior columns against the oracle (EXACT mode: 0 differences), plain launch and one-launch step, ragged width."""
+    import torch
+
+    w, h, n = 484, 40, 9
+    dev = torch.device("cuda:0")
+    frames_np = np.stack([oracle_mod.gen_noise(w, h, 800 + k) for k in range(n + 1)])
+    frames = torch.from_numpy(frames_np).to(dev)
+    s = torch.cuda.current_stream().cuda_stream
+    fb = w * h * 4
+    outs = {}
+    for beside in (1, 0):
+        u = nsc.PyWgpuUpscaler("quality", "lanczos3", lanczos_mode="exact")
+        u.set_option("edge_stream", beside)
+        u.initialize(w, h, 2 * w, 2 * h)
+        plain = torch.zeros((n, 2 * h, 2 * w, 4), dtype=torch.uint8, device=dev)
+        u.upscale_device(frames.data_ptr(), plain.data_ptr(), n, s)
+        mid = torch.zeros((n, h, w, 4), dtype=torch.uint8, device=dev)
+        up_real, up_mid = torch.zeros_like(plain), torch.zeros_like(plain)
+        u.upscale_unit_device(frames.data_ptr(), fb, frames.data_ptr() + fb, fb, 0.5, mid.data_ptr(), up_real.data_ptr(), up_mid.data_ptr(), n, s)
+        torch.cuda.synchronize()
+        outs[beside] = (plain, up_real, up_mid, mid)
+    for a, b in zip(outs[0], outs[1]):
+        assert torch.equal(a, b)
+    plain, up_real, up_mid, mid = outs[1]
+    assert torch.equal(plain, up_real)
+    for k in (0, n - 1):
+        want = oracle_mod.lanczos3(frames_np[k], 2 * w, 2 * h)
+        got = plain[k].cpu().numpy()
+        assert np.array_equal(got[:, :8], want[:, :8]) and np.array_equal(got[:, -8:], want[:, -8:]), "edge columns"
+        assert np.array_equal(got, want)
+        m = oracle_mod.warp_blend(frames_np[k], frames_np[k + 1], None, 0.5)
+        assert np.array_equal(mid[k].cpu().numpy(), m)
+        assert np.array_equal(up_mid[k].cpu().numpy(), oracle_mod.lanczos3(m, 2 * w, 2 * h))

@@ -17,9 +17,10 @@ flow = torch.empty((h, w, 2), dtype=torch.float32, device=dev)
 fe = nsc.FlowEstimator(levels=levels, coarse_iterations=ci, refine_iterations=ri)
 s = torch.cuda.current_stream().cuda_stream
 a, b = frames[0].data_ptr(), frames[1].data_ptr()
-modes = [int(m) for m in sys.argv[4:]] or [1]  # nus_flow_set_tiled: 1 kernels by size, 2 LDS tiles, 3 streamed
+modes = [int(m) for m in sys.argv[4:]] or [1]  # nus_flow_set_tiled: 1 kernels by size, 2 LDS tiles, 3 streamed; 9 = FAST arithmetic
 for mode in modes:
-    fe.set_tiled(mode)
+    fe.set_mode("fast" if mode == 9 else "exact")
+    fe.set_tiled(1 if mode == 9 else mode)
     for _ in range(2):
         fe.estimate_device(a, b, w, h, flow.data_ptr(), s)
     torch.cuda.synchronize()
