@@ -411,6 +411,28 @@ def test_copy_pool_stress(tmp_path):
             assert f"workers {threads} " in run.stdout
 
 
+def test_copy_pool_stress_under_thread_sanitizer(tmp_path):
+    """The same program built with -fsanitize=thread (CPU build; GPU sanitizers are not available on this pool): copies, populate
+    requests racing with copies into the same fresh mapping, the low-priority queue, worker start-up and shutdown -- no report."""
+    import shutil
+    import subprocess
+    if shutil.which("g++") is None:
+        pytest.skip("g++ not available")
+    src_dir = os.path.join(ROOT, "nu_scaler_amd", "csrc")
+    exe = str(tmp_path / "copy_pool_stress_tsan")
+    cmd = ["g++", "-O1", "-g", "-fsanitize=thread", "-std=c++17", "-pthread", "-I", src_dir,
+           os.path.join(ROOT, "tests", "c_abi", "copy_pool_stress.cpp"), os.path.join(src_dir, "nus_copy.cpp"), "-o", exe]
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if res.returncode != 0 and "tsan" in (res.stderr or "").lower():
+        pytest.skip("libtsan not installed")
+    assert res.returncode == 0, res.stderr
+    env = dict(os.environ, NUS_COPY_THREADS="3", TSAN_OPTIONS="halt_on_error=1 exitcode=66")
+    run = subprocess.run([exe], capture_output=True, text=True, env=env, timeout=600)
+    if "FATAL: ThreadSanitizer" in run.stderr and "memory layout" in run.stderr:
+        pytest.skip("ThreadSanitizer cannot map its shadow memory in this container")
+    assert run.returncode == 0 and "bad 0" in run.stdout and "WARNING: ThreadSanitizer" not in run.stderr, run.stdout + run.stderr
+
+
 def test_vram_stats_surface(nsc):
     """PyAdvancedWgpuUpscaler.get_vram_stats / get_vram_usage_percent (lib.rs:539-584): present; without a GPU
     they raise the reference's RuntimeError text, with one they report hipMemGetInfo."""
