@@ -21,11 +21,11 @@ import csv, glob, collections
 tot = collections.defaultdict(float); n = collections.Counter(); dur = []
 for f in glob.glob("$out/p*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        if "k_lanczos3_x2<" in r["Kernel_Name"] and "true>" in r["Kernel_Name"]:
+        if "k_lanczos3_x2<" in r["Kernel_Name"] and ", true, " in r["Kernel_Name"]:
             tot[r["Counter_Name"]] += float(r["Counter_Value"]); n[r["Counter_Name"]] += 1
 for f in glob.glob("$out/p1/**/*kernel_trace.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        if "k_lanczos3_x2<" in r["Kernel_Name"] and "true>" in r["Kernel_Name"]:
+        if "k_lanczos3_x2<" in r["Kernel_Name"] and ", true, " in r["Kernel_Name"]:
             dur.append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
 for k in sorted(tot): print(f"{k:34s} {tot[k]/n[k]:16.0f}  per launch ({n[k]} launches)")
 if dur: print(f"kernel duration (pass 1)           {sum(dur)/len(dur)/1e3:16.1f}  us per launch of 64 units")
