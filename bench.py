@@ -520,6 +520,7 @@ class ClockSampler:
         self._thread = threading.Thread(target=self._run, daemon=True)
         self.t0 = time.perf_counter()
         self.tool = None
+        self.power_cap_W = None
 
     @staticmethod
     def _parse(text):
@@ -561,6 +562,12 @@ class ClockSampler:
             if found:
                 power = found[0]
                 break
+        cap = glob.glob(os.path.join(base, "hwmon", "hwmon*", "power1_cap"))
+        try:
+            with open(cap[0]) as f:
+                self.power_cap_W = round(int(f.read().strip()) / 1e6, 1)
+        except (OSError, ValueError, IndexError):
+            self.power_cap_W = None
         return {"base": base, "power": power}
 
     def _sysfs_sample(self, paths):
@@ -668,7 +675,7 @@ def sustained_leg(torch, do_step, upscaler, seconds, tail_s=3.0, batch=20, bdf=N
         "ms_per_step_tail": round(tail_seconds / max(tail_steps, 1) * 1e3, 4),
         "tail_seconds": round(tail_seconds, 2), "tail_steps": tail_steps,
         "tail_upscale_launches": tail_launches, "tail_upscale_avg_launch_ms": round(tail_ms / max(tail_launches, 1), 4),
-        "clock_power_samples": {"tool": sampler.tool, "t_s__sclk_MHz__W__mclk_MHz__fclk_MHz": samples,
+        "clock_power_samples": {"tool": sampler.tool, "power_cap_W": sampler.power_cap_W, "t_s__sclk_MHz__W__mclk_MHz__fclk_MHz": samples,
                                 "tail_mean_sclk_MHz": ClockSampler.mean(in_tail, 1), "tail_mean_W": ClockSampler.mean(in_tail, 2, 1),
                                 "tail_mean_mclk_MHz": ClockSampler.mean(in_tail, 3), "tail_mean_fclk_MHz": ClockSampler.mean(in_tail, 4)},
     }
@@ -802,6 +809,17 @@ def worker(args):
         else:
             dist.init_process_group(args.backend, rank=rank, world_size=world)
     bdf = place.get("gpu_bdf")
+    # the binding was planned from sysfs before HIP was up: now that it is, HIP's own word on where this rank's device sits
+    try:
+        pr = torch.cuda.get_device_properties(device_index)
+        hip_bdf = f"{int(getattr(pr, 'pci_domain_id', 0)):04x}:{int(pr.pci_bus_id):02x}:{int(pr.pci_device_id):02x}.0"
+        place["gpu_bdf_by_hip"] = hip_bdf
+        place["gpu_bdf_verified"] = bool(bdf) and hip_bdf == bdf
+        if hip_bdf != bdf:  # (the CPU binding stays as planned; the clocks and power are read from the device HIP names)
+            bdf = hip_bdf
+    except Exception as e:  # an older torch without the PCI fields
+        place["gpu_bdf_verified"] = None
+        place["gpu_bdf_by_hip"] = f"unavailable: {type(e).__name__}"
     my_cpus = max(1, int(place.get("cpus_per_rank") or 1))
 
     w, h = args.width, args.height
@@ -902,6 +920,7 @@ def worker(args):
         "sclk_MHz": cps.get("tail_mean_sclk_MHz"), "mclk_MHz": cps.get("tail_mean_mclk_MHz"),
         "fclk_MHz": cps.get("tail_mean_fclk_MHz"), "W": cps.get("tail_mean_W"),
         "numa_node": place.get("numa_node"), "bound": 1.0 if place.get("bound") else 0.0, "cpus_per_rank": my_cpus,
+        "bdf_verified": None if place.get("gpu_bdf_verified") is None else (1.0 if place["gpu_bdf_verified"] else 0.0),
         "n_cpus_in_mask": place.get("n_cpus_in_mask"), "copy_threads": place.get("copy_threads"),
         "first_frame": start,
     }
@@ -1151,6 +1170,7 @@ def worker(args):
                     "rank0": place,
                     "numa_node_by_rank": [None if r["numa_node"] is None else int(r["numa_node"]) for r in rows],
                     "bound_by_rank": [bool(r["bound"]) for r in rows],
+                    "gpu_pci_address_confirmed_by_hip_by_rank": [None if r["bdf_verified"] is None else bool(r["bdf_verified"]) for r in rows],
                     "cpus_per_rank": [int(r["cpus_per_rank"]) for r in rows],
                     "n_cpus_in_mask_by_rank": [None if r["n_cpus_in_mask"] is None else int(r["n_cpus_in_mask"]) for r in rows],
                     "copy_threads_by_rank": [None if r["copy_threads"] is None else int(r["copy_threads"]) for r in rows],

@@ -1100,6 +1100,9 @@ hipError_t launch_hs_level_setup(const float *l1, const float *l2, float *coef, 
 #ifndef NUS_HS_STREAM_MAXK
 #define NUS_HS_STREAM_MAXK 5 // steps per launch of the streamed kernel (registers: 8 per level + 5 per delay-line row)
 #endif
+#ifndef NUS_HS_FAST_MAXK_LONG
+#define NUS_HS_FAST_MAXK_LONG 8 // ... of a level with >= 30 steps (50 steps: 7 launches instead of 10; -0.8 us per 1080p pair)
+#endif
 #ifndef NUS_HS_FAST_MAXK
 #define NUS_HS_FAST_MAXK 5 // steps per launch of k_hs_stream_fast (registers: 4 per level + 5 per delay-line row)
 #endif
@@ -1152,9 +1155,12 @@ hipError_t launch_hs_iterate(const float *coef, float lambda, float **flow_a, fl
 {
     if (kernel == kJacobiStreamFast) { // FAST arithmetic (k_hs_stream_fast): always streamed, always from the luminance planes
         if (lum1 == nullptr) return hipErrorInvalidValue;
-        uint32_t launches = (iterations + NUS_HS_FAST_MAXK - 1) / NUS_HS_FAST_MAXK;
+        // a level with many steps (the coarsest: 50) takes more of them per launch: its launches are short and memory-bound, and
+        // fewer of them move fewer bytes; the levels with 10 steps stay at 5 (ten per launch costs two waves per SIMD)
+        const uint32_t maxk = iterations >= 30 ? NUS_HS_FAST_MAXK_LONG : NUS_HS_FAST_MAXK;
+        uint32_t launches = (iterations + maxk - 1) / maxk;
         while (iterations > 0) {
-            const uint32_t k = (iterations + launches - 1) / launches; // even split, 1..MAXK steps per launch
+            const uint32_t k = (iterations + launches - 1) / launches; // even split, 1..maxk steps per launch
             size_t out_stride = flow_stride;
             if (final_out && launches == 1) { // the last launch writes the caller's buffer
                 *flow_b = final_out;
@@ -1179,7 +1185,7 @@ hipError_t launch_hs_iterate(const float *coef, float lambda, float **flow_a, fl
         break;
             switch (k) {
                 NUS_HSF(1) NUS_HSF(2) NUS_HSF(3) NUS_HSF(4) NUS_HSF(5)
-#if NUS_HS_FAST_MAXK > 5
+#if NUS_HS_FAST_MAXK > 5 || NUS_HS_FAST_MAXK_LONG > 5
                 NUS_HSF(6) NUS_HSF(7) NUS_HSF(8) NUS_HSF(9) NUS_HSF(10)
 #endif
             }
