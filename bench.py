@@ -50,6 +50,8 @@ import subprocess
 import sys
 import time
 
+os.environ.setdefault("LIBC_FATAL_STDERR_", "1")  # a fatal glibc message belongs in the run's stderr, not on a terminal nobody reads
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

@@ -8,6 +8,13 @@ try:  # torch bundles its own HIP runtime: load it before libnuscaler_hip.so pul
 except Exception:  # pragma: no cover
     torch = None
 
+# A fatal message of glibc (heap corruption, stack smashing) goes to the controlling terminal unless this is set: one full GPU run
+# of round 4 died of SIGABRT with nothing but "Fatal Python error: Aborted" in its log.  With it the cause would have been in the log.
+os.environ.setdefault("LIBC_FATAL_STDERR_", "1")
+import faulthandler  # noqa: E402
+
+faulthandler.enable(all_threads=True)
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "tests")):
     if p not in sys.path:

@@ -49,5 +49,7 @@ PY
 rm -rf $out/edge_prof
 python3 bench.py --gpus 2 --backend gloo --force-device 0 --steps 30 --warmup 3 --units 100 --sustained-seconds 2 > $out/bench_n2_gloo.log 2>&1; grep "^{" $out/bench_n2_gloo.log | tail -1 > $out/bench_rehearsal_n2_gloo_one_gpu.json
 echo "rehearsal done: $(cut -c1-120 $out/bench_rehearsal_n2_gloo_one_gpu.json)"
+timeout -k 10 400 python3 bench.py --gpus 4 --backend gloo --force-device 0 --steps 20 --warmup 3 --units 60 --sustained-seconds 2 --host-fed-seconds 1 > $out/bench_n4_gloo.log 2>&1; grep "^{" $out/bench_n4_gloo.log | tail -1 > $out/bench_rehearsal_n4_gloo_one_gpu.json
+echo "4-rank rehearsal done: $(cut -c1-120 $out/bench_rehearsal_n4_gloo_one_gpu.json)"
 rm -rf $out/bench_prof $out/bench3_prof $root/gpurun_out/flowsprof $root/gpurun_out/flowprof
 ls -la $out
