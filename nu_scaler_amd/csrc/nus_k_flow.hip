@@ -1,6 +1,7 @@
 // nus_k_flow.hip -- optical-flow front end: Gaussian pyramid + Horn-Schunck.
 #include "nus_device.hpp"
 #include <algorithm>
+#include <cstdlib>
 #include <type_traits>
 
 namespace nus {
@@ -1155,10 +1156,37 @@ hipError_t launch_hs_iterate(const float *coef, float lambda, float **flow_a, fl
 {
     if (kernel == kJacobiStreamFast) { // FAST arithmetic (k_hs_stream_fast): always streamed, always from the luminance planes
         if (lum1 == nullptr) return hipErrorInvalidValue;
+        // one launch of k steps over pairs [0, m) of the given bases
+        auto launch_one = [&](uint32_t k, bool ups, const float *lum, const float2 *fi, float2 *fo, size_t out_stride, const HsCoarse &hc,
+                              uint32_t m) -> hipError_t {
+            const HsStreamShape sh = hs_stream_shape(w, h, m, k, true);
+            const dim3 block(256), grid(cdiv(sh.strips * sh.row_blocks, 4), m);
+#define NUS_HSF(KK)                                                                                                                  \
+    case KK:                                                                                                                         \
+        if (ups)                                                                                                                     \
+            hipLaunchKernelGGL((k_hs_stream_fast<KK, true>), grid, block, 0, stream, lum, lum_stride, lambda, fi, flow_stride, fo,    \
+                               out_stride, (int)w, (int)h, (int)sh.strips, (int)sh.row_blocks, (int)sh.rows_per_block, hc);           \
+        else                                                                                                                         \
+            hipLaunchKernelGGL((k_hs_stream_fast<KK, false>), grid, block, 0, stream, lum, lum_stride, lambda, fi, flow_stride, fo,   \
+                               out_stride, (int)w, (int)h, (int)sh.strips, (int)sh.row_blocks, (int)sh.rows_per_block, hc);           \
+        break;
+            switch (k) {
+                NUS_HSF(1) NUS_HSF(2) NUS_HSF(3) NUS_HSF(4) NUS_HSF(5)
+#if NUS_HS_FAST_MAXK > 5 || NUS_HS_FAST_MAXK_LONG > 5
+                NUS_HSF(6) NUS_HSF(7) NUS_HSF(8) NUS_HSF(9) NUS_HSF(10)
+#endif
+            }
+#undef NUS_HSF
+            return hipGetLastError();
+        };
         // a level with many steps (the coarsest: 50) takes more of them per launch: its launches are short and memory-bound, and
         // fewer of them move fewer bytes; the levels with 10 steps stay at 5 (ten per launch costs two waves per SIMD)
         const uint32_t maxk = iterations >= 30 ? NUS_HS_FAST_MAXK_LONG : NUS_HS_FAST_MAXK;
         uint32_t launches = (iterations + maxk - 1) / maxk;
+        // (Measured and dropped, round 4: the finest level in sub-chunks of 4-50 pairs, its two launches back to back per sub-chunk so
+        // that the second finds the first's output and the luminance planes in the 256-MiB Infinity Cache -- identical flows,
+        // 61 / 58 / 55 / 54 / 53 / 52 / 50 us per pair at 4 / 6 / 8 / 12 / 16 / 25 / 50 pairs against 50.5 for the whole chunk: launches
+        // of a few thousand waves lose more than the cache gives.)
         while (iterations > 0) {
             const uint32_t k = (iterations + launches - 1) / launches; // even split, 1..maxk steps per launch
             size_t out_stride = flow_stride;
@@ -1169,28 +1197,10 @@ hipError_t launch_hs_iterate(const float *coef, float lambda, float **flow_a, fl
             auto fi = zero_start ? nullptr : reinterpret_cast<const float2 *>(*flow_a);
             auto fo = reinterpret_cast<float2 *>(*flow_b);
             zero_start = false;
-            const HsStreamShape sh = hs_stream_shape(w, h, n, k, true);
             const bool ups = coarse != nullptr; // the first launch of a level takes the coarser level's flow, upsampled as it loads it
             const HsCoarse hc{reinterpret_cast<const float2 *>(coarse), coarse_stride, (int)cw, (int)ch, coarse_scale};
             coarse = nullptr;
-            const dim3 block(256), grid(cdiv(sh.strips * sh.row_blocks, 4), n);
-#define NUS_HSF(KK)                                                                                                                  \
-    case KK:                                                                                                                         \
-        if (ups)                                                                                                                     \
-            hipLaunchKernelGGL((k_hs_stream_fast<KK, true>), grid, block, 0, stream, lum1, lum_stride, lambda, fi, flow_stride, fo,   \
-                               out_stride, (int)w, (int)h, (int)sh.strips, (int)sh.row_blocks, (int)sh.rows_per_block, hc);           \
-        else                                                                                                                         \
-            hipLaunchKernelGGL((k_hs_stream_fast<KK, false>), grid, block, 0, stream, lum1, lum_stride, lambda, fi, flow_stride, fo,  \
-                               out_stride, (int)w, (int)h, (int)sh.strips, (int)sh.row_blocks, (int)sh.rows_per_block, hc);           \
-        break;
-            switch (k) {
-                NUS_HSF(1) NUS_HSF(2) NUS_HSF(3) NUS_HSF(4) NUS_HSF(5)
-#if NUS_HS_FAST_MAXK > 5 || NUS_HS_FAST_MAXK_LONG > 5
-                NUS_HSF(6) NUS_HSF(7) NUS_HSF(8) NUS_HSF(9) NUS_HSF(10)
-#endif
-            }
-#undef NUS_HSF
-            hipError_t e = hipGetLastError();
+            hipError_t e = launch_one(k, ups, lum1, fi, fo, out_stride, hc, n);
             if (e != hipSuccess) return e;
             iterations -= k;
             --launches;

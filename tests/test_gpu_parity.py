@@ -1504,3 +1504,45 @@ def test_lanczos_x2_edge_pass_beside_the_main_kernel(nsc, oracle_mod):
         m = oracle_mod.warp_blend(frames_np[k], frames_np[k + 1], None, 0.5)
         assert np.array_equal(mid[k].cpu().numpy(), m)
         assert np.array_equal(up_mid[k].cpu().numpy(), oracle_mod.lanczos3(m, 2 * w, 2 * h))
+
+
+@pytest.mark.gpu
+def test_probe_device_kinds_move_the_bytes_they_claim(nsc):
+    """nus_probe_device (bench.py's box calibration): the copies copy, the 1 R : 4 W stream writes each 16-byte piece four times
+    where its header says, the write-only stream fills its range, bad arguments are refused; nothing writes outside its range."""
+    import torch
+
+    L = nsc._capi.lib()
+    dev = torch.device("cuda:0")
+    n = (1 << 20) + 4096 + 48  # not a multiple of the 16-KiB chunk of the stream kernels
+    src = torch.randint(0, 256, (n,), dtype=torch.uint8, device=dev)
+    guard = 4096
+    for kind in (0, 1):
+        dst = torch.full((n + guard,), 0xA5, dtype=torch.uint8, device=dev)
+        assert L.nus_probe_device(kind, src.data_ptr(), dst.data_ptr(), n, 0, None) == 0
+        torch.cuda.synchronize()
+        assert torch.equal(dst[:n], src) and bool((dst[n:] == 0xA5).all()), kind
+    dst = torch.full((n + guard,), 0xA5, dtype=torch.uint8, device=dev)
+    assert L.nus_probe_device(2, None, dst.data_ptr(), n, 0, None) == 0
+    torch.cuda.synchronize()
+    w = dst[:n].view(torch.int32).reshape(-1, 4)
+    assert torch.equal(w[:, 0], torch.arange(n // 16, dtype=torch.int32, device=dev)) and bool((w[:, 1:] == torch.tensor([1, 2, 3], dtype=torch.int32, device=dev)).all())
+    assert bool((dst[n:] == 0xA5).all())
+    sink = torch.zeros(16, dtype=torch.uint8, device=dev)
+    assert L.nus_probe_device(3, src.data_ptr(), sink.data_ptr(), n, 0, None) == 0  # read-only: nothing to compare, must not fault
+    m = 64 * 1024  # whole waves: 4096 pieces of 16 bytes
+    dst = torch.full((4 * m + guard,), 0xA5, dtype=torch.uint8, device=dev)
+    assert L.nus_probe_device(4, src.data_ptr(), dst.data_ptr(), m, 0, None) == 0
+    torch.cuda.synchronize()
+    pieces = src[:m].view(torch.int32).reshape(-1, 64, 4)          # [wave][lane][dword]
+    got = dst[:4 * m].view(torch.int32).reshape(-1, 4, 64, 4)      # [wave][copy j][lane][dword]
+    for j in range(4):
+        assert torch.equal(got[:, j], pieces), j
+    assert bool((dst[4 * m:] == 0xA5).all())
+    scratch = torch.zeros(2048 * 256, dtype=torch.float32, device=dev)
+    assert L.nus_probe_device(5, None, scratch.data_ptr(), 0, 100, None) == 0
+    torch.cuda.synchronize()
+    assert float(scratch.abs().max()) == 0.0  # the FMA chains never write
+    for bad in ((9, src.data_ptr(), dst.data_ptr(), 16, 0), (1, 0, dst.data_ptr(), 16, 0), (1, src.data_ptr() + 4, dst.data_ptr(), 16, 0),
+                (1, src.data_ptr(), dst.data_ptr(), 20, 0), (5, 0, scratch.data_ptr(), 0, 0)):
+        assert L.nus_probe_device(bad[0], bad[1] or None, bad[2], bad[3], bad[4], None) != 0
