@@ -260,7 +260,9 @@ def _flow_close(got, want, tol=1e-3):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("w,h,levels,coarse,refine", [(97, 45, 3, 9, 3), (333, 262, 3, 7, 6), (160, 90, 4, 30, 8), (613, 517, 2, 11, 5),
-                                                       (64, 64, 1, 13, 0), (129, 70, 2, 1, 1)])
+                                                       (64, 64, 1, 13, 0), (129, 70, 2, 1, 1),
+                                                       # levels narrower than a 16-byte load, single columns / rows, more than four strips
+                                                       (13, 9, 3, 5, 2), (9, 7, 3, 4, 2), (5, 5, 2, 3, 1), (3, 33, 2, 3, 2), (1030, 5, 2, 2, 2)])
 def test_flow_fast_mode_within_a_thousandth_of_a_pixel(nsc, oracle_mod, w, h, levels, coarse, refine):
     """FAST mode (separable 3x3 sums, multiply by 1/9, precomputed reciprocal, FMAs; every level in the register-pipelined
     kernel): the flow of every estimator entry point within 1e-3 px of the exact oracle's, on smooth moving content and on
