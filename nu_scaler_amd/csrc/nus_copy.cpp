@@ -237,7 +237,10 @@ bool parallel_populate_prepare(void *dst, size_t bytes)
     // MADV_POPULATE_WRITE first, 0.82 with the hint as well: profiles/r04_host_fresh_result_pages.txt).  One call for the whole
     // range, and only for fresh mappings: madvise takes the address space's lock exclusively, i.e. waits for every populate
     // request in flight -- issued per frame on resident buffers it serialised a batch (0.75 -> 1.48 ms per frame).
-    (void)madvise(reinterpret_cast<void *>(lo), hi - lo, MADV_HUGEPAGE);
+    // Not on the program break's heap (an allocator that serves a 33 MB block from there -- glibc does once its dynamic mmap threshold
+    // has grown past that size -- keeps the address range when the block is freed: the hint would stay on a piece of the process heap
+    // for good and khugepaged would work on it); a block that is its own mapping takes the hint with it when it is unmapped.
+    if (lo >= reinterpret_cast<uintptr_t>(sbrk(0))) (void)madvise(reinterpret_cast<void *>(lo), hi - lo, MADV_HUGEPAGE);
     return true;
 }
 
