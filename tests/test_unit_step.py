@@ -196,3 +196,38 @@ def test_unit_step_strided_source_frames_keep_mid_packed(nsc, oracle_mod):
     assert torch.equal(up_real, want_real) and torch.equal(up_mid, want_up_mid)
     for i in range(n):
         assert np.array_equal(mid[i].cpu().numpy(), oracle_mod.warp_blend(pool_np[2 * i], pool_np[2 * i + 1], None, 0.5))
+
+
+def test_unit_step_64_units_1080p_equals_three_stages_everywhere(nsc, oracle_mod):
+    """A batch big enough for everything a 300-unit step switches on (the edge passes beside the main kernel, rows per wave chosen
+    by the library) at full size: all three outputs of all 64 units bit-identical to the three separate stages on both contents,
+    and -- the size-independent property -- to themselves across two wave orders and a second run."""
+    import torch
+
+    from nu_scaler_amd import synthetic as syn
+
+    w, h, n = 1920, 1080, 64
+    dev = torch.device("cuda:0")
+    s = torch.cuda.current_stream().cuda_stream
+    for pattern in ("gradient", "noise"):
+        frames = (syn.gradient_stream_torch if pattern == "gradient" else syn.noise_stream_torch)(n + 1, w, h, dev)
+        pipe = nsc.FramePipeline(w, h, 2, "lanczos3", 0.5)
+        want = pipe.alloc(n, dev)
+        pipe.step(frames, *want, s)
+        torch.cuda.synchronize()
+        got = pipe.alloc(n, dev)
+        for order in (1, 0, 1):
+            pipe.upscaler.set_option("unit_order", order)
+            for t_ in got:
+                t_.zero_()
+            pipe.step_unit(frames, *got, s)
+            torch.cuda.synchronize()
+            for name, a, b in zip(("mid", "up_real", "up_mid"), got, want):
+                assert torch.equal(a, b), (pattern, order, name)
+        # and one unit against the oracle, edge columns included
+        k = n - 1
+        m = oracle_mod.warp_blend(frames[k].cpu().numpy(), frames[k + 1].cpu().numpy(), None, 0.5, threads=0)
+        assert np.array_equal(got[0][k].cpu().numpy(), m)
+        d = np.abs(got[2][k].cpu().numpy().astype(np.int16) - oracle_mod.lanczos3(m, 2 * w, 2 * h, threads=0).astype(np.int16))
+        assert d.max() <= 1 and (d > 0).mean() < 1e-3
+        del want, got, frames
