@@ -56,6 +56,25 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+
+
+def _install_crash_reports():
+    """faulthandler (Python frames of every thread) and, in front of it, the native backtrace of the thread that raised a fatal
+    signal (tests/helpers/abort_trace.c, test infrastructure, built on demand): a rank that dies says which library aborted."""
+    import faulthandler
+
+    faulthandler.enable(file=sys.__stderr__, all_threads=True)
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        from helpers import abort_trace
+
+        abort_trace.install(2)
+    except Exception:
+        pass
+    finally:
+        sys.path.remove(os.path.join(ROOT, "tests"))
+
+
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 
 
@@ -119,7 +138,9 @@ def launch_ranks(nproc: int, script: str, script_args, timeout=None):
     grandchildren.  Rendezvous on 127.0.0.1 (the container hostname may not resolve)."""
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL needs it on this driver
-    env.setdefault("OMP_NUM_THREADS", "4")  # torchrun's own default is 1; each rank re-sizes it from its CPU share (placement)
+    if "OMP_NUM_THREADS" not in env:  # torchrun's own default is 1; each rank re-sizes it from its CPU share (placement) --
+        env["OMP_NUM_THREADS"] = "4"  # unless the operator set one: the mark tells the ranks this value is the launcher's
+        env["NUS_OMP_THREADS_FROM_LAUNCHER"] = "1"
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={int(nproc)}",
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), script, *script_args]
     res = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True, timeout=timeout)
@@ -778,6 +799,7 @@ def worker(args):
     if world != args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE is {world}")
     device_index = args.force_device if args.force_device >= 0 else local_rank
+    _install_crash_reports()
 
     # Before this process makes its first HIP call: onto the CPUs of its GPU's NUMA node (a disjoint run of whole cores per
     # rank), host threads sized to the rank's share of the CPUs the job may keep busy (copy pool, OpenMP teams).  The GPU's PCI
@@ -810,18 +832,16 @@ def worker(args):
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group(args.backend, rank=rank, world_size=world)
-    bdf = place.get("gpu_bdf")
-    # the binding was planned from sysfs before HIP was up: now that it is, HIP's own word on where this rank's device sits
+    # the binding was planned from sysfs before HIP was up: now that it is, HIP's own word on where this rank's device sits; a
+    # mismatch re-plans the CPU binding from HIP's address (placement.verify_after_init) and is flagged in rank 0's line
     try:
         pr = torch.cuda.get_device_properties(device_index)
         hip_bdf = f"{int(getattr(pr, 'pci_domain_id', 0)):04x}:{int(pr.pci_bus_id):02x}:{int(pr.pci_device_id):02x}.0"
-        place["gpu_bdf_by_hip"] = hip_bdf
-        place["gpu_bdf_verified"] = bool(bdf) and hip_bdf == bdf
-        if hip_bdf != bdf:  # (the CPU binding stays as planned; the clocks and power are read from the device HIP names)
-            bdf = hip_bdf
     except Exception as e:  # an older torch without the PCI fields
-        place["gpu_bdf_verified"] = None
+        hip_bdf = None
         place["gpu_bdf_by_hip"] = f"unavailable: {type(e).__name__}"
+    plc.verify_after_init(place, hip_bdf, apply=not args.no_bind)
+    bdf = place.get("gpu_bdf_by_hip") if hip_bdf else place.get("gpu_bdf")  # clocks and power are read from the device HIP names
     my_cpus = max(1, int(place.get("cpus_per_rank") or 1))
 
     w, h = args.width, args.height

@@ -135,8 +135,12 @@ int nus_host_unpin(void *buffer);
  * device memory); 4 one read : four writes -- `bytes` read from d_src, 4 * `bytes` written to d_dst, each store instruction one
  * contiguous KiB per wave (the byte mix of a x2 upscale with no arithmetic); 5 VGPR-only f32 FMA chains, nothing touches
  * memory: 2048 blocks x 256 lanes x 16 chains x `iters` FMAs (d_dst: >= 2 MiB, never written).  Pointers 16-byte aligned,
- * `bytes` a multiple of 16. */
+ * `bytes` a multiple of 16 (kind 4: of 1024 -- whole waves, each of which writes four contiguous KiB; anything else is refused). */
 int nus_probe_device(int kind, const void *d_src, void *d_dst, size_t bytes, uint32_t iters, void *stream);
+/* Pieces (copies and page-populate requests) of the host path's helper-thread pool that are still queued or running, process-wide
+ * (not in the reference; diagnostics).  0 whenever no host call is in progress: every entry point waits for what it queued
+ * before it returns, on its error paths too -- the pieces point into the caller's buffers. */
+size_t nus_host_pending_pieces(void);
 /* Thread-local message of the last failing call on this thread ("" if none). */
 const char *nus_last_error(void);
 const char *nus_status_string(int status);

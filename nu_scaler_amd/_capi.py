@@ -107,6 +107,7 @@ SIGNATURES = [
     ("nus_frame_queue_capacity", _sz, [_vp]),
     ("nus_frame_queue_dropped", ctypes.c_uint64, [_vp]),
     ("nus_probe_device", _i, [_i, _vp, _vp, _sz, _u32, _vp]),
+    ("nus_host_pending_pieces", _sz, []),
     ("nus_swizzle_bgra_to_rgba_device", _i, [_vp, _vp, _sz, _vp]),
     ("nus_flow_create", _vp, []),
     ("nus_flow_destroy", None, [_vp]),

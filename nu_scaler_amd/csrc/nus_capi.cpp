@@ -585,13 +585,15 @@ size_t nus_frame_queue_size(const nus_frame_queue *q) { return q ? q->impl.size(
 size_t nus_frame_queue_capacity(const nus_frame_queue *q) { return q ? q->impl.capacity() : 0; }
 uint64_t nus_frame_queue_dropped(const nus_frame_queue *q) { return q ? q->impl.dropped() : 0; }
 
+size_t nus_host_pending_pieces(void) { return nus::parallel_copy_pending(); }
+
 int nus_probe_device(int kind, const void *d_src, void *d_dst, size_t bytes, uint32_t iters, void *stream)
 {
     return guarded<int>("nus_probe_device", [&]() -> int {
         auto misaligned = [](const void *p) { return (reinterpret_cast<uintptr_t>(p) % 16) != 0; };
         const bool needs_src = kind == 0 || kind == 1 || kind == 3 || kind == 4;
         if (kind < 0 || kind > 5 || !d_dst || (needs_src && !d_src) || misaligned(d_src) || misaligned(d_dst) || (bytes % 16) ||
-            (kind == 5 && iters == 0)) {
+            (kind == 5 && iters == 0) || (kind == 4 && (bytes % 1024))) { // kind 4: whole waves only (each writes 4 x 1 KiB)
             nus::set_thread_error("nus_probe_device: bad kind, pointer, size or iteration count");
             return NUS_ERR_INVALID_ARGUMENT;
         }

@@ -33,20 +33,59 @@ constexpr size_t kPopulateBytes = 2u << 20;    // work item of a populate reques
 // path (measured through the pyo3 shapes: 1.80 instead of 0.98 ms per call, 2.9 ms per frame of a batch), taken here they run
 // beside the frame's DMA and kernel.  MADV_POPULATE_WRITE (Linux 5.14) where the kernel has it, else an atomic add of zero to
 // one byte per page -- atomic, so a copy piece that writes the same page at the same time loses nothing.
-void populate_pages(char *p, size_t len)
-{
+// MADV_POPULATE_WRITE is asked about ONCE, on a page this library maps for itself: EINVAL on a caller's range also means "this
+// mapping cannot be populated" (VM_PFNMAP / VM_IO, no write permission), and must not turn the call off for the whole process.
 #ifndef MADV_POPULATE_WRITE
 #define MADV_POPULATE_WRITE 23
 #endif
+bool kernel_has_populate_write()
+{
+    static const bool have = [] {
+        void *pg = mmap(nullptr, 4096, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+        if (pg == MAP_FAILED) return false;
+        const bool ok = madvise(pg, 4096, MADV_POPULATE_WRITE) == 0;
+        munmap(pg, 4096);
+        return ok;
+    }();
+    return have;
+}
+
+void populate_pages(char *p, size_t len)
+{
     const uintptr_t a = reinterpret_cast<uintptr_t>(p);
     const uintptr_t lo = (a + 4095) & ~(uintptr_t)4095, hi = (a + len) & ~(uintptr_t)4095;
     if (hi <= lo) return;
-    static std::atomic<int> have_madvise{1};
-    if (have_madvise.load(std::memory_order_relaxed)) {
-        if (madvise(reinterpret_cast<void *>(lo), hi - lo, MADV_POPULATE_WRITE) == 0) return;
-        if (errno == EINVAL) have_madvise.store(0, std::memory_order_relaxed); // an older kernel: touch the pages instead
+    if (kernel_has_populate_write()) {
+        // Any failure (ENOMEM: part of the range is not mapped; EFAULT, EINVAL: a mapping that cannot be populated; EAGAIN) leaves
+        // the pages to the copy-out's own first-touch faults: this is an optimisation, and a range the kernel refuses is not one
+        // to dereference.
+        (void)madvise(reinterpret_cast<void *>(lo), hi - lo, MADV_POPULATE_WRITE);
+        return;
     }
+    // a kernel older than 5.14 (probed above): touch the pages instead.  Only ranges a caller has handed over as writable output
+    // get here, exactly as the copy-out would write them a moment later.
     for (uintptr_t q = lo; q < hi; q += 4096) (void)__atomic_fetch_add(reinterpret_cast<volatile char *>(q), 0, __ATOMIC_RELAXED);
+}
+
+// Is [p, p + len) a block that is its OWN mapping -- one the allocator maps for this block alone and unmaps when the block is
+// freed, so that a hint left on it (MADV_HUGEPAGE) goes away with it?  True for blocks of at least 32 MiB (glibc's mmap threshold
+// never grows past that: DEFAULT_MMAP_THRESHOLD_MAX) and for blocks that carry glibc's mmapped-chunk header: the word in front
+// of the first user byte of the mapping holds the chunk size (a whole number of pages, just enough for this block) with
+// IS_MMAPPED (2) set and PREV_INUSE (1) / NON_MAIN_ARENA (4) clear.  The user pointer may sit a few bytes into the chunk (a PyBytes
+// keeps a 32-byte object header in front of its data; a Vec / numpy array none): the header is looked for at the start of the
+// pointer's own page, which is readable because the block's first byte is.  Any other allocator, and blocks glibc carved out of
+// a heap (the program break's, or a thread arena's 64-MiB regions), answer false: they keep their address range when the block
+// is freed and a hint would stay on a piece of the process heap for good.
+bool is_own_mapping(const void *p, size_t len)
+{
+    if (len >= ((size_t)32 << 20)) return true;
+    const uintptr_t a = reinterpret_cast<uintptr_t>(p), page = a & ~(uintptr_t)4095, off = a - page;
+    if (off < 16 || off > 256) return false; // mmapped chunk: 16 bytes of chunk header at the start of the mapping, then the block
+    size_t hdr[2];
+    memcpy(hdr, reinterpret_cast<const void *>(page), sizeof(hdr));
+    const size_t size = hdr[1] & ~(size_t)7;
+    if (hdr[0] != 0 || (hdr[1] & 7) != 2 || size % 4096 != 0) return false;
+    return size >= off + len && size <= off + len + 2 * 4096;
 }
 
 // A queue of pieces (dst, src, len, ticket; src == nullptr: populate dst's pages) shared by every caller: several copies can be in flight at once -- the staging
@@ -70,6 +109,12 @@ public:
     static void shutdown_at_unload() { instance().shutdown(); }
 
     int workers() const { return getpid() == owner_ ? (int)threads_.size() : 0; }
+
+    size_t pending()
+    {
+        std::lock_guard<std::mutex> lk(m_);
+        return queue_.size() + queue_lo_.size() + running_;
+    }
 
     // Queue the pieces of one copy under `ticket` and wake the workers.  The bytes are copied by the time ticket.wait()
     // (or help()) returns; the caller keeps both buffers alive until then.
@@ -175,12 +220,14 @@ private:
         std::deque<Piece> &q = queue_.empty() ? queue_lo_ : queue_;
         const Piece p = q.front();
         q.pop_front();
+        ++running_;
         lk.unlock();
         if (p.src)
             memcpy(p.dst, p.src, p.len);
         else
             populate_pages(p.dst, p.len);
         lk.lock();
+        --running_;
         if (--p.ticket->left == 0) cv_done_.notify_all();
     }
 
@@ -199,6 +246,7 @@ private:
     std::deque<Piece> queue_;    // copies
     std::deque<Piece> queue_lo_; // populate requests: taken when no copy is waiting
     std::vector<std::thread> threads_;
+    size_t running_ = 0; // pieces popped and not yet finished
     bool stop_ = false;
     pid_t owner_ = 0;
 };
@@ -237,10 +285,11 @@ bool parallel_populate_prepare(void *dst, size_t bytes)
     // MADV_POPULATE_WRITE first, 0.82 with the hint as well: profiles/r04_host_fresh_result_pages.txt).  One call for the whole
     // range, and only for fresh mappings: madvise takes the address space's lock exclusively, i.e. waits for every populate
     // request in flight -- issued per frame on resident buffers it serialised a batch (0.75 -> 1.48 ms per frame).
-    // Not on the program break's heap (an allocator that serves a 33 MB block from there -- glibc does once its dynamic mmap threshold
-    // has grown past that size -- keeps the address range when the block is freed: the hint would stay on a piece of the process heap
-    // for good and khugepaged would work on it); a block that is its own mapping takes the hint with it when it is unmapped.
-    if (lo >= reinterpret_cast<uintptr_t>(sbrk(0))) (void)madvise(reinterpret_cast<void *>(lo), hi - lo, MADV_HUGEPAGE);
+    // Only on blocks that are their own mapping (is_own_mapping): there the hint is unmapped with the block.  On a block the
+    // allocator carved out of a heap -- glibc serves a 33 MB block from the program break once its dynamic mmap threshold has
+    // grown past that size, or from a thread arena -- the address range outlives the block and the hint would stay on a piece of
+    // the process heap for good (khugepaged would keep working on it): such blocks are populated without it.
+    if (is_own_mapping(dst, bytes)) (void)madvise(reinterpret_cast<void *>(lo), hi - lo, MADV_HUGEPAGE);
     return true;
 }
 
@@ -264,5 +313,9 @@ void parallel_copy(void *dst, const void *src, size_t bytes)
 }
 
 int parallel_copy_workers() { return CopyPool::instance().workers(); }
+
+size_t parallel_copy_pending() { return CopyPool::instance().pending(); }
+
+bool parallel_populate_own_mapping(const void *p, size_t bytes) { return is_own_mapping(p, bytes); }
 
 } // namespace nus

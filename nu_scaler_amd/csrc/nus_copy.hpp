@@ -35,6 +35,13 @@ void parallel_copy_wait(CopyTicket &ticket);
 bool parallel_populate_prepare(void *dst, size_t bytes);
 void parallel_populate_async(void *dst, size_t bytes, CopyTicket &ticket);
 
+// What parallel_populate_prepare asks before it leaves a transparent-huge-page hint on a buffer: is the block its own mapping (at
+// least 32 MiB, or carrying glibc's mmapped-chunk header), so that the hint is unmapped with it?  (Exposed for the host tests.)
+bool parallel_populate_own_mapping(const void *p, size_t bytes);
+
+// pieces queued or being worked on, over all tickets (0 when no host call is in progress)
+size_t parallel_copy_pending();
+
 // number of worker threads in use (0 when disabled or in a forked child)
 int parallel_copy_workers();
 

@@ -157,6 +157,11 @@ int HipUpscaler::set_option(const char *key, int64_t value)
         unit_order_ = (uint32_t)value;
         return kOk;
     }
+    if (!strcmp(key, "inject_retire_error")) { // TEST HOOK: the value-th frame retired from now on (1 = the next) reports a HIP error
+        if (value < 0 || value > 1000000) return fail(kInvalidArgument, "inject_retire_error out of range");
+        inject_retire_.store((int)value);
+        return kOk;
+    }
     return fail(kInvalidArgument, fmt("unknown option '%s'", key));
 }
 
@@ -870,6 +875,7 @@ void HipUpscaler::release_slot(Slot &s)
 {
     for (hipStream_t st : {s_in_, s_k_, s_out_})
         if (st) (void)hipStreamSynchronize(st);
+    parallel_copy_wait(s.populate); // the pool holds a pointer to this ticket for every request still queued under it
     if (s.d_in) (void)hipFree(s.d_in);
     if (s.d_out) (void)hipFree(s.d_out);
     if (s.h_in) (void)hipHostFree(s.h_in);
@@ -1035,8 +1041,10 @@ int HipUpscaler::retire_frame(Slot &S, uint8_t *out, bool direct, std::string *e
         if (err) *err = fmt("HIP error in %s: %s", what, hipGetErrorString(e));
         return e == hipErrorOutOfMemory ? kOutOfMemory : kHipError;
     };
+    // (test hook, option "inject_retire_error": this frame's wait reports a failure, as a lost device would)
+    const bool injected = inject_retire_.load() > 0 && inject_retire_.fetch_sub(1) == 1;
     if (direct) {
-        const hipError_t e = hipEventSynchronize(S.out_done);
+        const hipError_t e = injected ? hipErrorUnknown : hipEventSynchronize(S.out_done);
         return e == hipSuccess ? kOk : hip_failed(e, "hipEventSynchronize(out_done)");
     }
     struct PopulateDone { // on every way out: queued populate requests point into `out`
@@ -1047,7 +1055,7 @@ int HipUpscaler::retire_frame(Slot &S, uint8_t *out, bool direct, std::string *e
     int rc = kOk;
     size_t off = 0;
     for (int k = 0; k < S.nchunks; ++k) {
-        const hipError_t e = hipEventSynchronize(S.chunk_done[k]);
+        const hipError_t e = injected ? hipErrorUnknown : hipEventSynchronize(S.chunk_done[k]);
         if (e != hipSuccess) {
             rc = hip_failed(e, "hipEventSynchronize(chunk_done)");
             break;
@@ -1215,6 +1223,8 @@ int HipUpscaler::upscale_batch(const uint8_t *const *ins, const size_t *in_lens,
     // (pinned) output buffers afterwards
     struct Drain {
         hipStream_t st[3];
+        Slot *slots;
+        int nslots;
         bool armed = true;
         ~Drain()
         {
@@ -1222,8 +1232,11 @@ int HipUpscaler::upscale_batch(const uint8_t *const *ins, const size_t *in_lens,
             for (hipStream_t s : st)
                 if (s) (void)hipStreamSynchronize(s);
             (void)hipGetLastError();
+            // and no populate request of this call may stay queued: they point into outs[] (the caller frees those next) and
+            // into the slots' tickets (a request left behind would later decrement a count inside a freed HipUpscaler)
+            for (int s = 0; s < nslots; ++s) parallel_copy_wait(slots[s].populate);
         }
-    } drain{{s_in_, s_k_, s_out_}};
+    } drain{{s_in_, s_k_, s_out_}, slots_, nslots};
     // Frame i uses slot i % nslots: stage -> H2D (copy-in stream) -> kernel (compute stream) -> D2H (copy-out stream),
     // chained by the slot's events (submit_frame / retire_frame).  A slot is submitted to again only after its previous frame
     // has been retired (so its D2H, hence its kernel and its H2D, are complete): no stream needs to wait for an earlier frame.
@@ -1284,7 +1297,9 @@ int HipUpscaler::upscale_batch(const uint8_t *const *ins, const size_t *in_lens,
                 }
                 retired = i + 1;
                 cv.notify_all();
-                if (rc != kOk) return;
+                // (no early return on a failed frame: every frame that was SUBMITTED is retired -- retire_frame is what waits for
+                // the populate requests and copy pieces that point into the caller's outs[i] and into the slot's ticket; the
+                // submitter stops submitting as soon as it sees retire_status)
             }
         };
         // the retiring thread is told to stop and joined on EVERY way out of this scope (an exception on the submitting

@@ -12,6 +12,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdint>
 #include <memory>
 #include <condition_variable>
@@ -155,6 +156,7 @@ private:
     int batch_out_chunks_ = 2;  // option "batch_out_chunks": equal pieces per frame of upscale_batch / the stream ring
     void plan_chunks(Slot &s, size_t out_bytes, bool alone) const;
     int single_bands_ = 1;      // option "single_bands"
+    mutable std::atomic<int> inject_retire_{0}; // option "inject_retire_error" (test hook; read on the retiring thread)
     uint32_t band_alignment(uint32_t n_frames) const; // rows a band must be a multiple of; 0 = the variant has no row-range launch
     uint32_t lanczos_x2_rows_per_wave(uint32_t n_frames, bool unit) const;
     int submit_frame_banded(Slot &s, const uint8_t *in, uint8_t *out, bool *direct, uint32_t align, int populate);

@@ -277,9 +277,81 @@ def bind_rank(device_index: int, local_world: int, sysfs: str = "/sys", apply: b
         except OSError as e:
             plan.update(bound=False, why_not=f"sched_setaffinity: {e}", cpus=mask)
     budget = thread_budget(plan["cpus_per_rank"])
-    if apply:
-        os.environ["NUS_COPY_THREADS"] = str(budget["copy_threads"])
-        os.environ["OMP_NUM_THREADS"] = str(budget["omp_threads"])
+    from_env = _apply_thread_budget(budget) if apply else {}
     return {"bound": plan["bound"], "why_not": plan["why_not"], "gpu_bdf": plan["gpu_bdf"], "numa_node": plan["numa_node"],
             "cpus": format_cpulist(plan["cpus"]), "n_cpus_in_mask": len(plan["cpus"]), "cpus_per_rank": plan["cpus_per_rank"],
-            "ranks_on_node": plan["ranks_on_node"], "cgroup_cpu_quota": quota, "local_world": local_world, **budget}
+            "ranks_on_node": plan["ranks_on_node"], "cgroup_cpu_quota": quota, "local_world": local_world, **budget, **from_env,
+            "_replan": {"devices": devices, "mask": mask, "slot": slot, "device_index": device_index}}
+
+
+LAUNCHER_OMP_MARK = "NUS_OMP_THREADS_FROM_LAUNCHER"  # set by launch_ranks when IT chose OMP_NUM_THREADS (torchrun's default is 1)
+
+
+def _apply_thread_budget(budget: Dict[str, int]) -> Dict:
+    """Write the rank's thread counts into the environment -- unless the operator has: a NUS_COPY_THREADS or OMP_NUM_THREADS that
+    was set by hand wins (the launcher's own default for OMP_NUM_THREADS, marked with LAUNCHER_OMP_MARK, does not count as
+    one), is reported as such, and `budget` is updated to what will actually be used."""
+    rep = {}
+    user_copy = os.environ.get("NUS_COPY_THREADS")
+    if user_copy is not None and os.environ.get("NUS_COPY_THREADS_FROM_PLACEMENT") != "1":
+        try:
+            budget["copy_threads"] = max(0, int(user_copy))
+            rep["copy_threads_from_env"] = True
+        except ValueError:
+            user_copy = None
+    if not rep.get("copy_threads_from_env"):
+        os.environ["NUS_COPY_THREADS"] = str(budget["copy_threads"])
+        os.environ["NUS_COPY_THREADS_FROM_PLACEMENT"] = "1"  # a second bind_rank (a re-plan) may overwrite its own value
+    user_omp = os.environ.get("OMP_NUM_THREADS")
+    if user_omp is not None and os.environ.get(LAUNCHER_OMP_MARK) != "1":
+        try:
+            budget["omp_threads"] = max(1, int(user_omp.split(",")[0]))
+            rep["omp_threads_from_env"] = True
+        except ValueError:
+            user_omp = None
+    if not rep.get("omp_threads_from_env"):
+        os.environ["OMP_NUM_THREADS"] = str(budget["omp_threads"])
+        os.environ[LAUNCHER_OMP_MARK] = "1"
+    return rep
+
+
+def verify_after_init(place: Dict, hip_bdf: Optional[str], sysfs: str = "/sys", apply: bool = True) -> Dict:
+    """Second half of bind_rank, AFTER the process has initialised HIP: the binding was planned from the KFD topology in sysfs,
+    now HIP itself says where the rank's device sits (`hip_bdf`, '0000:d9:00.0').  Equal: verified.  Different (the sysfs order
+    was not HIP's order on this box): the affinity is planned again from HIP's address and applied -- sched_setaffinity is as
+    legal now as before; threads the runtime has started keep the old mask, the submitting / retiring threads and the copy pool
+    (started by the first host call) get the new one -- and the report says so loudly (`rebound_after_init`).  Updates and
+    returns `place`; the private planning fields are removed."""
+    st = place.pop("_replan", None) or {}
+    devices, mask0, slot, device_index = st.get("devices"), st.get("mask"), st.get("slot"), st.get("device_index")
+    planned = place.get("gpu_bdf")
+    if not hip_bdf:
+        place["gpu_bdf_verified"] = None
+        return place
+    hip_bdf = hip_bdf.lower()
+    place["gpu_bdf_by_hip"] = hip_bdf
+    place["gpu_bdf_verified"] = bool(planned) and planned == hip_bdf
+    if place["gpu_bdf_verified"] or devices is None or device_index is None or not place.get("bound"):
+        return place
+    # planned for another device than the one HIP gave this rank: plan again with HIP's word for this rank's entry
+    devs = list(devices)
+    while len(devs) <= device_index:
+        devs.append({"bdf": None, "numa_node": None, "local_cpus": []})
+    devs[device_index] = pci_numa(hip_bdf, sysfs)
+    lw = int(place.get("local_world") or 1)
+    if slot is None:
+        plan = plan_binding(devs, device_index, lw, mask0, place.get("cgroup_cpu_quota"), sysfs)
+    else:
+        plan = plan_binding(devs, slot, lw, mask0, place.get("cgroup_cpu_quota"), sysfs, device_of_rank=[device_index] * max(lw, slot + 1))
+    place["rebound_after_init"] = {"planned_bdf": planned, "planned_cpus": place.get("cpus"), "ok": False}
+    if plan["bound"] and apply:
+        try:
+            os.sched_setaffinity(0, plan["cpus"])
+            place["rebound_after_init"]["ok"] = True
+            place.update(gpu_bdf=hip_bdf, numa_node=plan["numa_node"], cpus=format_cpulist(plan["cpus"]),
+                         n_cpus_in_mask=len(plan["cpus"]), cpus_per_rank=plan["cpus_per_rank"], ranks_on_node=plan["ranks_on_node"])
+        except OSError as e:
+            place["rebound_after_init"]["error"] = f"sched_setaffinity: {e}"
+    elif not plan["bound"]:
+        place["rebound_after_init"]["error"] = plan["why_not"]
+    return place

@@ -10,6 +10,8 @@
 #include <thread>
 #include <vector>
 
+#include <cstdlib>
+#include <malloc.h>
 #include <sys/mman.h>
 #include <sys/wait.h>
 #include <unistd.h>
@@ -21,6 +23,9 @@ static uint64_t splitmix(uint64_t &s)
     z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
     return z ^ (z >> 31);
 }
+
+#define BAD() (fprintf(stderr, "check failed at line %d\n", __LINE__), ++bad)
+#define NOTE(msg) fprintf(stderr, "%s (line %d)\n", msg, __LINE__)
 
 int main()
 {
@@ -73,6 +78,97 @@ int main()
         if (nus::parallel_populate_prepare(fresh + off, n)) ++bad; // resident now: nothing to do
         for (size_t i = n - 4096; i < n; ++i) bad += fresh[off + i] != 0;
         munmap(fresh, n + 8192);
+    }
+    // populate requests on every kind of caller memory the host path can be handed (round 5, after the unexplained abort of
+    // round 4): blocks shorter than a page and blocks that straddle one page boundary (nothing to do, nothing touched), a piece
+    // of the program break's heap and a piece of a larger malloc block (populated, never hinted), a block that is its own
+    // mapping (hinted), and every one of them given back to the allocator IMMEDIATELY after the wait -- a request that outlived
+    // its wait would then touch freed or unmapped memory (the sanitizer builds of this program report it)
+    {
+        // never a page of its own: the predicate that guards the transparent-huge-page hint
+        std::vector<char> small(1 << 16, 1);
+        if (nus::parallel_populate_own_mapping(small.data(), small.size())) BAD();
+        if (!nus::parallel_populate_own_mapping(small.data(), (size_t)32 << 20)) BAD(); // by size alone (never dereferenced)
+        for (size_t len : {(size_t)1, (size_t)100, (size_t)4095, (size_t)4097, (size_t)8191}) {
+            char *b = static_cast<char *>(malloc(len + 4096));
+            memset(b, 0x5A, len + 4096);
+            nus::CopyTicket t;
+            nus::parallel_populate_async(b + 7, len, t);
+            nus::parallel_copy_wait(t);
+            for (size_t i = 0; i < len + 4096; ++i) bad += b[i] != 0x5A;
+            free(b);
+        }
+#if !defined(__SANITIZE_ADDRESS__) && !defined(__SANITIZE_THREAD__)
+        // the program break's heap: with the mmap threshold at its maximum (what glibc's dynamic threshold reaches by itself once
+        // a 32 MB block has been freed) a 9 MB block is carved out of it, and with a small trim threshold free() gives the
+        // range back to the kernel at once (the sanitizers' allocators do neither)
+        mallopt(M_MMAP_THRESHOLD, 32 << 20);
+        mallopt(M_TRIM_THRESHOLD, 128 << 10);
+        for (int round = 0; round < 3; ++round) {
+            const size_t brk_len = (size_t)9 << 20;
+            char *base = static_cast<char *>(malloc(brk_len));
+            const bool on_brk = base < static_cast<char *>(sbrk(0)) && base + brk_len <= static_cast<char *>(sbrk(0));
+            if (!on_brk) NOTE("(malloc did not use the program break: skipped)");
+            if (on_brk && nus::parallel_populate_own_mapping(base + 32, brk_len - 32)) BAD(); // a heap chunk, not a mapping
+            nus::CopyTicket t;
+            (void)nus::parallel_populate_prepare(base + 32, brk_len - 32);
+            nus::parallel_populate_async(base + 32, brk_len - 32, t);
+            nus::parallel_copy_wait(t);
+            free(base); // top of the heap, above the trim threshold: unmapped now
+        }
+        mallopt(M_MMAP_THRESHOLD, 128 << 10); // back to the default for the blocks below
+        // blocks the allocator maps for themselves: glibc's mmapped chunks (33 MB is above the initial threshold of 128 KiB; both
+        // are allocated before either is freed -- freeing one raises the threshold to its size and the next 33 MB block comes
+        // from the program break, which is exactly the case the predicate must answer "no" to, checked last)
+        {
+            const size_t n = (size_t)3840 * 2160 * 4, offs[2] = {0, 32}; // a Vec's pointer; a PyBytes' (32-byte object header first)
+            char *blk[2] = {static_cast<char *>(malloc(n + offs[0])), static_cast<char *>(malloc(n + offs[1]))};
+            for (int k = 0; k < 2; ++k) {
+                const size_t off = offs[k];
+                if (!nus::parallel_populate_own_mapping(blk[k] + off, n)) BAD();
+                if (nus::parallel_populate_own_mapping(blk[k] + off + 8192, n - 8192)) BAD(); // the inside of a block is not a block
+                nus::CopyTicket t;
+                if (nus::parallel_copy_workers() > 0 && !nus::parallel_populate_prepare(blk[k] + off, n)) BAD();
+                nus::parallel_populate_async(blk[k] + off, n, t);
+                nus::parallel_copy_wait(t);
+            }
+            free(blk[0]); // munmap: a late request would fault
+            free(blk[1]);
+            char *again = static_cast<char *>(malloc(n)); // now served from the heap (dynamic mmap threshold): never hinted
+            const bool heap_block = (reinterpret_cast<uintptr_t>(again) & 4095) != 16;
+            if (heap_block && nus::parallel_populate_own_mapping(again, n)) BAD();
+            nus::CopyTicket t;
+            nus::parallel_populate_async(again, n, t);
+            nus::parallel_copy_wait(t);
+            free(again);
+        }
+        // a piece of a larger malloc block: its own pages, but not its own mapping
+        {
+            const size_t n = (size_t)40 << 20;
+            char *blk = static_cast<char *>(calloc(1, n));
+            if (nus::parallel_populate_own_mapping(blk + ((size_t)4 << 20) + 16, (size_t)20 << 20)) BAD();
+            free(blk);
+        }
+#endif
+        // many tickets in flight at once, each buffer freed right after its own wait while the others' requests are still queued
+        std::vector<std::thread> th;
+        for (int k = 0; k < 4; ++k)
+            th.emplace_back([&, k] {
+                for (int round = 0; round < 16; ++round) {
+                    const size_t n = ((size_t)2 << 20) + (size_t)((k * 16 + round) * 123457 % (6 << 20));
+                    char *b = static_cast<char *>(malloc(n));
+                    std::vector<char> src(n, (char)(k + round));
+                    nus::CopyTicket pop, cp;
+                    nus::parallel_populate_async(b, n, pop);
+                    nus::parallel_copy_async(b, src.data(), n, cp);
+                    nus::parallel_copy_wait(cp);
+                    nus::parallel_copy_wait(pop);
+                    if (pop.left != 0 || cp.left != 0 || memcmp(b, src.data(), n) != 0) BAD();
+                    free(b);
+                }
+            });
+        for (auto &t : th) t.join();
+        if (nus::parallel_copy_pending() != 0) BAD(); // nothing may outlive the waits
     }
     // a forked child has the pool's state but none of its threads: it must still copy (alone) and exit cleanly
     const pid_t pid = fork();

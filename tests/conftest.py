@@ -8,12 +8,15 @@ try:  # torch bundles its own HIP runtime: load it before libnuscaler_hip.so pul
 except Exception:  # pragma: no cover
     torch = None
 
-# A fatal message of glibc (heap corruption, stack smashing) goes to the controlling terminal unless this is set: one full GPU run
-# of round 4 died of SIGABRT with nothing but "Fatal Python error: Aborted" in its log.  With it the cause would have been in the log.
+# Round 4: one full GPU run died of SIGABRT with nothing but "Fatal Python error: Aborted" in its log.  Why nothing: pytest's
+# fd-level capture holds file descriptor 2 while a test runs, so whatever the aborting runtime said (glibc, ROCr, libstdc++ all
+# write to fd 2) went into a capture file that died with the process.  pytest.ini now runs the suite with --capture=sys, and the
+# handler installed below (tests/helpers/abort_trace.c) writes the NATIVE backtrace of the aborting thread -- which library
+# called abort -- in front of faulthandler's Python frames.  (LIBC_FATAL_STDERR_ only matters to glibc < 2.27; kept for those.)
 os.environ.setdefault("LIBC_FATAL_STDERR_", "1")
 import faulthandler  # noqa: E402
 
-faulthandler.enable(all_threads=True)
+faulthandler.enable(file=sys.__stderr__, all_threads=True)  # (sys.stderr is pytest's capture object under --capture=sys)
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "tests")):
@@ -25,6 +28,13 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def pytest_sessionstart(session):
+    # after every plugin's configure step (pytest's own faulthandler plugin included): outermost handler, real stderr
+    from helpers import abort_trace
+
+    abort_trace.install(2)
 
 
 @pytest.fixture(scope="session")

@@ -463,6 +463,76 @@ def test_upscale_batch_pipeline_many_frames_every_buffer_kind(nsc, oracle_mod):
     assert np.array_equal(np.frombuffer(u.upscale(ins[2]), np.uint8).reshape(2 * h, 2 * w, 4), want[2])
 
 
+def test_failed_retire_mid_batch_leaves_nothing_queued(nsc, oracle_mod):
+    """A frame whose wait fails in the middle of a batch (test hook "inject_retire_error": what a lost device looks like) fails the
+    call -- and every frame that had been SUBMITTED is still retired: before round 5 the retiring thread left at the first failure,
+    the populate requests of the frames in the other slots stayed queued in the process-wide pool with pointers into the result
+    buffers the caller frees next and into the slots' tickets inside the upscaler.  Checked at 1080p -> 4K with fresh
+    `bytes` results (33 MB each: the buffers that get populate requests), for the batch, the single call and the ring: nothing
+    is pending when the failing call returns, the handle can be destroyed at once, and a new one computes correct frames."""
+    import gc
+
+    w, h, n = 1920, 1080, 7
+    frames = [oracle_mod.gen_noise(w, h, 900 + i) for i in range(2)]
+    want = [oracle_mod.bilinear(f, 2 * w, 2 * h, threads=0) for f in frames]
+    ins = [frames[i % 2].tobytes() for i in range(n)]
+    lib = nsc._capi.lib()
+    for fail_at in (1, 2, 3, 5):
+        u = nsc.PyWgpuUpscaler("quality", "bilinear")
+        u.initialize(w, h, 2 * w, 2 * h)
+        u.set_option("inject_retire_error", fail_at)
+        with pytest.raises(RuntimeError, match="HIP error in hipEventSynchronize"):
+            u.upscale_batch(ins)
+        assert lib.nus_host_pending_pieces() == 0, fail_at
+        del u
+        gc.collect()
+        assert lib.nus_host_pending_pieces() == 0
+    u = nsc.PyWgpuUpscaler("quality", "bilinear")
+    u.initialize(w, h, 2 * w, 2 * h)
+    u.set_option("inject_retire_error", 1)
+    with pytest.raises(RuntimeError, match="HIP error in hipEventSynchronize"):
+        u.upscale(ins[0])
+    assert lib.nus_host_pending_pieces() == 0
+    outs = u.upscale_batch(ins)  # the same handle goes on working
+    assert all(np.array_equal(np.frombuffer(o, np.uint8).reshape(2 * h, 2 * w, 4), want[i % 2]) for i, o in enumerate(outs))
+    # the ring: the failure is sticky, every submitted frame is still retired before stream_close returns
+    bufs = [bytearray(u.output_size) for _ in range(4)]
+    u.stream_open()
+    u.set_option("inject_retire_error", 2)
+    tickets = []
+    try:
+        for i in range(4):
+            tickets.append(u.stream_submit(ins[i], bufs[i]))
+    except RuntimeError:
+        pass
+    with pytest.raises(RuntimeError):
+        u.stream_close()
+    assert lib.nus_host_pending_pieces() == 0
+    del bufs, u
+    gc.collect()
+    u = nsc.PyWgpuUpscaler("quality", "bilinear")
+    u.initialize(w, h, 2 * w, 2 * h)
+    assert np.array_equal(np.frombuffer(u.upscale(ins[1]), np.uint8).reshape(2 * h, 2 * w, 4), want[1])
+
+
+def test_probe_one_read_four_writes_refuses_partial_waves(nsc):
+    """nus_probe_device kind 4 writes four contiguous KiB per wave: a size that is not a whole number of waves (1 KiB of input each)
+    used to store up to 3 KiB past 4 * bytes; now it is refused, and whole waves write exactly 4 * bytes."""
+    import torch
+
+    dev = torch.device("cuda:0")
+    lib = nsc._capi.lib()
+    src = torch.arange(0, 4096, dtype=torch.int32, device=dev)  # 16 KiB
+    dst = torch.full((4 * 4096 + 4096,), -1, dtype=torch.int32, device=dev)  # 4 x 16 KiB + a guard
+    for bad in (16, 1008, 1040, 16 * 1024 - 16):
+        assert lib.nus_probe_device(4, src.data_ptr(), dst.data_ptr(), bad, 0, None) == nsc._capi.ERR_INVALID_ARGUMENT
+    torch.cuda.synchronize()
+    assert int((dst != -1).sum()) == 0
+    assert lib.nus_probe_device(4, src.data_ptr(), dst.data_ptr(), 16 * 1024, 0, None) == nsc._capi.OK
+    torch.cuda.synchronize()
+    assert int((dst[:4 * 4096] == -1).sum()) == 0 and int((dst[4 * 4096:] != -1).sum()) == 0
+
+
 def test_stream_ring_frames_in_one_at_a_time(nsc, oracle_mod):
     """The persistent ring (nus_upscaler_stream_*): 20 frames submitted one by one with three in flight, results in order into
     caller-owned buffers (pageable and pinned), waited for from another thread; the other host entry points are refused while

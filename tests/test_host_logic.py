@@ -411,6 +411,70 @@ def test_copy_pool_stress(tmp_path):
             assert f"workers {threads} " in run.stdout
 
 
+def _sanitizer_build(tmp_path, name, sources, extra=()):
+    import shutil
+    import subprocess
+    if shutil.which("g++") is None:
+        pytest.skip("g++ not available")
+    src_dir = os.path.join(ROOT, "nu_scaler_amd", "csrc")
+    exe = str(tmp_path / name)
+    cmd = ["g++", "-O1", "-g", "-fsanitize=address,undefined", "-fno-omit-frame-pointer", "-std=c++17", "-pthread", "-I", src_dir,
+           *sources, *extra, "-o", exe]
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if res.returncode != 0 and ("asan" in (res.stderr or "").lower() or "ubsan" in (res.stderr or "").lower()):
+        pytest.skip("libasan / libubsan not installed")
+    assert res.returncode == 0, res.stderr
+    return exe
+
+
+_SAN_ENV = {"ASAN_OPTIONS": "detect_leaks=0:abort_on_error=0:exitcode=67", "UBSAN_OPTIONS": "print_stacktrace=1:halt_on_error=1:exitcode=68"}
+
+
+def test_copy_pool_stress_under_address_and_ub_sanitizers(tmp_path):
+    """Round 5: the copy pool and its populate requests under -fsanitize=address,undefined -- buffers shorter
+    than a page, buffers given back to the allocator immediately after their wait while other tickets' requests are still queued,
+    requests racing with copies into one fresh mapping.  (detect_leaks=0: the pool is never destroyed by design, and the forked
+    child of the program has its thread objects but none of its threads.)"""
+    import subprocess
+    src_dir = os.path.join(ROOT, "nu_scaler_amd", "csrc")
+    exe = _sanitizer_build(tmp_path, "copy_pool_stress_asan",
+                           [os.path.join(ROOT, "tests", "c_abi", "copy_pool_stress.cpp"), os.path.join(src_dir, "nus_copy.cpp")])
+    for threads in ("3", "0"):
+        run = subprocess.run([exe], capture_output=True, text=True, env=dict(os.environ, NUS_COPY_THREADS=threads, **_SAN_ENV), timeout=600)
+        assert run.returncode == 0 and "bad 0" in run.stdout and "ERROR: AddressSanitizer" not in run.stderr \
+            and "runtime error" not in run.stderr, run.stdout + run.stderr
+
+
+def test_copy_pool_stress_with_two_cpus(tmp_path):
+    """The corner an 8-rank job on a 16-CPU box reaches: two CPUs per process leave no CPU for a worker beside the submitting
+    and the retiring thread (nus_copy.cpp: n = cpus - 2 = 0) -- every copy is then done by its caller, populate requests are
+    declined, and nothing may wait for a worker that does not exist."""
+    import shutil
+    import subprocess
+    if shutil.which("g++") is None or shutil.which("taskset") is None or len(os.sched_getaffinity(0)) < 2:
+        pytest.skip("needs g++, taskset and two CPUs")
+    src_dir = os.path.join(ROOT, "nu_scaler_amd", "csrc")
+    exe = str(tmp_path / "copy_pool_stress")
+    res = subprocess.run(["g++", "-O2", "-std=c++17", "-pthread", "-I", src_dir, os.path.join(ROOT, "tests", "c_abi", "copy_pool_stress.cpp"),
+                          os.path.join(src_dir, "nus_copy.cpp"), "-o", exe], capture_output=True, text=True)
+    assert res.returncode == 0, res.stderr
+    cpus = sorted(os.sched_getaffinity(0))[:2]
+    env = {k: v for k, v in os.environ.items() if k != "NUS_COPY_THREADS"}
+    run = subprocess.run(["taskset", "-c", ",".join(map(str, cpus)), exe], capture_output=True, text=True, env=env, timeout=300)
+    assert run.returncode == 0 and "workers 0 bad 0" in run.stdout, run.stdout + run.stderr
+
+
+def test_host_tables_and_queue_under_address_and_ub_sanitizers(tmp_path):
+    """nus_tables.cpp (every builder over a sweep of sizes, ratios and filters, the exact-ratio views, serialisation round trips
+    and damaged blobs) and the frame queue, built with -fsanitize=address,undefined (tests/c_abi/host_tables_sanitize.cpp)."""
+    import subprocess
+    src_dir = os.path.join(ROOT, "nu_scaler_amd", "csrc")
+    exe = _sanitizer_build(tmp_path, "host_tables_asan",
+                           [os.path.join(ROOT, "tests", "c_abi", "host_tables_sanitize.cpp"), os.path.join(src_dir, "nus_tables.cpp")])
+    run = subprocess.run([exe], capture_output=True, text=True, env=dict(os.environ, **_SAN_ENV), timeout=600)
+    assert run.returncode == 0 and "bad 0" in run.stdout and "runtime error" not in run.stderr, run.stdout + run.stderr
+
+
 def test_copy_pool_stress_under_thread_sanitizer(tmp_path):
     """The same program built with -fsanitize=thread (CPU build; GPU sanitizers are not available on this pool): copies, populate
     requests racing with copies into the same fresh mapping, the low-priority queue, worker start-up and shutdown -- no report."""

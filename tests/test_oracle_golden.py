@@ -135,3 +135,26 @@ def test_many_core_resize_is_bit_identical_to_the_oracle(oracle_mod, filt):
             assert np.array_equal(oracle_mod.resize(img, ow, oh, filt, threads=threads), want), (filt, iw, ih, ow, oh, threads)
     big = oracle_mod.gen_gradient(640, 360, 3)
     assert np.array_equal(oracle_mod.lanczos3(big, 1280, 720, threads=0), oracle_mod.lanczos3(big, 1280, 720))
+
+
+def test_oracle_mt_entries_under_address_and_ub_sanitizers(tmp_path):
+    """Every orc_*_mt entry at 1920x1080 with threads=0 (all cores) and odd thread counts, and ragged small sizes, in a build of
+    the oracle with -fsanitize=address,undefined (tests/c_abi/oracle_mt_sanitize.c).  Round 5: orc_warp_blend_mt(.., threads=0)
+    at this size was the last native call before round 4's unexplained abort; no report."""
+    import os
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("gcc not available")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "oracle_mt_asan")
+    cmd = ["gcc", "-O1", "-g", "-fsanitize=address,undefined", "-fno-omit-frame-pointer", "-ffp-contract=off", "-fopenmp", "-std=c11",
+           "-I", os.path.join(root, "oracle"), os.path.join(root, "tests", "c_abi", "oracle_mt_sanitize.c"),
+           os.path.join(root, "oracle", "nus_oracle.c"), "-lm", "-o", exe]
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if res.returncode != 0 and "san" in (res.stderr or "").lower():
+        pytest.skip("libasan / libubsan not installed")
+    assert res.returncode == 0, res.stderr
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:exitcode=67", UBSAN_OPTIONS="print_stacktrace=1:halt_on_error=1:exitcode=68")
+    run = subprocess.run([exe], capture_output=True, text=True, env=env, timeout=900)
+    assert run.returncode == 0 and "all ok" in run.stdout and "runtime error" not in run.stderr, run.stdout[-2000:] + run.stderr[-4000:]

@@ -1,5 +1,6 @@
 """Per-rank CPU placement (nu_scaler_amd/placement.py): the planning step on made-up topologies (no GPU, no real sysfs), the
 cpulist helpers, and that bind_rank degrades to "not bound" with a reason on a box without a HIP device."""
+import json
 import os
 
 import pytest
@@ -97,6 +98,66 @@ def test_bind_rank_without_a_gpu_reports_and_changes_nothing(nsc, monkeypatch):
     assert rep["cpus_per_rank"] == max(1, min(len(before) // 2, int((p.cgroup_cpu_quota() or 1e9) / 2 + 0.5)))
     assert os.environ["NUS_COPY_THREADS"] == str(rep["copy_threads"])
     assert os.environ["OMP_NUM_THREADS"] == str(rep["omp_threads"])
+    json.dumps(rep)  # the report goes into a bench line as it is
+
+
+def test_bind_rank_respects_thread_counts_the_operator_set(nsc, monkeypatch):
+    """NUS_COPY_THREADS / OMP_NUM_THREADS set by hand win over the rank's budget and are reported as such; the
+    launcher's own OMP_NUM_THREADS default (marked) and the values an earlier bind_rank wrote do not count as the operator's."""
+    from nu_scaler_amd import placement as p
+
+    for k in ("NUS_COPY_THREADS", "OMP_NUM_THREADS", p.LAUNCHER_OMP_MARK, "NUS_COPY_THREADS_FROM_PLACEMENT"):
+        monkeypatch.delenv(k, raising=False)
+    monkeypatch.setenv("NUS_COPY_THREADS", "1")
+    monkeypatch.setenv("OMP_NUM_THREADS", "3")
+    rep = p.bind_rank(0, 1, sysfs="/nonexistent")
+    assert rep["copy_threads"] == 1 and rep["omp_threads"] == 3 and rep["copy_threads_from_env"] and rep["omp_threads_from_env"]
+    assert os.environ["NUS_COPY_THREADS"] == "1" and os.environ["OMP_NUM_THREADS"] == "3"
+    # the launcher's default: re-sized
+    monkeypatch.delenv("NUS_COPY_THREADS")
+    monkeypatch.setenv("OMP_NUM_THREADS", "4")
+    monkeypatch.setenv(p.LAUNCHER_OMP_MARK, "1")
+    rep = p.bind_rank(0, 1, sysfs="/nonexistent")
+    assert "omp_threads_from_env" not in rep and os.environ["OMP_NUM_THREADS"] == str(rep["omp_threads"]) == str(rep["cpus_per_rank"])
+    first = os.environ["NUS_COPY_THREADS"]
+    rep2 = p.bind_rank(0, 2, sysfs="/nonexistent")  # a second plan may overwrite what the first one wrote
+    assert "copy_threads_from_env" not in rep2 and os.environ["NUS_COPY_THREADS"] == str(rep2["copy_threads"])
+    assert int(first) >= int(os.environ["NUS_COPY_THREADS"])
+    # apply=False touches nothing
+    monkeypatch.setenv("NUS_COPY_THREADS", "5")
+    monkeypatch.delenv("NUS_COPY_THREADS_FROM_PLACEMENT")
+    p.bind_rank(0, 1, sysfs="/nonexistent", apply=False)
+    assert os.environ["NUS_COPY_THREADS"] == "5"
+
+
+def test_verify_after_init_replans_from_the_address_hip_reports(nsc, tmp_path, monkeypatch):
+    """The sysfs order was not HIP's on this (made-up) box: the rank planned for the GPU on node 0, HIP says its device is the one
+    on node 1 -- the binding is planned again from HIP's address, applied, and the report says so."""
+    from nu_scaler_amd import placement as p
+
+    mask = sorted(os.sched_getaffinity(0))
+    if len(mask) < 4:
+        pytest.skip("needs four CPUs")
+    half = len(mask) // 2
+    sysfs = tmp_path / "sys"
+    for bdf, node, cpus in (("0000:05:00.0", 0, mask[:half]), ("0000:85:00.0", 1, mask[half:])):
+        d = sysfs / "bus" / "pci" / "devices" / bdf
+        d.mkdir(parents=True)
+        (d / "numa_node").write_text(f"{node}\n")
+        (d / "local_cpulist").write_text(p.format_cpulist(cpus) + "\n")
+    devices = [p.pci_numa("0000:05:00.0", str(sysfs)), p.pci_numa("0000:85:00.0", str(sysfs))]
+    applied = []
+    monkeypatch.setattr(os, "sched_setaffinity", lambda pid, cpus: applied.append(sorted(cpus)))
+    plan = p.plan_binding(devices, 0, 2, mask, None, str(sysfs))
+    place = {"bound": True, "gpu_bdf": "0000:05:00.0", "numa_node": 0, "cpus": p.format_cpulist(plan["cpus"]), "local_world": 2,
+             "cgroup_cpu_quota": None, "_replan": {"devices": devices, "mask": mask, "slot": None, "device_index": 0}}
+    same = p.verify_after_init(dict(place, _replan=dict(place["_replan"])), "0000:05:00.0", str(sysfs))
+    assert same["gpu_bdf_verified"] is True and "rebound_after_init" not in same and "_replan" not in same and not applied
+    moved = p.verify_after_init(place, "0000:85:00.0", str(sysfs))
+    assert moved["gpu_bdf_verified"] is False and moved["rebound_after_init"]["ok"] and moved["numa_node"] == 1
+    assert applied and set(applied[-1]) <= set(mask[half:]) and moved["gpu_bdf"] == "0000:85:00.0"
+    assert moved["rebound_after_init"]["planned_bdf"] == "0000:05:00.0"
+    json.dumps(moved)
 
 
 def test_enumerate_gpus_from_the_kfd_topology(nsc, tmp_path):
