@@ -45,7 +45,6 @@ from __future__ import annotations
 import argparse
 import json
 import os
-import socket
 import subprocess
 import sys
 import time
@@ -123,28 +122,12 @@ def parse_args(argv=None):
 # N > 1 started directly: launch the ranks as a child process tree (never exec, never touch HIP)
 # ---------------------------------------------------------------------------------------------
 
-def _free_port() -> int:
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
-    return port
-
-
 def launch_ranks(nproc: int, script: str, script_args, timeout=None):
-    """Start `python -m torch.distributed.run --nproc-per-node nproc script *script_args` as a child
-    process and wait for it.  Returns (returncode, [stdout lines]).  The caller has not imported
-    torch.cuda or loaded libnuscaler_hip.so: this process stays off the GPU, the ranks are its
-    grandchildren.  Rendezvous on 127.0.0.1 (the container hostname may not resolve)."""
-    env = dict(os.environ)
-    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL needs it on this driver
-    if "OMP_NUM_THREADS" not in env:  # torchrun's own default is 1; each rank re-sizes it from its CPU share (placement) --
-        env["OMP_NUM_THREADS"] = "4"  # unless the operator set one: the mark tells the ranks this value is the launcher's
-        env["NUS_OMP_THREADS_FROM_LAUNCHER"] = "1"
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={int(nproc)}",
-           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), script, *script_args]
-    res = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True, timeout=timeout)
-    return res.returncode, res.stdout.splitlines()
+    """The product's launcher (nu_scaler_amd.launch.launch_ranks: `python -m torch.distributed.run` as a CHILD process, never an
+    exec; this process stays off the GPU -- importing the package loads neither torch nor libnuscaler_hip.so)."""
+    from nu_scaler_amd import launch
+
+    return launch.launch_ranks(nproc, script, script_args, timeout=timeout)
 
 
 def main_launcher(args) -> int:
@@ -349,29 +332,16 @@ def check_timed_outputs(frames, mid_t, up_real, up_mid, picks, w, h, first_frame
 
 
 def gather_rows(row, world, dist=None, torch=None, comm_dev=None):
-    """Every rank's row of numbers on every rank: ONE all_gather of a float64 vector (keys sorted; None travels as NaN).
-    world == 1: no collective.  Used for everything rank 0's line says about the other ranks."""
-    keys = sorted(row)
-    if world == 1:
-        return [dict(row)]
-    vals = [float("nan") if row[k] is None else float(row[k]) for k in keys]
-    t = torch.tensor(vals, dtype=torch.float64, device=comm_dev)
-    got = [torch.zeros_like(t) for _ in range(world)]
-    dist.all_gather(got, t)
-    rows = []
-    for g in got:
-        rows.append({k: (None if x != x else x) for k, x in zip(keys, g.cpu().tolist())})
-    return rows
+    """nu_scaler_amd.stream.gather_rows (every rank's row of numbers on every rank: one all_gather of a float64 vector)."""
+    from nu_scaler_amd import stream as S
+
+    return S.gather_rows(row, world, dist, torch, comm_dev)
 
 
 def spread(rows, key, digits=4):
-    """{min, max, by_rank} of one gathered column (None where no rank has it)."""
-    xs = [r.get(key) for r in rows]
-    have = [x for x in xs if x is not None]
-    if not have:
-        return None
-    return {"min": round(min(have), digits), "max": round(max(have), digits),
-            "by_rank": [None if x is None else round(x, digits) for x in xs]}
+    from nu_scaler_amd import stream as S
+
+    return S.spread(rows, key, digits)
 
 
 def pcie_ceiling(torch, dev, n_in, n_out):
@@ -799,111 +769,59 @@ def worker(args):
     if world != args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE is {world}")
     device_index = args.force_device if args.force_device >= 0 else local_rank
+    nccl = args.backend == "nccl"
     _install_crash_reports()
 
-    # Before this process makes its first HIP call: onto the CPUs of its GPU's NUMA node (a disjoint run of whole cores per
-    # rank), host threads sized to the rank's share of the CPUs the job may keep busy (copy pool, OpenMP teams).  The GPU's PCI
-    # address is asked of a child process; never a re-exec.
-    from nu_scaler_amd import placement as plc
+    # The rank's whole set-up is the product's (nu_scaler_amd.stream.ShardedStream; `python -m nu_scaler_amd.cli stream` runs the
+    # same object): onto the CPUs of its GPU's NUMA node BEFORE the first HIP call, host threads sized to the rank's CPU share,
+    # the process group, the pipeline, rank 0's LUTs to everyone (RCCL over xGMI), this rank's contiguous shard of the global
+    # stream plus the overlap frame, resident in HBM.  bench.py adds the measurement around it.
+    import nu_scaler_amd as nsc  # (importing the package loads neither torch nor the library)
+    from nu_scaler_amd import stream as S
+    from nu_scaler_amd import synthetic as syn
 
-    if args.no_bind:
-        place = plc.bind_rank(device_index, local_world, apply=False)
-        place.update(bound=False, why_not="--no-bind")
-    else:
-        place = plc.bind_rank(device_index, local_world, slot=local_rank if args.force_device >= 0 else None)
-
+    w, h = args.width, args.height
+    n_units = args.units
+    schedule = "fused" if args.fused else ("unit" if args.schedule == "unit" and not args.overlap else "three-stage")
+    try:
+        sh = S.ShardedStream(n_units * world, w, h, source=S.SyntheticSource(args.pattern), backend=args.backend,
+                             bind=not args.no_bind, force_device=args.force_device, schedule=schedule,
+                             lanczos_mode=args.lanczos_mode)
+    except RuntimeError as e:
+        raise SystemExit(f"bench.py: {e}")
     import torch
     import torch.distributed as dist
 
-    import nu_scaler_amd as nsc
-    from nu_scaler_amd import synthetic as syn
-
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
-    torch.cuda.set_device(device_index)
-    dev = torch.device("cuda", device_index)
-    nccl = args.backend == "nccl"
-    comm_dev = dev if nccl else torch.device("cpu")  # gloo rehearsal: collectives on host tensors
-    if world > 1:
-        if nccl:
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-        else:
-            dist.init_process_group(args.backend, rank=rank, world_size=world)
-    # the binding was planned from sysfs before HIP was up: now that it is, HIP's own word on where this rank's device sits; a
-    # mismatch re-plans the CPU binding from HIP's address (placement.verify_after_init) and is flagged in rank 0's line
-    try:
-        pr = torch.cuda.get_device_properties(device_index)
-        hip_bdf = f"{int(getattr(pr, 'pci_domain_id', 0)):04x}:{int(pr.pci_bus_id):02x}:{int(pr.pci_device_id):02x}.0"
-    except Exception as e:  # an older torch without the PCI fields
-        hip_bdf = None
-        place["gpu_bdf_by_hip"] = f"unavailable: {type(e).__name__}"
-    plc.verify_after_init(place, hip_bdf, apply=not args.no_bind)
-    bdf = place.get("gpu_bdf_by_hip") if hip_bdf else place.get("gpu_bdf")  # clocks and power are read from the device HIP names
+    place, pipe, dev, comm_dev = sh.placement, sh.pipeline, sh.device, sh.comm_device
+    if args.no_bind:
+        place.update(bound=False, why_not="--no-bind")
+    bdf = place.get("gpu_bdf_by_hip") if place.get("gpu_bdf_verified") is not None else place.get("gpu_bdf")
     my_cpus = max(1, int(place.get("cpus_per_rank") or 1))
-
-    w, h = args.width, args.height
-    pipe = nsc.FramePipeline(w, h, 2, "lanczos3", 0.5, device=device_index, lanczos_mode=args.lanczos_mode)
-    # shared LUTs: rank 0's tables to everyone (RCCL over xGMI), so all GPUs use identical weights
-    lut_bytes = nsc.broadcast_tables(pipe.upscaler, 0, comm_dev)
-
-    # this rank's contiguous shard of the global stream, plus the overlap frame
-    n_units = args.units
-    start, count = nsc.shard_frames(n_units * world, world, rank)
+    lut_bytes = sh.lut_bytes
+    start, count = sh.start, sh.count
     assert count == n_units
-    frames = torch.empty((count + 1, h, w, 4), dtype=torch.uint8, device=dev)
+    frames, mid, up_real, up_mid = sh.frames, sh.mid, sh.up_real, sh.up_mid
+    stream = sh.stream_handle()
+    barrier, gather = sh.barrier, sh.gather
 
     def fill(pattern):
-        for c0 in range(0, count + 1, 16):  # generate in chunks: int64 temporaries are 8x a frame
-            c1 = min(c0 + 16, count + 1)
-            if pattern == "gradient":
-                frames[c0:c1] = syn.gradient_stream_torch(c1 - c0, w, h, dev, first=start + c0)
-            else:
-                frames[c0:c1] = syn.noise_stream_torch(c1 - c0, w, h, dev, seed=0x5EED + start + c0)
+        sh.refill(S.SyntheticSource(pattern))
 
-    fill(args.pattern)
-    mid, up_real, up_mid = pipe.alloc(count, dev)
-    stream = torch.cuda.current_stream().cuda_stream
-
-    def barrier():
-        if world > 1:
-            if nccl:
-                dist.barrier(device_ids=[device_index])
-            else:
-                dist.barrier()
-
-    def gather(row):
-        return gather_rows(row, world, dist, torch, comm_dev)
-
-    unit_schedule = args.schedule == "unit" and not args.fused and not args.overlap
+    unit_schedule = schedule == "unit"
 
     def do_step():
-        if args.fused:
-            pipe.step_fused(frames, up_real, up_mid, stream)
-        elif args.overlap:
+        if args.overlap:
             pipe.step_overlapped(frames, mid, up_real, up_mid)
-        elif unit_schedule:
-            pipe.step_unit(frames, mid, up_real, up_mid, stream)
         else:
-            pipe.step(frames, mid, up_real, up_mid, stream)
+            sh.step()
 
-    for _ in range(args.warmup):
-        do_step()
-    torch.cuda.synchronize()
     profile = not args.no_profile
-    pipe.upscaler.set_profiling(profile)
-    pipe.upscaler.profile_collect()
 
-    barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        do_step()
-    torch.cuda.synchronize()
-    barrier()
-    elapsed_local = time.perf_counter() - t0
+    def before_timed():  # after the warm-up passes, before the first barrier: the hipEvent brackets of the timed launches
+        pipe.upscaler.set_profiling(profile)
+        pipe.upscaler.profile_collect()
+
+    elapsed_local = sh.run(args.steps, args.warmup, step=do_step, before_timed=before_timed)
 
     launches, kernel_ms = pipe.upscaler.profile_collect() if profile else (0, 0.0)
     pipe.upscaler.set_profiling(False)

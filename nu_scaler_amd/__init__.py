@@ -17,8 +17,9 @@ from .flow import FlowEstimator
 from .imagefile import interpolate_image_files, upscale_image_file
 from .interpolator import WgpuFrameInterpolator
 from .queue import FrameBuffer, swizzle_bgra_to_rgba_device
-from .stream import (FramePipeline, broadcast_blob, broadcast_tables, build_tables_blob, shard_frames,
-                     validate_tables_blob)
+from .launch import launch_ranks
+from .stream import (FramePipeline, ShardedStream, SyntheticSource, broadcast_blob, broadcast_tables, build_tables_blob,
+                     gather_rows, run_sharded, shard_frames, spread, validate_tables_blob)
 from .upscaler import PyAdvancedWgpuUpscaler, PyVramStats, PyWgpuUpscaler, create_advanced_upscaler
 
 # module constants of the reference's #[pymodule] (nu_scaler_core/src/lib.rs:746-761)
@@ -43,6 +44,7 @@ __all__ = [
     "upscale_image_file", "interpolate_image_files",
     "PyBenchmarkResult", "py_benchmark_upscaler", "py_run_comparison_benchmark",
     "WgpuFrameInterpolator", "FlowEstimator", "FrameBuffer", "swizzle_bgra_to_rgba_device", "FramePipeline", "shard_frames", "broadcast_tables",
+    "ShardedStream", "SyntheticSource", "run_sharded", "gather_rows", "spread", "launch_ranks",
     "broadcast_blob", "build_tables_blob", "validate_tables_blob",
     "NuScalerLibraryError", "PinnedBuffer", "build", "device_count",
     "QUALITY_ULTRA", "QUALITY_QUALITY", "QUALITY_BALANCED", "QUALITY_PERFORMANCE",

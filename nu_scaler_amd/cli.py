@@ -29,11 +29,75 @@ def build_parser() -> argparse.ArgumentParser:
     it.add_argument("--t", type=float, default=0.5, help="time of the new frame between A (0) and B (1)")
     it.add_argument("--flow", action="store_true", help="estimate motion (pyramid + Horn-Schunck) instead of zero flow")
     it.add_argument("--device", type=int, default=0)
+    st = sub.add_parser("stream", help="the sharded frame-queue stream: a synthetic 1080p stream through interpolate + x2 upscale "
+                                       "on N GPUs of this node, one process per GPU, frames sharded, LUTs broadcast over RCCL")
+    st.add_argument("--gpus", type=int, default=1, help="ranks = GPUs of this node (started as a child process tree)")
+    st.add_argument("--units", type=int, default=60, help="source frames per GPU (weak scaling: the stream has gpus x units)")
+    st.add_argument("--width", type=int, default=1920)
+    st.add_argument("--height", type=int, default=1080)
+    st.add_argument("--steps", type=int, default=5)
+    st.add_argument("--warmup", type=int, default=1)
+    st.add_argument("--pattern", default="gradient", choices=["gradient", "noise"])
+    st.add_argument("--schedule", default="unit", choices=["unit", "three-stage", "fused"])
+    st.add_argument("--algorithm", default="lanczos3", help="an exact-x2 resize filter: lanczos3, bicubic, triangle")
+    st.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="nccl = RCCL over xGMI; gloo: rehearsal")
+    st.add_argument("--force-device", type=int, default=-1, help="every rank on this device (rehearsal on a one-GPU box)")
+    st.add_argument("--no-bind", action="store_true", help="leave the ranks' CPU affinity alone")
+    st.add_argument("--digest", action="store_true", help="also print one digest per unit of the stream (sharding-invariant)")
     return ap
+
+
+def stream_command(args, argv) -> int:
+    """`stream`: started directly with --gpus N > 1 this process launches the N ranks as children (never an exec, never a HIP
+    call here) and relays rank 0's JSON line; inside a rank (or with one GPU) it runs the rank's whole job (stream.run_sharded)."""
+    import json
+
+    from . import launch
+
+    if args.gpus > 1 and not launch.under_launcher():
+        rc, lines = launch.launch_ranks(args.gpus, "nu_scaler_amd.cli", argv, module=True)
+        for ln in lines:
+            print(ln, flush=True, file=sys.stdout if ln.startswith("{") else sys.stderr)
+        return rc
+    import os
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        print(f"nu_scaler_cli: error: --gpus {args.gpus} but WORLD_SIZE is {world}", file=sys.stderr)
+        return 2
+    from . import stream as S
+
+    def sink(s):
+        if not args.digest:
+            return None
+        per_rank = -(-s.total_units // s.world)  # every rank sends the same number of columns
+        d = s.unit_digests()
+        return {f"digest_{k:05d}": (float(d[k]) if k < len(d) else None) for k in range(per_rank)}
+
+    out = S.run_sharded(args.units * args.gpus, args.width, args.height, steps=args.steps, warmup=args.warmup,
+                        source=S.SyntheticSource(args.pattern), sink=sink, backend=args.backend, bind=not args.no_bind,
+                        force_device=args.force_device, schedule=args.schedule, algorithm=args.algorithm)
+    if out["rank"] == 0:
+        rows = out.pop("rows")
+        if args.digest:
+            digests = []
+            for r in rows:
+                digests += [int(r[k]) for k in sorted(r) if k.startswith("sink_digest_") and r[k] is not None]
+            out["unit_digests"] = digests
+        out["bound_by_rank"] = [bool(r["bound"]) for r in rows]
+        out["numa_node_by_rank"] = [None if r["numa_node"] is None else int(r["numa_node"]) for r in rows]
+        print(json.dumps(out), flush=True)
+    return 0
 
 
 def main(argv=None) -> int:
     args = build_parser().parse_args(argv)
+    if args.command == "stream":
+        try:
+            return stream_command(args, list(sys.argv[1:] if argv is None else argv))
+        except (OSError, ValueError, RuntimeError) as e:
+            print(f"nu_scaler_cli: error: {e}", file=sys.stderr)
+            return 1
     from . import imagefile
     try:
         if args.command == "upscale":

@@ -284,7 +284,7 @@ def bind_rank(device_index: int, local_world: int, sysfs: str = "/sys", apply: b
             "_replan": {"devices": devices, "mask": mask, "slot": slot, "device_index": device_index}}
 
 
-LAUNCHER_OMP_MARK = "NUS_OMP_THREADS_FROM_LAUNCHER"  # set by launch_ranks when IT chose OMP_NUM_THREADS (torchrun's default is 1)
+from .launch import LAUNCHER_OMP_MARK  # set by launch_ranks when IT chose OMP_NUM_THREADS (torchrun's default is 1)
 
 
 def _apply_thread_budget(budget: Dict[str, int]) -> Dict:

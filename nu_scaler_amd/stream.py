@@ -208,3 +208,277 @@ class FramePipeline:
         self.upscaler.upscale_device(base, up_real.data_ptr(), n, main.cuda_stream)
         main.wait_event(self._ev_mid)
         self.upscaler.upscale_device(mid.data_ptr(), up_mid.data_ptr(), n, main.cuda_stream)
+
+
+# ---- the sharded frame-queue stream: one process per GPU, independent frames, no data-path collective ----------------------
+#
+# north_star: "a frame-queue stream shards independent frames across the 8 GPUs of one node with RCCL broadcast of shared LUTs
+# over xGMI only".  `ShardedStream` is one rank of it -- placement, process group, pipeline, LUT broadcast, this rank's contiguous
+# shard of the stream (+ the overlap frame), the step loop, the gather of every rank's numbers -- and `run_sharded` the whole
+# job of one rank in one call.  `python -m nu_scaler_amd.cli stream --gpus N` and bench.py are both built on it.
+
+
+def gather_rows(row, world, dist=None, torch=None, comm_dev=None):
+    """Every rank's row of numbers on every rank: ONE all_gather of a float64 vector (keys sorted; None travels as NaN).
+    world == 1: no collective."""
+    keys = sorted(row)
+    if world == 1:
+        return [dict(row)]
+    vals = [float("nan") if row[k] is None else float(row[k]) for k in keys]
+    t = torch.tensor(vals, dtype=torch.float64, device=comm_dev)
+    got = [torch.zeros_like(t) for _ in range(world)]
+    dist.all_gather(got, t)
+    rows = []
+    for g in got:
+        rows.append({k: (None if x != x else x) for k, x in zip(keys, g.cpu().tolist())})
+    return rows
+
+
+def spread(rows, key, digits=4):
+    """{min, max, by_rank} of one gathered column (None where no rank has it)."""
+    xs = [r.get(key) for r in rows]
+    have = [x for x in xs if x is not None]
+    if not have:
+        return None
+    return {"min": round(min(have), digits), "max": round(max(have), digits),
+            "by_rank": [None if x is None else round(x, digits) for x in xs]}
+
+
+class SyntheticSource:
+    """Frames [first, first + n) of a deterministic synthetic stream as an (n, h, w, 4) uint8 tensor on `device`, whoever asks
+    for them: frame k depends on k alone (never on the shard or the chunking), so a stream cut into shards is the stream.
+    pattern "gradient": S1 of SURVEY.md 8(d) (benchmark.rs:188-207) moving 1 px per frame, opaque; "noise": S3-like uniform
+    bytes, every frame from its own seed."""
+
+    def __init__(self, pattern: str = "gradient", seed: int = 0x5EED):
+        if pattern not in ("gradient", "noise"):
+            raise ValueError("pattern must be 'gradient' or 'noise'")
+        self.pattern, self.seed = pattern, int(seed)
+
+    def __call__(self, first: int, n: int, width: int, height: int, device):
+        import torch
+
+        from . import synthetic as syn
+
+        out = torch.empty((n, height, width, 4), dtype=torch.uint8, device=device)
+        if self.pattern == "gradient":
+            for c0 in range(0, n, 16):  # in chunks: the int64 temporaries are 8x a frame
+                c1 = min(c0 + 16, n)
+                out[c0:c1] = syn.gradient_stream_torch(c1 - c0, width, height, device, first=first + c0)
+        else:
+            for k in range(n):
+                out[k] = syn.noise_stream_torch(1, width, height, device, seed=self.seed + first + k)[0]
+        return out
+
+
+class ShardedStream:
+    """One rank of the sharded stream.  Construction does, in this order (the order matters):
+
+      1. rank / world from the launcher's environment (RANK, WORLD_SIZE, LOCAL_RANK, LOCAL_WORLD_SIZE; absent: a world of one);
+      2. placement: the process onto the CPUs of its GPU's NUMA node, host threads sized to its share -- BEFORE its first HIP
+         call (placement.bind_rank), checked against HIP's own word afterwards (placement.verify_after_init);
+      3. the process group (backend "nccl" = RCCL over xGMI; "gloo" for rehearsals on host tensors), unless one exists;
+      4. the pipeline on this rank's GPU, and rank 0's filter / index tables broadcast to everyone (the job's only collective
+         on the data side, a few KiB once);
+      5. this rank's contiguous shard of `total_units` units, frames [start, start + count] from `source` (count + 1 frames: the
+         overlap frame closes the last pair), and its output buffers -- everything resident in HBM.
+
+    `run(steps, warmup)` then times `steps` passes over the shard between two barriers; `gather(row)` brings every rank's
+    numbers to every rank; `close()` tears down what the object created.  No frame ever crosses to another GPU.
+
+    pipeline_factory(width, height, device_index, self) -> an object with .alloc(n, device), .step_unit / .step(frames, mid,
+    up_real, up_mid, stream), .unit_pixels, .unit_bytes and (optionally) .upscaler for the table broadcast; default: FramePipeline
+    on the HIP device.  (The CPU tests pass a host-tensor stand-in: the product itself has no CPU path.)"""
+
+    def __init__(self, total_units: int, width: int, height: int, *, source=None, backend: str = "nccl", bind: bool = True,
+                 force_device: int = -1, schedule: str = "unit", algorithm: str = "lanczos3", time_t: float = 0.5,
+                 lanczos_mode: str = "fma", pipeline_factory=None, environ=None, device_kind: str = "cuda"):
+        import os
+
+        env = os.environ if environ is None else environ
+        self.world = int(env.get("WORLD_SIZE", "1"))
+        self.rank = int(env.get("RANK", "0"))
+        self.local_rank = int(env.get("LOCAL_RANK", "0"))
+        self.local_world = int(env.get("LOCAL_WORLD_SIZE", str(self.world)))
+        if not (0 <= self.rank < self.world):
+            raise ValueError(f"RANK {self.rank} outside WORLD_SIZE {self.world}")
+        if schedule not in ("unit", "three-stage", "fused"):
+            raise ValueError("schedule must be 'unit', 'three-stage' or 'fused'")
+        self.width, self.height, self.schedule, self.backend = int(width), int(height), schedule, backend
+        self.device_index = int(force_device) if force_device >= 0 else self.local_rank
+        on_gpu = device_kind == "cuda"
+
+        # 2. placement, before anything of this process touches HIP
+        from . import placement as plc
+
+        slot = self.local_rank if force_device >= 0 else None
+        self.placement = plc.bind_rank(self.device_index, self.local_world, apply=bool(bind) and on_gpu, slot=slot)
+        if not bind:
+            self.placement.update(bound=False, why_not="binding turned off by the caller")
+
+        import torch
+        import torch.distributed as dist
+
+        self._torch, self._dist = torch, dist
+        if on_gpu:
+            if not torch.cuda.is_available():
+                raise RuntimeError("the sharded stream needs a HIP device (no CPU fallback)")
+            torch.cuda.set_device(self.device_index)
+            self.device = torch.device("cuda", self.device_index)
+        else:
+            self.device = torch.device("cpu")
+        nccl = backend == "nccl"
+        if nccl and not on_gpu:
+            raise ValueError("backend 'nccl' needs device_kind 'cuda'")
+        self.comm_device = self.device if nccl else torch.device("cpu")
+        # 3. the process group
+        self._own_group = False
+        if self.world > 1 and not (dist.is_available() and dist.is_initialized()):
+            env_set = os.environ.setdefault
+            env_set("MASTER_ADDR", "127.0.0.1")
+            env_set("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            if nccl:
+                dist.init_process_group("nccl", rank=self.rank, world_size=self.world, device_id=self.device)
+            else:
+                dist.init_process_group(backend, rank=self.rank, world_size=self.world)
+            self._own_group = True
+        hip_bdf = None
+        if on_gpu:
+            try:
+                pr = torch.cuda.get_device_properties(self.device_index)
+                hip_bdf = f"{int(getattr(pr, 'pci_domain_id', 0)):04x}:{int(pr.pci_bus_id):02x}:{int(pr.pci_device_id):02x}.0"
+            except Exception as e:  # an older torch without the PCI fields
+                self.placement["gpu_bdf_by_hip"] = f"unavailable: {type(e).__name__}"
+        plc.verify_after_init(self.placement, hip_bdf, apply=bool(bind) and on_gpu)
+        # 4. pipeline + shared LUTs
+        if pipeline_factory is None:
+            self.pipeline = FramePipeline(self.width, self.height, 2, algorithm, time_t, device=self.device_index,
+                                          lanczos_mode=lanczos_mode)
+        else:
+            self.pipeline = pipeline_factory(self.width, self.height, self.device_index, self)
+        up = getattr(self.pipeline, "upscaler", None)
+        self.lut_bytes = broadcast_tables(up, 0, self.comm_device) if up is not None else 0
+        # 5. this rank's shard, resident
+        self.total_units = int(total_units)
+        self.start, self.count = shard_frames(self.total_units, self.world, self.rank)
+        self.source = source if source is not None else SyntheticSource("gradient")
+        self.frames = self.source(self.start, self.count + 1, self.width, self.height, self.device)
+        self.mid, self.up_real, self.up_mid = self.pipeline.alloc(self.count, self.device)
+        self.elapsed_local = None
+        self.steps_run = 0
+
+    # -- collectives (control side only: a barrier and one all_gather of a few numbers)
+    def barrier(self) -> None:
+        if self.world > 1:
+            if self.backend == "nccl":
+                self._dist.barrier(device_ids=[self.device_index])
+            else:
+                self._dist.barrier()
+
+    def gather(self, row: dict):
+        return gather_rows(row, self.world, self._dist, self._torch, self.comm_device)
+
+    def _sync(self) -> None:
+        if self.device.type == "cuda":
+            self._torch.cuda.synchronize()
+
+    def stream_handle(self) -> int:
+        return self._torch.cuda.current_stream().cuda_stream if self.device.type == "cuda" else 0
+
+    def refill(self, source) -> None:
+        """The same shard from another source (another pattern of the synthetic stream)."""
+        self.source = source
+        self.frames.copy_(source(self.start, self.count + 1, self.width, self.height, self.device))
+
+    def step(self) -> None:
+        """Enqueue one pass over this rank's shard."""
+        p, s = self.pipeline, self.stream_handle()
+        if self.count == 0:
+            return
+        if self.schedule == "unit":
+            p.step_unit(self.frames, self.mid, self.up_real, self.up_mid, s)
+        elif self.schedule == "fused":
+            p.step_fused(self.frames, self.up_real, self.up_mid, s)
+        else:
+            p.step(self.frames, self.mid, self.up_real, self.up_mid, s)
+
+    def run(self, steps: int = 1, warmup: int = 0, step=None, before_timed=None) -> float:
+        """`warmup` untimed passes, then `steps` passes between barrier + device synchronisation on both sides.  Returns this
+        rank's seconds; the job's time is the maximum over the ranks (`gather`).  `step`: another pass than self.step (a
+        measurement variant); `before_timed`: called after the warm-up has drained, before the first barrier."""
+        import time
+
+        step = self.step if step is None else step
+        for _ in range(int(warmup)):
+            step()
+        self._sync()
+        if before_timed is not None:
+            before_timed()
+        self.barrier()
+        self._sync()
+        t0 = time.perf_counter()
+        for _ in range(int(steps)):
+            step()
+        self._sync()
+        self.barrier()
+        self.elapsed_local = time.perf_counter() - t0
+        self.steps_run = int(steps)
+        return self.elapsed_local
+
+    def summarize(self, rows) -> dict:
+        """What the job did, from the gathered rows (each holds at least elapsed_s): whole-job units and pixels per second
+        over the slowest rank's time."""
+        elapsed = max(r["elapsed_s"] for r in rows)
+        units = self.total_units * self.steps_run
+        return {"n_gpus": self.world, "steps": self.steps_run, "units_per_step": self.total_units, "elapsed_s": elapsed,
+                "ms_per_step": elapsed / max(1, self.steps_run) * 1e3, "units_per_s": units / elapsed,
+                "mpix_per_s": units * self.pipeline.unit_pixels / elapsed / 1e6, "elapsed_by_rank": spread(rows, "elapsed_s", 6),
+                "first_unit_by_rank": [int(r["first_unit"]) for r in rows], "units_by_rank": [int(r["units"]) for r in rows],
+                "lut_bytes": self.lut_bytes, "backend": self.backend if self.world > 1 else None, "schedule": self.schedule}
+
+    def unit_digests(self):
+        """One number per unit of this rank's shard: the byte sums of its three outputs folded together.  A property the domain
+        offers at any size: unit k's digest does not depend on how the stream was sharded (tests/test_sharded_stream.py)."""
+        t = self._torch
+        M = 4503599627370449  # below 2^52: a digest travels exactly in the float64 rows of `gather`
+        out = []
+        weights = {}
+        for k in range(self.count):
+            total = 0
+            for buf, mult in ((self.mid, 1), (self.up_real, 1000003), (self.up_mid, 998244353)):
+                if buf is None:
+                    continue
+                v = buf[k].reshape(-1).to(t.int64)  # one frame at a time: the int64 view of a 4K frame is 265 MB
+                n = v.shape[0]
+                if n not in weights:  # position-weighted, so that moved bytes change it: byte * (1 + index mod 251)
+                    weights[n] = (t.arange(n, device=v.device, dtype=t.int64) % 251) + 1
+                total = (total + int((v * weights[n]).sum().item()) % M * mult) % M
+            out.append(total)
+        return out
+
+    def close(self) -> None:
+        if self._own_group and self._dist.is_initialized():
+            self._dist.destroy_process_group()
+            self._own_group = False
+
+
+def run_sharded(total_units: int, width: int, height: int, *, steps: int = 1, warmup: int = 0, source=None, sink=None,
+                **kwargs) -> dict:
+    """The whole job of one rank: build the ShardedStream (placement -> process group -> pipeline -> LUT broadcast -> shard),
+    run it, hand this rank's buffers to `sink(stream) -> dict of numbers | None` (save them, check them: outside the timed
+    region, before anything is gathered -- nobody leaves early), gather, tear down.  Every rank returns the same summary
+    (ShardedStream.summarize) plus its own placement report and the gathered per-rank rows."""
+    s = ShardedStream(total_units, width, height, source=source, **kwargs)
+    try:
+        s.run(steps, warmup)
+        row = {"elapsed_s": s.elapsed_local, "first_unit": float(s.start), "units": float(s.count),
+               "numa_node": s.placement.get("numa_node"), "bound": 1.0 if s.placement.get("bound") else 0.0}
+        extra = sink(s) if sink is not None else None
+        if extra:
+            row.update({f"sink_{k}": v for k, v in extra.items()})
+        rows = s.gather(row)
+        out = s.summarize(rows)
+        out.update(rank=s.rank, rows=rows, placement={k: v for k, v in s.placement.items() if not k.startswith("_")})
+        return out
+    finally:
+        s.close()

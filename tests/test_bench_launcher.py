@@ -45,25 +45,30 @@ def test_launch_ranks_propagates_failure():
 
 
 def test_parent_process_never_imports_torch_or_the_library():
-    """`python bench.py --gpus 2` with no WORLD_SIZE: the parent must reach the launcher before anything
-    that could initialise HIP.  Run it with the launcher stubbed out and look at what got imported."""
+    """`python bench.py --gpus 2` with no WORLD_SIZE: the parent must reach the product's launcher (nu_scaler_amd.launch) and
+    start its child without anything that could initialise HIP -- torch is not imported, libnuscaler_hip.so is not loaded
+    (importing the package loads neither).  Run with the child process faked and look at what got imported."""
     code = (
-        "import sys, os; sys.path.insert(0, %r); os.environ.pop('WORLD_SIZE', None)\n"
+        "import sys, os; sys.path.insert(0, %r); os.environ.pop('WORLD_SIZE', None); os.environ.pop('RANK', None)\n"
         "import bench\n"
+        "from nu_scaler_amd import launch\n"
         "seen = {}\n"
-        "def fake(n, script, argv, timeout=None):\n"
-        "    seen.update(n=n, script=script, argv=list(argv), torch='torch' in sys.modules,\n"
-        "                lib='nu_scaler_amd' in sys.modules)\n"
-        "    return 0, ['{\"n_gpus\": %%d}' %% n]\n"
-        "bench.launch_ranks = fake\n"
+        "class R: returncode = 0; stdout = '{\"n_gpus\": 2}\\n'\n"
+        "def fake_run(cmd, **kw):\n"
+        "    import nu_scaler_amd\n"
+        "    seen.update(cmd=list(cmd), torch='torch' in sys.modules, lib=nu_scaler_amd._capi._lib is not None, env=kw['env'])\n"
+        "    return R()\n"
+        "launch.subprocess.run = fake_run\n"
         "sys.argv = ['bench.py', '--gpus', '2', '--steps', '1']\n"
         "try:\n"
         "    bench.main()\n"
         "except SystemExit as e:\n"
         "    assert e.code == 0, e.code\n"
-        "assert seen['n'] == 2 and seen['argv'] == ['--gpus', '2', '--steps', '1'], seen\n"
-        "assert os.path.basename(seen['script']) == 'bench.py'\n"
+        "cmd = seen['cmd']\n"
+        "assert cmd[1:3] == ['-m', 'torch.distributed.run'] and '--nproc-per-node=2' in cmd and '127.0.0.1' in cmd, cmd\n"
+        "assert os.path.basename(cmd[-5]) == 'bench.py' and cmd[-4:] == ['--gpus', '2', '--steps', '1'], cmd\n"
         "assert not seen['torch'] and not seen['lib'], seen\n"
+        "assert seen['env']['HSA_ENABLE_IPC_MODE_LEGACY'] == '0' and 'OMP_NUM_THREADS' in seen['env']\n"
         "print('ok')\n" % ROOT)
     res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
     assert res.returncode == 0, res.stderr

@@ -1,0 +1,142 @@
+"""The sharded frame-queue stream as a product entry point (nu_scaler_amd.stream.ShardedStream / run_sharded, `python -m
+nu_scaler_amd.cli stream`): placement -> process group -> pipeline -> LUT broadcast -> shard -> step loop -> gather.
+
+CPU, gloo, world_size 2: the rank loop on host tensors with an oracle-backed stand-in for the pipeline (the product has no CPU
+path: without a HIP device the real pipeline refuses, which is tested too).  GPU: the real pipeline, and the property the domain
+offers at any size -- a unit's outputs do not depend on how the stream was sharded."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+HELPER = os.path.join(ROOT, "tests", "helpers", "sharded_rank.py")
+
+
+def _launch(world, extra=(), timeout=600):
+    sys.path.insert(0, ROOT)
+    from nu_scaler_amd import launch
+
+    rc, lines = launch.launch_ranks(world, HELPER, list(extra), timeout=timeout)
+    out = [json.loads(ln) for ln in lines if ln.startswith("{")]
+    return rc, out
+
+
+def test_world2_gloo_rank_loop_on_host_tensors(nsc, oracle_mod):
+    """Two ranks, 7 units (shards of 4 and 3, each with its overlap frame): every rank checks the three outputs of EVERY unit of
+    its shard against the oracle, the tables reach rank 1 through the broadcast, the summary is the same on both ranks, and the
+    per-unit digests equal those of the same stream run by one rank."""
+    rc, out = _launch(2, ["--units-total", "7", "--steps", "2", "--warmup", "1"])
+    assert rc == 0 and len(out) == 1, out
+    two = out[0]
+    assert two["n_gpus"] == 2 and two["steps"] == 2 and two["units_per_step"] == 7
+    assert two["first_unit_by_rank"] == [0, 4] and two["units_by_rank"] == [4, 3]
+    assert two["checked_units_by_rank"] == [4, 3] and two["mismatches_by_rank"] == [0, 0]
+    assert two["lut_bytes"] == len(nsc.build_tables_blob(48, 20, 96, 40)) and two["tables_imported_by_rank"] == [0, 1]
+    assert two["summary_equal_on_all_ranks"] is True
+    assert two["elapsed_s"] == pytest.approx(max(two["elapsed_by_rank"]["by_rank"]), abs=1e-6) and two["elapsed_s"] > 0
+    assert two["mpix_per_s"] == pytest.approx(7 * 2 * two["unit_pixels"] / two["elapsed_s"] / 1e6)
+    rc, out = _launch(1, ["--units-total", "7", "--steps", "1"])
+    assert rc == 0 and len(out) == 1
+    one = out[0]
+    assert one["n_gpus"] == 1 and one["units_by_rank"] == [7] and one["lut_bytes"] == 0
+    assert one["unit_digests"] == two["unit_digests"] and len(one["unit_digests"]) == 7
+    assert len(set(one["unit_digests"])) == 7  # the stream moves: no two units alike
+
+
+def test_world3_ragged_shards_and_an_empty_rank(nsc):
+    """More ranks than units: a rank with an empty shard still takes part in every collective and reports zero units."""
+    rc, out = _launch(3, ["--units-total", "2", "--steps", "1"])
+    assert rc == 0 and len(out) == 1, out
+    assert out[0]["units_by_rank"] == [1, 1, 0] and out[0]["mismatches_by_rank"] == [0, 0, 0]
+    assert len(out[0]["unit_digests"]) == 2
+
+
+def test_cli_stream_without_a_gpu_fails_loudly(nsc):
+    """No CPU fallback: `stream` on a box without a HIP device says so and exits non-zero -- alone and through the launcher."""
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("needs a box without a GPU")
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    res = subprocess.run([sys.executable, "-m", "nu_scaler_amd.cli", "stream", "--units", "2", "--width", "64", "--height", "32"],
+                         capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+    assert res.returncode != 0 and "needs a HIP device" in res.stderr
+    res = subprocess.run([sys.executable, "-m", "nu_scaler_amd.cli", "stream", "--gpus", "2", "--backend", "gloo", "--units", "2",
+                          "--width", "64", "--height", "32"], capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert res.returncode != 0 and "needs a HIP device" in res.stderr and "{" not in res.stdout
+
+
+def test_synthetic_source_is_shard_invariant(nsc):
+    import torch
+
+    S = nsc.stream
+    for pattern in ("gradient", "noise"):
+        src = S.SyntheticSource(pattern)
+        whole = src(5, 40, 32, 8, torch.device("cpu"))
+        parts = torch.cat([src(5, 17, 32, 8, torch.device("cpu")), src(22, 23, 32, 8, torch.device("cpu"))])
+        assert torch.equal(whole, parts)
+    assert np.array_equal(S.SyntheticSource("gradient")(3, 1, 64, 16, torch.device("cpu"))[0].numpy(),
+                          nsc.synthetic.gradient_frame(64, 16, 3))
+
+
+@pytest.mark.gpu
+def test_sharded_stream_one_rank_against_the_oracle(nsc, oracle_mod):
+    """World of one on the GPU, the real pipeline: every unit's in-between frame bit-exact, both 4K frames within 1 LSB."""
+    w, h, n = 496, 270, 5
+    s = nsc.ShardedStream(n, w, h, bind=False)
+    try:
+        s.run(steps=2, warmup=1)
+        rows = s.gather({"elapsed_s": s.elapsed_local, "first_unit": float(s.start), "units": float(s.count)})
+        summ = s.summarize(rows)
+        assert summ["n_gpus"] == 1 and summ["units_by_rank"] == [n] and summ["steps"] == 2
+        assert s.placement["gpu_bdf_verified"] in (True, False, None) and "_replan" not in s.placement
+        for k in range(n):
+            a, b = oracle_mod.gen_gradient(w, h, k), oracle_mod.gen_gradient(w, h, k + 1)
+            assert np.array_equal(s.frames[k].cpu().numpy(), a)
+            m = oracle_mod.warp_blend(a, b, None, 0.5)
+            assert np.array_equal(s.mid[k].cpu().numpy(), m)
+            for got, src in ((s.up_real, a), (s.up_mid, m)):
+                d = np.abs(got[k].cpu().numpy().astype(np.int16) - oracle_mod.lanczos3(src, 2 * w, 2 * h, threads=0).astype(np.int16))
+                assert d.max() <= 1 and (d > 0).mean() < 1e-3
+        d1 = s.unit_digests()
+        s.schedule = "three-stage"
+        for t_ in (s.mid, s.up_real, s.up_mid):
+            t_.zero_()
+        s.run(steps=1)
+        assert s.unit_digests() == d1  # the one-launch step and the three stages write the same bytes
+    finally:
+        s.close()
+
+
+@pytest.mark.gpu
+def test_cli_stream_digests_do_not_depend_on_the_sharding(nsc):
+    """`python -m nu_scaler_amd.cli stream` at 1080p on the GPU box: 12 units by one rank, by two and by three ranks (gloo
+    rehearsal, all on device 0: the box has one GPU) -- the same 12 digests, in stream order, whoever computed them."""
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE"):
+        env.pop(k, None)
+
+    def run(gpus, units, pattern):
+        cmd = [sys.executable, "-m", "nu_scaler_amd.cli", "stream", "--gpus", str(gpus), "--units", str(units), "--steps", "2",
+               "--pattern", pattern, "--digest", "--backend", "gloo", "--force-device", "0"]
+        res = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+        assert res.returncode == 0, res.stderr[-3000:]
+        lines = [json.loads(ln) for ln in res.stdout.splitlines() if ln.startswith("{")]
+        assert len(lines) == 1
+        return lines[0]
+
+    for pattern in ("gradient", "noise"):
+        one = run(1, 12, pattern)
+        two = run(2, 6, pattern)
+        three = run(3, 4, pattern)
+        assert one["n_gpus"] == 1 and two["n_gpus"] == 2 and three["n_gpus"] == 3
+        assert two["units_by_rank"] == [6, 6] and three["first_unit_by_rank"] == [0, 4, 8]
+        assert len(one["unit_digests"]) == 12 and one["unit_digests"] == two["unit_digests"] == three["unit_digests"]
+        assert two["lut_bytes"] > 0 and two["backend"] == "gloo" and one["mpix_per_s"] > 0
