@@ -1012,6 +1012,7 @@ def worker(args):
                 "kernel": ("k_lanczos3_x2<FMA, blend-on-load, UNIT> (+ 2 x k_lanczos3_x2_edges): the whole step in one launch"
                            if unit_schedule else "k_lanczos3_x2 (+ k_lanczos3_x2_edges)"),
                 "achieved": r["achieved"], "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": r["frac"], "traffic": None,
+                "frac_basis": "SURVEY 8d algorithmic bytes, un-fused", "moved_frac": None,
                 "bytes_per_launch": launch_bytes(unit_schedule), "units_per_launch": count, "launches": launches,
                 "avg_launch_ms": r["avg_launch_ms"], "pattern": args.pattern,
                 "frac_by_rank": spread(rows, "frac"),
@@ -1171,6 +1172,11 @@ def worker(args):
                 t_s = roofline["avg_launch_ms"] / 1e3
                 moved = traffic / t_s / 1e9
                 cc = roofline.get("copy_ceiling") or {}
+                # both readings as short scalars next to each other (long strings are cut from the driver's parsed copy):
+                # frac = SURVEY 8(d) algorithmic bytes (the un-fused three stages) / time; moved_frac = PMC traffic / the same time
+                roofline["moved_frac"] = round(moved / HBM_PEAK_GBPS, 4)
+                roofline["moved_GBps"] = round(moved, 1)
+                roofline["moved_basis"] = "PMC traffic (2*FETCH_SIZE+WRITE_SIZE) / same bracket"
                 roofline["moved"] = {
                     "GBps": round(moved, 1), "frac_of_peak": round(moved / HBM_PEAK_GBPS, 4),
                     "frac_of_copy_ceiling": {k: round(moved / cc[k], 4) for k in
@@ -1183,7 +1189,7 @@ def worker(args):
         print(json.dumps(out), flush=True)
     if world > 1:
         barrier()
-        dist.destroy_process_group()
+    sh.close()  # the process group is the ShardedStream's
     if check_failed:
         bad = [i for i, r in enumerate(rows) if r["check_ok"] != 1.0]
         raise SystemExit(f"bench.py: timed outputs differ from the oracle on rank(s) {bad} (config.per_rank_check)")
