@@ -212,29 +212,52 @@ __device__ __forceinline__ void cvt_row(const uint4 raw, float (&dst)[16])
         for (int c = 0; c < 4; ++c) dst[m * 4 + c] = ch_f32(px[m], c);
 }
 
-// 1 when every pixel of this input row held by the wave (all 64 lanes x 4 columns) is opaque.
-// Rows whose whole 6-row tap window is opaque take the 3-channel path below: alpha of the output is
-// then 255 on both the CPU and here -- the taps are normalised, sum(w) * 255 is within 1e-3 of 255 in
-// f32 -- so it is stored as a constant and a quarter of the per-pixel arithmetic is skipped.
-// Captured and rendered frames are opaque; frames with real alpha just take the 4-channel path.
+// Rows whose alpha is ONE value over everything the wave holds of them (all 64 lanes x 4 columns) -- and the same value over
+// the whole 6-row tap window -- take the 3-channel path below: the taps are normalised (sum(w) is 1 within a few f32 ulps on
+// both axes), so the alpha the CPU computes for such a window is round(A (1 + eps)), |A eps| < 1e-3: A itself, which is stored as
+// a constant and a quarter of the per-pixel arithmetic is skipped.  Captured and rendered frames are opaque (A = 255, rounds 1-4's
+// "opaque path"); overlays and borders with a flat alpha (0, 128, ..) qualify as well since round 5; frames whose alpha varies
+// inside a window take the 4-channel path for that window.
+// AlphaRun: eq bit j = "input row (newest - j) is flat and so is the row before it, with the same alpha" -- five set bits are six
+// rows of one alpha; `alpha` = the newest row's alpha in bits 31:24 (meaningful while eq bit 0 is set).  All wave-uniform (SGPRs).
 #ifndef NUS_OPAQUE_PATH
 #define NUS_OPAQUE_PATH 1 // dev macro: 0 builds the x2 kernel without the 3-channel path (A/B timing only)
 #endif
 #ifndef NUS_BLEND_OPAQUE_PATH
 #define NUS_BLEND_OPAQUE_PATH 1 // dev macro: 0 = the blend variants without the 3-channel path, as in round 2 (A/B timing only)
 #endif
-#if (!NUS_OPAQUE_PATH || !NUS_BLEND_OPAQUE_PATH) && !defined(NUS_DEV_BUILD)
+#ifndef NUS_FLAT_ALPHA
+#define NUS_FLAT_ALPHA 1 // dev macro: 0 = rounds 1-4: only alpha == 255 takes the 3-channel path (A/B timing only)
+#endif
+#if (!NUS_OPAQUE_PATH || !NUS_BLEND_OPAQUE_PATH || !NUS_FLAT_ALPHA) && !defined(NUS_DEV_BUILD)
 #error "timing-only dev macros of k_lanczos3_x2 need -DNUS_DEV_BUILD: never in a product build"
 #endif
 #define NUS_LZ_BLEND_OPAQUE_PATH_OK(BLEND) ((BLEND) == 0 || NUS_BLEND_OPAQUE_PATH != 0)
-__device__ __forceinline__ uint32_t row_is_opaque(const uint4 raw)
+struct AlphaRun {
+    uint32_t eq = 0;    // history of "flat, and equal to the row before"
+    uint32_t alpha = 0; // alpha of the newest row << 24 (if it was flat)
+    uint32_t flat = 0;  // the newest row was flat
+};
+__device__ __forceinline__ void alpha_run_push(AlphaRun &R, const uint4 raw)
 {
 #if !NUS_OPAQUE_PATH
-    return 0u;
+    return;
 #endif
-    const bool lane_opaque = (raw.x & raw.y & raw.z & raw.w) >= 0xFF000000u;
-    return __builtin_amdgcn_ballot_w64(!lane_opaque) == 0ull ? 1u : 0u;
+#if NUS_FLAT_ALPHA
+    // the lane's four alphas agree (the xors leave nothing in the top byte) and equal the first lane's
+    const uint32_t first = __builtin_amdgcn_readfirstlane(raw.x) & 0xFF000000u;
+    const bool lane_ok = (((raw.x ^ raw.y) | (raw.x ^ raw.z) | (raw.x ^ raw.w) | (raw.x ^ first)) & 0xFF000000u) == 0u;
+#else
+    const uint32_t first = 0xFF000000u;
+    const bool lane_ok = (raw.x & raw.y & raw.z & raw.w) >= 0xFF000000u;
+#endif
+    const uint32_t flat = __builtin_amdgcn_ballot_w64(!lane_ok) == 0ull ? 1u : 0u;
+    R.eq = (R.eq << 1) | (flat & R.flat & (first == R.alpha ? 1u : 0u));
+    R.alpha = first;
+    R.flat = flat;
 }
+// the six newest rows carry one alpha: the 3-channel path may be taken, storing R.alpha
+__device__ __forceinline__ bool alpha_run_six(const AlphaRun &R) { return (R.eq & 0x1Fu) == 0x1Fu; }
 
 // Vertical pass of one output row: 6 taps from window slots BASE .. BASE+5 (mod 6).
 // NARROW: the filter's outermost taps (slots 0 and 5 of both phases) carry weight 0 on both axes (Catmull-Rom at x2: four taps;
@@ -277,9 +300,9 @@ __device__ __forceinline__ void lanczos_x2_vpass_edge(const float (&win)[6][16],
 
 // Horizontal pass of the lane's 8 output pixels, convert + pack.
 template <bool EXACT, bool ALPHA, bool NARROW = false>
-__device__ __forceinline__ void lanczos_x2_hpass(const float (&V)[16], const PhaseWeights &W, uint32_t (&o)[8])
+__device__ __forceinline__ void lanczos_x2_hpass(const float (&V)[16], const PhaseWeights &W, uint32_t (&o)[8], uint32_t flat_alpha = 0u)
 {
-    constexpr uint32_t a0 = ALPHA ? 0u : 0xFF000000u; // 3-channel path: opaque output
+    const uint32_t a0 = ALPHA ? 0u : flat_alpha; // 3-channel path: the window's one alpha (wave-uniform), already in bits 31:24
 #pragma unroll
     for (int q = 0; q < 8; ++q) o[q] = a0;
 #if NUS_LZ_ABLATE == 2 || NUS_LZ_ABLATE == 3
@@ -398,7 +421,7 @@ __device__ __forceinline__ void lanczos_x2_store_mid(const uint4 px, const MidSt
 
 template <bool EXACT, int BLEND, bool UNIT, int S, bool NARROW = false>
 __device__ __forceinline__ void lanczos_x2_step(float (&win)[6][16], const RowRing<BLEND> &ring, RowRaw<BLEND> (&raw)[2],
-                                                uint32_t &opaque, int r, uint32_t in_off, const RowStore &st,
+                                                AlphaRun &arun, int r, uint32_t in_off, const RowStore &st,
                                                 const LanczosX2Args &A, const PhaseWeights &W, const uint8_t *src,
                                                 const uint8_t *src_b, __amdgpu_buffer_rsrc_t rs, float t, const MidStore &ms)
 {
@@ -413,8 +436,9 @@ __device__ __forceinline__ void lanczos_x2_step(float (&win)[6][16], const RowRi
     float V[16];
     uint32_t o[8];
     RowRaw<BLEND> next; // row r+3
-    // `opaque`: bit j = input row (newest - j) is opaque; the six newest rows are this phase's taps
-    const uint32_t path = !interior ? 0u : ((OP && (opaque & 0x3Fu) == 0x3Fu) ? 1u : 2u); // wave-uniform
+    // the six newest rows are this phase's taps
+    const uint32_t path = !interior ? 0u : ((OP && alpha_run_six(arun)) ? 1u : 2u); // wave-uniform
+    const uint32_t alpha_e = arun.alpha;
     if (path == 0)
         lanczos_x2_vpass_edge<EXACT, S>(win, A.wy6, 2 * (uint32_t)r, V);
     else if (path == 1)
@@ -435,7 +459,7 @@ __device__ __forceinline__ void lanczos_x2_step(float (&win)[6][16], const RowRi
     }
 #endif
     if (path == 1)
-        lanczos_x2_hpass<EXACT, false, NARROW>(V, W, o);
+        lanczos_x2_hpass<EXACT, false, NARROW>(V, W, o, alpha_e);
     else
         lanczos_x2_hpass<EXACT, true, NARROW>(V, W, o);
     lanczos_x2_store(o, rs, st, off0); // after the paths have joined: straight-line code holds every memory instruction
@@ -447,7 +471,7 @@ __device__ __forceinline__ void lanczos_x2_step(float (&win)[6][16], const RowRi
     if (!HIDDEN) next = raw[S & 1];
     {
         const uint4 px = resolve_row<BLEND>(next, t, A.sel);
-        if (OP) opaque = (opaque << 1) | row_is_opaque(px);
+        if (OP) alpha_run_push(arun, px);
         cvt_row(px, win[S % 6]);
         lanczos_x2_store_mid<UNIT>(px, ms, r + 3, A.iw * 4);
     }
@@ -474,13 +498,13 @@ __device__ __forceinline__ void lanczos_x2_step(float (&win)[6][16], const RowRi
 #endif
             raw[S & 1] = fetch_row_plain<BLEND>(src, src_b, off);
     }
-    const uint32_t path_o = !interior ? 0u : ((OP && (opaque & 0x3Fu) == 0x3Fu) ? 1u : 2u);
+    const uint32_t path_o = !interior ? 0u : ((OP && alpha_run_six(arun)) ? 1u : 2u);
     if (path_o == 0) {
         lanczos_x2_vpass_edge<EXACT, S + 1>(win, A.wy6, 2 * (uint32_t)r + 1, V);
         lanczos_x2_hpass<EXACT, true, NARROW>(V, W, o);
     } else if (path_o == 1) {
         lanczos_x2_vpass<EXACT, S + 1, false, NARROW>(win, W.o, V);
-        lanczos_x2_hpass<EXACT, false, NARROW>(V, W, o);
+        lanczos_x2_hpass<EXACT, false, NARROW>(V, W, o, arun.alpha);
     } else {
         lanczos_x2_vpass<EXACT, S + 1, true, NARROW>(win, W.o, V);
         lanczos_x2_hpass<EXACT, true, NARROW>(V, W, o);
@@ -648,7 +672,7 @@ __global__ __launch_bounds__(256) void k_lanczos3_x2(const LanczosX2Args A)
         W.o[j] = vgpr(A.wxo[j]);
     }
     float win[6][16];
-    uint32_t opaque = 0;
+    AlphaRun arun;
     RowRaw<BLEND> raw[2];
     {
         // the six rows of the first window (ordinary loads, all in flight together), then the first requests
@@ -665,7 +689,7 @@ __global__ __launch_bounds__(256) void k_lanczos3_x2(const LanczosX2Args A)
 #pragma unroll
         for (int j = 0; j < 6; ++j) {
             const uint4 px = resolve_row<BLEND>(first[j], t, A.sel);
-            if (!EXACT && NUS_LZ_BLEND_OPAQUE_PATH_OK(BLEND)) opaque = (opaque << 1) | row_is_opaque(px);
+            if (!EXACT && NUS_LZ_BLEND_OPAQUE_PATH_OK(BLEND)) alpha_run_push(arun, px);
             cvt_row(px, win[j]);
             if (j >= 3) lanczos_x2_store_mid<UNIT>(px, ms, r0 - 3 + j, A.iw * 4); // rows r0 .. r0+2 (the loop stores r0+3 ..)
         }
@@ -677,7 +701,7 @@ __global__ __launch_bounds__(256) void k_lanczos3_x2(const LanczosX2Args A)
         // after its last row: a step is never skipped with a later one still to run, so every path through
         // the loop carries the vector memory instructions the hand-counted waits assume.
 #define NUS_LZ_STEP(S) \
-        lanczos_x2_step<EXACT, BLEND, UNIT, S, NARROW>(win, ring, raw, opaque, rbase + S, in_off, st, A, W, src, src_b, rs, t, ms); \
+        lanczos_x2_step<EXACT, BLEND, UNIT, S, NARROW>(win, ring, raw, arun, rbase + S, in_off, st, A, W, src, src_b, rs, t, ms); \
         if (S < 5 && rbase + S + 1 >= r_end) break
         NUS_LZ_STEP(0);
         NUS_LZ_STEP(1);

@@ -960,6 +960,62 @@ def test_lanczos_x2_opaque_and_mixed_alpha_rows(nsc, oracle_mod, alg):
         assert np.array_equal(got_e, want), name
 
 
+@pytest.mark.parametrize("alg", ["lanczos3", "bicubic"])
+def test_lanczos_x2_flat_alpha_windows_take_the_three_channel_path(nsc, oracle_mod, alg):
+    """Round 5: the 3-channel path of the x2 kernel is taken wherever the alpha of a wave's 6-row window is ONE value -- any value,
+    not only 255 (overlays with alpha 0 / 17 / 128, a band of another alpha across all rows, mixed rows).  Three proofs:
+      * against the oracle: every sample within 1 LSB, < 0.1 % different (the FMA contract), and the ALPHA channel equal to the
+        oracle's wherever the whole window is flat (the constant is what the CPU computes: taps are normalised);
+      * against the 4-channel path: the same frame with one alpha bit flipped in every (row, strip) -- no window is flat any more,
+        every wave takes the 4-channel path -- gives bit-identical R, G, B everywhere (channels never mix) and bit-identical alpha
+        outside the flipped pixels' tap footprints: where both paths computed an alpha, they computed the same byte;
+      * EXACT mode (no 3-channel path at all) equals the oracle bit for bit on the same frames."""
+    filt = oracle_mod.FILTER_LANCZOS3 if alg == "lanczos3" else oracle_mod.FILTER_CATMULLROM
+    w, h = 1000, 104  # five strips (four full + a ragged one), several row blocks
+    img = oracle_mod.gen_noise(w, h, 4242)
+    img[0:40, :, 3] = 255
+    img[40:60, :, 3] = 128
+    img[60:83, :, 3] = 17
+    img[83:, :, 3] = 0
+    img[:, 500:700, 3] = 200      # a band of another alpha down all rows: strips that straddle its borders are not flat
+    img[50, :, 3] = 129           # one row of its own inside a region: windows that hold it and its neighbours are mixed
+    rowwise = img.copy()
+    rowwise[:, :, 3] = (np.arange(h, dtype=np.uint8) * 3)[:, None]  # every row flat, no two rows alike: never six in a row
+    for name, frame in (("regions", img), ("rowwise", rowwise)):
+        want = oracle_mod.resize(frame, 2 * w, 2 * h, filt, threads=0)
+        got, u = _up(nsc, alg, frame, 2 * w, 2 * h, options={"rows_per_wave": 26})
+        assert u.kernel_variant == "lanczos3_x2_regwin"
+        d = np.abs(got.astype(np.int16) - want.astype(np.int16))
+        assert d.max() <= 1 and (d > 0).mean() < 1e-3, (name, int(d.max()), float((d > 0).mean()))
+        # flat windows: input alpha constant over rows y-3 .. y+3 and columns x-3 .. x+3 => both CPU and GPU say that constant
+        a = frame[..., 3].astype(np.int16)
+        flat = np.ones((h, w), bool)
+        for dy in range(-3, 4):
+            for dx in range(-3, 4):
+                sh = np.roll(np.roll(a, dy, 0), dx, 1)
+                flat &= sh == a
+        flat[:3] = flat[-3:] = False
+        flat[:, :3] = flat[:, -3:] = False
+        up_flat = np.repeat(np.repeat(flat, 2, 0), 2, 1)
+        up_a = np.repeat(np.repeat(frame[..., 3], 2, 0), 2, 1)
+        assert np.array_equal(want[..., 3][up_flat], up_a[up_flat]) and np.array_equal(got[..., 3][up_flat], up_a[up_flat]), name
+        if name == "regions":
+            assert up_flat.mean() > 0.5
+        # the same frame through the 4-channel path everywhere
+        broken = frame.copy()
+        xs = [s_ * 240 + 7 for s_ in range((w + 239) // 240)]
+        for x in xs:
+            broken[:, x, 3] ^= 1
+        got4, _ = _up(nsc, alg, broken, 2 * w, 2 * h, options={"rows_per_wave": 26})
+        assert np.array_equal(got[..., :3], got4[..., :3]), name
+        near = np.zeros((2 * h, 2 * w), bool)
+        for x in xs:
+            near[:, max(0, 2 * x - 8):2 * x + 10] = True
+        assert np.array_equal(got[..., 3][~near], got4[..., 3][~near]), name
+        got_e, _ = _up(nsc, alg, frame, 2 * w, 2 * h, lanczos_mode="exact")
+        assert np.array_equal(got_e, want), name
+
+
 @pytest.mark.parametrize("alg,filt", [("lanczos3", 0), ("bicubic", 1), ("triangle", 2)])
 @pytest.mark.parametrize("dims", [((320, 180), (480, 270)), ((320, 180), (960, 540)), ((250, 135), (1000, 540)),
                                   ((640, 360), (960, 540)), ((100, 37), (1000, 99)), ((480, 270), (680, 384)), ((600, 40), (900, 41)),

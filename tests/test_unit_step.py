@@ -33,11 +33,16 @@ def test_unit_step_equals_the_three_stages(nsc, oracle_mod, w, h, th, t):
     dev = torch.device("cuda:0")
     fb = w * h * 4
     s = torch.cuda.current_stream().cuda_stream
-    for content in ("noise", "opaque"):
+    for content in ("noise", "opaque", "flat"):
         frames_np = np.stack([oracle_mod.gen_noise(w, h, 700 + i) for i in range(n + 1)])
         if content == "opaque":
             frames_np[..., 3] = 255
             frames_np[2, h // 2:, :, 3] = 17  # one frame with real alpha in its lower half: mixed paths inside one launch
+        if content == "flat":  # round 5: any flat alpha takes the 3-channel path -- regions of 0 / 128 / 255 shared by all frames
+            frames_np[:, :h // 3, :, 3] = 0   # (the blend of two rows of one alpha has that alpha), and one frame out of step
+            frames_np[:, h // 3:2 * h // 3, :, 3] = 128
+            frames_np[:, 2 * h // 3:, :, 3] = 255
+            frames_np[3, :, :, 3] = 77
         frames = torch.from_numpy(frames_np).to(dev)
         for mode in ("fma", "exact"):
             for order in (1, 0):

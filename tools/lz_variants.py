@@ -70,7 +70,14 @@ def main():
     st = torch.cuda.current_stream().cuda_stream
     print(f"{a.alg} {iw}x{ih} -> {ow}x{oh}, {n} frames per launch, {mb:.2f} MB per frame algorithmic")
     for pattern in a.patterns.split(","):
-        frames = (syn.gradient_stream_torch if pattern == "gradient" else syn.noise_stream_torch)(n, iw, ih, dev)
+        # gradient: opaque; noise: every alpha its own; alpha128: the gradient with alpha 128 everywhere; alpharegions: thirds of
+        # alpha 0 / 128 / 255 (flat alphas take the 3-channel path since round 5)
+        frames = (syn.noise_stream_torch if pattern == "noise" else syn.gradient_stream_torch)(n, iw, ih, dev)
+        if pattern == "alpha128":
+            frames[..., 3] = 128
+        elif pattern == "alpharegions":
+            frames[:, :ih // 3, :, 3] = 0
+            frames[:, ih // 3:2 * ih // 3, :, 3] = 128
         ref = None
         times = {name: [] for name, _ in libs}
         for rnd in range(a.rounds + 1):
