@@ -764,7 +764,21 @@ struct HsFastCoef {
     float ix, iy, it, gx, gy;
 };
 
-template <int K, bool UPS>
+// RING (round 5): the same passes with every queue of the pipeline as a RING whose slot indices are compile-time constants -- the
+// coefficient delay line (K + 1 rows x 5 floats), each level's two previous rows, the rows in flight from memory.  The shifting
+// form above moves each of them down by one register per pass: 5 K + 4 K + 8 v_mov of the ~170 instructions of a 5-step pass, in a
+// kernel that is bound by instruction issue.  A pass's slot indices depend on (t - lo) mod R only, R = 6 rows for K <= 5 (a multiple
+// of 3 for the three-row rings, >= K + 1 for the delay line, >= 5 for the luminance rows t-1 .. t+3) and 9 rows for K = 6 .. 8, so the
+// pass is instantiated R times (x 2: steady / fill-and-drain) as one straight-line turn of the rings: no value ever changes
+// register.  Same operations on the same operands in the same order: bit-identical flows (tests/test_flow.py runs both forms).
+// K > 8 keeps the shifting form (12 copies of a ten-step pass would not fit the instruction cache).
+#ifndef NUS_HS_FAST_RING
+#define NUS_HS_FAST_RING 1
+#endif
+#ifndef NUS_HS_FAST_RING_MAXK
+#define NUS_HS_FAST_RING_MAXK 8 // launches of up to this many steps take the ring form
+#endif
+template <int K, bool UPS, bool RING = false>
 __global__ __launch_bounds__(256) void k_hs_stream_fast(const float *__restrict__ lum_all, size_t lum_stride, float lambda,
                                                         const float2 *__restrict__ fin_all, size_t fin_stride,
                                                         float2 *__restrict__ fout_all, size_t fout_stride, int w, int h, int strips,
@@ -784,8 +798,15 @@ __global__ __launch_bounds__(256) void k_hs_stream_fast(const float *__restrict_
     const int y0 = rb * rows_per_block, y1 = min(y0 + rows_per_block, h);
     const int lo = max(y0 - K, 0), hi = min(y1 + K, h);
 
-    float2 a1[K], a2[K];   // level j: its rows r-1 and r-2 (this lane's column)
-    HsFastCoef cf[K + 1];  // cf[d]: coefficients of row t - d (cf[0] is only the way in)
+    static_assert(!RING || K <= 8, "the ring form is instantiated for K <= 8 (R = 6 or 9)");
+    constexpr int R = K <= 5 ? 6 : 9; // RING: passes per turn of every ring
+    float2 a1[RING ? 1 : K], a2[RING ? 1 : K]; // level j: its rows r-1 and r-2 (this lane's column)
+    HsFastCoef cf[RING ? 1 : K + 1];           // cf[d]: coefficients of row t - d (cf[0] is only the way in)
+    float2 ar[RING ? K : 1][3];                // RING: level j's rows r, r-1, r-2 in slots (row - lo) mod 3
+    HsFastCoef cfr[RING ? R : 1];              // RING: coefficients of row t in slot (t - lo) mod R
+    float l1r[RING ? R : 1];                   // RING: frame 1's rows t-1 .. t+3 in slots (row - lo) mod R
+    float q2r[3];                              // RING: frame 2's rows t .. t+2
+    float2 qfr[3];                             // RING: the input flow's rows t .. t+2 (not UPS)
 
     // UPS: the level starts from the coarser level's flow, sampled as flow_upsample.wgsl:27-36 samples it (linear, clamp to edge,
     // texel space) while it is loaded.  The column part of the sample position is this lane's for the whole launch (the shader's own
@@ -863,6 +884,86 @@ __global__ __launch_bounds__(256) void k_hs_stream_fast(const float *__restrict_
     }
     float l1_above = lum1[(size_t)clampi(lo - 1, 0, h - 1) * w + xc], l1_row = lum1[(size_t)lo * w + xc]; // frame 1, rows t - 1, t
     const float ninth = 1.0f / 9.0f;
+    if constexpr (RING) {
+        static_assert(!RING || NUS_HS_FAST_AHEAD == 2, "the ring form keeps rows t .. t+2 in three-slot rings");
+        l1r[R - 1] = l1_above, l1r[0] = l1_row, l1r[1] = q1[0], l1r[2] = q1[1];
+        q2r[0] = q2[0], q2r[1] = q2[1];
+        if constexpr (!UPS) qfr[0] = qf[0], qfr[1] = qf[1];
+    }
+    // One pass in ring form, phase P = (t - lo) mod R (compile time)
+    auto ring_pass = [&](int t, auto steady_tag, auto phase_tag) __attribute__((always_inline)) {
+        constexpr bool STEADY = decltype(steady_tag)::value;
+        constexpr int P = decltype(phase_tag)::value;
+        float2 nf;
+        if constexpr (UPS) nf = load_flow(t);
+        else {
+            nf = qfr[P % 3];
+            qfr[(P + 2) % 3] = load_flow(t + 2); // in flight during this pass and the next
+        }
+        const float row = l1r[P % R], above = l1r[(P + R - 1) % R], n1 = l1r[(P + 1) % R], n2 = q2r[P % 3];
+        l1r[(P + 3) % R] = lum1[(size_t)clampi(t + 3, 0, h - 1) * w + xc];
+        q2r[(P + 2) % 3] = lum1[lum_stride + (size_t)clampi(t + 2, 0, h - 1) * w + xc];
+        {
+            const float left = wave_up(row), right = wave_down(row);
+            const float ix = ((self_r ? row : right) - (self_l ? row : left)) * 0.5f;
+            const float iy = (n1 - above) * 0.5f;
+            const float it = n2 - row;
+            const float rinv = __builtin_amdgcn_rcpf(__builtin_fmaf(iy, iy, __builtin_fmaf(ix, ix, lambda)));
+            cfr[P] = HsFastCoef{ix, iy, it, ix * rinv, iy * rinv};
+        }
+        float2 arr = nf; // level 0's arrival: row t of the input flow
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+            const int r = t - j; // the row arriving at level j in this pass
+            constexpr int kBig = 3 * R;
+            const int s0 = (P - j + kBig) % 3, s1 = (P - j - 1 + kBig) % 3, s2 = (P - j - 2 + kBig) % 3; // rows r, r-1, r-2 (constants once unrolled)
+            if (!STEADY) {
+                if (r < lo) break;    // the pipeline is still filling (wave-uniform)
+                if (r > hi) continue; // this level is done, deeper ones are draining
+                if (r == hi) arr = ar[j][s1]; // past the last row: it repeats
+                if (r == lo) { // first row: also the row above it
+                    ar[j][s0] = arr, ar[j][s1] = arr;
+                    break; // deeper levels have nothing yet
+                }
+            }
+            const float su = (ar[j][s2].x + ar[j][s1].x) + arr.x, sv = (ar[j][s2].y + ar[j][s1].y) + arr.y;
+            const float lu = wave_up(su), ru = wave_down(su), lv = wave_up(sv), rv = wave_down(sv);
+            const float ua = (((self_l ? su : lu) + su) + (self_r ? su : ru)) * ninth;
+            const float va = (((self_l ? sv : lv) + sv) + (self_r ? sv : rv)) * ninth;
+            const HsFastCoef c = cfr[(P - j - 1 + kBig) % R]; // row r-1 entered j+1 passes ago
+            const float num = __builtin_fmaf(c.ix, ua, __builtin_fmaf(c.iy, va, c.it));
+            ar[j][s0] = arr; // the arriving row takes the slot of row r-3, which nothing reads any more
+            arr = make_float2(__builtin_fmaf(-num, c.gx, ua), __builtin_fmaf(-num, c.gy, va));
+            if (j == K - 1) {
+                const int y = r - 1;
+                if (y >= y0 && y < y1 && writer) fout[(size_t)y * w + x] = arr;
+            }
+        }
+    };
+    // A whole turn of the rings (R passes) as straight-line code: every value keeps its register across the loop's back edge.
+    auto ring_turn = [&](int t, auto steady_tag) __attribute__((always_inline)) {
+        ring_pass(t, steady_tag, std::integral_constant<int, 0>{});
+        ring_pass(t + 1, steady_tag, std::integral_constant<int, 1>{});
+        ring_pass(t + 2, steady_tag, std::integral_constant<int, 2>{});
+        ring_pass(t + 3, steady_tag, std::integral_constant<int, 3>{});
+        ring_pass(t + 4, steady_tag, std::integral_constant<int, 4>{});
+        ring_pass(t + 5, steady_tag, std::integral_constant<int, 5>{});
+        if constexpr (R == 9) {
+            ring_pass(t + 6, steady_tag, std::integral_constant<int, 6>{});
+            ring_pass(t + 7, steady_tag, std::integral_constant<int, 7>{});
+            ring_pass(t + 8, steady_tag, std::integral_constant<int, 8>{});
+        }
+    };
+    if constexpr (RING) {
+        // the first turn fills the pipeline (K <= R - 1 passes of it) and the turns from the first one that reaches row hi on drain it:
+        // the general form of the pass, whose levels look at their row number (passes past hi + K find nothing to do); all turns in
+        // between are steady
+        int t = lo;
+        ring_turn(t, std::false_type{});
+        for (t += R; t + R <= hi; t += R) ring_turn(t, std::true_type{});
+        for (; t < hi + K; t += R) ring_turn(t, std::false_type{});
+        return;
+    }
 
     auto pass = [&](int t, auto steady_tag) {
         constexpr bool STEADY = decltype(steady_tag)::value;
@@ -1161,15 +1262,23 @@ hipError_t launch_hs_iterate(const float *coef, float lambda, float **flow_a, fl
                               uint32_t m) -> hipError_t {
             const HsStreamShape sh = hs_stream_shape(w, h, m, k, true);
             const dim3 block(256), grid(cdiv(sh.strips * sh.row_blocks, 4), m);
+#define NUS_HSF_L(KK, UU, RR)                                                                                                        \
+    hipLaunchKernelGGL((k_hs_stream_fast<KK, UU, RR>), grid, block, 0, stream, lum, lum_stride, lambda, fi, flow_stride, fo, out_stride, \
+                       (int)w, (int)h, (int)sh.strips, (int)sh.row_blocks, (int)sh.rows_per_block, hc)
 #define NUS_HSF(KK)                                                                                                                  \
     case KK:                                                                                                                         \
-        if (ups)                                                                                                                     \
-            hipLaunchKernelGGL((k_hs_stream_fast<KK, true>), grid, block, 0, stream, lum, lum_stride, lambda, fi, flow_stride, fo,    \
-                               out_stride, (int)w, (int)h, (int)sh.strips, (int)sh.row_blocks, (int)sh.rows_per_block, hc);           \
-        else                                                                                                                         \
-            hipLaunchKernelGGL((k_hs_stream_fast<KK, false>), grid, block, 0, stream, lum, lum_stride, lambda, fi, flow_stride, fo,   \
-                               out_stride, (int)w, (int)h, (int)sh.strips, (int)sh.row_blocks, (int)sh.rows_per_block, hc);           \
+        if constexpr (NUS_HS_FAST_RING != 0 && KK <= NUS_HS_FAST_RING_MAXK) {                                                                            \
+            if (!shifting) {                                                                                                         \
+                if (ups) NUS_HSF_L(KK, true, true); else NUS_HSF_L(KK, false, true);                                                 \
+                break;                                                                                                               \
+            }                                                                                                                        \
+        }                                                                                                                            \
+        if (ups) NUS_HSF_L(KK, true, false); else NUS_HSF_L(KK, false, false);                                                       \
         break;
+            // (test hook: NUS_HS_FAST_SHIFT=1 in the environment runs the shifting form of the pass where the ring form is the
+            // product's -- tests/test_flow.py compares the two bit for bit)
+            const char *shift_env = getenv("NUS_HS_FAST_SHIFT");
+            const bool shifting = shift_env != nullptr && shift_env[0] == '1';
             switch (k) {
                 NUS_HSF(1) NUS_HSF(2) NUS_HSF(3) NUS_HSF(4) NUS_HSF(5)
 #if NUS_HS_FAST_MAXK > 5 || NUS_HS_FAST_MAXK_LONG > 5
@@ -1177,6 +1286,7 @@ hipError_t launch_hs_iterate(const float *coef, float lambda, float **flow_a, fl
 #endif
             }
 #undef NUS_HSF
+#undef NUS_HSF_L
             return hipGetLastError();
         };
         // a level with many steps (the coarsest: 50) takes more of them per launch: its launches are short and memory-bound, and

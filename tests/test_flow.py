@@ -339,3 +339,37 @@ def test_flow_fast_mode_1080p_contract(nsc, oracle_mod):
     ref = oracle_mod.warp_blend(a, b, want, 0.5)
     d = np.abs(out.cpu().numpy().astype(np.int16) - ref.astype(np.int16))
     assert d.max() <= 1 and (d > 0).mean() < 1e-3, (int(d.max()), float((d > 0).mean()))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("w,h,levels,coarse,refine", [(333, 262, 3, 7, 6), (613, 517, 2, 11, 5), (97, 45, 3, 9, 3), (1030, 5, 2, 2, 2),
+                                                       (5, 5, 2, 3, 1), (1920, 1080, 3, 10, 5), (129, 700, 2, 4, 3), (160, 90, 2, 30, 8), (480, 270, 1, 50, 0),
+                                                       (333, 100, 1, 37, 0)])
+def test_flow_fast_ring_form_equals_the_shifting_form(nsc, oracle_mod, w, h, levels, coarse, refine, monkeypatch):
+    """Round 5: k_hs_stream_fast keeps every queue of its pipeline in rings with compile-time slot indices (six copies of the pass,
+    no register moves); the shifting form of rounds 3-4 is still in the library (launches of more than 5 steps use it) and
+    NUS_HS_FAST_SHIFT=1 selects it everywhere.  Same operations on the same operands in the same order: the flows of the two
+    forms are bit-identical -- ragged sizes, blocks shorter than a turn of the rings, several row blocks, 1..5 steps per launch."""
+    import torch
+
+    dev = torch.device("cuda:0")
+    n_frames = 3
+    frames = np.stack([oracle_mod.gen_noise(w, h, 900 + k) if (w * h) % 2 else _smooth(w, h, 1.1 * k) for k in range(n_frames)])
+    d_frames = torch.from_numpy(frames).to(dev)
+    s = torch.cuda.current_stream().cuda_stream
+    got = {}
+    for form in ("ring", "shift"):
+        if form == "shift":
+            monkeypatch.setenv("NUS_HS_FAST_SHIFT", "1")
+        else:
+            monkeypatch.delenv("NUS_HS_FAST_SHIFT", raising=False)
+        fe = nsc.FlowEstimator(levels=levels, coarse_iterations=coarse, refine_iterations=refine)
+        fe.set_mode("fast")
+        fe.set_tiled(3)  # the streamed kernels whatever the batch size
+        flows = torch.full((n_frames - 1, h, w, 2), float("nan"), dtype=torch.float32, device=dev)
+        fe.estimate_device_stream(d_frames.data_ptr(), n_frames, w, h, flows.data_ptr(), s)
+        torch.cuda.synchronize()
+        got[form] = flows.cpu().numpy()
+        assert np.isfinite(got[form]).all()
+    monkeypatch.delenv("NUS_HS_FAST_SHIFT", raising=False)
+    assert np.array_equal(got["ring"], got["shift"])

@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Time nus_flow_estimate_device_stream on a device-resident 1080p stream (dev tool): flow_stream_bench.py [frames] [modes: 1 by size, 2 LDS tiles, 3 streamed, 9 = FAST arithmetic (nus_flow_set_mode) ...]"""
+"""Time nus_flow_estimate_device_stream on a device-resident 1080p stream (dev tool): flow_stream_bench.py [frames] [modes: 1 by size, 2 LDS tiles, 3 streamed, 9 = FAST arithmetic (nus_flow_set_mode), 19 = FAST with the shifting pass ...]"""
 import os
 import sys
 
@@ -20,8 +20,12 @@ modes = [int(m) for m in sys.argv[2:]] or [1]
 ref = None
 for rnd in range(3 if len(modes) > 1 else 1):  # interleaved rounds when several kernels are compared
     for mode in modes:
-        fe.set_mode("fast" if mode == 9 else "exact")
-        fe.set_tiled(1 if mode == 9 else mode)
+        fe.set_mode("fast" if mode in (9, 19) else "exact")
+        fe.set_tiled(1 if mode in (9, 19) else mode)
+        if mode == 19:  # FAST with the shifting form of the pass (rounds 3-4) where the ring form is the product's
+            os.environ["NUS_HS_FAST_SHIFT"] = "1"
+        else:
+            os.environ.pop("NUS_HS_FAST_SHIFT", None)
         fe.estimate_device_stream(frames.data_ptr(), n, w, h, flows.data_ptr(), s)
         torch.cuda.synchronize()
         if ref is None:
