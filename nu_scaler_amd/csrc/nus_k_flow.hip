@@ -775,6 +775,11 @@ struct HsFastCoef {
 #ifndef NUS_HS_FAST_RING
 #define NUS_HS_FAST_RING 1
 #endif
+#ifndef NUS_HS_FAST_INNER_STRIPS
+#define NUS_HS_FAST_INNER_STRIPS 0 // dev macro: 1 = strips that touch no image border run a copy of the pass without the clamp's selects
+                                   // (22 of ~100 VALU instructions of a 5-step pass).  Measured, round 5: identical flows, 110 / 126 / 140 VGPRs
+                                   // instead of 95 / 108 / 122 (one wave per SIMD fewer), 42.1 - 42.8 us per 1080p pair against 41.7 - 42.3: not kept
+#endif
 #ifndef NUS_HS_FAST_RING_MAXK
 #define NUS_HS_FAST_RING_MAXK 8 // launches of up to this many steps take the ring form
 #endif
@@ -891,8 +896,12 @@ __global__ __launch_bounds__(256) void k_hs_stream_fast(const float *__restrict_
         if constexpr (!UPS) qfr[0] = qf[0], qfr[1] = qf[1];
     }
     // One pass in ring form, phase P = (t - lo) mod R (compile time)
-    auto ring_pass = [&](int t, auto steady_tag, auto phase_tag) __attribute__((always_inline)) {
+    auto ring_pass = [&](int t, auto steady_tag, auto phase_tag, auto border_tag) __attribute__((always_inline)) {
         constexpr bool STEADY = decltype(steady_tag)::value;
+        // BORDER = false: a strip all of whose 64 columns lie strictly inside the image (every strip but the first and the last) --
+        // no lane's neighbour is the lane itself, the selects that implement the shader's clamp drop out of the pass
+        constexpr bool BORDER = decltype(border_tag)::value;
+        const bool sl = BORDER && self_l, sr = BORDER && self_r;
         constexpr int P = decltype(phase_tag)::value;
         float2 nf;
         if constexpr (UPS) nf = load_flow(t);
@@ -905,7 +914,7 @@ __global__ __launch_bounds__(256) void k_hs_stream_fast(const float *__restrict_
         q2r[(P + 2) % 3] = lum1[lum_stride + (size_t)clampi(t + 2, 0, h - 1) * w + xc];
         {
             const float left = wave_up(row), right = wave_down(row);
-            const float ix = ((self_r ? row : right) - (self_l ? row : left)) * 0.5f;
+            const float ix = ((sr ? row : right) - (sl ? row : left)) * 0.5f;
             const float iy = (n1 - above) * 0.5f;
             const float it = n2 - row;
             const float rinv = __builtin_amdgcn_rcpf(__builtin_fmaf(iy, iy, __builtin_fmaf(ix, ix, lambda)));
@@ -928,8 +937,8 @@ __global__ __launch_bounds__(256) void k_hs_stream_fast(const float *__restrict_
             }
             const float su = (ar[j][s2].x + ar[j][s1].x) + arr.x, sv = (ar[j][s2].y + ar[j][s1].y) + arr.y;
             const float lu = wave_up(su), ru = wave_down(su), lv = wave_up(sv), rv = wave_down(sv);
-            const float ua = (((self_l ? su : lu) + su) + (self_r ? su : ru)) * ninth;
-            const float va = (((self_l ? sv : lv) + sv) + (self_r ? sv : rv)) * ninth;
+            const float ua = (((sl ? su : lu) + su) + (sr ? su : ru)) * ninth;
+            const float va = (((sl ? sv : lv) + sv) + (sr ? sv : rv)) * ninth;
             const HsFastCoef c = cfr[(P - j - 1 + kBig) % R]; // row r-1 entered j+1 passes ago
             const float num = __builtin_fmaf(c.ix, ua, __builtin_fmaf(c.iy, va, c.it));
             ar[j][s0] = arr; // the arriving row takes the slot of row r-3, which nothing reads any more
@@ -941,27 +950,35 @@ __global__ __launch_bounds__(256) void k_hs_stream_fast(const float *__restrict_
         }
     };
     // A whole turn of the rings (R passes) as straight-line code: every value keeps its register across the loop's back edge.
-    auto ring_turn = [&](int t, auto steady_tag) __attribute__((always_inline)) {
-        ring_pass(t, steady_tag, std::integral_constant<int, 0>{});
-        ring_pass(t + 1, steady_tag, std::integral_constant<int, 1>{});
-        ring_pass(t + 2, steady_tag, std::integral_constant<int, 2>{});
-        ring_pass(t + 3, steady_tag, std::integral_constant<int, 3>{});
-        ring_pass(t + 4, steady_tag, std::integral_constant<int, 4>{});
-        ring_pass(t + 5, steady_tag, std::integral_constant<int, 5>{});
+    auto ring_turn = [&](int t, auto steady_tag, auto border_tag) __attribute__((always_inline)) {
+        ring_pass(t, steady_tag, std::integral_constant<int, 0>{}, border_tag);
+        ring_pass(t + 1, steady_tag, std::integral_constant<int, 1>{}, border_tag);
+        ring_pass(t + 2, steady_tag, std::integral_constant<int, 2>{}, border_tag);
+        ring_pass(t + 3, steady_tag, std::integral_constant<int, 3>{}, border_tag);
+        ring_pass(t + 4, steady_tag, std::integral_constant<int, 4>{}, border_tag);
+        ring_pass(t + 5, steady_tag, std::integral_constant<int, 5>{}, border_tag);
         if constexpr (R == 9) {
-            ring_pass(t + 6, steady_tag, std::integral_constant<int, 6>{});
-            ring_pass(t + 7, steady_tag, std::integral_constant<int, 7>{});
-            ring_pass(t + 8, steady_tag, std::integral_constant<int, 8>{});
+            ring_pass(t + 6, steady_tag, std::integral_constant<int, 6>{}, border_tag);
+            ring_pass(t + 7, steady_tag, std::integral_constant<int, 7>{}, border_tag);
+            ring_pass(t + 8, steady_tag, std::integral_constant<int, 8>{}, border_tag);
         }
     };
     if constexpr (RING) {
         // the first turn fills the pipeline (K <= R - 1 passes of it) and the turns from the first one that reaches row hi on drain it:
         // the general form of the pass, whose levels look at their row number (passes past hi + K find nothing to do); all turns in
         // between are steady
-        int t = lo;
-        ring_turn(t, std::false_type{});
-        for (t += R; t + R <= hi; t += R) ring_turn(t, std::true_type{});
-        for (; t < hi + K; t += R) ring_turn(t, std::false_type{});
+        auto walk = [&](auto border_tag) __attribute__((always_inline)) {
+            int t = lo;
+            ring_turn(t, std::false_type{}, border_tag);
+            for (t += R; t + R <= hi; t += R) ring_turn(t, std::true_type{}, border_tag);
+            for (; t < hi + K; t += R) ring_turn(t, std::false_type{}, border_tag);
+        };
+#if NUS_HS_FAST_INNER_STRIPS
+        const bool inner = strip * U - K > 0 && strip * U - K + (kWave - 1) < w - 1; // wave-uniform
+        if (inner) walk(std::false_type{});
+        else
+#endif
+            walk(std::true_type{});
         return;
     }
 

@@ -164,11 +164,19 @@ class FramePipeline:
                                           up_real.data_ptr(), up_mid.data_ptr(), n, stream)
 
     def step_motion(self, frames, flows, mid, up_real, up_mid, stream: int = 0, levels: int = 3,
-                    coarse_iterations: int = 50, refine_iterations: int = 10, flow_mode: str = "exact") -> None:
+                    coarse_iterations: int = 50, refine_iterations: int = 10, flow_mode: str = "exact", pipelined: bool = False,
+                    chunk: int = 100) -> None:
         """Motion-compensated variant of `step`: a dense flow per pair from the
         pyramid + Horn-Schunck front end into `flows` ((n_units, h, w, 2) float32), then warp + blend with it
         instead of the reference's zero flow.  The flows are estimated pair by pair (several launches per pair,
-        each frame's pyramid built once), the warp and both upscales run once over the whole batch."""
+        each frame's pyramid built once), the warp and both upscales run once over the whole batch.
+
+        pipelined (round 5): the intended interpolate() of the reference is a PIPELINE -- pyramid -> coarse flow -> warp
+        (wgpu_interpolator.rs:881-935) -- and so is this: the batch goes through in chunks of `chunk` units, the estimator of
+        chunk i+1 on the caller's stream while warp + both upscales of chunk i run on a second stream.  The estimator's launches
+        are bound by memory and latency as often as by instruction issue, the warp and the resize kernels by instruction issue
+        alone, so the two streams fill each other's gaps; same kernels, same bytes, bit-identical outputs.  Uses torch for the
+        second stream and the events; `stream` must be torch's current stream (0 = that)."""
         from .flow import FlowEstimator
 
         if getattr(self, "_flow", None) is None:
@@ -178,11 +186,40 @@ class FramePipeline:
         n = mid.shape[0]
         base = frames.data_ptr()
         fb = self.frame_bytes
-        self._flow.estimate_device_stream(base, n + 1, self.w, self.h, flows.data_ptr(), stream)
-        self.interp.interpolate_device(base, fb, base + fb, fb, flows.data_ptr(), self.w, self.h, self.t, mid.data_ptr(), n,
-                                       stream)
-        self.upscaler.upscale_device(base, up_real.data_ptr(), n, stream)
-        self.upscaler.upscale_device(mid.data_ptr(), up_mid.data_ptr(), n, stream)
+        if not pipelined or n <= chunk:
+            self._flow.estimate_device_stream(base, n + 1, self.w, self.h, flows.data_ptr(), stream)
+            self.interp.interpolate_device(base, fb, base + fb, fb, flows.data_ptr(), self.w, self.h, self.t, mid.data_ptr(), n,
+                                           stream)
+            self.upscaler.upscale_device(base, up_real.data_ptr(), n, stream)
+            self.upscaler.upscale_device(mid.data_ptr(), up_mid.data_ptr(), n, stream)
+            return
+        import torch
+
+        main = torch.cuda.current_stream()
+        if stream not in (0, main.cuda_stream):
+            raise ValueError("step_motion(pipelined=True) runs on torch's current stream")
+        if self._aux is None:
+            self._aux = torch.cuda.Stream()
+            self._ev_start = torch.cuda.Event()
+            self._ev_mid = torch.cuda.Event()
+        if getattr(self, "_ev_chunks", None) is None or len(self._ev_chunks) < (n + chunk - 1) // chunk:
+            self._ev_chunks = [torch.cuda.Event() for _ in range((n + chunk - 1) // chunk)]
+        aux = self._aux
+        self._ev_start.record(main)
+        aux.wait_event(self._ev_start)  # whatever the caller queued before (readers of the output buffers) is done
+        ob = self.ow * self.oh * 4
+        for ci, k0 in enumerate(range(0, n, chunk)):
+            m = min(chunk, n - k0)
+            self._flow.estimate_device_stream(base + k0 * fb, m + 1, self.w, self.h, flows.data_ptr() + k0 * fb * 2, main.cuda_stream)
+            self._ev_chunks[ci].record(main)
+            aux.wait_event(self._ev_chunks[ci])
+            a = base + k0 * fb
+            self.interp.interpolate_device(a, fb, a + fb, fb, flows.data_ptr() + k0 * fb * 2, self.w, self.h, self.t,
+                                           mid.data_ptr() + k0 * fb, m, aux.cuda_stream)
+            self.upscaler.upscale_device(a, up_real.data_ptr() + k0 * ob, m, aux.cuda_stream)
+            self.upscaler.upscale_device(mid.data_ptr() + k0 * fb, up_mid.data_ptr() + k0 * ob, m, aux.cuda_stream)
+        self._ev_mid.record(aux)
+        main.wait_event(self._ev_mid)  # the caller's stream sees every output complete
 
     def step_overlapped(self, frames, mid, up_real, up_mid) -> None:
         """Same work with the blend on a second stream: the Lanczos kernel is bound by SIMD

@@ -249,6 +249,16 @@ def test_pipeline_step_motion_matches_stage_by_stage_oracle(nsc, oracle_mod):
         assert np.array_equal(mid[k].cpu().numpy(), want_mid), k
         assert np.array_equal(up_mid[k].cpu().numpy(), oracle_mod.lanczos3(want_mid, 2 * w, 2 * h)), k
         assert np.array_equal(up_real[k].cpu().numpy(), oracle_mod.lanczos3(frames[k], 2 * w, 2 * h)), k
+    # the same step as a two-stream pipeline over chunks (the estimator of chunk i+1 beside warp + upscales of chunk i): same bytes
+    want = [t.clone() for t in (flows, mid, up_real, up_mid)]
+    for chunk in (1, 2):
+        for t in (flows, mid, up_real, up_mid):
+            t.zero_()
+        pipe.step_motion(d_frames, flows, mid, up_real, up_mid, torch.cuda.current_stream().cuda_stream,
+                         levels=3, coarse_iterations=20, refine_iterations=5, pipelined=True, chunk=chunk)
+        torch.cuda.synchronize()
+        for got, w_ in zip((flows, mid, up_real, up_mid), want):
+            assert torch.equal(got, w_), chunk
 
 
 # ---- FAST mode of the estimators (nus_flow_set_mode): tolerance against the exact oracle ---------------------------------
