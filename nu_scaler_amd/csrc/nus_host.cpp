@@ -157,6 +157,11 @@ int HipUpscaler::set_option(const char *key, int64_t value)
         unit_order_ = (uint32_t)value;
         return kOk;
     }
+    if (!strcmp(key, "fsr_fast")) { // FSR1-style EASU in FAST arithmetic (nus_k_fsr.hip): 0 = the shaders' own operation order (default)
+        if (value != 0 && value != 1) return fail(kInvalidArgument, "fsr_fast must be 0 or 1");
+        fsr_fast_ = value != 0;
+        return kOk;
+    }
     if (!strcmp(key, "inject_retire_error")) { // TEST HOOK: the value-th frame retired from now on (1 = the next) reports a HIP error
         if (value < 0 || value > 1000000) return fail(kInvalidArgument, "inject_retire_error out of range");
         inject_retire_.store((int)value);
@@ -649,9 +654,9 @@ int HipUpscaler::enqueue(const uint8_t *d_in, uint8_t *d_out, uint32_t n_frames,
         e = launch_resize_rows(L, dt_, lanczos_exact_, resize_ncols_max_, resize_small_taps_, resize_union_taps_);
         break;
     case Variant::ResizeDown: e = launch_resize_down(L, dt_, lanczos_exact_, resize_ncols_max_, tx_.lz_max_taps, down_seg_w_); break;
-    case Variant::FsrEasu: e = launch_fsr1(L, 0, easu_sharpness(), rcas_sharpness()); break;
+    case Variant::FsrEasu: e = launch_fsr1(L, 0, easu_sharpness(), rcas_sharpness(), fsr_fast_); break;
     case Variant::FsrRcas: e = launch_fsr1(L, 1, easu_sharpness(), rcas_sharpness()); break;
-    case Variant::Fsr1Fused: e = launch_fsr1(L, 2, easu_sharpness(), rcas_sharpness()); break;
+    case Variant::Fsr1Fused: e = launch_fsr1(L, 2, easu_sharpness(), rcas_sharpness(), fsr_fast_); break;
     case Variant::LanczosR43RegWin: {
         uint32_t th = rows_per_wave_;
         if (th == 0) { // as at x3/2: 24 - 36 rows per wave on a batch, equal row blocks (taller blocks: + 5 - 10 %)

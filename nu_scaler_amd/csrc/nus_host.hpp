@@ -224,6 +224,7 @@ private:
     int device_ = 0;
     bool wgsl_bilinear_ = false;
     bool lanczos_exact_ = false;
+    bool fsr_fast_ = false;        // option "fsr_fast"
     bool force_general_ = false;
     bool force_per_pixel_ = false; // resize: never use the LDS row kernel
     bool force_rows_ = false;      // resize: never use the register-window variant of it

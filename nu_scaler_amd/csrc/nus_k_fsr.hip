@@ -115,6 +115,140 @@ __device__ __forceinline__ uint32_t fsr_easu_taps(TAP &&tap, float wx, float fx,
     return fsr_pack(sr, sg, sb);
 }
 
+// ---- FAST arithmetic (option "fsr_fast"; round 5) --------------------------------------------------------------------------
+// The exact kernel reproduces, operation for operation, two shaders the reference never dispatches (its FsrUpscaler returns "not
+// implemented", fsr.rs:316-332), at ~450 f32 instructions per output pixel of the fused pair.  FAST keeps the algorithm and the
+// decisions and drops the operation order where no decision depends on it:
+//   * a tap's distance d = |(x - fx) wx + (y - fy) wy| is computed exactly as the shader does (same products, same sum: the
+//     comparisons d <= 1, d <= 2 of FsrCubic -- the second one is a DISCONTINUITY of the weight, 1 -> 0 -- take the shader's side for
+//     every tap), scaled by 128 through wx, wy (exact: a power of two);
+//   * FsrCubic(d) from a table in LDS: 128 cells per unit of d, each cell (value at its left end, difference to its right end) inside
+//     ONE polynomial piece (the pieces meet at d = 1 = cell 128 and d = 2 = cell 256), linear interpolation with the cell's own
+//     fraction: |error| <= h^2 / 8 max|f''| = 5.3e-5 on weights of order 1; cell 256 (d = 2 exactly: weight 1) carries a slope that sends
+//     any d beyond it below zero, and the weight is max(., 0): 6 instructions + one ds_read_b64 where the two cubics, two compares and
+//     two selects take 13;
+//   * the 16-tap sums as FMAs, the division by the weight sum as v_rcp_f32 + one Newton step.
+// The direction weight of a texel (once per INPUT texel in the LDS prepass) and RCAS stay in the shader's own arithmetic.
+// Contract (tests/test_fsr1.py): EASU within 1 LSB of orc_fsr_easu (the truncating pack turns a 1e-6 difference into a count at
+// integer boundaries -- the exact pair itself returns {76, 77} for a flat 77); the fused pair is bit for bit orc_fsr_rcas applied to
+// the FAST EASU image (RCAS amplifies a count of its centre tap by 1 + 4 sharpness, so "within 1 LSB of orc_fsr1" is not a contract
+// any reordering of EASU can meet; EXACT remains the default and the verification mode).
+constexpr int kFsrLutScale = 128, kFsrLutCells = 3 * kFsrLutScale + 2; // d <= 3 (fx = fy = 0, tap (3, 3)): cells 0 .. 384 are reachable
+
+__device__ __forceinline__ float fsr_cubic_piece(float d, bool near_piece) // the shader's polynomials, plainly
+{
+    const float d2 = d * d, d3 = d * d2;
+    return near_piece ? 2.0f - 1.5f * d - 0.5f * d3 + d2 : 0.0f - 0.5f * d + 2.5f * d2 - d3;
+}
+
+__device__ __forceinline__ void fsr_build_lut(float2 *lut, int tid)
+{
+    for (int i = tid; i < kFsrLutCells; i += 256) {
+        const float a = (float)i / (float)kFsrLutScale, b = (float)(i + 1) / (float)kFsrLutScale;
+        float2 e = make_float2(0.0f, 0.0f);
+        if (i < 2 * kFsrLutScale) {
+            const bool near_piece = i < kFsrLutScale;
+            const float va = fsr_cubic_piece(a, near_piece);
+            e = make_float2(va, fsr_cubic_piece(b, near_piece) - va);
+        } else if (i == 2 * kFsrLutScale) {
+            e = make_float2(fsr_cubic_piece(2.0f, false), -1.0e9f); // d == 2 exactly keeps its weight; anything beyond goes negative
+        }
+        lut[i] = e;
+    }
+}
+
+template <typename TAP>
+__device__ __forceinline__ uint32_t fsr_easu_taps_fast(TAP &&tap, const float2 *lut, float wx, float fx, float fy, float sharp)
+{
+    const float wy = 1.0f - wx;
+    const float wxs = wx * (float)kFsrLutScale, wys = wy * (float)kFsrLutScale;
+    float X[4], Y[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        X[k] = ((float)k - fx) * wxs; // == (((float)k - fx) * wx) * 128: the shader's product, scaled exactly
+        Y[k] = ((float)k - fy) * wys;
+    }
+    float sr = 0.0f, sg = 0.0f, sb = 0.0f, sw = 0.0f;
+#pragma unroll
+    for (int y = 0; y < 4; ++y) {
+#pragma unroll
+        for (int x = 0; x < 4; ++x) {
+            const float4 c = tap(x, y);
+            const float ds = fabsf(X[x] + Y[y]); // 128 d, d as the shader rounds it
+            const float2 e = lut[(int)ds];
+            const float wgt = fmaxf(__builtin_fmaf(ds - floorf(ds), e.y, e.x), 0.0f);
+            sr = __builtin_fmaf(c.x, wgt, sr);
+            sg = __builtin_fmaf(c.y, wgt, sg);
+            sb = __builtin_fmaf(c.z, wgt, sb);
+            sw += wgt;
+        }
+    }
+    const float den = fmaxf(sw, 0.0001f);
+    float z = __builtin_amdgcn_rcpf(den);
+    z = z * __builtin_fmaf(-den, z, 2.0f); // one Newton step: relative error ~1e-7
+    sr *= z, sg *= z, sb *= z;
+    if (sharp > 0.001f) {
+        const float4 ctr = tap(1, 1);
+        const float ns = 1.0f - sharp;
+        sr = __builtin_fmaf(sr, ns, ctr.x * sharp);
+        sg = __builtin_fmaf(sg, ns, ctr.y * sharp);
+        sb = __builtin_fmaf(sb, ns, ctr.z * sharp);
+    }
+    return fsr_pack(sr, sg, sb);
+}
+
+// FAST at exactly x2: output pixels (2k + a, 2m + b), a, b in {0, 1}, all have (ix, iy) = (k, m) -- one 4x4 block of taps and one
+// direction weight for the four of them -- and fx, fy in {0.25, 0.75} exactly: the taps are read from LDS once per quad (a quarter of
+// the kernel's LDS traffic, which bounds it next to instruction issue) and the eight scaled offsets per axis are shared.  Per pixel
+// the operations are those of fsr_easu_taps_fast, in its order: the same bytes (tests/test_fsr1.py runs both).
+template <typename TAP>
+__device__ __forceinline__ void fsr_easu_quad_fast(TAP &&tap, const float2 *lut, float wx, float sharp, uint32_t (&out)[4])
+{
+    const float wy = 1.0f - wx;
+    const float wxs = wx * (float)kFsrLutScale, wys = wy * (float)kFsrLutScale;
+    float4 c[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) c[i] = tap(i & 3, i >> 2);
+    float X[2][4], Y[2][4];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float f = a ? 0.75f : 0.25f;
+            X[a][k] = ((float)k - f) * wxs;
+            Y[a][k] = ((float)k - f) * wys;
+        }
+    const float ns = 1.0f - sharp;
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            float sr = 0.0f, sg = 0.0f, sb = 0.0f, sw = 0.0f;
+#pragma unroll
+            for (int y = 0; y < 4; ++y)
+#pragma unroll
+                for (int x = 0; x < 4; ++x) {
+                    const float ds = fabsf(X[a][x] + Y[b][y]);
+                    const float2 e = lut[(int)ds];
+                    const float wgt = fmaxf(__builtin_fmaf(ds - floorf(ds), e.y, e.x), 0.0f);
+                    sr = __builtin_fmaf(c[y * 4 + x].x, wgt, sr);
+                    sg = __builtin_fmaf(c[y * 4 + x].y, wgt, sg);
+                    sb = __builtin_fmaf(c[y * 4 + x].z, wgt, sb);
+                    sw += wgt;
+                }
+            const float den = fmaxf(sw, 0.0001f);
+            float z = __builtin_amdgcn_rcpf(den);
+            z = z * __builtin_fmaf(-den, z, 2.0f);
+            sr *= z, sg *= z, sb *= z;
+            if (sharp > 0.001f) {
+                sr = __builtin_fmaf(sr, ns, c[5].x * sharp);
+                sg = __builtin_fmaf(sg, ns, c[5].y * sharp);
+                sb = __builtin_fmaf(sb, ns, c[5].z * sharp);
+            }
+            out[b * 2 + a] = fsr_pack(sr, sg, sb);
+        }
+}
+
 // EASU at output pixel (gx, gy), taps straight from memory: fsr.rs:104-169
 __device__ __forceinline__ uint32_t fsr_easu_px(const uint32_t *__restrict__ in, const FsrArgs &A, int gx, int gy)
 {
@@ -167,9 +301,13 @@ __device__ __forceinline__ uint32_t fsr_rcas_px(const float4 c, const float4 t, 
 // SRC_LDS: the input footprint of the tile is unpacked once into LDS as float4 (rgb / 255, and in .w
 // the direction weight wx of that texel), so an EASU evaluation is 16 ds_read_b128 + the tap sum; the
 // host picks it when the footprint of every tile fits `src_cap` texels (up-scaling; see launch_fsr1).
-template <FsrMode MODE, bool VEC, bool SRC_LDS>
+template <FsrMode MODE, bool VEC, bool SRC_LDS, bool FAST = false, bool QUAD = false>
 __global__ __launch_bounds__(256) void k_fsr1(const FsrArgs A, const int src_cap)
 {
+    static_assert(!FAST || (SRC_LDS && MODE != FsrMode::Rcas), "FAST: EASU out of the LDS source tile");
+    static_assert(!QUAD || FAST, "QUAD (exactly x2, host-checked): a variant of FAST");
+    __shared__ float2 lut[FAST ? kFsrLutCells : 1];
+    if constexpr (FAST) fsr_build_lut(lut, threadIdx.x); // (visible after the source tile's barriers)
     constexpr int HALO = MODE == FsrMode::Easu ? 0 : 1;
     constexpr int LW = kFsrTW + 2 * HALO, LH = kFsrTH + 2 * HALO;
     // Easu: packed pixels; Rcas / Fused: the pass-1 pixel re-unpacked once (what RCAS reads) + its luma
@@ -207,6 +345,65 @@ __global__ __launch_bounds__(256) void k_fsr1(const FsrArgs A, const int src_cap
     }
     (void)src_cap;
     // stage 1: the tile (+ halo), coordinates clamped into the image as both shaders' fetches do
+    if constexpr (QUAD) {
+        // one thread per 2x2 quad of output pixels (see fsr_easu_quad_fast); quads are aligned to even output coordinates, so with
+        // the halo of the fused mode the quad grid starts two pixels before the tile and covers one row / column more than it on
+        // each side (9 % of the quads' pixels are not stored).  Quads outside the image are skipped: the halo cells they would
+        // have filled hold the clamped pixel's value, copied below.
+        constexpr int Q0 = HALO ? 2 : 0, NQX = (kFsrTW + 2 * Q0) / 2, NQY = (kFsrTH + 2 * Q0) / 2;
+        constexpr int ROUNDS = (NQX * NQY + 255) / 256; // quads per thread (2 for EASU alone, 3 with the halo)
+        // the packed pixels of a thread's quads stay in registers until all of them are computed: unpacking them for RCAS next to
+        // the 16 taps and the tables of the quad still being summed cost 234 registers (two waves per SIMD)
+        uint32_t keep[ROUNDS][4];
+#pragma unroll
+        for (int r = 0; r < ROUNDS; ++r) {
+            const int q = tid + 256 * r;
+            const int qy = q / NQX, qx = q - qy * NQX;
+            const int k = (x0 - Q0) / 2 + qx, m = (y0 - Q0) / 2 + qy; // x0, y0 are even
+#pragma unroll
+            for (int j = 0; j < 4; ++j) keep[r][j] = 0u;
+            if (q >= NQX * NQY || k < 0 || k >= A.iw || m < 0 || m >= A.ih) continue;
+            const float4 *t = src + (m - 1 - fy0) * fw + (k - 1 - fx0);
+            fsr_easu_quad_fast([&](int x, int y) { return t[y * fw + x]; }, lut, t[fw + 1].w, A.easu_sharp, keep[r]);
+            if constexpr (MODE == FsrMode::Easu) { // no halo: the quad is four cells of the tile (87 registers this way, 102 held back)
+                tile[(2 * qy) * LW + 2 * qx] = keep[r][0], tile[(2 * qy) * LW + 2 * qx + 1] = keep[r][1];
+                tile[(2 * qy + 1) * LW + 2 * qx] = keep[r][2], tile[(2 * qy + 1) * LW + 2 * qx + 1] = keep[r][3];
+            } else {
+                asm volatile("" : "+v"(keep[r][0]), "+v"(keep[r][1]), "+v"(keep[r][2]), "+v"(keep[r][3])); // (keeps the rounds apart)
+            }
+        }
+        if constexpr (MODE != FsrMode::Easu)
+#pragma unroll
+        for (int r = 0; r < ROUNDS; ++r) {
+            const int q = tid + 256 * r;
+            const int qy = q / NQX, qx = q - qy * NQX;
+            const int k = (x0 - Q0) / 2 + qx, m = (y0 - Q0) / 2 + qy;
+            if (q >= NQX * NQY || k < 0 || k >= A.iw || m < 0 || m >= A.ih) continue;
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int a = 0; a < 2; ++a) {
+                    const int lx = 2 * qx + a - (Q0 - HALO), ly = 2 * qy + b - (Q0 - HALO);
+                    if (lx < 0 || lx >= LW || ly < 0 || ly >= LH) continue;
+                    if constexpr (MODE == FsrMode::Easu)
+                        tile[ly * LW + lx] = keep[r][b * 2 + a];
+                    else
+                        tile[ly * LW + lx] = fsr_rcas_tap(keep[r][b * 2 + a]);
+                }
+        }
+        if (HALO && (x0 == 0 || y0 == 0 || x0 + kFsrTW >= A.ow || y0 + kFsrTH >= A.oh)) { // (block-uniform) a tile at the image's border
+            __syncthreads();
+            for (int i = tid; i < LW * LH; i += 256) {
+                const int ly = i / LW, lx = i - ly * LW;
+                const int gx = x0 + lx - HALO, gy = y0 + ly - HALO;
+                const int cgx = clampi(gx, 0, A.ow - 1), cgy = clampi(gy, 0, A.oh - 1);
+                const int cl = (cgy - y0 + HALO) * LW + (cgx - x0 + HALO);
+                // (cells further out than the tile can reach are never read; the clamped cell is an in-image cell of this tile
+                // whenever the cell itself is one RCAS reads)
+                if ((cgx != gx || cgy != gy) && cgx - x0 + HALO < LW && cgy - y0 + HALO < LH) tile[i] = tile[cl];
+            }
+        }
+    } else
     for (int i = tid; i < LW * LH; i += 256) {
         const int ly = i / LW, lx = i - ly * LW;
         const int gx = clampi(x0 + lx - HALO, 0, A.ow - 1), gy = clampi(y0 + ly - HALO, 0, A.oh - 1);
@@ -217,8 +414,12 @@ __global__ __launch_bounds__(256) void k_fsr1(const FsrArgs A, const int src_cap
             const float cx = ((float)gx + 0.5f) * A.sx, cy = ((float)gy + 0.5f) * A.sy;
             const int ix = (int)cx, iy = (int)cy;
             const float4 *t = src + (iy - 1 - fy0) * fw + (ix - 1 - fx0);
-            p = fsr_easu_taps([&](int x, int y) { return t[y * fw + x]; }, t[fw + 1].w, cx - floorf(cx),
-                              cy - floorf(cy), A.easu_sharp);
+            if constexpr (FAST)
+                p = fsr_easu_taps_fast([&](int x, int y) { return t[y * fw + x]; }, lut, t[fw + 1].w, cx - floorf(cx),
+                                       cy - floorf(cy), A.easu_sharp);
+            else
+                p = fsr_easu_taps([&](int x, int y) { return t[y * fw + x]; }, t[fw + 1].w, cx - floorf(cx),
+                                  cy - floorf(cy), A.easu_sharp);
         } else {
             p = fsr_easu_px(in, A, gx, gy);
         }
@@ -274,7 +475,7 @@ size_t fsr_max_footprint(const FsrArgs &A, int halo)
 }
 } // namespace
 
-hipError_t launch_fsr1(const UpscaleLaunch &L, int mode, float easu_sharpness, float rcas_sharpness)
+hipError_t launch_fsr1(const UpscaleLaunch &L, int mode, float easu_sharpness, float rcas_sharpness, bool fast)
 {
     FsrArgs A;
     A.iw = (int)L.iw;
@@ -292,15 +493,32 @@ hipError_t launch_fsr1(const UpscaleLaunch &L, int mode, float easu_sharpness, f
     // LDS source tile when every tile's footprint fits beside the pixel tile in 64 KiB: 3072 texels for
     // EASU alone (any up-scaling ratio), 1700 next to the fused mode's float4 tile (ratios >= ~1.3)
     const size_t foot = mode == 1 ? 0 : fsr_max_footprint(A, mode == 2 ? 1 : 0);
-    const bool src_lds = mode != 1 && foot <= (mode == 2 ? 1700u : 3072u);
+    // (FAST adds the 3-KiB weight table to the block's LDS: its footprint caps are 192 texels lower; a shape that misses them runs
+    // the exact arithmetic, which meets the FAST contract trivially)
+    const bool src_lds = mode != 1 && foot <= (mode == 2 ? 1700u : 3072u) - (fast ? 192u : 0u);
     const size_t dyn = src_lds ? foot * sizeof(float4) : 0;
+#ifndef NUS_FSR_QUAD
+#define NUS_FSR_QUAD 1 // dev macro: 0 = FAST without the quad form at x2 (A/B timing)
+#endif
+    const bool quad = NUS_FSR_QUAD && fast && L.ow == 2 * L.iw && L.oh == 2 * L.ih; // exactly x2: four output pixels per input texel
     return for_frame_chunks(L, [&](const uint8_t *in, uint8_t *out, uint32_t n) {
         A.in = reinterpret_cast<const uint32_t *>(in);
         A.out = reinterpret_cast<uint32_t *>(out);
         const dim3 block(256), grid(cdiv(L.ow, kFsrTW), cdiv(L.oh, kFsrTH), n);
 #define NUS_FSR2(M, V, S) hipLaunchKernelGGL((k_fsr1<M, V, S>), grid, block, dyn, L.stream, A, (int)foot)
+#define NUS_FSRF(M, V)                                                                                       \
+    do {                                                                                                     \
+        if (quad)                                                                                            \
+            hipLaunchKernelGGL((k_fsr1<M, V, true, true, true>), grid, block, dyn, L.stream, A, (int)foot);  \
+        else                                                                                                 \
+            hipLaunchKernelGGL((k_fsr1<M, V, true, true, false>), grid, block, dyn, L.stream, A, (int)foot); \
+    } while (0)
 #define NUS_FSR(M)                      \
-    if (vec && src_lds)                 \
+    if (fast && src_lds && vec)         \
+        NUS_FSRF(M, true);              \
+    else if (fast && src_lds)           \
+        NUS_FSRF(M, false);             \
+    else if (vec && src_lds)            \
         NUS_FSR2(M, true, true);        \
     else if (vec)                       \
         NUS_FSR2(M, true, false);       \
@@ -319,6 +537,7 @@ hipError_t launch_fsr1(const UpscaleLaunch &L, int mode, float easu_sharpness, f
             NUS_FSR(FsrMode::Fused);
         }
 #undef NUS_FSR
+#undef NUS_FSRF
 #undef NUS_FSR2
     });
 }

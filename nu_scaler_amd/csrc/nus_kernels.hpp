@@ -150,7 +150,8 @@ hipError_t launch_lanczos_r32_edges(const UpscaleLaunch &L, const DeviceTables &
 hipError_t launch_lanczos_r43(const UpscaleLaunch &L, const DeviceTables &T, bool exact, uint32_t rows_per_wave);
 hipError_t launch_lanczos_r43_edges(const UpscaleLaunch &L, const DeviceTables &T, bool exact);
 // FSR1-style passes (fsr.rs:24-260).  mode 0: EASU, 1: RCAS (iw == ow, ih == oh), 2: EASU then RCAS fused.
-hipError_t launch_fsr1(const UpscaleLaunch &L, int mode, float easu_sharpness, float rcas_sharpness);
+// fast: EASU in FAST arithmetic where the LDS source tile applies (nus_k_fsr.hip; option "fsr_fast")
+hipError_t launch_fsr1(const UpscaleLaunch &L, int mode, float easu_sharpness, float rcas_sharpness, bool fast = false);
 
 constexpr uint32_t kLanczosX2EdgeCols = 8; // output columns left to the general kernel per side
 #ifndef NUS_LZ_STRIP_COLS

@@ -39,8 +39,10 @@ def test_oracle_fsr_properties(oracle_mod):
     assert d.min() >= 0 and d.max() <= 1 and (r[..., 3] == 255).all()
 
 
-def _run(nsc, alg, img, ow, oh, easu=-1.0, rcas=-1.0, quality="quality"):
+def _run(nsc, alg, img, ow, oh, easu=-1.0, rcas=-1.0, quality="quality", fast=False):
     u = nsc.PyWgpuUpscaler(quality, alg)
+    if fast:
+        u.set_option("fsr_fast", 1)
     u.set_sharpness(easu, rcas)
     ih, iw = img.shape[:2]
     u.initialize(iw, ih, ow, oh)
@@ -94,3 +96,64 @@ def test_gpu_fsr1_1080p_to_4k_device_batch(nsc, oracle_mod):
     got = d_out.cpu().numpy()
     for k in (0, 2):
         assert np.array_equal(got[k], oracle_mod.fsr1(frames[k], 2 * w, 2 * h, 0.0, 0.7))
+
+
+FAST_SIZES = [((64, 36), (128, 72)), ((320, 180), (640, 360)), ((100, 70), (257, 131)), ((17, 13), (40, 29)), ((5, 3), (130, 67)),
+              ((1, 1), (3, 2)), ((480, 270), (960, 540)), ((32, 24), (64, 48))]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dims", FAST_SIZES)
+def test_gpu_fsr_fast_mode_contract(nsc, oracle_mod, dims):
+    """Option "fsr_fast" (round 5): EASU's tap distances and piece decisions as the shader computes them, FsrCubic from a 128-cells-
+    per-unit table with linear interpolation, FMA sums, reciprocal + Newton step; direction weights and RCAS unchanged.  Contract:
+    EASU within 1 LSB of orc_fsr_easu on every sample (noise, gradient, flat and an edge image whose direction weight is exactly
+    0.5 -- taps at distance exactly 2, the discontinuity of the weight); the fused pair bit for bit orc_fsr_rcas of the FAST EASU
+    image.  EXACT (the default) stays bit-exact, and the two modes really differ somewhere."""
+    (w, h), (ow, oh) = dims
+    flat = np.full((h, w, 4), 77, np.uint8)
+    edge = np.zeros((h, w, 4), np.uint8)
+    edge[:, w // 2:] = 200  # a vertical edge: vgx = 0 on both sides of it, equal gradients in flat areas -> wx = 0.5 exactly
+    edge[h // 2:, :] //= 2
+    differs = False
+    for img in (oracle_mod.gen_noise(w, h, 77), oracle_mod.gen_gradient(w, h), flat, edge):
+        for es in (0.0, 0.3):
+            want_e = oracle_mod.fsr_easu(img, ow, oh, es)
+            got_e, u = _run(nsc, "easu", img, ow, oh, easu=es, fast=True)
+            assert u.kernel_variant == "fsr1_easu_tile"
+            d = np.abs(got_e.astype(np.int16) - want_e.astype(np.int16))
+            assert d.max() <= 1, (int(d.max()), es)
+            assert (got_e[..., 3] == 255).all()
+            differs = differs or bool(d.any())
+            got_f, u = _run(nsc, "fsr1", img, ow, oh, easu=es, rcas=0.7, fast=True)
+            assert u.kernel_variant == "fsr1_easu_rcas_fused_lds"
+            assert np.array_equal(got_f, oracle_mod.fsr_rcas(got_e, 0.7)), es
+        got_x, _ = _run(nsc, "fsr1", img, ow, oh, easu=0.0, rcas=0.7)  # the default mode is untouched
+        assert np.array_equal(got_x, oracle_mod.fsr1(img, ow, oh, 0.0, 0.7))
+    if w * h >= 64 * 36:
+        assert differs, "the FAST kernel did not run"
+    u = nsc.PyWgpuUpscaler("quality", "fsr1")
+    with pytest.raises(RuntimeError, match="fsr_fast must be 0 or 1"):
+        u.set_option("fsr_fast", 2)
+
+
+@pytest.mark.gpu
+def test_gpu_fsr_fast_1080p_to_4k_device_batch(nsc, oracle_mod):
+    """The FAST contract at the BASELINE size through the device path (3 frames per launch)."""
+    import torch
+    w, h = 1920, 1080
+    frames = np.stack([oracle_mod.gen_gradient(w, h, 3), oracle_mod.gen_noise(w, h, 35), oracle_mod.gen_noise(w, h, 36)])
+    d_in = torch.from_numpy(frames).cuda()
+    outs = {}
+    for alg in ("easu", "fsr1"):
+        u = nsc.PyWgpuUpscaler("quality", alg)
+        u.set_option("fsr_fast", 1)
+        u.initialize(w, h, 2 * w, 2 * h)
+        d_out = torch.empty((3, 2 * h, 2 * w, 4), dtype=torch.uint8, device="cuda")
+        u.upscale_device(d_in.data_ptr(), d_out.data_ptr(), 3, torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        outs[alg] = d_out.cpu().numpy()
+    for k in (0, 1):
+        d = np.abs(outs["easu"][k].astype(np.int16) - oracle_mod.fsr_easu(frames[k], 2 * w, 2 * h, 0.0).astype(np.int16))
+        assert d.max() <= 1
+        assert np.array_equal(outs["fsr1"][k], oracle_mod.fsr_rcas(outs["easu"][k], 0.7))

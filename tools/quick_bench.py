@@ -42,7 +42,8 @@ def main():
     print(f"frames={n} pattern={args.pattern}  (upscale: {up_bytes/1e6:.2f} MB/frame algorithmic)")
     cases = [("nearest", {}, {}), ("nearest", {}, {"force_general": 1}), ("bilinear", {}, {}), ("bilinear", {}, {"force_general": 1}),
              ("lanczos3", {"lanczos_mode": "fma"}, {}), ("lanczos3", {"lanczos_mode": "exact"}, {}),
-             ("bicubic", {"lanczos_mode": "fma"}, {}), ("easu", {}, {}), ("fsr1", {}, {})]
+             ("bicubic", {"lanczos_mode": "fma"}, {}), ("easu", {}, {}), ("fsr1", {}, {}),
+             ("easu", {}, {"fsr_fast": 1}), ("fsr1", {}, {"fsr_fast": 1})]
     if args.only:
         cases = [c for c in cases if c[0] in args.only.split(",")]
     if args.sweep:
