@@ -31,7 +31,8 @@ cp $(find $root/gpurun_out/flowprof -name "*kernel_stats.csv" | head -1) $out/fl
 python3 tools/flow_bench.py 2>&1 | grep "flow estimate" >> $out/flow_kernels.txt
 bash tools/flow_stream_prof.sh 101 3 > $out/flow_stream_kernels.txt 2>&1
 bash tools/flow_stream_prof.sh 101 9 > $out/flow_stream_kernels_fast_mode.txt 2>&1
-python3 tools/flow_stream_bench.py 101 3 9 2>&1 | grep "flow stream" > $out/flow_stream_exact_vs_fast.txt
+python3 tools/flow_stream_bench.py 101 3 9 19 2>&1 | grep "flow stream" > $out/flow_stream_exact_vs_fast_vs_shifting_fast.txt
+python3 tools/motion_bench.py 300 100 2>&1 | grep "motion step" > $out/motion_step_pipelined.txt
 echo "flow done"
 python3 tools/edge_stream_ab.py 2>&1 | grep -v amdgpu > $out/edge_stream_ab.txt
 (cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --output-format csv -d $out/edge_prof -o e -- python3 $root/tools/unit_only.py 300 3 > $out/edge_prof.log 2>&1)
