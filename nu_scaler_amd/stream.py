@@ -400,6 +400,11 @@ class ShardedStream:
         self.start, self.count = shard_frames(self.total_units, self.world, self.rank)
         self.source = source if source is not None else SyntheticSource("gradient")
         self.frames = self.source(self.start, self.count + 1, self.width, self.height, self.device)
+        want = (self.count + 1, self.height, self.width, 4)
+        if tuple(self.frames.shape) != want or self.frames.dtype != torch.uint8 or self.frames.device.type != self.device.type \
+                or not self.frames.is_contiguous():
+            raise ValueError(f"the frame source must return a contiguous uint8 tensor of shape {want} on {self.device}, "
+                             f"got {tuple(self.frames.shape)} {self.frames.dtype} on {self.frames.device}")
         self.mid, self.up_real, self.up_mid = self.pipeline.alloc(self.count, self.device)
         self.elapsed_local = None
         self.steps_run = 0
@@ -510,10 +515,28 @@ def run_sharded(total_units: int, width: int, height: int, *, steps: int = 1, wa
         s.run(steps, warmup)
         row = {"elapsed_s": s.elapsed_local, "first_unit": float(s.start), "units": float(s.count),
                "numa_node": s.placement.get("numa_node"), "bound": 1.0 if s.placement.get("bound") else 0.0}
-        extra = sink(s) if sink is not None else None
-        if extra:
-            row.update({f"sink_{k}": v for k, v in extra.items()})
+        # a sink that raises on ONE rank must not leave the others waiting in the gather: its failure travels in the row, every rank
+        # learns of it, and the exception is raised again (on the rank it happened on; RuntimeError on the others) after the gather
+        failure = None
+        row["sink_failed"] = 0.0
+        if sink is not None:
+            try:
+                extra = sink(s)
+                if extra:
+                    row.update({f"sink_{k}": v for k, v in extra.items()})
+            except Exception as e:  # noqa: BLE001 -- re-raised below
+                failure = e
+                row["sink_failed"] = 1.0
+        # (the rows of all ranks must have the same keys: a failed sink's numbers are missing, so only the fixed keys travel then)
+        any_failed = max(r["sink_failed"] for r in s.gather({"sink_failed": row["sink_failed"]})) > 0.0
+        if any_failed:
+            row = {k: v for k, v in row.items() if not k.startswith("sink_") or k == "sink_failed"}
         rows = s.gather(row)
+        if failure is not None:
+            raise failure
+        if any_failed:
+            bad = [i for i, r in enumerate(rows) if r["sink_failed"]]
+            raise RuntimeError(f"run_sharded: the sink failed on rank(s) {bad}")
         out = s.summarize(rows)
         out.update(rank=s.rank, rows=rows, placement={k: v for k, v in s.placement.items() if not k.startswith("_")})
         return out

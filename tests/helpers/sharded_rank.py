@@ -60,6 +60,7 @@ def main():
     ap.add_argument("--units-total", type=int, default=7)
     ap.add_argument("--steps", type=int, default=1)
     ap.add_argument("--warmup", type=int, default=0)
+    ap.add_argument("--sink-fails-on", type=int, default=-1, help="the sink raises on this rank (the job must end, not hang)")
     args = ap.parse_args()
     import nu_scaler_amd as nsc
     import oracle
@@ -72,6 +73,8 @@ def main():
         return pipes[-1]
 
     def sink(s):
+        if s.rank == args.sink_fails_on:
+            raise ValueError("sink failed on purpose")
         # every unit of THIS rank's shard, regenerated from its position in the global stream
         bad = 0
         for k in range(s.count):

@@ -56,6 +56,24 @@ def test_world3_ragged_shards_and_an_empty_rank(nsc):
     assert len(out[0]["unit_digests"]) == 2
 
 
+def test_a_sink_that_raises_on_one_rank_ends_the_job(nsc):
+    """run_sharded: the failure of one rank's sink travels through the gather -- every rank raises (the failing one its own
+    exception), nobody is left waiting in a collective, the launcher reports a non-zero exit code within seconds."""
+    import time
+
+    t0 = time.time()
+    rc, out = _launch(2, ["--units-total", "5", "--sink-fails-on", "1"], timeout=240)
+    assert rc != 0 and out == [] and time.time() - t0 < 200
+
+
+def test_frame_source_shape_is_checked(nsc):
+    import torch
+
+    with pytest.raises(ValueError, match="frame source must return"):
+        nsc.ShardedStream(3, 32, 8, source=lambda first, n, w, h, dev: torch.zeros((n, h, w, 3), dtype=torch.uint8), device_kind="cpu",
+                          backend="gloo", bind=False, pipeline_factory=lambda *a: None)
+
+
 def test_cli_stream_without_a_gpu_fails_loudly(nsc):
     """No CPU fallback: `stream` on a box without a HIP device says so and exits non-zero -- alone and through the launcher."""
     import torch
