@@ -29,3 +29,31 @@ for _ in range(24):
             bad += 1
             print("MISMATCH", w, h, levels, ci, ri, n, mode)
 print(f"{cases} cases, {bad} mismatches")
+
+# round 5: FAST mode, the ring form of the pass against the shifting form (bit for bit) and against the oracle (1e-3 px), random shapes
+for _ in range(16):
+    w = int(rng.integers(20, 700)); h = int(rng.integers(12, 400)); levels = int(rng.integers(1, 4))
+    ci = int(rng.integers(0, 40)); ri = int(rng.integers(0, 13)); n = int(rng.integers(2, 5))
+    frames = np.stack([orc.gen_noise(w, h, int(rng.integers(1, 999))) for _ in range(n)])
+    d_frames = torch.from_numpy(frames).to(dev)
+    got = {}
+    for form in ("ring", "shift"):
+        if form == "shift":
+            os.environ["NUS_HS_FAST_SHIFT"] = "1"
+        else:
+            os.environ.pop("NUS_HS_FAST_SHIFT", None)
+        fe = nsc.FlowEstimator(levels=levels, coarse_iterations=ci, refine_iterations=ri)
+        fe.set_mode("fast")
+        fe.set_tiled(3)
+        d_flows = torch.full((n - 1, h, w, 2), float("nan"), dtype=torch.float32, device=dev)
+        fe.estimate_device_stream(d_frames.data_ptr(), n, w, h, d_flows.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        got[form] = d_flows.cpu().numpy()
+    os.environ.pop("NUS_HS_FAST_SHIFT", None)
+    want = np.stack([orc.flow_estimate(frames[k], frames[k + 1], levels, ci, ri, fe.lambda_) for k in range(n - 1)])
+    cases += 1
+    err = float(np.abs(got["ring"].astype(np.float64) - want).max())
+    if not np.array_equal(got["ring"], got["shift"]) or not err <= 1e-3:
+        bad += 1
+        print("FAST MISMATCH", w, h, levels, ci, ri, n, "ring == shift:", np.array_equal(got["ring"], got["shift"]), "max err", err)
+print("fast-mode cases done; total", cases, "bad", bad)

@@ -28,9 +28,17 @@ for case in range(cases):
     mode = str(rng.choice(["fma", "exact"]))
     alg = str(rng.choice(["lanczos3", "lanczos3", "bicubic", "triangle"]))
     fmt = str(rng.choice(["rgba", "rgba", "bgra", "rgbx"]))
-    content = str(rng.choice(["noise", "opaque", "mixed"]))
+    content = str(rng.choice(["noise", "opaque", "mixed", "flat", "flat"]))
     frames_np = np.stack([oracle.gen_noise(w, h, int(rng.integers(1, 1 << 30))) for _ in range(n + 1)])
-    if content != "noise":
+    if content == "flat":  # round 5: regions of one alpha each (any value), the boundaries at random rows and columns, one frame out of step
+        a0, a1, a2 = (int(v) for v in rng.integers(0, 256, 3))
+        r1, r2 = sorted(int(v) for v in rng.integers(0, h, 2))
+        c1 = int(rng.integers(0, w))
+        frames_np[..., 3] = a0
+        frames_np[:, r1:r2, :, 3] = a1
+        frames_np[:, :, c1:, 3] = a2
+        frames_np[int(rng.integers(0, n + 1)), :, :, 3] = int(rng.integers(0, 256))
+    elif content != "noise":
         frames_np[..., 3] = 255
     if content == "mixed":
         k = int(rng.integers(0, n + 1))
