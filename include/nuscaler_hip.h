@@ -453,6 +453,15 @@ int nus_flow_estimate_device(nus_flow *h, const void *d_a, const void *d_b, uint
 int nus_flow_estimate_device_stream(nus_flow *h, const void *d_frames, uint32_t n_frames, uint32_t w, uint32_t hgt,
                                     uint32_t levels, uint32_t coarse_iters, uint32_t refine_iters, float lambda,
                                     void *d_flows, void *stream);
+/* Motion-compensated interpolation of a device-resident stream as ONE pipeline -- the reference's intended interpolate()
+ * (wgpu_interpolator.rs:881-935: build_pyramid -> compute_coarse_flow -> warp): the n_frames - 1 flows of
+ * nus_flow_estimate_device_stream AND the in-between frame of every pair (k, k + 1) at time_t in [0, 1], warped + blended with that
+ * flow (warp_blend.wgsl:25-43; dense-flow warp in FMA mode: within 1 LSB of the CPU blend, as nus_interp_set_mode(.., FMA)), tightly
+ * packed RGBA8 at d_mid.  d_flows may be NULL (the in-between frames only: the flows then stay in the estimator's workspace).
+ * Same bytes as nus_flow_estimate_device_stream followed by nus_interp_interpolate_device in FMA mode.  Pointers 16-byte aligned. */
+int nus_flow_interpolate_device_stream(nus_flow *h, const void *d_frames, uint32_t n_frames, uint32_t w, uint32_t hgt,
+                                       uint32_t levels, uint32_t coarse_iters, uint32_t refine_iters, float lambda, float time_t,
+                                       void *d_flows, void *d_mid, void *stream);
 
 #ifdef __cplusplus
 }

@@ -701,4 +701,15 @@ int nus_flow_estimate_device_stream(nus_flow *h, const void *d_frames, uint32_t 
     });
 }
 
+int nus_flow_interpolate_device_stream(nus_flow *h, const void *d_frames, uint32_t n_frames, uint32_t w, uint32_t hgt,
+                                       uint32_t levels, uint32_t coarse_iters, uint32_t refine_iters, float lambda, float time_t,
+                                       void *d_flows, void *d_mid, void *stream)
+{
+    return guarded<int>("nus_flow_interpolate_device_stream", [&]() -> int {
+        return h ? h->impl.interpolate_device_stream(d_frames, n_frames, w, hgt, levels, coarse_iters, refine_iters, lambda, time_t,
+                                                     d_flows, d_mid, static_cast<hipStream_t>(stream))
+                 : null_handle();
+    });
+}
+
 } // extern "C"

@@ -362,22 +362,60 @@ int HipFlowEstimator::estimate_device_stream(const void *d_frames, uint32_t n_fr
                                              void *d_flows, hipStream_t stream)
 {
     std::lock_guard<std::mutex> lk(mu_);
+    if (!d_flows) return fail(kInvalidArgument, "flow: null device pointer");
+    return stream_impl(d_frames, n_frames, w, h, levels, coarse_iters, refine_iters, lambda, d_flows, nullptr, 0.5f, stream);
+}
+
+int HipFlowEstimator::interpolate_device_stream(const void *d_frames, uint32_t n_frames, uint32_t w, uint32_t h, uint32_t levels,
+                                                uint32_t coarse_iters, uint32_t refine_iters, float lambda, float t, void *d_flows,
+                                                void *d_mid, hipStream_t stream)
+{
+    std::lock_guard<std::mutex> lk(mu_);
+    if (!d_mid) return fail(kInvalidArgument, "flow: null device pointer");
+    if (!(t >= 0.0f && t <= 1.0f)) return fail(kInvalidArgument, "flow: t must be in [0, 1]");
+    if ((reinterpret_cast<uintptr_t>(d_mid) % 16) || (reinterpret_cast<uintptr_t>(d_flows) % 16))
+        return fail(kInvalidArgument, "flow: device pointers must be 16-byte aligned");
+    return stream_impl(d_frames, n_frames, w, h, levels, coarse_iters, refine_iters, lambda, d_flows, d_mid, t, stream);
+}
+
+// (called with mu_ held)  d_flows may be null when d_mid is not: the caller wants the in-between frames only.
+int HipFlowEstimator::stream_impl(const void *d_frames, uint32_t n_frames, uint32_t w, uint32_t h, uint32_t levels,
+                                  uint32_t coarse_iters, uint32_t refine_iters, float lambda, void *d_flows, void *d_mid, float t,
+                                  hipStream_t stream)
+{
     CHECK_DIMS(w, h);
-    if (!d_frames || !d_flows) return fail(kInvalidArgument, "flow: null device pointer");
+    if (!d_frames || (!d_flows && !d_mid)) return fail(kInvalidArgument, "flow: null device pointer");
     if (n_frames < 2) return fail(kInvalidArgument, "flow: a stream needs at least 2 frames");
     Pyramid g;
     int rc = plan(w, h, levels, g);
     if (rc != kOk) return rc;
     const uint8_t *frames = static_cast<const uint8_t *>(d_frames);
-    uint8_t *flows = static_cast<uint8_t *>(d_flows);
+    uint8_t *flows = static_cast<uint8_t *>(d_flows), *mid = static_cast<uint8_t *>(d_mid);
     const size_t frame_bytes = (size_t)w * h * 4, flow_bytes = (size_t)w * h * 8;
+    // the warp kernel behind an estimator that did not warp itself: pairs [k0, k0 + n) with the flows at `fl`
+    auto warp_behind = [&](uint32_t k0, uint32_t n, const void *fl) -> int {
+        WarpLaunch L;
+        L.a = frames + (size_t)k0 * frame_bytes;
+        L.b = L.a + frame_bytes;
+        L.a_stride = L.b_stride = frame_bytes;
+        L.flow = static_cast<const float *>(fl);
+        L.fma = true;
+        L.out = mid + (size_t)k0 * frame_bytes;
+        L.w = w, L.h = h, L.t = t, L.n_pairs = n, L.stream = stream;
+        NUS_HIP(launch_warp_blend(L));
+        return kOk;
+    };
     if (!tiled_ && !fast_) { // the shader-shaped kernels, pair by pair (each frame's pyramid still built once)
+        if (mid && !flows) { // (they write a pair's flow where they are told to: one pair's worth of workspace)
+            if ((rc = reserve(flow_bytes, 9)) != kOk) return rc;
+        }
         if ((rc = build_pyramid(frames, 4, g, stream)) != kOk) return rc;
         for (uint32_t k = 0; k + 1 < n_frames; ++k) {
             const int slot_a = 4 + (int)(k & 1), slot_b = 5 - (int)(k & 1);
             if ((rc = build_pyramid(frames + (size_t)(k + 1) * frame_bytes, slot_b, g, stream)) != kOk) return rc;
-            if ((rc = solve(slot_a, slot_b, g, coarse_iters, refine_iters, lambda, flows + (size_t)k * flow_bytes, stream)) != kOk)
-                return rc;
+            void *fl = flows ? static_cast<void *>(flows + (size_t)k * flow_bytes) : slot_[9];
+            if ((rc = solve(slot_a, slot_b, g, coarse_iters, refine_iters, lambda, fl, stream)) != kOk) return rc;
+            if (mid && (rc = warp_behind(k, 1, fl)) != kOk) return rc;
         }
         return kOk;
     }
@@ -400,7 +438,8 @@ int HipFlowEstimator::estimate_device_stream(const void *d_frames, uint32_t n_fr
     for (uint32_t c0 = 0; c0 < n_pairs; c0 += chunk) {
         const uint32_t pairs = n_pairs - c0 < chunk ? n_pairs - c0 : chunk;
         if ((rc = solve_batch(frames + (size_t)c0 * frame_bytes, pairs, g, coarse_iters, refine_iters, lambda,
-                              flows + (size_t)c0 * flow_bytes, stream)) != kOk)
+                              flows ? flows + (size_t)c0 * flow_bytes : nullptr, stream, mid ? mid + (size_t)c0 * frame_bytes : nullptr,
+                              t)) != kOk)
             return rc;
     }
     return kOk;
@@ -409,8 +448,9 @@ int HipFlowEstimator::estimate_device_stream(const void *d_frames, uint32_t n_fr
 // `pairs` + 1 consecutive RGBA8 frames -> `pairs` flows, every stage one launch over the whole chunk.
 // Workspace (grow-only slots): 0 / 1 the f32 RGBA inputs of the odd / even pyramid levels of all frames,
 // 2 / 3 flow ping-pong [pair][level cells], 4 luminance planes [level][frame][cells], 5 coefficients [pair][cells][3].
+// d_mid != nullptr: also the pairs' in-between frames at time t (see interpolate_device_stream); d_flows may then be null.
 int HipFlowEstimator::solve_batch(const uint8_t *d_frames, uint32_t pairs, const Pyramid &g, uint32_t coarse_iters,
-                                  uint32_t refine_iters, float lambda, uint8_t *d_flows, hipStream_t stream)
+                                  uint32_t refine_iters, float lambda, uint8_t *d_flows, hipStream_t stream, uint8_t *d_mid, float t)
 {
     int rc;
     // The Jacobi kernel of a level.  FAST: k_hs_stream_fast where the level's batch would stream anyway (or the streamed kernel
@@ -461,12 +501,18 @@ int HipFlowEstimator::solve_batch(const uint8_t *d_frames, uint32_t pairs, const
                                      l + 1 < nl ? cells[l + 1] : 0, jacobi));
     }
     float *const out = reinterpret_cast<float *>(d_flows);
+    // the finest level's last launch warps the pairs itself where it can (HsWarp); `warped` says whether it did
+    HsWarp hw;
+    hw.frames = d_frames, hw.frame_stride = cells[0] * 4, hw.mid = d_mid, hw.t = t, hw.sel = kSelRGBA;
+    bool warped = false;
     // `coarse`: the level continues the flow of level l + 1 in f0, which the first launch upsamples as it loads it
     auto iterate = [&](uint32_t l, uint32_t iters, bool zero, bool coarse) -> int {
+        bool did = false;
         NUS_HIP(launch_hs_iterate(coef, lambda, &f0, &f1, g.w[l], g.h[l], iters, zero, l == 0 ? out : nullptr, stream, pairs,
                                   cells[l] * 3, cells[l], cells[0], level_kernel(l), from_planes(l) ? lum + lum_off[l] : nullptr, cells[l],
                                   coarse ? f0 : nullptr, coarse ? g.w[l + 1] : 0, coarse ? g.h[l + 1] : 0, 2.0f,
-                                  coarse ? cells[l + 1] : 0));
+                                  coarse ? cells[l + 1] : 0, l == 0 && d_mid ? &hw : nullptr, &did));
+        if (l == 0) warped = did;
         return kOk;
     };
     // coarsest level: from zero flow (compute_coarse_flow, :1136-1154)
@@ -494,7 +540,19 @@ int HipFlowEstimator::solve_batch(const uint8_t *d_frames, uint32_t pairs, const
         f1 = t;
         if (refine_iters > 0 && (rc = iterate((uint32_t)l, refine_iters, false, false)) != kOk) return rc;
     }
-    if (f0 != out) NUS_HIP(hipMemcpyAsync(out, f0, cells[0] * pairs * 8, hipMemcpyDeviceToDevice, stream));
+    // (after a launch that warped without storing its flow, f0 names a buffer nothing was written to: nobody reads it)
+    if (out && f0 != out && !(warped && d_mid)) NUS_HIP(hipMemcpyAsync(out, f0, cells[0] * pairs * 8, hipMemcpyDeviceToDevice, stream));
+    if (d_mid && !warped) { // the warp kernel behind the estimator, on the flow where it is (the caller's buffer, or the workspace)
+        WarpLaunch W;
+        W.a = d_frames;
+        W.b = d_frames + cells[0] * 4;
+        W.a_stride = W.b_stride = cells[0] * 4;
+        W.flow = out ? out : f0;
+        W.fma = true;
+        W.out = d_mid;
+        W.w = g.w[0], W.h = g.h[0], W.t = t, W.n_pairs = pairs, W.stream = stream;
+        NUS_HIP(launch_warp_blend(W));
+    }
     return kOk;
 }
 

@@ -49,6 +49,14 @@ public:
     int estimate_device_stream(const void *d_frames, uint32_t n_frames, uint32_t w, uint32_t h, uint32_t levels,
                                uint32_t coarse_iters, uint32_t refine_iters, float lambda, void *d_flows,
                                hipStream_t stream);
+    // The reference's intended interpolate() as ONE pipeline (wgpu_interpolator.rs:881-935: pyramid -> coarse flow -> warp): the
+    // flows of estimate_device_stream AND the n_frames - 1 in-between frames at time t warped + blended with them (dense-flow warp
+    // in FMA mode) into d_mid: the warp kernel runs behind the estimator on the flow where it is (the caller's buffer, or the
+    // workspace when d_flows == nullptr).  (NUS_HS_FUSED_WARP=1: the finest level's last Jacobi launch warps with the flow it has
+    // just finished instead -- HsWarp; same bytes, measured slower, off by default; tests/test_flow.py runs both.)
+    int interpolate_device_stream(const void *d_frames, uint32_t n_frames, uint32_t w, uint32_t h, uint32_t levels,
+                                  uint32_t coarse_iters, uint32_t refine_iters, float lambda, float t, void *d_flows, void *d_mid,
+                                  hipStream_t stream);
 
 private:
     struct Pyramid { // level geometry; levels are packed at `offset` (16 bytes per pixel reserved)
@@ -64,8 +72,10 @@ private:
     // 64 -> 100 pairs per chunk: 76 -> 71 us per pair on a 300-pair stream (profiles/r02_flow_jacobi_streamed_ab.txt)
     static constexpr uint32_t kStreamMaxChunkPairs = 100;
     static constexpr size_t kStreamWorkspaceBytes = (size_t)6 << 30;
+    int stream_impl(const void *d_frames, uint32_t n_frames, uint32_t w, uint32_t h, uint32_t levels, uint32_t coarse_iters,
+                    uint32_t refine_iters, float lambda, void *d_flows, void *d_mid, float t, hipStream_t stream);
     int solve_batch(const uint8_t *d_frames, uint32_t pairs, const Pyramid &g, uint32_t coarse_iters, uint32_t refine_iters,
-                    float lambda, uint8_t *d_flows, hipStream_t stream);
+                    float lambda, uint8_t *d_flows, hipStream_t stream, uint8_t *d_mid = nullptr, float t = 0.5f);
     int fail(int status, const std::string &msg);
     int fail_hip(hipError_t e, const char *what);
     int ensure_device();
@@ -79,7 +89,7 @@ private:
     int jacobi_ = 0; // JacobiKernel
     bool fast_ = false; // set_mode(1): the estimator's Jacobi steps in FAST arithmetic (k_hs_stream_fast), every level streamed
     hipStream_t stream_ = nullptr;
-    static constexpr int kSlotCount = 9; // 0-5 pyramids / flows / planes, 6-7 the host entry point's frames, 8 the FAST pair
+    static constexpr int kSlotCount = 10; // 0-5 pyramids / flows / planes, 6-7 the host entry point's frames, 8 the FAST pair, 9 one pair's flow
     void *slot_[kSlotCount] = {nullptr};
     size_t slot_cap_[kSlotCount] = {0};
     std::string error_;

@@ -1,5 +1,6 @@
 // nus_k_flow.hip -- optical-flow front end: Gaussian pyramid + Horn-Schunck.
 #include "nus_device.hpp"
+#include "nus_warp_device.hpp"
 #include <algorithm>
 #include <cstdlib>
 #include <type_traits>
@@ -783,12 +784,16 @@ struct HsFastCoef {
 #ifndef NUS_HS_FAST_RING_MAXK
 #define NUS_HS_FAST_RING_MAXK 8 // launches of up to this many steps take the ring form
 #endif
-template <int K, bool UPS, bool RING = false>
+// WARP (round 5, ring form only): the launch that finishes the finest level's flow also warps + blends the pair's two frames with it
+// (warp_blend_pixel<kWarpFma>, the very code of k_warp_blend_flow) and stores the in-between pixel; the flow itself is stored only
+// if the caller wants it (fout_all != nullptr).  Saves the flow's way through HBM to a separate warp launch (33 MB per 1080p pair).
+template <int K, bool UPS, bool RING = false, bool WARP = false>
 __global__ __launch_bounds__(256) void k_hs_stream_fast(const float *__restrict__ lum_all, size_t lum_stride, float lambda,
                                                         const float2 *__restrict__ fin_all, size_t fin_stride,
                                                         float2 *__restrict__ fout_all, size_t fout_stride, int w, int h, int strips,
-                                                        int row_blocks, int rows_per_block, HsCoarse coarse)
+                                                        int row_blocks, int rows_per_block, HsCoarse coarse, HsWarp warp)
 {
+    static_assert(!WARP || (RING && !UPS), "WARP: the ring form of a launch that continues a full-resolution flow");
     constexpr int U = kWave - 2 * K; // columns a wave writes
     const int lane = threadIdx.x & (kWave - 1);
     const int g = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6)); // wave-uniform, in an SGPR
@@ -797,6 +802,16 @@ __global__ __launch_bounds__(256) void k_hs_stream_fast(const float *__restrict_
     const float *lum1 = lum_all + blockIdx.y * lum_stride; // frame 1's plane; frame 2's follows lum_stride floats further on
     const float2 *fin = fin_all ? fin_all + blockIdx.y * fin_stride : nullptr; // null = start from zero flow
     float2 *fout = fout_all + blockIdx.y * fout_stride;
+    // WARP: the pair's frames through buffer resources (32-bit offsets: frames < 4 GiB, host-checked), per-lane copies of the constants
+    const uint32_t wframe_bytes = (uint32_t)w * (uint32_t)h * 4u;
+    const uint8_t *wfa = WARP ? warp.frames + (size_t)blockIdx.y * warp.frame_stride : nullptr;
+    const __amdgpu_buffer_rsrc_t wra = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(wfa), 0, WARP ? wframe_bytes : 0u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wrb = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<uint8_t *>(WARP ? wfa + warp.frame_stride : nullptr), 0, WARP ? wframe_bytes : 0u, 0x00020000);
+    uint32_t *wmid = WARP ? reinterpret_cast<uint32_t *>(warp.mid) + (size_t)blockIdx.y * (size_t)w * h : nullptr;
+    float wtv = warp.t, wwmax = (float)(w - 1), whmax = (float)(h - 1);
+    if constexpr (WARP) asm volatile("" : "+v"(wtv), "+v"(wwmax), "+v"(whmax));
+    const float wnt = 1.0f - wtv;
     const int x = strip * U - K + lane, xc = clampi(x, 0, w - 1);
     const bool self_l = x <= 0, self_r = x >= w - 1;
     const bool writer = lane >= K && lane < kWave - K && x < w;
@@ -945,7 +960,14 @@ __global__ __launch_bounds__(256) void k_hs_stream_fast(const float *__restrict_
             arr = make_float2(__builtin_fmaf(-num, c.gx, ua), __builtin_fmaf(-num, c.gy, va));
             if (j == K - 1) {
                 const int y = r - 1;
-                if (y >= y0 && y < y1 && writer) fout[(size_t)y * w + x] = arr;
+                if (y >= y0 && y < y1 && writer) {
+                    if (!WARP || fout_all != nullptr) fout[(size_t)y * w + x] = arr;
+                    if constexpr (WARP) {
+                        const uint32_t p = warp_blend_pixel<kWarpFma>(wra, wrb, (uint32_t)w * 4u, wwmax, whmax, (uint32_t)w - 2u, (uint32_t)h - 2u,
+                                                                      (float)x, (float)y, arr, wtv, wnt);
+                        wmid[(size_t)y * w + x] = swz(p, warp.sel);
+                    }
+                }
             }
         }
     };
@@ -1270,20 +1292,32 @@ bool hs_iterate_streams(uint32_t w, uint32_t h, uint32_t n, int kernel)
 hipError_t launch_hs_iterate(const float *coef, float lambda, float **flow_a, float **flow_b, uint32_t w, uint32_t h,
                              uint32_t iterations, bool zero_start, float *final_out, hipStream_t stream, uint32_t n,
                              size_t coef_stride, size_t flow_stride, size_t final_stride, int kernel, const float *lum1,
-                             size_t lum_stride, const float *coarse, uint32_t cw, uint32_t ch, float coarse_scale, size_t coarse_stride)
+                             size_t lum_stride, const float *coarse, uint32_t cw, uint32_t ch, float coarse_scale, size_t coarse_stride,
+                             const HsWarp *warp, bool *warped)
 {
     if (kernel == kJacobiStreamFast) { // FAST arithmetic (k_hs_stream_fast): always streamed, always from the luminance planes
         if (lum1 == nullptr) return hipErrorInvalidValue;
         // one launch of k steps over pairs [0, m) of the given bases
+        bool did_warp = false;
         auto launch_one = [&](uint32_t k, bool ups, const float *lum, const float2 *fi, float2 *fo, size_t out_stride, const HsCoarse &hc,
-                              uint32_t m) -> hipError_t {
+                              uint32_t m, const HsWarp *wp) -> hipError_t {
             const HsStreamShape sh = hs_stream_shape(w, h, m, k, true);
             const dim3 block(256), grid(cdiv(sh.strips * sh.row_blocks, 4), m);
 #define NUS_HSF_L(KK, UU, RR)                                                                                                        \
     hipLaunchKernelGGL((k_hs_stream_fast<KK, UU, RR>), grid, block, 0, stream, lum, lum_stride, lambda, fi, flow_stride, fo, out_stride, \
-                       (int)w, (int)h, (int)sh.strips, (int)sh.row_blocks, (int)sh.rows_per_block, hc)
+                       (int)w, (int)h, (int)sh.strips, (int)sh.row_blocks, (int)sh.rows_per_block, hc, HsWarp{})
+#define NUS_HSF_W(KK)                                                                                                                \
+    hipLaunchKernelGGL((k_hs_stream_fast<KK, false, true, true>), grid, block, 0, stream, lum, lum_stride, lambda, fi, flow_stride, fo, \
+                       out_stride, (int)w, (int)h, (int)sh.strips, (int)sh.row_blocks, (int)sh.rows_per_block, hc, *wp)
 #define NUS_HSF(KK)                                                                                                                  \
     case KK:                                                                                                                         \
+        if constexpr (NUS_HS_FAST_RING != 0 && KK <= 5) {                                                                            \
+            if (wp != nullptr && !shifting && !ups) {                                                                                \
+                NUS_HSF_W(KK);                                                                                                       \
+                did_warp = true;                                                                                                     \
+                break;                                                                                                               \
+            }                                                                                                                        \
+        }                                                                                                                            \
         if constexpr (NUS_HS_FAST_RING != 0 && KK <= NUS_HS_FAST_RING_MAXK) {                                                                            \
             if (!shifting) {                                                                                                         \
                 if (ups) NUS_HSF_L(KK, true, true); else NUS_HSF_L(KK, false, true);                                                 \
@@ -1304,6 +1338,7 @@ hipError_t launch_hs_iterate(const float *coef, float lambda, float **flow_a, fl
             }
 #undef NUS_HSF
 #undef NUS_HSF_L
+#undef NUS_HSF_W
             return hipGetLastError();
         };
         // a level with many steps (the coarsest: 50) takes more of them per launch: its launches are short and memory-bound, and
@@ -1327,7 +1362,20 @@ hipError_t launch_hs_iterate(const float *coef, float lambda, float **flow_a, fl
             const bool ups = coarse != nullptr; // the first launch of a level takes the coarser level's flow, upsampled as it loads it
             const HsCoarse hc{reinterpret_cast<const float2 *>(coarse), coarse_stride, (int)cw, (int)ch, coarse_scale};
             coarse = nullptr;
-            hipError_t e = launch_one(k, ups, lum1, fi, fo, out_stride, hc, n);
+            // the last launch of the level warps with the flow it finishes, where it can (see HsWarp); then the flow is stored only
+            // for a caller who asked for it
+            // OFF unless NUS_HS_FUSED_WARP=1 is in the environment: built and measured in round 5 -- identical bytes, but the fused launch
+            // takes 23 us per 1080p pair where the plain launch and the warp kernel take 12.2 + 7.9: the Jacobi pass has one pixel per
+            // lane, so the warp's gathers are 8-byte loads at a 4-byte lane stride (every texel pair fetched twice) and its ~140
+            // instructions per pixel run at four waves per SIMD (119 VGPRs) next to a pass that was at the memory rate, not below it
+            // (motion step 21.0 against 20.1 ms per 300 units).  The warp kernel's 2 x 2 pixels per thread is the better shape.
+            const char *fuse_env = getenv("NUS_HS_FUSED_WARP");
+            const bool can_warp = fuse_env != nullptr && fuse_env[0] == '1' &&
+                                  warp != nullptr && warp->frames != nullptr && warp->mid != nullptr && launches == 1 && !ups && k <= 5 &&
+                                  NUS_HS_FAST_RING != 0 && w >= 2 && h >= 2 && (uint64_t)w * h * 4 < (1ull << 32) &&
+                                  (uint64_t)w * 4 < (1u << 24) && h < (1u << 24);
+            if (can_warp && final_out == nullptr) fo = nullptr;
+            hipError_t e = launch_one(k, ups, lum1, fi, fo, out_stride, hc, n, can_warp ? warp : nullptr);
             if (e != hipSuccess) return e;
             iterations -= k;
             --launches;
@@ -1335,8 +1383,10 @@ hipError_t launch_hs_iterate(const float *coef, float lambda, float **flow_a, fl
             *flow_a = *flow_b;
             *flow_b = t;
         }
+        if (warped) *warped = did_warp;
         return hipSuccess;
     }
+    if (warped) *warped = false;
     if (hs_iterate_streams(w, h, n, kernel)) {
         if (lum1) coef = lum1, coef_stride = lum_stride; // the kernel takes the derivatives from the planes themselves
         uint32_t launches = (iterations + NUS_HS_STREAM_MAXK - 1) / NUS_HS_STREAM_MAXK;

@@ -2,6 +2,7 @@
 //   warp+blend nu_scaler_core/src/shaders/warp_blend.wgsl:18-47 (geometry),
 //              nu_scaler_core/src/interpolation/mod.rs:386-411, :467-510 (rounding)
 #include "nus_device.hpp"
+#include "nus_warp_device.hpp"
 
 #include <hip/hip_fp16.h>
 
@@ -80,39 +81,6 @@ __device__ __forceinline__ float4 sample_trunc(const uint32_t *__restrict__ f, u
 //    interpolation path (measured on noise frames with random flows: < 0.1 % of the samples differ, none by more than
 //    one count).  The blend of the two samples is exact in both modes (see the kernel).
 // The truncation of each sample to u8 (sample_frame returns u8: interpolation/mod.rs:506) stays in both modes.
-constexpr int kWarpExact = 0, kWarpFma = 1;
-
-template <int MODE>
-__device__ __forceinline__ float lerp_mode(float a, float b, float f, float nf)
-{
-    if (MODE == kWarpFma) return __builtin_fmaf(b, f, a * nf); // (the form a + f (b - a) makes the compiler subtract the packed
-                                                               // bytes and convert the difference: two slow-class instructions)
-    return a * nf + b * f;
-}
-
-template <int MODE>
-__device__ __forceinline__ float4 sample_corner(__amdgpu_buffer_rsrc_t rs, uint32_t row_bytes, float wmax, float hmax,
-                                                uint32_t xbmax, uint32_t ybmax, float x, float y)
-{
-    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-    x = __builtin_amdgcn_fmed3f(x, 0.0f, wmax); // clamp to [0, w-1] (interpolation/mod.rs:470-471)
-    y = __builtin_amdgcn_fmed3f(y, 0.0f, hmax);
-    const uint32_t xb = umin((uint32_t)x, xbmax), yb = umin((uint32_t)y, ybmax); // (uint32_t): truncation = floor, x >= 0
-    const float xf = x - (float)xb, yf = y - (float)yb;
-    const float nxf = 1.0f - xf, nyf = 1.0f - yf;
-    const uint32_t off = __umul24(yb, row_bytes) + xb * 4u;
-    const u32x2 r0 = __builtin_amdgcn_raw_buffer_load_b64(rs, off, 0, 0);
-    const u32x2 r1 = __builtin_amdgcn_raw_buffer_load_b64(rs, off, row_bytes, 0); // next row: scalar offset, always in range
-    float r[4];
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        const float top = lerp_mode<MODE>(ch_f32(r0.x, c), ch_f32(r0.y, c), xf, nxf);
-        const float bottom = lerp_mode<MODE>(ch_f32(r1.x, c), ch_f32(r1.y, c), xf, nxf);
-        r[c] = floorf(lerp_mode<MODE>(top, bottom, yf, nyf)); // `value as u8`: 0 <= value <= 255 (+ an ulp in FMA mode)
-    }
-    return make_float4(r[0], r[1], r[2], r[3]);
-}
-
 // Dense flow (2 x f32 or 2 x f16 per pixel, delta A -> B): A sampled at p - t*flow, B at p + (1-t)*flow
 // (warp_blend.wgsl:36-37 in texel space).  A thread owns XV consecutive pixels in each of RV rows (rows y, y + 4, .. of the
 // block's 4 RV): its flow vectors are loaded first, then the gathers of its pixels -- independent chains -- are in flight
@@ -199,26 +167,7 @@ __global__ __launch_bounds__(256) void k_warp_blend_flow(
         uint32_t o[XV];
 #pragma unroll
         for (int i = 0; i < XV; ++i) {
-            const float xfl = (float)(x0 + i);
-            float ax, ay, bx, by;
-            if (MODE == kWarpFma) {
-                ax = __builtin_fmaf(-tv, f[j][i].x, xfl), ay = __builtin_fmaf(-tv, f[j][i].y, yfl);
-                bx = __builtin_fmaf(nt, f[j][i].x, xfl), by = __builtin_fmaf(nt, f[j][i].y, yfl);
-            } else {
-                ax = xfl - tv * f[j][i].x, ay = yfl - tv * f[j][i].y;
-                bx = xfl + nt * f[j][i].x, by = yfl + nt * f[j][i].y;
-            }
-            const float4 sa = sample_corner<MODE>(ra, row_bytes, wmax, hmax, w - 2, h - 2, ax, ay);
-            const float4 sb = sample_corner<MODE>(rb, row_bytes, wmax, hmax, w - 2, h - 2, bx, by);
-            // the blend of the two truncated samples keeps the CPU's three roundings in both modes: with integer operands and
-            // a t like 0.3 a tenth of the exact results are integers themselves (0.7 * 10 + 0.3 * 20 = 13), and there the
-            // truncation turns any other rounding sequence into a count of difference (measured: 0.25 % of the samples with a
-            // fused blend)
-            uint32_t p = 0;
-            p = pack_trunc_u8(nt * sa.x + tv * sb.x, 0, p);
-            p = pack_trunc_u8(nt * sa.y + tv * sb.y, 1, p);
-            p = pack_trunc_u8(nt * sa.z + tv * sb.z, 2, p);
-            p = pack_trunc_u8(nt * sa.w + tv * sb.w, 3, p);
+            const uint32_t p = warp_blend_pixel<MODE>(ra, rb, row_bytes, wmax, hmax, w - 2, h - 2, (float)(x0 + i), yfl, f[j][i], tv, nt);
             o[i] = swz(p, sel);
         }
         uint32_t *dst = reinterpret_cast<uint32_t *>(out) + frame0 + (size_t)y * w + x0;

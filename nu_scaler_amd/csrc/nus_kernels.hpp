@@ -205,11 +205,26 @@ hipError_t launch_hs_level_setup(const float *l1, const float *l2, float *coef, 
                                  uint32_t cw, uint32_t ch, float *flow, float scale, hipStream_t stream, uint32_t n = 1,
                                  size_t lum_stride = 0, size_t coef_stride = 0, size_t coarse_stride = 0,
                                  size_t flow_stride = 0);
+// HsWarp (round 5; used only with NUS_HS_FUSED_WARP=1 in the environment: measured slower than the warp kernel behind the estimator):
+// the LAST launch of the finest level can warp + blend the pair's two frames with the flow it has just finished
+// (dense-flow warp in FMA mode, nus_warp_device.hpp) and store the in-between frame -- the flow then never has to be written for the
+// warp to read it back.  frames: RGBA8 frame of pair z at frames + z * frame_stride bytes, its partner one frame_stride further;
+// mid: w * h RGBA8 pixels per pair, tightly packed.  *warped tells the caller whether the launch that ran could do it (FAST ring
+// form, not the launch that upsamples the coarser level, frames of at least 2 x 2 pixels and less than 4 GiB); if not, the caller
+// runs the warp kernel itself.  With a warp and final_out == nullptr the flow of the last launch is not stored at all.
+struct HsWarp {
+    const uint8_t *frames = nullptr;
+    size_t frame_stride = 0;
+    uint8_t *mid = nullptr;
+    float t = 0.5f;
+    uint32_t sel = 0;
+};
 hipError_t launch_hs_iterate(const float *coef, float lambda, float **flow_a, float **flow_b, uint32_t w, uint32_t h,
                              uint32_t iterations, bool zero_start, float *final_out, hipStream_t stream, uint32_t n = 1,
                              size_t coef_stride = 0, size_t flow_stride = 0, size_t final_stride = 0, int kernel = 0,
                              const float *lum1 = nullptr, size_t lum_stride = 0, const float *coarse = nullptr, uint32_t cw = 0,
-                             uint32_t ch = 0, float coarse_scale = 0.0f, size_t coarse_stride = 0);
+                             uint32_t ch = 0, float coarse_scale = 0.0f, size_t coarse_stride = 0, const HsWarp *warp = nullptr,
+                             bool *warped = nullptr);
 bool hs_iterate_streams(uint32_t w, uint32_t h, uint32_t n, int kernel);
 hipError_t launch_flow_upsample(const float *src, uint32_t sw, uint32_t sh, float *dst, uint32_t dw, uint32_t dh,
                                 float scale, hipStream_t stream, uint32_t n = 1, size_t src_stride = 0, size_t dst_stride = 0);

@@ -165,7 +165,7 @@ class FramePipeline:
 
     def step_motion(self, frames, flows, mid, up_real, up_mid, stream: int = 0, levels: int = 3,
                     coarse_iterations: int = 50, refine_iterations: int = 10, flow_mode: str = "exact", pipelined: bool = False,
-                    chunk: int = 100) -> None:
+                    chunk: int = 100, fused_warp: bool = False) -> None:
         """Motion-compensated variant of `step`: a dense flow per pair from the
         pyramid + Horn-Schunck front end into `flows` ((n_units, h, w, 2) float32), then warp + blend with it
         instead of the reference's zero flow.  The flows are estimated pair by pair (several launches per pair,
@@ -176,7 +176,12 @@ class FramePipeline:
         chunk i+1 on the caller's stream while warp + both upscales of chunk i run on a second stream.  The estimator's launches
         are bound by memory and latency as often as by instruction issue, the warp and the resize kernels by instruction issue
         alone, so the two streams fill each other's gaps; same kernels, same bytes, bit-identical outputs.  Uses torch for the
-        second stream and the events; `stream` must be torch's current stream (0 = that)."""
+        second stream and the events; `stream` must be torch's current stream (0 = that).
+
+        fused_warp (round 5): estimator and warp through ONE entry point (FlowEstimator.interpolate_device_stream); `flows` may then
+        be None (they stay in the estimator's workspace).  The warp is the FMA-mode one whatever `self.interp`'s mode is; same bytes
+        as the separate FMA-mode warp.  (The in-kernel fusion -- the last Horn-Schunck launch warping with the flow it has just
+        finished -- exists behind NUS_HS_FUSED_WARP=1: identical bytes, measured slower.)"""
         from .flow import FlowEstimator
 
         if getattr(self, "_flow", None) is None:
@@ -186,10 +191,22 @@ class FramePipeline:
         n = mid.shape[0]
         base = frames.data_ptr()
         fb = self.frame_bytes
+        if flows is None and not fused_warp:
+            raise ValueError("step_motion: flows=None needs fused_warp=True")
+        fl0 = 0 if flows is None else flows.data_ptr()
+
+        def flow_and_warp(k0, m, st):  # units [k0, k0 + m): their flows (if wanted) and in-between frames
+            a = base + k0 * fb
+            fl = fl0 + k0 * fb * 2 if fl0 else 0
+            if fused_warp:
+                self._flow.interpolate_device_stream(a, m + 1, self.w, self.h, self.t, mid.data_ptr() + k0 * fb, fl, st)
+                return False
+            self._flow.estimate_device_stream(a, m + 1, self.w, self.h, fl, st)
+            return True  # the warp is still to do
+
         if not pipelined or n <= chunk:
-            self._flow.estimate_device_stream(base, n + 1, self.w, self.h, flows.data_ptr(), stream)
-            self.interp.interpolate_device(base, fb, base + fb, fb, flows.data_ptr(), self.w, self.h, self.t, mid.data_ptr(), n,
-                                           stream)
+            if flow_and_warp(0, n, stream):
+                self.interp.interpolate_device(base, fb, base + fb, fb, fl0, self.w, self.h, self.t, mid.data_ptr(), n, stream)
             self.upscaler.upscale_device(base, up_real.data_ptr(), n, stream)
             self.upscaler.upscale_device(mid.data_ptr(), up_mid.data_ptr(), n, stream)
             return
@@ -210,12 +227,13 @@ class FramePipeline:
         ob = self.ow * self.oh * 4
         for ci, k0 in enumerate(range(0, n, chunk)):
             m = min(chunk, n - k0)
-            self._flow.estimate_device_stream(base + k0 * fb, m + 1, self.w, self.h, flows.data_ptr() + k0 * fb * 2, main.cuda_stream)
+            warp_to_do = flow_and_warp(k0, m, main.cuda_stream)
             self._ev_chunks[ci].record(main)
             aux.wait_event(self._ev_chunks[ci])
             a = base + k0 * fb
-            self.interp.interpolate_device(a, fb, a + fb, fb, flows.data_ptr() + k0 * fb * 2, self.w, self.h, self.t,
-                                           mid.data_ptr() + k0 * fb, m, aux.cuda_stream)
+            if warp_to_do:
+                self.interp.interpolate_device(a, fb, a + fb, fb, fl0 + k0 * fb * 2, self.w, self.h, self.t,
+                                               mid.data_ptr() + k0 * fb, m, aux.cuda_stream)
             self.upscaler.upscale_device(a, up_real.data_ptr() + k0 * ob, m, aux.cuda_stream)
             self.upscaler.upscale_device(mid.data_ptr() + k0 * fb, up_mid.data_ptr() + k0 * ob, m, aux.cuda_stream)
         self._ev_mid.record(aux)

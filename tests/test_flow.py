@@ -383,3 +383,102 @@ def test_flow_fast_ring_form_equals_the_shifting_form(nsc, oracle_mod, w, h, lev
         assert np.isfinite(got[form]).all()
     monkeypatch.delenv("NUS_HS_FAST_SHIFT", raising=False)
     assert np.array_equal(got["ring"], got["shift"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("w,h,levels,coarse,refine", [(160, 96, 3, 20, 10), (333, 262, 3, 7, 7), (97, 45, 2, 9, 5), (64, 64, 1, 13, 0),
+                                                       (130, 70, 2, 4, 0), (1030, 6, 2, 2, 2), (2, 2, 1, 3, 0), (960, 540, 3, 10, 10)])
+@pytest.mark.parametrize("in_kernel", [False, True])
+def test_interpolate_device_stream_equals_estimate_then_warp(nsc, oracle_mod, w, h, levels, coarse, refine, in_kernel, monkeypatch):
+    """nus_flow_interpolate_device_stream (round 5: pyramid -> flow -> warp as ONE pipeline, wgpu_interpolator.rs:881-935): in every
+    kernel mode -- EXACT by size, EXACT pair by pair, FAST with the streamed kernels forced (the last Horn-Schunck launch of the finest
+    level warps with the flow it has just finished; also with 7 = 4 + 3 steps, with no refinement step at all, with one level) -- the
+    in-between frames are bit for bit those of nus_flow_estimate_device_stream followed by the FMA-mode warp kernel, with the flows
+    stored or not; the flows, when asked for, are the estimator's; and in EXACT mode everything equals the oracle within the warp's
+    FMA contract (<= 1 LSB)."""
+    import torch
+
+    # in_kernel: NUS_HS_FUSED_WARP=1 -- the finest level's last FAST launch warps with the flow it has just finished (HsWarp)
+    if in_kernel:
+        monkeypatch.setenv("NUS_HS_FUSED_WARP", "1")
+    else:
+        monkeypatch.delenv("NUS_HS_FUSED_WARP", raising=False)
+    dev = torch.device("cuda:0")
+    n_frames, t = 4, 0.3
+    frames = np.stack([_smooth(w, h, 1.2 * k) if k % 2 else oracle_mod.gen_noise(w, h, 50 + k) // 2 + _smooth(w, h, 0.7 * k) // 2
+                       for k in range(n_frames)])
+    d_frames = torch.from_numpy(frames).to(dev)
+    s = torch.cuda.current_stream().cuda_stream
+    fb = w * h * 4
+    it = nsc.WgpuFrameInterpolator()
+    it.set_mode("fma")
+    for mode, tiled in (("fast", 3), ("fast", 1), ("exact", 1), ("exact", 0)):
+        fe = nsc.FlowEstimator(levels=levels, coarse_iterations=coarse, refine_iterations=refine)
+        fe.set_mode(mode)
+        fe.set_tiled(tiled)
+        flows = torch.full((n_frames - 1, h, w, 2), float("nan"), dtype=torch.float32, device=dev)
+        fe.estimate_device_stream(d_frames.data_ptr(), n_frames, w, h, flows.data_ptr(), s)
+        want_mid = torch.zeros((n_frames - 1, h, w, 4), dtype=torch.uint8, device=dev)
+        it.interpolate_device(d_frames.data_ptr(), fb, d_frames.data_ptr() + fb, fb, flows.data_ptr(), w, h, t, want_mid.data_ptr(),
+                              n_frames - 1, s)
+        torch.cuda.synchronize()
+        for with_flows in (True, False):
+            got_flows = torch.full_like(flows, float("nan"))
+            got_mid = torch.full_like(want_mid, 0xAB)
+            fe.interpolate_device_stream(d_frames.data_ptr(), n_frames, w, h, t, got_mid.data_ptr(),
+                                         got_flows.data_ptr() if with_flows else 0, s)
+            torch.cuda.synchronize()
+            assert torch.equal(got_mid, want_mid), (mode, tiled, with_flows)
+            if with_flows:
+                assert torch.equal(got_flows, flows), (mode, tiled)
+            else:
+                assert bool(torch.isnan(got_flows).all())
+        if mode == "exact" and tiled == 1 and not in_kernel:
+            for k in range(n_frames - 1):
+                fl = oracle_mod.flow_estimate(frames[k], frames[k + 1], levels, coarse, refine, fe.lambda_)
+                assert np.array_equal(flows[k].cpu().numpy(), fl)
+                d = np.abs(want_mid[k].cpu().numpy().astype(np.int16) - oracle_mod.warp_blend(frames[k], frames[k + 1], fl, t).astype(np.int16))
+                assert d.max() <= 1
+    fe = nsc.FlowEstimator(levels=2, coarse_iterations=2, refine_iterations=2)
+    with pytest.raises(RuntimeError, match=r"t must be in \[0, 1\]"):
+        fe.interpolate_device_stream(d_frames.data_ptr(), n_frames, w, h, 1.5, want_mid.data_ptr(), 0, s)
+    with pytest.raises(RuntimeError, match="null device pointer"):
+        fe.interpolate_device_stream(d_frames.data_ptr(), n_frames, w, h, 0.5, 0, 0, s)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("in_kernel", [False, True])
+def test_step_motion_fused_warp_equals_separate_stages(nsc, oracle_mod, in_kernel, monkeypatch):
+    """FramePipeline.step_motion(fused_warp=True), stage after stage and as the two-stream pipeline, with the flows stored and not:
+    the in-between frames and both 4K outputs bit-identical to the step with the separate FMA-mode warp."""
+    import torch
+
+    if in_kernel:
+        monkeypatch.setenv("NUS_HS_FUSED_WARP", "1")
+    else:
+        monkeypatch.delenv("NUS_HS_FUSED_WARP", raising=False)
+    w, h, n = 480, 270, 7
+    dev = torch.device("cuda:0")
+    frames = torch.from_numpy(np.stack([_smooth(w, h, 1.1 * k) for k in range(n + 1)])).to(dev)
+    pipe = nsc.FramePipeline(w, h, 2, "lanczos3", 0.5)
+    pipe.interp.set_mode("fma")
+    s = torch.cuda.current_stream().cuda_stream
+    want = pipe.alloc(n, dev)
+    flows = torch.empty((n, h, w, 2), dtype=torch.float32, device=dev)
+    pipe.step_motion(frames, flows, *want, s, flow_mode="fast")
+    torch.cuda.synchronize()
+    for kw in (dict(fused_warp=True), dict(fused_warp=True, pipelined=True, chunk=3), dict(fused_warp=True, pipelined=True, chunk=3, no_flows=True),
+               dict(fused_warp=True, no_flows=True)):
+        no_flows = kw.pop("no_flows", False)
+        got = pipe.alloc(n, dev)
+        for t_ in got:
+            t_.zero_()
+        got_flows = None if no_flows else torch.zeros_like(flows)
+        pipe.step_motion(frames, got_flows, *got, s, flow_mode="fast", **kw)
+        torch.cuda.synchronize()
+        for a, b in zip(got, want):
+            assert torch.equal(a, b), kw
+        if got_flows is not None:
+            assert torch.equal(got_flows, flows), kw
+    with pytest.raises(ValueError, match="fused_warp"):
+        pipe.step_motion(frames, None, *want, s)

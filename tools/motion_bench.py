@@ -24,6 +24,11 @@ s = torch.cuda.current_stream().cuda_stream
 
 
 def timed(**kw):
+    fl = None if kw.get("fused_warp") else flows  # fused: the flow never goes to HBM
+    return _timed(fl, **kw)
+
+
+def _timed(flows, **kw):
     pipe.step_motion(frames, flows, mid, up_real, up_mid, s, flow_mode="fast", **kw)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -37,3 +42,10 @@ for rnd in range(2):
     print(f"motion step, {n} units, stage after stage: {timed():7.2f} ms", flush=True)
     for c in chunks:
         print(f"motion step, {n} units, pipelined, chunks of {c:3d}: {timed(pipelined=True, chunk=c):7.2f} ms", flush=True)
+    for env in ("0", "1"):  # one entry point (estimator, then the warp kernel behind it) / the warp inside the last Jacobi launch
+        os.environ["NUS_HS_FUSED_WARP"] = env
+        what = "warp inside the last Jacobi launch" if env == "1" else "one call, warp kernel behind the estimator"
+        print(f"motion step, {n} units, {what}, stage after stage: {timed(fused_warp=True):7.2f} ms", flush=True)
+        for c in chunks:
+            print(f"motion step, {n} units, {what}, pipelined, chunks of {c:3d}: {timed(fused_warp=True, pipelined=True, chunk=c):7.2f} ms", flush=True)
+    os.environ.pop("NUS_HS_FUSED_WARP", None)
