@@ -473,28 +473,6 @@ def host_path_leg(nsc, syn, torch, w, h, device):
     }
 
 
-def host_fed_leg(nsc, syn, w, h, device, seconds, barrier):
-    """Mode (ii) of SURVEY.md 8(d)/(e), on every rank at once: a host-resident shard of the stream (12 pageable 1080p frames)
-    goes through nus_upscaler_upscale_batch -- one submitting host thread, three slot streams per GPU, H2D / kernel / D2H
-    pipelined, outputs into caller-owned pageable 4K buffers -- for `seconds` of wall time between two barriers.
-    Returns this rank's 4K frames per second."""
-    nb = 12
-    frames = [syn.gradient_frame(w, h, k).tobytes() for k in range(nb)]
-    u = nsc.PyWgpuUpscaler("quality", "lanczos3", device=device)
-    u.initialize(w, h, 2 * w, 2 * h)
-    outs = [bytearray(u.output_size) for _ in range(nb)]
-    u.upscale_batch_into(frames, outs)  # allocates the slots, touches the buffers
-    barrier()
-    t0 = time.perf_counter()
-    n = 0
-    while time.perf_counter() - t0 < seconds:
-        u.upscale_batch_into(frames, outs)
-        n += nb
-    dt = time.perf_counter() - t0
-    barrier()
-    return n / dt
-
-
 class ClockSampler:
     """Clocks (sclk, mclk, fclk) and power of THIS rank's GPU while a leg runs, sampled by a thread of this process.
     The GPU is found by its PCI address (placement.query_gpu_pci: HIP's device order is not rocm-smi's on a host where the job
@@ -974,7 +952,7 @@ def worker(args):
     # legs: the same place in the process's life as config.host_path's batch figure
     host_fed = None
     if args.host_fed_seconds > 0 and not args.no_extras:
-        rate = host_fed_leg(nsc, syn, w, h, device_index, args.host_fed_seconds, barrier)
+        rate = sh.run_host_fed(args.host_fed_seconds)  # (the product's: nu_scaler_amd.stream.ShardedStream.run_host_fed)
         hrows = gather({"rate": rate, "numa_node": place.get("numa_node"), "bound": 1.0 if place.get("bound") else 0.0})
         rates = [r["rate"] for r in hrows]
         frame_mb = (w * h + 4 * w * h) * 4 / 1e6

@@ -44,6 +44,8 @@ def build_parser() -> argparse.ArgumentParser:
     st.add_argument("--force-device", type=int, default=-1, help="every rank on this device (rehearsal on a one-GPU box)")
     st.add_argument("--no-bind", action="store_true", help="leave the ranks' CPU affinity alone")
     st.add_argument("--digest", action="store_true", help="also print one digest per unit of the stream (sharding-invariant)")
+    st.add_argument("--host-fed-seconds", type=float, default=0.0,
+                    help="afterwards, every rank feeds its GPU from HOST memory through upscale_batch for this long (mode ii)")
     return ap
 
 
@@ -68,11 +70,14 @@ def stream_command(args, argv) -> int:
     from . import stream as S
 
     def sink(s):
-        if not args.digest:
-            return None
-        per_rank = -(-s.total_units // s.world)  # every rank sends the same number of columns
-        d = s.unit_digests()
-        return {f"digest_{k:05d}": (float(d[k]) if k < len(d) else None) for k in range(per_rank)}
+        row = {}
+        if args.host_fed_seconds > 0:
+            row["host_fed_frames_per_s"] = s.run_host_fed(args.host_fed_seconds, algorithm=args.algorithm)
+        if args.digest:
+            per_rank = -(-s.total_units // s.world)  # every rank sends the same number of columns
+            d = s.unit_digests()
+            row.update({f"digest_{k:05d}": (float(d[k]) if k < len(d) else None) for k in range(per_rank)})
+        return row or None
 
     out = S.run_sharded(args.units * args.gpus, args.width, args.height, steps=args.steps, warmup=args.warmup,
                         source=S.SyntheticSource(args.pattern), sink=sink, backend=args.backend, bind=not args.no_bind,
@@ -84,6 +89,9 @@ def stream_command(args, argv) -> int:
             for r in rows:
                 digests += [int(r[k]) for k in sorted(r) if k.startswith("sink_digest_") and r[k] is not None]
             out["unit_digests"] = digests
+        if args.host_fed_seconds > 0:
+            rates = [r["sink_host_fed_frames_per_s"] for r in rows]
+            out["host_fed_4k_frames_per_s"] = {"total": round(sum(rates), 1), "by_rank": [round(x, 1) for x in rates]}
         out["bound_by_rank"] = [bool(r["bound"]) for r in rows]
         out["numa_node_by_rank"] = [None if r["numa_node"] is None else int(r["numa_node"]) for r in rows]
         print(json.dumps(out), flush=True)

@@ -485,6 +485,32 @@ class ShardedStream:
         self.steps_run = int(steps)
         return self.elapsed_local
 
+    def run_host_fed(self, seconds: float, frames_per_call: int = 12, algorithm: str = "lanczos3") -> float:
+        """Mode (ii) of SURVEY.md 8(d)/(e) on this rank, all ranks at the same time: a HOST-resident piece of the stream
+        (`frames_per_call` pageable 1080p-shaped frames of this rank's shard) goes through the trait-shaped host entry point
+        nus_upscaler_upscale_batch -- one submitting host thread, a retiring thread, the copy pool, three slot streams per GPU,
+        H2D / kernel / D2H pipelined, outputs into caller-owned pageable buffers -- for `seconds` of wall time between two
+        barriers.  Returns this rank's output frames per second (gather them for the job's rate)."""
+        import time
+
+        from . import synthetic as syn
+
+        nb = int(frames_per_call)
+        frames = [syn.gradient_frame(self.width, self.height, self.start + k).tobytes() for k in range(nb)]
+        u = PyWgpuUpscaler("quality", algorithm, device=self.device_index)
+        u.initialize(self.width, self.height, 2 * self.width, 2 * self.height)
+        outs = [bytearray(u.output_size) for _ in range(nb)]
+        u.upscale_batch_into(frames, outs)  # allocates the slots, touches the buffers
+        self.barrier()
+        t0 = time.perf_counter()
+        n = 0
+        while time.perf_counter() - t0 < seconds:
+            u.upscale_batch_into(frames, outs)
+            n += nb
+        dt = time.perf_counter() - t0
+        self.barrier()
+        return n / dt
+
     def summarize(self, rows) -> dict:
         """What the job did, from the gathered rows (each holds at least elapsed_s): whole-job units and pixels per second
         over the slowest rank's time."""
