@@ -113,6 +113,9 @@ def parse_args(argv=None):
                          "0 = skip; N=1 only)")
     ap.add_argument("--no-bind", action="store_true", help="do not bind the rank to its GPU's NUMA node")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo for rehearsal)")
+    ap.add_argument("--force-collectives", action="store_true",
+                    help="N = 1 only: create the communicator all the same and issue every collective of the N > 1 path on it "
+                         "(the LUT broadcast, the barriers, the gathers): how a one-GPU box rehearses the RCCL calls of the 8-GPU run")
     ap.add_argument("--force-device", type=int, default=-1,
                     help="rehearsal only: put every rank on this GPU (with --backend gloo on a 1-GPU box)")
     return ap.parse_args(argv)
@@ -764,7 +767,7 @@ def worker(args):
     try:
         sh = S.ShardedStream(n_units * world, w, h, source=S.SyntheticSource(args.pattern), backend=args.backend,
                              bind=not args.no_bind, force_device=args.force_device, schedule=schedule,
-                             lanczos_mode=args.lanczos_mode)
+                             lanczos_mode=args.lanczos_mode, force_collectives=args.force_collectives and world == 1)
     except RuntimeError as e:
         raise SystemExit(f"bench.py: {e}")
     import torch

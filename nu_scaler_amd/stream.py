@@ -273,11 +273,11 @@ class FramePipeline:
 # job of one rank in one call.  `python -m nu_scaler_amd.cli stream --gpus N` and bench.py are both built on it.
 
 
-def gather_rows(row, world, dist=None, torch=None, comm_dev=None):
+def gather_rows(row, world, dist=None, torch=None, comm_dev=None, force=False):
     """Every rank's row of numbers on every rank: ONE all_gather of a float64 vector (keys sorted; None travels as NaN).
-    world == 1: no collective."""
+    world == 1: no collective (unless `force`: the collective is issued on the one-rank communicator all the same)."""
     keys = sorted(row)
-    if world == 1:
+    if world == 1 and not force:
         return [dict(row)]
     vals = [float("nan") if row[k] is None else float(row[k]) for k in keys]
     t = torch.tensor(vals, dtype=torch.float64, device=comm_dev)
@@ -326,6 +326,30 @@ class SyntheticSource:
         return out
 
 
+class _StdoutToStderr:
+    """File descriptor 1 pointed at file descriptor 2 for the duration of a `with`: RCCL prints a version banner (five lines:
+    "RCCL version : ...", "Librccl path : ...") on STDOUT when rank 0 creates its communicator, and a job's stdout is for its
+    one JSON line."""
+
+    def __enter__(self):
+        import os
+        import sys
+
+        sys.stdout.flush()
+        self._saved = os.dup(1)
+        os.dup2(2, 1)
+        return self
+
+    def __exit__(self, *exc):
+        import os
+        import sys
+
+        sys.stdout.flush()
+        os.dup2(self._saved, 1)
+        os.close(self._saved)
+        return False
+
+
 class ShardedStream:
     """One rank of the sharded stream.  Construction does, in this order (the order matters):
 
@@ -347,7 +371,8 @@ class ShardedStream:
 
     def __init__(self, total_units: int, width: int, height: int, *, source=None, backend: str = "nccl", bind: bool = True,
                  force_device: int = -1, schedule: str = "unit", algorithm: str = "lanczos3", time_t: float = 0.5,
-                 lanczos_mode: str = "fma", pipeline_factory=None, environ=None, device_kind: str = "cuda"):
+                 lanczos_mode: str = "fma", pipeline_factory=None, environ=None, device_kind: str = "cuda",
+                 force_collectives: bool = False):
         import os
 
         env = os.environ if environ is None else environ
@@ -387,15 +412,24 @@ class ShardedStream:
             raise ValueError("backend 'nccl' needs device_kind 'cuda'")
         self.comm_device = self.device if nccl else torch.device("cpu")
         # 3. the process group
+        # force_collectives: a world of ONE still creates its communicator and issues every collective of the job on it (the LUT
+        # broadcast, the barriers, the gather) -- how a one-GPU box rehearses the RCCL calls of the 8-GPU run
+        self._collectives = self.world > 1 or bool(force_collectives)
         self._own_group = False
-        if self.world > 1 and not (dist.is_available() and dist.is_initialized()):
+        if self._collectives and not (dist.is_available() and dist.is_initialized()):
             env_set = os.environ.setdefault
             env_set("MASTER_ADDR", "127.0.0.1")
             env_set("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-            if nccl:
-                dist.init_process_group("nccl", rank=self.rank, world_size=self.world, device_id=self.device)
-            else:
-                dist.init_process_group(backend, rank=self.rank, world_size=self.world)
+            if self.world == 1 and "MASTER_PORT" not in os.environ:  # force_collectives outside a launcher: a rendezvous of its own
+                from .launch import free_port
+
+                os.environ["MASTER_PORT"] = str(free_port())
+            with _StdoutToStderr():  # (RCCL's banner: see the class)
+                if nccl:
+                    dist.init_process_group("nccl", rank=self.rank, world_size=self.world, device_id=self.device)
+                    dist.barrier(device_ids=[self.device_index])  # the communicator exists (and has said so) before anything is timed
+                else:
+                    dist.init_process_group(backend, rank=self.rank, world_size=self.world)
             self._own_group = True
         hip_bdf = None
         if on_gpu:
@@ -412,7 +446,7 @@ class ShardedStream:
         else:
             self.pipeline = pipeline_factory(self.width, self.height, self.device_index, self)
         up = getattr(self.pipeline, "upscaler", None)
-        self.lut_bytes = broadcast_tables(up, 0, self.comm_device) if up is not None else 0
+        self.lut_bytes = broadcast_tables(up, 0, self.comm_device, force=bool(force_collectives)) if up is not None else 0
         # 5. this rank's shard, resident
         self.total_units = int(total_units)
         self.start, self.count = shard_frames(self.total_units, self.world, self.rank)
@@ -429,14 +463,14 @@ class ShardedStream:
 
     # -- collectives (control side only: a barrier and one all_gather of a few numbers)
     def barrier(self) -> None:
-        if self.world > 1:
+        if self._collectives:
             if self.backend == "nccl":
                 self._dist.barrier(device_ids=[self.device_index])
             else:
                 self._dist.barrier()
 
     def gather(self, row: dict):
-        return gather_rows(row, self.world, self._dist, self._torch, self.comm_device)
+        return gather_rows(row, self.world, self._dist, self._torch, self.comm_device, force=self._collectives)
 
     def _sync(self) -> None:
         if self.device.type == "cuda":

@@ -43,3 +43,20 @@ def test_two_rank_rehearsal_reports_every_rank(nsc):
     hf = c["host_fed"]
     assert len(hf["frames_4k_per_s_per_gpu"]["by_rank"]) == 2 and len(hf["fed_from_numa_node_by_rank"]) == 2
     assert "cpu_baseline" not in d and r["traffic"] is None  # N = 1 only legs
+
+
+def test_one_rank_rehearsal_over_rccl_keeps_stdout_to_one_line(nsc):
+    """bench.py --force-collectives: N = 1, but the communicator is created (backend nccl = RCCL, device_id = the GPU) and every
+    collective of the N > 1 path is issued on it.  RCCL prints a five-line version banner on STDOUT when rank 0 creates its
+    communicator: the product points fd 1 at fd 2 for that moment, so the job's stdout stays what the driver parses -- ONE JSON
+    line -- and the banner is in stderr."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--force-collectives", "--units", "20", "--steps", "3", "--warmup", "1",
+           "--sustained-seconds", "0", "--config3-seconds", "0", "--no-pmc", "--no-cpu-baseline", "--no-extras"]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
+    out_lines = [ln for ln in res.stdout.splitlines() if ln.strip()]
+    assert len(out_lines) == 1 and out_lines[0].startswith("{"), out_lines[:8]
+    d = json.loads(out_lines[0])
+    assert d["n_gpus"] == 1 and d["value"] > 0 and d["config"]["lut_broadcast_bytes"] > 0  # the tables went through the broadcast
+    assert "RCCL version" in res.stderr

@@ -35,6 +35,25 @@ def test_rccl_broadcast_of_tables_one_rank(nsc):
     assert r["kernel_variant"].startswith("lanczos3_x2")
 
 
+@pytest.mark.gpu
+def test_sharded_stream_over_rccl_one_rank(nsc):
+    """The product's rank loop (nu_scaler_amd.run_sharded) with backend "nccl" on the GPU box: one rank, but every collective of the
+    8-GPU job issued on its RCCL communicator (force_collectives) -- communicator creation with device_id, the LUT broadcast, the
+    barriers with device_ids around the timed steps, the all_gathers of the per-rank rows on the GPU -- and the shard's outputs
+    against the oracle."""
+    sys.path.insert(0, ROOT)
+    from nu_scaler_amd import launch
+
+    rc, lines = launch.launch_ranks(1, os.path.join(ROOT, "tests", "helpers", "rccl_stream_rank.py"), [], timeout=600)
+    out = [json.loads(ln) for ln in lines if ln.startswith("{")]
+    assert rc == 0 and len(out) == 1, lines
+    r = out[0]
+    assert r["n_gpus"] == 1 and r["backend"] is None and r["units_by_rank"] == [6] and r["steps"] == 3
+    assert r["lut_bytes"] == len(nsc.build_tables_blob(1920, 1080, 3840, 2160)), "the tables did not go through the broadcast"
+    assert r["bad"] == [0] and r["rccl_mapped"] == [True]
+    assert r["mpix_per_s"] > 0 and r["placement"]["gpu_bdf_verified"] in (True, False, None)
+
+
 def test_force_flag_is_a_no_op_without_a_process_group(nsc):
     """CPU: outside torch.distributed both helpers stay local whatever `force` says."""
     blob = nsc.build_tables_blob(64, 36, 128, 72)
