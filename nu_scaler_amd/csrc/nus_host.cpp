@@ -157,6 +157,12 @@ int HipUpscaler::set_option(const char *key, int64_t value)
         unit_order_ = (uint32_t)value;
         return kOk;
     }
+    if (!strcmp(key, "fsr_two_pass")) { // FSR1: EASU -> scratch image -> row-walking RCAS for frames of >= 1 MiB (default 1); 0 = fused tile always
+        if (initialized_) return fail(kInvalidArgument, "fsr_two_pass must be set before initialize");
+        if (value != 0 && value != 1) return fail(kInvalidArgument, "fsr_two_pass must be 0 or 1");
+        fsr_two_pass_ = value != 0;
+        return kOk;
+    }
     if (!strcmp(key, "fsr_fast")) { // FSR1-style EASU in FAST arithmetic (nus_k_fsr.hip): 0 = the shaders' own operation order (default)
         if (value != 0 && value != 1) return fail(kInvalidArgument, "fsr_fast must be 0 or 1");
         fsr_fast_ = value != 0;
@@ -237,7 +243,9 @@ void HipUpscaler::release()
         if (*st) (void)hipStreamDestroy(*st);
         *st = nullptr;
     }
-    for (hipEvent_t *ev : {&ev_fork_, &ev_join_}) {
+    if (fsr_scratch_) (void)hipFree(fsr_scratch_);
+    fsr_scratch_ = nullptr;
+    for (hipEvent_t *ev : {&ev_fork_, &ev_join_, &ev_fsr_}) {
         if (*ev) (void)hipEventDestroy(*ev);
         *ev = nullptr;
     }
@@ -429,7 +437,11 @@ void HipUpscaler::choose_variant()
     case Algorithm::Lanczos3:
     case Algorithm::Bicubic:
     case Algorithm::Triangle: choose_resize_variant(x2); break;
-    case Algorithm::Fsr1: variant_ = Variant::Fsr1Fused; break;
+    case Algorithm::Fsr1:
+        // two kernels with the EASU image in HBM between them beat the fused LDS tile on real frames (1080p -> 4K: EASU 65.5 + RCAS rows
+        // 21.7 against 98.2 us fused; FAST 43.0 + 21.7 against 80.2): the tile's phases add up, the two launches overlap their own
+        variant_ = fsr_two_pass_ && (size_t)ow_ * oh_ * 4 >= ((size_t)1 << 20) ? Variant::Fsr1TwoPass : Variant::Fsr1Fused;
+        break;
     case Algorithm::FsrEasu: variant_ = Variant::FsrEasu; break;
     case Algorithm::FsrRcas: variant_ = Variant::FsrRcas; break;
     }
@@ -557,6 +569,11 @@ int HipUpscaler::initialize(uint32_t in_w, uint32_t in_h, uint32_t out_w, uint32
     choose_variant();
     rc = upload_tables();
     if (rc != kOk) return rc;
+    if (variant_ == Variant::Fsr1TwoPass) { // the EASU images between the two passes: allocated here so that enqueue allocates nothing
+        NUS_HIP(hipMalloc(reinterpret_cast<void **>(&fsr_scratch_), (size_t)kFsrScratchFrames * ow_ * oh_ * 4));
+        NUS_HIP(hipEventCreateWithFlags(&ev_fsr_, hipEventDisableTiming));
+        fsr_pending_ = false;
+    }
     if (variant_ == Variant::LanczosX2RegWin) { // the edge stream of enqueue(): made here so that enqueue allocates nothing
         NUS_HIP(hipStreamCreateWithFlags(&s_edge_, hipStreamNonBlocking));
         NUS_HIP(hipEventCreateWithFlags(&ev_fork_, hipEventDisableTiming));
@@ -657,6 +674,31 @@ int HipUpscaler::enqueue(const uint8_t *d_in, uint8_t *d_out, uint32_t n_frames,
     case Variant::FsrEasu: e = launch_fsr1(L, 0, easu_sharpness(), rcas_sharpness(), fsr_fast_); break;
     case Variant::FsrRcas: e = launch_fsr1(L, 1, easu_sharpness(), rcas_sharpness()); break;
     case Variant::Fsr1Fused: e = launch_fsr1(L, 2, easu_sharpness(), rcas_sharpness(), fsr_fast_); break;
+    case Variant::Fsr1TwoPass: {
+        // chunks of kFsrScratchFrames frames: EASU into the scratch images, RCAS (rows) out of them.  The scratch belongs to the
+        // handle: a batch on another stream waits for the previous batch's last RCAS before it overwrites them.
+        if (fsr_pending_) e = hipStreamWaitEvent(stream, ev_fsr_, 0);
+        const size_t in_frame = (size_t)iw_ * ih_ * 4, out_frame = (size_t)ow_ * oh_ * 4;
+        for (uint32_t done = 0; done < n_frames && e == hipSuccess; done += kFsrScratchFrames) {
+            const uint32_t m = n_frames - done < kFsrScratchFrames ? n_frames - done : kFsrScratchFrames;
+            UpscaleLaunch E = L;
+            E.in = L.in + (size_t)done * in_frame;
+            E.out = fsr_scratch_;
+            E.n_frames = m;
+            e = launch_fsr1(E, 0, easu_sharpness(), rcas_sharpness(), fsr_fast_);
+            if (e != hipSuccess) break;
+            UpscaleLaunch Rc = L;
+            Rc.in = fsr_scratch_;
+            Rc.out = L.out + (size_t)done * out_frame;
+            Rc.iw = ow_, Rc.ih = oh_;
+            Rc.n_frames = m;
+            Rc.in_sel = kSelRGBA; // EASU has swizzled already
+            e = launch_fsr1(Rc, 1, easu_sharpness(), rcas_sharpness());
+        }
+        if (e == hipSuccess) e = hipEventRecord(ev_fsr_, stream);
+        fsr_pending_ = e == hipSuccess;
+        break;
+    }
     case Variant::LanczosR43RegWin: {
         uint32_t th = rows_per_wave_;
         if (th == 0) { // as at x3/2: 24 - 36 rows per wave on a batch, equal row blocks (taller blocks: + 5 - 10 %)

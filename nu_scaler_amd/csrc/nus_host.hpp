@@ -225,6 +225,13 @@ private:
     bool wgsl_bilinear_ = false;
     bool lanczos_exact_ = false;
     bool fsr_fast_ = false;        // option "fsr_fast"
+    bool fsr_two_pass_ = true;     // option "fsr_two_pass": 0 keeps the fused LDS tile at every size
+    // Fsr1TwoPass: kFsrScratchFrames EASU images (RGBA8, output size) between the two passes, and the event that keeps a second
+    // batch of this handle (on whatever stream) from writing them before the first batch's RCAS has read them
+    static constexpr uint32_t kFsrScratchFrames = 4;
+    uint8_t *fsr_scratch_ = nullptr;
+    hipEvent_t ev_fsr_ = nullptr;
+    bool fsr_pending_ = false;
     bool force_general_ = false;
     bool force_per_pixel_ = false; // resize: never use the LDS row kernel
     bool force_rows_ = false;      // resize: never use the register-window variant of it

@@ -455,6 +455,94 @@ __global__ __launch_bounds__(256) void k_fsr1(const FsrArgs A, const int src_cap
     }
 }
 
+// ---- RCAS as a row walker (round 5) ------------------------------------------------------------------------------------------
+// The tile form of RCAS above (mode Rcas of k_fsr1) unpacks a 66 x 34 tile into LDS, waits at a barrier and filters out of it: its
+// three phases -- loads, the LDS round trip, arithmetic + stores -- add up instead of overlapping (33 us per 4K frame for 65
+// instructions and 66 MB per frame).  Here a wave owns a strip of 248 columns (lane L: columns 4 (L - 1) .. 4 (L - 1) + 3 of the
+// strip; lanes 0 and 63 are the halo, as in the x2 resize kernel) and walks down its rows keeping THREE unpacked rows (rgb / 255 and
+// luma per pixel: the shader's own unpack, fsr_rcas_tap) in registers: top / centre / bottom taps come from the window, left / right
+// from the lane's own pixels or the neighbouring lane's (DPP), every input pixel is loaded and unpacked once per strip, no LDS, no
+// barrier.  Coordinates outside the image are clamped as the shader's fetches are (the loads clamp: a clamped row / column is the
+// border pixel again).  Same expressions as fsr_rcas_px: identical bits (tests/test_fsr1.py).
+constexpr int kRcasStripCols = 248;
+
+struct RcasWalkArgs {
+    const uint32_t *in;
+    uint32_t *out;
+    int w, h;
+    size_t px; // pixels per frame
+    int strips, row_blocks, rows_per_block;
+    float sharp;
+    uint32_t sel;
+};
+
+struct RcasRow {
+    float4 p[4]; // this lane's four pixels, unpacked (rgb in xyz, luma in w)
+};
+
+__device__ __forceinline__ float4 dpp_up4(const float4 v) { return make_float4(wave_up(v.x), wave_up(v.y), wave_up(v.z), wave_up(v.w)); }
+__device__ __forceinline__ float4 dpp_down4(const float4 v) { return make_float4(wave_down(v.x), wave_down(v.y), wave_down(v.z), wave_down(v.w)); }
+
+template <bool VEC>
+__global__ __launch_bounds__(256) void k_fsr_rcas_walk(const RcasWalkArgs A)
+{
+    const int lane = threadIdx.x & (kWave - 1);
+    const int g = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+    if (g >= A.strips * A.row_blocks) return;
+    const int rb = g / A.strips, strip = g - rb * A.strips;
+    const uint32_t *__restrict__ in = A.in + (size_t)blockIdx.y * A.px;
+    uint32_t *__restrict__ out = A.out + (size_t)blockIdx.y * A.px;
+    const int c0 = strip * kRcasStripCols - 4 + lane * 4; // first column of this lane
+    const int y0 = rb * A.rows_per_block, y1 = min(y0 + A.rows_per_block, A.h);
+    const bool writer = lane >= 1 && lane <= kRcasStripCols / 4 && c0 < A.w;
+    // columns of the lane's four pixels, clamped into the image (a clamped column IS the border pixel, as the shader fetches it)
+    int cc[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) cc[k] = clampi(c0 + k, 0, A.w - 1);
+    const bool vec_ok = VEC && c0 >= 0 && c0 + 4 <= A.w; // one 16-byte load
+    auto load_row = [&](int y) -> RcasRow {
+        const uint32_t *row = in + (size_t)clampi(y, 0, A.h - 1) * A.w;
+        uint32_t px[4];
+        if (vec_ok) {
+            const uint4 v = *reinterpret_cast<const uint4 *>(row + c0);
+            px[0] = v.x, px[1] = v.y, px[2] = v.z, px[3] = v.w;
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) px[k] = row[cc[k]];
+        }
+        RcasRow r;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) r.p[k] = fsr_rcas_tap(swz(px[k], A.sel));
+        return r;
+    };
+    // The lane's left / right neighbours in a row are its own pixels or the neighbouring lane's last / first.  The image's first and
+    // last column need nothing special: positions outside the image were LOADED clamped, so the position left of column 0 (the halo
+    // lane's last pixel) holds column 0 itself and the position right of column w - 1 holds column w - 1 -- the shader's clamp.
+    RcasRow top = load_row(y0 - 1), ctr = load_row(y0), bot = load_row(y0 + 1);
+    for (int y = y0; y < y1; ++y) {
+        const RcasRow nxt = load_row(y + 2); // in flight during this row
+        const float4 from_left = dpp_up4(ctr.p[3]), from_right = dpp_down4(ctr.p[0]);
+        uint32_t o[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float4 l = k == 0 ? from_left : ctr.p[k - 1];
+            const float4 r = k == 3 ? from_right : ctr.p[k + 1];
+            o[k] = fsr_rcas_px(ctr.p[k], top.p[k], bot.p[k], l, r, A.sharp);
+        }
+        if (writer) {
+            uint32_t *dst = out + (size_t)y * A.w + c0;
+            if (VEC && c0 + 4 <= A.w) {
+                *reinterpret_cast<uint4 *>(dst) = make_uint4(o[0], o[1], o[2], o[3]);
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (c0 + k < A.w) dst[k] = o[k];
+            }
+        }
+        top = ctr, ctr = bot, bot = nxt;
+    }
+}
+
 } // namespace
 
 namespace {
@@ -529,7 +617,25 @@ hipError_t launch_fsr1(const UpscaleLaunch &L, int mode, float easu_sharpness, f
         if (mode == 0) {
             NUS_FSR(FsrMode::Easu);
         } else if (mode == 1) {
-            if (vec)
+#ifndef NUS_RCAS_WALK
+#define NUS_RCAS_WALK 1 // dev macro: 0 = RCAS through the LDS tile (rounds 1-4; A/B timing)
+#endif
+            if (NUS_RCAS_WALK) {
+                RcasWalkArgs W;
+                W.in = A.in, W.out = A.out, W.w = A.ow, W.h = A.oh, W.px = A.opx, W.sharp = A.rcas_sharp, W.sel = A.sel;
+                W.strips = (int)cdiv(L.ow, (uint32_t)kRcasStripCols);
+                // row blocks: enough waves to fill the GPU several times over, blocks long enough that the 2 halo rows do not matter
+                uint32_t rows = 64;
+                while (rows > 16 && (uint64_t)W.strips * cdiv(L.oh, rows) * n < 8192) rows /= 2;
+                W.rows_per_block = (int)rows;
+                W.row_blocks = (int)cdiv(L.oh, rows);
+                const dim3 wblock(256), wgrid(cdiv((uint32_t)(W.strips * W.row_blocks), 4), n);
+                const bool wvec = vec && (reinterpret_cast<uintptr_t>(A.in) % 16) == 0 && (reinterpret_cast<uintptr_t>(A.out) % 16) == 0;
+                if (wvec)
+                    hipLaunchKernelGGL(k_fsr_rcas_walk<true>, wgrid, wblock, 0, L.stream, W);
+                else
+                    hipLaunchKernelGGL(k_fsr_rcas_walk<false>, wgrid, wblock, 0, L.stream, W);
+            } else if (vec)
                 NUS_FSR2(FsrMode::Rcas, true, false);
             else
                 NUS_FSR2(FsrMode::Rcas, false, false);

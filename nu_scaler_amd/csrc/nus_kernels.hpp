@@ -90,6 +90,7 @@ enum class Variant : int {
     FsrEasu,          // FSR1-style EASU alone (any scale)
     FsrRcas,          // FSR1-style RCAS alone (same size in and out)
     Fsr1Fused,        // EASU tile (+1 px halo) in LDS, RCAS out of it
+    Fsr1TwoPass,      // EASU into a scratch image in HBM, the row-walking RCAS out of it (frames of >= 1 MiB: faster than the fused tile)
 };
 
 const char *variant_name(Variant v);

@@ -66,7 +66,7 @@ def test_gpu_easu_rcas_and_fused_bit_exact(nsc, oracle_mod, dims):
             assert u.kernel_variant == "fsr1_easu_rcas_fused_lds"
             assert np.array_equal(got_f, oracle_mod.fsr1(img, ow, oh, es, 0.7))
         got_r, u = _run(nsc, "rcas", img, w, h, rcas=0.6)
-        assert u.kernel_variant == "fsr1_rcas_tile"
+        assert u.kernel_variant == "fsr1_rcas_rows"
         assert np.array_equal(got_r, oracle_mod.fsr_rcas(img, 0.6))
 
 
@@ -83,19 +83,42 @@ def test_gpu_fsr1_quality_default_and_errors(nsc, oracle_mod):
 
 @pytest.mark.gpu
 def test_gpu_fsr1_1080p_to_4k_device_batch(nsc, oracle_mod):
-    """BASELINE-size frame through the device path (3 frames per launch) against the oracle."""
+    """BASELINE-size frames through the device path against the oracle.  Round 5: frames of 1 MiB and more take two launches --
+    EASU into scratch images of the handle (4 frames at a time), the row-walking RCAS out of them -- instead of the fused LDS tile;
+    7 frames per call = two chunks; a second call on ANOTHER stream right behind the first must not overwrite the scratch images the
+    first is still reading (the handle's event); option fsr_two_pass = 0 keeps the fused tile, same bytes."""
     import torch
     w, h = 1920, 1080
-    frames = np.stack([oracle_mod.gen_gradient(w, h, k) for k in range(2)] + [oracle_mod.gen_noise(w, h, 34)])
+    frames = np.stack([oracle_mod.gen_gradient(w, h, k) for k in range(2)] + [oracle_mod.gen_noise(w, h, 34 + k) for k in range(5)])
+    n = len(frames)
     u = nsc.PyWgpuUpscaler("quality", "fsr1")
     u.initialize(w, h, 2 * w, 2 * h)
+    assert u.kernel_variant == "fsr1_easu_then_rcas_rows"
     d_in = torch.from_numpy(frames).cuda()
-    d_out = torch.empty((3, 2 * h, 2 * w, 4), dtype=torch.uint8, device="cuda")
-    u.upscale_device(d_in.data_ptr(), d_out.data_ptr(), 3, torch.cuda.current_stream().cuda_stream)
+    d_out = torch.empty((n, 2 * h, 2 * w, 4), dtype=torch.uint8, device="cuda")
+    d_out2 = torch.empty_like(d_out)
+    side = torch.cuda.Stream()
+    u.upscale_device(d_in.data_ptr(), d_out.data_ptr(), n, torch.cuda.current_stream().cuda_stream)
+    rev = d_in.flip(0).contiguous()
     torch.cuda.synchronize()
-    got = d_out.cpu().numpy()
-    for k in (0, 2):
-        assert np.array_equal(got[k], oracle_mod.fsr1(frames[k], 2 * w, 2 * h, 0.0, 0.7))
+    u.upscale_device(d_in.data_ptr(), d_out.data_ptr(), n, torch.cuda.current_stream().cuda_stream)
+    u.upscale_device(rev.data_ptr(), d_out2.data_ptr(), n, side.cuda_stream)  # other frames, other stream, same scratch
+    torch.cuda.synchronize()
+    got, got2 = d_out.cpu().numpy(), d_out2.cpu().numpy()
+    for k in (0, 2, 3, 4, n - 1):
+        want = oracle_mod.fsr1(frames[k], 2 * w, 2 * h, 0.0, 0.7)
+        assert np.array_equal(got[k], want), k
+        assert np.array_equal(got2[n - 1 - k], want), k
+    f = nsc.PyWgpuUpscaler("quality", "fsr1")
+    f.set_option("fsr_two_pass", 0)
+    f.initialize(w, h, 2 * w, 2 * h)
+    assert f.kernel_variant == "fsr1_easu_rcas_fused_lds"
+    d_out2.zero_()
+    f.upscale_device(d_in.data_ptr(), d_out2.data_ptr(), n, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert torch.equal(d_out, d_out2)
+    with pytest.raises(RuntimeError, match="before initialize"):
+        f.set_option("fsr_two_pass", 1)
 
 
 FAST_SIZES = [((64, 36), (128, 72)), ((320, 180), (640, 360)), ((100, 70), (257, 131)), ((17, 13), (40, 29)), ((5, 3), (130, 67)),
@@ -126,7 +149,7 @@ def test_gpu_fsr_fast_mode_contract(nsc, oracle_mod, dims):
             assert (got_e[..., 3] == 255).all()
             differs = differs or bool(d.any())
             got_f, u = _run(nsc, "fsr1", img, ow, oh, easu=es, rcas=0.7, fast=True)
-            assert u.kernel_variant == "fsr1_easu_rcas_fused_lds"
+            assert u.kernel_variant == ("fsr1_easu_then_rcas_rows" if ow * oh * 4 >= 1 << 20 else "fsr1_easu_rcas_fused_lds")
             assert np.array_equal(got_f, oracle_mod.fsr_rcas(got_e, 0.7)), es
         got_x, _ = _run(nsc, "fsr1", img, ow, oh, easu=0.0, rcas=0.7)  # the default mode is untouched
         assert np.array_equal(got_x, oracle_mod.fsr1(img, ow, oh, 0.0, 0.7))
