@@ -431,6 +431,15 @@ class ShardedStream:
                 else:
                     dist.init_process_group(backend, rank=self.rank, world_size=self.world)
             self._own_group = True
+        try:
+            self._finish_init(plc, torch, on_gpu, bind, pipeline_factory, algorithm, time_t, lanczos_mode, total_units, source,
+                              force_collectives)
+        except BaseException:
+            self.close()  # a rank that fails while it sets up must not leave its process group behind
+            raise
+
+    def _finish_init(self, plc, torch, on_gpu, bind, pipeline_factory, algorithm, time_t, lanczos_mode, total_units, source,
+                     force_collectives):
         hip_bdf = None
         if on_gpu:
             try:
