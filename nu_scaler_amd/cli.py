@@ -44,9 +44,39 @@ def build_parser() -> argparse.ArgumentParser:
     st.add_argument("--force-device", type=int, default=-1, help="every rank on this device (rehearsal on a one-GPU box)")
     st.add_argument("--no-bind", action="store_true", help="leave the ranks' CPU affinity alone")
     st.add_argument("--digest", action="store_true", help="also print one digest per unit of the stream (sharding-invariant)")
+    st.add_argument("--window", type=int, default=0,
+                    help="0: every rank holds its whole shard in HBM and repeats it --steps times; W > 0: ONE pass over the stream in "
+                         "windows of W units per rank, the next window fetched beside the current one (a stream that need not fit)")
     st.add_argument("--host-fed-seconds", type=float, default=0.0,
                     help="afterwards, every rank feeds its GPU from HOST memory through upscale_batch for this long (mode ii)")
     return ap
+
+
+def _stream_in_windows(args, S) -> dict:
+    """`stream --window W`: one pass over the stream, every rank's shard in windows (ShardedStream.run_windows)."""
+    s = S.ShardedStream(args.units * args.gpus, args.width, args.height, source=S.SyntheticSource(args.pattern), backend=args.backend,
+                        bind=not args.no_bind, force_device=args.force_device, schedule=args.schedule, algorithm=args.algorithm,
+                        resident=False)
+    try:
+        digests = []
+
+        def consume(st, first, n, mid, up_real, up_mid):
+            if args.digest:
+                digests.extend(st.unit_digests((mid, up_real, up_mid), n))
+
+        s.run_windows(args.window, consume if args.digest else None)
+        per_rank = -(-s.total_units // s.world)
+        row = {"elapsed_s": s.elapsed_local, "first_unit": float(s.start), "units": float(s.count),
+               "numa_node": s.placement.get("numa_node"), "bound": 1.0 if s.placement.get("bound") else 0.0}
+        if args.digest:
+            row.update({f"sink_digest_{k:05d}": (float(digests[k]) if k < len(digests) else None) for k in range(per_rank)})
+        rows = s.gather(row)
+        out = s.summarize(rows)
+        out.update(rank=s.rank, rows=rows, window=args.window,
+                   placement={k: v for k, v in s.placement.items() if not k.startswith("_")})
+        return out
+    finally:
+        s.close()
 
 
 def stream_command(args, argv) -> int:
@@ -79,9 +109,12 @@ def stream_command(args, argv) -> int:
             row.update({f"digest_{k:05d}": (float(d[k]) if k < len(d) else None) for k in range(per_rank)})
         return row or None
 
-    out = S.run_sharded(args.units * args.gpus, args.width, args.height, steps=args.steps, warmup=args.warmup,
-                        source=S.SyntheticSource(args.pattern), sink=sink, backend=args.backend, bind=not args.no_bind,
-                        force_device=args.force_device, schedule=args.schedule, algorithm=args.algorithm)
+    if args.window > 0:
+        out = _stream_in_windows(args, S)
+    else:
+        out = S.run_sharded(args.units * args.gpus, args.width, args.height, steps=args.steps, warmup=args.warmup,
+                            source=S.SyntheticSource(args.pattern), sink=sink, backend=args.backend, bind=not args.no_bind,
+                            force_device=args.force_device, schedule=args.schedule, algorithm=args.algorithm)
     if out["rank"] == 0:
         rows = out.pop("rows")
         if args.digest:

@@ -372,7 +372,7 @@ class ShardedStream:
     def __init__(self, total_units: int, width: int, height: int, *, source=None, backend: str = "nccl", bind: bool = True,
                  force_device: int = -1, schedule: str = "unit", algorithm: str = "lanczos3", time_t: float = 0.5,
                  lanczos_mode: str = "fma", pipeline_factory=None, environ=None, device_kind: str = "cuda",
-                 force_collectives: bool = False):
+                 force_collectives: bool = False, resident: bool = True):
         import os
 
         env = os.environ if environ is None else environ
@@ -433,13 +433,13 @@ class ShardedStream:
             self._own_group = True
         try:
             self._finish_init(plc, torch, on_gpu, bind, pipeline_factory, algorithm, time_t, lanczos_mode, total_units, source,
-                              force_collectives)
+                              force_collectives, resident)
         except BaseException:
             self.close()  # a rank that fails while it sets up must not leave its process group behind
             raise
 
     def _finish_init(self, plc, torch, on_gpu, bind, pipeline_factory, algorithm, time_t, lanczos_mode, total_units, source,
-                     force_collectives):
+                     force_collectives, resident=True):
         hip_bdf = None
         if on_gpu:
             try:
@@ -460,6 +460,11 @@ class ShardedStream:
         self.total_units = int(total_units)
         self.start, self.count = shard_frames(self.total_units, self.world, self.rank)
         self.source = source if source is not None else SyntheticSource("gradient")
+        self.elapsed_local = None
+        self.steps_run = 0
+        if not resident:  # the shard goes through in windows (run_windows): nothing of it is loaded here
+            self.frames = self.mid = self.up_real = self.up_mid = None
+            return
         self.frames = self.source(self.start, self.count + 1, self.width, self.height, self.device)
         want = (self.count + 1, self.height, self.width, 4)
         if tuple(self.frames.shape) != want or self.frames.dtype != torch.uint8 or self.frames.device.type != self.device.type \
@@ -528,6 +533,73 @@ class ShardedStream:
         self.steps_run = int(steps)
         return self.elapsed_local
 
+    def run_windows(self, window: int, consume=None) -> float:
+        """The shard as a STREAM: a frame queue has no end and need not fit in HBM.  The rank's units go through in windows of
+        `window` units (+ the overlap frame): window i + 1 is fetched from the source into the second of two frame buffers on a
+        side stream while window i is computed, `consume(stream, first_unit, n, mid, up_real, up_mid)` sees each window's outputs
+        before the next window overwrites them.  One pass over the shard between two barriers; returns this rank's seconds (source
+        and consumer included: that is what a stream costs).  Construct with resident=False.  Same kernels, same bytes per unit as
+        the resident step: a unit's digest does not depend on the window (tests/test_sharded_stream.py)."""
+        import time
+
+        torch = self._torch
+        W = int(window)
+        if W < 1:
+            raise ValueError("window must be at least one unit")
+        gpu = self.device.type == "cuda"
+        bufs = [torch.empty((W + 1, self.height, self.width, 4), dtype=torch.uint8, device=self.device) for _ in range(2)]
+        mid, up_real, up_mid = self.pipeline.alloc(W, self.device)
+        nwin = (self.count + W - 1) // W
+        main = torch.cuda.current_stream() if gpu else None
+        side = torch.cuda.Stream() if gpu else None
+        filled = [torch.cuda.Event() for _ in range(2)] if gpu else None
+        computed = [torch.cuda.Event() for _ in range(2)] if gpu else None
+
+        def fetch(wi):  # window wi into buffer wi % 2 (on the side stream: beside the previous window's kernels)
+            u0 = wi * W
+            m = min(W, self.count - u0)
+            if gpu:
+                if wi >= 2:
+                    side.wait_event(computed[wi % 2])  # its last reader
+                with torch.cuda.stream(side):
+                    bufs[wi % 2][:m + 1].copy_(self.source(self.start + u0, m + 1, self.width, self.height, self.device))
+                filled[wi % 2].record(side)
+            else:
+                bufs[wi % 2][:m + 1].copy_(self.source(self.start + u0, m + 1, self.width, self.height, self.device))
+
+        p = self.pipeline
+        self._sync()
+        self.barrier()
+        t0 = time.perf_counter()
+        if nwin:
+            fetch(0)
+        for wi in range(nwin):
+            u0 = wi * W
+            m = min(W, self.count - u0)
+            if gpu:
+                main.wait_event(filled[wi % 2])
+            if wi + 1 < nwin:
+                fetch(wi + 1)
+            fr = bufs[wi % 2][:m + 1]
+            s_ = self.stream_handle()
+            if self.schedule == "unit":
+                p.step_unit(fr, mid[:m], up_real[:m], up_mid[:m], s_)
+            elif self.schedule == "fused":
+                p.step_fused(fr, up_real[:m], up_mid[:m], s_)
+            else:
+                p.step(fr, mid[:m], up_real[:m], up_mid[:m], s_)
+            if gpu:
+                computed[wi % 2].record(main)
+            if consume is not None:
+                if gpu:
+                    main.synchronize()  # (the consumer reads the outputs; the next window's fetch stays in flight beside it)
+                consume(self, self.start + u0, m, mid[:m], up_real[:m], up_mid[:m])
+        self._sync()
+        self.barrier()
+        self.elapsed_local = time.perf_counter() - t0
+        self.steps_run = 1
+        return self.elapsed_local
+
     def run_host_fed(self, seconds: float, frames_per_call: int = 12, algorithm: str = "lanczos3") -> float:
         """Mode (ii) of SURVEY.md 8(d)/(e) on this rank, all ranks at the same time: a HOST-resident piece of the stream
         (`frames_per_call` pageable 1080p-shaped frames of this rank's shard) goes through the trait-shaped host entry point
@@ -565,16 +637,18 @@ class ShardedStream:
                 "first_unit_by_rank": [int(r["first_unit"]) for r in rows], "units_by_rank": [int(r["units"]) for r in rows],
                 "lut_bytes": self.lut_bytes, "backend": self.backend if self.world > 1 else None, "schedule": self.schedule}
 
-    def unit_digests(self):
-        """One number per unit of this rank's shard: the byte sums of its three outputs folded together.  A property the domain
-        offers at any size: unit k's digest does not depend on how the stream was sharded (tests/test_sharded_stream.py)."""
+    def unit_digests(self, bufs=None, n=None):
+        """One number per unit of this rank's shard (or of the `n` units in `bufs` = (mid, up_real, up_mid): a window): the byte sums
+        of its three outputs folded together.  A property the domain offers at any size: unit k's digest does not depend on how the
+        stream was sharded or windowed (tests/test_sharded_stream.py)."""
         t = self._torch
         M = 4503599627370449  # below 2^52: a digest travels exactly in the float64 rows of `gather`
         out = []
         weights = {}
-        for k in range(self.count):
+        mid, up_real, up_mid = bufs if bufs is not None else (self.mid, self.up_real, self.up_mid)
+        for k in range(self.count if n is None else n):
             total = 0
-            for buf, mult in ((self.mid, 1), (self.up_real, 1000003), (self.up_mid, 998244353)):
+            for buf, mult in ((mid, 1), (up_real, 1000003), (up_mid, 998244353)):
                 if buf is None:
                     continue
                 v = buf[k].reshape(-1).to(t.int64)  # one frame at a time: the int64 view of a 4K frame is 265 MB

@@ -61,6 +61,7 @@ def main():
     ap.add_argument("--steps", type=int, default=1)
     ap.add_argument("--warmup", type=int, default=0)
     ap.add_argument("--sink-fails-on", type=int, default=-1, help="the sink raises on this rank (the job must end, not hang)")
+    ap.add_argument("--window", type=int, default=0, help="> 0: the shard in windows of this many units (ShardedStream.run_windows)")
     args = ap.parse_args()
     import nu_scaler_amd as nsc
     import oracle
@@ -91,6 +92,8 @@ def main():
         row.update({f"digest_{k:05d}": (float(d[k]) if k < len(d) else None) for k in range(per_rank)})
         return row
 
+    if args.window > 0:
+        return windows_main(args, nsc, oracle, factory)
     # the process group is the caller's here (ShardedStream creates one only if none exists, and then tears it down itself;
     # tests/test_sharded_stream.py's GPU tests and the CLI go that way): it outlives run_sharded for the last assertion
     import torch.distributed as dist
@@ -121,6 +124,39 @@ def main():
                    summary_equal_on_all_ranks=same, unit_pixels=pipes[0].unit_pixels)
         out.pop("placement", None)
         print(json.dumps(out), flush=True)
+
+
+def windows_main(args, nsc, oracle, factory):
+    """The same stream in windows: every unit of every window against the oracle, digests gathered as the CLI gathers them."""
+    s = nsc.ShardedStream(args.units_total, W, H, backend="gloo", device_kind="cpu", pipeline_factory=factory, resident=False)
+    try:
+        digests, bad, seen = [], [0], []
+
+        def consume(st, first, n, mid, up_real, up_mid):
+            seen.append((first, n))
+            for k in range(n):
+                a, b = oracle.gen_gradient(W, H, first + k), oracle.gen_gradient(W, H, first + k + 1)
+                m = oracle.warp_blend(a, b, None, 0.5)
+                ok = (np.array_equal(mid[k].numpy(), m) and np.array_equal(up_real[k].numpy(), oracle.lanczos3(a, 2 * W, 2 * H))
+                      and np.array_equal(up_mid[k].numpy(), oracle.lanczos3(m, 2 * W, 2 * H)))
+                bad[0] += 0 if ok else 1
+            digests.extend(st.unit_digests((mid, up_real, up_mid), n))
+
+        s.run_windows(args.window, consume)
+        per_rank = -(-s.total_units // s.world)
+        row = {"elapsed_s": s.elapsed_local, "first_unit": float(s.start), "units": float(s.count), "bad": float(bad[0]),
+               "windows": float(len(seen))}
+        row.update({f"digest_{k:05d}": (float(digests[k]) if k < len(digests) else None) for k in range(per_rank)})
+        rows = s.gather(row)
+        if s.rank == 0:
+            out = s.summarize(rows)
+            allv = []
+            for r in rows:
+                allv += [int(r[k]) for k in sorted(r) if k.startswith("digest_") and r[k] is not None]
+            out.update(unit_digests=allv, mismatches_by_rank=[int(r["bad"]) for r in rows], windows_by_rank=[int(r["windows"]) for r in rows])
+            print(json.dumps(out), flush=True)
+    finally:
+        s.close()
 
 
 if __name__ == "__main__":

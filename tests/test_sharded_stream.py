@@ -56,6 +56,21 @@ def test_world3_ragged_shards_and_an_empty_rank(nsc):
     assert len(out[0]["unit_digests"]) == 2
 
 
+def test_the_shard_in_windows_is_the_same_stream(nsc):
+    """ShardedStream.run_windows: a stream need not fit in HBM -- each rank's shard goes through in windows (+ the overlap frame),
+    the next window fetched while the current one is computed.  Two ranks, 11 units, windows of 4: 6 + 5 units in 2 + 2 windows
+    (4 + 2, 4 + 1), every unit of every window against the oracle, and the digests of the 11 units equal those of the resident
+    one-rank run: a unit's outputs depend neither on the sharding nor on the window."""
+    rc, out = _launch(2, ["--units-total", "11", "--window", "4"])
+    assert rc == 0 and len(out) == 1, out
+    win = out[0]
+    assert win["units_by_rank"] == [6, 5] and win["windows_by_rank"] == [2, 2] and win["mismatches_by_rank"] == [0, 0]
+    rc, out = _launch(1, ["--units-total", "11"])
+    assert rc == 0 and out[0]["unit_digests"] == win["unit_digests"] and len(win["unit_digests"]) == 11
+    rc, out = _launch(1, ["--units-total", "11", "--window", "16"])  # one window larger than the shard
+    assert rc == 0 and out[0]["unit_digests"] == win["unit_digests"] and out[0]["windows_by_rank"] == [1]
+
+
 def test_a_sink_that_raises_on_one_rank_ends_the_job(nsc):
     """run_sharded: the failure of one rank's sink travels through the gather -- every rank raises (the failing one its own
     exception), nobody is left waiting in a collective, the launcher reports a non-zero exit code within seconds."""
@@ -157,4 +172,11 @@ def test_cli_stream_digests_do_not_depend_on_the_sharding(nsc):
         assert one["n_gpus"] == 1 and two["n_gpus"] == 2 and three["n_gpus"] == 3
         assert two["units_by_rank"] == [6, 6] and three["first_unit_by_rank"] == [0, 4, 8]
         assert len(one["unit_digests"]) == 12 and one["unit_digests"] == two["unit_digests"] == three["unit_digests"]
+        # and in windows (one pass, the next window fetched on a side stream beside the current one's kernels): the same stream
+        cmd = [sys.executable, "-m", "nu_scaler_amd.cli", "stream", "--gpus", "2", "--units", "6", "--pattern", pattern, "--digest",
+               "--backend", "gloo", "--force-device", "0", "--window", "4"]
+        res = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+        assert res.returncode == 0, res.stderr[-3000:]
+        win = [json.loads(ln) for ln in res.stdout.splitlines() if ln.startswith("{")][0]
+        assert win["window"] == 4 and win["steps"] == 1 and win["unit_digests"] == one["unit_digests"]
         assert two["lut_bytes"] > 0 and two["backend"] == "gloo" and one["mpix_per_s"] > 0
