@@ -41,6 +41,9 @@ def _timed(flows, **kw):
 for rnd in range(2):
     print(f"motion step, {n} units, stage after stage: {timed():7.2f} ms", flush=True)
     for c in chunks:
+        pipe._motion_real_first = False
+        print(f"motion step, {n} units, pipelined, chunks of {c:3d}, real frames per chunk: {timed(pipelined=True, chunk=c):7.2f} ms", flush=True)
+        pipe._motion_real_first = True
         print(f"motion step, {n} units, pipelined, chunks of {c:3d}: {timed(pipelined=True, chunk=c):7.2f} ms", flush=True)
     for env in ("0", "1"):  # one entry point (estimator, then the warp kernel behind it) / the warp inside the last Jacobi launch
         os.environ["NUS_HS_FUSED_WARP"] = env
