@@ -458,10 +458,13 @@ int nus_flow_estimate_device_stream(nus_flow *h, const void *d_frames, uint32_t 
  * nus_flow_estimate_device_stream AND the in-between frame of every pair (k, k + 1) at time_t in [0, 1], warped + blended with that
  * flow (warp_blend.wgsl:25-43; dense-flow warp in FMA mode: within 1 LSB of the CPU blend, as nus_interp_set_mode(.., FMA)), tightly
  * packed RGBA8 at d_mid.  d_flows may be NULL (the in-between frames only: the flows then stay in the estimator's workspace).
- * Same bytes as nus_flow_estimate_device_stream followed by nus_interp_interpolate_device in FMA mode.  Pointers 16-byte aligned. */
+ * flow_format: NUS_FLOW_F32 -- same bytes as nus_flow_estimate_device_stream followed by nus_interp_interpolate_device in FMA mode;
+ * NUS_FLOW_F16 -- the flows between estimator and warp (and at d_flows: w*h*4 bytes per pair) are the reference's live layout,
+ * Rg16Float (wgpu_interpolator.rs:276): each the f32 flow rounded to nearest even, and the warp reads them as such (2^-11 relative
+ * resolution: 5e-4 px on a 1-2 px flow; half the bytes of the hand-off).  Pointers 16-byte aligned. */
 int nus_flow_interpolate_device_stream(nus_flow *h, const void *d_frames, uint32_t n_frames, uint32_t w, uint32_t hgt,
                                        uint32_t levels, uint32_t coarse_iters, uint32_t refine_iters, float lambda, float time_t,
-                                       void *d_flows, void *d_mid, void *stream);
+                                       int flow_format, void *d_flows, void *d_mid, void *stream);
 
 #ifdef __cplusplus
 }

@@ -124,7 +124,7 @@ SIGNATURES = [
     ("nus_flow_estimate", _i, [_vp, _vp, _vp, _u32, _u32, _u32, _u32, _u32, _f, _vp]),
     ("nus_flow_estimate_device", _i, [_vp, _vp, _vp, _u32, _u32, _u32, _u32, _u32, _f, _vp, _vp]),
     ("nus_flow_estimate_device_stream", _i, [_vp, _vp, _u32, _u32, _u32, _u32, _u32, _u32, _f, _vp, _vp]),
-    ("nus_flow_interpolate_device_stream", _i, [_vp, _vp, _u32, _u32, _u32, _u32, _u32, _u32, _f, _f, _vp, _vp, _vp]),
+    ("nus_flow_interpolate_device_stream", _i, [_vp, _vp, _u32, _u32, _u32, _u32, _u32, _u32, _f, _f, _i, _vp, _vp, _vp]),
 ]
 
 

@@ -703,11 +703,15 @@ int nus_flow_estimate_device_stream(nus_flow *h, const void *d_frames, uint32_t 
 
 int nus_flow_interpolate_device_stream(nus_flow *h, const void *d_frames, uint32_t n_frames, uint32_t w, uint32_t hgt,
                                        uint32_t levels, uint32_t coarse_iters, uint32_t refine_iters, float lambda, float time_t,
-                                       void *d_flows, void *d_mid, void *stream)
+                                       int flow_format, void *d_flows, void *d_mid, void *stream)
 {
     return guarded<int>("nus_flow_interpolate_device_stream", [&]() -> int {
+        if (flow_format != NUS_FLOW_F32 && flow_format != NUS_FLOW_F16) {
+            nus::set_thread_error("nus_flow_interpolate_device_stream: flow_format must be NUS_FLOW_F32 or NUS_FLOW_F16");
+            return NUS_ERR_INVALID_ARGUMENT;
+        }
         return h ? h->impl.interpolate_device_stream(d_frames, n_frames, w, hgt, levels, coarse_iters, refine_iters, lambda, time_t,
-                                                     d_flows, d_mid, static_cast<hipStream_t>(stream))
+                                                     d_flows, d_mid, static_cast<hipStream_t>(stream), flow_format == NUS_FLOW_F16)
                  : null_handle();
     });
 }

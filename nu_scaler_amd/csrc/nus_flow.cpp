@@ -366,22 +366,24 @@ int HipFlowEstimator::estimate_device_stream(const void *d_frames, uint32_t n_fr
     return stream_impl(d_frames, n_frames, w, h, levels, coarse_iters, refine_iters, lambda, d_flows, nullptr, 0.5f, stream);
 }
 
+// flow_half: the flows between estimator and warp -- and at d_flows, if given -- as 2 x IEEE half per pixel (Rg16Float, the
+// reference's live flow layout: wgpu_interpolator.rs:276), each the f32 flow rounded to nearest even; the warp reads them as such.
 int HipFlowEstimator::interpolate_device_stream(const void *d_frames, uint32_t n_frames, uint32_t w, uint32_t h, uint32_t levels,
                                                 uint32_t coarse_iters, uint32_t refine_iters, float lambda, float t, void *d_flows,
-                                                void *d_mid, hipStream_t stream)
+                                                void *d_mid, hipStream_t stream, bool flow_half)
 {
     std::lock_guard<std::mutex> lk(mu_);
     if (!d_mid) return fail(kInvalidArgument, "flow: null device pointer");
     if (!(t >= 0.0f && t <= 1.0f)) return fail(kInvalidArgument, "flow: t must be in [0, 1]");
     if ((reinterpret_cast<uintptr_t>(d_mid) % 16) || (reinterpret_cast<uintptr_t>(d_flows) % 16))
         return fail(kInvalidArgument, "flow: device pointers must be 16-byte aligned");
-    return stream_impl(d_frames, n_frames, w, h, levels, coarse_iters, refine_iters, lambda, d_flows, d_mid, t, stream);
+    return stream_impl(d_frames, n_frames, w, h, levels, coarse_iters, refine_iters, lambda, d_flows, d_mid, t, stream, flow_half);
 }
 
 // (called with mu_ held)  d_flows may be null when d_mid is not: the caller wants the in-between frames only.
 int HipFlowEstimator::stream_impl(const void *d_frames, uint32_t n_frames, uint32_t w, uint32_t h, uint32_t levels,
                                   uint32_t coarse_iters, uint32_t refine_iters, float lambda, void *d_flows, void *d_mid, float t,
-                                  hipStream_t stream)
+                                  hipStream_t stream, bool flow_half)
 {
     CHECK_DIMS(w, h);
     if (!d_frames || (!d_flows && !d_mid)) return fail(kInvalidArgument, "flow: null device pointer");
@@ -391,7 +393,7 @@ int HipFlowEstimator::stream_impl(const void *d_frames, uint32_t n_frames, uint3
     if (rc != kOk) return rc;
     const uint8_t *frames = static_cast<const uint8_t *>(d_frames);
     uint8_t *flows = static_cast<uint8_t *>(d_flows), *mid = static_cast<uint8_t *>(d_mid);
-    const size_t frame_bytes = (size_t)w * h * 4, flow_bytes = (size_t)w * h * 8;
+    const size_t frame_bytes = (size_t)w * h * 4, flow_bytes = (size_t)w * h * (flow_half ? 4 : 8);
     // the warp kernel behind an estimator that did not warp itself: pairs [k0, k0 + n) with the flows at `fl`
     auto warp_behind = [&](uint32_t k0, uint32_t n, const void *fl) -> int {
         WarpLaunch L;
@@ -399,6 +401,7 @@ int HipFlowEstimator::stream_impl(const void *d_frames, uint32_t n_frames, uint3
         L.b = L.a + frame_bytes;
         L.a_stride = L.b_stride = frame_bytes;
         L.flow = static_cast<const float *>(fl);
+        L.flow_half = flow_half;
         L.fma = true;
         L.out = mid + (size_t)k0 * frame_bytes;
         L.w = w, L.h = h, L.t = t, L.n_pairs = n, L.stream = stream;
@@ -406,15 +409,22 @@ int HipFlowEstimator::stream_impl(const void *d_frames, uint32_t n_frames, uint3
         return kOk;
     };
     if (!tiled_ && !fast_) { // the shader-shaped kernels, pair by pair (each frame's pyramid still built once)
-        if (mid && !flows) { // (they write a pair's flow where they are told to: one pair's worth of workspace)
-            if ((rc = reserve(flow_bytes, 9)) != kOk) return rc;
+        const size_t f32_bytes = (size_t)w * h * 8;
+        if ((mid && !flows) || flow_half) { // (they write a pair's f32 flow where they are told to: one pair's worth of workspace)
+            if ((rc = reserve(f32_bytes, 9)) != kOk) return rc;
         }
+        if (flow_half && !flows && (rc = reserve(flow_bytes, 10)) != kOk) return rc;
         if ((rc = build_pyramid(frames, 4, g, stream)) != kOk) return rc;
         for (uint32_t k = 0; k + 1 < n_frames; ++k) {
             const int slot_a = 4 + (int)(k & 1), slot_b = 5 - (int)(k & 1);
             if ((rc = build_pyramid(frames + (size_t)(k + 1) * frame_bytes, slot_b, g, stream)) != kOk) return rc;
-            void *fl = flows ? static_cast<void *>(flows + (size_t)k * flow_bytes) : slot_[9];
+            void *fl = flows && !flow_half ? static_cast<void *>(flows + (size_t)k * flow_bytes) : slot_[9];
             if ((rc = solve(slot_a, slot_b, g, coarse_iters, refine_iters, lambda, fl, stream)) != kOk) return rc;
+            if (flow_half) {
+                void *hf = flows ? static_cast<void *>(flows + (size_t)k * flow_bytes) : slot_[10];
+                NUS_HIP(launch_flow_to_half(static_cast<const float *>(fl), hf, (size_t)w * h, stream));
+                fl = hf;
+            }
             if (mid && (rc = warp_behind(k, 1, fl)) != kOk) return rc;
         }
         return kOk;
@@ -439,7 +449,7 @@ int HipFlowEstimator::stream_impl(const void *d_frames, uint32_t n_frames, uint3
         const uint32_t pairs = n_pairs - c0 < chunk ? n_pairs - c0 : chunk;
         if ((rc = solve_batch(frames + (size_t)c0 * frame_bytes, pairs, g, coarse_iters, refine_iters, lambda,
                               flows ? flows + (size_t)c0 * flow_bytes : nullptr, stream, mid ? mid + (size_t)c0 * frame_bytes : nullptr,
-                              t)) != kOk)
+                              t, flow_half)) != kOk)
             return rc;
     }
     return kOk;
@@ -450,7 +460,8 @@ int HipFlowEstimator::stream_impl(const void *d_frames, uint32_t n_frames, uint3
 // 2 / 3 flow ping-pong [pair][level cells], 4 luminance planes [level][frame][cells], 5 coefficients [pair][cells][3].
 // d_mid != nullptr: also the pairs' in-between frames at time t (see interpolate_device_stream); d_flows may then be null.
 int HipFlowEstimator::solve_batch(const uint8_t *d_frames, uint32_t pairs, const Pyramid &g, uint32_t coarse_iters,
-                                  uint32_t refine_iters, float lambda, uint8_t *d_flows, hipStream_t stream, uint8_t *d_mid, float t)
+                                  uint32_t refine_iters, float lambda, uint8_t *d_flows, hipStream_t stream, uint8_t *d_mid, float t,
+                                  bool flow_half)
 {
     int rc;
     // The Jacobi kernel of a level.  FAST: k_hs_stream_fast where the level's batch would stream anyway (or the streamed kernel
@@ -504,15 +515,21 @@ int HipFlowEstimator::solve_batch(const uint8_t *d_frames, uint32_t pairs, const
     // the finest level's last launch warps the pairs itself where it can (HsWarp); `warped` says whether it did
     HsWarp hw;
     hw.frames = d_frames, hw.frame_stride = cells[0] * 4, hw.mid = d_mid, hw.t = t, hw.sel = kSelRGBA;
-    bool warped = false;
+    hw.out_half = flow_half ? 1u : 0u;
+    bool warped = false, wrote_half = false;
+    // Rg16Float hand-off: only the FAST streamed kernel's last launch stores halves itself.  The caller's buffer (4 bytes per cell
+    // then) may be handed to the solver only if that launch is what finishes level 0 -- every other kernel writes 2 x f32 per cell
+    // and must be kept in the workspace, its flow converted afterwards.
+    const bool fast_last = level_kernel(0) == kJacobiStreamFast && (nl > 1 ? refine_iters > 0 : coarse_iters > 0);
+    float *const solver_out = flow_half && !fast_last ? nullptr : out;
     // `coarse`: the level continues the flow of level l + 1 in f0, which the first launch upsamples as it loads it
     auto iterate = [&](uint32_t l, uint32_t iters, bool zero, bool coarse) -> int {
-        bool did = false;
-        NUS_HIP(launch_hs_iterate(coef, lambda, &f0, &f1, g.w[l], g.h[l], iters, zero, l == 0 ? out : nullptr, stream, pairs,
+        bool did = false, did_half = false;
+        NUS_HIP(launch_hs_iterate(coef, lambda, &f0, &f1, g.w[l], g.h[l], iters, zero, l == 0 ? solver_out : nullptr, stream, pairs,
                                   cells[l] * 3, cells[l], cells[0], level_kernel(l), from_planes(l) ? lum + lum_off[l] : nullptr, cells[l],
                                   coarse ? f0 : nullptr, coarse ? g.w[l + 1] : 0, coarse ? g.h[l + 1] : 0, 2.0f,
-                                  coarse ? cells[l + 1] : 0, l == 0 && d_mid ? &hw : nullptr, &did));
-        if (l == 0) warped = did;
+                                  coarse ? cells[l + 1] : 0, l == 0 && (d_mid || flow_half) ? &hw : nullptr, &did, &did_half));
+        if (l == 0) warped = did, wrote_half = did_half;
         return kOk;
     };
     // coarsest level: from zero flow (compute_coarse_flow, :1136-1154)
@@ -540,14 +557,32 @@ int HipFlowEstimator::solve_batch(const uint8_t *d_frames, uint32_t pairs, const
         f1 = t;
         if (refine_iters > 0 && (rc = iterate((uint32_t)l, refine_iters, false, false)) != kOk) return rc;
     }
-    // (after a launch that warped without storing its flow, f0 names a buffer nothing was written to: nobody reads it)
-    if (out && f0 != out && !(warped && d_mid)) NUS_HIP(hipMemcpyAsync(out, f0, cells[0] * pairs * 8, hipMemcpyDeviceToDevice, stream));
+    // Where the level's final flow is now, and in which format.  (After a launch that warped without storing its flow, f0 names a
+    // buffer nothing was written to: nobody reads it.)
+    const void *final_flow = f0;
+    const bool unstored = warped && d_mid && !out;
+    if (!flow_half) {
+        if (out && f0 != out && !unstored) NUS_HIP(hipMemcpyAsync(out, f0, cells[0] * pairs * 8, hipMemcpyDeviceToDevice, stream));
+        if (out) final_flow = out;
+    } else if (wrote_half) { // halves, in the caller's buffer if there is one (the launch wrote there), else in the workspace
+        if (out && f0 != out && !unstored) NUS_HIP(hipMemcpyAsync(out, f0, cells[0] * pairs * 4, hipMemcpyDeviceToDevice, stream));
+        if (out) final_flow = out;
+    } else if (!unstored) { // 2 x f32 per cell in the workspace (solver_out was null): converted into the caller's buffer, or beside it
+        void *dst = out;
+        if (!dst) {
+            if ((rc = reserve(cells[0] * pairs * 4, 10)) != kOk) return rc;
+            dst = slot_[10];
+        }
+        NUS_HIP(launch_flow_to_half(f0, dst, cells[0] * pairs, stream));
+        final_flow = dst;
+    }
     if (d_mid && !warped) { // the warp kernel behind the estimator, on the flow where it is (the caller's buffer, or the workspace)
         WarpLaunch W;
         W.a = d_frames;
         W.b = d_frames + cells[0] * 4;
         W.a_stride = W.b_stride = cells[0] * 4;
-        W.flow = out ? out : f0;
+        W.flow = static_cast<const float *>(final_flow);
+        W.flow_half = flow_half;
         W.fma = true;
         W.out = d_mid;
         W.w = g.w[0], W.h = g.h[0], W.t = t, W.n_pairs = pairs, W.stream = stream;

@@ -56,7 +56,7 @@ public:
     // just finished instead -- HsWarp; same bytes, measured slower, off by default; tests/test_flow.py runs both.)
     int interpolate_device_stream(const void *d_frames, uint32_t n_frames, uint32_t w, uint32_t h, uint32_t levels,
                                   uint32_t coarse_iters, uint32_t refine_iters, float lambda, float t, void *d_flows, void *d_mid,
-                                  hipStream_t stream);
+                                  hipStream_t stream, bool flow_half = false);
 
 private:
     struct Pyramid { // level geometry; levels are packed at `offset` (16 bytes per pixel reserved)
@@ -73,9 +73,10 @@ private:
     static constexpr uint32_t kStreamMaxChunkPairs = 100;
     static constexpr size_t kStreamWorkspaceBytes = (size_t)6 << 30;
     int stream_impl(const void *d_frames, uint32_t n_frames, uint32_t w, uint32_t h, uint32_t levels, uint32_t coarse_iters,
-                    uint32_t refine_iters, float lambda, void *d_flows, void *d_mid, float t, hipStream_t stream);
+                    uint32_t refine_iters, float lambda, void *d_flows, void *d_mid, float t, hipStream_t stream, bool flow_half = false);
     int solve_batch(const uint8_t *d_frames, uint32_t pairs, const Pyramid &g, uint32_t coarse_iters, uint32_t refine_iters,
-                    float lambda, uint8_t *d_flows, hipStream_t stream, uint8_t *d_mid = nullptr, float t = 0.5f);
+                    float lambda, uint8_t *d_flows, hipStream_t stream, uint8_t *d_mid = nullptr, float t = 0.5f,
+                    bool flow_half = false);
     int fail(int status, const std::string &msg);
     int fail_hip(hipError_t e, const char *what);
     int ensure_device();
@@ -89,7 +90,7 @@ private:
     int jacobi_ = 0; // JacobiKernel
     bool fast_ = false; // set_mode(1): the estimator's Jacobi steps in FAST arithmetic (k_hs_stream_fast), every level streamed
     hipStream_t stream_ = nullptr;
-    static constexpr int kSlotCount = 10; // 0-5 pyramids / flows / planes, 6-7 the host entry point's frames, 8 the FAST pair, 9 one pair's flow
+    static constexpr int kSlotCount = 11; // 0-5 pyramids / flows / planes, 6-7 the host entry point's frames, 8 the FAST pair, 9 one pair's flow, 10 a chunk's flows as f16
     void *slot_[kSlotCount] = {nullptr};
     size_t slot_cap_[kSlotCount] = {0};
     std::string error_;

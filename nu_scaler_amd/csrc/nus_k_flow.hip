@@ -1,6 +1,7 @@
 // nus_k_flow.hip -- optical-flow front end: Gaussian pyramid + Horn-Schunck.
 #include "nus_device.hpp"
 #include "nus_warp_device.hpp"
+#include <hip/hip_fp16.h>
 #include <algorithm>
 #include <cstdlib>
 #include <type_traits>
@@ -961,7 +962,12 @@ __global__ __launch_bounds__(256) void k_hs_stream_fast(const float *__restrict_
             if (j == K - 1) {
                 const int y = r - 1;
                 if (y >= y0 && y < y1 && writer) {
-                    if (!WARP || fout_all != nullptr) fout[(size_t)y * w + x] = arr;
+                    if (!WARP || fout_all != nullptr) {
+                        if (warp.out_half) // (wave-uniform) the level's final flow as Rg16Float
+                            reinterpret_cast<__half2 *>(fout_all)[blockIdx.y * fout_stride + (size_t)y * w + x] = __floats2half2_rn(arr.x, arr.y);
+                        else
+                            fout[(size_t)y * w + x] = arr;
+                    }
                     if constexpr (WARP) {
                         const uint32_t p = warp_blend_pixel<kWarpFma>(wra, wrb, (uint32_t)w * 4u, wwmax, whmax, (uint32_t)w - 2u, (uint32_t)h - 2u,
                                                                       (float)x, (float)y, arr, wtv, wnt);
@@ -1045,7 +1051,12 @@ __global__ __launch_bounds__(256) void k_hs_stream_fast(const float *__restrict_
             arr = make_float2(__builtin_fmaf(-num, c.gx, ua), __builtin_fmaf(-num, c.gy, va));
             if (j == K - 1) {
                 const int y = r - 1;
-                if (y >= y0 && y < y1 && writer) fout[(size_t)y * w + x] = arr;
+                if (y >= y0 && y < y1 && writer) {
+                    if (warp.out_half)
+                        reinterpret_cast<__half2 *>(fout_all)[blockIdx.y * fout_stride + (size_t)y * w + x] = __floats2half2_rn(arr.x, arr.y);
+                    else
+                        fout[(size_t)y * w + x] = arr;
+                }
             }
         }
 #pragma unroll
@@ -1293,19 +1304,24 @@ hipError_t launch_hs_iterate(const float *coef, float lambda, float **flow_a, fl
                              uint32_t iterations, bool zero_start, float *final_out, hipStream_t stream, uint32_t n,
                              size_t coef_stride, size_t flow_stride, size_t final_stride, int kernel, const float *lum1,
                              size_t lum_stride, const float *coarse, uint32_t cw, uint32_t ch, float coarse_scale, size_t coarse_stride,
-                             const HsWarp *warp, bool *warped)
+                             const HsWarp *warp, bool *warped, bool *wrote_half)
 {
     if (kernel == kJacobiStreamFast) { // FAST arithmetic (k_hs_stream_fast): always streamed, always from the luminance planes
         if (lum1 == nullptr) return hipErrorInvalidValue;
         // one launch of k steps over pairs [0, m) of the given bases
-        bool did_warp = false;
+        bool did_warp = false, did_half = false;
         auto launch_one = [&](uint32_t k, bool ups, const float *lum, const float2 *fi, float2 *fo, size_t out_stride, const HsCoarse &hc,
-                              uint32_t m, const HsWarp *wp) -> hipError_t {
+                              uint32_t m, const HsWarp *wp, bool half_out) -> hipError_t {
+            HsWarp tail; // what the plain instantiations see of it: only the format of the flow they store
+            tail.out_half = half_out ? 1u : 0u;
+            HsWarp wfull = wp ? *wp : HsWarp{};
+            wfull.out_half = tail.out_half;
+            if (wp) wp = &wfull;
             const HsStreamShape sh = hs_stream_shape(w, h, m, k, true);
             const dim3 block(256), grid(cdiv(sh.strips * sh.row_blocks, 4), m);
 #define NUS_HSF_L(KK, UU, RR)                                                                                                        \
     hipLaunchKernelGGL((k_hs_stream_fast<KK, UU, RR>), grid, block, 0, stream, lum, lum_stride, lambda, fi, flow_stride, fo, out_stride, \
-                       (int)w, (int)h, (int)sh.strips, (int)sh.row_blocks, (int)sh.rows_per_block, hc, HsWarp{})
+                       (int)w, (int)h, (int)sh.strips, (int)sh.row_blocks, (int)sh.rows_per_block, hc, tail)
 #define NUS_HSF_W(KK)                                                                                                                \
     hipLaunchKernelGGL((k_hs_stream_fast<KK, false, true, true>), grid, block, 0, stream, lum, lum_stride, lambda, fi, flow_stride, fo, \
                        out_stride, (int)w, (int)h, (int)sh.strips, (int)sh.row_blocks, (int)sh.rows_per_block, hc, *wp)
@@ -1375,7 +1391,9 @@ hipError_t launch_hs_iterate(const float *coef, float lambda, float **flow_a, fl
                                   NUS_HS_FAST_RING != 0 && w >= 2 && h >= 2 && (uint64_t)w * h * 4 < (1ull << 32) &&
                                   (uint64_t)w * 4 < (1u << 24) && h < (1u << 24);
             if (can_warp && final_out == nullptr) fo = nullptr;
-            hipError_t e = launch_one(k, ups, lum1, fi, fo, out_stride, hc, n, can_warp ? warp : nullptr);
+            const bool half_out = warp != nullptr && warp->out_half != 0 && launches == 1; // the level's final flow as Rg16Float
+            if (half_out) did_half = true;
+            hipError_t e = launch_one(k, ups, lum1, fi, fo, out_stride, hc, n, can_warp ? warp : nullptr, half_out);
             if (e != hipSuccess) return e;
             iterations -= k;
             --launches;
@@ -1384,9 +1402,11 @@ hipError_t launch_hs_iterate(const float *coef, float lambda, float **flow_a, fl
             *flow_b = t;
         }
         if (warped) *warped = did_warp;
+        if (wrote_half) *wrote_half = did_half;
         return hipSuccess;
     }
     if (warped) *warped = false;
+    if (wrote_half) *wrote_half = false;
     if (hs_iterate_streams(w, h, n, kernel)) {
         if (lum1) coef = lum1, coef_stride = lum_stride; // the kernel takes the derivatives from the planes themselves
         uint32_t launches = (iterations + NUS_HS_STREAM_MAXK - 1) / NUS_HS_STREAM_MAXK;
@@ -1479,6 +1499,25 @@ hipError_t launch_hs_iterate(const float *coef, float lambda, float **flow_a, fl
         *flow_b = t;
     }
     return hipSuccess;
+}
+
+namespace {
+__global__ __launch_bounds__(256) void k_flow_to_half(const float2 *__restrict__ src, __half2 *__restrict__ dst, size_t n)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) {
+        const float2 f = src[i];
+        dst[i] = __floats2half2_rn(f.x, f.y);
+    }
+}
+} // namespace
+
+hipError_t launch_flow_to_half(const float *src, void *dst, size_t n_cells, hipStream_t stream)
+{
+    if (n_cells == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_flow_to_half, dim3((uint32_t)((n_cells + 255) / 256)), dim3(256), 0, stream, reinterpret_cast<const float2 *>(src),
+                       static_cast<__half2 *>(dst), n_cells);
+    return hipGetLastError();
 }
 
 hipError_t launch_flow_upsample(const float *src, uint32_t sw, uint32_t sh, float *dst, uint32_t dw, uint32_t dh,

@@ -219,13 +219,19 @@ struct HsWarp {
     uint8_t *mid = nullptr;
     float t = 0.5f;
     uint32_t sel = 0;
+    // the level's FINAL flow as 2 x IEEE half per cell (round to nearest even) instead of 2 x f32: the reference's live flow layout,
+    // Rg16Float (wgpu_interpolator.rs:276), for a warp that reads it that way.  Honoured by the FAST streamed kernel's last launch
+    // (*wrote_half says so); everything else leaves f32 and the caller converts (launch_flow_to_half).
+    uint32_t out_half = 0;
 };
+// n cells of 2 x f32 -> 2 x f16 (round to nearest even)
+hipError_t launch_flow_to_half(const float *src, void *dst, size_t n_cells, hipStream_t stream);
 hipError_t launch_hs_iterate(const float *coef, float lambda, float **flow_a, float **flow_b, uint32_t w, uint32_t h,
                              uint32_t iterations, bool zero_start, float *final_out, hipStream_t stream, uint32_t n = 1,
                              size_t coef_stride = 0, size_t flow_stride = 0, size_t final_stride = 0, int kernel = 0,
                              const float *lum1 = nullptr, size_t lum_stride = 0, const float *coarse = nullptr, uint32_t cw = 0,
                              uint32_t ch = 0, float coarse_scale = 0.0f, size_t coarse_stride = 0, const HsWarp *warp = nullptr,
-                             bool *warped = nullptr);
+                             bool *warped = nullptr, bool *wrote_half = nullptr);
 bool hs_iterate_streams(uint32_t w, uint32_t h, uint32_t n, int kernel);
 hipError_t launch_flow_upsample(const float *src, uint32_t sw, uint32_t sh, float *dst, uint32_t dw, uint32_t dh,
                                 float scale, hipStream_t stream, uint32_t n = 1, size_t src_stride = 0, size_t dst_stride = 0);

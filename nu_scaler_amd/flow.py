@@ -127,11 +127,15 @@ class FlowEstimator:
                                                               self.lambda_, d_flows, stream or None))
 
     def interpolate_device_stream(self, d_frames: int, n_frames: int, width: int, height: int, time_t: float, d_mid: int,
-                                  d_flows: int = 0, stream: int = 0) -> None:
+                                  d_flows: int = 0, stream: int = 0, flow_format: str = "f32") -> None:
         """The reference's intended interpolate() as one pipeline (wgpu_interpolator.rs:881-935: pyramid -> coarse flow -> warp):
         `n_frames` consecutive RGBA8 frames on the device -> the `n_frames - 1` in-between frames at `time_t` at `d_mid`, warped +
         blended with each pair's flow (FMA-mode warp), and the flows themselves at `d_flows` if that is not 0
-        (nus_flow_interpolate_device_stream)."""
+        (nus_flow_interpolate_device_stream).  flow_format "f16": the flows between estimator and warp (and at `d_flows`) as
+        Rg16Float, the reference's live layout -- the f32 flow rounded to nearest even, read as such by the warp."""
+        fmt = {"f32": 0, "f16": 1}.get(flow_format)
+        if fmt is None:
+            raise ValueError("flow_format must be 'f32' or 'f16'")
         self._check(self._lib.nus_flow_interpolate_device_stream(self._h, d_frames, n_frames, width, height, self.levels,
                                                                  self.coarse_iterations, self.refine_iterations, self.lambda_,
-                                                                 float(time_t), d_flows or None, d_mid, stream or None))
+                                                                 float(time_t), fmt, d_flows or None, d_mid, stream or None))

@@ -165,7 +165,7 @@ class FramePipeline:
 
     def step_motion(self, frames, flows, mid, up_real, up_mid, stream: int = 0, levels: int = 3,
                     coarse_iterations: int = 50, refine_iterations: int = 10, flow_mode: str = "exact", pipelined: bool = False,
-                    chunk: int = 100, fused_warp: bool = False) -> None:
+                    chunk: int = 100, fused_warp: bool = False, flow_format: str = "f32") -> None:
         """Motion-compensated variant of `step`: a dense flow per pair from the
         pyramid + Horn-Schunck front end into `flows` ((n_units, h, w, 2) float32), then warp + blend with it
         instead of the reference's zero flow.  The flows are estimated pair by pair (several launches per pair,
@@ -193,13 +193,15 @@ class FramePipeline:
         fb = self.frame_bytes
         if flows is None and not fused_warp:
             raise ValueError("step_motion: flows=None needs fused_warp=True")
+        if flow_format != "f32" and not fused_warp:
+            raise ValueError("step_motion: flow_format 'f16' (the Rg16Float hand-off) needs fused_warp=True")
         fl0 = 0 if flows is None else flows.data_ptr()
 
         def flow_and_warp(k0, m, st):  # units [k0, k0 + m): their flows (if wanted) and in-between frames
             a = base + k0 * fb
-            fl = fl0 + k0 * fb * 2 if fl0 else 0
+            fl = fl0 + k0 * fb * (1 if flow_format == "f16" else 2) if fl0 else 0
             if fused_warp:
-                self._flow.interpolate_device_stream(a, m + 1, self.w, self.h, self.t, mid.data_ptr() + k0 * fb, fl, st)
+                self._flow.interpolate_device_stream(a, m + 1, self.w, self.h, self.t, mid.data_ptr() + k0 * fb, fl, st, flow_format)
                 return False
             self._flow.estimate_device_stream(a, m + 1, self.w, self.h, fl, st)
             return True  # the warp is still to do

@@ -482,3 +482,58 @@ def test_step_motion_fused_warp_equals_separate_stages(nsc, oracle_mod, in_kerne
             assert torch.equal(got_flows, flows), kw
     with pytest.raises(ValueError, match="fused_warp"):
         pipe.step_motion(frames, None, *want, s)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("w,h,levels,coarse,refine", [(160, 96, 3, 20, 10), (333, 262, 3, 7, 7), (64, 64, 1, 13, 0), (130, 70, 2, 4, 0),
+                                                       (960, 540, 3, 10, 10)])
+def test_interpolate_device_stream_rg16float_handoff(nsc, oracle_mod, w, h, levels, coarse, refine):
+    """flow_format NUS_FLOW_F16: the flows between estimator and warp as Rg16Float, the reference's live layout
+    (wgpu_interpolator.rs:276).  In every kernel mode the f16 flows are the f32 flows of the same estimator rounded to nearest even
+    (bit for bit: torch's float16 cast is the same rounding), stored at d_flows or not; the in-between frames are bit for bit the
+    FMA-mode warp kernel's on those f16 flows; and against the f32 hand-off they differ by at most 1 LSB."""
+    import torch
+
+    dev = torch.device("cuda:0")
+    n_frames, t = 4, 0.5
+    frames = np.stack([_smooth(w, h, 0.9 * k) for k in range(n_frames)])
+    d_frames = torch.from_numpy(frames).to(dev)
+    s = torch.cuda.current_stream().cuda_stream
+    fb = w * h * 4
+    it = nsc.WgpuFrameInterpolator()
+    it.set_mode("fma")
+    for mode, tiled in (("fast", 3), ("fast", 1), ("exact", 1), ("exact", 0)):
+        fe = nsc.FlowEstimator(levels=levels, coarse_iterations=coarse, refine_iterations=refine)
+        fe.set_mode(mode)
+        fe.set_tiled(tiled)
+        flows32 = torch.empty((n_frames - 1, h, w, 2), dtype=torch.float32, device=dev)
+        mid32 = torch.empty((n_frames - 1, h, w, 4), dtype=torch.uint8, device=dev)
+        fe.interpolate_device_stream(d_frames.data_ptr(), n_frames, w, h, t, mid32.data_ptr(), flows32.data_ptr(), s)
+        want16 = flows32.to(torch.float16)
+        it.set_flow_format("f16")
+        want_mid = torch.zeros_like(mid32)
+        it.interpolate_device(d_frames.data_ptr(), fb, d_frames.data_ptr() + fb, fb, want16.data_ptr(), w, h, t, want_mid.data_ptr(),
+                              n_frames - 1, s)
+        it.set_flow_format("f32")
+        torch.cuda.synchronize()
+        for with_flows in (True, False):
+            # the f16 flows take 4 bytes per cell: a guard of the same size again behind them must stay untouched (a kernel that
+            # stored 2 x f32 per cell into the caller's buffer would run over it -- the first version of this path did, round 5)
+            cells = (n_frames - 1) * h * w
+            buf = torch.full((2 * cells, 2), 1234.0, dtype=torch.float16, device=dev)
+            got16 = buf[:cells].view(n_frames - 1, h, w, 2)
+            got16.fill_(float("nan"))
+            got_mid = torch.full_like(mid32, 0xAB)
+            fe.interpolate_device_stream(d_frames.data_ptr(), n_frames, w, h, t, got_mid.data_ptr(), got16.data_ptr() if with_flows else 0,
+                                         s, "f16")
+            torch.cuda.synchronize()
+            assert bool((buf[cells:] == 1234.0).all()), (mode, tiled, with_flows, "wrote past the f16 flows")
+            assert torch.equal(got_mid, want_mid), (mode, tiled, with_flows)
+            if with_flows:
+                assert torch.equal(got16.view(torch.int16), want16.view(torch.int16)), (mode, tiled)
+            else:
+                assert bool(torch.isnan(got16).all())
+        d = (want_mid.to(torch.int16) - mid32.to(torch.int16)).abs()
+        assert int(d.max()) <= 1, (mode, tiled)
+    with pytest.raises(ValueError):
+        fe.interpolate_device_stream(d_frames.data_ptr(), n_frames, w, h, t, mid32.data_ptr(), 0, s, "bf16")

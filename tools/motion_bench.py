@@ -52,3 +52,6 @@ for rnd in range(2):
         for c in chunks:
             print(f"motion step, {n} units, {what}, pipelined, chunks of {c:3d}: {timed(fused_warp=True, pipelined=True, chunk=c):7.2f} ms", flush=True)
     os.environ.pop("NUS_HS_FUSED_WARP", None)
+    for c in chunks:
+        print(f"motion step, {n} units, one call, Rg16Float between estimator and warp, pipelined, chunks of {c:3d}: "
+              f"{timed(fused_warp=True, pipelined=True, chunk=c, flow_format='f16'):7.2f} ms", flush=True)
