@@ -332,6 +332,23 @@ void HipUpscaler::choose_resize_variant(bool x2)
         variant_ = Variant::LanczosR43RegWin;
         return;
     }
+    // x5/4, x6/5, x5/3, x5/2: P output rows per group of Q input rows, every output's weights from the tables in frame form
+    // (nus_k_lanczos_pq.hip); the ratios are not exact in f32, so nothing about the weights is assumed beyond their frames
+    pq_p_ = pq_q_ = 0;
+    if (!force_general_ && ow_ > iw_ && addressable && iw_ >= 32 && ih_ >= 12) {
+        uint64_t a = ow_, b = iw_;
+        while (b) {
+            const uint64_t r = a % b;
+            a = b, b = r;
+        }
+        const uint32_t P = (uint32_t)(ow_ / a), Q = (uint32_t)(iw_ / a);
+        if (lanczos_pq_supported(P, Q) && (uint64_t)oh_ * Q == (uint64_t)ih_ * P && (iw_ % Q) == 0 && (ih_ % Q) == 0 &&
+            lanczos_pq_phase_frame(tx_, P, Q, wx6_) && lanczos_pq_phase_frame(ty_, P, Q, wy6_)) {
+            pq_p_ = P, pq_q_ = Q;
+            variant_ = Variant::LanczosPqRegWin;
+            return;
+        }
+    }
     if (force_per_pixel_) return;
     // vertical down-scaling: stream the input rows through 7 accumulator slots, if the windows allow it and a
     // 64-column output segment's footprint fits 5 columns per lane
@@ -512,6 +529,10 @@ int HipUpscaler::upload_tables()
                     dt_.lz_wxs_left[q][j] = wx6_[(size_t)q * 6 + j];
                     dt_.lz_wxs_right[q][j] = wx6_[((size_t)ow_ - 8 + q) * 6 + j];
                 }
+            UP(wy6_, lz_wy6);
+        }
+        if (variant_ == Variant::LanczosPqRegWin) {
+            UP(wx6_, lz_wx6);
             UP(wy6_, lz_wy6);
         }
         if (variant_ == Variant::LanczosR32RegWin) {
@@ -710,6 +731,19 @@ int HipUpscaler::enqueue(const uint8_t *d_in, uint8_t *d_out, uint32_t n_frames,
         }
         e = launch_lanczos_r43(L, dt_, lanczos_exact_, th);
         if (e == hipSuccess) e = launch_lanczos_r43_edges(L, dt_, lanczos_exact_); // border columns
+        break;
+    }
+    case Variant::LanczosPqRegWin: {
+        uint32_t th = rows_per_wave_;
+        if (th == 0) { // as at x4/3: 12 - 36 rows per wave on a batch, equal row blocks
+            const uint32_t cols = lanczos_pq_strip_cols(pq_p_, pq_q_);
+            const uint64_t rows_total = (uint64_t)ih_ * ((iw_ + cols - 1) / cols) * n_frames;
+            uint64_t t = rows_total / 12288;
+            t = t < 12 ? 12 : (t > 36 ? 36 : t);
+            const uint64_t blocks = (ih_ + t - 1) / t;
+            th = (uint32_t)(((ih_ + blocks - 1) / blocks + pq_q_ - 1) / pq_q_ * pq_q_);
+        }
+        e = launch_lanczos_pq(L, dt_, lanczos_exact_, pq_p_, pq_q_, th);
         break;
     }
     case Variant::LanczosR32RegWin: {

@@ -253,6 +253,7 @@ private:
     Variant variant_ = Variant::NearestTable;
     AxisTables tx_, ty_;
     std::vector<float> wy6_, wx6_;
+    uint32_t pq_p_ = 0, pq_q_ = 0; // Variant::LanczosPqRegWin: the factor P / Q
     std::vector<uint32_t> xs_cls_x_, xs_cls_y_; // x3: weight class per input index, and the classes' weights
     std::vector<float> xs_wcls_x_, xs_wcls_y_;
     DeviceTables dt_;

@@ -397,6 +397,7 @@ const char *variant_name(Variant v){
     case Variant::LanczosXsRegWin: return "lanczos3_xs_regwin";
     case Variant::LanczosR32RegWin: return "lanczos3_r32_regwin";
     case Variant::LanczosR43RegWin: return "lanczos3_r43_regwin";
+    case Variant::LanczosPqRegWin: return "lanczos3_pq_regwin";
     case Variant::FsrEasu: return "fsr1_easu_tile";
     case Variant::FsrRcas: return "fsr1_rcas_rows";
     case Variant::Fsr1Fused: return "fsr1_easu_rcas_fused_lds";

@@ -26,6 +26,7 @@ struct DeviceTables {
     const int32_t *lz_down_done = nullptr;
     // lanczos x2 fast path: per-output-row weights in the 6-tap phase frame [oh][6]
     const float *lz_wy6 = nullptr;
+    const float *lz_wx6 = nullptr; // P/Q kernel: per-output-column weights in the 6-tap phase frame [ow][6]
     float lz_wxe[6] = {0}, lz_wxo[6] = {0}; // interior horizontal weights, even / odd outputs
     float lz_wx_left[48] = {0}, lz_wx_right[48] = {0}; // phase-frame weights of the 8 edge outputs per side
     float lz_wxs[4][6] = {{0}};                        // integer factors x3 / x4: interior weights per phase
@@ -87,6 +88,7 @@ enum class Variant : int {
     LanczosXsRegWin,  // exact x3 / x4, same design with S output rows per input row
     LanczosR32RegWin, // exact x3/2, same design: three output rows per pair of input rows
     LanczosR43RegWin, // exact x4/3, same design: four output rows per group of three input rows
+    LanczosPqRegWin,  // x5/4, x6/5, x5/3, x5/2, same design: P output rows per group of Q input rows, weights from the tables
     FsrEasu,          // FSR1-style EASU alone (any scale)
     FsrRcas,          // FSR1-style RCAS alone (same size in and out)
     Fsr1Fused,        // EASU tile (+1 px halo) in LDS, RCAS out of it
@@ -150,6 +152,11 @@ hipError_t launch_lanczos_r32_edges(const UpscaleLaunch &L, const DeviceTables &
 // follow it with launch_lanczos_r43_edges(L, T, exact).
 hipError_t launch_lanczos_r43(const UpscaleLaunch &L, const DeviceTables &T, bool exact, uint32_t rows_per_wave);
 hipError_t launch_lanczos_r43_edges(const UpscaleLaunch &L, const DeviceTables &T, bool exact);
+// x5/4, x6/5, x5/3, x5/2 (Q ow == P iw, Q oh == P ih, iw % Q == 0, ih % Q == 0; T.lz_wx6 / T.lz_wy6: the tables in frame form,
+// nus_tables.hpp: lanczos_pq_phase_frame).  Writes every output column: no edge pass.
+bool lanczos_pq_supported(uint32_t P, uint32_t Q);
+uint32_t lanczos_pq_strip_cols(uint32_t P, uint32_t Q); // input columns per wave
+hipError_t launch_lanczos_pq(const UpscaleLaunch &L, const DeviceTables &T, bool exact, uint32_t P, uint32_t Q, uint32_t rows_per_wave);
 // FSR1-style passes (fsr.rs:24-260).  mode 0: EASU, 1: RCAS (iw == ow, ih == oh), 2: EASU then RCAS fused.
 // fast: EASU in FAST arithmetic where the LDS source tile applies (nus_k_fsr.hip; option "fsr_fast")
 hipError_t launch_fsr1(const UpscaleLaunch &L, int mode, float easu_sharpness, float rcas_sharpness, bool fast = false);

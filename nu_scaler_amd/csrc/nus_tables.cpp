@@ -261,6 +261,27 @@ bool lanczos_r43_interior_uniform(const AxisTables &t, const std::vector<float> 
     return true;
 }
 
+bool lanczos_pq_phase_frame(const AxisTables &t, uint32_t P, uint32_t Q, std::vector<float> &w6)
+{
+    if (P <= Q || Q == 0 || (t.in_n % Q) != 0 || (uint64_t)Q * t.out_n != (uint64_t)P * t.in_n || t.lz_max_taps < 0) return false;
+    w6.assign((size_t)t.out_n * 6, 0.0f);
+    for (uint32_t o = 0; o < t.out_n; ++o) {
+        const int64_t p = o % P, num = (2 * p + 1) * (int64_t)Q - 7 * (int64_t)P, den = 2 * (int64_t)P;
+        const int64_t fl = num >= 0 ? num / den : -((-num + den - 1) / den);
+        const int32_t base = (int32_t)((int64_t)Q * (o / P) + fl + 1);
+        const float *ws = t.lz_w.data() + (size_t)o * kResizeMaxTaps;
+        for (uint32_t i = 0; i < t.lz_ntaps[o]; ++i) {
+            const int32_t j = t.lz_left[o] + (int32_t)i - base;
+            if (j < 0 || j >= 6) {
+                if (ws[i] != 0.0f) return false;
+                continue;
+            }
+            w6[(size_t)o * 6 + j] = ws[i];
+        }
+    }
+    return true;
+}
+
 bool lanczos_r32_weight_classes(const AxisTables &t, const std::vector<float> &w6, bool lanes, std::vector<uint32_t> &cls,
                                 std::vector<float> &classes)
 {

@@ -84,6 +84,10 @@ bool lanczos_r32_weight_classes(const AxisTables &t, const std::vector<float> &w
 bool lanczos_r43_phase_frame(const AxisTables &t, std::vector<float> &w6);
 // True when every output of the groups 2 .. in_n / 3 - 3 has the weights of output 8 + p of its phase.
 bool lanczos_r43_interior_uniform(const AxisTables &t, const std::vector<float> &w6);
+// Small rational factors P/Q (Q out_n == P in_n, P > Q; nus_k_lanczos_pq.hip): output o = P g + p belongs to the input group
+// g = (Q g .. Q g + Q - 1), frame start Q g + floor(((2 p + 1) Q - 7 P) / 2 P) + 1.  No uniformity is asked for: the kernel takes
+// every output's weights from w6.  False when a non-zero weight falls outside the frame.
+bool lanczos_pq_phase_frame(const AxisTables &t, uint32_t P, uint32_t Q, std::vector<float> &w6);
 
 // Down-scaling stream tables for k_resize_down (7 accumulator slots, slot of output y = y % 7).
 // rows: (in_n + extra) x 8 words -- per input row the f32 weight it carries in each slot (0 where the row is

@@ -1029,6 +1029,8 @@ def test_resize_register_window_variant(nsc, oracle_mod, alg, filt, dims):
     want = oracle_mod.resize(img, ow, oh, filt)
     # exact x3, x3/2 and x4/3 have their own kernels: ask for this one
     gen = {"force_general": 1} if (ow, oh) == (3 * w, 3 * h) or (2 * ow, 2 * oh) == (3 * w, 3 * h) or (3 * ow, 3 * oh) == (4 * w, 4 * h) else {}
+    if any((q * ow, q * oh) == (p * w, p * h) for p, q in ((5, 4), (6, 5), (5, 3), (5, 2), (7, 2))):
+        gen = {"force_general": 1}  # (these factors have the P/Q kernel since round 5)
     got_e, u = _up(nsc, alg, img, ow, oh, lanczos_mode="exact", options=dict(gen))
     assert u.kernel_variant == "resize_regwin_lds"
     assert np.array_equal(got_e, want)
@@ -1138,6 +1140,82 @@ def test_resize_factor_four_thirds_register_window(nsc, oracle_mod, alg, filt, s
     ub.initialize(w, h, ow, oh)
     got_b = np.frombuffer(ub.upscale(_bgra(img).tobytes()), np.uint8).reshape(oh, ow, 4)
     assert np.array_equal(got_b, want)
+
+
+_PQ_SIZES = {(5, 4): [(32, 12), (64, 36), (248, 40), (252, 20), (496, 24), (1000, 48), (1116, 32)],
+             (6, 5): [(35, 15), (310, 20), (315, 25), (620, 30), (1000, 50)],
+             (5, 3): [(33, 12), (186, 21), (189, 33), (372, 18), (960, 54)],
+             (5, 2): [(32, 12), (120, 20), (122, 14), (244, 30), (600, 40)],
+             (7, 2): [(32, 12), (120, 20), (126, 14), (242, 30)]}
+
+
+@pytest.mark.parametrize("alg,filt", [("lanczos3", 0), ("bicubic", 1), ("triangle", 2)])
+@pytest.mark.parametrize("factor,size", [(f, sz) for f, sizes in _PQ_SIZES.items() for sz in sizes])
+def test_resize_small_rational_factor_register_window(nsc, oracle_mod, alg, filt, factor, size):
+    """x5/4, x6/5, x5/3, x5/2, x7/2 (the reference's scale slider moves in tenths: nu_scaler_py/nu_scaler/main.py:457-459): P output rows per
+    group of Q input rows, one lane per group of Q columns, every output's weights from the tables in frame form (the ratios are not
+    exact in f32).  EXACT mode: 0 differences from the oracle; FMA mode: the bits of the general kernel; borders, strip joints
+    (widths around the strips of 62 Q / 60 Q columns), any number of rows per wave, opaque rows, BGRA input."""
+    P, Q = factor
+    w, h = size
+    ow, oh = P * w // Q, P * h // Q
+    img = oracle_mod.gen_noise(w, h, 97)
+    want = oracle_mod.resize(img, ow, oh, filt)
+    got_e, u = _up(nsc, alg, img, ow, oh, lanczos_mode="exact")
+    assert u.kernel_variant == "lanczos3_pq_regwin"
+    assert np.array_equal(got_e, want)
+    got_f, uf = _up(nsc, alg, img, ow, oh)
+    assert uf.kernel_variant == "lanczos3_pq_regwin"
+    assert _maxdiff(got_f, want) <= 1 and (got_f != want).mean() < (5e-2 if alg == "triangle" else 1e-3)
+    ref_f, ug = _up(nsc, alg, img, ow, oh, options={"force_general": 1})
+    assert ug.kernel_variant in ("resize_regwin_lds", "resize_rows_lds") and np.array_equal(got_f, ref_f)
+    for th in (Q, 7, 24, 40):
+        out_t, _ = _up(nsc, alg, img, ow, oh, lanczos_mode="exact", options={"rows_per_wave": th})
+        assert np.array_equal(out_t, want), th
+    opq = img.copy()
+    opq[..., 3] = 255
+    got_o, _ = _up(nsc, alg, opq, ow, oh)
+    ref_o, _ = _up(nsc, alg, opq, ow, oh, options={"force_general": 1})
+    assert np.array_equal(got_o, ref_o) and (got_o[..., 3] == 255).all()
+    band = opq.copy()
+    band[h // 2:h // 2 + 2, :, 3] = img[h // 2:h // 2 + 2, :, 3]
+    got_m, _ = _up(nsc, alg, band, ow, oh)
+    ref_m, _ = _up(nsc, alg, band, ow, oh, options={"force_general": 1})
+    assert np.array_equal(got_m, ref_m)
+    ub = nsc.PyWgpuUpscaler("quality", alg, lanczos_mode="exact")
+    ub.set_input_format("bgra")
+    ub.initialize(w, h, ow, oh)
+    got_b = np.frombuffer(ub.upscale(_bgra(img).tobytes()), np.uint8).reshape(oh, ow, 4)
+    assert np.array_equal(got_b, want)
+
+
+@pytest.mark.parametrize("dims", [((1536, 864), (1920, 1080)), ((1600, 900), (1920, 1080)), ((1920, 1080), (3200, 1800)),
+                                  ((1536, 864), (3840, 2160))])
+def test_small_rational_factors_at_full_size(nsc, oracle_mod, dims):
+    """864p / 900p -> 1080p, 1080p -> 1800p, 864p -> 4K at full size: both modes against the oracle, and a device batch against the
+    single frames."""
+    import torch
+
+    (w, h), (ow, oh) = dims
+    img = oracle_mod.gen_noise(w, h, 98)
+    want = oracle_mod.lanczos3(img, ow, oh, threads=0)
+    got_f, uf = _up(nsc, "lanczos3", img, ow, oh)
+    assert uf.kernel_variant == "lanczos3_pq_regwin"
+    d = np.abs(got_f.astype(np.int16) - want.astype(np.int16))
+    assert d.max() <= 1 and (d > 0).mean() < 1e-3
+    got_e, ue = _up(nsc, "lanczos3", img, ow, oh, lanczos_mode="exact")
+    assert ue.kernel_variant == "lanczos3_pq_regwin" and np.array_equal(got_e, want)
+    frames = np.stack([img, img[::-1].copy(), oracle_mod.gen_gradient(w, h)])
+    d_in = torch.from_numpy(frames).cuda()
+    d_out = torch.empty((3, oh, ow, 4), dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    uf.upscale_device(d_in.data_ptr(), d_out.data_ptr(), 3)
+    torch.cuda.synchronize()
+    got_b = d_out.cpu().numpy()
+    assert np.array_equal(got_b[0], got_f)
+    for k in (1, 2):
+        single, _ = _up(nsc, "lanczos3", frames[k], ow, oh)
+        assert np.array_equal(got_b[k], single), k
 
 
 def test_1080p_to_1440p_takes_the_four_thirds_kernel(nsc, oracle_mod):
@@ -1282,7 +1360,7 @@ def test_resize_window_opaque_rows(nsc, oracle_mod, alg, dims):
     v = base.copy(); v[..., 3] = 255; v[h // 3, w // 2, 3] = 254; v[0, 0, 3] = 0; v[h - 1, w - 1, 3] = 9; variants["pixels"] = v
     for name, img in variants.items():
         got, u = _up(nsc, alg, img, ow, oh)
-        assert u.kernel_variant in ("resize_regwin_lds", "lanczos3_xs_regwin", "lanczos3_r32_regwin", "lanczos3_r43_regwin")
+        assert u.kernel_variant in ("resize_regwin_lds", "lanczos3_xs_regwin", "lanczos3_r32_regwin", "lanczos3_r43_regwin", "lanczos3_pq_regwin")
         ref, ur = _up(nsc, alg, img, ow, oh, options={"force_general": 1, "force_rows": 1})
         assert ur.kernel_variant == "resize_rows_lds"
         assert np.array_equal(got, ref), name

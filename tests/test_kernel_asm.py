@@ -91,6 +91,40 @@ def test_lanczos_r43_row_ring_waits():
         assert "global_load_lds_dwordx3" in body
 
 
+def test_lanczos_pq_row_ring_waits():
+    """k_lanczos3_pq (x5/4, x6/5, x5/3, x5/2, x7/2): Q row requests of 1 - 2 LDS-DMA pieces and P rows of 2 stores per step, one
+    hand-counted wait per row request, tight on every path of every instantiation -- both store forms of a row (turned through LDS
+    into contiguous 16-byte pieces; direct) issue the same number of instructions, and the compiler has merged no two stores of a row
+    into one (it does where an instruction for the sum exists: the direct form stores 4 P bytes as 16-byte pieces and ONE smaller
+    piece for that reason)."""
+    import check_hidden_loads as chk
+
+    out = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-x", "hip",
+                          "--cuda-device-only", "-S", "-I", CSRC, "-I", os.path.join(ROOT, "include"), "-o", "-",
+                          os.path.join(CSRC, "nus_k_lanczos_pq.hip")], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr
+    bodies = list(chk.kernel_bodies(out.stdout, "k_lanczos3_pqIL"))
+    assert len(bodies) == 10, [n for n, _ in bodies]  # EXACT, FMA x five factors
+    # (P, Q) -> unrolled steps, LDS-DMA pieces per row request
+    shape = {(5, 4): (3, 1), (6, 5): (6, 2), (5, 3): (2, 1), (5, 2): (3, 2), (7, 2): (3, 2)}
+    for name, body in bodies:
+        import re
+
+        m = re.search(r"ILb[01]ELi(\d)ELi(\d)E", name)
+        P, Q = int(m.group(1)), int(m.group(2))
+        steps, pieces = shape[(P, Q)]
+        # the loop has no lane-divergent control flow (its stores are range-checked, its branches scalar); the two store forms of a row
+        # sit behind a scalar branch whose else-side the compiler skips with an `s_cbranch_execnz` used as "branch always"
+        loop = body[body.index("nus-wait back=0"):]  # everything behind the drain at the loop's entry
+        assert "s_cbranch_scc" in loop and "v_cmpx" not in loop and "saveexec" not in loop, name
+        r = chk.check(body, execnz_taken=True)
+        assert r["errors"] == [], (name, r["errors"][:3])
+        assert r["compiler_vmcnt_waits_in_loops"] == [], (name, r["compiler_vmcnt_waits_in_loops"][:3])
+        assert r["waits_not_tight"] == {}, (name, r["waits_not_tight"])
+        # Q requests per unrolled step + the first Q of a block; one hand wait per row request + the drain at loop entry
+        assert r["requests"] == (steps + 1) * Q * pieces and r["hand_waits"] == steps * Q + 1, (name, r["requests"], r["hand_waits"])
+
+
 def test_lanczos_xs_row_ring_waits():
     """k_lanczos3_xs (x3, x4: 720p / 540p -> 4K): one row request and S x S stores per step, one hand-counted wait per step,
     tight on every path of all six instantiations, no other vmcnt wait inside the loop."""

@@ -17,7 +17,10 @@ cannot express:
      conditional block (follows from 1 being tight on every path).
 
 Branches on EXEC == 0 only skip regions no lane executes and are not followed; the kernel's requests
-and waits sit in wave-uniform control flow.
+and waits sit in wave-uniform control flow.  `s_cbranch_execnz` is followed both ways by default; with
+execnz_taken=True it counts as always taken -- for kernels whose loop has no lane-divergent control flow at
+all (EXEC never changes there), where the compiler uses it as its "branch always" around the else-side of a
+SCALAR branch (k_lanczos3_pq: the two store forms of a row behind `s_cbranch_scc`).
 
 usage: check_hidden_loads.py file.s [kernel-name-substring]   (exit status 0 = ok)
 Used by tests/test_kernel_asm.py on a fresh `hipcc -S` of the kernel source.
@@ -40,6 +43,7 @@ def parse(body):
     """-> list of dicts: kind in dma / wait / cwait / vmem / label / branch / end (other instructions dropped)."""
     ins = []
     in_asm = False
+    far = None  # target of a long branch being assembled (s_getpc_b64; s_add_u32 .., (.LBBx_y-.Lpost_getpcN)..; s_setpc_b64)
     for raw in body.split("\n"):
         line = raw.strip()
         if not line:
@@ -60,6 +64,13 @@ def parse(body):
         code = code.strip()
         if not code:
             continue
+        m = re.search(r"\((\.LBB\d+_\d+)-\.Lpost_getpc\d+\)", code)
+        if m:
+            far = m.group(1)
+        if code.startswith("s_setpc_b64") and far:  # a branch beyond the reach of s_branch's 16-bit offset (kernels over 128 KiB)
+            ins.append({"kind": "branch", "text": "s_branch " + far, "target": far, "cond": False, "never": False})
+            far = None
+            continue
         if code.startswith("global_load_lds") or (code.startswith("buffer_load") and code.endswith(" lds")):
             ins.append({"kind": "dma", "text": code, "hidden": in_asm})
         elif code.startswith("s_waitcnt") and "vmcnt" in code:
@@ -79,7 +90,7 @@ def parse(body):
     return ins
 
 
-def blocks_of(ins):
+def blocks_of(ins, execnz_taken=False):
     """Basic blocks as (start, end_exclusive) and successor lists."""
     starts = {0}
     for i, x in enumerate(ins):
@@ -98,7 +109,8 @@ def blocks_of(ins):
         if last["kind"] == "branch":
             if not last["never"]:
                 out.append(index_of[label_at[last["target"]]])
-            if last["cond"] and e < len(ins):
+            always = execnz_taken and last["text"].startswith("s_cbranch_execnz")
+            if last["cond"] and e < len(ins) and not always:
                 out.append(index_of[e])
         elif last["kind"] != "end" and e < len(ins):
             out.append(index_of[e])
@@ -106,7 +118,7 @@ def blocks_of(ins):
     return blocks, succ
 
 
-def check(body, cap=CAP, kmax=KMAX):
+def check(body, cap=CAP, kmax=KMAX, execnz_taken=False):
     """cap / kmax: ages are counted up to `cap` and the `kmax` most recent requests are tracked.  The defaults suit kernels whose
     loop issues the same instructions on every path (k_lanczos3_x2: the tightness of every wait is checked too); a kernel with
     stores on some paths only (k_resize_down: its waits are deliberately conservative) needs just "never fewer than N" and gets a
@@ -116,7 +128,7 @@ def check(body, cap=CAP, kmax=KMAX):
     if not ins:
         return {"errors": ["empty kernel body"], "requests": 0, "hand_waits": 0, "compiler_vmcnt_waits_in_loops": [],
                 "waits_not_tight": {}}
-    blocks, succ = blocks_of(ins)
+    blocks, succ = blocks_of(ins, execnz_taken)
     errors, seen = set(), {}
     fresh = (CAP,) * KMAX  # ages[j] = vector memory instructions issued after the (j+1)-th most recent request
     state_in = [None] * len(blocks)  # set of age vectors (one per distinct path history)
@@ -184,7 +196,7 @@ def main():
     bad = found = 0
     for name, body in kernel_bodies(asm, want):
         found += 1
-        r = check(body)
+        r = check(body, execnz_taken="k_lanczos3_pq" in name)
         print(f"{name}: {r['requests']} hidden row requests, {r['hand_waits']} hand-counted waits, "
               f"{len(r['compiler_vmcnt_waits_in_loops'])} compiler vmcnt waits in loops, "
               f"{len(r['waits_not_tight'])} waits not tight, {len(r['errors'])} error(s)")
