@@ -57,14 +57,23 @@ __device__ __forceinline__ uint32_t fsr_pack(float r, float g, float b)
     return o;
 }
 
-// EASU direction weight wx of FsrDirA + fsr.rs:131-133, from the four unpacked neighbours
+// EASU direction weight wx of FsrDirA + fsr.rs:131-133, from the four unpacked neighbours.  The shader's five divisions in three
+// IEEE ones: x / 3.0 through the constant's reciprocal and dxr / len, dyr / len through one reciprocal of len (div_by_recip: the
+// correctly rounded quotient; a len whose mantissa is all ones takes the plain divisions) -- the same bits as before.
 __device__ __forceinline__ float fsr_dir_wx(const float3 up, const float3 dn, const float3 lf, const float3 rt)
 {
-    const float vgx = (fabsf(up.x - dn.x) + fabsf(up.y - dn.y) + fabsf(up.z - dn.z)) / 3.0f;
-    const float vgy = (fabsf(lf.x - rt.x) + fabsf(lf.y - rt.y) + fabsf(lf.z - rt.z)) / 3.0f;
+    const float third = 1.0f / 3.0f;
+    const float vgx = div_by_recip(fabsf(up.x - dn.x) + fabsf(up.y - dn.y) + fabsf(up.z - dn.z), 3.0f, third);
+    const float vgy = div_by_recip(fabsf(lf.x - rt.x) + fabsf(lf.y - rt.y) + fabsf(lf.z - rt.z), 3.0f, third);
     const float dxr = vgx + 0.0001f, dyr = vgy + 0.0001f;
     const float len = sqrtf(dxr * dxr + dyr * dyr);
-    const float dirx = dxr / len, diry = dyr / len;
+    float dirx, diry;
+    if ((__float_as_uint(len) & 0x007fffffu) == 0x007fffffu) {
+        dirx = dxr / len, diry = dyr / len;
+    } else {
+        const float z = 1.0f / len;
+        dirx = div_by_recip(dxr, len, z), diry = div_by_recip(dyr, len, z);
+    }
     return fabsf(dirx) / (fabsf(dirx) + fabsf(diry));
 }
 
@@ -153,8 +162,19 @@ __device__ __forceinline__ void fsr_build_lut(float2 *lut, int tid)
         } else if (i == 2 * kFsrLutScale) {
             e = make_float2(fsr_cubic_piece(2.0f, false), -1.0e9f); // d == 2 exactly keeps its weight; anything beyond goes negative
         }
-        lut[i] = e;
+        // HALF the weight (exact: a power of two; the sums and the quotient scale with it, bit for bit): FsrCubic runs from 0 to 2, half
+        // of it fits the [0, 1] clamp that the interpolating FMA applies for free (fsr_lut_weight)
+        lut[i] = make_float2(0.5f * e.x, 0.5f * e.y);
     }
+}
+
+// half the FsrCubic weight of a tap at scaled distance ds = 128 d >= 0: cell = floor(ds), linear inside the cell, clamped to [0, 1]
+// (the clamp is the FMA's output modifier; it is what makes everything beyond d = 2 zero).  v_fract_f32 + v_cvt_u32_f32 + the address
+// shift + ds_read_b64 + v_fma_f32 clamp.
+__device__ __forceinline__ float fsr_lut_weight(const float2 *lut, float ds)
+{
+    const float2 e = lut[(uint32_t)ds];
+    return __builtin_amdgcn_fmed3f(__builtin_fmaf(__builtin_amdgcn_fractf(ds), e.y, e.x), 0.0f, 1.0f);
 }
 
 template <typename TAP>
@@ -175,15 +195,14 @@ __device__ __forceinline__ uint32_t fsr_easu_taps_fast(TAP &&tap, const float2 *
         for (int x = 0; x < 4; ++x) {
             const float4 c = tap(x, y);
             const float ds = fabsf(X[x] + Y[y]); // 128 d, d as the shader rounds it
-            const float2 e = lut[(int)ds];
-            const float wgt = fmaxf(__builtin_fmaf(ds - floorf(ds), e.y, e.x), 0.0f);
+            const float wgt = fsr_lut_weight(lut, ds);
             sr = __builtin_fmaf(c.x, wgt, sr);
             sg = __builtin_fmaf(c.y, wgt, sg);
             sb = __builtin_fmaf(c.z, wgt, sb);
             sw += wgt;
         }
     }
-    const float den = fmaxf(sw, 0.0001f);
+    const float den = fmaxf(sw, 0.5f * 0.0001f); // (sw is half the shader's sum)
     float z = __builtin_amdgcn_rcpf(den);
     z = z * __builtin_fmaf(-den, z, 2.0f); // one Newton step: relative error ~1e-7
     sr *= z, sg *= z, sb *= z;
@@ -228,15 +247,16 @@ __device__ __forceinline__ void fsr_easu_quad_fast(TAP &&tap, const float2 *lut,
             for (int y = 0; y < 4; ++y)
 #pragma unroll
                 for (int x = 0; x < 4; ++x) {
+                    // (tap (3, 3) never counts at x2 -- 2.75 or 2.25 texels away on both axes --, but leaving it out breaks the pairing of
+                    // the taps' packed adds: 38.3 -> 41.1 us, measured)
                     const float ds = fabsf(X[a][x] + Y[b][y]);
-                    const float2 e = lut[(int)ds];
-                    const float wgt = fmaxf(__builtin_fmaf(ds - floorf(ds), e.y, e.x), 0.0f);
+                    const float wgt = fsr_lut_weight(lut, ds);
                     sr = __builtin_fmaf(c[y * 4 + x].x, wgt, sr);
                     sg = __builtin_fmaf(c[y * 4 + x].y, wgt, sg);
                     sb = __builtin_fmaf(c[y * 4 + x].z, wgt, sb);
                     sw += wgt;
                 }
-            const float den = fmaxf(sw, 0.0001f);
+            const float den = fmaxf(sw, 0.5f * 0.0001f); // (sw is half the shader's sum)
             float z = __builtin_amdgcn_rcpf(den);
             z = z * __builtin_fmaf(-den, z, 2.0f);
             sr *= z, sg *= z, sb *= z;
@@ -500,27 +520,29 @@ __global__ __launch_bounds__(256) void k_fsr_rcas_walk(const RcasWalkArgs A)
 #pragma unroll
     for (int k = 0; k < 4; ++k) cc[k] = clampi(c0 + k, 0, A.w - 1);
     const bool vec_ok = VEC && c0 >= 0 && c0 + 4 <= A.w; // one 16-byte load
-    auto load_row = [&](int y) -> RcasRow {
-        const uint32_t *row = in + (size_t)clampi(y, 0, A.h - 1) * A.w;
+    struct RawRow {
         uint32_t px[4];
+    };
+    auto load_raw = [&](int y) -> RawRow {
+        const uint32_t *row = in + (size_t)clampi(y, 0, A.h - 1) * A.w;
+        RawRow r;
         if (vec_ok) {
             const uint4 v = *reinterpret_cast<const uint4 *>(row + c0);
-            px[0] = v.x, px[1] = v.y, px[2] = v.z, px[3] = v.w;
+            r.px[0] = v.x, r.px[1] = v.y, r.px[2] = v.z, r.px[3] = v.w;
         } else {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) px[k] = row[cc[k]];
+            for (int k = 0; k < 4; ++k) r.px[k] = row[cc[k]];
         }
-        RcasRow r;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) r.p[k] = fsr_rcas_tap(swz(px[k], A.sel));
         return r;
+    };
+    auto unpack = [&](const RawRow &raw, RcasRow &r) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) r.p[k] = fsr_rcas_tap(swz(raw.px[k], A.sel));
     };
     // The lane's left / right neighbours in a row are its own pixels or the neighbouring lane's last / first.  The image's first and
     // last column need nothing special: positions outside the image were LOADED clamped, so the position left of column 0 (the halo
     // lane's last pixel) holds column 0 itself and the position right of column w - 1 holds column w - 1 -- the shader's clamp.
-    RcasRow top = load_row(y0 - 1), ctr = load_row(y0), bot = load_row(y0 + 1);
-    for (int y = y0; y < y1; ++y) {
-        const RcasRow nxt = load_row(y + 2); // in flight during this row
+    auto filter_row = [&](int y, const RcasRow &top, const RcasRow &ctr, const RcasRow &bot) {
         const float4 from_left = dpp_up4(ctr.p[3]), from_right = dpp_down4(ctr.p[0]);
         uint32_t o[4];
 #pragma unroll
@@ -539,7 +561,26 @@ __global__ __launch_bounds__(256) void k_fsr_rcas_walk(const RcasWalkArgs A)
                     if (c0 + k < A.w) dst[k] = o[k];
             }
         }
-        top = ctr, ctr = bot, bot = nxt;
+    };
+    // three rows in registers, their roles (top / centre / bottom) rotating with the row: three rows of the walk unrolled, the incoming
+    // row -- requested before the row's arithmetic, in flight during it -- unpacked straight into the registers of the row that has
+    // just left the window (round 5, first form: `top = ctr, ctr = bot, bot = nxt`, 36 register moves per row)
+    RcasRow r0, r1, r2;
+    unpack(load_raw(y0 - 1), r0);
+    unpack(load_raw(y0), r1);
+    unpack(load_raw(y0 + 1), r2);
+    for (int y = y0; y < y1; y += 3) {
+        RawRow nxt = load_raw(y + 2);
+        filter_row(y, r0, r1, r2);
+        unpack(nxt, r0);
+        if (y + 1 >= y1) break;
+        nxt = load_raw(y + 3);
+        filter_row(y + 1, r1, r2, r0);
+        unpack(nxt, r1);
+        if (y + 2 >= y1) break;
+        nxt = load_raw(y + 4);
+        filter_row(y + 2, r2, r0, r1);
+        unpack(nxt, r2);
     }
 }
 
