@@ -413,7 +413,7 @@ void HipUpscaler::choose_resize_variant(bool x2)
 // on a pixel ((o % P) Q % P == 0).
 bool HipUpscaler::ratio_shape(bool bilinear) const
 {
-    static const uint32_t kRatios[][2] = {{3, 2}, {4, 3}, {3, 1}, {4, 1}, {2, 1}};
+    static const uint32_t kRatios[][2] = {{3, 2}, {4, 3}, {3, 1}, {4, 1}, {2, 1}, {5, 4}, {6, 5}, {5, 3}, {5, 2}, {7, 2}};
     for (const auto &r : kRatios) {
         const uint32_t P = r[0], Q = r[1];
         if ((uint64_t)ow_ * Q != (uint64_t)iw_ * P || (uint64_t)oh_ * Q != (uint64_t)ih_ * P || iw_ % Q != 0 || ih_ % Q != 0) continue;

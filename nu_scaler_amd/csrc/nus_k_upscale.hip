@@ -436,7 +436,7 @@ hipError_t launch_nearest_table(const UpscaleLaunch &L, const DeviceTables &T)
 // (P, Q) of the fixed-ratio nearest / bilinear kernels for this launch, or false
 static bool ratio_of(const UpscaleLaunch &L, uint32_t &P, uint32_t &Q)
 {
-    static const uint32_t kRatios[][2] = {{3, 2}, {4, 3}, {3, 1}, {4, 1}, {2, 1}};
+    static const uint32_t kRatios[][2] = {{3, 2}, {4, 3}, {3, 1}, {4, 1}, {2, 1}, {5, 4}, {6, 5}, {5, 3}, {5, 2}, {7, 2}};
     for (const auto &r : kRatios)
         if ((uint64_t)L.ow * r[1] == (uint64_t)L.iw * r[0] && (uint64_t)L.oh * r[1] == (uint64_t)L.ih * r[0] && L.iw % r[1] == 0 &&
             L.ih % r[1] == 0) {
@@ -451,6 +451,11 @@ static bool ratio_of(const UpscaleLaunch &L, uint32_t &P, uint32_t &Q)
     else if (P == 4 && Q == 3) { CALL(4, 3); }   \
     else if (P == 3 && Q == 1) { CALL(3, 1); }   \
     else if (P == 4 && Q == 1) { CALL(4, 1); }   \
+    else if (P == 5 && Q == 4) { CALL(5, 4); }   \
+    else if (P == 6 && Q == 5) { CALL(6, 5); }   \
+    else if (P == 5 && Q == 3) { CALL(5, 3); }   \
+    else if (P == 5 && Q == 2) { CALL(5, 2); }   \
+    else if (P == 7 && Q == 2) { CALL(7, 2); }   \
     else { CALL(2, 1); }
 
 hipError_t launch_nearest_ratio(const UpscaleLaunch &L)

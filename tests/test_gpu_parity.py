@@ -81,15 +81,15 @@ def test_bilinear_general_bit_exact(nsc, oracle_mod, dims):
     assert np.array_equal(out_w, oracle_mod.bilinear_wgsl(img, ow, oh))
 
 
-@pytest.mark.parametrize("ratio", [(3, 2), (4, 3), (3, 1), (4, 1), (2, 1)])
+@pytest.mark.parametrize("ratio", [(3, 2), (4, 3), (3, 1), (4, 1), (2, 1), (5, 4), (6, 5), (5, 3), (5, 2), (7, 2)])
 @pytest.mark.parametrize("groups", [(1, 1), (2, 3), (32, 18), (33, 19), (63, 10), (64, 11), (65, 12), (250, 20), (640, 360)])
 def test_nearest_and_bilinear_fixed_ratio_kernels(nsc, oracle_mod, ratio, groups):
-    """The small rational factors (x3/2 -- the scale the reference's benchmark entry points default to --, x4/3, x3, x4) have
-    their own nearest and CPU-form bilinear kernels (one input group per lane, P outputs; row groups): bit-exact against the
+    """The small rational factors (x3/2 -- the scale the reference's benchmark entry points default to --, x4/3, x3, x4 and, since
+    round 5, the P/Q resize kernel's x5/4, x6/5, x5/3, x5/2, x7/2) have their own nearest and CPU-form bilinear kernels (one input group per lane, P outputs; row groups): bit-exact against the
     oracle and the table-driven kernels; the WGSL form keeps the table kernel."""
     P, Q = ratio
     w, h = Q * groups[0], Q * groups[1]
-    if (P, Q) == (4, 1) and w * h > 100000:
+    if (P, Q) in ((4, 1), (7, 2)) and w * h > 100000:
         pytest.skip("covered by the smaller sizes")
     if (P, Q) == (2, 1):
         if w % 4 == 0:

@@ -18,6 +18,8 @@ s = torch.cuda.current_stream().cuda_stream
 alg_bytes = (iw * ih + ow * oh) * 4
 for alg in ("nearest", "bilinear", "lanczos3", "bicubic"):
     u = nsc.PyWgpuUpscaler("quality", alg)
+    if os.environ.get("NUS_GENERAL"):
+        u.set_option("force_general", 1)  # the table-driven kernels even where a fixed-factor kernel exists
     u.initialize(iw, ih, ow, oh)
     for _ in range(2):
         u.upscale_device(frames.data_ptr(), out.data_ptr(), n, s)
