@@ -23,6 +23,9 @@
  *                     (imageops::resize = vertical_sample into f32, then horizontal_sample
  *                     with clamp + round-to-nearest) from its documentation/source as
  *                     remembered; it could not be verified against the crate here.
+ *                     Cross-checked (not pinned) against two witnesses that share no code with
+ *                     it: the float64 definition and Pillow's float resampler, equal on every
+ *                     sample up to rounding ties (tests/test_oracle_witness.py).
  *
  *   orc_fsr_easu /    PARITY UNPINNED.  Restates the WGSL EASU / RCAS shaders in
  *   orc_fsr_rcas      nu_scaler_core/src/upscale/fsr.rs:24-260, which the reference never runs

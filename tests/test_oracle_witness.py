@@ -108,6 +108,37 @@ def test_oracle_resize_agrees_with_the_float64_witness(oracle_mod, name, dims):
 
 
 @pytest.mark.parametrize("name", ["lanczos3", "catmullrom", "triangle"])
+@pytest.mark.parametrize("dims", [((64, 36), (128, 72)), ((480, 270), (960, 540)), ((320, 180), (480, 270)), ((300, 225), (400, 300)),
+                                  ((320, 180), (400, 225)), ((300, 180), (360, 216)), ((300, 180), (500, 300)), ((200, 150), (333, 251)),
+                                  ((256, 128), (128, 64)), ((300, 157), (150, 78)), ((97, 61), (240, 133)), ((1, 1), (4, 4)),
+                                  ((5, 3), (12, 7)), ((7, 5), (7, 5))])
+def test_oracle_resize_agrees_with_pillows_float_resampler(oracle_mod, name, dims):
+    """A THIRD-PARTY witness (round 5): Pillow's resampler on 32-bit float images (`Image.resize` in mode "F": the same filter
+    definitions -- Lanczos a = 3, the Keys cubic a = -1/2, the triangle --, the same half-pixel sample centres, support stretched on
+    down-scaling, windows cut and renormalised at the border; coefficients in double, horizontal pass first, nothing rounded or
+    clipped between the passes).  The oracle's bytes must equal round(clamp(.)) of Pillow's floats on every sample, up to samples whose
+    float value lies within 0.02 of a rounding tie (f32 sums against double ones; where in / out is not an f32 number, e.g. x5/3, the
+    crate's f32 sample centre is off by ~1e-4 px, which is most of that).  Pillow's 8-bit path is NOT the witness: it rounds
+    and clips the intermediate image to u8, which moves overshooting samples by tens of counts for the kernels with negative lobes.
+    This is what a maintainer of the reference would get from a widely used resampler of the same definition; it is not the `image`
+    crate, so the rows stay "parity unpinned" in the brief's sense."""
+    Image = pytest.importorskip("PIL.Image")
+    flt = {"lanczos3": Image.LANCZOS, "catmullrom": Image.BICUBIC, "triangle": Image.BILINEAR}[name]
+    (w, h), (ow, oh) = dims
+    for img in (oracle_mod.gen_noise(w, h, 5), oracle_mod.gen_gradient(w, h)):
+        got = oracle_mod.resize(img, ow, oh, FILTERS[name][0]).astype(np.int32)
+        f = np.stack([np.asarray(Image.fromarray(img[..., c].astype(np.float32), "F").resize((ow, oh), flt), dtype=np.float64)
+                      for c in range(4)], -1)
+        f = np.clip(f, 0.0, 255.0)
+        want = np.floor(f + 0.5).astype(np.int32)  # f32::round: half away from zero
+        d = np.abs(got - want)
+        assert d.max() <= 1, (name, dims, int(d.max()))
+        tie = np.abs((f + 0.5) - np.round(f + 0.5))
+        assert (tie[d > 0] < 2e-2).all(), (name, dims, float(tie[d > 0].max()))
+        assert (d > 0).mean() < 0.2  # (a gradient resized by a dyadic factor puts many samples ON a tie)
+
+
+@pytest.mark.parametrize("name", ["lanczos3", "catmullrom", "triangle"])
 def test_oracle_weights_match_the_closed_form(oracle_mod, name):
     for n_in, n_out in ((1920, 3840), (1080, 2160), (1280, 3840), (540, 2160), (515, 172), (50, 127)):
         left, ntaps, w = oracle_mod.resize_axis(n_in, n_out, FILTERS[name][0], 32)
