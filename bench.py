@@ -752,6 +752,9 @@ def worker(args):
     device_index = args.force_device if args.force_device >= 0 else local_rank
     nccl = args.backend == "nccl"
     _install_crash_reports()
+    from nu_scaler_amd import hostmem
+
+    hostmem.route_tensor_cpu_through_pinned_staging()  # the output check's device-to-host copies: never the runtime's pageable path
 
     # The rank's whole set-up is the product's (nu_scaler_amd.stream.ShardedStream; `python -m nu_scaler_amd.cli stream` runs the
     # same object): onto the CPUs of its GPU's NUMA node BEFORE the first HIP call, host threads sized to the rank's CPU share,

@@ -35,6 +35,11 @@ def pytest_sessionstart(session):
     from helpers import abort_trace
 
     abort_trace.install(2)
+    # Tensor.cpu() of frame-sized CUDA tensors through pinned staging: the HIP runtime's device-to-host copy into PAGEABLE memory is
+    # what died twice in long test sessions (ROCr: "Write access to a read-only page" at a brk-heap address; nu_scaler_amd/hostmem.py)
+    from nu_scaler_amd import hostmem
+
+    hostmem.route_tensor_cpu_through_pinned_staging()
 
 
 @pytest.fixture(scope="session")
