@@ -417,6 +417,9 @@ bool HipUpscaler::ratio_shape(bool bilinear) const
     for (const auto &r : kRatios) {
         const uint32_t P = r[0], Q = r[1];
         if ((uint64_t)ow_ * Q != (uint64_t)iw_ * P || (uint64_t)oh_ * Q != (uint64_t)ih_ * P || iw_ % Q != 0 || ih_ % Q != 0) continue;
+        // bilinear at x5/2 and x7/2: five / seven lerped outputs from two input columns per lane leave the fixed-ratio kernel behind the
+        // table kernel (864p -> 4K: 11.7 against 10.6 us per frame, profiles/r05_nearest_bilinear_pq_ratios.txt); nearest gains at every factor
+        if (bilinear && Q == 2 && P >= 5) return false;
         bool ok = true;
         for (const AxisTables *t : {&tx_, &ty_})
             for (uint32_t o = 0; ok && o < t->out_n; ++o) {
