@@ -342,7 +342,7 @@ void HipUpscaler::choose_resize_variant(bool x2)
             a = b, b = r;
         }
         const uint32_t P = (uint32_t)(ow_ / a), Q = (uint32_t)(iw_ / a);
-        if (lanczos_pq_supported(P, Q) && (uint64_t)oh_ * Q == (uint64_t)ih_ * P && (iw_ % Q) == 0 && (ih_ % Q) == 0 &&
+        if (lanczos_pq_supported(P, Q) && (uint64_t)oh_ * Q == (uint64_t)ih_ * P && (iw_ % Q) == 0 && (ih_ % Q) == 0 && (ow_ % 4) == 0 &&
             lanczos_pq_phase_frame(tx_, P, Q, wx6_) && lanczos_pq_phase_frame(ty_, P, Q, wy6_)) {
             pq_p_ = P, pq_q_ = Q;
             variant_ = Variant::LanczosPqRegWin;

@@ -1,5 +1,5 @@
 // nus_k_lanczos_pq.hip -- separable resize (Lanczos-3, Catmull-Rom, Triangle) at the small rational factors P/Q that have no kernel
-// of their own: 5/4 (864p -> 1080p), 6/5 (900p -> 1080p), 5/3 (1080p -> 1800p), 5/2 (864p -> 2160p), 7/2 -- tenths of the reference's
+// of their own: 5/4 (864p -> 1080p), 6/5 (900p -> 1080p), 7/5, 8/5, 5/3 (1080p -> 1800p), 5/2 (864p -> 2160p), 7/2 -- tenths of the reference's
 // scale slider (nu_scaler_py/nu_scaler/main.py:457-459) and the common capture sizes.  The register-window design of
 // nus_k_lanczos_x2.hip / nus_k_lanczos_r43.hip with P output rows per GROUP of Q input rows and P horizontal phases per group of Q
 // input columns.  image-0.24.9 imageops::resize as called at Nu_scale/src/upscale/common.rs:243-251 (vertical pass into f32, then
@@ -15,8 +15,8 @@
 // loads issued one row ahead.  Same numbers, same order of operations as the general kernels: EXACT mode is bit-identical to them
 // and to the oracle; the border columns and rows need no kernel of their own (their renormalised weights are table entries too).
 //
-// A lane owns ONE group of columns: 4 Q bytes in, its P outputs are 4 P contiguous bytes out -- consecutive lanes store consecutive
-// pieces.  Vertically a wave walks the input rows in groups of Q: phase p reads the window rows Q g + s(p) .. + 5; where s(p + 1) =
+// A lane owns ONE group of columns: 4 Q bytes in, P outputs; a wave's output row is turned round in LDS and stored as contiguous
+// 16-byte pieces (ow % 4 == 0, host-checked; other widths keep the any-scale kernels).  Vertically a wave walks the input rows in groups of Q: phase p reads the window rows Q g + s(p) .. + 5; where s(p + 1) =
 // s(p) + 1 the window moves one row between the two phases (compile-time pattern, Q moves per group).
 #ifndef NUS_STORE_AUX
 #define NUS_STORE_AUX 2 // nt: see nus_k_lanczos_x2.hip
@@ -57,12 +57,10 @@ struct PqGeom {
     // row requests: LDS-DMA pieces of 4 / 3 / 1 dwords (gfx950 has no 2-dword form)
     static constexpr int REQ = Q == 2 ? 2 : (Q == 5 ? 2 : 1);
     static constexpr uint32_t kSlotBytes = Q == 2 ? 512 : (Q == 5 ? 1280 : 1024);
-    // stores per output row, two forms with the same number of instructions (the hand-counted waits count them).  Turned: the row's
-    // NS P dwords go through LDS and leave as SP instructions of 64 contiguous 16-byte pieces (ow % 4 == 0).  Direct: 4 P bytes per
-    // lane as 16-byte pieces and ONE of 12 / 8 / 4 bytes (the compiler merges adjacent buffer stores where an instruction exists for
-    // the sum).
+    // stores per output row: the row's NS P dwords go through LDS and leave as SP instructions of 64 contiguous 16-byte pieces
+    // (the host requires ow % 4 == 0, so that every strip's row segment is a whole number of pieces)
     static constexpr int SP = (NS * P + 255) / 256;
-    static_assert(SP == (P / 4) + ((P % 4) != 0 ? 1 : 0) && (NS * P) % 4 == 0, "both store forms issue SP instructions per row");
+    static_assert((NS * P) % 4 == 0 && SP <= 2, "whole 16-byte pieces, at most two per lane");
     static constexpr int V = P * SP + Q * REQ; // vector memory instructions per step
     static constexpr int UNROLL = Q == 3 ? 2 : (Q == 5 ? 6 : 3); // steps until the 6-slot window is back at slot 0
     static constexpr bool ok()
@@ -85,7 +83,6 @@ struct LanczosPqArgs {
     uint32_t sel;     // input channel order
     uint32_t iw, ih, oh;
     uint32_t nstrips, nrowblocks, th; // th: input rows per wave, a multiple of Q
-    uint32_t turn;                    // 1: rows leave through LDS as contiguous 16-byte pieces (ow % 4 == 0)
     size_t in_frame_bytes, out_frame_bytes;
 };
 
@@ -211,14 +208,13 @@ __device__ __forceinline__ void pq_gather(const float (&v)[Q], float (&e)[PqGeom
 // exchange (columns -3 .. R around the lane's first one) and the horizontal pass of the lane's P output pixels (output p reads the
 // columns s(p) .. s(p) + 5), convert + pack; SP stores.  Channel by channel so that only Q vertical sums are live.
 // Where a wave's output row goes (cf. RowStore in nus_k_lanczos_x2.hip: store instructions whose lanes write 16 bytes at a 4 P-byte
-// stride leave every line partly written until the row's other instruction fills it in, at almost twice the cost of whole pieces).
+// stride leave every line partly written until the row's other instruction fills it in, at almost twice the cost of whole pieces --
+// measured here too: each lane storing its own 4 P bytes was 13 ... 40 % slower on opaque frames).
 struct PqStore {
     uint32_t *stage;      // this wave's 64 P dwords of LDS
     uint32_t widx;        // where this lane's P dwords go: storing lane k of the strip at k P, halo lanes behind them
-    uint32_t off[2];      // turned: byte offset inside an output row of the lane's 16-byte piece of store 0 / 1 (2^31: none)
-    uint32_t lane_off;    // direct: byte offset inside an output row of the lane's 4 P bytes (2^31: none)
+    uint32_t off[2];      // byte offset inside an output row of the lane's 16-byte piece of store 0 / 1 (2^31: none)
     int lane;
-    uint32_t turn;        // wave-uniform (a scalar register: the branch on it must be a scalar branch)
 };
 
 template <bool EXACT, int P, int Q, int B>
@@ -250,43 +246,21 @@ __device__ __forceinline__ void pq_row(const float (&win)[6][4 * Q], const float
             o[p] = pack_u8<EXACT>(a, c, o[p]);
         }
     }
-    // range-checked buffer stores: a lane that must not write has its offset beyond num_records (see the x2 kernel), so the
-    // stores issue on every path and for every lane -- the hand-counted waits rely on exactly SP per output row
+    // The row through LDS (instructions of one wave execute in order there: no barrier between the lanes' writes and the reads of
+    // other lanes' dwords), then range-checked buffer stores: a lane without a piece has its offset beyond num_records (see the x2
+    // kernel), so the stores issue on every path and for every lane -- the hand-counted waits rely on exactly SP per output row
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-    static_assert(G::SP <= 2, "two pieces per lane");
-    if (__builtin_amdgcn_readfirstlane(st.turn) != 0u) {
-        // LDS instructions of one wave execute in order: no barrier between the lanes' writes and the reads of other lanes' dwords
-        uint32_t *mine = st.stage + st.widx;
+    uint32_t *mine = st.stage + st.widx;
 #pragma unroll
-        for (int i = 0; i < P; ++i) mine[i] = o[i];
-        __builtin_amdgcn_wave_barrier(); // (compiler only)
-        u32x4 piece[G::SP];
+    for (int i = 0; i < P; ++i) mine[i] = o[i];
+    __builtin_amdgcn_wave_barrier(); // (compiler only)
+    u32x4 piece[G::SP];
 #pragma unroll
-        for (int k = 0; k < G::SP; ++k) piece[k] = *reinterpret_cast<const u32x4 *>(st.stage + 4 * (st.lane + kWave * k));
-        __builtin_amdgcn_wave_barrier();
+    for (int k = 0; k < G::SP; ++k) piece[k] = *reinterpret_cast<const u32x4 *>(st.stage + 4 * (st.lane + kWave * k));
+    __builtin_amdgcn_wave_barrier();
 #pragma unroll
-        for (int k = 0; k < G::SP; ++k)
-            __builtin_amdgcn_raw_buffer_store_b128(piece[k], rs, st.off[k] == 0x80000000u ? st.off[k] : row_off + st.off[k], 0, NUS_STORE_AUX);
-    } else {
-        const uint32_t off = st.lane_off == 0x80000000u ? st.lane_off : row_off + st.lane_off;
-        int at = 0;
-#pragma unroll
-        for (int k = 0; k < P / 4; ++k, at += 4) {
-            const u32x4 q = {o[at], o[at + 1], o[at + 2], o[at + 3]};
-            __builtin_amdgcn_raw_buffer_store_b128(q, rs, off + 4u * (uint32_t)at, 0, NUS_STORE_AUX);
-        }
-        if constexpr (P % 4 == 3) {
-            typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
-            const u32x3 q = {o[at], o[at + 1], o[at + 2]};
-            __builtin_amdgcn_raw_buffer_store_b96(q, rs, off + 4u * (uint32_t)at, 0, NUS_STORE_AUX);
-        } else if constexpr (P % 4 == 2) {
-            const u32x2 q = {o[at], o[at + 1]};
-            __builtin_amdgcn_raw_buffer_store_b64(q, rs, off + 4u * (uint32_t)at, 0, NUS_STORE_AUX);
-        } else if constexpr (P % 4 == 1) {
-            __builtin_amdgcn_raw_buffer_store_b32(o[at], rs, off + 4u * (uint32_t)at, 0, NUS_STORE_AUX);
-        }
-    }
+    for (int k = 0; k < G::SP; ++k)
+        __builtin_amdgcn_raw_buffer_store_b128(piece[k], rs, st.off[k] == 0x80000000u ? st.off[k] : row_off + st.off[k], 0, NUS_STORE_AUX);
 }
 
 struct PqStepCtx {
@@ -409,10 +383,7 @@ __global__ __launch_bounds__(256) void k_lanczos3_pq(const LanczosPqArgs A)
     const uint8_t *src = A.in + (size_t)frame * A.in_frame_bytes;
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
         A.out + (size_t)frame * A.out_frame_bytes, 0, (uint32_t)A.out_frame_bytes, 0x00020000);
-    // the lane's P output pixels are stored unless it is a halo lane or its group lies outside the image
-    const bool stores = lane >= G::HS && lane < kWave - G::HS && c + Q <= (int)A.iw;
-    const uint32_t lane_off = stores ? (uint32_t)(c / Q) * (4u * P) : 0x80000000u; // byte offset of its 4 P bytes inside an output row
-    const uint32_t in_off = (uint32_t)cl * 4u;                                     // and of its 4 Q bytes inside an input row
+    const uint32_t in_off = (uint32_t)cl * 4u; // byte offset of the lane's 4 Q bytes inside an input row
     const int r0 = (int)(rb * A.th); // a multiple of Q
     const int r_end = (r0 + (int)A.th) < (int)A.ih ? (r0 + (int)A.th) : (int)A.ih;
     const int rmax = (int)A.ih - 1;
@@ -467,9 +438,7 @@ __global__ __launch_bounds__(256) void k_lanczos3_pq(const LanczosPqArgs A)
     PqStore st;
     st.stage = &lds_stage[w][0];
     st.widx = (uint32_t)((lane - G::HS) & (kWave - 1)) * P;
-    st.lane_off = lane_off;
     st.lane = lane;
-    st.turn = A.turn;
     {
         // the strip's row segment: dwords strip NS P .. of the output row, as many as lie inside the image (a multiple of 4)
         const uint32_t first = strip * (uint32_t)(G::NS * P), row_dwords = A.iw / Q * P;
@@ -499,7 +468,6 @@ hipError_t launch_pq(const UpscaleLaunch &L, const DeviceTables &T, bool exact, 
     A.nstrips = cdiv(L.iw, (uint32_t)G::kStripCols);
     A.th = rows_per_wave ? (rows_per_wave + Q - 1) / Q * Q : 24;
     A.nrowblocks = cdiv(L.ih, A.th);
-    A.turn = (L.ow % 4) == 0 ? 1u : 0u;
     A.in_frame_bytes = launch_in_frame_bytes(L);
     A.out_frame_bytes = (size_t)L.ow * L.oh * 4;
     const uint32_t nwaves = A.nstrips * A.nrowblocks;
@@ -518,7 +486,8 @@ hipError_t launch_pq(const UpscaleLaunch &L, const DeviceTables &T, bool exact, 
 
 bool lanczos_pq_supported(uint32_t P, uint32_t Q)
 {
-    return (P == 5 && Q == 4) || (P == 6 && Q == 5) || (P == 5 && Q == 3) || (P == 5 && Q == 2) || (P == 7 && Q == 2);
+    return (P == 5 && Q == 4) || (P == 6 && Q == 5) || (P == 5 && Q == 3) || (P == 5 && Q == 2) || (P == 7 && Q == 2) ||
+           (P == 7 && Q == 5) || (P == 8 && Q == 5);
 }
 
 uint32_t lanczos_pq_strip_cols(uint32_t P, uint32_t Q)
@@ -528,18 +497,22 @@ uint32_t lanczos_pq_strip_cols(uint32_t P, uint32_t Q)
     if (P == 5 && Q == 3) return PqGeom<5, 3>::kStripCols;
     if (P == 5 && Q == 2) return PqGeom<5, 2>::kStripCols;
     if (P == 7 && Q == 2) return PqGeom<7, 2>::kStripCols;
+    if (P == 7 && Q == 5) return PqGeom<7, 5>::kStripCols;
+    if (P == 8 && Q == 5) return PqGeom<8, 5>::kStripCols;
     return 0;
 }
 
 hipError_t launch_lanczos_pq(const UpscaleLaunch &L, const DeviceTables &T, bool exact, uint32_t P, uint32_t Q, uint32_t rows_per_wave)
 {
     if (!lanczos_pq_supported(P, Q) || (uint64_t)L.ow * Q != (uint64_t)L.iw * P || (uint64_t)L.oh * Q != (uint64_t)L.ih * P ||
-        (L.iw % Q) != 0 || (L.ih % Q) != 0 || !T.lz_wx6 || !T.lz_wy6)
+        (L.iw % Q) != 0 || (L.ih % Q) != 0 || (L.ow % 4) != 0 || !T.lz_wx6 || !T.lz_wy6)
         return hipErrorInvalidValue;
     if (P == 5 && Q == 4) return launch_pq<5, 4>(L, T, exact, rows_per_wave);
     if (P == 6 && Q == 5) return launch_pq<6, 5>(L, T, exact, rows_per_wave);
     if (P == 5 && Q == 3) return launch_pq<5, 3>(L, T, exact, rows_per_wave);
     if (P == 7 && Q == 2) return launch_pq<7, 2>(L, T, exact, rows_per_wave);
+    if (P == 7 && Q == 5) return launch_pq<7, 5>(L, T, exact, rows_per_wave);
+    if (P == 8 && Q == 5) return launch_pq<8, 5>(L, T, exact, rows_per_wave);
     return launch_pq<5, 2>(L, T, exact, rows_per_wave);
 }
 

@@ -152,7 +152,7 @@ hipError_t launch_lanczos_r32_edges(const UpscaleLaunch &L, const DeviceTables &
 // follow it with launch_lanczos_r43_edges(L, T, exact).
 hipError_t launch_lanczos_r43(const UpscaleLaunch &L, const DeviceTables &T, bool exact, uint32_t rows_per_wave);
 hipError_t launch_lanczos_r43_edges(const UpscaleLaunch &L, const DeviceTables &T, bool exact);
-// x5/4, x6/5, x5/3, x5/2 (Q ow == P iw, Q oh == P ih, iw % Q == 0, ih % Q == 0; T.lz_wx6 / T.lz_wy6: the tables in frame form,
+// x5/4, x6/5, x7/5, x8/5, x5/3, x5/2, x7/2 (Q ow == P iw, Q oh == P ih, iw % Q == 0, ih % Q == 0, ow % 4 == 0; T.lz_wx6 / T.lz_wy6: the tables in frame form,
 // nus_tables.hpp: lanczos_pq_phase_frame).  Writes every output column: no edge pass.
 bool lanczos_pq_supported(uint32_t P, uint32_t Q);
 uint32_t lanczos_pq_strip_cols(uint32_t P, uint32_t Q); // input columns per wave
