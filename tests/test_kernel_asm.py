@@ -92,18 +92,25 @@ def test_lanczos_r43_row_ring_waits():
 
 
 def test_lanczos_pq_row_ring_waits():
-    """k_lanczos3_pq (x5/4, x6/5, x5/3, x5/2, x7/2): Q row requests of 1 - 2 LDS-DMA pieces and P rows of 2 stores per step, one
-    hand-counted wait per row request, tight on every path of every instantiation -- both store forms of a row (turned through LDS
-    into contiguous 16-byte pieces; direct) issue the same number of instructions, and the compiler has merged no two stores of a row
-    into one (it does where an instruction for the sum exists: the direct form stores 4 P bytes as 16-byte pieces and ONE smaller
-    piece for that reason)."""
+    """k_lanczos3_pq (x5/4, x6/5, x7/5, x8/5, x5/3, x5/2, x7/2): Q row requests of 1 - 2 LDS-DMA pieces and P rows of 2 stores per step,
+    one hand-counted wait per row request, tight on every path of every instantiation.  (The kernel's first form also had a second,
+    direct way of storing a row behind a scalar branch: there the checker caught the compiler merging an 8- and a 4-byte store into
+    one 12-byte instruction at P = 7, and later a branch pair turned into a flag that no control-flow analysis can follow -- the
+    reason there is one store form now.)"""
     import check_hidden_loads as chk
 
-    out = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-x", "hip",
-                          "--cuda-device-only", "-S", "-I", CSRC, "-I", os.path.join(ROOT, "include"), "-o", "-",
-                          os.path.join(CSRC, "nus_k_lanczos_pq.hip")], capture_output=True, text=True, timeout=1500)
-    assert out.returncode == 0, out.stderr
-    bodies = list(chk.kernel_bodies(out.stdout, "k_lanczos3_pqIL"))
+    from concurrent.futures import ThreadPoolExecutor
+
+    def asm_of(unit):  # (the Q = 5 factors are translation units of their own: a minute of compile time each)
+        out = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-x", "hip",
+                              "--cuda-device-only", "-S", "-I", CSRC, "-I", os.path.join(ROOT, "include"), "-o", "-",
+                              os.path.join(CSRC, unit)], capture_output=True, text=True, timeout=1500)
+        assert out.returncode == 0, out.stderr
+        return out.stdout
+
+    units = ["nus_k_lanczos_pq.hip", "nus_k_lanczos_pq_65.hip", "nus_k_lanczos_pq_75.hip", "nus_k_lanczos_pq_85.hip"]
+    with ThreadPoolExecutor(4) as pool:
+        bodies = [b for text in pool.map(asm_of, units) for b in chk.kernel_bodies(text, "k_lanczos3_pqIL")]
     assert len(bodies) == 14, [n for n, _ in bodies]  # EXACT, FMA x seven factors
     # (P, Q) -> unrolled steps, LDS-DMA pieces per row request
     shape = {(5, 4): (3, 1), (6, 5): (6, 2), (5, 3): (2, 1), (5, 2): (3, 2), (7, 2): (3, 2), (7, 5): (6, 2), (8, 5): (6, 2)}
@@ -113,8 +120,7 @@ def test_lanczos_pq_row_ring_waits():
         m = re.search(r"ILb[01]ELi(\d)ELi(\d)E", name)
         P, Q = int(m.group(1)), int(m.group(2))
         steps, pieces = shape[(P, Q)]
-        # the loop has no lane-divergent control flow (its stores are range-checked, its branches scalar); the two store forms of a row
-        # sit behind a scalar branch whose else-side the compiler skips with an `s_cbranch_execnz` used as "branch always"
+        # the loop has no lane-divergent control flow (its stores are range-checked, its branches scalar)
         loop = body[body.index("nus-wait back=0"):]  # everything behind the drain at the loop's entry
         assert "s_cbranch_scc" in loop and "v_cmpx" not in loop and "saveexec" not in loop, name
         r = chk.check(body, execnz_taken=True)
