@@ -25,6 +25,9 @@ echo "quick bench done"
 python3 tools/warp_bench.py 2>&1 | grep -v amdgpu.ids > $out/warp_kernel.txt
 python3 tools/host_path_bench.py 2>&1 | grep -v amdgpu.ids > $out/host_path.txt
 python3 tools/general_sweep.py > $out/general_scale_sweep.txt 2>&1
+python3 tools/pq_bench.py 128 2>&1 | grep -v amdgpu.ids > $out/pq_factors_vs_any_scale_kernel.txt
+bash tools/ratio_bench.sh 2>&1 | grep -v amdgpu.ids > $out/nearest_bilinear_pq_ratios.txt
+python3 tools/rcas_bench.py 60 2>&1 | grep -v amdgpu.ids > $out/rcas_rows.txt
 echo "sweep done"
 bash tools/flow_prof.sh > $out/flow_kernels.txt 2>&1
 cp $(find $root/gpurun_out/flowprof -name "*kernel_stats.csv" | head -1) $out/flow_front_end_kernel_stats.csv 2>/dev/null
