@@ -413,13 +413,14 @@ void HipUpscaler::choose_resize_variant(bool x2)
 // on a pixel ((o % P) Q % P == 0).
 bool HipUpscaler::ratio_shape(bool bilinear) const
 {
-    static const uint32_t kRatios[][2] = {{3, 2}, {4, 3}, {3, 1}, {4, 1}, {2, 1}, {5, 4}, {6, 5}, {5, 3}, {5, 2}, {7, 2}};
-    for (const auto &r : kRatios) {
+    static const uint32_t kRatios[][2] = {{3, 2}, {4, 3}, {3, 1}, {4, 1}, {2, 1}, {5, 4}, {6, 5}, {5, 3}, {5, 2}, {7, 2}, {7, 5}};
+    for (const auto &r : kRatios) { // (x8/5: the table kernel is the faster one for nearest too, 5.6 against 5.8 us at 1080p)
         const uint32_t P = r[0], Q = r[1];
         if ((uint64_t)ow_ * Q != (uint64_t)iw_ * P || (uint64_t)oh_ * Q != (uint64_t)ih_ * P || iw_ % Q != 0 || ih_ % Q != 0) continue;
         // bilinear at x5/2 and x7/2: five / seven lerped outputs from two input columns per lane leave the fixed-ratio kernel behind the
         // table kernel (864p -> 4K: 11.7 against 10.6 us per frame, profiles/r05_nearest_bilinear_pq_ratios.txt); nearest gains at every factor
         if (bilinear && Q == 2 && P >= 5) return false;
+        if (bilinear && Q == 5 && P >= 7) return false; // (nearest only: Q + 1 lerped rows of 4 P values do not fit the registers)
         bool ok = true;
         for (const AxisTables *t : {&tx_, &ty_})
             for (uint32_t o = 0; ok && o < t->out_n; ++o) {

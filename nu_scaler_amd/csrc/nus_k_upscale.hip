@@ -436,7 +436,8 @@ hipError_t launch_nearest_table(const UpscaleLaunch &L, const DeviceTables &T)
 // (P, Q) of the fixed-ratio nearest / bilinear kernels for this launch, or false
 static bool ratio_of(const UpscaleLaunch &L, uint32_t &P, uint32_t &Q)
 {
-    static const uint32_t kRatios[][2] = {{3, 2}, {4, 3}, {3, 1}, {4, 1}, {2, 1}, {5, 4}, {6, 5}, {5, 3}, {5, 2}, {7, 2}};
+    // ({7, 5}: nearest only -- the bilinear kernel's Q + 1 lerped rows of 4 P values do not fit the registers there; the host asks accordingly)
+    static const uint32_t kRatios[][2] = {{3, 2}, {4, 3}, {3, 1}, {4, 1}, {2, 1}, {5, 4}, {6, 5}, {5, 3}, {5, 2}, {7, 2}, {7, 5}};
     for (const auto &r : kRatios)
         if ((uint64_t)L.ow * r[1] == (uint64_t)L.iw * r[0] && (uint64_t)L.oh * r[1] == (uint64_t)L.ih * r[0] && L.iw % r[1] == 0 &&
             L.ih % r[1] == 0) {
@@ -468,7 +469,8 @@ hipError_t launch_nearest_ratio(const UpscaleLaunch &L)
 #define NUS_NR(PP, QQ)                                                                                                          \
     hipLaunchKernelGGL((k_nearest_ratio<PP, QQ>), grid, block, 0, L.stream, reinterpret_cast<const uint32_t *>(in),             \
                        reinterpret_cast<uint32_t *>(out), L.iw, L.ih, L.ow, ipx, opx, L.in_sel)
-        NUS_RATIO_DISPATCH(NUS_NR)
+        if (P == 7 && Q == 5) { NUS_NR(7, 5); }
+        else NUS_RATIO_DISPATCH(NUS_NR)
 #undef NUS_NR
     });
 }
@@ -507,7 +509,7 @@ hipError_t launch_bilinear_table(const UpscaleLaunch &L, const DeviceTables &T, 
 hipError_t launch_bilinear_ratio(const UpscaleLaunch &L, const DeviceTables &T)
 {
     uint32_t P = 0, Q = 0;
-    if (!ratio_of(L, P, Q)) return hipErrorInvalidValue;
+    if (!ratio_of(L, P, Q) || (Q == 5 && P >= 7)) return hipErrorInvalidValue;
     const size_t ipx = (size_t)L.iw * L.ih, opx = (size_t)L.ow * L.oh;
     return for_frame_chunks(L, [&](const uint8_t *in, uint8_t *out, uint32_t n) {
         const uint32_t strips = cdiv(L.iw / Q, kWave);

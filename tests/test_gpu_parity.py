@@ -81,7 +81,7 @@ def test_bilinear_general_bit_exact(nsc, oracle_mod, dims):
     assert np.array_equal(out_w, oracle_mod.bilinear_wgsl(img, ow, oh))
 
 
-@pytest.mark.parametrize("ratio", [(3, 2), (4, 3), (3, 1), (4, 1), (2, 1), (5, 4), (6, 5), (5, 3), (5, 2), (7, 2)])
+@pytest.mark.parametrize("ratio", [(3, 2), (4, 3), (3, 1), (4, 1), (2, 1), (5, 4), (6, 5), (5, 3), (5, 2), (7, 2), (7, 5)])
 @pytest.mark.parametrize("groups", [(1, 1), (2, 3), (32, 18), (33, 19), (63, 10), (64, 11), (65, 12), (250, 20), (640, 360)])
 def test_nearest_and_bilinear_fixed_ratio_kernels(nsc, oracle_mod, ratio, groups):
     """The small rational factors (x3/2 -- the scale the reference's benchmark entry points default to --, x4/3, x3, x4 and, since
@@ -99,8 +99,9 @@ def test_nearest_and_bilinear_fixed_ratio_kernels(nsc, oracle_mod, ratio, groups
     img = oracle_mod.gen_noise(w, h, 18)
     want = oracle_mod.bilinear(img, ow, oh)
     out, u = _up(nsc, "bilinear", img, ow, oh)
-    # (x5/2, x7/2: the table kernel is the faster one for bilinear; nearest takes the fixed-ratio kernel at every factor)
-    assert u.kernel_variant == ("bilinear_table_f32" if (P, Q) in ((5, 2), (7, 2)) else "bilinear_ratio_f32")
+    # (x5/2, x7/2: the table kernel is the faster one for bilinear, x7/5: the fixed-ratio one does not fit the registers;
+    # nearest takes the fixed-ratio kernel at every factor)
+    assert u.kernel_variant == ("bilinear_table_f32" if (P, Q) in ((5, 2), (7, 2), (7, 5)) else "bilinear_ratio_f32")
     assert np.array_equal(out, want)
     out_g, ug = _up(nsc, "bilinear", img, ow, oh, options={"force_general": 1})
     assert ug.kernel_variant == "bilinear_table_f32" and np.array_equal(out_g, want)
