@@ -6,7 +6,7 @@ namespace nus {
 bool lanczos_pq_supported(uint32_t P, uint32_t Q)
 {
     return (P == 5 && Q == 4) || (P == 6 && Q == 5) || (P == 5 && Q == 3) || (P == 5 && Q == 2) || (P == 7 && Q == 2) ||
-           (P == 7 && Q == 5) || (P == 8 && Q == 5);
+           (P == 7 && Q == 5) || (P == 8 && Q == 5) || (P == 9 && Q == 5);
 }
 
 uint32_t lanczos_pq_strip_cols(uint32_t P, uint32_t Q)
@@ -18,6 +18,7 @@ uint32_t lanczos_pq_strip_cols(uint32_t P, uint32_t Q)
     if (P == 7 && Q == 2) return PqGeom<7, 2>::kStripCols;
     if (P == 7 && Q == 5) return PqGeom<7, 5>::kStripCols;
     if (P == 8 && Q == 5) return PqGeom<8, 5>::kStripCols;
+    if (P == 9 && Q == 5) return PqGeom<9, 5>::kStripCols;
     return 0;
 }
 
@@ -32,6 +33,7 @@ hipError_t launch_lanczos_pq(const UpscaleLaunch &L, const DeviceTables &T, bool
     if (P == 7 && Q == 2) return launch_pq<7, 2>(L, T, exact, rows_per_wave);
     if (P == 7 && Q == 5) return launch_lanczos_pq_75(L, T, exact, rows_per_wave);
     if (P == 8 && Q == 5) return launch_lanczos_pq_85(L, T, exact, rows_per_wave);
+    if (P == 9 && Q == 5) return launch_lanczos_pq_95(L, T, exact, rows_per_wave);
     return launch_pq<5, 2>(L, T, exact, rows_per_wave);
 }
 

@@ -1,5 +1,5 @@
 // nus_k_lanczos_pq.hpp -- separable resize (Lanczos-3, Catmull-Rom, Triangle) at the small rational factors P/Q that have no kernel
-// of their own: 5/4 (864p -> 1080p), 6/5 (900p -> 1080p), 7/5, 8/5, 5/3 (1080p -> 1800p), 5/2 (864p -> 2160p), 7/2 -- tenths of the reference's
+// of their own: 5/4 (864p -> 1080p), 6/5 (900p -> 1080p), 7/5, 8/5, 9/5, 5/3 (1080p -> 1800p), 5/2 (864p -> 2160p), 7/2 -- tenths of the reference's
 // scale slider (nu_scaler_py/nu_scaler/main.py:457-459) and the common capture sizes.  The register-window design of
 // nus_k_lanczos_x2.hip / nus_k_lanczos_r43.hip with P output rows per GROUP of Q input rows and P horizontal phases per group of Q
 // input columns.  image-0.24.9 imageops::resize as called at Nu_scale/src/upscale/common.rs:243-251 (vertical pass into f32, then
@@ -42,7 +42,7 @@ constexpr int pq_floordiv(int a, int b) { return a >= 0 ? a / b : -((-a + b - 1)
 
 template <int P, int Q>
 struct PqGeom {
-    static_assert(P > Q && Q >= 2 && Q <= 5 && P <= 8, "up-scaling by a small rational factor");
+    static_assert(P > Q && Q >= 2 && Q <= 5 && P <= 9, "up-scaling by a small rational factor");
     static constexpr int s(int p) { return pq_floordiv((2 * p + 1) * Q - 7 * P, 2 * P) + 1; } // first frame slot of phase p
     static constexpr int adv(int p) { return s(p) + 3; }                                      // window moves before phase p
     // 1: the window moves one row after phase p (for the last phase: into the next group's phase 0, s = -3 there)
@@ -61,7 +61,7 @@ struct PqGeom {
     // stores per output row: the row's NS P dwords go through LDS and leave as SP instructions of 64 contiguous 16-byte pieces
     // (the host requires ow % 4 == 0, so that every strip's row segment is a whole number of pieces)
     static constexpr int SP = (NS * P + 255) / 256;
-    static_assert((NS * P) % 4 == 0 && SP <= 2, "whole 16-byte pieces, at most two per lane");
+    static_assert((NS * P) % 4 == 0 && SP <= 3, "whole 16-byte pieces, at most three per lane");
     static constexpr int V = P * SP + Q * REQ; // vector memory instructions per step
     static constexpr int UNROLL = Q == 3 ? 2 : (Q == 5 ? 6 : 3); // steps until the 6-slot window is back at slot 0
     static constexpr bool ok()
@@ -214,7 +214,7 @@ __device__ __forceinline__ void pq_gather(const float (&v)[Q], float (&e)[PqGeom
 struct PqStore {
     uint32_t *stage;      // this wave's 64 P dwords of LDS
     uint32_t widx;        // where this lane's P dwords go: storing lane k of the strip at k P, halo lanes behind them
-    uint32_t off[2];      // byte offset inside an output row of the lane's 16-byte piece of store 0 / 1 (2^31: none)
+    uint32_t off[3];      // byte offset inside an output row of the lane's 16-byte piece of store 0 .. SP - 1 (2^31: none)
     int lane;
 };
 
@@ -445,7 +445,7 @@ __global__ __launch_bounds__(256) void k_lanczos3_pq(const LanczosPqArgs A)
         const uint32_t first = strip * (uint32_t)(G::NS * P), row_dwords = A.iw / Q * P;
         const uint32_t valid = row_dwords - first < (uint32_t)(G::NS * P) ? row_dwords - first : (uint32_t)(G::NS * P);
 #pragma unroll
-        for (int k = 0; k < 2; ++k) {
+        for (int k = 0; k < 3; ++k) {
             const uint32_t d = 4u * (uint32_t)(lane + kWave * k);
             st.off[k] = d + 4u <= valid ? (first + d) * 4u : 0x80000000u;
         }
@@ -485,10 +485,11 @@ hipError_t launch_pq(const UpscaleLaunch &L, const DeviceTables &T, bool exact, 
 
 } // namespace
 
-// The Q = 5 factors are one translation unit each (nus_k_lanczos_pq_65.hip, _75, _85: their six unrolled row groups are 80 - 230 KB of
+// The Q = 5 factors are one translation unit each (nus_k_lanczos_pq_65.hip, _75, _85, _95: their six unrolled row groups are 80 - 230 KB of
 // code per instantiation and a minute of compile time); nus_k_lanczos_pq.hip holds the others and the dispatch.
 hipError_t launch_lanczos_pq_65(const UpscaleLaunch &L, const DeviceTables &T, bool exact, uint32_t rows_per_wave);
 hipError_t launch_lanczos_pq_75(const UpscaleLaunch &L, const DeviceTables &T, bool exact, uint32_t rows_per_wave);
 hipError_t launch_lanczos_pq_85(const UpscaleLaunch &L, const DeviceTables &T, bool exact, uint32_t rows_per_wave);
+hipError_t launch_lanczos_pq_95(const UpscaleLaunch &L, const DeviceTables &T, bool exact, uint32_t rows_per_wave);
 
 } // namespace nus

@@ -1,0 +1,11 @@
+// nus_k_lanczos_pq_95.hip -- k_lanczos3_pq at x9/5 (nus_k_lanczos_pq.hpp), a translation unit of its own for the build's sake.
+#include "nus_k_lanczos_pq.hpp"
+
+namespace nus {
+
+hipError_t launch_lanczos_pq_95(const UpscaleLaunch &L, const DeviceTables &T, bool exact, uint32_t rows_per_wave)
+{
+    return launch_pq<9, 5>(L, T, exact, rows_per_wave);
+}
+
+} // namespace nus

@@ -1031,7 +1031,7 @@ def test_resize_register_window_variant(nsc, oracle_mod, alg, filt, dims):
     want = oracle_mod.resize(img, ow, oh, filt)
     # exact x3, x3/2 and x4/3 have their own kernels: ask for this one
     gen = {"force_general": 1} if (ow, oh) == (3 * w, 3 * h) or (2 * ow, 2 * oh) == (3 * w, 3 * h) or (3 * ow, 3 * oh) == (4 * w, 4 * h) else {}
-    if any((q * ow, q * oh) == (p * w, p * h) for p, q in ((5, 4), (6, 5), (5, 3), (5, 2), (7, 2), (7, 5), (8, 5))):
+    if any((q * ow, q * oh) == (p * w, p * h) for p, q in ((5, 4), (6, 5), (5, 3), (5, 2), (7, 2), (7, 5), (8, 5), (9, 5))):
         gen = {"force_general": 1}  # (these factors have the P/Q kernel since round 5)
     got_e, u = _up(nsc, alg, img, ow, oh, lanczos_mode="exact", options=dict(gen))
     assert u.kernel_variant == "resize_regwin_lds"
@@ -1150,13 +1150,14 @@ _PQ_SIZES = {(5, 4): [(32, 12), (64, 36), (240, 40), (252, 20), (496, 24), (1008
              (5, 2): [(32, 12), (120, 20), (122, 14), (240, 30), (600, 40)],
              (7, 2): [(32, 12), (120, 20), (126, 14), (248, 30)],
              (7, 5): [(40, 15), (300, 20), (620, 30)],
-             (8, 5): [(35, 15), (315, 25), (1000, 50)]}
+             (8, 5): [(35, 15), (315, 25), (1000, 50)],
+             (9, 5): [(40, 15), (300, 20), (620, 30)]}
 
 
 @pytest.mark.parametrize("alg,filt", [("lanczos3", 0), ("bicubic", 1), ("triangle", 2)])
 @pytest.mark.parametrize("factor,size", [(f, sz) for f, sizes in _PQ_SIZES.items() for sz in sizes])
 def test_resize_small_rational_factor_register_window(nsc, oracle_mod, alg, filt, factor, size):
-    """x5/4, x6/5, x7/5, x8/5, x5/3, x5/2, x7/2 (the reference's scale slider moves in tenths: nu_scaler_py/nu_scaler/main.py:457-459): P output rows per
+    """x5/4, x6/5, x7/5, x8/5, x9/5, x5/3, x5/2, x7/2 (the reference's scale slider moves in tenths: nu_scaler_py/nu_scaler/main.py:457-459): P output rows per
     group of Q input rows, one lane per group of Q columns, every output's weights from the tables in frame form (the ratios are not
     exact in f32).  EXACT mode: 0 differences from the oracle; FMA mode: the bits of the general kernel; borders, strip joints
     (widths around the strips of 62 Q / 60 Q columns), any number of rows per wave, opaque rows, BGRA input.  Output widths that are

@@ -92,7 +92,7 @@ def test_lanczos_r43_row_ring_waits():
 
 
 def test_lanczos_pq_row_ring_waits():
-    """k_lanczos3_pq (x5/4, x6/5, x7/5, x8/5, x5/3, x5/2, x7/2): Q row requests of 1 - 2 LDS-DMA pieces and P rows of 2 stores per step,
+    """k_lanczos3_pq (x5/4, x6/5, x7/5, x8/5, x9/5, x5/3, x5/2, x7/2): Q row requests of 1 - 2 LDS-DMA pieces and P rows of 2 - 3 stores per step,
     one hand-counted wait per row request, tight on every path of every instantiation.  (The kernel's first form also had a second,
     direct way of storing a row behind a scalar branch: there the checker caught the compiler merging an 8- and a 4-byte store into
     one 12-byte instruction at P = 7, and later a branch pair turned into a flag that no control-flow analysis can follow -- the
@@ -108,12 +108,12 @@ def test_lanczos_pq_row_ring_waits():
         assert out.returncode == 0, out.stderr
         return out.stdout
 
-    units = ["nus_k_lanczos_pq.hip", "nus_k_lanczos_pq_65.hip", "nus_k_lanczos_pq_75.hip", "nus_k_lanczos_pq_85.hip"]
-    with ThreadPoolExecutor(4) as pool:
+    units = ["nus_k_lanczos_pq.hip", "nus_k_lanczos_pq_65.hip", "nus_k_lanczos_pq_75.hip", "nus_k_lanczos_pq_85.hip", "nus_k_lanczos_pq_95.hip"]
+    with ThreadPoolExecutor(5) as pool:
         bodies = [b for text in pool.map(asm_of, units) for b in chk.kernel_bodies(text, "k_lanczos3_pqIL")]
-    assert len(bodies) == 14, [n for n, _ in bodies]  # EXACT, FMA x seven factors
+    assert len(bodies) == 16, [n for n, _ in bodies]  # EXACT, FMA x eight factors
     # (P, Q) -> unrolled steps, LDS-DMA pieces per row request
-    shape = {(5, 4): (3, 1), (6, 5): (6, 2), (5, 3): (2, 1), (5, 2): (3, 2), (7, 2): (3, 2), (7, 5): (6, 2), (8, 5): (6, 2)}
+    shape = {(5, 4): (3, 1), (6, 5): (6, 2), (5, 3): (2, 1), (5, 2): (3, 2), (7, 2): (3, 2), (7, 5): (6, 2), (8, 5): (6, 2), (9, 5): (6, 2)}
     for name, body in bodies:
         import re
 

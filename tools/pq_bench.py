@@ -17,7 +17,7 @@ dev = torch.device("cuda:0")
 s = torch.cuda.current_stream().cuda_stream
 th = int(os.environ.get("NUS_PQ_TH", "0"))
 shapes = [(1536, 864, 1920, 1080), (1600, 900, 1920, 1080), (1920, 1080, 3200, 1800), (1536, 864, 3840, 2160), (1096, 616, 3836, 2156),
-          (1920, 1080, 2688, 1512), (1920, 1080, 3072, 1728)]
+          (1920, 1080, 2688, 1512), (1920, 1080, 3072, 1728), (1920, 1080, 3456, 1944)]
 for pattern in ("gradient", "noise"):
     for iw, ih, ow, oh in shapes:
         frames = (syn.gradient_stream_torch if pattern == "gradient" else syn.noise_stream_torch)(n, iw, ih, dev)
