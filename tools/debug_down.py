@@ -2,6 +2,8 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 import nu_scaler_amd as nsc
+from nu_scaler_amd import hostmem
+hostmem.route_tensor_cpu_through_pinned_staging()  # device -> pinned staging -> numpy (nu_scaler_amd/hostmem.py)
 import oracle
 w,h,ow,oh = 3840,2160,1920,1080
 n = int(sys.argv[1]) if len(sys.argv)>1 else 1

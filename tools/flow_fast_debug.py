@@ -6,6 +6,10 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(
 import numpy as np
 import torch
 import nu_scaler_amd as nsc
+
+from nu_scaler_amd import hostmem  # noqa: E402
+
+hostmem.route_tensor_cpu_through_pinned_staging()  # device -> pinned staging -> numpy (nu_scaler_amd/hostmem.py)
 import oracle
 from test_flow import _smooth
 w, h, levels, coarse, refine = [int(v) for v in sys.argv[1:6]]

@@ -5,6 +5,8 @@ import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 import nu_scaler_amd as nsc
+from nu_scaler_amd import hostmem
+hostmem.route_tensor_cpu_through_pinned_staging()  # device -> pinned staging -> numpy (nu_scaler_amd/hostmem.py)
 import oracle as orc
 rng = np.random.default_rng(11)
 bad = cases = 0

@@ -10,6 +10,10 @@ import numpy as np
 import torch
 
 import nu_scaler_amd as nsc
+
+from nu_scaler_amd import hostmem  # noqa: E402
+
+hostmem.route_tensor_cpu_through_pinned_staging()  # device -> pinned staging -> numpy (nu_scaler_amd/hostmem.py)
 import oracle
 
 oracle.build()
