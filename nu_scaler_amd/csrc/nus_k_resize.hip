@@ -296,6 +296,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((UNION > 0 
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int WR = kResizeWinRows;
+    static_assert(WR == 7, "the walk below is written out for seven window positions");
     static_assert(N == 4 || N == 2, "outputs per lane");
     constexpr uint32_t SEGW = kWave * N;
     // The ring serves every shape but the one whose union weights live in LDS (3 columns per lane + union H pass: 51 KB per block,
@@ -429,37 +430,42 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((UNION > 0 
     }
     uint32_t adv = 0; // window advances so far: row top + WR sits in ring slot adv % D
 
-    for (uint32_t y = y_begin; y < y_end; ++y) {
-        const int32_t ly = lyt_s[y];
-        if (ly != top) { // wave-uniform; ly == top + 1 (host-checked)
-            // Issued since the request of row top + WR: the VC pieces of the D - 1 rows behind it and at least one store per
-            // output row -- and an advance happens at most once per output row, so at least D stores: with (D - 1) VC + D
-            // instructions allowed outstanding the row has landed (more stores in between make the wait stricter, never looser)
-            if (RING) {
-                const uint32_t slot = adv % (uint32_t)(D > 0 ? D : 1);
-                win_wait_vmcnt<(D > 0 ? (D - 1) * VC + D : 0), (D > 0 ? (D - 1) * VC + 1 : 1)>();
+    // The window ROTATES (round 5; rounds 2 - 4 shifted it down by one row per advance: 6 x VC x 4 register moves in front of the row's
+    // arithmetic, a quarter of the kernel's time at x1.1 - x1.4, profiles/r05_resize_win_rotating_window.txt): row top + j sits in slot
+    // (R + j) % WR, and the row that leaves gives its slot to the row that enters.  R must be a compile-time constant (the window is
+    // registers), so the walk is written as one turn of the window -- WR positions, each with its output rows (at least one: the first
+    // tap row advances by 0 or 1 per output row, host-checked) and the advance behind them -- repeated until the block's rows are done.
+    uint32_t y = y_begin;
+    auto advance = [&](auto rc, const int32_t ly) __attribute__((always_inline)) { // wave-uniform; ly == top + 1 (host-checked)
+        constexpr int R = decltype(rc)::value;
+        // Issued since the request of row top + WR: the VC pieces of the D - 1 rows behind it and at least one store per
+        // output row -- and an advance happens at most once per output row, so at least D stores: with (D - 1) VC + D
+        // instructions allowed outstanding the row has landed (more stores in between make the wait stricter, never looser)
+        if (RING) {
+            const uint32_t slot = adv % (uint32_t)(D > 0 ? D : 1);
+            win_wait_vmcnt<(D > 0 ? (D - 1) * VC + D : 0), (D > 0 ? (D - 1) * VC + 1 : 1)>();
 #pragma unroll
-                for (int m = 0; m < VC; ++m) next[m] = s_ring[(slot * VC + m) * kWave + threadIdx.x];
-                // the slot is requested again only when its reads have RETURNED (nothing orders a queued ds_read behind a later
-                // LDS-DMA write: see k_resize_down)
-                asm volatile("s_waitcnt lgkmcnt(0)" : : : "memory");
-                request_row(ly + WR + D - 1, slot);
-                ++adv;
-            }
-#pragma unroll
-            for (int j = 0; j + 1 < WR; ++j)
-#pragma unroll
-                for (int k = 0; k < VC * 4; ++k) win[j][k] = win[j + 1][k];
-            if (OP) opq = (opq << 1) | row_opaque(next);
-            cvt(next, win[WR - 1]);
-            top = ly;
-            if (!RING) load_row(top + WR, next);
+            for (int m = 0; m < VC; ++m) next[m] = s_ring[(slot * VC + m) * kWave + threadIdx.x];
+            // the slot is requested again only when its reads have RETURNED (nothing orders a queued ds_read behind a later
+            // LDS-DMA write: see k_resize_down)
+            asm volatile("s_waitcnt lgkmcnt(0)" : : : "memory");
+            request_row(ly + WR + D - 1, slot);
+            ++adv;
         }
-        const float *wy = wyt + (size_t)y * stride;
+        if (OP) opq = (opq << 1) | row_opaque(next);
+        cvt(next, win[R]); // the slot of the row that leaves
+        top = ly;
+        if (!RING) load_row(top + WR, next);
+    };
+    auto output_row = [&](auto rc) __attribute__((always_inline)) {
+        constexpr int R = decltype(rc)::value;
+        // (scalar loads, spelled out: with the row counter shared between the window positions' loops the compiler no longer sees
+        // that the address is wave-uniform, and vector loads here cost a drain of the wave's stores per row)
+        const size_t wy = (size_t)__builtin_amdgcn_readfirstlane(y) * stride;
         float wv[WR];
 #pragma unroll
         for (int j = 0; j < WR; ++j) {
-            wv[j] = wy[j]; // zero padded beyond the row's tap count
+            wv[j] = uniform_load(wyt, wy + j); // zero padded beyond the row's tap count
             asm volatile("" : "+v"(wv[j])); // VGPR copy: scalar operands halve the VALU issue rate
         }
         const bool skip_alpha = OP && (opq & ((1u << WR) - 1u)) == ((1u << WR) - 1u); // wave-uniform
@@ -474,7 +480,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((UNION > 0 
                 }
                 float acc = 0.0f;
 #pragma unroll
-                for (int j = 0; j < WR; ++j) acc = mac<EXACT>(acc, win[j][m * 4 + c], wv[j]);
+                for (int j = 0; j < WR; ++j) acc = mac<EXACT>(acc, win[(R + j) % WR][m * 4 + c], wv[j]);
                 v[c] = acc;
             }
             const int32_t ci = (int32_t)threadIdx.x + kWave * m;
@@ -554,7 +560,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((UNION > 0 
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); // the next row's V pass overwrites s_v
         __builtin_amdgcn_wave_barrier();
+    };
+#define NUS_WIN_POSITION(R)                                          \
+    do {                                                             \
+        output_row(std::integral_constant<int, R>{});                \
+        ++y;                                                         \
+    } while (y < y_end && lyt_s[y] == top);                          \
+    if (y >= y_end) break;                                           \
+    advance(std::integral_constant<int, R>{}, lyt_s[y]);
+    for (;;) {
+        NUS_WIN_POSITION(0)
+        NUS_WIN_POSITION(1)
+        NUS_WIN_POSITION(2)
+        NUS_WIN_POSITION(3)
+        NUS_WIN_POSITION(4)
+        NUS_WIN_POSITION(5)
+        NUS_WIN_POSITION(6)
     }
+#undef NUS_WIN_POSITION
 }
 
 } // namespace
