@@ -436,6 +436,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((UNION > 0 
     // registers), so the walk is written as one turn of the window -- WR positions, each with its output rows (at least one: the first
     // tap row advances by 0 or 1 per output row, host-checked) and the advance behind them -- repeated until the block's rows are done.
     uint32_t y = y_begin;
+    int32_t ly_next = top;
     auto advance = [&](auto rc, const int32_t ly) __attribute__((always_inline)) { // wave-uniform; ly == top + 1 (host-checked)
         constexpr int R = decltype(rc)::value;
         // Issued since the request of row top + WR: the VC pieces of the D - 1 rows behind it and at least one store per
@@ -459,6 +460,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((UNION > 0 
     };
     auto output_row = [&](auto rc) __attribute__((always_inline)) {
         constexpr int R = decltype(rc)::value;
+        // the NEXT output row's first tap row, asked for now: the position's loop condition needs it when this row is done
+        ly_next = lyt_s[y + 1 < y_end ? y + 1 : y];
         // (scalar loads, spelled out: with the row counter shared between the window positions' loops the compiler no longer sees
         // that the address is wave-uniform, and vector loads here cost a drain of the wave's stores per row)
         const size_t wy = (size_t)__builtin_amdgcn_readfirstlane(y) * stride;
@@ -565,9 +568,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((UNION > 0 
     do {                                                             \
         output_row(std::integral_constant<int, R>{});                \
         ++y;                                                         \
-    } while (y < y_end && lyt_s[y] == top);                          \
+    } while (y < y_end && ly_next == top);                           \
     if (y >= y_end) break;                                           \
-    advance(std::integral_constant<int, R>{}, lyt_s[y]);
+    advance(std::integral_constant<int, R>{}, ly_next);
     for (;;) {
         NUS_WIN_POSITION(0)
         NUS_WIN_POSITION(1)
