@@ -108,13 +108,62 @@ __device__ __forceinline__ void bilinear_hrow(const uint32_t *__restrict__ row, 
     }
 }
 
+// The same from a STAGED source row (round 5).  bilinear_hrow fetches its 2 N texels with 2 N one-dword gathers per lane; with four
+// outputs per lane that is eight vector memory instructions per source row for ~300 bytes of texels per wave, and the texture
+// address unit, not the arithmetic, bounds the kernel (two gathers instead of eight, as an experiment: 5.5 -> 4.1 us per frame at
+// 1080p x1.1; profiles/r05_bilinear_table_staged_rows.txt).  On an up-scale the 256 outputs of a wave read at most 258 consecutive
+// texels (261 from a start rounded down to a multiple of 4): the wave loads them once, 16 aligned bytes per lane, parks them in its LDS row and every lane picks its texel pairs from there
+// (ds_read2_b32).  Texels past the row's end are loaded as the last texel, which is what the CPU's clamped x1 reads.
+struct StagedRow {
+    uint4 v;        // texels s0 + 4 lane .. + 3
+    uint32_t extra; // lanes 0 .. 5: texels s0 + 256 .. s0 + 261 (s0 is rounded down to a multiple of 4: aligned 16-byte loads)
+};
+
+__device__ __forceinline__ StagedRow bilinear_stage_load(const uint32_t *__restrict__ row, uint32_t s0, uint32_t iw, uint32_t lane)
+{
+    StagedRow r;
+    const uint32_t t = s0 + 4 * lane;
+    if (t + 3 < iw) {
+        r.v = *reinterpret_cast<const uint4 *>(row + t); // (16-byte aligned when the row is: s0 % 4 == 0)
+    } else { // the row's end: clamped, one texel at a time
+        r.v = make_uint4(row[umin(t, iw - 1)], row[umin(t + 1, iw - 1)], row[umin(t + 2, iw - 1)], row[iw - 1]);
+    }
+    r.extra = lane < 6 ? row[umin(s0 + 256 + lane, iw - 1)] : 0u;
+    return r;
+}
+
+template <bool WGSL>
+__device__ __forceinline__ void bilinear_hrow_staged(const StagedRow &raw, uint32_t *__restrict__ stage, const uint32_t (&rel)[4],
+                                                     const float (&xf)[4], uint32_t sel, uint32_t lane, float (&h)[16])
+{
+    // LDS instructions of one wave execute in order: the lanes' writes are in place when the reads below are served
+    *reinterpret_cast<uint4 *>(stage + 4 * lane) = raw.v;
+    if (lane < 6) stage[256 + lane] = raw.extra;
+    __builtin_amdgcn_wave_barrier(); // (compiler only)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const uint32_t p0 = swz(stage[rel[i]], sel), p1 = swz(stage[rel[i] + 1], sel);
+        const float dx = xf[i], ndx = 1.0f - dx;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            float a = ch_f32(p0, c), b = ch_f32(p1, c);
+            if (WGSL) {
+                a = div_by_recip(a, 255.0f, 1.0f / 255.0f);
+                b = div_by_recip(b, 255.0f, 1.0f / 255.0f);
+            }
+            h[i * 4 + c] = a * ndx + b * dx;
+        }
+    }
+    __builtin_amdgcn_wave_barrier(); // the next row's writes stay behind these reads
+}
+
 // Any scale; coordinates come from host-built tables so no division runs here and the index /
 // fraction values are exactly the CPU's.  blockDim = (64, 4): each wave owns a column segment
 // (4 outputs per lane when VEC) and walks `rows_per_wave` output rows.  The horizontally lerped
 // source rows ("top" / "bottom" of common.rs:221-222) depend only on the source row, so they stay
 // in registers while consecutive output rows map to the same source rows -- on an upscale each is
 // reused for ~scale output rows -- and only the vertical lerp + pack runs per output pixel.
-template <bool VEC, bool WGSL>
+template <bool VEC, bool WGSL, bool STAGE = false>
 __global__ __launch_bounds__(256) void k_bilinear_table(
     const uint32_t *__restrict__ in, uint32_t *__restrict__ out,
     const uint32_t *__restrict__ x0t, const float *__restrict__ fxt,
@@ -125,8 +174,11 @@ __global__ __launch_bounds__(256) void k_bilinear_table(
     constexpr int N = VEC ? 4 : 1;
     const uint32_t rb = __builtin_amdgcn_readfirstlane(blockIdx.y * 4 + threadIdx.y);
     const uint32_t y_begin = rb * rows_per_wave;
-    const uint32_t x = (blockIdx.x * kWave + threadIdx.x) * N;
-    if (y_begin >= oh || x >= ow) return;
+    const uint32_t x_own = (blockIdx.x * kWave + threadIdx.x) * N;
+    // (STAGE: lanes past the row's end stay -- they carry texels of the staged source row -- and only skip their stores)
+    const bool live = x_own < ow;
+    if (y_begin >= oh || (!STAGE && !live)) return;
+    const uint32_t x = live ? x_own : ow - N;
     const uint32_t y_end = umin(y_begin + rows_per_wave, oh);
     const uint32_t *base = in + (size_t)blockIdx.z * in_frame_px;
     uint32_t *dst = out + (size_t)blockIdx.z * out_frame_px + x;
@@ -141,6 +193,35 @@ __global__ __launch_bounds__(256) void k_bilinear_table(
         xi[0] = x0t[x];
         xf[0] = fxt[x];
     }
+    static_assert(!STAGE || VEC, "the staged source row serves four outputs per lane");
+    // STAGE (up-scaling, host-checked iw <= ow): the wave's 256 outputs read the texels s0 .. s0 + 260 of a source row
+    __shared__ __attribute__((aligned(16))) uint32_t s_stage[STAGE ? 4 : 1][STAGE ? 264 : 1];
+    uint32_t *stage = s_stage[STAGE ? threadIdx.y : 0];
+    const uint32_t s0 = STAGE ? __builtin_amdgcn_readfirstlane(uniform_load(x0t, (size_t)blockIdx.x * kWave * N)) & ~3u : 0u;
+    uint32_t rel[4] = {0u, 0u, 0u, 0u};
+    if (STAGE) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) rel[i] = xi[i] - s0;
+    }
+    // STAGE: the source row below the current pair is requested as soon as the pair is complete (an up-scale consumes the rows one
+    // by one), so that its texels are in registers when the window moves: the load's latency is spent under the vertical lerps
+    StagedRow pre = {make_uint4(0u, 0u, 0u, 0u), 0u};
+    uint32_t pre_row = 0xffffffffu; // wave-uniform
+    auto hrow = [&](uint32_t r, float (&h)[N * 4]) __attribute__((always_inline)) {
+        if constexpr (STAGE) {
+            float h16[16];
+            StagedRow raw;
+            if (r == pre_row)
+                raw = pre;
+            else
+                raw = bilinear_stage_load(base + (size_t)r * iw, s0, iw, threadIdx.x);
+            bilinear_hrow_staged<WGSL>(raw, stage, rel, reinterpret_cast<const float (&)[4]>(xf), sel, threadIdx.x, h16);
+#pragma unroll
+            for (int k = 0; k < N * 4; ++k) h[k] = h16[k];
+        } else {
+            bilinear_hrow<N, WGSL>(base + (size_t)r * iw, xi, xf, iw, sel, h);
+        }
+    };
     float ht[N * 4], hb[N * 4]; // lerped source rows top_row / bot_row
     uint32_t top_row = 0xffffffffu, bot_row = 0xffffffffu;
     for (uint32_t y = y_begin; y < y_end; ++y) {
@@ -154,7 +235,7 @@ __global__ __launch_bounds__(256) void k_bilinear_table(
 #pragma unroll
                 for (int k = 0; k < N * 4; ++k) ht[k] = hb[k];
             } else {
-                bilinear_hrow<N, WGSL>(base + (size_t)y0 * iw, xi, xf, iw, sel, ht);
+                hrow(y0, ht);
             }
             top_row = y0;
         }
@@ -163,9 +244,13 @@ __global__ __launch_bounds__(256) void k_bilinear_table(
 #pragma unroll
                 for (int k = 0; k < N * 4; ++k) hb[k] = ht[k];
             } else {
-                bilinear_hrow<N, WGSL>(base + (size_t)y1 * iw, xi, xf, iw, sel, hb);
+                hrow(y1, hb);
             }
             bot_row = y1;
+            if constexpr (STAGE) {
+                pre_row = umin(y1 + 1, ih - 1);
+                pre = bilinear_stage_load(base + (size_t)pre_row * iw, s0, iw, threadIdx.x);
+            }
         }
         uint32_t o[N];
 #pragma unroll
@@ -179,6 +264,7 @@ __global__ __launch_bounds__(256) void k_bilinear_table(
             }
             o[i] = px;
         }
+        if (STAGE && !live) continue;
         if (VEC)
             store_out16<false>(dst + (size_t)y * ow, make_uint4(o[0], o[N > 1 ? 1 : 0], o[N > 2 ? 2 : 0], o[N > 3 ? 3 : 0]));
         else
@@ -495,13 +581,17 @@ hipError_t launch_bilinear_table(const UpscaleLaunch &L, const DeviceTables &T, 
         const dim3 block(kWave, 4), grid(cdiv(L.ow, vec ? 256 : 64), cdiv(cdiv(L.oh, rpw), 4), n);
         auto *i32 = reinterpret_cast<const uint32_t *>(in);
         auto *o32 = reinterpret_cast<uint32_t *>(out);
-#define NUS_BL(V, W)                                                                                         \
-    hipLaunchKernelGGL((k_bilinear_table<V, W>), grid, block, 0, L.stream, i32, o32, T.bl_x0, T.bl_fx, T.bl_y0, \
+#define NUS_BL(V, W, S)                                                                                         \
+    hipLaunchKernelGGL((k_bilinear_table<V, W, S>), grid, block, 0, L.stream, i32, o32, T.bl_x0, T.bl_fx, T.bl_y0, \
                        T.bl_fy, L.iw, L.ih, L.ow, L.oh, rpw, ipx, opx, L.in_sel)
-        if (vec && wgsl_form) NUS_BL(true, true);
-        else if (vec) NUS_BL(true, false);
-        else if (wgsl_form) NUS_BL(false, true);
-        else NUS_BL(false, false);
+        // up-scaling in x (source indices advance by at most one per output): the source rows staged through LDS
+        const bool stage = vec && L.iw <= L.ow && L.iw >= 4;
+        if (stage && wgsl_form) NUS_BL(true, true, true);
+        else if (stage) NUS_BL(true, false, true);
+        else if (vec && wgsl_form) NUS_BL(true, true, false);
+        else if (vec) NUS_BL(true, false, false);
+        else if (wgsl_form) NUS_BL(false, true, false);
+        else NUS_BL(false, false, false);
 #undef NUS_BL
     });
 }
