@@ -527,3 +527,19 @@ def test_benchmark_api_surface(nsc):
                             output_width=3, output_height=4, scale_factor=2.0, avg_frame_time_ms=1.0, fps=1000.0,
                             frames_processed=5, total_duration_ms=5.0)
     assert (r.input_width, r.output_height, r.frames_processed, r.technology) == (1, 4, 5, "Wgpu")
+
+
+def test_hostmem_routing_is_idempotent_and_leaves_cpu_tensors_alone():
+    """nu_scaler_amd/hostmem.py (harness helper: device -> pinned staging -> numpy, because the HIP runtime's pageable device-to-host
+    copy faulted twice in long sessions): without a GPU it must be a no-op for CPU tensors and safe to install twice."""
+    import torch
+
+    from nu_scaler_amd import hostmem
+
+    hostmem.route_tensor_cpu_through_pinned_staging()
+    first = torch.Tensor.cpu
+    hostmem.route_tensor_cpu_through_pinned_staging()
+    assert torch.Tensor.cpu is first and hasattr(torch.Tensor, "_nus_plain_cpu")
+    t = torch.arange(1 << 18, dtype=torch.uint8)
+    assert hostmem.to_host(t) is t and t.cpu() is t  # (Tensor.cpu() of a CPU tensor returns the tensor itself)
+    assert hostmem.to_numpy(t).sum() == int(t.sum())
