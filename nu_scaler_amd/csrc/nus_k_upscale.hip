@@ -132,17 +132,31 @@ __device__ __forceinline__ StagedRow bilinear_stage_load(const uint32_t *__restr
     return r;
 }
 
-template <bool WGSL>
-__device__ __forceinline__ void bilinear_hrow_staged(const StagedRow &raw, uint32_t *__restrict__ stage, const uint32_t (&rel)[4],
-                                                     const float (&xf)[4], uint32_t sel, uint32_t lane, float (&h)[16])
+// the lanes' texel pairs of a staged row: raw -> LDS -> 8 registers (LDS instructions of one wave execute in order: the lanes' writes
+// are in place when the reads are served, and the next row's writes stay behind these reads)
+struct TexelPairs {
+    uint32_t p[8]; // (p0, p1) of the lane's four outputs
+};
+
+__device__ __forceinline__ TexelPairs bilinear_stage_pick(const StagedRow &raw, uint32_t *__restrict__ stage, const uint32_t (&rel)[4],
+                                                          uint32_t lane)
 {
-    // LDS instructions of one wave execute in order: the lanes' writes are in place when the reads below are served
     *reinterpret_cast<uint4 *>(stage + 4 * lane) = raw.v;
     if (lane < 6) stage[256 + lane] = raw.extra;
     __builtin_amdgcn_wave_barrier(); // (compiler only)
+    TexelPairs t;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) t.p[2 * i] = stage[rel[i]], t.p[2 * i + 1] = stage[rel[i] + 1];
+    __builtin_amdgcn_wave_barrier();
+    return t;
+}
+
+template <bool WGSL>
+__device__ __forceinline__ void bilinear_hrow_pairs(const TexelPairs &t, const float (&xf)[4], uint32_t sel, float (&h)[16])
+{
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const uint32_t p0 = swz(stage[rel[i]], sel), p1 = swz(stage[rel[i] + 1], sel);
+        const uint32_t p0 = swz(t.p[2 * i], sel), p1 = swz(t.p[2 * i + 1], sel);
         const float dx = xf[i], ndx = 1.0f - dx;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
@@ -154,7 +168,6 @@ __device__ __forceinline__ void bilinear_hrow_staged(const StagedRow &raw, uint3
             h[i * 4 + c] = a * ndx + b * dx;
         }
     }
-    __builtin_amdgcn_wave_barrier(); // the next row's writes stay behind these reads
 }
 
 // Any scale; coordinates come from host-built tables so no division runs here and the index /
@@ -203,21 +216,29 @@ __global__ __launch_bounds__(256) void k_bilinear_table(
 #pragma unroll
         for (int i = 0; i < N; ++i) rel[i] = xi[i] - s0;
     }
-    // STAGE: the source row below the current pair is requested as soon as the pair is complete (an up-scale consumes the rows one
-    // by one), so that its texels are in registers when the window moves: the load's latency is spent under the vertical lerps
+    // STAGE: a two-deep pipeline over the source rows (an up-scale consumes them one by one).  When row r has been lerped, row r + 1
+    // -- requested a step earlier -- goes through LDS into the lanes' texel-pair registers, and row r + 2 is requested: the global
+    // load's latency and the LDS round trip are both spent under the vertical lerps of the output rows in between.  A row that is in
+    // neither stage (a block's first row) is fetched on the spot.
     StagedRow pre = {make_uint4(0u, 0u, 0u, 0u), 0u};
-    uint32_t pre_row = 0xffffffffu; // wave-uniform
+    TexelPairs tex = {{0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u}};
+    uint32_t pre_row = 0xffffffffu, tex_row = 0xffffffffu; // wave-uniform
     auto hrow = [&](uint32_t r, float (&h)[N * 4]) __attribute__((always_inline)) {
         if constexpr (STAGE) {
             float h16[16];
-            StagedRow raw;
-            if (r == pre_row)
-                raw = pre;
-            else
-                raw = bilinear_stage_load(base + (size_t)r * iw, s0, iw, threadIdx.x);
-            bilinear_hrow_staged<WGSL>(raw, stage, rel, reinterpret_cast<const float (&)[4]>(xf), sel, threadIdx.x, h16);
+            if (r != tex_row) {
+                const StagedRow raw = r == pre_row ? pre : bilinear_stage_load(base + (size_t)r * iw, s0, iw, threadIdx.x);
+                tex = bilinear_stage_pick(raw, stage, rel, threadIdx.x);
+            }
+            bilinear_hrow_pairs<WGSL>(tex, reinterpret_cast<const float (&)[4]>(xf), sel, h16);
 #pragma unroll
             for (int k = 0; k < N * 4; ++k) h[k] = h16[k];
+            const uint32_t r1 = umin(r + 1, ih - 1), r2 = umin(r + 2, ih - 1);
+            if (pre_row != r1) pre = bilinear_stage_load(base + (size_t)r1 * iw, s0, iw, threadIdx.x); // (a block's first rows: waited for here)
+            tex = bilinear_stage_pick(pre, stage, rel, threadIdx.x);
+            tex_row = r1;
+            pre = bilinear_stage_load(base + (size_t)r2 * iw, s0, iw, threadIdx.x);
+            pre_row = r2;
         } else {
             bilinear_hrow<N, WGSL>(base + (size_t)r * iw, xi, xf, iw, sel, h);
         }
@@ -247,10 +268,6 @@ __global__ __launch_bounds__(256) void k_bilinear_table(
                 hrow(y1, hb);
             }
             bot_row = y1;
-            if constexpr (STAGE) {
-                pre_row = umin(y1 + 1, ih - 1);
-                pre = bilinear_stage_load(base + (size_t)pre_row * iw, s0, iw, threadIdx.x);
-            }
         }
         uint32_t o[N];
 #pragma unroll
