@@ -345,10 +345,24 @@ void HipUpscaler::choose_resize_variant(bool x2)
         if (lanczos_pq_supported(P, Q) && (uint64_t)oh_ * Q == (uint64_t)ih_ * P && (iw_ % Q) == 0 && (ih_ % Q) == 0 && (ow_ % 4) == 0 &&
             lanczos_pq_phase_frame(tx_, P, Q, wx6_) && lanczos_pq_phase_frame(ty_, P, Q, wy6_)) {
             pq_p_ = P, pq_q_ = Q;
-            variant_ = Variant::LanczosPqRegWin;
-            return;
         }
     }
+    if (pq_p_) {
+        // The any-scale kernel's parameters as well: at x6/5, x8/5, x9/5 the kernel's EXACT instantiations hold 250 - 430 registers (one
+        // wave per SIMD) and lose to it (1080p: 11.2 / 25.4 / 30.0 against 8.3 / 19.9 / 28.5 us; x7/5 wins, 11.6 against 17.4), so EXACT
+        // mode -- which can be switched on after initialize() -- takes it there (enqueue)
+        choose_general_resize_variant();
+        pq_exact_fallback_ = variant_ == Variant::ResizeWin && pq_q_ == 5 && pq_p_ != 7;
+        variant_ = Variant::LanczosPqRegWin;
+        return;
+    }
+    choose_general_resize_variant();
+}
+
+// ... and the kernels for every other shape: streamed down-scaling, the register-window / LDS-row any-scale kernels, per pixel
+void HipUpscaler::choose_general_resize_variant()
+{
+    variant_ = Variant::LanczosGeneral;
     if (force_per_pixel_) return;
     // vertical down-scaling: stream the input rows through 7 accumulator slots, if the windows allow it and a
     // 64-column output segment's footprint fits 5 columns per lane
@@ -747,7 +761,10 @@ int HipUpscaler::enqueue(const uint8_t *d_in, uint8_t *d_out, uint32_t n_frames,
             const uint64_t blocks = (ih_ + t - 1) / t;
             th = (uint32_t)(((ih_ + blocks - 1) / blocks + pq_q_ - 1) / pq_q_ * pq_q_);
         }
-        e = launch_lanczos_pq(L, dt_, lanczos_exact_, pq_p_, pq_q_, th);
+        if (lanczos_exact_ && pq_exact_fallback_) // (see choose_resize_variant)
+            e = launch_resize_win(L, dt_, true, resize_ncols_max_, resize_union_taps_, win_outputs_per_lane_);
+        else
+            e = launch_lanczos_pq(L, dt_, lanczos_exact_, pq_p_, pq_q_, th);
         break;
     }
     case Variant::LanczosR32RegWin: {

@@ -205,6 +205,7 @@ private:
     void choose_variant();
     bool ratio_shape(bool bilinear) const; // tables have the shape of the fixed-ratio nearest / bilinear kernels
     void choose_resize_variant(bool x2);
+    void choose_general_resize_variant();
     uint32_t widest_footprint(uint32_t segw) const;
     uint32_t widest_union(uint32_t n) const;
     struct BlendSrc {
@@ -254,6 +255,7 @@ private:
     AxisTables tx_, ty_;
     std::vector<float> wy6_, wx6_;
     uint32_t pq_p_ = 0, pq_q_ = 0; // Variant::LanczosPqRegWin: the factor P / Q
+    bool pq_exact_fallback_ = false; // ... and whether its EXACT mode runs on the any-scale kernel instead (Q = 5)
     std::vector<uint32_t> xs_cls_x_, xs_cls_y_; // x3: weight class per input index, and the classes' weights
     std::vector<float> xs_wcls_x_, xs_wcls_y_;
     DeviceTables dt_;
