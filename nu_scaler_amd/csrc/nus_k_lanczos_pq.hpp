@@ -49,7 +49,8 @@ struct PqGeom {
     static constexpr int moves(int p) { return p + 1 < P ? s(p + 1) - s(p) : Q - 3 - s(P - 1); }
     static constexpr int R = s(P - 1) + 5;                                                    // right-most column a lane's outputs read
     static constexpr int NE = R + 4;                                                          // columns -3 .. R
-    static constexpr int HL = ((R - Q + 1 + Q - 1) / Q) > ((3 + Q - 1) / Q) ? ((R - Q + 1 + Q - 1) / Q) : ((3 + Q - 1) / Q); // halo lanes
+    // lanes to either side a lane's outputs reach into: ceil(3 / Q) on the left, ceil((R - (Q - 1)) / Q) = R / Q on the right
+    static constexpr int HL = (R / Q) > ((3 + Q - 1) / Q) ? (R / Q) : ((3 + Q - 1) / Q);
     // halo lanes per side of a strip: HL, or one more where that makes the storing lanes' 4 P-byte pieces a whole number of 16-byte
     // pieces per row (the turned stores below)
     static constexpr int HS = ((kWave - 2 * HL) * P) % 4 == 0 ? HL : HL + 1;
