@@ -113,22 +113,28 @@ __device__ __forceinline__ void bilinear_hrow(const uint32_t *__restrict__ row, 
 // address unit, not the arithmetic, bounds the kernel (two gathers instead of eight, as an experiment: 5.5 -> 4.1 us per frame at
 // 1080p x1.1; profiles/r05_bilinear_table_staged_rows.txt).  On an up-scale the 256 outputs of a wave read at most 258 consecutive
 // texels (261 from a start rounded down to a multiple of 4): the wave loads them once, 16 aligned bytes per lane, parks them in its LDS row and every lane picks its texel pairs from there
-// (ds_read2_b32).  Texels past the row's end are loaded as the last texel, which is what the CPU's clamped x1 reads.
+// (ds_read2_b32).  Texels past the row's end are loaded as the last texel, which is what the CPU's clamped x1 reads.  Down-scaling by
+// 1.9 ... 2 takes the same road with KS = 2 wide loads per lane (a wave's outputs then reach 512 texels and need all of them).
+template <int KS>
 struct StagedRow {
-    uint4 v;        // texels s0 + 4 lane .. + 3
-    uint32_t extra; // lanes 0 .. 5: texels s0 + 256 .. s0 + 261 (s0 is rounded down to a multiple of 4: aligned 16-byte loads)
+    uint4 v[KS];    // texels s0 + 256 k + 4 lane .. + 3
+    uint32_t extra; // lanes 0 .. 5: texels s0 + 256 KS .. + 5 (s0 is rounded down to a multiple of 4: aligned 16-byte loads)
 };
 
-__device__ __forceinline__ StagedRow bilinear_stage_load(const uint32_t *__restrict__ row, uint32_t s0, uint32_t iw, uint32_t lane)
+template <int KS>
+__device__ __forceinline__ StagedRow<KS> bilinear_stage_load(const uint32_t *__restrict__ row, uint32_t s0, uint32_t iw, uint32_t lane)
 {
-    StagedRow r;
-    const uint32_t t = s0 + 4 * lane;
-    if (t + 3 < iw) {
-        r.v = *reinterpret_cast<const uint4 *>(row + t); // (16-byte aligned when the row is: s0 % 4 == 0)
-    } else { // the row's end: clamped, one texel at a time
-        r.v = make_uint4(row[umin(t, iw - 1)], row[umin(t + 1, iw - 1)], row[umin(t + 2, iw - 1)], row[iw - 1]);
+    StagedRow<KS> r;
+#pragma unroll
+    for (int k = 0; k < KS; ++k) {
+        const uint32_t t = s0 + 256 * k + 4 * lane;
+        if (t + 3 < iw) {
+            r.v[k] = *reinterpret_cast<const uint4 *>(row + t); // (16-byte aligned when the row is: s0 % 4 == 0)
+        } else { // the row's end: clamped, one texel at a time
+            r.v[k] = make_uint4(row[umin(t, iw - 1)], row[umin(t + 1, iw - 1)], row[umin(t + 2, iw - 1)], row[iw - 1]);
+        }
     }
-    r.extra = lane < 6 ? row[umin(s0 + 256 + lane, iw - 1)] : 0u;
+    r.extra = lane < 6 ? row[umin(s0 + 256 * KS + lane, iw - 1)] : 0u;
     return r;
 }
 
@@ -138,11 +144,13 @@ struct TexelPairs {
     uint32_t p[8]; // (p0, p1) of the lane's four outputs
 };
 
-__device__ __forceinline__ TexelPairs bilinear_stage_pick(const StagedRow &raw, uint32_t *__restrict__ stage, const uint32_t (&rel)[4],
+template <int KS>
+__device__ __forceinline__ TexelPairs bilinear_stage_pick(const StagedRow<KS> &raw, uint32_t *__restrict__ stage, const uint32_t (&rel)[4],
                                                           uint32_t lane)
 {
-    *reinterpret_cast<uint4 *>(stage + 4 * lane) = raw.v;
-    if (lane < 6) stage[256 + lane] = raw.extra;
+#pragma unroll
+    for (int k = 0; k < KS; ++k) *reinterpret_cast<uint4 *>(stage + 256 * k + 4 * lane) = raw.v[k];
+    if (lane < 6) stage[256 * KS + lane] = raw.extra;
     __builtin_amdgcn_wave_barrier(); // (compiler only)
     TexelPairs t;
 #pragma unroll
@@ -176,7 +184,7 @@ __device__ __forceinline__ void bilinear_hrow_pairs(const TexelPairs &t, const f
 // source rows ("top" / "bottom" of common.rs:221-222) depend only on the source row, so they stay
 // in registers while consecutive output rows map to the same source rows -- on an upscale each is
 // reused for ~scale output rows -- and only the vertical lerp + pack runs per output pixel.
-template <bool VEC, bool WGSL, bool STAGE = false>
+template <bool VEC, bool WGSL, int KS = 0>
 __global__ __launch_bounds__(256) void k_bilinear_table(
     const uint32_t *__restrict__ in, uint32_t *__restrict__ out,
     const uint32_t *__restrict__ x0t, const float *__restrict__ fxt,
@@ -185,6 +193,8 @@ __global__ __launch_bounds__(256) void k_bilinear_table(
     uint32_t sel)
 {
     constexpr int N = VEC ? 4 : 1;
+    constexpr bool STAGE = KS > 0;
+    constexpr int KSN = STAGE ? KS : 1;
     const uint32_t rb = __builtin_amdgcn_readfirstlane(blockIdx.y * 4 + threadIdx.y);
     const uint32_t y_begin = rb * rows_per_wave;
     const uint32_t x_own = (blockIdx.x * kWave + threadIdx.x) * N;
@@ -207,8 +217,8 @@ __global__ __launch_bounds__(256) void k_bilinear_table(
         xf[0] = fxt[x];
     }
     static_assert(!STAGE || VEC, "the staged source row serves four outputs per lane");
-    // STAGE (up-scaling, host-checked iw <= ow): the wave's 256 outputs read the texels s0 .. s0 + 260 of a source row
-    __shared__ __attribute__((aligned(16))) uint32_t s_stage[STAGE ? 4 : 1][STAGE ? 264 : 1];
+    // STAGE (host-checked): the wave's 256 outputs read the texels s0 .. s0 + 256 KS + 5 of a source row
+    __shared__ __attribute__((aligned(16))) uint32_t s_stage[STAGE ? 4 : 1][STAGE ? 256 * KSN + 8 : 1];
     uint32_t *stage = s_stage[STAGE ? threadIdx.y : 0];
     const uint32_t s0 = STAGE ? __builtin_amdgcn_readfirstlane(uniform_load(x0t, (size_t)blockIdx.x * kWave * N)) & ~3u : 0u;
     uint32_t rel[4] = {0u, 0u, 0u, 0u};
@@ -220,24 +230,24 @@ __global__ __launch_bounds__(256) void k_bilinear_table(
     // -- requested a step earlier -- goes through LDS into the lanes' texel-pair registers, and row r + 2 is requested: the global
     // load's latency and the LDS round trip are both spent under the vertical lerps of the output rows in between.  A row that is in
     // neither stage (a block's first row) is fetched on the spot.
-    StagedRow pre = {make_uint4(0u, 0u, 0u, 0u), 0u};
+    StagedRow<KSN> pre = {};
     TexelPairs tex = {{0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u}};
     uint32_t pre_row = 0xffffffffu, tex_row = 0xffffffffu; // wave-uniform
     auto hrow = [&](uint32_t r, float (&h)[N * 4]) __attribute__((always_inline)) {
         if constexpr (STAGE) {
             float h16[16];
             if (r != tex_row) {
-                const StagedRow raw = r == pre_row ? pre : bilinear_stage_load(base + (size_t)r * iw, s0, iw, threadIdx.x);
-                tex = bilinear_stage_pick(raw, stage, rel, threadIdx.x);
+                const StagedRow<KSN> raw = r == pre_row ? pre : bilinear_stage_load<KSN>(base + (size_t)r * iw, s0, iw, threadIdx.x);
+                tex = bilinear_stage_pick<KSN>(raw, stage, rel, threadIdx.x);
             }
             bilinear_hrow_pairs<WGSL>(tex, reinterpret_cast<const float (&)[4]>(xf), sel, h16);
 #pragma unroll
             for (int k = 0; k < N * 4; ++k) h[k] = h16[k];
             const uint32_t r1 = umin(r + 1, ih - 1), r2 = umin(r + 2, ih - 1);
-            if (pre_row != r1) pre = bilinear_stage_load(base + (size_t)r1 * iw, s0, iw, threadIdx.x); // (a block's first rows: waited for here)
-            tex = bilinear_stage_pick(pre, stage, rel, threadIdx.x);
+            if (pre_row != r1) pre = bilinear_stage_load<KSN>(base + (size_t)r1 * iw, s0, iw, threadIdx.x); // (a block's first rows, rows skipped on a down-scale: waited for here)
+            tex = bilinear_stage_pick<KSN>(pre, stage, rel, threadIdx.x);
             tex_row = r1;
-            pre = bilinear_stage_load(base + (size_t)r2 * iw, s0, iw, threadIdx.x);
+            pre = bilinear_stage_load<KSN>(base + (size_t)r2 * iw, s0, iw, threadIdx.x);
             pre_row = r2;
         } else {
             bilinear_hrow<N, WGSL>(base + (size_t)r * iw, xi, xf, iw, sel, h);
@@ -601,14 +611,18 @@ hipError_t launch_bilinear_table(const UpscaleLaunch &L, const DeviceTables &T, 
 #define NUS_BL(V, W, S)                                                                                         \
     hipLaunchKernelGGL((k_bilinear_table<V, W, S>), grid, block, 0, L.stream, i32, o32, T.bl_x0, T.bl_fx, T.bl_y0, \
                        T.bl_fy, L.iw, L.ih, L.ow, L.oh, rpw, ipx, opx, L.in_sel)
-        // up-scaling in x (source indices advance by at most one per output): the source rows staged through LDS
-        const bool stage = vec && L.iw <= L.ow && L.iw >= 4;
-        if (stage && wgsl_form) NUS_BL(true, true, true);
-        else if (stage) NUS_BL(true, false, true);
-        else if (vec && wgsl_form) NUS_BL(true, true, false);
-        else if (vec) NUS_BL(true, false, false);
-        else if (wgsl_form) NUS_BL(false, true, false);
-        else NUS_BL(false, false, false);
+        // the source rows staged through LDS where a wave's 256 outputs reach at most 256 KS texels (+ 5) AND need nearly all of them:
+        // every up-scale (KS = 1) and down-scaling by 1.9 ... 2 (KS = 2; 4K -> 1080p 17.0 -> 10.8 us per frame).  Between them the
+        // second wide load is half wasted (1440p -> 1080p 7.1 -> 8.0: gathers kept), beyond 2 bilinear skips texels and whole rows,
+        // which the gathers never fetch (4K -> 720p 5.8 against 10.1 staged): profiles/r05_bilinear_table_staged_rows.txt
+        const uint32_t reach = (uint32_t)((uint64_t)255 * L.iw / L.ow) + 1; // (+ 1: the table's f32 indices may sit one above the quotient)
+        const int ks = !(vec && L.iw >= 4) ? 0 : (reach <= 256 ? 1 : (reach >= 480 && reach <= 512 ? 2 : 0));
+        if (ks == 1) { if (wgsl_form) NUS_BL(true, true, 1); else NUS_BL(true, false, 1); }
+        else if (ks == 2) { if (wgsl_form) NUS_BL(true, true, 2); else NUS_BL(true, false, 2); }
+        else if (vec && wgsl_form) NUS_BL(true, true, 0);
+        else if (vec) NUS_BL(true, false, 0);
+        else if (wgsl_form) NUS_BL(false, true, 0);
+        else NUS_BL(false, false, 0);
 #undef NUS_BL
     });
 }
