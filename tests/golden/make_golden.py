@@ -64,6 +64,19 @@ def main():
     vec["lanczos3_x4"] = oracle.lanczos3(small, 96, 56)
     vec["lanczos3_half"] = oracle.lanczos3(noise, 24, 13)
     vec["catmullrom_third"] = oracle.resize(noise, 16, 9, oracle.FILTER_CATMULLROM)
+    # round 5: the small rational factors of the P/Q register-window kernel (x6/5, x7/5, x5/4, x5/3, x5/2)
+    pq = oracle.gen_noise(40, 15, 0xD1CE)
+    vec["noise_40x15"] = pq
+    vec["lanczos3_x6o5"] = oracle.lanczos3(pq, 48, 18)
+    vec["catmullrom_x7o5"] = oracle.resize(pq, 56, 21, oracle.FILTER_CATMULLROM)
+    pq2 = oracle.gen_noise(36, 12, 0xFACE)
+    vec["noise_36x12"] = pq2
+    vec["lanczos3_x5o3"] = oracle.lanczos3(pq2, 60, 20)
+    vec["triangle_x5o3"] = oracle.resize(pq2, 60, 20, oracle.FILTER_TRIANGLE)
+    pq3 = oracle.gen_noise(32, 12, 0xCAFE)
+    vec["noise_32x12"] = pq3
+    vec["lanczos3_x5o4"] = oracle.lanczos3(pq3, 40, 15)
+    vec["lanczos3_x5o2"] = oracle.lanczos3(pq3, 80, 30)
     vec["fsr1_x2"] = oracle.fsr1(small, 48, 28, 0.0, 0.7)
     vec["flow_l2_c5_r2"] = oracle.flow_estimate(a, b, 2, 5, 2, 0.02 ** 2)  # lambda: FlowEstimator's default
     np.savez_compressed(os.path.join(HERE, "oracle_vectors.npz"), **vec)

@@ -238,9 +238,16 @@ def test_committed_oracle_vectors(nsc):
     small = v["noise_24x14"]
     for alg, src, (ow, oh), key in (("bicubic", small, (48, 28), "catmullrom_x2"), ("triangle", small, (36, 21), "triangle_x1p5"),
                                     ("lanczos3", small, (96, 56), "lanczos3_x4"), ("lanczos3", noise, (24, 13), "lanczos3_half"),
-                                    ("bicubic", noise, (16, 9), "catmullrom_third")):
-        assert np.array_equal(_up(nsc, alg, src, ow, oh, lanczos_mode="exact")[0], v[key]), key
+                                    ("bicubic", noise, (16, 9), "catmullrom_third"),
+                                    # round 5: the P/Q register-window kernel's factors
+                                    ("lanczos3", v["noise_40x15"], (48, 18), "lanczos3_x6o5"), ("bicubic", v["noise_40x15"], (56, 21), "catmullrom_x7o5"),
+                                    ("lanczos3", v["noise_36x12"], (60, 20), "lanczos3_x5o3"), ("triangle", v["noise_36x12"], (60, 20), "triangle_x5o3"),
+                                    ("lanczos3", v["noise_32x12"], (40, 15), "lanczos3_x5o4"), ("lanczos3", v["noise_32x12"], (80, 30), "lanczos3_x5o2")):
+        got_e, ue = _up(nsc, alg, src, ow, oh, lanczos_mode="exact")
+        assert np.array_equal(got_e, v[key]), key
         assert _maxdiff(_up(nsc, alg, src, ow, oh)[0], v[key]) <= 1, key
+        if key in ("lanczos3_x6o5", "catmullrom_x7o5", "lanczos3_x5o3", "triangle_x5o3", "lanczos3_x5o4", "lanczos3_x5o2"):
+            assert ue.kernel_variant == "lanczos3_pq_regwin", (key, ue.kernel_variant)
     u = nsc.PyWgpuUpscaler("quality", "fsr1")
     u.set_sharpness(0.0, 0.7)
     u.initialize(24, 14, 48, 28)

@@ -102,6 +102,16 @@ def test_oracle_vectors_stable(oracle_mod):
     assert np.array_equal(v["lanczos3_x4"], oracle_mod.lanczos3(small, 96, 56))
     assert np.array_equal(v["lanczos3_half"], oracle_mod.lanczos3(noise, 24, 13))
     assert np.array_equal(v["catmullrom_third"], oracle_mod.resize(noise, 16, 9, oracle_mod.FILTER_CATMULLROM))
+    # round 5: the P/Q factors
+    pq, pq2, pq3 = v["noise_40x15"], v["noise_36x12"], v["noise_32x12"]
+    assert np.array_equal(pq, oracle_mod.gen_noise(40, 15, 0xD1CE)) and np.array_equal(pq2, oracle_mod.gen_noise(36, 12, 0xFACE))
+    assert np.array_equal(pq3, oracle_mod.gen_noise(32, 12, 0xCAFE))
+    assert np.array_equal(v["lanczos3_x6o5"], oracle_mod.lanczos3(pq, 48, 18))
+    assert np.array_equal(v["catmullrom_x7o5"], oracle_mod.resize(pq, 56, 21, oracle_mod.FILTER_CATMULLROM))
+    assert np.array_equal(v["lanczos3_x5o3"], oracle_mod.lanczos3(pq2, 60, 20))
+    assert np.array_equal(v["triangle_x5o3"], oracle_mod.resize(pq2, 60, 20, oracle_mod.FILTER_TRIANGLE))
+    assert np.array_equal(v["lanczos3_x5o4"], oracle_mod.lanczos3(pq3, 40, 15))
+    assert np.array_equal(v["lanczos3_x5o2"], oracle_mod.lanczos3(pq3, 80, 30))
     assert np.array_equal(v["fsr1_x2"], oracle_mod.fsr1(small, 48, 28, 0.0, 0.7))
     assert np.array_equal(v["flow_l2_c5_r2"], oracle_mod.flow_estimate(a, b, 2, 5, 2, 0.02 ** 2))
 
