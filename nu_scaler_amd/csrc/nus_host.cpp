@@ -265,12 +265,16 @@ uint32_t HipUpscaler::widest_footprint(uint32_t segw) const
     return widest;
 }
 
-// widest union of the 8-slot tap windows of `n` adjacent outputs (a lane's outputs in the union-window H pass); ow_ % n == 0
+// widest union of the tap windows of `n` adjacent outputs (a lane's outputs in the union-window H pass); ow_ % n == 0.  For two
+// outputs per lane a window is as long as the axis's widest one (7 for Lanczos-3 on an up-scale; the table's slots beyond a window's
+// taps hold zeros), so that their union fits the 8-tap pass; for four the table's 8 slots as before (counted tightly, x1.4 - x1.5 would
+// move from the plain 8-slot pass to the 10-tap union with its weights in LDS, which is slower there: 768p -> 1080p 6.1 -> 7.3 us)
 uint32_t HipUpscaler::widest_union(uint32_t n) const
 {
     uint32_t widest = 0;
+    const uint32_t taps = n == 2 && tx_.lz_max_taps > 0 && tx_.lz_max_taps < 8 ? (uint32_t)tx_.lz_max_taps : 8u;
     for (uint32_t x0 = 0; x0 < ow_; x0 += n) {
-        const uint32_t u = (uint32_t)(tx_.lz_left[x0 + n - 1] - tx_.lz_left[x0]) + 8u;
+        const uint32_t u = (uint32_t)(tx_.lz_left[x0 + n - 1] - tx_.lz_left[x0]) + taps;
         if (u > widest) widest = u;
     }
     return widest;

@@ -647,7 +647,10 @@ hipError_t launch_resize_win(const UpscaleLaunch &L, const DeviceTables &T, bool
     const size_t ipx = (size_t)L.iw * L.ih, opx = (size_t)L.ow * L.oh;
     const int vc = ncols_max <= 128 ? 2 : (ncols_max <= 192 ? 3 : 0); // 4 columns per lane: 256 VGPRs, slower than the LDS-row kernel
     if (vc == 0 || (L.ow % 4) != 0 || (outputs_per_lane != 4 && outputs_per_lane != 2)) return hipErrorInvalidValue;
-    const int uni = (union_taps > 0 && union_taps <= 10) ? 10 : 0; // wider unions: plain 8-slot H pass (VGPR budget)
+    // union-window H pass of 8 taps (two outputs per lane: their windows differ by at most one column) or 10; wider unions: the plain
+    // 8-slot H pass (VGPR budget)
+    // (the plain pass in place of a union was measured again in round 5: equal at x1.4 / x1.7, 14 - 40 % slower at x1.3, x2.2, x2.5)
+    const int uni = (union_taps > 0 && union_taps <= 8 && outputs_per_lane == 2) ? 8 : ((union_taps > 0 && union_taps <= 10) ? 10 : 0);
     // the four waves' rows, then (3 columns per lane with the union H pass) their union weights: [tap][64] float4 per wave
     const size_t lds = ((vc == 3 && uni) ? 0 : (size_t)4 * kWinDepth * vc * kWave * sizeof(uint32_t)) + // (the row rings: see the kernel)
                        (size_t)4 * (ncols_max + kResizeSlack) * sizeof(float4) +
@@ -666,8 +669,9 @@ hipError_t launch_resize_win(const UpscaleLaunch &L, const DeviceTables &T, bool
 #define NUS_RW3(E, NN)                                                           \
     if (vc == 2) { if (uni) NUS_RW(E, 2, 10, NN); else NUS_RW(E, 2, 0, NN); }    \
     else { if (uni) NUS_RW(E, 3, 10, NN); else NUS_RW(E, 3, 0, NN); }
-#define NUS_RW2(E)                                  \
-    if (outputs_per_lane == 4) { NUS_RW3(E, 4) }    \
+#define NUS_RW2(E)                                                                         \
+    if (outputs_per_lane == 4) { NUS_RW3(E, 4) }                                           \
+    else if (uni == 8) { if (vc == 2) NUS_RW(E, 2, 8, 2); else NUS_RW(E, 3, 8, 2); }       \
     else { NUS_RW3(E, 2) }
         if (exact) {
             NUS_RW2(true)

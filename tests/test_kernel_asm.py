@@ -164,7 +164,7 @@ def test_resize_win_row_ring_waits():
                           os.path.join(CSRC, "nus_k_resize.hip")], capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr
     bodies = list(chk.kernel_bodies(out.stdout, "k_resize_winIL"))
-    assert len(bodies) == 16, len(bodies)  # EXACT x VC {2, 3} x UNION {0, 10} x N {4, 2}
+    assert len(bodies) == 20, len(bodies)  # EXACT x VC {2, 3} x (UNION {0, 10} x N {4, 2} + UNION 8 at N = 2)
     ringed = 0
     for name, body in bodies:
         vc, uni = (int(v) for v in re.search(r"k_resize_winILb[01]ELi(\d)ELi(\d+)E", name).groups())
@@ -182,7 +182,7 @@ def test_resize_win_row_ring_waits():
             n = int(re.search(r"vmcnt\((\d+)\)", t).group(1))
             assert min(counts) >= n, (name, t, counts)
         assert re.search(r"s_waitcnt lgkmcnt\(0\)[^\n]*\n(?:[^\n]*\n){0,16}?[^\n]*global_load_lds_dword", body), name
-    assert ringed == 12
+    assert ringed == 14
 
 
 def test_resize_down_row_ring_waits():
