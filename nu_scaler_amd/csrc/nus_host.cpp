@@ -413,11 +413,16 @@ void HipUpscaler::choose_general_resize_variant()
         win_ok = d == 0 || d == 1;
     }
     if (!win_ok) return;
-    if (widest <= 192) {
+    // Four outputs per lane (segments of 256 output columns) from x2 up.  Below x2 two outputs per lane win wherever their 8-tap union
+    // pass applies (two input columns per lane, union weights in registers, rows through the ring -- the four-output shape there needs
+    // three columns per lane and keeps its union weights in LDS): 768p -> 1080p 7.2 -> 6.5, x1.7 18.6 -> 15.8, x1.9 21.2 -> 19.0 us per
+    // frame; from x2.2 up the four-output shape is the faster one again (profiles/r05_resize_win_rotating_window.txt)
+    const bool two_per_lane = 2 * (uint64_t)iw_ > ow_ && widest_footprint(128) <= 128 && widest_union(2) <= 8;
+    if (widest <= 192 && !two_per_lane) {
         variant_ = Variant::ResizeWin;
         return;
     }
-    // factors x1.0 .. x1.4: two outputs per lane, segments of 128 output columns
+    // factors x1.0 .. x2: two outputs per lane, segments of 128 output columns
     const uint32_t widest2 = widest_footprint(128);
     if (widest2 > 192) return;
     variant_ = Variant::ResizeWin;
