@@ -58,20 +58,17 @@ if ROOT not in sys.path:
 
 
 def _install_crash_reports():
-    """faulthandler (Python frames of every thread) and, in front of it, the native backtrace of the thread that raised a fatal
-    signal (tests/helpers/abort_trace.c, test infrastructure, built on demand): a rank that dies says which library aborted."""
+    """faulthandler (Python frames of every thread) and, in front of it, the library's own fatal-signal report
+    (nus_install_fatal_trace: native backtrace of the raising thread, the host ranges the library holds, /proc/self/maps):
+    a rank that dies says which library aborted and where the address in the runtime's last words lies."""
     import faulthandler
 
     faulthandler.enable(file=sys.__stderr__, all_threads=True)
-    try:
-        sys.path.insert(0, os.path.join(ROOT, "tests"))
-        from helpers import abort_trace
+    import torch  # noqa: F401  before the library: torch brings its own HIP runtime and must be the first to load one (no HIP call yet)
 
-        abort_trace.install(2)
-    except Exception:
-        pass
-    finally:
-        sys.path.remove(os.path.join(ROOT, "tests"))
+    import nu_scaler_amd
+
+    nu_scaler_amd.install_fatal_trace(2)  # (loads libnuscaler_hip.so; initialises nothing on the GPU)
 
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
@@ -304,6 +301,7 @@ def check_timed_outputs(frames, mid_t, up_real, up_mid, picks, w, h, first_frame
     import numpy as np
 
     import oracle
+    from nu_scaler_amd.transfer import to_numpy as fetch  # device -> host through nus_download (the product's own road)
 
     oracle.build()
     th = threads or usable_cpus()
@@ -311,19 +309,19 @@ def check_timed_outputs(frames, mid_t, up_real, up_mid, picks, w, h, first_frame
     summary = {"ok": 1.0, "input_ok": 1.0, "mid_exact": 1.0, "max_abs_diff": 0.0, "frac_differing": 0.0, "frames": float(len(picks))}
     for k in picks:
         a, b = oracle.gen_gradient(w, h, first_frame + k), oracle.gen_gradient(w, h, first_frame + k + 1)
-        same_in = bool(np.array_equal(frames[k].cpu().numpy(), a) and np.array_equal(frames[k + 1].cpu().numpy(), b))
+        same_in = bool(np.array_equal(fetch(frames[k]), a) and np.array_equal(fetch(frames[k + 1]), b))
         report.append({"frame": int(k), "stream_frame": int(first_frame + k), "buffer": "input", "bit_exact": same_in})
         if not same_in:
             summary["input_ok"] = summary["ok"] = 0.0
         mid = oracle.warp_blend(a, b, None, 0.5, threads=th)
         if mid_t is not None:
-            same = bool(np.array_equal(mid_t[k].cpu().numpy(), mid))
+            same = bool(np.array_equal(fetch(mid_t[k]), mid))
             report.append({"frame": int(k), "buffer": "mid", "bit_exact": same})
             if not same:
                 summary["mid_exact"] = summary["ok"] = 0.0
         for name, got_t, src in (("up_real", up_real, a), ("up_mid", up_mid, mid)):
             want = oracle.lanczos3(src, 2 * w, 2 * h, threads=th).astype(np.int16)
-            got = got_t[k].cpu().numpy().astype(np.int16)
+            got = fetch(got_t[k]).astype(np.int16)
             d = np.abs(got - want)
             mx, frac = int(d.max()), float((d != 0).mean())
             report.append({"frame": int(k), "buffer": name, "max_abs_diff": mx, "frac_differing": round(frac, 7)})
@@ -742,7 +740,25 @@ def config3_leg(torch, upscaler, frames, up_real, count, stream, seconds, bdf, d
 # one rank
 # ---------------------------------------------------------------------------------------------
 
+class _OneLineStdout:
+    """A rank's stdout is for ONE JSON line (the driver parses it).  Libraries write there too -- RCCL's version banner when rank 0
+    creates its communicator, gloo's "[Gloo] Rank r is connected to n peer ranks" from every rank of an 8-rank job (seen in the
+    world-8 rehearsal, tests/test_bench_launcher.py) -- so for the life of the worker file descriptor 1 points at stderr, and
+    the line goes to a duplicate of the real stdout taken before anything else ran."""
+
+    def __init__(self):
+        sys.stdout.flush()
+        self._fd = os.dup(1)
+        os.dup2(2, 1)
+
+    def emit(self, line: str) -> None:
+        data = (line + "\n").encode()
+        while data:
+            data = data[os.write(self._fd, data):]
+
+
 def worker(args):
+    stdout_line = _OneLineStdout()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -752,9 +768,6 @@ def worker(args):
     device_index = args.force_device if args.force_device >= 0 else local_rank
     nccl = args.backend == "nccl"
     _install_crash_reports()
-    from nu_scaler_amd import hostmem
-
-    hostmem.route_tensor_cpu_through_pinned_staging()  # the output check's device-to-host copies: never the runtime's pageable path
 
     # The rank's whole set-up is the product's (nu_scaler_amd.stream.ShardedStream; `python -m nu_scaler_amd.cli stream` runs the
     # same object): onto the CPUs of its GPU's NUMA node BEFORE the first HIP call, host threads sized to the rank's CPU share,
@@ -1180,7 +1193,7 @@ def worker(args):
                             "HBM-throughput reading of the same launch, next to `frac` (algorithmic bytes, SURVEY.md 8d)"}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, pipe.unit_pixels)
-        print(json.dumps(out), flush=True)
+        stdout_line.emit(json.dumps(out))
     if world > 1:
         barrier()
     sh.close()  # the process group is the ShardedStream's

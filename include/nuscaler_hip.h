@@ -127,7 +127,40 @@ int nus_device_memory_info(int device, uint64_t *free_bytes, uint64_t *total_byt
  * must not be freed or re-allocated while pinned).  Buffers that are not pinned work as before.  The library never pins a
  * caller's buffer by itself: it cannot know when the memory is given back. */
 int nus_host_pin(void *buffer, size_t bytes);
+/* Only a pointer nus_host_pin accepted and that has not been unpinned since (anything else: NUS_ERR_INVALID_ARGUMENT, the runtime
+ * is not asked).  A failing hipHostUnregister is NUS_ERR_HIP and the range stays in the library's record (nus_host_ranges): the
+ * registration may still exist, and a registration that outlives its buffer is exactly what must not go unnoticed. */
 int nus_host_unpin(void *buffer);
+/* The road between HBM and a caller's host buffer for users of the *_device entry points -- what the reference's upscale() does at
+ * its end (map the staging buffer, wait, to_vec: nu_scaler_core/src/upscale/mod.rs:1041-1057) and before its dispatch
+ * (queue.write_buffer, :968-1008).  The host pointer may be pageable: it is NEVER handed to the HIP runtime (whose pageable copies
+ * pin the caller's pages on the fly and cache that registration by address -- a freed and re-used heap block then meets a stale
+ * one; docs/d2h_fault_analysis.md).  The bytes travel through a ring of pinned chunks the library allocates on first use
+ * (4 x 8 MiB per device, kept for the life of the process) and are moved between ring and buffer by the copy threads of the host
+ * path while the next chunk is on the wire.  A pinned host buffer (hipHostMalloc, nus_host_pin) is copied to / from directly.
+ *   nus_download: ordered after the work already enqueued on `stream`; returns when host_dst holds the bytes.
+ *   nus_upload:   returns when host_src may be re-used; the device bytes are in place for work enqueued on `stream` afterwards.
+ * `stream`: a hipStream_t of the device that owns the device pointer (NULL: its null stream).  Concurrent transfers on one device
+ * take turns.  NUS_ERR_INVALID_ARGUMENT for null pointers or a device pointer the runtime does not know as device memory. */
+int nus_download(void *host_dst, const void *d_src, size_t bytes, void *stream);
+int nus_upload(void *d_dst, const void *host_src, size_t bytes, void *stream);
+/* Diagnostics (not in the reference).  The host ranges the library has registered with the runtime (nus_host_pin), allocated as
+ * pinned memory itself (slots, staging, the transfer ring) or left a transparent-huge-page hint on (fresh result buffers of the
+ * host path).  history = 0: the live entries; 1: the last <= 128 events, oldest first (op 1 = added, 0 = removed).
+ * Returns the number of records written (<= cap). */
+typedef struct nus_host_range {
+    uint64_t seq;  /* order of the event, process-wide, from 1 */
+    uintptr_t lo;  /* first byte */
+    uintptr_t hi;  /* one past the last byte */
+    uint32_t kind; /* 1 pinned by the caller (nus_host_pin), 2 hipHostMalloc by the library, 3 MADV_HUGEPAGE hint */
+    uint32_t op;
+} nus_host_range;
+size_t nus_host_ranges(nus_host_range *out, size_t cap, int history);
+/* On SIGABRT / SIGSEGV / SIGBUS / SIGILL / SIGFPE write, to a duplicate of descriptor `fd` and with async-signal-safe calls only:
+ * the native backtrace of the raising thread (which library called abort()), the ranges above, and /proc/self/maps -- then hand
+ * over to the handler that was installed before (or the default action).  Off unless called; idempotent.  A GPU page fault
+ * reaches a process as ROCr's abort() with an address in its message: this is what lets that address be placed afterwards. */
+int nus_install_fatal_trace(int fd);
 /* Calibration of the box a measurement runs on (not in the reference; bench.py's denominators next to the 8 TB/s spec figure --
  * SURVEY.md section 8(d) "on-box copy ceiling" -- never on the product path).  Enqueues ONE plain kernel (or the runtime's
  * copy) on `stream`; the caller brackets it with events.  kind: 0 hipMemcpyDtoDAsync of `bytes`; 1 stream copy, 16 B per lane,

@@ -39,6 +39,10 @@ SIGNATURES = [
     ("nus_device_memory_info", _i, [_i, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64)]),
     ("nus_host_pin", _i, [_vp, _sz]),
     ("nus_host_unpin", _i, [_vp]),
+    ("nus_download", _i, [_vp, _vp, _sz, _vp]),
+    ("nus_upload", _i, [_vp, _vp, _sz, _vp]),
+    ("nus_host_ranges", _sz, [_vp, _sz, _i]),
+    ("nus_install_fatal_trace", _i, [_i]),
     ("nus_last_error", _cp, []),
     ("nus_status_string", _cp, [_i]),
     ("nus_upscaler_create", _vp, [_i, _i]),
@@ -220,9 +224,13 @@ class PinnedBuffer:
             raise RuntimeError(last_error())
 
     def unpin(self) -> None:
-        addr, self._addr = self._addr, None
+        """Raises if the runtime refuses: a registration that outlives its buffer must not go unnoticed (the buffer is kept
+        alive by this object in that case)."""
+        addr = self._addr
         if addr is not None:
-            lib().nus_host_unpin(addr)
+            if lib().nus_host_unpin(addr) != OK:
+                raise RuntimeError(last_error())
+            self._addr = None
             self._arr = None
 
     def __enter__(self):
@@ -232,7 +240,4 @@ class PinnedBuffer:
         self.unpin()
 
     def __del__(self):
-        try:
-            self.unpin()
-        except Exception:
-            pass
+        self.unpin()  # (a failure here is printed by the interpreter as "Exception ignored in ...": loud on purpose)

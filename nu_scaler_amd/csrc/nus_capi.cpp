@@ -10,6 +10,8 @@
 #include "nus_flow.hpp"
 #include "nus_host.hpp"
 #include "nus_queue.hpp"
+#include "nus_ranges.hpp"
+#include "nus_transfer.hpp"
 
 struct nus_upscaler {
     nus::HipUpscaler impl;
@@ -104,6 +106,7 @@ int nus_host_pin(void *buffer, size_t bytes)
             nus::set_thread_error(std::string("nus_host_pin: hipHostRegister failed: ") + hipGetErrorString(e));
             return e == hipErrorOutOfMemory ? NUS_ERR_OUT_OF_MEMORY : NUS_ERR_HIP;
         }
+        nus::range_note(nus::kRangePinned, buffer, bytes);
         return NUS_OK;
     });
 }
@@ -115,14 +118,29 @@ int nus_host_unpin(void *buffer)
             nus::set_thread_error("nus_host_unpin: null buffer");
             return NUS_ERR_INVALID_ARGUMENT;
         }
+        if (!nus::range_is_live(nus::kRangePinned, buffer)) {
+            nus::set_thread_error("nus_host_unpin: this pointer is not the start of a buffer pinned with nus_host_pin");
+            return NUS_ERR_INVALID_ARGUMENT;
+        }
         const hipError_t e = hipHostUnregister(buffer);
-        if (e != hipSuccess) {
+        if (e != hipSuccess) { // the entry stays in the record: the registration may still exist
             (void)hipGetLastError();
             nus::set_thread_error(std::string("nus_host_unpin: hipHostUnregister failed: ") + hipGetErrorString(e));
             return NUS_ERR_HIP;
         }
+        nus::range_forget(nus::kRangePinned, buffer);
         return NUS_OK;
     });
+}
+
+int nus_download(void *host_dst, const void *d_src, size_t bytes, void *stream)
+{
+    return guarded<int>("nus_download", [&]() -> int { return nus::download(host_dst, d_src, bytes, static_cast<hipStream_t>(stream)); });
+}
+
+int nus_upload(void *d_dst, const void *host_src, size_t bytes, void *stream)
+{
+    return guarded<int>("nus_upload", [&]() -> int { return nus::upload(d_dst, host_src, bytes, static_cast<hipStream_t>(stream)); });
 }
 
 int nus_device_memory_info(int device, uint64_t *free_bytes, uint64_t *total_bytes)

@@ -7,6 +7,7 @@
 
 #include "nus_host.hpp"
 #include "nus_kernels.hpp"
+#include "nus_transfer.hpp"
 
 namespace nus {
 
@@ -26,6 +27,14 @@ int device_count_()
     do {                                                  \
         hipError_t e_ = (call);                           \
         if (e_ != hipSuccess) return fail_hip(e_, #call); \
+    } while (0)
+
+// The host entry points move their images through the library's own pinned ring (nus_transfer.hpp): a caller's pageable
+// buffer is never handed to the runtime's copy.
+#define NUS_XFER(call)                                        \
+    do {                                                      \
+        const int x_ = (call);                                \
+        if (x_ != kOk) return fail(x_, thread_error());       \
     } while (0)
 
 HipFlowEstimator::~HipFlowEstimator() { release(); }
@@ -124,9 +133,9 @@ int HipFlowEstimator::rgba8_to_f32(const uint8_t *in, uint32_t w, uint32_t h, fl
     if (rc != kOk) return rc;
     const size_t npx = (size_t)w * h;
     if ((rc = reserve(npx * 4, 0)) != kOk || (rc = reserve(npx * 16, 1)) != kOk) return rc;
-    NUS_HIP(hipMemcpyAsync(slot_[0], in, npx * 4, hipMemcpyHostToDevice, stream_));
+    NUS_XFER(upload(slot_[0], in, npx * 4, stream_));
     NUS_HIP(launch_rgba8_to_f32(static_cast<const uint8_t *>(slot_[0]), static_cast<float *>(slot_[1]), w, h, stream_));
-    NUS_HIP(hipMemcpyAsync(out, slot_[1], npx * 16, hipMemcpyDeviceToHost, stream_));
+    NUS_XFER(download(out, slot_[1], npx * 16, stream_));
     NUS_HIP(hipStreamSynchronize(stream_));
     return kOk;
 }
@@ -141,10 +150,10 @@ int HipFlowEstimator::blur(const float *in, uint32_t w, uint32_t h, float *out)
     const size_t bytes = (size_t)w * h * 16;
     if ((rc = reserve(bytes, 0)) != kOk || (rc = reserve(bytes, 1)) != kOk) return rc;
     float *d0 = static_cast<float *>(slot_[0]), *d1 = static_cast<float *>(slot_[1]);
-    NUS_HIP(hipMemcpyAsync(d0, in, bytes, hipMemcpyHostToDevice, stream_));
+    NUS_XFER(upload(d0, in, bytes, stream_));
     NUS_HIP(launch_blur(d0, d1, w, h, true, stream_));
     NUS_HIP(launch_blur(d1, d0, w, h, false, stream_));
-    NUS_HIP(hipMemcpyAsync(out, d0, bytes, hipMemcpyDeviceToHost, stream_));
+    NUS_XFER(download(out, d0, bytes, stream_));
     NUS_HIP(hipStreamSynchronize(stream_));
     return kOk;
 }
@@ -158,9 +167,9 @@ int HipFlowEstimator::downsample(const float *in, uint32_t w, uint32_t h, float 
     if (rc != kOk) return rc;
     const size_t bytes = (size_t)w * h * 16, obytes = (size_t)((w + 1) / 2) * ((h + 1) / 2) * 16;
     if ((rc = reserve(bytes, 0)) != kOk || (rc = reserve(obytes, 1)) != kOk) return rc;
-    NUS_HIP(hipMemcpyAsync(slot_[0], in, bytes, hipMemcpyHostToDevice, stream_));
+    NUS_XFER(upload(slot_[0], in, bytes, stream_));
     NUS_HIP(launch_downsample(static_cast<const float *>(slot_[0]), static_cast<float *>(slot_[1]), w, h, stream_));
-    NUS_HIP(hipMemcpyAsync(out, slot_[1], obytes, hipMemcpyDeviceToHost, stream_));
+    NUS_XFER(download(out, slot_[1], obytes, stream_));
     NUS_HIP(hipStreamSynchronize(stream_));
     return kOk;
 }
@@ -177,10 +186,10 @@ int HipFlowEstimator::horn_schunck(const float *i1, const float *i2, const float
     if ((rc = reserve(ib, 0)) != kOk || (rc = reserve(ib, 1)) != kOk || (rc = reserve(fb, 2)) != kOk ||
         (rc = reserve(fb, 3)) != kOk)
         return rc;
-    NUS_HIP(hipMemcpyAsync(slot_[0], i1, ib, hipMemcpyHostToDevice, stream_));
-    NUS_HIP(hipMemcpyAsync(slot_[1], i2, ib, hipMemcpyHostToDevice, stream_));
+    NUS_XFER(upload(slot_[0], i1, ib, stream_));
+    NUS_XFER(upload(slot_[1], i2, ib, stream_));
     if (flow_in)
-        NUS_HIP(hipMemcpyAsync(slot_[2], flow_in, fb, hipMemcpyHostToDevice, stream_));
+        NUS_XFER(upload(slot_[2], flow_in, fb, stream_));
     else
         NUS_HIP(hipMemsetAsync(slot_[2], 0, fb, stream_)); // compute_coarse_flow clears the flow (:1136-1154)
     float *f0 = static_cast<float *>(slot_[2]), *f1 = static_cast<float *>(slot_[3]);
@@ -197,7 +206,7 @@ int HipFlowEstimator::horn_schunck(const float *i1, const float *i2, const float
             f1 = t;
         }
     }
-    NUS_HIP(hipMemcpyAsync(flow_out, f0, fb, hipMemcpyDeviceToHost, stream_));
+    NUS_XFER(download(flow_out, f0, fb, stream_));
     NUS_HIP(hipStreamSynchronize(stream_));
     return kOk;
 }
@@ -212,9 +221,9 @@ int HipFlowEstimator::upsample(const float *src, uint32_t sw, uint32_t sh, float
     if (rc != kOk) return rc;
     const size_t sb = (size_t)sw * sh * 8, db = (size_t)dw * dh * 8;
     if ((rc = reserve(sb, 2)) != kOk || (rc = reserve(db, 3)) != kOk) return rc;
-    NUS_HIP(hipMemcpyAsync(slot_[2], src, sb, hipMemcpyHostToDevice, stream_));
+    NUS_XFER(upload(slot_[2], src, sb, stream_));
     NUS_HIP(launch_flow_upsample(static_cast<const float *>(slot_[2]), sw, sh, static_cast<float *>(slot_[3]), dw, dh, scale, stream_));
-    NUS_HIP(hipMemcpyAsync(dst, slot_[3], db, hipMemcpyDeviceToHost, stream_));
+    NUS_XFER(download(dst, slot_[3], db, stream_));
     NUS_HIP(hipStreamSynchronize(stream_));
     return kOk;
 }
@@ -602,15 +611,15 @@ int HipFlowEstimator::estimate(const uint8_t *a, const uint8_t *b, uint32_t w, u
         if (rc != kOk) return rc;
         const size_t fbytes = (size_t)w * h * 4;
         if ((rc = reserve(fbytes, 6)) != kOk || (rc = reserve(fbytes > (size_t)w * h * 8 ? fbytes : (size_t)w * h * 8, 7)) != kOk) return rc;
-        NUS_HIP(hipMemcpyAsync(slot_[6], a, fbytes, hipMemcpyHostToDevice, stream_));
-        NUS_HIP(hipMemcpyAsync(slot_[7], b, fbytes, hipMemcpyHostToDevice, stream_));
+        NUS_XFER(upload(slot_[6], a, fbytes, stream_));
+        NUS_XFER(upload(slot_[7], b, fbytes, stream_));
     }
     // slot 7 doubles as the flow output once frame B has been converted (estimate_device copies
     // into it last, after every reader of frame B has been enqueued on the same stream)
     int rc = estimate_device(slot_[6], slot_[7], w, h, levels, coarse_iters, refine_iters, lambda, slot_[7], stream_);
     if (rc != kOk) return rc;
     std::lock_guard<std::mutex> lk(mu_);
-    NUS_HIP(hipMemcpyAsync(flow_out, slot_[7], (size_t)w * h * 8, hipMemcpyDeviceToHost, stream_));
+    NUS_XFER(download(flow_out, slot_[7], (size_t)w * h * 8, stream_));
     NUS_HIP(hipStreamSynchronize(stream_));
     return kOk;
 }

@@ -971,8 +971,8 @@ int HipUpscaler::ensure_slot(Slot &S, size_t in_bytes, size_t out_bytes)
         for (hipEvent_t &ev : S.chunk_done) NUS_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
         for (hipEvent_t &ev : S.band_in) NUS_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
         for (hipEvent_t &ev : S.band_k) NUS_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-        NUS_HIP(hipHostMalloc(reinterpret_cast<void **>(&S.h_in), in_bytes, hipHostMallocDefault));
-        NUS_HIP(hipHostMalloc(reinterpret_cast<void **>(&S.h_out), out_bytes, hipHostMallocDefault));
+        NUS_HIP(pinned_alloc(reinterpret_cast<void **>(&S.h_in), in_bytes));
+        NUS_HIP(pinned_alloc(reinterpret_cast<void **>(&S.h_out), out_bytes));
         NUS_HIP(hipMalloc(reinterpret_cast<void **>(&S.d_out), out_bytes));
         NUS_HIP(hipMalloc(reinterpret_cast<void **>(&S.d_in), in_bytes)); // last: d_in set = the slot is complete
         return kOk;
@@ -989,8 +989,8 @@ void HipUpscaler::release_slot(Slot &s)
     parallel_copy_wait(s.populate); // the pool holds a pointer to this ticket for every request still queued under it
     if (s.d_in) (void)hipFree(s.d_in);
     if (s.d_out) (void)hipFree(s.d_out);
-    if (s.h_in) (void)hipHostFree(s.h_in);
-    if (s.h_out) (void)hipHostFree(s.h_out);
+    pinned_free(s.h_in);
+    pinned_free(s.h_out);
     for (hipEvent_t ev : {s.k_begin, s.k_end, s.in_done, s.out_done})
         if (ev) (void)hipEventDestroy(ev);
     for (hipEvent_t ev : s.chunk_done)

@@ -58,8 +58,8 @@ void HipFrameInterpolator::release()
     if (d_b_) (void)hipFree(d_b_);
     if (d_out_) (void)hipFree(d_out_);
     if (d_flow_) (void)hipFree(d_flow_);
-    if (h_stage_) (void)hipHostFree(h_stage_);
-    if (h_flow_) (void)hipHostFree(h_flow_);
+    pinned_free(h_stage_);
+    pinned_free(h_flow_);
     d_a_ = d_b_ = d_out_ = nullptr;
     d_flow_ = nullptr;
     h_stage_ = nullptr;
@@ -91,10 +91,10 @@ int HipFrameInterpolator::ensure(size_t frame_bytes, bool with_flow)
         NUS_HIP(hipMalloc(reinterpret_cast<void **>(&d_a_), want));
         NUS_HIP(hipMalloc(reinterpret_cast<void **>(&d_b_), want));
         NUS_HIP(hipMalloc(reinterpret_cast<void **>(&d_out_), want));
-        NUS_HIP(hipHostMalloc(reinterpret_cast<void **>(&h_stage_), want * 3, hipHostMallocDefault));
+        NUS_HIP(pinned_alloc(reinterpret_cast<void **>(&h_stage_), want * 3));
         if (flow) {
             NUS_HIP(hipMalloc(reinterpret_cast<void **>(&d_flow_), want * 2));
-            NUS_HIP(hipHostMalloc(reinterpret_cast<void **>(&h_flow_), want * 2, hipHostMallocDefault));
+            NUS_HIP(pinned_alloc(reinterpret_cast<void **>(&h_flow_), want * 2));
         }
         cap_bytes_ = want;
         cap_flow_ = flow;

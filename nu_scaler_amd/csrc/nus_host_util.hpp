@@ -7,6 +7,8 @@
 #include <cstdio>
 #include <string>
 
+#include "nus_ranges.hpp"
+
 namespace nus {
 
 namespace {
@@ -32,6 +34,21 @@ bool is_pinned_host(const void *p)
         return false;
     }
     return attr.type == hipMemoryTypeHost;
+}
+
+// hipHostMalloc / hipHostFree that keep the library's record of its own pinned memory (nus_ranges.hpp)
+hipError_t pinned_alloc(void **p, size_t bytes)
+{
+    const hipError_t e = hipHostMalloc(p, bytes, hipHostMallocDefault);
+    if (e == hipSuccess) range_note(kRangeHostAlloc, *p, bytes);
+    return e;
+}
+
+void pinned_free(void *p)
+{
+    if (!p) return;
+    range_forget(kRangeHostAlloc, p);
+    (void)hipHostFree(p);
 }
 
 int device_count()

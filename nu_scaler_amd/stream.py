@@ -14,6 +14,7 @@ from __future__ import annotations
 
 from typing import Tuple
 
+from . import transfer
 from .interpolator import WgpuFrameInterpolator
 from .upscaler import PyWgpuUpscaler
 
@@ -72,13 +73,17 @@ def broadcast_blob(blob, src: int = 0, device=None, force: bool = False) -> byte
     n = torch.tensor([len(blob) if rank == src else 0], dtype=torch.int64, device=device)
     dist.broadcast(n, src)
     size = int(n.item())
+    on_gpu = device is not None and torch.device(device).type == "cuda"
     if rank == src:
         t = torch.frombuffer(bytearray(blob), dtype=torch.uint8)
-        t = t.to(device) if device is not None else t
+        if on_gpu:  # (host <-> HBM through the library's pinned ring, never the runtime's pageable copy: transfer.py)
+            t = transfer.to_device(t, device)
+        elif device is not None:
+            t = t.to(device)
     else:
         t = torch.empty(size, dtype=torch.uint8, device=device)
     dist.broadcast(t, src)
-    return t.cpu().numpy().tobytes()
+    return transfer.to_numpy(t).tobytes()
 
 
 def broadcast_tables(upscaler: PyWgpuUpscaler, src: int = 0, device=None, force: bool = False) -> int:

@@ -2,6 +2,7 @@
 // copies of random sizes and alignments from several threads at once, every result compared with the source;
 // then the same from a forked child.
 #include "nus_copy.hpp"
+#include "nus_ranges.hpp"
 
 #include <atomic>
 #include <cstdint>
@@ -179,6 +180,36 @@ int main()
     }
     int status = 0;
     if (pid < 0 || waitpid(pid, &status, 0) != pid || !WIFEXITED(status) || WEXITSTATUS(status) != 0) ++bad;
+    // the record of host ranges (nus_ranges.hpp): four threads note and forget at once; afterwards exactly the entries that were
+    // not forgotten are live, each found by its start address, and the history holds the last events in order
+    {
+        auto ranges = [&](int id) {
+            for (uintptr_t i = 0; i < 200; ++i) {
+                void *p = reinterpret_cast<void *>(((uintptr_t)(id + 1) << 32) + (i << 12));
+                if (!nus::range_note(nus::kRangePinned, p, 4096)) BAD();
+                if (!nus::range_is_live(nus::kRangePinned, p)) BAD();
+                if (nus::range_is_live(nus::kRangeHostAlloc, p)) BAD(); // another kind at the same address is another entry
+                if (i % 8 != 0 && !nus::range_forget(nus::kRangePinned, p)) BAD();
+                if (i % 8 != 0 && nus::range_forget(nus::kRangePinned, p)) BAD(); // twice: the second finds nothing
+            }
+        };
+        std::vector<std::thread> rt;
+        for (int t = 0; t < 4; ++t) rt.emplace_back(ranges, t);
+        for (auto &t : rt) t.join();
+        static nus::RangeRecord recs[256];
+        const size_t live = nus::range_live_snapshot(recs, 256);
+        if (live != 4 * 25 || nus::range_overflowed()) BAD();
+        for (size_t i = 0; i < live; ++i)
+            if (recs[i].kind != nus::kRangePinned || recs[i].hi - recs[i].lo != 4096 || ((recs[i].lo >> 12) & 7) != 0) BAD();
+        const size_t hist = nus::range_history_snapshot(recs, 256);
+        if (hist == 0 || hist > 128) BAD();
+        for (size_t i = 1; i < hist; ++i)
+            if (recs[i].seq == recs[i - 1].seq) BAD();
+        size_t taken = live; // fill the table (256 slots): one note more is refused, and the record says it is incomplete
+        for (uintptr_t i = 0; taken < 256; ++i, ++taken)
+            if (!nus::range_note(nus::kRangeHostAlloc, reinterpret_cast<void *>((uintptr_t)9 << 40 | i << 12), 4096)) BAD();
+        if (nus::range_note(nus::kRangeHostAlloc, reinterpret_cast<void *>((uintptr_t)10 << 40), 4096) || !nus::range_overflowed()) BAD();
+    }
     printf("workers %d bad %d\n", nus::parallel_copy_workers(), bad.load());
     return bad.load() == 0 ? 0 : 1;
 }

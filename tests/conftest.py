@@ -11,8 +11,8 @@ except Exception:  # pragma: no cover
 # Round 4: one full GPU run died of SIGABRT with nothing but "Fatal Python error: Aborted" in its log.  Why nothing: pytest's
 # fd-level capture holds file descriptor 2 while a test runs, so whatever the aborting runtime said (glibc, ROCr, libstdc++ all
 # write to fd 2) went into a capture file that died with the process.  pytest.ini now runs the suite with --capture=sys, and the
-# handler installed below (tests/helpers/abort_trace.c) writes the NATIVE backtrace of the aborting thread -- which library
-# called abort -- in front of faulthandler's Python frames.  (LIBC_FATAL_STDERR_ only matters to glibc < 2.27; kept for those.)
+# handler installed below (the library's nus_install_fatal_trace) writes the NATIVE backtrace of the aborting thread -- which
+# library called abort --, the host ranges the library holds and /proc/self/maps in front of faulthandler's Python frames.  (LIBC_FATAL_STDERR_ only matters to glibc < 2.27; kept for those.)
 os.environ.setdefault("LIBC_FATAL_STDERR_", "1")
 import faulthandler  # noqa: E402
 
@@ -32,14 +32,14 @@ def pytest_configure(config):
 
 def pytest_sessionstart(session):
     # after every plugin's configure step (pytest's own faulthandler plugin included): outermost handler, real stderr
-    from helpers import abort_trace
+    import nu_scaler_amd
 
-    abort_trace.install(2)
-    # Tensor.cpu() of frame-sized CUDA tensors through pinned staging: the HIP runtime's device-to-host copy into PAGEABLE memory is
-    # what died twice in long test sessions (ROCr: "Write access to a read-only page" at a brk-heap address; nu_scaler_amd/hostmem.py)
-    from nu_scaler_amd import hostmem
-
-    hostmem.route_tensor_cpu_through_pinned_staging()
+    if os.path.exists(nu_scaler_amd._capi.LIB_PATH):
+        nu_scaler_amd.install_fatal_trace(2)
+    # Device tensors come down through nu_scaler_amd.transfer.to_numpy (`fetch` in the test modules: nus_download, the product's
+    # own road), never Tensor.cpu(): the HIP runtime's copy into PAGEABLE memory is what died twice in long test sessions
+    # (ROCr: "Write access to a read-only page" at a brk-heap address; docs/d2h_fault_analysis.md).  tests/test_no_tensor_cpu.py
+    # keeps it that way.
 
 
 @pytest.fixture(scope="session")

@@ -29,6 +29,8 @@ def main():
         import numpy as np
 
         import nu_scaler_amd as nsc
+
+    fetch = nsc.transfer.to_numpy  # device -> host through nus_download, never Tensor.cpu() (docs/d2h_fault_analysis.md)
         import oracle
 
         oracle.build()
@@ -48,8 +50,8 @@ def main():
         torch.cuda.synchronize()
         worst, differing = 0, 0.0
         for k in range(n):
-            want = oracle.lanczos3(frames[k].cpu().numpy(), 2 * w, 2 * h, threads=0).astype(np.int16)
-            d = np.abs(out[k].cpu().numpy().astype(np.int16) - want)
+            want = oracle.lanczos3(fetch(frames[k]), 2 * w, 2 * h, threads=0).astype(np.int16)
+            d = np.abs(fetch(out[k]).astype(np.int16) - want)
             worst, differing = max(worst, int(d.max())), max(differing, float((d != 0).mean()))
         t = torch.tensor([float(worst)], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)  # one more collective kind through RCCL

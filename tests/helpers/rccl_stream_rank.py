@@ -15,6 +15,8 @@ sys.path.insert(0, ROOT)
 
 def main():
     import nu_scaler_amd as nsc
+
+    fetch = nsc.transfer.to_numpy  # device -> host through nus_download, never Tensor.cpu() (docs/d2h_fault_analysis.md)
     import oracle
 
     oracle.build()
@@ -28,9 +30,9 @@ def main():
         for k in (0, s.count - 1):
             a, b = oracle.gen_gradient(w, h, s.start + k), oracle.gen_gradient(w, h, s.start + k + 1)
             m = oracle.warp_blend(a, b, None, 0.5, threads=0)
-            ok = np.array_equal(s.mid[k].cpu().numpy(), m)
+            ok = np.array_equal(fetch(s.mid[k]), m)
             for got, src in ((s.up_real, a), (s.up_mid, m)):
-                d = np.abs(got[k].cpu().numpy().astype(np.int16) - oracle.lanczos3(src, 2 * w, 2 * h, threads=0).astype(np.int16))
+                d = np.abs(fetch(got[k]).astype(np.int16) - oracle.lanczos3(src, 2 * w, 2 * h, threads=0).astype(np.int16))
                 ok = ok and d.max() <= 1 and (d > 0).mean() < 1e-3
             bad += 0 if ok else 1
         with open("/proc/self/maps") as f:

@@ -13,10 +13,14 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 def main():
     world = int(os.environ["WORLD_SIZE"])
     rank = int(os.environ["RANK"])
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    try:
-        import nu_scaler_amd as nsc
+    import nu_scaler_amd as nsc
 
+    # as the product creates its group (ShardedStream): whatever the backend prints while it connects -- RCCL's version banner,
+    # gloo's "[Gloo] Rank r is connected to n peer ranks" -- goes to stderr; the job's stdout is for rank 0's ONE JSON line
+    with nsc.stream._StdoutToStderr():
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        dist.barrier()
+    try:
         blob = nsc.build_tables_blob(64, 36, 128, 72) if rank == 0 else b""
         got = nsc.broadcast_blob(blob, src=0)
         t = torch.tensor([float(rank + 1)], dtype=torch.float64)

@@ -38,6 +38,28 @@ def test_launch_ranks_world2_gloo_relays_rank0_json(nsc):
     assert all(r["cpus_per_rank"] >= 1 for r in rows)
 
 
+def test_launch_ranks_world8_gloo_every_by_rank_list_has_eight_entries(nsc):
+    """the launcher and the gather with WORLD_SIZE = 8 on the CPU -- stdout is exactly ONE JSON line (what
+    the driver parses), every per-rank list in it has eight entries in rank order, the shard arithmetic covers 80 frames without
+    gap or overlap, the LUT reached everybody, and the copy pool of a rank with an eighth of this box's CPUs has no workers."""
+    bench = _bench()
+    rc, lines = bench.launch_ranks(8, STUB, ["--steps", "2"], timeout=600)
+    assert rc == 0
+    text = [ln for ln in lines if ln.strip()]
+    assert len(text) == 1 and text[0].startswith("{"), text[:6]
+    out = json.loads(text[0])
+    assert out["n_gpus"] == 8 and out["max"] == 8.0 and out["shard"] == [0, 10]
+    assert out["lut"] == len(nsc.build_tables_blob(64, 36, 128, 72))
+    rows = out["rows"]
+    assert len(rows) == 8 and [r["first_frame"] for r in rows] == [10.0 * r for r in range(8)]
+    assert [r["elapsed_s"] for r in rows] == [1.0 + r for r in range(8)]
+    for key in ("elapsed", "sclk"):
+        assert len(out[key]["by_rank"]) == 8, key
+    assert out["elapsed"] == {"min": 1.0, "max": 8.0, "by_rank": [1.0 + r for r in range(8)]}
+    assert out["sclk"]["by_rank"] == [2100.0] + [None] * 7
+    assert all(r["cpus_per_rank"] >= 1 for r in rows)
+
+
 def test_launch_ranks_propagates_failure():
     bench = _bench()
     rc, _ = bench.launch_ranks(2, STUB, ["--fail"], timeout=300)

@@ -2,6 +2,8 @@
 HIP kernels against the oracle on GPU.  No reference fixture pins this row."""
 import numpy as np
 import pytest
+from nu_scaler_amd.transfer import to_device as put, to_numpy as fetch  # host <-> HBM through nus_upload / nus_download, never
+# torch's pageable copies (docs/d2h_fault_analysis.md)
 
 
 def _smooth(w, h, shift=0.0):
@@ -164,19 +166,19 @@ def test_flow_estimate_device_path(nsc, oracle_mod):
     w, h = 160, 90
     a, b = _smooth(w, h, 0.0), _smooth(w, h, 1.5)
     dev = torch.device("cuda:0")
-    da, db = torch.from_numpy(a).to(dev), torch.from_numpy(b).to(dev)
+    da, db = put(a), put(b)
     dflow = torch.empty((h, w, 2), dtype=torch.float32, device=dev)
     fe = nsc.FlowEstimator(levels=4, coarse_iterations=30, refine_iterations=8)
     fe.estimate_device(da.data_ptr(), db.data_ptr(), w, h, dflow.data_ptr(), torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
-    assert np.array_equal(dflow.cpu().numpy(), oracle_mod.flow_estimate(a, b, 4, 30, 8, fe.lambda_))
+    assert np.array_equal(fetch(dflow), oracle_mod.flow_estimate(a, b, 4, 30, 8, fe.lambda_))
     # and straight into the warp on the device
     it = nsc.WgpuFrameInterpolator()
     out = torch.empty((h, w, 4), dtype=torch.uint8, device=dev)
     it.interpolate_device(da.data_ptr(), w * h * 4, db.data_ptr(), w * h * 4, dflow.data_ptr(), w, h, 0.5, out.data_ptr(), 1,
                           torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
-    assert np.array_equal(out.cpu().numpy(), oracle_mod.warp_blend(a, b, dflow.cpu().numpy(), 0.5))
+    assert np.array_equal(fetch(out), oracle_mod.warp_blend(a, b, fetch(dflow), 0.5))
 
 
 @pytest.mark.gpu
@@ -190,7 +192,7 @@ def test_flow_estimate_device_stream_equals_pairwise(nsc, oracle_mod, n_frames):
     w, h = 97, 45
     frames = np.stack([oracle_mod.gen_noise(w, h, 60 + k) for k in range(n_frames)])
     dev = torch.device("cuda:0")
-    d_frames = torch.from_numpy(frames).to(dev)
+    d_frames = put(frames)
     d_flows = torch.full((n_frames - 1, h, w, 2), float("nan"), dtype=torch.float32, device=dev)
     fe = nsc.FlowEstimator(levels=3, coarse_iterations=9, refine_iterations=3)
     want = [oracle_mod.flow_estimate(frames[k], frames[k + 1], 3, 9, 3, fe.lambda_) for k in range(n_frames - 1)]
@@ -199,7 +201,7 @@ def test_flow_estimate_device_stream_equals_pairwise(nsc, oracle_mod, n_frames):
         d_flows.fill_(float("nan"))
         fe.estimate_device_stream(d_frames.data_ptr(), n_frames, w, h, d_flows.data_ptr(), torch.cuda.current_stream().cuda_stream)
         torch.cuda.synchronize()
-        got = d_flows.cpu().numpy()
+        got = fetch(d_flows)
         for k in range(n_frames - 1):
             assert np.array_equal(got[k], want[k]), (k, tiled)
     with pytest.raises(Exception):
@@ -215,12 +217,12 @@ def test_flow_estimate_device_stream_big_batch(nsc, oracle_mod):
     w, h, n_frames = 333, 262, 13
     frames = np.stack([oracle_mod.gen_noise(w, h, 90 + k) for k in range(n_frames)])
     dev = torch.device("cuda:0")
-    d_frames = torch.from_numpy(frames).to(dev)
+    d_frames = put(frames)
     d_flows = torch.full((n_frames - 1, h, w, 2), float("nan"), dtype=torch.float32, device=dev)
     fe = nsc.FlowEstimator(levels=3, coarse_iterations=7, refine_iterations=6)
     fe.estimate_device_stream(d_frames.data_ptr(), n_frames, w, h, d_flows.data_ptr(), torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
-    got = d_flows.cpu().numpy()
+    got = fetch(d_flows)
     for k in range(n_frames - 1):
         assert np.array_equal(got[k], oracle_mod.flow_estimate(frames[k], frames[k + 1], 3, 7, 6, fe.lambda_)), k
 
@@ -234,7 +236,7 @@ def test_pipeline_step_motion_matches_stage_by_stage_oracle(nsc, oracle_mod):
     w, h, n = 160, 96, 3
     frames = np.stack([_smooth(w, h, 1.5 * k) for k in range(n + 1)])
     dev = torch.device("cuda:0")
-    d_frames = torch.from_numpy(frames).to(dev)
+    d_frames = put(frames)
     pipe = nsc.FramePipeline(w, h, 2, "lanczos3", 0.5, lanczos_mode="exact")
     mid, up_real, up_mid = pipe.alloc(n, dev)
     flows = torch.empty((n, h, w, 2), dtype=torch.float32, device=dev)
@@ -244,11 +246,11 @@ def test_pipeline_step_motion_matches_stage_by_stage_oracle(nsc, oracle_mod):
     lam = pipe._flow.lambda_
     for k in range(n):
         want_flow = oracle_mod.flow_estimate(frames[k], frames[k + 1], 3, 20, 5, lam)
-        assert np.array_equal(flows[k].cpu().numpy(), want_flow), k
+        assert np.array_equal(fetch(flows[k]), want_flow), k
         want_mid = oracle_mod.warp_blend(frames[k], frames[k + 1], want_flow, 0.5)
-        assert np.array_equal(mid[k].cpu().numpy(), want_mid), k
-        assert np.array_equal(up_mid[k].cpu().numpy(), oracle_mod.lanczos3(want_mid, 2 * w, 2 * h)), k
-        assert np.array_equal(up_real[k].cpu().numpy(), oracle_mod.lanczos3(frames[k], 2 * w, 2 * h)), k
+        assert np.array_equal(fetch(mid[k]), want_mid), k
+        assert np.array_equal(fetch(up_mid[k]), oracle_mod.lanczos3(want_mid, 2 * w, 2 * h)), k
+        assert np.array_equal(fetch(up_real[k]), oracle_mod.lanczos3(frames[k], 2 * w, 2 * h)), k
     # the same step as a two-stream pipeline over chunks (the estimator of chunk i+1 beside warp + upscales of chunk i): same bytes
     want = [t.clone() for t in (flows, mid, up_real, up_mid)]
     for chunk in (1, 2):
@@ -288,7 +290,7 @@ def test_flow_fast_mode_within_a_thousandth_of_a_pixel(nsc, oracle_mod, w, h, le
         fe.set_mode("fast")
         assert fe.mode == "fast"
         want = [oracle_mod.flow_estimate(frames[k], frames[k + 1], levels, coarse, refine, fe.lambda_) for k in range(n_frames - 1)]
-        d_frames = torch.from_numpy(frames).to(dev)
+        d_frames = put(frames)
         d_flows = torch.full((n_frames - 1, h, w, 2), float("nan"), dtype=torch.float32, device=dev)
         s = torch.cuda.current_stream().cuda_stream
         # kernels by size (1): a batch this small takes the exact LDS-tile kernels, whose result meets the contract trivially;
@@ -298,7 +300,7 @@ def test_flow_fast_mode_within_a_thousandth_of_a_pixel(nsc, oracle_mod, w, h, le
             d_flows.fill_(float("nan"))
             fe.estimate_device_stream(d_frames.data_ptr(), n_frames, w, h, d_flows.data_ptr(), s)
             torch.cuda.synchronize()
-            got = d_flows.cpu().numpy()
+            got = fetch(d_flows)
             assert np.isfinite(got).all()
             for k in range(n_frames - 1):
                 ok, mx = _flow_close(got[k], want[k])
@@ -308,7 +310,7 @@ def test_flow_fast_mode_within_a_thousandth_of_a_pixel(nsc, oracle_mod, w, h, le
             one = torch.full((h, w, 2), float("nan"), dtype=torch.float32, device=dev)
             fe.estimate_device(d_frames[1].data_ptr(), d_frames[2].data_ptr(), w, h, one.data_ptr(), s)
             torch.cuda.synchronize()
-            assert np.array_equal(one.cpu().numpy(), got[1]), (kind, tiled, "a pair alone = the same pair inside a stream")
+            assert np.array_equal(fetch(one), got[1]), (kind, tiled, "a pair alone = the same pair inside a stream")
             assert np.array_equal(fe.estimate(frames[0], frames[1], w, h), got[0]), (kind, tiled, "host entry point")
         fe.set_mode("exact")  # and back: bit-exact again
         fe.set_tiled(1)
@@ -333,12 +335,12 @@ def test_flow_fast_mode_1080p_contract(nsc, oracle_mod):
     fe = nsc.FlowEstimator(levels=3, coarse_iterations=50, refine_iterations=10)
     want = oracle_mod.flow_estimate(a, b, 3, 50, 10, fe.lambda_)
     fe.set_mode("fast")
-    frames = torch.from_numpy(np.stack([a, b])).to(dev)
+    frames = put(np.stack([a, b]))
     flow = torch.empty((1, h, w, 2), dtype=torch.float32, device=dev)
     s = torch.cuda.current_stream().cuda_stream
     fe.estimate_device_stream(frames.data_ptr(), 2, w, h, flow.data_ptr(), s)
     torch.cuda.synchronize()
-    got = flow[0].cpu().numpy()
+    got = fetch(flow[0])
     ok, mx = _flow_close(got, want)
     assert ok, mx
     it = nsc.WgpuFrameInterpolator()
@@ -347,7 +349,7 @@ def test_flow_fast_mode_1080p_contract(nsc, oracle_mod):
     it.interpolate_device(frames.data_ptr(), fb, frames.data_ptr() + fb, fb, flow.data_ptr(), w, h, 0.5, out.data_ptr(), 1, s)
     torch.cuda.synchronize()
     ref = oracle_mod.warp_blend(a, b, want, 0.5)
-    d = np.abs(out.cpu().numpy().astype(np.int16) - ref.astype(np.int16))
+    d = np.abs(fetch(out).astype(np.int16) - ref.astype(np.int16))
     assert d.max() <= 1 and (d > 0).mean() < 1e-3, (int(d.max()), float((d > 0).mean()))
 
 
@@ -365,7 +367,7 @@ def test_flow_fast_ring_form_equals_the_shifting_form(nsc, oracle_mod, w, h, lev
     dev = torch.device("cuda:0")
     n_frames = 3
     frames = np.stack([oracle_mod.gen_noise(w, h, 900 + k) if (w * h) % 2 else _smooth(w, h, 1.1 * k) for k in range(n_frames)])
-    d_frames = torch.from_numpy(frames).to(dev)
+    d_frames = put(frames)
     s = torch.cuda.current_stream().cuda_stream
     got = {}
     for form in ("ring", "shift"):
@@ -379,7 +381,7 @@ def test_flow_fast_ring_form_equals_the_shifting_form(nsc, oracle_mod, w, h, lev
         flows = torch.full((n_frames - 1, h, w, 2), float("nan"), dtype=torch.float32, device=dev)
         fe.estimate_device_stream(d_frames.data_ptr(), n_frames, w, h, flows.data_ptr(), s)
         torch.cuda.synchronize()
-        got[form] = flows.cpu().numpy()
+        got[form] = fetch(flows)
         assert np.isfinite(got[form]).all()
     monkeypatch.delenv("NUS_HS_FAST_SHIFT", raising=False)
     assert np.array_equal(got["ring"], got["shift"])
@@ -407,7 +409,7 @@ def test_interpolate_device_stream_equals_estimate_then_warp(nsc, oracle_mod, w,
     n_frames, t = 4, 0.3
     frames = np.stack([_smooth(w, h, 1.2 * k) if k % 2 else oracle_mod.gen_noise(w, h, 50 + k) // 2 + _smooth(w, h, 0.7 * k) // 2
                        for k in range(n_frames)])
-    d_frames = torch.from_numpy(frames).to(dev)
+    d_frames = put(frames)
     s = torch.cuda.current_stream().cuda_stream
     fb = w * h * 4
     it = nsc.WgpuFrameInterpolator()
@@ -436,8 +438,8 @@ def test_interpolate_device_stream_equals_estimate_then_warp(nsc, oracle_mod, w,
         if mode == "exact" and tiled == 1 and not in_kernel:
             for k in range(n_frames - 1):
                 fl = oracle_mod.flow_estimate(frames[k], frames[k + 1], levels, coarse, refine, fe.lambda_)
-                assert np.array_equal(flows[k].cpu().numpy(), fl)
-                d = np.abs(want_mid[k].cpu().numpy().astype(np.int16) - oracle_mod.warp_blend(frames[k], frames[k + 1], fl, t).astype(np.int16))
+                assert np.array_equal(fetch(flows[k]), fl)
+                d = np.abs(fetch(want_mid[k]).astype(np.int16) - oracle_mod.warp_blend(frames[k], frames[k + 1], fl, t).astype(np.int16))
                 assert d.max() <= 1
     fe = nsc.FlowEstimator(levels=2, coarse_iterations=2, refine_iterations=2)
     with pytest.raises(RuntimeError, match=r"t must be in \[0, 1\]"):
@@ -459,7 +461,7 @@ def test_step_motion_fused_warp_equals_separate_stages(nsc, oracle_mod, in_kerne
         monkeypatch.delenv("NUS_HS_FUSED_WARP", raising=False)
     w, h, n = 480, 270, 7
     dev = torch.device("cuda:0")
-    frames = torch.from_numpy(np.stack([_smooth(w, h, 1.1 * k) for k in range(n + 1)])).to(dev)
+    frames = put(np.stack([_smooth(w, h, 1.1 * k) for k in range(n + 1)]))
     pipe = nsc.FramePipeline(w, h, 2, "lanczos3", 0.5)
     pipe.interp.set_mode("fma")
     s = torch.cuda.current_stream().cuda_stream
@@ -497,7 +499,7 @@ def test_interpolate_device_stream_rg16float_handoff(nsc, oracle_mod, w, h, leve
     dev = torch.device("cuda:0")
     n_frames, t = 4, 0.5
     frames = np.stack([_smooth(w, h, 0.9 * k) for k in range(n_frames)])
-    d_frames = torch.from_numpy(frames).to(dev)
+    d_frames = put(frames)
     s = torch.cuda.current_stream().cuda_stream
     fb = w * h * 4
     it = nsc.WgpuFrameInterpolator()

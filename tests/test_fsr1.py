@@ -7,6 +7,8 @@ the C oracle -- each pass alone and the fused pair.
 """
 import numpy as np
 import pytest
+from nu_scaler_amd.transfer import to_device as put, to_numpy as fetch  # host <-> HBM through nus_upload / nus_download, never
+# torch's pageable copies (docs/d2h_fault_analysis.md)
 
 SIZES = [((32, 24), (64, 48)), ((17, 13), (40, 29)), ((20, 20), (20, 20)), ((33, 21), (25, 17)), ((1, 1), (3, 2)),
          ((5, 3), (130, 67))]
@@ -94,7 +96,7 @@ def test_gpu_fsr1_1080p_to_4k_device_batch(nsc, oracle_mod):
     u = nsc.PyWgpuUpscaler("quality", "fsr1")
     u.initialize(w, h, 2 * w, 2 * h)
     assert u.kernel_variant == "fsr1_easu_then_rcas_rows"
-    d_in = torch.from_numpy(frames).cuda()
+    d_in = put(frames)
     d_out = torch.empty((n, 2 * h, 2 * w, 4), dtype=torch.uint8, device="cuda")
     d_out2 = torch.empty_like(d_out)
     side = torch.cuda.Stream()
@@ -104,7 +106,7 @@ def test_gpu_fsr1_1080p_to_4k_device_batch(nsc, oracle_mod):
     u.upscale_device(d_in.data_ptr(), d_out.data_ptr(), n, torch.cuda.current_stream().cuda_stream)
     u.upscale_device(rev.data_ptr(), d_out2.data_ptr(), n, side.cuda_stream)  # other frames, other stream, same scratch
     torch.cuda.synchronize()
-    got, got2 = d_out.cpu().numpy(), d_out2.cpu().numpy()
+    got, got2 = fetch(d_out), fetch(d_out2)
     for k in (0, 2, 3, 4, n - 1):
         want = oracle_mod.fsr1(frames[k], 2 * w, 2 * h, 0.0, 0.7)
         assert np.array_equal(got[k], want), k
@@ -166,7 +168,7 @@ def test_gpu_fsr_fast_1080p_to_4k_device_batch(nsc, oracle_mod):
     import torch
     w, h = 1920, 1080
     frames = np.stack([oracle_mod.gen_gradient(w, h, 3), oracle_mod.gen_noise(w, h, 35), oracle_mod.gen_noise(w, h, 36)])
-    d_in = torch.from_numpy(frames).cuda()
+    d_in = put(frames)
     outs = {}
     for alg in ("easu", "fsr1"):
         u = nsc.PyWgpuUpscaler("quality", alg)
@@ -175,7 +177,7 @@ def test_gpu_fsr_fast_1080p_to_4k_device_batch(nsc, oracle_mod):
         d_out = torch.empty((3, 2 * h, 2 * w, 4), dtype=torch.uint8, device="cuda")
         u.upscale_device(d_in.data_ptr(), d_out.data_ptr(), 3, torch.cuda.current_stream().cuda_stream)
         torch.cuda.synchronize()
-        outs[alg] = d_out.cpu().numpy()
+        outs[alg] = fetch(d_out)
     for k in (0, 1):
         d = np.abs(outs["easu"][k].astype(np.int16) - oracle_mod.fsr_easu(frames[k], 2 * w, 2 * h, 0.0).astype(np.int16))
         assert d.max() <= 1

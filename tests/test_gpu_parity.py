@@ -10,6 +10,8 @@ import numpy as np
 import pytest
 
 from conftest import GOLDEN
+from nu_scaler_amd.transfer import to_device as put, to_numpy as fetch  # host <-> HBM through nus_upload / nus_download, never
+# torch's pageable copies (docs/d2h_fault_analysis.md)
 
 pytestmark = pytest.mark.gpu
 
@@ -306,7 +308,7 @@ def test_warp_blend_fma_mode_within_one_lsb(nsc, oracle_mod, size):
     flow = (rng.standard_normal((n, h, w, 2)) * 6).astype(np.float32)
     flow[:, 0, 0] = (1000.0, -1000.0)
     flow[:, -1, -1] = (-0.25, 7.5)
-    frames = torch.from_numpy(frames_np).to(dev)
+    frames = put(frames_np)
     fb = w * h * 4
     s = torch.cuda.current_stream().cuda_stream
     it = nsc.WgpuFrameInterpolator()
@@ -315,7 +317,7 @@ def test_warp_blend_fma_mode_within_one_lsb(nsc, oracle_mod, size):
     for t in (0.5, 0.3):
         for fmt in ("f32", "f16"):
             fl_np = flow if fmt == "f32" else flow.astype(np.float16)
-            d_flow = torch.from_numpy(fl_np).to(dev)
+            d_flow = put(fl_np)
             it.set_flow_format(fmt)
             want = [oracle_mod.warp_blend(frames_np[i], frames_np[i + 1], fl_np[i].astype(np.float32), t, threads=0) for i in range(n)]
             for mode in ("exact", "fma"):
@@ -323,7 +325,7 @@ def test_warp_blend_fma_mode_within_one_lsb(nsc, oracle_mod, size):
                 out.zero_()
                 it.interpolate_device(frames.data_ptr(), fb, frames.data_ptr() + fb, fb, d_flow.data_ptr(), w, h, t, out.data_ptr(), n, s)
                 torch.cuda.synchronize()
-                got = out.cpu().numpy()
+                got = fetch(out)
                 for i in range(n):
                     if mode == "exact":
                         assert np.array_equal(got[i], want[i]), (size, t, fmt, i)
@@ -355,8 +357,8 @@ def test_warp_blend_with_f16_flow_field(nsc, oracle_mod):
     flow32 = (rng.random((n, h, w, 2)) * 8.0 - 4.0).astype(np.float32)
     flow16 = flow32.astype(np.float16)
     dev = torch.device("cuda:0")
-    frames = torch.from_numpy(frames_np).to(dev)
-    d_flow16 = torch.from_numpy(flow16).to(dev)
+    frames = put(frames_np)
+    d_flow16 = put(flow16)
     out = torch.zeros((n, h, w, 4), dtype=torch.uint8, device=dev)
     it = nsc.WgpuFrameInterpolator()
     it.set_flow_format("f16")
@@ -364,7 +366,7 @@ def test_warp_blend_with_f16_flow_field(nsc, oracle_mod):
     it.interpolate_device(frames.data_ptr(), fb, frames.data_ptr() + fb, fb, d_flow16.data_ptr(), w, h, 0.5, out.data_ptr(), n,
                           torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
-    got = out.cpu().numpy()
+    got = fetch(out)
     for i in range(n):
         want = oracle_mod.warp_blend(frames_np[i], frames_np[i + 1], flow16[i].astype(np.float32), 0.5)
         assert np.array_equal(got[i], want), i
@@ -375,11 +377,11 @@ def test_warp_blend_with_f16_flow_field(nsc, oracle_mod):
         assert d.max() <= 2 and (d > 0).mean() < 0.15, (i, int(d.max()), float((d > 0).mean()))
     # back to f32: the same entry point reads 8 bytes per pixel again
     it.set_flow_format("f32")
-    d_flow32 = torch.from_numpy(flow32).to(dev)
+    d_flow32 = put(flow32)
     it.interpolate_device(frames.data_ptr(), fb, frames.data_ptr() + fb, fb, d_flow32.data_ptr(), w, h, 0.5, out.data_ptr(), n,
                           torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
-    assert np.array_equal(out[0].cpu().numpy(), oracle_mod.warp_blend(frames_np[0], frames_np[1], flow32[0], 0.5))
+    assert np.array_equal(fetch(out[0]), oracle_mod.warp_blend(frames_np[0], frames_np[1], flow32[0], 0.5))
     with pytest.raises(ValueError):
         it.set_flow_format("bf16")
 
@@ -616,14 +618,14 @@ def test_device_batch_path_matches_host_path(nsc, oracle_mod):
     w, h, n = 128, 24, 5
     dev = torch.device("cuda:0")
     frames_np = np.stack([oracle_mod.gen_noise(w, h, 200 + i) for i in range(n + 1)])
-    frames = torch.from_numpy(frames_np).to(dev)
+    frames = put(frames_np)
     for alg, ref in (("nearest", oracle_mod.nearest), ("bilinear", oracle_mod.bilinear), ("lanczos3", oracle_mod.lanczos3)):
         u = nsc.PyWgpuUpscaler("quality", alg, lanczos_mode="exact")
         u.initialize(w, h, 2 * w, 2 * h)
         out = torch.zeros((n, 2 * h, 2 * w, 4), dtype=torch.uint8, device=dev)
         u.upscale_device(frames.data_ptr(), out.data_ptr(), n, torch.cuda.current_stream().cuda_stream)
         torch.cuda.synchronize()
-        got = out.cpu().numpy()
+        got = fetch(out)
         for i in range(n):
             assert np.array_equal(got[i], ref(frames_np[i], 2 * w, 2 * h)), (alg, i)
     pipe = nsc.FramePipeline(w, h, 2, "lanczos3", 0.5, lanczos_mode="exact")
@@ -632,9 +634,9 @@ def test_device_batch_path_matches_host_path(nsc, oracle_mod):
     torch.cuda.synchronize()
     for i in range(n):
         m = oracle_mod.warp_blend(frames_np[i], frames_np[i + 1], None, 0.5)
-        assert np.array_equal(mid[i].cpu().numpy(), m)
-        assert np.array_equal(up_real[i].cpu().numpy(), oracle_mod.lanczos3(frames_np[i], 2 * w, 2 * h))
-        assert np.array_equal(up_mid[i].cpu().numpy(), oracle_mod.lanczos3(m, 2 * w, 2 * h))
+        assert np.array_equal(fetch(mid[i]), m)
+        assert np.array_equal(fetch(up_real[i]), oracle_mod.lanczos3(frames_np[i], 2 * w, 2 * h))
+        assert np.array_equal(fetch(up_mid[i]), oracle_mod.lanczos3(m, 2 * w, 2 * h))
 
 
 # ---- BASELINE.json configurations at full size -----------------------------------------
@@ -686,7 +688,7 @@ def test_bench_launch_shape_1080p_batch_rows_per_wave_36(nsc, oracle_mod):
     for pattern in ("gradient", "noise"):
         gen = (lambda k: oracle_mod.gen_gradient(w, h, k)) if pattern == "gradient" else (lambda k: oracle_mod.gen_noise(w, h, 900 + k))
         frames_np = np.stack([gen(k) for k in range(n + 1)])
-        frames = torch.from_numpy(frames_np).to(dev)
+        frames = put(frames_np)
         u = nsc.PyWgpuUpscaler("quality", "lanczos3")
         u.set_option("rows_per_wave", 36)
         u.initialize(w, h, 2 * w, 2 * h)
@@ -699,11 +701,11 @@ def test_bench_launch_shape_1080p_batch_rows_per_wave_36(nsc, oracle_mod):
         torch.cuda.synchronize()
         for k in (0, 3, n - 1):
             want = oracle_mod.lanczos3(frames_np[k], 2 * w, 2 * h, threads=0).astype(np.int16)
-            d = np.abs(out[k].cpu().numpy().astype(np.int16) - want)
+            d = np.abs(fetch(out[k]).astype(np.int16) - want)
             assert d.max() <= 1 and (d > 0).mean() < 1e-3, (pattern, k, int(d.max()), float((d > 0).mean()))
             mid = oracle_mod.warp_blend(frames_np[k], frames_np[k + 1], None, 0.5, threads=0)
             want = oracle_mod.lanczos3(mid, 2 * w, 2 * h, threads=0).astype(np.int16)
-            d = np.abs(fused[k].cpu().numpy().astype(np.int16) - want)
+            d = np.abs(fetch(fused[k]).astype(np.int16) - want)
             assert d.max() <= 1 and (d > 0).mean() < 1e-3, (pattern, "fused", k, int(d.max()), float((d > 0).mean()))
         del frames, out, fused
 
@@ -728,14 +730,14 @@ def test_swizzle_bgra_to_rgba_device(nsc, oracle_mod):
     import torch
 
     for n in (64 * 36, 61 * 7):  # vector and scalar paths
-        bgra = torch.from_numpy(oracle_mod.gen_noise(n, 1, 77).reshape(n, 4).copy()).to("cuda:0")
+        bgra = put(oracle_mod.gen_noise(n, 1, 77).reshape(n, 4).copy())
         out = torch.empty_like(bgra)
         nsc.swizzle_bgra_to_rgba_device(bgra.data_ptr(), out.data_ptr(), n, torch.cuda.current_stream().cuda_stream)
         torch.cuda.synchronize()
-        assert torch.equal(out.cpu(), bgra.cpu()[:, [2, 1, 0, 3]])
+        assert np.array_equal(fetch(out), fetch(bgra)[:, [2, 1, 0, 3]])
         nsc.swizzle_bgra_to_rgba_device(out.data_ptr(), out.data_ptr(), n, torch.cuda.current_stream().cuda_stream)  # in place
         torch.cuda.synchronize()
-        assert torch.equal(out.cpu(), bgra.cpu())
+        assert np.array_equal(fetch(out), fetch(bgra))
 
 
 @pytest.mark.parametrize("alg", ["lanczos3", "bicubic"])
@@ -747,7 +749,7 @@ def test_fused_blend_upscale_equals_two_stage(nsc, oracle_mod, alg, t):
     w, h, n = 128, 40, 4
     dev = torch.device("cuda:0")
     frames_np = np.stack([oracle_mod.gen_noise(w, h, 300 + i) for i in range(n + 1)])
-    frames = torch.from_numpy(frames_np).to(dev)
+    frames = put(frames_np)
     filt = {"lanczos3": 0, "bicubic": 1}[alg]
     for mode in ("exact", "fma"):
         u = nsc.PyWgpuUpscaler("quality", alg, lanczos_mode=mode)
@@ -768,7 +770,7 @@ def test_fused_blend_upscale_equals_two_stage(nsc, oracle_mod, alg, t):
         if mode == "exact":
             for i in range(n):
                 m = oracle_mod.warp_blend(frames_np[i], frames_np[i + 1], None, t)
-                assert np.array_equal(fused[i].cpu().numpy(), oracle_mod.resize(m, 2 * w, 2 * h, filt)), (alg, t, i)
+                assert np.array_equal(fetch(fused[i]), oracle_mod.resize(m, 2 * w, 2 * h, filt)), (alg, t, i)
     ub = nsc.PyWgpuUpscaler("quality", "bilinear")
     ub.initialize(w, h, 2 * w, 2 * h)
     with pytest.raises(RuntimeError, match="only the exact-x2 resize kernels"):
@@ -810,7 +812,7 @@ def test_device_path_is_graph_capturable(nsc, oracle_mod):
     w, h, n = 128, 24, 3
     dev = torch.device("cuda:0")
     frames_np = np.stack([oracle_mod.gen_noise(w, h, 600 + i) for i in range(n + 1)])
-    frames = torch.from_numpy(frames_np).to(dev)
+    frames = put(frames_np)
     pipe = nsc.FramePipeline(w, h, 2, "lanczos3", 0.5, lanczos_mode="exact")
     mid, up_real, up_mid = pipe.alloc(n, dev)
     side = torch.cuda.Stream()
@@ -828,9 +830,9 @@ def test_device_path_is_graph_capturable(nsc, oracle_mod):
     torch.cuda.synchronize()
     for i in range(n):
         m = oracle_mod.warp_blend(frames_np[i], frames_np[i + 1], None, 0.5)
-        assert np.array_equal(mid[i].cpu().numpy(), m)
-        assert np.array_equal(up_real[i].cpu().numpy(), oracle_mod.lanczos3(frames_np[i], 2 * w, 2 * h))
-        assert np.array_equal(up_mid[i].cpu().numpy(), oracle_mod.lanczos3(m, 2 * w, 2 * h))
+        assert np.array_equal(fetch(mid[i]), m)
+        assert np.array_equal(fetch(up_real[i]), oracle_mod.lanczos3(frames_np[i], 2 * w, 2 * h))
+        assert np.array_equal(fetch(up_mid[i]), oracle_mod.lanczos3(m, 2 * w, 2 * h))
 
 
 # ---- BGRA input: the capture feed's channel order, swizzled inside the kernels' loads ----------
@@ -885,11 +887,11 @@ def test_bgra_input_interpolator_and_fused_blend(nsc, oracle_mod):
             mid = oracle_mod.warp_blend(a, b, None, t)
             want = np.frombuffer(u.upscale(mid.tobytes()), np.uint8).reshape(2 * h, 2 * w, 4)
             u.set_input_format("bgra")
-            da, db = torch.from_numpy(_bgra(a)).cuda(), torch.from_numpy(_bgra(b)).cuda()
+            da, db = put(_bgra(a)), put(_bgra(b))
             out = torch.empty((2 * h, 2 * w, 4), dtype=torch.uint8, device="cuda")
             u.upscale_blend_device(da.data_ptr(), 0, db.data_ptr(), 0, t, out.data_ptr(), 1, torch.cuda.current_stream().cuda_stream)
             torch.cuda.synchronize()
-            assert np.array_equal(out.cpu().numpy(), want), (alg, t)
+            assert np.array_equal(fetch(out), want), (alg, t)
 
 
 # ---- seeded random shape sweep: ragged widths around the kernels' segment sizes --------------------
@@ -1221,12 +1223,12 @@ def test_small_rational_factors_at_full_size(nsc, oracle_mod, dims):
     got_e, ue = _up(nsc, "lanczos3", img, ow, oh, lanczos_mode="exact")
     assert ue.kernel_variant == "lanczos3_pq_regwin" and np.array_equal(got_e, want)
     frames = np.stack([img, img[::-1].copy(), oracle_mod.gen_gradient(w, h)])
-    d_in = torch.from_numpy(frames).cuda()
+    d_in = put(frames)
     d_out = torch.empty((3, oh, ow, 4), dtype=torch.uint8, device="cuda")
     torch.cuda.synchronize()
     uf.upscale_device(d_in.data_ptr(), d_out.data_ptr(), 3)
     torch.cuda.synchronize()
-    got_b = d_out.cpu().numpy()
+    got_b = fetch(d_out)
     assert np.array_equal(got_b[0], got_f)
     for k in (1, 2):
         single, _ = _up(nsc, "lanczos3", frames[k], ow, oh)
@@ -1260,7 +1262,7 @@ def test_1440p_to_4k_takes_the_three_halves_kernel(nsc, oracle_mod):
     assert ue.kernel_variant == "lanczos3_r32_regwin" and np.array_equal(got_e, want)
     n = 3
     frames_np = np.stack([oracle_mod.gen_gradient(w, h, k) for k in range(n)])
-    frames = torch.from_numpy(frames_np).to("cuda:0")
+    frames = put(frames_np)
     out = torch.zeros((n, oh, ow, 4), dtype=torch.uint8, device="cuda:0")
     uf.upscale_device(frames.data_ptr(), out.data_ptr(), n, torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
@@ -1269,7 +1271,7 @@ def test_1440p_to_4k_takes_the_three_halves_kernel(nsc, oracle_mod):
     ug.initialize(w, h, ow, oh)
     assert ug.kernel_variant == "resize_regwin_lds"
     for k in range(n):
-        got_k = out[k].cpu().numpy()
+        got_k = fetch(out[k])
         wk = oracle_mod.lanczos3(frames_np[k], ow, oh, threads=0).astype(np.int16)
         dk = np.abs(got_k.astype(np.int16) - wk)
         # the smooth gradient puts many sums of the FMA mode within a rounding of a .5 tie: more 1-LSB differences than on noise,
@@ -1296,13 +1298,13 @@ def test_720p_to_4k_x3_takes_the_fixed_weight_kernel(nsc, oracle_mod):
     assert ue.kernel_variant == "lanczos3_xs_regwin" and np.array_equal(got_e, want)
     n = 3
     frames_np = np.stack([oracle_mod.gen_gradient(w, h, k) for k in range(n)])
-    frames = torch.from_numpy(frames_np).to("cuda:0")
+    frames = put(frames_np)
     out = torch.zeros((n, oh, ow, 4), dtype=torch.uint8, device="cuda:0")
     uf.upscale_device(frames.data_ptr(), out.data_ptr(), n, torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
     for k in range(n):
         wk = oracle_mod.lanczos3(frames_np[k], ow, oh, threads=0).astype(np.int16)
-        dk = np.abs(out[k].cpu().numpy().astype(np.int16) - wk)
+        dk = np.abs(fetch(out[k]).astype(np.int16) - wk)
         assert dk.max() <= 1 and (dk > 0).mean() < 1e-3, k
 
 
@@ -1317,11 +1319,11 @@ def test_device_batch_every_variant(nsc, oracle_mod, alg, dims):
     u = nsc.PyWgpuUpscaler("quality", alg)
     u.initialize(w, h, ow, oh)
     want = [np.frombuffer(u.upscale(f.tobytes()), np.uint8).reshape(oh, ow, 4) for f in frames]
-    d_in = torch.from_numpy(frames).cuda()
+    d_in = put(frames)
     d_out = torch.zeros((3, oh, ow, 4), dtype=torch.uint8, device="cuda")
     u.upscale_device(d_in.data_ptr(), d_out.data_ptr(), 3, torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
-    got = d_out.cpu().numpy()
+    got = fetch(d_out)
     for k in range(3):
         assert np.array_equal(got[k], want[k]), (alg, u.kernel_variant, k)
 
@@ -1474,11 +1476,11 @@ def test_resize_down_random_shapes(nsc, oracle_mod, seed):
         except RuntimeError as e:  # windows beyond 32 taps are refused by every resize kernel
             assert "exceeds 32 taps" in str(e), (w, h, ow, oh, str(e))
             continue
-        d_in = torch.from_numpy(frames).cuda()
+        d_in = put(frames)
         d_out = torch.zeros((n, oh, ow, 4), dtype=torch.uint8, device="cuda")
         u.upscale_device(d_in.data_ptr(), d_out.data_ptr(), n, torch.cuda.current_stream().cuda_stream)
         torch.cuda.synchronize()
-        got = d_out.cpu().numpy()
+        got = fetch(d_out)
         for k in range(n):
             want = oracle_mod.resize(frames[k], ow, oh, filt)
             assert np.array_equal(got[k], want), ((w, h), (ow, oh), n, k, alg, u.kernel_variant, _maxdiff(got[k], want))
@@ -1492,11 +1494,11 @@ def test_resize_down_4k_to_1080p_batch(nsc, oracle_mod):
     u = nsc.PyWgpuUpscaler("quality", "lanczos3")
     u.initialize(w, h, ow, oh)
     assert u.kernel_variant == "resize_down_stream"
-    d_in = torch.from_numpy(frames).cuda()
+    d_in = put(frames)
     d_out = torch.zeros((3, oh, ow, 4), dtype=torch.uint8, device="cuda")
     u.upscale_device(d_in.data_ptr(), d_out.data_ptr(), 3, torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
-    got = d_out.cpu().numpy()
+    got = fetch(d_out)
     assert _maxdiff(got[0], oracle_mod.resize(frames[0], ow, oh, 0)) <= 1
     r = nsc.PyWgpuUpscaler("quality", "lanczos3")
     r.set_option("force_rows", 1)
@@ -1600,7 +1602,7 @@ def test_more_frames_than_one_grid_axis_holds(nsc, oracle_mod):
     import torch
     n, w, h = 66000, 16, 16
     rng = np.random.default_rng(5)
-    frames = torch.from_numpy(rng.integers(0, 256, (n + 1, h, w, 4), dtype=np.uint8)).cuda()
+    frames = put(rng.integers(0, 256, (n + 1, h, w, 4), dtype=np.uint8))
     out = torch.empty((n, 2 * h, 2 * w, 4), dtype=torch.uint8, device="cuda")
     s = torch.cuda.current_stream().cuda_stream
     probe = [0, 1, 65534, 65535, 65536, n - 1]
@@ -1610,8 +1612,8 @@ def test_more_frames_than_one_grid_axis_holds(nsc, oracle_mod):
         u.upscale_device(frames.data_ptr(), out.data_ptr(), n, s)
         torch.cuda.synchronize()
         for k in probe:
-            want = np.frombuffer(u.upscale(frames[k].cpu().numpy().tobytes()), np.uint8).reshape(2 * h, 2 * w, 4)
-            assert np.array_equal(out[k].cpu().numpy(), want), (alg, k)
+            want = np.frombuffer(u.upscale(fetch(frames[k]).tobytes()), np.uint8).reshape(2 * h, 2 * w, 4)
+            assert np.array_equal(fetch(out[k]), want), (alg, k)
     # fused blend of (frame k, frame k+1) + upscale: the second input must advance with the chunk
     u = nsc.PyWgpuUpscaler("quality", "lanczos3")
     u.initialize(w, h, 2 * w, 2 * h)
@@ -1619,17 +1621,17 @@ def test_more_frames_than_one_grid_axis_holds(nsc, oracle_mod):
     u.upscale_blend_device(frames.data_ptr(), fb, frames.data_ptr() + fb, fb, 0.5, out.data_ptr(), n, s)
     torch.cuda.synchronize()
     for k in probe:
-        a, b = frames[k].cpu().numpy(), frames[k + 1].cpu().numpy()
+        a, b = fetch(frames[k]), fetch(frames[k + 1])
         mid = oracle_mod.warp_blend(a, b, None, 0.5)
         want = np.frombuffer(u.upscale(mid.tobytes()), np.uint8).reshape(2 * h, 2 * w, 4)
-        assert np.array_equal(out[k].cpu().numpy(), want), ("fused", k)
+        assert np.array_equal(fetch(out[k]), want), ("fused", k)
     it = nsc.WgpuFrameInterpolator()
     mid_all = torch.empty((n, h, w, 4), dtype=torch.uint8, device="cuda")
     it.interpolate_device(frames.data_ptr(), fb, frames.data_ptr() + fb, fb, 0, w, h, 0.5, mid_all.data_ptr(), n, s)
     torch.cuda.synchronize()
     for k in probe:
-        want = oracle_mod.warp_blend(frames[k].cpu().numpy(), frames[k + 1].cpu().numpy(), None, 0.5)
-        assert np.array_equal(mid_all[k].cpu().numpy(), want), ("interp", k)
+        want = oracle_mod.warp_blend(fetch(frames[k]), fetch(frames[k + 1]), None, 0.5)
+        assert np.array_equal(fetch(mid_all[k]), want), ("interp", k)
 
 
 def test_reinitialise_and_destroy_do_not_leak_device_memory(nsc, oracle_mod):
@@ -1696,7 +1698,7 @@ def test_lanczos_x2_edge_pass_beside_the_main_kernel(nsc, oracle_mod):
     w, h, n = 484, 40, 9
     dev = torch.device("cuda:0")
     frames_np = np.stack([oracle_mod.gen_noise(w, h, 800 + k) for k in range(n + 1)])
-    frames = torch.from_numpy(frames_np).to(dev)
+    frames = put(frames_np)
     s = torch.cuda.current_stream().cuda_stream
     fb = w * h * 4
     outs = {}
@@ -1717,12 +1719,12 @@ def test_lanczos_x2_edge_pass_beside_the_main_kernel(nsc, oracle_mod):
     assert torch.equal(plain, up_real)
     for k in (0, n - 1):
         want = oracle_mod.lanczos3(frames_np[k], 2 * w, 2 * h)
-        got = plain[k].cpu().numpy()
+        got = fetch(plain[k])
         assert np.array_equal(got[:, :8], want[:, :8]) and np.array_equal(got[:, -8:], want[:, -8:]), "edge columns"
         assert np.array_equal(got, want)
         m = oracle_mod.warp_blend(frames_np[k], frames_np[k + 1], None, 0.5)
-        assert np.array_equal(mid[k].cpu().numpy(), m)
-        assert np.array_equal(up_mid[k].cpu().numpy(), oracle_mod.lanczos3(m, 2 * w, 2 * h))
+        assert np.array_equal(fetch(mid[k]), m)
+        assert np.array_equal(fetch(up_mid[k]), oracle_mod.lanczos3(m, 2 * w, 2 * h))
 
 
 @pytest.mark.gpu

@@ -398,7 +398,7 @@ def test_copy_pool_stress(tmp_path):
     src_dir = os.path.join(ROOT, "nu_scaler_amd", "csrc")
     exe = str(tmp_path / "copy_pool_stress")
     cmd = ["g++", "-O2", "-std=c++17", "-pthread", "-Wall", "-Wextra", "-I", src_dir,
-           os.path.join(ROOT, "tests", "c_abi", "copy_pool_stress.cpp"), os.path.join(src_dir, "nus_copy.cpp"), "-o", exe]
+           os.path.join(ROOT, "tests", "c_abi", "copy_pool_stress.cpp"), os.path.join(src_dir, "nus_copy.cpp"), os.path.join(src_dir, "nus_ranges.cpp"), "-o", exe]
     res = subprocess.run(cmd, capture_output=True, text=True)
     assert res.returncode == 0, res.stderr
     for threads in (None, "0", "7"):
@@ -438,7 +438,7 @@ def test_copy_pool_stress_under_address_and_ub_sanitizers(tmp_path):
     import subprocess
     src_dir = os.path.join(ROOT, "nu_scaler_amd", "csrc")
     exe = _sanitizer_build(tmp_path, "copy_pool_stress_asan",
-                           [os.path.join(ROOT, "tests", "c_abi", "copy_pool_stress.cpp"), os.path.join(src_dir, "nus_copy.cpp")])
+                           [os.path.join(ROOT, "tests", "c_abi", "copy_pool_stress.cpp"), os.path.join(src_dir, "nus_copy.cpp"), os.path.join(src_dir, "nus_ranges.cpp")])
     for threads in ("3", "0"):
         run = subprocess.run([exe], capture_output=True, text=True, env=dict(os.environ, NUS_COPY_THREADS=threads, **_SAN_ENV), timeout=600)
         assert run.returncode == 0 and "bad 0" in run.stdout and "ERROR: AddressSanitizer" not in run.stderr \
@@ -456,7 +456,7 @@ def test_copy_pool_stress_with_two_cpus(tmp_path):
     src_dir = os.path.join(ROOT, "nu_scaler_amd", "csrc")
     exe = str(tmp_path / "copy_pool_stress")
     res = subprocess.run(["g++", "-O2", "-std=c++17", "-pthread", "-I", src_dir, os.path.join(ROOT, "tests", "c_abi", "copy_pool_stress.cpp"),
-                          os.path.join(src_dir, "nus_copy.cpp"), "-o", exe], capture_output=True, text=True)
+                          os.path.join(src_dir, "nus_copy.cpp"), os.path.join(src_dir, "nus_ranges.cpp"), "-o", exe], capture_output=True, text=True)
     assert res.returncode == 0, res.stderr
     cpus = sorted(os.sched_getaffinity(0))[:2]
     env = {k: v for k, v in os.environ.items() if k != "NUS_COPY_THREADS"}
@@ -485,7 +485,7 @@ def test_copy_pool_stress_under_thread_sanitizer(tmp_path):
     src_dir = os.path.join(ROOT, "nu_scaler_amd", "csrc")
     exe = str(tmp_path / "copy_pool_stress_tsan")
     cmd = ["g++", "-O1", "-g", "-fsanitize=thread", "-std=c++17", "-pthread", "-I", src_dir,
-           os.path.join(ROOT, "tests", "c_abi", "copy_pool_stress.cpp"), os.path.join(src_dir, "nus_copy.cpp"), "-o", exe]
+           os.path.join(ROOT, "tests", "c_abi", "copy_pool_stress.cpp"), os.path.join(src_dir, "nus_copy.cpp"), os.path.join(src_dir, "nus_ranges.cpp"), "-o", exe]
     res = subprocess.run(cmd, capture_output=True, text=True)
     if res.returncode != 0 and "tsan" in (res.stderr or "").lower():
         pytest.skip("libtsan not installed")
@@ -529,17 +529,86 @@ def test_benchmark_api_surface(nsc):
     assert (r.input_width, r.output_height, r.frames_processed, r.technology) == (1, 4, 5, "Wgpu")
 
 
-def test_hostmem_routing_is_idempotent_and_leaves_cpu_tensors_alone():
-    """nu_scaler_amd/hostmem.py (harness helper: device -> pinned staging -> numpy, because the HIP runtime's pageable device-to-host
-    copy faulted twice in long sessions): without a GPU it must be a no-op for CPU tensors and safe to install twice."""
+def test_transfer_module_without_a_gpu(nsc):
+    """nu_scaler_amd/transfer.py (nus_download / nus_upload): CPU tensors pass through untouched, and with no HIP device the
+    entry points refuse loudly -- there is no fallback to a runtime copy or to torch."""
     import torch
 
-    from nu_scaler_amd import hostmem
+    from nu_scaler_amd import _capi, transfer
 
-    hostmem.route_tensor_cpu_through_pinned_staging()
-    first = torch.Tensor.cpu
-    hostmem.route_tensor_cpu_through_pinned_staging()
-    assert torch.Tensor.cpu is first and hasattr(torch.Tensor, "_nus_plain_cpu")
     t = torch.arange(1 << 18, dtype=torch.uint8)
-    assert hostmem.to_host(t) is t and t.cpu() is t  # (Tensor.cpu() of a CPU tensor returns the tensor itself)
-    assert hostmem.to_numpy(t).sum() == int(t.sum())
+    a = transfer.to_numpy(t)
+    assert a.base is not None or a.ctypes.data == t.data_ptr()  # the tensor's own memory, no copy
+    assert int(a.sum()) == int(t.sum())
+    L = _capi.lib()
+    assert L.nus_download(None, None, 0, None) == _capi.OK  # nothing to move
+    assert L.nus_download(None, None, 16, None) == _capi.ERR_INVALID_ARGUMENT and "null pointer" in _capi.last_error()
+    assert L.nus_upload(None, None, 16, None) == _capi.ERR_INVALID_ARGUMENT
+    if nsc.device_count() == 0:
+        buf = bytearray(64)
+        with pytest.raises(RuntimeError, match="no HIP device"):
+            transfer.download(0x1000, 64, buf)
+        with pytest.raises(RuntimeError, match="no HIP device"):
+            transfer.upload(0x1000, buf)
+    with pytest.raises(ValueError):
+        transfer.download(0x1000, 65, bytearray(64))
+    with pytest.raises(TypeError):
+        transfer.download(0x1000, 4, b"abcd")  # read-only output
+
+
+def test_unpin_of_a_pointer_that_was_never_pinned_is_refused(nsc):
+    """nus_host_unpin asks the library's own record (nus_host_ranges) before the runtime: an arbitrary pointer is an
+    invalid argument, not a call into hipHostUnregister."""
+    import ctypes
+
+    from nu_scaler_amd import _capi
+
+    b = bytearray(4096)
+    a = (ctypes.c_ubyte * 4096).from_buffer(b)
+    L = _capi.lib()
+    assert L.nus_host_unpin(ctypes.addressof(a)) == _capi.ERR_INVALID_ARGUMENT
+    assert "not the start of a buffer pinned with nus_host_pin" in _capi.last_error()
+    assert L.nus_host_unpin(None) == _capi.ERR_INVALID_ARGUMENT
+
+
+def test_no_replacement_of_tensor_cpu_anywhere():
+    """the harness fetches device tensors through the product's nus_download (`fetch`), the product package
+    holds no assignment to torch.Tensor.cpu, and no test / bench / smoke code calls `.cpu()` on what may be a device tensor."""
+    import glob
+    import re
+
+    pkg = glob.glob(os.path.join(ROOT, "nu_scaler_amd", "*.py"))
+    for p in pkg + [os.path.join(ROOT, "bench.py"), os.path.join(ROOT, "__graft_entry__.py"), os.path.join(ROOT, "tests", "conftest.py")]:
+        src = open(p).read()
+        assert not re.search(r"Tensor\.cpu\s*=", src), p
+        assert "route_tensor_cpu" not in src, p
+    allowed = {("stream.py", "g.cpu().tolist()")}  # one gathered row of float64 numbers (a few hundred bytes)
+    for p in pkg + glob.glob(os.path.join(ROOT, "tests", "*.py")) + glob.glob(os.path.join(ROOT, "tests", "helpers", "*.py")) + \
+            [os.path.join(ROOT, "bench.py"), os.path.join(ROOT, "__graft_entry__.py")]:
+        if os.path.basename(p) == "test_host_logic.py":
+            continue
+        for ln in open(p).read().splitlines():
+            code = ln.split("#", 1)[0]
+            if ".cpu()" in code:
+                assert any(os.path.basename(p) == f and frag in code for f, frag in allowed), (p, ln)
+
+
+def test_fatal_trace_report_of_a_dying_child(nsc, tmp_path):
+    """nus_install_fatal_trace: a child that aborts leaves, in this order, the native frames of the raising thread, the library's
+    record of host ranges and /proc/self/maps (with its heap line) on the descriptor it named, then dies of SIGABRT as before."""
+    import signal
+    import subprocess
+
+    code = ("import os, sys\nsys.path.insert(0, %r)\nimport nu_scaler_amd as n\n"
+            "assert n.install_fatal_trace(2) and n.install_fatal_trace(2)\nos.abort()\n" % ROOT)
+    import sys
+
+    run = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert run.returncode == -signal.SIGABRT, (run.returncode, run.stderr[-2000:])
+    err = run.stderr
+    marks = ["[nus_fatal_trace] fatal signal SIGABRT", "[nus_fatal_trace] end of native frames",
+             "[nus_fatal_trace] host ranges the library holds now: 0", "[nus_fatal_trace] last 0 range events",
+             "[nus_fatal_trace] /proc/self/maps", "[heap]", "[nus_fatal_trace] end of /proc/self/maps"]
+    pos = [err.find(m) for m in marks]
+    assert all(p >= 0 for p in pos) and pos == sorted(pos), pos
+    assert "abort" in err[pos[0]:pos[1]] and "libnuscaler_hip.so" in err[pos[4]:pos[6]]

@@ -183,3 +183,48 @@ def test_enumerate_gpus_from_the_kfd_topology(nsc, tmp_path):
     assert p.enumerate_gpus_sysfs(str(sysfs), str(dev), environ={"ROCR_VISIBLE_DEVICES": "2,0", "HIP_VISIBLE_DEVICES": "1"})["bdf"] == ["0000:a4:00.0"]
     assert "index list" in p.enumerate_gpus_sysfs(str(sysfs), str(dev), environ={"HIP_VISIBLE_DEVICES": "GPU-abc"})["error"]
     assert p.enumerate_gpus_sysfs(str(tmp_path / "nothing"), str(dev), environ={})["bdf"] == []
+
+
+def test_bind_rank_for_all_eight_slots_of_the_node_the_driver_will_use(nsc, tmp_path, monkeypatch):
+    """the shape of the first 8-GPU contact -- eight GPUs in the KFD topology behind two CPU nodes, 2 x 64
+    cores with SMT (256 hardware threads in the mask), a cgroup quota of 16 CPUs for the whole job -- driven through bind_rank
+    itself for every slot: each rank is planned onto 32 CPUs of ITS GPU's node (whole cores, disjoint from every other rank),
+    may keep 2 of them busy, and so runs a ZERO-worker copy pool (the submitting and the retiring thread are its two)."""
+    from nu_scaler_amd import placement as p
+
+    sysfs = tmp_path / "sys"
+    nodes = sysfs / "class" / "kfd" / "kfd" / "topology" / "nodes"
+    bdfs = []
+    for n in range(10):  # two CPU nodes, then the eight GPUs in ROCr's order
+        d = nodes / str(n)
+        d.mkdir(parents=True)
+        if n < 2:
+            (d / "properties").write_text("cpu_cores_count 64\nsimd_count 0\nlocation_id 0\ndomain 0\ndrm_render_minor -1\n")
+            continue
+        g = n - 2
+        bus = 0x05 + 0x20 * g
+        bdfs.append(f"0000:{bus:02x}:00.0")
+        (d / "properties").write_text(f"cpu_cores_count 0\nsimd_count 1024\nlocation_id {bus << 8}\ndomain 0\ndrm_render_minor -1\n")
+    _fake_sysfs(str(sysfs), {b: (0 if i < 4 else 1, "0-63,128-191" if i < 4 else "64-127,192-255") for i, b in enumerate(bdfs)},
+                {c: f"{c % 128},{c % 128 + 128}" for c in range(256)})
+    monkeypatch.setattr(p, "cgroup_cpu_quota", lambda: 16.0)
+    monkeypatch.setattr(p.os, "sched_getaffinity", lambda pid: set(range(256)))
+    for k in ("NUS_COPY_THREADS", "OMP_NUM_THREADS", p.LAUNCHER_OMP_MARK, "NUS_COPY_THREADS_FROM_PLACEMENT"):
+        monkeypatch.setenv(k, "registered-for-restore")  # (so that what _apply_thread_budget writes below is undone afterwards)
+        monkeypatch.delenv(k)
+    seen = set()
+    for r in range(8):
+        rep = p.bind_rank(r, 8, sysfs=str(sysfs), apply=False)
+        assert rep["bound"] and rep["why_not"] is None and rep["gpu_bdf"] == bdfs[r], rep
+        assert rep["numa_node"] == (0 if r < 4 else 1) and rep["ranks_on_node"] == 4 and rep["local_world"] == 8
+        cpus = p.parse_cpulist(rep["cpus"])
+        assert len(cpus) == 32 == rep["n_cpus_in_mask"] and not (set(cpus) & seen)
+        assert all(((c + 128) if c < 128 else (c - 128)) in cpus for c in cpus), "SMT siblings stay together"
+        seen |= set(cpus)
+        assert rep["cgroup_cpu_quota"] == 16.0 and rep["cpus_per_rank"] == 2
+        assert rep["copy_threads"] == 0 and rep["omp_threads"] == 2
+        json.dumps({k: v for k, v in rep.items() if k != "_replan"})
+        # what apply=True writes for the library's copy pool of this rank (read once, when the pool starts)
+        budget = p.thread_budget(rep["cpus_per_rank"])
+        assert p._apply_thread_budget(budget) == {} and os.environ["NUS_COPY_THREADS"] == "0" and os.environ["OMP_NUM_THREADS"] == "2"
+    assert seen == set(range(256))

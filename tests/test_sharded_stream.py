@@ -13,6 +13,8 @@ import numpy as np
 import pytest
 
 from conftest import ROOT
+from nu_scaler_amd.transfer import to_device as put, to_numpy as fetch  # host <-> HBM through nus_upload / nus_download, never
+# torch's pageable copies (docs/d2h_fault_analysis.md)
 
 HELPER = os.path.join(ROOT, "tests", "helpers", "sharded_rank.py")
 
@@ -69,6 +71,42 @@ def test_the_shard_in_windows_is_the_same_stream(nsc):
     assert rc == 0 and out[0]["unit_digests"] == win["unit_digests"] and len(win["unit_digests"]) == 11
     rc, out = _launch(1, ["--units-total", "11", "--window", "16"])  # one window larger than the shard
     assert rc == 0 and out[0]["unit_digests"] == win["unit_digests"] and out[0]["windows_by_rank"] == [1]
+
+
+def test_world8_gloo_ragged(nsc):
+    """the rank arithmetic of the 8-GPU job, end to end, before the driver's first 8-GPU contact --
+    launch_ranks(8) -> placement -> process group -> LUT broadcast to seven ranks -> shard_frames -> step loop -> gather, on
+    host tensors over gloo.  301 units: five shards of 38 and three of 37 (each with its overlap frame), every unit of every
+    shard against the oracle on its own rank, the 301 digests equal to the one-rank run's.  5 units: five ranks with one unit,
+    THREE EMPTY ranks that still take part in every collective.  A sink that fails on rank 6 ends the job on all eight."""
+    import time
+
+    rc, out = _launch(8, ["--units-total", "301", "--steps", "1"], timeout=900)
+    assert rc == 0 and len(out) == 1, out
+    eight = out[0]
+    assert eight["n_gpus"] == 8 and eight["units_per_step"] == 301
+    shards = [nsc.shard_frames(301, 8, r) for r in range(8)]
+    assert [c for _, c in shards] == [38] * 5 + [37] * 3 and [s for s, _ in shards] == [0, 38, 76, 114, 152, 190, 227, 264]
+    assert eight["units_by_rank"] == [c for _, c in shards] and eight["first_unit_by_rank"] == [s for s, _ in shards]
+    assert eight["checked_units_by_rank"] == eight["units_by_rank"] and eight["mismatches_by_rank"] == [0] * 8
+    assert eight["lut_bytes"] == len(nsc.build_tables_blob(48, 20, 96, 40)) and eight["tables_imported_by_rank"] == [0] + [1] * 7
+    assert eight["summary_equal_on_all_ranks"] is True
+    assert len(eight["elapsed_by_rank"]["by_rank"]) == 8 and eight["elapsed_s"] == pytest.approx(max(eight["elapsed_by_rank"]["by_rank"]), abs=1e-6)
+    rc, out = _launch(1, ["--units-total", "301", "--steps", "1"], timeout=900)
+    assert rc == 0 and len(out) == 1
+    d = eight["unit_digests"]
+    assert out[0]["unit_digests"] == d and len(d) == 301
+    # (frame k is the gradient shifted by k mod w: the 48-pixel-wide stream repeats after 48 units, across shard borders too)
+    assert len(set(d)) == 48 and all(d[k] == d[k + 48] for k in range(301 - 48))
+    rc, out = _launch(8, ["--units-total", "5", "--steps", "2", "--warmup", "1"], timeout=600)
+    assert rc == 0 and len(out) == 1, out
+    five = out[0]
+    assert five["units_by_rank"] == [1] * 5 + [0] * 3 and five["mismatches_by_rank"] == [0] * 8
+    assert five["checked_units_by_rank"] == [1] * 5 + [0] * 3 and five["tables_imported_by_rank"] == [0] + [1] * 7
+    assert five["unit_digests"] == eight["unit_digests"][:5]
+    t0 = time.time()
+    rc, out = _launch(8, ["--units-total", "20", "--sink-fails-on", "6"], timeout=300)
+    assert rc != 0 and out == [] and time.time() - t0 < 250
 
 
 def test_a_sink_that_raises_on_one_rank_ends_the_job(nsc):
@@ -132,11 +170,11 @@ def test_sharded_stream_one_rank_against_the_oracle(nsc, oracle_mod):
         assert s.placement["gpu_bdf_verified"] in (True, False, None) and "_replan" not in s.placement
         for k in range(n):
             a, b = oracle_mod.gen_gradient(w, h, k), oracle_mod.gen_gradient(w, h, k + 1)
-            assert np.array_equal(s.frames[k].cpu().numpy(), a)
+            assert np.array_equal(fetch(s.frames[k]), a)
             m = oracle_mod.warp_blend(a, b, None, 0.5)
-            assert np.array_equal(s.mid[k].cpu().numpy(), m)
+            assert np.array_equal(fetch(s.mid[k]), m)
             for got, src in ((s.up_real, a), (s.up_mid, m)):
-                d = np.abs(got[k].cpu().numpy().astype(np.int16) - oracle_mod.lanczos3(src, 2 * w, 2 * h, threads=0).astype(np.int16))
+                d = np.abs(fetch(got[k]).astype(np.int16) - oracle_mod.lanczos3(src, 2 * w, 2 * h, threads=0).astype(np.int16))
                 assert d.max() <= 1 and (d > 0).mean() < 1e-3
         d1 = s.unit_digests()
         s.schedule = "three-stage"

@@ -3,6 +3,8 @@ in-between frame blend(A, B) and upscale(blend(A, B)) for a batch of pairs from 
 Checked against the three separate stages (bit for bit, every mode) and against the CPU oracle."""
 import numpy as np
 import pytest
+from nu_scaler_amd.transfer import to_device as put, to_numpy as fetch  # host <-> HBM through nus_upload / nus_download, never
+# torch's pageable copies (docs/d2h_fault_analysis.md)
 
 pytestmark = pytest.mark.gpu
 
@@ -43,7 +45,7 @@ def test_unit_step_equals_the_three_stages(nsc, oracle_mod, w, h, th, t):
             frames_np[:, h // 3:2 * h // 3, :, 3] = 128
             frames_np[:, 2 * h // 3:, :, 3] = 255
             frames_np[3, :, :, 3] = 77
-        frames = torch.from_numpy(frames_np).to(dev)
+        frames = put(frames_np)
         for mode in ("fma", "exact"):
             for order in (1, 0):
                 u = nsc.PyWgpuUpscaler("quality", "lanczos3", lanczos_mode=mode)
@@ -65,7 +67,7 @@ def test_unit_step_equals_the_three_stages(nsc, oracle_mod, w, h, th, t):
                 assert torch.equal(up_mid, want_up_mid), ("up_mid", tag)
         # the in-between frames against the oracle itself (bit-exact: interpolation/mod.rs:407-411 truncation)
         for i in (0, n - 1):
-            assert np.array_equal(mid[i].cpu().numpy(), oracle_mod.warp_blend(frames_np[i], frames_np[i + 1], None, t))
+            assert np.array_equal(fetch(mid[i]), oracle_mod.warp_blend(frames_np[i], frames_np[i + 1], None, t))
 
 
 def test_unit_step_without_mid_buffer_and_separate_pair_buffers(nsc, oracle_mod):
@@ -76,7 +78,7 @@ def test_unit_step_without_mid_buffer_and_separate_pair_buffers(nsc, oracle_mod)
     dev = torch.device("cuda:0")
     a_np = np.stack([oracle_mod.gen_noise(w, h, 40 + i) for i in range(n)])
     b_np = np.stack([oracle_mod.gen_noise(w, h, 90 + i) for i in range(n)])
-    a, b = torch.from_numpy(a_np).to(dev), torch.from_numpy(b_np).to(dev)
+    a, b = put(a_np), put(b_np)
     u = nsc.PyWgpuUpscaler("quality", "lanczos3", lanczos_mode="exact")
     u.initialize(w, h, 2 * w, 2 * h)
     up_real = torch.zeros((n, 2 * h, 2 * w, 4), dtype=torch.uint8, device=dev)
@@ -85,9 +87,9 @@ def test_unit_step_without_mid_buffer_and_separate_pair_buffers(nsc, oracle_mod)
                           torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
     for i in range(n):
-        assert np.array_equal(up_real[i].cpu().numpy(), oracle_mod.lanczos3(a_np[i], 2 * w, 2 * h))
+        assert np.array_equal(fetch(up_real[i]), oracle_mod.lanczos3(a_np[i], 2 * w, 2 * h))
         m = oracle_mod.warp_blend(a_np[i], b_np[i], None, 0.5)
-        assert np.array_equal(up_mid[i].cpu().numpy(), oracle_mod.lanczos3(m, 2 * w, 2 * h))
+        assert np.array_equal(fetch(up_mid[i]), oracle_mod.lanczos3(m, 2 * w, 2 * h))
 
 
 def test_unit_step_bgra_input_and_other_filters(nsc, oracle_mod):
@@ -97,7 +99,7 @@ def test_unit_step_bgra_input_and_other_filters(nsc, oracle_mod):
     w, h, n = 248, 33, 2
     dev = torch.device("cuda:0")
     frames_np = np.stack([oracle_mod.gen_noise(w, h, 5 + i) for i in range(n + 1)])
-    frames = torch.from_numpy(frames_np).to(dev)
+    frames = put(frames_np)
     fb = w * h * 4
     s = torch.cuda.current_stream().cuda_stream
     for alg, fmt in (("lanczos3", "bgra"), ("bicubic", "rgba"), ("triangle", "rgba")):
@@ -134,7 +136,7 @@ def test_unit_step_1080p_bench_shape(nsc, oracle_mod, rows_per_wave):
     for pattern in ("gradient", "noise"):
         gen = (lambda k: oracle_mod.gen_gradient(w, h, k)) if pattern == "gradient" else (lambda k: oracle_mod.gen_noise(w, h, 60 + k))
         frames_np = np.stack([gen(k) for k in range(n + 1)])
-        frames = torch.from_numpy(frames_np).to(dev)
+        frames = put(frames_np)
         pipe = nsc.FramePipeline(w, h, 2, "lanczos3", 0.5)
         pipe.upscaler.set_option("rows_per_wave", rows_per_wave)
         mid, up_real, up_mid = pipe.alloc(n, dev)
@@ -144,10 +146,10 @@ def test_unit_step_1080p_bench_shape(nsc, oracle_mod, rows_per_wave):
         torch.cuda.synchronize()
         for k in (0, n - 1):
             m = oracle_mod.warp_blend(frames_np[k], frames_np[k + 1], None, 0.5, threads=0)
-            assert np.array_equal(mid[k].cpu().numpy(), m), (pattern, k)
+            assert np.array_equal(fetch(mid[k]), m), (pattern, k)
             for got, src in ((up_real, frames_np[k]), (up_mid, m)):
                 want = oracle_mod.lanczos3(src, 2 * w, 2 * h, threads=0).astype(np.int16)
-                d = np.abs(got[k].cpu().numpy().astype(np.int16) - want)
+                d = np.abs(fetch(got[k]).astype(np.int16) - want)
                 assert d.max() <= 1 and (d > 0).mean() < 1e-3, (pattern, k, int(d.max()), float((d > 0).mean()))
 
 
@@ -182,7 +184,7 @@ def test_unit_step_strided_source_frames_keep_mid_packed(nsc, oracle_mod):
     fb = w * h * 4
     s = torch.cuda.current_stream().cuda_stream
     pool_np = np.stack([oracle_mod.gen_noise(w, h, 300 + i) for i in range(2 * n)])
-    pool = torch.from_numpy(pool_np).to(dev)
+    pool = put(pool_np)
     a, b = pool[0::2].contiguous(), pool[1::2].contiguous()
     u = nsc.PyWgpuUpscaler("quality", "lanczos3")
     u.set_option("rows_per_wave", 12)
@@ -200,7 +202,7 @@ def test_unit_step_strided_source_frames_keep_mid_packed(nsc, oracle_mod):
     assert bool((mid[n:] == 0xAB).all()), "in-between frames written at the source stride"
     assert torch.equal(up_real, want_real) and torch.equal(up_mid, want_up_mid)
     for i in range(n):
-        assert np.array_equal(mid[i].cpu().numpy(), oracle_mod.warp_blend(pool_np[2 * i], pool_np[2 * i + 1], None, 0.5))
+        assert np.array_equal(fetch(mid[i]), oracle_mod.warp_blend(pool_np[2 * i], pool_np[2 * i + 1], None, 0.5))
 
 
 def test_unit_step_64_units_1080p_equals_three_stages_everywhere(nsc, oracle_mod):
@@ -231,8 +233,8 @@ def test_unit_step_64_units_1080p_equals_three_stages_everywhere(nsc, oracle_mod
                 assert torch.equal(a, b), (pattern, order, name)
         # and one unit against the oracle, edge columns included
         k = n - 1
-        m = oracle_mod.warp_blend(frames[k].cpu().numpy(), frames[k + 1].cpu().numpy(), None, 0.5, threads=0)
-        assert np.array_equal(got[0][k].cpu().numpy(), m)
-        d = np.abs(got[2][k].cpu().numpy().astype(np.int16) - oracle_mod.lanczos3(m, 2 * w, 2 * h, threads=0).astype(np.int16))
+        m = oracle_mod.warp_blend(fetch(frames[k]), fetch(frames[k + 1]), None, 0.5, threads=0)
+        assert np.array_equal(fetch(got[0][k]), m)
+        d = np.abs(fetch(got[2][k]).astype(np.int16) - oracle_mod.lanczos3(m, 2 * w, 2 * h, threads=0).astype(np.int16))
         assert d.max() <= 1 and (d > 0).mean() < 1e-3
         del want, got, frames

@@ -10,9 +10,8 @@ import torch
 
 import nu_scaler_amd as nsc
 import oracle as orc
-from nu_scaler_amd import hostmem
+from nu_scaler_amd.transfer import to_numpy as fetch  # noqa: E402  (device -> host through nus_download)
 
-hostmem.route_tensor_cpu_through_pinned_staging()
 rng = np.random.default_rng(11)
 bad = cases = 0
 for k in range(80):
@@ -48,7 +47,7 @@ for k in range(80):
         u.initialize(w, h, ow, oh)
         u.upscale_device(d_in.data_ptr(), d_out.data_ptr(), 3)
         torch.cuda.synchronize()
-        got = d_out.cpu().numpy()
+        got = fetch(d_out)
         for j in range(3):
             cases += 1
             if not np.array_equal(got[j], orc.bilinear(frames[j], ow, oh)):

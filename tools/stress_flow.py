@@ -5,8 +5,7 @@ import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 import nu_scaler_amd as nsc
-from nu_scaler_amd import hostmem
-hostmem.route_tensor_cpu_through_pinned_staging()  # device -> pinned staging -> numpy (nu_scaler_amd/hostmem.py)
+from nu_scaler_amd.transfer import to_numpy as fetch  # noqa: E402  (device -> host through nus_download)
 import oracle as orc
 rng = np.random.default_rng(11)
 bad = cases = 0
@@ -24,7 +23,7 @@ for _ in range(24):
         d_flows.fill_(float("nan"))
         fe.estimate_device_stream(d_frames.data_ptr(), n, w, h, d_flows.data_ptr(), torch.cuda.current_stream().cuda_stream)
         torch.cuda.synchronize()
-        got = d_flows.cpu().numpy()
+        got = fetch(d_flows)
         ok = all(np.array_equal(got[k], want[k]) for k in range(n - 1))
         cases += 1
         if not ok:
@@ -50,7 +49,7 @@ for _ in range(16):
         d_flows = torch.full((n - 1, h, w, 2), float("nan"), dtype=torch.float32, device=dev)
         fe.estimate_device_stream(d_frames.data_ptr(), n, w, h, d_flows.data_ptr(), torch.cuda.current_stream().cuda_stream)
         torch.cuda.synchronize()
-        got[form] = d_flows.cpu().numpy()
+        got[form] = fetch(d_flows)
     os.environ.pop("NUS_HS_FAST_SHIFT", None)
     want = np.stack([orc.flow_estimate(frames[k], frames[k + 1], levels, ci, ri, fe.lambda_) for k in range(n - 1)])
     cases += 1

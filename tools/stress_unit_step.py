@@ -11,9 +11,8 @@ import torch
 
 import nu_scaler_amd as nsc
 
-from nu_scaler_amd import hostmem  # noqa: E402
+from nu_scaler_amd.transfer import to_numpy as fetch  # noqa: E402  (device -> host through nus_download)
 
-hostmem.route_tensor_cpu_through_pinned_staging()  # device -> pinned staging -> numpy (nu_scaler_amd/hostmem.py)
 import oracle
 
 oracle.build()
@@ -74,8 +73,8 @@ for case in range(cases):
         filt = {"lanczos3": 0, "bicubic": 1, "triangle": 2}[alg]
         k = int(rng.integers(0, n))
         m = oracle.warp_blend(frames_np[k], frames_np[k + 1], None, t)
-        ok = (np.array_equal(mid[k].cpu().numpy(), m) and np.array_equal(up_real[k].cpu().numpy(), oracle.resize(frames_np[k], 2 * w, 2 * h, filt))
-              and np.array_equal(up_mid[k].cpu().numpy(), oracle.resize(m, 2 * w, 2 * h, filt)))
+        ok = (np.array_equal(fetch(mid[k]), m) and np.array_equal(fetch(up_real[k]), oracle.resize(frames_np[k], 2 * w, 2 * h, filt))
+              and np.array_equal(fetch(up_mid[k]), oracle.resize(m, 2 * w, 2 * h, filt)))
     if not ok:
         bad += 1
         print("MISMATCH", dict(w=w, h=h, n=n, th=th, t=t, order=order, mode=mode, alg=alg, fmt=fmt, content=content), flush=True)
