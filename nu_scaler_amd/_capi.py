@@ -212,6 +212,8 @@ class PinnedBuffer:
     the host entry points then copy straight from / into it (nus_host_pin / nus_host_unpin).  Keep the object as long as the
     buffer is handed to upscale / upscale_batch / interpolate calls; do not resize the buffer meanwhile."""
 
+    _addr = None  # (so that __del__ of an object whose __init__ raised early finds the attribute)
+
     def __init__(self, buffer):
         mv = memoryview(buffer)
         if mv.readonly or not mv.c_contiguous:

@@ -71,3 +71,76 @@ def golden():
         "test_output": read_png(os.path.join(GOLDEN, "ref_test_output.png")),
         "interp_half": read_png(os.path.join(GOLDEN, "ref_interp_half.png")),
     }
+
+
+class _Guarded:
+    """Device tensors for the OUTPUTS of the `*_device` entry points, carved out of a larger allocation with 64 KiB of a poison
+    byte in front of and behind the tensor (a kernel that stored past a caller's buffer once passed its first
+    test shape because the overrun landed in memory the process owned).  Same call shapes as torch.empty / zeros / full /
+    *_like; `assert_intact()` synchronises and checks every guard handed out since the last check -- the autouse fixture below
+    calls it after every test, tests may call it earlier."""
+
+    GUARD = 1 << 16
+    POISON = 0xA7
+
+    def __init__(self):
+        self._live = []
+
+    def _carve(self, shape, dtype, device, fill):
+        import math
+
+        import torch
+
+        if len(shape) == 1 and not isinstance(shape[0], int):
+            shape = tuple(shape[0])
+        shape = tuple(int(s) for s in shape)
+        dtype = dtype or torch.float32
+        n = math.prod(shape) * torch.empty((), dtype=dtype).element_size()
+        pad = (-n) % 256
+        flat = torch.full((2 * self.GUARD + n + pad,), self.POISON, dtype=torch.uint8, device=device)
+        payload = flat[self.GUARD:self.GUARD + n].view(dtype).view(shape)
+        if fill is not None:
+            payload.fill_(fill)
+        self._live.append((flat, n))
+        return payload
+
+    def empty(self, *shape, dtype=None, device=None):
+        return self._carve(shape, dtype, device, None)  # (poison inside as well: an output the kernel must write completely)
+
+    def zeros(self, *shape, dtype=None, device=None):
+        return self._carve(shape, dtype, device, 0)
+
+    def full(self, shape, value, dtype=None, device=None):
+        return self._carve((shape,) if isinstance(shape, int) else tuple(shape), dtype, device, value)
+
+    def empty_like(self, t):
+        return self._carve(tuple(t.shape), t.dtype, t.device, None)
+
+    def zeros_like(self, t):
+        return self._carve(tuple(t.shape), t.dtype, t.device, 0)
+
+    def like(self, tensors):
+        """Zero-filled guarded tensors with the shapes of `tensors` (what FramePipeline.alloc returns)."""
+        return tuple(self.zeros_like(t) for t in tensors)
+
+    def assert_intact(self):
+        if not self._live:
+            return
+        import torch
+
+        torch.cuda.synchronize()
+        live, self._live = self._live, []
+        for i, (flat, n) in enumerate(live):
+            front, back = flat[:self.GUARD], flat[self.GUARD + n:]
+            bad_f, bad_b = int((front != self.POISON).sum()), int((back != self.POISON).sum())
+            assert bad_f == 0 and bad_b == 0, (f"guard band of device output #{i} ({n} bytes) was written: {bad_f} bytes in front, "
+                                               f"{bad_b} bytes behind")
+
+
+guarded = _Guarded()
+
+
+@pytest.fixture(autouse=True)
+def _device_output_guards():
+    yield
+    guarded.assert_intact()

@@ -30,7 +30,7 @@ def main():
 
         import nu_scaler_amd as nsc
 
-    fetch = nsc.transfer.to_numpy  # device -> host through nus_download, never Tensor.cpu() (docs/d2h_fault_analysis.md)
+        fetch = nsc.transfer.to_numpy  # device -> host through nus_download, never Tensor.cpu() (docs/d2h_fault_analysis.md)
         import oracle
 
         oracle.build()
@@ -44,7 +44,7 @@ def main():
         dst.initialize(w, h, 2 * w, 2 * h)
         dst.import_tables(got)
         lut = nsc.broadcast_tables(dst, 0, dev, force=True)  # the bench's own call, world-1 return bypassed
-        frames = torch.stack([torch.from_numpy(oracle.gen_noise(w, h, 11 + rank * n + k)) for k in range(n)]).to(dev)
+        frames = nsc.transfer.to_device(np.stack([oracle.gen_noise(w, h, 11 + rank * n + k) for k in range(n)]), dev)
         out = torch.empty((n, 2 * h, 2 * w, 4), dtype=torch.uint8, device=dev)
         dst.upscale_device(frames.data_ptr(), out.data_ptr(), n, torch.cuda.current_stream().cuda_stream)
         torch.cuda.synchronize()

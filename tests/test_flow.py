@@ -2,6 +2,7 @@
 HIP kernels against the oracle on GPU.  No reference fixture pins this row."""
 import numpy as np
 import pytest
+from conftest import guarded  # device outputs between poisoned guard bands (tests/conftest.py)
 from nu_scaler_amd.transfer import to_device as put, to_numpy as fetch  # host <-> HBM through nus_upload / nus_download, never
 # torch's pageable copies (docs/d2h_fault_analysis.md)
 
@@ -167,14 +168,14 @@ def test_flow_estimate_device_path(nsc, oracle_mod):
     a, b = _smooth(w, h, 0.0), _smooth(w, h, 1.5)
     dev = torch.device("cuda:0")
     da, db = put(a), put(b)
-    dflow = torch.empty((h, w, 2), dtype=torch.float32, device=dev)
+    dflow = guarded.empty((h, w, 2), dtype=torch.float32, device=dev)
     fe = nsc.FlowEstimator(levels=4, coarse_iterations=30, refine_iterations=8)
     fe.estimate_device(da.data_ptr(), db.data_ptr(), w, h, dflow.data_ptr(), torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
     assert np.array_equal(fetch(dflow), oracle_mod.flow_estimate(a, b, 4, 30, 8, fe.lambda_))
     # and straight into the warp on the device
     it = nsc.WgpuFrameInterpolator()
-    out = torch.empty((h, w, 4), dtype=torch.uint8, device=dev)
+    out = guarded.empty((h, w, 4), dtype=torch.uint8, device=dev)
     it.interpolate_device(da.data_ptr(), w * h * 4, db.data_ptr(), w * h * 4, dflow.data_ptr(), w, h, 0.5, out.data_ptr(), 1,
                           torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
@@ -193,7 +194,7 @@ def test_flow_estimate_device_stream_equals_pairwise(nsc, oracle_mod, n_frames):
     frames = np.stack([oracle_mod.gen_noise(w, h, 60 + k) for k in range(n_frames)])
     dev = torch.device("cuda:0")
     d_frames = put(frames)
-    d_flows = torch.full((n_frames - 1, h, w, 2), float("nan"), dtype=torch.float32, device=dev)
+    d_flows = guarded.full((n_frames - 1, h, w, 2), float("nan"), dtype=torch.float32, device=dev)
     fe = nsc.FlowEstimator(levels=3, coarse_iterations=9, refine_iterations=3)
     want = [oracle_mod.flow_estimate(frames[k], frames[k + 1], 3, 9, 3, fe.lambda_) for k in range(n_frames - 1)]
     for tiled in (1, 2, 3, 0):
@@ -218,7 +219,7 @@ def test_flow_estimate_device_stream_big_batch(nsc, oracle_mod):
     frames = np.stack([oracle_mod.gen_noise(w, h, 90 + k) for k in range(n_frames)])
     dev = torch.device("cuda:0")
     d_frames = put(frames)
-    d_flows = torch.full((n_frames - 1, h, w, 2), float("nan"), dtype=torch.float32, device=dev)
+    d_flows = guarded.full((n_frames - 1, h, w, 2), float("nan"), dtype=torch.float32, device=dev)
     fe = nsc.FlowEstimator(levels=3, coarse_iterations=7, refine_iterations=6)
     fe.estimate_device_stream(d_frames.data_ptr(), n_frames, w, h, d_flows.data_ptr(), torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
@@ -238,8 +239,8 @@ def test_pipeline_step_motion_matches_stage_by_stage_oracle(nsc, oracle_mod):
     dev = torch.device("cuda:0")
     d_frames = put(frames)
     pipe = nsc.FramePipeline(w, h, 2, "lanczos3", 0.5, lanczos_mode="exact")
-    mid, up_real, up_mid = pipe.alloc(n, dev)
-    flows = torch.empty((n, h, w, 2), dtype=torch.float32, device=dev)
+    mid, up_real, up_mid = guarded.like(pipe.alloc(n, dev))
+    flows = guarded.empty((n, h, w, 2), dtype=torch.float32, device=dev)
     pipe.step_motion(d_frames, flows, mid, up_real, up_mid, torch.cuda.current_stream().cuda_stream,
                      levels=3, coarse_iterations=20, refine_iterations=5)
     torch.cuda.synchronize()
@@ -291,7 +292,7 @@ def test_flow_fast_mode_within_a_thousandth_of_a_pixel(nsc, oracle_mod, w, h, le
         assert fe.mode == "fast"
         want = [oracle_mod.flow_estimate(frames[k], frames[k + 1], levels, coarse, refine, fe.lambda_) for k in range(n_frames - 1)]
         d_frames = put(frames)
-        d_flows = torch.full((n_frames - 1, h, w, 2), float("nan"), dtype=torch.float32, device=dev)
+        d_flows = guarded.full((n_frames - 1, h, w, 2), float("nan"), dtype=torch.float32, device=dev)
         s = torch.cuda.current_stream().cuda_stream
         # kernels by size (1): a batch this small takes the exact LDS-tile kernels, whose result meets the contract trivially;
         # streamed kernel forced (3): the FAST kernels themselves -- k_pyramid_fast, k_hs_stream_fast -- at these ragged sizes
@@ -307,7 +308,7 @@ def test_flow_fast_mode_within_a_thousandth_of_a_pixel(nsc, oracle_mod, w, h, le
                 assert ok, (kind, "stream", tiled, k, mx)
             if tiled == 3:
                 assert any(not np.array_equal(got[k], want[k]) for k in range(n_frames - 1)), "the FAST kernels did not run"
-            one = torch.full((h, w, 2), float("nan"), dtype=torch.float32, device=dev)
+            one = guarded.full((h, w, 2), float("nan"), dtype=torch.float32, device=dev)
             fe.estimate_device(d_frames[1].data_ptr(), d_frames[2].data_ptr(), w, h, one.data_ptr(), s)
             torch.cuda.synchronize()
             assert np.array_equal(fetch(one), got[1]), (kind, tiled, "a pair alone = the same pair inside a stream")
@@ -336,7 +337,7 @@ def test_flow_fast_mode_1080p_contract(nsc, oracle_mod):
     want = oracle_mod.flow_estimate(a, b, 3, 50, 10, fe.lambda_)
     fe.set_mode("fast")
     frames = put(np.stack([a, b]))
-    flow = torch.empty((1, h, w, 2), dtype=torch.float32, device=dev)
+    flow = guarded.empty((1, h, w, 2), dtype=torch.float32, device=dev)
     s = torch.cuda.current_stream().cuda_stream
     fe.estimate_device_stream(frames.data_ptr(), 2, w, h, flow.data_ptr(), s)
     torch.cuda.synchronize()
@@ -344,7 +345,7 @@ def test_flow_fast_mode_1080p_contract(nsc, oracle_mod):
     ok, mx = _flow_close(got, want)
     assert ok, mx
     it = nsc.WgpuFrameInterpolator()
-    out = torch.empty((h, w, 4), dtype=torch.uint8, device=dev)
+    out = guarded.empty((h, w, 4), dtype=torch.uint8, device=dev)
     fb = w * h * 4
     it.interpolate_device(frames.data_ptr(), fb, frames.data_ptr() + fb, fb, flow.data_ptr(), w, h, 0.5, out.data_ptr(), 1, s)
     torch.cuda.synchronize()
@@ -378,7 +379,7 @@ def test_flow_fast_ring_form_equals_the_shifting_form(nsc, oracle_mod, w, h, lev
         fe = nsc.FlowEstimator(levels=levels, coarse_iterations=coarse, refine_iterations=refine)
         fe.set_mode("fast")
         fe.set_tiled(3)  # the streamed kernels whatever the batch size
-        flows = torch.full((n_frames - 1, h, w, 2), float("nan"), dtype=torch.float32, device=dev)
+        flows = guarded.full((n_frames - 1, h, w, 2), float("nan"), dtype=torch.float32, device=dev)
         fe.estimate_device_stream(d_frames.data_ptr(), n_frames, w, h, flows.data_ptr(), s)
         torch.cuda.synchronize()
         got[form] = fetch(flows)
@@ -418,9 +419,9 @@ def test_interpolate_device_stream_equals_estimate_then_warp(nsc, oracle_mod, w,
         fe = nsc.FlowEstimator(levels=levels, coarse_iterations=coarse, refine_iterations=refine)
         fe.set_mode(mode)
         fe.set_tiled(tiled)
-        flows = torch.full((n_frames - 1, h, w, 2), float("nan"), dtype=torch.float32, device=dev)
+        flows = guarded.full((n_frames - 1, h, w, 2), float("nan"), dtype=torch.float32, device=dev)
         fe.estimate_device_stream(d_frames.data_ptr(), n_frames, w, h, flows.data_ptr(), s)
-        want_mid = torch.zeros((n_frames - 1, h, w, 4), dtype=torch.uint8, device=dev)
+        want_mid = guarded.zeros((n_frames - 1, h, w, 4), dtype=torch.uint8, device=dev)
         it.interpolate_device(d_frames.data_ptr(), fb, d_frames.data_ptr() + fb, fb, flows.data_ptr(), w, h, t, want_mid.data_ptr(),
                               n_frames - 1, s)
         torch.cuda.synchronize()
@@ -465,17 +466,17 @@ def test_step_motion_fused_warp_equals_separate_stages(nsc, oracle_mod, in_kerne
     pipe = nsc.FramePipeline(w, h, 2, "lanczos3", 0.5)
     pipe.interp.set_mode("fma")
     s = torch.cuda.current_stream().cuda_stream
-    want = pipe.alloc(n, dev)
-    flows = torch.empty((n, h, w, 2), dtype=torch.float32, device=dev)
+    want = guarded.like(pipe.alloc(n, dev))
+    flows = guarded.empty((n, h, w, 2), dtype=torch.float32, device=dev)
     pipe.step_motion(frames, flows, *want, s, flow_mode="fast")
     torch.cuda.synchronize()
     for kw in (dict(fused_warp=True), dict(fused_warp=True, pipelined=True, chunk=3), dict(fused_warp=True, pipelined=True, chunk=3, no_flows=True),
                dict(fused_warp=True, no_flows=True)):
         no_flows = kw.pop("no_flows", False)
-        got = pipe.alloc(n, dev)
+        got = guarded.like(pipe.alloc(n, dev))
         for t_ in got:
             t_.zero_()
-        got_flows = None if no_flows else torch.zeros_like(flows)
+        got_flows = None if no_flows else guarded.zeros_like(flows)
         pipe.step_motion(frames, got_flows, *got, s, flow_mode="fast", **kw)
         torch.cuda.synchronize()
         for a, b in zip(got, want):
@@ -508,12 +509,12 @@ def test_interpolate_device_stream_rg16float_handoff(nsc, oracle_mod, w, h, leve
         fe = nsc.FlowEstimator(levels=levels, coarse_iterations=coarse, refine_iterations=refine)
         fe.set_mode(mode)
         fe.set_tiled(tiled)
-        flows32 = torch.empty((n_frames - 1, h, w, 2), dtype=torch.float32, device=dev)
-        mid32 = torch.empty((n_frames - 1, h, w, 4), dtype=torch.uint8, device=dev)
+        flows32 = guarded.empty((n_frames - 1, h, w, 2), dtype=torch.float32, device=dev)
+        mid32 = guarded.empty((n_frames - 1, h, w, 4), dtype=torch.uint8, device=dev)
         fe.interpolate_device_stream(d_frames.data_ptr(), n_frames, w, h, t, mid32.data_ptr(), flows32.data_ptr(), s)
         want16 = flows32.to(torch.float16)
         it.set_flow_format("f16")
-        want_mid = torch.zeros_like(mid32)
+        want_mid = guarded.zeros_like(mid32)
         it.interpolate_device(d_frames.data_ptr(), fb, d_frames.data_ptr() + fb, fb, want16.data_ptr(), w, h, t, want_mid.data_ptr(),
                               n_frames - 1, s)
         it.set_flow_format("f32")
@@ -522,7 +523,7 @@ def test_interpolate_device_stream_rg16float_handoff(nsc, oracle_mod, w, h, leve
             # the f16 flows take 4 bytes per cell: a guard of the same size again behind them must stay untouched (a kernel that
             # stored 2 x f32 per cell into the caller's buffer would run over it -- the first version of this path did, round 5)
             cells = (n_frames - 1) * h * w
-            buf = torch.full((2 * cells, 2), 1234.0, dtype=torch.float16, device=dev)
+            buf = guarded.full((2 * cells, 2), 1234.0, dtype=torch.float16, device=dev)
             got16 = buf[:cells].view(n_frames - 1, h, w, 2)
             got16.fill_(float("nan"))
             got_mid = torch.full_like(mid32, 0xAB)

@@ -7,6 +7,7 @@ the C oracle -- each pass alone and the fused pair.
 """
 import numpy as np
 import pytest
+from conftest import guarded  # device outputs between poisoned guard bands (tests/conftest.py)
 from nu_scaler_amd.transfer import to_device as put, to_numpy as fetch  # host <-> HBM through nus_upload / nus_download, never
 # torch's pageable copies (docs/d2h_fault_analysis.md)
 
@@ -97,8 +98,8 @@ def test_gpu_fsr1_1080p_to_4k_device_batch(nsc, oracle_mod):
     u.initialize(w, h, 2 * w, 2 * h)
     assert u.kernel_variant == "fsr1_easu_then_rcas_rows"
     d_in = put(frames)
-    d_out = torch.empty((n, 2 * h, 2 * w, 4), dtype=torch.uint8, device="cuda")
-    d_out2 = torch.empty_like(d_out)
+    d_out = guarded.empty((n, 2 * h, 2 * w, 4), dtype=torch.uint8, device="cuda")
+    d_out2 = guarded.empty_like(d_out)
     side = torch.cuda.Stream()
     u.upscale_device(d_in.data_ptr(), d_out.data_ptr(), n, torch.cuda.current_stream().cuda_stream)
     rev = d_in.flip(0).contiguous()
@@ -174,7 +175,7 @@ def test_gpu_fsr_fast_1080p_to_4k_device_batch(nsc, oracle_mod):
         u = nsc.PyWgpuUpscaler("quality", alg)
         u.set_option("fsr_fast", 1)
         u.initialize(w, h, 2 * w, 2 * h)
-        d_out = torch.empty((3, 2 * h, 2 * w, 4), dtype=torch.uint8, device="cuda")
+        d_out = guarded.empty((3, 2 * h, 2 * w, 4), dtype=torch.uint8, device="cuda")
         u.upscale_device(d_in.data_ptr(), d_out.data_ptr(), 3, torch.cuda.current_stream().cuda_stream)
         torch.cuda.synchronize()
         outs[alg] = fetch(d_out)

@@ -9,7 +9,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import GOLDEN
+from conftest import GOLDEN, guarded
 from nu_scaler_amd.transfer import to_device as put, to_numpy as fetch  # host <-> HBM through nus_upload / nus_download, never
 # torch's pageable copies (docs/d2h_fault_analysis.md)
 
@@ -313,7 +313,7 @@ def test_warp_blend_fma_mode_within_one_lsb(nsc, oracle_mod, size):
     s = torch.cuda.current_stream().cuda_stream
     it = nsc.WgpuFrameInterpolator()
     assert it.mode == "exact"
-    out = torch.zeros((n, h, w, 4), dtype=torch.uint8, device=dev)
+    out = guarded.zeros((n, h, w, 4), dtype=torch.uint8, device=dev)
     for t in (0.5, 0.3):
         for fmt in ("f32", "f16"):
             fl_np = flow if fmt == "f32" else flow.astype(np.float16)
@@ -359,7 +359,7 @@ def test_warp_blend_with_f16_flow_field(nsc, oracle_mod):
     dev = torch.device("cuda:0")
     frames = put(frames_np)
     d_flow16 = put(flow16)
-    out = torch.zeros((n, h, w, 4), dtype=torch.uint8, device=dev)
+    out = guarded.zeros((n, h, w, 4), dtype=torch.uint8, device=dev)
     it = nsc.WgpuFrameInterpolator()
     it.set_flow_format("f16")
     fb = w * h * 4
@@ -622,14 +622,14 @@ def test_device_batch_path_matches_host_path(nsc, oracle_mod):
     for alg, ref in (("nearest", oracle_mod.nearest), ("bilinear", oracle_mod.bilinear), ("lanczos3", oracle_mod.lanczos3)):
         u = nsc.PyWgpuUpscaler("quality", alg, lanczos_mode="exact")
         u.initialize(w, h, 2 * w, 2 * h)
-        out = torch.zeros((n, 2 * h, 2 * w, 4), dtype=torch.uint8, device=dev)
+        out = guarded.zeros((n, 2 * h, 2 * w, 4), dtype=torch.uint8, device=dev)
         u.upscale_device(frames.data_ptr(), out.data_ptr(), n, torch.cuda.current_stream().cuda_stream)
         torch.cuda.synchronize()
         got = fetch(out)
         for i in range(n):
             assert np.array_equal(got[i], ref(frames_np[i], 2 * w, 2 * h)), (alg, i)
     pipe = nsc.FramePipeline(w, h, 2, "lanczos3", 0.5, lanczos_mode="exact")
-    mid, up_real, up_mid = pipe.alloc(n, dev)
+    mid, up_real, up_mid = guarded.like(pipe.alloc(n, dev))
     pipe.step(frames, mid, up_real, up_mid, torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
     for i in range(n):
@@ -693,9 +693,9 @@ def test_bench_launch_shape_1080p_batch_rows_per_wave_36(nsc, oracle_mod):
         u.set_option("rows_per_wave", 36)
         u.initialize(w, h, 2 * w, 2 * h)
         assert u.kernel_variant == "lanczos3_x2_regwin"
-        out = torch.zeros((n, 2 * h, 2 * w, 4), dtype=torch.uint8, device=dev)
+        out = guarded.zeros((n, 2 * h, 2 * w, 4), dtype=torch.uint8, device=dev)
         u.upscale_device(frames.data_ptr(), out.data_ptr(), n, st)
-        fused = torch.zeros((n, 2 * h, 2 * w, 4), dtype=torch.uint8, device=dev)
+        fused = guarded.zeros((n, 2 * h, 2 * w, 4), dtype=torch.uint8, device=dev)
         fb = w * h * 4
         u.upscale_blend_device(frames.data_ptr(), fb, frames.data_ptr() + fb, fb, 0.5, fused.data_ptr(), n, st)
         torch.cuda.synchronize()
@@ -731,7 +731,7 @@ def test_swizzle_bgra_to_rgba_device(nsc, oracle_mod):
 
     for n in (64 * 36, 61 * 7):  # vector and scalar paths
         bgra = put(oracle_mod.gen_noise(n, 1, 77).reshape(n, 4).copy())
-        out = torch.empty_like(bgra)
+        out = guarded.empty_like(bgra)
         nsc.swizzle_bgra_to_rgba_device(bgra.data_ptr(), out.data_ptr(), n, torch.cuda.current_stream().cuda_stream)
         torch.cuda.synchronize()
         assert np.array_equal(fetch(out), fetch(bgra)[:, [2, 1, 0, 3]])
@@ -754,14 +754,14 @@ def test_fused_blend_upscale_equals_two_stage(nsc, oracle_mod, alg, t):
     for mode in ("exact", "fma"):
         u = nsc.PyWgpuUpscaler("quality", alg, lanczos_mode=mode)
         u.initialize(w, h, 2 * w, 2 * h)
-        fused = torch.zeros((n, 2 * h, 2 * w, 4), dtype=torch.uint8, device=dev)
+        fused = guarded.zeros((n, 2 * h, 2 * w, 4), dtype=torch.uint8, device=dev)
         fb = w * h * 4
         u.upscale_blend_device(frames.data_ptr(), fb, frames.data_ptr() + fb, fb, t, fused.data_ptr(), n,
                                torch.cuda.current_stream().cuda_stream)
         # two-stage reference on the GPU
         it = nsc.WgpuFrameInterpolator()
-        mid = torch.empty((n, h, w, 4), dtype=torch.uint8, device=dev)
-        two = torch.zeros_like(fused)
+        mid = guarded.empty((n, h, w, 4), dtype=torch.uint8, device=dev)
+        two = guarded.zeros_like(fused)
         s = torch.cuda.current_stream().cuda_stream
         it.interpolate_device(frames.data_ptr(), fb, frames.data_ptr() + fb, fb, 0, w, h, t, mid.data_ptr(), n, s)
         u.upscale_device(mid.data_ptr(), two.data_ptr(), n, s)
@@ -814,7 +814,7 @@ def test_device_path_is_graph_capturable(nsc, oracle_mod):
     frames_np = np.stack([oracle_mod.gen_noise(w, h, 600 + i) for i in range(n + 1)])
     frames = put(frames_np)
     pipe = nsc.FramePipeline(w, h, 2, "lanczos3", 0.5, lanczos_mode="exact")
-    mid, up_real, up_mid = pipe.alloc(n, dev)
+    mid, up_real, up_mid = guarded.like(pipe.alloc(n, dev))
     side = torch.cuda.Stream()
     with torch.cuda.stream(side):
         pipe.step(frames, mid, up_real, up_mid, side.cuda_stream)  # warm-up outside capture
@@ -888,7 +888,7 @@ def test_bgra_input_interpolator_and_fused_blend(nsc, oracle_mod):
             want = np.frombuffer(u.upscale(mid.tobytes()), np.uint8).reshape(2 * h, 2 * w, 4)
             u.set_input_format("bgra")
             da, db = put(_bgra(a)), put(_bgra(b))
-            out = torch.empty((2 * h, 2 * w, 4), dtype=torch.uint8, device="cuda")
+            out = guarded.empty((2 * h, 2 * w, 4), dtype=torch.uint8, device="cuda")
             u.upscale_blend_device(da.data_ptr(), 0, db.data_ptr(), 0, t, out.data_ptr(), 1, torch.cuda.current_stream().cuda_stream)
             torch.cuda.synchronize()
             assert np.array_equal(fetch(out), want), (alg, t)
@@ -1224,7 +1224,7 @@ def test_small_rational_factors_at_full_size(nsc, oracle_mod, dims):
     assert ue.kernel_variant == "lanczos3_pq_regwin" and np.array_equal(got_e, want)
     frames = np.stack([img, img[::-1].copy(), oracle_mod.gen_gradient(w, h)])
     d_in = put(frames)
-    d_out = torch.empty((3, oh, ow, 4), dtype=torch.uint8, device="cuda")
+    d_out = guarded.empty((3, oh, ow, 4), dtype=torch.uint8, device="cuda")
     torch.cuda.synchronize()
     uf.upscale_device(d_in.data_ptr(), d_out.data_ptr(), 3)
     torch.cuda.synchronize()
@@ -1263,7 +1263,7 @@ def test_1440p_to_4k_takes_the_three_halves_kernel(nsc, oracle_mod):
     n = 3
     frames_np = np.stack([oracle_mod.gen_gradient(w, h, k) for k in range(n)])
     frames = put(frames_np)
-    out = torch.zeros((n, oh, ow, 4), dtype=torch.uint8, device="cuda:0")
+    out = guarded.zeros((n, oh, ow, 4), dtype=torch.uint8, device="cuda:0")
     uf.upscale_device(frames.data_ptr(), out.data_ptr(), n, torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
     ug = nsc.PyWgpuUpscaler("quality", "lanczos3")
@@ -1299,7 +1299,7 @@ def test_720p_to_4k_x3_takes_the_fixed_weight_kernel(nsc, oracle_mod):
     n = 3
     frames_np = np.stack([oracle_mod.gen_gradient(w, h, k) for k in range(n)])
     frames = put(frames_np)
-    out = torch.zeros((n, oh, ow, 4), dtype=torch.uint8, device="cuda:0")
+    out = guarded.zeros((n, oh, ow, 4), dtype=torch.uint8, device="cuda:0")
     uf.upscale_device(frames.data_ptr(), out.data_ptr(), n, torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
     for k in range(n):
@@ -1320,7 +1320,7 @@ def test_device_batch_every_variant(nsc, oracle_mod, alg, dims):
     u.initialize(w, h, ow, oh)
     want = [np.frombuffer(u.upscale(f.tobytes()), np.uint8).reshape(oh, ow, 4) for f in frames]
     d_in = put(frames)
-    d_out = torch.zeros((3, oh, ow, 4), dtype=torch.uint8, device="cuda")
+    d_out = guarded.zeros((3, oh, ow, 4), dtype=torch.uint8, device="cuda")
     u.upscale_device(d_in.data_ptr(), d_out.data_ptr(), 3, torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
     got = fetch(d_out)
@@ -1477,7 +1477,7 @@ def test_resize_down_random_shapes(nsc, oracle_mod, seed):
             assert "exceeds 32 taps" in str(e), (w, h, ow, oh, str(e))
             continue
         d_in = put(frames)
-        d_out = torch.zeros((n, oh, ow, 4), dtype=torch.uint8, device="cuda")
+        d_out = guarded.zeros((n, oh, ow, 4), dtype=torch.uint8, device="cuda")
         u.upscale_device(d_in.data_ptr(), d_out.data_ptr(), n, torch.cuda.current_stream().cuda_stream)
         torch.cuda.synchronize()
         got = fetch(d_out)
@@ -1495,7 +1495,7 @@ def test_resize_down_4k_to_1080p_batch(nsc, oracle_mod):
     u.initialize(w, h, ow, oh)
     assert u.kernel_variant == "resize_down_stream"
     d_in = put(frames)
-    d_out = torch.zeros((3, oh, ow, 4), dtype=torch.uint8, device="cuda")
+    d_out = guarded.zeros((3, oh, ow, 4), dtype=torch.uint8, device="cuda")
     u.upscale_device(d_in.data_ptr(), d_out.data_ptr(), 3, torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
     got = fetch(d_out)
@@ -1603,7 +1603,7 @@ def test_more_frames_than_one_grid_axis_holds(nsc, oracle_mod):
     n, w, h = 66000, 16, 16
     rng = np.random.default_rng(5)
     frames = put(rng.integers(0, 256, (n + 1, h, w, 4), dtype=np.uint8))
-    out = torch.empty((n, 2 * h, 2 * w, 4), dtype=torch.uint8, device="cuda")
+    out = guarded.empty((n, 2 * h, 2 * w, 4), dtype=torch.uint8, device="cuda")
     s = torch.cuda.current_stream().cuda_stream
     probe = [0, 1, 65534, 65535, 65536, n - 1]
     for alg in ("nearest", "bilinear", "lanczos3"):
@@ -1626,7 +1626,7 @@ def test_more_frames_than_one_grid_axis_holds(nsc, oracle_mod):
         want = np.frombuffer(u.upscale(mid.tobytes()), np.uint8).reshape(2 * h, 2 * w, 4)
         assert np.array_equal(fetch(out[k]), want), ("fused", k)
     it = nsc.WgpuFrameInterpolator()
-    mid_all = torch.empty((n, h, w, 4), dtype=torch.uint8, device="cuda")
+    mid_all = guarded.empty((n, h, w, 4), dtype=torch.uint8, device="cuda")
     it.interpolate_device(frames.data_ptr(), fb, frames.data_ptr() + fb, fb, 0, w, h, 0.5, mid_all.data_ptr(), n, s)
     torch.cuda.synchronize()
     for k in probe:
@@ -1706,10 +1706,10 @@ def test_lanczos_x2_edge_pass_beside_the_main_kernel(nsc, oracle_mod):
         u = nsc.PyWgpuUpscaler("quality", "lanczos3", lanczos_mode="exact")
         u.set_option("edge_stream", beside)
         u.initialize(w, h, 2 * w, 2 * h)
-        plain = torch.zeros((n, 2 * h, 2 * w, 4), dtype=torch.uint8, device=dev)
+        plain = guarded.zeros((n, 2 * h, 2 * w, 4), dtype=torch.uint8, device=dev)
         u.upscale_device(frames.data_ptr(), plain.data_ptr(), n, s)
-        mid = torch.zeros((n, h, w, 4), dtype=torch.uint8, device=dev)
-        up_real, up_mid = torch.zeros_like(plain), torch.zeros_like(plain)
+        mid = guarded.zeros((n, h, w, 4), dtype=torch.uint8, device=dev)
+        up_real, up_mid = guarded.zeros_like(plain), guarded.zeros_like(plain)
         u.upscale_unit_device(frames.data_ptr(), fb, frames.data_ptr() + fb, fb, 0.5, mid.data_ptr(), up_real.data_ptr(), up_mid.data_ptr(), n, s)
         torch.cuda.synchronize()
         outs[beside] = (plain, up_real, up_mid, mid)
@@ -1749,7 +1749,7 @@ def test_probe_device_kinds_move_the_bytes_they_claim(nsc):
     w = dst[:n].view(torch.int32).reshape(-1, 4)
     assert torch.equal(w[:, 0], torch.arange(n // 16, dtype=torch.int32, device=dev)) and bool((w[:, 1:] == torch.tensor([1, 2, 3], dtype=torch.int32, device=dev)).all())
     assert bool((dst[n:] == 0xA5).all())
-    sink = torch.zeros(16, dtype=torch.uint8, device=dev)
+    sink = guarded.zeros(16, dtype=torch.uint8, device=dev)
     assert L.nus_probe_device(3, src.data_ptr(), sink.data_ptr(), n, 0, None) == 0  # read-only: nothing to compare, must not fault
     m = 64 * 1024  # whole waves: 4096 pieces of 16 bytes
     dst = torch.full((4 * m + guard,), 0xA5, dtype=torch.uint8, device=dev)
@@ -1760,7 +1760,7 @@ def test_probe_device_kinds_move_the_bytes_they_claim(nsc):
     for j in range(4):
         assert torch.equal(got[:, j], pieces), j
     assert bool((dst[4 * m:] == 0xA5).all())
-    scratch = torch.zeros(2048 * 256, dtype=torch.float32, device=dev)
+    scratch = guarded.zeros(2048 * 256, dtype=torch.float32, device=dev)
     assert L.nus_probe_device(5, None, scratch.data_ptr(), 0, 100, None) == 0
     torch.cuda.synchronize()
     assert float(scratch.abs().max()) == 0.0  # the FMA chains never write

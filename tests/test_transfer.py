@@ -164,3 +164,28 @@ def test_host_ranges_record_pins_and_the_librarys_own_pinned_memory(nsc):
     hist = [r for r in snapshot(1) if r[0] == addr and r[2] == 1]
     assert [r[3] for r in hist[-2:]] == [1, 0]
     assert L.nus_host_unpin(addr) == _capi.ERR_INVALID_ARGUMENT
+
+
+def test_guard_bands_catch_a_store_past_the_end(nsc):
+    """tests/conftest.py `guarded`: a kernel that writes 1 KiB past the end of a device output (the library's own write-only
+    probe kernel, told a size 1 KiB larger than the tensor -- the overrun stays inside the guarded allocation) is caught by the
+    check every GPU test runs at its end; an exact-size write is not."""
+    import torch
+
+    from conftest import guarded
+
+    n = 1 << 20
+    st = torch.cuda.current_stream().cuda_stream
+    L = _capi.lib()
+    src = torch.zeros(16, dtype=torch.uint8, device="cuda:0")
+    ok = guarded.empty(n, dtype=torch.uint8, device="cuda:0")
+    assert L.nus_probe_device(2, src.data_ptr(), ok.data_ptr(), n, 0, st) == _capi.OK, _capi.last_error()
+    guarded.assert_intact()
+    over = guarded.empty(n, dtype=torch.uint8, device="cuda:0")
+    assert L.nus_probe_device(2, src.data_ptr(), over.data_ptr(), n + 1024, 0, st) == _capi.OK, _capi.last_error()
+    with pytest.raises(AssertionError, match="guard band of device output #0 .* 1024 bytes behind"):
+        guarded.assert_intact()
+    under = guarded.empty(n, dtype=torch.uint8, device="cuda:0")
+    assert L.nus_probe_device(2, src.data_ptr(), under.data_ptr() - 512, n, 0, st) == _capi.OK, _capi.last_error()
+    with pytest.raises(AssertionError, match="512 bytes in front"):
+        guarded.assert_intact()

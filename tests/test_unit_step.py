@@ -3,6 +3,7 @@ in-between frame blend(A, B) and upscale(blend(A, B)) for a batch of pairs from 
 Checked against the three separate stages (bit for bit, every mode) and against the CPU oracle."""
 import numpy as np
 import pytest
+from conftest import guarded  # device outputs between poisoned guard bands (tests/conftest.py)
 from nu_scaler_amd.transfer import to_device as put, to_numpy as fetch  # host <-> HBM through nus_upload / nus_download, never
 # torch's pageable copies (docs/d2h_fault_analysis.md)
 
@@ -14,9 +15,9 @@ def _three_stage(nsc, torch, u, frames, w, h, n, t):
     fb = w * h * 4
     s = torch.cuda.current_stream().cuda_stream
     it = nsc.WgpuFrameInterpolator()
-    mid = torch.empty((n, h, w, 4), dtype=torch.uint8, device=dev)
-    up_real = torch.zeros((n, 2 * h, 2 * w, 4), dtype=torch.uint8, device=dev)
-    up_mid = torch.zeros_like(up_real)
+    mid = guarded.empty((n, h, w, 4), dtype=torch.uint8, device=dev)
+    up_real = guarded.zeros((n, 2 * h, 2 * w, 4), dtype=torch.uint8, device=dev)
+    up_mid = guarded.zeros_like(up_real)
     it.interpolate_device(frames.data_ptr(), fb, frames.data_ptr() + fb, fb, 0, w, h, t, mid.data_ptr(), n, s)
     u.upscale_device(frames.data_ptr(), up_real.data_ptr(), n, s)
     u.upscale_device(mid.data_ptr(), up_mid.data_ptr(), n, s)
@@ -55,9 +56,9 @@ def test_unit_step_equals_the_three_stages(nsc, oracle_mod, w, h, th, t):
                 u.initialize(w, h, 2 * w, 2 * h)
                 assert u.kernel_variant == "lanczos3_x2_regwin"
                 want_mid, want_real, want_up_mid = _three_stage(nsc, torch, u, frames, w, h, n, t)
-                mid = torch.zeros((n, h, w, 4), dtype=torch.uint8, device=dev)
-                up_real = torch.zeros((n, 2 * h, 2 * w, 4), dtype=torch.uint8, device=dev)
-                up_mid = torch.zeros_like(up_real)
+                mid = guarded.zeros((n, h, w, 4), dtype=torch.uint8, device=dev)
+                up_real = guarded.zeros((n, 2 * h, 2 * w, 4), dtype=torch.uint8, device=dev)
+                up_mid = guarded.zeros_like(up_real)
                 u.upscale_unit_device(frames.data_ptr(), fb, frames.data_ptr() + fb, fb, t, mid.data_ptr(), up_real.data_ptr(),
                                       up_mid.data_ptr(), n, s)
                 torch.cuda.synchronize()
@@ -81,8 +82,8 @@ def test_unit_step_without_mid_buffer_and_separate_pair_buffers(nsc, oracle_mod)
     a, b = put(a_np), put(b_np)
     u = nsc.PyWgpuUpscaler("quality", "lanczos3", lanczos_mode="exact")
     u.initialize(w, h, 2 * w, 2 * h)
-    up_real = torch.zeros((n, 2 * h, 2 * w, 4), dtype=torch.uint8, device=dev)
-    up_mid = torch.zeros_like(up_real)
+    up_real = guarded.zeros((n, 2 * h, 2 * w, 4), dtype=torch.uint8, device=dev)
+    up_mid = guarded.zeros_like(up_real)
     u.upscale_unit_device(a.data_ptr(), 0, b.data_ptr(), 0, 0.5, 0, up_real.data_ptr(), up_mid.data_ptr(), n,
                           torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
@@ -108,16 +109,16 @@ def test_unit_step_bgra_input_and_other_filters(nsc, oracle_mod):
         u.initialize(w, h, 2 * w, 2 * h)
         it = nsc.WgpuFrameInterpolator()
         it.set_input_format(fmt)
-        want_mid = torch.empty((n, h, w, 4), dtype=torch.uint8, device=dev)
+        want_mid = guarded.empty((n, h, w, 4), dtype=torch.uint8, device=dev)
         it.interpolate_device(frames.data_ptr(), fb, frames.data_ptr() + fb, fb, 0, w, h, 0.5, want_mid.data_ptr(), n, s)
-        want_real = torch.zeros((n, 2 * h, 2 * w, 4), dtype=torch.uint8, device=dev)
+        want_real = guarded.zeros((n, 2 * h, 2 * w, 4), dtype=torch.uint8, device=dev)
         u.upscale_device(frames.data_ptr(), want_real.data_ptr(), n, s)
         u.set_input_format("rgba")  # the in-between frames are RGBA already
-        want_up_mid = torch.zeros_like(want_real)
+        want_up_mid = guarded.zeros_like(want_real)
         u.upscale_device(want_mid.data_ptr(), want_up_mid.data_ptr(), n, s)
         u.set_input_format(fmt)
-        mid = torch.zeros_like(want_mid)
-        up_real, up_mid = torch.zeros_like(want_real), torch.zeros_like(want_real)
+        mid = guarded.zeros_like(want_mid)
+        up_real, up_mid = guarded.zeros_like(want_real), guarded.zeros_like(want_real)
         u.upscale_unit_device(frames.data_ptr(), fb, frames.data_ptr() + fb, fb, 0.5, mid.data_ptr(), up_real.data_ptr(),
                               up_mid.data_ptr(), n, s)
         torch.cuda.synchronize()
@@ -139,7 +140,7 @@ def test_unit_step_1080p_bench_shape(nsc, oracle_mod, rows_per_wave):
         frames = put(frames_np)
         pipe = nsc.FramePipeline(w, h, 2, "lanczos3", 0.5)
         pipe.upscaler.set_option("rows_per_wave", rows_per_wave)
-        mid, up_real, up_mid = pipe.alloc(n, dev)
+        mid, up_real, up_mid = guarded.like(pipe.alloc(n, dev))
         for tns in (mid, up_real, up_mid):
             tns.zero_()
         pipe.step_unit(frames, mid, up_real, up_mid, torch.cuda.current_stream().cuda_stream)
@@ -157,7 +158,7 @@ def test_unit_step_errors(nsc):
     import torch
 
     dev = torch.device("cuda:0")
-    x = torch.zeros(1 << 20, dtype=torch.uint8, device=dev)
+    x = guarded.zeros(1 << 20, dtype=torch.uint8, device=dev)
     u = nsc.PyWgpuUpscaler("quality", "bilinear")
     u.initialize(64, 32, 128, 64)
     with pytest.raises(RuntimeError, match="only the exact-x2 resize kernels"):
@@ -189,12 +190,12 @@ def test_unit_step_strided_source_frames_keep_mid_packed(nsc, oracle_mod):
     u = nsc.PyWgpuUpscaler("quality", "lanczos3")
     u.set_option("rows_per_wave", 12)
     u.initialize(w, h, 2 * w, 2 * h)
-    want_mid = torch.zeros((n, h, w, 4), dtype=torch.uint8, device=dev)
-    want_real = torch.zeros((n, 2 * h, 2 * w, 4), dtype=torch.uint8, device=dev)
-    want_up_mid = torch.zeros_like(want_real)
+    want_mid = guarded.zeros((n, h, w, 4), dtype=torch.uint8, device=dev)
+    want_real = guarded.zeros((n, 2 * h, 2 * w, 4), dtype=torch.uint8, device=dev)
+    want_up_mid = guarded.zeros_like(want_real)
     u.upscale_unit_device(a.data_ptr(), 0, b.data_ptr(), 0, 0.5, want_mid.data_ptr(), want_real.data_ptr(), want_up_mid.data_ptr(), n, s)
     mid = torch.full((2 * n, h, w, 4), 0xAB, dtype=torch.uint8, device=dev)  # n frames + n guard frames
-    up_real, up_mid = torch.zeros_like(want_real), torch.zeros_like(want_real)
+    up_real, up_mid = guarded.zeros_like(want_real), guarded.zeros_like(want_real)
     u.upscale_unit_device(pool.data_ptr(), 2 * fb, pool.data_ptr() + fb, 2 * fb, 0.5, mid.data_ptr(), up_real.data_ptr(),
                           up_mid.data_ptr(), n, s)
     torch.cuda.synchronize()
@@ -219,10 +220,10 @@ def test_unit_step_64_units_1080p_equals_three_stages_everywhere(nsc, oracle_mod
     for pattern in ("gradient", "noise"):
         frames = (syn.gradient_stream_torch if pattern == "gradient" else syn.noise_stream_torch)(n + 1, w, h, dev)
         pipe = nsc.FramePipeline(w, h, 2, "lanczos3", 0.5)
-        want = pipe.alloc(n, dev)
+        want = guarded.like(pipe.alloc(n, dev))
         pipe.step(frames, *want, s)
         torch.cuda.synchronize()
-        got = pipe.alloc(n, dev)
+        got = guarded.like(pipe.alloc(n, dev))
         for order in (1, 0, 1):
             pipe.upscaler.set_option("unit_order", order)
             for t_ in got:

@@ -9,9 +9,13 @@ out=gpurun_out/probe_pageable_d2h.txt
 {
   echo "== timings (33 177 600 B)"; ./tools/probe_pageable_d2h 33177600 24
   echo "== timings (4 MiB)"; ./tools/probe_pageable_d2h 4194304 24
-  echo "== AMD_LOG_LEVEL=4, one 4K frame: lines that name the copy's road"
-  AMD_LOG_LEVEL=4 ./tools/probe_pageable_d2h 33177600 3 2>&1 | grep -i "pinned resource\|staging resource\|Unpinned\|staging D2H\|pin" | sort | uniq -c | sort -rn | head -12 || true
-  echo "== AMD_LOG_LEVEL=4, 512 KiB"
-  AMD_LOG_LEVEL=4 ./tools/probe_pageable_d2h 524288 3 2>&1 | grep -i "pinned resource\|staging resource\|Unpinned\|staging D2H\|pin" | sort | uniq -c | sort -rn | head -12 || true
+  echo "== AMD_LOG_LEVEL=4, one 4K frame into pageable memory: what the runtime logs between the call and its return (2nd copy of the pageable case)"
+  AMD_LOG_LEVEL=4 ./tools/probe_pageable_d2h 33177600 2 > /dev/null 2> gpurun_out/probe_amdlog.txt || true
+  grep -n "hipMemcpy" gpurun_out/probe_amdlog.txt | head -20
+  # the 4th hipMemcpy of the run is the second copy into the same pageable block (after two into the pinned block and one into this one)
+  awk '/hipMemcpy \(/{n++} n==4' gpurun_out/probe_amdlog.txt | cut -c1-230 | head -60
+  echo "== the same for the 3rd hipMemcpy (first copy into that pageable block)"
+  awk '/hipMemcpy \(/{n++} n==3' gpurun_out/probe_amdlog.txt | cut -c1-230 | head -60
+  rm -f gpurun_out/probe_amdlog.txt
 } > $out 2>&1
 cat $out
