@@ -14,12 +14,18 @@ CHUNK = 8 << 20  # nus_transfer.hpp: kTransferChunkBytes; the ring holds 4
 
 
 def _heap_range():
+    """[start of the brk heap, the program break): the heap may be several VMAs in /proc/self/maps (every one labelled [heap])."""
+    lo = hi = 0
     with open("/proc/self/maps") as f:
         for ln in f:
             if ln.rstrip().endswith("[heap]"):
-                lo, hi = ln.split()[0].split("-")
-                return int(lo, 16), int(hi, 16)
-    return 0, 0
+                a, b = (int(x, 16) for x in ln.split()[0].split("-"))
+                lo = a if lo == 0 else min(lo, a)
+                hi = max(hi, b)
+    libc = ctypes.CDLL(None)
+    libc.sbrk.restype = ctypes.c_void_p
+    libc.sbrk.argtypes = [ctypes.c_ssize_t]
+    return lo, max(hi, libc.sbrk(0) or 0)
 
 
 class _Malloc:
