@@ -931,10 +931,12 @@ def worker(args):
         motion = {}
         # the flow front end in its product mode (flow within 1e-3 px), stage after stage and as a two-stream pipeline over chunks
         # of 100 units (the estimator of chunk i+1 beside warp + upscales of chunk i), and in its verification mode
-        for fmode, piped in (("fast", True), ("fast", False), ("exact", False)):
+        for name, fmode, piped, fmt in (("fast_pipelined", "fast", True, None), ("fast_pipelined_f32_handoff", "fast", True, "f32"),
+                                         ("fast", "fast", False, None), ("exact", "exact", False, None)):
             # the pipeline through ONE entry point (nus_flow_interpolate_device_stream: frames in, in-between frames out; the flows stay
-            # in the estimator's workspace); the stage-after-stage legs store the flows as rounds 2-4 did
-            kw = dict(flow_mode=fmode, pipelined=piped, fused_warp=piped)
+            # in the estimator's workspace, as Rg16Float unless "f32" is asked for); the stage-after-stage legs store f32 flows as
+            # rounds 2-4 did
+            kw = dict(flow_mode=fmode, pipelined=piped, fused_warp=piped, flow_format=fmt)
             fl = None if piped else flows
             pipe.step_motion(frames, fl, mid, up_real, up_mid, stream, **kw)
             torch.cuda.synchronize()
@@ -942,8 +944,8 @@ def worker(args):
             for _ in range(2):
                 pipe.step_motion(frames, fl, mid, up_real, up_mid, stream, **kw)
             torch.cuda.synchronize()
-            motion[fmode + ("_pipelined" if piped else "")] = (time.perf_counter() - tm) / 2 * 1e3
-        motion_ms = min(motion["fast_pipelined"], motion["fast"])
+            motion[name] = (time.perf_counter() - tm) / 2 * 1e3
+        motion_ms = motion["fast_pipelined"]  # ONE named configuration: the product's default; the others are listed beside it
         pipe.interp.set_mode("exact")
         del flows
 
@@ -1156,12 +1158,15 @@ def worker(args):
                 "motion_variant": None if motion_ms is None else {
                     "what": "three-stage step with a dense flow per pair (3-level pyramid, 50 + 10 + 10 Horn-Schunck steps, FAST "
                             "arithmetic: flow within 1e-3 px of the exact one) feeding the warp (FMA mode) instead of zero flow; "
-                            "ms_per_step: the better of the two-stream pipeline over 100-unit chunks (estimator + warp through one entry "
-                            "point, the real frames' upscale first on the second stream) and stage after stage; "
-                            "informational, this rank only; exact_flow_ms_per_step: the same with the bit-exact front end",
+                            "ms_per_step is ONE configuration, FramePipeline.step_motion's default: the two-stream pipeline over "
+                            "100-unit chunks, estimator + warp through one entry point with the flow handed over as Rg16Float, the "
+                            "real frames' upscale first on the second stream; beside it the same with an f32 hand-off, stage after "
+                            "stage (f32 flows stored), and stage after stage with the bit-exact front end; informational, this rank only",
+                    "configuration": "fast flow, pipelined, fused entry point, Rg16Float hand-off",
                     "ms_per_step": round(motion_ms, 3),
                     "units_per_s_per_gpu": round(n_units / motion_ms * 1e3, 1),
                     "pipelined_ms_per_step": round(motion["fast_pipelined"], 3),
+                    "pipelined_f32_handoff_ms_per_step": round(motion["fast_pipelined_f32_handoff"], 3),
                     "stage_by_stage_ms_per_step": round(motion["fast"], 3),
                     "exact_flow_ms_per_step": round(motion["exact"], 3)},
                 "host_path": host_path,

@@ -196,10 +196,15 @@ int nus_upscaler_set_lanczos_mode(nus_upscaler *h, int mode);
  * "force_rows" (0/1, before initialize: resize without the register-window variant of it),
  * "rows_per_wave" (fixed-factor resize kernels: input rows per wave, 0 = auto), "unit_order" (below),
  * "down_seg_width" (0..64, before initialize: output columns per wave of the down-scaling kernel, 0 = auto),
+ * "pq_narrow" (1 default / 0: see nus_upscaler_get_option),
  * host path: "single_bands" (1 = nus_upscaler_upscale sends one frame through the pipeline in row bands where the
  * kernel allows it, default; 0 = whole), "single_out_plan" (0..3) / "batch_out_chunks" (1..8): how a pageable
  * output frame is cut into device-to-host pieces when it is alone in the pipeline / has others behind it. */
 int nus_upscaler_set_option(nus_upscaler *h, const char *key, int64_t value);
+/* What the library decided (diagnostics; not in the reference): "pq_p" / "pq_q" (the factor P / Q of the small-rational-factor
+ * resize kernel, 0 when another kernel runs), "pq_narrow_active" (1: that kernel sums the 4 non-zero taps of a support-2 filter,
+ * option "pq_narrow" 0 turns it off: same bytes either way), "rows_per_wave".  Unknown key: NUS_ERR_INVALID_ARGUMENT. */
+int nus_upscaler_get_option(nus_upscaler *h, const char *key, int64_t *value);
 /* Channel order of the input frames.  Captured frames arrive as BGRA and the reference swizzles them
  * on the CPU before upscaling (nu_scaler_core/src/lib.rs:251-270); with NUS_FORMAT_BGRA8 the kernels
  * do it inside their loads (one v_perm_b32 per loaded pixel, no extra pass).  Output is always RGBA8.

@@ -52,6 +52,7 @@ SIGNATURES = [
     ("nus_upscaler_set_bilinear_variant", _i, [_vp, _i]),
     ("nus_upscaler_set_lanczos_mode", _i, [_vp, _i]),
     ("nus_upscaler_set_option", _i, [_vp, _cp, _i64]),
+    ("nus_upscaler_get_option", _i, [_vp, _cp, ctypes.POINTER(_i64)]),
     ("nus_upscaler_set_input_format", _i, [_vp, _i]),
     ("nus_upscaler_set_sharpness", _i, [_vp, _f, _f]),
     ("nus_upscaler_get_sharpness", _i, [_vp, ctypes.POINTER(_f), ctypes.POINTER(_f)]),

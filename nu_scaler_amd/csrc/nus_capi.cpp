@@ -225,6 +225,10 @@ int nus_upscaler_set_option(nus_upscaler *h, const char *key, int64_t value)
 {
     return guarded<int>("nus_upscaler_set_option", [&]() -> int { return h ? h->impl.set_option(key, value) : null_handle(); });
 }
+int nus_upscaler_get_option(nus_upscaler *h, const char *key, int64_t *value)
+{
+    return guarded<int>("nus_upscaler_get_option", [&]() -> int { return h ? h->impl.get_option(key, value) : null_handle(); });
+}
 int nus_upscaler_set_input_format(nus_upscaler *h, int format)
 {
     return guarded<int>("nus_upscaler_set_input_format", [&]() -> int { return h ? h->impl.set_input_format(format) : null_handle(); });

@@ -168,12 +168,34 @@ int HipUpscaler::set_option(const char *key, int64_t value)
         fsr_fast_ = value != 0;
         return kOk;
     }
+    if (!strcmp(key, "pq_narrow")) { // 1 (default): the x P/Q kernel runs a support-2 filter's sums over its 4 non-zero taps; 0: all 6 slots
+        if (value != 0 && value != 1) return fail(kInvalidArgument, "pq_narrow must be 0 or 1");
+        pq_narrow_allowed_ = value != 0;
+        return kOk;
+    }
     if (!strcmp(key, "inject_retire_error")) { // TEST HOOK: the value-th frame retired from now on (1 = the next) reports a HIP error
+        // refused unless the PROCESS asked for test hooks (environment NUS_TEST_HOOKS=1, read per call): not something a caller of
+        // the production library can switch on by accident; release() clears it
+        const char *hooks = getenv("NUS_TEST_HOOKS");
+        if (!hooks || strcmp(hooks, "1") != 0) return fail(kInvalidArgument, "unknown option 'inject_retire_error'");
         if (value < 0 || value > 1000000) return fail(kInvalidArgument, "inject_retire_error out of range");
         inject_retire_.store((int)value);
         return kOk;
     }
     return fail(kInvalidArgument, fmt("unknown option '%s'", key));
+}
+
+int HipUpscaler::get_option(const char *key, int64_t *value)
+{
+    std::lock_guard<std::mutex> lk(mu_);
+    if (!key || !value) return fail(kInvalidArgument, "null option key or result pointer");
+    const bool pq = initialized_ && variant_ == Variant::LanczosPqRegWin;
+    if (!strcmp(key, "pq_p")) *value = pq ? pq_p_ : 0;
+    else if (!strcmp(key, "pq_q")) *value = pq ? pq_q_ : 0;
+    else if (!strcmp(key, "pq_narrow_active")) *value = pq && pq_narrow_ && pq_narrow_allowed_ ? 1 : 0;
+    else if (!strcmp(key, "rows_per_wave")) *value = rows_per_wave_;
+    else return fail(kInvalidArgument, fmt("unknown option '%s'", key));
+    return kOk;
 }
 
 int HipUpscaler::set_input_format(int format)
@@ -231,6 +253,7 @@ void HipUpscaler::release()
         if (ring_.thread.joinable()) ring_.thread.join();
         ring_.open = false;
     }
+    inject_retire_.store(0); // (the test hook does not outlive an initialize())
     if (device_count() > 0) (void)hipSetDevice(device_);
     for (void *p : table_allocs_) (void)hipFree(p);
     table_allocs_.clear();
@@ -339,6 +362,7 @@ void HipUpscaler::choose_resize_variant(bool x2)
     // x5/4, x6/5, x5/3, x5/2: P output rows per group of Q input rows, every output's weights from the tables in frame form
     // (nus_k_lanczos_pq.hip); the ratios are not exact in f32, so nothing about the weights is assumed beyond their frames
     pq_p_ = pq_q_ = 0;
+    pq_narrow_ = false;
     if (!force_general_ && ow_ > iw_ && addressable && iw_ >= 32 && ih_ >= 12) {
         uint64_t a = ow_, b = iw_;
         while (b) {
@@ -349,6 +373,14 @@ void HipUpscaler::choose_resize_variant(bool x2)
         if (lanczos_pq_supported(P, Q) && (uint64_t)oh_ * Q == (uint64_t)ih_ * P && (iw_ % Q) == 0 && (ih_ % Q) == 0 && (ow_ % 4) == 0 &&
             lanczos_pq_phase_frame(tx_, P, Q, wx6_) && lanczos_pq_phase_frame(ty_, P, Q, wy6_)) {
             pq_p_ = P, pq_q_ = Q;
+            // a filter of support 2 or less (Catmull-Rom, Triangle): slots 0 and 5 of every output's frame are zero on both axes, and
+            // the kernel may sum slots 1 .. 4 only (checked on the tables themselves, border outputs included)
+            auto edge_slots_zero = [](const std::vector<float> &w6) {
+                for (size_t o = 0; o + 6 <= w6.size(); o += 6)
+                    if (w6[o] != 0.0f || w6[o + 5] != 0.0f) return false;
+                return true;
+            };
+            pq_narrow_ = edge_slots_zero(wx6_) && edge_slots_zero(wy6_);
         }
     }
     if (pq_p_) {
@@ -773,7 +805,7 @@ int HipUpscaler::enqueue(const uint8_t *d_in, uint8_t *d_out, uint32_t n_frames,
         if (lanczos_exact_ && pq_exact_fallback_) // (see choose_resize_variant)
             e = launch_resize_win(L, dt_, true, resize_ncols_max_, resize_union_taps_, win_outputs_per_lane_);
         else
-            e = launch_lanczos_pq(L, dt_, lanczos_exact_, pq_p_, pq_q_, th);
+            e = launch_lanczos_pq(L, dt_, lanczos_exact_, pq_p_, pq_q_, th, pq_narrow_ && pq_narrow_allowed_);
         break;
     }
     case Variant::LanczosR32RegWin: {

@@ -100,6 +100,7 @@ public:
     int set_bilinear_variant(int variant);
     int set_lanczos_mode(int mode);
     int set_option(const char *key, int64_t value);
+    int get_option(const char *key, int64_t *value);
     // nus_pixel_format: 0 RGBA8 (default), 1 BGRA8, 2 RGBX8, 3 BGRX8 -- swizzled / made opaque inside the kernels' loads
     // (the reference's CPU loop: nu_scaler_core/src/lib.rs:251-270).  Output is always RGBA8.
     int set_input_format(int format);
@@ -256,6 +257,8 @@ private:
     std::vector<float> wy6_, wx6_;
     uint32_t pq_p_ = 0, pq_q_ = 0; // Variant::LanczosPqRegWin: the factor P / Q
     bool pq_exact_fallback_ = false; // ... and whether its EXACT mode runs on the any-scale kernel instead (Q = 5)
+    bool pq_narrow_ = false;         // ... and whether every output's frame slots 0 and 5 are zero (a support-2 filter: 4-tap sums)
+    bool pq_narrow_allowed_ = true;  // option "pq_narrow"
     std::vector<uint32_t> xs_cls_x_, xs_cls_y_; // x3: weight class per input index, and the classes' weights
     std::vector<float> xs_wcls_x_, xs_wcls_y_;
     DeviceTables dt_;

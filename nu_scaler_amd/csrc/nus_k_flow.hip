@@ -380,7 +380,12 @@ __global__ __launch_bounds__(256) void k_pyramid_fast(const void *__restrict__ i
 #pragma unroll
         for (int i = 0; i < 4; ++i)
             v[i] = blur5_fast(hb[(P + 1) % 5][i], hb[(P + 2) % 5][i], hb[(P + 3) % 5][i], hb[(P + 4) % 5][i], hb[P][i]);
+#if defined(NUS_ABLATE_PYR_NO_LUM0_STORE) // timing-only dev build (profiles/r06_flow_level0_luminance_in_jacobi_ablation.txt): the level-0
+        // pass without its luminance-plane store -- the most a Jacobi kernel that forms level 0's luminance itself could save here
+        if (writer && !U8IN) {
+#else
         if (writer) {
+#endif
             float *dst = level_lum + (size_t)y * w;
             if (plain) {
                 dst[xa] = v[0], dst[xa + 1] = v[1], dst[xa + 2] = v[2], dst[xa + 3] = v[3]; // (merged into one 16-byte store where aligned)
@@ -828,6 +833,11 @@ __global__ __launch_bounds__(256) void k_hs_stream_fast(const float *__restrict_
     float l1r[RING ? R : 1];                   // RING: frame 1's rows t-1 .. t+3 in slots (row - lo) mod R
     float q2r[3];                              // RING: frame 2's rows t .. t+2
     float2 qfr[3];                             // RING: the input flow's rows t .. t+2 (not UPS)
+#if defined(NUS_ABLATE_HS_LUM0_COST)
+    float abl_ring[2][R];
+#pragma unroll
+    for (int i = 0; i < R; ++i) abl_ring[0][i] = abl_ring[1][i] = 0.0f;
+#endif
 
     // UPS: the level starts from the coarser level's flow, sampled as flow_upsample.wgsl:27-36 samples it (linear, clamp to edge,
     // texel space) while it is loaded.  The column part of the sample position is this lane's for the whole launch (the shader's own
@@ -925,7 +935,28 @@ __global__ __launch_bounds__(256) void k_hs_stream_fast(const float *__restrict_
             nf = qfr[P % 3];
             qfr[(P + 2) % 3] = load_flow(t + 2); // in flight during this pass and the next
         }
+#if defined(NUS_ABLATE_HS_LUM0_COST) // timing-only dev build (same file): per pass and frame, the instructions an in-kernel level-0
+        // luminance costs at least -- RGBA8 -> luminance (3 converts, 2 adds, 1 multiply), the two halo columns per side from the
+        // neighbouring lanes (4 DPP moves), the 5-tap row blur, a ring of blurred rows and the 5-tap column blur -- run on values
+        // that have already arrived and folded into them as + 0 * result (IEEE: not removable; the flows stay the same).  Not
+        // counted: the 4 extra halo lanes per wave such a kernel needs (U = 50 instead of 54 columns at K = 5).
+        float row = l1r[P % R];
+        const float above = l1r[(P + R - 1) % R], n1 = l1r[(P + 1) % R];
+        float n2 = q2r[P % 3];
+        if (w > 1000) { // (wave-uniform: level 0 of a 1080p stream only)
+            auto cost = [&](float v, float (&ring)[R]) {
+                const uint32_t p = __float_as_uint(v);
+                const float l = ((ch_f32(p, 0) + ch_f32(p, 1)) + ch_f32(p, 2)) * (0.33333f / 255.0f);
+                const float m1 = wave_up(l), p1 = wave_down(l), m2 = wave_up(m1), p2 = wave_down(p1);
+                ring[P % R] = blur5_fast(m2, m1, l, p1, p2);
+                return blur5_fast(ring[(P + 1) % R], ring[(P + 2) % R], ring[(P + 3) % R], ring[(P + 4) % R], ring[P % R]);
+            };
+            row = __builtin_fmaf(0.0f, cost(row, abl_ring[0]), row);
+            n2 = __builtin_fmaf(0.0f, cost(n2, abl_ring[1]), n2);
+        }
+#else
         const float row = l1r[P % R], above = l1r[(P + R - 1) % R], n1 = l1r[(P + 1) % R], n2 = q2r[P % 3];
+#endif
         l1r[(P + 3) % R] = lum1[(size_t)clampi(t + 3, 0, h - 1) * w + xc];
         q2r[(P + 2) % 3] = lum1[lum_stride + (size_t)clampi(t + 2, 0, h - 1) * w + xc];
         {

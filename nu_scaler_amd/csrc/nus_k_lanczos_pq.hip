@@ -22,19 +22,20 @@ uint32_t lanczos_pq_strip_cols(uint32_t P, uint32_t Q)
     return 0;
 }
 
-hipError_t launch_lanczos_pq(const UpscaleLaunch &L, const DeviceTables &T, bool exact, uint32_t P, uint32_t Q, uint32_t rows_per_wave)
+hipError_t launch_lanczos_pq(const UpscaleLaunch &L, const DeviceTables &T, bool exact, uint32_t P, uint32_t Q, uint32_t rows_per_wave,
+                             bool narrow)
 {
     if (!lanczos_pq_supported(P, Q) || (uint64_t)L.ow * Q != (uint64_t)L.iw * P || (uint64_t)L.oh * Q != (uint64_t)L.ih * P ||
         (L.iw % Q) != 0 || (L.ih % Q) != 0 || (L.ow % 4) != 0 || !T.lz_wx6 || !T.lz_wy6)
         return hipErrorInvalidValue;
-    if (P == 5 && Q == 4) return launch_pq<5, 4>(L, T, exact, rows_per_wave);
-    if (P == 6 && Q == 5) return launch_lanczos_pq_65(L, T, exact, rows_per_wave);
-    if (P == 5 && Q == 3) return launch_pq<5, 3>(L, T, exact, rows_per_wave);
-    if (P == 7 && Q == 2) return launch_pq<7, 2>(L, T, exact, rows_per_wave);
-    if (P == 7 && Q == 5) return launch_lanczos_pq_75(L, T, exact, rows_per_wave);
-    if (P == 8 && Q == 5) return launch_lanczos_pq_85(L, T, exact, rows_per_wave);
-    if (P == 9 && Q == 5) return launch_lanczos_pq_95(L, T, exact, rows_per_wave);
-    return launch_pq<5, 2>(L, T, exact, rows_per_wave);
+    if (P == 5 && Q == 4) return launch_pq<5, 4>(L, T, exact, rows_per_wave, narrow);
+    if (P == 6 && Q == 5) return launch_lanczos_pq_65(L, T, exact, rows_per_wave, narrow);
+    if (P == 5 && Q == 3) return launch_pq<5, 3>(L, T, exact, rows_per_wave, narrow);
+    if (P == 7 && Q == 2) return launch_pq<7, 2>(L, T, exact, rows_per_wave, narrow);
+    if (P == 7 && Q == 5) return launch_lanczos_pq_75(L, T, exact, rows_per_wave, narrow);
+    if (P == 8 && Q == 5) return launch_lanczos_pq_85(L, T, exact, rows_per_wave, narrow);
+    if (P == 9 && Q == 5) return launch_lanczos_pq_95(L, T, exact, rows_per_wave, narrow);
+    return launch_pq<5, 2>(L, T, exact, rows_per_wave, narrow);
 }
 
 } // namespace nus

@@ -219,11 +219,18 @@ struct PqStore {
     int lane;
 };
 
-template <bool EXACT, int P, int Q, int B>
+// NARROW (round 6): a filter of support 2 -- Catmull-Rom, the reference's Bicubic (Nu_scale/src/upscale/common.rs:233-241) -- has its
+// non-zero taps in slots 1 .. 4 of the 6-slot frame (the frame starts at the first input index inside (c - 3, c + 3), the filter's
+// taps lie inside (c - 2, c + 2)): slots 0 and 5 carry weight 0 for every output, which the host checks on the tables of both axes
+// before it asks for this form.  Both passes then run 4 multiply-adds per sum instead of 6.  v * 0 changes no sum (at most the sign
+// of a zero, which no later operation sees), so the outputs are those of the 6-tap form bit for bit, in both modes
+// (tests/test_gpu_parity.py::test_pq_narrow_taps_are_the_six_tap_kernel_bit_for_bit).
+template <bool EXACT, int P, int Q, int B, bool NARROW>
 __device__ __forceinline__ void pq_row(const float (&win)[6][4 * Q], const float (&wv)[6], const float (&W)[P][6],
                                        __amdgpu_buffer_rsrc_t rs, const PqStore &st, uint32_t row_off, bool skip_alpha)
 {
     using G = PqGeom<P, Q>;
+    constexpr int J0 = NARROW ? 1 : 0, J1 = NARROW ? 5 : 6; // taps J0 .. J1 - 1 of the frame
     uint32_t o[P];
 #pragma unroll
     for (int i = 0; i < P; ++i) o[i] = skip_alpha ? 0xFF000000u : 0u;
@@ -233,18 +240,18 @@ __device__ __forceinline__ void pq_row(const float (&win)[6][4 * Q], const float
         float v[Q];
 #pragma unroll
         for (int m = 0; m < Q; ++m) {
-            float acc = win[B % 6][m * 4 + c] * wv[0]; // == fma(.., 0) and a VOP2 instruction
+            float acc = win[(B + J0) % 6][m * 4 + c] * wv[J0]; // == fma(.., 0) and a VOP2 instruction
 #pragma unroll
-            for (int j = 1; j < 6; ++j) acc = pq_mac<EXACT>(acc, win[(B + j) % 6][m * 4 + c], wv[j]);
+            for (int j = J0 + 1; j < J1; ++j) acc = pq_mac<EXACT>(acc, win[(B + j) % 6][m * 4 + c], wv[j]);
             v[m] = acc;
         }
         float e[G::NE];
         pq_gather<P, Q, 0>(v, e);
 #pragma unroll
         for (int p = 0; p < P; ++p) {
-            float a = e[G::s(p) + 3] * W[p][0];
+            float a = e[G::s(p) + 3 + J0] * W[p][J0];
 #pragma unroll
-            for (int j = 1; j < 6; ++j) a = pq_mac<EXACT>(a, e[G::s(p) + 3 + j], W[p][j]);
+            for (int j = J0 + 1; j < J1; ++j) a = pq_mac<EXACT>(a, e[G::s(p) + 3 + j], W[p][j]);
             o[p] = pack_u8<EXACT>(a, c, o[p]);
         }
     }
@@ -279,7 +286,7 @@ struct PqStepCtx {
 // Phase PH of a step (see pq_step): output row P r / Q + PH from the window slots S + adv(PH) .. + 5, then -- where the window
 // moves after this phase -- row r + 3 + adv(PH) in.  wnext: the NEXT output row's vertical weights (scalar registers), loaded
 // during this phase.
-template <bool EXACT, int P, int Q, int S, int PH>
+template <bool EXACT, int P, int Q, int S, int PH, bool NARROW>
 __device__ __forceinline__ void pq_phase(float (&win)[6][4 * Q], const PqStepCtx &C, uint32_t pos, int r, const float (&W)[P][6],
                                          float (&wnext)[6], uint32_t &opaque)
 {
@@ -313,7 +320,7 @@ __device__ __forceinline__ void pq_phase(float (&win)[6][4 * Q], const PqStepCtx
 #pragma unroll
         for (int j = 0; j < 6; ++j) wnext[j] = wt[j];
     }
-    pq_row<EXACT, P, Q, S + ADV>(win, wv, W, C.rs, C.st, oy * row_bytes, skip_alpha);
+    pq_row<EXACT, P, Q, S + ADV, NARROW>(win, wv, W, C.rs, C.st, oy * row_bytes, skip_alpha);
     if constexpr (MOVES) {
         // the oldest row out, row r + 3 + ADV in; then request row r + 3 + ADV + Q D into the same ring slot
         const PxQ<Q> px = pq_swz<Q>(next, A.sel);
@@ -328,13 +335,13 @@ __device__ __forceinline__ void pq_phase(float (&win)[6][4 * Q], const PqStepCtx
     }
 }
 
-template <bool EXACT, int P, int Q, int S, int PH>
+template <bool EXACT, int P, int Q, int S, int PH, bool NARROW>
 __device__ __forceinline__ void pq_phases(float (&win)[6][4 * Q], const PqStepCtx &C, uint32_t pos, int r, const float (&W)[P][6],
                                           float (&wnext)[6], uint32_t &opaque)
 {
     if constexpr (PH < P) {
-        pq_phase<EXACT, P, Q, S, PH>(win, C, pos, r, W, wnext, opaque);
-        pq_phases<EXACT, P, Q, S, PH + 1>(win, C, pos, r, W, wnext, opaque);
+        pq_phase<EXACT, P, Q, S, PH, NARROW>(win, C, pos, r, W, wnext, opaque);
+        pq_phases<EXACT, P, Q, S, PH + 1, NARROW>(win, C, pos, r, W, wnext, opaque);
     }
 }
 
@@ -342,32 +349,32 @@ __device__ __forceinline__ void pq_phases(float (&win)[6][4 * Q], const PqStepCt
 // holds input row r - 3 + j and the ring's Q slots at `pos` hold rows r + 3 .. r + 2 + Q (requested kPqDepth steps ago).
 // Vector memory instructions of a step, in issue order and on every path: per phase its SP stores, then -- where the window moves
 // -- the REQ pieces of a row request.
-template <bool EXACT, int P, int Q, int S>
+template <bool EXACT, int P, int Q, int S, bool NARROW>
 __device__ __forceinline__ void pq_step(float (&win)[6][4 * Q], const PqStepCtx &C, uint32_t &pos, int r, const float (&W)[P][6],
                                         float (&wnext)[6], uint32_t &opaque)
 {
     using G = PqGeom<P, Q>;
-    pq_phases<EXACT, P, Q, S, 0>(win, C, pos, r, W, wnext, opaque);
+    pq_phases<EXACT, P, Q, S, 0, NARROW>(win, C, pos, r, W, wnext, opaque);
     pos = pos + Q * G::kSlotBytes == (uint32_t)(Q * kPqDepth) * G::kSlotBytes ? 0u : pos + Q * G::kSlotBytes;
 }
 
-template <bool EXACT, int P, int Q, int U>
+template <bool EXACT, int P, int Q, int U, bool NARROW>
 __device__ __forceinline__ bool pq_steps(float (&win)[6][4 * Q], const PqStepCtx &C, uint32_t &pos, int rbase, int r_end,
                                          const float (&W)[P][6], float (&wnext)[6], uint32_t &opaque)
 {
     // UNROLL steps so the rotating window indices are compile-time constants; the block leaves the loop after its last row group,
     // so every path through the loop carries the vector memory instructions the hand-counted waits assume
     if constexpr (U < PqGeom<P, Q>::UNROLL) {
-        pq_step<EXACT, P, Q, (U * Q) % 6>(win, C, pos, rbase + U * Q, W, wnext, opaque);
+        pq_step<EXACT, P, Q, (U * Q) % 6, NARROW>(win, C, pos, rbase + U * Q, W, wnext, opaque);
         if (rbase + (U + 1) * Q >= r_end) return true;
-        return pq_steps<EXACT, P, Q, U + 1>(win, C, pos, rbase, r_end, W, wnext, opaque);
+        return pq_steps<EXACT, P, Q, U + 1, NARROW>(win, C, pos, rbase, r_end, W, wnext, opaque);
     }
     return false;
 }
 
 // One wave loads a strip of 64 Q input columns (Q per lane; the HL first and last lanes are the halo of the others) and walks `th`
 // input rows with a 6-row f32 window.
-template <bool EXACT, int P, int Q>
+template <bool EXACT, int P, int Q, bool NARROW = false>
 __global__ __launch_bounds__(256) void k_lanczos3_pq(const LanczosPqArgs A)
 {
     using G = PqGeom<P, Q>;
@@ -453,11 +460,11 @@ __global__ __launch_bounds__(256) void k_lanczos3_pq(const LanczosPqArgs A)
     }
     const PqStepCtx C = {A, &lds_rows[w][0], ring_lds, lane, src, rs, in_off, st};
     for (int rbase = r0; rbase < r_end; rbase += Q * G::UNROLL)
-        if (pq_steps<EXACT, P, Q, 0>(win, C, pos, rbase, r_end, W, wnext, opaque)) break;
+        if (pq_steps<EXACT, P, Q, 0, NARROW>(win, C, pos, rbase, r_end, W, wnext, opaque)) break;
 }
 
 template <int P, int Q>
-hipError_t launch_pq(const UpscaleLaunch &L, const DeviceTables &T, bool exact, uint32_t rows_per_wave)
+hipError_t launch_pq(const UpscaleLaunch &L, const DeviceTables &T, bool exact, uint32_t rows_per_wave, bool narrow)
 {
     using G = PqGeom<P, Q>;
     LanczosPqArgs A;
@@ -477,10 +484,14 @@ hipError_t launch_pq(const UpscaleLaunch &L, const DeviceTables &T, bool exact, 
         A.in = in;
         A.out = out;
         const dim3 block(256), grid(cdiv(nwaves, 4), n);
-        if (exact)
-            hipLaunchKernelGGL((k_lanczos3_pq<true, P, Q>), grid, block, 0, L.stream, A);
+        if (exact && narrow)
+            hipLaunchKernelGGL((k_lanczos3_pq<true, P, Q, true>), grid, block, 0, L.stream, A);
+        else if (exact)
+            hipLaunchKernelGGL((k_lanczos3_pq<true, P, Q, false>), grid, block, 0, L.stream, A);
+        else if (narrow)
+            hipLaunchKernelGGL((k_lanczos3_pq<false, P, Q, true>), grid, block, 0, L.stream, A);
         else
-            hipLaunchKernelGGL((k_lanczos3_pq<false, P, Q>), grid, block, 0, L.stream, A);
+            hipLaunchKernelGGL((k_lanczos3_pq<false, P, Q, false>), grid, block, 0, L.stream, A);
     });
 }
 
@@ -488,9 +499,9 @@ hipError_t launch_pq(const UpscaleLaunch &L, const DeviceTables &T, bool exact, 
 
 // The Q = 5 factors are one translation unit each (nus_k_lanczos_pq_65.hip, _75, _85, _95: their six unrolled row groups are 80 - 230 KB of
 // code per instantiation and a minute of compile time); nus_k_lanczos_pq.hip holds the others and the dispatch.
-hipError_t launch_lanczos_pq_65(const UpscaleLaunch &L, const DeviceTables &T, bool exact, uint32_t rows_per_wave);
-hipError_t launch_lanczos_pq_75(const UpscaleLaunch &L, const DeviceTables &T, bool exact, uint32_t rows_per_wave);
-hipError_t launch_lanczos_pq_85(const UpscaleLaunch &L, const DeviceTables &T, bool exact, uint32_t rows_per_wave);
-hipError_t launch_lanczos_pq_95(const UpscaleLaunch &L, const DeviceTables &T, bool exact, uint32_t rows_per_wave);
+hipError_t launch_lanczos_pq_65(const UpscaleLaunch &L, const DeviceTables &T, bool exact, uint32_t rows_per_wave, bool narrow);
+hipError_t launch_lanczos_pq_75(const UpscaleLaunch &L, const DeviceTables &T, bool exact, uint32_t rows_per_wave, bool narrow);
+hipError_t launch_lanczos_pq_85(const UpscaleLaunch &L, const DeviceTables &T, bool exact, uint32_t rows_per_wave, bool narrow);
+hipError_t launch_lanczos_pq_95(const UpscaleLaunch &L, const DeviceTables &T, bool exact, uint32_t rows_per_wave, bool narrow);
 
 } // namespace nus

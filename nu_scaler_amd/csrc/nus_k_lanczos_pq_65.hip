@@ -3,9 +3,9 @@
 
 namespace nus {
 
-hipError_t launch_lanczos_pq_65(const UpscaleLaunch &L, const DeviceTables &T, bool exact, uint32_t rows_per_wave)
+hipError_t launch_lanczos_pq_65(const UpscaleLaunch &L, const DeviceTables &T, bool exact, uint32_t rows_per_wave, bool narrow)
 {
-    return launch_pq<6, 5>(L, T, exact, rows_per_wave);
+    return launch_pq<6, 5>(L, T, exact, rows_per_wave, narrow);
 }
 
 } // namespace nus

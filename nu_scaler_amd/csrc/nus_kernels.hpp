@@ -156,7 +156,8 @@ hipError_t launch_lanczos_r43_edges(const UpscaleLaunch &L, const DeviceTables &
 // nus_tables.hpp: lanczos_pq_phase_frame).  Writes every output column: no edge pass.
 bool lanczos_pq_supported(uint32_t P, uint32_t Q);
 uint32_t lanczos_pq_strip_cols(uint32_t P, uint32_t Q); // input columns per wave
-hipError_t launch_lanczos_pq(const UpscaleLaunch &L, const DeviceTables &T, bool exact, uint32_t P, uint32_t Q, uint32_t rows_per_wave);
+hipError_t launch_lanczos_pq(const UpscaleLaunch &L, const DeviceTables &T, bool exact, uint32_t P, uint32_t Q, uint32_t rows_per_wave,
+                             bool narrow);
 // FSR1-style passes (fsr.rs:24-260).  mode 0: EASU, 1: RCAS (iw == ow, ih == oh), 2: EASU then RCAS fused.
 // fast: EASU in FAST arithmetic where the LDS source tile applies (nus_k_fsr.hip; option "fsr_fast")
 hipError_t launch_fsr1(const UpscaleLaunch &L, int mode, float easu_sharpness, float rcas_sharpness, bool fast = false);

@@ -12,7 +12,7 @@ the filter tables (RCCL over xGMI when the backend is nccl).
 """
 from __future__ import annotations
 
-from typing import Tuple
+from typing import Optional, Tuple
 
 from . import transfer
 from .interpolator import WgpuFrameInterpolator
@@ -170,7 +170,7 @@ class FramePipeline:
 
     def step_motion(self, frames, flows, mid, up_real, up_mid, stream: int = 0, levels: int = 3,
                     coarse_iterations: int = 50, refine_iterations: int = 10, flow_mode: str = "exact", pipelined: bool = False,
-                    chunk: int = 100, fused_warp: bool = False, flow_format: str = "f32") -> None:
+                    chunk: int = 100, fused_warp: bool = False, flow_format: Optional[str] = None) -> None:
         """Motion-compensated variant of `step`: a dense flow per pair from the
         pyramid + Horn-Schunck front end into `flows` ((n_units, h, w, 2) float32), then warp + blend with it
         instead of the reference's zero flow.  The flows are estimated pair by pair (several launches per pair,
@@ -198,6 +198,11 @@ class FramePipeline:
         fb = self.frame_bytes
         if flows is None and not fused_warp:
             raise ValueError("step_motion: flows=None needs fused_warp=True")
+        # Between estimator and warp the flow travels as Rg16Float by default in FAST mode -- the layout the reference's live path
+        # binds (wgpu_interpolator.rs:275-276), half the hand-off's bytes, 5e-4 px of rounding on a 1-2 px flow inside FAST's own
+        # 1e-3 px contract; "f32" stays selectable, and is what the exact mode and a caller who wants the flows stored get.
+        if flow_format is None:
+            flow_format = "f16" if (fused_warp and flow_mode == "fast" and flows is None) else "f32"
         if flow_format != "f32" and not fused_warp:
             raise ValueError("step_motion: flow_format 'f16' (the Rg16Float hand-off) needs fused_warp=True")
         fl0 = 0 if flows is None else flows.data_ptr()

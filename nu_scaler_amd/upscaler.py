@@ -245,6 +245,14 @@ class PyWgpuUpscaler:
     def set_option(self, key: str, value: int) -> None:
         self._check(self._lib.nus_upscaler_set_option(self._h, key.encode(), int(value)))
 
+    def get_option(self, key: str) -> int:
+        """What the library decided ("pq_p", "pq_q", "pq_narrow_active", "rows_per_wave": nus_upscaler_get_option)."""
+        import ctypes
+
+        v = ctypes.c_int64(0)
+        self._check(self._lib.nus_upscaler_get_option(self._h, key.encode(), ctypes.byref(v)))
+        return int(v.value)
+
     def set_input_format(self, fmt: str) -> None:
         """"rgba" (default) or "bgra": captured frames are swizzled inside the kernels' loads
         (the reference's CPU loop, lib.rs:251-270).  The output is always RGBA."""

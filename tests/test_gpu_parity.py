@@ -474,7 +474,7 @@ def test_upscale_batch_pipeline_many_frames_every_buffer_kind(nsc, oracle_mod):
     assert np.array_equal(np.frombuffer(u.upscale(ins[2]), np.uint8).reshape(2 * h, 2 * w, 4), want[2])
 
 
-def test_failed_retire_mid_batch_leaves_nothing_queued(nsc, oracle_mod):
+def test_failed_retire_mid_batch_leaves_nothing_queued(nsc, oracle_mod, monkeypatch):
     """A frame whose wait fails in the middle of a batch (test hook "inject_retire_error": what a lost device looks like) fails the
     call -- and every frame that had been SUBMITTED is still retired: before round 5 the retiring thread left at the first failure,
     the populate requests of the frames in the other slots stayed queued in the process-wide pool with pointers into the result
@@ -483,6 +483,11 @@ def test_failed_retire_mid_batch_leaves_nothing_queued(nsc, oracle_mod):
     is pending when the failing call returns, the handle can be destroyed at once, and a new one computes correct frames."""
     import gc
 
+    u = nsc.PyWgpuUpscaler("quality", "bilinear")
+    monkeypatch.delenv("NUS_TEST_HOOKS", raising=False)
+    with pytest.raises(RuntimeError, match="unknown option 'inject_retire_error'"):
+        u.set_option("inject_retire_error", 1)  # the production library does not know the hook unless the process asks for hooks
+    monkeypatch.setenv("NUS_TEST_HOOKS", "1")
     w, h, n = 1920, 1080, 7
     frames = [oracle_mod.gen_noise(w, h, 900 + i) for i in range(2)]
     want = [oracle_mod.bilinear(f, 2 * w, 2 * h, threads=0) for f in frames]
