@@ -291,6 +291,12 @@ __device__ __forceinline__ float blur5_fast(float m2, float m1, float c0, float 
 #ifndef NUS_PYR_FAST_AHEAD
 #define NUS_PYR_FAST_AHEAD 2
 #endif
+#ifndef NUS_PYR_FAST_NT
+#define NUS_PYR_FAST_NT 0 // 1: the luminance plane leaves with non-temporal stores (measured, round 6: see the comment at the store)
+#endif
+#ifndef NUS_HS_FAST_NT
+#define NUS_HS_FAST_NT 0 // bit 0: the flow a launch writes leaves non-temporal; bit 1: the luminance rows and the input flow come in non-temporal
+#endif
 template <bool U8IN>
 __global__ __launch_bounds__(256) void k_pyramid_fast(const void *__restrict__ in_all, size_t in_stride,
                                                       float *__restrict__ lum_all, size_t lum_stride,
@@ -388,7 +394,14 @@ __global__ __launch_bounds__(256) void k_pyramid_fast(const void *__restrict__ i
 #endif
             float *dst = level_lum + (size_t)y * w;
             if (plain) {
+#if NUS_PYR_FAST_NT // the plane is read again only after the coarser levels have been solved: nothing to keep in the caches
+                typedef float f32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
+                f32x4_a4 q;
+                q.x = v[0], q.y = v[1], q.z = v[2], q.w = v[3];
+                __builtin_nontemporal_store(q, reinterpret_cast<f32x4_a4 *>(dst + xa));
+#else
                 dst[xa] = v[0], dst[xa + 1] = v[1], dst[xa + 2] = v[2], dst[xa + 3] = v[3]; // (merged into one 16-byte store where aligned)
+#endif
             } else {
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
@@ -767,6 +780,18 @@ __global__ __launch_bounds__(256) void k_hs_stream(const float *__restrict__ coe
 #ifndef NUS_HS_FAST_AHEAD
 #define NUS_HS_FAST_AHEAD 2 // passes between a row's request and its use in k_hs_stream_fast
 #endif
+typedef float f32x2_nt __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void nt_store_f2(float2 v, float2 *p)
+{
+    f32x2_nt q;
+    q.x = v.x, q.y = v.y;
+    __builtin_nontemporal_store(q, reinterpret_cast<f32x2_nt *>(p));
+}
+__device__ __forceinline__ float2 nt_load_f2(const float2 *p)
+{
+    const f32x2_nt q = __builtin_nontemporal_load(reinterpret_cast<const f32x2_nt *>(p));
+    return make_float2(q.x, q.y);
+}
 struct HsFastCoef {
     float ix, iy, it, gx, gy;
 };
@@ -899,6 +924,7 @@ __global__ __launch_bounds__(256) void k_hs_stream_fast(const float *__restrict_
             return upsampled_row(r);
 #endif
         } else {
+            if (NUS_HS_FAST_NT & 2) return fin ? nt_load_f2(&fin[(size_t)min(r, hi - 1) * w + xc]) : make_float2(0.0f, 0.0f);
             return fin ? fin[(size_t)min(r, hi - 1) * w + xc] : make_float2(0.0f, 0.0f);
         }
     };
@@ -957,8 +983,13 @@ __global__ __launch_bounds__(256) void k_hs_stream_fast(const float *__restrict_
 #else
         const float row = l1r[P % R], above = l1r[(P + R - 1) % R], n1 = l1r[(P + 1) % R], n2 = q2r[P % 3];
 #endif
-        l1r[(P + 3) % R] = lum1[(size_t)clampi(t + 3, 0, h - 1) * w + xc];
-        q2r[(P + 2) % 3] = lum1[lum_stride + (size_t)clampi(t + 2, 0, h - 1) * w + xc];
+        if (NUS_HS_FAST_NT & 2) {
+            l1r[(P + 3) % R] = __builtin_nontemporal_load(&lum1[(size_t)clampi(t + 3, 0, h - 1) * w + xc]);
+            q2r[(P + 2) % 3] = __builtin_nontemporal_load(&lum1[lum_stride + (size_t)clampi(t + 2, 0, h - 1) * w + xc]);
+        } else {
+            l1r[(P + 3) % R] = lum1[(size_t)clampi(t + 3, 0, h - 1) * w + xc];
+            q2r[(P + 2) % 3] = lum1[lum_stride + (size_t)clampi(t + 2, 0, h - 1) * w + xc];
+        }
         {
             const float left = wave_up(row), right = wave_down(row);
             const float ix = ((sr ? row : right) - (sl ? row : left)) * 0.5f;
@@ -996,6 +1027,8 @@ __global__ __launch_bounds__(256) void k_hs_stream_fast(const float *__restrict_
                     if (!WARP || fout_all != nullptr) {
                         if (warp.out_half) // (wave-uniform) the level's final flow as Rg16Float
                             reinterpret_cast<__half2 *>(fout_all)[blockIdx.y * fout_stride + (size_t)y * w + x] = __floats2half2_rn(arr.x, arr.y);
+                        else if (NUS_HS_FAST_NT & 1)
+                            nt_store_f2(arr, &fout[(size_t)y * w + x]);
                         else
                             fout[(size_t)y * w + x] = arr;
                     }

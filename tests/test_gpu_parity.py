@@ -1191,6 +1191,16 @@ def test_resize_small_rational_factor_register_window(nsc, oracle_mod, alg, filt
     assert _maxdiff(got_f, want) <= 1 and (got_f != want).mean() < (5e-2 if alg == "triangle" else 1e-3)
     ref_f, ug = _up(nsc, alg, img, ow, oh, options={"force_general": 1})
     assert ug.kernel_variant in ("resize_regwin_lds", "resize_rows_lds") and np.array_equal(got_f, ref_f)
+    if kernel == "lanczos3_pq_regwin":
+        # round 6: a support-2 (Catmull-Rom) or support-1 (Triangle) filter leaves slots 0 and 5 of every 6-slot frame zero, and the
+        # kernel then sums 4 taps per pass (NARROW): the very bytes of the 6-tap form, in both modes (v * 0 changes no sum)
+        assert (uf.get_option("pq_p"), uf.get_option("pq_q")) == (P, Q)
+        assert uf.get_option("pq_narrow_active") == (0 if alg == "lanczos3" else 1)
+        if alg != "lanczos3":
+            six_f, u6 = _up(nsc, alg, img, ow, oh, options={"pq_narrow": 0})
+            assert u6.get_option("pq_narrow_active") == 0 and u6.kernel_variant == kernel and np.array_equal(six_f, got_f)
+            six_e, _ = _up(nsc, alg, img, ow, oh, lanczos_mode="exact", options={"pq_narrow": 0})
+            assert np.array_equal(six_e, got_e)
     for th in (Q, 7, 24, 40):
         out_t, _ = _up(nsc, alg, img, ow, oh, lanczos_mode="exact", options={"rows_per_wave": th})
         assert np.array_equal(out_t, want), th
