@@ -664,6 +664,8 @@ class ShardedStream:
         out = []
         weights = {}
         mid, up_real, up_mid = bufs if bufs is not None else (self.mid, self.up_real, self.up_mid)
+        if self.schedule == "fused":
+            mid = None  # the fused schedule never writes the in-between frames (they exist only inside the kernel): nothing to digest
         for k in range(self.count if n is None else n):
             total = 0
             for buf, mult in ((mid, 1), (up_real, 1000003), (up_mid, 998244353)):

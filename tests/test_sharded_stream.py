@@ -182,6 +182,19 @@ def test_sharded_stream_one_rank_against_the_oracle(nsc, oracle_mod):
             t_.zero_()
         s.run(steps=1)
         assert s.unit_digests() == d1  # the one-launch step and the three stages write the same bytes
+        # the fused schedule never writes `mid`: its digest folds the two 4K outputs only -- whatever `mid` holds (it was
+        # digesting uninitialised HBM), and equal to the same fold of the unit schedule's outputs
+        s.schedule = "fused"
+        for t_ in (s.up_real, s.up_mid):
+            t_.zero_()
+        s.mid.fill_(0x5A)
+        s.run(steps=1)
+        df = s.unit_digests()
+        s.mid.fill_(0xC3)
+        assert s.unit_digests() == df and df != d1
+        s.schedule = "unit"
+        s.run(steps=1)
+        assert s.unit_digests() == d1 and s.unit_digests((None, s.up_real, s.up_mid), s.count) == df
     finally:
         s.close()
 

@@ -26,7 +26,8 @@ for pattern in ("gradient", "noise"):
         for alg in ("lanczos3", "bicubic"):
             for mode in ("fma", "exact"):
                 line = f"{pattern:8s} {iw}x{ih}->{ow}x{oh} {alg:8s} {mode:5s}"
-                for opts in ({}, {"force_general": 1}):
+                # bicubic: the kernel's 4-tap form (round 6, the default), its 6-tap form (option pq_narrow 0), the any-scale kernel
+                for opts in (({}, {"pq_narrow": 0}, {"force_general": 1}) if alg == "bicubic" else ({}, {"force_general": 1})):
                     u = nsc.PyWgpuUpscaler("quality", alg, lanczos_mode=mode)
                     for k, v in opts.items():
                         u.set_option(k, v)
@@ -46,5 +47,6 @@ for pattern in ("gradient", "noise"):
                         torch.cuda.synchronize()
                         best = min(best, a.elapsed_time(b) / 5 / n * 1e3)
                     us = best
-                    line += f"  {u.kernel_variant:20s} {us:7.2f} us/frame {alg_bytes / us / 1e6:5.2f} TB/s"
+                    tag = u.kernel_variant + ("/4tap" if u.get_option("pq_narrow_active") else "")
+                    line += f"  {tag:24s} {us:7.2f} us/frame {alg_bytes / us / 1e6:5.2f} TB/s"
                 print(line, flush=True)
