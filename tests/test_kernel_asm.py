@@ -111,7 +111,7 @@ def test_lanczos_pq_row_ring_waits():
     units = ["nus_k_lanczos_pq.hip", "nus_k_lanczos_pq_65.hip", "nus_k_lanczos_pq_75.hip", "nus_k_lanczos_pq_85.hip", "nus_k_lanczos_pq_95.hip"]
     with ThreadPoolExecutor(5) as pool:
         bodies = [b for text in pool.map(asm_of, units) for b in chk.kernel_bodies(text, "k_lanczos3_pqIL")]
-    assert len(bodies) == 16, [n for n, _ in bodies]  # EXACT, FMA x eight factors
+    assert len(bodies) == 32, [n for n, _ in bodies]  # (EXACT, FMA) x (6-tap, 4-tap: round 6) x eight factors
     # (P, Q) -> unrolled steps, LDS-DMA pieces per row request
     shape = {(5, 4): (3, 1), (6, 5): (6, 2), (5, 3): (2, 1), (5, 2): (3, 2), (7, 2): (3, 2), (7, 5): (6, 2), (8, 5): (6, 2), (9, 5): (6, 2)}
     for name, body in bodies:

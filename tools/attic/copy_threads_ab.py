@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Host path by copy-pool size (NUS_COPY_THREADS, read once per process): upscale(), upscale_batch, interpolate_py, 1080p."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import nu_scaler_amd as nsc
 from nu_scaler_amd import synthetic as syn
 w, h = 1920, 1080

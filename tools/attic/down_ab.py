@@ -4,7 +4,7 @@ gradient and noise input.  usage: down_ab.py iw ih ow oh frames width[,width...]
 import os
 import sys
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 
 import nu_scaler_amd as nsc

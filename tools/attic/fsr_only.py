@@ -4,7 +4,7 @@ usage: fsr_only.py easu|fsr1|rcas fast(0|1) pattern frames launches"""
 import os
 import sys
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 
 import nu_scaler_amd as nsc

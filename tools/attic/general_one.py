@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Launch one algorithm at one size a few times (for rocprofv3 --pmc passes): general_one.py iw ih ow oh alg [frames]"""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 import nu_scaler_amd as nsc
 from nu_scaler_amd import synthetic as syn

@@ -4,7 +4,7 @@ rocprofv3 --kernel-trace --stats to read the per-K kernel durations)."""
 import os
 import sys
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 
 import nu_scaler_amd as nsc

@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Lanczos x2 kernel only, gradient stream, with an input format (for --pmc passes): lanczos_fmt.py <fmt> [frames]"""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 import nu_scaler_amd as nsc
 from nu_scaler_amd import synthetic as syn

@@ -2,7 +2,7 @@
 """One pass over the 'next row' kernels (FSR1 pair, x4 / any-factor resize, flow front end, warp with flow, swizzle)
 for a rocprofv3 --kernel-trace --stats summary."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 import nu_scaler_amd as nsc
 from nu_scaler_amd import synthetic as syn

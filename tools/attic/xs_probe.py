@@ -2,7 +2,7 @@
 """Timing of the fixed-factor kernels against rows per wave (dev tool): python tools/xs_probe.py [frames] [rows_per_wave ...]
 NUS_DIMS=iwxih:owxoh picks another size (default 960x540:3840x2160), NUS_PATTERN=gradient the opaque stream."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 import nu_scaler_amd as nsc
 from nu_scaler_amd import synthetic as syn
