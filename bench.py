@@ -58,17 +58,21 @@ if ROOT not in sys.path:
 
 
 def _install_crash_reports():
-    """faulthandler (Python frames of every thread) and, in front of it, the library's own fatal-signal report
+    """faulthandler (Python frames of every thread); the library's own fatal-signal report follows in _install_fatal_trace
     (nus_install_fatal_trace: native backtrace of the raising thread, the host ranges the library holds, /proc/self/maps):
     a rank that dies says which library aborted and where the address in the runtime's last words lies."""
     import faulthandler
 
     faulthandler.enable(file=sys.__stderr__, all_threads=True)
-    import torch  # noqa: F401  before the library: torch brings its own HIP runtime and must be the first to load one (no HIP call yet)
 
+
+def _install_fatal_trace():
+    """The library's half of the crash report.  Called AFTER the ShardedStream exists: loading libnuscaler_hip.so pulls in a HIP
+    runtime, and torch -- which must be the first to load one -- is imported by the ShardedStream only after the rank has bound
+    itself to its GPU's NUMA node and sized OMP_NUM_THREADS (libgomp reads it when it is loaded)."""
     import nu_scaler_amd
 
-    nu_scaler_amd.install_fatal_trace(2)  # (loads libnuscaler_hip.so; initialises nothing on the GPU)
+    nu_scaler_amd.install_fatal_trace(2)
 
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
@@ -786,6 +790,7 @@ def worker(args):
                              lanczos_mode=args.lanczos_mode, force_collectives=args.force_collectives and world == 1)
     except RuntimeError as e:
         raise SystemExit(f"bench.py: {e}")
+    _install_fatal_trace()
     import torch
     import torch.distributed as dist
 

@@ -10,7 +10,7 @@
 //      0x5b7cd2d8f000", round 5) can be placed: heap, a thread arena, an anonymous mapping, a file;
 // then hands over to the handler that was installed before it (Python's faulthandler in the harness processes, which dumps the
 // Python frames and re-raises; the default action otherwise).
-// Off unless a process asks for it (tests/conftest.py, bench.py, __graft_entry__.smoke(), nu_scaler_cli --fatal-trace).
+// Off unless a process asks for it (tests/conftest.py, bench.py, __graft_entry__.smoke() do).
 #include "../../include/nuscaler_hip.h"
 
 #include "nus_ranges.hpp"

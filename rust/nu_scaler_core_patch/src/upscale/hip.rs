@@ -45,6 +45,29 @@ impl HipUpscaler {
         self.check(unsafe { sys::nus_upscaler_set_input_format(self.h, f) })
     }
 
+    /// Device-resident results to host bytes: what `WgpuUpscaler::upscale` does at its end (map the staging buffer, wait, `to_vec`:
+    /// `upscale/mod.rs:1041-1057`) for callers of the `*_device` entry points.  `d_src` is a device pointer, `stream` the `hipStream_t`
+    /// the frame was computed on (null: the device's null stream); the copy is ordered after that work.  The `Vec` is pageable memory
+    /// and is never handed to the HIP runtime: the library stages through pinned chunks of its own (`nus_download`).
+    pub fn download(d_src: *const std::ffi::c_void, bytes: usize, stream: *mut std::ffi::c_void) -> Result<Vec<u8>> {
+        let mut out: Vec<u8> = Vec::with_capacity(bytes);
+        let rc = unsafe { sys::nus_download(out.as_mut_ptr() as *mut std::ffi::c_void, d_src, bytes, stream) };
+        if rc != sys::NUS_OK {
+            return Err(anyhow!(last_thread_error()));
+        }
+        unsafe { out.set_len(bytes) };
+        Ok(out)
+    }
+
+    /// Host bytes to a device buffer (`queue.write_buffer`, `upscale/mod.rs:968-1008`); `src` may be re-used on return.
+    pub fn upload(d_dst: *mut std::ffi::c_void, src: &[u8], stream: *mut std::ffi::c_void) -> Result<()> {
+        let rc = unsafe { sys::nus_upload(d_dst, src.as_ptr() as *const std::ffi::c_void, src.len(), stream) };
+        if rc != sys::NUS_OK {
+            return Err(anyhow!(last_thread_error()));
+        }
+        Ok(())
+    }
+
     /// `WgpuUpscaler::upscale_batch` (`upscale/mod.rs:609-640`, an inherent method there too, called by
     /// `PyWgpuUpscaler::upscale_batch`, `lib.rs:140-154`).
     pub fn upscale_batch(&self, frames: &[&[u8]]) -> Result<Vec<Vec<u8>>> {

@@ -63,6 +63,26 @@ int main(void)
         long long n = nus_tables_build_blob(320, 240, 640, 480, 0, NULL, 0);
         CHECK(n > 0);
     }
+    {
+        /* round 6: the transfer road and the diagnostics, as far as they go without a device */
+        unsigned char host[64] = {0};
+        nus_host_range r[4];
+        long long v = -1;
+        CHECK(nus_download(host, NULL, 0, NULL) == NUS_OK);                        /* nothing to move */
+        CHECK(nus_download(NULL, host, sizeof host, NULL) == NUS_ERR_INVALID_ARGUMENT);
+        CHECK(nus_upload(NULL, host, sizeof host, NULL) == NUS_ERR_INVALID_ARGUMENT);
+        CHECK(nus_host_unpin(host) == NUS_ERR_INVALID_ARGUMENT);                   /* never pinned: the runtime is not asked */
+        CHECK(strstr(nus_last_error(), "nus_host_pin") != NULL);
+        CHECK(nus_host_ranges(r, 4, 0) == 0 && nus_host_ranges(NULL, 4, 1) == 0);
+        CHECK(sizeof(nus_host_range) == 32);
+        nus_upscaler *g = nus_upscaler_create(NUS_ALG_BICUBIC, NUS_QUALITY_QUALITY);
+        CHECK(g != NULL);
+        CHECK(nus_upscaler_get_option(g, "pq_narrow_active", (int64_t *)&v) == NUS_OK && v == 0); /* not initialized: no kernel yet */
+        CHECK(nus_upscaler_set_option(g, "pq_narrow", 0) == NUS_OK && nus_upscaler_set_option(g, "pq_narrow", 2) == NUS_ERR_INVALID_ARGUMENT);
+        CHECK(nus_upscaler_get_option(g, "no_such_option", (int64_t *)&v) == NUS_ERR_INVALID_ARGUMENT);
+        CHECK(nus_upscaler_set_option(g, "inject_retire_error", 1) == NUS_ERR_INVALID_ARGUMENT); /* a test hook: NUS_TEST_HOOKS=1 only */
+        nus_upscaler_destroy(g);
+    }
     printf("abi_check ok\n");
     return 0;
 }

@@ -195,3 +195,36 @@ def test_guard_bands_catch_a_store_past_the_end(nsc):
     assert L.nus_probe_device(2, src.data_ptr(), under.data_ptr() - 512, n, 0, st) == _capi.OK, _capi.last_error()
     with pytest.raises(AssertionError, match="512 bytes in front"):
         guarded.assert_intact()
+
+
+def test_transfers_from_several_threads_take_turns(nsc):
+    """Concurrent nus_download / nus_upload calls on one device share the ring behind a mutex: four threads, each round-tripping
+    its own 20 MiB pattern eight times on its own stream, nobody sees anybody else's bytes."""
+    import threading
+
+    import torch
+
+    n = 20 << 20
+    errors = []
+
+    def worker(k):
+        try:
+            torch.cuda.set_device(0)
+            s = torch.cuda.Stream()
+            rng = np.random.default_rng(100 + k)
+            d = torch.empty(n, dtype=torch.uint8, device="cuda:0")
+            for it in range(8):
+                src = rng.integers(0, 256, n, dtype=np.uint8)
+                transfer.upload(d.data_ptr(), src, s.cuda_stream)
+                back = transfer.download(d.data_ptr(), n, np.empty(n, np.uint8), s.cuda_stream)
+                if not np.array_equal(back, src):
+                    errors.append((k, it))
+        except Exception as e:  # noqa: BLE001
+            errors.append((k, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(k,)) for k in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert errors == []
