@@ -303,7 +303,12 @@ __global__ __launch_bounds__(256) void k_pyramid_fast(const void *__restrict__ i
                                                       float *__restrict__ next_all, size_t next_stride, int w, int h, int strips,
                                                       int row_blocks, int rows_per_block)
 {
-    constexpr int U = 4 * kWave - 8; // columns a wave writes
+#if defined(NUS_ABLATE_PYR_ALIGNED_STRIPS) // timing-only dev build: every lane writes, a wave's row segment is one aligned KiB (the halo
+    // columns of lanes 0 and 63 are WRONG: they take their own values) -- what whole-line stores would be worth to this pass
+    constexpr int U = 4 * kWave, XOFF = 0;
+#else
+    constexpr int U = 4 * kWave - 8, XOFF = -4; // columns a wave writes
+#endif
     const int lane = threadIdx.x & (kWave - 1);
     const int g = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
     if (g >= strips * row_blocks) return;
@@ -312,10 +317,10 @@ __global__ __launch_bounds__(256) void k_pyramid_fast(const void *__restrict__ i
     const float *inf = U8IN ? nullptr : static_cast<const float *>(in_all) + blockIdx.y * in_stride;
     float *level_lum = lum_all + blockIdx.y * lum_stride;
     float *next = next_all ? next_all + blockIdx.y * next_stride : nullptr;
-    const int xa = strip * U - 4 + 4 * lane; // this lane's first column (a multiple of 4)
-    const bool writer = lane >= 1 && lane <= kWave - 2;
+    const int xa = strip * U + XOFF + 4 * lane; // this lane's first column (a multiple of 4)
+    const bool writer = XOFF == 0 || (lane >= 1 && lane <= kWave - 2);
     // vector-wide rows need all four columns inside the image (and the wave's other lanes too: wave-uniform choice)
-    const bool plain = __builtin_amdgcn_readfirstlane((int)(strip * U - 4 >= 0 && strip * U - 4 + 4 * kWave <= w)) != 0;
+    const bool plain = __builtin_amdgcn_readfirstlane((int)(strip * U + XOFF >= 0 && strip * U + XOFF + 4 * kWave <= w)) != 0;
     int cx[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) cx[i] = clampi(xa + i, 0, w - 1);
@@ -1215,7 +1220,11 @@ hipError_t launch_horn_schunck(const float *i1, const float *i2, const float *fl
 hipError_t launch_pyramid_level_fast(const void *in, bool u8_input, float *level_lum, float *next, uint32_t w, uint32_t h,
                                      hipStream_t stream, uint32_t n, size_t in_stride, size_t lum_stride, size_t next_stride)
 {
+#if defined(NUS_ABLATE_PYR_ALIGNED_STRIPS)
+    const uint32_t strips = cdiv(w, 4 * kWave);
+#else
     const uint32_t strips = cdiv(w, 4 * kWave - 8);
+#endif
     const uint64_t columns = (uint64_t)strips * n;
     const uint32_t want = (uint32_t)std::min<uint64_t>((NUS_PYR_STREAM_WAVES + columns - 1) / columns,
                                                        std::max<uint32_t>(h / NUS_PYR_STREAM_MIN_ROWS, 1));
