@@ -362,6 +362,21 @@ struct RowStore {
 #ifndef NUS_LZ_CONTIG_STORES
 #define NUS_LZ_CONTIG_STORES 1 // dev macro: 0 = each lane stores its own 2 x 16 B (A/B timing only)
 #endif
+// Round 6: the same contiguous KiB per store instruction WITHOUT the turn through LDS.  gfx950's v_permlane32_swap_b32 vdst, src
+// swaps lanes 32..63 of vdst with lanes 0..31 of src.  With vdst = the lane's first 16 bytes (A) and src = its second 16 (B), four
+// swaps (one per dword) leave in A the 32 bytes of each of lanes 0..31 -- A of lane l in lane l, B of lane l in lane l + 32 -- and
+// in B those of lanes 32..63: each store instruction still writes ONE contiguous KiB, in an interleaved lane order (lane l < 32 at
+// 32 l, lane l >= 32 at 32 (l - 32) + 16), which the memory system takes at the rate of the lane-ordered KiB
+// (tools/probe_row_store_shapes.hip: 7.1 / 7.1 us per frame of stores + loads against 9.7 for the lane's own strided pieces).
+// No LDS write, no LDS read, no lgkmcnt wait between a row's arithmetic and its stores; 8 KiB of LDS per block less.  Built, bit-identical
+// (385 GPU parity cases), and measured against the LDS turn in one process: one-launch step 5.691 against 5.693 ms per 300 units
+// (gradient), 6.751 / 6.787 (noise); the plain kernel 2.667 / 2.647 and 3.310 / 3.310 ms per 300 frames
+// (profiles/r06_x2_row_store_without_lds_ab.txt).  The turn through LDS was not what held the kernel: it sits on its memory and
+// issue floors either way.  The product keeps the LDS turn, whose stores cover whole 128-byte lines per
+// instruction (with 60 storing lanes the swap form splits one line in fifteen between its two stores).
+#ifndef NUS_LZ_SWAP_STORES
+#define NUS_LZ_SWAP_STORES 0 // 1 = the permlane32_swap form (A/B builds)
+#endif
 
 // The two 16-B stores of an output row.  Buffer stores: lanes that must not write carry an offset beyond
 // num_records and the hardware range check drops them, so the store instructions issue on every path and
@@ -375,7 +390,14 @@ __device__ __forceinline__ void lanczos_x2_store(const uint32_t (&o)[8], __amdgp
     return;
 #endif
     u32x4 lo = {o[0], o[1], o[2], o[3]}, hi = {o[4], o[5], o[6], o[7]};
-#if NUS_LZ_CONTIG_STORES
+#if NUS_LZ_CONTIG_STORES && NUS_LZ_SWAP_STORES
+    typedef uint32_t u32x2_sw __attribute__((ext_vector_type(2)));
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const u32x2_sw r = __builtin_amdgcn_permlane32_swap(lo[k], hi[k], false, false); // (the compiler pads the VALU -> swap hazard)
+        lo[k] = r.x, hi[k] = r.y;
+    }
+#elif NUS_LZ_CONTIG_STORES
     st.stage[2 * st.lane] = lo;
     st.stage[2 * st.lane + 1] = hi;
     __builtin_amdgcn_wave_barrier(); // compiler only: the reads below see other lanes' writes (same wave, in-order LDS)
@@ -621,7 +643,18 @@ __global__ __launch_bounds__(256) void k_lanczos3_x2(const LanczosX2Args A)
     };
     RowStore st;
     st.lane = lane;
-#if NUS_LZ_CONTIG_STORES
+#if NUS_LZ_CONTIG_STORES && NUS_LZ_SWAP_STORES
+    {
+        // after the swaps: store A carries lane l's first piece (l < 32) or lane l - 32's second piece; store B lane l + 32's first
+        // (l < 32) or lane l's second -- each piece dropped (offset 2^31) when the lane that COMPUTED it stores nothing
+        const int span0 = ((int)(strip * kLanczosX2StripCols) - 4) * 8; // byte offset of the span in an output row (may be < 0)
+        const int la = lane < 32 ? lane : lane - 32, lb = lane < 32 ? lane + 32 : lane;
+        const int half = lane < 32 ? 0 : 16;
+        st.off_a = computes_stored_pixels(la) ? (uint32_t)(span0 + 32 * la + half) : 0x80000000u;
+        st.off_b = computes_stored_pixels(lb) ? (uint32_t)(span0 + 32 * lb + half) : 0x80000000u;
+        st.idx_a = st.idx_b = 0;
+    }
+#elif NUS_LZ_CONTIG_STORES
     {
         // after the turn in LDS this lane holds 16 B of the wave's 512-pixel span for each store: SKIP bytes into the span
         // for the first store, 1024 further for the second; they were computed by lanes (SKIP + 16 lane) / 32 and
@@ -657,7 +690,7 @@ __global__ __launch_bounds__(256) void k_lanczos3_x2(const LanczosX2Args A)
         ring.slot = lds_rows[HIDDEN ? w : 0];
         ring.lds = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)&lds_rows[HIDDEN ? w : 0][0][0]);
         ring.lane = lane;
-#if NUS_LZ_CONTIG_STORES
+#if NUS_LZ_CONTIG_STORES && !NUS_LZ_SWAP_STORES
         __shared__ u32x4 lds_stage[4][128]; // one output row (2 KiB) per wave, turned round between compute and store order
         st.stage = lds_stage[w];
 #else
