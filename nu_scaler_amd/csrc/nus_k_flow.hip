@@ -929,6 +929,10 @@ __global__ __launch_bounds__(256) void k_hs_stream_fast(const float *__restrict_
             return upsampled_row(r);
 #endif
         } else {
+            if (warp.in_half) { // (wave-uniform) the previous launch of this level stored halves
+                const __half2 hv = reinterpret_cast<const __half2 *>(fin_all)[blockIdx.y * fin_stride + (size_t)min(r, hi - 1) * w + xc];
+                return __half22float2(hv);
+            }
             if (NUS_HS_FAST_NT & 2) return fin ? nt_load_f2(&fin[(size_t)min(r, hi - 1) * w + xc]) : make_float2(0.0f, 0.0f);
             return fin ? fin[(size_t)min(r, hi - 1) * w + xc] : make_float2(0.0f, 0.0f);
         }
@@ -1384,11 +1388,13 @@ hipError_t launch_hs_iterate(const float *coef, float lambda, float **flow_a, fl
         // one launch of k steps over pairs [0, m) of the given bases
         bool did_warp = false, did_half = false;
         auto launch_one = [&](uint32_t k, bool ups, const float *lum, const float2 *fi, float2 *fo, size_t out_stride, const HsCoarse &hc,
-                              uint32_t m, const HsWarp *wp, bool half_out) -> hipError_t {
-            HsWarp tail; // what the plain instantiations see of it: only the format of the flow they store
+                              uint32_t m, const HsWarp *wp, bool half_out, bool half_in) -> hipError_t {
+            HsWarp tail; // what the plain instantiations see of it: only the format of the flow they store (and load)
             tail.out_half = half_out ? 1u : 0u;
+            tail.in_half = half_in ? 1u : 0u;
             HsWarp wfull = wp ? *wp : HsWarp{};
             wfull.out_half = tail.out_half;
+            wfull.in_half = tail.in_half;
             if (wp) wp = &wfull;
             const HsStreamShape sh = hs_stream_shape(w, h, m, k, true);
             const dim3 block(256), grid(cdiv(sh.strips * sh.row_blocks, 4), m);
@@ -1434,6 +1440,9 @@ hipError_t launch_hs_iterate(const float *coef, float lambda, float **flow_a, fl
         // fewer of them move fewer bytes; the levels with 10 steps stay at 5 (ten per launch costs two waves per SIMD)
         const uint32_t maxk = iterations >= 30 ? NUS_HS_FAST_MAXK_LONG : NUS_HS_FAST_MAXK;
         uint32_t launches = (iterations + maxk - 1) / maxk;
+        const char *hb_env = getenv("NUS_HS_L0_HALF_BETWEEN"); // dev switch: see HsWarp::in_half
+        const bool half_between = hb_env != nullptr && hb_env[0] == '1' && warp != nullptr && launches == 2 && !zero_start;
+        bool prev_stored_half = false;
         // (Measured and dropped, round 4: the finest level in sub-chunks of 4-50 pairs, its two launches back to back per sub-chunk so
         // that the second finds the first's output and the luminance planes in the 256-MiB Infinity Cache -- identical flows,
         // 61 / 58 / 55 / 54 / 53 / 52 / 50 us per pair at 4 / 6 / 8 / 12 / 16 / 25 / 50 pairs against 50.5 for the whole chunk: launches
@@ -1466,7 +1475,9 @@ hipError_t launch_hs_iterate(const float *coef, float lambda, float **flow_a, fl
             if (can_warp && final_out == nullptr) fo = nullptr;
             const bool half_out = warp != nullptr && warp->out_half != 0 && launches == 1; // the level's final flow as Rg16Float
             if (half_out) did_half = true;
-            hipError_t e = launch_one(k, ups, lum1, fi, fo, out_stride, hc, n, can_warp ? warp : nullptr, half_out);
+            const bool mid_half = half_between && launches == 2; // the first of the two launches stores halves for the second
+            hipError_t e = launch_one(k, ups, lum1, fi, fo, out_stride, hc, n, can_warp ? warp : nullptr, half_out || mid_half, prev_stored_half);
+            prev_stored_half = mid_half;
             if (e != hipSuccess) return e;
             iterations -= k;
             --launches;

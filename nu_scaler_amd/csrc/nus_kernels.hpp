@@ -231,6 +231,9 @@ struct HsWarp {
     // Rg16Float (wgpu_interpolator.rs:276), for a warp that reads it that way.  Honoured by the FAST streamed kernel's last launch
     // (*wrote_half says so); everything else leaves f32 and the caller converts (launch_flow_to_half).
     uint32_t out_half = 0;
+    // dev switch NUS_HS_L0_HALF_BETWEEN=1 (round 6, measured: profiles/r06_flow_level0_half_between_launches.txt): the flow BETWEEN the
+    // finest level's two launches as Rg16Float as well -- the launch reads 2 x half per cell
+    uint32_t in_half = 0;
 };
 // n cells of 2 x f32 -> 2 x f16 (round to nearest even)
 hipError_t launch_flow_to_half(const float *src, void *dst, size_t n_cells, hipStream_t stream);
