@@ -1782,3 +1782,26 @@ def test_probe_device_kinds_move_the_bytes_they_claim(nsc):
     for bad in ((9, src.data_ptr(), dst.data_ptr(), 16, 0), (1, 0, dst.data_ptr(), 16, 0), (1, src.data_ptr() + 4, dst.data_ptr(), 16, 0),
                 (1, src.data_ptr(), dst.data_ptr(), 20, 0), (5, 0, scratch.data_ptr(), 0, 0)):
         assert L.nus_probe_device(bad[0], bad[1] or None, bad[2], bad[3], bad[4], None) != 0
+
+
+@pytest.mark.parametrize("dims", [((3840, 2160), (7680, 4320)), ((16384, 32), (32768, 64)), ((32, 16384), (64, 32768)), ((8192, 8), (8192 * 3 // 2, 12))])
+def test_large_and_extreme_aspect_frames(nsc, oracle_mod, dims):
+    """Sizes at the edge of what the reference's own path can hold (its textures stop at 8192 - 16384 a side): 4K -> 8K, a frame 16 384
+    pixels wide and 32 tall, one 32 wide and 16 384 tall, an 8192-wide frame at x3/2 -- every filter against the oracle (strip and row-block
+    arithmetic, 32-bit offsets inside a frame), outputs between guard bands."""
+    import torch
+
+    (w, h), (ow, oh) = dims
+    img = oracle_mod.gen_noise(w, h, 321)
+    d_in = put(img[None])
+    for alg, want, tol in (("nearest", oracle_mod.nearest(img, ow, oh), 0), ("bilinear", oracle_mod.bilinear(img, ow, oh, threads=0), 0),
+                           ("lanczos3", oracle_mod.lanczos3(img, ow, oh, threads=0), 1)):
+        u = nsc.PyWgpuUpscaler("quality", alg)
+        u.initialize(w, h, ow, oh)
+        d_out = guarded.empty((1, oh, ow, 4), dtype=torch.uint8, device="cuda")
+        u.upscale_device(d_in.data_ptr(), d_out.data_ptr(), 1)
+        got = fetch(d_out)[0]
+        d = np.abs(got.astype(np.int16) - want.astype(np.int16))
+        assert d.max() <= tol and (tol == 0 or (d > 0).mean() < 1e-3), (alg, u.kernel_variant, int(d.max()), float((d > 0).mean()))
+        guarded.assert_intact()
+        del d_out
