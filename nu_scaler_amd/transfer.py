@@ -56,7 +56,8 @@ def upload(device_ptr: int, data, stream: int = 0) -> None:
 
 
 _NP_OF_TORCH = {"torch.uint8": np.uint8, "torch.int8": np.int8, "torch.int16": np.int16, "torch.int32": np.int32,
-                "torch.int64": np.int64, "torch.float16": np.float16, "torch.float32": np.float32, "torch.float64": np.float64}
+                "torch.int64": np.int64, "torch.float16": np.float16, "torch.float32": np.float32, "torch.float64": np.float64,
+                "torch.bool": np.bool_}
 
 
 def to_numpy(t) -> np.ndarray:

@@ -48,9 +48,9 @@ for rnd in range(2):
     for env in ("0", "1"):  # one entry point (estimator, then the warp kernel behind it) / the warp inside the last Jacobi launch
         os.environ["NUS_HS_FUSED_WARP"] = env
         what = "warp inside the last Jacobi launch" if env == "1" else "one call, warp kernel behind the estimator"
-        print(f"motion step, {n} units, {what}, stage after stage: {timed(fused_warp=True, flow_format="f32"):7.2f} ms", flush=True)
+        print(f"motion step, {n} units, {what}, stage after stage: {timed(fused_warp=True, flow_format='f32'):7.2f} ms", flush=True)
         for c in chunks:
-            print(f"motion step, {n} units, {what}, pipelined, chunks of {c:3d}: {timed(fused_warp=True, pipelined=True, chunk=c, flow_format="f32"):7.2f} ms", flush=True)
+            print(f"motion step, {n} units, {what}, pipelined, chunks of {c:3d}: {timed(fused_warp=True, pipelined=True, chunk=c, flow_format='f32'):7.2f} ms", flush=True)
     os.environ.pop("NUS_HS_FUSED_WARP", None)
     for c in chunks:
         print(f"motion step, {n} units, one call, Rg16Float between estimator and warp, pipelined, chunks of {c:3d}: "
