@@ -89,6 +89,17 @@ int device_of(const void *d, const char *who, int *device)
     return kOk;
 }
 
+// a "host" pointer that is really device memory would be handed to memcpy: refuse it
+bool points_into_device_memory(const void *p)
+{
+    hipPointerAttribute_t attr;
+    if (hipPointerGetAttributes(&attr, p) != hipSuccess) {
+        (void)hipGetLastError(); // pageable memory: unknown to the runtime
+        return false;
+    }
+    return attr.type == hipMemoryTypeDevice;
+}
+
 int wait_chunk(Ring &r, int k)
 {
     if (!r.busy[k]) return kOk;
@@ -106,6 +117,7 @@ int download(void *host_dst, const void *d_src, size_t bytes, hipStream_t stream
     int device = 0;
     int rc = device_of(d_src, "nus_download", &device);
     if (rc != kOk) return rc;
+    if (points_into_device_memory(host_dst)) return fail(kInvalidArgument, "nus_download: the host pointer points into device memory");
     DeviceScope scope(device);
     if (is_pinned_host(host_dst)) { // the engines can write it themselves
         NUS_HIP(hipMemcpyAsync(host_dst, d_src, bytes, hipMemcpyDeviceToHost, stream));
@@ -148,6 +160,7 @@ int upload(void *d_dst, const void *host_src, size_t bytes, hipStream_t stream)
     int device = 0;
     int rc = device_of(d_dst, "nus_upload", &device);
     if (rc != kOk) return rc;
+    if (points_into_device_memory(host_src)) return fail(kInvalidArgument, "nus_upload: the host pointer points into device memory");
     DeviceScope scope(device);
     if (is_pinned_host(host_src)) {
         NUS_HIP(hipMemcpyAsync(d_dst, host_src, bytes, hipMemcpyHostToDevice, stream));

@@ -143,6 +143,10 @@ def test_transfer_refuses_what_is_not_device_memory(nsc):
     assert L.nus_upload(pinned.data_ptr(), host.ctypes.data, 64, None) == _capi.ERR_INVALID_ARGUMENT  # pinned HOST memory is not a device destination
     d = torch.zeros(64, dtype=torch.uint8, device="cuda:0")
     assert L.nus_download(host.ctypes.data, d.data_ptr(), 0, None) == _capi.OK
+    d2 = torch.zeros(64, dtype=torch.uint8, device="cuda:0")
+    assert L.nus_download(d2.data_ptr(), d.data_ptr(), 64, None) == _capi.ERR_INVALID_ARGUMENT  # a device pointer as the HOST side
+    assert "host pointer points into device memory" in _capi.last_error()
+    assert L.nus_upload(d.data_ptr(), d2.data_ptr(), 64, None) == _capi.ERR_INVALID_ARGUMENT
 
 
 def test_host_ranges_record_pins_and_the_librarys_own_pinned_memory(nsc):
