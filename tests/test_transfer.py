@@ -234,3 +234,58 @@ def test_transfers_from_several_threads_take_turns(nsc):
     for t in threads:
         t.join()
     assert errors == []
+
+
+_SEQUENCE = r"""
+import ctypes, sys
+import numpy as np
+import torch
+sys.path.insert(0, %r)
+import nu_scaler_amd as nsc
+from nu_scaler_amd import _capi
+nsc.install_fatal_trace(2)
+libc = ctypes.CDLL(None)
+libc.malloc.restype = ctypes.c_void_p; libc.malloc.argtypes = [ctypes.c_size_t]
+libc.free.argtypes = [ctypes.c_void_p]; libc.sbrk.restype = ctypes.c_void_p; libc.sbrk.argtypes = [ctypes.c_ssize_t]
+n = 3840 * 2160 * 4
+L = _capi.lib()
+st = torch.cuda.current_stream().cuda_stream
+first = libc.malloc(n); libc.free(first)          # raises glibc's dynamic mmap threshold past one 4K frame
+seen = []
+for step in range(3):
+    d = torch.randint(0, 255, (n,), dtype=torch.uint8, device="cuda:0")
+    want = d.sum().item()
+    p = libc.malloc(n)                            # a block of the program break's heap
+    brk_before = libc.sbrk(0)
+    assert L.nus_download(p, d.data_ptr(), n, st) == _capi.OK, _capi.last_error()
+    got = int(np.ctypeslib.as_array((ctypes.c_ubyte * n).from_address(p)).sum(dtype=np.int64))
+    assert got == want, (step, got, want)
+    libc.free(p)
+    libc.malloc_trim(0)                           # the block's pages go back to the kernel (the break lowered, or MADV_DONTNEED inside the heap)
+    lo = (p + 4095) & ~4095
+    pages = (p + n - lo) // 4096
+    vec = (ctypes.c_ubyte * pages)()
+    assert libc.mincore(ctypes.c_void_p(lo), ctypes.c_size_t(pages * 4096), vec) in (0, -1)
+    resident = sum(v & 1 for v in vec) if libc.sbrk(0) >= lo + pages * 4096 else 0   # (beyond the lowered break: unmapped = gone)
+    seen.append((p, brk_before, libc.sbrk(0), resident, pages))
+same_address = seen[0][0] == seen[1][0] == seen[2][0]
+pages_gone = all(res * 10 < pages for _, _, _, res, pages in seen)
+print("SEQUENCE ok same_address=%%s pages_gone=%%s resident=%%s" %% (same_address, pages_gone, [r[3] for r in seen]))
+"""
+
+
+def test_download_into_a_heap_block_that_was_freed_trimmed_and_regrown(nsc):
+    """the hypothesised sequence of the round-5 fault, deterministically, in a child process -- but through the PRODUCT's
+    road: a 33 MB block of the brk heap as the destination of a device-to-host transfer, free, malloc_trim (the pages go back to the
+    kernel), the heap regrown, a block at the same address as the destination again, three times over.  With nus_download no
+    registration of the caller's pages exists that could go stale: every round's bytes are right.  (The runtime's own pageable copy is
+    deliberately NOT put through this: docs/d2h_fault_analysis.md.)"""
+    import subprocess
+    import sys
+
+    from conftest import ROOT
+
+    run = subprocess.run([sys.executable, "-c", _SEQUENCE % ROOT], capture_output=True, text=True, timeout=300)
+    assert run.returncode == 0 and "SEQUENCE ok" in run.stdout, run.stdout[-1500:] + run.stderr[-3000:]
+    # what makes it the sequence in question: the block's pages really went back to the kernel in between (and, normally, the same address came back)
+    assert "pages_gone=True" in run.stdout, run.stdout
