@@ -612,3 +612,27 @@ def test_fatal_trace_report_of_a_dying_child(nsc, tmp_path):
     pos = [err.find(m) for m in marks]
     assert all(p >= 0 for p in pos) and pos == sorted(pos), pos
     assert "abort" in err[pos[0]:pos[1]] and "libnuscaler_hip.so" in err[pos[4]:pos[6]]
+
+
+def test_guard_registry_of_the_tests_is_the_one_the_teardown_checks(request):
+    """tests/conftest.py `guarded`: the object the test modules import is the object the autouse fixture checks after every test (a
+    second copy of conftest -- another import mode -- would leave every guard band unchecked without anybody noticing)."""
+    from conftest import guarded
+
+    plugins = [m for m in request.config.pluginmanager.get_plugins() if getattr(m, "__name__", "") == "conftest"]
+    assert plugins and all(getattr(m, "guarded") is guarded for m in plugins)
+    # and a damaged guard is reported (host tensors: the check itself needs no GPU)
+    import torch
+
+    t = guarded.zeros((4, 8), dtype=torch.int16, device="cpu")
+    assert t.shape == (4, 8) and int(t.abs().sum()) == 0
+    flat, n = guarded._live[-1]
+    assert n == 64 and flat.numel() == 2 * guarded.GUARD + 64 + 192
+    flat[guarded.GUARD - 1] = 0
+    torch_cuda_sync = torch.cuda.synchronize
+    torch.cuda.synchronize = lambda: None  # (no device here)
+    try:
+        with pytest.raises(AssertionError, match="1 bytes in front"):
+            guarded.assert_intact()
+    finally:
+        torch.cuda.synchronize = torch_cuda_sync
