@@ -174,14 +174,35 @@ int upload(void *d_dst, const void *host_src, size_t bytes, hipStream_t stream)
     const size_t n = (bytes + kTransferChunkBytes - 1) / kTransferChunkBytes;
     const uint8_t *src = static_cast<const uint8_t *>(host_src);
     uint8_t *dst = static_cast<uint8_t *>(d_dst);
-    for (size_t i = 0; i < n; ++i) {
+    auto len_of = [&](size_t i) { return i + 1 < n ? kTransferChunkBytes : bytes - i * kTransferChunkBytes; };
+    // The staging copies of up to kTransferChunks - 1 chunks run on the pool's workers AHEAD of the chunk whose DMA is being issued:
+    // one ticket per ring slot; on every way out the tickets are waited for (their pieces point into the caller's buffer).
+    struct Tickets {
+        CopyTicket t[kTransferChunks];
+        ~Tickets()
+        {
+            for (CopyTicket &x : t) parallel_copy_wait(x);
+        }
+    } tk;
+    auto stage = [&](size_t i) -> int { // chunk i into its slot, asynchronously, once the DMA that last read the slot has finished
         const int k = (int)(i % kTransferChunks);
-        const size_t len = i + 1 < n ? kTransferChunkBytes : bytes - i * kTransferChunkBytes;
-        if ((rc = wait_chunk(r, k)) != kOk) return rc; // the DMA that last read this chunk has finished
-        parallel_copy(r.stage[k], src + i * kTransferChunkBytes, len);
-        NUS_HIP(hipMemcpyAsync(dst + i * kTransferChunkBytes, r.stage[k], len, hipMemcpyHostToDevice, stream));
+        const int w = wait_chunk(r, k);
+        if (w != kOk) return w;
+        parallel_copy_async(r.stage[k], src + i * kTransferChunkBytes, len_of(i), tk.t[k]);
+        return kOk;
+    };
+    for (size_t i = 0; i < n && i + 1 < (size_t)kTransferChunks; ++i)
+        if ((rc = stage(i)) != kOk) return rc;
+    for (size_t j = 0; j < n; ++j) {
+        const int k = (int)(j % kTransferChunks);
+        parallel_copy_wait(tk.t[k]); // (the calling thread copies pieces too while it waits)
+        NUS_HIP(hipMemcpyAsync(dst + j * kTransferChunkBytes, r.stage[k], len_of(j), hipMemcpyHostToDevice, stream));
         NUS_HIP(hipEventRecord(r.done[k], stream));
         r.busy[k] = true;
+        // the slot to stage next is the one of chunk j - 1 ... whose DMA sits in front of the one just issued: waiting for it leaves
+        // the engine with work queued
+        const size_t nxt = j + kTransferChunks - 1;
+        if (nxt < n && (rc = stage(nxt)) != kOk) return rc;
     }
     return kOk;
 }
