@@ -1164,10 +1164,10 @@ def worker(args):
                     "what": "three-stage step with a dense flow per pair (3-level pyramid, 50 + 10 + 10 Horn-Schunck steps, FAST "
                             "arithmetic: flow within 1e-3 px of the exact one) feeding the warp (FMA mode) instead of zero flow; "
                             "ms_per_step is ONE configuration, FramePipeline.step_motion's default: the two-stream pipeline over "
-                            "100-unit chunks, estimator + warp through one entry point with the flow handed over as Rg16Float, the "
+                            "150-unit chunks, estimator + warp through one entry point with the flow handed over as Rg16Float, the "
                             "real frames' upscale first on the second stream; beside it the same with an f32 hand-off, stage after "
                             "stage (f32 flows stored), and stage after stage with the bit-exact front end; informational, this rank only",
-                    "configuration": "fast flow, pipelined, fused entry point, Rg16Float hand-off",
+                    "configuration": "fast flow, pipelined over 150-unit chunks, fused entry point, Rg16Float hand-off",
                     "ms_per_step": round(motion_ms, 3),
                     "units_per_s_per_gpu": round(n_units / motion_ms * 1e3, 1),
                     "pipelined_ms_per_step": round(motion["fast_pipelined"], 3),

@@ -443,9 +443,13 @@ int HipFlowEstimator::stream_impl(const void *d_frames, uint32_t n_frames, uint3
     const uint32_t n_pairs = n_frames - 1;
     // per pair: luminance planes 4/3 x 4 B, level inputs (1/4 + 1/16) x 16 B, two flows 16 B per pixel -- and 12 B of
     // coefficients if some level's Jacobi steps run on LDS tiles (the streamed kernel takes them from the planes)
+    // (dev overrides, round 6 -- measured and left at the defaults: profiles/r06_flow_chunk_size.txt)
+    const char *env_pairs = getenv("NUS_FLOW_MAX_CHUNK_PAIRS"), *env_gb = getenv("NUS_FLOW_WORKSPACE_GB");
+    const uint32_t max_pairs = env_pairs && atoi(env_pairs) > 0 ? (uint32_t)atoi(env_pairs) : kStreamMaxChunkPairs;
+    const size_t workspace = env_gb && atoi(env_gb) > 0 ? (size_t)atoi(env_gb) << 30 : kStreamWorkspaceBytes;
     auto chunk_for = [&](size_t bytes_per_pixel) {
-        const uint32_t c = (uint32_t)(kStreamWorkspaceBytes / ((size_t)w * h * bytes_per_pixel));
-        return c < 1 ? 1u : (c > kStreamMaxChunkPairs ? kStreamMaxChunkPairs : c);
+        const uint32_t c = (uint32_t)(workspace / ((size_t)w * h * bytes_per_pixel));
+        return c < 1 ? 1u : (c > max_pairs ? max_pairs : c);
     };
     uint32_t chunk = chunk_for(31);
     if (chunk > n_pairs) chunk = n_pairs;

@@ -68,10 +68,12 @@ private:
     int solve(int slot_a, int slot_b, const Pyramid &g, uint32_t coarse_iters, uint32_t refine_iters, float lambda,
               void *d_flow_out, hipStream_t stream);
     // multi-step kernels, a chunk of consecutive pairs per launch (pairs on the grid's y / z axis): as many as fit the
-    // workspace budget (64 MB per 1080p pair, 88 MB with coefficient planes), at most 100 -- 1080p: 93 pairs;
-    // 64 -> 100 pairs per chunk: 76 -> 71 us per pair on a 300-pair stream (profiles/r02_flow_jacobi_streamed_ab.txt)
-    static constexpr uint32_t kStreamMaxChunkPairs = 100;
-    static constexpr size_t kStreamWorkspaceBytes = (size_t)6 << 30;
+    // workspace budget (64 MB per 1080p pair, 88 MB with coefficient planes), at most 150 (round 6; 100 and 6 GiB before: with
+    // more pairs per launch the levels are cut into fewer row blocks, i.e. fewer halo rows are recomputed -- the motion step with
+    // chunks of 150 units 19.5 - 19.7 against 20.0 - 20.4 ms per 300 units, profiles/r06_flow_chunk_size.txt; 12 GiB of the
+    // GPU's 288);  64 -> 100 pairs per chunk had been 76 -> 71 us per pair (profiles/r02_flow_jacobi_streamed_ab.txt)
+    static constexpr uint32_t kStreamMaxChunkPairs = 150;
+    static constexpr size_t kStreamWorkspaceBytes = (size_t)12 << 30;
     int stream_impl(const void *d_frames, uint32_t n_frames, uint32_t w, uint32_t h, uint32_t levels, uint32_t coarse_iters,
                     uint32_t refine_iters, float lambda, void *d_flows, void *d_mid, float t, hipStream_t stream, bool flow_half = false);
     int solve_batch(const uint8_t *d_frames, uint32_t pairs, const Pyramid &g, uint32_t coarse_iters, uint32_t refine_iters,

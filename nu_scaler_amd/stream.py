@@ -170,7 +170,7 @@ class FramePipeline:
 
     def step_motion(self, frames, flows, mid, up_real, up_mid, stream: int = 0, levels: int = 3,
                     coarse_iterations: int = 50, refine_iterations: int = 10, flow_mode: str = "exact", pipelined: bool = False,
-                    chunk: int = 100, fused_warp: bool = False, flow_format: Optional[str] = None) -> None:
+                    chunk: int = 150, fused_warp: bool = False, flow_format: Optional[str] = None) -> None:
         """Motion-compensated variant of `step`: a dense flow per pair from the
         pyramid + Horn-Schunck front end into `flows` ((n_units, h, w, 2) float32), then warp + blend with it
         instead of the reference's zero flow.  The flows are estimated pair by pair (several launches per pair,
