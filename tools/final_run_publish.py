@@ -1,9 +1,6 @@
 #!/usr/bin/env python
-"""Copies a finished evidence run (gpurun_out/evidence, tools/round_evidence.sh a + b) into profiles/rNN_final_run/, writes its README.txt and
-patches the two lines of DESIGN.md / README.md that quote the round's own final run.  final_run_publish.py <round number>   (dev tool)"""
-import json
+"""Copies a finished evidence run (gpurun_out/evidence, tools/round_evidence.sh a + b) into profiles/rNN_final_run/, writes its README.txt (the documents quote the round's boxes by hand).  final_run_publish.py <round number>   (dev tool)"""
 import os
-import re
 import shutil
 import subprocess
 import sys
@@ -25,21 +22,4 @@ for name, to in (("r06_gpu_tests_final.txt", "gpu_tests.txt"), ("r06_smoke.txt",
         shutil.copy(p, os.path.join(dst, to))
 readme = subprocess.run([sys.executable, os.path.join(root, "tools", "final_run_readme.py"), src, rnd], capture_output=True, text=True, check=True).stdout
 open(os.path.join(dst, "README.txt"), "w").write(readme)
-d = json.load(open(os.path.join(dst, "bench_driver_command_steps20.json")))
-r = d["roofline"]
-mpix = f"{d['value']:,.0f}".replace(",", " ")
-cc = r["copy_ceiling"].get("stream_copy_float4_GBps") / 1e3
-design = os.path.join(root, "DESIGN.md")
-s = open(design, encoding="utf-8").read()
-s2 = re.sub(r"NEVER_MATCH_the box of that call: stream copy [\d.]+ TB/s\): [\d ]+ Mpix/s, [\d.]+ ms, [\d.]+ / moved [\d.]+ with the driver's\s+command",
-            f"(`profiles/r06_final_run/`, the box of that call: stream copy {cc:.2f} TB/s): {mpix} Mpix/s, {d['ms_per_step']:.3f} ms, {r['frac']:.3f} / moved "
-            f"{r['moved_frac']:.3f} with the driver's command", s, count=1)
-print("DESIGN patched" if s2 != s else "DESIGN: pattern not found (or unchanged)")
-open(design, "w", encoding="utf-8").write(s2)
-rp = os.path.join(root, "README.md")
-s = open(rp, encoding="utf-8").read()
-s2 = re.sub(r"\(`profiles/r06_final_run/`\): [\d ]+ Mpix/s, [\d.]+ ms,\n[\d.]+ / moved [\d.]+;",
-            f"(`profiles/r06_final_run/`): {mpix} Mpix/s, {d['ms_per_step']:.2f} ms,\n{r['frac']:.3f} / moved {r['moved_frac']:.3f};", s, count=1)
-print("README patched" if s2 != s else "README: pattern not found (or unchanged)")
-open(rp, "w", encoding="utf-8").write(s2)
-print(readme[:600])
+print(readme[:900])
