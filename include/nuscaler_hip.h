@@ -25,7 +25,8 @@
  * CPU mask or cgroup quota is smaller; environment: NUS_COPY_THREADS=n, 0 = copy on the calling thread only).  The same
  * threads make the pages of a pageable OUTPUT buffer present while its frame is on the GPU (a result buffer fresh from the
  * allocator -- the Vec / PyBytes of the trait's `upscale` -- otherwise takes its first-touch faults inside the copy-out);
- * buffer contents are never touched before the frame's bytes arrive.
+ * buffer contents are never touched before the frame's bytes arrive.  A fresh buffer that is its own mapping also gets a transparent-huge-page
+ * hint (environment NUS_NO_THP_HINT=1 turns that off).
  */
 #ifndef NUSCALER_HIP_H
 #define NUSCALER_HIP_H

@@ -291,7 +291,10 @@ bool parallel_populate_prepare(void *dst, size_t bytes)
     // allocator carved out of a heap -- glibc serves a 33 MB block from the program break once its dynamic mmap threshold has
     // grown past that size, or from a thread arena -- the address range outlives the block and the hint would stay on a piece of
     // the process heap for good (khugepaged would keep working on it): such blocks are populated without it.
-    if (is_own_mapping(dst, bytes)) {
+    // NUS_NO_THP_HINT (any value): never give the hint -- for processes under an allocator other than glibc's whose blocks of less than
+    // 32 MiB might look like glibc's mmapped chunks (is_own_mapping reads glibc's chunk header), or that manage huge pages themselves
+    static const bool hint_allowed = getenv("NUS_NO_THP_HINT") == nullptr;
+    if (hint_allowed && is_own_mapping(dst, bytes)) {
         (void)madvise(reinterpret_cast<void *>(lo), hi - lo, MADV_HUGEPAGE);
         range_event(kRangeHugeHint, reinterpret_cast<void *>(lo), hi - lo); // (nus_ranges.hpp: what a fatal-signal report lists)
     }
