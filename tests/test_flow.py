@@ -183,10 +183,10 @@ def test_flow_estimate_device_path(nsc, oracle_mod):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n_frames", [2, 3, 5, 67, 103])
+@pytest.mark.parametrize("n_frames", [2, 3, 5, 67, 103, 153])
 def test_flow_estimate_device_stream_equals_pairwise(nsc, oracle_mod, n_frames):
-    """The stream entry point takes chunks of up to 100 pairs through every stage together (pairs on the grid's z axis,
-    each frame's pyramid built once per chunk; 103 frames: two chunks): every flow must still be the oracle's flow of its own pair -- also
+    """The stream entry point takes chunks of up to 150 pairs (100 until round 6) through every stage together (pairs on the grid's z axis,
+    each frame's pyramid built once per chunk; 153 frames: two chunks): every flow must still be the oracle's flow of its own pair -- also
     with the shader-shaped kernels, which go pair by pair."""
     import torch
 
